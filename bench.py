@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- pass 1 of `pregraph` (k-mer extraction + hash-set insert) on synthetic reads resident in HBM.
+
+    python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
+
+One step = one full pass of the hot path over the workload: empty the k-mer set, then extract and insert every
+k-mer occurrence of every read (for N > 1: extract + route by owner, RCCL all-to-all, insert).  Reads are
+generated on the GPU before the timed region and stay resident in HBM; FASTQ parsing and PCIe are not in `value`.
+Workload = BASELINE.json configs[2] ("C. elegans-scale 200M x 150 bp synthetic, K=63, 1xMI355X"), the
+configuration the metric (K = 63) is quoted on; per-GPU work is fixed as N grows (weak scaling).
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import re
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def gen_packed_reads(torch, dev, genome_len, n_reads, read_len, err, seed, chunk=2_000_000):
+    """Synthetic reads of SURVEY.md 8d drawn on the GPU (uniform genome, uniform starts, strand flip p=0.5,
+    substitution errors), packed 2 bit/base MSB-first, word-aligned: int64 tensor [n_reads * wpr + 8]."""
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    genome = torch.randint(0, 4, (genome_len,), dtype=torch.uint8, device=dev, generator=g)
+    wpr = (read_len + 31) // 32
+    out = torch.zeros(n_reads * wpr + 8, dtype=torch.int64, device=dev)
+    ar = torch.arange(read_len, device=dev, dtype=torch.int64)
+    shifts = (62 - 2 * torch.arange(32, device=dev, dtype=torch.int64))
+    for lo in range(0, n_reads, chunk):
+        n = min(chunk, n_reads - lo)
+        starts = torch.randint(0, genome_len - read_len, (n,), device=dev, generator=g, dtype=torch.int64)
+        reads = genome[starts[:, None] + ar[None, :]]
+        flip = torch.rand(n, device=dev, generator=g) < 0.5
+        rc = torch.flip(reads, dims=[1]) ^ 2
+        reads = torch.where(flip[:, None], rc, reads)
+        if err > 0:
+            mask = torch.rand(reads.shape, device=dev, generator=g) < err
+            shift = torch.randint(1, 4, reads.shape, device=dev, generator=g, dtype=torch.uint8)
+            reads = torch.where(mask, (reads + shift) & 3, reads)
+        padded = torch.zeros((n, wpr * 32), dtype=torch.int64, device=dev)
+        padded[:, :read_len] = reads.to(torch.int64)
+        words = (padded.view(n, wpr, 32) << shifts[None, None, :]).sum(dim=2)
+        out[lo * wpr:(lo + n) * wpr] = words.view(-1)
+        del reads, rc, padded, words, starts, flip
+    return out
+
+
+def cpu_baseline(args, cores):
+    """The reference's own pthreaded pregraph (oracle/_ref, built from /root/reference by oracle/Makefile.ref)
+    timed on this box's host cores on a bounded sample of the same read distribution; pass-1 time is the
+    reference's own 'Time spent on hashing reads' line."""
+    from soapdenovo2_amd import synth
+    ref = os.path.join(ROOT, "oracle", "_ref", "SOAPdenovo-63mer")
+    n = args.cpu_sample_reads
+    with tempfile.TemporaryDirectory() as td:
+        g = min(args.genome, 20_000_000)
+        cfg = synth.make_case(td, "cpu", g, n, args.read_len, args.err, args.seed + 1)
+        if os.path.exists(ref):
+            t0 = time.time()
+            out = subprocess.run([ref, "pregraph", "-s", cfg, "-K", str(args.kmer), "-o", os.path.join(td, "o"), "-p", str(cores)],
+                                 capture_output=True, text=True)
+            wall = time.time() - t0
+            m = re.search(r"Time spent on hashing reads: (\d+)s", out.stderr)
+            m2 = re.search(r"Time spent on pre-graph construction: (\d+)s", out.stderr)
+            sec = float(m.group(1)) if m else None
+            if not sec:
+                sec = float(m2.group(1)) if m2 and float(m2.group(1)) > 0 else wall
+            return {"value": n / sec, "unit": "reads/s", "cores": cores, "kind": "reference",
+                    "sample": f"{n} reads x {args.read_len} bp, genome {g}, err {args.err}, K={args.kmer}, -p {cores}; "
+                              f"pass 1 {sec:.0f} s of {wall:.0f} s whole command"}
+        # fall back to the single-threaded C restatement
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from oracle_binding import Oracle
+        codes = synth.reads_codes(g, n // 8, args.read_len, args.err, args.seed + 1)
+        o = Oracle(args.kmer, P=8, max_read_len=args.read_len)
+        t0 = time.time()
+        o.add_reads(codes)
+        sec = time.time() - t0
+        o.close()
+        return {"value": (n // 8) / sec, "unit": "reads/s", "cores": 1, "kind": "port",
+                "sample": f"{n // 8} reads x {args.read_len} bp, K={args.kmer}, oracle/pregraph_oracle.c pass 1"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--reads", type=int, default=200_000_000, help="reads per GPU")
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--kmer", type=int, default=63)
+    ap.add_argument("--genome", type=int, default=100_000_000)
+    ap.add_argument("--err", type=float, default=0.001)
+    ap.add_argument("--seed", type=int, default=3)
+    ap.add_argument("--sets", type=int, default=8, help="the reference's -p (k-mer sets)")
+    ap.add_argument("--batch-reads", type=int, default=16_000_000)
+    ap.add_argument("--log2-slots", type=int, default=0, help="0 = size from the expected distinct count")
+    ap.add_argument("--cpu-sample-reads", type=int, default=400_000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from soapdenovo2_amd import api
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=dev)
+
+    K, L, P = args.kmer, args.read_len, args.sets
+    kpr = L - K + 1
+    n_reads = args.reads
+    n_kmers = n_reads * kpr
+    # expected distinct k-mers per GPU: genomic (<= genome) + error k-mers (~ K per error, capped by read geometry)
+    exp_err = n_reads * L * args.err * min(K, kpr)
+    expected = min(n_kmers, args.genome + exp_err) * (1.0 if world == 1 else 1.15)
+    log2_slots = args.log2_slots
+    if not log2_slots:
+        log2_slots = 20
+        while (1 << log2_slots) * 0.6 < expected:
+            log2_slots += 1
+    packed = gen_packed_reads(torch, dev, args.genome, n_reads, L, args.err, args.seed + 1000 * rank)
+    kc = api.KmerCounter(K, n_sets=P, log2_slots=log2_slots, device=local)
+    kc.set_autogrow(False)
+    wpr = (L + 31) // 32
+    batches = [(lo, min(args.batch_reads, n_reads - lo)) for lo in range(0, n_reads, args.batch_reads)]
+    ord0 = rank * n_kmers
+    ev = []
+
+    def step(timed):
+        kc.reset()
+        for lo, n in batches:
+            view = packed[lo * wpr:]
+            if world == 1:
+                if timed:
+                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    e0.record()
+                kc.count_uniform(view, n, L, ord0 + lo * kpr)
+                if timed:
+                    e1.record()
+                    ev.append((e0, e1, n))
+            else:
+                counts = kc.route_count(view, n, L, world)
+                off = torch.zeros(world + 1, dtype=torch.int64, device=dev)
+                off[1:] = torch.cumsum(counts, 0)
+                send_counts = counts.clone()
+                recv_counts = torch.empty_like(send_counts)
+                dist.all_to_all_single(recv_counts, send_counts)
+                sc, rc = send_counts.tolist(), recv_counts.tolist()
+                rw = kc.nw + 1
+                out = torch.empty(sum(sc) * rw, dtype=torch.int64, device=dev)
+                kc.route_scatter(view, n, L, ord0 + lo * kpr, world, off, out)
+                inp = torch.empty(sum(rc) * rw, dtype=torch.int64, device=dev)
+                dist.all_to_all_single(inp, out, [c * rw for c in rc], [c * rw for c in sc])
+                kc.count_records(inp, sum(rc))
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step(False)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step(True)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    distinct = kc.distinct()                       # also raises if the set overflowed
+    if world > 1:
+        t = torch.tensor([distinct], dtype=torch.int64, device=dev)
+        dist.all_reduce(t)
+        distinct = int(t.item())
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        total_reads = n_reads * world
+        rec = {
+            "metric": f"pregraph_pass1_reads_per_sec_K{K}", "value": total_reads / (dt / args.steps), "unit": "reads/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
+            "distinct_kmers_per_sec": distinct / (dt / args.steps),
+            "kmer_occurrences_per_sec": n_kmers * world / (dt / args.steps),
+            "config": {"workload": f"C. elegans-scale synthetic: {n_reads} reads/GPU x {L} bp, genome {args.genome} bp, err {args.err}, "
+                                   f"K={K}, -p {P} sets (BASELINE.json configs[2])",
+                       "reads_per_gpu": n_reads, "read_len": L, "K": K, "genome": args.genome, "err": args.err,
+                       "distinct_kmers": distinct, "table_slots_log2": log2_slots,
+                       "parallelism": "single GPU, fused extract+insert" if world == 1 else f"set-id owner partition, RCCL all-to-all x{world}"},
+        }
+        if world == 1 and ev:
+            slot_b = 48 if K <= 63 else 80
+            bytes_per_read = kpr * slot_b + (L + 3) // 4          # node read + node write per occurrence + packed read
+            dur = [e0.elapsed_time(e1) * 1e-3 for e0, e1, _ in ev]
+            alg = [n * bytes_per_read for _, _, n in ev]
+            achieved = sum(alg) / sum(dur) / 1e9
+            traffic = None
+            tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            if os.path.exists(tf):
+                try:
+                    traffic = json.load(open(tf)).get("count_reads_kernel_bytes_per_launch")
+                except Exception:
+                    traffic = None
+            rec["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                               "traffic": traffic, "kernel": "count_reads_kernel<2>" if K <= 63 else "count_reads_kernel<4>",
+                               "launches": len(ev), "avg_launch_ms": sum(dur) / len(dur) * 1e3,
+                               "algorithmic_bytes_per_launch": sum(alg) / len(alg)}
+            if not args.no_cpu_baseline:
+                rec["cpu_baseline"] = cpu_baseline(args, os.cpu_count() or 1)
+        print(json.dumps(rec), flush=True)
+    kc.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,170 @@
+/*
+ * soapdenovo2_amd.h -- C ABI of libsoapdenovo2_amd.so: the MI355X-native `pregraph` hot path of SOAPdenovo2.
+ *
+ * Plain C, plain pointers and sizes.  Three layers, outermost first:
+ *
+ *  1. call_pregraph()      the drop-in boundary.  Same signature, argv grammar, output files and exit
+ *                          behaviour as the reference's `int call_pregraph(int argc, char **argv)`
+ *                          (standardPregraph/pregraph.c:62; reached from main, standardPregraph/main.c:72-75).
+ *  2. pg_host_*()          host-side stages that need no GPU: k-mer-set layout replay, tip clipping, edge
+ *                          construction and the writers (replaces newhash.c:340-455, cutTipPreGraph.c,
+ *                          node2edge.c, output_pregraph.c).
+ *  3. pg_* (device)        the HIP operators of pass 1 on caller-owned device buffers: k-mer extraction +
+ *                          hash-set insert, finalize (low-coverage filter, linear marking, k-mer frequency
+ *                          histogram), export (replaces prlHashReads.c:163-259 chopKmer4read,
+ *                          hashFunction.c:155 hash_kmer, newhash.c:473-528 put_kmerset,
+ *                          prlHashReads.c:953-1132 thread_delow/thread_mark/freqStat).
+ *
+ * Every function returns 0 on success and a negative PG_E* code on failure unless stated otherwise;
+ * pg_last_error() returns a thread-local message.  There is no CPU fallback: device functions fail with
+ * PG_ENODEV when no HIP device is usable.
+ */
+#ifndef SOAPDENOVO2_AMD_H
+#define SOAPDENOVO2_AMD_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PG_OK 0
+#define PG_EINVAL (-1)   /* bad argument */
+#define PG_ENODEV (-2)   /* no usable HIP device / HIP runtime error */
+#define PG_ENOMEM (-3)   /* host or device allocation failed, or table full and cannot grow */
+#define PG_EIO (-4)      /* file error */
+#define PG_ESTATE (-5)   /* call order violated */
+
+const char *pg_last_error(void);
+const char *pg_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * 1. Drop-in boundary.
+ *
+ * argv grammar = the reference's getopt string "a:s:o:K:p:d:R" (pregraph.c:142-220):
+ *   pregraph -s configFile -o outputGraph [-K kmer -p n_sets -a initMemoryAssumption -d KmerFreqCutoff -R]
+ * -p is the number of k-mer sets ("threads" in the reference); it fixes the order of .vertex/.edge.gz and
+ * is honoured as such regardless of how many GPUs or host threads do the work.
+ * Writes <o>.kmerFreq <o>.preGraphBasic <o>.vertex <o>.edge.gz (and <o>.preArc, section 8f-1 of SURVEY.md).
+ * Returns 0; fatal errors print to stderr and exit(), as the reference does (check.c:31,96).
+ * call_pregraph        = behaviour of the SOAPdenovo-63mer binary (K <= 63, two hex words per k-mer)
+ * call_pregraph_127mer = behaviour of the SOAPdenovo-127mer binary (K <= 127, four hex words)
+ * Extra environment knobs (not in the reference): SOAPDENOVO2_AMD_DEVICE (HIP device ordinal, default 0).
+ * ------------------------------------------------------------------------------------------------ */
+int call_pregraph(int argc, char **argv);
+int call_pregraph_127mer(int argc, char **argv);
+
+/* ------------------------------------------------------------------------------------------------
+ * Common record type: one distinct canonical k-mer after pass 1.
+ *   key[0..nw)  k-mer words, most significant first (nw = 2 for the 63-mer flavour, 4 for the 127-mer one)
+ *   cnt         low 32 bit = word A (l_links | covs<<24), high 32 bit = word B (r_links | flag bits),
+ *               exactly the two 32-bit words of the reference's kmer_t (inc/newhash.h:77-102)
+ *   ord         bits 55:0 = global ordinal of the k-mer's first occurrence (running k-mer index over all
+ *               accepted reads, prlHashReads.c:647-648); bits 63:56 = k-mer set id = hash_kmer % n_sets
+ * A record is (nw + 2) uint64_t; arrays of records are dense.
+ * ------------------------------------------------------------------------------------------------ */
+#define PG_ORD_BITS 56
+#define PG_ORD_MASK ((1ULL << PG_ORD_BITS) - 1)
+
+/* ------------------------------------------------------------------------------------------------
+ * 2. Host stages (no GPU needed).
+ * ------------------------------------------------------------------------------------------------ */
+
+/* Pack base codes (one byte per base, values 0..3 = A C T G) into the device read format: 2 bits per base,
+ * first base in the most significant bits of a 64-bit word, every read starting on a word boundary.
+ * words_out must hold pg_packed_words(len) words.  Replaces the seqBuffer layout of prlHashReads.c:354-361. */
+size_t pg_packed_words(uint32_t len);
+void pg_pack_read(const uint8_t *codes, uint32_t len, uint64_t *words_out);
+
+/* Build the reference's k-mer-set layout from the distinct k-mers of pass 1 and run everything after it:
+ * [-d] is assumed already applied to `records` by pg_finalize; this replays put_kmerset/encap_kmerset slot
+ * placement (newhash.c:340-528) for n_sets sets, then removeSingleTips/removeMinorTips, kmer2edges and
+ * output_vertex (pregraph.c:106-131), writing <prefix>.vertex .edge.gz .preGraphBasic.
+ *   records        n_records records as described above, any order
+ *   set_last_put   per set: 1 + ordinal of the last k-mer occurrence routed to that set (0 = none); needed
+ *                  to decide whether a duplicate put arrived after the set's last distinct key (the growth
+ *                  check of newhash.c:477 runs before the probe)
+ *   cut_single     non-zero = run removeSingleTips first (the reference does when -d 0, pregraph.c:106)
+ *   a_gb           the -a value (0 = growable sets starting at 1031 slots)
+ *   n_threads      host threads for the per-set replay (0 = hardware concurrency)
+ * out_num_vertex / out_num_edge (may be NULL) receive the counts written to .preGraphBasic. */
+int pg_host_build_graph(const uint64_t *records, uint64_t n_records, const uint64_t *set_last_put,
+                        int K, int mer127, int n_sets, int cut_single, int a_gb, int max_read_len,
+                        int n_threads, const char *prefix, int *out_num_vertex, int *out_num_edge);
+
+/* The layout replay alone (init_kmerset / put_kmerset / encap_kmerset, newhash.c:200-233,340-528): for every
+ * record the slot it occupies in its reference k-mer set, and per set the final table size. */
+int pg_host_replay_layout(const uint64_t *records, uint64_t n_records, const uint64_t *set_last_put, int mer127,
+                          int n_sets, int a_gb, uint64_t *out_slot /* [n_records] */,
+                          uint64_t *out_set_size /* [n_sets], may be NULL */);
+
+/* Write <prefix>.kmerFreq from the 256-bin coverage histogram (freqStat, prlHashReads.c:1104-1132). */
+int pg_host_write_kmerfreq(const uint64_t hist[256], const char *prefix);
+
+/* ------------------------------------------------------------------------------------------------
+ * 3. Device operators (HIP, gfx950).  All pointers named d_* are device pointers owned by the caller;
+ *    `stream` is a hipStream_t (NULL = default stream).  Launches are asynchronous on that stream unless
+ *    stated otherwise.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct pg_ctx pg_ctx;
+
+/* Create a counting context on HIP device `device`.
+ *   K        k-mer size after the reference's clamp (odd, 13..63 or 13..127)
+ *   mer127   0 = two-word k-mers (63-mer binary), 1 = four-word k-mers (127-mer binary)
+ *   n_sets   the reference's -p (1..255)
+ *   log2_slots  initial capacity of the device hash set (it grows by rehash when load would exceed 70 %) */
+pg_ctx *pg_create(int device, int K, int mer127, int n_sets, int log2_slots);
+void pg_destroy(pg_ctx *ctx);
+/* Empty the set (keeps its current capacity); asynchronous on `stream`. */
+int pg_reset(pg_ctx *ctx, void *stream);
+/* on = 0: never grow (and never synchronise) in pg_count_*: the caller guarantees the capacity; if the set
+ * fills up anyway the lost occurrences are reported as PG_ENOMEM by pg_distinct / pg_finalize / pg_export. */
+int pg_set_autogrow(pg_ctx *ctx, int on);
+
+/* Pass 1 over one batch of packed reads already resident in HBM (chopKmer4read + put_kmerset).
+ *   d_packed     packed reads (pg_pack_read layout), padded with >= 4 readable words after the last read
+ *   n_reads      reads in the batch (all have length >= K + 1)
+ *   uniform_len  if non-zero every read has this length, read r starts at word r * pg_packed_words(len) and
+ *                its first k-mer has ordinal ord_base + r * (len - K + 1); d_word_off / d_kmer_base unused
+ *   d_word_off   [n_reads]      start word of each read in d_packed          (ragged batches)
+ *   d_kmer_base  [n_reads + 1]  exclusive prefix sum of (len - K + 1), so read r has
+ *                               d_kmer_base[r+1] - d_kmer_base[r] k-mers      (ragged batches)
+ *   ord_base     ordinal of the batch's first k-mer
+ * The set grows first if this batch could push the load past 70 % (synchronises the stream in that case). */
+int pg_count_reads(pg_ctx *ctx, const uint64_t *d_packed, const uint64_t *d_word_off,
+                   const uint64_t *d_kmer_base, uint64_t n_reads, uint32_t uniform_len,
+                   uint64_t n_kmers, uint64_t ord_base, void *stream);
+
+/* Multi-GPU path, step 1: extract the batch's k-mer occurrences as routed records instead of inserting.
+ * Record = (nw + 1) uint64_t: key words, then meta = ordinal << 6 | left << 3 | right (left/right = base code
+ * or 4 for none).  Records are written grouped by owner = set id % n_owners into d_out at the offsets
+ * d_owner_off[n_owners + 1] computed by pg_route_count (exclusive prefix sum of its counts). */
+int pg_route_count(pg_ctx *ctx, const uint64_t *d_packed, const uint64_t *d_word_off, const uint64_t *d_kmer_base,
+                   uint64_t n_reads, uint32_t uniform_len, uint64_t n_kmers, int n_owners,
+                   uint64_t *d_counts /* [n_owners], zeroed by the call */, void *stream);
+int pg_route_scatter(pg_ctx *ctx, const uint64_t *d_packed, const uint64_t *d_word_off, const uint64_t *d_kmer_base,
+                     uint64_t n_reads, uint32_t uniform_len, uint64_t n_kmers, uint64_t ord_base, int n_owners,
+                     const uint64_t *d_owner_off, uint64_t *d_cursor /* [n_owners] scratch */, uint64_t *d_out,
+                     void *stream);
+/* Multi-GPU path, step 2 (after the all-to-all): insert routed records into this rank's set. */
+int pg_count_records(pg_ctx *ctx, const uint64_t *d_records, uint64_t n_records, void *stream);
+
+/* Number of distinct k-mers stored so far (synchronises the stream). */
+int pg_distinct(pg_ctx *ctx, uint64_t *out, void *stream);
+/* Current capacity (slots) and bytes per slot of the device set. */
+int pg_table_info(pg_ctx *ctx, uint64_t *slots, uint32_t *slot_bytes);
+
+/* After the last batch: apply the -d filter (thread_delow), mark linear nodes and build the coverage
+ * histogram (thread_mark, freqStat) in one scan over the set.  hist_out[256] (host) receives the histogram;
+ * set_last_put_out[n_sets] (host, may be NULL) receives the per-set last-put values.  Synchronises. */
+int pg_finalize(pg_ctx *ctx, int delow, uint64_t hist_out[256], uint64_t *set_last_put_out, void *stream);
+
+/* Compact the stored k-mers into records (layout above) in device memory, d_records holding room for
+ * pg_distinct() records; order is unspecified.  *n_out (host) receives the count.  Synchronises. */
+int pg_export(pg_ctx *ctx, uint64_t *d_records, uint64_t capacity, uint64_t *n_out, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOAPDENOVO2_AMD_H */

@@ -1,0 +1,271 @@
+"""ctypes binding of libsoapdenovo2_amd.so -- the C ABI declared in include/soapdenovo2_amd.h.
+
+Python is plumbing here (tests, bench.py, the multi-GPU launcher): the product is the shared library and
+the SOAPdenovo-63mer / SOAPdenovo-127mer executables next to it.  There is no Python or CPU fallback for the
+device operators: if the library is missing, or no HIP device is usable, the calls raise.
+
+Mirrors the reference's entry point `int call_pregraph(int argc, char **argv)`
+(standardPregraph/pregraph.c:62) as :func:`call_pregraph`.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+import sys
+from typing import Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(_HERE)
+LIB_PATH = os.path.join(_HERE, "libsoapdenovo2_amd.so")
+BIN_DIR = os.path.join(_HERE, "bin")
+
+PG_ORD_BITS = 56
+PG_ORD_MASK = (1 << PG_ORD_BITS) - 1
+
+_lib = None
+
+
+class PgError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> None:
+    """Compile the HIP extension and executables for gfx950 (hipcc cross-compiles without a GPU)."""
+    out = subprocess.run(["make", "-C", ROOT, "-j8"], capture_output=not verbose, text=True)
+    if out.returncode != 0:
+        raise PgError("build failed:\n" + (out.stdout or "") + (out.stderr or ""))
+
+
+def lib() -> C.CDLL:
+    """Load the shared library (import torch first when torch is used in the same process, so that both
+    share torch's HIP runtime)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PgError(f"{LIB_PATH} is missing: run `make` (or __graft_entry__.build()) first; "
+                      "there is no fallback implementation")
+    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    u64p = C.c_void_p
+    L.pg_last_error.restype = C.c_char_p
+    L.pg_version.restype = C.c_char_p
+    L.call_pregraph.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
+    L.call_pregraph_127mer.argtypes = [C.c_int, C.POINTER(C.c_char_p)]
+    L.pg_packed_words.restype = C.c_size_t
+    L.pg_packed_words.argtypes = [C.c_uint32]
+    L.pg_pack_read.argtypes = [C.c_void_p, C.c_uint32, C.c_void_p]
+    L.pg_host_build_graph.argtypes = [u64p, C.c_uint64, u64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                      C.c_int, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
+    L.pg_host_write_kmerfreq.argtypes = [u64p, C.c_char_p]
+    L.pg_host_replay_layout.argtypes = [u64p, C.c_uint64, u64p, C.c_int, C.c_int, C.c_int, u64p, u64p]
+    L.pg_create.restype = C.c_void_p
+    L.pg_create.argtypes = [C.c_int] * 5
+    L.pg_destroy.argtypes = [C.c_void_p]
+    L.pg_reset.argtypes = [C.c_void_p, C.c_void_p]
+    L.pg_set_autogrow.argtypes = [C.c_void_p, C.c_int]
+    L.pg_count_reads.argtypes = [C.c_void_p, u64p, u64p, u64p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p]
+    L.pg_route_count.argtypes = [C.c_void_p, u64p, u64p, u64p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, u64p, C.c_void_p]
+    L.pg_route_scatter.argtypes = [C.c_void_p, u64p, u64p, u64p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int,
+                                   u64p, u64p, u64p, C.c_void_p]
+    L.pg_count_records.argtypes = [C.c_void_p, u64p, C.c_uint64, C.c_void_p]
+    L.pg_distinct.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]
+    L.pg_table_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    L.pg_finalize.argtypes = [C.c_void_p, C.c_int, u64p, u64p, C.c_void_p]
+    L.pg_export.argtypes = [C.c_void_p, u64p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = [
+    "pg_last_error", "pg_version", "call_pregraph", "call_pregraph_127mer", "pg_packed_words", "pg_pack_read",
+    "pg_host_build_graph", "pg_host_replay_layout", "pg_host_write_kmerfreq", "pg_create", "pg_destroy", "pg_reset", "pg_set_autogrow", "pg_count_reads", "pg_route_count",
+    "pg_route_scatter", "pg_count_records", "pg_distinct", "pg_table_info", "pg_finalize", "pg_export",
+]
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise PgError(f"{what} failed ({rc}): {lib().pg_last_error().decode()}")
+
+
+def binary(mer127: bool = False) -> str:
+    return os.path.join(BIN_DIR, "SOAPdenovo-127mer" if mer127 else "SOAPdenovo-63mer")
+
+
+def call_pregraph(args: Sequence[str], mer127: bool = False, in_process: bool = False) -> int:
+    """`pregraph <args>`; args as for the reference, e.g. ["-s", cfg, "-K", "31", "-o", prefix, "-p", "8"].
+
+    By default runs the executable in a child process (fatal input errors `exit()` like the reference's);
+    in_process=True calls the C entry point directly."""
+    if in_process:
+        argv = [b"pregraph"] + [str(a).encode() for a in args]
+        arr = (C.c_char_p * (len(argv) + 1))(*argv, None)
+        fn = lib().call_pregraph_127mer if mer127 else lib().call_pregraph
+        return fn(len(argv), arr)
+    return subprocess.run([binary(mer127), "pregraph"] + [str(a) for a in args]).returncode
+
+
+# ---------------------------------------------------------------------------------------------------------
+# host helpers
+# ---------------------------------------------------------------------------------------------------------
+def packed_words(length: int) -> int:
+    return (length + 31) // 32
+
+
+def pack_reads_uniform(codes: np.ndarray) -> np.ndarray:
+    """(n, L) uint8 base codes -> (n * words_per_read + 8,) uint64 in the device read format (vectorised
+    equivalent of pg_pack_read: first base in the most significant bits, reads word-aligned; 8 words of
+    readable padding at the end)."""
+    codes = np.ascontiguousarray(codes, dtype=np.uint8)
+    n, L = codes.shape
+    wpr = packed_words(L)
+    padded = np.zeros((n, wpr * 32), dtype=np.uint64)
+    padded[:, :L] = codes & 3
+    shifts = (62 - 2 * np.arange(32, dtype=np.uint64)).astype(np.uint64)
+    words = (padded.reshape(n, wpr, 32) << shifts[None, None, :]).sum(axis=2, dtype=np.uint64)
+    out = np.zeros(n * wpr + 8, dtype=np.uint64)
+    out[: n * wpr] = words.reshape(-1)
+    return out
+
+
+def pack_reads_ragged(reads: Sequence[np.ndarray], K: int):
+    """List of 1-D uint8 code arrays (each len >= K + 1) -> (words, word_off, kmer_base) numpy uint64 arrays."""
+    L = lib()
+    n = len(reads)
+    word_off = np.zeros(n, dtype=np.uint64)
+    kmer_base = np.zeros(n + 1, dtype=np.uint64)
+    total = 0
+    for i, r in enumerate(reads):
+        word_off[i] = total
+        total += packed_words(len(r))
+        kmer_base[i + 1] = kmer_base[i] + np.uint64(len(r) - K + 1)
+    words = np.zeros(total + 8, dtype=np.uint64)
+    for i, r in enumerate(reads):
+        r = np.ascontiguousarray(r, dtype=np.uint8)
+        L.pg_pack_read(r.ctypes.data, len(r), words[int(word_off[i]):].ctypes.data)
+    return words, word_off, kmer_base
+
+
+def host_build_graph(records: np.ndarray, set_last_put, K: int, n_sets: int, prefix: str, mer127: bool = False,
+                     cut_single: bool = True, a_gb: int = 0, max_read_len: int = 100, n_threads: int = 0):
+    """records: (n, nw + 2) uint64.  Writes <prefix>.vertex/.edge.gz/.preGraphBasic; returns (n_vertex, n_edge)."""
+    records = np.ascontiguousarray(records, dtype=np.uint64)
+    slp = np.ascontiguousarray(set_last_put, dtype=np.uint64)
+    nv, ne = C.c_int(0), C.c_int(0)
+    rc = lib().pg_host_build_graph(records.ctypes.data, records.shape[0], slp.ctypes.data, K, int(mer127), n_sets,
+                                   int(cut_single), a_gb, max_read_len, n_threads, prefix.encode(), C.byref(nv), C.byref(ne))
+    _check(rc, "pg_host_build_graph")
+    return nv.value, ne.value
+
+
+def host_replay_layout(records: np.ndarray, set_last_put, n_sets: int, mer127: bool = False, a_gb: int = 0):
+    """Slot of every record in its reference k-mer set, and the per-set table sizes."""
+    records = np.ascontiguousarray(records, dtype=np.uint64)
+    slp = np.ascontiguousarray(set_last_put, dtype=np.uint64)
+    slots = np.zeros(records.shape[0], dtype=np.uint64)
+    sizes = np.zeros(n_sets, dtype=np.uint64)
+    _check(lib().pg_host_replay_layout(records.ctypes.data, records.shape[0], slp.ctypes.data, int(mer127), n_sets, a_gb,
+                                       slots.ctypes.data, sizes.ctypes.data), "pg_host_replay_layout")
+    return slots, sizes
+
+
+def host_write_kmerfreq(hist: np.ndarray, prefix: str) -> None:
+    hist = np.ascontiguousarray(hist, dtype=np.uint64)
+    assert hist.shape == (256,)
+    _check(lib().pg_host_write_kmerfreq(hist.ctypes.data, prefix.encode()), "pg_host_write_kmerfreq")
+
+
+# ---------------------------------------------------------------------------------------------------------
+# device operators (torch tensors carry the device memory; the kernels are the library's)
+# ---------------------------------------------------------------------------------------------------------
+class KmerCounter:
+    """Pass-1 counting context on one GPU (pg_create ... pg_export)."""
+
+    def __init__(self, K: int, n_sets: int = 8, mer127: bool = False, log2_slots: int = 24, device: int = 0):
+        import torch  # noqa: F401  (must be loaded before the library, see lib())
+        self.torch = torch
+        self.K, self.P, self.mer127, self.device = K, n_sets, mer127, device
+        self.nw = 4 if mer127 else 2
+        self.h = lib().pg_create(device, K, int(mer127), n_sets, log2_slots)
+        if not self.h:
+            raise PgError("pg_create failed: " + lib().pg_last_error().decode())
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def count_uniform(self, d_packed, n_reads: int, read_len: int, ord_base: int = 0) -> int:
+        """d_packed: int64/uint64 CUDA tensor in the device read format.  Returns the k-mers in the batch."""
+        n_kmers = n_reads * (read_len - self.K + 1)
+        _check(lib().pg_count_reads(self.h, d_packed.data_ptr(), None, None, n_reads, read_len, n_kmers, ord_base,
+                                    self._stream()), "pg_count_reads")
+        return n_kmers
+
+    def count_ragged(self, d_packed, d_word_off, d_kmer_base, n_reads: int, n_kmers: int, ord_base: int = 0) -> int:
+        _check(lib().pg_count_reads(self.h, d_packed.data_ptr(), d_word_off.data_ptr(), d_kmer_base.data_ptr(), n_reads, 0,
+                                    n_kmers, ord_base, self._stream()), "pg_count_reads")
+        return n_kmers
+
+    def route_count(self, d_packed, n_reads: int, read_len: int, n_owners: int):
+        t = self.torch
+        counts = t.zeros(n_owners, dtype=t.int64, device=f"cuda:{self.device}")
+        n_kmers = n_reads * (read_len - self.K + 1)
+        _check(lib().pg_route_count(self.h, d_packed.data_ptr(), None, None, n_reads, read_len, n_kmers, n_owners,
+                                    counts.data_ptr(), self._stream()), "pg_route_count")
+        return counts
+
+    def route_scatter(self, d_packed, n_reads: int, read_len: int, ord_base: int, n_owners: int, owner_off, out):
+        t = self.torch
+        cursor = t.zeros(n_owners, dtype=t.int64, device=f"cuda:{self.device}")
+        n_kmers = n_reads * (read_len - self.K + 1)
+        _check(lib().pg_route_scatter(self.h, d_packed.data_ptr(), None, None, n_reads, read_len, n_kmers, ord_base, n_owners,
+                                      owner_off.data_ptr(), cursor.data_ptr(), out.data_ptr(), self._stream()), "pg_route_scatter")
+
+    def count_records(self, d_records, n_records: int) -> None:
+        _check(lib().pg_count_records(self.h, d_records.data_ptr(), n_records, self._stream()), "pg_count_records")
+
+    def set_autogrow(self, on: bool) -> None:
+        _check(lib().pg_set_autogrow(self.h, int(on)), "pg_set_autogrow")
+
+    def reset(self) -> None:
+        _check(lib().pg_reset(self.h, self._stream()), "pg_reset")
+
+    def distinct(self) -> int:
+        out = C.c_uint64(0)
+        _check(lib().pg_distinct(self.h, C.byref(out), self._stream()), "pg_distinct")
+        return out.value
+
+    def table_info(self):
+        s, b = C.c_uint64(0), C.c_uint32(0)
+        _check(lib().pg_table_info(self.h, C.byref(s), C.byref(b)), "pg_table_info")
+        return s.value, b.value
+
+    def finalize(self, delow: int = 0):
+        hist = np.zeros(256, dtype=np.uint64)
+        last = np.zeros(self.P, dtype=np.uint64)
+        _check(lib().pg_finalize(self.h, delow, hist.ctypes.data, last.ctypes.data, self._stream()), "pg_finalize")
+        return hist, last
+
+    def export(self) -> np.ndarray:
+        """(n, nw + 2) uint64 records on the host (key words, cnt, set << 56 | first ordinal)."""
+        t = self.torch
+        n = self.distinct()
+        rw = self.nw + 2
+        d = t.empty(max(n, 1) * rw, dtype=t.int64, device=f"cuda:{self.device}")
+        got = C.c_uint64(0)
+        _check(lib().pg_export(self.h, d.data_ptr(), n, C.byref(got), self._stream()), "pg_export")
+        assert got.value == n
+        return d[: n * rw].cpu().numpy().view(np.uint64).reshape(n, rw)
+
+    def close(self) -> None:
+        if self.h:
+            lib().pg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

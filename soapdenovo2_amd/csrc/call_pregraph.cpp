@@ -1,0 +1,265 @@
+// call_pregraph.cpp -- the drop-in boundary: `pregraph -s config -o prefix [-K k -p sets -a GB -d cut -R]`.
+//
+// Mirrors standardPregraph/pregraph.c:62-220 (call_pregraph, initenv): same getopt string, same K clamp, same
+// phase order and stderr phase lines, same output files.  Pass 1 runs on the GPU through the pg_* device
+// operators (there is no CPU fallback); the k-mer-set layout replay, tip clipping and edge construction run
+// on the host (host_graph.cpp).
+#include <getopt.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <string>
+#include <vector>
+
+#include <hip/hip_runtime_api.h>
+
+#include "host_graph.hpp"
+#include "host_reads.hpp"
+#include "../../include/soapdenovo2_amd.h"
+
+extern "C" size_t pg_packed_words(uint32_t len) { return (len + 31) / 32; }
+
+extern "C" void pg_pack_read(const uint8_t* codes, uint32_t len, uint64_t* out) {
+    const size_t nw = pg_packed_words(len);
+    for (size_t w = 0; w < nw; w++) {
+        uint64_t v = 0;
+        const uint32_t lo = (uint32_t)w * 32, hi = std::min(len, lo + 32);
+        for (uint32_t i = lo; i < hi; i++) v |= (uint64_t)(codes[i] & 3) << (62 - 2 * (i - lo));
+        out[w] = v;
+    }
+}
+
+namespace {
+
+struct Options {
+    std::string config, prefix;
+    int K = 23, sets = 8, delow = 0, a_gb = 0;       // defaults: inc/global.h:59,79
+    bool reps = false;
+};
+
+void usage(bool mer127) {      // display_pregraph_usage, pregraph.c:222-236
+    fprintf(stderr, "\npregraph -s configFile -o outputGraph [-R] [-K kmer -p n_cpu -a initMemoryAssumption -d KmerFreqCutoff]\n");
+    fprintf(stderr, "  -s <string>      configFile: the config file of solexa reads\n");
+    fprintf(stderr, "  -o <string>      outputGraph: prefix of output graph file name\n");
+    fprintf(stderr, "  -K <int>         kmer(min 13, max %d): kmer size, [23]\n", mer127 ? 127 : 63);
+    fprintf(stderr, "  -p <int>         n_cpu: number of cpu for use, [8]\n");
+    fprintf(stderr, "  -a <int>         initMemoryAssumption: memory assumption initialized to avoid further reallocation, unit GB, [0]\n");
+    fprintf(stderr, "  -R (optional)    output extra information for resolving repeats in contig step, [NO]\n");
+    fprintf(stderr, "  -d <int>         KmerFreqCutoff: kmers with frequency no larger than KmerFreqCutoff will be deleted, [0]\n");
+}
+
+Options parse_args(int argc, char** argv, bool mer127) {      // initenv, pregraph.c:142-220
+    Options o;
+    bool in = false, out = false;
+    optind = 1;
+    fprintf(stderr, "Parameters: pregraph ");
+    int c;
+    while ((c = getopt(argc, argv, "a:s:o:K:p:d:R")) != EOF) {
+        switch (c) {
+            case 's': fprintf(stderr, "-s %s ", optarg); in = true; o.config = optarg; break;
+            case 'o': fprintf(stderr, "-o %s ", optarg); out = true; o.prefix = optarg; break;
+            case 'K': fprintf(stderr, "-K %s ", optarg); o.K = atoi(optarg); break;
+            case 'p': fprintf(stderr, "-p %s ", optarg); o.sets = atoi(optarg); break;
+            case 'R': o.reps = true; fprintf(stderr, "-R "); break;
+            case 'd': fprintf(stderr, "-d %s ", optarg); o.delow = atoi(optarg) >= 0 ? atoi(optarg) : 0; break;
+            case 'a': fprintf(stderr, "-a %s ", optarg); o.a_gb = atoi(optarg); break;
+            default:
+                if (!in || !out) { usage(mer127); exit(-1); }
+        }
+    }
+    fprintf(stderr, "\n\n");
+    if (!in || !out) { usage(mer127); exit(-1); }
+    return o;
+}
+
+[[noreturn]] void die(const char* what) {
+    fprintf(stderr, "%s: %s\n", what, pg_last_error());
+    exit(-1);
+}
+#define HIP_OK(expr)                                                                               \
+    do {                                                                                           \
+        hipError_t e_ = (expr);                                                                    \
+        if (e_ != hipSuccess) { fprintf(stderr, "%s: %s\n", #expr, hipGetErrorString(e_)); exit(-1); } \
+    } while (0)
+
+// Pass 1 driver: reads -> 2-bit packed pinned batches -> hipMemcpyAsync -> pg_count_reads.  Two batches in
+// flight so parsing overlaps the copy + kernel of the previous batch.
+class Pass1 : public pg::ReadSink {
+public:
+    Pass1(pg_ctx* ctx, int K, size_t max_words, size_t max_reads)
+        : ctx_(ctx), K_(K), max_words_(max_words), max_reads_(max_reads) {
+        HIP_OK(hipStreamCreate(&stream_));
+        for (int i = 0; i < 2; i++) {
+            Buf& b = buf_[i];
+            HIP_OK(hipHostMalloc((void**)&b.h_words, (max_words_ + 8) * sizeof(uint64_t), hipHostMallocDefault));
+            HIP_OK(hipHostMalloc((void**)&b.h_off, max_reads_ * sizeof(uint64_t), hipHostMallocDefault));
+            HIP_OK(hipHostMalloc((void**)&b.h_base, (max_reads_ + 1) * sizeof(uint64_t), hipHostMallocDefault));
+            HIP_OK(hipMalloc((void**)&b.d_words, (max_words_ + 8) * sizeof(uint64_t)));
+            HIP_OK(hipMalloc((void**)&b.d_off, max_reads_ * sizeof(uint64_t)));
+            HIP_OK(hipMalloc((void**)&b.d_base, (max_reads_ + 1) * sizeof(uint64_t)));
+            HIP_OK(hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
+            b.busy = false;
+        }
+        reset(buf_[0]);
+    }
+    ~Pass1() {
+        for (int i = 0; i < 2; i++) {
+            Buf& b = buf_[i];
+            hipHostFree(b.h_words); hipHostFree(b.h_off); hipHostFree(b.h_base);
+            hipFree(b.d_words); hipFree(b.d_off); hipFree(b.d_base);
+            hipEventDestroy(b.done);
+        }
+        hipStreamDestroy(stream_);
+    }
+    void on_read(const uint8_t* codes, int len) override {
+        if (len < K_ + 1) return;                               // prlHashReads.c:642
+        const size_t nw = pg_packed_words((uint32_t)len);
+        Buf* b = &buf_[cur_];
+        if (b->n_reads == max_reads_ || b->n_words + nw > max_words_) { submit(); b = &buf_[cur_]; }
+        pg_pack_read(codes, (uint32_t)len, b->h_words + b->n_words);
+        b->h_off[b->n_reads] = b->n_words;
+        b->h_base[b->n_reads] = b->n_kmers;
+        if (b->n_reads == 0) b->first_len = len; else if (len != b->first_len) b->uniform = false;
+        b->n_words += nw;
+        b->n_kmers += (uint64_t)(len - K_ + 1);
+        b->n_reads++;
+        accepted_++;
+    }
+    void finish() { submit(); HIP_OK(hipStreamSynchronize(stream_)); }
+    uint64_t total_kmers() const { return ord_; }
+    hipStream_t stream() const { return stream_; }
+
+private:
+    struct Buf {
+        uint64_t *h_words, *h_off, *h_base, *d_words, *d_off, *d_base;
+        size_t n_reads, n_words;
+        uint64_t n_kmers;
+        int first_len;
+        bool uniform, busy;
+        hipEvent_t done;
+    };
+    void reset(Buf& b) { b.n_reads = 0; b.n_words = 0; b.n_kmers = 0; b.first_len = 0; b.uniform = true; }
+    void submit() {
+        Buf& b = buf_[cur_];
+        if (b.n_reads) {
+            for (int i = 0; i < 8; i++) b.h_words[b.n_words + i] = 0;          // readable padding for the window loads
+            b.h_base[b.n_reads] = b.n_kmers;
+            HIP_OK(hipMemcpyAsync(b.d_words, b.h_words, (b.n_words + 8) * sizeof(uint64_t), hipMemcpyHostToDevice, stream_));
+            if (!b.uniform) {
+                HIP_OK(hipMemcpyAsync(b.d_off, b.h_off, b.n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, stream_));
+                HIP_OK(hipMemcpyAsync(b.d_base, b.h_base, (b.n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream_));
+            }
+            if (pg_count_reads(ctx_, b.d_words, b.uniform ? nullptr : b.d_off, b.uniform ? nullptr : b.d_base, b.n_reads,
+                               b.uniform ? (uint32_t)b.first_len : 0u, b.n_kmers, ord_, stream_) != PG_OK)
+                die("pg_count_reads");
+            HIP_OK(hipEventRecord(b.done, stream_));
+            b.busy = true;
+            ord_ += b.n_kmers;
+        }
+        cur_ ^= 1;
+        Buf& n = buf_[cur_];
+        if (n.busy) { HIP_OK(hipEventSynchronize(n.done)); n.busy = false; }
+        reset(n);
+    }
+    pg_ctx* ctx_;
+    int K_;
+    size_t max_words_, max_reads_;
+    Buf buf_[2];
+    int cur_ = 0;
+    uint64_t ord_ = 0;
+    long long accepted_ = 0;
+    hipStream_t stream_;
+};
+
+int run(int argc, char** argv, bool mer127) {
+    const time_t t_start = time(nullptr);
+    fprintf(stderr, "\n********************\nPregraph\n********************\n\n");
+    Options o = parse_args(argc, argv, mer127);
+    int K = o.K;                                                   // pregraph.c:71-97
+    if (K % 2 == 0) { K++; fprintf(stderr, "K should be an odd number.\n"); }
+    if (K < 13) { K = 13; fprintf(stderr, "K should not be less than 13.\n"); }
+    else if (K > (mer127 ? 127 : 63)) { K = mer127 ? 127 : 63; fprintf(stderr, "K should not be greater than %d.\n", K); }
+    if (o.sets < 1 || o.sets > 255) { fprintf(stderr, "-p must be within 1..255 (k-mer sets).\n"); exit(-1); }
+
+    // ---- pass 1 (prlRead2HashTable, prlHashReads.c:304-760)
+    time_t t0 = time(nullptr);
+    pg::LibConfig cfg = pg::parse_lib_config(o.config.c_str());
+    const int max_read_len = cfg.max_rd_len ? cfg.max_rd_len : 100;          // prlHashReads.c:325-328
+    fprintf(stderr, "In %s, %d lib(s), maximum read length %d, maximum name length %d.\n\n", o.config.c_str(),
+            (int)cfg.libs.size(), max_read_len, 256);
+    std::vector<pg::InputFile> files = pg::input_order(cfg, max_read_len);
+
+    int device = 0;
+    if (const char* e = getenv("SOAPDENOVO2_AMD_DEVICE")) device = atoi(e);
+    // initial device-set size: from -a (24 / 40 bytes per node as the reference assumes) or 2^24 slots; it grows
+    int log2_slots = 24;
+    if (o.a_gb > 0) {
+        const double nodes = (double)o.a_gb * 1073741824.0 / (mer127 ? 40 : 24);
+        while (log2_slots < 36 && (double)((uint64_t)1 << log2_slots) * 0.7 < nodes) log2_slots++;
+    }
+    pg_ctx* ctx = pg_create(device, K, mer127 ? 1 : 0, o.sets, log2_slots);
+    if (!ctx) die("pg_create");
+    fprintf(stderr, "%d k-mer set(s) on HIP device %d.\n", o.sets, device);
+
+    long long n_records = 0;
+    uint64_t total_kmers = 0;
+    {
+        Pass1 p1(ctx, K, (size_t)1 << 23, (size_t)1 << 21);     // 64 MiB of packed reads / 2 M reads per batch
+        for (const pg::InputFile& f : files) {
+            fprintf(stderr, "Import reads from file:\n %s\n", f.path1.c_str());
+            if (!f.path2.empty()) fprintf(stderr, "Import reads from file:\n %s\n", f.path2.c_str());
+            n_records += pg::stream_reads(f, p1);
+        }
+        p1.finish();
+        total_kmers = p1.total_kmers();
+    }
+    uint64_t n_distinct = 0;
+    if (pg_distinct(ctx, &n_distinct, nullptr) != PG_OK) die("pg_distinct");
+    time_t t1 = time(nullptr);
+    fprintf(stderr, "Time spent on hashing reads: %ds, %lld read(s) processed.\n", (int)(t1 - t0), n_records);
+    fprintf(stderr, "%llu node(s) allocated, %llu kmer(s) in reads, %llu kmer(s) processed.\n", (unsigned long long)n_distinct,
+            (unsigned long long)total_kmers, (unsigned long long)total_kmers);
+    fprintf(stderr, "done hashing nodes\n");
+
+    // ---- -d filter, linear marking, .kmerFreq (deLowCov / Mark1in1outNode / freqStat)
+    t0 = time(nullptr);
+    uint64_t hist[256];
+    std::vector<uint64_t> set_last(o.sets, 0);
+    if (pg_finalize(ctx, o.delow, hist, set_last.data(), nullptr) != PG_OK) die("pg_finalize");
+    if (pg_host_write_kmerfreq(hist, o.prefix.c_str()) != PG_OK) die("kmerFreq");
+    fprintf(stderr, "Time spent on marking linear nodes: %ds.\n", (int)(time(nullptr) - t0));
+    fprintf(stderr, "Time spent on pre-graph construction: %ds.\n\n", (int)(time(nullptr) - t_start));
+
+    // ---- export the distinct k-mers and hand over to the host stages
+    const int rw = (mer127 ? 4 : 2) + 2;
+    std::vector<uint64_t> records((size_t)n_distinct * rw);
+    if (n_distinct) {
+        uint64_t* d_rec = nullptr;
+        HIP_OK(hipMalloc((void**)&d_rec, records.size() * sizeof(uint64_t)));
+        uint64_t got = 0;
+        if (pg_export(ctx, d_rec, n_distinct, &got, nullptr) != PG_OK) die("pg_export");
+        if (got != n_distinct) { fprintf(stderr, "export count mismatch\n"); exit(-1); }
+        HIP_OK(hipMemcpy(records.data(), d_rec, records.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        hipFree(d_rec);
+    }
+    pg_destroy(ctx);
+
+    t0 = time(nullptr);
+    int num_vt = 0, num_ed = 0;
+    if (pg_host_build_graph(records.data(), n_distinct, set_last.data(), K, mer127 ? 1 : 0, o.sets, o.delow == 0, o.a_gb,
+                            max_read_len, 0, o.prefix.c_str(), &num_vt, &num_ed) != PG_OK)
+        die("pg_host_build_graph");
+    fprintf(stderr, "Time spent on removing tips and constructing edges: %ds.\n\n", (int)(time(nullptr) - t0));
+    fprintf(stderr, "Overall time spent on constructing pre-graph: %dm.\n\n", (int)(time(nullptr) - t_start) / 60);
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int call_pregraph(int argc, char** argv) { return run(argc, argv, false); }
+extern "C" int call_pregraph_127mer(int argc, char** argv) { return run(argc, argv, true); }

@@ -1,0 +1,573 @@
+// host_graph.cpp -- host stages after pass 1: rebuild the reference's k-mer-set layout from the device's
+// distinct k-mers, then tip clipping, edge construction and the writers.
+//
+// Why a layout replay: .vertex and .edge.gz are emitted by walking KmerSets[0..P-1] slot by slot
+// (node2edge.c:383-406, output_pregraph.c:60-75) and tip clipping mutates nodes in that order
+// (cutTipPreGraph.c:374-395,428-455), so the bytes of the outputs are a function of the slot every k-mer
+// occupies.  A slot is decided by (key mod prime) + linear probing + the whole grow/rehash history
+// (newhash.c:340-528), which depends only on the per-set sequence of distinct keys in first-occurrence
+// order.  The device provides that order (first-occurrence ordinal per key, set id), this file replays it.
+//
+// Everything here is plain C++ (no HIP), templated on NW = words per k-mer (2 = 63-mer binary flavour,
+// 4 = 127-mer flavour).
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <math.h>
+#include <zlib.h>
+
+#include <algorithm>
+#include <atomic>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "kmer.hpp"
+#include "host_graph.hpp"
+#include "../../include/soapdenovo2_amd.h"
+
+namespace pg {
+
+static uint32_t g_crc_tab[256];
+static std::atomic<bool> g_crc_ready{false};
+const uint32_t* host_crc_table() {
+    if (!g_crc_ready.load(std::memory_order_acquire)) {
+        for (uint32_t i = 0; i < 256; i++) g_crc_tab[i] = crc32_table_entry(i);
+        g_crc_ready.store(true, std::memory_order_release);
+    }
+    return g_crc_tab;
+}
+
+// ---- the reference's size schedule (newhash.c:142-185) ----------------------------------------------
+// is_prime_kh tests odd divisors 3 <= i < (u64)sqrt((float)n) -- strict '<' and a float sqrt, so squares of
+// primes pass; table sizes must come from exactly this function.
+static bool ref_is_prime(uint64_t n) {
+    if (n < 4) return true;
+    if ((n & 1) == 0) return false;
+    const uint64_t lim = (uint64_t)sqrt((float)n);
+    for (uint64_t i = 3; i < lim; i += 2)
+        if (n % i == 0) return false;
+    return true;
+}
+static uint64_t ref_next_prime(uint64_t n) {
+    if ((n & 1) == 0) n++;
+    while (!ref_is_prime(n)) n += 2;
+    return n;
+}
+uint64_t ref_initial_set_size(int a_gb, int n_sets, int mer127) {     // prlHashReads.c:369-390 + init_kmerset
+    uint64_t init = 1024;
+    if (a_gb) {
+        const uint64_t want = (uint64_t)((double)a_gb * 1024.0f * 1024.0f * 1024.0f / (double)n_sets / (mer127 ? 40 : 24));
+        uint64_t k = 0;
+        do { ++k; } while (k * 0xFFFFFFULL < want);
+        init = k * 0xFFFFFFULL;
+    }
+    return init < 3 ? 3 : ref_next_prime(init);
+}
+
+template <int NW>
+struct HNode {
+    Kmer<NW> seq;
+    uint32_t A, B;
+};
+
+template <int NW>
+struct HSet {
+    std::vector<HNode<NW>> array;
+    std::vector<uint8_t> occ;
+    uint64_t size = 0, count = 0, max = 0;
+    float lf = 0.77f;
+
+    // home slot (modular, newhash.c:36-57): exact 128-bit modulus for NW = 2; the 127-mer build reduces the
+    // key in 32-bit chunks, which is a true modulus only while size < 2^32 -- restated as is
+    uint64_t home(const Kmer<NW>& k) const {
+        if (NW == 2) {
+            unsigned __int128 t = ((unsigned __int128)k.w[0] << 64) | k.w[1];
+            return (uint64_t)(t % size);
+        }
+        uint64_t t = k.w[0] % size;
+        for (int i = 1; i < NW; i++) {
+            t = (t << 32 | (k.w[i] >> 32)) % size;
+            t = (t << 32 | (k.w[i] & 0xffffffffULL)) % size;
+        }
+        return t;
+    }
+    void init(uint64_t sz) {
+        size = sz; count = 0; lf = 0.77f;
+        max = (uint64_t)((float)size * lf);
+        array.assign(size, HNode<NW>());
+        occ.assign(size, 0);
+    }
+    // encap_kmerset, growable case (newhash.c:368-454): next size, then re-home in place in old-slot order,
+    // an element that lands on a not-yet-moved old element kicks it out and that one is placed next
+    void grow() {
+        uint64_t n = size;
+        do {
+            n = (n < 0xFFFFFFFULL) ? (n << 1) : (n + 0xFFFFFFULL);
+            n = ref_next_prime(n);
+        } while ((float)n * lf < (float)(count + 1));
+        const uint64_t old = size;
+        array.resize(n);
+        std::vector<uint8_t> placed(n, 0);
+        std::vector<uint8_t>& pending = occ;          // 1 = old element not moved yet
+        size = n;
+        max = (uint64_t)((float)n * lf);
+        for (uint64_t i = 0; i < old; i++) {
+            if (!pending[i]) continue;
+            HNode<NW> cur = array[i];
+            pending[i] = 0;
+            for (;;) {
+                uint64_t hc = home(cur.seq);
+                while (placed[hc]) { if (++hc == size) hc = 0; }
+                placed[hc] = 1;
+                if (hc < old && pending[hc]) {
+                    std::swap(cur, array[hc]);
+                    pending[hc] = 0;
+                } else {
+                    array[hc] = cur;
+                    break;
+                }
+            }
+        }
+        occ.swap(placed);
+    }
+    // the growth test of put_kmerset (newhash.c:477) for a static (-a) pool only raises the load factor
+    void before_put(bool static_pool) {
+        if (count + 1 <= max) return;
+        if (static_pool) { lf = 0.88f; max = (uint64_t)((float)size * lf); return; }
+        grow();
+    }
+    void put_new(const HNode<NW>& nd, bool static_pool) {
+        before_put(static_pool);
+        uint64_t hc = home(nd.seq);
+        while (occ[hc]) { if (++hc == size) hc = 0; }
+        occ[hc] = 1;
+        array[hc] = nd;
+        count++;
+    }
+    HNode<NW>* find(const Kmer<NW>& k) {                 // search_kmerset, newhash.c:277-318
+        uint64_t hc = home(k);
+        for (;;) {
+            if (!occ[hc]) return nullptr;
+            if (kmer_eq<NW>(array[hc].seq, k)) return &array[hc];
+            if (++hc == size) hc = 0;
+        }
+    }
+};
+
+template <int NW> static inline int nL(const HNode<NW>& n, int i) { return (n.A >> (6 * i)) & 63; }
+template <int NW> static inline int nR(const HNode<NW>& n, int i) { return (n.B >> (6 * i)) & 63; }
+template <int NW> static inline void clrL(HNode<NW>& n, int i) { n.A &= ~(63u << (6 * i)); }
+template <int NW> static inline void clrR(HNode<NW>& n, int i) { n.B &= ~(63u << (6 * i)); }
+template <int NW> static inline int n_in(const HNode<NW>& n) { int c = 0; for (int i = 0; i < 4; i++) c += nL(n, i) > 0; return c; }
+template <int NW> static inline int n_out(const HNode<NW>& n) { int c = 0; for (int i = 0; i < 4; i++) c += nR(n, i) > 0; return c; }
+
+template <int NW>
+struct Graph {
+    int K, P;
+    Kmer<NW> filter;
+    uint32_t bias;
+    const uint32_t* crc;
+    std::vector<HSet<NW>> sets;
+
+    int set_of(const Kmer<NW>& k) const { return (int)set_of_crc(kmer_crc32<NW>(k, crc), (uint32_t)P, bias); }
+
+    struct Hit { HNode<NW>* node; Kmer<NW> oriented; bool smaller; };
+    // canonicalise a walk-oriented k-mer and look its node up
+    Hit lookup(const Kmer<NW>& word) {
+        Kmer<NW> bal = kmer_rc<NW>(word, K);
+        Hit h;
+        h.oriented = word;
+        if (kmer_less<NW>(bal, word)) { h.smaller = false; h.node = sets[set_of(bal)].find(bal); }
+        else { h.smaller = true; h.node = sets[set_of(word)].find(word); }
+        return h;
+    }
+    // the single outgoing base of a linear node in walk orientation
+    static int only_out(const HNode<NW>& n, bool smaller) {
+        int ch;
+        if (smaller) { for (ch = 0; ch < 4; ch++) if (nR(n, ch)) break; return ch; }
+        for (ch = 0; ch < 4; ch++) if (nL(n, ch)) break;
+        return ch ^ 2;
+    }
+    // dislink2prevUncertain / dislink2nextUncertain (newhash.c:681-717)
+    static void cut_prev(HNode<NW>& n, int ch, bool smaller) { if (smaller) clrL(n, ch); else clrR(n, ch ^ 2); }
+    static void cut_next(HNode<NW>& n, int ch, bool smaller) { if (smaller) clrR(n, ch); else clrL(n, ch ^ 2); }
+
+    // Mark1in1outNode of cutTipPreGraph.c:532-564,603-639
+    void remark_linear() {
+        for (auto& s : sets)
+            for (uint64_t i = 0; i < s.size; i++) {
+                if (!s.occ[i]) continue;
+                HNode<NW>& n = s.array[i];
+                if (n.B & (B_DELETED | B_LINEAR)) continue;
+                if (n_in(n) == 1 && n_out(n) == 1) n.B |= B_LINEAR;
+            }
+    }
+
+    // clipTipFromNode (cutTipPreGraph.c:43-346)
+    bool clip_tip(HNode<NW>& start, int cut_len, bool thin, long long& tips) {
+        const int in = n_in(start), out = n_out(start);
+        Kmer<NW> prev;
+        int ch;
+        if (in == 0 && out == 1) {
+            prev = start.seq;
+            for (ch = 0; ch < 4; ch++) if (nR(start, ch)) break;
+        } else if (in == 1 && out == 0) {
+            prev = kmer_rc<NW>(start.seq, K);
+            for (ch = 0; ch < 4; ch++) if (nL(start, ch)) break;
+            ch ^= 2;
+        } else return false;
+        int count = 1;
+        Hit h = lookup(kmer_next<NW>(prev, ch, filter));
+        if (!h.node) { fprintf(stderr, "Kmer is not found while clipping a tip.\n"); exit(1); }
+        while (h.node->B & B_LINEAR) {
+            count++;
+            if (thin && !(h.node->B & B_SINGLE)) break;
+            if (count > cut_len) return false;
+            prev = h.oriented;
+            h = lookup(kmer_next<NW>(prev, only_out(*h.node, h.smaller), filter));
+            if (!h.node) { fprintf(stderr, "Kmer is not found while clipping a tip.\n"); exit(1); }
+        }
+        HNode<NW>& far = *h.node;
+        if (n_in(far) + n_out(far) == 1) {
+            tips++; start.B |= B_DELETED; far.B |= B_DELETED;
+            return true;
+        }
+        const int first = kmer_first<NW>(prev, K);
+        if (thin) {
+            tips++; start.B |= B_DELETED;
+            cut_prev(far, first, h.smaller);
+            far.B &= ~B_LINEAR;
+            return true;
+        }
+        int strongest = 0;
+        for (int c = 0; c < 4; c++) strongest = std::max(strongest, h.smaller ? nL(far, c) : nR(far, c));
+        const int mine = h.smaller ? nL(far, first) : nR(far, first ^ 2);
+        if (mine < strongest) {
+            tips++; start.B |= B_DELETED;
+            cut_prev(far, first, h.smaller);
+            if (n_in(far) == 1 && n_out(far) == 1) far.B |= B_LINEAR;
+            return true;
+        }
+        return false;
+    }
+
+    // removeSingleTips (cutTipPreGraph.c:363-399)
+    void remove_single_tips() {
+        const int cut = 2 * K;
+        long long tips = 0;
+        fprintf(stderr, "Start to remove frequency-one-kmer tips shorter than %d.\n", cut);
+        for (auto& s : sets)
+            for (uint64_t i = 0; i < s.size; i++) {
+                if (!s.occ[i]) continue;
+                HNode<NW>& n = s.array[i];
+                if (!(n.B & (B_LINEAR | B_DELETED)) && (n.B & B_SINGLE)) clip_tip(n, cut, true, tips);
+            }
+        fprintf(stderr, "Total %lld tip(s) removed.\n", tips);
+        remark_linear();
+    }
+    // removeMinorTips (cutTipPreGraph.c:414-488)
+    void remove_minor_tips() {
+        const int cut = 2 * K;
+        long long tips = 0;
+        fprintf(stderr, "Start to remove tips with minority links.\n");
+        int round = 1;
+        for (;;) {
+            int removed = 0;
+            for (auto& s : sets)
+                for (uint64_t i = 0; i < s.size; i++) {
+                    if (!s.occ[i]) continue;
+                    HNode<NW>& n = s.array[i];
+                    if (!(n.B & (B_LINEAR | B_DELETED))) removed += clip_tip(n, cut, false, tips);
+                }
+            fprintf(stderr, "%d tip(s) removed in cycle %d.\n", removed, round++);
+            if (!removed) break;
+        }
+        fprintf(stderr, "Total %lld tip(s) removed.\n", tips);
+        remark_linear();
+    }
+};
+
+// ---- writers -------------------------------------------------------------------------------------------
+struct GzText {
+    gzFile f = nullptr;
+    std::string buf;
+    bool open(const std::string& path) {
+        f = gzopen(path.c_str(), "w");                   // default level, as gzopen(...,"w") in node2edge.c:66
+        if (f) gzbuffer(f, 1 << 20);
+        buf.reserve(1 << 22);
+        return f != nullptr;
+    }
+    void flush() { if (!buf.empty()) { gzwrite(f, buf.data(), (unsigned)buf.size()); buf.clear(); } }
+    void put(const char* s, size_t n) { buf.append(s, n); if (buf.size() > (1u << 22) - 65536) flush(); }
+    void close() { flush(); gzclose(f); f = nullptr; }
+};
+
+template <int NW>
+static int fmt_kmer(char* dst, const Kmer<NW>& k, char tail) {             // print_kmer, kmer.c:807-817 / 495-505
+    int n = 0;
+    for (int i = 0; i < NW; i++) n += sprintf(dst + n, i ? " %llx" : "%llx", (unsigned long long)k.w[i]);
+    dst[n++] = tail;
+    return n;
+}
+
+template <int NW>
+struct EdgeBuilder {
+    Graph<NW>& g;
+    GzText& out;
+    struct Bead { HNode<NW>* node; Kmer<NW> kmer; bool smaller; };
+    std::vector<Bead> beads;
+    std::string seq;
+    int edge_c = 0;        // running edge id (both strands)
+    long long records = 0, extra_nodes = 0;
+
+    EdgeBuilder(Graph<NW>& g_, GzText& o) : g(g_), out(o) {}
+
+    // stringBeads (node2edge.c:86-218)
+    void walk(int nextch) {
+        typename Graph<NW>::Hit h = g.lookup(kmer_next<NW>(beads[0].kmer, nextch, g.filter));
+        while (h.node && (h.node->B & B_LINEAR)) {
+            beads.push_back(Bead{h.node, h.oriented, h.smaller});
+            h = g.lookup(kmer_next<NW>(h.oriented, Graph<NW>::only_out(*h.node, h.smaller), g.filter));
+        }
+        if (!h.node) { fprintf(stderr, "Kmer is not found while building an edge.\n"); exit(1); }
+        beads.push_back(Bead{h.node, h.oriented, h.smaller});
+    }
+    // check_iden_kmerList (node2edge.c:624-649)
+    bool palindrome() const {
+        const size_t n = beads.size();
+        for (size_t i = 0; i < n; i++)
+            if (!kmer_eq<NW>(beads[i].kmer, kmer_rc<NW>(beads[n - 1 - i].kmer, g.K))) return false;
+        return true;
+    }
+    // merge_linearV2 + output_1edge (node2edge.c:430-609, output_pregraph.c:88-110)
+    void emit() {
+        const int bal = palindrome() ? 0 : 1;
+        const int count = (int)beads.size(), length = count - 1;
+        Bead& first = beads[0];
+        Bead& last = beads[count - 1];
+        Graph<NW>::cut_prev(*last.node, kmer_first<NW>(beads[count - 2].kmer, g.K), last.smaller);
+        Graph<NW>::cut_next(*first.node, kmer_last<NW>(beads[1].kmer), first.smaller);
+        edge_c++;
+        records++;
+        if (length == 1) extra_nodes++;     // the (K+1)-mer of a length-1 edge is pass-2 state (node2edge.c:481-542)
+        long long sum = 0;
+        for (int i = 1; i < count - 1; i++) {
+            const HNode<NW>& n = *beads[i].node;
+            sum += nL(n, 0) + nL(n, 1) + nL(n, 2) + nL(n, 3);
+        }
+        for (int i = 1; i < count - 1; i++) {
+            HNode<NW>& n = *beads[i].node;
+            const uint32_t twin = beads[i].smaller ? (uint32_t)(bal + 1) : (uint32_t)(1 - bal);
+            n.A = beads[i].smaller ? (uint32_t)edge_c : (uint32_t)(edge_c + bal);   // edge id replaces word A
+            n.B = (n.B & 0x0FFFFFFFu) | (twin << B_TWIN_SHIFT) | (1u << B_INEDGE_SHIFT);
+        }
+        int cvg = 0;
+        if (length > 1) { long long v = sum / (length - 1) * 10; cvg = v > 16000 ? 16000 : (int)v; }
+        char head[256];
+        int n = sprintf(head, ">length %d,", length);
+        n += fmt_kmer<NW>(head + n, first.kmer, ',');
+        n += fmt_kmer<NW>(head + n, last.kmer, ',');
+        n += sprintf(head + n, "cvg %d, %d\n", cvg, bal);
+        out.put(head, n);
+        seq.clear();
+        for (int i = 0; i < length; i++) {
+            seq.push_back("ACTG"[kmer_last<NW>(beads[i + 1].kmer)]);
+            if ((i + 1) % 100 == 0) seq.push_back('\n');
+        }
+        if (length % 100 != 0) seq.push_back('\n');
+        out.put(seq.data(), seq.size());
+        edge_c += bal;
+    }
+    // make_edge + startEdgeFromNode (node2edge.c:237-411)
+    void run() {
+        for (auto& s : g.sets)
+            for (uint64_t i = 0; i < s.size; i++) {
+                if (!s.occ[i]) continue;
+                HNode<NW>& n = s.array[i];
+                if (n.B & (B_LINEAR | B_DELETED)) continue;
+                const Kmer<NW> fwd = n.seq, rev = kmer_rc<NW>(n.seq, g.K);
+                for (int ch = 0; ch < 4; ch++) {
+                    if (!nR(n, ch)) continue;
+                    beads.clear();
+                    beads.push_back(Bead{&n, fwd, true});
+                    walk(ch);
+                    emit();
+                }
+                for (int ch = 0; ch < 4; ch++) {
+                    if (!nL(n, ch)) continue;
+                    beads.clear();
+                    beads.push_back(Bead{&n, rev, false});
+                    walk(ch ^ 2);
+                    emit();
+                }
+            }
+    }
+};
+
+// output_vertex (output_pregraph.c:50-86)
+template <int NW>
+static int write_vertex(Graph<NW>& g, const std::string& prefix, int num_ed, int max_read_len, int& num_vt) {
+    FILE* fp = fopen((prefix + ".vertex").c_str(), "w");
+    if (!fp) { pg_set_error("cannot open " + prefix + ".vertex"); return PG_EIO; }
+    std::vector<char> big(1 << 22);
+    setvbuf(fp, big.data(), _IOFBF, big.size());
+    int cnt = 0;
+    char tmp[128];
+    for (auto& s : g.sets)
+        for (uint64_t i = 0; i < s.size; i++) {
+            if (!s.occ[i]) continue;
+            const HNode<NW>& n = s.array[i];
+            if (n.B & (B_LINEAR | B_DELETED)) continue;
+            cnt++;
+            int len = fmt_kmer<NW>(tmp, n.seq, ' ');
+            if (cnt % 8 == 0) tmp[len++] = '\n';
+            fwrite(tmp, 1, len, fp);
+        }
+    fputc('\n', fp);
+    fclose(fp);
+    fprintf(stderr, "%d vertex(es) output.\n", cnt);
+    num_vt = cnt;
+    fp = fopen((prefix + ".preGraphBasic").c_str(), "w");
+    if (!fp) { pg_set_error("cannot open " + prefix + ".preGraphBasic"); return PG_EIO; }
+    fprintf(fp, "VERTEX %d K %d\n", cnt, g.K);
+    fprintf(fp, "\nEDGEs %d\n", num_ed);
+    fprintf(fp, "\nMaxReadLen %d MinReadLen %d MaxNameLen %d\n", max_read_len, 0, 256);
+    fclose(fp);
+    return PG_OK;
+}
+
+// Replay put_kmerset / encap_kmerset slot placement for all sets (newhash.c:340-528): group the records by
+// set, order each group by first-occurrence ordinal, insert in that order (sets in parallel).
+template <int NW>
+static int replay_layout(Graph<NW>& g, const uint64_t* records, uint64_t n, const uint64_t* set_last_put, int K, int P,
+                         int a_gb, int n_threads) {
+    constexpr int RW = NW + 2;
+    g.K = K; g.P = P; g.filter = kmer_filter<NW>(K); g.bias = set_bias((uint32_t)P); g.crc = host_crc_table();
+    g.sets.clear();
+    g.sets.resize(P);
+    std::vector<uint64_t> per_set(P + 1, 0);
+    for (uint64_t i = 0; i < n; i++) {
+        const uint64_t s = records[i * RW + NW + 1] >> PG_ORD_BITS;
+        if (s >= (uint64_t)P) { pg_set_error("record with set id >= n_sets"); return PG_EINVAL; }
+        per_set[s + 1]++;
+    }
+    for (int s = 0; s < P; s++) per_set[s + 1] += per_set[s];
+    struct Ref { uint64_t ord; uint64_t idx; };
+    std::vector<Ref> order(n);
+    {
+        std::vector<uint64_t> cur(per_set.begin(), per_set.end() - 1);
+        for (uint64_t i = 0; i < n; i++) {
+            const uint64_t tag = records[i * RW + NW + 1];
+            order[cur[tag >> PG_ORD_BITS]++] = Ref{tag & PG_ORD_MASK, i};
+        }
+    }
+    const uint64_t init_size = ref_initial_set_size(a_gb, P, NW == 4);
+    std::atomic<int> next{0};
+    auto worker = [&]() {
+        for (;;) {
+            const int s = next.fetch_add(1);
+            if (s >= P) break;
+            Ref* lo = order.data() + per_set[s];
+            Ref* hi = order.data() + per_set[s + 1];
+            std::sort(lo, hi, [](const Ref& a, const Ref& b) { return a.ord < b.ord; });
+            HSet<NW>& hs = g.sets[s];
+            hs.init(init_size);
+            for (Ref* r = lo; r != hi; ++r) {
+                const uint64_t* rec = records + r->idx * RW;
+                HNode<NW> nd;
+                for (int w = 0; w < NW; w++) nd.seq.w[w] = rec[w];
+                nd.A = (uint32_t)rec[NW];
+                nd.B = (uint32_t)(rec[NW] >> 32);
+                hs.put_new(nd, a_gb != 0);
+            }
+            // a duplicate put that arrived after the set's last new key still ran the growth test (newhash.c:477)
+            if (lo != hi && set_last_put && set_last_put[s] > (hi - 1)->ord + 1) hs.before_put(a_gb != 0);
+        }
+    };
+    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    nt = std::max(1, std::min(nt, P));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; t++) pool.emplace_back(worker);
+    worker();
+    for (auto& t : pool) t.join();
+    return PG_OK;
+}
+
+template <int NW>
+static int layout_only(const uint64_t* records, uint64_t n, const uint64_t* set_last_put, int P, int a_gb, uint64_t* out_slot,
+                       uint64_t* out_size) {
+    constexpr int RW = NW + 2;
+    Graph<NW> g;
+    int rc = replay_layout<NW>(g, records, n, set_last_put, 13, P, a_gb, 0);
+    if (rc) return rc;
+    for (uint64_t i = 0; i < n; i++) {
+        const uint64_t* rec = records + i * RW;
+        Kmer<NW> k;
+        for (int w = 0; w < NW; w++) k.w[w] = rec[w];
+        HSet<NW>& hs = g.sets[rec[NW + 1] >> PG_ORD_BITS];
+        out_slot[i] = (uint64_t)(hs.find(k) - hs.array.data());
+    }
+    if (out_size) for (int s = 0; s < P; s++) out_size[s] = g.sets[s].size;
+    return PG_OK;
+}
+
+template <int NW>
+static int build_graph(const uint64_t* records, uint64_t n, const uint64_t* set_last_put, int K, int P, int cut_single,
+                       int a_gb, int max_read_len, int n_threads, const char* prefix_c, int* out_vt, int* out_ed) {
+    const std::string prefix(prefix_c);
+    Graph<NW> g;
+    int rc0 = replay_layout<NW>(g, records, n, set_last_put, K, P, a_gb, n_threads);
+    if (rc0) return rc0;
+
+    // ---- tips (pregraph.c:106-120)
+    if (cut_single) g.remove_single_tips();
+    g.remove_minor_tips();
+
+    // ---- edges (pregraph.c:122-127)
+    GzText gz;
+    if (!gz.open(prefix + ".edge.gz")) { pg_set_error("cannot open " + prefix + ".edge.gz"); return PG_EIO; }
+    EdgeBuilder<NW> eb(g, gz);
+    eb.run();
+    gz.close();
+    fprintf(stderr, "%d (%lld) edge(s) and %lld extra node(s) constructed.\n", eb.edge_c, eb.records, eb.extra_nodes);
+
+    int num_vt = 0;
+    int rc = write_vertex<NW>(g, prefix, eb.edge_c, max_read_len, num_vt);
+    if (rc) return rc;
+    if (out_vt) *out_vt = num_vt;
+    if (out_ed) *out_ed = eb.edge_c;
+    return PG_OK;
+}
+
+}  // namespace pg
+
+extern "C" int pg_host_build_graph(const uint64_t* records, uint64_t n_records, const uint64_t* set_last_put, int K, int mer127,
+                                   int n_sets, int cut_single, int a_gb, int max_read_len, int n_threads, const char* prefix,
+                                   int* out_num_vertex, int* out_num_edge) {
+    if ((!records && n_records) || !prefix) { pg_set_error("null argument"); return PG_EINVAL; }
+    const int maxK = mer127 ? 127 : 63;
+    if (K < 13 || K > maxK || !(K & 1)) { pg_set_error("K must be odd and within 13.." + std::to_string(maxK)); return PG_EINVAL; }
+    if (n_sets < 1 || n_sets > 255) { pg_set_error("n_sets must be 1..255"); return PG_EINVAL; }
+    if (mer127)
+        return pg::build_graph<4>(records, n_records, set_last_put, K, n_sets, cut_single, a_gb, max_read_len, n_threads, prefix, out_num_vertex, out_num_edge);
+    return pg::build_graph<2>(records, n_records, set_last_put, K, n_sets, cut_single, a_gb, max_read_len, n_threads, prefix, out_num_vertex, out_num_edge);
+}
+
+extern "C" int pg_host_replay_layout(const uint64_t* records, uint64_t n_records, const uint64_t* set_last_put, int mer127,
+                                     int n_sets, int a_gb, uint64_t* out_slot, uint64_t* out_set_size) {
+    if ((!records && n_records) || !out_slot) { pg_set_error("null argument"); return PG_EINVAL; }
+    if (n_sets < 1 || n_sets > 255) { pg_set_error("n_sets must be 1..255"); return PG_EINVAL; }
+    if (mer127) return pg::layout_only<4>(records, n_records, set_last_put, n_sets, a_gb, out_slot, out_set_size);
+    return pg::layout_only<2>(records, n_records, set_last_put, n_sets, a_gb, out_slot, out_set_size);
+}
+
+extern "C" int pg_host_write_kmerfreq(const uint64_t hist[256], const char* prefix) {
+    if (!hist || !prefix) { pg_set_error("null argument"); return PG_EINVAL; }
+    FILE* fo = fopen((std::string(prefix) + ".kmerFreq").c_str(), "w");
+    if (!fo) { pg_set_error(std::string("cannot open ") + prefix + ".kmerFreq"); return PG_EIO; }
+    for (int i = 1; i < 256; i++) fprintf(fo, "%lld\n", (long long)hist[i]);     // rows 1..255 only (prlHashReads.c:1113)
+    fclose(fo);
+    return PG_OK;
+}

@@ -1,0 +1,304 @@
+// host_reads.cpp -- library config parser and read ingestion (plain C++, no HIP).
+//
+// Replaces, for the pregraph stage: scan_libInfo (standardPregraph/lib.c:130-506), nextValidIndex /
+// openFileInLib (readseq1by1.c:595-786), AIORead (prlHashReads.c:771-901), readseqfq / readseqInBuf /
+// readseqInLib (readseq1by1.c:138-360, 927-1035).  The point of following the reference's chunking is that
+// the SET and ORDER of reads it hands to pass 1 defines the first-occurrence order of every k-mer and with
+// it the bytes of .vertex / .edge.gz, including its corner cases (reads cut at max_rd_len, records that
+// straddle a 32 KiB chunk, a file whose size is a multiple of 32768).
+#include "host_reads.hpp"
+
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+
+namespace pg {
+
+// ---- config ----------------------------------------------------------------------------------------------
+// splitColumn (lib.c:70-108): the first two maximal runs of printable characters (32..126) other than '='
+static bool split_column(const char* line, std::string tok[2]) {
+    const int len = (int)strlen(line);
+    int i = 0, n = 0;
+    auto ok = [](char c) { return c >= 32 && c <= 126 && c != '='; };
+    while (i < len) {
+        if (ok(line[i])) {
+            tok[n].clear();
+            while (i < len && ok(line[i])) tok[n].push_back(line[i++]);
+            if (++n == 2) return true;
+        }
+        i++;
+    }
+    return false;
+}
+
+LibConfig parse_lib_config(const char* path) {
+    FILE* fp = fopen(path, "r");
+    if (!fp) { fprintf(stderr, "Cannot open %s. Now exit to system...\n", path); exit(-1); }
+    LibConfig cfg;
+    char line[1024];
+    std::string tok[2];
+    int cur = -1;
+    std::vector<bool> pe;
+    while (fgets(line, sizeof line, fp)) {
+        if (strncmp(line, "[LIB]", 5) == 0) {
+            cfg.libs.emplace_back();
+            pe.push_back(false);
+            cur++;
+            continue;
+        }
+        if (!split_column(line, tok)) continue;
+        if (cur < 0) {                                     // only max_rd_len is looked at before the first [LIB]
+            if (tok[0] == "max_rd_len") cfg.max_rd_len = atoi(tok[1].c_str());
+            continue;
+        }
+        LibInfo& L = cfg.libs[cur];
+        const std::string& k = tok[0];
+        const std::string& v = tok[1];
+        if (k == "f1") { L.f1.push_back(v); pe[cur] = true; }
+        else if (k == "q1") { L.q1.push_back(v); pe[cur] = true; }
+        else if (k == "f2") { L.f2.push_back(v); pe[cur] = true; }
+        else if (k == "q2") { L.q2.push_back(v); pe[cur] = true; }
+        else if (k == "f") L.f.push_back(v);
+        else if (k == "q") L.q.push_back(v);
+        else if (k == "p") { L.p.push_back(v); pe[cur] = true; }
+        else if (k == "b") { L.b.push_back(v); pe[cur] = true; }
+        else if (k == "min_ins") L.min_ins = atoi(v.c_str());
+        else if (k == "max_ins") L.max_ins = atoi(v.c_str());
+        else if (k == "avg_ins") L.avg_ins = atoi(v.c_str());
+        else if (k == "rd_len_cutoff") L.rd_len_cutoff = atoi(v.c_str());
+        else if (k == "reverse_seq") L.reverse = atoi(v.c_str());
+        else if (k == "asm_flags") L.asm_flag = atoi(v.c_str());
+        else if (k == "rank") L.rank = atoi(v.c_str());
+        else if (k == "pair_num_cutoff") L.pair_num_cut = atoi(v.c_str());
+        else if (k == "map_len") L.map_len = atoi(v.c_str());
+    }
+    fclose(fp);
+    if (cfg.libs.empty()) { fprintf(stderr, "Config file error: no [LIB] in file\n"); exit(-1); }
+    for (size_t i = 0; i < cfg.libs.size(); i++) {
+        const LibInfo& L = cfg.libs[i];
+        if (L.f1.size() != L.f2.size()) { fprintf(stderr, "Config file error: the number of mark \"f1\" is not the same as \"f2\"!\n"); exit(-1); }
+        if (L.q1.size() != L.q2.size()) { fprintf(stderr, "Config file error: the number of mark \"q1\" is not the same as \"q2\"!\n"); exit(-1); }
+        for (size_t j = 0; j < L.f1.size(); j++)
+            if (L.f1[j] == L.f2[j]) { fprintf(stderr, "Config file error: f2 file is the same as f1 file\nf1=%s\nf2=%s\n", L.f1[j].c_str(), L.f2[j].c_str()); exit(-1); }
+        for (size_t j = 0; j < L.q1.size(); j++)
+            if (L.q1[j] == L.q2[j]) { fprintf(stderr, "Config file error: q2 file is the same as q1 file\nq1=%s\nq2=%s\n", L.q1[j].c_str(), L.q2[j].c_str()); exit(-1); }
+        if (pe[i] && L.avg_ins == 0) { fprintf(stderr, "Config file error: PE reads need avg_ins in [LIB] %d\n", (int)i + 1); exit(-1); }
+    }
+    std::stable_sort(cfg.libs.begin(), cfg.libs.end(), [](const LibInfo& a, const LibInfo& b) { return a.avg_ins < b.avg_ins; });
+    return cfg;
+}
+
+std::vector<InputFile> input_order(const LibConfig& cfg, int max_all) {
+    std::vector<InputFile> out;
+    for (size_t i = 0; i < cfg.libs.size(); i++) {
+        const LibInfo& L = cfg.libs[i];
+        if (L.asm_flag != 1 && L.asm_flag != 3) continue;              // asm_ctg == 1 (prlHashReads.c:308,406)
+        const int mrl = L.rd_len_cutoff > 0 ? std::min(L.rd_len_cutoff, max_all) : max_all;
+        auto add = [&](int type, const std::string& a, const std::string& b) {
+            out.push_back(InputFile{(int)i, type, a, b, mrl, L.reverse});
+        };
+        for (size_t j = 0; j < L.f1.size(); j++) add(1, L.f1[j], L.f2[j]);
+        for (size_t j = 0; j < L.q1.size(); j++) add(2, L.q1[j], L.q2[j]);
+        for (size_t j = 0; j < L.p.size(); j++) add(3, L.p[j], "");
+        for (size_t j = 0; j < L.b.size(); j++) add(4, L.b[j], "");
+        for (size_t j = 0; j < L.f.size(); j++) add(5, L.f[j], "");
+        for (size_t j = 0; j < L.q.size(); j++) add(6, L.q[j], "");
+    }
+    return out;
+}
+
+// ---- chunked file access -----------------------------------------------------------------------------------
+namespace {
+
+constexpr size_t CHUNK = 32768;                          // maxAIOSize, prlHashReads.c:345
+
+struct Source {
+    FILE* fp = nullptr;
+    bool piped = false;
+    void open(std::string name) {                          // openFile4read, readseq1by1.c:676-714
+        while (!name.empty() && name.back() == ' ') name.pop_back();
+        if (name.size() > 3 && name.compare(name.size() - 3, 3, ".gz") == 0) {
+            fp = popen(("gzip -dc " + name).c_str(), "r");
+            piped = true;
+        } else fp = fopen(name.c_str(), "r");
+        if (!fp) { fprintf(stderr, "Cannot open %s. Now exit to system...\n", name.c_str()); exit(-1); }
+    }
+    void close() { if (fp) { if (piped) pclose(fp); else fclose(fp); fp = nullptr; } }
+};
+
+// Where to cut a full 32 KiB FASTQ chunk so the buffer ends on a record boundary: the last "\n@", moved one
+// record back when that '@' opens a quality line (the heuristic of prlHashReads.c:820-855, restated).
+size_t fastq_cut(const char* t, size_t get) {
+    long i = (long)get - 1;
+    int newlines = 0;
+    while (i > 0 && !(t[i] == '@' && t[i - 1] == '\n')) { if (t[i] == '\n') newlines++; i--; }
+    if (i <= 0) return 0;
+    if (newlines <= 1) {
+        long i2 = i - 2;
+        while (i2 >= 0 && t[i2] != '\n') i2--;                     // start of the line before the '@' line
+        if (i2 >= 0 && t[i2 + 1] == '+') {                         // ... it is a '+' line: the '@' line is a quality string
+            i2--;
+            while (i2 >= 0 && t[i2] != '\n') i2--;
+            if (i2 >= 0 && t[i2 + 1] != '+') {
+                long k = i2 - 1;
+                while (k > 0 && !(t[k] == '@' && t[k - 1] == '\n')) k--;
+                i = k > 0 ? k : 0;
+            }
+        }
+    }
+    return (size_t)i;
+}
+size_t fasta_cut(const char* t, size_t get) {                    // prlHashReads.c:856-860
+    long i = (long)get - 1;
+    while (i > 0 && t[i] != '>') i--;
+    return (size_t)i;
+}
+
+// One file read the way AIORead hands it out: buffers that end on record boundaries.
+struct ChunkStream {
+    Source src;
+    bool fastq;
+    std::vector<char> chunk;
+    std::string cache, buf;
+    bool last = false;
+    ChunkStream(const std::string& path, bool fq) : fastq(fq), chunk(CHUNK) { src.open(path); }
+    ~ChunkStream() { src.close(); }
+    // false = nothing more to parse; otherwise `buf` holds the next buffer
+    bool next() {
+        if (last) return false;
+        const size_t get = fread(chunk.data(), 1, CHUNK, src.fp);
+        if (get > 0) {
+            if (get % CHUNK != 0) {
+                buf = cache; buf.append(chunk.data(), get); cache.clear();
+                last = true;
+                return true;
+            }
+            const size_t cut = fastq ? fastq_cut(chunk.data(), get) : fasta_cut(chunk.data(), get);
+            buf = cache; buf.append(chunk.data(), cut);
+            cache.assign(chunk.data() + cut, get - cut);
+            return true;
+        }
+        // The file size is a multiple of 32768: the reference re-parses its previous buffer and loses the
+        // cached tail record (prlHashReads.c:873-877).
+        fprintf(stderr, "Warning : aio_return zero, the size of input file must be N * 32768.\n");
+        cache.clear();
+        last = true;
+        return true;
+    }
+};
+
+inline int base_code(char c) { return (c & 0x06) >> 1; }            // base2int, inc/def.h:39
+
+// letters -> codes, '.' -> A, everything else skipped (readseq1by1.c:322-339)
+inline int convert_line(const char* s, int n, int max_len, uint8_t* out) {
+    if (n > max_len) n = max_len;
+    int k = 0;
+    for (int i = 0; i < n; i++) {
+        const char c = s[i];
+        if (c >= 'a' && c <= 'z') out[k++] = (uint8_t)base_code((char)(c - 'a' + 'A'));
+        else if (c >= 'A' && c <= 'Z') out[k++] = (uint8_t)base_code(c);
+        else if (c == '.') out[k++] = 0;
+    }
+    return k;
+}
+
+// readseqfq (readseq1by1.c:279-360): next record of a FASTQ buffer; returns the read length (0 = none)
+int parse_fastq(const std::string& buf, size_t& start, int max_len, uint8_t* out) {
+    const size_t end = buf.size();
+    size_t p = 0;
+    for (size_t m = start; m < end; m++) {
+        const char c = buf[m];
+        if (c == '@') p = m;
+        else if (c == '\n' && buf[p] == '@') p = m;
+        else if (c == '\n' && buf[p] == '\n' && m > p) {
+            const size_t line_len = m - p - 1;
+            // strlen() of the copied line: stops at an embedded NUL
+            const size_t sl = strnlen(buf.data() + p + 1, line_len);
+            const int n = convert_line(buf.data() + p + 1, (int)sl, max_len, out);
+            size_t q = m + 1;
+            while (q < end && buf[q] != '\n') q++;                   // the '+' line
+            start = q + 2 + sl;                                      // skip the quality line: same length as the sequence line
+            return n;
+        }
+    }
+    return 0;
+}
+
+// readseqInBuf (readseq1by1.c:138-209): next record of a FASTA buffer (single-line sequences)
+int parse_fasta(const std::string& buf, size_t& start, int max_len, uint8_t* out) {
+    const size_t end = buf.size();
+    long p = -1;
+    for (size_t m = start; m < end; m++) {
+        const char c = buf[m];
+        if (c == '>') p = (long)m;
+        else if (c == '\n' && p >= 0 && buf[p] == '>') p = (long)m;
+        else if (c == '\n' && p >= 0 && buf[p] == '\n') {
+            const size_t line_len = m - p - 1;
+            const size_t sl = strnlen(buf.data() + p + 1, line_len);
+            start = m + 1;
+            return convert_line(buf.data() + p + 1, (int)sl, max_len, out);
+        }
+    }
+    return 0;
+}
+
+void reverse_complement(uint8_t* s, int n) {                       // reverse2k, readseq1by1.c:788-802
+    for (int i = 0, j = n - 1; i < j; i++, j--) { uint8_t a = s[i] ^ 2, b = s[j] ^ 2; s[i] = b; s[j] = a; }
+    if (n & 1) s[n / 2] ^= 2;
+}
+
+[[noreturn]] void bad_record(const std::string& buf, size_t start) {   // prlHashReads.c:624-630
+    fprintf(stderr, "readseqInLib return error! please make sure input file is correct fastq/fasta file \n");
+    fprintf(stderr, "invalid data left in buffer:\n%s\n", buf.c_str() + std::min(start, buf.size()));
+    exit(-1);
+}
+
+}  // namespace
+
+long long stream_reads(const InputFile& in, ReadSink& sink) {
+    if (in.type == 4) { fprintf(stderr, "BAM input (b=) is not supported by this build.\n"); exit(-1); }
+    const bool fastq = (in.type == 2 || in.type == 6);
+    std::vector<uint8_t> codes((size_t)std::max(in.max_read_len, 1) + 8);
+    long long n_records = 0;
+    auto parse = [&](const std::string& buf, size_t& start) {
+        const int n = fastq ? parse_fastq(buf, start, in.max_read_len, codes.data())
+                            : parse_fasta(buf, start, in.max_read_len, codes.data());
+        if (n < 1) bad_record(buf, start);
+        if (in.reverse) reverse_complement(codes.data(), n);
+        n_records++;
+        sink.on_read(codes.data(), n);
+    };
+    if (in.type == 1 || in.type == 2) {
+        // mate files: reads alternate file 1, file 2, ... (prlHashReads.c:464-609)
+        ChunkStream s1(in.path1, fastq), s2(in.path2, fastq);
+        bool ok1 = s1.next(), ok2 = s2.next();
+        size_t st1 = 0, st2 = 0;
+        int turn = 1;
+        while ((ok1 && st1 < s1.buf.size()) || (ok2 && st2 < s2.buf.size())) {
+            if (turn == 1) {
+                turn = 2;
+                if (!(ok1 && st1 < s1.buf.size())) bad_record(s1.buf, st1);
+                parse(s1.buf, st1);
+                if (st1 >= s1.buf.size()) { st1 = 0; ok1 = s1.next(); if (!ok1) s1.buf.clear(); }
+            } else {
+                turn = 1;
+                if (!(ok2 && st2 < s2.buf.size())) bad_record(s2.buf, st2);
+                parse(s2.buf, st2);
+                if (st2 >= s2.buf.size()) {
+                    if (s2.last) break;
+                    st2 = 0; ok2 = s2.next(); if (!ok2) s2.buf.clear();
+                }
+            }
+        }
+        return n_records;
+    }
+    ChunkStream s(in.path1, fastq);
+    while (s.next()) {
+        size_t start = 0;
+        while (start < s.buf.size()) parse(s.buf, start);
+    }
+    return n_records;
+}
+
+}  // namespace pg

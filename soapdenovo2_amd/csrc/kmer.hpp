@@ -1,0 +1,198 @@
+// kmer.hpp -- k-mer word arithmetic shared by the host pipeline and the HIP kernels.
+//
+// A k-mer is NW 64-bit words, w[0] most significant, first base in the most significant used bits and the
+// last base in bits 1:0 of w[NW-1] -- the same value the reference keeps in Kmer{high,low} (NW = 2, the
+// "63mer" binary) or Kmer{high1,low1,high2,low2} (NW = 4, the "127mer" binary); standardPregraph/inc/def.h:46-56.
+// Base codes A0 C1 T2 G3, complement = code ^ 2 (inc/def.h:39-42).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define PG_HD __host__ __device__ __forceinline__
+#else
+#define PG_HD inline
+#endif
+
+namespace pg {
+
+template <int NW>
+struct Kmer {
+    uint64_t w[NW];
+};
+
+template <int NW>
+PG_HD bool kmer_eq(const Kmer<NW>& a, const Kmer<NW>& b) {
+    bool e = true;
+#pragma unroll
+    for (int i = 0; i < NW; i++) e = e && (a.w[i] == b.w[i]);
+    return e;
+}
+
+// a < b, most significant word first (KmerSmaller, standardPregraph/kmer.c:608-629)
+template <int NW>
+PG_HD bool kmer_less(const Kmer<NW>& a, const Kmer<NW>& b) {
+    bool lt = false, decided = false;
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+        if (!decided && a.w[i] != b.w[i]) {
+            lt = a.w[i] < b.w[i];
+            decided = true;
+        }
+    }
+    return lt;
+}
+
+// low 2K bits set (createFilter, kmer.c:738-758)
+template <int NW>
+PG_HD Kmer<NW> kmer_filter(int K) {
+    Kmer<NW> f;
+    int bits = 2 * K;
+#pragma unroll
+    for (int i = NW - 1; i >= 0; i--) {
+        f.w[i] = bits >= 64 ? ~0ULL : (bits > 0 ? ((1ULL << bits) - 1) : 0ULL);
+        bits -= 64;
+    }
+    return f;
+}
+
+// reverse the 32 two-bit groups of x
+PG_HD uint64_t rev2bit(uint64_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    x = __builtin_bitreverse64(x);
+    return ((x >> 1) & 0x5555555555555555ULL) | ((x & 0x5555555555555555ULL) << 1);
+#else
+    x = ((x & 0x3333333333333333ULL) << 2) | ((x >> 2) & 0x3333333333333333ULL);
+    x = ((x & 0x0F0F0F0F0F0F0F0FULL) << 4) | ((x >> 4) & 0x0F0F0F0F0F0F0F0FULL);
+    return __builtin_bswap64(x);
+#endif
+}
+
+// logical right shift of the NW-word value by d bits, 0 <= d < 64*NW, written without runtime-indexed
+// arrays so the device version stays in registers
+template <int NW>
+PG_HD Kmer<NW> kmer_shr(Kmer<NW> a, int d) {
+#pragma unroll
+    for (int step = 0; step < NW - 1; step++) {
+        if (d >= 64) {
+#pragma unroll
+            for (int i = NW - 1; i > 0; i--) a.w[i] = a.w[i - 1];
+            a.w[0] = 0;
+            d -= 64;
+        }
+    }
+    if (d > 0) {
+#pragma unroll
+        for (int i = NW - 1; i > 0; i--) a.w[i] = (a.w[i] >> d) | (a.w[i - 1] << (64 - d));
+        a.w[0] >>= d;
+    }
+    return a;
+}
+
+// reverse complement of a right-aligned `len`-mer (reverseComplement, kmer.c:819-855 / 532-591)
+template <int NW>
+PG_HD Kmer<NW> kmer_rc(const Kmer<NW>& a, int len) {
+    Kmer<NW> r;
+#pragma unroll
+    for (int i = 0; i < NW; i++) r.w[NW - 1 - i] = rev2bit(a.w[i] ^ 0xAAAAAAAAAAAAAAAAULL);
+    return kmer_shr<NW>(r, 64 * NW - 2 * len);
+}
+
+// append base ch and drop the first base (nextKmer, kmer.c:696-702)
+template <int NW>
+PG_HD Kmer<NW> kmer_next(Kmer<NW> a, int ch, const Kmer<NW>& filter) {
+#pragma unroll
+    for (int i = 0; i < NW - 1; i++) a.w[i] = ((a.w[i] << 2) | (a.w[i + 1] >> 62)) & filter.w[i];
+    a.w[NW - 1] = ((a.w[NW - 1] << 2) & filter.w[NW - 1]) | (uint64_t)ch;
+    return a;
+}
+
+template <int NW>
+PG_HD int kmer_last(const Kmer<NW>& a) { return (int)(a.w[NW - 1] & 3); }      // lastCharInKmer, kmer.c:720
+
+template <int NW>
+PG_HD int kmer_first(const Kmer<NW>& a, int K) {                                // firstCharInKmer, kmer.c:724
+    int bit = 2 * (K - 1);
+    uint64_t v = 0;
+#pragma unroll
+    for (int i = 0; i < NW; i++)
+        if (NW - 1 - bit / 64 == i) v = a.w[i];
+    return (int)((v >> (bit % 64)) & 3);
+}
+
+// ---- node counter word: the reference's two 32-bit words of kmer_t (inc/newhash.h:77-102) as one u64,
+// A in the low half, B in the high half.
+//   A = l_links (4 x 6 bit, index = base code preceding the canonical k-mer) | covs << 24
+//   B = r_links (4 x 6 bit) | linear << 24 | deleted << 25 | checked << 26 | single << 27 | twin << 28 | inEdge << 30
+constexpr uint32_t B_LINEAR = 1u << 24;
+constexpr uint32_t B_DELETED = 1u << 25;
+constexpr uint32_t B_SINGLE = 1u << 27;
+constexpr int B_TWIN_SHIFT = 28;
+constexpr int B_INEDGE_SHIFT = 30;
+
+// set_new_kmer (newhash.c:123-140): counters for the first occurrence; left/right = 4 means "none"
+PG_HD uint64_t node_first(int left, int right) {
+    uint32_t A = 1u << 24, B = B_SINGLE;
+    if (left < 4) A |= 1u << (6 * left);
+    if (right < 4) B |= 1u << (6 * right);
+    return (uint64_t)A | ((uint64_t)B << 32);
+}
+
+// update_kmer + single = 0 (newhash.c:74-106, 510-511): saturating 6-bit arc counters, 8-bit total
+PG_HD uint64_t node_update(uint64_t cnt, int left, int right) {
+    uint32_t A = (uint32_t)cnt, B = (uint32_t)(cnt >> 32);
+    if (left < 4 && ((A >> (6 * left)) & 63u) < 63u) A += 1u << (6 * left);
+    if (right < 4 && ((B >> (6 * right)) & 63u) < 63u) B += 1u << (6 * right);
+    if ((left < 4 || right < 4) && (A >> 24) < 255u) A += 1u << 24;
+    B &= ~B_SINGLE;
+    return (uint64_t)A | ((uint64_t)B << 32);
+}
+
+// ---- hash_kmer (hashFunction.c:123-158): CRC-32 (reflected 0xEDB88320, init 0, final xor) over the raw
+// struct bytes, returned as `int` by the reference and therefore sign-extended before `% thrd_num`.
+PG_HD uint32_t crc32_table_entry(uint32_t i) {
+    uint32_t c = i;
+#pragma unroll
+    for (int k = 0; k < 8; k++) c = (c & 1) ? (0xEDB88320u ^ (c >> 1)) : (c >> 1);
+    return c;
+}
+
+template <int NW, typename Table>
+PG_HD uint32_t kmer_crc32(const Kmer<NW>& a, const Table& tab) {
+    uint32_t crc = 0;
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+#pragma unroll
+        for (int b = 0; b < 8; b++) crc = tab[(crc ^ (uint32_t)(a.w[i] >> (8 * b))) & 0xff] ^ (crc >> 8);
+    }
+    return crc ^ 0xffffffffu;
+}
+
+// set picker: signext(crc) % P.  For a negative crc the 64-bit value is 2^64 - 2^32 + crc, so the result is
+// ((2^64 - 2^32) % P + crc % P) % P; `bias` = (2^64 - 2^32) % P is precomputed by the caller.
+PG_HD uint32_t set_of_crc(uint32_t crc, uint32_t P, uint32_t bias) {
+    uint32_t r = crc % P;
+    if (crc & 0x80000000u) {
+        r += bias;
+        if (r >= P) r -= P;
+    }
+    return r;
+}
+inline uint32_t set_bias(uint32_t P) { return (uint32_t)(0xFFFFFFFF00000000ULL % P); }
+
+// device-table slot hash (free design; the reference layout is rebuilt on the host, see layout_replay.cpp)
+template <int NW>
+PG_HD uint64_t kmer_mix(const Kmer<NW>& a) {
+    uint64_t h = 0x9E3779B97F4A7C15ULL;
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+        h ^= a.w[i];
+        h *= 0xD6E8FEB86659FD93ULL;
+        h ^= h >> 32;
+    }
+    h *= 0xD6E8FEB86659FD93ULL;
+    h ^= h >> 29;
+    return h;
+}
+
+}  // namespace pg

@@ -1,0 +1,28 @@
+// main.cpp -- `${bin} pregraph -s config -K k -o prefix ...` (standardPregraph/main.c:59-104 dispatches the same
+// way).  Built twice: SOAPdenovo-63mer (call_pregraph) and SOAPdenovo-127mer (-DPG_MER127, call_pregraph_127mer).
+// Only the pregraph sub-command lives here; contig / map / scaff are the reference's unchanged stages and
+// consume the files this one writes.
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/soapdenovo2_amd.h"
+
+static void usage(void) {
+    fprintf(stderr, "\n%s\n\nUsage: SOAPdenovo <command> [option]\n", pg_version());
+    fprintf(stderr, "    pregraph        construct kmer-graph (MI355X)\n");
+    fprintf(stderr, "  (sparse_pregraph, contig, map, scaff, all: run the reference binary on the files written here)\n");
+}
+
+int main(int argc, char** argv) {
+    if (argc < 2) { usage(); return 1; }
+    if (strcmp(argv[1], "pregraph") == 0) {
+#ifdef PG_MER127
+        return call_pregraph_127mer(argc - 1, argv + 1);
+#else
+        return call_pregraph(argc - 1, argv + 1);
+#endif
+    }
+    fprintf(stderr, "Command '%s' is not part of this build.\n", argv[1]);
+    usage();
+    return 1;
+}

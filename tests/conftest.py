@@ -1,0 +1,72 @@
+import gzip
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run on the GPU box with -m gpu)")
+
+
+def _ensure_built():
+    from soapdenovo2_amd import api
+    if not os.path.exists(api.LIB_PATH) or not os.path.exists(api.binary(False)):
+        api.build()
+    if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
+        subprocess.check_call(["make", "-f", "oracle/Makefile", "oracle/liboracle.so"], cwd=ROOT)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def built():
+    _ensure_built()
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return json.load(open(os.path.join(GOLDEN, "cases.json")))
+
+
+def case_tag(name, run):
+    P, D, a, m = run
+    return f"{name}_p{P}_d{D}_a{a}_{'127' if m else '63'}"
+
+
+def md5_file(path):
+    return hashlib.md5(open(path, "rb").read()).hexdigest()
+
+
+def md5_gz_text(path):
+    return hashlib.md5(gzip.open(path, "rb").read()).hexdigest()
+
+
+def case_codes(case):
+    from soapdenovo2_amd import synth
+    return synth.reads_codes(case["G"], case["N"], case["L"], case["err"], case["seed"])
+
+
+def oracle_records(codes, K, P, D=0, mer127=False, a_gb=0, prefix=None):
+    """Pass 1 through the oracle, returned in the product's record format (key words, cnt, set<<56|ord)."""
+    from oracle_binding import Oracle
+    o = Oracle(K, P=P, D=D, a_gb=a_gb, mer127=mer127, max_read_len=codes.shape[1])
+    o.add_reads(codes)
+    o.finish_count(prefix if prefix else os.devnull[:-4] + "null")
+    nd = o.nodes()
+    nw = o.NW
+    rec = np.zeros((len(nd["A"]), nw + 2), dtype=np.uint64)
+    rec[:, :nw] = nd["keys"]
+    rec[:, nw] = nd["A"].astype(np.uint64) | (nd["B"].astype(np.uint64) << np.uint64(32))
+    rec[:, nw + 1] = (nd["set"].astype(np.uint64) << np.uint64(56)) | nd["ord"]
+    last = np.array(o.set_last_put(), dtype=np.uint64)
+    K_eff = o.K
+    o.close()
+    return rec, last, K_eff

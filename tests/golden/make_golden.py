@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Regenerates tests/golden/ by running the reference binaries built by oracle/Makefile.ref (oracle/_ref) on
+synthetic inputs from soapdenovo2_amd.synth.  The reference ships no tests or vectors of its own,
+so these files ARE the parity pin.  Only data is stored: input parameters (cases.json), the reference's output
+files for the small cases, and md5 digests for the larger ones.
+
+    python tests/golden/make_golden.py
+"""
+import gzip, hashlib, json, os, shutil, subprocess, sys, tempfile
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from soapdenovo2_amd import synth
+
+# name: genome, reads, len, err, seed, K, runs [(P, D, a, mer127)], keep full files?
+CASES = {
+    "t6k_k31":  dict(G=30000, N=6000, L=100, err=0.005, seed=20260926, K=31,
+                     runs=[(1,0,0,0), (8,0,0,0), (7,0,0,0), (3,1,0,0), (2,0,1,0)], full=[(1,0,0,0), (8,0,0,0)]),
+    "t8k_k63":  dict(G=40000, N=8000, L=150, err=0.003, seed=3, K=63,
+                     runs=[(2,0,0,0), (8,0,0,0), (2,0,0,1)], full=[(2,0,0,0)]),
+    "t6k_k127": dict(G=40000, N=6000, L=250, err=0.002, seed=5, K=127, runs=[(3,0,0,1)], full=[]),
+    "t5k_k24":  dict(G=20000, N=5000, L=80, err=0.01, seed=12, K=24, runs=[(8,0,0,0)], full=[]),
+    "m100k_k31": dict(G=500000, N=100000, L=100, err=0.005, seed=7, K=31, runs=[(8,0,0,0)], full=[]),
+    "m60k_k63": dict(G=400000, N=60000, L=150, err=0.002, seed=8, K=63, runs=[(8,0,0,0), (8,0,0,1)], full=[]),
+}
+EXTS = ("kmerFreq", "preGraphBasic", "vertex", "edge", "preArc")
+
+
+def tag(name, run):
+    P, D, a, m = run
+    return f"{name}_p{P}_d{D}_a{a}_{'127' if m else '63'}"
+
+
+def main():
+    digests = {}
+    with tempfile.TemporaryDirectory() as td:
+        for name, c in CASES.items():
+            cfg = synth.make_case(td, name, c["G"], c["N"], c["L"], c["err"], c["seed"])
+            for run in c["runs"]:
+                P, D, a, m = run
+                t = tag(name, run)
+                pre = os.path.join(td, t)
+                binary = os.path.join(ROOT, "oracle", "_ref", "SOAPdenovo-127mer" if m else "SOAPdenovo-63mer")
+                cmd = [binary, "pregraph", "-s", cfg, "-K", str(c["K"]), "-o", pre, "-p", str(P)]
+                if D: cmd += ["-d", str(D)]
+                if a: cmd += ["-a", str(a)]
+                subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                with open(pre + ".edge", "wb") as f:          # compare decompressed: gzip bytes depend on the zlib build
+                    f.write(gzip.open(pre + ".edge.gz", "rb").read())
+                digests[t] = {e: hashlib.md5(open(f"{pre}.{e}", "rb").read()).hexdigest() for e in EXTS}
+                # downstream pin (P3): the reference's contig stage on the reference's pregraph files
+                subprocess.run([binary, "contig", "-g", pre], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                digests[t]["contig"] = hashlib.md5(open(pre + ".contig", "rb").read()).hexdigest()
+                if list(run) in [list(r) for r in c["full"]]:
+                    for e in EXTS:
+                        if e == "edge":
+                            with gzip.GzipFile(os.path.join(HERE, f"{t}.edge.gz"), "wb", mtime=0) as g:
+                                g.write(open(pre + ".edge", "rb").read())
+                        else:
+                            shutil.copy(f"{pre}.{e}", os.path.join(HERE, f"{t}.{e}"))
+                print("golden", t, flush=True)
+    cases = {k: {kk: vv for kk, vv in v.items()} for k, v in CASES.items()}
+    json.dump({"cases": cases, "md5": digests}, open(os.path.join(HERE, "cases.json"), "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

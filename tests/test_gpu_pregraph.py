@@ -1,0 +1,218 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path through the C ABI against the CPU oracle on the
+same seeded inputs and against the golden files produced by the real reference."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, case_codes, case_tag, md5_file, md5_gz_text, oracle_records
+
+pytestmark = pytest.mark.gpu
+
+
+def _sorted(rec, nw):
+    order = np.lexsort([rec[:, i] for i in range(nw - 1, -1, -1)])
+    return rec[order]
+
+
+def _gpu_records(codes, K, P, mer127=False, D=0, log2_slots=20, batches=1):
+    import torch
+    from soapdenovo2_amd import api
+    n, L = codes.shape
+    kc = api.KmerCounter(K, n_sets=P, mer127=mer127, log2_slots=log2_slots)
+    kpr = L - K + 1
+    bounds = np.linspace(0, n, batches + 1).astype(int)
+    order = list(range(batches))
+    if batches > 1:
+        order = order[::-1]                 # batches in reverse: the first-occurrence ordinal must not care
+    for b in order:
+        lo, hi = bounds[b], bounds[b + 1]
+        if hi == lo:
+            continue
+        packed = torch.from_numpy(api.pack_reads_uniform(codes[lo:hi]).view(np.int64)).cuda()
+        kc.count_uniform(packed, hi - lo, L, ord_base=int(lo) * kpr)
+    hist, last = kc.finalize(D)
+    rec = kc.export()
+    info = kc.table_info()
+    kc.close()
+    return rec, hist, last, info
+
+
+@pytest.mark.parametrize("name,P,m,D", [("t6k_k31", 8, False, 0), ("t6k_k31", 7, False, 1), ("t8k_k63", 2, False, 0),
+                                        ("t8k_k63", 5, True, 0), ("t6k_k127", 3, True, 0), ("t5k_k24", 8, False, 0)])
+def test_count_matches_oracle(golden, tmp_path, name, P, m, D):
+    c = golden["cases"][name]
+    codes = case_codes(c)
+    want, last_want, K = oracle_records(codes, c["K"], P, D=D, mer127=m, prefix=str(tmp_path / "o"))
+    got, hist, last, _ = _gpu_records(codes, K, P, mer127=m, D=D)
+    nw = 4 if m else 2
+    assert got.shape == want.shape
+    assert (_sorted(got, nw) == _sorted(want, nw)).all()         # keys, counters+flags, set id, first ordinal: bit-exact
+    assert (last == last_want).all()
+    freq = [int(x) for x in open(str(tmp_path / "o.kmerFreq")).read().split()]
+    assert [int(x) for x in hist[1:]] == freq
+
+
+def test_growth_and_batch_order(golden, tmp_path):
+    """Tiny initial set (grows by device rehash several times) and batches submitted in reverse order."""
+    c = golden["cases"]["t6k_k31"]
+    codes = case_codes(c)
+    want, last_want, K = oracle_records(codes, c["K"], 8, prefix=str(tmp_path / "o"))
+    got, hist, last, info = _gpu_records(codes, K, 8, log2_slots=10, batches=5)
+    assert info[0] > 1024
+    assert (_sorted(got, 2) == _sorted(want, 2)).all()
+    assert (last == last_want).all()
+
+
+def test_ragged_batch(tmp_path):
+    """Reads of different lengths (K+1 .. 150) in one batch through the prefix-sum path."""
+    import torch
+    from soapdenovo2_amd import api, synth
+    from oracle_binding import Oracle
+    K, P = 41, 4
+    rng = np.random.default_rng(17)
+    base = synth.reads_codes(20000, 3000, 150, 0.004, 99)
+    lens = rng.integers(K + 1, 151, size=3000)
+    lens[:5] = K + 1
+    reads = [base[i, : lens[i]].copy() for i in range(3000)]
+    o = Oracle(K, P=P, max_read_len=150)
+    o.add_reads(base, lens=lens)
+    o.finish_count(str(tmp_path / "o"))
+    nd = o.nodes()
+    want = np.zeros((len(nd["A"]), 4), dtype=np.uint64)
+    want[:, :2] = nd["keys"]
+    want[:, 2] = nd["A"].astype(np.uint64) | (nd["B"].astype(np.uint64) << np.uint64(32))
+    want[:, 3] = (nd["set"].astype(np.uint64) << np.uint64(56)) | nd["ord"]
+    o.close()
+    words, off, kb = api.pack_reads_ragged(reads, K)
+    kc = api.KmerCounter(K, n_sets=P, log2_slots=18)
+    kc.count_ragged(torch.from_numpy(words.view(np.int64)).cuda(), torch.from_numpy(off.view(np.int64)).cuda(),
+                    torch.from_numpy(kb.view(np.int64)).cuda(), len(reads), int(kb[-1]))
+    kc.finalize(0)
+    got = kc.export()
+    kc.close()
+    assert (_sorted(got, 2) == _sorted(want, 2)).all()
+
+
+def test_route_then_count_equals_fused(golden, tmp_path):
+    """The multi-GPU data path on one GPU: extract + route to 2 owners, insert each owner's records into its own
+    set; the union must equal the fused single-set result, and owners must partition the reference sets."""
+    import torch
+    from soapdenovo2_amd import api
+    c = golden["cases"]["t8k_k63"]
+    codes = case_codes(c)
+    K, P, L, n = c["K"], 8, c["L"], codes.shape[0]
+    want, last_want, _ = oracle_records(codes, K, P, prefix=str(tmp_path / "o"))
+    packed = torch.from_numpy(api.pack_reads_uniform(codes).view(np.int64)).cuda()
+    router = api.KmerCounter(K, n_sets=P, log2_slots=10)
+    owners = 2
+    counts = router.route_count(packed, n, L, owners)
+    off = torch.zeros(owners + 1, dtype=torch.int64, device="cuda")
+    off[1:] = torch.cumsum(counts, 0)
+    total = int(off[-1])
+    assert total == n * (L - K + 1)
+    out = torch.empty(total * 3, dtype=torch.int64, device="cuda")
+    router.route_scatter(packed, n, L, 0, owners, off, out)
+    torch.cuda.synchronize()
+    parts, lasts = [], []
+    for o in range(owners):
+        lo, hi = int(off[o]), int(off[o + 1])
+        kc = api.KmerCounter(K, n_sets=P, log2_slots=18)
+        kc.count_records(out[lo * 3: hi * 3], hi - lo)
+        _, last = kc.finalize(0)
+        rec = kc.export()
+        assert ((rec[:, 3] >> np.uint64(56)) % owners == o).all()
+        parts.append(rec)
+        lasts.append(last)
+        kc.close()
+    router.close()
+    got = np.concatenate(parts)
+    assert (_sorted(got, 2) == _sorted(want, 2)).all()
+    assert (np.maximum(lasts[0], lasts[1]) == last_want).all()
+
+
+def _run_cli(cfg, K, prefix, P, D, a, m):
+    from soapdenovo2_amd import api
+    args = ["-s", cfg, "-K", str(K), "-o", prefix, "-p", str(P)]
+    if D:
+        args += ["-d", str(D)]
+    if a:
+        args += ["-a", str(a)]
+    rc = subprocess.run([api.binary(bool(m)), "pregraph"] + args, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    assert rc.returncode == 0, rc.stderr[-2000:]
+    return rc.stderr
+
+
+@pytest.mark.parametrize("name", ["t6k_k31", "t8k_k63", "t6k_k127", "t5k_k24", "m100k_k31", "m60k_k63"])
+def test_cli_matches_reference_files(golden, tmp_path, name):
+    """`SOAPdenovo-63mer|127mer pregraph -s cfg -K k -o pfx -p n [-d -a]` end to end against the reference's files."""
+    from soapdenovo2_amd import synth
+    c = golden["cases"][name]
+    cfg = synth.make_case(str(tmp_path), name, c["G"], c["N"], c["L"], c["err"], c["seed"])
+    for run in c["runs"]:
+        P, D, a, m = run
+        t = case_tag(name, run)
+        pre = str(tmp_path / t)
+        _run_cli(cfg, c["K"], pre, P, D, a, m)
+        want = golden["md5"][t]
+        assert md5_file(pre + ".kmerFreq") == want["kmerFreq"], t
+        assert md5_file(pre + ".preGraphBasic") == want["preGraphBasic"], t
+        assert md5_file(pre + ".vertex") == want["vertex"], t
+        assert md5_gz_text(pre + ".edge.gz") == want["edge"], t
+
+
+def test_cli_fasta_and_reference_binary(golden, tmp_path):
+    """FASTA input (f=) gives the same files as FASTQ (q=); and, when the reference binary travelled with the
+    snapshot (oracle/_ref), a direct byte comparison on a fresh seed that has no golden file."""
+    from soapdenovo2_amd import synth
+    ref = os.path.join(ROOT, "oracle", "_ref", "SOAPdenovo-63mer")
+    G, N, L, err, seed, K, P = 60000, 20000, 120, 0.004, 4242, 45, 6
+    cfq = synth.make_case(str(tmp_path), "fq", G, N, L, err, seed, fmt="fastq")
+    cfa = synth.make_case(str(tmp_path), "fa", G, N, L, err, seed, fmt="fasta")
+    _run_cli(cfq, K, str(tmp_path / "a"), P, 0, 0, 0)
+    _run_cli(cfa, K, str(tmp_path / "b"), P, 0, 0, 0)
+    for ext in ("kmerFreq", "preGraphBasic", "vertex"):
+        assert md5_file(str(tmp_path / ("a." + ext))) == md5_file(str(tmp_path / ("b." + ext)))
+    assert md5_gz_text(str(tmp_path / "a.edge.gz")) == md5_gz_text(str(tmp_path / "b.edge.gz"))
+    if os.path.exists(ref):
+        subprocess.run([ref, "pregraph", "-s", cfq, "-K", str(K), "-o", str(tmp_path / "r"), "-p", str(P)], check=True,
+                       stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        for ext in ("kmerFreq", "preGraphBasic", "vertex"):
+            assert md5_file(str(tmp_path / ("a." + ext))) == md5_file(str(tmp_path / ("r." + ext))), ext
+        assert md5_gz_text(str(tmp_path / "a.edge.gz")) == md5_gz_text(str(tmp_path / "r.edge.gz"))
+
+
+def test_full_size_properties():
+    """Size-independent properties at a bench-like size (2 M reads x 150 bp, K = 63): every occurrence is
+    accounted for, the histogram covers every stored k-mer, counting the same reads twice doubles nothing but
+    the saturating counters, and a second pass leaves first-occurrence ordinals untouched."""
+    import torch
+    from soapdenovo2_amd import api, synth
+    K, L, n = 63, 150, 2_000_000
+    codes = synth.reads_codes(2_000_000, n, L, 0.001, 31)
+    packed = torch.from_numpy(api.pack_reads_uniform(codes).view(np.int64)).cuda()
+    kc = api.KmerCounter(K, n_sets=8, log2_slots=26)
+    kc.count_uniform(packed, n, L, 0)
+    d1 = kc.distinct()
+    hist, last = kc.finalize(0)
+    r1 = kc.export()
+    assert int(hist.sum()) == d1 == r1.shape[0]
+    assert int(last.max()) == n * (L - K + 1)                      # the very last occurrence went somewhere
+    cov = (r1[:, 2] & np.uint64(0xFFFFFFFF)) >> np.uint64(24)
+    # total coverage (unsaturated part) equals the number of occurrences
+    unsat = cov < 255
+    assert int(cov[unsat].sum()) + int((~unsat).sum()) * 255 <= n * (L - K + 1)
+    kc.reset()
+    kc.count_uniform(packed, n, L, 0)
+    kc.count_uniform(packed, n, L, n * (L - K + 1))                # same reads again, later ordinals
+    assert kc.distinct() == d1
+    kc.finalize(0)
+    r2 = kc.export()
+    kc.close()
+    s1, s2 = _sorted(r1, 2), _sorted(r2, 2)
+    assert (s1[:, :2] == s2[:, :2]).all()
+    assert (s1[:, 3] == s2[:, 3]).all()                            # first ordinals and set ids unchanged
+    cov2 = (s2[:, 2] & np.uint64(0xFFFFFFFF)) >> np.uint64(24)
+    cov1 = (s1[:, 2] & np.uint64(0xFFFFFFFF)) >> np.uint64(24)
+    assert (cov2 == np.minimum(2 * cov1, 255)).all()
