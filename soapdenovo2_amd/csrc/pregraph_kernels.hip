@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <string>
 #include <algorithm>
@@ -207,6 +208,80 @@ __device__ __forceinline__ void table_put(const Table<NW>& t, const Kmer<NW>& ke
     atomicAdd(&ctr->overflow, 1ULL);
 }
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// One slot snapshot in a single round trip: two 16-byte agent-scope (sc1) loads.  A word of a slot only ever
+// goes from its initial value (~0) to its final key value (cnt / ord keep changing but are only used as CAS
+// expectations / skip hints), so a torn or early snapshot is detected by the caller: see table_put_wide.
+__device__ __forceinline__ void load_slot32(const uint64_t* s, uint64_t& a0, uint64_t& a1, uint64_t& b0, uint64_t& b1) {
+    u32x4 lo, hi;
+    asm volatile("global_load_dwordx4 %0, %2, off sc1\n\t"
+                 "global_load_dwordx4 %1, %2, off offset:16 sc1\n\t"
+                 "s_waitcnt vmcnt(0)"
+                 : "=&v"(lo), "=&v"(hi)
+                 : "v"(s)
+                 : "memory");
+    a0 = (uint64_t)lo.x | ((uint64_t)lo.y << 32);
+    a1 = (uint64_t)lo.z | ((uint64_t)lo.w << 32);
+    b0 = (uint64_t)hi.x | ((uint64_t)hi.y << 32);
+    b1 = (uint64_t)hi.z | ((uint64_t)hi.w << 32);
+}
+
+// Same semantics as table_put, two round trips per occurrence in the common (update) case instead of five:
+// one 32-byte snapshot {key[0], key[1], cnt, ord}, then the CAS on cnt seeded with the snapshot.  NW = 2 only.
+__device__ __forceinline__ void table_put_wide(const Table<2>& t, const Kmer<2>& key, int left, int right, uint64_t ord,
+                                               DevCounters* ctr) {
+    uint64_t h = kmer_mix<2>(key) & t.mask;
+    for (uint64_t probes = 0; probes <= t.mask;) {
+        uint64_t* s = t.slots + h * 4;
+        uint64_t w0, w1, cur, o;
+        load_slot32(s, w0, w1, cur, o);
+        if (w0 == SLOT_EMPTY) {
+            uint64_t old = acas(s, SLOT_EMPTY, SLOT_LOCKED);
+            if (old == SLOT_EMPTY) {
+                uint64_t r = axchg(s + 1, key.w[1]);
+                r |= axchg(s + 2, node_first(left, right));
+                r |= axchg(s + 3, ord);
+                asm volatile("" ::"v"(r) : "memory");
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                axchg(s, key.w[0]);
+                atomicAdd(&ctr->n_distinct, 1ULL);
+                return;
+            }
+            // lost the race: the slot is being filled (or was filled) by someone else -- look again
+            __builtin_amdgcn_s_sleep(1);
+            continue;
+        }
+        if (w0 == SLOT_LOCKED) { __builtin_amdgcn_s_sleep(1); continue; }
+        if (w0 == key.w[0]) {
+            // key[1] is written before key[0] is published, but the two halves of the snapshot are not one
+            // atomic read: an unwritten (~0) key[1] next to a published key[0] is re-read before it is believed
+            if (w1 == ~0ULL) w1 = aload(s + 1);
+            if (w1 == key.w[1]) {
+                for (;;) {
+                    uint64_t nxt = node_update(cur, left, right);
+                    if (nxt == cur) break;
+                    uint64_t old = acas(s + 2, cur, nxt);
+                    if (old == cur) break;
+                    cur = old;
+                }
+                if (ord < o) __hip_atomic_fetch_min(s + 3, ord, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                return;
+            }
+        }
+        h = (h + 1) & t.mask;
+        probes++;
+    }
+    atomicAdd(&ctr->overflow, 1ULL);
+}
+
+template <int NW, bool WIDE>
+__device__ __forceinline__ void table_put_any(const Table<NW>& t, const Kmer<NW>& key, int left, int right, uint64_t ord,
+                                              DevCounters* ctr) {
+    if constexpr (WIDE && NW == 2) table_put_wide(t, key, left, right, ord, ctr);
+    else table_put<NW>(t, key, left, right, ord, ctr);
+}
+
 // move one complete node into a fresh table (rehash on growth); keys are unique
 template <int NW>
 __device__ __forceinline__ void table_move(const Table<NW>& t, const Kmer<NW>& key, uint64_t cnt, uint64_t ord,
@@ -231,7 +306,7 @@ __device__ __forceinline__ void table_move(const Table<NW>& t, const Kmer<NW>& k
 // ---- kernels -------------------------------------------------------------------------------------------
 struct SetParams { uint32_t P, bias; };
 
-template <int NW>
+template <int NW, bool WIDE>
 __global__ __launch_bounds__(BLOCK) void count_reads_kernel(Batch b, Table<NW> t, int K, SetParams sp, uint64_t ord_base,
                                                             DevCounters* ctr) {
     __shared__ uint32_t crc_tab[256];
@@ -255,13 +330,13 @@ __global__ __launch_bounds__(BLOCK) void count_reads_kernel(Batch b, Table<NW> t
         const uint64_t ord = ord_base + g;
         const uint32_t set = set_of_crc(kmer_crc32<NW>(key, crc_tab), sp.P, sp.bias);
         atomicMax(&set_last[set], (unsigned long long)(ord + 1));
-        table_put<NW>(t, key, occ.left, occ.right, ord, ctr);
+        table_put_any<NW, WIDE>(t, key, occ.left, occ.right, ord, ctr);
     }
     __syncthreads();
     if (threadIdx.x < sp.P && set_last[threadIdx.x]) atomicMax(&ctr->set_last[threadIdx.x], set_last[threadIdx.x]);
 }
 
-template <int NW>
+template <int NW, bool WIDE>
 __global__ __launch_bounds__(BLOCK) void count_records_kernel(const uint64_t* recs, uint64_t n, Table<NW> t, SetParams sp,
                                                               DevCounters* ctr) {
     __shared__ uint32_t crc_tab[256];
@@ -278,7 +353,7 @@ __global__ __launch_bounds__(BLOCK) void count_records_kernel(const uint64_t* re
         const uint64_t ord = meta >> 6;
         const uint32_t set = set_of_crc(kmer_crc32<NW>(key, crc_tab), sp.P, sp.bias);
         atomicMax(&set_last[set], (unsigned long long)(ord + 1));
-        table_put<NW>(t, key, (int)((meta >> 3) & 7), (int)(meta & 7), ord, ctr);
+        table_put_any<NW, WIDE>(t, key, (int)((meta >> 3) & 7), (int)(meta & 7), ord, ctr);
     }
     __syncthreads();
     if (threadIdx.x < sp.P && set_last[threadIdx.x]) atomicMax(&ctr->set_last[threadIdx.x], set_last[threadIdx.x]);
@@ -468,6 +543,7 @@ struct pg_ctx {
     uint64_t ub_distinct;    // host upper bound on stored keys (avoids a sync per batch)
     bool finalized;
     bool autogrow;
+    int variant;             // 0 = word-wise atomic loads, 1 = 32-byte slot snapshot (PG_VARIANT, default 1)
 };
 
 static inline uint64_t slot_bytes(int NW) { return (NW == 2 ? 4 : 8) * sizeof(uint64_t); }
@@ -484,6 +560,8 @@ extern "C" pg_ctx* pg_create(int device, int K, int mer127, int n_sets, int log2
     pg_ctx* c = new pg_ctx();
     c->device = device; c->K = K; c->NW = mer127 ? 4 : 2; c->P = n_sets; c->log2_slots = log2_slots;
     c->ub_distinct = 0; c->finalized = false; c->autogrow = true; c->slots = nullptr; c->ctr = nullptr;
+    c->variant = 1;
+    if (const char* v = getenv("PG_VARIANT")) c->variant = atoi(v);
     const size_t bytes = ((size_t)1 << log2_slots) * slot_bytes(c->NW);
     if (hipMalloc(&c->slots, bytes) != hipSuccess) { g_err = "pg_create: hipMalloc of the k-mer set failed"; delete c; return nullptr; }
     if (hipMalloc(&c->ctr, sizeof(DevCounters)) != hipSuccess) { g_err = "pg_create: hipMalloc failed"; hipFree(c->slots); delete c; return nullptr; }
@@ -602,10 +680,13 @@ extern "C" int pg_count_reads(pg_ctx* c, const uint64_t* d_packed, const uint64_
     const uint64_t mask = ((uint64_t)1 << c->log2_slots) - 1;
     if (c->NW == 2) {
         Table<2> t{c->slots, mask};
-        hipLaunchKernelGGL(count_reads_kernel<2>, dim3((unsigned)grid), dim3(BLOCK), 0, st, b, t, c->K, set_params(c), ord_base, c->ctr);
+        if (c->variant == 1)
+            hipLaunchKernelGGL((count_reads_kernel<2, true>), dim3((unsigned)grid), dim3(BLOCK), 0, st, b, t, c->K, set_params(c), ord_base, c->ctr);
+        else
+            hipLaunchKernelGGL((count_reads_kernel<2, false>), dim3((unsigned)grid), dim3(BLOCK), 0, st, b, t, c->K, set_params(c), ord_base, c->ctr);
     } else {
         Table<4> t{c->slots, mask};
-        hipLaunchKernelGGL(count_reads_kernel<4>, dim3((unsigned)grid), dim3(BLOCK), 0, st, b, t, c->K, set_params(c), ord_base, c->ctr);
+        hipLaunchKernelGGL((count_reads_kernel<4, false>), dim3((unsigned)grid), dim3(BLOCK), 0, st, b, t, c->K, set_params(c), ord_base, c->ctr);
     }
     HIP_TRY(hipGetLastError());
     return PG_OK;
@@ -623,10 +704,13 @@ extern "C" int pg_count_records(pg_ctx* c, const uint64_t* d_records, uint64_t n
     const uint64_t mask = ((uint64_t)1 << c->log2_slots) - 1;
     if (c->NW == 2) {
         Table<2> t{c->slots, mask};
-        hipLaunchKernelGGL(count_records_kernel<2>, dim3(grid), dim3(BLOCK), 0, st, d_records, n, t, set_params(c), c->ctr);
+        if (c->variant == 1)
+            hipLaunchKernelGGL((count_records_kernel<2, true>), dim3(grid), dim3(BLOCK), 0, st, d_records, n, t, set_params(c), c->ctr);
+        else
+            hipLaunchKernelGGL((count_records_kernel<2, false>), dim3(grid), dim3(BLOCK), 0, st, d_records, n, t, set_params(c), c->ctr);
     } else {
         Table<4> t{c->slots, mask};
-        hipLaunchKernelGGL(count_records_kernel<4>, dim3(grid), dim3(BLOCK), 0, st, d_records, n, t, set_params(c), c->ctr);
+        hipLaunchKernelGGL((count_records_kernel<4, false>), dim3(grid), dim3(BLOCK), 0, st, d_records, n, t, set_params(c), c->ctr);
     }
     HIP_TRY(hipGetLastError());
     return PG_OK;
