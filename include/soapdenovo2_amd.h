@@ -77,6 +77,14 @@ int call_pregraph_127mer(int argc, char **argv);
 size_t pg_packed_words(uint32_t len);
 void pg_pack_read(const uint8_t *codes, uint32_t len, uint64_t *words_out);
 
+/* The ingestion stage alone (scan_libInfo lib.c:130-506, openNextFile/AIORead prlHashReads.c:771-951, readseqInLib
+ * readseq1by1.c:927-1035): parse `config`, visit the input files in the reference's order and deliver every read it
+ * would hand to pass 1 (length >= K + 1 after truncation to max_rd_len / rd_len_cutoff, reverse_seq applied) as base
+ * codes, read i at codes_out + i * stride with its length in lens_out[i].  codes_out = NULL only counts.
+ * n_records = records parsed (the reference's "read(s) processed"), n_accepted = reads delivered. */
+int pg_host_read_all(const char *config, int K, uint8_t *codes_out, int32_t *lens_out, uint64_t capacity_reads,
+                     uint64_t stride, uint64_t *n_records, uint64_t *n_accepted, int *max_read_len_out);
+
 /* Build the reference's k-mer-set layout from the distinct k-mers of pass 1 and run everything after it:
  * [-d] is assumed already applied to `records` by pg_finalize; this replays put_kmerset/encap_kmerset slot
  * placement (newhash.c:340-528) for n_sets sets, then removeSingleTips/removeMinorTips, kmer2edges and

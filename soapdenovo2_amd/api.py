@@ -60,6 +60,8 @@ def lib() -> C.CDLL:
     L.pg_host_build_graph.argtypes = [u64p, C.c_uint64, u64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                       C.c_int, C.c_char_p, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.pg_host_write_kmerfreq.argtypes = [u64p, C.c_char_p]
+    L.pg_host_read_all.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
+                                   C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
     L.pg_host_replay_layout.argtypes = [u64p, C.c_uint64, u64p, C.c_int, C.c_int, C.c_int, u64p, u64p]
     L.pg_create.restype = C.c_void_p
     L.pg_create.argtypes = [C.c_int] * 5
@@ -81,7 +83,7 @@ def lib() -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "pg_last_error", "pg_version", "call_pregraph", "call_pregraph_127mer", "pg_packed_words", "pg_pack_read",
-    "pg_host_build_graph", "pg_host_replay_layout", "pg_host_write_kmerfreq", "pg_create", "pg_destroy", "pg_reset", "pg_set_autogrow", "pg_count_reads", "pg_route_count",
+    "pg_host_build_graph", "pg_host_read_all", "pg_host_replay_layout", "pg_host_write_kmerfreq", "pg_create", "pg_destroy", "pg_reset", "pg_set_autogrow", "pg_count_reads", "pg_route_count",
     "pg_route_scatter", "pg_count_records", "pg_distinct", "pg_table_info", "pg_finalize", "pg_export",
 ]
 
@@ -159,6 +161,18 @@ def host_build_graph(records: np.ndarray, set_last_put, K: int, n_sets: int, pre
                                    int(cut_single), a_gb, max_read_len, n_threads, prefix.encode(), C.byref(nv), C.byref(ne))
     _check(rc, "pg_host_build_graph")
     return nv.value, ne.value
+
+
+def host_read_all(config: str, K: int):
+    """All reads the reference would hand to pass 1, in its order: (codes [n, stride] uint8, lens int32, n_records, max_rd_len)."""
+    nrec, nacc, mrl = C.c_uint64(0), C.c_uint64(0), C.c_int(0)
+    _check(lib().pg_host_read_all(config.encode(), K, None, None, 0, 0, C.byref(nrec), C.byref(nacc), C.byref(mrl)), "pg_host_read_all")
+    n, stride = nacc.value, max(mrl.value, 1)
+    codes = np.zeros((max(n, 1), stride), dtype=np.uint8)
+    lens = np.zeros(max(n, 1), dtype=np.int32)
+    _check(lib().pg_host_read_all(config.encode(), K, codes.ctypes.data, lens.ctypes.data, n, stride, C.byref(nrec), C.byref(nacc),
+                                  C.byref(mrl)), "pg_host_read_all")
+    return codes[:n], lens[:n], nrec.value, mrl.value
 
 
 def host_replay_layout(records: np.ndarray, set_last_put, n_sets: int, mer127: bool = False, a_gb: int = 0):

@@ -34,6 +34,34 @@ extern "C" void pg_pack_read(const uint8_t* codes, uint32_t len, uint64_t* out) 
     }
 }
 
+// Host-only view of the ingestion stage (a1 + a2): every accepted read in the reference's order.
+extern "C" int pg_host_read_all(const char* config, int K, uint8_t* codes_out, int32_t* lens_out, uint64_t capacity_reads,
+                                uint64_t stride, uint64_t* n_records, uint64_t* n_accepted, int* max_read_len_out) {
+    if (!config) { pg_set_error("null config path"); return PG_EINVAL; }
+    struct Collect : pg::ReadSink {
+        int K; uint8_t* codes; int32_t* lens; uint64_t cap, stride, n = 0; bool overflow = false;
+        void on_read(const uint8_t* c, int len) override {
+            if (len < K + 1) return;
+            if (codes) {
+                if (n >= cap || (uint64_t)len > stride) { overflow = true; n++; return; }
+                memcpy(codes + n * stride, c, (size_t)len);
+                if (lens) lens[n] = len;
+            }
+            n++;
+        }
+    } sink;
+    sink.K = K; sink.codes = codes_out; sink.lens = lens_out; sink.cap = capacity_reads; sink.stride = stride;
+    pg::LibConfig cfg = pg::parse_lib_config(config);
+    const int mrl = cfg.max_rd_len ? cfg.max_rd_len : 100;
+    long long rec = 0;
+    for (const pg::InputFile& f : pg::input_order(cfg, mrl)) rec += pg::stream_reads(f, sink);
+    if (n_records) *n_records = (uint64_t)rec;
+    if (n_accepted) *n_accepted = sink.n;
+    if (max_read_len_out) *max_read_len_out = mrl;
+    if (sink.overflow) { pg_set_error("pg_host_read_all: output buffers too small"); return PG_ENOMEM; }
+    return PG_OK;
+}
+
 namespace {
 
 struct Options {

@@ -89,3 +89,79 @@ def make_case(outdir: str, name: str, genome_len: int, n_reads: int, read_len: i
     cfg = os.path.join(outdir, name + ".cfg")
     write_config(cfg, data, read_len, key)
     return cfg
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Reader corner cases (SURVEY.md section 7 "bit-exactness quirks"): small inputs that exercise the reference's
+# chunked reader and record parsers.  Deterministic; used by tests/golden/make_golden.py and the tests.
+# ---------------------------------------------------------------------------------------------------------
+def _fastq_blob(codes_list, names, lower_every=0, n_every=0, dot_every=0):
+    chunks = []
+    for i, (c, nm) in enumerate(zip(codes_list, names)):
+        seq = bytearray(_ASCII[np.asarray(c, dtype=np.uint8)].tobytes())
+        if n_every and i % n_every == 1 and len(seq) > 5:
+            seq[3] = ord("N")
+        if dot_every and i % dot_every == 2 and len(seq) > 7:
+            seq[6] = ord(".")
+        if lower_every and i % lower_every == 0:
+            seq = bytearray(bytes(seq).lower())
+        chunks.append(b"@" + nm + b"\n" + bytes(seq) + b"\n+\n" + b"I" * len(seq) + b"\n")
+    return chunks
+
+
+def make_quirk_case(outdir: str, name: str) -> str:
+    """Write the input files + config of one reader corner case; returns the config path."""
+    os.makedirs(outdir, exist_ok=True)
+    p = lambda f: os.path.abspath(os.path.join(outdir, f))
+    cfg = p(name + ".cfg")
+    if name == "rq_32k":
+        # file size an exact multiple of 32768: the reference parses its last full buffer twice and drops the tail
+        codes = reads_codes(20000, 700, 100, 0.005, 101)
+        names = [b"r%d" % i for i in range(700)]
+        size = sum(len(n) for n in names) + 700 * (1 + 1 + 100 + 1 + 2 + 100 + 1)
+        deficit = (-size) % 32768
+        per, extra = divmod(deficit, 700)
+        names = [n + b"x" * (per + (1 if i < extra else 0)) for i, n in enumerate(names)]
+        blob = b"".join(_fastq_blob(list(codes), names))
+        assert len(blob) % 32768 == 0
+        open(p(name + ".fq"), "wb").write(blob)
+        open(cfg, "w").write(f"max_rd_len=100\n[LIB]\navg_ins=200\nasm_flags=3\nq={p(name + '.fq')}\n")
+    elif name == "rq_trunc":
+        # two libs visited in avg_ins order (the second in the file comes first), max_rd_len cut, rd_len_cutoff,
+        # reverse_seq, FASTA + FASTQ in one lib, lower case / N / '.' bases, a lib with asm_flags=2 (skipped)
+        a = reads_codes(15000, 900, 100, 0.004, 102)
+        b = reads_codes(15000, 600, 100, 0.004, 103)
+        c = reads_codes(15000, 300, 100, 0.004, 104)
+        open(p(name + "_a.fq"), "wb").write(b"".join(_fastq_blob(list(a), [b"a%d some text" % i for i in range(900)], lower_every=7, n_every=11, dot_every=13)))
+        fa = b"".join(b">b%d\n" % i + _ASCII[b[i]].tobytes() + b"\n" for i in range(600))
+        open(p(name + "_b.fa"), "wb").write(fa)
+        open(p(name + "_c.fq"), "wb").write(b"".join(_fastq_blob(list(c), [b"c%d" % i for i in range(300)])))
+        open(cfg, "w").write(
+            f"max_rd_len=80\n[LIB]\navg_ins=500\nreverse_seq=1\nasm_flags=3\nrank=2\nq={p(name + '_a.fq')}\n"
+            f"[LIB]\navg_ins=200\nreverse_seq=0\nasm_flags=1\nrd_len_cutoff=60\nq={p(name + '_c.fq')}\nf={p(name + '_b.fa')}\n"
+            f"[LIB]\navg_ins=300\nasm_flags=2\nq={p(name + '_a.fq')}\n")
+    elif name == "rq_ragged":
+        # read lengths 20..120 (some shorter than K + 1 = 32 and dropped), records straddling 32 KiB chunk boundaries
+        rng = np.random.default_rng(105)
+        base = reads_codes(30000, 2500, 120, 0.004, 106)
+        lens = rng.integers(20, 121, size=2500)
+        open(p(name + ".fq"), "wb").write(b"".join(_fastq_blob([base[i, :lens[i]] for i in range(2500)], [b"read_%d/1" % i for i in range(2500)])))
+        open(cfg, "w").write(f"max_rd_len=120\n[LIB]\navg_ins=200\nasm_flags=3\nq={p(name + '.fq')}\n")
+    elif name == "rq_pair":
+        # mate files: reads alternate file 1 / file 2 (q1/q2 and f1/f2 in one lib)
+        a = reads_codes(20000, 800, 90, 0.004, 107)
+        b = reads_codes(20000, 800, 90, 0.004, 108)
+        c = reads_codes(20000, 400, 90, 0.004, 109)
+        d = reads_codes(20000, 400, 90, 0.004, 110)
+        open(p(name + "_1.fq"), "wb").write(b"".join(_fastq_blob(list(a), [b"p%d/1" % i for i in range(800)])))
+        open(p(name + "_2.fq"), "wb").write(b"".join(_fastq_blob(list(b), [b"p%d/2" % i for i in range(800)])))
+        open(p(name + "_1.fa"), "wb").write(b"".join(b">s%d/1\n" % i + _ASCII[c[i]].tobytes() + b"\n" for i in range(400)))
+        open(p(name + "_2.fa"), "wb").write(b"".join(b">s%d/2\n" % i + _ASCII[d[i]].tobytes() + b"\n" for i in range(400)))
+        open(cfg, "w").write(f"max_rd_len=90\n[LIB]\navg_ins=300\nreverse_seq=0\nasm_flags=3\n"
+                             f"q1={p(name + '_1.fq')}\nq2={p(name + '_2.fq')}\nf1={p(name + '_1.fa')}\nf2={p(name + '_2.fa')}\n")
+    else:
+        raise ValueError(name)
+    return cfg
+
+
+QUIRK_CASES = ["rq_32k", "rq_trunc", "rq_ragged", "rq_pair"]

@@ -59,8 +59,23 @@ def main():
                         else:
                             shutil.copy(f"{pre}.{e}", os.path.join(HERE, f"{t}.{e}"))
                 print("golden", t, flush=True)
+        # reader corner cases: K = 31, -p 3; also pin the reference's "read(s) processed" count
+        import re
+        quirks = {}
+        for name in synth.QUIRK_CASES:
+            cfg = synth.make_quirk_case(td, name)
+            pre = os.path.join(td, name)
+            binary = os.path.join(ROOT, "oracle", "_ref", "SOAPdenovo-63mer")
+            out = subprocess.run([binary, "pregraph", "-s", cfg, "-K", "31", "-o", pre, "-p", "3"], check=True, capture_output=True, text=True)
+            with open(pre + ".edge", "wb") as f:
+                f.write(gzip.open(pre + ".edge.gz", "rb").read())
+            digests[name] = {e: hashlib.md5(open(f"{pre}.{e}", "rb").read()).hexdigest() for e in EXTS}
+            m = re.search(r"Time spent on hashing reads: \d+s, (\d+) read\(s\) processed", out.stderr)
+            m2 = re.search(r"(\d+) node\(s\) allocated, (\d+) kmer\(s\) in reads", out.stderr)
+            quirks[name] = {"reads_processed": int(m.group(1)), "nodes": int(m2.group(1)), "kmers": int(m2.group(2))}
+            print("golden", name, quirks[name], flush=True)
     cases = {k: {kk: vv for kk, vv in v.items()} for k, v in CASES.items()}
-    json.dump({"cases": cases, "md5": digests}, open(os.path.join(HERE, "cases.json"), "w"), indent=1, sort_keys=True)
+    json.dump({"cases": cases, "md5": digests, "quirks": quirks}, open(os.path.join(HERE, "cases.json"), "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":

@@ -216,3 +216,21 @@ def test_full_size_properties():
     cov2 = (s2[:, 2] & np.uint64(0xFFFFFFFF)) >> np.uint64(24)
     cov1 = (s1[:, 2] & np.uint64(0xFFFFFFFF)) >> np.uint64(24)
     assert (cov2 == np.minimum(2 * cov1, 255)).all()
+
+
+def test_cli_reader_corner_cases(golden, tmp_path):
+    """The executable on the reader corner cases (N x 32768 file, truncation / lib order / reverse_seq, ragged reads,
+    mate files) against the reference's files."""
+    from soapdenovo2_amd import synth
+    for name in synth.QUIRK_CASES:
+        cfg = synth.make_quirk_case(str(tmp_path), name)
+        pre = str(tmp_path / ("cli_" + name))
+        log = _run_cli(cfg, 31, pre, 3, 0, 0, 0)
+        q = golden["quirks"][name]
+        assert f"{q['reads_processed']} read(s) processed" in log
+        assert f"{q['nodes']} node(s) allocated, {q['kmers']} kmer(s) in reads" in log
+        want = golden["md5"][name]
+        assert md5_file(pre + ".kmerFreq") == want["kmerFreq"], name
+        assert md5_file(pre + ".preGraphBasic") == want["preGraphBasic"], name
+        assert md5_file(pre + ".vertex") == want["vertex"], name
+        assert md5_gz_text(pre + ".edge.gz") == want["edge"], name
