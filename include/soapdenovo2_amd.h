@@ -123,6 +123,12 @@ typedef struct pg_ctx pg_ctx;
  *   n_sets   the reference's -p (1..255)
  *   log2_slots  initial capacity of the device hash set (it grows by rehash when load would exceed 70 %) */
 pg_ctx *pg_create(int device, int K, int mer127, int n_sets, int log2_slots);
+/* Same, choosing the pass-1 formulation explicitly (pg_create uses 2 unless PG_ENGINE says otherwise):
+ *   1 = one DRAM-resident open-addressed set, one atomic insert per k-mer occurrence; supports pg_count_records
+ *   2 = reads are cut into super-k-mers routed by minimizer partition, every partition is counted in LDS by one
+ *       workgroup during pg_finalize; pg_distinct / pg_export are valid only after pg_finalize.
+ * Both give bit-identical records. */
+pg_ctx *pg_create_engine(int device, int K, int mer127, int n_sets, int log2_slots, int engine);
 void pg_destroy(pg_ctx *ctx);
 /* Empty the set (keeps its current capacity); asynchronous on `stream`. */
 int pg_reset(pg_ctx *ctx, void *stream);

@@ -65,6 +65,8 @@ def lib() -> C.CDLL:
     L.pg_host_replay_layout.argtypes = [u64p, C.c_uint64, u64p, C.c_int, C.c_int, C.c_int, u64p, u64p]
     L.pg_create.restype = C.c_void_p
     L.pg_create.argtypes = [C.c_int] * 5
+    L.pg_create_engine.restype = C.c_void_p
+    L.pg_create_engine.argtypes = [C.c_int] * 6
     L.pg_destroy.argtypes = [C.c_void_p]
     L.pg_reset.argtypes = [C.c_void_p, C.c_void_p]
     L.pg_set_autogrow.argtypes = [C.c_void_p, C.c_int]
@@ -83,7 +85,7 @@ def lib() -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "pg_last_error", "pg_version", "call_pregraph", "call_pregraph_127mer", "pg_packed_words", "pg_pack_read",
-    "pg_host_build_graph", "pg_host_read_all", "pg_host_replay_layout", "pg_host_write_kmerfreq", "pg_create", "pg_destroy", "pg_reset", "pg_set_autogrow", "pg_count_reads", "pg_route_count",
+    "pg_host_build_graph", "pg_host_read_all", "pg_host_replay_layout", "pg_host_write_kmerfreq", "pg_create", "pg_create_engine", "pg_destroy", "pg_reset", "pg_set_autogrow", "pg_count_reads", "pg_route_count",
     "pg_route_scatter", "pg_count_records", "pg_distinct", "pg_table_info", "pg_finalize", "pg_export",
 ]
 
@@ -198,12 +200,13 @@ def host_write_kmerfreq(hist: np.ndarray, prefix: str) -> None:
 class KmerCounter:
     """Pass-1 counting context on one GPU (pg_create ... pg_export)."""
 
-    def __init__(self, K: int, n_sets: int = 8, mer127: bool = False, log2_slots: int = 24, device: int = 0):
+    def __init__(self, K: int, n_sets: int = 8, mer127: bool = False, log2_slots: int = 24, device: int = 0, engine: int = 0):
         import torch  # noqa: F401  (must be loaded before the library, see lib())
         self.torch = torch
         self.K, self.P, self.mer127, self.device = K, n_sets, mer127, device
         self.nw = 4 if mer127 else 2
-        self.h = lib().pg_create(device, K, int(mer127), n_sets, log2_slots)
+        self.h = (lib().pg_create_engine(device, K, int(mer127), n_sets, log2_slots, engine) if engine
+                  else lib().pg_create(device, K, int(mer127), n_sets, log2_slots))
         if not self.h:
             raise PgError("pg_create failed: " + lib().pg_last_error().decode())
 

@@ -1,0 +1,68 @@
+// device_ctx.hpp -- state shared by the two pass-1 engines behind the pg_* device operators.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string>
+
+#include "kmer.hpp"
+#include "skm.hpp"
+
+void pg_set_error(const std::string& s);
+
+namespace pg {
+
+constexpr int BLOCK = 256;
+
+struct DevCounters {
+    unsigned long long n_distinct;
+    unsigned long long overflow;
+    unsigned long long hist[256];
+    unsigned long long set_last[256];
+    unsigned long long n_export;
+    // partition engine
+    unsigned long long pool_next;      // chunks handed out
+    unsigned long long e2_flags;       // bit 0 pool exhausted, bit 1 partition chunk list full, bit 2 output full, bit 3 split exhausted
+    unsigned long long n_records;      // super-k-mer records written
+};
+
+struct SetParams { uint32_t P, bias; };
+
+// Partition engine (engine 2): super-k-mer streams + per-partition LDS counting.
+struct E2 {
+    SkmGeom g;
+    int log2_parts = 0;
+    uint32_t rpc = 32;            // records per chunk
+    uint32_t maxc = 0;            // chunk-table entries per partition
+    uint64_t pool_chunks = 0;
+    uint32_t* cursor = nullptr;   // [parts] records appended
+    uint32_t* chunk_tbl = nullptr;// [parts * maxc] chunk id + 1, 0 = not allocated
+    uint64_t* pool = nullptr;     // pool_chunks * rpc * rw words (+ padding)
+    uint64_t* out = nullptr;      // export records
+    uint64_t out_capacity = 0;    // records
+    bool counted = false;
+    uint64_t est_chunks = 0;      // host estimate of chunks in use (pool growth without a sync per batch)
+};
+
+}  // namespace pg
+
+struct pg_ctx {
+    int device, K, NW, P, log2_slots;
+    uint64_t* slots;             // engine 1: the open-addressed set
+    pg::DevCounters* ctr;        // device
+    uint64_t ub_distinct;        // engine 1: host upper bound on stored keys (avoids a sync per batch)
+    bool finalized;
+    bool autogrow;
+    int variant;                 // engine 1: 0 = word-wise atomic loads, 1 = 32-byte slot snapshot (PG_VARIANT)
+    int engine;                  // 1 = global hash set, 2 = super-k-mer partitions counted in LDS (PG_ENGINE)
+    pg::E2 e2;
+};
+
+// engine 2 entry points (partition_kernels.hip)
+namespace pg {
+int e2_create(pg_ctx* c);
+void e2_destroy(pg_ctx* c);
+int e2_reset(pg_ctx* c, hipStream_t st);
+int e2_scatter(pg_ctx* c, const uint64_t* d_packed, const uint64_t* d_word_off, const uint64_t* d_kmer_base, uint64_t n_reads,
+               uint32_t uniform_len, uint64_t n_kmers_hint, uint64_t ord_base, hipStream_t st);
+int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st);
+}  // namespace pg

@@ -1,0 +1,466 @@
+// partition_kernels.hip -- pass 1 as "partition, then count in LDS" (engine 2), gfx950.
+//
+// Same contract as the global-set engine of pregraph_kernels.hip (per distinct canonical k-mer: the reference's
+// two node words, first-occurrence ordinal, set id; prlHashReads.c:163-259 + newhash.c:473-528), different
+// formulation, chosen because a DRAM-resident set is capped by the chip's random-atomic rate (~24 G ops/s,
+// profiles/r01_membench_random_access.log) at ~13 % of the HBM roofline:
+//
+//   K1  skm_scatter_kernel   one lane per read: cut the read into super-k-mers by minimizer partition
+//                            (skm.hpp), append each as a fixed-size record to its partition's stream
+//                            (streams = chains of 1.5 KB chunks from one pool; one atomic per record, not per
+//                            k-mer: ~20x fewer, and the write side is plain 48-byte stores).
+//   K2  skm_count_kernel     one workgroup per partition (persistent grid): expand the partition's records
+//                            back into k-mer occurrences and insert them into a set that lives in LDS
+//                            (64 KB, word-wise CAS claim from the all-ones pattern, 63-bit key words), then
+//                            finalize (-d filter, linear flag, coverage histogram: prlHashReads.c:953-1132)
+//                            and emit the distinct k-mers as export records.  All occurrences of a k-mer
+//                            are in ONE partition, so its LDS result is final: no global table at all.
+//                            A partition that does not fit the LDS set is split by key-hash bits and
+//                            re-read (the records are small and L2-resident).
+//   K3  skm_lastput_kernel   per reference set the ordinal of the last put (needed by the host layout replay
+//                            only in a boundary case, so it is a separate, optional pass).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string>
+#include <algorithm>
+
+#include "device_ctx.hpp"
+#include "extract.hpp"
+#include "../../include/soapdenovo2_amd.h"
+
+namespace pg {
+
+constexpr uint64_t L_EMPTY = ~0ULL;
+constexpr unsigned long long F_POOL = 1, F_CHUNKS = 2, F_OUT = 4, F_SPLIT = 8;
+
+template <int NW> struct E2Cfg;
+template <> struct E2Cfg<2> { static constexpr int PW = 5, KW = 2, SW = 4, SLOTS = 2048; };   // 32-B slots, 64 KB
+template <> struct E2Cfg<4> { static constexpr int PW = 7, KW = 5, SW = 8, SLOTS = 1024; };   // 64-B slots, 64 KB
+
+struct E2Dev {
+    SkmGeom g;
+    uint32_t rpc, maxc;
+    uint64_t pool_chunks;
+    uint32_t* cursor;
+    uint32_t* chunk_tbl;
+    uint64_t* pool;
+    uint64_t* out;
+    uint64_t out_capacity;
+};
+
+struct ReadsArg {
+    const uint64_t* packed;
+    const uint64_t* word_off;
+    const uint64_t* kmer_base;
+    uint64_t n_reads;
+    uint32_t uniform_len, kpr, wpr;
+    uint64_t ord_base;
+};
+
+// address of record q of partition pid, allocating its chunk on first touch.  Racing lanes may each draw a chunk
+// from the pool; the CAS decides whose id goes into the table, the others are simply never used.
+__device__ __forceinline__ uint64_t* record_slot(const E2Dev& e, uint32_t pid, uint32_t q, DevCounters* ctr, int rw) {
+    const uint32_t ci = q / e.rpc, ri = q % e.rpc;
+    if (ci >= e.maxc) { atomicOr(&ctr->e2_flags, F_CHUNKS); return nullptr; }
+    uint32_t* t = e.chunk_tbl + (uint64_t)pid * e.maxc + ci;
+    uint32_t c = __hip_atomic_load(t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (c == 0) {
+        const unsigned long long nc = atomicAdd(&ctr->pool_next, 1ULL) + 1;
+        if (nc > e.pool_chunks) { atomicOr(&ctr->e2_flags, F_POOL); return nullptr; }
+        const uint32_t old = atomicCAS(t, 0u, (uint32_t)nc);
+        c = old ? old : (uint32_t)nc;
+    }
+    return e.pool + ((uint64_t)(c - 1) * e.rpc + ri) * (uint64_t)rw;
+}
+
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void skm_scatter_kernel(ReadsArg a, E2Dev e, DevCounters* ctr) {
+    constexpr int PW = E2Cfg<NW>::PW, RW = PW + 1;
+    const uint64_t r = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
+    if (r >= a.n_reads) return;
+    const uint64_t* rd;
+    int len;
+    uint64_t ord0;
+    if (a.uniform_len) {
+        rd = a.packed + r * a.wpr; len = (int)a.uniform_len; ord0 = a.ord_base + r * a.kpr;
+    } else {
+        const uint64_t kb = a.kmer_base[r];
+        rd = a.packed + a.word_off[r]; len = (int)(a.kmer_base[r + 1] - kb) + e.g.K - 1; ord0 = a.ord_base + kb;
+    }
+    skm_split_read(rd, len, e.g, [&](int j0, int n, uint32_t pid) {
+        const uint32_t q = atomicAdd(&e.cursor[pid], 1u);
+        uint64_t* dst = record_slot(e, pid, q, ctr, RW);
+        if (!dst) return;
+        uint64_t rec[RW];
+        skm_make_record<PW>(rd, len, j0, n, ord0, e.g, rec);
+#pragma unroll
+        for (int i = 0; i < RW; i++) dst[i] = rec[i];
+    });
+}
+
+// ---- the LDS set ---------------------------------------------------------------------------------------------
+// slot = KW key words (63 bit each) | cnt | ord, every word starts as ~0.  Claim word by word: an empty word is
+// taken with CAS(~0 -> mine); a word holding something else means another key owns the slot.  cnt starts from ~0
+// too: whoever gets CAS(~0 -> node_first) is the k-mer's first counted occurrence, later ones apply node_update
+// (the reduction is order independent, newhash.c:74-140); ord is a plain atomic min.
+// Returns false when the set is full (caller aborts the attempt and splits the key range).
+template <int NW>
+__device__ __forceinline__ bool lds_put(unsigned long long* tab, const Key63<NW>& key, uint64_t hash, int left, int right, uint64_t ord,
+                                        unsigned int* n_keys, unsigned int limit) {
+    constexpr int KW = E2Cfg<NW>::KW, SW = E2Cfg<NW>::SW, SLOTS = E2Cfg<NW>::SLOTS;
+    uint32_t h = (uint32_t)hash & (SLOTS - 1);
+    for (int probes = 0; probes < SLOTS; probes++) {
+        unsigned long long* s = tab + (size_t)h * SW;
+        bool mine = true;
+#pragma unroll
+        for (int i = 0; i < KW; i++) {
+            if (!mine) break;
+            unsigned long long cur = s[i];
+            if (cur == L_EMPTY) {
+                const unsigned long long old = atomicCAS(&s[i], L_EMPTY, (unsigned long long)key.w[i]);
+                cur = old == L_EMPTY ? key.w[i] : old;
+            }
+            mine = cur == key.w[i];
+        }
+        if (mine) {
+            unsigned long long cur = s[KW];
+            for (;;) {
+                const unsigned long long nxt = cur == L_EMPTY ? node_first(left, right) : node_update(cur, left, right);
+                if (nxt == cur) break;
+                const unsigned long long old = atomicCAS(&s[KW], cur, nxt);
+                if (old == cur) {
+                    if (cur == L_EMPTY && atomicAdd(n_keys, 1u) + 1 > limit) return false;
+                    break;
+                }
+                cur = old;
+            }
+            if (ord < s[KW + 1]) atomicMin(&s[KW + 1], (unsigned long long)ord);
+            return true;
+        }
+        h = (h + 1) & (SLOTS - 1);
+    }
+    return false;
+}
+
+__device__ __forceinline__ const uint64_t* record_ptr(const E2Dev& e, uint32_t pid, uint32_t i, int rw) {
+    const uint32_t c = e.chunk_tbl[(uint64_t)pid * e.maxc + i / e.rpc];
+    if (c == 0) return nullptr;                      // pool ran dry in K1 (flagged there; the run fails in e2_count)
+    return e.pool + ((uint64_t)(c - 1) * e.rpc + i % e.rpc) * (uint64_t)rw;
+}
+
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void skm_count_kernel(E2Dev e, int D, SetParams sp, DevCounters* ctr) {
+    constexpr int PW = E2Cfg<NW>::PW, RW = PW + 1, KW = E2Cfg<NW>::KW, SW = E2Cfg<NW>::SW, SLOTS = E2Cfg<NW>::SLOTS;
+    constexpr unsigned LIMIT = SLOTS * 7 / 10;
+    __shared__ unsigned long long tab[SLOTS * SW];
+    __shared__ uint32_t crc_tab[256];
+    __shared__ unsigned int hist[256];
+    __shared__ unsigned int n_keys, aborted, sp_top, s_mask[40], s_val[40], cur_mask, cur_val;
+    crc_tab[threadIdx.x] = crc32_table_entry(threadIdx.x);
+    hist[threadIdx.x] = 0;
+    const Kmer<NW> filter = kmer_filter<NW>(e.g.K);
+    const int K = e.g.K;
+    const uint32_t parts = 1u << e.g.log2_parts;
+    const int lane = threadIdx.x & 63;
+    for (uint32_t pid = blockIdx.x; pid < parts; pid += gridDim.x) {
+        const uint32_t nrec = e.cursor[pid];
+        const uint32_t usable = min(nrec, e.maxc * e.rpc);             // an overfull partition was flagged by K1
+        if (usable == 0) continue;
+        __syncthreads();
+        if (threadIdx.x == 0) { sp_top = 1; s_mask[0] = 0; s_val[0] = 0; }
+        __syncthreads();
+        while (sp_top > 0) {
+            __syncthreads();
+            if (threadIdx.x == 0) { sp_top--; cur_mask = s_mask[sp_top]; cur_val = s_val[sp_top]; n_keys = 0; aborted = 0; }
+            for (int i = threadIdx.x; i < SLOTS * SW; i += BLOCK) tab[i] = L_EMPTY;
+            __syncthreads();
+            const uint32_t mask = cur_mask, val = cur_val;
+            volatile unsigned int* abort_flag = &aborted;
+            for (uint32_t i = threadIdx.x; i < usable && !*abort_flag; i += BLOCK) {
+                const uint64_t* rec = record_ptr(e, pid, i, RW);
+                if (!rec) continue;
+                const uint64_t h = rec[0];
+                const int n = skm_n(h), hl = skm_has_left(h), nb = skm_record_bases(h, K);
+                const uint64_t ord0 = skm_ord(h);
+                for (int t = 0; t < n; t++) {
+                    Occurrence occ;
+                    const Kmer<NW> key = canonical_occurrence<NW>(rec + 1, hl + t, nb, K, filter, occ);
+                    const uint64_t hh = kmer_mix<NW>(key);
+                    if (((uint32_t)(hh >> 32) & mask) != val) continue;
+                    if (!lds_put<NW>(tab, key63_from_kmer<NW>(key), hh, occ.left, occ.right, ord0 + (uint64_t)t, &n_keys, LIMIT)) {
+                        aborted = 1;
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+            if (aborted) {
+                // too many distinct keys for the LDS set: split this key range on the next hash bit and redo both halves
+                if (threadIdx.x == 0) {
+                    const uint32_t bit = mask + 1;                                    // masks are 2^k - 1
+                    if (bit >= (1u << 24) || sp_top + 2 > 40) atomicOr(&ctr->e2_flags, F_SPLIT);
+                    else {
+                        s_mask[sp_top] = mask | bit; s_val[sp_top] = val; sp_top++;
+                        s_mask[sp_top] = mask | bit; s_val[sp_top] = val | bit; sp_top++;
+                    }
+                }
+                __syncthreads();
+                continue;
+            }
+            // ---- emit: finalize every stored node and append it to the export array
+            for (int base = 0; base < SLOTS; base += BLOCK) {
+                const int si = base + threadIdx.x;
+                const unsigned long long* s = tab + (size_t)si * SW;
+                const bool live = s[KW] != L_EMPTY;          // cnt is only set once every key word is claimed
+                const unsigned long long m = __ballot(live);
+                if (m == 0) continue;
+                unsigned long long pos0 = 0;
+                if (lane == 0) pos0 = atomicAdd(&ctr->n_export, (unsigned long long)__popcll(m));
+                pos0 = __shfl(pos0, 0, 64);
+                if (live) {
+                    Key63<NW> k63;
+#pragma unroll
+                    for (int w = 0; w < KW; w++) k63.w[w] = s[w];
+                    const Kmer<NW> key = kmer_from_key63<NW>(k63);
+                    uint64_t cnt = s[KW];
+                    uint32_t A = (uint32_t)cnt, B = (uint32_t)(cnt >> 32);
+                    int nin = 0, nout = 0;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {                                   // thread_delow + thread_mark
+                        uint32_t l = (A >> (6 * c)) & 63u, r = (B >> (6 * c)) & 63u;
+                        if (D > 0 && l > 0 && l <= (uint32_t)D) { A &= ~(63u << (6 * c)); l = 0; }
+                        if (D > 0 && r > 0 && r <= (uint32_t)D) { B &= ~(63u << (6 * c)); r = 0; }
+                        nin += l > 0; nout += r > 0;
+                    }
+                    if (D > 0 && nin == 0 && nout == 0) B |= B_DELETED;
+                    if (nin == 1 && nout == 1) B |= B_LINEAR;
+                    atomicAdd(&hist[A >> 24], 1u);
+                    const uint64_t pos = pos0 + __popcll(m & ((1ULL << lane) - 1));
+                    if (pos < e.out_capacity) {
+                        const uint32_t set = set_of_crc(kmer_crc32<NW>(key, crc_tab), sp.P, sp.bias);
+                        uint64_t* o = e.out + pos * (NW + 2);
+#pragma unroll
+                        for (int w = 0; w < NW; w++) o[w] = key.w[w];
+                        o[NW] = (uint64_t)A | ((uint64_t)B << 32);
+                        o[NW + 1] = ((uint64_t)set << PG_ORD_BITS) | (s[KW + 1] & PG_ORD_MASK);
+                    } else atomicOr(&ctr->e2_flags, F_OUT);
+                }
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    if (hist[threadIdx.x]) atomicAdd(&ctr->hist[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+}
+
+// per reference set: 1 + ordinal of the last k-mer occurrence routed to it (see host_graph.cpp, before_put)
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void skm_lastput_kernel(E2Dev e, SetParams sp, DevCounters* ctr) {
+    constexpr int PW = E2Cfg<NW>::PW, RW = PW + 1;
+    __shared__ uint32_t crc_tab[256];
+    __shared__ unsigned long long set_last[256];
+    crc_tab[threadIdx.x] = crc32_table_entry(threadIdx.x);
+    set_last[threadIdx.x] = 0;
+    __syncthreads();
+    const Kmer<NW> filter = kmer_filter<NW>(e.g.K);
+    const int K = e.g.K;
+    const uint32_t parts = 1u << e.g.log2_parts;
+    for (uint32_t pid = blockIdx.x; pid < parts; pid += gridDim.x) {
+        const uint32_t usable = min(e.cursor[pid], e.maxc * e.rpc);
+        for (uint32_t i = threadIdx.x; i < usable; i += BLOCK) {
+            const uint64_t* rec = record_ptr(e, pid, i, RW);
+            if (!rec) continue;
+            const uint64_t h = rec[0];
+            const int n = skm_n(h), hl = skm_has_left(h), nb = skm_record_bases(h, K);
+            for (int t = 0; t < n; t++) {
+                Occurrence occ;
+                const Kmer<NW> key = canonical_occurrence<NW>(rec + 1, hl + t, nb, K, filter, occ);
+                const uint32_t set = set_of_crc(kmer_crc32<NW>(key, crc_tab), sp.P, sp.bias);
+                atomicMax(&set_last[set], (unsigned long long)(skm_ord(h) + (uint64_t)t + 1));
+            }
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < sp.P && set_last[threadIdx.x]) atomicMax(&ctr->set_last[threadIdx.x], set_last[threadIdx.x]);
+}
+
+// =========================================================================================================
+// host side of engine 2
+// =========================================================================================================
+#define E2_TRY(expr)                                                                           \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            pg_set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                   \
+            return (e_ == hipErrorOutOfMemory) ? PG_ENOMEM : PG_ENODEV;                        \
+        }                                                                                      \
+    } while (0)
+
+static E2Dev dev_view(const pg_ctx* c) {
+    const E2& s = c->e2;
+    return E2Dev{s.g, s.rpc, s.maxc, s.pool_chunks, s.cursor, s.chunk_tbl, s.pool, s.out, s.out_capacity};
+}
+
+int e2_create(pg_ctx* c) {
+    E2& s = c->e2;
+    // partitions: expected distinct / ~1000 so a partition usually fits the LDS set in one attempt
+    s.log2_parts = std::max(8, std::min(22, c->log2_slots - 11));
+    if (const char* v = getenv("PG_LOG2_PARTS")) s.log2_parts = std::max(4, std::min(24, atoi(v)));
+    s.g = skm_geometry(c->K, s.log2_parts, c->NW);
+    s.rpc = 32;
+    const uint64_t parts = (uint64_t)1 << s.log2_parts;
+    const uint64_t rec_bytes = (uint64_t)s.g.rw * 8, chunk_bytes = rec_bytes * s.rpc;
+    size_t free_b = 0, total_b = 0;
+    E2_TRY(hipMemGetInfo(&free_b, &total_b));
+    // export array: what a set of 2^log2_slots slots would hold at 70 % load
+    s.out_capacity = (uint64_t)(0.7 * (double)((uint64_t)1 << c->log2_slots));
+    const uint64_t out_bytes = s.out_capacity * (uint64_t)(c->NW + 2) * 8;
+    // record pool: every partition keeps one partly filled chunk, plus the records themselves (about one record per
+    // 20 k-mers); default = as much as a set of 2^log2_slots 64-byte slots, capped by what is free
+    uint64_t pool_bytes = ((uint64_t)1 << c->log2_slots) * 64 + parts * chunk_bytes * 2;
+    if (const char* v = getenv("PG_POOL_MB")) pool_bytes = (uint64_t)atoll(v) << 20;
+    const uint64_t budget = (uint64_t)(free_b * 0.85);
+    if (out_bytes + parts * 8 > budget) { pg_set_error("partition engine: export array does not fit in device memory"); return PG_ENOMEM; }
+    pool_bytes = std::min<uint64_t>(pool_bytes, (budget - out_bytes) * 9 / 10);
+    s.pool_chunks = pool_bytes / chunk_bytes;
+    if (s.pool_chunks < parts + 16) { pg_set_error("partition engine: record pool too small for the partition count"); return PG_ENOMEM; }
+    // chunk table: up to 2^28 entries in total, at least enough for an even spread x8
+    const uint64_t even = (s.pool_chunks + parts - 1) / parts;
+    s.maxc = (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>(((uint64_t)1 << 28) / parts, even * 8));
+    E2_TRY(hipMalloc(&s.cursor, parts * sizeof(uint32_t)));
+    E2_TRY(hipMalloc(&s.chunk_tbl, parts * s.maxc * sizeof(uint32_t)));
+    E2_TRY(hipMalloc(&s.pool, s.pool_chunks * chunk_bytes + 64));
+    E2_TRY(hipMalloc(&s.out, std::max<uint64_t>(out_bytes, 64)));
+    E2_TRY(hipMemset(s.cursor, 0, parts * sizeof(uint32_t)));
+    E2_TRY(hipMemset(s.chunk_tbl, 0, parts * s.maxc * sizeof(uint32_t)));
+    s.counted = false;
+    s.est_chunks = 0;
+    return PG_OK;
+}
+
+void e2_destroy(pg_ctx* c) {
+    E2& s = c->e2;
+    if (s.cursor) (void)hipFree(s.cursor);
+    if (s.chunk_tbl) (void)hipFree(s.chunk_tbl);
+    if (s.pool) (void)hipFree(s.pool);
+    if (s.out) (void)hipFree(s.out);
+    s = E2();
+}
+
+int e2_reset(pg_ctx* c, hipStream_t st) {
+    E2& s = c->e2;
+    const uint64_t parts = (uint64_t)1 << s.log2_parts;
+    E2_TRY(hipMemsetAsync(s.cursor, 0, parts * sizeof(uint32_t), st));
+    E2_TRY(hipMemsetAsync(s.chunk_tbl, 0, parts * s.maxc * sizeof(uint32_t), st));
+    s.counted = false;
+    s.est_chunks = 0;
+    return PG_OK;
+}
+
+// Before a batch: make sure the pool can take it.  A read of k k-mers makes ~ 2k/(w+1) + 1 records on average;
+// room is kept for 4x that plus one open chunk per partition.  Chunks are referenced by index, so growing the pool
+// is a plain copy into a larger allocation.
+static int e2_ensure_pool(pg_ctx* c, uint64_t n_reads, uint64_t n_kmers, hipStream_t st) {
+    E2& s = c->e2;
+    if (!c->autogrow) return PG_OK;
+    const uint64_t parts = (uint64_t)1 << s.log2_parts;
+    const uint64_t est_records = 4 * (2 * n_kmers / (uint64_t)(s.g.w + 1) + n_reads) + 64;
+    s.est_chunks += est_records / s.rpc + 1;
+    const uint64_t need = s.est_chunks + parts + 16;
+    if (need <= s.pool_chunks) return PG_OK;
+    // the estimate is loose: look at what was really handed out
+    E2_TRY(hipStreamSynchronize(st));
+    unsigned long long used = 0;
+    E2_TRY(hipMemcpy(&used, &c->ctr->pool_next, sizeof used, hipMemcpyDeviceToHost));
+    s.est_chunks = used + est_records / s.rpc + 1;
+    const uint64_t need2 = s.est_chunks + parts + 16;
+    if (need2 <= s.pool_chunks) return PG_OK;
+    const uint64_t chunk_bytes = (uint64_t)s.g.rw * 8 * s.rpc;
+    const uint64_t fresh_chunks = std::max(need2 * 2, s.pool_chunks * 2);
+    uint64_t* fresh = nullptr;
+    E2_TRY(hipMalloc(&fresh, fresh_chunks * chunk_bytes + 64));
+    E2_TRY(hipMemcpy(fresh, s.pool, std::min<uint64_t>(used, s.pool_chunks) * chunk_bytes, hipMemcpyDeviceToDevice));
+    E2_TRY(hipFree(s.pool));
+    s.pool = fresh;
+    s.pool_chunks = fresh_chunks;
+    // a longer chunk list per partition too, if the table allows (rebuild with the wider stride)
+    const uint64_t even = (fresh_chunks + parts - 1) / parts;
+    const uint32_t want = (uint32_t)std::max<uint64_t>(s.maxc, std::min<uint64_t>(((uint64_t)1 << 28) / parts, even * 8));
+    if (want > s.maxc) {
+        uint32_t* tbl = nullptr;
+        E2_TRY(hipMalloc(&tbl, parts * want * sizeof(uint32_t)));
+        E2_TRY(hipMemset(tbl, 0, parts * want * sizeof(uint32_t)));
+        E2_TRY(hipMemcpy2D(tbl, want * sizeof(uint32_t), s.chunk_tbl, s.maxc * sizeof(uint32_t), s.maxc * sizeof(uint32_t), parts, hipMemcpyDeviceToDevice));
+        E2_TRY(hipFree(s.chunk_tbl));
+        s.chunk_tbl = tbl;
+        s.maxc = want;
+    }
+    return PG_OK;
+}
+
+int e2_scatter(pg_ctx* c, const uint64_t* d_packed, const uint64_t* d_word_off, const uint64_t* d_kmer_base, uint64_t n_reads,
+               uint32_t uniform_len, uint64_t n_kmers_hint, uint64_t ord_base, hipStream_t st) {
+    {
+        const uint64_t nk = uniform_len ? n_reads * (uint64_t)(uniform_len - c->K + 1) : n_kmers_hint;
+        int rc = e2_ensure_pool(c, n_reads, nk, st);
+        if (rc) return rc;
+    }
+    if ((ord_base >> (64 - SKM_ORD_SHIFT)) != 0) { pg_set_error("ordinal exceeds the 46 bits of a super-k-mer header"); return PG_EINVAL; }
+    ReadsArg a;
+    a.packed = d_packed; a.word_off = d_word_off; a.kmer_base = d_kmer_base; a.n_reads = n_reads; a.uniform_len = uniform_len;
+    a.kpr = uniform_len ? uniform_len - c->K + 1 : 0;
+    a.wpr = uniform_len ? (uniform_len + 31) / 32 : 0;
+    a.ord_base = ord_base;
+    const uint64_t grid = (n_reads + BLOCK - 1) / BLOCK;
+    if (grid > 0x7FFFFFFFULL) { pg_set_error("batch too large for one launch"); return PG_EINVAL; }
+    if (c->NW == 2) hipLaunchKernelGGL(skm_scatter_kernel<2>, dim3((unsigned)grid), dim3(BLOCK), 0, st, a, dev_view(c), c->ctr);
+    else hipLaunchKernelGGL(skm_scatter_kernel<4>, dim3((unsigned)grid), dim3(BLOCK), 0, st, a, dev_view(c), c->ctr);
+    E2_TRY(hipGetLastError());
+    c->e2.counted = false;
+    return PG_OK;
+}
+
+int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
+    E2& s = c->e2;
+    const SetParams sp{(uint32_t)c->P, set_bias((uint32_t)c->P)};
+    E2_TRY(hipMemsetAsync(&c->ctr->n_export, 0, sizeof(unsigned long long), st));
+    E2_TRY(hipMemsetAsync(c->ctr->hist, 0, sizeof(unsigned long long) * 256, st));
+    const uint32_t parts = 1u << s.log2_parts;
+    int n_cu = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) n_cu = prop.multiProcessorCount;
+    const unsigned grid = std::min<unsigned>(parts, (unsigned)n_cu * 2u * 4u);      // 2 resident blocks per CU (64 KB LDS each), x4 for balance
+    if (c->NW == 2) hipLaunchKernelGGL(skm_count_kernel<2>, dim3(grid), dim3(BLOCK), 0, st, dev_view(c), delow, sp, c->ctr);
+    else hipLaunchKernelGGL(skm_count_kernel<4>, dim3(grid), dim3(BLOCK), 0, st, dev_view(c), delow, sp, c->ctr);
+    E2_TRY(hipGetLastError());
+    if (want_last_put) {
+        E2_TRY(hipMemsetAsync(c->ctr->set_last, 0, sizeof(unsigned long long) * 256, st));
+        if (c->NW == 2) hipLaunchKernelGGL(skm_lastput_kernel<2>, dim3(grid), dim3(BLOCK), 0, st, dev_view(c), sp, c->ctr);
+        else hipLaunchKernelGGL(skm_lastput_kernel<4>, dim3(grid), dim3(BLOCK), 0, st, dev_view(c), sp, c->ctr);
+        E2_TRY(hipGetLastError());
+    }
+    E2_TRY(hipStreamSynchronize(st));
+    DevCounters h;
+    E2_TRY(hipMemcpy(&h, c->ctr, sizeof h, hipMemcpyDeviceToHost));
+    if (h.e2_flags & F_POOL) { pg_set_error("partition engine: record pool exhausted (raise log2_slots or PG_POOL_MB)"); return PG_ENOMEM; }
+    if (h.e2_flags & F_CHUNKS) { pg_set_error("partition engine: one partition outgrew its chunk list (heavily skewed minimizers)"); return PG_ENOMEM; }
+    if ((h.e2_flags & F_OUT) && c->autogrow && !(h.e2_flags & (F_POOL | F_CHUNKS | F_SPLIT))) {
+        // the streams are intact: count again into an export array that holds everything (n_export is the true count)
+        const uint64_t want = h.n_export + h.n_export / 8 + 64;
+        uint64_t* fresh = nullptr;
+        E2_TRY(hipMalloc(&fresh, want * (uint64_t)(c->NW + 2) * 8));
+        E2_TRY(hipFree(s.out));
+        s.out = fresh;
+        s.out_capacity = want;
+        unsigned long long keep = h.e2_flags & ~F_OUT;
+        E2_TRY(hipMemcpy(&c->ctr->e2_flags, &keep, sizeof keep, hipMemcpyHostToDevice));
+        return e2_count(c, delow, want_last_put, st);
+    }
+    if (h.e2_flags & F_OUT) { pg_set_error("partition engine: more distinct k-mers than the export array holds (raise log2_slots)"); return PG_ENOMEM; }
+    if (h.e2_flags & F_SPLIT) { pg_set_error("partition engine: a partition could not be split to fit the LDS set"); return PG_ENOMEM; }
+    s.counted = true;
+    return PG_OK;
+}
+
+}  // namespace pg

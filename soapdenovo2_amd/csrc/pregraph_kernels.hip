@@ -29,25 +29,19 @@
 #include <algorithm>
 
 #include "kmer.hpp"
+#include "extract.hpp"
+#include "device_ctx.hpp"
 #include "../../include/soapdenovo2_amd.h"
 
 namespace pg {
 
 constexpr uint64_t SLOT_EMPTY = ~0ULL;
 constexpr uint64_t SLOT_LOCKED = ~0ULL - 1;
-constexpr int BLOCK = 256;
 constexpr int ITEMS = 8;                 // k-mer occurrences per lane in the count kernels
 constexpr int TILE = BLOCK * ITEMS;      // per block
 
 template <int NW> struct SlotWords { static constexpr int value = (NW == 2) ? 4 : 8; };
 
-struct DevCounters {
-    unsigned long long n_distinct;
-    unsigned long long overflow;
-    unsigned long long hist[256];
-    unsigned long long set_last[256];
-    unsigned long long n_export;
-};
 
 __device__ __forceinline__ uint64_t aload(const uint64_t* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -59,45 +53,6 @@ __device__ __forceinline__ uint64_t acas(uint64_t* p, uint64_t expected, uint64_
 }
 __device__ __forceinline__ uint64_t axchg(uint64_t* p, uint64_t v) {
     return __hip_atomic_exchange(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// ---- read access ---------------------------------------------------------------------------------------
-__device__ __forceinline__ int read_base(const uint64_t* rd, int i) {
-    return (int)((rd[i >> 5] >> (62 - 2 * (i & 31))) & 3);
-}
-
-// right-aligned k-mer of bases [j, j+K) of a packed read (first base in the most significant bits)
-template <int NW>
-__device__ __forceinline__ Kmer<NW> read_kmer(const uint64_t* rd, int j, int K, const Kmer<NW>& filter) {
-    const int s = 2 * j, e = s + 2 * K;
-    const int a = s >> 6;
-    Kmer<NW + 1> v;
-#pragma unroll
-    for (int i = 0; i <= NW; i++) v.w[i] = rd[a + i];          // buffer is padded, always readable
-    v = kmer_shr<NW + 1>(v, 64 * (NW + 1) - (e - 64 * a));
-    Kmer<NW> k;
-#pragma unroll
-    for (int i = 0; i < NW; i++) k.w[i] = v.w[i + 1] & filter.w[i];
-    return k;
-}
-
-struct Occurrence { int left, right; };
-
-// canonical k-mer + flanking bases in canonical orientation (prlHashReads.c:198-257)
-template <int NW>
-__device__ __forceinline__ Kmer<NW> canonical_occurrence(const uint64_t* rd, int j, int len, int K,
-                                                         const Kmer<NW>& filter, Occurrence& occ) {
-    Kmer<NW> word = read_kmer<NW>(rd, j, K, filter);
-    Kmer<NW> bal = kmer_rc<NW>(word, K);
-    const int prev = j > 0 ? read_base(rd, j - 1) : 4;
-    const int next = j < len - K ? read_base(rd, j + K) : 4;
-    if (kmer_less<NW>(word, bal)) {
-        occ.left = prev; occ.right = next;
-        return word;
-    }
-    occ.left = next < 4 ? (next ^ 2) : 4;
-    occ.right = prev < 4 ? (prev ^ 2) : 4;
-    return bal;
 }
 
 // ---- batch geometry ------------------------------------------------------------------------------------
@@ -304,7 +259,6 @@ __device__ __forceinline__ void table_move(const Table<NW>& t, const Kmer<NW>& k
 }
 
 // ---- kernels -------------------------------------------------------------------------------------------
-struct SetParams { uint32_t P, bias; };
 
 template <int NW, bool WIDE>
 __global__ __launch_bounds__(BLOCK) void count_reads_kernel(Batch b, Table<NW> t, int K, SetParams sp, uint64_t ord_base,
@@ -536,19 +490,17 @@ void pg_set_error(const std::string& s) { g_err = s; }
         }                                                                                      \
     } while (0)
 
-struct pg_ctx {
-    int device, K, NW, P, log2_slots;
-    uint64_t* slots;
-    DevCounters* ctr;        // device
-    uint64_t ub_distinct;    // host upper bound on stored keys (avoids a sync per batch)
-    bool finalized;
-    bool autogrow;
-    int variant;             // 0 = word-wise atomic loads, 1 = 32-byte slot snapshot (PG_VARIANT, default 1)
-};
 
 static inline uint64_t slot_bytes(int NW) { return (NW == 2 ? 4 : 8) * sizeof(uint64_t); }
 
+extern "C" pg_ctx* pg_create_engine(int device, int K, int mer127, int n_sets, int log2_slots, int engine);
 extern "C" pg_ctx* pg_create(int device, int K, int mer127, int n_sets, int log2_slots) {
+    int engine = 2;
+    if (const char* v = getenv("PG_ENGINE")) engine = atoi(v);
+    return pg_create_engine(device, K, mer127, n_sets, log2_slots, engine);
+}
+
+extern "C" pg_ctx* pg_create_engine(int device, int K, int mer127, int n_sets, int log2_slots, int engine) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { g_err = "pg_create: no HIP device available"; return nullptr; }
     if (device < 0 || device >= n) { g_err = "pg_create: bad device ordinal"; return nullptr; }
@@ -556,12 +508,21 @@ extern "C" pg_ctx* pg_create(int device, int K, int mer127, int n_sets, int log2
     if (K < 13 || K > maxK || (K & 1) == 0) { g_err = "pg_create: K must be odd and within 13.." + std::to_string(maxK); return nullptr; }
     if (n_sets < 1 || n_sets > 255) { g_err = "pg_create: n_sets must be 1..255"; return nullptr; }
     if (log2_slots < 10 || log2_slots > 40) { g_err = "pg_create: log2_slots out of range"; return nullptr; }
+    if (engine != 1 && engine != 2) { g_err = "pg_create: engine must be 1 (global set) or 2 (partitions)"; return nullptr; }
     if (hipSetDevice(device) != hipSuccess) { g_err = "pg_create: hipSetDevice failed"; return nullptr; }
     pg_ctx* c = new pg_ctx();
     c->device = device; c->K = K; c->NW = mer127 ? 4 : 2; c->P = n_sets; c->log2_slots = log2_slots;
     c->ub_distinct = 0; c->finalized = false; c->autogrow = true; c->slots = nullptr; c->ctr = nullptr;
     c->variant = 1;
+    c->engine = engine;
     if (const char* v = getenv("PG_VARIANT")) c->variant = atoi(v);
+    if (engine == 2) {
+        if (hipMalloc(&c->ctr, sizeof(DevCounters)) != hipSuccess) { g_err = "pg_create: hipMalloc failed"; delete c; return nullptr; }
+        (void)hipMemset(c->ctr, 0, sizeof(DevCounters));
+        if (e2_create(c) != PG_OK) { e2_destroy(c); (void)hipFree(c->ctr); delete c; return nullptr; }
+        (void)hipDeviceSynchronize();
+        return c;
+    }
     const size_t bytes = ((size_t)1 << log2_slots) * slot_bytes(c->NW);
     if (hipMalloc(&c->slots, bytes) != hipSuccess) { g_err = "pg_create: hipMalloc of the k-mer set failed"; delete c; return nullptr; }
     if (hipMalloc(&c->ctr, sizeof(DevCounters)) != hipSuccess) { g_err = "pg_create: hipMalloc failed"; hipFree(c->slots); delete c; return nullptr; }
@@ -576,7 +537,8 @@ extern "C" int pg_reset(pg_ctx* c, void* stream) {
     if (!c) { g_err = "null context"; return PG_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(c->device));
-    HIP_TRY(hipMemsetAsync(c->slots, 0xFF, ((size_t)1 << c->log2_slots) * slot_bytes(c->NW), st));
+    if (c->engine == 2) { int rc = e2_reset(c, st); if (rc) return rc; }
+    else HIP_TRY(hipMemsetAsync(c->slots, 0xFF, ((size_t)1 << c->log2_slots) * slot_bytes(c->NW), st));
     HIP_TRY(hipMemsetAsync(c->ctr, 0, sizeof(DevCounters), st));
     c->ub_distinct = 0;
     c->finalized = false;
@@ -592,6 +554,7 @@ extern "C" int pg_set_autogrow(pg_ctx* c, int on) {
 extern "C" void pg_destroy(pg_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
+    if (c->engine == 2) e2_destroy(c);
     if (c->slots) hipFree(c->slots);
     if (c->ctr) hipFree(c->ctr);
     delete c;
@@ -672,6 +635,7 @@ extern "C" int pg_count_reads(pg_ctx* c, const uint64_t* d_packed, const uint64_
     if (n_kmers == 0) return PG_OK;
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(c->device));
+    if (c->engine == 2) return e2_scatter(c, d_packed, d_word_off, d_kmer_base, n_reads, uniform_len, n_kmers, ord_base, st);
     rc = ensure_capacity(c, n_kmers, st);
     if (rc) return rc;
     Batch b = make_batch(c, d_packed, d_word_off, d_kmer_base, n_reads, uniform_len, n_kmers);
@@ -695,6 +659,7 @@ extern "C" int pg_count_reads(pg_ctx* c, const uint64_t* d_packed, const uint64_
 extern "C" int pg_count_records(pg_ctx* c, const uint64_t* d_records, uint64_t n, void* stream) {
     if (!c || (!d_records && n)) { g_err = "null argument"; return PG_EINVAL; }
     if (c->finalized) { g_err = "pg_count_records after pg_finalize"; return PG_ESTATE; }
+    if (c->engine == 2) { g_err = "pg_count_records needs the global-set engine (pg_create_engine(..., 1))"; return PG_ESTATE; }
     if (n == 0) return PG_OK;
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(c->device));
@@ -769,12 +734,22 @@ extern "C" int pg_distinct(pg_ctx* c, uint64_t* out, void* stream) {
     DevCounters h;
     int rc = check_overflow(c, h);
     if (rc) return rc;
+    if (c->engine == 2) {
+        if (!c->e2.counted) { g_err = "pg_distinct: the partition engine knows the count only after pg_finalize"; return PG_ESTATE; }
+        *out = h.n_export;
+        return PG_OK;
+    }
     *out = h.n_distinct;
     return PG_OK;
 }
 
 extern "C" int pg_table_info(pg_ctx* c, uint64_t* slots, uint32_t* sbytes) {
     if (!c) { g_err = "null context"; return PG_EINVAL; }
+    if (c->engine == 2) {
+        if (slots) *slots = c->e2.out_capacity;
+        if (sbytes) *sbytes = (uint32_t)((c->NW + 2) * 8);
+        return PG_OK;
+    }
     if (slots) *slots = (uint64_t)1 << c->log2_slots;
     if (sbytes) *sbytes = (uint32_t)slot_bytes(c->NW);
     return PG_OK;
@@ -785,6 +760,16 @@ extern "C" int pg_finalize(pg_ctx* c, int delow, uint64_t hist_out[256], uint64_
     if (c->finalized) { g_err = "pg_finalize called twice"; return PG_ESTATE; }
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(c->device));
+    if (c->engine == 2) {
+        int rc = e2_count(c, delow, set_last_put_out != nullptr, st);
+        if (rc) return rc;
+        DevCounters h;
+        HIP_TRY(hipMemcpy(&h, c->ctr, sizeof h, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 256; i++) hist_out[i] = h.hist[i];
+        if (set_last_put_out) for (int i = 0; i < c->P; i++) set_last_put_out[i] = h.set_last[i];
+        c->finalized = true;
+        return PG_OK;
+    }
     const uint64_t cap = (uint64_t)1 << c->log2_slots;
     const unsigned grid = (unsigned)std::min<uint64_t>((cap + BLOCK - 1) / BLOCK, 256u * 32u);
     if (c->NW == 2) {
@@ -809,6 +794,16 @@ extern "C" int pg_export(pg_ctx* c, uint64_t* d_records, uint64_t capacity, uint
     if (!c || !d_records || !n_out) { g_err = "null argument"; return PG_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(c->device));
+    if (c->engine == 2) {
+        if (!c->e2.counted) { g_err = "pg_export: call pg_finalize first"; return PG_ESTATE; }
+        unsigned long long n = 0;
+        HIP_TRY(hipMemcpy(&n, &c->ctr->n_export, sizeof n, hipMemcpyDeviceToHost));
+        if (n > capacity) { g_err = "pg_export: capacity too small"; return PG_EINVAL; }
+        HIP_TRY(hipMemcpyAsync(d_records, c->e2.out, n * (uint64_t)(c->NW + 2) * 8, hipMemcpyDeviceToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        *n_out = n;
+        return PG_OK;
+    }
     HIP_TRY(hipMemsetAsync(&c->ctr->n_export, 0, sizeof(unsigned long long), st));
     const uint64_t cap = (uint64_t)1 << c->log2_slots;
     const unsigned grid = (unsigned)std::min<uint64_t>((cap + BLOCK - 1) / BLOCK, 256u * 32u);

@@ -1,0 +1,181 @@
+// skm.hpp -- super-k-mer partitioning shared by the HIP kernels of the partition engine and its CPU
+// test harness (tests/emu_skm.cpp).  New design, nothing in the reference to mirror: the reference inserts
+// every k-mer occurrence into a DRAM-resident table (prlHashReads.c:79-90, newhash.c:473-528), which on a
+// GPU is bound by the chip's random-atomic rate.  Here occurrences are first grouped
+// so that all occurrences of one canonical k-mer meet in one small partition that is counted in LDS:
+//
+//   partition(k-mer) = f(min over the canonical m-mers inside the k-mer of hash(m-mer))        (minimizer)
+//
+// which is a function of the canonical k-mer only (both strands contain the same canonical m-mers), and
+// consecutive k-mers of a read mostly share it, so a read is cut into a few runs ("super-k-mers") that are
+// stored as one fixed-size record each: a header word and the run's bases (2 bit/base, MSB first) with one
+// flanking base on each side where the read has one.  A record is a miniature read: k-mer i of the run is
+// position has_left + i of the record's bases, and the flank rules of chopKmer4read (prlHashReads.c:198-257)
+// apply unchanged to it.
+#pragma once
+#include "kmer.hpp"
+
+namespace pg {
+
+// ---- geometry -------------------------------------------------------------------------------------------
+struct SkmGeom {
+    int K;          // k-mer size
+    int m;          // minimizer length (m-mer)
+    int w;          // m-mers per k-mer = K - m + 1
+    int pw;         // payload words per record
+    int rw;         // record words = 1 + pw
+    int nmax;       // max k-mers per record
+    int log2_parts; // partitions = 1 << log2_parts
+};
+
+// nw = words per k-mer of the build flavour (2 or 4): fixes the record size so kernels can keep it static
+PG_HD SkmGeom skm_geometry(int K, int log2_parts, int nw = 2) {
+    SkmGeom g;
+    g.K = K;
+    g.m = K - 6 < 7 ? 7 : (K - 6 > 13 ? 13 : K - 6);
+    g.w = K - g.m + 1;
+    g.pw = nw == 2 ? 5 : 7;                       // 160 / 224 bases per record
+    g.rw = 1 + g.pw;
+    g.nmax = 32 * g.pw - (K - 1) - 2;             // leaves room for both flanks
+    g.log2_parts = log2_parts;
+    return g;
+}
+
+// header = first ordinal << 18 | n_kmers << 2 | has_left << 1 | has_right
+constexpr int SKM_ORD_SHIFT = 18;
+PG_HD uint64_t skm_header(uint64_t ord_first, int n, int has_left, int has_right) {
+    return (ord_first << SKM_ORD_SHIFT) | ((uint64_t)n << 2) | ((uint64_t)has_left << 1) | (uint64_t)has_right;
+}
+PG_HD uint64_t skm_ord(uint64_t h) { return h >> SKM_ORD_SHIFT; }
+PG_HD int skm_n(uint64_t h) { return (int)((h >> 2) & 0xFFFF); }
+PG_HD int skm_has_left(uint64_t h) { return (int)((h >> 1) & 1); }
+PG_HD int skm_has_right(uint64_t h) { return (int)(h & 1); }
+
+// ---- minimizer value of the m-mer at base p of a packed read ------------------------------------------------
+// 64 bits of the read starting at bit `bit` (MSB-first bit string); rd must be readable one word past
+PG_HD uint64_t bits_at(const uint64_t* rd, int bit) {
+    const int a = bit >> 6, o = bit & 63;
+    uint64_t v = rd[a] << o;
+    if (o) v |= rd[a + 1] >> (64 - o);
+    return v;
+}
+PG_HD uint64_t mmer_value(const uint64_t* rd, int p, int m) {
+    const uint64_t fwd = bits_at(rd, 2 * p) >> (64 - 2 * m);
+    const uint64_t rc = rev2bit(fwd ^ 0xAAAAAAAAAAAAAAAAULL) >> (64 - 2 * m);
+    uint64_t x = fwd < rc ? fwd : rc;
+    x *= 0x9E3779B97F4A7C15ULL;            // order m-mers by a hash, not lexicographically (poly-A would win everywhere)
+    x ^= x >> 29;
+    x *= 0xBF58476D1CE4E5B9ULL;
+    x ^= x >> 32;
+    return x;
+}
+PG_HD uint32_t skm_partition(uint64_t minval, int log2_parts) {
+    return (uint32_t)((minval * 0xD6E8FEB86659FD93ULL) >> (64 - log2_parts));
+}
+
+// ---- cutting a read into runs ------------------------------------------------------------------------------
+// Calls emit(j0, n, partition) for every maximal run of consecutive k-mers [j0, j0 + n) with the same partition
+// (runs are also cut at nmax k-mers).  Sliding minimum without a queue: remember the (rightmost) minimum and its
+// position, rescan the window only when it slides out -- expected once per ~ (w + 1) / 2 steps.
+template <typename Emit>
+PG_HD void skm_split_read(const uint64_t* rd, int len, const SkmGeom& g, Emit&& emit) {
+    const int nk = len - g.K + 1;
+    uint64_t minval = ~0ULL;
+    int minpos = -1;
+    for (int p = 0; p < g.w; p++) {
+        const uint64_t v = mmer_value(rd, p, g.m);
+        if (v <= minval) { minval = v; minpos = p; }
+    }
+    uint32_t cur = skm_partition(minval, g.log2_parts);
+    int j0 = 0;
+    for (int j = 1; j < nk; j++) {
+        const int pnew = j + g.w - 1;
+        const uint64_t v = mmer_value(rd, pnew, g.m);
+        if (minpos < j) {                       // the minimum left the window
+            minval = ~0ULL;
+            for (int p = j; p <= pnew; p++) {
+                const uint64_t u = mmer_value(rd, p, g.m);
+                if (u <= minval) { minval = u; minpos = p; }
+            }
+        } else if (v <= minval) { minval = v; minpos = pnew; }
+        const uint32_t pid = skm_partition(minval, g.log2_parts);
+        if (pid != cur || j - j0 == g.nmax) {
+            emit(j0, j - j0, cur);
+            j0 = j;
+            cur = pid;
+        }
+    }
+    emit(j0, nk - j0, cur);
+}
+
+// ---- records ---------------------------------------------------------------------------------------------
+// Fill `rec[0..rw)` for the run [j0, j0 + n) of a read of `len` bases whose first k-mer has ordinal ord0.
+template <int PW>
+PG_HD void skm_make_record(const uint64_t* rd, int len, int j0, int n, uint64_t ord0, const SkmGeom& g, uint64_t* rec) {
+    const int has_left = j0 > 0, has_right = (j0 + n - 1 + g.K) < len;
+    const int b0 = j0 - has_left;
+    const int nb = n + g.K - 1 + has_left + has_right;
+    rec[0] = skm_header(ord0 + (uint64_t)j0, n, has_left, has_right);
+#pragma unroll
+    for (int i = 0; i < PW; i++) {
+        const int first = 32 * i;               // first base of this payload word, relative to b0
+        uint64_t v = 0;
+        if (first < nb) {
+            v = bits_at(rd, 2 * (b0 + first));
+            const int valid = nb - first;       // bases of this word that belong to the run
+            if (valid < 32) v &= ~0ULL << (64 - 2 * valid);
+        }
+        rec[1 + i] = v;
+    }
+}
+PG_HD int skm_record_bases(uint64_t header, int K) {
+    return skm_n(header) + K - 1 + skm_has_left(header) + skm_has_right(header);
+}
+
+// ---- 63-bit key words -------------------------------------------------------------------------------------
+// The in-LDS set claims a slot word by word with 64-bit CAS from the all-ones "empty" pattern, so no key word
+// may be all ones: the 64*NW-bit k-mer is re-cut into KW words of 63 bits (KW = 2 for NW = 2: 2K <= 126 bits;
+// KW = 5 for NW = 4).
+template <int NW> struct KeyWords { static constexpr int value = NW == 2 ? 2 : 5; };
+
+template <int NW>
+struct Key63 { uint64_t w[KeyWords<NW>::value]; };
+
+template <int NW>
+PG_HD Key63<NW> key63_from_kmer(const Kmer<NW>& k) {
+    constexpr int KW = KeyWords<NW>::value;
+    const uint64_t M63 = (1ULL << 63) - 1;
+    Key63<NW> r;
+    // word i = bits [63 i, 63 i + 63) of the value, i = 0 least significant
+#pragma unroll
+    for (int i = 0; i < KW; i++) {
+        const int lo = 63 * i;                    // bit offset from the LSB of the whole value
+        const int wi = lo >> 6, bo = lo & 63;     // word index from the least significant end
+        uint64_t v = 0;
+        if (wi < NW) {
+            v = k.w[NW - 1 - wi] >> bo;
+            if (bo > 1 && wi + 1 < NW) v |= k.w[NW - 2 - wi] << (64 - bo);
+        }
+        r.w[i] = v & M63;
+    }
+    return r;
+}
+template <int NW>
+PG_HD Kmer<NW> kmer_from_key63(const Key63<NW>& r) {
+    constexpr int KW = KeyWords<NW>::value;
+    Kmer<NW> k;
+#pragma unroll
+    for (int i = 0; i < NW; i++) k.w[i] = 0;
+#pragma unroll
+    for (int i = 0; i < KW; i++) {
+        const int lo = 63 * i;
+        const int wi = lo >> 6, bo = lo & 63;
+        if (wi < NW) {
+            k.w[NW - 1 - wi] |= r.w[i] << bo;
+            if (bo > 1 && wi + 1 < NW) k.w[NW - 2 - wi] |= r.w[i] >> (64 - bo);
+        }
+    }
+    return k;
+}
+
+}  // namespace pg

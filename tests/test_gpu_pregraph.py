@@ -16,11 +16,14 @@ def _sorted(rec, nw):
     return rec[order]
 
 
-def _gpu_records(codes, K, P, mer127=False, D=0, log2_slots=20, batches=1):
+ENGINES = [1, 2]       # 1 = DRAM-resident set, 2 = super-k-mer partitions counted in LDS (default)
+
+
+def _gpu_records(codes, K, P, mer127=False, D=0, log2_slots=20, batches=1, engine=0):
     import torch
     from soapdenovo2_amd import api
     n, L = codes.shape
-    kc = api.KmerCounter(K, n_sets=P, mer127=mer127, log2_slots=log2_slots)
+    kc = api.KmerCounter(K, n_sets=P, mer127=mer127, log2_slots=log2_slots, engine=engine)
     kpr = L - K + 1
     bounds = np.linspace(0, n, batches + 1).astype(int)
     order = list(range(batches))
@@ -39,13 +42,14 @@ def _gpu_records(codes, K, P, mer127=False, D=0, log2_slots=20, batches=1):
     return rec, hist, last, info
 
 
+@pytest.mark.parametrize("engine", ENGINES)
 @pytest.mark.parametrize("name,P,m,D", [("t6k_k31", 8, False, 0), ("t6k_k31", 7, False, 1), ("t8k_k63", 2, False, 0),
                                         ("t8k_k63", 5, True, 0), ("t6k_k127", 3, True, 0), ("t5k_k24", 8, False, 0)])
-def test_count_matches_oracle(golden, tmp_path, name, P, m, D):
+def test_count_matches_oracle(golden, tmp_path, name, P, m, D, engine):
     c = golden["cases"][name]
     codes = case_codes(c)
     want, last_want, K = oracle_records(codes, c["K"], P, D=D, mer127=m, prefix=str(tmp_path / "o"))
-    got, hist, last, _ = _gpu_records(codes, K, P, mer127=m, D=D)
+    got, hist, last, _ = _gpu_records(codes, K, P, mer127=m, D=D, engine=engine)
     nw = 4 if m else 2
     assert got.shape == want.shape
     assert (_sorted(got, nw) == _sorted(want, nw)).all()         # keys, counters+flags, set id, first ordinal: bit-exact
@@ -54,18 +58,21 @@ def test_count_matches_oracle(golden, tmp_path, name, P, m, D):
     assert [int(x) for x in hist[1:]] == freq
 
 
-def test_growth_and_batch_order(golden, tmp_path):
-    """Tiny initial set (grows by device rehash several times) and batches submitted in reverse order."""
+@pytest.mark.parametrize("engine", ENGINES)
+def test_growth_and_batch_order(golden, tmp_path, engine):
+    """Tiny initial sizing (the set / the record pool and export array grow several times) and batches submitted in
+    reverse order."""
     c = golden["cases"]["t6k_k31"]
     codes = case_codes(c)
     want, last_want, K = oracle_records(codes, c["K"], 8, prefix=str(tmp_path / "o"))
-    got, hist, last, info = _gpu_records(codes, K, 8, log2_slots=10, batches=5)
+    got, hist, last, info = _gpu_records(codes, K, 8, log2_slots=10, batches=5, engine=engine)
     assert info[0] > 1024
     assert (_sorted(got, 2) == _sorted(want, 2)).all()
     assert (last == last_want).all()
 
 
-def test_ragged_batch(tmp_path):
+@pytest.mark.parametrize("engine", ENGINES)
+def test_ragged_batch(tmp_path, engine):
     """Reads of different lengths (K+1 .. 150) in one batch through the prefix-sum path."""
     import torch
     from soapdenovo2_amd import api, synth
@@ -86,7 +93,7 @@ def test_ragged_batch(tmp_path):
     want[:, 3] = (nd["set"].astype(np.uint64) << np.uint64(56)) | nd["ord"]
     o.close()
     words, off, kb = api.pack_reads_ragged(reads, K)
-    kc = api.KmerCounter(K, n_sets=P, log2_slots=18)
+    kc = api.KmerCounter(K, n_sets=P, log2_slots=18, engine=engine)
     kc.count_ragged(torch.from_numpy(words.view(np.int64)).cuda(), torch.from_numpy(off.view(np.int64)).cuda(),
                     torch.from_numpy(kb.view(np.int64)).cuda(), len(reads), int(kb[-1]))
     kc.finalize(0)
@@ -105,7 +112,7 @@ def test_route_then_count_equals_fused(golden, tmp_path):
     K, P, L, n = c["K"], 8, c["L"], codes.shape[0]
     want, last_want, _ = oracle_records(codes, K, P, prefix=str(tmp_path / "o"))
     packed = torch.from_numpy(api.pack_reads_uniform(codes).view(np.int64)).cuda()
-    router = api.KmerCounter(K, n_sets=P, log2_slots=10)
+    router = api.KmerCounter(K, n_sets=P, log2_slots=10, engine=1)
     owners = 2
     counts = router.route_count(packed, n, L, owners)
     off = torch.zeros(owners + 1, dtype=torch.int64, device="cuda")
@@ -118,7 +125,7 @@ def test_route_then_count_equals_fused(golden, tmp_path):
     parts, lasts = [], []
     for o in range(owners):
         lo, hi = int(off[o]), int(off[o + 1])
-        kc = api.KmerCounter(K, n_sets=P, log2_slots=18)
+        kc = api.KmerCounter(K, n_sets=P, log2_slots=18, engine=1)
         kc.count_records(out[lo * 3: hi * 3], hi - lo)
         _, last = kc.finalize(0)
         rec = kc.export()
@@ -132,20 +139,24 @@ def test_route_then_count_equals_fused(golden, tmp_path):
     assert (np.maximum(lasts[0], lasts[1]) == last_want).all()
 
 
-def _run_cli(cfg, K, prefix, P, D, a, m):
+def _run_cli(cfg, K, prefix, P, D, a, m, engine=None):
     from soapdenovo2_amd import api
+    env = dict(os.environ)
+    if engine:
+        env["PG_ENGINE"] = str(engine)
     args = ["-s", cfg, "-K", str(K), "-o", prefix, "-p", str(P)]
     if D:
         args += ["-d", str(D)]
     if a:
         args += ["-a", str(a)]
-    rc = subprocess.run([api.binary(bool(m)), "pregraph"] + args, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    rc = subprocess.run([api.binary(bool(m)), "pregraph"] + args, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, env=env)
     assert rc.returncode == 0, rc.stderr[-2000:]
     return rc.stderr
 
 
+@pytest.mark.parametrize("engine", ENGINES)
 @pytest.mark.parametrize("name", ["t6k_k31", "t8k_k63", "t6k_k127", "t5k_k24", "m100k_k31", "m60k_k63"])
-def test_cli_matches_reference_files(golden, tmp_path, name):
+def test_cli_matches_reference_files(golden, tmp_path, name, engine):
     """`SOAPdenovo-63mer|127mer pregraph -s cfg -K k -o pfx -p n [-d -a]` end to end against the reference's files."""
     from soapdenovo2_amd import synth
     c = golden["cases"][name]
@@ -154,7 +165,7 @@ def test_cli_matches_reference_files(golden, tmp_path, name):
         P, D, a, m = run
         t = case_tag(name, run)
         pre = str(tmp_path / t)
-        _run_cli(cfg, c["K"], pre, P, D, a, m)
+        _run_cli(cfg, c["K"], pre, P, D, a, m, engine=engine)
         want = golden["md5"][t]
         assert md5_file(pre + ".kmerFreq") == want["kmerFreq"], t
         assert md5_file(pre + ".preGraphBasic") == want["preGraphBasic"], t
@@ -194,8 +205,8 @@ def test_full_size_properties():
     packed = torch.from_numpy(api.pack_reads_uniform(codes).view(np.int64)).cuda()
     kc = api.KmerCounter(K, n_sets=8, log2_slots=26)
     kc.count_uniform(packed, n, L, 0)
-    d1 = kc.distinct()
     hist, last = kc.finalize(0)
+    d1 = kc.distinct()
     r1 = kc.export()
     assert int(hist.sum()) == d1 == r1.shape[0]
     assert int(last.max()) == n * (L - K + 1)                      # the very last occurrence went somewhere
@@ -206,8 +217,8 @@ def test_full_size_properties():
     kc.reset()
     kc.count_uniform(packed, n, L, 0)
     kc.count_uniform(packed, n, L, n * (L - K + 1))                # same reads again, later ordinals
-    assert kc.distinct() == d1
     kc.finalize(0)
+    assert kc.distinct() == d1
     r2 = kc.export()
     kc.close()
     s1, s2 = _sorted(r1, 2), _sorted(r2, 2)

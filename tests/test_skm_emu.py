@@ -1,0 +1,48 @@
+"""CPU check of the partition engine's shared host/device logic (csrc/skm.hpp + csrc/extract.hpp) through the
+serial harness tests/emu_skm.cpp: super-k-mer cutting, record format, flank rules, ordinals, 63-bit key re-cut
+and the one-k-mer-one-partition invariant, against the oracle's per-k-mer records."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, case_codes, oracle_records
+from soapdenovo2_amd import api
+
+
+@pytest.fixture(scope="module")
+def emu(tmp_path_factory):
+    so = str(tmp_path_factory.mktemp("emu") / "libemu_skm.so")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-Wno-unknown-pragmas",
+                           os.path.join(ROOT, "tests", "emu_skm.cpp"), "-o", so])
+    L = C.CDLL(so)
+    L.emu_skm_count.restype = C.c_int64
+    L.emu_skm_count.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64,
+                                C.POINTER(C.c_int64), C.POINTER(C.c_int64)]
+    return L
+
+
+@pytest.mark.parametrize("name,m127,log2_parts", [("t6k_k31", False, 8), ("t8k_k63", False, 10), ("t8k_k63", True, 6),
+                                                   ("t6k_k127", True, 8), ("t5k_k24", False, 4)])
+def test_partition_logic_matches_oracle(golden, emu, tmp_path, name, m127, log2_parts):
+    c = golden["cases"][name]
+    codes = case_codes(c)
+    want, _, K = oracle_records(codes, c["K"], 1, mer127=m127, prefix=str(tmp_path / "o"))
+    nw = 4 if m127 else 2
+    packed = api.pack_reads_uniform(codes)
+    out = np.zeros((want.shape[0] + 16, nw + 2), dtype=np.uint64)
+    nrec, maxd = C.c_int64(0), C.c_int64(0)
+    n = emu.emu_skm_count(packed.ctypes.data, codes.shape[0], codes.shape[1], K, int(m127), log2_parts, out.ctypes.data,
+                          out.shape[0], C.byref(nrec), C.byref(maxd))
+    assert n == want.shape[0], n
+    got = out[:n]
+    key = lambda r: r[np.lexsort([r[:, i] for i in range(nw - 1, -1, -1)])]
+    w = key(want).copy()
+    w[:, nw + 1] &= np.uint64((1 << 56) - 1)                 # oracle records carry the set id in the top byte
+    w[:, nw] &= np.uint64(~(1 << (32 + 24)) & 0xFFFFFFFFFFFFFFFF)   # ... and the linear flag set by finish_count
+    assert (key(got) == w).all()
+    reads, kpr = codes.shape[0], codes.shape[1] - K + 1
+    assert reads <= nrec.value <= reads * kpr
+    print(name, "records/read", nrec.value / reads, "max distinct in a partition", maxd.value)
