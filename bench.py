@@ -106,6 +106,7 @@ def main():
     ap.add_argument("--log2-slots", type=int, default=0, help="0 = size from the expected distinct count")
     ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--engine", type=int, default=0, help="0 = 2 (partitions) on one GPU, 1 (global set) when routing across GPUs")
     args = ap.parse_args()
 
     import torch
@@ -134,12 +135,13 @@ def main():
         while (1 << log2_slots) * 0.6 < expected:
             log2_slots += 1
     packed = gen_packed_reads(torch, dev, args.genome, n_reads, L, args.err, args.seed + 1000 * rank)
-    kc = api.KmerCounter(K, n_sets=P, log2_slots=log2_slots, device=local)
+    engine = args.engine or (2 if world == 1 else 1)
+    kc = api.KmerCounter(K, n_sets=P, log2_slots=log2_slots, device=local, engine=engine)
     kc.set_autogrow(False)
     wpr = (L + 31) // 32
     batches = [(lo, min(args.batch_reads, n_reads - lo)) for lo in range(0, n_reads, args.batch_reads)]
     ord0 = rank * n_kmers
-    ev = []
+    ev, ev2 = [], []
 
     def step(timed):
         kc.reset()
@@ -167,6 +169,14 @@ def main():
                 inp = torch.empty(sum(rc) * rw, dtype=torch.int64, device=dev)
                 dist.all_to_all_single(inp, out, [c * rw for c in rc], [c * rw for c in sc])
                 kc.count_records(inp, sum(rc))
+        # -d filter + linear marking + coverage histogram (for the partition engine this is also where counting happens)
+        if timed:
+            f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            f0.record()
+        kc.finalize(0, want_last_put=False)
+        if timed:
+            f1.record()
+            ev2.append((f0, f1))
 
     def barrier():
         torch.cuda.synchronize()
@@ -205,25 +215,51 @@ def main():
                                    f"K={K}, -p {P} sets (BASELINE.json configs[2])",
                        "reads_per_gpu": n_reads, "read_len": L, "K": K, "genome": args.genome, "err": args.err,
                        "distinct_kmers": distinct, "table_slots_log2": log2_slots,
-                       "parallelism": "single GPU, fused extract+insert" if world == 1 else f"set-id owner partition, RCCL all-to-all x{world}"},
+                       "engine": engine,
+                       "parallelism": ("single GPU, " + ("super-k-mer partitions counted in LDS" if engine == 2 else "fused extract+insert into one DRAM set"))
+                       if world == 1 else f"set-id owner partition, RCCL all-to-all x{world}"},
         }
         if world == 1 and ev:
             slot_b = 48 if K <= 63 else 80
             bytes_per_read = kpr * slot_b + (L + 3) // 4          # node read + node write per occurrence + packed read
             dur = [e0.elapsed_time(e1) * 1e-3 for e0, e1, _ in ev]
-            alg = [n * bytes_per_read for _, _, n in ev]
-            achieved = sum(alg) / sum(dur) / 1e9
+            dur2 = [f0.elapsed_time(f1) * 1e-3 for f0, f1 in ev2]
             traffic = None
             tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+            nwk = "2" if K <= 63 else "4"
+            if engine == 1:
+                kernel = f"count_reads_kernel<{nwk}>"
+                alg = [n * bytes_per_read for _, _, n in ev]
+                achieved = sum(alg) / sum(dur) / 1e9
+                launches, avg_ms, per_launch = len(ev), sum(dur) / len(dur) * 1e3, sum(alg) / len(alg)
+                extra = {}
+            else:
+                # partition formulation: count passes x record bytes.  K1 reads the packed reads and writes
+                # the super-k-mer records; K2 reads the records and writes the distinct k-mers.
+                st = kc.stats()
+                rec_bytes = st["records"] * st["unit_bytes"]
+                k1_bytes = n_reads * wpr * 8 + rec_bytes
+                k2_bytes = rec_bytes + distinct * (kc.nw + 2) * 8
+                k1_s, k2_s = sum(dur) / args.steps, sum(dur2) / args.steps
+                if k1_s >= k2_s:
+                    kernel, achieved = f"skm_scatter_kernel<{nwk}>", k1_bytes / k1_s / 1e9
+                    launches, avg_ms, per_launch = len(ev), sum(dur) / len(dur) * 1e3, k1_bytes / len(batches)
+                else:
+                    kernel, achieved = f"skm_count_kernel<{nwk}>", k2_bytes / k2_s / 1e9
+                    launches, avg_ms, per_launch = len(ev2), k2_s * 1e3, k2_bytes
+                extra = {"k1_scatter_ms_per_step": k1_s * 1e3, "k2_count_ms_per_step": k2_s * 1e3,
+                         "k1_GBps": k1_bytes / k1_s / 1e9, "k2_GBps": k2_bytes / k2_s / 1e9,
+                         "records_per_read": st["records"] / n_reads, "record_bytes": st["unit_bytes"],
+                         "hash_formulation_equivalent_GBps": n_reads * bytes_per_read / (dt / args.steps) / 1e9,
+                         "hash_formulation_equivalent_frac": n_reads * bytes_per_read / (dt / args.steps) / 1e9 / 8000.0}
             if os.path.exists(tf):
                 try:
-                    traffic = json.load(open(tf)).get("count_reads_kernel_bytes_per_launch")
+                    traffic = json.load(open(tf)).get(kernel.split("<")[0] + "_bytes_per_launch")
                 except Exception:
                     traffic = None
             rec["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                               "traffic": traffic, "kernel": "count_reads_kernel<2>" if K <= 63 else "count_reads_kernel<4>",
-                               "launches": len(ev), "avg_launch_ms": sum(dur) / len(dur) * 1e3,
-                               "algorithmic_bytes_per_launch": sum(alg) / len(alg)}
+                               "traffic": traffic, "kernel": kernel, "launches": launches, "avg_launch_ms": avg_ms,
+                               "algorithmic_bytes_per_launch": per_launch, **extra}
             if not args.no_cpu_baseline:
                 # the reference's workers each scan the whole k-mer buffer (prlHashReads.c:79-90), so its pass 1 stops
                 # scaling long before a 100+-core host is used up: cap -p at 16 and say so

@@ -169,6 +169,11 @@ int pg_distinct(pg_ctx *ctx, uint64_t *out, void *stream);
 /* Current capacity (slots) and bytes per slot of the device set. */
 int pg_table_info(pg_ctx *ctx, uint64_t *slots, uint32_t *slot_bytes);
 
+/* Counters for reporting (synchronise first): out[0] engine, out[1] distinct k-mers, out[2] super-k-mer records,
+ * out[3] bytes per record (engine 2) / per slot (engine 1), out[4] pool chunks handed out, out[5] pool chunks,
+ * out[6] partitions (engine 2) / slots (engine 1), out[7] export capacity. */
+int pg_stats(pg_ctx *ctx, uint64_t out[8]);
+
 /* After the last batch: apply the -d filter (thread_delow), mark linear nodes and build the coverage
  * histogram (thread_mark, freqStat) in one scan over the set.  hist_out[256] (host) receives the histogram;
  * set_last_put_out[n_sets] (host, may be NULL) receives the per-set last-put values.  Synchronises. */

@@ -77,6 +77,7 @@ def lib() -> C.CDLL:
     L.pg_count_records.argtypes = [C.c_void_p, u64p, C.c_uint64, C.c_void_p]
     L.pg_distinct.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]
     L.pg_table_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+    L.pg_stats.argtypes = [C.c_void_p, u64p]
     L.pg_finalize.argtypes = [C.c_void_p, C.c_int, u64p, u64p, C.c_void_p]
     L.pg_export.argtypes = [C.c_void_p, u64p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]
     _lib = L
@@ -86,7 +87,7 @@ def lib() -> C.CDLL:
 EXPORTED_SYMBOLS = [
     "pg_last_error", "pg_version", "call_pregraph", "call_pregraph_127mer", "pg_packed_words", "pg_pack_read",
     "pg_host_build_graph", "pg_host_read_all", "pg_host_replay_layout", "pg_host_write_kmerfreq", "pg_create", "pg_create_engine", "pg_destroy", "pg_reset", "pg_set_autogrow", "pg_count_reads", "pg_route_count",
-    "pg_route_scatter", "pg_count_records", "pg_distinct", "pg_table_info", "pg_finalize", "pg_export",
+    "pg_route_scatter", "pg_count_records", "pg_distinct", "pg_stats", "pg_table_info", "pg_finalize", "pg_export",
 ]
 
 
@@ -259,11 +260,18 @@ class KmerCounter:
         _check(lib().pg_table_info(self.h, C.byref(s), C.byref(b)), "pg_table_info")
         return s.value, b.value
 
-    def finalize(self, delow: int = 0):
+    def finalize(self, delow: int = 0, want_last_put: bool = True):
         hist = np.zeros(256, dtype=np.uint64)
         last = np.zeros(self.P, dtype=np.uint64)
-        _check(lib().pg_finalize(self.h, delow, hist.ctypes.data, last.ctypes.data, self._stream()), "pg_finalize")
+        _check(lib().pg_finalize(self.h, delow, hist.ctypes.data, last.ctypes.data if want_last_put else None, self._stream()),
+               "pg_finalize")
         return hist, last
+
+    def stats(self) -> dict:
+        out = np.zeros(8, dtype=np.uint64)
+        _check(lib().pg_stats(self.h, out.ctypes.data), "pg_stats")
+        keys = ["engine", "distinct", "records", "unit_bytes", "pool_used", "pool_chunks", "parts_or_slots", "export_capacity"]
+        return {k: int(v) for k, v in zip(keys, out)}
 
     def export(self) -> np.ndarray:
         """(n, nw + 2) uint64 records on the host (key words, cnt, set << 56 | first ordinal)."""

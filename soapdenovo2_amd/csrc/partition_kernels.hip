@@ -163,9 +163,11 @@ __global__ __launch_bounds__(BLOCK) void skm_count_kernel(E2Dev e, int D, SetPar
     const int K = e.g.K;
     const uint32_t parts = 1u << e.g.log2_parts;
     const int lane = threadIdx.x & 63;
+    unsigned long long my_records = 0;
     for (uint32_t pid = blockIdx.x; pid < parts; pid += gridDim.x) {
         const uint32_t nrec = e.cursor[pid];
         const uint32_t usable = min(nrec, e.maxc * e.rpc);             // an overfull partition was flagged by K1
+        my_records += usable;
         if (usable == 0) continue;
         __syncthreads();
         if (threadIdx.x == 0) { sp_top = 1; s_mask[0] = 0; s_val[0] = 0; }
@@ -252,6 +254,7 @@ __global__ __launch_bounds__(BLOCK) void skm_count_kernel(E2Dev e, int D, SetPar
     }
     __syncthreads();
     if (hist[threadIdx.x]) atomicAdd(&ctr->hist[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+    if (threadIdx.x == 0 && my_records) atomicAdd(&ctr->n_records, my_records);
 }
 
 // per reference set: 1 + ordinal of the last k-mer occurrence routed to it (see host_graph.cpp, before_put)
@@ -426,6 +429,7 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     const SetParams sp{(uint32_t)c->P, set_bias((uint32_t)c->P)};
     E2_TRY(hipMemsetAsync(&c->ctr->n_export, 0, sizeof(unsigned long long), st));
     E2_TRY(hipMemsetAsync(c->ctr->hist, 0, sizeof(unsigned long long) * 256, st));
+    E2_TRY(hipMemsetAsync(&c->ctr->n_records, 0, sizeof(unsigned long long), st));
     const uint32_t parts = 1u << s.log2_parts;
     int n_cu = 256;
     hipDeviceProp_t prop;

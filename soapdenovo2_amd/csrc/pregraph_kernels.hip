@@ -743,6 +743,28 @@ extern "C" int pg_distinct(pg_ctx* c, uint64_t* out, void* stream) {
     return PG_OK;
 }
 
+extern "C" int pg_stats(pg_ctx* c, uint64_t out[8]) {
+    if (!c || !out) { g_err = "null argument"; return PG_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    DevCounters h;
+    HIP_TRY(hipMemcpy(&h, c->ctr, sizeof h, hipMemcpyDeviceToHost));
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    out[0] = (uint64_t)c->engine;
+    out[1] = c->engine == 2 ? h.n_export : h.n_distinct;
+    if (c->engine == 2) {
+        out[2] = h.n_records;
+        out[3] = (uint64_t)c->e2.g.rw * 8;
+        out[4] = h.pool_next;
+        out[5] = c->e2.pool_chunks;
+        out[6] = (uint64_t)1 << c->e2.log2_parts;
+        out[7] = c->e2.out_capacity;
+    } else {
+        out[6] = (uint64_t)1 << c->log2_slots;
+        out[3] = slot_bytes(c->NW);
+    }
+    return PG_OK;
+}
+
 extern "C" int pg_table_info(pg_ctx* c, uint64_t* slots, uint32_t* sbytes) {
     if (!c) { g_err = "null context"; return PG_EINVAL; }
     if (c->engine == 2) {
