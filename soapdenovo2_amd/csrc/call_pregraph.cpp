@@ -246,6 +246,11 @@ int run(int argc, char** argv, bool mer127) {
         p1.finish();
         total_kmers = p1.total_kmers();
     }
+    // ---- -d filter, linear marking, .kmerFreq (deLowCov / Mark1in1outNode / freqStat); with the partition engine this
+    // is also where the partitions are counted, so the node count is known only afterwards
+    uint64_t hist[256];
+    std::vector<uint64_t> set_last(o.sets, 0);
+    if (pg_finalize(ctx, o.delow, hist, set_last.data(), nullptr) != PG_OK) die("pg_finalize");
     uint64_t n_distinct = 0;
     if (pg_distinct(ctx, &n_distinct, nullptr) != PG_OK) die("pg_distinct");
     time_t t1 = time(nullptr);
@@ -253,12 +258,7 @@ int run(int argc, char** argv, bool mer127) {
     fprintf(stderr, "%llu node(s) allocated, %llu kmer(s) in reads, %llu kmer(s) processed.\n", (unsigned long long)n_distinct,
             (unsigned long long)total_kmers, (unsigned long long)total_kmers);
     fprintf(stderr, "done hashing nodes\n");
-
-    // ---- -d filter, linear marking, .kmerFreq (deLowCov / Mark1in1outNode / freqStat)
     t0 = time(nullptr);
-    uint64_t hist[256];
-    std::vector<uint64_t> set_last(o.sets, 0);
-    if (pg_finalize(ctx, o.delow, hist, set_last.data(), nullptr) != PG_OK) die("pg_finalize");
     if (pg_host_write_kmerfreq(hist, o.prefix.c_str()) != PG_OK) die("kmerFreq");
     fprintf(stderr, "Time spent on marking linear nodes: %ds.\n", (int)(time(nullptr) - t0));
     fprintf(stderr, "Time spent on pre-graph construction: %ds.\n\n", (int)(time(nullptr) - t_start));

@@ -156,7 +156,8 @@ __global__ __launch_bounds__(BLOCK) void skm_count_kernel(E2Dev e, int D, SetPar
     __shared__ unsigned long long tab[SLOTS * SW];
     __shared__ uint32_t crc_tab[256];
     __shared__ unsigned int hist[256];
-    __shared__ unsigned int n_keys, aborted, sp_top, s_mask[40], s_val[40], cur_mask, cur_val;
+    __shared__ unsigned int n_keys, aborted, sp_top, s_mask[40], s_val[40], cur_mask, cur_val, wave_cnt[BLOCK / 64], wave_off[BLOCK / 64];
+    __shared__ unsigned long long out_base;
     crc_tab[threadIdx.x] = crc32_table_entry(threadIdx.x);
     hist[threadIdx.x] = 0;
     const Kmer<NW> filter = kmer_filter<NW>(e.g.K);
@@ -210,16 +211,26 @@ __global__ __launch_bounds__(BLOCK) void skm_count_kernel(E2Dev e, int D, SetPar
                 __syncthreads();
                 continue;
             }
-            // ---- emit: finalize every stored node and append it to the export array
+            // ---- emit: finalize every stored node and append it to the export array.  One global atomic per attempt:
+            // the block's live slots are counted first (n_keys is exact: every first CAS on cnt bumped it).
+            if (threadIdx.x == 0) out_base = atomicAdd(&ctr->n_export, (unsigned long long)n_keys);
+            if (threadIdx.x < BLOCK / 64) wave_off[threadIdx.x] = 0;
+            __syncthreads();
+            unsigned long long run = out_base;          // same in every lane; advanced stripe by stripe
             for (int base = 0; base < SLOTS; base += BLOCK) {
                 const int si = base + threadIdx.x;
                 const unsigned long long* s = tab + (size_t)si * SW;
                 const bool live = s[KW] != L_EMPTY;          // cnt is only set once every key word is claimed
                 const unsigned long long m = __ballot(live);
-                if (m == 0) continue;
-                unsigned long long pos0 = 0;
-                if (lane == 0) pos0 = atomicAdd(&ctr->n_export, (unsigned long long)__popcll(m));
-                pos0 = __shfl(pos0, 0, 64);
+                if (lane == 0) wave_cnt[threadIdx.x >> 6] = (unsigned int)__popcll(m);
+                __syncthreads();
+                unsigned int before = 0, total = 0;
+#pragma unroll
+                for (int wv = 0; wv < BLOCK / 64; wv++) {
+                    const unsigned int cw = wave_cnt[wv];
+                    if (wv < (int)(threadIdx.x >> 6)) before += cw;
+                    total += cw;
+                }
                 if (live) {
                     Key63<NW> k63;
 #pragma unroll
@@ -238,7 +249,7 @@ __global__ __launch_bounds__(BLOCK) void skm_count_kernel(E2Dev e, int D, SetPar
                     if (D > 0 && nin == 0 && nout == 0) B |= B_DELETED;
                     if (nin == 1 && nout == 1) B |= B_LINEAR;
                     atomicAdd(&hist[A >> 24], 1u);
-                    const uint64_t pos = pos0 + __popcll(m & ((1ULL << lane) - 1));
+                    const uint64_t pos = run + before + __popcll(m & ((1ULL << lane) - 1));
                     if (pos < e.out_capacity) {
                         const uint32_t set = set_of_crc(kmer_crc32<NW>(key, crc_tab), sp.P, sp.bias);
                         uint64_t* o = e.out + pos * (NW + 2);
@@ -248,6 +259,8 @@ __global__ __launch_bounds__(BLOCK) void skm_count_kernel(E2Dev e, int D, SetPar
                         o[NW + 1] = ((uint64_t)set << PG_ORD_BITS) | (s[KW + 1] & PG_ORD_MASK);
                     } else atomicOr(&ctr->e2_flags, F_OUT);
                 }
+                run += total;
+                __syncthreads();
             }
             __syncthreads();
         }
