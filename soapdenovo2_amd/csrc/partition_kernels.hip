@@ -150,7 +150,7 @@ __device__ __forceinline__ const uint64_t* record_ptr(const E2Dev& e, uint32_t p
 }
 
 template <int NW>
-__global__ __launch_bounds__(BLOCK) void skm_count_kernel(E2Dev e, int D, SetParams sp, DevCounters* ctr) {
+__global__ __launch_bounds__(BLOCK) void skm_count_kernel(E2Dev e, int D, SetParams sp, DevCounters* ctr, int dbg) {
     constexpr int PW = E2Cfg<NW>::PW, RW = PW + 1, KW = E2Cfg<NW>::KW, SW = E2Cfg<NW>::SW, SLOTS = E2Cfg<NW>::SLOTS;
     constexpr unsigned LIMIT = SLOTS * 7 / 10;
     __shared__ unsigned long long tab[SLOTS * SW];
@@ -191,6 +191,7 @@ __global__ __launch_bounds__(BLOCK) void skm_count_kernel(E2Dev e, int D, SetPar
                     const Kmer<NW> key = canonical_occurrence<NW>(rec + 1, hl + t, nb, K, filter, occ);
                     const uint64_t hh = kmer_mix<NW>(key);
                     if (((uint32_t)(hh >> 32) & mask) != val) continue;
+                    if (dbg & 1) { if (hh == 0x1234) aborted = 1; continue; }       // measurement aid: extraction only
                     if (!lds_put<NW>(tab, key63_from_kmer<NW>(key), hh, occ.left, occ.right, ord0 + (uint64_t)t, &n_keys, LIMIT)) {
                         aborted = 1;
                         break;
@@ -448,8 +449,10 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) n_cu = prop.multiProcessorCount;
     const unsigned grid = std::min<unsigned>(parts, (unsigned)n_cu * 2u * 4u);      // 2 resident blocks per CU (64 KB LDS each), x4 for balance
-    if (c->NW == 2) hipLaunchKernelGGL(skm_count_kernel<2>, dim3(grid), dim3(BLOCK), 0, st, dev_view(c), delow, sp, c->ctr);
-    else hipLaunchKernelGGL(skm_count_kernel<4>, dim3(grid), dim3(BLOCK), 0, st, dev_view(c), delow, sp, c->ctr);
+    int dbg = 0;
+    if (const char* v = getenv("PG_DBG")) dbg = atoi(v);
+    if (c->NW == 2) hipLaunchKernelGGL(skm_count_kernel<2>, dim3(grid), dim3(BLOCK), 0, st, dev_view(c), delow, sp, c->ctr, dbg);
+    else hipLaunchKernelGGL(skm_count_kernel<4>, dim3(grid), dim3(BLOCK), 0, st, dev_view(c), delow, sp, c->ctr, dbg);
     E2_TRY(hipGetLastError());
     if (want_last_put) {
         E2_TRY(hipMemsetAsync(c->ctr->set_last, 0, sizeof(unsigned long long) * 256, st));
