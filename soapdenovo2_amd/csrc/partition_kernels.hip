@@ -35,8 +35,9 @@ constexpr uint64_t L_EMPTY = ~0ULL;
 constexpr unsigned long long F_POOL = 1, F_CHUNKS = 2, F_OUT = 4, F_SPLIT = 8;
 
 template <int NW> struct E2Cfg;
-template <> struct E2Cfg<2> { static constexpr int PW = 5, KW = 2, SW = 4, SLOTS = 2048; };   // 32-B slots, 64 KB
-template <> struct E2Cfg<4> { static constexpr int PW = 7, KW = 5, SW = 8, SLOTS = 1024; };   // 64-B slots, 64 KB
+// LDS slot = KW key words | ord | 10 x u32 counters (L[4], R[4], puts, spare)
+template <> struct E2Cfg<2> { static constexpr int PW = 5, KW = 2, SW = 8, SLOTS = 1024; };    // 64-B slots, 64 KB
+template <> struct E2Cfg<4> { static constexpr int PW = 7, KW = 5, SW = 11, SLOTS = 512; };    // 88-B slots, 44 KB
 
 struct E2Dev {
     SkmGeom g;
@@ -99,6 +100,85 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_kernel(ReadsArg a, E2Dev e,
     });
 }
 
+// Tiled K1 for uniform-length reads: no data-dependent control flow per k-mer.  A workgroup takes R reads:
+//   A  every m-mer value of the tile into LDS (one lane per m-mer position)
+//   B  sliding-window minimum by doubling: V_k[p] = min(V_{k-1}[p], V_{k-1}[p + 2^(k-1)]), window = two overlapping V_lv
+//   C  partition of every k-mer; D  run starts (a local rule, skm.hpp) and run lengths -> compact item list in LDS
+//   E  one lane per run: reserve a record slot in the partition's stream, build the record from the staged words,
+//      store it with 16-byte writes.
+// Only E touches global memory besides the coalesced tile load.
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void skm_scatter_tiled_kernel(ReadsArg a, E2Dev e, DevCounters* ctr, int R, int np, int lv) {
+    constexpr int PW = E2Cfg<NW>::PW, RW = PW + 1;
+    extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int wpr = (int)a.wpr, kpr = (int)a.kpr, ws = wpr + 1, len = (int)a.uniform_len;
+    uint64_t* words = (uint64_t*)smem_raw;                       // R * ws
+    uint64_t* v0 = words + (size_t)R * ws;                        // R * np
+    uint64_t* v1 = v0 + (size_t)R * np;                           // R * np
+    uint32_t* pids = (uint32_t*)(v1 + (size_t)R * np);            // R * kpr
+    uint32_t* items = pids + (size_t)R * kpr;                     // R * kpr  (r << 24 | j << 12 | n)
+    __shared__ unsigned int n_items;
+    const uint64_t r0 = (uint64_t)blockIdx.x * R;
+    const int nr = (int)min((uint64_t)R, a.n_reads - r0);
+    if (threadIdx.x == 0) n_items = 0;
+    // stage the tile: contiguous in the packed buffer
+    for (int i = threadIdx.x; i < nr * wpr; i += BLOCK) {
+        const int r = i / wpr, k = i - r * wpr;
+        words[r * ws + k] = a.packed[r0 * wpr + i];
+    }
+    for (int r = threadIdx.x; r < nr; r += BLOCK) words[r * ws + wpr] = 0;
+    __syncthreads();
+    const int m = e.g.m, w = e.g.w;
+    for (int i = threadIdx.x; i < nr * np; i += BLOCK) {
+        const int r = i / np, p = i - r * np;
+        v0[i] = mmer_value(words + r * ws, p, m);
+    }
+    __syncthreads();
+    uint64_t* src = v0;
+    uint64_t* dst = v1;
+    for (int k = 1; k <= lv; k++) {
+        const int half = 1 << (k - 1);
+        for (int i = threadIdx.x; i < nr * np; i += BLOCK) {
+            const int p = i % np;
+            const uint64_t x = src[i];
+            dst[i] = (p + half < np) ? min(x, src[i + half]) : x;
+        }
+        __syncthreads();
+        uint64_t* t = src; src = dst; dst = t;
+    }
+    const int span = 1 << lv;                                      // src[p] = min over [p, p + span)
+    for (int i = threadIdx.x; i < nr * kpr; i += BLOCK) {
+        const int r = i / kpr, j = i - r * kpr;
+        const uint64_t mn = min(src[r * np + j], src[r * np + j + w - span]);
+        pids[i] = skm_partition(mn, e.g.log2_parts);
+    }
+    __syncthreads();
+    const int nmax = e.g.nmax;
+    for (int i = threadIdx.x; i < nr * kpr; i += BLOCK) {
+        const int r = i / kpr, j = i - r * kpr;
+        if (j == 0 || pids[i] != pids[i - 1] || j % nmax == 0) {
+            int n = 1;
+            while (j + n < kpr && pids[i + n] == pids[i + n - 1] && (j + n) % nmax != 0) n++;
+            items[atomicAdd(&n_items, 1u)] = ((uint32_t)r << 24) | ((uint32_t)j << 12) | (uint32_t)n;
+        }
+    }
+    __syncthreads();
+    const int total = (int)n_items;
+    for (int it = threadIdx.x; it < total; it += BLOCK) {
+        const uint32_t pk = items[it];
+        const int r = (int)(pk >> 24), j0 = (int)((pk >> 12) & 0xFFF), n = (int)(pk & 0xFFF);
+        const uint32_t pid = pids[r * kpr + j0];
+        const uint32_t q = atomicAdd(&e.cursor[pid], 1u);
+        uint64_t* out = record_slot(e, pid, q, ctr, RW);
+        if (!out) continue;
+        uint64_t rec[RW];
+        skm_make_record<PW>(words + r * ws, len, j0, n, a.ord_base + (r0 + (uint64_t)r) * (uint64_t)kpr, e.g, rec);
+        ulonglong2* o2 = (ulonglong2*)out;
+#pragma unroll
+        for (int k = 0; k < RW / 2; k++) o2[k] = make_ulonglong2(rec[2 * k], rec[2 * k + 1]);
+    }
+}
+
 // ---- the LDS set ---------------------------------------------------------------------------------------------
 // slot = KW key words (63 bit each) | cnt | ord, every word starts as ~0.  Claim word by word: an empty word is
 // taken with CAS(~0 -> mine); a word holding something else means another key owns the slot.  cnt starts from ~0
@@ -112,30 +192,28 @@ __device__ __forceinline__ bool lds_put(unsigned long long* tab, const Key63<NW>
     uint32_t h = (uint32_t)hash & (SLOTS - 1);
     for (int probes = 0; probes < SLOTS; probes++) {
         unsigned long long* s = tab + (size_t)h * SW;
-        bool mine = true;
+        bool mine = true, inserted = false;
 #pragma unroll
         for (int i = 0; i < KW; i++) {
             if (!mine) break;
             unsigned long long cur = s[i];
             if (cur == L_EMPTY) {
                 const unsigned long long old = atomicCAS(&s[i], L_EMPTY, (unsigned long long)key.w[i]);
-                cur = old == L_EMPTY ? key.w[i] : old;
+                if (old == L_EMPTY) { cur = key.w[i]; if (i == KW - 1) inserted = true; }
+                else cur = old;
             }
             mine = cur == key.w[i];
         }
         if (mine) {
-            unsigned long long cur = s[KW];
-            for (;;) {
-                const unsigned long long nxt = cur == L_EMPTY ? node_first(left, right) : node_update(cur, left, right);
-                if (nxt == cur) break;
-                const unsigned long long old = atomicCAS(&s[KW], cur, nxt);
-                if (old == cur) {
-                    if (cur == L_EMPTY && atomicAdd(n_keys, 1u) + 1 > limit) return false;
-                    break;
-                }
-                cur = old;
-            }
-            if (ord < s[KW + 1]) atomicMin(&s[KW + 1], (unsigned long long)ord);
+            // the lane that completed the claim (won the last key word) accounts for the new key
+            if (inserted && atomicAdd(n_keys, 1u) + 1 > limit) return false;
+            // plain counters, saturated when the node is emitted: a sum of +1's clipped at the end equals the
+            // reference's saturating increments (newhash.c:74-106), and adds need no retry under contention
+            unsigned int* c = (unsigned int*)(s + KW + 1);
+            if (left < 4) atomicAdd(&c[left], 1u);
+            if (right < 4) atomicAdd(&c[4 + right], 1u);
+            atomicAdd(&c[8], 1u);
+            atomicMin(&s[KW], (unsigned long long)ord);
             return true;
         }
         h = (h + 1) & (SLOTS - 1);
@@ -176,7 +254,7 @@ __global__ __launch_bounds__(BLOCK) void skm_count_kernel(E2Dev e, int D, SetPar
         while (sp_top > 0) {
             __syncthreads();
             if (threadIdx.x == 0) { sp_top--; cur_mask = s_mask[sp_top]; cur_val = s_val[sp_top]; n_keys = 0; aborted = 0; }
-            for (int i = threadIdx.x; i < SLOTS * SW; i += BLOCK) tab[i] = L_EMPTY;
+            for (int i = threadIdx.x; i < SLOTS * SW; i += BLOCK) tab[i] = (i % SW) <= KW ? L_EMPTY : 0ULL;   // keys + ord = ~0, counters = 0
             __syncthreads();
             const uint32_t mask = cur_mask, val = cur_val;
             volatile unsigned int* abort_flag = &aborted;
@@ -221,7 +299,8 @@ __global__ __launch_bounds__(BLOCK) void skm_count_kernel(E2Dev e, int D, SetPar
             for (int base = 0; base < SLOTS; base += BLOCK) {
                 const int si = base + threadIdx.x;
                 const unsigned long long* s = tab + (size_t)si * SW;
-                const bool live = s[KW] != L_EMPTY;          // cnt is only set once every key word is claimed
+                const unsigned int* cn = (const unsigned int*)(s + KW + 1);
+                const bool live = cn[8] != 0;                // a put is only counted once every key word is claimed
                 const unsigned long long m = __ballot(live);
                 if (lane == 0) wave_cnt[threadIdx.x >> 6] = (unsigned int)__popcll(m);
                 __syncthreads();
@@ -237,8 +316,9 @@ __global__ __launch_bounds__(BLOCK) void skm_count_kernel(E2Dev e, int D, SetPar
 #pragma unroll
                     for (int w = 0; w < KW; w++) k63.w[w] = s[w];
                     const Kmer<NW> key = kmer_from_key63<NW>(k63);
-                    uint64_t cnt = s[KW];
-                    uint32_t A = (uint32_t)cnt, B = (uint32_t)(cnt >> 32);
+                    uint32_t A = min(cn[8], 255u) << 24, B = cn[8] == 1 ? B_SINGLE : 0u;
+#pragma unroll
+                    for (int c = 0; c < 4; c++) { A |= min(cn[c], 63u) << (6 * c); B |= min(cn[4 + c], 63u) << (6 * c); }
                     int nin = 0, nout = 0;
 #pragma unroll
                     for (int c = 0; c < 4; c++) {                                   // thread_delow + thread_mark
@@ -257,7 +337,7 @@ __global__ __launch_bounds__(BLOCK) void skm_count_kernel(E2Dev e, int D, SetPar
 #pragma unroll
                         for (int w = 0; w < NW; w++) o[w] = key.w[w];
                         o[NW] = (uint64_t)A | ((uint64_t)B << 32);
-                        o[NW + 1] = ((uint64_t)set << PG_ORD_BITS) | (s[KW + 1] & PG_ORD_MASK);
+                        o[NW + 1] = ((uint64_t)set << PG_ORD_BITS) | (s[KW] & PG_ORD_MASK);
                     } else atomicOr(&ctr->e2_flags, F_OUT);
                 }
                 run += total;
@@ -322,7 +402,7 @@ static E2Dev dev_view(const pg_ctx* c) {
 int e2_create(pg_ctx* c) {
     E2& s = c->e2;
     // partitions: expected distinct / ~1000 so a partition usually fits the LDS set in one attempt
-    s.log2_parts = std::max(8, std::min(22, c->log2_slots - 11));
+    s.log2_parts = std::max(8, std::min(22, c->log2_slots - 10));
     if (const char* v = getenv("PG_LOG2_PARTS")) s.log2_parts = std::max(4, std::min(24, atoi(v)));
     s.g = skm_geometry(c->K, s.log2_parts, c->NW);
     s.rpc = 32;
@@ -429,6 +509,26 @@ int e2_scatter(pg_ctx* c, const uint64_t* d_packed, const uint64_t* d_word_off, 
     a.kpr = uniform_len ? uniform_len - c->K + 1 : 0;
     a.wpr = uniform_len ? (uniform_len + 31) / 32 : 0;
     a.ord_base = ord_base;
+    // tiled kernel for uniform batches whose per-read LDS footprint allows at least 4 reads per workgroup
+    int tiled = uniform_len && uniform_len < 4096 && (int)a.kpr < 4096;
+    if (const char* v = getenv("PG_K1")) tiled = tiled && atoi(v) != 0;
+    if (tiled) {
+        const int np = (int)uniform_len - c->e2.g.m + 1;
+        const size_t per_read = (size_t)(a.wpr + 1) * 8 + (size_t)np * 16 + (size_t)a.kpr * 8;
+        int R = (int)std::min<size_t>(16, (60 * 1024) / per_read);
+        if (R >= 4) {
+            int lv = 0;
+            while ((2 << lv) <= c->e2.g.w) lv++;
+            const uint64_t grid = (n_reads + R - 1) / R;
+            if (grid > 0x7FFFFFFFULL) { pg_set_error("batch too large for one launch"); return PG_EINVAL; }
+            const size_t smem = per_read * R;
+            if (c->NW == 2) hipLaunchKernelGGL(skm_scatter_tiled_kernel<2>, dim3((unsigned)grid), dim3(BLOCK), smem, st, a, dev_view(c), c->ctr, R, np, lv);
+            else hipLaunchKernelGGL(skm_scatter_tiled_kernel<4>, dim3((unsigned)grid), dim3(BLOCK), smem, st, a, dev_view(c), c->ctr, R, np, lv);
+            E2_TRY(hipGetLastError());
+            c->e2.counted = false;
+            return PG_OK;
+        }
+    }
     const uint64_t grid = (n_reads + BLOCK - 1) / BLOCK;
     if (grid > 0x7FFFFFFFULL) { pg_set_error("batch too large for one launch"); return PG_EINVAL; }
     if (c->NW == 2) hipLaunchKernelGGL(skm_scatter_kernel<2>, dim3((unsigned)grid), dim3(BLOCK), 0, st, a, dev_view(c), c->ctr);

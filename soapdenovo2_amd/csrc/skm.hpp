@@ -74,8 +74,10 @@ PG_HD uint32_t skm_partition(uint64_t minval, int log2_parts) {
 }
 
 // ---- cutting a read into runs ------------------------------------------------------------------------------
-// Calls emit(j0, n, partition) for every maximal run of consecutive k-mers [j0, j0 + n) with the same partition
-// (runs are also cut at nmax k-mers).  Sliding minimum without a queue: remember the (rightmost) minimum and its
+// Calls emit(j0, n, partition) for every maximal run of consecutive k-mers [j0, j0 + n) with the same partition;
+// runs are also cut at every position that is a multiple of nmax, so "k-mer j starts a run" is a local property:
+//     starts(j) = j == 0 || partition(j) != partition(j - 1) || j % nmax == 0
+// (the tiled GPU kernel evaluates exactly this per lane; this serial walk is the reference formulation).  Sliding minimum without a queue: remember the (rightmost) minimum and its
 // position, rescan the window only when it slides out -- expected once per ~ (w + 1) / 2 steps.
 template <typename Emit>
 PG_HD void skm_split_read(const uint64_t* rd, int len, const SkmGeom& g, Emit&& emit) {
@@ -99,7 +101,7 @@ PG_HD void skm_split_read(const uint64_t* rd, int len, const SkmGeom& g, Emit&& 
             }
         } else if (v <= minval) { minval = v; minpos = pnew; }
         const uint32_t pid = skm_partition(minval, g.log2_parts);
-        if (pid != cur || j - j0 == g.nmax) {
+        if (pid != cur || j % g.nmax == 0) {
             emit(j0, j - j0, cur);
             j0 = j;
             cur = pid;
