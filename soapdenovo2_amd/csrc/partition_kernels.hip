@@ -59,19 +59,28 @@ struct ReadsArg {
     uint64_t ord_base;
 };
 
-// address of record q of partition pid, allocating its chunk on first touch.  Racing lanes may each draw a chunk
-// from the pool; the CAS decides whose id goes into the table, the others are simply never used.
+// address of record q of partition pid.  The lane that draws the first record of a chunk (q % rpc == 0) takes a
+// chunk from the pool and publishes its id; lanes with later records of the same chunk wait for the id.  The
+// publisher never waits on anybody and executes its store before it could reach the wait loop, so lanes of one
+// wavefront cannot deadlock.
 __device__ __forceinline__ uint64_t* record_slot(const E2Dev& e, uint32_t pid, uint32_t q, DevCounters* ctr, int rw) {
     const uint32_t ci = q / e.rpc, ri = q % e.rpc;
     if (ci >= e.maxc) { atomicOr(&ctr->e2_flags, F_CHUNKS); return nullptr; }
     uint32_t* t = e.chunk_tbl + (uint64_t)pid * e.maxc + ci;
-    uint32_t c = __hip_atomic_load(t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (c == 0) {
+    uint32_t c;
+    if (ri == 0) {
         const unsigned long long nc = atomicAdd(&ctr->pool_next, 1ULL) + 1;
-        if (nc > e.pool_chunks) { atomicOr(&ctr->e2_flags, F_POOL); return nullptr; }
-        const uint32_t old = atomicCAS(t, 0u, (uint32_t)nc);
-        c = old ? old : (uint32_t)nc;
+        c = nc > e.pool_chunks ? 0xFFFFFFFFu : (uint32_t)nc;              // 0xFFFFFFFF = "pool exhausted", wakes the waiters too
+        if (nc > e.pool_chunks) atomicOr(&ctr->e2_flags, F_POOL);
+        __hip_atomic_store(t, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        c = __hip_atomic_load(t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while (c == 0) {
+            __builtin_amdgcn_s_sleep(2);
+            c = __hip_atomic_load(t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
     }
+    if (c == 0xFFFFFFFFu) return nullptr;
     return e.pool + ((uint64_t)(c - 1) * e.rpc + ri) * (uint64_t)rw;
 }
 
@@ -223,7 +232,7 @@ __device__ __forceinline__ bool lds_put(unsigned long long* tab, const Key63<NW>
 
 __device__ __forceinline__ const uint64_t* record_ptr(const E2Dev& e, uint32_t pid, uint32_t i, int rw) {
     const uint32_t c = e.chunk_tbl[(uint64_t)pid * e.maxc + i / e.rpc];
-    if (c == 0) return nullptr;                      // pool ran dry in K1 (flagged there; the run fails in e2_count)
+    if (c == 0 || c == 0xFFFFFFFFu) return nullptr;  // pool ran dry in K1 (flagged there; the run fails in e2_count)
     return e.pool + ((uint64_t)(c - 1) * e.rpc + i % e.rpc) * (uint64_t)rw;
 }
 
