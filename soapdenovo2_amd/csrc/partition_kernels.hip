@@ -60,26 +60,28 @@ struct ReadsArg {
 };
 
 // address of record q of partition pid.  The lane that draws the first record of a chunk (q % rpc == 0) takes a
-// chunk from the pool and publishes its id; lanes with later records of the same chunk wait for the id.  The
-// publisher never waits on anybody and executes its store before it could reach the wait loop, so lanes of one
-// wavefront cannot deadlock.
+// chunk from the pool and publishes its id; lanes with later records of the same chunk wait for the id.
+// Deadlock freedom inside a wavefront: the publish is NOT the other arm of the wait (`if (first) publish; else wait`
+// lets the compiler run the wait arm first and starve the publisher of the same wave); every lane runs
+// "publish if first" and THEN the wait loop, and a publisher never waits for anything before its store.  The lane
+// with q % rpc == 0 drew its number before any lane with a later number of that chunk, so its publish is already
+// issued (same or earlier instruction of this wave, or an independent wave).  The wait is bounded anyway.
 __device__ __forceinline__ uint64_t* record_slot(const E2Dev& e, uint32_t pid, uint32_t q, DevCounters* ctr, int rw) {
     const uint32_t ci = q / e.rpc, ri = q % e.rpc;
     if (ci >= e.maxc) { atomicOr(&ctr->e2_flags, F_CHUNKS); return nullptr; }
     uint32_t* t = e.chunk_tbl + (uint64_t)pid * e.maxc + ci;
-    uint32_t c;
     if (ri == 0) {
         const unsigned long long nc = atomicAdd(&ctr->pool_next, 1ULL) + 1;
-        c = nc > e.pool_chunks ? 0xFFFFFFFFu : (uint32_t)nc;              // 0xFFFFFFFF = "pool exhausted", wakes the waiters too
+        const uint32_t id = nc > e.pool_chunks ? 0xFFFFFFFFu : (uint32_t)nc;     // 0xFFFFFFFF = "pool exhausted", releases the waiters too
         if (nc > e.pool_chunks) atomicOr(&ctr->e2_flags, F_POOL);
-        __hip_atomic_store(t, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        c = __hip_atomic_load(t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        while (c == 0) {
-            __builtin_amdgcn_s_sleep(2);
-            c = __hip_atomic_load(t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
+        __hip_atomic_store(t, id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+    uint32_t c = __hip_atomic_load(t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    for (int spin = 0; c == 0 && spin < (1 << 20); spin++) {
+        __builtin_amdgcn_s_sleep(2);
+        c = __hip_atomic_load(t, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (c == 0) { atomicOr(&ctr->e2_flags, F_POOL); return nullptr; }
     if (c == 0xFFFFFFFFu) return nullptr;
     return e.pool + ((uint64_t)(c - 1) * e.rpc + ri) * (uint64_t)rw;
 }
