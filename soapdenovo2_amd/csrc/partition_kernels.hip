@@ -36,8 +36,8 @@ constexpr unsigned long long F_POOL = 1, F_CHUNKS = 2, F_OUT = 4, F_SPLIT = 8;
 
 template <int NW> struct E2Cfg;
 // LDS slot = KW key words | ord | 10 x u32 counters (L[4], R[4], puts, spare)
-template <> struct E2Cfg<2> { static constexpr int PW = 5, KW = 2, SW = 8, SLOTS = 1024; };    // 64-B slots, 64 KB
-template <> struct E2Cfg<4> { static constexpr int PW = 7, KW = 5, SW = 11, SLOTS = 512; };    // 88-B slots, 44 KB
+template <> struct E2Cfg<2> { static constexpr int PW = 5, KW = 2, SLOTS = 1024; };    // 60 B per slot -> 60 KB
+template <> struct E2Cfg<4> { static constexpr int PW = 7, KW = 5, SLOTS = 512; };     // 84 B per slot -> 42 KB
 
 struct E2Dev {
     SkmGeom g;
@@ -112,61 +112,65 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_kernel(ReadsArg a, E2Dev e,
 }
 
 // Tiled K1 for uniform-length reads: no data-dependent control flow per k-mer.  A workgroup takes R reads:
-//   A  every m-mer value of the tile into LDS (one lane per m-mer position)
+//   A  every m-mer value of the tile into LDS (one lane per m-mer position, 32-bit values)
 //   B  sliding-window minimum by doubling: V_k[p] = min(V_{k-1}[p], V_{k-1}[p + 2^(k-1)]), window = two overlapping V_lv
 //   C  partition of every k-mer; D  run starts (a local rule, skm.hpp) and run lengths -> compact item list in LDS
 //   E  one lane per run: reserve a record slot in the partition's stream, build the record from the staged words,
 //      store it with 16-byte writes.
-// Only E touches global memory besides the coalesced tile load.
+// Only E touches global memory besides the coalesced tile load.  Index arithmetic is 32-bit with multiply-high
+// reciprocals (the GPU has neither an integer divider nor a 64-bit multiplier).
+struct TileArg { int R, np, lv; uint32_t inv_np, inv_kpr, inv_wpr; };
+__device__ __forceinline__ uint32_t fastdiv(uint32_t i, uint32_t inv) { return __umulhi(i, inv); }
+
 template <int NW>
-__global__ __launch_bounds__(BLOCK) void skm_scatter_tiled_kernel(ReadsArg a, E2Dev e, DevCounters* ctr, int R, int np, int lv) {
+__global__ __launch_bounds__(BLOCK) void skm_scatter_tiled_kernel(ReadsArg a, E2Dev e, DevCounters* ctr, TileArg ta) {
     constexpr int PW = E2Cfg<NW>::PW, RW = PW + 1;
     extern __shared__ __align__(16) unsigned char smem_raw[];
+    const int R = ta.R, np = ta.np, lv = ta.lv;
     const int wpr = (int)a.wpr, kpr = (int)a.kpr, ws = wpr + 1, len = (int)a.uniform_len;
     uint64_t* words = (uint64_t*)smem_raw;                       // R * ws
-    uint64_t* v0 = words + (size_t)R * ws;                        // R * np
-    uint64_t* v1 = v0 + (size_t)R * np;                           // R * np
-    uint32_t* pids = (uint32_t*)(v1 + (size_t)R * np);            // R * kpr
+    uint32_t* v0 = (uint32_t*)(words + (size_t)R * ws);           // R * np
+    uint32_t* v1 = v0 + (size_t)R * np;                           // R * np
+    uint32_t* pids = v1 + (size_t)R * np;                         // R * kpr
     uint32_t* items = pids + (size_t)R * kpr;                     // R * kpr  (r << 24 | j << 12 | n)
     __shared__ unsigned int n_items;
     const uint64_t r0 = (uint64_t)blockIdx.x * R;
     const int nr = (int)min((uint64_t)R, a.n_reads - r0);
     if (threadIdx.x == 0) n_items = 0;
-    // stage the tile: contiguous in the packed buffer
     for (int i = threadIdx.x; i < nr * wpr; i += BLOCK) {
-        const int r = i / wpr, k = i - r * wpr;
+        const int r = (int)fastdiv(i, ta.inv_wpr), k = i - r * wpr;
         words[r * ws + k] = a.packed[r0 * wpr + i];
     }
     for (int r = threadIdx.x; r < nr; r += BLOCK) words[r * ws + wpr] = 0;
     __syncthreads();
     const int m = e.g.m, w = e.g.w;
     for (int i = threadIdx.x; i < nr * np; i += BLOCK) {
-        const int r = i / np, p = i - r * np;
+        const int r = (int)fastdiv(i, ta.inv_np), p = i - r * np;
         v0[i] = mmer_value(words + r * ws, p, m);
     }
     __syncthreads();
-    uint64_t* src = v0;
-    uint64_t* dst = v1;
+    uint32_t* src = v0;
+    uint32_t* dst = v1;
     for (int k = 1; k <= lv; k++) {
         const int half = 1 << (k - 1);
         for (int i = threadIdx.x; i < nr * np; i += BLOCK) {
-            const int p = i % np;
-            const uint64_t x = src[i];
+            const int p = i - (int)fastdiv(i, ta.inv_np) * np;
+            const uint32_t x = src[i];
             dst[i] = (p + half < np) ? min(x, src[i + half]) : x;
         }
         __syncthreads();
-        uint64_t* t = src; src = dst; dst = t;
+        uint32_t* t = src; src = dst; dst = t;
     }
     const int span = 1 << lv;                                      // src[p] = min over [p, p + span)
     for (int i = threadIdx.x; i < nr * kpr; i += BLOCK) {
-        const int r = i / kpr, j = i - r * kpr;
-        const uint64_t mn = min(src[r * np + j], src[r * np + j + w - span]);
+        const int r = (int)fastdiv(i, ta.inv_kpr), j = i - r * kpr;
+        const uint32_t mn = min(src[r * np + j], src[r * np + j + w - span]);
         pids[i] = skm_partition(mn, e.g.log2_parts);
     }
     __syncthreads();
     const int nmax = e.g.nmax;
     for (int i = threadIdx.x; i < nr * kpr; i += BLOCK) {
-        const int r = i / kpr, j = i - r * kpr;
+        const int r = (int)fastdiv(i, ta.inv_kpr), j = i - r * kpr;
         if (j == 0 || pids[i] != pids[i - 1] || j % nmax == 0) {
             int n = 1;
             while (j + n < kpr && pids[i + n] == pids[i + n - 1] && (j + n) % nmax != 0) n++;
@@ -191,25 +195,36 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_tiled_kernel(ReadsArg a, E2
 }
 
 // ---- the LDS set ---------------------------------------------------------------------------------------------
-// slot = KW key words (63 bit each) | cnt | ord, every word starts as ~0.  Claim word by word: an empty word is
-// taken with CAS(~0 -> mine); a word holding something else means another key owns the slot.  cnt starts from ~0
-// too: whoever gets CAS(~0 -> node_first) is the k-mer's first counted occurrence, later ones apply node_update
-// (the reduction is order independent, newhash.c:74-140); ord is a plain atomic min.
+// Struct of arrays, so lanes that hit different slots hit different banks: key[KW][SLOTS] (63-bit words), ord[SLOTS],
+// cnt[9][SLOTS] (u32: L[4], R[4], puts).  Keys and ord start as ~0, counters as 0.  A slot is claimed key word by key
+// word: an empty word is taken with CAS(~0 -> mine), a word holding something else means another key owns the slot.
+// Counting is plain atomic adds, saturated when the node is emitted: a sum of +1's clipped at the end equals the
+// reference's saturating increments (newhash.c:74-106) and, unlike a CAS on packed counters, needs no retry when many
+// lanes hit one hot k-mer.  `single` = exactly one put (newhash.c:127,511).
+constexpr int K2_THREADS = 512;
+
+template <int NW>
+struct LdsSet {
+    static constexpr int KW = E2Cfg<NW>::KW, SLOTS = E2Cfg<NW>::SLOTS;
+    unsigned long long key[KW][SLOTS];
+    unsigned long long ord[SLOTS];
+    unsigned int cnt[9][SLOTS];
+};
+
 // Returns false when the set is full (caller aborts the attempt and splits the key range).
 template <int NW>
-__device__ __forceinline__ bool lds_put(unsigned long long* tab, const Key63<NW>& key, uint64_t hash, int left, int right, uint64_t ord,
+__device__ __forceinline__ bool lds_put(LdsSet<NW>& t, const Key63<NW>& key, uint64_t hash, int left, int right, uint64_t ord,
                                         unsigned int* n_keys, unsigned int limit) {
-    constexpr int KW = E2Cfg<NW>::KW, SW = E2Cfg<NW>::SW, SLOTS = E2Cfg<NW>::SLOTS;
+    constexpr int KW = E2Cfg<NW>::KW, SLOTS = E2Cfg<NW>::SLOTS;
     uint32_t h = (uint32_t)hash & (SLOTS - 1);
     for (int probes = 0; probes < SLOTS; probes++) {
-        unsigned long long* s = tab + (size_t)h * SW;
         bool mine = true, inserted = false;
 #pragma unroll
         for (int i = 0; i < KW; i++) {
             if (!mine) break;
-            unsigned long long cur = s[i];
+            unsigned long long cur = t.key[i][h];
             if (cur == L_EMPTY) {
-                const unsigned long long old = atomicCAS(&s[i], L_EMPTY, (unsigned long long)key.w[i]);
+                const unsigned long long old = atomicCAS(&t.key[i][h], L_EMPTY, (unsigned long long)key.w[i]);
                 if (old == L_EMPTY) { cur = key.w[i]; if (i == KW - 1) inserted = true; }
                 else cur = old;
             }
@@ -218,13 +233,10 @@ __device__ __forceinline__ bool lds_put(unsigned long long* tab, const Key63<NW>
         if (mine) {
             // the lane that completed the claim (won the last key word) accounts for the new key
             if (inserted && atomicAdd(n_keys, 1u) + 1 > limit) return false;
-            // plain counters, saturated when the node is emitted: a sum of +1's clipped at the end equals the
-            // reference's saturating increments (newhash.c:74-106), and adds need no retry under contention
-            unsigned int* c = (unsigned int*)(s + KW + 1);
-            if (left < 4) atomicAdd(&c[left], 1u);
-            if (right < 4) atomicAdd(&c[4 + right], 1u);
-            atomicAdd(&c[8], 1u);
-            atomicMin(&s[KW], (unsigned long long)ord);
+            if (left < 4) atomicAdd(&t.cnt[left][h], 1u);
+            if (right < 4) atomicAdd(&t.cnt[4 + right][h], 1u);
+            atomicAdd(&t.cnt[8][h], 1u);
+            atomicMin(&t.ord[h], (unsigned long long)ord);
             return true;
         }
         h = (h + 1) & (SLOTS - 1);
@@ -239,20 +251,19 @@ __device__ __forceinline__ const uint64_t* record_ptr(const E2Dev& e, uint32_t p
 }
 
 template <int NW>
-__global__ __launch_bounds__(BLOCK) void skm_count_kernel(E2Dev e, int D, SetParams sp, DevCounters* ctr, int dbg) {
-    constexpr int PW = E2Cfg<NW>::PW, RW = PW + 1, KW = E2Cfg<NW>::KW, SW = E2Cfg<NW>::SW, SLOTS = E2Cfg<NW>::SLOTS;
+__global__ __launch_bounds__(K2_THREADS) void skm_count_kernel(E2Dev e, int D, SetParams sp, DevCounters* ctr, int dbg) {
+    constexpr int PW = E2Cfg<NW>::PW, RW = PW + 1, KW = E2Cfg<NW>::KW, SLOTS = E2Cfg<NW>::SLOTS, NWAVE = K2_THREADS / 64;
     constexpr unsigned LIMIT = SLOTS * 7 / 10;
-    __shared__ unsigned long long tab[SLOTS * SW];
+    __shared__ LdsSet<NW> set;
     __shared__ uint32_t crc_tab[256];
     __shared__ unsigned int hist[256];
-    __shared__ unsigned int n_keys, aborted, sp_top, s_mask[40], s_val[40], cur_mask, cur_val, wave_cnt[BLOCK / 64], wave_off[BLOCK / 64];
+    __shared__ unsigned int n_keys, aborted, sp_top, s_mask[40], s_val[40], cur_mask, cur_val, wave_cnt[NWAVE];
     __shared__ unsigned long long out_base;
-    crc_tab[threadIdx.x] = crc32_table_entry(threadIdx.x);
-    hist[threadIdx.x] = 0;
+    if (threadIdx.x < 256) { crc_tab[threadIdx.x] = crc32_table_entry(threadIdx.x); hist[threadIdx.x] = 0; }
     const Kmer<NW> filter = kmer_filter<NW>(e.g.K);
     const int K = e.g.K;
     const uint32_t parts = 1u << e.g.log2_parts;
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long my_records = 0;
     for (uint32_t pid = blockIdx.x; pid < parts; pid += gridDim.x) {
         const uint32_t nrec = e.cursor[pid];
@@ -265,27 +276,27 @@ __global__ __launch_bounds__(BLOCK) void skm_count_kernel(E2Dev e, int D, SetPar
         while (sp_top > 0) {
             __syncthreads();
             if (threadIdx.x == 0) { sp_top--; cur_mask = s_mask[sp_top]; cur_val = s_val[sp_top]; n_keys = 0; aborted = 0; }
-            for (int i = threadIdx.x; i < SLOTS * SW; i += BLOCK) tab[i] = (i % SW) <= KW ? L_EMPTY : 0ULL;   // keys + ord = ~0, counters = 0
+            for (int i = threadIdx.x; i < SLOTS; i += K2_THREADS) {
+#pragma unroll
+                for (int q = 0; q < KW; q++) set.key[q][i] = L_EMPTY;
+                set.ord[i] = L_EMPTY;
+#pragma unroll
+                for (int q = 0; q < 9; q++) set.cnt[q][i] = 0;
+            }
             __syncthreads();
             const uint32_t mask = cur_mask, val = cur_val;
             volatile unsigned int* abort_flag = &aborted;
-            for (uint32_t i = threadIdx.x; i < usable && !*abort_flag; i += BLOCK) {
+            for (uint32_t i = threadIdx.x; i < usable && !*abort_flag; i += K2_THREADS) {
                 const uint64_t* rec = record_ptr(e, pid, i, RW);
                 if (!rec) continue;
-                const uint64_t h = rec[0];
-                const int n = skm_n(h), hl = skm_has_left(h), nb = skm_record_bases(h, K);
-                const uint64_t ord0 = skm_ord(h);
-                for (int t = 0; t < n; t++) {
-                    Occurrence occ;
-                    const Kmer<NW> key = canonical_occurrence<NW>(rec + 1, hl + t, nb, K, filter, occ);
+                bool full = false;
+                skm_expand_record<NW>(rec, K, filter, [&](const Kmer<NW>& key, int left, int right, uint64_t ord) {
                     const uint64_t hh = kmer_mix<NW>(key);
-                    if (((uint32_t)(hh >> 32) & mask) != val) continue;
-                    if (dbg & 1) { if (hh == 0x1234) aborted = 1; continue; }       // measurement aid: extraction only
-                    if (!lds_put<NW>(tab, key63_from_kmer<NW>(key), hh, occ.left, occ.right, ord0 + (uint64_t)t, &n_keys, LIMIT)) {
-                        aborted = 1;
-                        break;
-                    }
-                }
+                    if (full || ((uint32_t)(hh >> 32) & mask) != val) return;
+                    if (dbg & 1) { if (hh == 0x1234) full = true; return; }            // measurement aid: expansion only
+                    if (!lds_put<NW>(set, key63_from_kmer<NW>(key), hh, left, right, ord, &n_keys, LIMIT)) full = true;
+                });
+                if (full) aborted = 1;
             }
             __syncthreads();
             if (aborted) {
@@ -301,41 +312,38 @@ __global__ __launch_bounds__(BLOCK) void skm_count_kernel(E2Dev e, int D, SetPar
                 __syncthreads();
                 continue;
             }
-            // ---- emit: finalize every stored node and append it to the export array.  One global atomic per attempt:
-            // the block's live slots are counted first (n_keys is exact: every first CAS on cnt bumped it).
+            // ---- emit: finalize every stored node and append it to the export array.  One global atomic per attempt
+            // (n_keys is exact: every completed claim bumped it once).
             if (threadIdx.x == 0) out_base = atomicAdd(&ctr->n_export, (unsigned long long)n_keys);
-            if (threadIdx.x < BLOCK / 64) wave_off[threadIdx.x] = 0;
             __syncthreads();
-            unsigned long long run = out_base;          // same in every lane; advanced stripe by stripe
-            for (int base = 0; base < SLOTS; base += BLOCK) {
+            unsigned long long run = out_base;
+            for (int base = 0; base < SLOTS; base += K2_THREADS) {
                 const int si = base + threadIdx.x;
-                const unsigned long long* s = tab + (size_t)si * SW;
-                const unsigned int* cn = (const unsigned int*)(s + KW + 1);
-                const bool live = cn[8] != 0;                // a put is only counted once every key word is claimed
+                const unsigned int puts = set.cnt[8][si];
+                const bool live = puts != 0;                // a put is only counted once every key word is claimed
                 const unsigned long long m = __ballot(live);
-                if (lane == 0) wave_cnt[threadIdx.x >> 6] = (unsigned int)__popcll(m);
+                if (lane == 0) wave_cnt[wave] = (unsigned int)__popcll(m);
                 __syncthreads();
                 unsigned int before = 0, total = 0;
 #pragma unroll
-                for (int wv = 0; wv < BLOCK / 64; wv++) {
+                for (int wv = 0; wv < NWAVE; wv++) {
                     const unsigned int cw = wave_cnt[wv];
-                    if (wv < (int)(threadIdx.x >> 6)) before += cw;
+                    if (wv < wave) before += cw;
                     total += cw;
                 }
                 if (live) {
                     Key63<NW> k63;
 #pragma unroll
-                    for (int w = 0; w < KW; w++) k63.w[w] = s[w];
+                    for (int w = 0; w < KW; w++) k63.w[w] = set.key[w][si];
                     const Kmer<NW> key = kmer_from_key63<NW>(k63);
-                    uint32_t A = min(cn[8], 255u) << 24, B = cn[8] == 1 ? B_SINGLE : 0u;
-#pragma unroll
-                    for (int c = 0; c < 4; c++) { A |= min(cn[c], 63u) << (6 * c); B |= min(cn[4 + c], 63u) << (6 * c); }
+                    uint32_t A = min(puts, 255u) << 24, B = puts == 1 ? B_SINGLE : 0u;
                     int nin = 0, nout = 0;
 #pragma unroll
-                    for (int c = 0; c < 4; c++) {                                   // thread_delow + thread_mark
-                        uint32_t l = (A >> (6 * c)) & 63u, r = (B >> (6 * c)) & 63u;
-                        if (D > 0 && l > 0 && l <= (uint32_t)D) { A &= ~(63u << (6 * c)); l = 0; }
-                        if (D > 0 && r > 0 && r <= (uint32_t)D) { B &= ~(63u << (6 * c)); r = 0; }
+                    for (int c = 0; c < 4; c++) {                                   // saturate, then thread_delow + thread_mark
+                        uint32_t l = min(set.cnt[c][si], 63u), r = min(set.cnt[4 + c][si], 63u);
+                        if (D > 0 && l <= (uint32_t)D) l = 0;
+                        if (D > 0 && r <= (uint32_t)D) r = 0;
+                        A |= l << (6 * c); B |= r << (6 * c);
                         nin += l > 0; nout += r > 0;
                     }
                     if (D > 0 && nin == 0 && nout == 0) B |= B_DELETED;
@@ -343,22 +351,21 @@ __global__ __launch_bounds__(BLOCK) void skm_count_kernel(E2Dev e, int D, SetPar
                     atomicAdd(&hist[A >> 24], 1u);
                     const uint64_t pos = run + before + __popcll(m & ((1ULL << lane) - 1));
                     if (pos < e.out_capacity) {
-                        const uint32_t set = set_of_crc(kmer_crc32<NW>(key, crc_tab), sp.P, sp.bias);
+                        const uint32_t sid = set_of_crc(kmer_crc32<NW>(key, crc_tab), sp.P, sp.bias);
                         uint64_t* o = e.out + pos * (NW + 2);
 #pragma unroll
                         for (int w = 0; w < NW; w++) o[w] = key.w[w];
                         o[NW] = (uint64_t)A | ((uint64_t)B << 32);
-                        o[NW + 1] = ((uint64_t)set << PG_ORD_BITS) | (s[KW] & PG_ORD_MASK);
+                        o[NW + 1] = ((uint64_t)sid << PG_ORD_BITS) | (set.ord[si] & PG_ORD_MASK);
                     } else atomicOr(&ctr->e2_flags, F_OUT);
                 }
                 run += total;
                 __syncthreads();
             }
-            __syncthreads();
         }
     }
     __syncthreads();
-    if (hist[threadIdx.x]) atomicAdd(&ctr->hist[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+    if (threadIdx.x < 256 && hist[threadIdx.x]) atomicAdd(&ctr->hist[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
     if (threadIdx.x == 0 && my_records) atomicAdd(&ctr->n_records, my_records);
 }
 
@@ -379,14 +386,10 @@ __global__ __launch_bounds__(BLOCK) void skm_lastput_kernel(E2Dev e, SetParams s
         for (uint32_t i = threadIdx.x; i < usable; i += BLOCK) {
             const uint64_t* rec = record_ptr(e, pid, i, RW);
             if (!rec) continue;
-            const uint64_t h = rec[0];
-            const int n = skm_n(h), hl = skm_has_left(h), nb = skm_record_bases(h, K);
-            for (int t = 0; t < n; t++) {
-                Occurrence occ;
-                const Kmer<NW> key = canonical_occurrence<NW>(rec + 1, hl + t, nb, K, filter, occ);
-                const uint32_t set = set_of_crc(kmer_crc32<NW>(key, crc_tab), sp.P, sp.bias);
-                atomicMax(&set_last[set], (unsigned long long)(skm_ord(h) + (uint64_t)t + 1));
-            }
+            skm_expand_record<NW>(rec, K, filter, [&](const Kmer<NW>& key, int, int, uint64_t ord) {
+                const uint32_t sid = set_of_crc(kmer_crc32<NW>(key, crc_tab), sp.P, sp.bias);
+                atomicMax(&set_last[sid], (unsigned long long)(ord + 1));
+            });
         }
     }
     __syncthreads();
@@ -525,16 +528,18 @@ int e2_scatter(pg_ctx* c, const uint64_t* d_packed, const uint64_t* d_word_off, 
     if (const char* v = getenv("PG_K1")) tiled = tiled && atoi(v) != 0;
     if (tiled) {
         const int np = (int)uniform_len - c->e2.g.m + 1;
-        const size_t per_read = (size_t)(a.wpr + 1) * 8 + (size_t)np * 16 + (size_t)a.kpr * 8;
-        int R = (int)std::min<size_t>(16, (60 * 1024) / per_read);
+        const size_t per_read = (size_t)(a.wpr + 1) * 8 + (size_t)np * 8 + (size_t)a.kpr * 8;
+        int R = (int)std::min<size_t>(32, (56 * 1024) / per_read);
         if (R >= 4) {
             int lv = 0;
             while ((2 << lv) <= c->e2.g.w) lv++;
             const uint64_t grid = (n_reads + R - 1) / R;
             if (grid > 0x7FFFFFFFULL) { pg_set_error("batch too large for one launch"); return PG_EINVAL; }
             const size_t smem = per_read * R;
-            if (c->NW == 2) hipLaunchKernelGGL(skm_scatter_tiled_kernel<2>, dim3((unsigned)grid), dim3(BLOCK), smem, st, a, dev_view(c), c->ctr, R, np, lv);
-            else hipLaunchKernelGGL(skm_scatter_tiled_kernel<4>, dim3((unsigned)grid), dim3(BLOCK), smem, st, a, dev_view(c), c->ctr, R, np, lv);
+            auto inv = [](uint32_t d) { return (uint32_t)(((1ULL << 32) + d - 1) / d); };
+            TileArg ta{R, np, lv, inv((uint32_t)np), inv(a.kpr), inv(a.wpr)};
+            if (c->NW == 2) hipLaunchKernelGGL(skm_scatter_tiled_kernel<2>, dim3((unsigned)grid), dim3(BLOCK), smem, st, a, dev_view(c), c->ctr, ta);
+            else hipLaunchKernelGGL(skm_scatter_tiled_kernel<4>, dim3((unsigned)grid), dim3(BLOCK), smem, st, a, dev_view(c), c->ctr, ta);
             E2_TRY(hipGetLastError());
             c->e2.counted = false;
             return PG_OK;
@@ -562,8 +567,8 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     const unsigned grid = std::min<unsigned>(parts, (unsigned)n_cu * 2u * 4u);      // 2 resident blocks per CU (64 KB LDS each), x4 for balance
     int dbg = 0;
     if (const char* v = getenv("PG_DBG")) dbg = atoi(v);
-    if (c->NW == 2) hipLaunchKernelGGL(skm_count_kernel<2>, dim3(grid), dim3(BLOCK), 0, st, dev_view(c), delow, sp, c->ctr, dbg);
-    else hipLaunchKernelGGL(skm_count_kernel<4>, dim3(grid), dim3(BLOCK), 0, st, dev_view(c), delow, sp, c->ctr, dbg);
+    if (c->NW == 2) hipLaunchKernelGGL(skm_count_kernel<2>, dim3(grid), dim3(K2_THREADS), 0, st, dev_view(c), delow, sp, c->ctr, dbg);
+    else hipLaunchKernelGGL(skm_count_kernel<4>, dim3(grid), dim3(K2_THREADS), 0, st, dev_view(c), delow, sp, c->ctr, dbg);
     E2_TRY(hipGetLastError());
     if (want_last_put) {
         E2_TRY(hipMemsetAsync(c->ctr->set_last, 0, sizeof(unsigned long long) * 256, st));

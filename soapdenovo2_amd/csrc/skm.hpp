@@ -59,18 +59,30 @@ PG_HD uint64_t bits_at(const uint64_t* rd, int bit) {
     if (o) v |= rd[a + 1] >> (64 - o);
     return v;
 }
-PG_HD uint64_t mmer_value(const uint64_t* rd, int p, int m) {
-    const uint64_t fwd = bits_at(rd, 2 * p) >> (64 - 2 * m);
-    const uint64_t rc = rev2bit(fwd ^ 0xAAAAAAAAAAAAAAAAULL) >> (64 - 2 * m);
-    uint64_t x = fwd < rc ? fwd : rc;
-    x *= 0x9E3779B97F4A7C15ULL;            // order m-mers by a hash, not lexicographically (poly-A would win everywhere)
-    x ^= x >> 29;
-    x *= 0xBF58476D1CE4E5B9ULL;
-    x ^= x >> 32;
+// 32-bit arithmetic on purpose: the GPU has no 64-bit integer multiplier, and these run once per base.
+PG_HD uint32_t rev2bit32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    x = __builtin_bitreverse32(x);
+    return ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+#else
+    x = ((x & 0x33333333u) << 2) | ((x >> 2) & 0x33333333u);
+    x = ((x & 0x0F0F0F0Fu) << 4) | ((x >> 4) & 0x0F0F0F0Fu);
+    return __builtin_bswap32(x);
+#endif
+}
+PG_HD uint32_t mmer_value(const uint64_t* rd, int p, int m) {          // m <= 13: an m-mer is at most 26 bits
+    const uint32_t fwd = (uint32_t)(bits_at(rd, 2 * p) >> (64 - 2 * m));
+    const uint32_t rc = rev2bit32(fwd ^ 0xAAAAAAAAu) >> (32 - 2 * m);
+    uint32_t x = fwd < rc ? fwd : rc;
+    x ^= x >> 16;                          // order m-mers by a hash, not lexicographically (poly-A would win everywhere)
+    x *= 0x85EBCA6Bu;
+    x ^= x >> 13;
+    x *= 0xC2B2AE35u;
+    x ^= x >> 16;
     return x;
 }
-PG_HD uint32_t skm_partition(uint64_t minval, int log2_parts) {
-    return (uint32_t)((minval * 0xD6E8FEB86659FD93ULL) >> (64 - log2_parts));
+PG_HD uint32_t skm_partition(uint32_t minval, int log2_parts) {
+    return (uint32_t)(minval * 0x9E3779B1u) >> (32 - log2_parts);
 }
 
 // ---- cutting a read into runs ------------------------------------------------------------------------------
@@ -82,21 +94,21 @@ PG_HD uint32_t skm_partition(uint64_t minval, int log2_parts) {
 template <typename Emit>
 PG_HD void skm_split_read(const uint64_t* rd, int len, const SkmGeom& g, Emit&& emit) {
     const int nk = len - g.K + 1;
-    uint64_t minval = ~0ULL;
+    uint32_t minval = ~0u;
     int minpos = -1;
     for (int p = 0; p < g.w; p++) {
-        const uint64_t v = mmer_value(rd, p, g.m);
+        const uint32_t v = mmer_value(rd, p, g.m);
         if (v <= minval) { minval = v; minpos = p; }
     }
     uint32_t cur = skm_partition(minval, g.log2_parts);
     int j0 = 0;
     for (int j = 1; j < nk; j++) {
         const int pnew = j + g.w - 1;
-        const uint64_t v = mmer_value(rd, pnew, g.m);
+        const uint32_t v = mmer_value(rd, pnew, g.m);
         if (minpos < j) {                       // the minimum left the window
-            minval = ~0ULL;
+            minval = ~0u;
             for (int p = j; p <= pnew; p++) {
-                const uint64_t u = mmer_value(rd, p, g.m);
+                const uint32_t u = mmer_value(rd, p, g.m);
                 if (u <= minval) { minval = u; minpos = p; }
             }
         } else if (v <= minval) { minval = v; minpos = pnew; }
@@ -132,6 +144,46 @@ PG_HD void skm_make_record(const uint64_t* rd, int len, int j0, int n, uint64_t 
 }
 PG_HD int skm_record_bases(uint64_t header, int K) {
     return skm_n(header) + K - 1 + skm_has_left(header) + skm_has_right(header);
+}
+
+// ---- expanding a record back into k-mer occurrences ---------------------------------------------------------
+// One pass over the record's bases with a rolling forward and reverse-complement k-mer (nextKmer / prevKmer of
+// kmer.c:696-718), calling f(canonical key, left, right, ordinal) for each of its n k-mers with the flank rules of
+// chopKmer4read (prlHashReads.c:198-257).  Equivalent to canonical_occurrence(rec + 1, has_left + t, nb, ...) for
+// t = 0..n-1, at a few instructions per base instead of a window extraction per k-mer.
+template <int NW, typename F>
+PG_HD void skm_expand_record(const uint64_t* rec, int K, const Kmer<NW>& filter, F&& f) {
+    const uint64_t h = rec[0];
+    const int hl = skm_has_left(h), nb = skm_record_bases(h, K);
+    const uint64_t ord0 = skm_ord(h);
+    const int topw = NW - 1 - (2 * (K - 1)) / 64, tops = (2 * (K - 1)) % 64;     // where the first base of a k-mer sits
+    Kmer<NW> fwd, rc;
+#pragma unroll
+    for (int i = 0; i < NW; i++) { fwd.w[i] = 0; rc.w[i] = 0; }
+    uint64_t cur = 0;
+    int left_prev = 4;
+    auto emit = [&](int right, uint64_t ord) {
+        if (kmer_less<NW>(fwd, rc)) f(fwd, left_prev, right, ord);
+        else f(rc, right < 4 ? (right ^ 2) : 4, left_prev < 4 ? (left_prev ^ 2) : 4, ord);
+    };
+    const int first_end = K - 1 + hl;                       // position of the last base of the record's first k-mer
+    for (int p = 0; p < nb; p++) {
+        if ((p & 31) == 0) cur = rec[1 + (p >> 5)];
+        const int b = (int)(cur >> 62);
+        cur <<= 2;
+        if (p - 1 >= first_end) emit(b, ord0 + (uint64_t)(p - 1 - first_end));     // the k-mer that ended at p - 1
+        uint64_t topword = 0;
+#pragma unroll
+        for (int i = 0; i < NW; i++) if (i == topw) topword = fwd.w[i];
+        left_prev = p >= K ? (int)((topword >> tops) & 3) : 4;                        // base p - K
+        fwd = kmer_next<NW>(fwd, b, filter);
+#pragma unroll
+        for (int i = NW - 1; i > 0; i--) rc.w[i] = (rc.w[i] >> 2) | (rc.w[i - 1] << 62);
+        rc.w[0] >>= 2;
+#pragma unroll
+        for (int i = 0; i < NW; i++) if (i == topw) rc.w[i] |= (uint64_t)(b ^ 2) << tops;
+    }
+    if (!skm_has_right(h)) emit(4, ord0 + (uint64_t)(nb - 1 - first_end));     // with a right flank the last base ends no k-mer
 }
 
 // ---- 63-bit key words -------------------------------------------------------------------------------------

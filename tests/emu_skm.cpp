@@ -50,25 +50,30 @@ static int64_t run(const uint64_t* packed, int64_t n_reads, int len, int K, int 
             const uint64_t* rec = v.data() + i * g.rw;
             const uint64_t h = rec[0];
             const int n = skm_n(h), hl = skm_has_left(h), nb = skm_record_bases(h, K);
-            for (int t = 0; t < n; t++) {
+            int t = 0, bad = 0;
+            skm_expand_record<NW>(rec, K, filter, [&](const Kmer<NW>& key, int left, int right, uint64_t ord) {
+                // the rolling expansion must agree with the window extraction of extract.hpp position by position
                 Occurrence occ;
-                Kmer<NW> key = canonical_occurrence<NW>(rec + 1, hl + t, nb, K, filter, occ);
+                Kmer<NW> ref = canonical_occurrence<NW>(rec + 1, hl + t, nb, K, filter, occ);
+                if (!kmer_eq<NW>(ref, key) || occ.left != left || occ.right != right || ord != skm_ord(h) + (uint64_t)t) bad = 1;
+                t++;
                 // the 63-bit re-cut used by the LDS set must round-trip
                 Kmer<NW> back = kmer_from_key63<NW>(key63_from_kmer<NW>(key));
-                if (!kmer_eq<NW>(back, key)) return -3;
+                if (!kmer_eq<NW>(back, key)) bad = 3;
                 Key63<NW> k63 = key63_from_kmer<NW>(key);
-                for (int q = 0; q < KeyWords<NW>::value; q++) if (k63.w[q] >> 63) return -4;
+                for (int q = 0; q < KeyWords<NW>::value; q++) if (k63.w[q] >> 63) bad = 4;
                 std::array<uint64_t, NW> kk;
                 for (int q = 0; q < NW; q++) kk[q] = key.w[q];
-                const uint64_t ord = skm_ord(h) + (uint64_t)t;
                 auto it = all.find(kk);
-                if (it == all.end()) { all[kk] = Node{node_first(occ.left, occ.right), ord, (int)p}; distinct_here++; }
+                if (it == all.end()) { all[kk] = Node{node_first(left, right), ord, (int)p}; distinct_here++; }
                 else {
-                    if (it->second.part != (int)p) return -5;          // a canonical k-mer must live in ONE partition
-                    it->second.cnt = node_update(it->second.cnt, occ.left, occ.right);
+                    if (it->second.part != (int)p) bad = 5;          // a canonical k-mer must live in ONE partition
+                    it->second.cnt = node_update(it->second.cnt, left, right);
                     if (ord < it->second.ord) it->second.ord = ord;
                 }
-            }
+            });
+            if (t != n) return -7;
+            if (bad) return -10 - bad;
         }
         if (distinct_here > maxd) maxd = distinct_here;
     }
