@@ -201,7 +201,8 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_tiled_kernel(ReadsArg a, E2
 // Counting is plain atomic adds, saturated when the node is emitted: a sum of +1's clipped at the end equals the
 // reference's saturating increments (newhash.c:74-106) and, unlike a CAS on packed counters, needs no retry when many
 // lanes hit one hot k-mer.  `single` = exactly one put (newhash.c:127,511).
-constexpr int K2_THREADS = 512;
+constexpr int K2_THREADS = 1024;
+constexpr int K2_MAXREC = 4096;       // records of one partition that one pass can index (maxc * rpc is capped to this)
 
 template <int NW>
 struct LdsSet {
@@ -251,13 +252,14 @@ __device__ __forceinline__ const uint64_t* record_ptr(const E2Dev& e, uint32_t p
 }
 
 template <int NW>
-__global__ __launch_bounds__(K2_THREADS) void skm_count_kernel(E2Dev e, int D, SetParams sp, DevCounters* ctr, int dbg) {
+__global__ __launch_bounds__(K2_THREADS, 8) void skm_count_kernel(E2Dev e, int D, SetParams sp, DevCounters* ctr, int dbg) {
     constexpr int PW = E2Cfg<NW>::PW, RW = PW + 1, KW = E2Cfg<NW>::KW, SLOTS = E2Cfg<NW>::SLOTS, NWAVE = K2_THREADS / 64;
     constexpr unsigned LIMIT = SLOTS * 7 / 10;
     __shared__ LdsSet<NW> set;
     __shared__ uint32_t crc_tab[256];
     __shared__ unsigned int hist[256];
     __shared__ unsigned int n_keys, aborted, sp_top, s_mask[40], s_val[40], cur_mask, cur_val, wave_cnt[NWAVE];
+    __shared__ unsigned int noff[K2_MAXREC + 1];          // exclusive prefix sum of the records' k-mer counts
     __shared__ unsigned long long out_base;
     if (threadIdx.x < 256) { crc_tab[threadIdx.x] = crc32_table_entry(threadIdx.x); hist[threadIdx.x] = 0; }
     const Kmer<NW> filter = kmer_filter<NW>(e.g.K);
@@ -267,12 +269,48 @@ __global__ __launch_bounds__(K2_THREADS) void skm_count_kernel(E2Dev e, int D, S
     unsigned long long my_records = 0;
     for (uint32_t pid = blockIdx.x; pid < parts; pid += gridDim.x) {
         const uint32_t nrec = e.cursor[pid];
-        const uint32_t usable = min(nrec, e.maxc * e.rpc);             // an overfull partition was flagged by K1
+        const uint32_t usable = min(min(nrec, e.maxc * e.rpc), (uint32_t)K2_MAXREC);   // an overfull partition was flagged by K1
         my_records += usable;
         if (usable == 0) continue;
         __syncthreads();
+        // flatten the partition: occurrence idx -> (record, t) through a prefix sum of the records' k-mer counts, so every
+        // lane gets an equal, contiguous share of occurrences whatever the run lengths are
+        {
+            constexpr int PER = K2_MAXREC / K2_THREADS;                   // consecutive records per lane
+            unsigned int mine[PER], sum = 0;
+#pragma unroll
+            for (int q = 0; q < PER; q++) {
+                const uint32_t i = threadIdx.x * PER + q;
+                unsigned int n = 0;
+                if (i < usable) { const uint64_t* rec = record_ptr(e, pid, i, RW); if (rec) n = (unsigned int)skm_n(rec[0]); }
+                mine[q] = sum;
+                sum += n;
+            }
+            unsigned int incl = sum;                                      // wave inclusive scan of the lane sums
+#pragma unroll
+            for (int d = 1; d < 64; d <<= 1) { const unsigned int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+            if (lane == 63) wave_cnt[wave] = incl;
+            __syncthreads();
+            unsigned int base = 0;
+#pragma unroll
+            for (int wv = 0; wv < NWAVE; wv++) if (wv < wave) base += wave_cnt[wv];
+            const unsigned int excl = base + incl - sum;
+#pragma unroll
+            for (int q = 0; q < PER; q++) { const uint32_t i = threadIdx.x * PER + q; if (i < usable) noff[i] = excl + mine[q]; }
+            if (threadIdx.x == K2_THREADS - 1) noff[usable] = base + incl;   // records past `usable` contributed 0
+        }
         if (threadIdx.x == 0) { sp_top = 1; s_mask[0] = 0; s_val[0] = 0; }
         __syncthreads();
+        const uint32_t total_occ = noff[usable];
+        const uint32_t share = (total_occ + K2_THREADS - 1) / K2_THREADS;
+        const uint32_t idx0 = min(total_occ, threadIdx.x * share), idx1 = min(total_occ, idx0 + share);
+        // first record of this lane's share: largest r with noff[r] <= idx0
+        uint32_t rec0 = 0;
+        if (idx0 < idx1) {
+            uint32_t lo = 0, hi = usable - 1;
+            while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (noff[mid] <= idx0) lo = mid; else hi = mid - 1; }
+            rec0 = lo;
+        }
         while (sp_top > 0) {
             __syncthreads();
             if (threadIdx.x == 0) { sp_top--; cur_mask = s_mask[sp_top]; cur_val = s_val[sp_top]; n_keys = 0; aborted = 0; }
@@ -286,17 +324,33 @@ __global__ __launch_bounds__(K2_THREADS) void skm_count_kernel(E2Dev e, int D, S
             __syncthreads();
             const uint32_t mask = cur_mask, val = cur_val;
             volatile unsigned int* abort_flag = &aborted;
-            for (uint32_t i = threadIdx.x; i < usable && !*abort_flag; i += K2_THREADS) {
-                const uint64_t* rec = record_ptr(e, pid, i, RW);
-                if (!rec) continue;
-                bool full = false;
-                skm_expand_record<NW>(rec, K, filter, [&](const Kmer<NW>& key, int left, int right, uint64_t ord) {
+            {
+                uint32_t r = rec0, next_off = idx0 < idx1 ? noff[r + 1] : 0;
+                const uint64_t* rec = nullptr;
+                uint64_t hdr = 0;
+                int hl = 0, nb = 0;
+                uint32_t roff = 0;
+                bool fresh = true;
+                for (uint32_t idx = idx0; idx < idx1; idx++) {
+                    while (idx >= next_off) { r++; next_off = noff[r + 1]; fresh = true; }
+                    if (fresh) {
+                        rec = record_ptr(e, pid, r, RW);
+                        hdr = rec ? rec[0] : 0;
+                        hl = skm_has_left(hdr); nb = skm_record_bases(hdr, K); roff = noff[r];
+                        fresh = false;
+                        if (*abort_flag) break;
+                    }
+                    if (!rec) continue;
+                    Occurrence occ;
+                    const Kmer<NW> key = canonical_occurrence<NW>(rec + 1, hl + (int)(idx - roff), nb, K, filter, occ);
                     const uint64_t hh = kmer_mix<NW>(key);
-                    if (full || ((uint32_t)(hh >> 32) & mask) != val) return;
-                    if (dbg & 1) { if (hh == 0x1234) full = true; return; }            // measurement aid: expansion only
-                    if (!lds_put<NW>(set, key63_from_kmer<NW>(key), hh, left, right, ord, &n_keys, LIMIT)) full = true;
-                });
-                if (full) aborted = 1;
+                    if (((uint32_t)(hh >> 32) & mask) != val) continue;
+                    if (dbg & 1) { if (hh == 0x1234) aborted = 1; continue; }          // measurement aid: extraction only
+                    if (!lds_put<NW>(set, key63_from_kmer<NW>(key), hh, occ.left, occ.right, skm_ord(hdr) + (uint64_t)(idx - roff), &n_keys, LIMIT)) {
+                        aborted = 1;
+                        break;
+                    }
+                }
             }
             __syncthreads();
             if (aborted) {
@@ -438,7 +492,7 @@ int e2_create(pg_ctx* c) {
     if (s.pool_chunks < parts + 16) { pg_set_error("partition engine: record pool too small for the partition count"); return PG_ENOMEM; }
     // chunk table: up to 2^28 entries in total, at least enough for an even spread x8
     const uint64_t even = (s.pool_chunks + parts - 1) / parts;
-    s.maxc = (uint32_t)std::max<uint64_t>(16, std::min<uint64_t>(((uint64_t)1 << 28) / parts, even * 8));
+    s.maxc = (uint32_t)std::min<uint64_t>(K2_MAXREC / s.rpc, std::max<uint64_t>(16, std::min<uint64_t>(((uint64_t)1 << 28) / parts, even * 8)));
     E2_TRY(hipMalloc(&s.cursor, parts * sizeof(uint32_t)));
     E2_TRY(hipMalloc(&s.chunk_tbl, parts * s.maxc * sizeof(uint32_t)));
     E2_TRY(hipMalloc(&s.pool, s.pool_chunks * chunk_bytes + 64));
@@ -497,7 +551,7 @@ static int e2_ensure_pool(pg_ctx* c, uint64_t n_reads, uint64_t n_kmers, hipStre
     s.pool_chunks = fresh_chunks;
     // a longer chunk list per partition too, if the table allows (rebuild with the wider stride)
     const uint64_t even = (fresh_chunks + parts - 1) / parts;
-    const uint32_t want = (uint32_t)std::max<uint64_t>(s.maxc, std::min<uint64_t>(((uint64_t)1 << 28) / parts, even * 8));
+    const uint32_t want = (uint32_t)std::min<uint64_t>(K2_MAXREC / s.rpc, std::max<uint64_t>(s.maxc, std::min<uint64_t>(((uint64_t)1 << 28) / parts, even * 8)));
     if (want > s.maxc) {
         uint32_t* tbl = nullptr;
         E2_TRY(hipMalloc(&tbl, parts * want * sizeof(uint32_t)));
@@ -529,8 +583,9 @@ int e2_scatter(pg_ctx* c, const uint64_t* d_packed, const uint64_t* d_word_off, 
     if (tiled) {
         const int np = (int)uniform_len - c->e2.g.m + 1;
         const size_t per_read = (size_t)(a.wpr + 1) * 8 + (size_t)np * 8 + (size_t)a.kpr * 8;
-        int R = (int)std::min<size_t>(32, (56 * 1024) / per_read);
-        if (R >= 4) {
+        int R = (int)std::min<size_t>(8, (56 * 1024) / per_read);          // small tiles: many resident workgroups hide the LDS / atomic latency
+        if (const char* v = getenv("PG_K1_R")) R = std::max(1, std::min(atoi(v), (int)((56 * 1024) / per_read)));
+        if (R >= 1) {
             int lv = 0;
             while ((2 << lv) <= c->e2.g.w) lv++;
             const uint64_t grid = (n_reads + R - 1) / R;
