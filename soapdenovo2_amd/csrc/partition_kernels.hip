@@ -373,7 +373,7 @@ __global__ __launch_bounds__(K2_THREADS, 8) void skm_count_kernel(E2Dev e, int D
             unsigned long long run = out_base;
             for (int base = 0; base < SLOTS; base += K2_THREADS) {
                 const int si = base + threadIdx.x;
-                const unsigned int puts = set.cnt[8][si];
+                const unsigned int puts = si < SLOTS ? set.cnt[8][si] : 0u;
                 const bool live = puts != 0;                // a put is only counted once every key word is claimed
                 const unsigned long long m = __ballot(live);
                 if (lane == 0) wave_cnt[wave] = (unsigned int)__popcll(m);
