@@ -31,7 +31,7 @@ struct SetParams { uint32_t P, bias; };
 struct E2 {
     SkmGeom g;
     int log2_parts = 0;
-    uint32_t rpc = 32;            // records per chunk
+    uint32_t rpc = 128;           // records per chunk
     uint32_t maxc = 0;            // chunk-table entries per partition
     uint64_t pool_chunks = 0;
     uint32_t* cursor = nullptr;   // [parts] records appended

@@ -36,8 +36,8 @@ constexpr unsigned long long F_POOL = 1, F_CHUNKS = 2, F_OUT = 4, F_SPLIT = 8;
 
 template <int NW> struct E2Cfg;
 // LDS slot = KW key words | ord | 10 x u32 counters (L[4], R[4], puts, spare)
-template <> struct E2Cfg<2> { static constexpr int PW = 5, KW = 2, SLOTS = 1024; };    // 60 B per slot -> 60 KB
-template <> struct E2Cfg<4> { static constexpr int PW = 7, KW = 5, SLOTS = 512; };     // 84 B per slot -> 42 KB
+template <> struct E2Cfg<2> { static constexpr int PW = 5, KW = 2, SLOTS = 2048; };    // 60 B per slot -> 120 KB: one workgroup per CU
+template <> struct E2Cfg<4> { static constexpr int PW = 7, KW = 5, SLOTS = 1024; };    // 84 B per slot ->  84 KB
 
 struct E2Dev {
     SkmGeom g;
@@ -252,7 +252,7 @@ __device__ __forceinline__ const uint64_t* record_ptr(const E2Dev& e, uint32_t p
 }
 
 template <int NW>
-__global__ __launch_bounds__(K2_THREADS, 8) void skm_count_kernel(E2Dev e, int D, SetParams sp, DevCounters* ctr, int dbg) {
+__global__ __launch_bounds__(K2_THREADS) void skm_count_kernel(E2Dev e, int D, SetParams sp, DevCounters* ctr, int dbg) {
     constexpr int PW = E2Cfg<NW>::PW, RW = PW + 1, KW = E2Cfg<NW>::KW, SLOTS = E2Cfg<NW>::SLOTS, NWAVE = K2_THREADS / 64;
     constexpr unsigned LIMIT = SLOTS * 7 / 10;
     __shared__ LdsSet<NW> set;
@@ -269,48 +269,12 @@ __global__ __launch_bounds__(K2_THREADS, 8) void skm_count_kernel(E2Dev e, int D
     unsigned long long my_records = 0;
     for (uint32_t pid = blockIdx.x; pid < parts; pid += gridDim.x) {
         const uint32_t nrec = e.cursor[pid];
-        const uint32_t usable = min(min(nrec, e.maxc * e.rpc), (uint32_t)K2_MAXREC);   // an overfull partition was flagged by K1
+        const uint32_t usable = min(nrec, e.maxc * e.rpc);               // an overfull partition was flagged by K1
         my_records += usable;
         if (usable == 0) continue;
         __syncthreads();
-        // flatten the partition: occurrence idx -> (record, t) through a prefix sum of the records' k-mer counts, so every
-        // lane gets an equal, contiguous share of occurrences whatever the run lengths are
-        {
-            constexpr int PER = K2_MAXREC / K2_THREADS;                   // consecutive records per lane
-            unsigned int mine[PER], sum = 0;
-#pragma unroll
-            for (int q = 0; q < PER; q++) {
-                const uint32_t i = threadIdx.x * PER + q;
-                unsigned int n = 0;
-                if (i < usable) { const uint64_t* rec = record_ptr(e, pid, i, RW); if (rec) n = (unsigned int)skm_n(rec[0]); }
-                mine[q] = sum;
-                sum += n;
-            }
-            unsigned int incl = sum;                                      // wave inclusive scan of the lane sums
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const unsigned int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
-            if (lane == 63) wave_cnt[wave] = incl;
-            __syncthreads();
-            unsigned int base = 0;
-#pragma unroll
-            for (int wv = 0; wv < NWAVE; wv++) if (wv < wave) base += wave_cnt[wv];
-            const unsigned int excl = base + incl - sum;
-#pragma unroll
-            for (int q = 0; q < PER; q++) { const uint32_t i = threadIdx.x * PER + q; if (i < usable) noff[i] = excl + mine[q]; }
-            if (threadIdx.x == K2_THREADS - 1) noff[usable] = base + incl;   // records past `usable` contributed 0
-        }
         if (threadIdx.x == 0) { sp_top = 1; s_mask[0] = 0; s_val[0] = 0; }
         __syncthreads();
-        const uint32_t total_occ = noff[usable];
-        const uint32_t share = (total_occ + K2_THREADS - 1) / K2_THREADS;
-        const uint32_t idx0 = min(total_occ, threadIdx.x * share), idx1 = min(total_occ, idx0 + share);
-        // first record of this lane's share: largest r with noff[r] <= idx0
-        uint32_t rec0 = 0;
-        if (idx0 < idx1) {
-            uint32_t lo = 0, hi = usable - 1;
-            while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (noff[mid] <= idx0) lo = mid; else hi = mid - 1; }
-            rec0 = lo;
-        }
         while (sp_top > 0) {
             __syncthreads();
             if (threadIdx.x == 0) { sp_top--; cur_mask = s_mask[sp_top]; cur_val = s_val[sp_top]; n_keys = 0; aborted = 0; }
@@ -324,33 +288,71 @@ __global__ __launch_bounds__(K2_THREADS, 8) void skm_count_kernel(E2Dev e, int D
             __syncthreads();
             const uint32_t mask = cur_mask, val = cur_val;
             volatile unsigned int* abort_flag = &aborted;
-            {
-                uint32_t r = rec0, next_off = idx0 < idx1 ? noff[r + 1] : 0;
-                const uint64_t* rec = nullptr;
-                uint64_t hdr = 0;
-                int hl = 0, nb = 0;
-                uint32_t roff = 0;
-                bool fresh = true;
-                for (uint32_t idx = idx0; idx < idx1; idx++) {
-                    while (idx >= next_off) { r++; next_off = noff[r + 1]; fresh = true; }
-                    if (fresh) {
-                        rec = record_ptr(e, pid, r, RW);
-                        hdr = rec ? rec[0] : 0;
-                        hl = skm_has_left(hdr); nb = skm_record_bases(hdr, K); roff = noff[r];
-                        fresh = false;
-                        if (*abort_flag) break;
+            // the partition's records, K2_MAXREC at a time
+            for (uint32_t w0 = 0; w0 < usable; w0 += K2_MAXREC) {
+                const uint32_t wn = min((uint32_t)K2_MAXREC, usable - w0);
+                // flatten the window: occurrence idx -> (record, t) through a prefix sum of the records' k-mer counts, so
+                // every lane gets an equal, contiguous share of occurrences whatever the run lengths are
+                {
+                    constexpr int PER = K2_MAXREC / K2_THREADS;               // consecutive records per lane
+                    unsigned int mine[PER], sum = 0;
+#pragma unroll
+                    for (int q = 0; q < PER; q++) {
+                        const uint32_t i = threadIdx.x * PER + q;
+                        unsigned int n = 0;
+                        if (i < wn) { const uint64_t* rec = record_ptr(e, pid, w0 + i, RW); if (rec) n = (unsigned int)skm_n(rec[0]); }
+                        mine[q] = sum;
+                        sum += n;
                     }
-                    if (!rec) continue;
-                    Occurrence occ;
-                    const Kmer<NW> key = canonical_occurrence<NW>(rec + 1, hl + (int)(idx - roff), nb, K, filter, occ);
-                    const uint64_t hh = kmer_mix<NW>(key);
-                    if (((uint32_t)(hh >> 32) & mask) != val) continue;
-                    if (dbg & 1) { if (hh == 0x1234) aborted = 1; continue; }          // measurement aid: extraction only
-                    if (!lds_put<NW>(set, key63_from_kmer<NW>(key), hh, occ.left, occ.right, skm_ord(hdr) + (uint64_t)(idx - roff), &n_keys, LIMIT)) {
-                        aborted = 1;
-                        break;
+                    unsigned int incl = sum;                                  // wave inclusive scan of the lane sums
+#pragma unroll
+                    for (int d = 1; d < 64; d <<= 1) { const unsigned int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+                    if (lane == 63) wave_cnt[wave] = incl;
+                    __syncthreads();
+                    unsigned int base = 0;
+#pragma unroll
+                    for (int wv = 0; wv < NWAVE; wv++) if (wv < wave) base += wave_cnt[wv];
+                    const unsigned int excl = base + incl - sum;
+#pragma unroll
+                    for (int q = 0; q < PER; q++) { const uint32_t i = threadIdx.x * PER + q; if (i < wn) noff[i] = excl + mine[q]; }
+                    if (threadIdx.x == K2_THREADS - 1) noff[wn] = base + incl;   // records past wn contributed 0
+                }
+                __syncthreads();
+                if (!*abort_flag) {
+                    const uint32_t total_occ = noff[wn];
+                    const uint32_t share = (total_occ + K2_THREADS - 1) / K2_THREADS;
+                    const uint32_t idx0 = min(total_occ, threadIdx.x * share), idx1 = min(total_occ, idx0 + share);
+                    if (idx0 < idx1) {
+                        uint32_t lo = 0, hi = wn - 1;                         // first record of this lane's share
+                        while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (noff[mid] <= idx0) lo = mid; else hi = mid - 1; }
+                        uint32_t r = lo, next_off = noff[r + 1], roff = 0;
+                        const uint64_t* rec = nullptr;
+                        uint64_t hdr = 0;
+                        int hl = 0, nb = 0;
+                        bool fresh = true;
+                        for (uint32_t idx = idx0; idx < idx1; idx++) {
+                            while (idx >= next_off) { r++; next_off = noff[r + 1]; fresh = true; }
+                            if (fresh) {
+                                rec = record_ptr(e, pid, w0 + r, RW);
+                                hdr = rec ? rec[0] : 0;
+                                hl = skm_has_left(hdr); nb = skm_record_bases(hdr, K); roff = noff[r];
+                                fresh = false;
+                                if (*abort_flag) break;
+                            }
+                            if (!rec) continue;
+                            Occurrence occ;
+                            const Kmer<NW> key = canonical_occurrence<NW>(rec + 1, hl + (int)(idx - roff), nb, K, filter, occ);
+                            const uint64_t hh = kmer_mix<NW>(key);
+                            if (((uint32_t)(hh >> 32) & mask) != val) continue;
+                            if (dbg & 1) { if (hh == 0x1234) aborted = 1; continue; }      // measurement aid: extraction only
+                            if (!lds_put<NW>(set, key63_from_kmer<NW>(key), hh, occ.left, occ.right, skm_ord(hdr) + (uint64_t)(idx - roff), &n_keys, LIMIT)) {
+                                aborted = 1;
+                                break;
+                            }
+                        }
                     }
                 }
+                __syncthreads();                                              // noff is rewritten by the next window
             }
             __syncthreads();
             if (aborted) {
@@ -470,10 +472,10 @@ static E2Dev dev_view(const pg_ctx* c) {
 int e2_create(pg_ctx* c) {
     E2& s = c->e2;
     // partitions: expected distinct / ~1000 so a partition usually fits the LDS set in one attempt
-    s.log2_parts = std::max(8, std::min(22, c->log2_slots - 10));
+    s.log2_parts = std::max(8, std::min(21, c->log2_slots - 11));
     if (const char* v = getenv("PG_LOG2_PARTS")) s.log2_parts = std::max(4, std::min(24, atoi(v)));
     s.g = skm_geometry(c->K, s.log2_parts, c->NW);
-    s.rpc = 32;
+    s.rpc = 128;
     const uint64_t parts = (uint64_t)1 << s.log2_parts;
     const uint64_t rec_bytes = (uint64_t)s.g.rw * 8, chunk_bytes = rec_bytes * s.rpc;
     size_t free_b = 0, total_b = 0;
@@ -492,7 +494,7 @@ int e2_create(pg_ctx* c) {
     if (s.pool_chunks < parts + 16) { pg_set_error("partition engine: record pool too small for the partition count"); return PG_ENOMEM; }
     // chunk table: up to 2^28 entries in total, at least enough for an even spread x8
     const uint64_t even = (s.pool_chunks + parts - 1) / parts;
-    s.maxc = (uint32_t)std::min<uint64_t>(K2_MAXREC / s.rpc, std::max<uint64_t>(16, std::min<uint64_t>(((uint64_t)1 << 28) / parts, even * 8)));
+    s.maxc = (uint32_t)std::max<uint64_t>(8, std::min<uint64_t>(std::min<uint64_t>(256, ((uint64_t)1 << 28) / parts), even * 16));
     E2_TRY(hipMalloc(&s.cursor, parts * sizeof(uint32_t)));
     E2_TRY(hipMalloc(&s.chunk_tbl, parts * s.maxc * sizeof(uint32_t)));
     E2_TRY(hipMalloc(&s.pool, s.pool_chunks * chunk_bytes + 64));
@@ -551,7 +553,7 @@ static int e2_ensure_pool(pg_ctx* c, uint64_t n_reads, uint64_t n_kmers, hipStre
     s.pool_chunks = fresh_chunks;
     // a longer chunk list per partition too, if the table allows (rebuild with the wider stride)
     const uint64_t even = (fresh_chunks + parts - 1) / parts;
-    const uint32_t want = (uint32_t)std::min<uint64_t>(K2_MAXREC / s.rpc, std::max<uint64_t>(s.maxc, std::min<uint64_t>(((uint64_t)1 << 28) / parts, even * 8)));
+    const uint32_t want = (uint32_t)std::max<uint64_t>(s.maxc, std::min<uint64_t>(std::min<uint64_t>(256, ((uint64_t)1 << 28) / parts), even * 16));
     if (want > s.maxc) {
         uint32_t* tbl = nullptr;
         E2_TRY(hipMalloc(&tbl, parts * want * sizeof(uint32_t)));
@@ -619,7 +621,7 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     int n_cu = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) n_cu = prop.multiProcessorCount;
-    const unsigned grid = std::min<unsigned>(parts, (unsigned)n_cu * 2u * 4u);      // 2 resident blocks per CU (64 KB LDS each), x4 for balance
+    const unsigned grid = std::min<unsigned>(parts, (unsigned)n_cu * 8u);           // one resident workgroup per CU (LDS), x8 for balance
     int dbg = 0;
     if (const char* v = getenv("PG_DBG")) dbg = atoi(v);
     if (c->NW == 2) hipLaunchKernelGGL(skm_count_kernel<2>, dim3(grid), dim3(K2_THREADS), 0, st, dev_view(c), delow, sp, c->ctr, dbg);
