@@ -212,28 +212,27 @@ struct LdsSet {
     unsigned int cnt[9][SLOTS];
 };
 
-// Returns false when the set is full (caller aborts the attempt and splits the key range).
+// Returns false when the set is too full (a probe sequence longer than MAXPROBE): the caller aborts the attempt and
+// splits the key range.  No shared key counter on this path -- a same-address LDS atomic per new key serialises the
+// whole workgroup; the keys are counted once, at emit time.
+constexpr int K2_MAXPROBE = 48;
 template <int NW>
-__device__ __forceinline__ bool lds_put(LdsSet<NW>& t, const Key63<NW>& key, uint64_t hash, int left, int right, uint64_t ord,
-                                        unsigned int* n_keys, unsigned int limit) {
+__device__ __forceinline__ bool lds_put(LdsSet<NW>& t, const Key63<NW>& key, uint64_t hash, int left, int right, uint64_t ord) {
     constexpr int KW = E2Cfg<NW>::KW, SLOTS = E2Cfg<NW>::SLOTS;
     uint32_t h = (uint32_t)hash & (SLOTS - 1);
-    for (int probes = 0; probes < SLOTS; probes++) {
-        bool mine = true, inserted = false;
+    for (int probes = 0; probes < K2_MAXPROBE; probes++) {
+        bool mine = true;
 #pragma unroll
         for (int i = 0; i < KW; i++) {
             if (!mine) break;
             unsigned long long cur = t.key[i][h];
             if (cur == L_EMPTY) {
                 const unsigned long long old = atomicCAS(&t.key[i][h], L_EMPTY, (unsigned long long)key.w[i]);
-                if (old == L_EMPTY) { cur = key.w[i]; if (i == KW - 1) inserted = true; }
-                else cur = old;
+                cur = old == L_EMPTY ? (unsigned long long)key.w[i] : old;
             }
             mine = cur == key.w[i];
         }
         if (mine) {
-            // the lane that completed the claim (won the last key word) accounts for the new key
-            if (inserted && atomicAdd(n_keys, 1u) + 1 > limit) return false;
             if (left < 4) atomicAdd(&t.cnt[left][h], 1u);
             if (right < 4) atomicAdd(&t.cnt[4 + right][h], 1u);
             atomicAdd(&t.cnt[8][h], 1u);
@@ -254,11 +253,10 @@ __device__ __forceinline__ const uint64_t* record_ptr(const E2Dev& e, uint32_t p
 template <int NW>
 __global__ __launch_bounds__(K2_THREADS) void skm_count_kernel(E2Dev e, int D, SetParams sp, DevCounters* ctr, int dbg) {
     constexpr int PW = E2Cfg<NW>::PW, RW = PW + 1, KW = E2Cfg<NW>::KW, SLOTS = E2Cfg<NW>::SLOTS, NWAVE = K2_THREADS / 64;
-    constexpr unsigned LIMIT = SLOTS * 7 / 10;
     __shared__ LdsSet<NW> set;
     __shared__ uint32_t crc_tab[256];
     __shared__ unsigned int hist[256];
-    __shared__ unsigned int n_keys, aborted, sp_top, s_mask[40], s_val[40], cur_mask, cur_val, wave_cnt[NWAVE];
+    __shared__ unsigned int aborted, sp_top, s_mask[40], s_val[40], cur_mask, cur_val, wave_cnt[NWAVE];
     __shared__ unsigned int noff[K2_MAXREC + 1];          // exclusive prefix sum of the records' k-mer counts
     __shared__ unsigned long long out_base;
     if (threadIdx.x < 256) { crc_tab[threadIdx.x] = crc32_table_entry(threadIdx.x); hist[threadIdx.x] = 0; }
@@ -277,7 +275,7 @@ __global__ __launch_bounds__(K2_THREADS) void skm_count_kernel(E2Dev e, int D, S
         __syncthreads();
         while (sp_top > 0) {
             __syncthreads();
-            if (threadIdx.x == 0) { sp_top--; cur_mask = s_mask[sp_top]; cur_val = s_val[sp_top]; n_keys = 0; aborted = 0; }
+            if (threadIdx.x == 0) { sp_top--; cur_mask = s_mask[sp_top]; cur_val = s_val[sp_top]; aborted = 0; }
             for (int i = threadIdx.x; i < SLOTS; i += K2_THREADS) {
 #pragma unroll
                 for (int q = 0; q < KW; q++) set.key[q][i] = L_EMPTY;
@@ -345,7 +343,7 @@ __global__ __launch_bounds__(K2_THREADS) void skm_count_kernel(E2Dev e, int D, S
                             const uint64_t hh = kmer_mix<NW>(key);
                             if (((uint32_t)(hh >> 32) & mask) != val) continue;
                             if (dbg & 1) { if (hh == 0x1234) aborted = 1; continue; }      // measurement aid: extraction only
-                            if (!lds_put<NW>(set, key63_from_kmer<NW>(key), hh, occ.left, occ.right, skm_ord(hdr) + (uint64_t)(idx - roff), &n_keys, LIMIT)) {
+                            if (!lds_put<NW>(set, key63_from_kmer<NW>(key), hh, occ.left, occ.right, skm_ord(hdr) + (uint64_t)(idx - roff))) {
                                 aborted = 1;
                                 break;
                             }
@@ -368,10 +366,22 @@ __global__ __launch_bounds__(K2_THREADS) void skm_count_kernel(E2Dev e, int D, S
                 __syncthreads();
                 continue;
             }
-            // ---- emit: finalize every stored node and append it to the export array.  One global atomic per attempt
-            // (n_keys is exact: every completed claim bumped it once).
-            if (threadIdx.x == 0) out_base = atomicAdd(&ctr->n_export, (unsigned long long)n_keys);
-            __syncthreads();
+            // ---- emit: finalize every stored node and append it to the export array.  Count the live slots, then one
+            // global atomic per attempt.
+            {
+                unsigned int mine_live = 0;
+                for (int si = threadIdx.x; si < SLOTS; si += K2_THREADS) mine_live += set.cnt[8][si] != 0;
+#pragma unroll
+                for (int d = 32; d > 0; d >>= 1) mine_live += __shfl_down(mine_live, d, 64);
+                if (lane == 0) wave_cnt[wave] = mine_live;
+                __syncthreads();
+                if (threadIdx.x == 0) {
+                    unsigned int tot = 0;
+                    for (int wv = 0; wv < NWAVE; wv++) tot += wave_cnt[wv];
+                    out_base = atomicAdd(&ctr->n_export, (unsigned long long)tot);
+                }
+                __syncthreads();
+            }
             unsigned long long run = out_base;
             for (int base = 0; base < SLOTS; base += K2_THREADS) {
                 const int si = base + threadIdx.x;
