@@ -128,14 +128,17 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_tiled_kernel(ReadsArg a, E2
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int R = ta.R, np = ta.np, lv = ta.lv;
     const int wpr = (int)a.wpr, kpr = (int)a.kpr, ws = wpr + 1, len = (int)a.uniform_len;
+    const int nch = (kpr + 63) >> 6;                               // 64-k-mer chunks per read (one wave each)
     uint64_t* words = (uint64_t*)smem_raw;                       // R * ws
-    uint32_t* v0 = (uint32_t*)(words + (size_t)R * ws);           // R * np
+    unsigned long long* masks = (unsigned long long*)(words + (size_t)R * ws);   // R * nch: run-start bits
+    uint32_t* v0 = (uint32_t*)(masks + (size_t)R * nch);          // R * np
     uint32_t* v1 = v0 + (size_t)R * np;                           // R * np
     uint32_t* pids = v1 + (size_t)R * np;                         // R * kpr
     uint32_t* items = pids + (size_t)R * kpr;                     // R * kpr  (r << 24 | j << 12 | n)
     __shared__ unsigned int n_items;
     const uint64_t r0 = (uint64_t)blockIdx.x * R;
     const int nr = (int)min((uint64_t)R, a.n_reads - r0);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) n_items = 0;
     for (int i = threadIdx.x; i < nr * wpr; i += BLOCK) {
         const int r = (int)fastdiv(i, ta.inv_wpr), k = i - r * wpr;
@@ -162,20 +165,47 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_tiled_kernel(ReadsArg a, E2
         uint32_t* t = src; src = dst; dst = t;
     }
     const int span = 1 << lv;                                      // src[p] = min over [p, p + span)
-    for (int i = threadIdx.x; i < nr * kpr; i += BLOCK) {
-        const int r = (int)fastdiv(i, ta.inv_kpr), j = i - r * kpr;
-        const uint32_t mn = min(src[r * np + j], src[r * np + j + w - span]);
-        pids[i] = skm_partition(mn, e.g.log2_parts);
+    const int nmax = e.g.nmax;
+    // C: partition per k-mer and run-start bits, one wave per 64-k-mer chunk of a read (the ballot IS the bit mask)
+    for (int wi = wave; wi < nr * nch; wi += BLOCK / 64) {
+        const int r = wi / nch, c = wi - r * nch;
+        const int j = c * 64 + lane;
+        const bool valid = j < kpr;
+        const uint32_t* sv = src + r * np;
+        uint32_t pid = 0xFFFFFFFFu, prev = 0xFFFFFFFFu;
+        if (valid) {
+            pid = skm_partition(min(sv[j], sv[j + w - span]), e.g.log2_parts);
+            pids[r * kpr + j] = pid;
+            if (j > 0) prev = skm_partition(min(sv[j - 1], sv[j - 1 + w - span]), e.g.log2_parts);
+        }
+        const bool start = valid && (j == 0 || pid != prev || j % nmax == 0);
+        const unsigned long long mk = __ballot(start);
+        if (lane == 0) masks[wi] = mk;
     }
     __syncthreads();
-    const int nmax = e.g.nmax;
-    for (int i = threadIdx.x; i < nr * kpr; i += BLOCK) {
-        const int r = (int)fastdiv(i, ta.inv_kpr), j = i - r * kpr;
-        if (j == 0 || pids[i] != pids[i - 1] || j % nmax == 0) {
-            int n = 1;
-            while (j + n < kpr && pids[i + n] == pids[i + n - 1] && (j + n) % nmax != 0) n++;
-            items[atomicAdd(&n_items, 1u)] = ((uint32_t)r << 24) | ((uint32_t)j << 12) | (uint32_t)n;
+    // D: every run start finds the next start in the bit masks (no per-lane walk) and queues one item
+    for (int wi = wave; wi < nr * nch; wi += BLOCK / 64) {
+        const int r = wi / nch, c = wi - r * nch;
+        const int j = c * 64 + lane;
+        const unsigned long long mk = masks[wi];
+        const bool start = (mk >> lane) & 1ULL;
+        uint32_t item = 0;
+        if (start) {
+            int next = kpr;
+            const unsigned long long above = lane < 63 ? (mk >> (lane + 1)) : 0ULL;
+            if (above) next = j + __ffsll((long long)above);
+            else {
+                for (int cc = c + 1; cc < nch; cc++) {
+                    const unsigned long long mm = masks[r * nch + cc];
+                    if (mm) { next = cc * 64 + __ffsll((long long)mm) - 1; break; }
+                }
+            }
+            item = ((uint32_t)r << 24) | ((uint32_t)j << 12) | (uint32_t)(next - j);
         }
+        unsigned int base = 0;
+        if (lane == 0 && mk) base = atomicAdd(&n_items, (unsigned int)__popcll(mk));
+        base = __shfl(base, 0, 64);
+        if (start) items[base + __popcll(mk & ((1ULL << lane) - 1))] = item;
     }
     __syncthreads();
     const int total = (int)n_items;
@@ -390,7 +420,7 @@ __global__ __launch_bounds__(K2_THREADS) void skm_count_kernel(E2Dev e, int D, S
                 const unsigned long long m = __ballot(live);
                 if (lane == 0) wave_cnt[wave] = (unsigned int)__popcll(m);
                 __syncthreads();
-                unsigned int before = 0, total = 0;
+                unsigned int before = 0, total = 0, cov_bin = 0;          // cov_bin 0 = not live (a live node has cov >= 1)
 #pragma unroll
                 for (int wv = 0; wv < NWAVE; wv++) {
                     const unsigned int cw = wave_cnt[wv];
@@ -414,7 +444,7 @@ __global__ __launch_bounds__(K2_THREADS) void skm_count_kernel(E2Dev e, int D, S
                     }
                     if (D > 0 && nin == 0 && nout == 0) B |= B_DELETED;
                     if (nin == 1 && nout == 1) B |= B_LINEAR;
-                    atomicAdd(&hist[A >> 24], 1u);
+                    cov_bin = A >> 24;
                     const uint64_t pos = run + before + __popcll(m & ((1ULL << lane) - 1));
                     if (pos < e.out_capacity) {
                         const uint32_t sid = set_of_crc(kmer_crc32<NW>(key, crc_tab), sp.P, sp.bias);
@@ -424,6 +454,13 @@ __global__ __launch_bounds__(K2_THREADS) void skm_count_kernel(E2Dev e, int D, S
                         o[NW] = (uint64_t)A | ((uint64_t)B << 32);
                         o[NW + 1] = ((uint64_t)sid << PG_ORD_BITS) | (set.ord[si] & PG_ORD_MASK);
                     } else atomicOr(&ctr->e2_flags, F_OUT);
+                }
+                // coverage histogram: most nodes of a partition share one or two coverage values (1 for error k-mers),
+                // so count those per wave instead of hammering one LDS word
+                {
+                    const unsigned long long ones = __ballot(cov_bin == 1);
+                    if (lane == 0 && ones) atomicAdd(&hist[1], (unsigned int)__popcll(ones));
+                    if (cov_bin > 1) atomicAdd(&hist[cov_bin], 1u);
                 }
                 run += total;
                 __syncthreads();
@@ -594,7 +631,7 @@ int e2_scatter(pg_ctx* c, const uint64_t* d_packed, const uint64_t* d_word_off, 
     if (const char* v = getenv("PG_K1")) tiled = tiled && atoi(v) != 0;
     if (tiled) {
         const int np = (int)uniform_len - c->e2.g.m + 1;
-        const size_t per_read = (size_t)(a.wpr + 1) * 8 + (size_t)np * 8 + (size_t)a.kpr * 8;
+        const size_t per_read = (size_t)(a.wpr + 1) * 8 + (size_t)((a.kpr + 63) / 64) * 8 + (size_t)np * 8 + (size_t)a.kpr * 8;
         int R = (int)std::min<size_t>(8, (56 * 1024) / per_read);          // small tiles: many resident workgroups hide the LDS / atomic latency
         if (const char* v = getenv("PG_K1_R")) R = std::max(1, std::min(atoi(v), (int)((56 * 1024) / per_read)));
         if (R >= 1) {
