@@ -36,8 +36,8 @@ constexpr unsigned long long F_POOL = 1, F_CHUNKS = 2, F_OUT = 4, F_SPLIT = 8;
 
 template <int NW> struct E2Cfg;
 // LDS slot = KW key words | ord | 10 x u32 counters (L[4], R[4], puts, spare)
-template <> struct E2Cfg<2> { static constexpr int PW = 5, KW = 2, SLOTS = 2048; };    // 60 B per slot -> 120 KB: one workgroup per CU
-template <> struct E2Cfg<4> { static constexpr int PW = 7, KW = 5, SLOTS = 1024; };    // 84 B per slot ->  84 KB
+template <> struct E2Cfg<2> { static constexpr int PW = 5, KW = 2; };    // LDS slot: 2 key words + ord + 9 counters = 60 B
+template <> struct E2Cfg<4> { static constexpr int PW = 7, KW = 5; };    // 5 key words + ord + 9 counters = 84 B
 
 struct E2Dev {
     SkmGeom g;
@@ -231,12 +231,9 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_tiled_kernel(ReadsArg a, E2
 // Counting is plain atomic adds, saturated when the node is emitted: a sum of +1's clipped at the end equals the
 // reference's saturating increments (newhash.c:74-106) and, unlike a CAS on packed counters, needs no retry when many
 // lanes hit one hot k-mer.  `single` = exactly one put (newhash.c:127,511).
-constexpr int K2_THREADS = 1024;
-constexpr int K2_MAXREC = 4096;       // records of one partition that one pass can index (maxc * rpc is capped to this)
-
-template <int NW>
+template <int NW, int SLOTS>
 struct LdsSet {
-    static constexpr int KW = E2Cfg<NW>::KW, SLOTS = E2Cfg<NW>::SLOTS;
+    static constexpr int KW = E2Cfg<NW>::KW;
     unsigned long long key[KW][SLOTS];
     unsigned long long ord[SLOTS];
     unsigned int cnt[9][SLOTS];
@@ -246,9 +243,9 @@ struct LdsSet {
 // splits the key range.  No shared key counter on this path -- a same-address LDS atomic per new key serialises the
 // whole workgroup; the keys are counted once, at emit time.
 constexpr int K2_MAXPROBE = 48;
-template <int NW>
-__device__ __forceinline__ bool lds_put(LdsSet<NW>& t, const Key63<NW>& key, uint64_t hash, int left, int right, uint64_t ord) {
-    constexpr int KW = E2Cfg<NW>::KW, SLOTS = E2Cfg<NW>::SLOTS;
+template <int NW, int SLOTS>
+__device__ __forceinline__ bool lds_put(LdsSet<NW, SLOTS>& t, const Key63<NW>& key, uint64_t hash, int left, int right, uint64_t ord) {
+    constexpr int KW = E2Cfg<NW>::KW;
     uint32_t h = (uint32_t)hash & (SLOTS - 1);
     for (int probes = 0; probes < K2_MAXPROBE; probes++) {
         bool mine = true;
@@ -280,16 +277,23 @@ __device__ __forceinline__ const uint64_t* record_ptr(const E2Dev& e, uint32_t p
     return e.pool + ((uint64_t)(c - 1) * e.rpc + i % e.rpc) * (uint64_t)rw;
 }
 
-template <int NW>
-__global__ __launch_bounds__(K2_THREADS) void skm_count_kernel(E2Dev e, int D, SetParams sp, DevCounters* ctr, int dbg) {
-    constexpr int PW = E2Cfg<NW>::PW, RW = PW + 1, KW = E2Cfg<NW>::KW, SLOTS = E2Cfg<NW>::SLOTS, NWAVE = K2_THREADS / 64;
-    __shared__ LdsSet<NW> set;
+// K2.  One workgroup per partition (persistent grid).  The partition's records are taken WIN at a time: staged into
+// LDS with coalesced 16-byte copies (so the per-occurrence work never waits on global memory), flattened through a
+// prefix sum of their k-mer counts so every lane gets an equal contiguous share of occurrences, expanded and inserted
+// into the LDS set.  If the set overflows, the attempt is dropped and the key range is split on a hash bit.
+template <int NW, int SLOTS, int THREADS, int WIN>
+__global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetParams sp, DevCounters* ctr, int dbg) {
+    constexpr int PW = E2Cfg<NW>::PW, RW = PW + 1, KW = E2Cfg<NW>::KW, NWAVE = THREADS / 64, PIECES = RW / 2;
+    static_assert(WIN <= THREADS, "one record per lane in the flatten step");
+    __shared__ LdsSet<NW, SLOTS> set;
+    __shared__ __align__(16) uint64_t recs[WIN * RW + 8];                 // + readable padding for the window loads
+    __shared__ unsigned int noff[WIN + 1];                                // exclusive prefix sum of the records' k-mer counts
     __shared__ uint32_t crc_tab[256];
     __shared__ unsigned int hist[256];
     __shared__ unsigned int aborted, sp_top, s_mask[40], s_val[40], cur_mask, cur_val, wave_cnt[NWAVE];
-    __shared__ unsigned int noff[K2_MAXREC + 1];          // exclusive prefix sum of the records' k-mer counts
     __shared__ unsigned long long out_base;
-    if (threadIdx.x < 256) { crc_tab[threadIdx.x] = crc32_table_entry(threadIdx.x); hist[threadIdx.x] = 0; }
+    for (int i = threadIdx.x; i < 256; i += THREADS) { crc_tab[i] = crc32_table_entry(i); hist[i] = 0; }
+    if (threadIdx.x < 8) recs[WIN * RW + threadIdx.x] = 0;
     const Kmer<NW> filter = kmer_filter<NW>(e.g.K);
     const int K = e.g.K;
     const uint32_t parts = 1u << e.g.log2_parts;
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(K2_THREADS) void skm_count_kernel(E2Dev e, int D, S
         while (sp_top > 0) {
             __syncthreads();
             if (threadIdx.x == 0) { sp_top--; cur_mask = s_mask[sp_top]; cur_val = s_val[sp_top]; aborted = 0; }
-            for (int i = threadIdx.x; i < SLOTS; i += K2_THREADS) {
+            for (int i = threadIdx.x; i < SLOTS; i += THREADS) {
 #pragma unroll
                 for (int q = 0; q < KW; q++) set.key[q][i] = L_EMPTY;
                 set.ord[i] = L_EMPTY;
@@ -316,23 +320,21 @@ __global__ __launch_bounds__(K2_THREADS) void skm_count_kernel(E2Dev e, int D, S
             __syncthreads();
             const uint32_t mask = cur_mask, val = cur_val;
             volatile unsigned int* abort_flag = &aborted;
-            // the partition's records, K2_MAXREC at a time
-            for (uint32_t w0 = 0; w0 < usable; w0 += K2_MAXREC) {
-                const uint32_t wn = min((uint32_t)K2_MAXREC, usable - w0);
-                // flatten the window: occurrence idx -> (record, t) through a prefix sum of the records' k-mer counts, so
-                // every lane gets an equal, contiguous share of occurrences whatever the run lengths are
+            for (uint32_t w0 = 0; w0 < usable; w0 += WIN) {
+                const uint32_t wn = min((uint32_t)WIN, usable - w0);
+                // stage the window's records: 16 bytes per lane and step, consecutive lanes -> consecutive pieces
+                for (uint32_t pc = threadIdx.x; pc < wn * PIECES; pc += THREADS) {
+                    const uint32_t ri = pc / PIECES, part = pc - ri * PIECES;
+                    const uint64_t* src = record_ptr(e, pid, w0 + ri, RW);
+                    ulonglong2 v = make_ulonglong2(0, 0);
+                    if (src) v = ((const ulonglong2*)src)[part];
+                    ((ulonglong2*)recs)[pc] = v;
+                }
+                __syncthreads();
+                // flatten: occurrence idx -> (record, t)
                 {
-                    constexpr int PER = K2_MAXREC / K2_THREADS;               // consecutive records per lane
-                    unsigned int mine[PER], sum = 0;
-#pragma unroll
-                    for (int q = 0; q < PER; q++) {
-                        const uint32_t i = threadIdx.x * PER + q;
-                        unsigned int n = 0;
-                        if (i < wn) { const uint64_t* rec = record_ptr(e, pid, w0 + i, RW); if (rec) n = (unsigned int)skm_n(rec[0]); }
-                        mine[q] = sum;
-                        sum += n;
-                    }
-                    unsigned int incl = sum;                                  // wave inclusive scan of the lane sums
+                    const unsigned int n = threadIdx.x < wn ? (unsigned int)skm_n(recs[threadIdx.x * RW]) : 0u;
+                    unsigned int incl = n;
 #pragma unroll
                     for (int d = 1; d < 64; d <<= 1) { const unsigned int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
                     if (lane == 63) wave_cnt[wave] = incl;
@@ -340,49 +342,45 @@ __global__ __launch_bounds__(K2_THREADS) void skm_count_kernel(E2Dev e, int D, S
                     unsigned int base = 0;
 #pragma unroll
                     for (int wv = 0; wv < NWAVE; wv++) if (wv < wave) base += wave_cnt[wv];
-                    const unsigned int excl = base + incl - sum;
-#pragma unroll
-                    for (int q = 0; q < PER; q++) { const uint32_t i = threadIdx.x * PER + q; if (i < wn) noff[i] = excl + mine[q]; }
-                    if (threadIdx.x == K2_THREADS - 1) noff[wn] = base + incl;   // records past wn contributed 0
+                    if (threadIdx.x < wn) noff[threadIdx.x] = base + incl - n;
+                    if (threadIdx.x == THREADS - 1) noff[wn] = base + incl;       // lanes past wn contributed 0
                 }
                 __syncthreads();
                 if (!*abort_flag) {
                     const uint32_t total_occ = noff[wn];
-                    const uint32_t share = (total_occ + K2_THREADS - 1) / K2_THREADS;
+                    const uint32_t share = (total_occ + THREADS - 1) / THREADS;
                     const uint32_t idx0 = min(total_occ, threadIdx.x * share), idx1 = min(total_occ, idx0 + share);
                     if (idx0 < idx1) {
-                        uint32_t lo = 0, hi = wn - 1;                         // first record of this lane's share
+                        uint32_t lo = 0, hi = wn - 1;                             // first record of this lane's share
                         while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (noff[mid] <= idx0) lo = mid; else hi = mid - 1; }
                         uint32_t r = lo, next_off = noff[r + 1], roff = 0;
-                        const uint64_t* rec = nullptr;
+                        const uint64_t* rec = recs;
                         uint64_t hdr = 0;
                         int hl = 0, nb = 0;
                         bool fresh = true;
                         for (uint32_t idx = idx0; idx < idx1; idx++) {
                             while (idx >= next_off) { r++; next_off = noff[r + 1]; fresh = true; }
                             if (fresh) {
-                                rec = record_ptr(e, pid, w0 + r, RW);
-                                hdr = rec ? rec[0] : 0;
+                                rec = recs + r * RW;
+                                hdr = rec[0];
                                 hl = skm_has_left(hdr); nb = skm_record_bases(hdr, K); roff = noff[r];
                                 fresh = false;
                                 if (*abort_flag) break;
                             }
-                            if (!rec) continue;
                             Occurrence occ;
                             const Kmer<NW> key = canonical_occurrence<NW>(rec + 1, hl + (int)(idx - roff), nb, K, filter, occ);
                             const uint64_t hh = kmer_mix<NW>(key);
                             if (((uint32_t)(hh >> 32) & mask) != val) continue;
                             if (dbg & 1) { if (hh == 0x1234) aborted = 1; continue; }      // measurement aid: extraction only
-                            if (!lds_put<NW>(set, key63_from_kmer<NW>(key), hh, occ.left, occ.right, skm_ord(hdr) + (uint64_t)(idx - roff))) {
+                            if (!lds_put<NW, SLOTS>(set, key63_from_kmer<NW>(key), hh, occ.left, occ.right, skm_ord(hdr) + (uint64_t)(idx - roff))) {
                                 aborted = 1;
                                 break;
                             }
                         }
                     }
                 }
-                __syncthreads();                                              // noff is rewritten by the next window
+                __syncthreads();                                                  // recs / noff are rewritten by the next window
             }
-            __syncthreads();
             if (aborted) {
                 // too many distinct keys for the LDS set: split this key range on the next hash bit and redo both halves
                 if (threadIdx.x == 0) {
@@ -400,7 +398,7 @@ __global__ __launch_bounds__(K2_THREADS) void skm_count_kernel(E2Dev e, int D, S
             // global atomic per attempt.
             {
                 unsigned int mine_live = 0;
-                for (int si = threadIdx.x; si < SLOTS; si += K2_THREADS) mine_live += set.cnt[8][si] != 0;
+                for (int si = threadIdx.x; si < SLOTS; si += THREADS) mine_live += set.cnt[8][si] != 0;
 #pragma unroll
                 for (int d = 32; d > 0; d >>= 1) mine_live += __shfl_down(mine_live, d, 64);
                 if (lane == 0) wave_cnt[wave] = mine_live;
@@ -413,7 +411,7 @@ __global__ __launch_bounds__(K2_THREADS) void skm_count_kernel(E2Dev e, int D, S
                 __syncthreads();
             }
             unsigned long long run = out_base;
-            for (int base = 0; base < SLOTS; base += K2_THREADS) {
+            for (int base = 0; base < SLOTS; base += THREADS) {
                 const int si = base + threadIdx.x;
                 const unsigned int puts = si < SLOTS ? set.cnt[8][si] : 0u;
                 const bool live = puts != 0;                // a put is only counted once every key word is claimed
@@ -468,7 +466,7 @@ __global__ __launch_bounds__(K2_THREADS) void skm_count_kernel(E2Dev e, int D, S
         }
     }
     __syncthreads();
-    if (threadIdx.x < 256 && hist[threadIdx.x]) atomicAdd(&ctr->hist[threadIdx.x], (unsigned long long)hist[threadIdx.x]);
+    for (int i = threadIdx.x; i < 256; i += THREADS) if (hist[i]) atomicAdd(&ctr->hist[i], (unsigned long long)hist[i]);
     if (threadIdx.x == 0 && my_records) atomicAdd(&ctr->n_records, my_records);
 }
 
@@ -668,11 +666,19 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     int n_cu = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) n_cu = prop.multiProcessorCount;
-    const unsigned grid = std::min<unsigned>(parts, (unsigned)n_cu * 8u);           // one resident workgroup per CU (LDS), x8 for balance
-    int dbg = 0;
+    const unsigned grid = std::min<unsigned>(parts, (unsigned)n_cu * 8u);           // persistent workgroups, x8 per CU for balance
+    int dbg = 0, cfg = 0;
     if (const char* v = getenv("PG_DBG")) dbg = atoi(v);
-    if (c->NW == 2) hipLaunchKernelGGL(skm_count_kernel<2>, dim3(grid), dim3(K2_THREADS), 0, st, dev_view(c), delow, sp, c->ctr, dbg);
-    else hipLaunchKernelGGL(skm_count_kernel<4>, dim3(grid), dim3(K2_THREADS), 0, st, dev_view(c), delow, sp, c->ctr, dbg);
+    if (const char* v = getenv("PG_K2CFG")) cfg = atoi(v);
+    // cfg 0: 2048-slot set, 1024 lanes, 512-record windows  -> ~150 KB LDS, one workgroup per CU
+    // cfg 1: 1024-slot set,  512 lanes, 256-record windows  ->  ~77 KB LDS, two workgroups per CU
+    if (c->NW == 2) {
+        if (cfg == 0) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, c->ctr, dbg);
+        else hipLaunchKernelGGL((skm_count_kernel<2, 1024, 512, 256>), dim3(grid), dim3(512), 0, st, dev_view(c), delow, sp, c->ctr, dbg);
+    } else {
+        if (cfg == 0) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, c->ctr, dbg);
+        else hipLaunchKernelGGL((skm_count_kernel<4, 512, 512, 256>), dim3(grid), dim3(512), 0, st, dev_view(c), delow, sp, c->ctr, dbg);
+    }
     E2_TRY(hipGetLastError());
     if (want_last_put) {
         E2_TRY(hipMemsetAsync(c->ctr->set_last, 0, sizeof(unsigned long long) * 256, st));
