@@ -104,7 +104,7 @@ def main():
     ap.add_argument("--sets", type=int, default=8, help="the reference's -p (k-mer sets)")
     ap.add_argument("--batch-reads", type=int, default=16_000_000)
     ap.add_argument("--log2-slots", type=int, default=0, help="0 = size from the expected distinct count")
-    ap.add_argument("--cpu-sample-reads", type=int, default=1_000_000)
+    ap.add_argument("--cpu-sample-reads", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--engine", type=int, default=0, help="0 = 2 (partitions) on one GPU, 1 (global set) when routing across GPUs")
     args = ap.parse_args()
@@ -234,24 +234,29 @@ def main():
                 launches, avg_ms, per_launch = len(ev), sum(dur) / len(dur) * 1e3, sum(alg) / len(alg)
                 extra = {}
             else:
-                # partition formulation: count passes x record bytes.  K1 reads the packed reads and writes
-                # the super-k-mer records; K2 reads the records and writes the distinct k-mers.
+                # Partition engine: two kernels share the pass.  K1 (skm_scatter_tiled_kernel) reads the packed reads and
+                # writes super-k-mer records; K2 (skm_count_kernel) reads the records, counts every partition in LDS and writes
+                # the distinct k-mers.  `achieved` follows the contract: SURVEY.md 8d's algorithmic bytes per read (one node
+                # read + one node write per k-mer occurrence + the packed read) x the reads one launch of the dominant kernel
+                # processes / its duration.  The bytes that formulation really moves (passes x record bytes) are listed too.
                 st = kc.stats()
                 rec_bytes = st["records"] * st["unit_bytes"]
                 k1_bytes = n_reads * wpr * 8 + rec_bytes
                 k2_bytes = rec_bytes + distinct * (kc.nw + 2) * 8
                 k1_s, k2_s = sum(dur) / args.steps, sum(dur2) / args.steps
+                alg_pass = n_reads * bytes_per_read
                 if k1_s >= k2_s:
-                    kernel, achieved = f"skm_scatter_kernel<{nwk}>", k1_bytes / k1_s / 1e9
-                    launches, avg_ms, per_launch = len(ev), sum(dur) / len(dur) * 1e3, k1_bytes / len(batches)
+                    kernel, achieved = f"skm_scatter_tiled_kernel<{nwk}>", alg_pass / k1_s / 1e9
+                    launches, avg_ms, per_launch = len(ev), sum(dur) / len(dur) * 1e3, alg_pass / len(batches)
                 else:
-                    kernel, achieved = f"skm_count_kernel<{nwk}>", k2_bytes / k2_s / 1e9
-                    launches, avg_ms, per_launch = len(ev2), k2_s * 1e3, k2_bytes
-                extra = {"k1_scatter_ms_per_step": k1_s * 1e3, "k2_count_ms_per_step": k2_s * 1e3,
-                         "k1_GBps": k1_bytes / k1_s / 1e9, "k2_GBps": k2_bytes / k2_s / 1e9,
-                         "records_per_read": st["records"] / n_reads, "record_bytes": st["unit_bytes"],
-                         "hash_formulation_equivalent_GBps": n_reads * bytes_per_read / (dt / args.steps) / 1e9,
-                         "hash_formulation_equivalent_frac": n_reads * bytes_per_read / (dt / args.steps) / 1e9 / 8000.0}
+                    kernel, achieved = f"skm_count_kernel<{nwk}>", alg_pass / k2_s / 1e9
+                    launches, avg_ms, per_launch = len(ev2), k2_s * 1e3, alg_pass
+                extra = {"definition": "SURVEY.md 8d algorithmic bytes/read x reads per launch / launch time of the dominant kernel",
+                         "pass1_both_kernels_GBps": alg_pass / (k1_s + k2_s) / 1e9, "pass1_both_kernels_frac": alg_pass / (k1_s + k2_s) / 1e9 / 8000.0,
+                         "k1_scatter_ms_per_step": k1_s * 1e3, "k2_count_ms_per_step": k2_s * 1e3,
+                         "k1_moved_GBps": k1_bytes / k1_s / 1e9, "k2_moved_GBps": k2_bytes / k2_s / 1e9,
+                         "moved_bytes_per_step": k1_bytes + k2_bytes, "moved_over_algorithmic": (k1_bytes + k2_bytes) / alg_pass,
+                         "records_per_read": st["records"] / n_reads, "record_bytes": st["unit_bytes"], "partitions": st["parts_or_slots"]}
             if os.path.exists(tf):
                 try:
                     traffic = json.load(open(tf)).get(kernel.split("<")[0] + "_bytes_per_launch")
