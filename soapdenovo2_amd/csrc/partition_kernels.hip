@@ -290,7 +290,9 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     __shared__ unsigned int noff[WIN + 1];                                // exclusive prefix sum of the records' k-mer counts
     __shared__ uint32_t crc_tab[256];
     __shared__ unsigned int hist[256];
-    __shared__ unsigned int aborted, sp_top, s_mask[40], s_val[40], cur_mask, cur_val, wave_cnt[NWAVE];
+    constexpr int STRIPES = (SLOTS + THREADS - 1) / THREADS;
+    __shared__ unsigned int aborted, sp_top, s_mask[40], s_val[40], cur_mask, cur_val, wave_cnt[STRIPES][NWAVE];
+    __shared__ unsigned int chunk_ids[256];                                // this partition's chunk list (maxc <= 256)
     __shared__ unsigned long long out_base;
     for (int i = threadIdx.x; i < 256; i += THREADS) { crc_tab[i] = crc32_table_entry(i); hist[i] = 0; }
     if (threadIdx.x < 8) recs[WIN * RW + threadIdx.x] = 0;
@@ -299,12 +301,26 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     const uint32_t parts = 1u << e.g.log2_parts;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long my_records = 0;
+    // the next partition's record count and chunk list are fetched while the current one is processed
+    uint32_t pf_nrec = 0, pf_cid = 0;
+    if (blockIdx.x < parts) {
+        pf_nrec = e.cursor[blockIdx.x];
+        if (threadIdx.x < e.maxc) pf_cid = e.chunk_tbl[(uint64_t)blockIdx.x * e.maxc + threadIdx.x];
+    }
     for (uint32_t pid = blockIdx.x; pid < parts; pid += gridDim.x) {
-        const uint32_t nrec = e.cursor[pid];
+        const uint32_t nrec = pf_nrec, my_cid = pf_cid;
+        {
+            const uint32_t nxt = pid + gridDim.x;
+            if (nxt < parts) {
+                pf_nrec = e.cursor[nxt];
+                if (threadIdx.x < e.maxc) pf_cid = e.chunk_tbl[(uint64_t)nxt * e.maxc + threadIdx.x];
+            }
+        }
         const uint32_t usable = min(nrec, e.maxc * e.rpc);               // an overfull partition was flagged by K1
         my_records += usable;
         if (usable == 0) continue;
         __syncthreads();
+        if (threadIdx.x < e.maxc) chunk_ids[threadIdx.x] = my_cid;
         if (threadIdx.x == 0) { sp_top = 1; s_mask[0] = 0; s_val[0] = 0; }
         __syncthreads();
         while (sp_top > 0) {
@@ -325,9 +341,10 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 // stage the window's records: 16 bytes per lane and step, consecutive lanes -> consecutive pieces
                 for (uint32_t pc = threadIdx.x; pc < wn * PIECES; pc += THREADS) {
                     const uint32_t ri = pc / PIECES, part = pc - ri * PIECES;
-                    const uint64_t* src = record_ptr(e, pid, w0 + ri, RW);
+                    const uint32_t gi = w0 + ri, cid = chunk_ids[gi / e.rpc];
                     ulonglong2 v = make_ulonglong2(0, 0);
-                    if (src) v = ((const ulonglong2*)src)[part];
+                    if (cid != 0 && cid != 0xFFFFFFFFu)
+                        v = ((const ulonglong2*)(e.pool + ((uint64_t)(cid - 1) * e.rpc + gi % e.rpc) * (uint64_t)RW))[part];
                     ((ulonglong2*)recs)[pc] = v;
                 }
                 __syncthreads();
@@ -337,11 +354,11 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     unsigned int incl = n;
 #pragma unroll
                     for (int d = 1; d < 64; d <<= 1) { const unsigned int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
-                    if (lane == 63) wave_cnt[wave] = incl;
+                    if (lane == 63) wave_cnt[0][wave] = incl;
                     __syncthreads();
                     unsigned int base = 0;
 #pragma unroll
-                    for (int wv = 0; wv < NWAVE; wv++) if (wv < wave) base += wave_cnt[wv];
+                    for (int wv = 0; wv < NWAVE; wv++) if (wv < wave) base += wave_cnt[0][wv];
                     if (threadIdx.x < wn) noff[threadIdx.x] = base + incl - n;
                     if (threadIdx.x == THREADS - 1) noff[wn] = base + incl;       // lanes past wn contributed 0
                 }
@@ -394,38 +411,41 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 __syncthreads();
                 continue;
             }
-            // ---- emit: finalize every stored node and append it to the export array.  Count the live slots, then one
-            // global atomic per attempt.
-            {
-                unsigned int mine_live = 0;
-                for (int si = threadIdx.x; si < SLOTS; si += THREADS) mine_live += set.cnt[8][si] != 0;
+            // ---- emit: finalize every stored node and append it to the export array.  One global atomic per attempt,
+            // issued as soon as the live slots are counted so that its latency hides behind the node finalisation.
+            bool live[STRIPES];
+            unsigned long long bal[STRIPES];
 #pragma unroll
-                for (int d = 32; d > 0; d >>= 1) mine_live += __shfl_down(mine_live, d, 64);
-                if (lane == 0) wave_cnt[wave] = mine_live;
-                __syncthreads();
-                if (threadIdx.x == 0) {
-                    unsigned int tot = 0;
-                    for (int wv = 0; wv < NWAVE; wv++) tot += wave_cnt[wv];
-                    out_base = atomicAdd(&ctr->n_export, (unsigned long long)tot);
-                }
-                __syncthreads();
+            for (int st = 0; st < STRIPES; st++) {
+                const int si = st * THREADS + threadIdx.x;
+                live[st] = si < SLOTS && set.cnt[8][si] != 0;          // a put is only counted once every key word is claimed
+                bal[st] = __ballot(live[st]);
+                if (lane == 0) wave_cnt[st][wave] = (unsigned int)__popcll(bal[st]);
             }
-            unsigned long long run = out_base;
-            for (int base = 0; base < SLOTS; base += THREADS) {
-                const int si = base + threadIdx.x;
-                const unsigned int puts = si < SLOTS ? set.cnt[8][si] : 0u;
-                const bool live = puts != 0;                // a put is only counted once every key word is claimed
-                const unsigned long long m = __ballot(live);
-                if (lane == 0) wave_cnt[wave] = (unsigned int)__popcll(m);
-                __syncthreads();
-                unsigned int before = 0, total = 0, cov_bin = 0;          // cov_bin 0 = not live (a live node has cov >= 1)
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                unsigned int tot = 0;
+                for (int st = 0; st < STRIPES; st++) for (int wv = 0; wv < NWAVE; wv++) tot += wave_cnt[st][wv];
+                out_base = atomicAdd(&ctr->n_export, (unsigned long long)tot);
+            }
+            uint64_t rec_out[STRIPES][NW + 2];
+            unsigned int off[STRIPES], cov_bin[STRIPES];
+            unsigned int running = 0;
+#pragma unroll
+            for (int st = 0; st < STRIPES; st++) {
+                unsigned int before = 0, total = 0;
 #pragma unroll
                 for (int wv = 0; wv < NWAVE; wv++) {
-                    const unsigned int cw = wave_cnt[wv];
+                    const unsigned int cw = wave_cnt[st][wv];
                     if (wv < wave) before += cw;
                     total += cw;
                 }
-                if (live) {
+                off[st] = running + before + (unsigned int)__popcll(bal[st] & ((1ULL << lane) - 1));
+                running += total;
+                cov_bin[st] = 0;                                          // 0 = not live (a live node has cov >= 1)
+                if (live[st]) {
+                    const int si = st * THREADS + threadIdx.x;
+                    const unsigned int puts = set.cnt[8][si];
                     Key63<NW> k63;
 #pragma unroll
                     for (int w = 0; w < KW; w++) k63.w[w] = set.key[w][si];
@@ -433,7 +453,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     uint32_t A = min(puts, 255u) << 24, B = puts == 1 ? B_SINGLE : 0u;
                     int nin = 0, nout = 0;
 #pragma unroll
-                    for (int c = 0; c < 4; c++) {                                   // saturate, then thread_delow + thread_mark
+                    for (int c = 0; c < 4; c++) {                               // saturate, then thread_delow + thread_mark
                         uint32_t l = min(set.cnt[c][si], 63u), r = min(set.cnt[4 + c][si], 63u);
                         if (D > 0 && l <= (uint32_t)D) l = 0;
                         if (D > 0 && r <= (uint32_t)D) r = 0;
@@ -442,26 +462,31 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     }
                     if (D > 0 && nin == 0 && nout == 0) B |= B_DELETED;
                     if (nin == 1 && nout == 1) B |= B_LINEAR;
-                    cov_bin = A >> 24;
-                    const uint64_t pos = run + before + __popcll(m & ((1ULL << lane) - 1));
-                    if (pos < e.out_capacity) {
-                        const uint32_t sid = set_of_crc(kmer_crc32<NW>(key, crc_tab), sp.P, sp.bias);
-                        uint64_t* o = e.out + pos * (NW + 2);
+                    cov_bin[st] = A >> 24;
+                    const uint32_t sid = set_of_crc(kmer_crc32<NW>(key, crc_tab), sp.P, sp.bias);
 #pragma unroll
-                        for (int w = 0; w < NW; w++) o[w] = key.w[w];
-                        o[NW] = (uint64_t)A | ((uint64_t)B << 32);
-                        o[NW + 1] = ((uint64_t)sid << PG_ORD_BITS) | (set.ord[si] & PG_ORD_MASK);
-                    } else atomicOr(&ctr->e2_flags, F_OUT);
+                    for (int w = 0; w < NW; w++) rec_out[st][w] = key.w[w];
+                    rec_out[st][NW] = (uint64_t)A | ((uint64_t)B << 32);
+                    rec_out[st][NW + 1] = ((uint64_t)sid << PG_ORD_BITS) | (set.ord[si] & PG_ORD_MASK);
                 }
                 // coverage histogram: most nodes of a partition share one or two coverage values (1 for error k-mers),
                 // so count those per wave instead of hammering one LDS word
-                {
-                    const unsigned long long ones = __ballot(cov_bin == 1);
-                    if (lane == 0 && ones) atomicAdd(&hist[1], (unsigned int)__popcll(ones));
-                    if (cov_bin > 1) atomicAdd(&hist[cov_bin], 1u);
+                const unsigned long long ones = __ballot(cov_bin[st] == 1);
+                if (lane == 0 && ones) atomicAdd(&hist[1], (unsigned int)__popcll(ones));
+                if (cov_bin[st] > 1) atomicAdd(&hist[cov_bin[st]], 1u);
+            }
+            __syncthreads();                                              // out_base is in; the set may be cleared after this
+            const unsigned long long ob = out_base;
+#pragma unroll
+            for (int st = 0; st < STRIPES; st++) {
+                if (live[st]) {
+                    const uint64_t pos = ob + off[st];
+                    if (pos < e.out_capacity) {
+                        uint64_t* o = e.out + pos * (NW + 2);
+#pragma unroll
+                        for (int w = 0; w < NW + 2; w++) o[w] = rec_out[st][w];
+                    } else atomicOr(&ctr->e2_flags, F_OUT);
                 }
-                run += total;
-                __syncthreads();
             }
         }
     }
