@@ -301,6 +301,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     const uint32_t parts = 1u << e.g.log2_parts;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long my_records = 0;
+    bool dirty = true;                                                    // workgroup-uniform: the LDS set needs a full reset
     // the next partition's record count and chunk list are fetched while the current one is processed
     uint32_t pf_nrec = 0, pf_cid = 0;
     if (blockIdx.x < parts) {
@@ -326,12 +327,15 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
         while (sp_top > 0) {
             __syncthreads();
             if (threadIdx.x == 0) { sp_top--; cur_mask = s_mask[sp_top]; cur_val = s_val[sp_top]; aborted = 0; }
-            for (int i = threadIdx.x; i < SLOTS; i += THREADS) {
+            if (dirty) {                // full reset only at start and after a dropped attempt; emit resets what it reads
+                for (int i = threadIdx.x; i < SLOTS; i += THREADS) {
 #pragma unroll
-                for (int q = 0; q < KW; q++) set.key[q][i] = L_EMPTY;
-                set.ord[i] = L_EMPTY;
+                    for (int q = 0; q < KW; q++) set.key[q][i] = L_EMPTY;
+                    set.ord[i] = L_EMPTY;
 #pragma unroll
-                for (int q = 0; q < 9; q++) set.cnt[q][i] = 0;
+                    for (int q = 0; q < 9; q++) set.cnt[q][i] = 0;
+                }
+                dirty = false;
             }
             __syncthreads();
             const uint32_t mask = cur_mask, val = cur_val;
@@ -375,17 +379,26 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                         uint64_t hdr = 0;
                         int hl = 0, nb = 0;
                         bool fresh = true;
+                        Kmer<NW> word, bal;                                       // rolling pair inside one record
                         for (uint32_t idx = idx0; idx < idx1; idx++) {
                             while (idx >= next_off) { r++; next_off = noff[r + 1]; fresh = true; }
+                            int j;
                             if (fresh) {
                                 rec = recs + r * RW;
                                 hdr = rec[0];
                                 hl = skm_has_left(hdr); nb = skm_record_bases(hdr, K); roff = noff[r];
                                 fresh = false;
                                 if (*abort_flag) break;
+                                j = hl + (int)(idx - roff);
+                                word = read_kmer<NW>(rec + 1, j, K, filter);
+                                bal = kmer_rc<NW>(word, K);
+                            } else {
+                                j = hl + (int)(idx - roff);
+                                kmer_roll<NW>(word, bal, read_base(rec + 1, j + K - 1), K, filter);
                             }
                             Occurrence occ;
-                            const Kmer<NW> key = canonical_occurrence<NW>(rec + 1, hl + (int)(idx - roff), nb, K, filter, occ);
+                            const Kmer<NW> key = canonical_pair<NW>(word, bal, j > 0 ? read_base(rec + 1, j - 1) : 4,
+                                                                    j < nb - K ? read_base(rec + 1, j + K) : 4, occ);
                             const uint64_t hh = kmer_mix<NW>(key);
                             if (((uint32_t)(hh >> 32) & mask) != val) continue;
                             if (dbg & 1) { if (hh == 0x1234) aborted = 1; continue; }      // measurement aid: extraction only
@@ -408,6 +421,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                         s_mask[sp_top] = mask | bit; s_val[sp_top] = val | bit; sp_top++;
                     }
                 }
+                dirty = true;
                 __syncthreads();
                 continue;
             }
@@ -463,11 +477,16 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     if (D > 0 && nin == 0 && nout == 0) B |= B_DELETED;
                     if (nin == 1 && nout == 1) B |= B_LINEAR;
                     cov_bin[st] = A >> 24;
-                    const uint32_t sid = set_of_crc(kmer_crc32<NW>(key, crc_tab), sp.P, sp.bias);
 #pragma unroll
                     for (int w = 0; w < NW; w++) rec_out[st][w] = key.w[w];
                     rec_out[st][NW] = (uint64_t)A | ((uint64_t)B << 32);
-                    rec_out[st][NW + 1] = ((uint64_t)sid << PG_ORD_BITS) | (set.ord[si] & PG_ORD_MASK);
+                    rec_out[st][NW + 1] = set.ord[si] & PG_ORD_MASK;      // the set id is filled in by set_id_kernel
+                    // leave the slot empty for the next partition
+#pragma unroll
+                    for (int w = 0; w < KW; w++) set.key[w][si] = L_EMPTY;
+                    set.ord[si] = L_EMPTY;
+#pragma unroll
+                    for (int c = 0; c < 9; c++) set.cnt[c][si] = 0;
                 }
                 // coverage histogram: most nodes of a partition share one or two coverage values (1 for error k-mers),
                 // so count those per wave instead of hammering one LDS word
@@ -493,6 +512,24 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     __syncthreads();
     for (int i = threadIdx.x; i < 256; i += THREADS) if (hist[i]) atomicAdd(&ctr->hist[i], (unsigned long long)hist[i]);
     if (threadIdx.x == 0 && my_records) atomicAdd(&ctr->n_records, my_records);
+}
+
+// set id = hash_kmer % thrd_num (hashFunction.c:155) of every exported k-mer, as a dense streaming pass (doing the
+// 16 table look-ups inside K2's emit made every lane of a stripe pay for the few live ones)
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void set_id_kernel(uint64_t* out, uint64_t capacity, SetParams sp, const DevCounters* ctr) {
+    __shared__ uint32_t crc_tab[256];
+    crc_tab[threadIdx.x] = crc32_table_entry(threadIdx.x);
+    __syncthreads();
+    const uint64_t n = min((uint64_t)ctr->n_export, capacity);
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
+        uint64_t* o = out + i * (NW + 2);
+        Kmer<NW> key;
+#pragma unroll
+        for (int w = 0; w < NW; w++) key.w[w] = o[w];
+        const uint32_t sid = set_of_crc(kmer_crc32<NW>(key, crc_tab), sp.P, sp.bias);
+        o[NW + 1] = (o[NW + 1] & PG_ORD_MASK) | ((uint64_t)sid << PG_ORD_BITS);
+    }
 }
 
 // per reference set: 1 + ordinal of the last k-mer occurrence routed to it (see host_graph.cpp, before_put)
@@ -704,6 +741,9 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
         if (cfg == 0) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, c->ctr, dbg);
         else hipLaunchKernelGGL((skm_count_kernel<4, 512, 512, 256>), dim3(grid), dim3(512), 0, st, dev_view(c), delow, sp, c->ctr, dbg);
     }
+    E2_TRY(hipGetLastError());
+    if (c->NW == 2) hipLaunchKernelGGL(set_id_kernel<2>, dim3(n_cu * 8), dim3(BLOCK), 0, st, s.out, s.out_capacity, sp, c->ctr);
+    else hipLaunchKernelGGL(set_id_kernel<4>, dim3(n_cu * 8), dim3(BLOCK), 0, st, s.out, s.out_capacity, sp, c->ctr);
     E2_TRY(hipGetLastError());
     if (want_last_put) {
         E2_TRY(hipMemsetAsync(c->ctr->set_last, 0, sizeof(unsigned long long) * 256, st));
