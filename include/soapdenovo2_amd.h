@@ -46,7 +46,7 @@ const char *pg_version(void);
  *   pregraph -s configFile -o outputGraph [-K kmer -p n_sets -a initMemoryAssumption -d KmerFreqCutoff -R]
  * -p is the number of k-mer sets ("threads" in the reference); it fixes the order of .vertex/.edge.gz and
  * is honoured as such regardless of how many GPUs or host threads do the work.
- * Writes <o>.kmerFreq <o>.preGraphBasic <o>.vertex <o>.edge.gz (and <o>.preArc, section 8f-1 of SURVEY.md).
+ * Writes <o>.kmerFreq <o>.preGraphBasic <o>.vertex <o>.edge.gz <o>.preArc (-R is accepted; .path / .markOnEdge are not written yet).
  * Returns 0; fatal errors print to stderr and exit(), as the reference does (check.c:31,96).
  * call_pregraph        = behaviour of the SOAPdenovo-63mer binary (K <= 63, two hex words per k-mer)
  * call_pregraph_127mer = behaviour of the SOAPdenovo-127mer binary (K <= 127, four hex words)
@@ -100,6 +100,20 @@ int pg_host_read_all(const char *config, int K, uint8_t *codes_out, int32_t *len
 int pg_host_build_graph(const uint64_t *records, uint64_t n_records, const uint64_t *set_last_put,
                         int K, int mer127, int n_sets, int cut_single, int a_gb, int max_read_len,
                         int n_threads, const char *prefix, int *out_num_vertex, int *out_num_edge);
+
+/* The same host stages kept alive for pass 2 (prlRead2edge, prlRead2path.c:786-1370: read -> edge threading, pre-arcs):
+ *   pg_host_graph_begin      replay + tips + edges (writes <prefix>.edge.gz), keeps the k-mer sets and the (K+1)-mer
+ *                            patch table of the length-1 edges (KmerSetsPatch, node2edge.c:481-542) in memory
+ *   pg_host_graph_add_reads  threads a batch of reads (base codes, read i at codes + i * stride, lens[i] bases or
+ *                            `stride` bases when lens is NULL) through the graph and accumulates the pre-arcs; batches
+ *                            must come in the reference's read order (the order of a pre-arc list is first-encounter order)
+ *   pg_host_graph_finish     writes <prefix>.preArc, <prefix>.vertex, <prefix>.preGraphBasic and frees the handle */
+typedef struct pg_graph pg_graph;
+pg_graph *pg_host_graph_begin(const uint64_t *records, uint64_t n_records, const uint64_t *set_last_put, int K, int mer127,
+                              int n_sets, int cut_single, int a_gb, int max_read_len, int n_threads, const char *prefix);
+int pg_host_graph_add_reads(pg_graph *g, const uint8_t *codes, const int32_t *lens, uint64_t n_reads, uint64_t stride,
+                            int n_threads);
+int pg_host_graph_finish(pg_graph *g, int *out_num_vertex, int *out_num_edge, long long *out_num_prearc);
 
 /* The layout replay alone (init_kmerset / put_kmerset / encap_kmerset, newhash.c:200-233,340-528): for every
  * record the slot it occupies in its reference k-mer set, and per set the final table size. */

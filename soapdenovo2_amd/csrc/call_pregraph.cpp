@@ -277,12 +277,47 @@ int run(int argc, char** argv, bool mer127) {
     }
     pg_destroy(ctx);
 
+    // ---- tips + edges (removeSingleTips / removeMinorTips / kmer2edges), graph kept for pass 2
     t0 = time(nullptr);
-    int num_vt = 0, num_ed = 0;
-    if (pg_host_build_graph(records.data(), n_distinct, set_last.data(), K, mer127 ? 1 : 0, o.sets, o.delow == 0, o.a_gb,
-                            max_read_len, 0, o.prefix.c_str(), &num_vt, &num_ed) != PG_OK)
-        die("pg_host_build_graph");
+    pg_graph* graph = pg_host_graph_begin(records.data(), n_distinct, set_last.data(), K, mer127 ? 1 : 0, o.sets, o.delow == 0, o.a_gb,
+                                          max_read_len, 0, o.prefix.c_str());
+    if (!graph) die("pg_host_graph_begin");
+    { std::vector<uint64_t>().swap(records); }
     fprintf(stderr, "Time spent on removing tips and constructing edges: %ds.\n\n", (int)(time(nullptr) - t0));
+
+    // ---- pass 2 (prlRead2edge): the reads again, in the same order, threaded through the edges -> .preArc
+    t0 = time(nullptr);
+    {
+        struct Pass2 : pg::ReadSink {
+            pg_graph* g; int K; size_t stride, cap, n = 0;
+            std::vector<uint8_t> codes; std::vector<int32_t> lens;
+            void flush() {
+                if (!n) return;
+                if (pg_host_graph_add_reads(g, codes.data(), lens.data(), n, stride, 0) != PG_OK) die("pg_host_graph_add_reads");
+                n = 0;
+            }
+            void on_read(const uint8_t* c, int len) override {
+                if (len < K + 1) return;                              // prlRead2path.c:1103
+                memcpy(codes.data() + n * stride, c, (size_t)len);
+                lens[n++] = len;
+                if (n == cap) flush();
+            }
+        } p2;
+        p2.g = graph; p2.K = K; p2.stride = (size_t)max_read_len; p2.cap = (size_t)1 << 20;
+        p2.codes.resize(p2.stride * p2.cap); p2.lens.resize(p2.cap);
+        fprintf(stderr, "In file: %s, max seq len %d, max name len %d.\n", o.config.c_str(), max_read_len, 256);
+        long long n2 = 0;
+        for (const pg::InputFile& f : files) {
+            fprintf(stderr, "Import reads from file:\n %s\n", f.path1.c_str());
+            n2 += pg::stream_reads(f, p2);
+        }
+        p2.flush();
+        fprintf(stderr, "%lld read(s) processed.\n", n2);
+    }
+    int num_vt = 0, num_ed = 0;
+    long long num_arc = 0;
+    if (pg_host_graph_finish(graph, &num_vt, &num_ed, &num_arc) != PG_OK) die("pg_host_graph_finish");
+    fprintf(stderr, "Time spent on aligning reads: %ds.\n\n", (int)(time(nullptr) - t0));
     fprintf(stderr, "Overall time spent on constructing pre-graph: %dm.\n\n", (int)(time(nullptr) - t_start) / 60);
     return 0;
 }

@@ -21,6 +21,7 @@
 #include <atomic>
 #include <string>
 #include <thread>
+#include <unordered_map>
 #include <vector>
 
 #include "kmer.hpp"
@@ -164,12 +165,47 @@ template <int NW> static inline int n_in(const HNode<NW>& n) { int c = 0; for (i
 template <int NW> static inline int n_out(const HNode<NW>& n) { int c = 0; for (int i = 0; i < 4; i++) c += nR(n, i) > 0; return c; }
 
 template <int NW>
+struct KmerHash {
+    size_t operator()(const Kmer<NW>& k) const { return (size_t)kmer_mix<NW>(k); }
+};
+template <int NW>
+struct KmerEq {
+    bool operator()(const Kmer<NW>& a, const Kmer<NW>& b) const { return kmer_eq<NW>(a, b); }
+};
+
+// reverseComplement(word, K + 1) exactly as the reference computes it for the (K+1)-mer of a length-1 edge
+// (node2edge.c:485, prlRead2path.c:694).  The 127-mer binary passes the length through a `char` (kmer.c:532): for
+// K = 127 the length 128 wraps to -128, takes the `seq_size < 32` exit and only the lowest word is complemented and
+// reversed (the shift count 64 - (-256) = 320 is applied modulo 64 by the hardware, i.e. not at all).
+template <int NW>
+static Kmer<NW> rc_plus(const Kmer<NW>& word, int K) {
+    if (NW == 4 && K + 1 >= 128) {
+        Kmer<NW> r = word;
+        r.w[NW - 1] = rev2bit(word.w[NW - 1] ^ 0xAAAAAAAAAAAAAAAAULL);
+        return r;
+    }
+    return kmer_rc<NW>(word, K + 1);
+}
+// KmerPlus (kmer.c:690-694): append one base without masking
+template <int NW>
+static Kmer<NW> kmer_plus(Kmer<NW> a, int ch) {
+    for (int i = 0; i < NW - 1; i++) a.w[i] = (a.w[i] << 2) | (a.w[i + 1] >> 62);
+    a.w[NW - 1] = (a.w[NW - 1] << 2) | (uint64_t)ch;
+    return a;
+}
+
+struct PatchVal { uint32_t id; uint32_t twin; };
+
+template <int NW>
 struct Graph {
     int K, P;
     Kmer<NW> filter;
     uint32_t bias;
     const uint32_t* crc;
     std::vector<HSet<NW>> sets;
+    // KmerSetsPatch (node2edge.c:371-376,481-542): canonical (K+1)-mer of every length-1 edge -> edge id, twin.  Only
+    // looked up by key (prlRead2path.c:558-596), so a plain map replaces the reference's second family of hash sets.
+    std::unordered_map<Kmer<NW>, PatchVal, KmerHash<NW>, KmerEq<NW>> patch;
 
     int set_of(const Kmer<NW>& k) const { return (int)set_of_crc(kmer_crc32<NW>(k, crc), (uint32_t)P, bias); }
 
@@ -351,7 +387,13 @@ struct EdgeBuilder {
         Graph<NW>::cut_next(*first.node, kmer_last<NW>(beads[1].kmer), first.smaller);
         edge_c++;
         records++;
-        if (length == 1) extra_nodes++;     // the (K+1)-mer of a length-1 edge is pass-2 state (node2edge.c:481-542)
+        if (length == 1) {                   // the (K+1)-mer joining two branch nodes (node2edge.c:481-542)
+            extra_nodes++;
+            const Kmer<NW> plus = kmer_plus<NW>(first.kmer, kmer_last<NW>(last.kmer));
+            const Kmer<NW> bal_plus = rc_plus<NW>(plus, g.K);
+            if (kmer_less<NW>(plus, bal_plus)) g.patch[plus] = PatchVal{(uint32_t)edge_c, (uint32_t)(bal + 1)};
+            else g.patch[bal_plus] = PatchVal{(uint32_t)(edge_c + bal), (uint32_t)(1 - bal)};
+        }
         long long sum = 0;
         for (int i = 1; i < count - 1; i++) {
             const HNode<NW>& n = *beads[i].node;
@@ -513,6 +555,186 @@ static int layout_only(const uint64_t* records, uint64_t n, const uint64_t* set_
     return PG_OK;
 }
 
+// ---- pass 2: read -> edge threading and pre-arcs (prlRead2edge, prlRead2path.c:786-1370) ----------------------
+// Per read: every k-mer -> its node (chopKmer4read + searchKmer, prlRead2path.c:271-368); parse1read
+// (prlRead2path.c:598-745) turns the node list into edge ids: a deleted node or a linear node outside any edge restarts
+// the list while it has fewer than two items and ends it otherwise; a linear node contributes its (oriented) edge id
+// once; two consecutive branch nodes contribute the (K+1)-mer joining them, resolved through the patch map to the id
+// of the length-1 edge (search1kmerPlus, prlRead2path.c:558-596; a miss truncates the list).  Every adjacent pair
+// (a, b) of the list then counts one pre-arc a -> b (thread_add1preArc, prlRead2path.c:388-403).
+template <int NW>
+struct ReadThreader {
+    Graph<NW>& g;
+    explicit ReadThreader(Graph<NW>& g_) : g(g_) {}
+
+    struct Item { uint32_t id; bool kplus; bool smaller; Kmer<NW> plus; };
+
+    // appends the read's pairs (from, to) to `out`; returns false when the read yielded no usable item at all
+    // (the reference's "read(s) deleted" counter, prlRead2path.c:722-725)
+    bool thread_read(const uint8_t* codes, int len, std::vector<Item>& items, std::vector<std::pair<uint32_t, uint32_t>>& out) {
+        const int K = g.K;
+        items.clear();
+        unsigned retain = 0;
+        bool is_prev = false;
+        Kmer<NW> prev_k;
+        for (int i = 0; i < NW; i++) prev_k.w[i] = 0;
+        Kmer<NW> word;
+        for (int i = 0; i < NW; i++) word.w[i] = 0;
+        for (int i = 0; i < K - 1; i++) word = kmer_next<NW>(word, codes[i], g.filter);
+        for (int j = 0; j + K <= len; j++) {
+            word = kmer_next<NW>(word, codes[j + K - 1], g.filter);
+            const Kmer<NW> bal = kmer_rc<NW>(word, K);
+            const bool smaller = kmer_less<NW>(word, bal);
+            const Kmer<NW>& key = smaller ? word : bal;
+            const HNode<NW>* node = g.sets[g.set_of(key)].find(key);
+            if (!node) { fprintf(stderr, "SearchKmer: kmer is not found.\n"); exit(1); }
+            const uint32_t B = node->B;
+            const bool linear = B & B_LINEAR, in_edge = (B >> B_INEDGE_SHIFT) & 3;
+            if ((B & B_DELETED) || (linear && !in_edge)) {
+                if (retain < 2) { retain = 0; items.clear(); continue; }      // is_prev / prev_k keep their stale values
+                break;
+            }
+            if (linear) {
+                const uint32_t twin = (B >> B_TWIN_SHIFT) & 3;
+                const uint32_t e = smaller ? node->A : node->A + twin - 1;
+                if (retain == 0 || is_prev) { retain++; items.push_back(Item{e, false, false, Kmer<NW>()}); is_prev = false; }
+                else if (e != items.back().id) { retain++; items.push_back(Item{e, false, false, Kmer<NW>()}); }
+            } else {
+                const Kmer<NW> cur = word;            // the node's k-mer in read orientation (prlRead2path.c:680-687)
+                if (is_prev) {
+                    retain++;
+                    const Kmer<NW> plus = kmer_plus<NW>(prev_k, kmer_last<NW>(cur));
+                    const Kmer<NW> bal_plus = rc_plus<NW>(plus, K);
+                    Item it;
+                    it.kplus = true;
+                    it.smaller = kmer_less<NW>(plus, bal_plus);
+                    it.plus = it.smaller ? plus : bal_plus;
+                    it.id = 0;
+                    items.push_back(it);
+                }
+                is_prev = true;
+                prev_k = cur;
+            }
+        }
+        if (retain < 2) return retain >= 1;
+        for (Item& it : items) {
+            if (!it.kplus) continue;
+            auto f = g.patch.find(it.plus);
+            it.id = f == g.patch.end() ? 0u : (it.smaller ? f->second.id : f->second.id + f->second.twin - 1);
+        }
+        for (size_t i = 0; i + 1 < items.size(); i++) {
+            if (items[i].id == 0 || items[i + 1].id == 0) break;
+            out.emplace_back(items[i].id, items[i + 1].id);
+        }
+        return true;
+    }
+};
+
+// pre-arc lists: new targets go to the head of their source's list (prlRead2path.c:388-403), output walks from the
+// head (output_arcs, prlRead2path.c:426-476)
+struct PreArcs {
+    std::vector<uint32_t> head;            // per from-edge, index + 1 into the pools, 0 = empty
+    std::vector<uint32_t> to, mult, next;
+    long long count = 0;
+    void init(uint32_t num_ed) { head.assign((size_t)num_ed + 1, 0); }
+    void add(uint32_t from, uint32_t t) {
+        for (uint32_t i = head[from]; i; i = next[i - 1])
+            if (to[i - 1] == t) { mult[i - 1]++; return; }
+        to.push_back(t); mult.push_back(1); next.push_back(head[from]);
+        head[from] = (uint32_t)to.size();
+        count++;
+    }
+    int write(const std::string& path) const {
+        FILE* fp = fopen(path.c_str(), "w");
+        if (!fp) { pg_set_error("cannot open " + path); return PG_EIO; }
+        std::vector<char> big(1 << 22);
+        setvbuf(fp, big.data(), _IOFBF, big.size());
+        for (size_t e = 1; e < head.size(); e++) {
+            if (!head[e]) continue;
+            fprintf(fp, "%u", (unsigned)e);
+            for (uint32_t i = head[e]; i; i = next[i - 1]) fprintf(fp, " %u %u", to[i - 1], mult[i - 1]);
+            fputc('\n', fp);
+        }
+        fclose(fp);
+        return PG_OK;
+    }
+};
+
+// The graph kept alive between edge construction and pass 2.
+struct GraphHandleBase {
+    virtual ~GraphHandleBase() {}
+    virtual int add_reads(const uint8_t* codes, const int32_t* lens, uint64_t n, uint64_t stride, int n_threads) = 0;
+    virtual int finish(long long* n_arcs) = 0;
+    int num_vt = 0, num_ed = 0;
+};
+
+template <int NW>
+struct GraphHandle : GraphHandleBase {
+    Graph<NW> g;
+    PreArcs arcs;
+    std::string prefix;
+    int max_read_len = 0;
+    long long reads_seen = 0, reads_deleted = 0;
+
+    int add_reads(const uint8_t* codes, const int32_t* lens, uint64_t n, uint64_t stride, int n_threads) override {
+        int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+        nt = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)nt, (n + 255) / 256));
+        std::vector<std::vector<std::pair<uint32_t, uint32_t>>> pairs(nt);
+        std::vector<long long> deleted(nt, 0);
+        auto worker = [&](int t) {
+            ReadThreader<NW> rt(g);
+            std::vector<typename ReadThreader<NW>::Item> items;
+            const uint64_t lo = n * t / nt, hi = n * (t + 1) / nt;
+            for (uint64_t r = lo; r < hi; r++) {
+                const int len = lens ? lens[r] : (int)stride;
+                if (len < g.K + 1) continue;                                  // prlRead2path.c:1103 (same filter as pass 1)
+                if (!rt.thread_read(codes + r * stride, len, items, pairs[t])) deleted[t]++;
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; t++) pool.emplace_back(worker, t);
+        worker(0);
+        for (auto& th : pool) th.join();
+        // the lists depend on first-encounter order: fold the chunks in read order, serially
+        for (int t = 0; t < nt; t++) {
+            for (auto& pr : pairs[t]) {
+                if (pr.first >= arcs.head.size()) { pg_set_error("edge id out of range in pass 2"); return PG_EINVAL; }
+                arcs.add(pr.first, pr.second);
+            }
+            reads_deleted += deleted[t];
+        }
+        reads_seen += (long long)n;
+        return PG_OK;
+    }
+    int finish(long long* n_arcs) override {
+        int rc = arcs.write(prefix + ".preArc");
+        if (rc) return rc;
+        fprintf(stderr, "Reads alignment done, %lld read(s) deleted, %lld pre-arc(s) added.\n", reads_deleted, arcs.count);
+        if (n_arcs) *n_arcs = arcs.count;
+        return write_vertex<NW>(g, prefix, num_ed, max_read_len, num_vt);
+    }
+};
+
+template <int NW>
+static GraphHandleBase* graph_begin(const uint64_t* records, uint64_t n, const uint64_t* set_last_put, int K, int P, int cut_single,
+                                    int a_gb, int max_read_len, int n_threads, const char* prefix_c) {
+    GraphHandle<NW>* h = new GraphHandle<NW>();
+    h->prefix = prefix_c;
+    h->max_read_len = max_read_len;
+    if (replay_layout<NW>(h->g, records, n, set_last_put, K, P, a_gb, n_threads) != PG_OK) { delete h; return nullptr; }
+    if (cut_single) h->g.remove_single_tips();
+    h->g.remove_minor_tips();
+    GzText gz;
+    if (!gz.open(h->prefix + ".edge.gz")) { pg_set_error("cannot open " + h->prefix + ".edge.gz"); delete h; return nullptr; }
+    EdgeBuilder<NW> eb(h->g, gz);
+    eb.run();
+    gz.close();
+    fprintf(stderr, "%d (%lld) edge(s) and %lld extra node(s) constructed.\n", eb.edge_c, eb.records, eb.extra_nodes);
+    h->num_ed = eb.edge_c;
+    h->arcs.init((uint32_t)eb.edge_c);
+    return h;
+}
+
 template <int NW>
 static int build_graph(const uint64_t* records, uint64_t n, const uint64_t* set_last_put, int K, int P, int cut_single,
                        int a_gb, int max_read_len, int n_threads, const char* prefix_c, int* out_vt, int* out_ed) {
@@ -553,6 +775,30 @@ extern "C" int pg_host_build_graph(const uint64_t* records, uint64_t n_records, 
     if (mer127)
         return pg::build_graph<4>(records, n_records, set_last_put, K, n_sets, cut_single, a_gb, max_read_len, n_threads, prefix, out_num_vertex, out_num_edge);
     return pg::build_graph<2>(records, n_records, set_last_put, K, n_sets, cut_single, a_gb, max_read_len, n_threads, prefix, out_num_vertex, out_num_edge);
+}
+
+extern "C" pg_graph* pg_host_graph_begin(const uint64_t* records, uint64_t n_records, const uint64_t* set_last_put, int K, int mer127,
+                                         int n_sets, int cut_single, int a_gb, int max_read_len, int n_threads, const char* prefix) {
+    if ((!records && n_records) || !prefix) { pg_set_error("null argument"); return nullptr; }
+    const int maxK = mer127 ? 127 : 63;
+    if (K < 13 || K > maxK || !(K & 1)) { pg_set_error("K must be odd and within 13.." + std::to_string(maxK)); return nullptr; }
+    if (n_sets < 1 || n_sets > 255) { pg_set_error("n_sets must be 1..255"); return nullptr; }
+    pg::GraphHandleBase* h = mer127 ? pg::graph_begin<4>(records, n_records, set_last_put, K, n_sets, cut_single, a_gb, max_read_len, n_threads, prefix)
+                                    : pg::graph_begin<2>(records, n_records, set_last_put, K, n_sets, cut_single, a_gb, max_read_len, n_threads, prefix);
+    return (pg_graph*)h;
+}
+extern "C" int pg_host_graph_add_reads(pg_graph* g, const uint8_t* codes, const int32_t* lens, uint64_t n_reads, uint64_t stride, int n_threads) {
+    if (!g || (!codes && n_reads)) { pg_set_error("null argument"); return PG_EINVAL; }
+    return ((pg::GraphHandleBase*)g)->add_reads(codes, lens, n_reads, stride, n_threads);
+}
+extern "C" int pg_host_graph_finish(pg_graph* g, int* out_num_vertex, int* out_num_edge, long long* out_num_prearc) {
+    if (!g) { pg_set_error("null argument"); return PG_EINVAL; }
+    pg::GraphHandleBase* h = (pg::GraphHandleBase*)g;
+    int rc = h->finish(out_num_prearc);
+    if (out_num_vertex) *out_num_vertex = h->num_vt;
+    if (out_num_edge) *out_num_edge = h->num_ed;
+    delete h;
+    return rc;
 }
 
 extern "C" int pg_host_replay_layout(const uint64_t* records, uint64_t n_records, const uint64_t* set_last_put, int mer127,

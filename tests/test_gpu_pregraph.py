@@ -171,6 +171,13 @@ def test_cli_matches_reference_files(golden, tmp_path, name, engine):
         assert md5_file(pre + ".preGraphBasic") == want["preGraphBasic"], t
         assert md5_file(pre + ".vertex") == want["vertex"], t
         assert md5_gz_text(pre + ".edge.gz") == want["edge"], t
+        assert md5_file(pre + ".preArc") == want["preArc"], t
+    # P3: the reference's unchanged contig stage consumes the files of the last run and produces the same contigs
+    ref = os.path.join(ROOT, "oracle", "_ref", "SOAPdenovo-127mer" if m else "SOAPdenovo-63mer")
+    if engine == 2 and os.path.exists(ref):
+        out = subprocess.run([ref, "contig", "-g", pre], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr[-500:]
+        assert md5_file(pre + ".contig") == golden["md5"][t]["contig"], t
 
 
 def test_cli_fasta_and_reference_binary(golden, tmp_path):
@@ -189,7 +196,7 @@ def test_cli_fasta_and_reference_binary(golden, tmp_path):
     if os.path.exists(ref):
         subprocess.run([ref, "pregraph", "-s", cfq, "-K", str(K), "-o", str(tmp_path / "r"), "-p", str(P)], check=True,
                        stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
-        for ext in ("kmerFreq", "preGraphBasic", "vertex"):
+        for ext in ("kmerFreq", "preGraphBasic", "vertex", "preArc"):
             assert md5_file(str(tmp_path / ("a." + ext))) == md5_file(str(tmp_path / ("r." + ext))), ext
         assert md5_gz_text(str(tmp_path / "a.edge.gz")) == md5_gz_text(str(tmp_path / "r.edge.gz"))
 
@@ -245,3 +252,4 @@ def test_cli_reader_corner_cases(golden, tmp_path):
         assert md5_file(pre + ".preGraphBasic") == want["preGraphBasic"], name
         assert md5_file(pre + ".vertex") == want["vertex"], name
         assert md5_gz_text(pre + ".edge.gz") == want["edge"], name
+        assert md5_file(pre + ".preArc") == want["preArc"], name

@@ -1,0 +1,71 @@
+"""Pass 2 of pregraph on the host (read -> edge threading, pre-arcs: pg_host_graph_begin / add_reads / finish) on CPU:
+fed with the oracle's pass-1 records and the same reads it must reproduce the reference's .preArc byte for byte
+(plus the three graph files again, now written through the handle API)."""
+import numpy as np
+import pytest
+
+from conftest import case_codes, case_tag, md5_file, md5_gz_text, oracle_records
+from soapdenovo2_amd import api
+
+
+@pytest.mark.parametrize("name", ["t6k_k31", "t8k_k63", "t6k_k127", "t5k_k24", "m60k_k63"])
+def test_prearc_matches_reference(golden, tmp_path, name):
+    c = golden["cases"][name]
+    codes = case_codes(c)
+    for run in c["runs"]:
+        P, D, a, m = run
+        t = case_tag(name, run)
+        rec, last, K = oracle_records(codes, c["K"], P, D=D, mer127=bool(m), a_gb=a, prefix=str(tmp_path / ("o_" + t)))
+        pre = str(tmp_path / t)
+        nv, ne, na = api.host_pregraph_files(rec, last, codes, None, K, P, pre, mer127=bool(m), cut_single=(D == 0), a_gb=a,
+                                             max_read_len=c["L"], batches=3)
+        want = golden["md5"][t]
+        assert md5_file(pre + ".preArc") == want["preArc"], t
+        assert md5_file(pre + ".vertex") == want["vertex"], t
+        assert md5_file(pre + ".preGraphBasic") == want["preGraphBasic"], t
+        assert md5_gz_text(pre + ".edge.gz") == want["edge"], t
+        assert na > 0
+
+
+def test_prearc_on_reader_corner_cases(golden, tmp_path):
+    """Ragged reads, truncated reads, mate files: pass 2 sees exactly the reads pass 1 saw."""
+    from soapdenovo2_amd import synth
+    from oracle_binding import Oracle
+    K, P = 31, 3
+    for name in synth.QUIRK_CASES:
+        cfg = synth.make_quirk_case(str(tmp_path), name)
+        codes, lens, _, mrl = api.host_read_all(cfg, K)
+        o = Oracle(K, P=P, max_read_len=mrl)
+        o.add_reads(codes, lens=lens)
+        o.finish_count(str(tmp_path / ("o_" + name)))
+        nd = o.nodes()
+        rec = np.zeros((len(nd["A"]), 4), dtype=np.uint64)
+        rec[:, :2] = nd["keys"]
+        rec[:, 2] = nd["A"].astype(np.uint64) | (nd["B"].astype(np.uint64) << np.uint64(32))
+        rec[:, 3] = (nd["set"].astype(np.uint64) << np.uint64(56)) | nd["ord"]
+        last = np.array(o.set_last_put(), dtype=np.uint64)
+        o.close()
+        pre = str(tmp_path / name)
+        api.host_pregraph_files(rec, last, codes, lens, K, P, pre, max_read_len=mrl)
+        assert md5_file(pre + ".preArc") == golden["md5"][name]["preArc"], name
+
+
+def test_contig_stage_accepts_our_files(golden, tmp_path):
+    """P3: the reference's unchanged `contig` stage on the files written by the host stages gives the same contigs as on
+    the reference's own pregraph output (needs oracle/_ref, which also travels to the GPU box)."""
+    import os, subprocess
+    from conftest import ROOT
+    ref = os.path.join(ROOT, "oracle", "_ref", "SOAPdenovo-63mer")
+    if not os.path.exists(ref):
+        pytest.skip("reference binary not built")
+    for name, run in (("t6k_k31", (8, 0, 0, 0)), ("t8k_k63", (2, 0, 0, 0))):
+        c = golden["cases"][name]
+        codes = case_codes(c)
+        P, D, a, m = run
+        t = case_tag(name, run)
+        rec, last, K = oracle_records(codes, c["K"], P, prefix=str(tmp_path / ("o_" + t)))
+        pre = str(tmp_path / t)
+        api.host_pregraph_files(rec, last, codes, None, K, P, pre, max_read_len=c["L"])
+        out = subprocess.run([ref, "contig", "-g", pre], capture_output=True, text=True)
+        assert out.returncode == 0, out.stderr[-500:]
+        assert md5_file(pre + ".contig") == golden["md5"][t]["contig"], t
