@@ -106,7 +106,9 @@ def main():
     ap.add_argument("--log2-slots", type=int, default=0, help="0 = size from the expected distinct count")
     ap.add_argument("--cpu-sample-reads", type=int, default=2_000_000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--engine", type=int, default=0, help="0 = 2 (partitions) on one GPU, 1 (global set) when routing across GPUs")
+    ap.add_argument("--engine", type=int, default=2, help="2 = super-k-mer partitions counted in LDS (default), 1 = one DRAM-resident set")
+    ap.add_argument("--comm", default="nccl", help="nccl (RCCL over xGMI) or gloo (test only: exchange staged through the host)")
+    ap.add_argument("--share-gpu", action="store_true", help="test only: every rank uses cuda:0")
     args = ap.parse_args()
 
     import torch
@@ -117,13 +119,28 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
+    if args.share_gpu:
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl", device_id=dev)
+        if args.comm == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group("gloo")
+
+    def a2a(out_t, in_t, out_splits, in_splits):
+        """variable-size all-to-all of int64/int32 device tensors (RCCL; gloo goes through host copies)"""
+        if args.comm == "nccl":
+            dist.all_to_all_single(out_t, in_t, out_splits, in_splits)
+        else:
+            o = torch.empty(out_t.shape, dtype=out_t.dtype)
+            dist.all_to_all_single(o, in_t.cpu(), out_splits, in_splits)
+            out_t.copy_(o)
 
     K, L, P = args.kmer, args.read_len, args.sets
     kpr = L - K + 1
+    kpr_w = K - max(7, min(13, K - 6)) + 1          # m-mers per k-mer (skm.hpp): a read makes about 2*kpr/(w+1) + 1 records
     n_reads = args.reads
     n_kmers = n_reads * kpr
     # expected distinct k-mers per GPU: genomic (<= genome) + error k-mers (~ K per error, capped by read geometry)
@@ -135,7 +152,7 @@ def main():
         while (1 << log2_slots) * 0.6 < expected:
             log2_slots += 1
     packed = gen_packed_reads(torch, dev, args.genome, n_reads, L, args.err, args.seed + 1000 * rank)
-    engine = args.engine or (2 if world == 1 else 1)
+    engine = args.engine
     kc = api.KmerCounter(K, n_sets=P, log2_slots=log2_slots, device=local, engine=engine)
     kc.set_autogrow(False)
     wpr = (L + 31) // 32
@@ -155,19 +172,34 @@ def main():
                 if timed:
                     e1.record()
                     ev.append((e0, e1, n))
+            elif engine == 2:
+                # partition engine across GPUs: owner(partition) = partition mod world; super-k-mer records travel
+                rw = kc.record_words()
+                cap = int(n * (2.0 * kpr / (kpr_w + 1) + 1) * 1.5 / world) + 1024
+                recs, parts, counts = kc.skm_route(view, n, L, ord0 + lo * kpr, world, cap)
+                recv_counts = torch.empty_like(counts)
+                a2a(recv_counts, counts, None, None)
+                sc, rc = counts.tolist(), recv_counts.tolist()
+                send_r = torch.cat([recs[o, :sc[o]].reshape(-1) for o in range(world)])
+                send_p = torch.cat([parts[o, :sc[o]] for o in range(world)])
+                in_r = torch.empty(sum(rc) * rw, dtype=torch.int64, device=dev)
+                in_p = torch.empty(sum(rc), dtype=torch.int32, device=dev)
+                a2a(in_r, send_r, [c * rw for c in rc], [c * rw for c in sc])
+                a2a(in_p, send_p, rc, sc)
+                kc.skm_ingest(in_r, in_p, sum(rc))
             else:
                 counts = kc.route_count(view, n, L, world)
                 off = torch.zeros(world + 1, dtype=torch.int64, device=dev)
                 off[1:] = torch.cumsum(counts, 0)
                 send_counts = counts.clone()
                 recv_counts = torch.empty_like(send_counts)
-                dist.all_to_all_single(recv_counts, send_counts)
+                a2a(recv_counts, send_counts, None, None)
                 sc, rc = send_counts.tolist(), recv_counts.tolist()
                 rw = kc.nw + 1
                 out = torch.empty(sum(sc) * rw, dtype=torch.int64, device=dev)
                 kc.route_scatter(view, n, L, ord0 + lo * kpr, world, off, out)
                 inp = torch.empty(sum(rc) * rw, dtype=torch.int64, device=dev)
-                dist.all_to_all_single(inp, out, [c * rw for c in rc], [c * rw for c in sc])
+                a2a(inp, out, [c * rw for c in rc], [c * rw for c in sc])
                 kc.count_records(inp, sum(rc))
         # -d filter + linear marking + coverage histogram (for the partition engine this is also where counting happens)
         if timed:
@@ -217,7 +249,8 @@ def main():
                        "distinct_kmers": distinct, "table_slots_log2": log2_slots,
                        "engine": engine,
                        "parallelism": ("single GPU, " + ("super-k-mer partitions counted in LDS" if engine == 2 else "fused extract+insert into one DRAM set"))
-                       if world == 1 else f"set-id owner partition, RCCL all-to-all x{world}"},
+                       if world == 1 else (f"partition-owner (partition mod {world}), super-k-mer records over RCCL all-to-all" if engine == 2
+                                           else f"set-id owner, k-mer records over RCCL all-to-all x{world}")},
         }
         if world == 1 and ev:
             slot_b = 48 if K <= 63 else 80

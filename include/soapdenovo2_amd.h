@@ -178,6 +178,18 @@ int pg_route_scatter(pg_ctx *ctx, const uint64_t *d_packed, const uint64_t *d_wo
 /* Multi-GPU path, step 2 (after the all-to-all): insert routed records into this rank's set. */
 int pg_count_records(pg_ctx *ctx, const uint64_t *d_records, uint64_t n_records, void *stream);
 
+/* Multi-GPU path of the partition engine (engine 2): what travels between GPUs is super-k-mer records (about one per
+ * 20 k-mers) instead of k-mer records.  owner(partition) = partition mod n_owners, so a rank owns whole partitions and
+ * counts them locally afterwards (pg_finalize); no other exchange is needed.
+ *   pg_skm_route   cut a uniform-length batch and write its records grouped by owner: owner o's records at
+ *                  d_send_records + o * capacity_per_owner * W words (W = pg_stats out[3] / 8) and their partition ids at
+ *                  d_send_parts + o * capacity_per_owner; d_counts[o] (zeroed by the call) = records for owner o.
+ *                  An owner region that overflows is reported as PG_ENOMEM by the next pg_finalize.
+ *   pg_skm_ingest  append records received from other ranks (and the rank's own share) to the local partition streams. */
+int pg_skm_route(pg_ctx *ctx, const uint64_t *d_packed, uint64_t n_reads, uint32_t uniform_len, uint64_t ord_base, int n_owners,
+                 uint64_t *d_send_records, uint32_t *d_send_parts, uint64_t capacity_per_owner, uint64_t *d_counts, void *stream);
+int pg_skm_ingest(pg_ctx *ctx, const uint64_t *d_records, const uint32_t *d_parts, uint64_t n_records, void *stream);
+
 /* Number of distinct k-mers stored so far (synchronises the stream). */
 int pg_distinct(pg_ctx *ctx, uint64_t *out, void *stream);
 /* Current capacity (slots) and bytes per slot of the device set. */

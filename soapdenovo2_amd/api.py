@@ -79,6 +79,8 @@ def lib() -> C.CDLL:
     L.pg_route_scatter.argtypes = [C.c_void_p, u64p, u64p, u64p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int,
                                    u64p, u64p, u64p, C.c_void_p]
     L.pg_count_records.argtypes = [C.c_void_p, u64p, C.c_uint64, C.c_void_p]
+    L.pg_skm_route.argtypes = [C.c_void_p, u64p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, u64p, u64p, C.c_uint64, u64p, C.c_void_p]
+    L.pg_skm_ingest.argtypes = [C.c_void_p, u64p, u64p, C.c_uint64, C.c_void_p]
     L.pg_distinct.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]
     L.pg_table_info.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
     L.pg_stats.argtypes = [C.c_void_p, u64p]
@@ -91,7 +93,7 @@ def lib() -> C.CDLL:
 EXPORTED_SYMBOLS = [
     "pg_last_error", "pg_version", "call_pregraph", "call_pregraph_127mer", "pg_packed_words", "pg_pack_read",
     "pg_host_build_graph", "pg_host_graph_begin", "pg_host_graph_add_reads", "pg_host_graph_finish", "pg_host_read_all", "pg_host_replay_layout", "pg_host_write_kmerfreq", "pg_create", "pg_create_engine", "pg_destroy", "pg_reset", "pg_set_autogrow", "pg_count_reads", "pg_route_count",
-    "pg_route_scatter", "pg_count_records", "pg_distinct", "pg_stats", "pg_table_info", "pg_finalize", "pg_export",
+    "pg_route_scatter", "pg_count_records", "pg_skm_route", "pg_skm_ingest", "pg_distinct", "pg_stats", "pg_table_info", "pg_finalize", "pg_export",
 ]
 
 
@@ -269,6 +271,23 @@ class KmerCounter:
         n_kmers = n_reads * (read_len - self.K + 1)
         _check(lib().pg_route_scatter(self.h, d_packed.data_ptr(), None, None, n_reads, read_len, n_kmers, ord_base, n_owners,
                                       owner_off.data_ptr(), cursor.data_ptr(), out.data_ptr(), self._stream()), "pg_route_scatter")
+
+    def record_words(self) -> int:
+        return 6 if self.nw == 2 else 8
+
+    def skm_route(self, d_packed, n_reads: int, read_len: int, ord_base: int, n_owners: int, cap: int):
+        """Engine 2, multi-GPU step 1 -> (records [n_owners, cap, W] int64, parts [n_owners, cap] int32, counts [n_owners] int64)."""
+        t = self.torch
+        dev = f"cuda:{self.device}"
+        recs = t.empty((n_owners, cap, self.record_words()), dtype=t.int64, device=dev)
+        parts = t.empty((n_owners, cap), dtype=t.int32, device=dev)
+        counts = t.zeros(n_owners, dtype=t.int64, device=dev)
+        _check(lib().pg_skm_route(self.h, d_packed.data_ptr(), n_reads, read_len, ord_base, n_owners, recs.data_ptr(), parts.data_ptr(),
+                                  cap, counts.data_ptr(), self._stream()), "pg_skm_route")
+        return recs, parts, counts
+
+    def skm_ingest(self, d_records, d_parts, n_records: int) -> None:
+        _check(lib().pg_skm_ingest(self.h, d_records.data_ptr(), d_parts.data_ptr(), n_records, self._stream()), "pg_skm_ingest")
 
     def count_records(self, d_records, n_records: int) -> None:
         _check(lib().pg_count_records(self.h, d_records.data_ptr(), n_records, self._stream()), "pg_count_records")

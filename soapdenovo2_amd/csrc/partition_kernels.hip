@@ -120,10 +120,13 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_kernel(ReadsArg a, E2Dev e,
 // Only E touches global memory besides the coalesced tile load.  Index arithmetic is 32-bit with multiply-high
 // reciprocals (the GPU has neither an integer divider nor a 64-bit multiplier).
 struct TileArg { int R, np, lv; uint32_t inv_np, inv_kpr, inv_wpr; };
+// multi-GPU: instead of appending to the local partition streams, records go to per-owner send regions (owner =
+// partition mod n_owners), `cap` records each, with the partition id alongside; cursor[o] counts what owner o gets.
+struct RouteArg { uint64_t* recs; uint32_t* pids; unsigned long long* cursor; uint64_t cap; int n_owners; };
 __device__ __forceinline__ uint32_t fastdiv(uint32_t i, uint32_t inv) { return __umulhi(i, inv); }
 
-template <int NW>
-__global__ __launch_bounds__(BLOCK) void skm_scatter_tiled_kernel(ReadsArg a, E2Dev e, DevCounters* ctr, TileArg ta) {
+template <int NW, bool ROUTE>
+__global__ __launch_bounds__(BLOCK) void skm_scatter_tiled_kernel(ReadsArg a, E2Dev e, DevCounters* ctr, TileArg ta, RouteArg ro) {
     constexpr int PW = E2Cfg<NW>::PW, RW = PW + 1;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int R = ta.R, np = ta.np, lv = ta.lv;
@@ -209,18 +212,61 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_tiled_kernel(ReadsArg a, E2
     }
     __syncthreads();
     const int total = (int)n_items;
+    __shared__ unsigned int ocnt[256];
+    __shared__ unsigned long long obase[256];
+    uint32_t* ranks = v0;                                          // the m-mer values are dead by now
+    if (ROUTE) {
+        ocnt[threadIdx.x] = 0;
+        __syncthreads();
+        for (int it = threadIdx.x; it < total; it += BLOCK) {
+            const uint32_t pk = items[it];
+            const uint32_t pid = pids[(int)(pk >> 24) * kpr + (int)((pk >> 12) & 0xFFF)];
+            ranks[it] = atomicAdd(&ocnt[pid % (uint32_t)ro.n_owners], 1u);
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < ro.n_owners && ocnt[threadIdx.x])
+            obase[threadIdx.x] = atomicAdd(&ro.cursor[threadIdx.x], (unsigned long long)ocnt[threadIdx.x]);
+        __syncthreads();
+    }
     for (int it = threadIdx.x; it < total; it += BLOCK) {
         const uint32_t pk = items[it];
         const int r = (int)(pk >> 24), j0 = (int)((pk >> 12) & 0xFFF), n = (int)(pk & 0xFFF);
         const uint32_t pid = pids[r * kpr + j0];
-        const uint32_t q = atomicAdd(&e.cursor[pid], 1u);
-        uint64_t* out = record_slot(e, pid, q, ctr, RW);
+        uint64_t* out;
+        if (ROUTE) {
+            const uint32_t o = pid % (uint32_t)ro.n_owners;
+            const unsigned long long at = obase[o] + ranks[it];
+            if (at >= ro.cap) { atomicOr(&ctr->e2_flags, F_POOL); continue; }
+            ro.pids[(uint64_t)o * ro.cap + at] = pid;
+            out = ro.recs + ((uint64_t)o * ro.cap + at) * RW;
+        } else {
+            const uint32_t q = atomicAdd(&e.cursor[pid], 1u);
+            out = record_slot(e, pid, q, ctr, RW);
+        }
         if (!out) continue;
         uint64_t rec[RW];
         skm_make_record<PW>(words + r * ws, len, j0, n, a.ord_base + (r0 + (uint64_t)r) * (uint64_t)kpr, e.g, rec);
         ulonglong2* o2 = (ulonglong2*)out;
 #pragma unroll
         for (int k = 0; k < RW / 2; k++) o2[k] = make_ulonglong2(rec[2 * k], rec[2 * k + 1]);
+    }
+}
+
+// multi-GPU, receiving side: append routed records to the local partition streams
+template <int NW>
+__global__ __launch_bounds__(BLOCK) void skm_ingest_kernel(const uint64_t* recs, const uint32_t* rpids, uint64_t n, E2Dev e, DevCounters* ctr) {
+    constexpr int RW = E2Cfg<NW>::PW + 1;
+    const uint32_t parts = 1u << e.g.log2_parts;
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
+        const uint32_t pid = rpids[i];
+        if (pid >= parts) { atomicOr(&ctr->e2_flags, F_CHUNKS); continue; }
+        const uint32_t q = atomicAdd(&e.cursor[pid], 1u);
+        uint64_t* out = record_slot(e, pid, q, ctr, RW);
+        if (!out) continue;
+        const ulonglong2* src = (const ulonglong2*)(recs + i * RW);
+        ulonglong2* o2 = (ulonglong2*)out;
+#pragma unroll
+        for (int k = 0; k < RW / 2; k++) o2[k] = src[k];
     }
 }
 
@@ -673,6 +719,68 @@ static int e2_ensure_pool(pg_ctx* c, uint64_t n_reads, uint64_t n_kmers, hipStre
     return PG_OK;
 }
 
+// launch the tiled K1; returns PG_OK / an error, or 1 when the reads are too long for a tile (caller falls back)
+static int launch_tiled(pg_ctx* c, const ReadsArg& a, const RouteArg* route, hipStream_t st) {
+    const int np = (int)a.uniform_len - c->e2.g.m + 1;
+    const size_t per_read = (size_t)(a.wpr + 1) * 8 + (size_t)((a.kpr + 63) / 64) * 8 + (size_t)np * 8 + (size_t)a.kpr * 8;
+    int R = (int)std::min<size_t>(8, (56 * 1024) / per_read);          // small tiles: many resident workgroups hide the LDS / atomic latency
+    if (const char* v = getenv("PG_K1_R")) R = std::max(1, std::min(atoi(v), (int)((56 * 1024) / per_read)));
+    if (R < 1) return 1;
+    int lv = 0;
+    while ((2 << lv) <= c->e2.g.w) lv++;
+    const uint64_t grid = (a.n_reads + R - 1) / R;
+    if (grid > 0x7FFFFFFFULL) { pg_set_error("batch too large for one launch"); return PG_EINVAL; }
+    const size_t smem = per_read * R;
+    auto inv = [](uint32_t d) { return (uint32_t)(((1ULL << 32) + d - 1) / d); };
+    TileArg ta{R, np, lv, inv((uint32_t)np), inv(a.kpr), inv(a.wpr)};
+    RouteArg ro{nullptr, nullptr, nullptr, 0, 1};
+    if (route) ro = *route;
+    if (c->NW == 2) {
+        if (route) hipLaunchKernelGGL((skm_scatter_tiled_kernel<2, true>), dim3((unsigned)grid), dim3(BLOCK), smem, st, a, dev_view(c), c->ctr, ta, ro);
+        else hipLaunchKernelGGL((skm_scatter_tiled_kernel<2, false>), dim3((unsigned)grid), dim3(BLOCK), smem, st, a, dev_view(c), c->ctr, ta, ro);
+    } else {
+        if (route) hipLaunchKernelGGL((skm_scatter_tiled_kernel<4, true>), dim3((unsigned)grid), dim3(BLOCK), smem, st, a, dev_view(c), c->ctr, ta, ro);
+        else hipLaunchKernelGGL((skm_scatter_tiled_kernel<4, false>), dim3((unsigned)grid), dim3(BLOCK), smem, st, a, dev_view(c), c->ctr, ta, ro);
+    }
+    E2_TRY(hipGetLastError());
+    c->e2.counted = false;
+    return PG_OK;
+}
+
+// multi-GPU step 1: cut a uniform batch into records grouped by owner (partition mod n_owners)
+int e2_route(pg_ctx* c, const uint64_t* d_packed, uint64_t n_reads, uint32_t uniform_len, uint64_t ord_base, int n_owners,
+             uint64_t* d_recs, uint32_t* d_pids, uint64_t cap, uint64_t* d_counts, hipStream_t st) {
+    if (!uniform_len || uniform_len >= 4096) { pg_set_error("pg_skm_route needs a uniform-length batch"); return PG_EINVAL; }
+    if ((ord_base >> (64 - SKM_ORD_SHIFT)) != 0) { pg_set_error("ordinal exceeds the 46 bits of a super-k-mer header"); return PG_EINVAL; }
+    ReadsArg a;
+    a.packed = d_packed; a.word_off = nullptr; a.kmer_base = nullptr; a.n_reads = n_reads; a.uniform_len = uniform_len;
+    a.kpr = uniform_len - c->K + 1; a.wpr = (uniform_len + 31) / 32; a.ord_base = ord_base;
+    E2_TRY(hipMemsetAsync(d_counts, 0, sizeof(uint64_t) * n_owners, st));
+    RouteArg ro{d_recs, d_pids, (unsigned long long*)d_counts, cap, n_owners};
+    int rc = launch_tiled(c, a, &ro, st);
+    if (rc == 1) { pg_set_error("reads too long for the tiled kernel"); return PG_EINVAL; }
+    return rc;
+}
+
+// multi-GPU step 2: take records another rank cut for this rank's partitions
+int e2_ingest(pg_ctx* c, const uint64_t* d_recs, const uint32_t* d_pids, uint64_t n, hipStream_t st) {
+    if (n == 0) return PG_OK;
+    E2& s = c->e2;
+    if (c->autogrow) {                       // room for n more records (+ one open chunk per partition is already counted)
+        s.est_chunks += n / s.rpc + 1;
+        if (s.est_chunks + ((uint64_t)1 << s.log2_parts) + 16 > s.pool_chunks) {
+            int rc = e2_ensure_pool(c, 0, 0, st);
+            if (rc) return rc;
+        }
+    }
+    const unsigned grid = (unsigned)std::min<uint64_t>((n + BLOCK - 1) / BLOCK, 1u << 20);
+    if (c->NW == 2) hipLaunchKernelGGL(skm_ingest_kernel<2>, dim3(grid), dim3(BLOCK), 0, st, d_recs, d_pids, n, dev_view(c), c->ctr);
+    else hipLaunchKernelGGL(skm_ingest_kernel<4>, dim3(grid), dim3(BLOCK), 0, st, d_recs, d_pids, n, dev_view(c), c->ctr);
+    E2_TRY(hipGetLastError());
+    s.counted = false;
+    return PG_OK;
+}
+
 int e2_scatter(pg_ctx* c, const uint64_t* d_packed, const uint64_t* d_word_off, const uint64_t* d_kmer_base, uint64_t n_reads,
                uint32_t uniform_len, uint64_t n_kmers_hint, uint64_t ord_base, hipStream_t st) {
     {
@@ -686,28 +794,12 @@ int e2_scatter(pg_ctx* c, const uint64_t* d_packed, const uint64_t* d_word_off, 
     a.kpr = uniform_len ? uniform_len - c->K + 1 : 0;
     a.wpr = uniform_len ? (uniform_len + 31) / 32 : 0;
     a.ord_base = ord_base;
-    // tiled kernel for uniform batches whose per-read LDS footprint allows at least 4 reads per workgroup
+    // tiled kernel for uniform batches whose per-read LDS footprint fits
     int tiled = uniform_len && uniform_len < 4096 && (int)a.kpr < 4096;
     if (const char* v = getenv("PG_K1")) tiled = tiled && atoi(v) != 0;
     if (tiled) {
-        const int np = (int)uniform_len - c->e2.g.m + 1;
-        const size_t per_read = (size_t)(a.wpr + 1) * 8 + (size_t)((a.kpr + 63) / 64) * 8 + (size_t)np * 8 + (size_t)a.kpr * 8;
-        int R = (int)std::min<size_t>(8, (56 * 1024) / per_read);          // small tiles: many resident workgroups hide the LDS / atomic latency
-        if (const char* v = getenv("PG_K1_R")) R = std::max(1, std::min(atoi(v), (int)((56 * 1024) / per_read)));
-        if (R >= 1) {
-            int lv = 0;
-            while ((2 << lv) <= c->e2.g.w) lv++;
-            const uint64_t grid = (n_reads + R - 1) / R;
-            if (grid > 0x7FFFFFFFULL) { pg_set_error("batch too large for one launch"); return PG_EINVAL; }
-            const size_t smem = per_read * R;
-            auto inv = [](uint32_t d) { return (uint32_t)(((1ULL << 32) + d - 1) / d); };
-            TileArg ta{R, np, lv, inv((uint32_t)np), inv(a.kpr), inv(a.wpr)};
-            if (c->NW == 2) hipLaunchKernelGGL(skm_scatter_tiled_kernel<2>, dim3((unsigned)grid), dim3(BLOCK), smem, st, a, dev_view(c), c->ctr, ta);
-            else hipLaunchKernelGGL(skm_scatter_tiled_kernel<4>, dim3((unsigned)grid), dim3(BLOCK), smem, st, a, dev_view(c), c->ctr, ta);
-            E2_TRY(hipGetLastError());
-            c->e2.counted = false;
-            return PG_OK;
-        }
+        int rc = launch_tiled(c, a, nullptr, st);
+        if (rc != 1) return rc;
     }
     const uint64_t grid = (n_reads + BLOCK - 1) / BLOCK;
     if (grid > 0x7FFFFFFFULL) { pg_set_error("batch too large for one launch"); return PG_EINVAL; }

@@ -743,6 +743,24 @@ extern "C" int pg_distinct(pg_ctx* c, uint64_t* out, void* stream) {
     return PG_OK;
 }
 
+extern "C" int pg_skm_route(pg_ctx* c, const uint64_t* d_packed, uint64_t n_reads, uint32_t uniform_len, uint64_t ord_base, int n_owners,
+                            uint64_t* d_send_records, uint32_t* d_send_parts, uint64_t capacity_per_owner, uint64_t* d_counts, void* stream) {
+    if (!c || !d_packed || !d_send_records || !d_send_parts || !d_counts) { g_err = "null argument"; return PG_EINVAL; }
+    if (c->engine != 2) { g_err = "pg_skm_route needs the partition engine"; return PG_ESTATE; }
+    if (n_owners < 1 || n_owners > 256) { g_err = "bad n_owners"; return PG_EINVAL; }
+    HIP_TRY(hipSetDevice(c->device));
+    return e2_route(c, d_packed, n_reads, uniform_len, ord_base, n_owners, d_send_records, d_send_parts, capacity_per_owner, d_counts,
+                    (hipStream_t)stream);
+}
+
+extern "C" int pg_skm_ingest(pg_ctx* c, const uint64_t* d_records, const uint32_t* d_parts, uint64_t n_records, void* stream) {
+    if (!c || ((!d_records || !d_parts) && n_records)) { g_err = "null argument"; return PG_EINVAL; }
+    if (c->engine != 2) { g_err = "pg_skm_ingest needs the partition engine"; return PG_ESTATE; }
+    if (c->finalized) { g_err = "pg_skm_ingest after pg_finalize"; return PG_ESTATE; }
+    HIP_TRY(hipSetDevice(c->device));
+    return e2_ingest(c, d_records, d_parts, n_records, (hipStream_t)stream);
+}
+
 extern "C" int pg_stats(pg_ctx* c, uint64_t out[8]) {
     if (!c || !out) { g_err = "null argument"; return PG_EINVAL; }
     HIP_TRY(hipSetDevice(c->device));

@@ -139,6 +139,37 @@ def test_route_then_count_equals_fused(golden, tmp_path):
     assert (np.maximum(lasts[0], lasts[1]) == last_want).all()
 
 
+def test_skm_route_then_ingest_equals_local(golden, tmp_path):
+    """The multi-GPU data path of the partition engine on one GPU: cut + route to 3 owners, ingest each owner's records
+    into its own context; owners must partition the partitions and the union must equal the oracle."""
+    import torch
+    from soapdenovo2_amd import api
+    c = golden["cases"]["t8k_k63"]
+    codes = case_codes(c)
+    K, P, L, n = c["K"], 8, c["L"], codes.shape[0]
+    want, last_want, _ = oracle_records(codes, K, P, prefix=str(tmp_path / "o"))
+    packed = torch.from_numpy(api.pack_reads_uniform(codes).view(np.int64)).cuda()
+    owners = 3
+    router = api.KmerCounter(K, n_sets=P, log2_slots=18, engine=2)
+    recs, parts, counts = router.skm_route(packed, n, L, 0, owners, 40000)
+    torch.cuda.synchronize()
+    cn = counts.tolist()
+    assert n <= sum(cn) <= n * (L - K + 1) and max(cn) < 40000
+    got, lasts = [], []
+    for o in range(owners):
+        assert bool((parts[o, :cn[o]] % owners == o).all())
+        kc = api.KmerCounter(K, n_sets=P, log2_slots=18, engine=2)
+        kc.skm_ingest(recs[o, :cn[o]].contiguous(), parts[o, :cn[o]].contiguous(), cn[o])
+        _, last = kc.finalize(0)
+        got.append(kc.export())
+        lasts.append(last)
+        kc.close()
+    router.close()
+    allrec = np.concatenate(got)
+    assert (_sorted(allrec, 2) == _sorted(want, 2)).all()
+    assert (np.maximum.reduce(lasts) == last_want).all()
+
+
 def _run_cli(cfg, K, prefix, P, D, a, m, engine=None):
     from soapdenovo2_amd import api
     env = dict(os.environ)
