@@ -19,6 +19,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -721,15 +722,22 @@ static GraphHandleBase* graph_begin(const uint64_t* records, uint64_t n, const u
     GraphHandle<NW>* h = new GraphHandle<NW>();
     h->prefix = prefix_c;
     h->max_read_len = max_read_len;
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    double t0 = now();
     if (replay_layout<NW>(h->g, records, n, set_last_put, K, P, a_gb, n_threads) != PG_OK) { delete h; return nullptr; }
+    fprintf(stderr, "Time spent on rebuilding the k-mer set layout: %.1fs.\n", now() - t0);
+    t0 = now();
     if (cut_single) h->g.remove_single_tips();
     h->g.remove_minor_tips();
+    fprintf(stderr, "Time spent on removing tips: %.1fs.\n\n", now() - t0);
+    t0 = now();
     GzText gz;
     if (!gz.open(h->prefix + ".edge.gz")) { pg_set_error("cannot open " + h->prefix + ".edge.gz"); delete h; return nullptr; }
     EdgeBuilder<NW> eb(h->g, gz);
     eb.run();
     gz.close();
     fprintf(stderr, "%d (%lld) edge(s) and %lld extra node(s) constructed.\n", eb.edge_c, eb.records, eb.extra_nodes);
+    fprintf(stderr, "Time spent on constructing edges: %.1fs.\n\n", now() - t0);
     h->num_ed = eb.edge_c;
     h->arcs.init((uint32_t)eb.edge_c);
     return h;
