@@ -272,18 +272,28 @@ __global__ __launch_bounds__(BLOCK) void skm_ingest_kernel(const uint64_t* recs,
 
 // ---- the LDS set ---------------------------------------------------------------------------------------------
 // Struct of arrays, so lanes that hit different slots hit different banks: key[KW][SLOTS] (63-bit words), ord[SLOTS],
-// cnt[9][SLOTS] (u32: L[4], R[4], puts).  Keys and ord start as ~0, counters as 0.  A slot is claimed key word by key
-// word: an empty word is taken with CAS(~0 -> mine), a word holding something else means another key owns the slot.
-// Counting is plain atomic adds, saturated when the node is emitted: a sum of +1's clipped at the end equals the
-// reference's saturating increments (newhash.c:74-106) and, unlike a CAS on packed counters, needs no retry when many
-// lanes hit one hot k-mer.  `single` = exactly one put (newhash.c:127,511).
+// ca[SLOTS], cb[SLOTS].  Keys and ord start as ~0, counters as 0.  A slot is claimed key word by key word: an empty
+// word is taken with CAS(~0 -> mine), a word holding something else means another key owns the slot.
+// Counters: 12-bit fields, ca = L0 | L1<<12 | L2<<24 | L3<<36 | R0<<48, cb = R1 | R2<<12 | R3<<24 | puts<<36, so one
+// occurrence is exactly two 64-bit atomic adds (LDS atomics are the scarce resource of this kernel).  An arc field is
+// only incremented while the lane's (possibly stale) snapshot shows it below 64: the true value can then overshoot
+// 63 by at most the number of lanes in flight (1024) and never reaches 4096; it is clipped to 63 when the node is
+// emitted, which is what the reference's saturating increments give (newhash.c:74-106).  puts has 28 bits and is
+// clipped to 255; `single` = exactly one put (newhash.c:127,511).  Plain adds need no retry when many lanes hit one
+// hot k-mer, unlike a CAS on the reference's packed words.
 template <int NW, int SLOTS>
 struct LdsSet {
     static constexpr int KW = E2Cfg<NW>::KW;
     unsigned long long key[KW][SLOTS];
     unsigned long long ord[SLOTS];
-    unsigned int cnt[9][SLOTS];
+    unsigned long long ca[SLOTS];
+    unsigned long long cb[SLOTS];
 };
+constexpr int CNT_PUTS_SHIFT = 36;
+__device__ __forceinline__ uint32_t cnt_L(unsigned long long ca, int i) { return (uint32_t)(ca >> (12 * i)) & 0xFFFu; }
+__device__ __forceinline__ uint32_t cnt_R(unsigned long long ca, unsigned long long cb, int i) {
+    return i == 0 ? (uint32_t)(ca >> 48) & 0xFFFu : (uint32_t)(cb >> (12 * (i - 1))) & 0xFFFu;
+}
 
 // Returns false when the set is too full (a probe sequence longer than MAXPROBE): the caller aborts the attempt and
 // splits the key range.  No shared key counter on this path -- a same-address LDS atomic per new key serialises the
@@ -306,10 +316,13 @@ __device__ __forceinline__ bool lds_put(LdsSet<NW, SLOTS>& t, const Key63<NW>& k
             mine = cur == key.w[i];
         }
         if (mine) {
-            if (left < 4) atomicAdd(&t.cnt[left][h], 1u);
-            if (right < 4) atomicAdd(&t.cnt[4 + right][h], 1u);
-            atomicAdd(&t.cnt[8][h], 1u);
-            atomicMin(&t.ord[h], (unsigned long long)ord);
+            const unsigned long long sa = t.ca[h], sb = t.cb[h];             // snapshots, only used to stop counting past 63
+            unsigned long long da = 0, db = 1ULL << CNT_PUTS_SHIFT;
+            if (left < 4 && cnt_L(sa, left) < 64u) da += 1ULL << (12 * left);
+            if (right < 4 && cnt_R(sa, sb, right) < 64u) { if (right == 0) da += 1ULL << 48; else db += 1ULL << (12 * (right - 1)); }
+            if (da) atomicAdd(&t.ca[h], da);
+            atomicAdd(&t.cb[h], db);
+            if (ord < t.ord[h]) atomicMin(&t.ord[h], (unsigned long long)ord);
             return true;
         }
         h = (h + 1) & (SLOTS - 1);
@@ -378,8 +391,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
 #pragma unroll
                     for (int q = 0; q < KW; q++) set.key[q][i] = L_EMPTY;
                     set.ord[i] = L_EMPTY;
-#pragma unroll
-                    for (int q = 0; q < 9; q++) set.cnt[q][i] = 0;
+                    set.ca[i] = 0; set.cb[i] = 0;
                 }
                 dirty = false;
             }
@@ -478,7 +490,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
 #pragma unroll
             for (int st = 0; st < STRIPES; st++) {
                 const int si = st * THREADS + threadIdx.x;
-                live[st] = si < SLOTS && set.cnt[8][si] != 0;          // a put is only counted once every key word is claimed
+                live[st] = si < SLOTS && (set.cb[si] >> CNT_PUTS_SHIFT) != 0;   // a put is only counted once every key word is claimed
                 bal[st] = __ballot(live[st]);
                 if (lane == 0) wave_cnt[st][wave] = (unsigned int)__popcll(bal[st]);
             }
@@ -505,7 +517,8 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 cov_bin[st] = 0;                                          // 0 = not live (a live node has cov >= 1)
                 if (live[st]) {
                     const int si = st * THREADS + threadIdx.x;
-                    const unsigned int puts = set.cnt[8][si];
+                    const unsigned long long qa = set.ca[si], qb = set.cb[si];
+                    const unsigned int puts = (unsigned int)(qb >> CNT_PUTS_SHIFT);
                     Key63<NW> k63;
 #pragma unroll
                     for (int w = 0; w < KW; w++) k63.w[w] = set.key[w][si];
@@ -514,7 +527,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     int nin = 0, nout = 0;
 #pragma unroll
                     for (int c = 0; c < 4; c++) {                               // saturate, then thread_delow + thread_mark
-                        uint32_t l = min(set.cnt[c][si], 63u), r = min(set.cnt[4 + c][si], 63u);
+                        uint32_t l = min(cnt_L(qa, c), 63u), r = min(cnt_R(qa, qb, c), 63u);
                         if (D > 0 && l <= (uint32_t)D) l = 0;
                         if (D > 0 && r <= (uint32_t)D) r = 0;
                         A |= l << (6 * c); B |= r << (6 * c);
@@ -531,8 +544,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
 #pragma unroll
                     for (int w = 0; w < KW; w++) set.key[w][si] = L_EMPTY;
                     set.ord[si] = L_EMPTY;
-#pragma unroll
-                    for (int c = 0; c < 9; c++) set.cnt[c][si] = 0;
+                    set.ca[si] = 0; set.cb[si] = 0;
                 }
                 // coverage histogram: most nodes of a partition share one or two coverage values (1 for error k-mers),
                 // so count those per wave instead of hammering one LDS word
@@ -541,219 +553,6 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 if (cov_bin[st] > 1) atomicAdd(&hist[cov_bin[st]], 1u);
             }
             __syncthreads();                                              // out_base is in; the set may be cleared after this
-            const unsigned long long ob = out_base;
-#pragma unroll
-            for (int st = 0; st < STRIPES; st++) {
-                if (live[st]) {
-                    const uint64_t pos = ob + off[st];
-                    if (pos < e.out_capacity) {
-                        uint64_t* o = e.out + pos * (NW + 2);
-#pragma unroll
-                        for (int w = 0; w < NW + 2; w++) o[w] = rec_out[st][w];
-                    } else atomicOr(&ctr->e2_flags, F_OUT);
-                }
-            }
-        }
-    }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 256; i += THREADS) if (hist[i]) atomicAdd(&ctr->hist[i], (unsigned long long)hist[i]);
-    if (threadIdx.x == 0 && my_records) atomicAdd(&ctr->n_records, my_records);
-}
-
-// K2, batched form.  A workgroup owns a contiguous range of partitions and takes them several at a time: as many
-// consecutive partitions as together have <= THREADS records (k-mers of different partitions are different keys, so
-// they can share one LDS set).  One lane per record: it pulls its record (three 16-byte loads), builds the first
-// k-mer by window extraction and then rolls through the run (nextKmer / prevKmer), inserting as it goes.  Runs are cut
-// at 32 k-mers by K1 so lanes stay balanced.  Compared with the one-partition-at-a-time form this spends its barriers,
-// its global round trips and its emit scan on ~5x more k-mers, and the emit finds most slots live.
-// Overflow (probe too long): a multi-partition batch is halved; a single partition is split on a hash bit.
-template <int NW, int SLOTS, int THREADS>
-__global__ __launch_bounds__(THREADS) void skm_count_batched_kernel(E2Dev e, int D, SetParams sp, DevCounters* ctr, int dbg) {
-    constexpr int PW = E2Cfg<NW>::PW, RW = PW + 1, KW = E2Cfg<NW>::KW, NWAVE = THREADS / 64, STRIPES = (SLOTS + THREADS - 1) / THREADS;
-    constexpr int MAXB = 32;                                              // partitions per batch
-    __shared__ LdsSet<NW, SLOTS> set;
-    __shared__ unsigned int hist[256];
-    __shared__ unsigned int b_pid0, b_n, b_off[MAXB + 1];                  // batch: partitions b_pid0 .. b_pid0 + b_n - 1, record prefix sums
-    __shared__ unsigned int aborted, sp_top, s_lo[48], s_hi[48], s_mask[48], s_val[48], c_lo, c_hi, c_mask, c_val, wave_cnt[STRIPES][NWAVE];
-    __shared__ unsigned long long out_base;
-    for (int i = threadIdx.x; i < 256; i += THREADS) hist[i] = 0;
-    const Kmer<NW> filter = kmer_filter<NW>(e.g.K);
-    const int K = e.g.K;
-    const uint32_t parts = 1u << e.g.log2_parts;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    // contiguous partition range of this workgroup
-    const uint32_t per = (parts + gridDim.x - 1) / gridDim.x;
-    const uint32_t p_begin = min(parts, blockIdx.x * per), p_end = min(parts, p_begin + per);
-    unsigned long long my_records = 0;
-    bool dirty = true;
-    uint32_t p_next = p_begin;
-    while (p_next < p_end) {
-        __syncthreads();
-        // ---- form the batch (wave 0): consecutive partitions while the records fit one pass of the workgroup
-        if (wave == 0) {
-            uint32_t n = 0, q = p_next + lane;
-            if (lane < MAXB && q < p_end) n = min(e.cursor[q], e.maxc * e.rpc);
-            unsigned int incl = n;
-#pragma unroll
-            for (int d = 1; d < 64; d <<= 1) { const unsigned int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
-            // partitions 0..m-1 fit if their inclusive sum <= THREADS; always take at least one
-            const unsigned long long fits = __ballot(lane < MAXB && q < p_end && (incl <= (unsigned)THREADS || lane == 0));
-            const int m = __ffsll((long long)~fits) - 1;                  // first lane that does not fit
-            if (lane < MAXB) b_off[lane + 1] = incl;
-            if (lane == 0) { b_off[0] = 0; b_pid0 = p_next; b_n = (unsigned)m; sp_top = 1; s_lo[0] = 0; s_hi[0] = (unsigned)m; s_mask[0] = 0; s_val[0] = 0; }
-        }
-        __syncthreads();
-        const uint32_t pid0 = b_pid0, bn = b_n;
-        p_next = pid0 + bn;
-        my_records += b_off[bn];
-        if (b_off[bn] == 0) continue;
-        while (sp_top > 0) {
-            __syncthreads();
-            if (threadIdx.x == 0) { sp_top--; c_lo = s_lo[sp_top]; c_hi = s_hi[sp_top]; c_mask = s_mask[sp_top]; c_val = s_val[sp_top]; aborted = 0; }
-            if (dirty) {
-                for (int i = threadIdx.x; i < SLOTS; i += THREADS) {
-#pragma unroll
-                    for (int q = 0; q < KW; q++) set.key[q][i] = L_EMPTY;
-                    set.ord[i] = L_EMPTY;
-#pragma unroll
-                    for (int q = 0; q < 9; q++) set.cnt[q][i] = 0;
-                }
-                dirty = false;
-            }
-            __syncthreads();
-            const uint32_t lo = c_lo, hi = c_hi, mask = c_mask, val = c_val;
-            const uint32_t g_lo = b_off[lo], g_hi = b_off[hi];              // record range of this attempt in batch numbering
-            volatile unsigned int* abort_flag = &aborted;
-            for (uint32_t w0 = g_lo; w0 < g_hi && !*abort_flag; w0 += THREADS) {
-                const uint32_t g = w0 + threadIdx.x;
-                if (g < g_hi) {
-                    uint32_t q = lo;                                       // partition of record g
-                    while (b_off[q + 1] <= g) q++;
-                    const uint32_t ri = g - b_off[q], pid = pid0 + q;
-                    const uint32_t cid = e.chunk_tbl[(uint64_t)pid * e.maxc + ri / e.rpc];
-                    if (cid != 0 && cid != 0xFFFFFFFFu) {
-                        const ulonglong2* src = (const ulonglong2*)(e.pool + ((uint64_t)(cid - 1) * e.rpc + ri % e.rpc) * (uint64_t)RW);
-                        uint64_t rw[RW];
-#pragma unroll
-                        for (int k = 0; k < RW / 2; k++) { const ulonglong2 v = src[k]; rw[2 * k] = v.x; rw[2 * k + 1] = v.y; }
-                        const uint64_t hdr = rw[0];
-                        const int n = skm_n(hdr), hl = skm_has_left(hdr), nb = skm_record_bases(hdr, K);
-                        const uint64_t ord0 = skm_ord(hdr);
-                        // base p of the record from the register copy (select chain instead of an indexed array)
-                        auto base_at = [&](int p) -> int {
-                            uint64_t w = rw[1];
-#pragma unroll
-                            for (int k = 1; k < PW; k++) if ((p >> 5) == k) w = rw[1 + k];
-                            return (int)((w >> (62 - 2 * (p & 31))) & 3);
-                        };
-                        // first k-mer: bases [hl, hl + K)
-                        Kmer<NW> word, bal;
-#pragma unroll
-                        for (int i = 0; i < NW; i++) word.w[i] = 0;
-                        for (int p = hl; p < hl + K; p++) word = kmer_next<NW>(word, base_at(p), filter);
-                        bal = kmer_rc<NW>(word, K);
-                        bool full = false;
-                        for (int t = 0; t < n; t++) {
-                            const int j = hl + t;
-                            if (t > 0) kmer_roll<NW>(word, bal, base_at(j + K - 1), K, filter);
-                            Occurrence occ;
-                            const Kmer<NW> key = canonical_pair<NW>(word, bal, j > 0 ? base_at(j - 1) : 4, j < nb - K ? base_at(j + K) : 4, occ);
-                            const uint64_t hh = kmer_mix<NW>(key);
-                            if (((uint32_t)(hh >> 32) & mask) != val) continue;
-                            if (dbg & 1) { if (hh == 0x1234) full = true; continue; }
-                            if (!lds_put<NW, SLOTS>(set, key63_from_kmer<NW>(key), hh, occ.left, occ.right, ord0 + (uint64_t)t)) { full = true; break; }
-                        }
-                        if (full) aborted = 1;
-                    }
-                }
-            }
-            __syncthreads();
-            if (aborted) {
-                if (threadIdx.x == 0) {
-                    if (sp_top + 2 > 48) atomicOr(&ctr->e2_flags, F_SPLIT);
-                    else if (hi - lo > 1) {                                // halve the batch
-                        const uint32_t mid = (lo + hi) >> 1;
-                        s_lo[sp_top] = mid; s_hi[sp_top] = hi; s_mask[sp_top] = mask; s_val[sp_top] = val; sp_top++;
-                        s_lo[sp_top] = lo; s_hi[sp_top] = mid; s_mask[sp_top] = mask; s_val[sp_top] = val; sp_top++;
-                    } else {                                                // one partition: split its keys on the next hash bit
-                        const uint32_t bit = mask + 1;
-                        if (bit >= (1u << 24)) atomicOr(&ctr->e2_flags, F_SPLIT);
-                        else {
-                            s_lo[sp_top] = lo; s_hi[sp_top] = hi; s_mask[sp_top] = mask | bit; s_val[sp_top] = val; sp_top++;
-                            s_lo[sp_top] = lo; s_hi[sp_top] = hi; s_mask[sp_top] = mask | bit; s_val[sp_top] = val | bit; sp_top++;
-                        }
-                    }
-                }
-                dirty = true;
-                __syncthreads();
-                continue;
-            }
-            // ---- emit (same as the one-partition form)
-            bool live[STRIPES];
-            unsigned long long bal_m[STRIPES];
-#pragma unroll
-            for (int st = 0; st < STRIPES; st++) {
-                const int si = st * THREADS + threadIdx.x;
-                live[st] = si < SLOTS && set.cnt[8][si] != 0;
-                bal_m[st] = __ballot(live[st]);
-                if (lane == 0) wave_cnt[st][wave] = (unsigned int)__popcll(bal_m[st]);
-            }
-            __syncthreads();
-            if (threadIdx.x == 0) {
-                unsigned int tot = 0;
-                for (int st = 0; st < STRIPES; st++) for (int wv = 0; wv < NWAVE; wv++) tot += wave_cnt[st][wv];
-                out_base = atomicAdd(&ctr->n_export, (unsigned long long)tot);
-            }
-            uint64_t rec_out[STRIPES][NW + 2];
-            unsigned int off[STRIPES], cov_bin[STRIPES];
-            unsigned int running = 0;
-#pragma unroll
-            for (int st = 0; st < STRIPES; st++) {
-                unsigned int before = 0, total = 0;
-#pragma unroll
-                for (int wv = 0; wv < NWAVE; wv++) {
-                    const unsigned int cw = wave_cnt[st][wv];
-                    if (wv < wave) before += cw;
-                    total += cw;
-                }
-                off[st] = running + before + (unsigned int)__popcll(bal_m[st] & ((1ULL << lane) - 1));
-                running += total;
-                cov_bin[st] = 0;
-                if (live[st]) {
-                    const int si = st * THREADS + threadIdx.x;
-                    const unsigned int puts = set.cnt[8][si];
-                    Key63<NW> k63;
-#pragma unroll
-                    for (int w = 0; w < KW; w++) k63.w[w] = set.key[w][si];
-                    const Kmer<NW> key = kmer_from_key63<NW>(k63);
-                    uint32_t A = min(puts, 255u) << 24, B = puts == 1 ? B_SINGLE : 0u;
-                    int nin = 0, nout = 0;
-#pragma unroll
-                    for (int c = 0; c < 4; c++) {
-                        uint32_t l = min(set.cnt[c][si], 63u), r = min(set.cnt[4 + c][si], 63u);
-                        if (D > 0 && l <= (uint32_t)D) l = 0;
-                        if (D > 0 && r <= (uint32_t)D) r = 0;
-                        A |= l << (6 * c); B |= r << (6 * c);
-                        nin += l > 0; nout += r > 0;
-                    }
-                    if (D > 0 && nin == 0 && nout == 0) B |= B_DELETED;
-                    if (nin == 1 && nout == 1) B |= B_LINEAR;
-                    cov_bin[st] = A >> 24;
-#pragma unroll
-                    for (int w = 0; w < NW; w++) rec_out[st][w] = key.w[w];
-                    rec_out[st][NW] = (uint64_t)A | ((uint64_t)B << 32);
-                    rec_out[st][NW + 1] = set.ord[si] & PG_ORD_MASK;
-#pragma unroll
-                    for (int w = 0; w < KW; w++) set.key[w][si] = L_EMPTY;
-                    set.ord[si] = L_EMPTY;
-#pragma unroll
-                    for (int c = 0; c < 9; c++) set.cnt[c][si] = 0;
-                }
-                const unsigned long long ones = __ballot(cov_bin[st] == 1);
-                if (lane == 0 && ones) atomicAdd(&hist[1], (unsigned int)__popcll(ones));
-                if (cov_bin[st] > 1) atomicAdd(&hist[cov_bin[st]], 1u);
-            }
-            __syncthreads();
             const unsigned long long ob = out_base;
 #pragma unroll
             for (int st = 0; st < STRIPES; st++) {
@@ -1039,11 +838,7 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     if (const char* v = getenv("PG_K2CFG")) cfg = atoi(v);
     // cfg 0: 2048-slot set, 1024 lanes, 512-record windows  -> ~150 KB LDS, one workgroup per CU
     // cfg 1: 1024-slot set,  512 lanes, 256-record windows  ->  ~77 KB LDS, two workgroups per CU
-    if (cfg == 2) {
-        // batched form: several partitions per pass, one lane per record
-        if (c->NW == 2) hipLaunchKernelGGL((skm_count_batched_kernel<2, 2048, 1024>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, c->ctr, dbg);
-        else hipLaunchKernelGGL((skm_count_batched_kernel<4, 1024, 1024>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, c->ctr, dbg);
-    } else if (c->NW == 2) {
+    if (c->NW == 2) {
         if (cfg == 0) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, c->ctr, dbg);
         else hipLaunchKernelGGL((skm_count_kernel<2, 1024, 512, 256>), dim3(grid), dim3(512), 0, st, dev_view(c), delow, sp, c->ctr, dbg);
     } else {

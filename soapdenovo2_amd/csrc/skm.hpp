@@ -37,7 +37,6 @@ PG_HD SkmGeom skm_geometry(int K, int log2_parts, int nw = 2) {
     g.pw = nw == 2 ? 5 : 7;                       // 160 / 224 bases per record
     g.rw = 1 + g.pw;
     g.nmax = 32 * g.pw - (K - 1) - 2;             // leaves room for both flanks
-    if (g.nmax > 32) g.nmax = 32;                 // short runs keep the one-lane-per-record counting kernel balanced
     g.log2_parts = log2_parts;
     return g;
 }
