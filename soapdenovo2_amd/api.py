@@ -45,10 +45,11 @@ def lib() -> C.CDLL:
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
-        raise PgError(f"{LIB_PATH} is missing: run `make` (or __graft_entry__.build()) first; "
+    path = os.environ.get("SOAPDENOVO2_AMD_LIB", LIB_PATH)        # A/B builds of the library (development aid)
+    if not os.path.exists(path):
+        raise PgError(f"{path} is missing: run `make` (or __graft_entry__.build()) first; "
                       "there is no fallback implementation")
-    L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+    L = C.CDLL(path, mode=C.RTLD_GLOBAL)
     u64p = C.c_void_p
     L.pg_last_error.restype = C.c_char_p
     L.pg_version.restype = C.c_char_p
@@ -79,6 +80,9 @@ def lib() -> C.CDLL:
     L.pg_route_scatter.argtypes = [C.c_void_p, u64p, u64p, u64p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int,
                                    u64p, u64p, u64p, C.c_void_p]
     L.pg_count_records.argtypes = [C.c_void_p, u64p, C.c_uint64, C.c_void_p]
+    if not hasattr(L, "pg_skm_route"):          # an older A/B build of the library
+        _lib = L
+        return L
     L.pg_skm_route.argtypes = [C.c_void_p, u64p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_int, u64p, u64p, C.c_uint64, u64p, C.c_void_p]
     L.pg_skm_ingest.argtypes = [C.c_void_p, u64p, u64p, C.c_uint64, C.c_void_p]
     L.pg_distinct.argtypes = [C.c_void_p, C.POINTER(C.c_uint64), C.c_void_p]
