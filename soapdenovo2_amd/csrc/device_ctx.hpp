@@ -23,6 +23,7 @@ struct DevCounters {
     unsigned long long pool_next;      // chunks handed out
     unsigned long long e2_flags;       // bit 0 pool exhausted, bit 1 partition chunk list full, bit 2 output full, bit 3 split exhausted
     unsigned long long n_records;      // super-k-mer records written
+    unsigned long long phase[12];      // PG_DBG=2: cycles of workgroup thread 0 per K2 phase (measurement aid)
 };
 
 struct SetParams { uint32_t P, bias; };

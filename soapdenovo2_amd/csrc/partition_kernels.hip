@@ -272,28 +272,18 @@ __global__ __launch_bounds__(BLOCK) void skm_ingest_kernel(const uint64_t* recs,
 
 // ---- the LDS set ---------------------------------------------------------------------------------------------
 // Struct of arrays, so lanes that hit different slots hit different banks: key[KW][SLOTS] (63-bit words), ord[SLOTS],
-// ca[SLOTS], cb[SLOTS].  Keys and ord start as ~0, counters as 0.  A slot is claimed key word by key word: an empty
-// word is taken with CAS(~0 -> mine), a word holding something else means another key owns the slot.
-// Counters: 12-bit fields, ca = L0 | L1<<12 | L2<<24 | L3<<36 | R0<<48, cb = R1 | R2<<12 | R3<<24 | puts<<36, so one
-// occurrence is exactly two 64-bit atomic adds (LDS atomics are the scarce resource of this kernel).  An arc field is
-// only incremented while the lane's (possibly stale) snapshot shows it below 64: the true value can then overshoot
-// 63 by at most the number of lanes in flight (1024) and never reaches 4096; it is clipped to 63 when the node is
-// emitted, which is what the reference's saturating increments give (newhash.c:74-106).  puts has 28 bits and is
-// clipped to 255; `single` = exactly one put (newhash.c:127,511).  Plain adds need no retry when many lanes hit one
-// hot k-mer, unlike a CAS on the reference's packed words.
+// cnt[9][SLOTS] (u32: L[4], R[4], puts).  Keys and ord start as ~0, counters as 0.  A slot is claimed key word by key
+// word: an empty word is taken with CAS(~0 -> mine), a word holding something else means another key owns the slot.
+// Counting is plain atomic adds, saturated when the node is emitted: a sum of +1's clipped at the end equals the
+// reference's saturating increments (newhash.c:74-106) and, unlike a CAS on packed counters, needs no retry when many
+// lanes hit one hot k-mer.  `single` = exactly one put (newhash.c:127,511).
 template <int NW, int SLOTS>
 struct LdsSet {
     static constexpr int KW = E2Cfg<NW>::KW;
     unsigned long long key[KW][SLOTS];
     unsigned long long ord[SLOTS];
-    unsigned long long ca[SLOTS];
-    unsigned long long cb[SLOTS];
+    unsigned int cnt[9][SLOTS];
 };
-constexpr int CNT_PUTS_SHIFT = 36;
-__device__ __forceinline__ uint32_t cnt_L(unsigned long long ca, int i) { return (uint32_t)(ca >> (12 * i)) & 0xFFFu; }
-__device__ __forceinline__ uint32_t cnt_R(unsigned long long ca, unsigned long long cb, int i) {
-    return i == 0 ? (uint32_t)(ca >> 48) & 0xFFFu : (uint32_t)(cb >> (12 * (i - 1))) & 0xFFFu;
-}
 
 // Returns false when the set is too full (a probe sequence longer than MAXPROBE): the caller aborts the attempt and
 // splits the key range.  No shared key counter on this path -- a same-address LDS atomic per new key serialises the
@@ -316,13 +306,10 @@ __device__ __forceinline__ bool lds_put(LdsSet<NW, SLOTS>& t, const Key63<NW>& k
             mine = cur == key.w[i];
         }
         if (mine) {
-            const unsigned long long sa = t.ca[h], sb = t.cb[h];             // snapshots, only used to stop counting past 63
-            unsigned long long da = 0, db = 1ULL << CNT_PUTS_SHIFT;
-            if (left < 4 && cnt_L(sa, left) < 64u) da += 1ULL << (12 * left);
-            if (right < 4 && cnt_R(sa, sb, right) < 64u) { if (right == 0) da += 1ULL << 48; else db += 1ULL << (12 * (right - 1)); }
-            if (da) atomicAdd(&t.ca[h], da);
-            atomicAdd(&t.cb[h], db);
-            if (ord < t.ord[h]) atomicMin(&t.ord[h], (unsigned long long)ord);
+            if (left < 4) atomicAdd(&t.cnt[left][h], 1u);
+            if (right < 4) atomicAdd(&t.cnt[4 + right][h], 1u);
+            atomicAdd(&t.cnt[8][h], 1u);
+            atomicMin(&t.ord[h], (unsigned long long)ord);
             return true;
         }
         h = (h + 1) & (SLOTS - 1);
@@ -360,7 +347,8 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     const uint32_t parts = 1u << e.g.log2_parts;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long my_records = 0;
-    bool dirty = true;                                                    // workgroup-uniform: the LDS set needs a full reset
+    unsigned long long tp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+#define K2_TICK(i) do { if (dbg & 2) { const unsigned long long tn_ = clock64(); tp[i] += tn_ - tlast; tlast = tn_; } } while (0)
     // the next partition's record count and chunk list are fetched while the current one is processed
     uint32_t pf_nrec = 0, pf_cid = 0;
     if (blockIdx.x < parts) {
@@ -383,19 +371,19 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
         if (threadIdx.x < e.maxc) chunk_ids[threadIdx.x] = my_cid;
         if (threadIdx.x == 0) { sp_top = 1; s_mask[0] = 0; s_val[0] = 0; }
         __syncthreads();
+        K2_TICK(0);
         while (sp_top > 0) {
             __syncthreads();
             if (threadIdx.x == 0) { sp_top--; cur_mask = s_mask[sp_top]; cur_val = s_val[sp_top]; aborted = 0; }
-            if (dirty) {                // full reset only at start and after a dropped attempt; emit resets what it reads
-                for (int i = threadIdx.x; i < SLOTS; i += THREADS) {
+            for (int i = threadIdx.x; i < SLOTS; i += THREADS) {
 #pragma unroll
-                    for (int q = 0; q < KW; q++) set.key[q][i] = L_EMPTY;
-                    set.ord[i] = L_EMPTY;
-                    set.ca[i] = 0; set.cb[i] = 0;
-                }
-                dirty = false;
+                for (int q = 0; q < KW; q++) set.key[q][i] = L_EMPTY;
+                set.ord[i] = L_EMPTY;
+#pragma unroll
+                for (int q = 0; q < 9; q++) set.cnt[q][i] = 0;
             }
             __syncthreads();
+            K2_TICK(1);
             const uint32_t mask = cur_mask, val = cur_val;
             volatile unsigned int* abort_flag = &aborted;
             for (uint32_t w0 = 0; w0 < usable; w0 += WIN) {
@@ -410,6 +398,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     ((ulonglong2*)recs)[pc] = v;
                 }
                 __syncthreads();
+                K2_TICK(2);
                 // flatten: occurrence idx -> (record, t)
                 {
                     const unsigned int n = threadIdx.x < wn ? (unsigned int)skm_n(recs[threadIdx.x * RW]) : 0u;
@@ -425,6 +414,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     if (threadIdx.x == THREADS - 1) noff[wn] = base + incl;       // lanes past wn contributed 0
                 }
                 __syncthreads();
+                K2_TICK(3);
                 if (!*abort_flag) {
                     const uint32_t total_occ = noff[wn];
                     const uint32_t share = (total_occ + THREADS - 1) / THREADS;
@@ -437,26 +427,17 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                         uint64_t hdr = 0;
                         int hl = 0, nb = 0;
                         bool fresh = true;
-                        Kmer<NW> word, bal;                                       // rolling pair inside one record
                         for (uint32_t idx = idx0; idx < idx1; idx++) {
                             while (idx >= next_off) { r++; next_off = noff[r + 1]; fresh = true; }
-                            int j;
                             if (fresh) {
                                 rec = recs + r * RW;
                                 hdr = rec[0];
                                 hl = skm_has_left(hdr); nb = skm_record_bases(hdr, K); roff = noff[r];
                                 fresh = false;
                                 if (*abort_flag) break;
-                                j = hl + (int)(idx - roff);
-                                word = read_kmer<NW>(rec + 1, j, K, filter);
-                                bal = kmer_rc<NW>(word, K);
-                            } else {
-                                j = hl + (int)(idx - roff);
-                                kmer_roll<NW>(word, bal, read_base(rec + 1, j + K - 1), K, filter);
                             }
                             Occurrence occ;
-                            const Kmer<NW> key = canonical_pair<NW>(word, bal, j > 0 ? read_base(rec + 1, j - 1) : 4,
-                                                                    j < nb - K ? read_base(rec + 1, j + K) : 4, occ);
+                            const Kmer<NW> key = canonical_occurrence<NW>(rec + 1, hl + (int)(idx - roff), nb, K, filter, occ);
                             const uint64_t hh = kmer_mix<NW>(key);
                             if (((uint32_t)(hh >> 32) & mask) != val) continue;
                             if (dbg & 1) { if (hh == 0x1234) aborted = 1; continue; }      // measurement aid: extraction only
@@ -467,9 +448,12 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                         }
                     }
                 }
+                K2_TICK(4);
                 __syncthreads();                                                  // recs / noff are rewritten by the next window
+                K2_TICK(5);
             }
             if (aborted) {
+                if (dbg & 2) tp[9]++;
                 // too many distinct keys for the LDS set: split this key range on the next hash bit and redo both halves
                 if (threadIdx.x == 0) {
                     const uint32_t bit = mask + 1;                                    // masks are 2^k - 1
@@ -479,7 +463,6 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                         s_mask[sp_top] = mask | bit; s_val[sp_top] = val | bit; sp_top++;
                     }
                 }
-                dirty = true;
                 __syncthreads();
                 continue;
             }
@@ -490,7 +473,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
 #pragma unroll
             for (int st = 0; st < STRIPES; st++) {
                 const int si = st * THREADS + threadIdx.x;
-                live[st] = si < SLOTS && (set.cb[si] >> CNT_PUTS_SHIFT) != 0;   // a put is only counted once every key word is claimed
+                live[st] = si < SLOTS && set.cnt[8][si] != 0;          // a put is only counted once every key word is claimed
                 bal[st] = __ballot(live[st]);
                 if (lane == 0) wave_cnt[st][wave] = (unsigned int)__popcll(bal[st]);
             }
@@ -517,8 +500,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 cov_bin[st] = 0;                                          // 0 = not live (a live node has cov >= 1)
                 if (live[st]) {
                     const int si = st * THREADS + threadIdx.x;
-                    const unsigned long long qa = set.ca[si], qb = set.cb[si];
-                    const unsigned int puts = (unsigned int)(qb >> CNT_PUTS_SHIFT);
+                    const unsigned int puts = set.cnt[8][si];
                     Key63<NW> k63;
 #pragma unroll
                     for (int w = 0; w < KW; w++) k63.w[w] = set.key[w][si];
@@ -527,7 +509,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     int nin = 0, nout = 0;
 #pragma unroll
                     for (int c = 0; c < 4; c++) {                               // saturate, then thread_delow + thread_mark
-                        uint32_t l = min(cnt_L(qa, c), 63u), r = min(cnt_R(qa, qb, c), 63u);
+                        uint32_t l = min(set.cnt[c][si], 63u), r = min(set.cnt[4 + c][si], 63u);
                         if (D > 0 && l <= (uint32_t)D) l = 0;
                         if (D > 0 && r <= (uint32_t)D) r = 0;
                         A |= l << (6 * c); B |= r << (6 * c);
@@ -536,15 +518,11 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     if (D > 0 && nin == 0 && nout == 0) B |= B_DELETED;
                     if (nin == 1 && nout == 1) B |= B_LINEAR;
                     cov_bin[st] = A >> 24;
+                    const uint32_t sid = set_of_crc(kmer_crc32<NW>(key, crc_tab), sp.P, sp.bias);
 #pragma unroll
                     for (int w = 0; w < NW; w++) rec_out[st][w] = key.w[w];
                     rec_out[st][NW] = (uint64_t)A | ((uint64_t)B << 32);
-                    rec_out[st][NW + 1] = set.ord[si] & PG_ORD_MASK;      // the set id is filled in by set_id_kernel
-                    // leave the slot empty for the next partition
-#pragma unroll
-                    for (int w = 0; w < KW; w++) set.key[w][si] = L_EMPTY;
-                    set.ord[si] = L_EMPTY;
-                    set.ca[si] = 0; set.cb[si] = 0;
+                    rec_out[st][NW + 1] = ((uint64_t)sid << PG_ORD_BITS) | (set.ord[si] & PG_ORD_MASK);
                 }
                 // coverage histogram: most nodes of a partition share one or two coverage values (1 for error k-mers),
                 // so count those per wave instead of hammering one LDS word
@@ -552,7 +530,9 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 if (lane == 0 && ones) atomicAdd(&hist[1], (unsigned int)__popcll(ones));
                 if (cov_bin[st] > 1) atomicAdd(&hist[cov_bin[st]], 1u);
             }
+            K2_TICK(6);
             __syncthreads();                                              // out_base is in; the set may be cleared after this
+            K2_TICK(7);
             const unsigned long long ob = out_base;
 #pragma unroll
             for (int st = 0; st < STRIPES; st++) {
@@ -565,29 +545,14 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     } else atomicOr(&ctr->e2_flags, F_OUT);
                 }
             }
+            K2_TICK(8);
         }
     }
     __syncthreads();
     for (int i = threadIdx.x; i < 256; i += THREADS) if (hist[i]) atomicAdd(&ctr->hist[i], (unsigned long long)hist[i]);
     if (threadIdx.x == 0 && my_records) atomicAdd(&ctr->n_records, my_records);
-}
-
-// set id = hash_kmer % thrd_num (hashFunction.c:155) of every exported k-mer, as a dense streaming pass (doing the
-// 16 table look-ups inside K2's emit made every lane of a stripe pay for the few live ones)
-template <int NW>
-__global__ __launch_bounds__(BLOCK) void set_id_kernel(uint64_t* out, uint64_t capacity, SetParams sp, const DevCounters* ctr) {
-    __shared__ uint32_t crc_tab[256];
-    crc_tab[threadIdx.x] = crc32_table_entry(threadIdx.x);
-    __syncthreads();
-    const uint64_t n = min((uint64_t)ctr->n_export, capacity);
-    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
-        uint64_t* o = out + i * (NW + 2);
-        Kmer<NW> key;
-#pragma unroll
-        for (int w = 0; w < NW; w++) key.w[w] = o[w];
-        const uint32_t sid = set_of_crc(kmer_crc32<NW>(key, crc_tab), sp.P, sp.bias);
-        o[NW + 1] = (o[NW + 1] & PG_ORD_MASK) | ((uint64_t)sid << PG_ORD_BITS);
-    }
+    if ((dbg & 2) && threadIdx.x == 0) for (int i = 0; i < 10; i++) atomicAdd(&ctr->phase[i], tp[i]);
+#undef K2_TICK
 }
 
 // per reference set: 1 + ordinal of the last k-mer occurrence routed to it (see host_graph.cpp, before_put)
@@ -828,6 +793,7 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     E2_TRY(hipMemsetAsync(&c->ctr->n_export, 0, sizeof(unsigned long long), st));
     E2_TRY(hipMemsetAsync(c->ctr->hist, 0, sizeof(unsigned long long) * 256, st));
     E2_TRY(hipMemsetAsync(&c->ctr->n_records, 0, sizeof(unsigned long long), st));
+    E2_TRY(hipMemsetAsync(c->ctr->phase, 0, sizeof(unsigned long long) * 12, st));
     const uint32_t parts = 1u << s.log2_parts;
     int n_cu = 256;
     hipDeviceProp_t prop;
@@ -845,9 +811,6 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
         if (cfg == 0) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, c->ctr, dbg);
         else hipLaunchKernelGGL((skm_count_kernel<4, 512, 512, 256>), dim3(grid), dim3(512), 0, st, dev_view(c), delow, sp, c->ctr, dbg);
     }
-    E2_TRY(hipGetLastError());
-    if (c->NW == 2) hipLaunchKernelGGL(set_id_kernel<2>, dim3(n_cu * 8), dim3(BLOCK), 0, st, s.out, s.out_capacity, sp, c->ctr);
-    else hipLaunchKernelGGL(set_id_kernel<4>, dim3(n_cu * 8), dim3(BLOCK), 0, st, s.out, s.out_capacity, sp, c->ctr);
     E2_TRY(hipGetLastError());
     if (want_last_put) {
         E2_TRY(hipMemsetAsync(c->ctr->set_last, 0, sizeof(unsigned long long) * 256, st));
@@ -874,6 +837,13 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     }
     if (h.e2_flags & F_OUT) { pg_set_error("partition engine: more distinct k-mers than the export array holds (raise log2_slots)"); return PG_ENOMEM; }
     if (h.e2_flags & F_SPLIT) { pg_set_error("partition engine: a partition could not be split to fit the LDS set"); return PG_ENOMEM; }
+    if (dbg & 2) {
+        static const char* names[10] = {"meta+sync", "clear", "stage", "flatten", "occurrences (own share)", "wait for the slowest lane",
+                                        "emit: count+atomic+finalise", "emit: wait for the atomic", "emit: writes", "dropped attempts"};
+        unsigned long long tot = 0;
+        for (int i = 0; i < 9; i++) tot += h.phase[i];
+        for (int i = 0; i < 10; i++) fprintf(stderr, "K2 phase %-32s %14llu  %5.1f%%\n", names[i], h.phase[i], i < 9 ? 100.0 * h.phase[i] / (double)(tot ? tot : 1) : 0.0);
+    }
     s.counted = true;
     return PG_OK;
 }
