@@ -140,7 +140,7 @@ def main():
 
     K, L, P = args.kmer, args.read_len, args.sets
     kpr = L - K + 1
-    kpr_w = K - max(7, min(13, K - 6)) + 1          # m-mers per k-mer (skm.hpp): a read makes about 2*kpr/(w+1) + 1 records
+    kpr_w = K - max(7, min(16, K - 6)) + 1          # m-mers per k-mer (skm.hpp): a read makes about 2*kpr/(w+1) + 1 records
     n_reads = args.reads
     n_kmers = n_reads * kpr
     # expected distinct k-mers per GPU: genomic (<= genome) + error k-mers (~ K per error, capped by read geometry)

@@ -32,7 +32,11 @@ struct SkmGeom {
 PG_HD SkmGeom skm_geometry(int K, int log2_parts, int nw = 2) {
     SkmGeom g;
     g.K = K;
-    g.m = K - 6 < 7 ? 7 : (K - 6 > 13 ? 13 : K - 6);
+    // 16 = the most that fits the 32-bit m-mer arithmetic.  It matters at scale: only ~1/25 of the canonical m-mers ever
+    // win a window, and all sites that share a winning m-mer share a partition -- with m = 13 (33 M canonical 13-mers,
+    // ~1.3 M effective minimizers) a 100 Mb genome already put ~3 sites into every used partition and overflowed the
+    // LDS set of 6 % of them.
+    g.m = K - 6 < 7 ? 7 : (K - 6 > 16 ? 16 : K - 6);
     g.w = K - g.m + 1;
     g.pw = nw == 2 ? 5 : 7;                       // 160 / 224 bases per record
     g.rw = 1 + g.pw;
@@ -70,7 +74,7 @@ PG_HD uint32_t rev2bit32(uint32_t x) {
     return __builtin_bswap32(x);
 #endif
 }
-PG_HD uint32_t mmer_value(const uint64_t* rd, int p, int m) {          // m <= 13: an m-mer is at most 26 bits
+PG_HD uint32_t mmer_value(const uint64_t* rd, int p, int m) {          // m <= 16: an m-mer is at most 32 bits
     const uint32_t fwd = (uint32_t)(bits_at(rd, 2 * p) >> (64 - 2 * m));
     const uint32_t rc = rev2bit32(fwd ^ 0xAAAAAAAAu) >> (32 - 2 * m);
     uint32_t x = fwd < rc ? fwd : rc;
