@@ -291,8 +291,16 @@ def main():
                          "moved_bytes_per_step": k1_bytes + k2_bytes, "moved_over_algorithmic": (k1_bytes + k2_bytes) / alg_pass,
                          "records_per_read": st["records"] / n_reads, "record_bytes": st["unit_bytes"], "partitions": st["parts_or_slots"]}
             if os.path.exists(tf):
+                # PMC bytes (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes) are kept per read in profiles/pmc_traffic.json
+                # (measured on the 20 M-read variant of this workload) and scaled to the reads of one launch
                 try:
-                    traffic = json.load(open(tf)).get(kernel.split("<")[0] + "_bytes_per_launch")
+                    tj = json.load(open(tf))
+                    kn = kernel.split("<")[0]
+                    if kn + "_bytes_per_read" in tj:
+                        reads_per_launch = n_reads if kn == "skm_count_kernel" else n_reads / len(batches)
+                        traffic = tj[kn + "_bytes_per_read"] * reads_per_launch
+                    else:
+                        traffic = tj.get(kn + "_bytes_per_launch")
                 except Exception:
                     traffic = None
             rec["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
