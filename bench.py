@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--err", type=float, default=0.001)
     ap.add_argument("--seed", type=int, default=3)
     ap.add_argument("--sets", type=int, default=8, help="the reference's -p (k-mer sets)")
+    ap.add_argument("--mer127", action="store_true", help="four-word k-mers (the SOAPdenovo-127mer flavour); implied by --kmer > 63")
     ap.add_argument("--batch-reads", type=int, default=16_000_000)
     ap.add_argument("--log2-slots", type=int, default=0, help="0 = size from the expected distinct count")
     ap.add_argument("--cpu-sample-reads", type=int, default=2_000_000)
@@ -153,7 +154,8 @@ def main():
             log2_slots += 1
     packed = gen_packed_reads(torch, dev, args.genome, n_reads, L, args.err, args.seed + 1000 * rank)
     engine = args.engine
-    kc = api.KmerCounter(K, n_sets=P, log2_slots=log2_slots, device=local, engine=engine)
+    mer127 = args.mer127 or K > 63
+    kc = api.KmerCounter(K, n_sets=P, mer127=mer127, log2_slots=log2_slots, device=local, engine=engine)
     kc.set_autogrow(False)
     wpr = (L + 31) // 32
     batches = [(lo, min(args.batch_reads, n_reads - lo)) for lo in range(0, n_reads, args.batch_reads)]
@@ -253,13 +255,13 @@ def main():
                                            else f"set-id owner, k-mer records over RCCL all-to-all x{world}")},
         }
         if world == 1 and ev:
-            slot_b = 48 if K <= 63 else 80
+            slot_b = 80 if mer127 else 48
             bytes_per_read = kpr * slot_b + (L + 3) // 4          # node read + node write per occurrence + packed read
             dur = [e0.elapsed_time(e1) * 1e-3 for e0, e1, _ in ev]
             dur2 = [f0.elapsed_time(f1) * 1e-3 for f0, f1 in ev2]
             traffic = None
             tf = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-            nwk = "2" if K <= 63 else "4"
+            nwk = "4" if mer127 else "2"
             if engine == 1:
                 kernel = f"count_reads_kernel<{nwk}>"
                 alg = [n * bytes_per_read for _, _, n in ev]
