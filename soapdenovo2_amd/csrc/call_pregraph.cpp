@@ -282,6 +282,7 @@ int run(int argc, char** argv, bool mer127) {
     pg_graph* graph = pg_host_graph_begin(records.data(), n_distinct, set_last.data(), K, mer127 ? 1 : 0, o.sets, o.delow == 0, o.a_gb,
                                           max_read_len, 0, o.prefix.c_str());
     if (!graph) die("pg_host_graph_begin");
+    if (o.reps && pg_host_graph_resolve_repeats(graph, 1) != PG_OK) die("pg_host_graph_resolve_repeats");
     { std::vector<uint64_t>().swap(records); }
     fprintf(stderr, "Time spent on removing tips and constructing edges: %ds.\n\n", (int)(time(nullptr) - t0));
 

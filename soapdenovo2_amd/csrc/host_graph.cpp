@@ -572,7 +572,10 @@ struct ReadThreader {
 
     // appends the read's pairs (from, to) to `out`; returns false when the read yielded no usable item at all
     // (the reference's "read(s) deleted" counter, prlRead2path.c:722-725)
-    bool thread_read(const uint8_t* codes, int len, std::vector<Item>& items, std::vector<std::pair<uint32_t, uint32_t>>& out) {
+    // With `path` set (-R, prlRead2path.c:478-543 recordPathBin) the read's edge walk is also appended to *path as
+    // <count:u8><count x u32 edge id> and every id on it to *marks, when its first three entries are resolved.
+    bool thread_read(const uint8_t* codes, int len, std::vector<Item>& items, std::vector<std::pair<uint32_t, uint32_t>>& out,
+                     std::vector<uint8_t>* path = nullptr, std::vector<uint32_t>* marks = nullptr) {
         const int K = g.K;
         items.clear();
         unsigned retain = 0;
@@ -627,6 +630,20 @@ struct ReadThreader {
             if (items[i].id == 0 || items[i + 1].id == 0) break;
             out.emplace_back(items[i].id, items[i + 1].id);
         }
+        if (path && items.size() >= 3 && items[0].id && items[1].id && items[2].id) {
+            // the reference counts with an unsigned char that also indexes its staging buffer, so a walk longer than
+            // 255 entries wraps around and overwrites the front (prlRead2path.c:481, 529)
+            uint32_t buf[256];
+            uint8_t counter = 0;
+            for (const Item& it : items) {
+                if (it.id == 0) break;
+                buf[counter++] = it.id;
+                marks->push_back(it.id);
+            }
+            path->push_back(counter);
+            const uint8_t* b = reinterpret_cast<const uint8_t*>(buf);
+            path->insert(path->end(), b, b + 4 * (size_t)counter);
+        }
         return true;
     }
 };
@@ -666,6 +683,7 @@ struct GraphHandleBase {
     virtual ~GraphHandleBase() {}
     virtual int add_reads(const uint8_t* codes, const int32_t* lens, uint64_t n, uint64_t stride, int n_threads) = 0;
     virtual int finish(long long* n_arcs) = 0;
+    virtual int resolve_repeats(int on) = 0;
     int num_vt = 0, num_ed = 0;
 };
 
@@ -676,12 +694,31 @@ struct GraphHandle : GraphHandleBase {
     std::string prefix;
     int max_read_len = 0;
     long long reads_seen = 0, reads_deleted = 0;
+    // -R (pregraph.c:181-184): <prefix>.path is appended batch by batch, the per-edge marker counts go to
+    // <prefix>.markOnEdge at the end (prlRead2path.c:813-818, 435-449)
+    FILE* path_fp = nullptr;
+    std::vector<uint8_t> marker;
+    long long mark_count = 0;
+
+    ~GraphHandle() override { if (path_fp) fclose(path_fp); }
+    int resolve_repeats(int on) override {
+        if (path_fp) { fclose(path_fp); path_fp = nullptr; }
+        marker.clear();
+        if (!on) return PG_OK;
+        path_fp = fopen((prefix + ".path").c_str(), "wb");
+        if (!path_fp) { pg_set_error("cannot open " + prefix + ".path"); return PG_EIO; }
+        marker.assign((size_t)num_ed + 1, 0);
+        return PG_OK;
+    }
 
     int add_reads(const uint8_t* codes, const int32_t* lens, uint64_t n, uint64_t stride, int n_threads) override {
         int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
         nt = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)nt, (n + 255) / 256));
         std::vector<std::vector<std::pair<uint32_t, uint32_t>>> pairs(nt);
         std::vector<long long> deleted(nt, 0);
+        const bool reps = path_fp != nullptr;
+        std::vector<std::vector<uint8_t>> paths(reps ? nt : 0);
+        std::vector<std::vector<uint32_t>> marks(reps ? nt : 0);
         auto worker = [&](int t) {
             ReadThreader<NW> rt(g);
             std::vector<typename ReadThreader<NW>::Item> items;
@@ -689,7 +726,7 @@ struct GraphHandle : GraphHandleBase {
             for (uint64_t r = lo; r < hi; r++) {
                 const int len = lens ? lens[r] : (int)stride;
                 if (len < g.K + 1) continue;                                  // prlRead2path.c:1103 (same filter as pass 1)
-                if (!rt.thread_read(codes + r * stride, len, items, pairs[t])) deleted[t]++;
+                if (!rt.thread_read(codes + r * stride, len, items, pairs[t], reps ? &paths[t] : nullptr, reps ? &marks[t] : nullptr)) deleted[t]++;
             }
         };
         std::vector<std::thread> pool;
@@ -703,6 +740,17 @@ struct GraphHandle : GraphHandleBase {
                 arcs.add(pr.first, pr.second);
             }
             reads_deleted += deleted[t];
+            if (reps) {
+                if (!paths[t].empty() && fwrite(paths[t].data(), 1, paths[t].size(), path_fp) != paths[t].size()) {
+                    pg_set_error("short write on " + prefix + ".path");
+                    return PG_EIO;
+                }
+                for (uint32_t e : marks[t]) {
+                    if (e >= marker.size()) { pg_set_error("edge id out of range in pass 2"); return PG_EINVAL; }
+                    if (marker[e] < 255) marker[e]++;
+                }
+                mark_count += (long long)marks[t].size();
+            }
         }
         reads_seen += (long long)n;
         return PG_OK;
@@ -710,6 +758,15 @@ struct GraphHandle : GraphHandleBase {
     int finish(long long* n_arcs) override {
         int rc = arcs.write(prefix + ".preArc");
         if (rc) return rc;
+        if (path_fp) {
+            fclose(path_fp);
+            path_fp = nullptr;
+            fprintf(stderr, "%lld marker(s) output.\n", mark_count);
+            FILE* fp = fopen((prefix + ".markOnEdge").c_str(), "w");
+            if (!fp) { pg_set_error("cannot open " + prefix + ".markOnEdge"); return PG_EIO; }
+            for (size_t e = 1; e < marker.size(); e++) fprintf(fp, "%d\n", (int)marker[e]);
+            fclose(fp);
+        }
         fprintf(stderr, "Reads alignment done, %lld read(s) deleted, %lld pre-arc(s) added.\n", reads_deleted, arcs.count);
         if (n_arcs) *n_arcs = arcs.count;
         return write_vertex<NW>(g, prefix, num_ed, max_read_len, num_vt);
@@ -794,6 +851,10 @@ extern "C" pg_graph* pg_host_graph_begin(const uint64_t* records, uint64_t n_rec
     pg::GraphHandleBase* h = mer127 ? pg::graph_begin<4>(records, n_records, set_last_put, K, n_sets, cut_single, a_gb, max_read_len, n_threads, prefix)
                                     : pg::graph_begin<2>(records, n_records, set_last_put, K, n_sets, cut_single, a_gb, max_read_len, n_threads, prefix);
     return (pg_graph*)h;
+}
+extern "C" int pg_host_graph_resolve_repeats(pg_graph* g, int on) {
+    if (!g) { pg_set_error("null argument"); return PG_EINVAL; }
+    return ((pg::GraphHandleBase*)g)->resolve_repeats(on);
 }
 extern "C" int pg_host_graph_add_reads(pg_graph* g, const uint8_t* codes, const int32_t* lens, uint64_t n_reads, uint64_t stride, int n_threads) {
     if (!g || (!codes && n_reads)) { pg_set_error("null argument"); return PG_EINVAL; }

@@ -51,6 +51,14 @@ def main():
                 # downstream pin (P3): the reference's contig stage on the reference's pregraph files
                 subprocess.run([binary, "contig", "-g", pre], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
                 digests[t]["contig"] = hashlib.md5(open(pre + ".contig", "rb").read()).hexdigest()
+                # -R (repeat resolution by reads): two more files from pass 2, and the contig stage that consumes them
+                preR = pre + "_R"
+                subprocess.run([preR if x == pre else x for x in cmd] + ["-R"],
+                               check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                for e in ("path", "markOnEdge"):
+                    digests[t][e] = hashlib.md5(open(f"{preR}.{e}", "rb").read()).hexdigest()
+                subprocess.run([binary, "contig", "-g", preR, "-R"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+                digests[t]["contigR"] = hashlib.md5(open(preR + ".contig", "rb").read()).hexdigest()
                 if list(run) in [list(r) for r in c["full"]]:
                     for e in EXTS:
                         if e == "edge":

@@ -170,7 +170,7 @@ def test_skm_route_then_ingest_equals_local(golden, tmp_path):
     assert (np.maximum.reduce(lasts) == last_want).all()
 
 
-def _run_cli(cfg, K, prefix, P, D, a, m, engine=None):
+def _run_cli(cfg, K, prefix, P, D, a, m, engine=None, R=False):
     from soapdenovo2_amd import api
     env = dict(os.environ)
     if engine:
@@ -180,6 +180,8 @@ def _run_cli(cfg, K, prefix, P, D, a, m, engine=None):
         args += ["-d", str(D)]
     if a:
         args += ["-a", str(a)]
+    if R:
+        args += ["-R"]
     rc = subprocess.run([api.binary(bool(m)), "pregraph"] + args, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, env=env)
     assert rc.returncode == 0, rc.stderr[-2000:]
     return rc.stderr
@@ -196,8 +198,11 @@ def test_cli_matches_reference_files(golden, tmp_path, name, engine):
         P, D, a, m = run
         t = case_tag(name, run)
         pre = str(tmp_path / t)
-        _run_cli(cfg, c["K"], pre, P, D, a, m, engine=engine)
+        _run_cli(cfg, c["K"], pre, P, D, a, m, engine=engine, R=(engine == 2))
         want = golden["md5"][t]
+        if engine == 2:                                                # -R: the read paths and the per-edge marker counts
+            assert md5_file(pre + ".path") == want["path"], t
+            assert md5_file(pre + ".markOnEdge") == want["markOnEdge"], t
         assert md5_file(pre + ".kmerFreq") == want["kmerFreq"], t
         assert md5_file(pre + ".preGraphBasic") == want["preGraphBasic"], t
         assert md5_file(pre + ".vertex") == want["vertex"], t

@@ -18,9 +18,11 @@ def test_prearc_matches_reference(golden, tmp_path, name):
         rec, last, K = oracle_records(codes, c["K"], P, D=D, mer127=bool(m), a_gb=a, prefix=str(tmp_path / ("o_" + t)))
         pre = str(tmp_path / t)
         nv, ne, na = api.host_pregraph_files(rec, last, codes, None, K, P, pre, mer127=bool(m), cut_single=(D == 0), a_gb=a,
-                                             max_read_len=c["L"], batches=3)
+                                             max_read_len=c["L"], batches=3, resolve_repeats=True)
         want = golden["md5"][t]
         assert md5_file(pre + ".preArc") == want["preArc"], t
+        assert md5_file(pre + ".path") == want["path"], t                  # the -R files (prlRead2path.c:478-543, 435-449)
+        assert md5_file(pre + ".markOnEdge") == want["markOnEdge"], t
         assert md5_file(pre + ".vertex") == want["vertex"], t
         assert md5_file(pre + ".preGraphBasic") == want["preGraphBasic"], t
         assert md5_gz_text(pre + ".edge.gz") == want["edge"], t
@@ -65,7 +67,10 @@ def test_contig_stage_accepts_our_files(golden, tmp_path):
         t = case_tag(name, run)
         rec, last, K = oracle_records(codes, c["K"], P, prefix=str(tmp_path / ("o_" + t)))
         pre = str(tmp_path / t)
-        api.host_pregraph_files(rec, last, codes, None, K, P, pre, max_read_len=c["L"])
+        api.host_pregraph_files(rec, last, codes, None, K, P, pre, max_read_len=c["L"], resolve_repeats=True)
         out = subprocess.run([ref, "contig", "-g", pre], capture_output=True, text=True)
         assert out.returncode == 0, out.stderr[-500:]
         assert md5_file(pre + ".contig") == golden["md5"][t]["contig"], t
+        out = subprocess.run([ref, "contig", "-g", pre, "-R"], capture_output=True, text=True)   # consumes .path / .markOnEdge
+        assert out.returncode == 0, out.stderr[-500:]
+        assert md5_file(pre + ".contig") == golden["md5"][t]["contigR"], t
