@@ -16,10 +16,12 @@
 #include <string.h>
 #include <math.h>
 #include <zlib.h>
+#include <sys/mman.h>
 
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <functional>
 #include <string>
 #include <thread>
 #include <unordered_map>
@@ -33,6 +35,36 @@ namespace pg {
 
 static uint32_t g_crc_tab[256];
 static std::atomic<bool> g_crc_ready{false};
+// the same CRC eight bytes at a time (slicing-by-8 tables derived from the byte table)
+static uint32_t g_crc8[8][256];
+static std::atomic<bool> g_crc8_ready{false};
+const uint32_t* host_crc_table();
+static void host_crc8_init() {
+    if (g_crc8_ready.load(std::memory_order_acquire)) return;
+    const uint32_t* t0 = host_crc_table();
+    uint32_t tmp[8][256];
+    for (uint32_t i = 0; i < 256; i++) tmp[0][i] = t0[i];
+    for (int k = 1; k < 8; k++)
+        for (uint32_t i = 0; i < 256; i++) tmp[k][i] = (tmp[k - 1][i] >> 8) ^ t0[tmp[k - 1][i] & 0xff];
+    static std::atomic_flag lock = ATOMIC_FLAG_INIT;
+    while (lock.test_and_set(std::memory_order_acquire)) {}
+    if (!g_crc8_ready.load(std::memory_order_relaxed)) {
+        memcpy(g_crc8, tmp, sizeof(tmp));
+        g_crc8_ready.store(true, std::memory_order_release);
+    }
+    lock.clear(std::memory_order_release);
+}
+template <int NW>
+static inline uint32_t host_crc32(const Kmer<NW>& a) {
+    uint32_t crc = 0;
+    for (int i = 0; i < NW; i++) {
+        const uint64_t v = a.w[i] ^ crc;
+        crc = g_crc8[7][v & 0xff] ^ g_crc8[6][(v >> 8) & 0xff] ^ g_crc8[5][(v >> 16) & 0xff] ^ g_crc8[4][(v >> 24) & 0xff] ^
+              g_crc8[3][(v >> 32) & 0xff] ^ g_crc8[2][(v >> 40) & 0xff] ^ g_crc8[1][(v >> 48) & 0xff] ^ g_crc8[0][v >> 56];
+    }
+    return crc ^ 0xffffffffu;
+}
+
 const uint32_t* host_crc_table() {
     if (!g_crc_ready.load(std::memory_order_acquire)) {
         for (uint32_t i = 0; i < 256; i++) g_crc_tab[i] = crc32_table_entry(i);
@@ -74,10 +106,49 @@ struct HNode {
     uint32_t A, B;
 };
 
+// A big zero-filled array on 2 MiB-aligned anonymous memory with transparent huge pages requested: the k-mer sets are
+// probed at random, and with 4 KiB pages nearly every probe also misses the TLB.
+template <typename T>
+struct HugeArray {
+    T* p = nullptr;
+    size_t n = 0, bytes = 0;
+    HugeArray() {}
+    HugeArray(const HugeArray&) = delete;
+    HugeArray& operator=(const HugeArray&) = delete;
+    HugeArray(HugeArray&& o) noexcept : p(o.p), n(o.n), bytes(o.bytes) { o.p = nullptr; o.n = o.bytes = 0; }
+    HugeArray& operator=(HugeArray&& o) noexcept { release(); p = o.p; n = o.n; bytes = o.bytes; o.p = nullptr; o.n = o.bytes = 0; return *this; }
+    ~HugeArray() { release(); }
+    void release() { if (p) munmap(p, bytes); p = nullptr; n = bytes = 0; }
+    // new zeroed storage of `count` elements; the first `keep` old elements are carried over
+    void reset(size_t count, size_t keep = 0) {
+        const size_t HP = (size_t)2 << 20;
+        size_t nb = (count * sizeof(T) + HP - 1) / HP * HP;
+        if (nb == 0) nb = HP;
+        void* q = mmap(nullptr, nb + HP, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (q == MAP_FAILED) { fprintf(stderr, "out of memory (%zu bytes for a k-mer set)\n", nb); exit(1); }
+        // trim to a 2 MiB boundary so that whole huge pages can back the range
+        uintptr_t a = (uintptr_t)q, al = (a + HP - 1) / HP * HP;
+        if (al > a) munmap(q, al - a);
+        if (al + nb < a + nb + HP) munmap((void*)(al + nb), a + HP - al);
+        madvise((void*)al, nb, MADV_HUGEPAGE);
+        T* np = (T*)al;
+        if (keep) memcpy((void*)np, (const void*)p, keep * sizeof(T));
+        release();
+        p = np; n = count; bytes = nb;
+    }
+    T& operator[](size_t i) { return p[i]; }
+    const T& operator[](size_t i) const { return p[i]; }
+    T* data() { return p; }
+    const T* data() const { return p; }
+};
+
 template <int NW>
 struct HSet {
-    std::vector<HNode<NW>> array;
+    HugeArray<HNode<NW>> array;
     std::vector<uint8_t> occ;
+    // An empty slot carries a key no k-mer can have (K <= 63 / 127 leaves the two top bits of word 0 clear), so that a
+    // lookup touches the slot array only; `occ` mirrors it for the in-order scans and the in-place rehash.
+    static constexpr uint64_t EMPTY = ~0ULL;
     uint64_t size = 0, count = 0, max = 0;
     float lf = 0.77f;
 
@@ -85,8 +156,15 @@ struct HSet {
     // key in 32-bit chunks, which is a true modulus only while size < 2^32 -- restated as is
     uint64_t home(const Kmer<NW>& k) const {
         if (NW == 2) {
+#if defined(__x86_64__)
+            // (hi * 2^64 + lo) % size as two 64-bit divisions (the generic 128-bit modulus is a slow library call)
+            uint64_t hi = k.w[0] % size, q, r;
+            __asm__("divq %4" : "=a"(q), "=d"(r) : "a"(k.w[1]), "d"(hi), "r"(size) : "cc");
+            return r;
+#else
             unsigned __int128 t = ((unsigned __int128)k.w[0] << 64) | k.w[1];
             return (uint64_t)(t % size);
+#endif
         }
         uint64_t t = k.w[0] % size;
         for (int i = 1; i < NW; i++) {
@@ -98,7 +176,8 @@ struct HSet {
     void init(uint64_t sz) {
         size = sz; count = 0; lf = 0.77f;
         max = (uint64_t)((float)size * lf);
-        array.assign(size, HNode<NW>());
+        array.reset(size);
+        for (uint64_t i = 0; i < size; i++) array[i].seq.w[0] = EMPTY;
         occ.assign(size, 0);
     }
     // encap_kmerset, growable case (newhash.c:368-454): next size, then re-home in place in old-slot order,
@@ -110,7 +189,8 @@ struct HSet {
             n = ref_next_prime(n);
         } while ((float)n * lf < (float)(count + 1));
         const uint64_t old = size;
-        array.resize(n);
+        array.reset(n, old);
+        for (uint64_t i = old; i < n; i++) array[i].seq.w[0] = EMPTY;
         std::vector<uint8_t> placed(n, 0);
         std::vector<uint8_t>& pending = occ;          // 1 = old element not moved yet
         size = n;
@@ -132,6 +212,8 @@ struct HSet {
                 }
             }
         }
+        for (uint64_t i = 0; i < old; i++)
+            if (!placed[i]) array[i].seq.w[0] = EMPTY;             // vacated and not reused
         occ.swap(placed);
     }
     // the growth test of put_kmerset (newhash.c:477) for a static (-a) pool only raises the load factor
@@ -148,10 +230,11 @@ struct HSet {
         array[hc] = nd;
         count++;
     }
-    HNode<NW>* find(const Kmer<NW>& k) {                 // search_kmerset, newhash.c:277-318
-        uint64_t hc = home(k);
+    HNode<NW>* find(const Kmer<NW>& k) { return find_from(k, home(k)); }   // search_kmerset, newhash.c:277-318
+    void prefetch(uint64_t hc) const { __builtin_prefetch(&array[hc]); }
+    HNode<NW>* find_from(const Kmer<NW>& k, uint64_t hc) {
         for (;;) {
-            if (!occ[hc]) return nullptr;
+            if (array[hc].seq.w[0] == EMPTY) return nullptr;
             if (kmer_eq<NW>(array[hc].seq, k)) return &array[hc];
             if (++hc == size) hc = 0;
         }
@@ -208,16 +291,16 @@ struct Graph {
     // looked up by key (prlRead2path.c:558-596), so a plain map replaces the reference's second family of hash sets.
     std::unordered_map<Kmer<NW>, PatchVal, KmerHash<NW>, KmerEq<NW>> patch;
 
-    int set_of(const Kmer<NW>& k) const { return (int)set_of_crc(kmer_crc32<NW>(k, crc), (uint32_t)P, bias); }
+    int set_of(const Kmer<NW>& k) const { return (int)set_of_crc(host_crc32<NW>(k), (uint32_t)P, bias); }
 
-    struct Hit { HNode<NW>* node; Kmer<NW> oriented; bool smaller; };
+    struct Hit { HNode<NW>* node; Kmer<NW> oriented; bool smaller; int set; };
     // canonicalise a walk-oriented k-mer and look its node up
     Hit lookup(const Kmer<NW>& word) {
         Kmer<NW> bal = kmer_rc<NW>(word, K);
         Hit h;
         h.oriented = word;
-        if (kmer_less<NW>(bal, word)) { h.smaller = false; h.node = sets[set_of(bal)].find(bal); }
-        else { h.smaller = true; h.node = sets[set_of(word)].find(word); }
+        if (kmer_less<NW>(bal, word)) { h.smaller = false; h.set = set_of(bal); h.node = sets[h.set].find(bal); }
+        else { h.smaller = true; h.set = set_of(word); h.node = sets[h.set].find(word); }
         return h;
     }
     // the single outgoing base of a linear node in walk orientation
@@ -449,6 +532,255 @@ struct EdgeBuilder {
     }
 };
 
+
+// ---------------------------------------------------------------------------------------------------------------------
+// The same edges, built by all host threads.  Every chain of linear nodes between two branch nodes can be entered
+// from exactly two (node, arc) positions -- its two ends -- and the sequential scan (make_edge, node2edge.c:237-411)
+// emits it from whichever end it meets first and unlinks the other.  A walk only reads state that no emit changes
+// before the chain itself is emitted, so the walks are independent:
+//   1. the slot ranges are walked in parallel; a walk whose other end precedes it in scan order is dropped, the
+//      others are formatted (text record, interior nodes, arcs to unlink, (K+1)-mer of a length-1 edge);
+//   2. edge ids are a prefix sum over the ranges in scan order;
+//   3. in parallel again: unlink the end arcs, tag the interior nodes with their edge id, deflate each range's text
+//      into its own gzip member;
+//   4. serially: the (K+1)-mer patch entries in scan order, the gzip members in scan order.
+// ---------------------------------------------------------------------------------------------------------------------
+template <int NW>
+struct ParallelEdgeBuilder {
+    Graph<NW>& g;
+    int edge_c = 0;
+    long long records = 0, extra_nodes = 0;
+    explicit ParallelEdgeBuilder(Graph<NW>& g_) : g(g_) {}
+
+    struct Cand {
+        HNode<NW>* first; HNode<NW>* last;
+        uint64_t inner_off; uint32_t n_inner;
+        uint8_t next_ch, prev_ch; bool first_smaller, last_smaller;
+        uint8_t bal; bool len1, plus_smaller;
+        uint32_t plus_idx;
+    };
+    struct Chunk {
+        int set; uint64_t lo, hi;
+        std::vector<Cand> cands;
+        std::vector<uintptr_t> inner;                // interior node pointer | smaller
+        std::vector<Kmer<NW>> plus;                  // canonical (K+1)-mers of the length-1 edges
+        std::string text;
+        std::vector<uint8_t> gz;
+        std::vector<std::pair<Kmer<NW>, PatchVal>> patch;
+        int ids = 0, base = 0;
+        long long extra = 0;
+    };
+
+    struct Walker {
+        Graph<NW>& g;
+        struct Bead { HNode<NW>* node; Kmer<NW> kmer; bool smaller; int set; };
+        std::vector<Bead> beads;
+        explicit Walker(Graph<NW>& g_) : g(g_) {}
+        void walk(int nextch) {                      // stringBeads (node2edge.c:86-218)
+            typename Graph<NW>::Hit h = g.lookup(kmer_next<NW>(beads[0].kmer, nextch, g.filter));
+            while (h.node && (h.node->B & B_LINEAR)) {
+                beads.push_back(Bead{h.node, h.oriented, h.smaller, h.set});
+                h = g.lookup(kmer_next<NW>(h.oriented, Graph<NW>::only_out(*h.node, h.smaller), g.filter));
+            }
+            if (!h.node) { fprintf(stderr, "Kmer is not found while building an edge.\n"); exit(1); }
+            beads.push_back(Bead{h.node, h.oriented, h.smaller, h.set});
+        }
+        bool palindrome() const {                    // check_iden_kmerList (node2edge.c:624-649)
+            const size_t n = beads.size();
+            for (size_t i = 0; i < n; i++)
+                if (!kmer_eq<NW>(beads[i].kmer, kmer_rc<NW>(beads[n - 1 - i].kmer, g.K))) return false;
+            return true;
+        }
+    };
+
+    // one start (node, arc): walk, decide, format
+    void consider(Walker& w, Chunk& c, int set, uint64_t slot, int arc_order) {
+        const int count = (int)w.beads.size(), length = count - 1;
+        typename Walker::Bead& first = w.beads[0];
+        typename Walker::Bead& last = w.beads[count - 1];
+        const int prev_ch = kmer_first<NW>(w.beads[count - 2].kmer, g.K);
+        const int next_ch = kmer_last<NW>(w.beads[1].kmer);
+        // where the sequential scan would start the same chain from its other end
+        const uint64_t tslot = (uint64_t)(last.node - g.sets[last.set].array.data());
+        const int torder = last.smaller ? 4 + prev_ch : (prev_ch ^ 2);
+        if (last.set != set ? last.set < set : (tslot != slot ? tslot < slot : torder < arc_order)) return;
+        Cand cd;
+        cd.first = first.node; cd.last = last.node;
+        cd.first_smaller = first.smaller; cd.last_smaller = last.smaller;
+        cd.next_ch = (uint8_t)next_ch; cd.prev_ch = (uint8_t)prev_ch;
+        cd.bal = w.palindrome() ? 0 : 1;
+        cd.len1 = length == 1;
+        cd.plus_smaller = false; cd.plus_idx = 0;
+        if (cd.len1) {                               // the (K+1)-mer joining two branch nodes (node2edge.c:481-542)
+            const Kmer<NW> plus = kmer_plus<NW>(first.kmer, kmer_last<NW>(last.kmer));
+            const Kmer<NW> bal_plus = rc_plus<NW>(plus, g.K);
+            cd.plus_smaller = kmer_less<NW>(plus, bal_plus);
+            cd.plus_idx = (uint32_t)c.plus.size();
+            c.plus.push_back(cd.plus_smaller ? plus : bal_plus);
+            c.extra++;
+        }
+        cd.inner_off = c.inner.size();
+        cd.n_inner = (uint32_t)(count - 2);
+        long long sum = 0;
+        for (int i = 1; i < count - 1; i++) {
+            const HNode<NW>& n = *w.beads[i].node;
+            sum += nL(n, 0) + nL(n, 1) + nL(n, 2) + nL(n, 3);
+            c.inner.push_back((uintptr_t)w.beads[i].node | (uintptr_t)(w.beads[i].smaller ? 1 : 0));
+        }
+        int cvg = 0;
+        if (length > 1) { long long v = sum / (length - 1) * 10; cvg = v > 16000 ? 16000 : (int)v; }
+        char head[256];
+        int n = sprintf(head, ">length %d,", length);
+        n += fmt_kmer<NW>(head + n, first.kmer, ',');
+        n += fmt_kmer<NW>(head + n, last.kmer, ',');
+        n += sprintf(head + n, "cvg %d, %d\n", cvg, (int)cd.bal);
+        c.text.append(head, n);
+        for (int i = 0; i < length; i++) {
+            c.text.push_back("ACTG"[kmer_last<NW>(w.beads[i + 1].kmer)]);
+            if ((i + 1) % 100 == 0) c.text.push_back('\n');
+        }
+        if (length % 100 != 0) c.text.push_back('\n');
+        c.ids += 1 + cd.bal;
+        c.cands.push_back(cd);
+    }
+
+    void scan(Walker& w, Chunk& c) {
+        HSet<NW>& s = g.sets[c.set];
+        for (uint64_t i = c.lo; i < c.hi; i++) {
+            if (!s.occ[i]) continue;
+            HNode<NW>& n = s.array[i];
+            if (n.B & (B_LINEAR | B_DELETED)) continue;
+            const Kmer<NW> fwd = n.seq, rev = kmer_rc<NW>(n.seq, g.K);
+            for (int ch = 0; ch < 4; ch++) {
+                if (!nR(n, ch)) continue;
+                w.beads.clear();
+                w.beads.push_back(typename Walker::Bead{&n, fwd, true, c.set});
+                w.walk(ch);
+                consider(w, c, c.set, i, ch);
+            }
+            for (int ch = 0; ch < 4; ch++) {
+                if (!nL(n, ch)) continue;
+                w.beads.clear();
+                w.beads.push_back(typename Walker::Bead{&n, rev, false, c.set});
+                w.walk(ch ^ 2);
+                consider(w, c, c.set, i, 4 + ch);
+            }
+        }
+    }
+
+    static void clear_arc(uint32_t& word, int i) { __atomic_fetch_and(&word, ~(63u << (6 * i)), __ATOMIC_RELAXED); }
+    static bool gz_member(const std::string& text, std::vector<uint8_t>& out) {
+        z_stream z;
+        memset(&z, 0, sizeof(z));
+        if (deflateInit2(&z, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+        out.resize(deflateBound(&z, (uLong)text.size()) + 64);
+        z.next_in = (Bytef*)text.data(); z.avail_in = (uInt)text.size();
+        z.next_out = out.data(); z.avail_out = (uInt)out.size();
+        const int rc = deflate(&z, Z_FINISH);
+        out.resize(z.total_out);
+        deflateEnd(&z);
+        return rc == Z_STREAM_END;
+    }
+    // merge_linearV2 (node2edge.c:430-609) for the walks of one range, ids starting after c.base
+    bool apply(Chunk& c) {
+        int id = c.base;
+        for (const Cand& cd : c.cands) {
+            id++;
+            const int bal = cd.bal;
+            // dislink2prevUncertain / dislink2nextUncertain on the two end nodes (other ranges may touch the same words)
+            if (cd.last_smaller) clear_arc(cd.last->A, cd.prev_ch); else clear_arc(cd.last->B, cd.prev_ch ^ 2);
+            if (cd.first_smaller) clear_arc(cd.first->B, cd.next_ch); else clear_arc(cd.first->A, cd.next_ch ^ 2);
+            if (cd.len1) {
+                const PatchVal v = cd.plus_smaller ? PatchVal{(uint32_t)id, (uint32_t)(bal + 1)} : PatchVal{(uint32_t)(id + bal), (uint32_t)(1 - bal)};
+                c.patch.emplace_back(c.plus[cd.plus_idx], v);
+            }
+            for (uint32_t i = 0; i < cd.n_inner; i++) {
+                const uintptr_t v = c.inner[cd.inner_off + i];
+                HNode<NW>& n = *(HNode<NW>*)(v & ~(uintptr_t)1);
+                const bool smaller = v & 1;
+                if ((n.B >> B_INEDGE_SHIFT) & 3) return false;               // a linear node can sit on one chain only
+                const uint32_t twin = smaller ? (uint32_t)(bal + 1) : (uint32_t)(1 - bal);
+                n.A = smaller ? (uint32_t)id : (uint32_t)(id + bal);          // edge id replaces word A
+                n.B = (n.B & 0x0FFFFFFFu) | (twin << B_TWIN_SHIFT) | (1u << B_INEDGE_SHIFT);
+            }
+            id += bal;
+        }
+        std::vector<uintptr_t>().swap(c.inner);
+        std::vector<Kmer<NW>>().swap(c.plus);
+        if (!c.text.empty() && !gz_member(c.text, c.gz)) return false;
+        std::string().swap(c.text);
+        return true;
+    }
+
+    int run(const std::string& path, int n_threads) {
+        int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+        if (nt < 1) nt = 1;
+        std::vector<Chunk> chunks;
+        const uint64_t STEP = 1 << 15;
+        for (int si = 0; si < (int)g.sets.size(); si++)
+            for (uint64_t lo = 0; lo < g.sets[si].size; lo += STEP) {
+                chunks.emplace_back();
+                chunks.back().set = si; chunks.back().lo = lo; chunks.back().hi = std::min<uint64_t>(g.sets[si].size, lo + STEP);
+            }
+        auto for_chunks = [&](const std::function<void(Chunk&, Walker&)>& fn) {
+            std::atomic<size_t> next{0};
+            auto body = [&]() {
+                Walker w(g);
+                for (;;) {
+                    const size_t i = next.fetch_add(1);
+                    if (i >= chunks.size()) break;
+                    fn(chunks[i], w);
+                }
+            };
+            std::vector<std::thread> pool;
+            for (int t = 1; t < nt; t++) pool.emplace_back(body);
+            body();
+            for (auto& th : pool) th.join();
+        };
+        for_chunks([&](Chunk& c, Walker& w) { scan(w, c); });
+        int base = 0;
+        for (Chunk& c : chunks) { c.base = base; base += c.ids; records += (long long)c.cands.size(); extra_nodes += c.extra; }
+        edge_c = base;
+        std::atomic<int> failed{0};
+        for_chunks([&](Chunk& c, Walker&) { if (!apply(c)) failed.store(1); });
+        if (failed.load()) { pg_set_error("edge construction: inconsistent arcs or deflate failure (PG_SERIAL_EDGES=1 runs the sequential builder)"); return PG_EINVAL; }
+        FILE* fp = fopen(path.c_str(), "wb");
+        if (!fp) { pg_set_error("cannot open " + path); return PG_EIO; }
+        bool any = false;
+        for (Chunk& c : chunks) {
+            for (auto& kv : c.patch) g.patch[kv.first] = kv.second;
+            if (!c.gz.empty()) { any = true; if (fwrite(c.gz.data(), 1, c.gz.size(), fp) != c.gz.size()) { fclose(fp); pg_set_error("short write on " + path); return PG_EIO; } }
+            std::vector<uint8_t>().swap(c.gz);
+        }
+        if (!any) {                                  // no edge at all: still a valid (empty) gzip file
+            std::vector<uint8_t> e;
+            gz_member(std::string(), e);
+            fwrite(e.data(), 1, e.size(), fp);
+        }
+        fclose(fp);
+        return PG_OK;
+    }
+};
+
+// make_edge over all sets -> <prefix>.edge.gz; fills the counters of the stderr banner
+template <int NW>
+static int construct_edges(Graph<NW>& g, const std::string& prefix, int n_threads, int& edge_c, long long& records, long long& extra_nodes) {
+    const char* serial = getenv("PG_SERIAL_EDGES");
+    if (serial && atoi(serial)) {
+        GzText gz;
+        if (!gz.open(prefix + ".edge.gz")) { pg_set_error("cannot open " + prefix + ".edge.gz"); return PG_EIO; }
+        EdgeBuilder<NW> eb(g, gz);
+        eb.run();
+        gz.close();
+        edge_c = eb.edge_c; records = eb.records; extra_nodes = eb.extra_nodes;
+        return PG_OK;
+    }
+    ParallelEdgeBuilder<NW> eb(g);
+    const int rc = eb.run(prefix + ".edge.gz", n_threads);
+    edge_c = eb.edge_c; records = eb.records; extra_nodes = eb.extra_nodes;
+    return rc;
+}
+
 // output_vertex (output_pregraph.c:50-86)
 template <int NW>
 static int write_vertex(Graph<NW>& g, const std::string& prefix, int num_ed, int max_read_len, int& num_vt) {
@@ -488,6 +820,7 @@ static int replay_layout(Graph<NW>& g, const uint64_t* records, uint64_t n, cons
                          int a_gb, int n_threads) {
     constexpr int RW = NW + 2;
     g.K = K; g.P = P; g.filter = kmer_filter<NW>(K); g.bias = set_bias((uint32_t)P); g.crc = host_crc_table();
+    host_crc8_init();
     g.sets.clear();
     g.sets.resize(P);
     std::vector<uint64_t> per_set(P + 1, 0);
@@ -569,6 +902,8 @@ struct ReadThreader {
     explicit ReadThreader(Graph<NW>& g_) : g(g_) {}
 
     struct Item { uint32_t id; bool kplus; bool smaller; Kmer<NW> plus; };
+    struct Probe { Kmer<NW> key; uint64_t home; int set; bool smaller; };
+    std::vector<Probe> probes;
 
     // appends the read's pairs (from, to) to `out`; returns false when the read yielded no usable item at all
     // (the reference's "read(s) deleted" counter, prlRead2path.c:722-725)
@@ -582,15 +917,33 @@ struct ReadThreader {
         bool is_prev = false;
         Kmer<NW> prev_k;
         for (int i = 0; i < NW; i++) prev_k.w[i] = 0;
-        Kmer<NW> word;
-        for (int i = 0; i < NW; i++) word.w[i] = 0;
-        for (int i = 0; i < K - 1; i++) word = kmer_next<NW>(word, codes[i], g.filter);
-        for (int j = 0; j + K <= len; j++) {
-            word = kmer_next<NW>(word, codes[j + K - 1], g.filter);
-            const Kmer<NW> bal = kmer_rc<NW>(word, K);
-            const bool smaller = kmer_less<NW>(word, bal);
-            const Kmer<NW>& key = smaller ? word : bal;
-            const HNode<NW>* node = g.sets[g.set_of(key)].find(key);
+        // stage 1: every canonical k-mer of the read, its set and home slot; the slots are prefetched so that the
+        // probes of stage 2 overlap their cache misses (chopKmer4read + searchKmer, prlRead2path.c:159-330)
+        const int nk = len - K + 1;
+        if ((int)probes.size() < nk) probes.resize(nk);
+        {
+            Kmer<NW> word, bal;
+            for (int i = 0; i < NW; i++) word.w[i] = 0;
+            for (int i = 0; i < K - 1; i++) word = kmer_next<NW>(word, codes[i], g.filter);
+            bal = kmer_rc<NW>(word, K - 1);                       // reverse complement of the first K - 1 bases
+            const int top = 2 * (K - 1), tw = NW - 1 - top / 64, ts = top % 64;
+            for (int j = 0; j < nk; j++) {
+                const int c = codes[j + K - 1];
+                word = kmer_next<NW>(word, c, g.filter);
+                if (j) bal = kmer_shr<NW>(bal, 2);
+                bal.w[tw] |= (uint64_t)(c ^ 2) << ts;
+                Probe& pr = probes[j];
+                pr.smaller = kmer_less<NW>(word, bal);
+                pr.key = pr.smaller ? word : bal;
+                pr.set = g.set_of(pr.key);
+                pr.home = g.sets[pr.set].home(pr.key);
+                g.sets[pr.set].prefetch(pr.home);
+            }
+        }
+        for (int j = 0; j < nk; j++) {
+            const Probe& pr = probes[j];
+            const bool smaller = pr.smaller;
+            const HNode<NW>* node = g.sets[pr.set].find_from(pr.key, pr.home);
             if (!node) { fprintf(stderr, "SearchKmer: kmer is not found.\n"); exit(1); }
             const uint32_t B = node->B;
             const bool linear = B & B_LINEAR, in_edge = (B >> B_INEDGE_SHIFT) & 3;
@@ -604,7 +957,7 @@ struct ReadThreader {
                 if (retain == 0 || is_prev) { retain++; items.push_back(Item{e, false, false, Kmer<NW>()}); is_prev = false; }
                 else if (e != items.back().id) { retain++; items.push_back(Item{e, false, false, Kmer<NW>()}); }
             } else {
-                const Kmer<NW> cur = word;            // the node's k-mer in read orientation (prlRead2path.c:680-687)
+                const Kmer<NW> cur = smaller ? pr.key : kmer_rc<NW>(pr.key, K);   // the node's k-mer in read orientation (prlRead2path.c:680-687)
                 if (is_prev) {
                     retain++;
                     const Kmer<NW> plus = kmer_plus<NW>(prev_k, kmer_last<NW>(cur));
@@ -651,17 +1004,23 @@ struct ReadThreader {
 // pre-arc lists: new targets go to the head of their source's list (prlRead2path.c:388-403), output walks from the
 // head (output_arcs, prlRead2path.c:426-476)
 struct PreArcs {
-    std::vector<uint32_t> head;            // per from-edge, index + 1 into the pools, 0 = empty
-    std::vector<uint32_t> to, mult, next;
-    long long count = 0;
-    void init(uint32_t num_ed) { head.assign((size_t)num_ed + 1, 0); }
-    void add(uint32_t from, uint32_t t) {
-        for (uint32_t i = head[from]; i; i = next[i - 1])
-            if (to[i - 1] == t) { mult[i - 1]++; return; }
-        to.push_back(t); mult.push_back(1); next.push_back(head[from]);
-        head[from] = (uint32_t)to.size();
-        count++;
+    // The order of a list depends only on the order in which the pairs of its own source edge arrive, so the source
+    // edges are cut into NP contiguous ranges that are folded independently (each range owns its pools).
+    static constexpr int NP = 64;
+    struct Pool { std::vector<uint32_t> to, mult, next; long long count = 0; };
+    std::vector<uint32_t> head;            // per from-edge, index + 1 into its range's pools, 0 = empty
+    Pool pool[NP];
+    uint64_t n_from = 1;
+    void init(uint32_t num_ed) { head.assign((size_t)num_ed + 1, 0); n_from = (uint64_t)num_ed + 1; }
+    int part_of(uint32_t from) const { return (int)((uint64_t)from * NP / n_from); }
+    void add(Pool& p, uint32_t from, uint32_t t) {
+        for (uint32_t i = head[from]; i; i = p.next[i - 1])
+            if (p.to[i - 1] == t) { p.mult[i - 1]++; return; }
+        p.to.push_back(t); p.mult.push_back(1); p.next.push_back(head[from]);
+        head[from] = (uint32_t)p.to.size();
+        p.count++;
     }
+    long long count() const { long long c = 0; for (const Pool& p : pool) c += p.count; return c; }
     int write(const std::string& path) const {
         FILE* fp = fopen(path.c_str(), "w");
         if (!fp) { pg_set_error("cannot open " + path); return PG_EIO; }
@@ -669,8 +1028,9 @@ struct PreArcs {
         setvbuf(fp, big.data(), _IOFBF, big.size());
         for (size_t e = 1; e < head.size(); e++) {
             if (!head[e]) continue;
+            const Pool& p = pool[part_of((uint32_t)e)];
             fprintf(fp, "%u", (unsigned)e);
-            for (uint32_t i = head[e]; i; i = next[i - 1]) fprintf(fp, " %u %u", to[i - 1], mult[i - 1]);
+            for (uint32_t i = head[e]; i; i = p.next[i - 1]) fprintf(fp, " %u %u", p.to[i - 1], p.mult[i - 1]);
             fputc('\n', fp);
         }
         fclose(fp);
@@ -699,6 +1059,8 @@ struct GraphHandle : GraphHandleBase {
     FILE* path_fp = nullptr;
     std::vector<uint8_t> marker;
     long long mark_count = 0;
+    double t_thread = 0, t_fold = 0;
+    static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
     ~GraphHandle() override { if (path_fp) fclose(path_fp); }
     int resolve_repeats(int on) override {
@@ -714,45 +1076,78 @@ struct GraphHandle : GraphHandleBase {
     int add_reads(const uint8_t* codes, const int32_t* lens, uint64_t n, uint64_t stride, int n_threads) override {
         int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
         nt = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)nt, (n + 255) / 256));
-        std::vector<std::vector<std::pair<uint32_t, uint32_t>>> pairs(nt);
-        std::vector<long long> deleted(nt, 0);
+        constexpr int NP = PreArcs::NP;
+        typedef std::vector<std::pair<uint32_t, uint32_t>> Pairs;
+        std::vector<Pairs> pairs((size_t)nt * NP);                            // [thread][source-edge range]
+        std::vector<long long> deleted(nt, 0), marked(nt, 0);
         const bool reps = path_fp != nullptr;
         std::vector<std::vector<uint8_t>> paths(reps ? nt : 0);
-        std::vector<std::vector<uint32_t>> marks(reps ? nt : 0);
+        std::atomic<int> bad{0};
+        const uint32_t id_end = (uint32_t)arcs.head.size();
         auto worker = [&](int t) {
             ReadThreader<NW> rt(g);
             std::vector<typename ReadThreader<NW>::Item> items;
+            Pairs one;
+            std::vector<uint32_t> marks;
             const uint64_t lo = n * t / nt, hi = n * (t + 1) / nt;
             for (uint64_t r = lo; r < hi; r++) {
                 const int len = lens ? lens[r] : (int)stride;
                 if (len < g.K + 1) continue;                                  // prlRead2path.c:1103 (same filter as pass 1)
-                if (!rt.thread_read(codes + r * stride, len, items, pairs[t], reps ? &paths[t] : nullptr, reps ? &marks[t] : nullptr)) deleted[t]++;
+                one.clear();
+                marks.clear();
+                if (!rt.thread_read(codes + r * stride, len, items, one, reps ? &paths[t] : nullptr, reps ? &marks : nullptr)) deleted[t]++;
+                for (auto& pr : one) {
+                    if (pr.first >= id_end) { bad.store(1); continue; }
+                    pairs[(size_t)t * NP + arcs.part_of(pr.first)].push_back(pr);
+                }
+                // saturating per-edge marker counts: increments commute, so they are applied right here
+                for (uint32_t e : marks) {
+                    if (e >= marker.size()) { bad.store(1); continue; }
+                    uint8_t v = __atomic_load_n(&marker[e], __ATOMIC_RELAXED);
+                    while (v < 255 && !__atomic_compare_exchange_n(&marker[e], &v, (uint8_t)(v + 1), true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+                }
+                marked[t] += (long long)marks.size();
             }
         };
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nt; t++) pool.emplace_back(worker, t);
-        worker(0);
-        for (auto& th : pool) th.join();
-        // the lists depend on first-encounter order: fold the chunks in read order, serially
+        const double t0 = now();
+        {
+            std::vector<std::thread> pool;
+            for (int t = 1; t < nt; t++) pool.emplace_back(worker, t);
+            worker(0);
+            for (auto& th : pool) th.join();
+        }
+        const double t1 = now();
+        t_thread += t1 - t0;
+        if (bad.load()) { pg_set_error("edge id out of range in pass 2"); return PG_EINVAL; }
+        // fold: every source-edge range takes its pairs thread by thread, i.e. in read order
+        {
+            std::atomic<int> next{0};
+            auto folder = [&]() {
+                for (;;) {
+                    const int part = next.fetch_add(1);
+                    if (part >= NP) break;
+                    PreArcs::Pool& pl = arcs.pool[part];
+                    for (int t = 0; t < nt; t++)
+                        for (auto& pr : pairs[(size_t)t * NP + part]) arcs.add(pl, pr.first, pr.second);
+                }
+            };
+            std::vector<std::thread> pool;
+            for (int t = 1; t < std::min(nt, NP); t++) pool.emplace_back(folder);
+            folder();
+            for (auto& th : pool) th.join();
+        }
         for (int t = 0; t < nt; t++) {
-            for (auto& pr : pairs[t]) {
-                if (pr.first >= arcs.head.size()) { pg_set_error("edge id out of range in pass 2"); return PG_EINVAL; }
-                arcs.add(pr.first, pr.second);
-            }
             reads_deleted += deleted[t];
             if (reps) {
                 if (!paths[t].empty() && fwrite(paths[t].data(), 1, paths[t].size(), path_fp) != paths[t].size()) {
                     pg_set_error("short write on " + prefix + ".path");
                     return PG_EIO;
                 }
-                for (uint32_t e : marks[t]) {
-                    if (e >= marker.size()) { pg_set_error("edge id out of range in pass 2"); return PG_EINVAL; }
-                    if (marker[e] < 255) marker[e]++;
-                }
-                mark_count += (long long)marks[t].size();
+                mark_count += marked[t];
             }
         }
         reads_seen += (long long)n;
+        t_fold += now() - t1;
         return PG_OK;
     }
     int finish(long long* n_arcs) override {
@@ -767,8 +1162,9 @@ struct GraphHandle : GraphHandleBase {
             for (size_t e = 1; e < marker.size(); e++) fprintf(fp, "%d\n", (int)marker[e]);
             fclose(fp);
         }
-        fprintf(stderr, "Reads alignment done, %lld read(s) deleted, %lld pre-arc(s) added.\n", reads_deleted, arcs.count);
-        if (n_arcs) *n_arcs = arcs.count;
+        fprintf(stderr, "Reads alignment done, %lld read(s) deleted, %lld pre-arc(s) added.\n", reads_deleted, arcs.count());
+        fprintf(stderr, "Time spent on threading reads: %.1fs, on folding pre-arcs: %.1fs.\n", t_thread, t_fold);
+        if (n_arcs) *n_arcs = arcs.count();
         return write_vertex<NW>(g, prefix, num_ed, max_read_len, num_vt);
     }
 };
@@ -788,15 +1184,13 @@ static GraphHandleBase* graph_begin(const uint64_t* records, uint64_t n, const u
     h->g.remove_minor_tips();
     fprintf(stderr, "Time spent on removing tips: %.1fs.\n\n", now() - t0);
     t0 = now();
-    GzText gz;
-    if (!gz.open(h->prefix + ".edge.gz")) { pg_set_error("cannot open " + h->prefix + ".edge.gz"); delete h; return nullptr; }
-    EdgeBuilder<NW> eb(h->g, gz);
-    eb.run();
-    gz.close();
-    fprintf(stderr, "%d (%lld) edge(s) and %lld extra node(s) constructed.\n", eb.edge_c, eb.records, eb.extra_nodes);
+    int edge_c = 0;
+    long long records_c = 0, extra_nodes = 0;
+    if (construct_edges<NW>(h->g, h->prefix, n_threads, edge_c, records_c, extra_nodes) != PG_OK) { delete h; return nullptr; }
+    fprintf(stderr, "%d (%lld) edge(s) and %lld extra node(s) constructed.\n", edge_c, records_c, extra_nodes);
     fprintf(stderr, "Time spent on constructing edges: %.1fs.\n\n", now() - t0);
-    h->num_ed = eb.edge_c;
-    h->arcs.init((uint32_t)eb.edge_c);
+    h->num_ed = edge_c;
+    h->arcs.init((uint32_t)edge_c);
     return h;
 }
 
@@ -813,18 +1207,17 @@ static int build_graph(const uint64_t* records, uint64_t n, const uint64_t* set_
     g.remove_minor_tips();
 
     // ---- edges (pregraph.c:122-127)
-    GzText gz;
-    if (!gz.open(prefix + ".edge.gz")) { pg_set_error("cannot open " + prefix + ".edge.gz"); return PG_EIO; }
-    EdgeBuilder<NW> eb(g, gz);
-    eb.run();
-    gz.close();
-    fprintf(stderr, "%d (%lld) edge(s) and %lld extra node(s) constructed.\n", eb.edge_c, eb.records, eb.extra_nodes);
+    int edge_c = 0;
+    long long records_c = 0, extra_nodes = 0;
+    int rc = construct_edges<NW>(g, prefix, n_threads, edge_c, records_c, extra_nodes);
+    if (rc) return rc;
+    fprintf(stderr, "%d (%lld) edge(s) and %lld extra node(s) constructed.\n", edge_c, records_c, extra_nodes);
 
     int num_vt = 0;
-    int rc = write_vertex<NW>(g, prefix, eb.edge_c, max_read_len, num_vt);
+    rc = write_vertex<NW>(g, prefix, edge_c, max_read_len, num_vt);
     if (rc) return rc;
     if (out_vt) *out_vt = num_vt;
-    if (out_ed) *out_ed = eb.edge_c;
+    if (out_ed) *out_ed = edge_c;
     return PG_OK;
 }
 
