@@ -24,7 +24,9 @@
 #include <functional>
 #include <string>
 #include <thread>
+#include <queue>
 #include <unordered_map>
+#include <unordered_set>
 #include <vector>
 
 #include "kmer.hpp"
@@ -130,7 +132,7 @@ struct HugeArray {
         uintptr_t a = (uintptr_t)q, al = (a + HP - 1) / HP * HP;
         if (al > a) munmap(q, al - a);
         if (al + nb < a + nb + HP) munmap((void*)(al + nb), a + HP - al);
-        madvise((void*)al, nb, MADV_HUGEPAGE);
+        if (!getenv("PG_NO_THP")) madvise((void*)al, nb, MADV_HUGEPAGE);
         T* np = (T*)al;
         if (keep) memcpy((void*)np, (const void*)p, keep * sizeof(T));
         release();
@@ -173,23 +175,43 @@ struct HSet {
         }
         return t;
     }
-    void init(uint64_t sz) {
+    // the size after `puts` growth tests starting from an empty set of `sz` slots (the schedule depends on counts only)
+    static uint64_t final_size(uint64_t sz, uint64_t puts, bool static_pool) {
+        if (static_pool) return sz;
+        const float lf = 0.77f;
+        uint64_t max = (uint64_t)((float)sz * lf);
+        while (puts > max) {                                   // the put with count + 1 == max + 1 grows the set
+            uint64_t n = sz;
+            do {
+                n = (n < 0xFFFFFFFULL) ? (n << 1) : (n + 0xFFFFFFULL);
+                n = ref_next_prime(n);
+            } while ((float)n * lf < (float)(max + 1));
+            sz = n;
+            max = (uint64_t)((float)sz * lf);
+        }
+        return sz;
+    }
+    // `capacity` slots are reserved up front (untouched pages cost nothing) so that growing never has to move the array
+    void init(uint64_t sz, uint64_t capacity = 0) {
         size = sz; count = 0; lf = 0.77f;
         max = (uint64_t)((float)size * lf);
-        array.reset(size);
+        array.reset(std::max(size, capacity));
         for (uint64_t i = 0; i < size; i++) array[i].seq.w[0] = EMPTY;
         occ.assign(size, 0);
     }
     // encap_kmerset, growable case (newhash.c:368-454): next size, then re-home in place in old-slot order,
     // an element that lands on a not-yet-moved old element kicks it out and that one is placed next
+    double t_grow = 0;
     void grow() {
+        const auto tg0 = std::chrono::steady_clock::now();
+        struct Acc { double& t; std::chrono::steady_clock::time_point t0; ~Acc() { t += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(); } } acc{t_grow, tg0};
         uint64_t n = size;
         do {
             n = (n < 0xFFFFFFFULL) ? (n << 1) : (n + 0xFFFFFFULL);
             n = ref_next_prime(n);
         } while ((float)n * lf < (float)(count + 1));
         const uint64_t old = size;
-        array.reset(n, old);
+        if (n > array.n) array.reset(n, old);
         for (uint64_t i = old; i < n; i++) array[i].seq.w[0] = EMPTY;
         std::vector<uint8_t> placed(n, 0);
         std::vector<uint8_t>& pending = occ;          // 1 = old element not moved yet
@@ -224,7 +246,10 @@ struct HSet {
     }
     void put_new(const HNode<NW>& nd, bool static_pool) {
         before_put(static_pool);
-        uint64_t hc = home(nd.seq);
+        put_new_at(nd, home(nd.seq));
+    }
+    void prefetch_put(uint64_t hc) const { __builtin_prefetch(&array[hc], 1); __builtin_prefetch(&occ[hc], 1); }
+    void put_new_at(const HNode<NW>& nd, uint64_t hc) {                 // the caller ran before_put
         while (occ[hc]) { if (++hc == size) hc = 0; }
         occ[hc] = 1;
         array[hc] = nd;
@@ -283,6 +308,7 @@ struct PatchVal { uint32_t id; uint32_t twin; };
 template <int NW>
 struct Graph {
     int K, P;
+    int n_threads = 0;             // host threads for the parallel scans (0 = all)
     Kmer<NW> filter;
     uint32_t bias;
     const uint32_t* crc;
@@ -316,17 +342,47 @@ struct Graph {
 
     // Mark1in1outNode of cutTipPreGraph.c:532-564,603-639
     void remark_linear() {
-        for (auto& s : sets)
-            for (uint64_t i = 0; i < s.size; i++) {
-                if (!s.occ[i]) continue;
-                HNode<NW>& n = s.array[i];
-                if (n.B & (B_DELETED | B_LINEAR)) continue;
-                if (n_in(n) == 1 && n_out(n) == 1) n.B |= B_LINEAR;
+        int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+        if (nt < 1) nt = 1;
+        std::atomic<uint64_t> next{0};
+        const uint64_t STEP = 1 << 18;
+        std::vector<std::pair<int, uint64_t>> chunks;
+        for (int si = 0; si < (int)sets.size(); si++)
+            for (uint64_t lo = 0; lo < sets[si].size; lo += STEP) chunks.emplace_back(si, lo);
+        auto body = [&]() {
+            for (;;) {
+                const uint64_t ci = next.fetch_add(1);
+                if (ci >= chunks.size()) break;
+                HSet<NW>& s = sets[chunks[ci].first];
+                const uint64_t hi = std::min<uint64_t>(s.size, chunks[ci].second + STEP);
+                for (uint64_t i = chunks[ci].second; i < hi; i++) {
+                    if (!s.occ[i]) continue;
+                    HNode<NW>& n = s.array[i];
+                    if (n.B & (B_DELETED | B_LINEAR)) continue;
+                    if (n_in(n) == 1 && n_out(n) == 1) n.B |= B_LINEAR;
+                }
             }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; t++) pool.emplace_back(body);
+        body();
+        for (auto& th : pool) th.join();
     }
 
-    // clipTipFromNode (cutTipPreGraph.c:43-346)
-    bool clip_tip(HNode<NW>& start, int cut_len, bool thin, long long& tips) {
+    // clipTipFromNode (cutTipPreGraph.c:43-346), split into the read-only walk and the mutation it decides on, so
+    // that the walks can run ahead of the (order-dependent) mutations
+    struct TipDecision {
+        int action = 0;                // 0 nothing, 1 both ends dead, 2 thin cut, 3 minority cut
+        HNode<NW>* far = nullptr;
+        int far_set = 0, first = 0;
+        bool far_smaller = false;
+    };
+    static bool dead_end(const HNode<NW>& n) {
+        const int in = n_in(n), out = n_out(n);
+        return (in == 0 && out == 1) || (in == 1 && out == 0);
+    }
+    TipDecision tip_evaluate(const HNode<NW>& start, int cut_len, bool thin) {
+        TipDecision d;
         const int in = n_in(start), out = n_out(start);
         Kmer<NW> prev;
         int ch;
@@ -337,40 +393,117 @@ struct Graph {
             prev = kmer_rc<NW>(start.seq, K);
             for (ch = 0; ch < 4; ch++) if (nL(start, ch)) break;
             ch ^= 2;
-        } else return false;
+        } else return d;
         int count = 1;
         Hit h = lookup(kmer_next<NW>(prev, ch, filter));
         if (!h.node) { fprintf(stderr, "Kmer is not found while clipping a tip.\n"); exit(1); }
         while (h.node->B & B_LINEAR) {
             count++;
             if (thin && !(h.node->B & B_SINGLE)) break;
-            if (count > cut_len) return false;
+            if (count > cut_len) return d;
             prev = h.oriented;
             h = lookup(kmer_next<NW>(prev, only_out(*h.node, h.smaller), filter));
             if (!h.node) { fprintf(stderr, "Kmer is not found while clipping a tip.\n"); exit(1); }
         }
-        HNode<NW>& far = *h.node;
-        if (n_in(far) + n_out(far) == 1) {
-            tips++; start.B |= B_DELETED; far.B |= B_DELETED;
-            return true;
-        }
-        const int first = kmer_first<NW>(prev, K);
-        if (thin) {
-            tips++; start.B |= B_DELETED;
-            cut_prev(far, first, h.smaller);
-            far.B &= ~B_LINEAR;
-            return true;
-        }
+        const HNode<NW>& far = *h.node;
+        d.far = h.node; d.far_set = h.set; d.far_smaller = h.smaller;
+        d.first = kmer_first<NW>(prev, K);
+        if (n_in(far) + n_out(far) == 1) { d.action = 1; return d; }
+        if (thin) { d.action = 2; return d; }
         int strongest = 0;
         for (int c = 0; c < 4; c++) strongest = std::max(strongest, h.smaller ? nL(far, c) : nR(far, c));
-        const int mine = h.smaller ? nL(far, first) : nR(far, first ^ 2);
-        if (mine < strongest) {
-            tips++; start.B |= B_DELETED;
-            cut_prev(far, first, h.smaller);
-            if (n_in(far) == 1 && n_out(far) == 1) far.B |= B_LINEAR;
-            return true;
+        const int mine = h.smaller ? nL(far, d.first) : nR(far, d.first ^ 2);
+        if (mine < strongest) d.action = 3;
+        return d;
+    }
+    bool tip_apply(HNode<NW>& start, const TipDecision& d, long long& tips) {
+        if (!d.action) return false;
+        HNode<NW>& far = *d.far;
+        tips++;
+        start.B |= B_DELETED;
+        if (d.action == 1) { far.B |= B_DELETED; return true; }
+        cut_prev(far, d.first, d.far_smaller);
+        if (d.action == 2) far.B &= ~B_LINEAR;
+        else if (n_in(far) == 1 && n_out(far) == 1) far.B |= B_LINEAR;
+        return true;
+    }
+    bool clip_tip(HNode<NW>& start, int cut_len, bool thin, long long& tips) {
+        return tip_apply(start, tip_evaluate(start, cut_len, thin), tips);
+    }
+
+    // One scan of removeSingleTips / removeMinorTips over all sets (cutTipPreGraph.c:363-399,414-488) with the walks done
+    // by all host threads.  A walk reads its start node, linear interior nodes and the node it stops at; a clipped tip
+    // changes only its start node and its stop node, and neither was the interior of any walk when the scan began.  So:
+    // every dead-end start is walked in parallel up front; the scan order is then replayed serially, taking the
+    // precomputed decision when neither end of the walk has been touched since and walking again otherwise.  A stop node
+    // that becomes a dead end further down the scan is visited there, as the sequential scan would.
+    long long tip_scan(int cut_len, bool thin, long long& tips) {
+        int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+        if (nt < 1) nt = 1;
+        struct Cand { uint64_t pos; TipDecision d; };
+        struct Chunk { int set; uint64_t lo, hi; std::vector<Cand> c; };
+        std::vector<Chunk> chunks;
+        const uint64_t STEP = 1 << 16;
+        for (int si = 0; si < (int)sets.size(); si++)
+            for (uint64_t lo = 0; lo < sets[si].size; lo += STEP) chunks.push_back(Chunk{si, lo, std::min<uint64_t>(sets[si].size, lo + STEP), {}});
+        auto startable = [thin](const HNode<NW>& n) { return !(n.B & (B_LINEAR | B_DELETED)) && (!thin || (n.B & B_SINGLE)); };
+        {
+            std::atomic<size_t> next{0};
+            auto body = [&]() {
+                for (;;) {
+                    const size_t ci = next.fetch_add(1);
+                    if (ci >= chunks.size()) break;
+                    Chunk& ck = chunks[ci];
+                    HSet<NW>& s = sets[ck.set];
+                    for (uint64_t i = ck.lo; i < ck.hi; i++) {
+                        if (!s.occ[i]) continue;
+                        const HNode<NW>& n = s.array[i];
+                        if (!startable(n) || !dead_end(n)) continue;
+                        ck.c.push_back(Cand{((uint64_t)ck.set << 40) | i, tip_evaluate(n, cut_len, thin)});
+                    }
+                }
+            };
+            std::vector<std::thread> pool;
+            for (int t = 1; t < nt; t++) pool.emplace_back(body);
+            body();
+            for (auto& th : pool) th.join();
         }
-        return false;
+        std::unordered_set<const HNode<NW>*> touched;
+        std::priority_queue<uint64_t, std::vector<uint64_t>, std::greater<uint64_t>> later;
+        long long removed = 0, rewalked = 0;
+        auto node_at = [&](uint64_t pos) -> HNode<NW>& { return sets[pos >> 40].array[pos & ((1ULL << 40) - 1)]; };
+        auto visit = [&](uint64_t pos, const TipDecision* spec) {
+            HNode<NW>& n = node_at(pos);
+            if (!startable(n)) return;
+            TipDecision d;
+            if (spec && !touched.count(&n) && (!spec->far || !touched.count(spec->far))) d = *spec;
+            else { d = tip_evaluate(n, cut_len, thin); rewalked++; }
+            if (!tip_apply(n, d, tips)) return;
+            removed++;
+            touched.insert(&n);
+            touched.insert(d.far);
+            if (d.action != 1) {
+                const uint64_t fpos = ((uint64_t)d.far_set << 40) | (uint64_t)(d.far - sets[d.far_set].array.data());
+                if (fpos > pos) later.push(fpos);
+            }
+        };
+        for (Chunk& ck : chunks)
+            for (Cand& cd : ck.c) {
+                while (!later.empty() && later.top() < cd.pos) {
+                    const uint64_t p = later.top();
+                    while (!later.empty() && later.top() == p) later.pop();
+                    visit(p, nullptr);
+                }
+                while (!later.empty() && later.top() == cd.pos) later.pop();     // already on the list: visited once
+                visit(cd.pos, &cd.d);
+            }
+        while (!later.empty()) {
+            const uint64_t p = later.top();
+            while (!later.empty() && later.top() == p) later.pop();
+            visit(p, nullptr);
+        }
+        if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "tip scan: %lld removed, %lld walked again\n", removed, rewalked);
+        return removed;
     }
 
     // removeSingleTips (cutTipPreGraph.c:363-399)
@@ -378,12 +511,7 @@ struct Graph {
         const int cut = 2 * K;
         long long tips = 0;
         fprintf(stderr, "Start to remove frequency-one-kmer tips shorter than %d.\n", cut);
-        for (auto& s : sets)
-            for (uint64_t i = 0; i < s.size; i++) {
-                if (!s.occ[i]) continue;
-                HNode<NW>& n = s.array[i];
-                if (!(n.B & (B_LINEAR | B_DELETED)) && (n.B & B_SINGLE)) clip_tip(n, cut, true, tips);
-            }
+        tip_scan(cut, true, tips);
         fprintf(stderr, "Total %lld tip(s) removed.\n", tips);
         remark_linear();
     }
@@ -394,14 +522,8 @@ struct Graph {
         fprintf(stderr, "Start to remove tips with minority links.\n");
         int round = 1;
         for (;;) {
-            int removed = 0;
-            for (auto& s : sets)
-                for (uint64_t i = 0; i < s.size; i++) {
-                    if (!s.occ[i]) continue;
-                    HNode<NW>& n = s.array[i];
-                    if (!(n.B & (B_LINEAR | B_DELETED))) removed += clip_tip(n, cut, false, tips);
-                }
-            fprintf(stderr, "%d tip(s) removed in cycle %d.\n", removed, round++);
+            const long long removed = tip_scan(cut, false, tips);
+            fprintf(stderr, "%lld tip(s) removed in cycle %d.\n", removed, round++);
             if (!removed) break;
         }
         fprintf(stderr, "Total %lld tip(s) removed.\n", tips);
@@ -821,6 +943,7 @@ static int replay_layout(Graph<NW>& g, const uint64_t* records, uint64_t n, cons
     constexpr int RW = NW + 2;
     g.K = K; g.P = P; g.filter = kmer_filter<NW>(K); g.bias = set_bias((uint32_t)P); g.crc = host_crc_table();
     host_crc8_init();
+    g.n_threads = n_threads;
     g.sets.clear();
     g.sets.resize(P);
     std::vector<uint64_t> per_set(P + 1, 0);
@@ -840,6 +963,9 @@ static int replay_layout(Graph<NW>& g, const uint64_t* records, uint64_t n, cons
         }
     }
     const uint64_t init_size = ref_initial_set_size(a_gb, P, NW == 4);
+    if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "replay: bucketing done\n");
+    const bool verbose = getenv("PG_HOST_VERBOSE") != nullptr;
+    auto nowf = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     std::atomic<int> next{0};
     auto worker = [&]() {
         for (;;) {
@@ -847,19 +973,57 @@ static int replay_layout(Graph<NW>& g, const uint64_t* records, uint64_t n, cons
             if (s >= P) break;
             Ref* lo = order.data() + per_set[s];
             Ref* hi = order.data() + per_set[s + 1];
-            std::sort(lo, hi, [](const Ref& a, const Ref& b) { return a.ord < b.ord; });
+            const double ts0 = nowf();
+            {   // LSD radix sort on the ordinal, 16 bits a pass (ordinals are distinct within a set)
+                const size_t cnt = (size_t)(hi - lo);
+                uint64_t top = 0;
+                for (Ref* r = lo; r != hi; ++r) top |= r->ord;
+                std::vector<Ref> tmp(cnt);
+                Ref* src = lo;
+                Ref* dst = tmp.data();
+                std::vector<size_t> hist(65536);
+                for (int shift = 0; shift < 64 && (top >> shift); shift += 16) {
+                    std::fill(hist.begin(), hist.end(), 0);
+                    for (size_t i = 0; i < cnt; i++) hist[(src[i].ord >> shift) & 0xffff]++;
+                    size_t run = 0;
+                    for (size_t d = 0; d < 65536; d++) { const size_t c = hist[d]; hist[d] = run; run += c; }
+                    for (size_t i = 0; i < cnt; i++) dst[hist[(src[i].ord >> shift) & 0xffff]++] = src[i];
+                    std::swap(src, dst);
+                }
+                if (src != lo) memcpy((void*)lo, (const void*)src, cnt * sizeof(Ref));
+            }
+            const double ts1 = nowf();
             HSet<NW>& hs = g.sets[s];
-            hs.init(init_size);
-            for (Ref* r = lo; r != hi; ++r) {
+            hs.init(init_size, HSet<NW>::final_size(init_size, (uint64_t)(hi - lo) + 1, a_gb != 0));
+            // the inserts are strictly ordered, but their cache misses need not be: the record and the home slot of the
+            // insert AHEAD steps further on are prefetched (a home computed for an outgrown size is simply recomputed)
+            constexpr int AHEAD = 16;
+            uint64_t ring_home[AHEAD], ring_size[AHEAD];
+            for (int i = 0; i < AHEAD; i++) ring_size[i] = 0;
+            const int64_t cnt = hi - lo;
+            auto key_of = [&](const Ref* r) { Kmer<NW> k; const uint64_t* rec = records + r->idx * RW; for (int w = 0; w < NW; w++) k.w[w] = rec[w]; return k; };
+            for (int64_t i = 0; i < std::min<int64_t>(cnt, 2 * AHEAD); i++) __builtin_prefetch(records + lo[i].idx * RW);
+            for (int64_t i = 0; i < std::min<int64_t>(cnt, AHEAD); i++) {
+                ring_home[i] = hs.home(key_of(lo + i)); ring_size[i] = hs.size; hs.prefetch_put(ring_home[i]);
+            }
+            for (int64_t i = 0; i < cnt; i++) {
+                const Ref* r = lo + i;
                 const uint64_t* rec = records + r->idx * RW;
                 HNode<NW> nd;
                 for (int w = 0; w < NW; w++) nd.seq.w[w] = rec[w];
                 nd.A = (uint32_t)rec[NW];
                 nd.B = (uint32_t)(rec[NW] >> 32);
-                hs.put_new(nd, a_gb != 0);
+                hs.before_put(a_gb != 0);
+                const int slot = (int)(i % AHEAD);
+                hs.put_new_at(nd, ring_size[slot] == hs.size ? ring_home[slot] : hs.home(nd.seq));
+                if (i + 2 * AHEAD < cnt) __builtin_prefetch(records + lo[i + 2 * AHEAD].idx * RW);
+                if (i + AHEAD < cnt) {
+                    ring_home[slot] = hs.home(key_of(lo + i + AHEAD)); ring_size[slot] = hs.size; hs.prefetch_put(ring_home[slot]);
+                }
             }
             // a duplicate put that arrived after the set's last new key still ran the growth test (newhash.c:477)
             if (lo != hi && set_last_put && set_last_put[s] > (hi - 1)->ord + 1) hs.before_put(a_gb != 0);
+            if (verbose) fprintf(stderr, "replay set %d: %lld keys, sort %.2fs, inserts %.2fs (of which growing %.2fs)\n", s, (long long)(hi - lo), ts1 - ts0, nowf() - ts1, hs.t_grow);
         }
     };
     int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();

@@ -74,3 +74,28 @@ def test_contig_stage_accepts_our_files(golden, tmp_path):
         out = subprocess.run([ref, "contig", "-g", pre, "-R"], capture_output=True, text=True)   # consumes .path / .markOnEdge
         assert out.returncode == 0, out.stderr[-500:]
         assert md5_file(pre + ".contig") == golden["md5"][t]["contigR"], t
+
+
+@pytest.mark.parametrize("n_threads", [1, 3, 16])
+def test_host_stages_do_not_depend_on_thread_count(golden, tmp_path, n_threads):
+    """Tips, edges and pre-arcs are built by all host threads (speculative walks, ordered commits): the files must not
+    change with the number of threads, nor with the sequential edge builder (PG_SERIAL_EDGES=1)."""
+    import os
+    name, run = "m60k_k63", (8, 0, 0, 0)
+    c = golden["cases"][name]
+    codes = case_codes(c)
+    P, D, a, m = run
+    t = case_tag(name, run)
+    rec, last, K = oracle_records(codes, c["K"], P, prefix=str(tmp_path / ("o_" + t)))
+    want = golden["md5"][t]
+    for serial in ("0", "1") if n_threads == 3 else ("0",):
+        os.environ["PG_SERIAL_EDGES"] = serial
+        try:
+            pre = str(tmp_path / (t + "_" + serial))
+            api.host_pregraph_files(rec, last, codes, None, K, P, pre, max_read_len=c["L"], batches=2, n_threads=n_threads,
+                                    resolve_repeats=True)
+        finally:
+            del os.environ["PG_SERIAL_EDGES"]
+        for ext in ("preArc", "vertex", "preGraphBasic", "path", "markOnEdge"):
+            assert md5_file(pre + "." + ext) == want[ext], (ext, n_threads, serial)
+        assert md5_gz_text(pre + ".edge.gz") == want["edge"], (n_threads, serial)
