@@ -107,6 +107,9 @@ int pg_host_build_graph(const uint64_t *records, uint64_t n_records, const uint6
  *   pg_host_graph_add_reads  threads a batch of reads (base codes, read i at codes + i * stride, lens[i] bases or
  *                            `stride` bases when lens is NULL) through the graph and accumulates the pre-arcs; batches
  *                            must come in the reference's read order (the order of a pre-arc list is first-encounter order)
+ *   pg_host_graph_add_packed the same for reads packed with pg_pack_read and laid back to back (read i starts
+ *                            pg_packed_words(lens[0]) + ... + pg_packed_words(lens[i-1]) words in): lets a caller that kept
+ *                            pass 1's packed reads in memory skip the second parse of the input files
  *   pg_host_graph_resolve_repeats  the reference's -R (pregraph.c:181-184): call with on != 0 right after _begin to also
  *                            record every read's edge walk in <prefix>.path (recordPathBin, prlRead2path.c:478-543) and the
  *                            per-edge marker counts in <prefix>.markOnEdge (output_arcs, prlRead2path.c:435-449)
@@ -115,6 +118,7 @@ typedef struct pg_graph pg_graph;
 pg_graph *pg_host_graph_begin(const uint64_t *records, uint64_t n_records, const uint64_t *set_last_put, int K, int mer127,
                               int n_sets, int cut_single, int a_gb, int max_read_len, int n_threads, const char *prefix);
 int pg_host_graph_resolve_repeats(pg_graph *g, int on);
+int pg_host_graph_add_packed(pg_graph *g, const uint64_t *words, const int32_t *lens, uint64_t n_reads, int n_threads);
 int pg_host_graph_add_reads(pg_graph *g, const uint8_t *codes, const int32_t *lens, uint64_t n_reads, uint64_t stride,
                             int n_threads);
 int pg_host_graph_finish(pg_graph *g, int *out_num_vertex, int *out_num_edge, long long *out_num_prearc);

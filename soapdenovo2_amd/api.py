@@ -66,6 +66,7 @@ def lib() -> C.CDLL:
     L.pg_host_graph_add_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int]
     L.pg_host_graph_finish.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]
     L.pg_host_graph_resolve_repeats.argtypes = [C.c_void_p, C.c_int]
+    L.pg_host_graph_add_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
     L.pg_host_read_all.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
                                    C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
     L.pg_host_replay_layout.argtypes = [u64p, C.c_uint64, u64p, C.c_int, C.c_int, C.c_int, u64p, u64p]
@@ -97,7 +98,7 @@ def lib() -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "pg_last_error", "pg_version", "call_pregraph", "call_pregraph_127mer", "pg_packed_words", "pg_pack_read",
-    "pg_host_build_graph", "pg_host_graph_begin", "pg_host_graph_add_reads", "pg_host_graph_finish", "pg_host_graph_resolve_repeats", "pg_host_read_all", "pg_host_replay_layout", "pg_host_write_kmerfreq", "pg_create", "pg_create_engine", "pg_destroy", "pg_reset", "pg_set_autogrow", "pg_count_reads", "pg_route_count",
+    "pg_host_build_graph", "pg_host_graph_begin", "pg_host_graph_add_reads", "pg_host_graph_finish", "pg_host_graph_resolve_repeats", "pg_host_graph_add_packed", "pg_host_read_all", "pg_host_replay_layout", "pg_host_write_kmerfreq", "pg_create", "pg_create_engine", "pg_destroy", "pg_reset", "pg_set_autogrow", "pg_count_reads", "pg_route_count",
     "pg_route_scatter", "pg_count_records", "pg_skm_route", "pg_skm_ingest", "pg_distinct", "pg_stats", "pg_table_info", "pg_finalize", "pg_export",
 ]
 
@@ -179,7 +180,7 @@ def host_build_graph(records: np.ndarray, set_last_put, K: int, n_sets: int, pre
 
 def host_pregraph_files(records: np.ndarray, set_last_put, codes: np.ndarray, lens, K: int, n_sets: int, prefix: str,
                         mer127: bool = False, cut_single: bool = True, a_gb: int = 0, max_read_len: int = 100, n_threads: int = 0,
-                        batches: int = 1, resolve_repeats: bool = False):
+                        batches: int = 1, resolve_repeats: bool = False, packed: bool = False):
     """All host stages incl. pass 2: writes .edge.gz .preArc .vertex .preGraphBasic (and, with resolve_repeats, the
     reference's -R files .path and .markOnEdge); returns (n_vertex, n_edge, n_prearc)."""
     records = np.ascontiguousarray(records, dtype=np.uint64)
@@ -197,7 +198,12 @@ def host_pregraph_files(records: np.ndarray, set_last_put, codes: np.ndarray, le
     bounds = np.linspace(0, n, batches + 1).astype(int)
     for b in range(batches):
         lo, hi = int(bounds[b]), int(bounds[b + 1])
-        if hi > lo:
+        if hi > lo and packed:           # the reads as pass 1 packs them (pg_pack_read), back to back
+            ls = lens[lo:hi] if lens is not None else np.full(hi - lo, stride, dtype=np.int32)
+            words, _, _ = pack_reads_ragged([codes[i, :ls[i - lo]] for i in range(lo, hi)], K)
+            ls = np.ascontiguousarray(ls, dtype=np.int32)
+            _check(lib().pg_host_graph_add_packed(h, words.ctypes.data, ls.ctypes.data, hi - lo, n_threads), "pg_host_graph_add_packed")
+        elif hi > lo:
             _check(lib().pg_host_graph_add_reads(h, codes[lo:].ctypes.data, lens[lo:].ctypes.data if lens is not None else None,
                                                  hi - lo, stride, n_threads), "pg_host_graph_add_reads")
     nv, ne, na = C.c_int(0), C.c_int(0), C.c_longlong(0)

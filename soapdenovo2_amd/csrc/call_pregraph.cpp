@@ -150,6 +150,16 @@ public:
         Buf* b = &buf_[cur_];
         if (b->n_reads == max_reads_ || b->n_words + nw > max_words_) { submit(); b = &buf_[cur_]; }
         pg_pack_read(codes, (uint32_t)len, b->h_words + b->n_words);
+        if (keep_) {                                            // pass 2 threads the same reads again (prlRead2edge)
+            if ((kept_words_.size() + nw) * sizeof(uint64_t) + kept_lens_.size() * sizeof(int32_t) > keep_budget_) {
+                keep_ = false;
+                std::vector<uint64_t>().swap(kept_words_);
+                std::vector<int32_t>().swap(kept_lens_);
+            } else {
+                kept_words_.insert(kept_words_.end(), b->h_words + b->n_words, b->h_words + b->n_words + nw);
+                kept_lens_.push_back(len);
+            }
+        }
         b->h_off[b->n_reads] = b->n_words;
         b->h_base[b->n_reads] = b->n_kmers;
         if (b->n_reads == 0) b->first_len = len; else if (len != b->first_len) b->uniform = false;
@@ -161,6 +171,13 @@ public:
     void finish() { submit(); HIP_OK(hipStreamSynchronize(stream_)); }
     uint64_t total_kmers() const { return ord_; }
     hipStream_t stream() const { return stream_; }
+    // the packed reads kept for pass 2, or nothing when they outgrew the budget (then the files are parsed again)
+    void keep_reads(size_t budget_bytes) { keep_ = budget_bytes > 0; keep_budget_ = budget_bytes; }
+    bool take_kept(std::vector<uint64_t>& words, std::vector<int32_t>& lens) {
+        if (!keep_) return false;
+        words.swap(kept_words_); lens.swap(kept_lens_);
+        return true;
+    }
 
 private:
     struct Buf {
@@ -194,6 +211,10 @@ private:
         if (n.busy) { HIP_OK(hipEventSynchronize(n.done)); n.busy = false; }
         reset(n);
     }
+    bool keep_ = false;
+    size_t keep_budget_ = 0;
+    std::vector<uint64_t> kept_words_;
+    std::vector<int32_t> kept_lens_;
     pg_ctx* ctx_;
     int K_;
     size_t max_words_, max_reads_;
@@ -236,8 +257,16 @@ int run(int argc, char** argv, bool mer127) {
 
     long long n_records = 0;
     uint64_t total_kmers = 0;
+    // Packed reads (2 bits a base) stay in host memory for pass 2 while they fit a quarter of the physical memory
+    // (SOAPDENOVO2_AMD_KEEP_READS_GB overrides, 0 = always parse the files twice as the reference does).
+    size_t keep_budget = (size_t)sysconf(_SC_PHYS_PAGES) * (size_t)sysconf(_SC_PAGE_SIZE) / 4;
+    if (const char* e = getenv("SOAPDENOVO2_AMD_KEEP_READS_GB")) keep_budget = (size_t)(atof(e) * 1073741824.0);
+    std::vector<uint64_t> kept_words;
+    std::vector<int32_t> kept_lens;
+    bool have_kept = false;
     {
         Pass1 p1(ctx, K, (size_t)1 << 23, (size_t)1 << 21);     // 64 MiB of packed reads / 2 M reads per batch
+        p1.keep_reads(keep_budget);
         for (const pg::InputFile& f : files) {
             fprintf(stderr, "Import reads from file:\n %s\n", f.path1.c_str());
             if (!f.path2.empty()) fprintf(stderr, "Import reads from file:\n %s\n", f.path2.c_str());
@@ -245,6 +274,7 @@ int run(int argc, char** argv, bool mer127) {
         }
         p1.finish();
         total_kmers = p1.total_kmers();
+        have_kept = p1.take_kept(kept_words, kept_lens);
     }
     // ---- -d filter, linear marking, .kmerFreq (deLowCov / Mark1in1outNode / freqStat); with the partition engine this
     // is also where the partitions are counted, so the node count is known only afterwards
@@ -288,7 +318,17 @@ int run(int argc, char** argv, bool mer127) {
 
     // ---- pass 2 (prlRead2edge): the reads again, in the same order, threaded through the edges -> .preArc
     t0 = time(nullptr);
-    {
+    if (have_kept) {
+        fprintf(stderr, "In file: %s, max seq len %d, max name len %d.\n", o.config.c_str(), max_read_len, 256);
+        const uint64_t total = kept_lens.size(), step = (uint64_t)1 << 22;
+        uint64_t word_at = 0;
+        for (uint64_t lo = 0; lo < total; lo += step) {
+            const uint64_t n = std::min(step, total - lo);
+            if (pg_host_graph_add_packed(graph, kept_words.data() + word_at, kept_lens.data() + lo, n, 0) != PG_OK) die("pg_host_graph_add_packed");
+            for (uint64_t r = lo; r < lo + n; r++) word_at += pg_packed_words((uint32_t)kept_lens[r]);
+        }
+        fprintf(stderr, "%lld read(s) processed.\n", n_records);
+    } else {
         struct Pass2 : pg::ReadSink {
             pg_graph* g; int K; size_t stride, cap, n = 0;
             std::vector<uint8_t> codes; std::vector<int32_t> lens;

@@ -1206,6 +1206,7 @@ struct PreArcs {
 struct GraphHandleBase {
     virtual ~GraphHandleBase() {}
     virtual int add_reads(const uint8_t* codes, const int32_t* lens, uint64_t n, uint64_t stride, int n_threads) = 0;
+    virtual int add_packed(const uint64_t* words, const int32_t* lens, uint64_t n, int n_threads) = 0;
     virtual int finish(long long* n_arcs) = 0;
     virtual int resolve_repeats(int on) = 0;
     int num_vt = 0, num_ed = 0;
@@ -1238,6 +1239,28 @@ struct GraphHandle : GraphHandleBase {
     }
 
     int add_reads(const uint8_t* codes, const int32_t* lens, uint64_t n, uint64_t stride, int n_threads) override {
+        return add_any(n, n_threads, [&](uint64_t r, std::vector<uint8_t>&, int& len) -> const uint8_t* {
+            len = lens ? lens[r] : (int)stride;
+            return codes + r * stride;
+        });
+    }
+    // reads packed 2 bits a base, 32 bases a word, first base in the top bits (pg_pack_read), back to back
+    int add_packed(const uint64_t* words, const int32_t* lens, uint64_t n, int n_threads) override {
+        std::vector<uint64_t> off(n + 1, 0);
+        for (uint64_t r = 0; r < n; r++) off[r + 1] = off[r] + ((uint64_t)lens[r] + 31) / 32;
+        return add_any(n, n_threads, [&](uint64_t r, std::vector<uint8_t>& buf, int& len) -> const uint8_t* {
+            len = lens[r];
+            if ((int)buf.size() < len + 32) buf.resize((size_t)len + 32);
+            const uint64_t* w = words + off[r];
+            for (int i = 0; i < len; i += 32) {
+                const uint64_t v = w[i >> 5];
+                for (int j = 0; j < 32; j++) buf[i + j] = (uint8_t)((v >> (62 - 2 * j)) & 3);
+            }
+            return buf.data();
+        });
+    }
+    template <typename Get>
+    int add_any(uint64_t n, int n_threads, Get get) {
         int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
         nt = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)nt, (n + 255) / 256));
         constexpr int NP = PreArcs::NP;
@@ -1253,13 +1276,15 @@ struct GraphHandle : GraphHandleBase {
             std::vector<typename ReadThreader<NW>::Item> items;
             Pairs one;
             std::vector<uint32_t> marks;
+            std::vector<uint8_t> unpacked;
             const uint64_t lo = n * t / nt, hi = n * (t + 1) / nt;
             for (uint64_t r = lo; r < hi; r++) {
-                const int len = lens ? lens[r] : (int)stride;
+                int len = 0;
+                const uint8_t* rd = get(r, unpacked, len);
                 if (len < g.K + 1) continue;                                  // prlRead2path.c:1103 (same filter as pass 1)
                 one.clear();
                 marks.clear();
-                if (!rt.thread_read(codes + r * stride, len, items, one, reps ? &paths[t] : nullptr, reps ? &marks : nullptr)) deleted[t]++;
+                if (!rt.thread_read(rd, len, items, one, reps ? &paths[t] : nullptr, reps ? &marks : nullptr)) deleted[t]++;
                 for (auto& pr : one) {
                     if (pr.first >= id_end) { bad.store(1); continue; }
                     pairs[(size_t)t * NP + arcs.part_of(pr.first)].push_back(pr);
@@ -1412,6 +1437,10 @@ extern "C" pg_graph* pg_host_graph_begin(const uint64_t* records, uint64_t n_rec
 extern "C" int pg_host_graph_resolve_repeats(pg_graph* g, int on) {
     if (!g) { pg_set_error("null argument"); return PG_EINVAL; }
     return ((pg::GraphHandleBase*)g)->resolve_repeats(on);
+}
+extern "C" int pg_host_graph_add_packed(pg_graph* g, const uint64_t* words, const int32_t* lens, uint64_t n_reads, int n_threads) {
+    if (!g || ((!words || !lens) && n_reads)) { pg_set_error("null argument"); return PG_EINVAL; }
+    return ((pg::GraphHandleBase*)g)->add_packed(words, lens, n_reads, n_threads);
 }
 extern "C" int pg_host_graph_add_reads(pg_graph* g, const uint8_t* codes, const int32_t* lens, uint64_t n_reads, uint64_t stride, int n_threads) {
     if (!g || (!codes && n_reads)) { pg_set_error("null argument"); return PG_EINVAL; }

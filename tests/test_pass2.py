@@ -50,6 +50,9 @@ def test_prearc_on_reader_corner_cases(golden, tmp_path):
         pre = str(tmp_path / name)
         api.host_pregraph_files(rec, last, codes, lens, K, P, pre, max_read_len=mrl)
         assert md5_file(pre + ".preArc") == golden["md5"][name]["preArc"], name
+        # the same reads handed over 2-bit packed (pg_host_graph_add_packed: what the executable keeps from pass 1)
+        api.host_pregraph_files(rec, last, codes, lens, K, P, pre + "_pk", max_read_len=mrl, packed=True, batches=3)
+        assert md5_file(pre + "_pk.preArc") == golden["md5"][name]["preArc"], name
 
 
 def test_contig_stage_accepts_our_files(golden, tmp_path):
