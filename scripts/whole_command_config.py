@@ -72,6 +72,7 @@ def main():
     ap.add_argument("--sets", type=int, default=8)
     ap.add_argument("--ref-threads", type=int, default=16)
     ap.add_argument("--skip-ref", action="store_true")
+    ap.add_argument("--expect", default="", help="a result.json of an earlier run on the same input: compare md5s with its ref_md5")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     fq, cfg = os.path.join(a.out, "reads.fq"), os.path.join(a.out, "lib.cfg")
@@ -81,10 +82,10 @@ def main():
     res = {"workload": f"{a.reads} x {a.read_len} bp, genome {a.genome}, err {a.err}, K={a.kmer}, -p {a.sets}", "fastq_s": time.time() - t}
     t = time.time()
     r = subprocess.run([api.binary(False), "pregraph", "-s", cfg, "-K", str(a.kmer), "-o", os.path.join(a.out, "amd"), "-p", str(a.sets)],
-                       capture_output=True, text=True)
+                       capture_output=True, text=True, env=dict(os.environ, PG_HOST_VERBOSE="1"))
     res["amd_wall_s"] = time.time() - t
     res["amd_rc"] = r.returncode
-    res["amd_log"] = [l for l in r.stderr.splitlines() if "Time spent" in l or "node(s) allocated" in l or "read(s) processed" in l or "edge(s)" in l or "pre-arc" in l]
+    res["amd_log"] = [l for l in r.stderr.splitlines() if "Time spent" in l or "node(s) allocated" in l or "read(s) processed" in l or "edge(s)" in l or "pre-arc" in l or "tip scan" in l]
     if r.returncode == 0:
         res["amd_md5"] = md5s(os.path.join(a.out, "amd"))
     ref = os.path.join(ROOT, "oracle", "_ref", "SOAPdenovo-63mer")
@@ -95,6 +96,9 @@ def main():
         res["ref_log"] = [l for l in r.stderr.splitlines() if "Time spent" in l or "node(s) allocated" in l]
         res["ref_md5"] = md5s(os.path.join(a.out, "ref"))
         res["identical"] = res.get("amd_md5") == res["ref_md5"]
+    if a.expect and os.path.exists(a.expect):
+        want = json.load(open(a.expect)).get("ref_md5")
+        res["identical_to_expected_ref_md5"] = (want is not None and res.get("amd_md5") == want)
     for f in ("reads.fq",):
         os.remove(os.path.join(a.out, f))
     for pre in ("amd", "ref"):

@@ -22,6 +22,7 @@
 #include <atomic>
 #include <chrono>
 #include <functional>
+#include <memory>
 #include <string>
 #include <thread>
 #include <queue>
@@ -37,6 +38,36 @@ namespace pg {
 
 static uint32_t g_crc_tab[256];
 static std::atomic<bool> g_crc_ready{false};
+// host threads for the parallel stages: the caller's count, else SOAPDENOVO2_AMD_HOST_THREADS, else every hardware thread
+static int pick_threads(int n_threads) {
+    if (n_threads > 0) return n_threads;
+    if (const char* e = getenv("SOAPDENOVO2_AMD_HOST_THREADS")) { const int v = atoi(e); if (v > 0) return v; }
+    static const int usable = []() {
+        int hw = (int)std::thread::hardware_concurrency();
+        if (hw < 1) hw = 1;
+        // a container's CPU quota (cgroup v2 cpu.max "quota period", v1 cfs_quota_us / cfs_period_us): more runnable
+        // threads than that only get throttled
+        double quota = -1, period = 0;
+        if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+            char q[64];
+            if (fscanf(f, "%63s %lf", q, &period) == 2 && strcmp(q, "max") != 0) quota = atof(q);
+            fclose(f);
+        } else {
+            FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r");
+            FILE* fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r");
+            if (fq && fp && fscanf(fq, "%lf", &quota) == 1 && fscanf(fp, "%lf", &period) == 1) {}
+            if (fq) fclose(fq);
+            if (fp) fclose(fp);
+        }
+        if (quota > 0 && period > 0) {
+            const int cores = (int)((quota + period - 1) / period);
+            if (cores >= 1 && cores < hw) hw = cores;
+        }
+        return hw;
+    }();
+    return usable;
+}
+
 // the same CRC eight bytes at a time (slicing-by-8 tables derived from the byte table)
 static uint32_t g_crc8[8][256];
 static std::atomic<bool> g_crc8_ready{false};
@@ -342,7 +373,7 @@ struct Graph {
 
     // Mark1in1outNode of cutTipPreGraph.c:532-564,603-639
     void remark_linear() {
-        int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+        int nt = pick_threads(n_threads);
         if (nt < 1) nt = 1;
         std::atomic<uint64_t> next{0};
         const uint64_t STEP = 1 << 18;
@@ -438,7 +469,7 @@ struct Graph {
     // precomputed decision when neither end of the walk has been touched since and walking again otherwise.  A stop node
     // that becomes a dead end further down the scan is visited there, as the sequential scan would.
     long long tip_scan(int cut_len, bool thin, long long& tips) {
-        int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+        int nt = pick_threads(n_threads);
         if (nt < 1) nt = 1;
         struct Cand { uint64_t pos; TipDecision d; };
         struct Chunk { int set; uint64_t lo, hi; std::vector<Cand> c; };
@@ -835,7 +866,7 @@ struct ParallelEdgeBuilder {
     }
 
     int run(const std::string& path, int n_threads) {
-        int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+        int nt = pick_threads(n_threads);
         if (nt < 1) nt = 1;
         std::vector<Chunk> chunks;
         const uint64_t STEP = 1 << 15;
@@ -1026,7 +1057,7 @@ static int replay_layout(Graph<NW>& g, const uint64_t* records, uint64_t n, cons
             if (verbose) fprintf(stderr, "replay set %d: %lld keys, sort %.2fs, inserts %.2fs (of which growing %.2fs)\n", s, (long long)(hi - lo), ts1 - ts0, nowf() - ts1, hs.t_grow);
         }
     };
-    int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+    int nt = pick_threads(n_threads);
     nt = std::max(1, std::min(nt, P));
     std::vector<std::thread> pool;
     for (int t = 1; t < nt; t++) pool.emplace_back(worker);
@@ -1225,6 +1256,16 @@ struct GraphHandle : GraphHandleBase {
     std::vector<uint8_t> marker;
     long long mark_count = 0;
     double t_thread = 0, t_fold = 0;
+    struct Scratch {
+        std::unique_ptr<ReadThreader<NW>> rt;
+        std::vector<typename ReadThreader<NW>::Item> items;
+        std::vector<std::pair<uint32_t, uint32_t>> pairs, sorted;
+        std::vector<uint32_t> marks;
+        std::vector<uint8_t> unpacked, path;
+        size_t off[PreArcs::NP + 1];
+        long long deleted = 0, marked = 0;
+    };
+    std::vector<Scratch> scratch;
     static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
     ~GraphHandle() override { if (path_fp) fclose(path_fp); }
@@ -1261,42 +1302,43 @@ struct GraphHandle : GraphHandleBase {
     }
     template <typename Get>
     int add_any(uint64_t n, int n_threads, Get get) {
-        int nt = n_threads > 0 ? n_threads : (int)std::thread::hardware_concurrency();
+        int nt = pick_threads(n_threads);
         nt = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)nt, (n + 255) / 256));
         constexpr int NP = PreArcs::NP;
-        typedef std::vector<std::pair<uint32_t, uint32_t>> Pairs;
-        std::vector<Pairs> pairs((size_t)nt * NP);                            // [thread][source-edge range]
-        std::vector<long long> deleted(nt, 0), marked(nt, 0);
+        if ((int)scratch.size() < nt) scratch.resize(nt);                    // buffers live across batches: no fresh pages
         const bool reps = path_fp != nullptr;
-        std::vector<std::vector<uint8_t>> paths(reps ? nt : 0);
         std::atomic<int> bad{0};
         const uint32_t id_end = (uint32_t)arcs.head.size();
         auto worker = [&](int t) {
-            ReadThreader<NW> rt(g);
-            std::vector<typename ReadThreader<NW>::Item> items;
-            Pairs one;
-            std::vector<uint32_t> marks;
-            std::vector<uint8_t> unpacked;
+            Scratch& sc = scratch[t];
+            if (!sc.rt) sc.rt.reset(new ReadThreader<NW>(g));
+            sc.pairs.clear(); sc.path.clear(); sc.deleted = 0; sc.marked = 0;
             const uint64_t lo = n * t / nt, hi = n * (t + 1) / nt;
             for (uint64_t r = lo; r < hi; r++) {
                 int len = 0;
-                const uint8_t* rd = get(r, unpacked, len);
+                const uint8_t* rd = get(r, sc.unpacked, len);
                 if (len < g.K + 1) continue;                                  // prlRead2path.c:1103 (same filter as pass 1)
-                one.clear();
-                marks.clear();
-                if (!rt.thread_read(rd, len, items, one, reps ? &paths[t] : nullptr, reps ? &marks : nullptr)) deleted[t]++;
-                for (auto& pr : one) {
-                    if (pr.first >= id_end) { bad.store(1); continue; }
-                    pairs[(size_t)t * NP + arcs.part_of(pr.first)].push_back(pr);
-                }
+                sc.marks.clear();
+                if (!sc.rt->thread_read(rd, len, sc.items, sc.pairs, reps ? &sc.path : nullptr, reps ? &sc.marks : nullptr)) sc.deleted++;
                 // saturating per-edge marker counts: increments commute, so they are applied right here
-                for (uint32_t e : marks) {
+                for (uint32_t e : sc.marks) {
                     if (e >= marker.size()) { bad.store(1); continue; }
                     uint8_t v = __atomic_load_n(&marker[e], __ATOMIC_RELAXED);
                     while (v < 255 && !__atomic_compare_exchange_n(&marker[e], &v, (uint8_t)(v + 1), true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
                 }
-                marked[t] += (long long)marks.size();
+                sc.marked += (long long)sc.marks.size();
             }
+            // stable counting sort of this thread's pairs by source-edge range
+            for (int i = 0; i <= NP; i++) sc.off[i] = 0;
+            for (auto& pr : sc.pairs) {
+                if (pr.first >= id_end) { bad.store(1); return; }
+                sc.off[arcs.part_of(pr.first) + 1]++;
+            }
+            for (int i = 0; i < NP; i++) sc.off[i + 1] += sc.off[i];
+            sc.sorted.resize(sc.pairs.size());
+            size_t cur[NP];
+            for (int i = 0; i < NP; i++) cur[i] = sc.off[i];
+            for (auto& pr : sc.pairs) sc.sorted[cur[arcs.part_of(pr.first)]++] = pr;
         };
         const double t0 = now();
         {
@@ -1316,8 +1358,10 @@ struct GraphHandle : GraphHandleBase {
                     const int part = next.fetch_add(1);
                     if (part >= NP) break;
                     PreArcs::Pool& pl = arcs.pool[part];
-                    for (int t = 0; t < nt; t++)
-                        for (auto& pr : pairs[(size_t)t * NP + part]) arcs.add(pl, pr.first, pr.second);
+                    for (int t = 0; t < nt; t++) {
+                        const Scratch& sc = scratch[t];
+                        for (size_t i = sc.off[part]; i < sc.off[part + 1]; i++) arcs.add(pl, sc.sorted[i].first, sc.sorted[i].second);
+                    }
                 }
             };
             std::vector<std::thread> pool;
@@ -1326,13 +1370,14 @@ struct GraphHandle : GraphHandleBase {
             for (auto& th : pool) th.join();
         }
         for (int t = 0; t < nt; t++) {
-            reads_deleted += deleted[t];
+            const Scratch& sc = scratch[t];
+            reads_deleted += sc.deleted;
             if (reps) {
-                if (!paths[t].empty() && fwrite(paths[t].data(), 1, paths[t].size(), path_fp) != paths[t].size()) {
+                if (!sc.path.empty() && fwrite(sc.path.data(), 1, sc.path.size(), path_fp) != sc.path.size()) {
                     pg_set_error("short write on " + prefix + ".path");
                     return PG_EIO;
                 }
-                mark_count += marked[t];
+                mark_count += sc.marked;
             }
         }
         reads_seen += (long long)n;
