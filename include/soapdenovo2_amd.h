@@ -113,11 +113,16 @@ int pg_host_build_graph(const uint64_t *records, uint64_t n_records, const uint6
  *   pg_host_graph_resolve_repeats  the reference's -R (pregraph.c:181-184): call with on != 0 right after _begin to also
  *                            record every read's edge walk in <prefix>.path (recordPathBin, prlRead2path.c:478-543) and the
  *                            per-edge marker counts in <prefix>.markOnEdge (output_arcs, prlRead2path.c:435-449)
+ *   pg_graph_use_device      call right after _begin (and _resolve_repeats) to run pass 2 on HIP device `device` instead of the
+ *                            host threads: the k-mer sets and the (K+1)-mer table are copied to HBM once, every batch is
+ *                            threaded by one kernel (a lane a read) and the pre-arcs are accumulated in a device table
+ *                            (multiplicity + first-met order per (from, to)); same files, byte for byte
  *   pg_host_graph_finish     writes <prefix>.preArc, <prefix>.vertex, <prefix>.preGraphBasic and frees the handle */
 typedef struct pg_graph pg_graph;
 pg_graph *pg_host_graph_begin(const uint64_t *records, uint64_t n_records, const uint64_t *set_last_put, int K, int mer127,
                               int n_sets, int cut_single, int a_gb, int max_read_len, int n_threads, const char *prefix);
 int pg_host_graph_resolve_repeats(pg_graph *g, int on);
+int pg_graph_use_device(pg_graph *g, int device);
 int pg_host_graph_add_packed(pg_graph *g, const uint64_t *words, const int32_t *lens, uint64_t n_reads, int n_threads);
 int pg_host_graph_add_reads(pg_graph *g, const uint8_t *codes, const int32_t *lens, uint64_t n_reads, uint64_t stride,
                             int n_threads);

@@ -66,6 +66,7 @@ def lib() -> C.CDLL:
     L.pg_host_graph_add_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int]
     L.pg_host_graph_finish.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]
     L.pg_host_graph_resolve_repeats.argtypes = [C.c_void_p, C.c_int]
+    L.pg_graph_use_device.argtypes = [C.c_void_p, C.c_int]
     L.pg_host_graph_add_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
     L.pg_host_read_all.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
                                    C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
@@ -98,7 +99,7 @@ def lib() -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "pg_last_error", "pg_version", "call_pregraph", "call_pregraph_127mer", "pg_packed_words", "pg_pack_read",
-    "pg_host_build_graph", "pg_host_graph_begin", "pg_host_graph_add_reads", "pg_host_graph_finish", "pg_host_graph_resolve_repeats", "pg_host_graph_add_packed", "pg_host_read_all", "pg_host_replay_layout", "pg_host_write_kmerfreq", "pg_create", "pg_create_engine", "pg_destroy", "pg_reset", "pg_set_autogrow", "pg_count_reads", "pg_route_count",
+    "pg_host_build_graph", "pg_host_graph_begin", "pg_host_graph_add_reads", "pg_host_graph_finish", "pg_host_graph_resolve_repeats", "pg_host_graph_add_packed", "pg_graph_use_device", "pg_host_read_all", "pg_host_replay_layout", "pg_host_write_kmerfreq", "pg_create", "pg_create_engine", "pg_destroy", "pg_reset", "pg_set_autogrow", "pg_count_reads", "pg_route_count",
     "pg_route_scatter", "pg_count_records", "pg_skm_route", "pg_skm_ingest", "pg_distinct", "pg_stats", "pg_table_info", "pg_finalize", "pg_export",
 ]
 
@@ -180,7 +181,8 @@ def host_build_graph(records: np.ndarray, set_last_put, K: int, n_sets: int, pre
 
 def host_pregraph_files(records: np.ndarray, set_last_put, codes: np.ndarray, lens, K: int, n_sets: int, prefix: str,
                         mer127: bool = False, cut_single: bool = True, a_gb: int = 0, max_read_len: int = 100, n_threads: int = 0,
-                        batches: int = 1, resolve_repeats: bool = False, packed: bool = False):
+                        batches: int = 1, resolve_repeats: bool = False, packed: bool = False,
+                        device: int = -1):
     """All host stages incl. pass 2: writes .edge.gz .preArc .vertex .preGraphBasic (and, with resolve_repeats, the
     reference's -R files .path and .markOnEdge); returns (n_vertex, n_edge, n_prearc)."""
     records = np.ascontiguousarray(records, dtype=np.uint64)
@@ -191,6 +193,8 @@ def host_pregraph_files(records: np.ndarray, set_last_put, codes: np.ndarray, le
         raise PgError("pg_host_graph_begin failed: " + lib().pg_last_error().decode())
     if resolve_repeats:
         _check(lib().pg_host_graph_resolve_repeats(h, 1), "pg_host_graph_resolve_repeats")
+    if device >= 0:                      # pass 2 on the HIP device instead of the host threads
+        _check(lib().pg_graph_use_device(h, device), "pg_graph_use_device")
     codes = np.ascontiguousarray(codes, dtype=np.uint8)
     n, stride = codes.shape
     if lens is not None:

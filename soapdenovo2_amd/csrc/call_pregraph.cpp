@@ -313,6 +313,10 @@ int run(int argc, char** argv, bool mer127) {
                                           max_read_len, 0, o.prefix.c_str());
     if (!graph) die("pg_host_graph_begin");
     if (o.reps && pg_host_graph_resolve_repeats(graph, 1) != PG_OK) die("pg_host_graph_resolve_repeats");
+    {   // pass 2 runs on the device too; SOAPDENOVO2_AMD_PASS2=host keeps it on the host threads
+        const char* e = getenv("SOAPDENOVO2_AMD_PASS2");
+        if (!(e && strcmp(e, "host") == 0) && pg_graph_use_device(graph, device) != PG_OK) die("pg_graph_use_device");
+    }
     { std::vector<uint64_t>().swap(records); }
     fprintf(stderr, "Time spent on removing tips and constructing edges: %ds.\n\n", (int)(time(nullptr) - t0));
 

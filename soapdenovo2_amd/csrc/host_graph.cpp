@@ -32,6 +32,7 @@
 
 #include "kmer.hpp"
 #include "host_graph.hpp"
+#include "pass2.hpp"
 #include "../../include/soapdenovo2_amd.h"
 
 namespace pg {
@@ -312,27 +313,6 @@ template <int NW>
 struct KmerEq {
     bool operator()(const Kmer<NW>& a, const Kmer<NW>& b) const { return kmer_eq<NW>(a, b); }
 };
-
-// reverseComplement(word, K + 1) exactly as the reference computes it for the (K+1)-mer of a length-1 edge
-// (node2edge.c:485, prlRead2path.c:694).  The 127-mer binary passes the length through a `char` (kmer.c:532): for
-// K = 127 the length 128 wraps to -128, takes the `seq_size < 32` exit and only the lowest word is complemented and
-// reversed (the shift count 64 - (-256) = 320 is applied modulo 64 by the hardware, i.e. not at all).
-template <int NW>
-static Kmer<NW> rc_plus(const Kmer<NW>& word, int K) {
-    if (NW == 4 && K + 1 >= 128) {
-        Kmer<NW> r = word;
-        r.w[NW - 1] = rev2bit(word.w[NW - 1] ^ 0xAAAAAAAAAAAAAAAAULL);
-        return r;
-    }
-    return kmer_rc<NW>(word, K + 1);
-}
-// KmerPlus (kmer.c:690-694): append one base without masking
-template <int NW>
-static Kmer<NW> kmer_plus(Kmer<NW> a, int ch) {
-    for (int i = 0; i < NW - 1; i++) a.w[i] = (a.w[i] << 2) | (a.w[i + 1] >> 62);
-    a.w[NW - 1] = (a.w[NW - 1] << 2) | (uint64_t)ch;
-    return a;
-}
 
 struct PatchVal { uint32_t id; uint32_t twin; };
 
@@ -1240,6 +1220,7 @@ struct GraphHandleBase {
     virtual int add_packed(const uint64_t* words, const int32_t* lens, uint64_t n, int n_threads) = 0;
     virtual int finish(long long* n_arcs) = 0;
     virtual int resolve_repeats(int on) = 0;
+    virtual int use_device(int device) = 0;
     int num_vt = 0, num_ed = 0;
 };
 
@@ -1268,7 +1249,111 @@ struct GraphHandle : GraphHandleBase {
     std::vector<Scratch> scratch;
     static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-    ~GraphHandle() override { if (path_fp) fclose(path_fp); }
+    // pass 2 on a HIP device (pass2_kernels.hip) instead of the host threads
+    bool dev_on = false;
+    int dev_id = 0;
+    P2Device* dev = nullptr;
+    std::vector<uint32_t> dev_walks;
+    std::vector<uint16_t> dev_walk_len;
+
+    ~GraphHandle() override { if (path_fp) fclose(path_fp); if (dev) p2_destroy(dev); }
+    int use_device(int device) override {
+        if (dev) { pg_set_error("pass 2 already started"); return PG_ESTATE; }
+        dev_on = device >= 0; dev_id = device;
+        return PG_OK;
+    }
+    int max_nk() const { return std::max(1, max_read_len - g.K + 1); }
+    int dev_begin() {
+        if (dev) return PG_OK;
+        P2Sets sets;
+        for (int si = 0; si < g.P; si++) { sets.nodes[si] = g.sets[si].array.data(); sets.size[si] = g.sets[si].size; }
+        // KmerSetsPatch as an open-addressing table the device can probe
+        uint64_t cap = 1024;
+        while (cap < 2 * (uint64_t)g.patch.size() + 2) cap <<= 1;
+        std::vector<uint64_t> keys(cap * NW, 0);
+        std::vector<uint32_t> val(cap * 2, 0);
+        for (auto& kv : g.patch) {
+            uint64_t h = kmer_mix<NW>(kv.first) & (cap - 1);
+            while (val[2 * h]) h = (h + 1) & (cap - 1);
+            for (int w = 0; w < NW; w++) keys[h * NW + w] = kv.first.w[w];
+            val[2 * h] = kv.second.id; val[2 * h + 1] = kv.second.twin;
+        }
+        dev = p2_create(dev_id, g.K, NW, g.P, sets, keys.data(), val.data(), cap, (uint32_t)num_ed, max_nk(), path_fp != nullptr);
+        return dev ? PG_OK : PG_ENODEV;
+    }
+    // reads already packed: straight to the device, in slices when the walks have to come back (-R)
+    int dev_add_packed(const uint64_t* words, const int32_t* lens, uint64_t n) {
+        const double t0 = now();
+        int rc = dev_begin();
+        if (rc) return rc;
+        const bool reps = path_fp != nullptr;
+        const int mnk = max_nk();
+        std::vector<uint64_t> off(n + 1, 0);
+        for (uint64_t r = 0; r < n; r++) {
+            if (lens[r] - g.K + 1 > mnk) { pg_set_error("a read is longer than the maximum read length given at pg_host_graph_begin"); return PG_EINVAL; }
+            off[r + 1] = off[r] + ((uint64_t)std::max(lens[r], 0) + 31) / 32;
+        }
+        const uint64_t step = reps ? std::max<uint64_t>(1, ((uint64_t)64 << 20) / (uint64_t)mnk) : n;
+        for (uint64_t lo = 0; lo < n; lo += step) {
+            const uint64_t m = std::min(step, n - lo);
+            std::vector<uint64_t> rel;
+            const uint64_t* offp = off.data() + lo;
+            if (lo) { rel.resize(m); for (uint64_t i = 0; i < m; i++) rel[i] = off[lo + i] - off[lo]; offp = rel.data(); }
+            if (reps) {
+                if (dev_walks.size() < m * (size_t)mnk) dev_walks.resize(m * (size_t)mnk);
+                if (dev_walk_len.size() < m) dev_walk_len.resize(m);
+            }
+            rc = p2_add_packed(dev, words + off[lo], offp, lens + lo, m, off[lo + m] - off[lo], reps ? dev_walks.data() : nullptr,
+                               reps ? dev_walk_len.data() : nullptr);
+            if (rc) return rc;
+            if (reps) {                              // recordPathBin's record format, with its one-byte counter (prlRead2path.c:478-543)
+                std::vector<uint8_t> bytes;
+                for (uint64_t r = 0; r < m; r++) {
+                    const int upto = dev_walk_len[r];
+                    if (!upto) continue;
+                    const uint32_t* row = dev_walks.data() + r * (size_t)mnk;
+                    uint32_t buf[256];
+                    uint8_t counter = 0;
+                    for (int i = 0; i < upto; i++) buf[counter++] = row[i];
+                    bytes.push_back(counter);
+                    const uint8_t* b = reinterpret_cast<const uint8_t*>(buf);
+                    bytes.insert(bytes.end(), b, b + 4 * (size_t)counter);
+                }
+                if (!bytes.empty() && fwrite(bytes.data(), 1, bytes.size(), path_fp) != bytes.size()) { pg_set_error("short write on " + prefix + ".path"); return PG_EIO; }
+            }
+        }
+        reads_seen += (long long)n;
+        t_thread += now() - t0;
+        return PG_OK;
+    }
+    int dev_finish() {
+        const double t0 = now();
+        int rc = dev_begin();                        // no read at all: still an (empty) result
+        if (rc) return rc;
+        P2Result res;
+        rc = p2_finish(dev, res);
+        if (rc) return rc;
+        reads_deleted = res.reads_deleted;
+        mark_count = res.markers;
+        // a list shows its targets latest first-met first (prlRead2path.c:388-403, 443-467)
+        std::sort(res.arcs.begin(), res.arcs.end(), [](const P2Arc& a, const P2Arc& b) { return a.from != b.from ? a.from < b.from : a.first > b.first; });
+        FILE* fp = fopen((prefix + ".preArc").c_str(), "w");
+        if (!fp) { pg_set_error("cannot open " + prefix + ".preArc"); return PG_EIO; }
+        std::vector<char> big(1 << 22);
+        setvbuf(fp, big.data(), _IOFBF, big.size());
+        for (size_t i = 0; i < res.arcs.size();) {
+            const uint32_t from = res.arcs[i].from;
+            fprintf(fp, "%u", from);
+            for (; i < res.arcs.size() && res.arcs[i].from == from; i++) fprintf(fp, " %u %u", res.arcs[i].to, res.arcs[i].mult);
+            fputc('\n', fp);
+        }
+        fclose(fp);
+        dev_arc_count = (long long)res.arcs.size();
+        if (path_fp) for (size_t e = 0; e < marker.size() && e < res.marker.size(); e++) marker[e] = (uint8_t)std::min(255u, res.marker[e]);
+        t_fold += now() - t0;
+        return PG_OK;
+    }
+    long long dev_arc_count = 0;
     int resolve_repeats(int on) override {
         if (path_fp) { fclose(path_fp); path_fp = nullptr; }
         marker.clear();
@@ -1280,6 +1365,25 @@ struct GraphHandle : GraphHandleBase {
     }
 
     int add_reads(const uint8_t* codes, const int32_t* lens, uint64_t n, uint64_t stride, int n_threads) override {
+        if (dev_on) {                                // pack (pg_pack_read's layout) with the host threads, thread on the device
+            std::vector<int32_t> ls(n);
+            std::vector<uint64_t> off(n + 1, 0);
+            for (uint64_t r = 0; r < n; r++) { ls[r] = lens ? lens[r] : (int32_t)stride; off[r + 1] = off[r] + ((uint64_t)std::max(ls[r], 0) + 31) / 32; }
+            std::vector<uint64_t> words(off[n] + 1, 0);
+            const int nt = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)pick_threads(n_threads), (n + 4095) / 4096));
+            auto body = [&](int t) {
+                for (uint64_t r = n * t / nt; r < n * (t + 1) / nt; r++) {
+                    const uint8_t* c = codes + r * stride;
+                    uint64_t* w = words.data() + off[r];
+                    for (int i = 0; i < ls[r]; i++) w[i >> 5] |= (uint64_t)(c[i] & 3) << (62 - 2 * (i & 31));
+                }
+            };
+            std::vector<std::thread> pool;
+            for (int t = 1; t < nt; t++) pool.emplace_back(body, t);
+            body(0);
+            for (auto& th : pool) th.join();
+            return dev_add_packed(words.data(), ls.data(), n);
+        }
         return add_any(n, n_threads, [&](uint64_t r, std::vector<uint8_t>&, int& len) -> const uint8_t* {
             len = lens ? lens[r] : (int)stride;
             return codes + r * stride;
@@ -1287,6 +1391,7 @@ struct GraphHandle : GraphHandleBase {
     }
     // reads packed 2 bits a base, 32 bases a word, first base in the top bits (pg_pack_read), back to back
     int add_packed(const uint64_t* words, const int32_t* lens, uint64_t n, int n_threads) override {
+        if (dev_on) return dev_add_packed(words, lens, n);
         std::vector<uint64_t> off(n + 1, 0);
         for (uint64_t r = 0; r < n; r++) off[r + 1] = off[r] + ((uint64_t)lens[r] + 31) / 32;
         return add_any(n, n_threads, [&](uint64_t r, std::vector<uint8_t>& buf, int& len) -> const uint8_t* {
@@ -1385,8 +1490,9 @@ struct GraphHandle : GraphHandleBase {
         return PG_OK;
     }
     int finish(long long* n_arcs) override {
-        int rc = arcs.write(prefix + ".preArc");
+        int rc = dev_on ? dev_finish() : arcs.write(prefix + ".preArc");
         if (rc) return rc;
+        const long long arc_count = dev_on ? dev_arc_count : arcs.count();
         if (path_fp) {
             fclose(path_fp);
             path_fp = nullptr;
@@ -1396,9 +1502,9 @@ struct GraphHandle : GraphHandleBase {
             for (size_t e = 1; e < marker.size(); e++) fprintf(fp, "%d\n", (int)marker[e]);
             fclose(fp);
         }
-        fprintf(stderr, "Reads alignment done, %lld read(s) deleted, %lld pre-arc(s) added.\n", reads_deleted, arcs.count());
+        fprintf(stderr, "Reads alignment done, %lld read(s) deleted, %lld pre-arc(s) added.\n", reads_deleted, arc_count);
         fprintf(stderr, "Time spent on threading reads: %.1fs, on folding pre-arcs: %.1fs.\n", t_thread, t_fold);
-        if (n_arcs) *n_arcs = arcs.count();
+        if (n_arcs) *n_arcs = arc_count;
         return write_vertex<NW>(g, prefix, num_ed, max_read_len, num_vt);
     }
 };
@@ -1482,6 +1588,10 @@ extern "C" pg_graph* pg_host_graph_begin(const uint64_t* records, uint64_t n_rec
 extern "C" int pg_host_graph_resolve_repeats(pg_graph* g, int on) {
     if (!g) { pg_set_error("null argument"); return PG_EINVAL; }
     return ((pg::GraphHandleBase*)g)->resolve_repeats(on);
+}
+extern "C" int pg_graph_use_device(pg_graph* g, int device) {
+    if (!g) { pg_set_error("null argument"); return PG_EINVAL; }
+    return ((pg::GraphHandleBase*)g)->use_device(device);
 }
 extern "C" int pg_host_graph_add_packed(pg_graph* g, const uint64_t* words, const int32_t* lens, uint64_t n_reads, int n_threads) {
     if (!g || ((!words || !lens) && n_reads)) { pg_set_error("null argument"); return PG_EINVAL; }

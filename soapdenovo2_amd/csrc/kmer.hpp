@@ -120,6 +120,27 @@ PG_HD int kmer_first(const Kmer<NW>& a, int K) {                                
     return (int)((v >> (bit % 64)) & 3);
 }
 
+// reverseComplement(word, K + 1) exactly as the reference computes it for the (K+1)-mer of a length-1 edge
+// (node2edge.c:485, prlRead2path.c:694).  The 127-mer binary passes the length through a `char` (kmer.c:532): for
+// K = 127 the length 128 wraps to -128, takes the `seq_size < 32` exit and only the lowest word is complemented and
+// reversed (the shift count 64 - (-256) = 320 is applied modulo 64 by the hardware, i.e. not at all).
+template <int NW>
+PG_HD Kmer<NW> rc_plus(const Kmer<NW>& word, int K) {
+    if (NW == 4 && K + 1 >= 128) {
+        Kmer<NW> r = word;
+        r.w[NW - 1] = rev2bit(word.w[NW - 1] ^ 0xAAAAAAAAAAAAAAAAULL);
+        return r;
+    }
+    return kmer_rc<NW>(word, K + 1);
+}
+// KmerPlus (kmer.c:690-694): append one base without masking
+template <int NW>
+PG_HD Kmer<NW> kmer_plus(Kmer<NW> a, int ch) {
+    for (int i = 0; i < NW - 1; i++) a.w[i] = (a.w[i] << 2) | (a.w[i + 1] >> 62);
+    a.w[NW - 1] = (a.w[NW - 1] << 2) | (uint64_t)ch;
+    return a;
+}
+
 // ---- node counter word: the reference's two 32-bit words of kmer_t (inc/newhash.h:77-102) as one u64,
 // A in the low half, B in the high half.
 //   A = l_links (4 x 6 bit, index = base code preceding the canonical k-mer) | covs << 24

@@ -1,0 +1,35 @@
+// pass2.hpp -- seam between the host graph (host_graph.cpp, g++) and the device pass 2 (pass2_kernels.hip, hipcc).
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+namespace pg {
+
+struct P2Device;
+
+// the k-mer sets as the host stages left them: per set a slot array of (NW + 1) 64-bit words a slot (key words, then
+// A | B << 32), an empty slot has all-ones in its first word
+struct P2Sets {
+    const void* nodes[255];
+    uint64_t size[255];
+};
+struct P2Arc { uint32_t from, to, mult; uint64_t first; };       // first = smallest (read ordinal << 16 | position)
+struct P2Result {
+    std::vector<P2Arc> arcs;
+    std::vector<unsigned int> marker;                             // per edge id, unsaturated (-R only)
+    long long reads_deleted = 0, markers = 0;
+};
+
+// patch table: open addressing over `patch_cap` (a power of two) entries, NW key words + (id, twin) an entry, id 0 =
+// empty, slot = kmer_mix(key) & (cap - 1), linear probing
+P2Device* p2_create(int device, int K, int nw, int n_sets, const P2Sets& sets, const uint64_t* patch_keys, const uint32_t* patch_val,
+                    uint64_t patch_cap, uint32_t num_ed, int max_nk, bool reps);
+void p2_destroy(P2Device* d);
+// one batch of 2-bit packed reads (pg_pack_read), read i at words + word_off[i]; with reps the walks come back as rows of
+// max_nk ids (walks_out) with their lengths (walk_len_out, 0 = the read has no recorded walk)
+int p2_add_packed(P2Device* d, const uint64_t* words, const uint64_t* word_off, const int32_t* lens, uint64_t n_reads, uint64_t n_words,
+                  uint32_t* walks_out, uint16_t* walk_len_out);
+int p2_finish(P2Device* d, P2Result& out);
+
+}  // namespace pg

@@ -289,3 +289,51 @@ def test_cli_reader_corner_cases(golden, tmp_path):
         assert md5_file(pre + ".vertex") == want["vertex"], name
         assert md5_gz_text(pre + ".edge.gz") == want["edge"], name
         assert md5_file(pre + ".preArc") == want["preArc"], name
+
+
+@pytest.mark.parametrize("name", ["t6k_k31", "t8k_k63", "t6k_k127", "t5k_k24", "m60k_k63"])
+def test_device_pass2_matches_reference(golden, tmp_path, name):
+    """pg_graph_use_device: read -> edge threading and the pre-arc table on the GPU (pass2_kernels.hip), fed with the
+    oracle's pass-1 records: .preArc, and with -R .path / .markOnEdge, byte for byte as the reference wrote them."""
+    from conftest import case_codes, oracle_records
+    from soapdenovo2_amd import api
+    c = golden["cases"][name]
+    codes = case_codes(c)
+    for run in c["runs"]:
+        P, D, a, m = run
+        t = case_tag(name, run)
+        rec, last, K = oracle_records(codes, c["K"], P, D=D, mer127=bool(m), a_gb=a, prefix=str(tmp_path / ("o_" + t)))
+        want = golden["md5"][t]
+        for reps in (False, True):
+            pre = str(tmp_path / (t + ("_R" if reps else "")))
+            nv, ne, na = api.host_pregraph_files(rec, last, codes, None, K, P, pre, mer127=bool(m), cut_single=(D == 0), a_gb=a,
+                                                 max_read_len=c["L"], batches=3, resolve_repeats=reps, device=0, packed=reps)
+            assert md5_file(pre + ".preArc") == want["preArc"], (t, reps)
+            assert md5_file(pre + ".vertex") == want["vertex"], (t, reps)
+            if reps:
+                assert md5_file(pre + ".path") == want["path"], t
+                assert md5_file(pre + ".markOnEdge") == want["markOnEdge"], t
+
+
+def test_device_pass2_on_reader_corner_cases(golden, tmp_path):
+    """Ragged / truncated / mate-file reads through the device pass 2 (both hand-over formats)."""
+    from soapdenovo2_amd import api, synth
+    from oracle_binding import Oracle
+    K, P = 31, 3
+    for name in synth.QUIRK_CASES:
+        cfg = synth.make_quirk_case(str(tmp_path), name)
+        codes, lens, _, mrl = api.host_read_all(cfg, K)
+        o = Oracle(K, P=P, max_read_len=mrl)
+        o.add_reads(codes, lens=lens)
+        o.finish_count(str(tmp_path / ("o_" + name)))
+        nd = o.nodes()
+        rec = np.zeros((len(nd["A"]), 4), dtype=np.uint64)
+        rec[:, :2] = nd["keys"]
+        rec[:, 2] = nd["A"].astype(np.uint64) | (nd["B"].astype(np.uint64) << np.uint64(32))
+        rec[:, 3] = (nd["set"].astype(np.uint64) << np.uint64(56)) | nd["ord"]
+        last = np.array(o.set_last_put(), dtype=np.uint64)
+        o.close()
+        for packed in (False, True):
+            pre = str(tmp_path / (name + ("_pk" if packed else "")))
+            api.host_pregraph_files(rec, last, codes, lens, K, P, pre, max_read_len=mrl, device=0, packed=packed, batches=2)
+            assert md5_file(pre + ".preArc") == golden["md5"][name]["preArc"], (name, packed)
