@@ -227,6 +227,10 @@ private:
 
 int run(int argc, char** argv, bool mer127) {
     const time_t t_start = time(nullptr);
+    const bool verbose = getenv("PG_HOST_VERBOSE") != nullptr;
+    auto nowf = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
+    double tv = nowf();
+    auto lap = [&](const char* what) { if (verbose) { const double t = nowf(); fprintf(stderr, "[cli] %s: %.2fs\n", what, t - tv); tv = t; } };
     fprintf(stderr, "\n********************\nPregraph\n********************\n\n");
     Options o = parse_args(argc, argv, mer127);
     int K = o.K;                                                   // pregraph.c:71-97
@@ -276,6 +280,7 @@ int run(int argc, char** argv, bool mer127) {
         total_kmers = p1.total_kmers();
         have_kept = p1.take_kept(kept_words, kept_lens);
     }
+    lap("parse + scatter (pass 1)");
     // ---- -d filter, linear marking, .kmerFreq (deLowCov / Mark1in1outNode / freqStat); with the partition engine this
     // is also where the partitions are counted, so the node count is known only afterwards
     uint64_t hist[256];
@@ -283,6 +288,7 @@ int run(int argc, char** argv, bool mer127) {
     if (pg_finalize(ctx, o.delow, hist, set_last.data(), nullptr) != PG_OK) die("pg_finalize");
     uint64_t n_distinct = 0;
     if (pg_distinct(ctx, &n_distinct, nullptr) != PG_OK) die("pg_distinct");
+    lap("count partitions (finalize)");
     time_t t1 = time(nullptr);
     fprintf(stderr, "Time spent on hashing reads: %ds, %lld read(s) processed.\n", (int)(t1 - t0), n_records);
     fprintf(stderr, "%llu node(s) allocated, %llu kmer(s) in reads, %llu kmer(s) processed.\n", (unsigned long long)n_distinct,
@@ -306,6 +312,7 @@ int run(int argc, char** argv, bool mer127) {
         hipFree(d_rec);
     }
     pg_destroy(ctx);
+    lap("export + download records");
 
     // ---- tips + edges (removeSingleTips / removeMinorTips / kmer2edges), graph kept for pass 2
     t0 = time(nullptr);
@@ -319,6 +326,7 @@ int run(int argc, char** argv, bool mer127) {
     }
     { std::vector<uint64_t>().swap(records); }
     fprintf(stderr, "Time spent on removing tips and constructing edges: %ds.\n\n", (int)(time(nullptr) - t0));
+    lap("layout + tips + edges");
 
     // ---- pass 2 (prlRead2edge): the reads again, in the same order, threaded through the edges -> .preArc
     t0 = time(nullptr);
@@ -359,9 +367,11 @@ int run(int argc, char** argv, bool mer127) {
         p2.flush();
         fprintf(stderr, "%lld read(s) processed.\n", n2);
     }
+    lap("pass 2 batches");
     int num_vt = 0, num_ed = 0;
     long long num_arc = 0;
     if (pg_host_graph_finish(graph, &num_vt, &num_ed, &num_arc) != PG_OK) die("pg_host_graph_finish");
+    lap("pass 2 finish (preArc, vertex)");
     fprintf(stderr, "Time spent on aligning reads: %ds.\n\n", (int)(time(nullptr) - t0));
     fprintf(stderr, "Overall time spent on constructing pre-graph: %dm.\n\n", (int)(time(nullptr) - t_start) / 60);
     return 0;

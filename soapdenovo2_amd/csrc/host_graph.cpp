@@ -384,7 +384,7 @@ struct Graph {
     // that the walks can run ahead of the (order-dependent) mutations
     struct TipDecision {
         int action = 0;                // 0 nothing, 1 both ends dead, 2 thin cut, 3 minority cut
-        HNode<NW>* far = nullptr;
+        HNode<NW>* far = nullptr;      // where the walk stopped (null: no walk, or longer than the cut-off)
         int far_set = 0, first = 0;
         bool far_smaller = false;
     };
@@ -392,7 +392,8 @@ struct Graph {
         const int in = n_in(n), out = n_out(n);
         return (in == 0 && out == 1) || (in == 1 && out == 0);
     }
-    TipDecision tip_evaluate(const HNode<NW>& start, int cut_len, bool thin) {
+    // the walk: from a dead-end start over linear nodes to the node it stops at
+    TipDecision tip_walk(const HNode<NW>& start, int cut_len, bool thin) {
         TipDecision d;
         const int in = n_in(start), out = n_out(start);
         Kmer<NW> prev;
@@ -416,15 +417,27 @@ struct Graph {
             h = lookup(kmer_next<NW>(prev, only_out(*h.node, h.smaller), filter));
             if (!h.node) { fprintf(stderr, "Kmer is not found while clipping a tip.\n"); exit(1); }
         }
-        const HNode<NW>& far = *h.node;
         d.far = h.node; d.far_set = h.set; d.far_smaller = h.smaller;
         d.first = kmer_first<NW>(prev, K);
-        if (n_in(far) + n_out(far) == 1) { d.action = 1; return d; }
-        if (thin) { d.action = 2; return d; }
+        return d;
+    }
+    // would a walk arriving at `far` still stop there?
+    static bool walk_stops_at(const HNode<NW>& far, bool thin) { return !(far.B & B_LINEAR) || (thin && !(far.B & B_SINGLE)); }
+    // the verdict, from the stop node as it is now
+    void tip_decide(TipDecision& d, bool thin) const {
+        d.action = 0;
+        if (!d.far) return;
+        const HNode<NW>& far = *d.far;
+        if (n_in(far) + n_out(far) == 1) { d.action = 1; return; }
+        if (thin) { d.action = 2; return; }
         int strongest = 0;
-        for (int c = 0; c < 4; c++) strongest = std::max(strongest, h.smaller ? nL(far, c) : nR(far, c));
-        const int mine = h.smaller ? nL(far, d.first) : nR(far, d.first ^ 2);
+        for (int c = 0; c < 4; c++) strongest = std::max(strongest, d.far_smaller ? nL(far, c) : nR(far, c));
+        const int mine = d.far_smaller ? nL(far, d.first) : nR(far, d.first ^ 2);
         if (mine < strongest) d.action = 3;
+    }
+    TipDecision tip_evaluate(const HNode<NW>& start, int cut_len, bool thin) {
+        TipDecision d = tip_walk(start, cut_len, thin);
+        tip_decide(d, thin);
         return d;
     }
     bool tip_apply(HNode<NW>& start, const TipDecision& d, long long& tips) {
@@ -479,22 +492,34 @@ struct Graph {
             body();
             for (auto& th : pool) th.join();
         }
-        std::unordered_set<const HNode<NW>*> touched;
+        // nodes changed during this scan (one byte a slot; only the slots of clipped tips' ends are ever set)
+        std::vector<std::vector<uint8_t>> touched(sets.size());
+        for (size_t si = 0; si < sets.size(); si++) touched[si].assign(sets[si].size, 0);
+        auto is_touched = [&](int set, const HNode<NW>* n) { return touched[set][(size_t)(n - sets[set].array.data())] != 0; };
         std::priority_queue<uint64_t, std::vector<uint64_t>, std::greater<uint64_t>> later;
-        long long removed = 0, rewalked = 0;
+        long long removed = 0, rewalked = 0, redecided = 0;
         auto node_at = [&](uint64_t pos) -> HNode<NW>& { return sets[pos >> 40].array[pos & ((1ULL << 40) - 1)]; };
         auto visit = [&](uint64_t pos, const TipDecision* spec) {
             HNode<NW>& n = node_at(pos);
             if (!startable(n)) return;
             TipDecision d;
-            if (spec && !touched.count(&n) && (!spec->far || !touched.count(spec->far))) d = *spec;
-            else { d = tip_evaluate(n, cut_len, thin); rewalked++; }
+            const int nset = (int)(pos >> 40);
+            if (spec && !is_touched(nset, &n)) {
+                d = *spec;
+                if (d.far && is_touched(d.far_set, d.far)) {
+                    // the walk itself only crossed nodes nothing changes; if it still ends where it did, only the verdict
+                    // has to be taken again from that node's present state
+                    if (walk_stops_at(*d.far, thin)) { tip_decide(d, thin); redecided++; }
+                    else { d = tip_evaluate(n, cut_len, thin); rewalked++; }
+                }
+            } else { d = tip_evaluate(n, cut_len, thin); rewalked++; }
             if (!tip_apply(n, d, tips)) return;
             removed++;
-            touched.insert(&n);
-            touched.insert(d.far);
+            touched[nset][pos & ((1ULL << 40) - 1)] = 1;
+            const uint64_t fslot = (uint64_t)(d.far - sets[d.far_set].array.data());
+            touched[d.far_set][fslot] = 1;
             if (d.action != 1) {
-                const uint64_t fpos = ((uint64_t)d.far_set << 40) | (uint64_t)(d.far - sets[d.far_set].array.data());
+                const uint64_t fpos = ((uint64_t)d.far_set << 40) | fslot;
                 if (fpos > pos) later.push(fpos);
             }
         };
@@ -513,7 +538,7 @@ struct Graph {
             while (!later.empty() && later.top() == p) later.pop();
             visit(p, nullptr);
         }
-        if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "tip scan: %lld removed, %lld walked again\n", removed, rewalked);
+        if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "tip scan: %lld removed, %lld walked again, %lld decided again\n", removed, rewalked, redecided);
         return removed;
     }
 
@@ -870,13 +895,18 @@ struct ParallelEdgeBuilder {
             body();
             for (auto& th : pool) th.join();
         };
+        const bool verbose = getenv("PG_HOST_VERBOSE") != nullptr;
+        auto nowf = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double te0 = nowf();
         for_chunks([&](Chunk& c, Walker& w) { scan(w, c); });
+        const double te1 = nowf();
         int base = 0;
         for (Chunk& c : chunks) { c.base = base; base += c.ids; records += (long long)c.cands.size(); extra_nodes += c.extra; }
         edge_c = base;
         std::atomic<int> failed{0};
         for_chunks([&](Chunk& c, Walker&) { if (!apply(c)) failed.store(1); });
         if (failed.load()) { pg_set_error("edge construction: inconsistent arcs or deflate failure (PG_SERIAL_EDGES=1 runs the sequential builder)"); return PG_EINVAL; }
+        const double te2 = nowf();
         FILE* fp = fopen(path.c_str(), "wb");
         if (!fp) { pg_set_error("cannot open " + path); return PG_EIO; }
         bool any = false;
@@ -891,6 +921,7 @@ struct ParallelEdgeBuilder {
             fwrite(e.data(), 1, e.size(), fp);
         }
         fclose(fp);
+        if (verbose) fprintf(stderr, "edges: walks %.2fs, tagging + deflate %.2fs, patch table + file %.2fs (%d threads)\n", te1 - te0, te2 - te1, nowf() - te2, nt);
         return PG_OK;
     }
 };
@@ -1335,18 +1366,44 @@ struct GraphHandle : GraphHandleBase {
         if (rc) return rc;
         reads_deleted = res.reads_deleted;
         mark_count = res.markers;
-        // a list shows its targets latest first-met first (prlRead2path.c:388-403, 443-467)
-        std::sort(res.arcs.begin(), res.arcs.end(), [](const P2Arc& a, const P2Arc& b) { return a.from != b.from ? a.from < b.from : a.first > b.first; });
+        // a list shows its targets latest first-met first (prlRead2path.c:388-403, 443-467); the source edges are cut
+        // into ranges that are sorted and printed by all host threads
+        const int nt = std::max(1, pick_threads(0));
+        const uint64_t n_from = (uint64_t)num_ed + 1;
+        std::vector<size_t> start(nt + 1, 0);
+        for (const P2Arc& a : res.arcs) start[(size_t)((uint64_t)a.from * nt / n_from) + 1]++;
+        for (int t = 0; t < nt; t++) start[t + 1] += start[t];
+        std::vector<P2Arc> sorted(res.arcs.size());
+        {
+            std::vector<size_t> cur(start.begin(), start.end() - 1);
+            for (const P2Arc& a : res.arcs) sorted[cur[(size_t)((uint64_t)a.from * nt / n_from)]++] = a;
+        }
+        std::vector<std::string> text(nt);
+        auto body = [&](int t) {
+            P2Arc* lo = sorted.data() + start[t];
+            P2Arc* hi = sorted.data() + start[t + 1];
+            std::sort(lo, hi, [](const P2Arc& a, const P2Arc& b) { return a.from != b.from ? a.from < b.from : a.first > b.first; });
+            std::string& out = text[t];
+            out.reserve((size_t)(hi - lo) * 12);
+            char tmp[16];
+            auto put = [&](uint32_t v) { int n = 0; do { tmp[n++] = (char)('0' + v % 10); v /= 10; } while (v); while (n) out.push_back(tmp[--n]); };
+            for (P2Arc* a = lo; a != hi;) {
+                const uint32_t from = a->from;
+                put(from);
+                for (; a != hi && a->from == from; ++a) { out.push_back(' '); put(a->to); out.push_back(' '); put(a->mult); }
+                out.push_back('\n');
+            }
+        };
+        {
+            std::vector<std::thread> pool;
+            for (int t = 1; t < nt; t++) pool.emplace_back(body, t);
+            body(0);
+            for (auto& th : pool) th.join();
+        }
         FILE* fp = fopen((prefix + ".preArc").c_str(), "w");
         if (!fp) { pg_set_error("cannot open " + prefix + ".preArc"); return PG_EIO; }
-        std::vector<char> big(1 << 22);
-        setvbuf(fp, big.data(), _IOFBF, big.size());
-        for (size_t i = 0; i < res.arcs.size();) {
-            const uint32_t from = res.arcs[i].from;
-            fprintf(fp, "%u", from);
-            for (; i < res.arcs.size() && res.arcs[i].from == from; i++) fprintf(fp, " %u %u", res.arcs[i].to, res.arcs[i].mult);
-            fputc('\n', fp);
-        }
+        for (int t = 0; t < nt; t++)
+            if (!text[t].empty() && fwrite(text[t].data(), 1, text[t].size(), fp) != text[t].size()) { fclose(fp); pg_set_error("short write on " + prefix + ".preArc"); return PG_EIO; }
         fclose(fp);
         dev_arc_count = (long long)res.arcs.size();
         if (path_fp) for (size_t e = 0; e < marker.size() && e < res.marker.size(); e++) marker[e] = (uint8_t)std::min(255u, res.marker[e]);

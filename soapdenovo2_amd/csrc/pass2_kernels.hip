@@ -238,6 +238,17 @@ __global__ __launch_bounds__(256) void p2_thread_kernel(P2Params p, const uint64
     atomicAdd(&p.counters[4], (unsigned long long)upto);
 }
 
+// the occupied slots of the pre-arc table, densely (order does not matter: the host sorts)
+__global__ void p2_compact_arcs(const unsigned long long* key, const unsigned int* cnt, const unsigned long long* first, uint64_t cap,
+                                P2Arc* out, unsigned long long* n_out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long k = key[i];
+        if (!k) continue;
+        const unsigned long long at = atomicAdd(n_out, 1ULL);
+        out[at] = P2Arc{(uint32_t)(k >> 32), (uint32_t)k, cnt[i], first[i]};
+    }
+}
+
 __global__ void p2_fill_u64(unsigned long long* a, uint64_t n, unsigned long long v) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) a[i] = v;
 }
@@ -386,16 +397,20 @@ int p2_finish(P2Device* d, P2Result& out) {
     out.reads_deleted = (long long)c[0];
     out.markers = (long long)c[4];
     const uint64_t cap = d->prm.arc_mask + 1;
-    std::vector<unsigned long long> key(cap), first(cap);
-    std::vector<unsigned int> cnt(cap);
-    P2_HIP(hipMemcpy(key.data(), d->d_arc_key, cap * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    P2_HIP(hipMemcpy(cnt.data(), d->d_arc_cnt, cap * sizeof(unsigned int), hipMemcpyDeviceToHost));
-    P2_HIP(hipMemcpy(first.data(), d->d_arc_first, cap * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-    out.arcs.clear();
-    out.arcs.reserve((size_t)c[3]);
-    for (uint64_t i = 0; i < cap; i++)
-        if (key[i]) out.arcs.push_back(P2Arc{(uint32_t)(key[i] >> 32), (uint32_t)key[i], cnt[i], first[i]});
-    if (out.arcs.size() != (size_t)c[3]) { pg_set_error("pass 2: pre-arc table is inconsistent"); return PG_EINVAL; }
+    const size_t n_arcs = (size_t)c[3];
+    out.arcs.assign(n_arcs, P2Arc{0, 0, 0, 0});
+    if (n_arcs) {
+        P2Arc* d_arcs = nullptr;
+        P2_HIP(hipMalloc((void**)&d_arcs, n_arcs * sizeof(P2Arc)));
+        P2_HIP(hipMemsetAsync(d->d_counters + 6, 0, sizeof(unsigned long long), d->stream));
+        hipLaunchKernelGGL(p2_compact_arcs, dim3(2048), dim3(256), 0, d->stream, d->d_arc_key, d->d_arc_cnt, d->d_arc_first, cap, d_arcs, d->d_counters + 6);
+        P2_HIP(hipMemcpyAsync(out.arcs.data(), d_arcs, n_arcs * sizeof(P2Arc), hipMemcpyDeviceToHost, d->stream));
+        unsigned long long got = 0;
+        P2_HIP(hipMemcpyAsync(&got, d->d_counters + 6, sizeof(got), hipMemcpyDeviceToHost, d->stream));
+        P2_HIP(hipStreamSynchronize(d->stream));
+        hipFree(d_arcs);
+        if (got != n_arcs) { pg_set_error("pass 2: pre-arc table is inconsistent"); return PG_EINVAL; }
+    }
     out.marker.clear();
     if (d->reps) {
         out.marker.resize((size_t)d->num_ed + 1);
