@@ -150,16 +150,7 @@ public:
         Buf* b = &buf_[cur_];
         if (b->n_reads == max_reads_ || b->n_words + nw > max_words_) { submit(); b = &buf_[cur_]; }
         pg_pack_read(codes, (uint32_t)len, b->h_words + b->n_words);
-        if (keep_) {                                            // pass 2 threads the same reads again (prlRead2edge)
-            if ((kept_words_.size() + nw) * sizeof(uint64_t) + kept_lens_.size() * sizeof(int32_t) > keep_budget_) {
-                keep_ = false;
-                std::vector<uint64_t>().swap(kept_words_);
-                std::vector<int32_t>().swap(kept_lens_);
-            } else {
-                kept_words_.insert(kept_words_.end(), b->h_words + b->n_words, b->h_words + b->n_words + nw);
-                kept_lens_.push_back(len);
-            }
-        }
+        if (keep_) { const int32_t l32 = len; keep_append(b->h_words + b->n_words, nw, &l32, 1); }   // pass 2 threads the same reads again
         b->h_off[b->n_reads] = b->n_words;
         b->h_base[b->n_reads] = b->n_kmers;
         if (b->n_reads == 0) b->first_len = len; else if (len != b->first_len) b->uniform = false;
@@ -167,6 +158,51 @@ public:
         b->n_kmers += (uint64_t)(len - K_ + 1);
         b->n_reads++;
         accepted_++;
+    }
+    // runs from the multi-threaded reader: the words are copied as they are
+    void on_packed(const uint64_t* words, const int32_t* lens, size_t n, int min_len, int max_len) override {
+        size_t at = 0;
+        if (min_len >= K_ + 1 && min_len == max_len) {          // every read accepted and of one length: block copies
+            const int len = min_len;
+            const size_t wpr = pg_packed_words((uint32_t)len);
+            const uint64_t kpr = (uint64_t)(len - K_ + 1);
+            size_t r = 0;
+            while (r < n) {
+                Buf* b = &buf_[cur_];
+                size_t take = std::min(n - r, max_reads_ - b->n_reads);
+                take = std::min(take, (max_words_ - b->n_words) / wpr);
+                if (take == 0) { submit(); continue; }
+                memcpy(b->h_words + b->n_words, words + at, take * wpr * sizeof(uint64_t));
+                if (b->n_reads == 0) b->first_len = len; else if (len != b->first_len) b->uniform = false;
+                for (size_t i = 0; i < take; i++) {
+                    b->h_off[b->n_reads + i] = b->n_words + i * wpr;
+                    b->h_base[b->n_reads + i] = b->n_kmers + i * kpr;
+                }
+                if (keep_) keep_append(words + at, take * wpr, lens + r, take);
+                b->n_words += take * wpr; b->n_kmers += take * kpr; b->n_reads += take;
+                accepted_ += (long long)take;
+                at += take * wpr; r += take;
+            }
+            return;
+        }
+        for (size_t r = 0; r < n; r++) {
+            const int len = lens[r];
+            const size_t nw = pg_packed_words((uint32_t)len);
+            if (len >= K_ + 1) {                                    // prlHashReads.c:642
+                Buf* b = &buf_[cur_];
+                if (b->n_reads == max_reads_ || b->n_words + nw > max_words_) { submit(); b = &buf_[cur_]; }
+                memcpy(b->h_words + b->n_words, words + at, nw * sizeof(uint64_t));
+                if (keep_) keep_append(words + at, nw, &lens[r], 1);
+                b->h_off[b->n_reads] = b->n_words;
+                b->h_base[b->n_reads] = b->n_kmers;
+                if (b->n_reads == 0) b->first_len = len; else if (len != b->first_len) b->uniform = false;
+                b->n_words += nw;
+                b->n_kmers += (uint64_t)(len - K_ + 1);
+                b->n_reads++;
+                accepted_++;
+            }
+            at += nw;
+        }
     }
     void finish() { submit(); HIP_OK(hipStreamSynchronize(stream_)); }
     uint64_t total_kmers() const { return ord_; }
@@ -180,6 +216,16 @@ public:
     }
 
 private:
+    void keep_append(const uint64_t* w, size_t nw, const int32_t* lens, size_t n) {
+        if ((kept_words_.size() + nw) * sizeof(uint64_t) + (kept_lens_.size() + n) * sizeof(int32_t) > keep_budget_) {
+            keep_ = false;
+            std::vector<uint64_t>().swap(kept_words_);
+            std::vector<int32_t>().swap(kept_lens_);
+            return;
+        }
+        kept_words_.insert(kept_words_.end(), w, w + nw);
+        kept_lens_.insert(kept_lens_.end(), lens, lens + n);
+    }
     struct Buf {
         uint64_t *h_words, *h_off, *h_base, *d_words, *d_off, *d_base;
         size_t n_reads, n_words;

@@ -40,7 +40,9 @@ namespace pg {
 static uint32_t g_crc_tab[256];
 static std::atomic<bool> g_crc_ready{false};
 // host threads for the parallel stages: the caller's count, else SOAPDENOVO2_AMD_HOST_THREADS, else every hardware thread
-static int pick_threads(int n_threads) {
+int host_threads(int n_threads);
+static int pick_threads(int n_threads) { return host_threads(n_threads); }
+int host_threads(int n_threads) {
     if (n_threads > 0) return n_threads;
     if (const char* e = getenv("SOAPDENOVO2_AMD_HOST_THREADS")) { const int v = atoi(e); if (v > 0) return v; }
     static const int usable = []() {
@@ -952,18 +954,49 @@ static int write_vertex(Graph<NW>& g, const std::string& prefix, int num_ed, int
     if (!fp) { pg_set_error("cannot open " + prefix + ".vertex"); return PG_EIO; }
     std::vector<char> big(1 << 22);
     setvbuf(fp, big.data(), _IOFBF, big.size());
-    int cnt = 0;
-    char tmp[128];
-    for (auto& s : g.sets)
-        for (uint64_t i = 0; i < s.size; i++) {
+    // the slot ranges are scanned by all host threads: count the vertices per range first (the line break after every
+    // eighth vertex depends on the running count), then format
+    struct Range { int set; uint64_t lo, hi; long long n; std::string text; };
+    std::vector<Range> ranges;
+    const uint64_t STEP = 1 << 18;
+    for (int si = 0; si < (int)g.sets.size(); si++)
+        for (uint64_t lo = 0; lo < g.sets[si].size; lo += STEP) ranges.push_back(Range{si, lo, std::min<uint64_t>(g.sets[si].size, lo + STEP), 0, std::string()});
+    const int nt = std::max(1, pick_threads(g.n_threads));
+    auto for_ranges = [&](const std::function<void(Range&)>& fn) {
+        std::atomic<size_t> next{0};
+        auto body = [&]() { for (;;) { const size_t i = next.fetch_add(1); if (i >= ranges.size()) break; fn(ranges[i]); } };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; t++) pool.emplace_back(body);
+        body();
+        for (auto& th : pool) th.join();
+    };
+    for_ranges([&](Range& r) {
+        const HSet<NW>& s = g.sets[r.set];
+        long long n = 0;
+        for (uint64_t i = r.lo; i < r.hi; i++) n += s.occ[i] && !(s.array[i].B & (B_LINEAR | B_DELETED));
+        r.n = n;
+    });
+    long long run = 0;
+    std::vector<long long> before(ranges.size());
+    for (size_t i = 0; i < ranges.size(); i++) { before[i] = run; run += ranges[i].n; }
+    for_ranges([&](Range& r) {
+        const HSet<NW>& s = g.sets[r.set];
+        long long c = before[&r - ranges.data()];
+        char tmp[128];
+        r.text.reserve((size_t)r.n * (NW == 2 ? 34 : 68));
+        for (uint64_t i = r.lo; i < r.hi; i++) {
             if (!s.occ[i]) continue;
             const HNode<NW>& n = s.array[i];
             if (n.B & (B_LINEAR | B_DELETED)) continue;
-            cnt++;
+            c++;
             int len = fmt_kmer<NW>(tmp, n.seq, ' ');
-            if (cnt % 8 == 0) tmp[len++] = '\n';
-            fwrite(tmp, 1, len, fp);
+            if (c % 8 == 0) tmp[len++] = '\n';
+            r.text.append(tmp, (size_t)len);
         }
+    });
+    const int cnt = (int)run;
+    for (Range& r : ranges)
+        if (!r.text.empty()) fwrite(r.text.data(), 1, r.text.size(), fp);
     fputc('\n', fp);
     fclose(fp);
     fprintf(stderr, "%d vertex(es) output.\n", cnt);

@@ -10,8 +10,10 @@
 
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 
 #include <algorithm>
+#include <thread>
 
 namespace pg {
 
@@ -204,8 +206,7 @@ inline int convert_line(const char* s, int n, int max_len, uint8_t* out) {
 }
 
 // readseqfq (readseq1by1.c:279-360): next record of a FASTQ buffer; returns the read length (0 = none)
-int parse_fastq(const std::string& buf, size_t& start, int max_len, uint8_t* out) {
-    const size_t end = buf.size();
+int parse_fastq(const char* buf, size_t end, size_t& start, int max_len, uint8_t* out) {
     size_t p = 0;
     for (size_t m = start; m < end; m++) {
         const char c = buf[m];
@@ -214,8 +215,8 @@ int parse_fastq(const std::string& buf, size_t& start, int max_len, uint8_t* out
         else if (c == '\n' && buf[p] == '\n' && m > p) {
             const size_t line_len = m - p - 1;
             // strlen() of the copied line: stops at an embedded NUL
-            const size_t sl = strnlen(buf.data() + p + 1, line_len);
-            const int n = convert_line(buf.data() + p + 1, (int)sl, max_len, out);
+            const size_t sl = strnlen(buf + p + 1, line_len);
+            const int n = convert_line(buf + p + 1, (int)sl, max_len, out);
             size_t q = m + 1;
             while (q < end && buf[q] != '\n') q++;                   // the '+' line
             start = q + 2 + sl;                                      // skip the quality line: same length as the sequence line
@@ -226,8 +227,7 @@ int parse_fastq(const std::string& buf, size_t& start, int max_len, uint8_t* out
 }
 
 // readseqInBuf (readseq1by1.c:138-209): next record of a FASTA buffer (single-line sequences)
-int parse_fasta(const std::string& buf, size_t& start, int max_len, uint8_t* out) {
-    const size_t end = buf.size();
+int parse_fasta(const char* buf, size_t end, size_t& start, int max_len, uint8_t* out) {
     long p = -1;
     for (size_t m = start; m < end; m++) {
         const char c = buf[m];
@@ -235,9 +235,9 @@ int parse_fasta(const std::string& buf, size_t& start, int max_len, uint8_t* out
         else if (c == '\n' && p >= 0 && buf[p] == '>') p = (long)m;
         else if (c == '\n' && p >= 0 && buf[p] == '\n') {
             const size_t line_len = m - p - 1;
-            const size_t sl = strnlen(buf.data() + p + 1, line_len);
+            const size_t sl = strnlen(buf + p + 1, line_len);
             start = m + 1;
-            return convert_line(buf.data() + p + 1, (int)sl, max_len, out);
+            return convert_line(buf + p + 1, (int)sl, max_len, out);
         }
     }
     return 0;
@@ -248,13 +248,148 @@ void reverse_complement(uint8_t* s, int n) {                       // reverse2k,
     if (n & 1) s[n / 2] ^= 2;
 }
 
-[[noreturn]] void bad_record(const std::string& buf, size_t start) {   // prlHashReads.c:624-630
+[[noreturn]] void bad_record(const char* buf, size_t size, size_t start) {   // prlHashReads.c:624-630
     fprintf(stderr, "readseqInLib return error! please make sure input file is correct fastq/fasta file \n");
-    fprintf(stderr, "invalid data left in buffer:\n%s\n", buf.c_str() + std::min(start, buf.size()));
+    const std::string rest(buf + std::min(start, size), size - std::min(start, size));
+    fprintf(stderr, "invalid data left in buffer:\n%s\n", rest.c_str());
     exit(-1);
+}
+[[noreturn]] void bad_record(const std::string& buf, size_t start) { bad_record(buf.data(), buf.size(), start); }
+
+
+// ---- the same stream, parsed by all host threads ------------------------------------------------------------------
+// Where a 32 KiB chunk is cut depends on that chunk alone, and every buffer the reference parses is the stretch of file
+// between two consecutive cuts, parsed on its own.  So a window of chunks is read at once, the cuts and then the
+// buffers are handled in parallel (each thread packs its reads 2 bits a base), and the runs go to the sink in file
+// order.  Single-file inputs only; the mate-file interleave stays sequential.
+struct PackedRun {
+    std::vector<uint64_t> words;
+    std::vector<int32_t> lens;
+    long long records = 0;
+    int min_len = 0x7fffffff, max_len = 0;
+    void clear() { words.clear(); lens.clear(); records = 0; min_len = 0x7fffffff; max_len = 0; }
+};
+
+void parse_range(const InputFile& in, bool fastq, const char* buf, size_t size, std::vector<uint8_t>& codes, PackedRun& out) {
+    size_t start = 0;
+    while (start < size) {
+        const int n = fastq ? parse_fastq(buf, size, start, in.max_read_len, codes.data()) : parse_fasta(buf, size, start, in.max_read_len, codes.data());
+        if (n < 1) bad_record(buf, size, start);
+        if (in.reverse) reverse_complement(codes.data(), n);
+        out.records++;
+        const size_t nw = ((size_t)n + 31) / 32, at = out.words.size();
+        out.words.resize(at + nw);
+        for (size_t w = 0; w < nw; w++) {
+            uint64_t v = 0;
+            const int lo = (int)w * 32, hi = std::min(n, lo + 32);
+            for (int i = lo; i < hi; i++) v |= (uint64_t)(codes[i] & 3) << (62 - 2 * (i - lo));
+            out.words[at + w] = v;
+        }
+        out.lens.push_back(n);
+        out.min_len = std::min(out.min_len, n);
+        out.max_len = std::max(out.max_len, n);
+    }
+}
+
+long long stream_reads_parallel(const InputFile& in, ReadSink& sink, bool fastq, int nt, size_t window_chunks) {
+    Source src;
+    src.open(in.path1);
+    std::vector<char> win;
+    std::vector<size_t> cuts;
+    std::vector<std::pair<size_t, size_t>> bufs;
+    std::vector<PackedRun> runs(nt);
+    std::vector<std::vector<uint8_t>> codes(nt, std::vector<uint8_t>((size_t)std::max(in.max_read_len, 1) + 8));
+    std::string last_buf;                                   // the buffer parsed last, for the N x 32768 rerun
+    size_t carry = 0;
+    bool any = false;
+    long long n_records = 0;
+    auto deliver = [&](int used) {
+        for (int t = 0; t < used; t++) {
+            PackedRun& r = runs[t];
+            n_records += r.records;
+            if (!r.lens.empty()) sink.on_packed(r.words.data(), r.lens.data(), r.lens.size(), r.min_len, r.max_len);
+        }
+    };
+    auto parse_all = [&]() {
+        // contiguous groups of buffers of about equal size, one per thread
+        size_t total = 0;
+        for (auto& b : bufs) total += b.second - b.first;
+        std::vector<size_t> first(nt + 1, bufs.size());
+        first[0] = 0;
+        size_t acc = 0, bi = 0;
+        for (int t = 1; t < nt; t++) {
+            const size_t want = total * (size_t)t / (size_t)nt;
+            while (bi < bufs.size() && acc < want) { acc += bufs[bi].second - bufs[bi].first; bi++; }
+            first[t] = bi;
+        }
+        auto body = [&](int t) {
+            runs[t].clear();
+            for (size_t i = first[t]; i < first[t + 1]; i++) parse_range(in, fastq, win.data() + bufs[i].first, bufs[i].second - bufs[i].first, codes[t], runs[t]);
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; t++) pool.emplace_back(body, t);
+        body(0);
+        for (auto& th : pool) th.join();
+        deliver(nt);
+    };
+    for (;;) {
+        win.resize(carry + window_chunks * CHUNK);
+        const size_t got = fread(win.data() + carry, 1, window_chunks * CHUNK, src.fp);
+        if (got == 0) {
+            // the file ended on a chunk boundary: the reference parses its previous buffer again and loses the tail it
+            // had cached (prlHashReads.c:873-877)
+            fprintf(stderr, "Warning : aio_return zero, the size of input file must be N * 32768.\n");
+            if (any) {
+                runs[0].clear();
+                parse_range(in, fastq, last_buf.data(), last_buf.size(), codes[0], runs[0]);
+                deliver(1);
+            }
+            break;
+        }
+        any = true;
+        const size_t n_full = got / CHUNK, rem = got % CHUNK;
+        cuts.assign(n_full, 0);
+        {
+            auto body = [&](int t) {
+                for (size_t i = n_full * t / nt; i < n_full * (t + 1) / nt; i++)
+                    cuts[i] = fastq ? fastq_cut(win.data() + carry + i * CHUNK, CHUNK) : fasta_cut(win.data() + carry + i * CHUNK, CHUNK);
+            };
+            std::vector<std::thread> pool;
+            for (int t = 1; t < nt; t++) pool.emplace_back(body, t);
+            body(0);
+            for (auto& th : pool) th.join();
+        }
+        bufs.clear();
+        size_t begin = 0;
+        for (size_t i = 0; i < n_full; i++) {
+            const size_t end = carry + i * CHUNK + cuts[i];
+            bufs.emplace_back(begin, end);
+            begin = end;
+        }
+        if (rem) bufs.emplace_back(begin, carry + got);       // the short last chunk goes out whole, behind the cached tail
+        parse_all();
+        if (rem) break;
+        last_buf.assign(win.data() + bufs.back().first, bufs.back().second - bufs.back().first);
+        const size_t tail = carry + got - begin;
+        memmove(win.data(), win.data() + begin, tail);
+        carry = tail;
+    }
+    src.close();
+    return n_records;
 }
 
 }  // namespace
+
+void ReadSink::on_packed(const uint64_t* words, const int32_t* lens, size_t n, int, int max_len) {
+    std::vector<uint8_t> codes((size_t)std::max(max_len, 1) + 32);
+    size_t at = 0;
+    for (size_t r = 0; r < n; r++) {
+        const int len = lens[r];
+        for (int i = 0; i < len; i++) codes[i] = (uint8_t)((words[at + (i >> 5)] >> (62 - 2 * (i & 31))) & 3);
+        on_read(codes.data(), len);
+        at += ((size_t)len + 31) / 32;
+    }
+}
 
 long long stream_reads(const InputFile& in, ReadSink& sink) {
     if (in.type == 4) { fprintf(stderr, "BAM input (b=) is not supported by this build.\n"); exit(-1); }
@@ -262,8 +397,8 @@ long long stream_reads(const InputFile& in, ReadSink& sink) {
     std::vector<uint8_t> codes((size_t)std::max(in.max_read_len, 1) + 8);
     long long n_records = 0;
     auto parse = [&](const std::string& buf, size_t& start) {
-        const int n = fastq ? parse_fastq(buf, start, in.max_read_len, codes.data())
-                            : parse_fasta(buf, start, in.max_read_len, codes.data());
+        const int n = fastq ? parse_fastq(buf.data(), buf.size(), start, in.max_read_len, codes.data())
+                            : parse_fasta(buf.data(), buf.size(), start, in.max_read_len, codes.data());
         if (n < 1) bad_record(buf, start);
         if (in.reverse) reverse_complement(codes.data(), n);
         n_records++;
@@ -292,6 +427,17 @@ long long stream_reads(const InputFile& in, ReadSink& sink) {
             }
         }
         return n_records;
+    }
+    {   // single file: all host threads, unless the file is small (or SOAPDENOVO2_AMD_PARSE_THREADS=1)
+        int nt = host_threads(0);
+        if (const char* e = getenv("SOAPDENOVO2_AMD_PARSE_THREADS")) { const int v = atoi(e); if (v > 0) nt = v; }
+        size_t window = 4096;                                    // 128 MiB of text at a time
+        if (const char* e = getenv("SOAPDENOVO2_AMD_PARSE_WINDOW")) { const long v = atol(e); if (v > 0) window = (size_t)v; }
+        size_t min_bytes = (size_t)8 << 20;
+        if (const char* e = getenv("SOAPDENOVO2_AMD_PARSE_PARALLEL_MIN")) min_bytes = (size_t)atol(e);
+        struct stat st;
+        const bool big = stat(in.path1.c_str(), &st) != 0 || (size_t)st.st_size >= min_bytes || !S_ISREG(st.st_mode);
+        if (nt > 1 && big) return stream_reads_parallel(in, sink, fastq, nt, window);
     }
     ChunkStream s(in.path1, fastq);
     while (s.next()) {

@@ -37,8 +37,16 @@ std::vector<InputFile> input_order(const LibConfig& cfg, int max_read_len_all);
 // Sink for accepted reads: base codes 0..3, one byte per base.
 struct ReadSink {
     virtual void on_read(const uint8_t* codes, int len) = 0;
+    // A run of reads already packed 2 bits a base (32 bases a word, first base in the top bits, every read starting
+    // on a word: the layout of pg_pack_read), handed over by the multi-threaded reader.  min_len / max_len bound the
+    // read lengths of the run.  The default unpacks and calls on_read.
+    virtual void on_packed(const uint64_t* words, const int32_t* lens, size_t n, int min_len, int max_len);
     virtual ~ReadSink() {}
 };
+
+// host threads for the parallel stages: `n_threads` if positive, else SOAPDENOVO2_AMD_HOST_THREADS, else the hardware
+// threads capped by the container's CPU quota
+int host_threads(int n_threads);
 
 // Streams every read of `in` to `sink` in the reference's order, reproducing its 32 KiB chunking
 // (AIORead, prlHashReads.c:771-901) and record parsers (readseqfq / readseqInBuf, readseq1by1.c:138-360).

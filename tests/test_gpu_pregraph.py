@@ -170,9 +170,14 @@ def test_skm_route_then_ingest_equals_local(golden, tmp_path):
     assert (np.maximum.reduce(lasts) == last_want).all()
 
 
-def _run_cli(cfg, K, prefix, P, D, a, m, engine=None, R=False):
+PARALLEL_PARSE = {"SOAPDENOVO2_AMD_PARSE_PARALLEL_MIN": "0", "SOAPDENOVO2_AMD_PARSE_THREADS": "4", "SOAPDENOVO2_AMD_PARSE_WINDOW": "8"}
+
+
+def _run_cli(cfg, K, prefix, P, D, a, m, engine=None, R=False, extra_env=None):
     from soapdenovo2_amd import api
     env = dict(os.environ)
+    if extra_env:
+        env.update(extra_env)
     if engine:
         env["PG_ENGINE"] = str(engine)
     args = ["-s", cfg, "-K", str(K), "-o", prefix, "-p", str(P)]
@@ -198,7 +203,8 @@ def test_cli_matches_reference_files(golden, tmp_path, name, engine):
         P, D, a, m = run
         t = case_tag(name, run)
         pre = str(tmp_path / t)
-        _run_cli(cfg, c["K"], pre, P, D, a, m, engine=engine, R=(engine == 2))
+        # engine 2 also takes the multi-threaded reader (packed runs straight into the pinned batches)
+        _run_cli(cfg, c["K"], pre, P, D, a, m, engine=engine, R=(engine == 2), extra_env=PARALLEL_PARSE if engine == 2 else None)
         want = golden["md5"][t]
         if engine == 2:                                                # -R: the read paths and the per-edge marker counts
             assert md5_file(pre + ".path") == want["path"], t
@@ -279,6 +285,9 @@ def test_cli_reader_corner_cases(golden, tmp_path):
     for name in synth.QUIRK_CASES:
         cfg = synth.make_quirk_case(str(tmp_path), name)
         pre = str(tmp_path / ("cli_" + name))
+        _run_cli(cfg, 31, pre + "_par", 3, 0, 0, 0, extra_env=PARALLEL_PARSE)
+        for ext in ("kmerFreq", "vertex", "preArc"):
+            assert md5_file(pre + "_par." + ext) == golden["md5"][name][ext], (name, ext)
         log = _run_cli(cfg, 31, pre, 3, 0, 0, 0)
         q = golden["quirks"][name]
         assert f"{q['reads_processed']} read(s) processed" in log

@@ -44,3 +44,32 @@ def test_config_errors_exit_like_the_reference(tmp_path):
     code = ("import sys; sys.path.insert(0, %r); from soapdenovo2_amd import api; api.host_read_all(%r, 31)" % (str(api.ROOT), str(missing)))
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True)
     assert r.returncode != 0 and "Cannot open /nonexistent.fq" in r.stderr
+
+
+@pytest.mark.parametrize("threads,window", [(3, 2), (5, 1), (2, 64)])
+def test_parallel_reader_delivers_the_same_reads(tmp_path, threads, window):
+    """Single files are parsed by all host threads (windows of 32 KiB chunks, cuts and buffers in parallel): same reads,
+    same order, same record count as the sequential chunk emulation -- on the corner cases (N x 32768 file, ragged reads,
+    truncation, two libs, lower case / N / '.') and on plain FASTQ / FASTA, with tiny windows to cross window borders."""
+    import os
+    import numpy as np
+    cfgs = [(synth.make_quirk_case(str(tmp_path), name), 31) for name in synth.QUIRK_CASES]
+    for fmt in ("fastq", "fasta"):
+        cfgs.append((synth.make_case(str(tmp_path), "p_" + fmt, 30000, 4000, 90, 0.01, 9, fmt=fmt), 25))
+    knobs = {"SOAPDENOVO2_AMD_PARSE_PARALLEL_MIN": "0", "SOAPDENOVO2_AMD_PARSE_THREADS": str(threads),
+             "SOAPDENOVO2_AMD_PARSE_WINDOW": str(window)}
+    for cfg, K in cfgs:
+        os.environ["SOAPDENOVO2_AMD_PARSE_THREADS"] = "1"
+        try:
+            want = api.host_read_all(cfg, K)
+        finally:
+            del os.environ["SOAPDENOVO2_AMD_PARSE_THREADS"]
+        os.environ.update(knobs)
+        try:
+            got = api.host_read_all(cfg, K)
+        finally:
+            for k in knobs:
+                del os.environ[k]
+        assert got[2] == want[2] and got[3] == want[3], cfg
+        assert np.array_equal(got[1], want[1]), cfg
+        assert np.array_equal(got[0], want[0]), cfg
