@@ -222,6 +222,12 @@ int pg_finalize(pg_ctx *ctx, int delow, uint64_t hist_out[256], uint64_t *set_la
  * pg_distinct() records; order is unspecified.  *n_out (host) receives the count.  Synchronises. */
 int pg_export(pg_ctx *ctx, uint64_t *d_records, uint64_t capacity, uint64_t *n_out, void *stream);
 
+/* Order exported records (device memory, on the current device) by their last word, i.e. by k-mer set and then by
+ * first-occurrence ordinal: the order in which the layout replay of pg_host_build_graph / pg_host_graph_begin inserts
+ * them (put_kmerset order, newhash.c:473-528).  Records handed over in this order are inserted as they lie; otherwise
+ * the host buckets and sorts them itself.  n_records < 2^31.  Synchronises. */
+int pg_sort_records(uint64_t *d_records, uint64_t n_records, int mer127, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -67,6 +67,7 @@ def lib() -> C.CDLL:
     L.pg_host_graph_finish.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]
     L.pg_host_graph_resolve_repeats.argtypes = [C.c_void_p, C.c_int]
     L.pg_graph_use_device.argtypes = [C.c_void_p, C.c_int]
+    L.pg_sort_records.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
     L.pg_host_graph_add_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
     L.pg_host_read_all.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
                                    C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int)]
@@ -99,7 +100,7 @@ def lib() -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "pg_last_error", "pg_version", "call_pregraph", "call_pregraph_127mer", "pg_packed_words", "pg_pack_read",
-    "pg_host_build_graph", "pg_host_graph_begin", "pg_host_graph_add_reads", "pg_host_graph_finish", "pg_host_graph_resolve_repeats", "pg_host_graph_add_packed", "pg_graph_use_device", "pg_host_read_all", "pg_host_replay_layout", "pg_host_write_kmerfreq", "pg_create", "pg_create_engine", "pg_destroy", "pg_reset", "pg_set_autogrow", "pg_count_reads", "pg_route_count",
+    "pg_host_build_graph", "pg_host_graph_begin", "pg_host_graph_add_reads", "pg_host_graph_finish", "pg_host_graph_resolve_repeats", "pg_host_graph_add_packed", "pg_graph_use_device", "pg_sort_records", "pg_host_read_all", "pg_host_replay_layout", "pg_host_write_kmerfreq", "pg_create", "pg_create_engine", "pg_destroy", "pg_reset", "pg_set_autogrow", "pg_count_reads", "pg_route_count",
     "pg_route_scatter", "pg_count_records", "pg_skm_route", "pg_skm_ingest", "pg_distinct", "pg_stats", "pg_table_info", "pg_finalize", "pg_export",
 ]
 
@@ -339,8 +340,9 @@ class KmerCounter:
         keys = ["engine", "distinct", "records", "unit_bytes", "pool_used", "pool_chunks", "parts_or_slots", "export_capacity"]
         return {k: int(v) for k, v in zip(keys, out)}
 
-    def export(self) -> np.ndarray:
-        """(n, nw + 2) uint64 records on the host (key words, cnt, set << 56 | first ordinal)."""
+    def export(self, sort: bool = False) -> np.ndarray:
+        """(n, nw + 2) uint64 records on the host (key words, cnt, set << 56 | first ordinal); with sort=True in the layout
+        replay's insertion order (pg_sort_records on the device)."""
         t = self.torch
         n = self.distinct()
         rw = self.nw + 2
@@ -348,6 +350,9 @@ class KmerCounter:
         got = C.c_uint64(0)
         _check(lib().pg_export(self.h, d.data_ptr(), n, C.byref(got), self._stream()), "pg_export")
         assert got.value == n
+        if sort:
+            with t.cuda.device(self.device):
+                _check(lib().pg_sort_records(d.data_ptr(), n, int(self.nw == 4), self._stream()), "pg_sort_records")
         return d[: n * rw].cpu().numpy().view(np.uint64).reshape(n, rw)
 
     def close(self) -> None:

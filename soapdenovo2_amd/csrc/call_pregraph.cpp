@@ -354,6 +354,8 @@ int run(int argc, char** argv, bool mer127) {
         uint64_t got = 0;
         if (pg_export(ctx, d_rec, n_distinct, &got, nullptr) != PG_OK) die("pg_export");
         if (got != n_distinct) { fprintf(stderr, "export count mismatch\n"); exit(-1); }
+        // replay order (set, first occurrence) on the device; beyond 2^31 records the host sorts instead
+        if (n_distinct < 0x7fffffffULL && pg_sort_records(d_rec, n_distinct, mer127 ? 1 : 0, nullptr) != PG_OK) die("pg_sort_records");
         HIP_OK(hipMemcpy(records.data(), d_rec, records.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
         hipFree(d_rec);
     }

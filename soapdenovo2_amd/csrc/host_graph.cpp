@@ -1022,15 +1022,39 @@ static int replay_layout(Graph<NW>& g, const uint64_t* records, uint64_t n, cons
     g.sets.clear();
     g.sets.resize(P);
     std::vector<uint64_t> per_set(P + 1, 0);
-    for (uint64_t i = 0; i < n; i++) {
-        const uint64_t s = records[i * RW + NW + 1] >> PG_ORD_BITS;
-        if (s >= (uint64_t)P) { pg_set_error("record with set id >= n_sets"); return PG_EINVAL; }
-        per_set[s + 1]++;
+    // Records that already come in replay order -- by set, then by ordinal (pg_sort_records does that on the device) --
+    // are inserted as they lie; anything else is bucketed and sorted here.
+    bool presorted = true;
+    {
+        const int nt = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)pick_threads(n_threads), n / 65536 + 1));
+        std::vector<std::vector<uint64_t>> cnt(nt, std::vector<uint64_t>(P + 1, 0));
+        std::atomic<int> unsorted{0}, bad{0};
+        auto body = [&](int t) {
+            const uint64_t lo = n * t / nt, hi = n * (t + 1) / nt;
+            uint64_t prev = lo ? records[(lo - 1) * RW + NW + 1] : 0;
+            bool ok = true;
+            for (uint64_t i = lo; i < hi; i++) {
+                const uint64_t tag = records[i * RW + NW + 1];
+                const uint64_t s = tag >> PG_ORD_BITS;
+                if (s >= (uint64_t)P) { bad.store(1); return; }
+                cnt[t][s + 1]++;
+                ok = ok && tag >= prev;
+                prev = tag;
+            }
+            if (!ok) unsorted.store(1);
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; t++) pool.emplace_back(body, t);
+        body(0);
+        for (auto& th : pool) th.join();
+        if (bad.load()) { pg_set_error("record with set id >= n_sets"); return PG_EINVAL; }
+        presorted = !unsorted.load();
+        for (int t = 0; t < nt; t++) for (int s = 0; s < P; s++) per_set[s + 1] += cnt[t][s + 1];
     }
     for (int s = 0; s < P; s++) per_set[s + 1] += per_set[s];
     struct Ref { uint64_t ord; uint64_t idx; };
-    std::vector<Ref> order(n);
-    {
+    std::vector<Ref> order(presorted ? 0 : n);
+    if (!presorted) {
         std::vector<uint64_t> cur(per_set.begin(), per_set.end() - 1);
         for (uint64_t i = 0; i < n; i++) {
             const uint64_t tag = records[i * RW + NW + 1];
@@ -1046,10 +1070,15 @@ static int replay_layout(Graph<NW>& g, const uint64_t* records, uint64_t n, cons
         for (;;) {
             const int s = next.fetch_add(1);
             if (s >= P) break;
-            Ref* lo = order.data() + per_set[s];
-            Ref* hi = order.data() + per_set[s + 1];
+            std::vector<Ref> own;
+            if (presorted) {                                  // the set's records lie in order: refer to them in place
+                own.resize(per_set[s + 1] - per_set[s]);
+                for (uint64_t i = per_set[s]; i < per_set[s + 1]; i++) own[i - per_set[s]] = Ref{records[i * RW + NW + 1] & PG_ORD_MASK, i};
+            }
+            Ref* lo = presorted ? own.data() : order.data() + per_set[s];
+            Ref* hi = lo + (per_set[s + 1] - per_set[s]);
             const double ts0 = nowf();
-            {   // LSD radix sort on the ordinal, 16 bits a pass (ordinals are distinct within a set)
+            if (!presorted) {   // LSD radix sort on the ordinal, 16 bits a pass (ordinals are distinct within a set)
                 const size_t cnt = (size_t)(hi - lo);
                 uint64_t top = 0;
                 for (Ref* r = lo; r != hi; ++r) top |= r->ord;

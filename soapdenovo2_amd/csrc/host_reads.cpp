@@ -332,9 +332,12 @@ long long stream_reads_parallel(const InputFile& in, ReadSink& sink, bool fastq,
         for (auto& th : pool) th.join();
         deliver(nt);
     };
+    // two windows: while the threads parse one, the next stretch of the file is read into the other
+    std::vector<char> next_win;
+    size_t got = 0;
+    win.resize(window_chunks * CHUNK);
+    got = fread(win.data(), 1, window_chunks * CHUNK, src.fp);
     for (;;) {
-        win.resize(carry + window_chunks * CHUNK);
-        const size_t got = fread(win.data() + carry, 1, window_chunks * CHUNK, src.fp);
         if (got == 0) {
             // the file ended on a chunk boundary: the reference parses its previous buffer again and loses the tail it
             // had cached (prlHashReads.c:873-877)
@@ -367,12 +370,18 @@ long long stream_reads_parallel(const InputFile& in, ReadSink& sink, bool fastq,
             begin = end;
         }
         if (rem) bufs.emplace_back(begin, carry + got);       // the short last chunk goes out whole, behind the cached tail
-        parse_all();
-        if (rem) break;
+        if (rem) { parse_all(); break; }
         last_buf.assign(win.data() + bufs.back().first, bufs.back().second - bufs.back().first);
         const size_t tail = carry + got - begin;
-        memmove(win.data(), win.data() + begin, tail);
+        next_win.resize(tail + window_chunks * CHUNK);
+        memcpy(next_win.data(), win.data() + begin, tail);
+        size_t next_got = 0;
+        std::thread reader([&]() { next_got = fread(next_win.data() + tail, 1, window_chunks * CHUNK, src.fp); });
+        parse_all();
+        reader.join();
+        win.swap(next_win);
         carry = tail;
+        got = next_got;
     }
     src.close();
     return n_records;

@@ -346,3 +346,23 @@ def test_device_pass2_on_reader_corner_cases(golden, tmp_path):
             pre = str(tmp_path / (name + ("_pk" if packed else "")))
             api.host_pregraph_files(rec, last, codes, lens, K, P, pre, max_read_len=mrl, device=0, packed=packed, batches=2)
             assert md5_file(pre + ".preArc") == golden["md5"][name]["preArc"], (name, packed)
+
+
+@pytest.mark.parametrize("K,m", [(31, 0), (127, 1)])
+def test_sort_records_is_replay_order(K, m):
+    """pg_sort_records: exported records ordered by (set, first ordinal) -- the same multiset, sorted by the last word."""
+    import torch
+    from soapdenovo2_amd import api, synth
+    L, n = 150, 40000
+    codes = synth.reads_codes(50000, n, L, 0.004, 77)
+    packed = torch.from_numpy(api.pack_reads_uniform(codes).view(np.int64)).cuda()
+    kc = api.KmerCounter(K, n_sets=7, mer127=bool(m), log2_slots=22)
+    kc.count_uniform(packed, n, L, 0)
+    kc.finalize(0)
+    a = kc.export()
+    b = kc.export(sort=True)
+    assert a.shape == b.shape
+    tags = b[:, -1]
+    assert (tags[1:] > tags[:-1]).all()                        # distinct ordinals within a set, sets ascending
+    order = np.argsort(a[:, -1], kind="stable")
+    assert np.array_equal(a[order], b)
