@@ -131,12 +131,11 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_tiled_kernel(ReadsArg a, E2
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int R = ta.R, np = ta.np, lv = ta.lv;
     const int wpr = (int)a.wpr, kpr = (int)a.kpr, ws = wpr + 1, len = (int)a.uniform_len;
-    const int nch = (kpr + 63) >> 6;                               // 64-k-mer chunks per read (one wave each)
+    const int nch = (kpr + 62) / 63;                               // 63-k-mer chunks per read (one wave each)
     uint64_t* words = (uint64_t*)smem_raw;                       // R * ws
     unsigned long long* masks = (unsigned long long*)(words + (size_t)R * ws);   // R * nch: run-start bits
-    uint32_t* v0 = (uint32_t*)(masks + (size_t)R * nch);          // R * np
-    uint32_t* v1 = v0 + (size_t)R * np;                           // R * np
-    uint32_t* pids = v1 + (size_t)R * np;                         // R * kpr
+    uint32_t* v0 = (uint32_t*)(masks + (size_t)R * nch);          // R * np: m-mer values
+    uint32_t* pids = v0 + (size_t)R * np;                         // R * kpr
     uint32_t* items = pids + (size_t)R * kpr;                     // R * kpr  (r << 24 | j << 12 | n)
     __shared__ unsigned int n_items;
     const uint64_t r0 = (uint64_t)blockIdx.x * R;
@@ -155,32 +154,44 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_tiled_kernel(ReadsArg a, E2
         v0[i] = mmer_value(words + r * ws, p, m);
     }
     __syncthreads();
-    uint32_t* src = v0;
-    uint32_t* dst = v1;
-    for (int k = 1; k <= lv; k++) {
-        const int half = 1 << (k - 1);
-        for (int i = threadIdx.x; i < nr * np; i += BLOCK) {
-            const int p = i - (int)fastdiv(i, ta.inv_np) * np;
-            const uint32_t x = src[i];
-            dst[i] = (p + half < np) ? min(x, src[i + half]) : x;
-        }
-        __syncthreads();
-        uint32_t* t = src; src = dst; dst = t;
-    }
-    const int span = 1 << lv;                                      // src[p] = min over [p, p + span)
+    const int span = 1 << lv;                                      // doubling reaches min over [p, p + span), span <= w
     const int nmax = e.g.nmax;
-    // C: partition per k-mer and run-start bits, one wave per 64-k-mer chunk of a read (the ballot IS the bit mask)
+    // B + C in registers, one wave per chunk of 63 k-mers of a read: lane l holds k-mer j = 63 c - 1 + l (lane 0 only
+    // supplies the predecessor of lane 1) and the m-mer values at j, j + 64, j + 128.  The sliding minimum over the
+    // w m-mers of a k-mer is lv doubling steps of "min with the value d lanes up" (shuffles, no LDS pass, no barrier),
+    // then one more shifted min for the remainder of the window; the ballot of the run starts IS the bit mask.
     for (int wi = wave; wi < nr * nch; wi += BLOCK / 64) {
         const int r = wi / nch, c = wi - r * nch;
-        const int j = c * 64 + lane;
-        const bool valid = j < kpr;
-        const uint32_t* sv = src + r * np;
-        uint32_t pid = 0xFFFFFFFFu, prev = 0xFFFFFFFFu;
-        if (valid) {
-            pid = skm_partition(min(sv[j], sv[j + w - span]), e.g.log2_parts);
-            pids[r * kpr + j] = pid;
-            if (j > 0) prev = skm_partition(min(sv[j - 1], sv[j - 1 + w - span]), e.g.log2_parts);
+        const int j = 63 * c - 1 + lane;
+        const uint32_t* sv = v0 + r * np;
+        uint32_t x0 = (j >= 0 && j < np) ? sv[j] : 0xFFFFFFFFu;
+        uint32_t x1 = (j + 64 < np) ? sv[j + 64] : 0xFFFFFFFFu;
+        uint32_t x2 = (j + 128 < np) ? sv[j + 128] : 0xFFFFFFFFu;
+        auto shifted_min = [&](int d) {                             // x_i[l] = min(x_i[l], value d positions further on)
+            const int srcl = (lane + d) & 63;
+            const bool wrap = lane + d >= 64;
+            const uint32_t a0 = __shfl(x0, srcl, 64), a1 = __shfl(x1, srcl, 64), a2 = __shfl(x2, srcl, 64);
+            x0 = min(x0, wrap ? a1 : a0);
+            x1 = min(x1, wrap ? a2 : a1);
+            x2 = min(x2, wrap ? 0xFFFFFFFFu : a2);
+        };
+        for (int k = 0; k < lv && k < 6; k++) shifted_min(1 << k);
+        if (lv >= 7) { x0 = min(x0, x1); x1 = min(x1, x2); }      // a step of 64 is the next register (w >= 128 only)
+        uint32_t mv = x0;                                           // min over [j, j + span)
+        {
+            const int sft = w - span;                               // the rest of the window: [j + w - span, j + w)
+            if (sft > 0) {
+                const int d = sft & 63;
+                const int srcl = (lane + d) & 63;
+                const bool wrap = lane + d >= 64;
+                const uint32_t a0 = __shfl(x0, srcl, 64), a1 = __shfl(x1, srcl, 64), a2 = __shfl(x2, srcl, 64);
+                mv = sft >= 64 ? min(x0, wrap ? a2 : a1) : min(x0, wrap ? a1 : a0);
+            }
         }
+        const bool valid = lane > 0 ? (j < kpr) : false;
+        const uint32_t pid = skm_partition(mv, e.g.log2_parts);
+        const uint32_t prev = __shfl_up(pid, 1, 64);
+        if (valid) pids[r * kpr + j] = pid;
         const bool start = valid && (j == 0 || pid != prev || j % nmax == 0);
         const unsigned long long mk = __ballot(start);
         if (lane == 0) masks[wi] = mk;
@@ -189,7 +200,7 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_tiled_kernel(ReadsArg a, E2
     // D: every run start finds the next start in the bit masks (no per-lane walk) and queues one item
     for (int wi = wave; wi < nr * nch; wi += BLOCK / 64) {
         const int r = wi / nch, c = wi - r * nch;
-        const int j = c * 64 + lane;
+        const int j = 63 * c - 1 + lane;
         const unsigned long long mk = masks[wi];
         const bool start = (mk >> lane) & 1ULL;
         uint32_t item = 0;
@@ -200,7 +211,7 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_tiled_kernel(ReadsArg a, E2
             else {
                 for (int cc = c + 1; cc < nch; cc++) {
                     const unsigned long long mm = masks[r * nch + cc];
-                    if (mm) { next = cc * 64 + __ffsll((long long)mm) - 1; break; }
+                    if (mm) { next = 63 * cc - 1 + __ffsll((long long)mm) - 1; break; }
                 }
             }
             item = ((uint32_t)r << 24) | ((uint32_t)j << 12) | (uint32_t)(next - j);
@@ -699,7 +710,7 @@ static int e2_ensure_pool(pg_ctx* c, uint64_t n_reads, uint64_t n_kmers, hipStre
 // launch the tiled K1; returns PG_OK / an error, or 1 when the reads are too long for a tile (caller falls back)
 static int launch_tiled(pg_ctx* c, const ReadsArg& a, const RouteArg* route, hipStream_t st) {
     const int np = (int)a.uniform_len - c->e2.g.m + 1;
-    const size_t per_read = (size_t)(a.wpr + 1) * 8 + (size_t)((a.kpr + 63) / 64) * 8 + (size_t)np * 8 + (size_t)a.kpr * 8;
+    const size_t per_read = (size_t)(a.wpr + 1) * 8 + (size_t)((a.kpr + 62) / 63) * 8 + (size_t)np * 4 + (size_t)a.kpr * 8;
     int R = (int)std::min<size_t>(8, (56 * 1024) / per_read);          // small tiles: many resident workgroups hide the LDS / atomic latency
     if (const char* v = getenv("PG_K1_R")) R = std::max(1, std::min(atoi(v), (int)((56 * 1024) / per_read)));
     if (R < 1) return 1;
