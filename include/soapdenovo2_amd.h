@@ -208,6 +208,11 @@ int pg_distinct(pg_ctx *ctx, uint64_t *out, void *stream);
 /* Current capacity (slots) and bytes per slot of the device set. */
 int pg_table_info(pg_ctx *ctx, uint64_t *slots, uint32_t *slot_bytes);
 
+/* Tell the context how many k-mer occurrences the whole input will bring (an estimate is fine).  The partition engine
+ * sizes its partition count from it -- about 8 k occurrences a partition, so that one partition is counted in one LDS
+ * pass -- instead of from log2_slots, which sizes the export array for the DISTINCT k-mers.  Before the first batch. */
+int pg_expect_kmers(pg_ctx *ctx, uint64_t total_kmers);
+
 /* Counters for reporting (synchronise first): out[0] engine, out[1] distinct k-mers, out[2] super-k-mer records,
  * out[3] bytes per record (engine 2) / per slot (engine 1), out[4] pool chunks handed out, out[5] pool chunks,
  * out[6] partitions (engine 2) / slots (engine 1), out[7] export capacity. */

@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 #include <time.h>
 #include <unistd.h>
 
@@ -205,6 +206,7 @@ public:
         }
     }
     void finish() { submit(); HIP_OK(hipStreamSynchronize(stream_)); }
+    bool finish_ok() { finish(); return !failed_; }
     uint64_t total_kmers() const { return ord_; }
     hipStream_t stream() const { return stream_; }
     // the packed reads kept for pass 2, or nothing when they outgrew the budget (then the files are parsed again)
@@ -245,9 +247,9 @@ private:
                 HIP_OK(hipMemcpyAsync(b.d_off, b.h_off, b.n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, stream_));
                 HIP_OK(hipMemcpyAsync(b.d_base, b.h_base, (b.n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream_));
             }
-            if (pg_count_reads(ctx_, b.d_words, b.uniform ? nullptr : b.d_off, b.uniform ? nullptr : b.d_base, b.n_reads,
-                               b.uniform ? (uint32_t)b.first_len : 0u, b.n_kmers, ord_, stream_) != PG_OK)
-                die("pg_count_reads");
+            if (!failed_ && pg_count_reads(ctx_, b.d_words, b.uniform ? nullptr : b.d_off, b.uniform ? nullptr : b.d_base, b.n_reads,
+                                           b.uniform ? (uint32_t)b.first_len : 0u, b.n_kmers, ord_, stream_) != PG_OK)
+                failed_ = true;                                     // the caller decides (finish_ok)
             HIP_OK(hipEventRecord(b.done, stream_));
             b.busy = true;
             ord_ += b.n_kmers;
@@ -257,6 +259,7 @@ private:
         if (n.busy) { HIP_OK(hipEventSynchronize(n.done)); n.busy = false; }
         reset(n);
     }
+    bool failed_ = false;
     bool keep_ = false;
     size_t keep_budget_ = 0;
     std::vector<uint64_t> kept_words_;
@@ -301,39 +304,71 @@ int run(int argc, char** argv, bool mer127) {
         const double nodes = (double)o.a_gb * 1073741824.0 / (mer127 ? 40 : 24);
         while (log2_slots < 36 && (double)((uint64_t)1 << log2_slots) * 0.7 < nodes) log2_slots++;
     }
-    pg_ctx* ctx = pg_create(device, K, mer127 ? 1 : 0, o.sets, log2_slots);
-    if (!ctx) die("pg_create");
-    fprintf(stderr, "%d k-mer set(s) on HIP device %d.\n", o.sets, device);
-
-    long long n_records = 0;
-    uint64_t total_kmers = 0;
-    // Packed reads (2 bits a base) stay in host memory for pass 2 while they fit a quarter of the physical memory
-    // (SOAPDENOVO2_AMD_KEEP_READS_GB overrides, 0 = always parse the files twice as the reference does).
+    // how much is coming: bases ~ half the bytes of a FASTQ file, all of a FASTA file (x4 behind gzip)
+    uint64_t est_kmers = 0;
+    for (const pg::InputFile& f : files)
+        for (const std::string* path : {&f.path1, &f.path2}) {
+            struct stat st;
+            if (path->empty() || stat(path->c_str(), &st) != 0) continue;
+            double bases = (double)st.st_size * ((f.type == 2 || f.type == 6) ? 0.5 : 1.0);
+            if (path->size() > 3 && path->compare(path->size() - 3, 3, ".gz") == 0) bases *= 4.0;
+            est_kmers += (uint64_t)bases;
+        }
+    if (o.a_gb == 0) {                                               // room for a fifth of them to be distinct; it grows
+        while (log2_slots < 34 && (double)((uint64_t)1 << log2_slots) * 0.7 < (double)est_kmers / 5.0) log2_slots++;
+    }
     size_t keep_budget = (size_t)sysconf(_SC_PHYS_PAGES) * (size_t)sysconf(_SC_PAGE_SIZE) / 4;
     if (const char* e = getenv("SOAPDENOVO2_AMD_KEEP_READS_GB")) keep_budget = (size_t)(atof(e) * 1073741824.0);
     std::vector<uint64_t> kept_words;
     std::vector<int32_t> kept_lens;
     bool have_kept = false;
-    {
-        Pass1 p1(ctx, K, (size_t)1 << 23, (size_t)1 << 21);     // 64 MiB of packed reads / 2 M reads per batch
-        p1.keep_reads(keep_budget);
-        for (const pg::InputFile& f : files) {
-            fprintf(stderr, "Import reads from file:\n %s\n", f.path1.c_str());
-            if (!f.path2.empty()) fprintf(stderr, "Import reads from file:\n %s\n", f.path2.c_str());
-            n_records += pg::stream_reads(f, p1);
-        }
-        p1.finish();
-        total_kmers = p1.total_kmers();
-        have_kept = p1.take_kept(kept_words, kept_lens);
-    }
-    lap("parse + scatter (pass 1)");
-    // ---- -d filter, linear marking, .kmerFreq (deLowCov / Mark1in1outNode / freqStat); with the partition engine this
-    // is also where the partitions are counted, so the node count is known only afterwards
+    long long n_records = 0;
+    uint64_t total_kmers = 0;
     uint64_t hist[256];
     std::vector<uint64_t> set_last(o.sets, 0);
-    if (pg_finalize(ctx, o.delow, hist, set_last.data(), nullptr) != PG_OK) die("pg_finalize");
     uint64_t n_distinct = 0;
-    if (pg_distinct(ctx, &n_distinct, nullptr) != PG_OK) die("pg_distinct");
+    pg_ctx* ctx = nullptr;
+    // Pass 1 on the partition engine; should one partition outgrow its chunk list (one minimizer owning a huge share of
+    // the input) the reads go through the global-set engine instead -- slower, indifferent to skew, same result.
+    int engine = 2;
+    if (const char* e = getenv("PG_ENGINE")) engine = atoi(e);
+    for (int attempt = 0;; attempt++) {
+        ctx = pg_create_engine(device, K, mer127 ? 1 : 0, o.sets, log2_slots, engine);
+        if (!ctx) die("pg_create");
+        if (est_kmers && pg_expect_kmers(ctx, est_kmers) != PG_OK) die("pg_expect_kmers");
+        if (attempt == 0) fprintf(stderr, "%d k-mer set(s) on HIP device %d.\n", o.sets, device);
+        bool ok = true;
+        {
+            Pass1 p1(ctx, K, (size_t)1 << 23, (size_t)1 << 21);     // 64 MiB of packed reads / 2 M reads per batch
+            if (attempt == 0) {
+                p1.keep_reads(keep_budget);
+                for (const pg::InputFile& f : files) {
+                    fprintf(stderr, "Import reads from file:\n %s\n", f.path1.c_str());
+                    if (!f.path2.empty()) fprintf(stderr, "Import reads from file:\n %s\n", f.path2.c_str());
+                    n_records += pg::stream_reads(f, p1);
+                }
+            } else if (have_kept) {
+                int mn = 0x7fffffff, mx = 0;
+                for (int32_t l : kept_lens) { mn = std::min(mn, (int)l); mx = std::max(mx, (int)l); }
+                if (!kept_lens.empty()) p1.on_packed(kept_words.data(), kept_lens.data(), kept_lens.size(), mn, mx);
+            } else {
+                for (const pg::InputFile& f : files) pg::stream_reads(f, p1);
+            }
+            ok = p1.finish_ok();
+            total_kmers = p1.total_kmers();
+            if (attempt == 0) have_kept = p1.take_kept(kept_words, kept_lens);
+        }
+        lap("parse + scatter (pass 1)");
+        // ---- -d filter, linear marking, .kmerFreq (deLowCov / Mark1in1outNode / freqStat); with the partition engine
+        // this is also where the partitions are counted, so the node count is known only afterwards
+        if (ok && pg_finalize(ctx, o.delow, hist, set_last.data(), nullptr) != PG_OK) ok = false;
+        if (ok && pg_distinct(ctx, &n_distinct, nullptr) != PG_OK) ok = false;
+        if (ok) break;
+        if (engine != 2 || attempt > 0) die("pass 1");
+        fprintf(stderr, "Partition engine gave up (%s); counting again with the global k-mer set.\n", pg_last_error());
+        pg_destroy(ctx);
+        engine = 1;
+    }
     lap("count partitions (finalize)");
     time_t t1 = time(nullptr);
     fprintf(stderr, "Time spent on hashing reads: %ds, %lld read(s) processed.\n", (int)(t1 - t0), n_records);

@@ -532,6 +532,32 @@ extern "C" pg_ctx* pg_create_engine(int device, int K, int mer127, int n_sets, i
     return c;
 }
 
+// The partition count of engine 2 follows the number of k-mer occurrences to come (about 8 k of them, i.e. some 400
+// super-k-mer records, a partition), not the number of distinct k-mers the export array is sized for.  Before the first
+// batch only; a no-op for engine 1.
+extern "C" int pg_expect_kmers(pg_ctx* c, uint64_t total_kmers) {
+    if (!c) { g_err = "null context"; return PG_EINVAL; }
+    if (c->engine != 2) return PG_OK;
+    if (c->batches) { g_err = "pg_expect_kmers: batches were already counted"; return PG_ESTATE; }
+    int lp = 8;
+    while (lp < 23 && ((uint64_t)8192 << lp) < total_kmers) lp++;
+    if (lp == c->e2.log2_parts) return PG_OK;
+    HIP_TRY(hipSetDevice(c->device));
+    const int old = c->hint_log2_parts;
+    e2_destroy(c);
+    c->hint_log2_parts = lp;
+    int rc = e2_create(c);
+    if (rc != PG_OK) {                       // e.g. no room for that many open chunks: keep the previous geometry
+        e2_destroy(c);
+        c->hint_log2_parts = old;
+        const std::string why = g_err;
+        if (e2_create(c) != PG_OK) return PG_ENOMEM;
+        g_err = why;
+    }
+    (void)hipDeviceSynchronize();
+    return PG_OK;
+}
+
 // forget everything counted so far, keep the capacity (bench / repeated runs)
 extern "C" int pg_reset(pg_ctx* c, void* stream) {
     if (!c) { g_err = "null context"; return PG_EINVAL; }
@@ -540,6 +566,7 @@ extern "C" int pg_reset(pg_ctx* c, void* stream) {
     if (c->engine == 2) { int rc = e2_reset(c, st); if (rc) return rc; }
     else HIP_TRY(hipMemsetAsync(c->slots, 0xFF, ((size_t)1 << c->log2_slots) * slot_bytes(c->NW), st));
     HIP_TRY(hipMemsetAsync(c->ctr, 0, sizeof(DevCounters), st));
+    c->batches = 0;
     c->ub_distinct = 0;
     c->finalized = false;
     return PG_OK;
@@ -635,6 +662,7 @@ extern "C" int pg_count_reads(pg_ctx* c, const uint64_t* d_packed, const uint64_
     if (n_kmers == 0) return PG_OK;
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(c->device));
+    c->batches++;
     if (c->engine == 2) return e2_scatter(c, d_packed, d_word_off, d_kmer_base, n_reads, uniform_len, n_kmers, ord_base, st);
     rc = ensure_capacity(c, n_kmers, st);
     if (rc) return rc;

@@ -366,3 +366,22 @@ def test_sort_records_is_replay_order(K, m):
     assert (tags[1:] > tags[:-1]).all()                        # distinct ordinals within a set, sets ascending
     order = np.argsort(a[:, -1], kind="stable")
     assert np.array_equal(a[order], b)
+
+
+def test_cli_falls_back_to_the_global_set_on_a_skewed_partition(golden, tmp_path):
+    """With 16 partitions forced, a partition outgrows its chunk list: the executable must notice, count again with the
+    global-set engine (another HIP path, not the CPU) and still write the reference's files."""
+    from soapdenovo2_amd import synth
+    name = "m100k_k31"
+    c = golden["cases"][name]
+    cfg = synth.make_case(str(tmp_path), name, c["G"], c["N"], c["L"], c["err"], c["seed"])
+    run = c["runs"][0]
+    P, D, a, m = run
+    t = case_tag(name, run)
+    pre = str(tmp_path / t)
+    log = _run_cli(cfg, c["K"], pre, P, D, a, m, extra_env={"PG_LOG2_PARTS": "4"})
+    assert "counting again with the global k-mer set" in log
+    want = golden["md5"][t]
+    for ext in ("kmerFreq", "preGraphBasic", "vertex", "preArc"):
+        assert md5_file(pre + "." + ext) == want[ext], ext
+    assert md5_gz_text(pre + ".edge.gz") == want["edge"]
