@@ -212,6 +212,8 @@ int pg_table_info(pg_ctx *ctx, uint64_t *slots, uint32_t *slot_bytes);
  * sizes its partition count from it -- about 8 k occurrences a partition, so that one partition is counted in one LDS
  * pass -- instead of from log2_slots, which sizes the export array for the DISTINCT k-mers.  Before the first batch. */
 int pg_expect_kmers(pg_ctx *ctx, uint64_t total_kmers);
+/* pg_create_engine with that estimate known up front (no second allocation); expected_kmers = 0: unknown. */
+pg_ctx *pg_create_sized(int device, int K, int mer127, int n_sets, int log2_slots, int engine, uint64_t expected_kmers);
 
 /* Counters for reporting (synchronise first): out[0] engine, out[1] distinct k-mers, out[2] super-k-mer records,
  * out[3] bytes per record (engine 2) / per slot (engine 1), out[4] pool chunks handed out, out[5] pool chunks,

@@ -77,6 +77,8 @@ def lib() -> C.CDLL:
     L.pg_create.argtypes = [C.c_int] * 5
     L.pg_create_engine.restype = C.c_void_p
     L.pg_create_engine.argtypes = [C.c_int] * 6
+    L.pg_create_sized.restype = C.c_void_p
+    L.pg_create_sized.argtypes = [C.c_int] * 6 + [C.c_uint64]
     L.pg_destroy.argtypes = [C.c_void_p]
     L.pg_reset.argtypes = [C.c_void_p, C.c_void_p]
     L.pg_set_autogrow.argtypes = [C.c_void_p, C.c_int]
@@ -101,7 +103,7 @@ def lib() -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "pg_last_error", "pg_version", "call_pregraph", "call_pregraph_127mer", "pg_packed_words", "pg_pack_read",
-    "pg_host_build_graph", "pg_host_graph_begin", "pg_host_graph_add_reads", "pg_host_graph_finish", "pg_host_graph_resolve_repeats", "pg_host_graph_add_packed", "pg_graph_use_device", "pg_sort_records", "pg_expect_kmers", "pg_host_read_all", "pg_host_replay_layout", "pg_host_write_kmerfreq", "pg_create", "pg_create_engine", "pg_destroy", "pg_reset", "pg_set_autogrow", "pg_count_reads", "pg_route_count",
+    "pg_host_build_graph", "pg_host_graph_begin", "pg_host_graph_add_reads", "pg_host_graph_finish", "pg_host_graph_resolve_repeats", "pg_host_graph_add_packed", "pg_graph_use_device", "pg_sort_records", "pg_expect_kmers", "pg_create_sized", "pg_host_read_all", "pg_host_replay_layout", "pg_host_write_kmerfreq", "pg_create", "pg_create_engine", "pg_destroy", "pg_reset", "pg_set_autogrow", "pg_count_reads", "pg_route_count",
     "pg_route_scatter", "pg_count_records", "pg_skm_route", "pg_skm_ingest", "pg_distinct", "pg_stats", "pg_table_info", "pg_finalize", "pg_export",
 ]
 

@@ -315,7 +315,7 @@ int run(int argc, char** argv, bool mer127) {
             est_kmers += (uint64_t)bases;
         }
     if (o.a_gb == 0) {                                               // room for a fifth of them to be distinct; it grows
-        while (log2_slots < 34 && (double)((uint64_t)1 << log2_slots) * 0.7 < (double)est_kmers / 5.0) log2_slots++;
+        while (log2_slots < 34 && (double)((uint64_t)1 << log2_slots) * 0.7 < (double)est_kmers / 8.0) log2_slots++;
     }
     size_t keep_budget = (size_t)sysconf(_SC_PHYS_PAGES) * (size_t)sysconf(_SC_PAGE_SIZE) / 4;
     if (const char* e = getenv("SOAPDENOVO2_AMD_KEEP_READS_GB")) keep_budget = (size_t)(atof(e) * 1073741824.0);
@@ -333,9 +333,8 @@ int run(int argc, char** argv, bool mer127) {
     int engine = 2;
     if (const char* e = getenv("PG_ENGINE")) engine = atoi(e);
     for (int attempt = 0;; attempt++) {
-        ctx = pg_create_engine(device, K, mer127 ? 1 : 0, o.sets, log2_slots, engine);
+        ctx = pg_create_sized(device, K, mer127 ? 1 : 0, o.sets, log2_slots, engine, est_kmers);
         if (!ctx) die("pg_create");
-        if (est_kmers && pg_expect_kmers(ctx, est_kmers) != PG_OK) die("pg_expect_kmers");
         if (attempt == 0) fprintf(stderr, "%d k-mer set(s) on HIP device %d.\n", o.sets, device);
         bool ok = true;
         {

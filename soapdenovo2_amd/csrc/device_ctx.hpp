@@ -56,6 +56,7 @@ struct pg_ctx {
     int variant;                 // engine 1: 0 = word-wise atomic loads, 1 = 32-byte slot snapshot (PG_VARIANT)
     int engine;                  // 1 = global hash set, 2 = super-k-mer partitions counted in LDS (PG_ENGINE)
     int hint_log2_parts = -1;    // engine 2: partition count asked for by pg_expect_kmers (-1 = derive from log2_slots)
+    uint64_t hint_kmers = 0;     // engine 2: k-mer occurrences to come, 0 = unknown (sizes the record pool)
     uint64_t batches = 0;        // batches taken since create / reset
     pg::E2 e2;
 };

@@ -628,6 +628,8 @@ int e2_create(pg_ctx* c) {
     // record pool: every partition keeps one partly filled chunk, plus the records themselves (about one record per
     // 20 k-mers); default = as much as a set of 2^log2_slots 64-byte slots, capped by what is free
     uint64_t pool_bytes = ((uint64_t)1 << c->log2_slots) * 64 + parts * chunk_bytes * 2;
+    if (c->hint_kmers)                       // known input size: 2 / (w + 1) records a k-mer, half as much again, it grows
+        pool_bytes = (uint64_t)((double)c->hint_kmers * 3.0 / (double)(s.g.w + 1)) * rec_bytes + parts * chunk_bytes * 2 + ((uint64_t)64 << 20);
     if (const char* v = getenv("PG_POOL_MB")) pool_bytes = (uint64_t)atoll(v) << 20;
     const uint64_t budget = (uint64_t)(free_b * 0.85);
     if (out_bytes + parts * 8 > budget) { pg_set_error("partition engine: export array does not fit in device memory"); return PG_ENOMEM; }

@@ -500,7 +500,16 @@ extern "C" pg_ctx* pg_create(int device, int K, int mer127, int n_sets, int log2
     return pg_create_engine(device, K, mer127, n_sets, log2_slots, engine);
 }
 
+static int parts_for_kmers(uint64_t total_kmers) {
+    int lp = 8;
+    while (lp < 23 && ((uint64_t)8192 << lp) < total_kmers) lp++;
+    return lp;
+}
+extern "C" pg_ctx* pg_create_sized(int device, int K, int mer127, int n_sets, int log2_slots, int engine, uint64_t expected_kmers);
 extern "C" pg_ctx* pg_create_engine(int device, int K, int mer127, int n_sets, int log2_slots, int engine) {
+    return pg_create_sized(device, K, mer127, n_sets, log2_slots, engine, 0);
+}
+extern "C" pg_ctx* pg_create_sized(int device, int K, int mer127, int n_sets, int log2_slots, int engine, uint64_t expected_kmers) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { g_err = "pg_create: no HIP device available"; return nullptr; }
     if (device < 0 || device >= n) { g_err = "pg_create: bad device ordinal"; return nullptr; }
@@ -515,6 +524,7 @@ extern "C" pg_ctx* pg_create_engine(int device, int K, int mer127, int n_sets, i
     c->ub_distinct = 0; c->finalized = false; c->autogrow = true; c->slots = nullptr; c->ctr = nullptr;
     c->variant = 1;
     c->engine = engine;
+    if (expected_kmers) { c->hint_kmers = expected_kmers; c->hint_log2_parts = parts_for_kmers(expected_kmers); }
     if (const char* v = getenv("PG_VARIANT")) c->variant = atoi(v);
     if (engine == 2) {
         if (hipMalloc(&c->ctr, sizeof(DevCounters)) != hipSuccess) { g_err = "pg_create: hipMalloc failed"; delete c; return nullptr; }
@@ -539,17 +549,19 @@ extern "C" int pg_expect_kmers(pg_ctx* c, uint64_t total_kmers) {
     if (!c) { g_err = "null context"; return PG_EINVAL; }
     if (c->engine != 2) return PG_OK;
     if (c->batches) { g_err = "pg_expect_kmers: batches were already counted"; return PG_ESTATE; }
-    int lp = 8;
-    while (lp < 23 && ((uint64_t)8192 << lp) < total_kmers) lp++;
+    const int lp = parts_for_kmers(total_kmers);
     if (lp == c->e2.log2_parts) return PG_OK;
     HIP_TRY(hipSetDevice(c->device));
     const int old = c->hint_log2_parts;
+    const uint64_t old_kmers = c->hint_kmers;
     e2_destroy(c);
     c->hint_log2_parts = lp;
+    c->hint_kmers = total_kmers;
     int rc = e2_create(c);
     if (rc != PG_OK) {                       // e.g. no room for that many open chunks: keep the previous geometry
         e2_destroy(c);
         c->hint_log2_parts = old;
+        c->hint_kmers = old_kmers;
         const std::string why = g_err;
         if (e2_create(c) != PG_OK) return PG_ENOMEM;
         g_err = why;
