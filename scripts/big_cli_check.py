@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Larger-than-golden check of the executable (run on the GPU box): one synthetic FASTQ through the default partition engine
+and through the global-set engine (PG_ENGINE=1); both must write the same five files.  Prints timings and md5s.
+
+    python scripts/big_cli_check.py --reads 30000000 --read-len 100 --genome 15000000 --kmer 31
+"""
+import argparse, json, os, subprocess, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from soapdenovo2_amd import synth, api
+from scripts.whole_command_config import write_fastq_fast, gpu_codes, md5s
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--out", default="gpurun_out/big")
+    ap.add_argument("--reads", type=int, default=30_000_000)
+    ap.add_argument("--read-len", type=int, default=100)
+    ap.add_argument("--genome", type=int, default=15_000_000)
+    ap.add_argument("--err", type=float, default=0.004)
+    ap.add_argument("--kmer", type=int, default=31)
+    ap.add_argument("--sets", type=int, default=8)
+    a = ap.parse_args()
+    os.makedirs(a.out, exist_ok=True)
+    fq, cfg = os.path.join(a.out, "reads.fq"), os.path.join(a.out, "lib.cfg")
+    write_fastq_fast(fq, gpu_codes(a.genome, a.reads, a.read_len, a.err, 7))
+    synth.write_config(cfg, fq, a.read_len)
+    res = {"workload": vars(a)}
+    for tag, env in (("partitions", {}), ("global_set", {"PG_ENGINE": "1"})):
+        t = time.time()
+        r = subprocess.run([api.binary(False), "pregraph", "-s", cfg, "-K", str(a.kmer), "-o", os.path.join(a.out, tag), "-p", str(a.sets)],
+                           capture_output=True, text=True, env=dict(os.environ, PG_HOST_VERBOSE="1", **env))
+        res[tag] = {"wall_s": time.time() - t, "rc": r.returncode,
+                    "log": [l for l in r.stderr.splitlines() if "[cli]" in l or "node(s) allocated" in l or "edge(s)" in l or "pre-arc" in l or "again" in l]}
+        if r.returncode == 0:
+            res[tag]["md5"] = md5s(os.path.join(a.out, tag))
+        else:
+            res[tag]["stderr_tail"] = r.stderr[-1500:]
+    res["engines_agree"] = res["partitions"].get("md5") is not None and res["partitions"].get("md5") == res["global_set"].get("md5")
+    for f in os.listdir(a.out):
+        if f not in ("result.json",):
+            os.remove(os.path.join(a.out, f))
+    print(json.dumps(res, indent=1))
+    json.dump(res, open(os.path.join(a.out, "result.json"), "w"), indent=1)
+
+
+if __name__ == "__main__":
+    main()
