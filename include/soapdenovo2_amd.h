@@ -119,6 +119,13 @@ int pg_host_build_graph(const uint64_t *records, uint64_t n_records, const uint6
  *                            (multiplicity + first-met order per (from, to)); same files, byte for byte
  *   pg_host_graph_finish     writes <prefix>.preArc, <prefix>.vertex, <prefix>.preGraphBasic and frees the handle */
 typedef struct pg_graph pg_graph;
+/* pg_graph_begin: as pg_host_graph_begin, but with device >= 0 the edges are built on that HIP device (make_edge /
+ * stringBeads / merge_linearV2, node2edge.c:61-649): after the layout replay and the tips the k-mer sets are copied to HBM,
+ * every (vertex, arc) is walked by a lane, the walk that comes first in slot order keeps its chain, ids follow from a sort
+ * and a prefix sum, interior nodes are tagged and length-1 edges entered into KmerSetsPatch on the device; the host only
+ * formats <prefix>.edge.gz.  Pass 2 then runs on the same device (pg_graph_use_device is implied).  device = -1: host. */
+pg_graph *pg_graph_begin(const uint64_t *records, uint64_t n_records, const uint64_t *set_last_put, int K, int mer127,
+                         int n_sets, int cut_single, int a_gb, int max_read_len, int n_threads, const char *prefix, int device);
 pg_graph *pg_host_graph_begin(const uint64_t *records, uint64_t n_records, const uint64_t *set_last_put, int K, int mer127,
                               int n_sets, int cut_single, int a_gb, int max_read_len, int n_threads, const char *prefix);
 int pg_host_graph_resolve_repeats(pg_graph *g, int on);

@@ -63,6 +63,8 @@ def lib() -> C.CDLL:
     L.pg_host_write_kmerfreq.argtypes = [u64p, C.c_char_p]
     L.pg_host_graph_begin.restype = C.c_void_p
     L.pg_host_graph_begin.argtypes = [u64p, C.c_uint64, u64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]
+    L.pg_graph_begin.restype = C.c_void_p
+    L.pg_graph_begin.argtypes = [u64p, C.c_uint64, u64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]
     L.pg_host_graph_add_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int]
     L.pg_host_graph_finish.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]
     L.pg_host_graph_resolve_repeats.argtypes = [C.c_void_p, C.c_int]
@@ -103,7 +105,7 @@ def lib() -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "pg_last_error", "pg_version", "call_pregraph", "call_pregraph_127mer", "pg_packed_words", "pg_pack_read",
-    "pg_host_build_graph", "pg_host_graph_begin", "pg_host_graph_add_reads", "pg_host_graph_finish", "pg_host_graph_resolve_repeats", "pg_host_graph_add_packed", "pg_graph_use_device", "pg_sort_records", "pg_expect_kmers", "pg_create_sized", "pg_host_read_all", "pg_host_replay_layout", "pg_host_write_kmerfreq", "pg_create", "pg_create_engine", "pg_destroy", "pg_reset", "pg_set_autogrow", "pg_count_reads", "pg_route_count",
+    "pg_host_build_graph", "pg_host_graph_begin", "pg_host_graph_add_reads", "pg_host_graph_finish", "pg_host_graph_resolve_repeats", "pg_host_graph_add_packed", "pg_graph_use_device", "pg_sort_records", "pg_expect_kmers", "pg_create_sized", "pg_graph_begin", "pg_host_read_all", "pg_host_replay_layout", "pg_host_write_kmerfreq", "pg_create", "pg_create_engine", "pg_destroy", "pg_reset", "pg_set_autogrow", "pg_count_reads", "pg_route_count",
     "pg_route_scatter", "pg_count_records", "pg_skm_route", "pg_skm_ingest", "pg_distinct", "pg_stats", "pg_table_info", "pg_finalize", "pg_export",
 ]
 
@@ -186,15 +188,19 @@ def host_build_graph(records: np.ndarray, set_last_put, K: int, n_sets: int, pre
 def host_pregraph_files(records: np.ndarray, set_last_put, codes: np.ndarray, lens, K: int, n_sets: int, prefix: str,
                         mer127: bool = False, cut_single: bool = True, a_gb: int = 0, max_read_len: int = 100, n_threads: int = 0,
                         batches: int = 1, resolve_repeats: bool = False, packed: bool = False,
-                        device: int = -1):
+                        device: int = -1, device_edges: bool = False):
     """All host stages incl. pass 2: writes .edge.gz .preArc .vertex .preGraphBasic (and, with resolve_repeats, the
     reference's -R files .path and .markOnEdge); returns (n_vertex, n_edge, n_prearc)."""
     records = np.ascontiguousarray(records, dtype=np.uint64)
     slp = np.ascontiguousarray(set_last_put, dtype=np.uint64)
-    h = lib().pg_host_graph_begin(records.ctypes.data, records.shape[0], slp.ctypes.data, K, int(mer127), n_sets, int(cut_single),
-                                  a_gb, max_read_len, n_threads, prefix.encode())
+    if device_edges:                     # edges (and then pass 2) on HIP device `device`
+        h = lib().pg_graph_begin(records.ctypes.data, records.shape[0], slp.ctypes.data, K, int(mer127), n_sets, int(cut_single),
+                                 a_gb, max_read_len, n_threads, prefix.encode(), device)
+    else:
+        h = lib().pg_host_graph_begin(records.ctypes.data, records.shape[0], slp.ctypes.data, K, int(mer127), n_sets, int(cut_single),
+                                      a_gb, max_read_len, n_threads, prefix.encode())
     if not h:
-        raise PgError("pg_host_graph_begin failed: " + lib().pg_last_error().decode())
+        raise PgError("pg_graph_begin failed: " + lib().pg_last_error().decode())
     if resolve_repeats:
         _check(lib().pg_host_graph_resolve_repeats(h, 1), "pg_host_graph_resolve_repeats")
     if device >= 0:                      # pass 2 on the HIP device instead of the host threads

@@ -398,14 +398,16 @@ int run(int argc, char** argv, bool mer127) {
 
     // ---- tips + edges (removeSingleTips / removeMinorTips / kmer2edges), graph kept for pass 2
     t0 = time(nullptr);
-    pg_graph* graph = pg_host_graph_begin(records.data(), n_distinct, set_last.data(), K, mer127 ? 1 : 0, o.sets, o.delow == 0, o.a_gb,
-                                          max_read_len, 0, o.prefix.c_str());
+    // edges and pass 2 on the device; SOAPDENOVO2_AMD_EDGES=host / SOAPDENOVO2_AMD_PASS2=host keep them on the host threads
+    bool host_edges = false, host_pass2 = false;
+    if (const char* e = getenv("SOAPDENOVO2_AMD_EDGES")) host_edges = strcmp(e, "host") == 0;
+    if (const char* e = getenv("SOAPDENOVO2_AMD_PASS2")) host_pass2 = strcmp(e, "host") == 0;
+    if (host_pass2) host_edges = true;                               // host pass 2 needs the host copy of the sets tagged
+    pg_graph* graph = pg_graph_begin(records.data(), n_distinct, set_last.data(), K, mer127 ? 1 : 0, o.sets, o.delow == 0, o.a_gb,
+                                     max_read_len, 0, o.prefix.c_str(), host_edges ? -1 : device);
     if (!graph) die("pg_host_graph_begin");
     if (o.reps && pg_host_graph_resolve_repeats(graph, 1) != PG_OK) die("pg_host_graph_resolve_repeats");
-    {   // pass 2 runs on the device too; SOAPDENOVO2_AMD_PASS2=host keeps it on the host threads
-        const char* e = getenv("SOAPDENOVO2_AMD_PASS2");
-        if (!(e && strcmp(e, "host") == 0) && pg_graph_use_device(graph, device) != PG_OK) die("pg_graph_use_device");
-    }
+    if (!host_pass2 && pg_graph_use_device(graph, device) != PG_OK) die("pg_graph_use_device");
     { std::vector<uint64_t>().swap(records); }
     fprintf(stderr, "Time spent on removing tips and constructing edges: %ds.\n\n", (int)(time(nullptr) - t0));
     lap("layout + tips + edges");

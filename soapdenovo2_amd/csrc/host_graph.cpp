@@ -1351,13 +1351,86 @@ struct GraphHandle : GraphHandleBase {
 
     ~GraphHandle() override { if (path_fp) fclose(path_fp); if (dev) p2_destroy(dev); }
     int use_device(int device) override {
+        if (dev_edges) {                             // the sets live on the device, tagged there: pass 2 stays there
+            if (device == dev_id) return PG_OK;
+            pg_set_error("the edges were built on another device");
+            return PG_ESTATE;
+        }
         if (dev) { pg_set_error("pass 2 already started"); return PG_ESTATE; }
         dev_on = device >= 0; dev_id = device;
         return PG_OK;
     }
     int max_nk() const { return std::max(1, max_read_len - g.K + 1); }
+    // edges on the device (pass2_kernels.hip: eb_*): upload the sets, build, then format output_1edge's text here
+    int dev_build_edges(int device, int n_threads, int& edge_c, long long& records_c, long long& extra_nodes) {
+        dev_on = true; dev_id = device;
+        P2Sets sets;
+        for (int si = 0; si < g.P; si++) { sets.nodes[si] = g.sets[si].array.data(); sets.size[si] = g.sets[si].size; }
+        dev = p2_open(dev_id, g.K, NW, g.P, sets, max_nk());
+        if (!dev) return PG_ENODEV;
+        P2Edges ed;
+        int rc = p2_build_edges(dev, ed);
+        if (rc) return rc;
+        edge_c = (int)ed.n_ids; records_c = (long long)ed.recs.size(); extra_nodes = ed.n_len1;
+        dev_edges = true;
+        // text records, one gzip member per range of edges, formatted and deflated by all host threads
+        const size_t STEP = 1 << 15, n_chunks = (ed.recs.size() + STEP - 1) / STEP;
+        std::vector<std::vector<uint8_t>> gz(n_chunks);
+        std::atomic<size_t> next{0};
+        std::atomic<int> failed{0};
+        auto body = [&]() {
+            std::string text;
+            for (;;) {
+                const size_t c = next.fetch_add(1);
+                if (c >= n_chunks) break;
+                text.clear();
+                for (size_t i = c * STEP; i < std::min(ed.recs.size(), (c + 1) * STEP); i++) {
+                    const P2EdgeRec& r = ed.recs[i];
+                    const int length = (int)r.length;
+                    int cvg = 0;
+                    if (length > 1) { long long v = (long long)(r.sum / (unsigned long long)(length - 1)) * 10; cvg = v > 16000 ? 16000 : (int)v; }
+                    Kmer<NW> fk, lk;
+                    for (int k = 0; k < NW; k++) { fk.w[k] = r.first_kmer[k]; lk.w[k] = r.last_kmer[k]; }
+                    char head[256];
+                    int n = sprintf(head, ">length %d,", length);
+                    n += fmt_kmer<NW>(head + n, fk, ',');
+                    n += fmt_kmer<NW>(head + n, lk, ',');
+                    n += sprintf(head + n, "cvg %d, %d\n", cvg, (int)r.bal);
+                    text.append(head, n);
+                    const char* b = ed.text.data() + r.text_off;
+                    for (int at = 0; at < length; at += 100) {
+                        text.append(b + at, (size_t)std::min(100, length - at));
+                        text.push_back('\n');
+                    }
+                }
+                if (!text.empty() && !ParallelEdgeBuilder<NW>::gz_member(text, gz[c])) failed.store(1);
+            }
+        };
+        {
+            const int nt = std::max(1, pick_threads(n_threads));
+            std::vector<std::thread> pool;
+            for (int t = 1; t < nt; t++) pool.emplace_back(body);
+            body();
+            for (auto& th : pool) th.join();
+        }
+        if (failed.load()) { pg_set_error("deflate failed"); return PG_EIO; }
+        FILE* fp = fopen((prefix + ".edge.gz").c_str(), "wb");
+        if (!fp) { pg_set_error("cannot open " + prefix + ".edge.gz"); return PG_EIO; }
+        bool any = false;
+        for (auto& m : gz)
+            if (!m.empty()) { any = true; if (fwrite(m.data(), 1, m.size(), fp) != m.size()) { fclose(fp); pg_set_error("short write on " + prefix + ".edge.gz"); return PG_EIO; } }
+        if (!any) { std::vector<uint8_t> e; ParallelEdgeBuilder<NW>::gz_member(std::string(), e); fwrite(e.data(), 1, e.size(), fp); }
+        fclose(fp);
+        return PG_OK;
+    }
+    bool dev_edges = false;
     int dev_begin() {
-        if (dev) return PG_OK;
+        if (dev_ready) return PG_OK;
+        if (dev) {                                   // opened for the edges: the (K+1)-mer table is on the device already
+            int rc = p2_begin_reads(dev, (uint32_t)num_ed, path_fp != nullptr);
+            if (rc == PG_OK) dev_ready = true;
+            return rc;
+        }
         P2Sets sets;
         for (int si = 0; si < g.P; si++) { sets.nodes[si] = g.sets[si].array.data(); sets.size[si] = g.sets[si].size; }
         // KmerSetsPatch as an open-addressing table the device can probe
@@ -1372,8 +1445,10 @@ struct GraphHandle : GraphHandleBase {
             val[2 * h] = kv.second.id; val[2 * h + 1] = kv.second.twin;
         }
         dev = p2_create(dev_id, g.K, NW, g.P, sets, keys.data(), val.data(), cap, (uint32_t)num_ed, max_nk(), path_fp != nullptr);
+        if (dev) dev_ready = true;
         return dev ? PG_OK : PG_ENODEV;
     }
+    bool dev_ready = false;
     // reads already packed: straight to the device, in slices when the walks have to come back (-R)
     int dev_add_packed(const uint64_t* words, const int32_t* lens, uint64_t n) {
         const double t0 = now();
@@ -1630,7 +1705,7 @@ struct GraphHandle : GraphHandleBase {
 
 template <int NW>
 static GraphHandleBase* graph_begin(const uint64_t* records, uint64_t n, const uint64_t* set_last_put, int K, int P, int cut_single,
-                                    int a_gb, int max_read_len, int n_threads, const char* prefix_c) {
+                                    int a_gb, int max_read_len, int n_threads, const char* prefix_c, int device) {
     GraphHandle<NW>* h = new GraphHandle<NW>();
     h->prefix = prefix_c;
     h->max_read_len = max_read_len;
@@ -1645,7 +1720,9 @@ static GraphHandleBase* graph_begin(const uint64_t* records, uint64_t n, const u
     t0 = now();
     int edge_c = 0;
     long long records_c = 0, extra_nodes = 0;
-    if (construct_edges<NW>(h->g, h->prefix, n_threads, edge_c, records_c, extra_nodes) != PG_OK) { delete h; return nullptr; }
+    const int rc_edges = device >= 0 ? h->dev_build_edges(device, n_threads, edge_c, records_c, extra_nodes)
+                                     : construct_edges<NW>(h->g, h->prefix, n_threads, edge_c, records_c, extra_nodes);
+    if (rc_edges != PG_OK) { delete h; return nullptr; }
     fprintf(stderr, "%d (%lld) edge(s) and %lld extra node(s) constructed.\n", edge_c, records_c, extra_nodes);
     fprintf(stderr, "Time spent on constructing edges: %.1fs.\n\n", now() - t0);
     h->num_ed = edge_c;
@@ -1700,8 +1777,18 @@ extern "C" pg_graph* pg_host_graph_begin(const uint64_t* records, uint64_t n_rec
     const int maxK = mer127 ? 127 : 63;
     if (K < 13 || K > maxK || !(K & 1)) { pg_set_error("K must be odd and within 13.." + std::to_string(maxK)); return nullptr; }
     if (n_sets < 1 || n_sets > 255) { pg_set_error("n_sets must be 1..255"); return nullptr; }
-    pg::GraphHandleBase* h = mer127 ? pg::graph_begin<4>(records, n_records, set_last_put, K, n_sets, cut_single, a_gb, max_read_len, n_threads, prefix)
-                                    : pg::graph_begin<2>(records, n_records, set_last_put, K, n_sets, cut_single, a_gb, max_read_len, n_threads, prefix);
+    pg::GraphHandleBase* h = mer127 ? pg::graph_begin<4>(records, n_records, set_last_put, K, n_sets, cut_single, a_gb, max_read_len, n_threads, prefix, -1)
+                                    : pg::graph_begin<2>(records, n_records, set_last_put, K, n_sets, cut_single, a_gb, max_read_len, n_threads, prefix, -1);
+    return (pg_graph*)h;
+}
+extern "C" pg_graph* pg_graph_begin(const uint64_t* records, uint64_t n_records, const uint64_t* set_last_put, int K, int mer127,
+                                    int n_sets, int cut_single, int a_gb, int max_read_len, int n_threads, const char* prefix, int device) {
+    if ((!records && n_records) || !prefix) { pg_set_error("null argument"); return nullptr; }
+    const int maxK = mer127 ? 127 : 63;
+    if (K < 13 || K > maxK || !(K & 1)) { pg_set_error("K must be odd and within 13.." + std::to_string(maxK)); return nullptr; }
+    if (n_sets < 1 || n_sets > 255) { pg_set_error("n_sets must be 1..255"); return nullptr; }
+    pg::GraphHandleBase* h = mer127 ? pg::graph_begin<4>(records, n_records, set_last_put, K, n_sets, cut_single, a_gb, max_read_len, n_threads, prefix, device)
+                                    : pg::graph_begin<2>(records, n_records, set_last_put, K, n_sets, cut_single, a_gb, max_read_len, n_threads, prefix, device);
     return (pg_graph*)h;
 }
 extern "C" int pg_host_graph_resolve_repeats(pg_graph* g, int on) {

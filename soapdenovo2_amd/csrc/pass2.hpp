@@ -2,6 +2,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <string>
 #include <vector>
 
 namespace pg {
@@ -20,6 +21,26 @@ struct P2Result {
     std::vector<unsigned int> marker;                             // per edge id, unsaturated (-R only)
     long long reads_deleted = 0, markers = 0;
 };
+
+// one edge record as the device built it, in the reference's order (the host formats output_1edge's text from it)
+struct P2EdgeRec {
+    uint32_t length, bal;
+    unsigned long long sum;              // sum of the interior nodes' left-arc counters
+    unsigned long long text_off;         // where its `length` bases start in P2Edges::text
+    uint64_t first_kmer[4], last_kmer[4];
+};
+struct P2Edges {
+    std::vector<P2EdgeRec> recs;
+    std::string text;
+    long long n_ids = 0, n_len1 = 0;
+};
+
+// step by step: upload the sets; then either the host's (K+1)-mer table (p2_set_patch) or the edges built on the device
+// (p2_build_edges: tags the device copy of the sets and fills the device (K+1)-mer table itself); then p2_begin_reads
+P2Device* p2_open(int device, int K, int nw, int n_sets, const P2Sets& sets, int max_nk);
+int p2_set_patch(P2Device* d, const uint64_t* patch_keys, const uint32_t* patch_val, uint64_t patch_cap);
+int p2_build_edges(P2Device* d, P2Edges& out);
+int p2_begin_reads(P2Device* d, uint32_t num_ed, bool reps);
 
 // patch table: open addressing over `patch_cap` (a power of two) entries, NW key words + (id, twin) an entry, id 0 =
 // empty, slot = kmer_mix(key) & (cap - 1), linear probing

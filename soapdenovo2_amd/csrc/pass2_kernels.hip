@@ -15,6 +15,7 @@
 //     counts are atomic adds (saturated to 255 when written).
 // All integer work, HBM-latency bound (one random 24/40-byte probe per k-mer); nothing here is shaped for MFMA.
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -92,6 +93,26 @@ __device__ inline uint64_t home_slot(const Kmer<NW>& k, uint64_t size) {
         t = (t << 32 | (k.w[i] & 0xffffffffULL)) % size;
     }
     return t;
+}
+
+// search_kmerset, returning the node's global slot (set base + slot), ~0 when absent
+template <int NW>
+__device__ inline uint64_t find_slot(const P2Params& p, const Kmer<NW>& key, const uint32_t* crc_tab, const uint64_t* set_geo) {
+    const uint32_t set = set_of_crc(kmer_crc32<NW>(key, crc_tab), p.P, p.bias);
+    const uint64_t size = set_geo[2 * set + 1], first = set_geo[2 * set];
+    const uint64_t* base = p.nodes + first * (NW + 1);
+    uint64_t hc = home_slot<NW>(key, size);
+    for (uint64_t step = 0; step < size; step++) {
+        const uint64_t* nd = base + hc * (NW + 1);
+        const uint64_t w0 = nd[0];
+        if (w0 == P2_EMPTY) return ~0ULL;
+        bool eq = w0 == key.w[0];
+#pragma unroll
+        for (int i = 1; i < NW; i++) eq = eq && nd[i] == key.w[i];
+        if (eq) return first + hc;
+        if (++hc == size) hc = 0;
+    }
+    return ~0ULL;
 }
 
 // search_kmerset: the node's two counter words, or false
@@ -238,6 +259,206 @@ __global__ __launch_bounds__(256) void p2_thread_kernel(P2Params p, const uint64
     atomicAdd(&p.counters[4], (unsigned long long)upto);
 }
 
+
+// =====================================================================================================================
+// Edge construction on the device (make_edge / startEdgeFromNode / stringBeads / merge_linearV2, node2edge.c:61-649).
+// A chain of linear nodes between two branch nodes has exactly two entrances; the reference's slot-order scan emits it
+// from the entrance it meets first and unlinks the other.  Walks read nothing an earlier emit changes, hence:
+//   eb_list_branch   every occupied, non-linear, non-deleted slot (the vertices), in any order
+//   eb_walk          a lane per (vertex, arc): walk to the next branch node; keep the walk unless the position of its other
+//                    entrance (global slot, arc order) precedes its own; a walk that is its own twin is a palindrome
+//   sort by (slot, arc) + prefix sums    edge ids and text offsets in the reference's order
+//   eb_apply         a lane per kept walk: walk again, write the bases, tag the interior nodes with the edge id, unlink the
+//                    two end arcs, enter the (K+1)-mer of a length-1 edge into the device copy of KmerSetsPatch
+// The host only formats the text records (output_1edge, output_pregraph.c:88-110).
+// =====================================================================================================================
+struct EdgeRec {                      // one kept walk
+    unsigned long long key;           // (global slot of the start node) << 3 | arc order (right arcs 0..3, left arcs 4..7)
+    unsigned long long far_slot;
+    unsigned long long sum;           // sum of the left-arc counters of the interior nodes (coverage)
+    uint32_t length;                  // bases = nodes on the walk - 1
+    uint32_t flags;                   // next_ch | prev_ch << 2 | first_smaller << 4 | last_smaller << 5 | bal << 6
+    uint64_t first_kmer[4], last_kmer[4];
+};
+
+template <int NW>
+struct WalkState {
+    Kmer<NW> first, cur, prev;        // walk-oriented k-mers: start node, latest node, the one before it
+    uint64_t cur_slot;
+    uint64_t ab;                      // counter words of the latest node
+    bool cur_smaller;
+    uint32_t count;                   // nodes on the walk so far
+    int next_ch;                      // last base of the second node
+};
+
+// the single outgoing base of a linear node in walk orientation (only_out)
+__device__ inline int linear_out(uint64_t ab, bool smaller) {
+    const uint32_t A = (uint32_t)ab, B = (uint32_t)(ab >> 32);
+    int ch;
+    if (smaller) { for (ch = 0; ch < 4; ch++) if ((B >> (6 * ch)) & 63) break; return ch; }
+    for (ch = 0; ch < 4; ch++) if ((A >> (6 * ch)) & 63) break;
+    return ch ^ 2;
+}
+
+// one step: the node of `word`; false = not in the sets
+template <int NW>
+__device__ inline bool walk_step(const P2Params& p, const Kmer<NW>& word, int K, const uint32_t* crc_tab, const uint64_t* set_geo,
+                                 uint64_t& slot, uint64_t& ab, bool& smaller) {
+    const Kmer<NW> bal = kmer_rc<NW>(word, K);
+    smaller = !kmer_less<NW>(bal, word);
+    slot = find_slot<NW>(p, smaller ? word : bal, crc_tab, set_geo);
+    if (slot == ~0ULL) return false;
+    ab = p.nodes[slot * (NW + 1) + NW];
+    return true;
+}
+
+__global__ void eb_list_branch(const uint64_t* nodes, int nw1, uint64_t n_slots, unsigned long long* list, unsigned long long* n_list) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t* nd = nodes + i * nw1;
+        if (nd[0] == P2_EMPTY) continue;
+        const uint32_t B = (uint32_t)(nd[nw1 - 1] >> 32);
+        if (B & (B_LINEAR | B_DELETED)) continue;
+        list[atomicAdd(n_list, 1ULL)] = i;
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(256) void eb_walk(P2Params p, const unsigned long long* list, uint64_t n_list, EdgeRec* out, uint64_t cap,
+                                               unsigned long long* n_out, unsigned long long* n_len1, unsigned long long* errors) {
+    __shared__ uint32_t crc_tab[256];
+    __shared__ uint64_t set_geo[2 * P2_MAX_SETS];
+    crc_tab[threadIdx.x] = crc32_table_entry(threadIdx.x);
+    if (threadIdx.x < p.P) { set_geo[2 * threadIdx.x] = p.set_base[threadIdx.x]; set_geo[2 * threadIdx.x + 1] = p.set_size[threadIdx.x]; }
+    __syncthreads();
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_list * 8) return;
+    const uint64_t slot0 = list[t >> 3];
+    const int order = (int)(t & 7);
+    const uint64_t* nd0 = p.nodes + slot0 * (NW + 1);
+    const uint64_t ab0 = nd0[NW];
+    const int ch = order & 3;
+    const bool right = order < 4;
+    if (!(((right ? (uint32_t)(ab0 >> 32) : (uint32_t)ab0) >> (6 * ch)) & 63)) return;      // no such arc
+    const int K = p.K;
+    const Kmer<NW> filter = kmer_filter<NW>(K);
+    Kmer<NW> seq;
+#pragma unroll
+    for (int i = 0; i < NW; i++) seq.w[i] = nd0[i];
+    const Kmer<NW> first = right ? seq : kmer_rc<NW>(seq, K);
+    const int nextch = right ? ch : (ch ^ 2);
+    // stringBeads
+    Kmer<NW> prev = first, cur = kmer_next<NW>(first, nextch, filter);
+    uint64_t slot, ab;
+    bool smaller;
+    if (!walk_step<NW>(p, cur, K, crc_tab, set_geo, slot, ab, smaller)) { atomicAdd(errors, 1ULL); return; }
+    const int next_ch = kmer_last<NW>(cur);
+    uint32_t count = 2;
+    unsigned long long sum = 0;
+    while ((uint32_t)(ab >> 32) & B_LINEAR) {
+        const uint32_t A = (uint32_t)ab;
+        sum += (A & 63) + ((A >> 6) & 63) + ((A >> 12) & 63) + ((A >> 18) & 63);
+        prev = cur;
+        cur = kmer_next<NW>(cur, linear_out(ab, smaller), filter);
+        if (!walk_step<NW>(p, cur, K, crc_tab, set_geo, slot, ab, smaller)) { atomicAdd(errors, 1ULL); return; }
+        count++;
+    }
+    const int prev_ch = kmer_first<NW>(prev, K);
+    // where the slot-order scan would start this chain from its other end
+    const unsigned long long own = ((unsigned long long)slot0 << 3) | (unsigned)order;
+    const unsigned long long twin = ((unsigned long long)slot << 3) | (unsigned)(smaller ? 4 + prev_ch : (prev_ch ^ 2));
+    if (twin < own) return;
+    EdgeRec r;
+    r.key = own; r.far_slot = slot; r.sum = sum; r.length = count - 1;
+    const uint32_t bal = twin != own;
+    r.flags = (uint32_t)next_ch | ((uint32_t)prev_ch << 2) | ((right ? 1u : 0u) << 4) | ((smaller ? 1u : 0u) << 5) | (bal << 6);
+#pragma unroll
+    for (int i = 0; i < 4; i++) { r.first_kmer[i] = i < NW ? first.w[i] : 0; r.last_kmer[i] = i < NW ? cur.w[i] : 0; }
+    const unsigned long long at = atomicAdd(n_out, 1ULL);
+    if (at < cap) out[at] = r;                                      // the host checks the count against the capacity
+    if (count == 2) atomicAdd(n_len1, 1ULL);
+}
+
+__global__ void eb_keys(const EdgeRec* recs, uint64_t n, unsigned long long* key, uint32_t* idx) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) { key[i] = recs[i].key; idx[i] = (uint32_t)i; }
+}
+// per kept walk in slot order: ids it takes (1 + bal) and bases it writes
+__global__ void eb_sizes(const EdgeRec* recs, const uint32_t* order, uint64_t n, unsigned long long* ids, unsigned long long* bases) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const EdgeRec& r = recs[order[i]];
+        ids[i] = 1 + ((r.flags >> 6) & 1);
+        bases[i] = r.length;
+    }
+}
+
+template <int NW>
+__global__ __launch_bounds__(256) void eb_apply(P2Params p, uint64_t* nodes_rw, const EdgeRec* recs, const uint32_t* order, uint64_t n,
+                                                const unsigned long long* id_before, const unsigned long long* base_before, char* text,
+                                                uint64_t* patch_keys, uint32_t* patch_val, uint64_t patch_mask, unsigned long long* errors) {
+    __shared__ uint32_t crc_tab[256];
+    __shared__ uint64_t set_geo[2 * P2_MAX_SETS];
+    crc_tab[threadIdx.x] = crc32_table_entry(threadIdx.x);
+    if (threadIdx.x < p.P) { set_geo[2 * threadIdx.x] = p.set_base[threadIdx.x]; set_geo[2 * threadIdx.x + 1] = p.set_size[threadIdx.x]; }
+    __syncthreads();
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const EdgeRec r = recs[order[i]];
+    const int K = p.K;
+    const Kmer<NW> filter = kmer_filter<NW>(K);
+    const uint32_t id = (uint32_t)id_before[i] + 1;
+    const uint32_t bal = (r.flags >> 6) & 1;
+    const int next_ch = r.flags & 3, prev_ch = (r.flags >> 2) & 3;
+    const bool first_smaller = (r.flags >> 4) & 1, last_smaller = (r.flags >> 5) & 1;
+    char* seq = text + base_before[i];
+    Kmer<NW> first;
+#pragma unroll
+    for (int k = 0; k < NW; k++) first.w[k] = r.first_kmer[k];
+    const uint64_t slot0 = r.key >> 3;
+    // walk again: bases out, interior nodes tagged (edge id replaces word A, twin / inEdge in word B)
+    Kmer<NW> cur = kmer_next<NW>(first, next_ch, filter);
+    uint64_t slot, ab;
+    bool smaller;
+    for (uint32_t b = 0; b < r.length; b++) {
+        if (!walk_step<NW>(p, cur, K, crc_tab, set_geo, slot, ab, smaller)) { atomicAdd(errors, 1ULL); return; }
+        seq[b] = "ACTG"[kmer_last<NW>(cur)];
+        if (b + 1 == r.length) break;                               // the far branch node
+        const uint32_t A = smaller ? id : id + bal;
+        const uint32_t twin = smaller ? bal + 1 : 1 - bal;
+        const uint32_t B = ((uint32_t)(ab >> 32) & 0x0FFFFFFFu) | (twin << B_TWIN_SHIFT) | (1u << B_INEDGE_SHIFT);
+        const int out = linear_out(ab, smaller);
+        nodes_rw[slot * (NW + 1) + NW] = (uint64_t)A | ((uint64_t)B << 32);
+        cur = kmer_next<NW>(cur, out, filter);
+    }
+    if (slot != r.far_slot) { atomicAdd(errors, 1ULL); return; }
+    // dislink2prevUncertain on the far node, dislink2nextUncertain on the start node (64-bit word: A low, B high)
+    {
+        const int bit = last_smaller ? 6 * prev_ch : 32 + 6 * (prev_ch ^ 2);
+        atomicAnd((unsigned long long*)&nodes_rw[r.far_slot * (NW + 1) + NW], ~(63ULL << bit));
+        const int bit0 = first_smaller ? 32 + 6 * next_ch : 6 * (next_ch ^ 2);
+        atomicAnd((unsigned long long*)&nodes_rw[slot0 * (NW + 1) + NW], ~(63ULL << bit0));
+    }
+    if (r.length == 1) {                                            // KmerSetsPatch (node2edge.c:481-542)
+        Kmer<NW> last;
+#pragma unroll
+        for (int k = 0; k < NW; k++) last.w[k] = r.last_kmer[k];
+        const Kmer<NW> plus = kmer_plus<NW>(first, kmer_last<NW>(last));
+        const Kmer<NW> bal_plus = rc_plus<NW>(plus, K);
+        const bool sm = kmer_less<NW>(plus, bal_plus);
+        const Kmer<NW> key = sm ? plus : bal_plus;
+        const uint32_t pid = sm ? id : id + bal, ptwin = sm ? bal + 1 : 1 - bal;
+        uint64_t h = kmer_mix<NW>(key) & patch_mask;
+        for (;;) {
+            const unsigned int old = atomicCAS(&patch_val[2 * h], 0u, pid);
+            if (old == 0) {
+#pragma unroll
+                for (int k = 0; k < NW; k++) patch_keys[h * NW + k] = key.w[k];
+                patch_val[2 * h + 1] = ptwin;
+                break;
+            }
+            h = (h + 1) & patch_mask;
+        }
+    }
+}
+
 // the occupied slots of the pre-arc table, densely (order does not matter: the host sorts)
 __global__ void p2_compact_arcs(const unsigned long long* key, const unsigned int* cnt, const unsigned long long* first, uint64_t cap,
                                 P2Arc* out, unsigned long long* n_out) {
@@ -273,6 +494,8 @@ struct P2Device {
     uint64_t* d_off = nullptr; int32_t* d_lens = nullptr; size_t cap_reads = 0;
     uint32_t* d_stage = nullptr; uint16_t* d_walk_len = nullptr; size_t cap_stage_reads = 0;
     uint64_t ordinal = 0;
+    uint64_t n_slots = 0;
+    bool reads_ready = false;
     hipStream_t stream = nullptr;
 };
 
@@ -287,7 +510,7 @@ static void p2_free(P2Device* d) {
     delete d;
 }
 
-static int p2_create_impl(P2Device* d, const P2Sets& sets, const uint64_t* patch_keys, const uint32_t* patch_val, uint64_t patch_cap) {
+static int p2_open_impl(P2Device* d, const P2Sets& sets) {
     P2_HIP(hipSetDevice(d->device));
     P2_HIP(hipStreamCreate(&d->stream));
     memset(&d->prm, 0, sizeof(d->prm));
@@ -295,16 +518,52 @@ static int p2_create_impl(P2Device* d, const P2Sets& sets, const uint64_t* patch
     uint64_t total = 0;
     std::vector<uint64_t> geo(2 * (size_t)d->P);
     for (int s = 0; s < d->P; s++) { geo[s] = total; geo[d->P + s] = sets.size[s]; total += sets.size[s]; }
+    d->n_slots = total;
     P2_HIP(hipMalloc((void**)&d->d_geo, geo.size() * sizeof(uint64_t)));
     P2_HIP(hipMemcpy(d->d_geo, geo.data(), geo.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
     P2_HIP(hipMalloc((void**)&d->d_nodes, std::max<uint64_t>(total, 1) * NW1 * sizeof(uint64_t)));
     for (int s = 0; s < d->P; s++)
         if (sets.size[s])
             P2_HIP(hipMemcpyAsync(d->d_nodes + geo[s] * NW1, sets.nodes[s], sets.size[s] * NW1 * sizeof(uint64_t), hipMemcpyHostToDevice, d->stream));
+    P2_HIP(hipMalloc((void**)&d->d_counters, 8 * sizeof(unsigned long long)));
+    P2_HIP(hipMemsetAsync(d->d_counters, 0, 8 * sizeof(unsigned long long), d->stream));
+    P2_HIP(hipStreamSynchronize(d->stream));
+    P2Params& p = d->prm;
+    p.nodes = d->d_nodes;
+    p.set_base = d->d_geo; p.set_size = d->d_geo + d->P;
+    p.P = (uint32_t)d->P; p.bias = set_bias((uint32_t)d->P); p.K = d->K;
+    p.max_nk = d->max_nk;
+    p.counters = d->d_counters;
+    return PG_OK;
+}
+
+P2Device* p2_open(int device, int K, int nw, int n_sets, const P2Sets& sets, int max_nk) {
+    if (n_sets < 1 || n_sets > P2_MAX_SETS || (nw != 2 && nw != 4)) { pg_set_error("pass 2: bad arguments"); return nullptr; }
+    P2Device* d = new P2Device();
+    d->device = device; d->K = K; d->nw = nw; d->P = n_sets; d->max_nk = std::max(max_nk, 1);
+    if (p2_open_impl(d, sets) != PG_OK) { p2_free(d); return nullptr; }
+    return d;
+}
+
+// KmerSetsPatch as the host built it
+int p2_set_patch(P2Device* d, const uint64_t* patch_keys, const uint32_t* patch_val, uint64_t patch_cap) {
+    if ((patch_cap & (patch_cap - 1)) || !patch_cap) { pg_set_error("pass 2: patch table size must be a power of two"); return PG_EINVAL; }
+    P2_HIP(hipSetDevice(d->device));
+    hipFree(d->d_patch_keys); hipFree(d->d_patch_val);
+    d->d_patch_keys = nullptr; d->d_patch_val = nullptr;
     P2_HIP(hipMalloc((void**)&d->d_patch_keys, patch_cap * d->nw * sizeof(uint64_t)));
     P2_HIP(hipMalloc((void**)&d->d_patch_val, patch_cap * 2 * sizeof(uint32_t)));
-    P2_HIP(hipMemcpyAsync(d->d_patch_keys, patch_keys, patch_cap * d->nw * sizeof(uint64_t), hipMemcpyHostToDevice, d->stream));
-    P2_HIP(hipMemcpyAsync(d->d_patch_val, patch_val, patch_cap * 2 * sizeof(uint32_t), hipMemcpyHostToDevice, d->stream));
+    P2_HIP(hipMemcpy(d->d_patch_keys, patch_keys, patch_cap * d->nw * sizeof(uint64_t), hipMemcpyHostToDevice));
+    P2_HIP(hipMemcpy(d->d_patch_val, patch_val, patch_cap * 2 * sizeof(uint32_t), hipMemcpyHostToDevice));
+    d->prm.patch_keys = d->d_patch_keys; d->prm.patch_val = d->d_patch_val; d->prm.patch_mask = patch_cap - 1;
+    return PG_OK;
+}
+
+// the pre-arc table and, with -R, the marker counts
+int p2_begin_reads(P2Device* d, uint32_t num_ed, bool reps) {
+    P2_HIP(hipSetDevice(d->device));
+    if (!d->d_patch_val) { pg_set_error("pass 2: no (K+1)-mer table yet"); return PG_ESTATE; }
+    d->num_ed = num_ed; d->reps = reps;
     // every edge has a handful of successors: eight slots an edge id keep the load low; the kernel counts overflows
     uint64_t arc_cap = 1 << 16;
     while (arc_cap < (uint64_t)d->num_ed * 8) arc_cap <<= 1;
@@ -314,7 +573,6 @@ static int p2_create_impl(P2Device* d, const P2Sets& sets, const uint64_t* patch
     P2_HIP(hipMemsetAsync(d->d_arc_key, 0, arc_cap * sizeof(unsigned long long), d->stream));
     P2_HIP(hipMemsetAsync(d->d_arc_cnt, 0, arc_cap * sizeof(unsigned int), d->stream));
     hipLaunchKernelGGL(p2_fill_u64, dim3(1024), dim3(256), 0, d->stream, d->d_arc_first, arc_cap, ~0ULL);
-    P2_HIP(hipMalloc((void**)&d->d_counters, 8 * sizeof(unsigned long long)));
     P2_HIP(hipMemsetAsync(d->d_counters, 0, 8 * sizeof(unsigned long long), d->stream));
     if (d->reps) {
         P2_HIP(hipMalloc((void**)&d->d_marker, ((size_t)d->num_ed + 1) * sizeof(unsigned int)));
@@ -322,32 +580,144 @@ static int p2_create_impl(P2Device* d, const P2Sets& sets, const uint64_t* patch
     }
     P2_HIP(hipStreamSynchronize(d->stream));
     P2Params& p = d->prm;
-    p.nodes = d->d_nodes;
-    p.set_base = d->d_geo; p.set_size = d->d_geo + d->P;
-    p.P = (uint32_t)d->P; p.bias = set_bias((uint32_t)d->P); p.K = d->K;
-    p.patch_keys = d->d_patch_keys; p.patch_val = d->d_patch_val; p.patch_mask = patch_cap - 1;
     p.arc_key = d->d_arc_key; p.arc_cnt = d->d_arc_cnt; p.arc_first = d->d_arc_first; p.arc_mask = arc_cap - 1;
-    p.marker = d->d_marker; p.max_nk = d->max_nk; p.id_end = d->num_ed + 1;
-    p.counters = d->d_counters;
+    p.marker = d->d_marker; p.id_end = d->num_ed + 1;
+    d->reads_ready = true;
     return PG_OK;
 }
 
 P2Device* p2_create(int device, int K, int nw, int n_sets, const P2Sets& sets, const uint64_t* patch_keys, const uint32_t* patch_val,
                     uint64_t patch_cap, uint32_t num_ed, int max_nk, bool reps) {
-    if (n_sets < 1 || n_sets > P2_MAX_SETS || (nw != 2 && nw != 4) || (patch_cap & (patch_cap - 1)) || !patch_cap) {
-        pg_set_error("pass 2: bad arguments");
-        return nullptr;
-    }
-    P2Device* d = new P2Device();
-    d->device = device; d->K = K; d->nw = nw; d->P = n_sets; d->num_ed = num_ed; d->max_nk = std::max(max_nk, 1); d->reps = reps;
-    if (p2_create_impl(d, sets, patch_keys, patch_val, patch_cap) != PG_OK) { p2_free(d); return nullptr; }
+    P2Device* d = p2_open(device, K, nw, n_sets, sets, max_nk);
+    if (!d) return nullptr;
+    if (p2_set_patch(d, patch_keys, patch_val, patch_cap) != PG_OK || p2_begin_reads(d, num_ed, reps) != PG_OK) { p2_free(d); return nullptr; }
     return d;
+}
+
+// ---- edges ------------------------------------------------------------------------------------------------------------
+#define P2_HIP_GOTO(call)                                                                                    \
+    do {                                                                                                     \
+        hipError_t e_ = (call);                                                                              \
+        if (e_ != hipSuccess) { pg_set_error(std::string("edges: ") + #call + ": " + hipGetErrorString(e_)); rc = PG_ENODEV; goto done; } \
+    } while (0)
+
+int p2_build_edges(P2Device* d, P2Edges& out) {
+    int rc = PG_OK;
+    const int NW1 = d->nw + 1;
+    hipStream_t st = d->stream;
+    unsigned long long *d_list = nullptr, *d_cnt = nullptr, *d_key = nullptr, *d_key2 = nullptr, *d_ids = nullptr, *d_bases = nullptr,
+                       *d_id_before = nullptr, *d_base_before = nullptr;
+    uint32_t *d_idx = nullptr, *d_order = nullptr;
+    EdgeRec* d_recs = nullptr;
+    char* d_text = nullptr;
+    void* d_tmp = nullptr;
+    size_t tmp_bytes = 0, tmp2 = 0;
+    unsigned long long cnt[4] = {0, 0, 0, 0};        // vertices, kept walks, length-1 walks, errors
+    uint64_t n_list = 0, n_rec = 0, cap_rec = 0, patch_cap = 1024;
+    unsigned long long total_ids = 0, total_bases = 0, last_ids = 0, last_bases = 0, last_idb = 0, last_bb = 0;
+    if (hipSetDevice(d->device) != hipSuccess) { pg_set_error("edges: hipSetDevice failed"); return PG_ENODEV; }
+    P2_HIP_GOTO(hipMalloc((void**)&d_cnt, 4 * sizeof(unsigned long long)));
+    P2_HIP_GOTO(hipMemsetAsync(d_cnt, 0, 4 * sizeof(unsigned long long), st));
+    P2_HIP_GOTO(hipMalloc((void**)&d_list, std::max<uint64_t>(d->n_slots, 1) * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(eb_list_branch, dim3(4096), dim3(256), 0, st, d->d_nodes, NW1, d->n_slots, d_list, d_cnt);
+    P2_HIP_GOTO(hipMemcpyAsync(cnt, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+    P2_HIP_GOTO(hipStreamSynchronize(st));
+    n_list = cnt[0];
+    // a vertex has at most eight arcs and every chain is kept from one of its two ends (palindromes aside, which are few)
+    cap_rec = n_list * 5 + 1024;
+    P2_HIP_GOTO(hipMalloc((void**)&d_recs, cap_rec * sizeof(EdgeRec)));
+    if (n_list) {
+        const dim3 grid((unsigned)((n_list * 8 + 255) / 256));
+        if (n_list * 8 / 256 >= 0x7FFFFFFFULL) { pg_set_error("edges: too many vertices for one launch"); rc = PG_EINVAL; goto done; }
+        if (d->nw == 2) hipLaunchKernelGGL(eb_walk<2>, grid, dim3(256), 0, st, d->prm, d_list, n_list, d_recs, cap_rec, d_cnt + 1, d_cnt + 2, d_cnt + 3);
+        else hipLaunchKernelGGL(eb_walk<4>, grid, dim3(256), 0, st, d->prm, d_list, n_list, d_recs, cap_rec, d_cnt + 1, d_cnt + 2, d_cnt + 3);
+        P2_HIP_GOTO(hipGetLastError());
+    }
+    P2_HIP_GOTO(hipMemcpyAsync(cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, st));
+    P2_HIP_GOTO(hipStreamSynchronize(st));
+    if (cnt[3]) { pg_set_error("Kmer is not found while building an edge."); rc = PG_EINVAL; goto done; }
+    n_rec = cnt[1];
+    if (n_rec > cap_rec) { pg_set_error("edges: more walks than expected (SOAPDENOVO2_AMD_EDGES=host builds them on the host)"); rc = PG_ENOMEM; goto done; }
+    if (n_rec >= 0x7FFFFFFFULL) { pg_set_error("edges: more than 2^31 - 1 edge records"); rc = PG_EINVAL; goto done; }
+    while (patch_cap < 2 * cnt[2] + 2) patch_cap <<= 1;
+    hipFree(d->d_patch_keys); hipFree(d->d_patch_val);
+    d->d_patch_keys = nullptr; d->d_patch_val = nullptr;
+    P2_HIP_GOTO(hipMalloc((void**)&d->d_patch_keys, patch_cap * d->nw * sizeof(uint64_t)));
+    P2_HIP_GOTO(hipMalloc((void**)&d->d_patch_val, patch_cap * 2 * sizeof(uint32_t)));
+    P2_HIP_GOTO(hipMemsetAsync(d->d_patch_keys, 0, patch_cap * d->nw * sizeof(uint64_t), st));
+    P2_HIP_GOTO(hipMemsetAsync(d->d_patch_val, 0, patch_cap * 2 * sizeof(uint32_t), st));
+    d->prm.patch_keys = d->d_patch_keys; d->prm.patch_val = d->d_patch_val; d->prm.patch_mask = patch_cap - 1;
+    out.recs.clear(); out.text.clear();
+    out.n_ids = 0; out.n_len1 = (long long)cnt[2];
+    if (n_rec) {
+        P2_HIP_GOTO(hipMalloc((void**)&d_key, n_rec * sizeof(unsigned long long)));
+        P2_HIP_GOTO(hipMalloc((void**)&d_key2, n_rec * sizeof(unsigned long long)));
+        P2_HIP_GOTO(hipMalloc((void**)&d_idx, n_rec * sizeof(uint32_t)));
+        P2_HIP_GOTO(hipMalloc((void**)&d_order, n_rec * sizeof(uint32_t)));
+        P2_HIP_GOTO(hipMalloc((void**)&d_ids, n_rec * sizeof(unsigned long long)));
+        P2_HIP_GOTO(hipMalloc((void**)&d_bases, n_rec * sizeof(unsigned long long)));
+        P2_HIP_GOTO(hipMalloc((void**)&d_id_before, n_rec * sizeof(unsigned long long)));
+        P2_HIP_GOTO(hipMalloc((void**)&d_base_before, n_rec * sizeof(unsigned long long)));
+        hipLaunchKernelGGL(eb_keys, dim3(2048), dim3(256), 0, st, d_recs, n_rec, d_key, d_idx);
+        P2_HIP_GOTO(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_key, d_key2, d_idx, d_order, (int)n_rec, 0, 64, st));
+        P2_HIP_GOTO(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, d_ids, d_id_before, (int)n_rec, st));
+        tmp_bytes = std::max(tmp_bytes, tmp2);
+        P2_HIP_GOTO(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
+        P2_HIP_GOTO(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_key, d_key2, d_idx, d_order, (int)n_rec, 0, 64, st));
+        hipLaunchKernelGGL(eb_sizes, dim3(2048), dim3(256), 0, st, d_recs, d_order, n_rec, d_ids, d_bases);
+        P2_HIP_GOTO(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_ids, d_id_before, (int)n_rec, st));
+        P2_HIP_GOTO(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_bases, d_base_before, (int)n_rec, st));
+        P2_HIP_GOTO(hipMemcpyAsync(&last_ids, d_ids + n_rec - 1, sizeof(last_ids), hipMemcpyDeviceToHost, st));
+        P2_HIP_GOTO(hipMemcpyAsync(&last_bases, d_bases + n_rec - 1, sizeof(last_bases), hipMemcpyDeviceToHost, st));
+        P2_HIP_GOTO(hipMemcpyAsync(&last_idb, d_id_before + n_rec - 1, sizeof(last_idb), hipMemcpyDeviceToHost, st));
+        P2_HIP_GOTO(hipMemcpyAsync(&last_bb, d_base_before + n_rec - 1, sizeof(last_bb), hipMemcpyDeviceToHost, st));
+        P2_HIP_GOTO(hipStreamSynchronize(st));
+        total_ids = last_idb + last_ids;
+        total_bases = last_bb + last_bases;
+        if (total_ids >= 0xFFFFFFFFULL) { pg_set_error("edges: edge ids exceed 32 bits"); rc = PG_EINVAL; goto done; }
+        P2_HIP_GOTO(hipMalloc((void**)&d_text, std::max<unsigned long long>(total_bases, 1)));
+        {
+            const dim3 grid((unsigned)((n_rec + 255) / 256));
+            if (d->nw == 2) hipLaunchKernelGGL(eb_apply<2>, grid, dim3(256), 0, st, d->prm, d->d_nodes, d_recs, d_order, n_rec, d_id_before, d_base_before, d_text,
+                                               d->d_patch_keys, d->d_patch_val, patch_cap - 1, d_cnt + 3);
+            else hipLaunchKernelGGL(eb_apply<4>, grid, dim3(256), 0, st, d->prm, d->d_nodes, d_recs, d_order, n_rec, d_id_before, d_base_before, d_text,
+                                    d->d_patch_keys, d->d_patch_val, patch_cap - 1, d_cnt + 3);
+            P2_HIP_GOTO(hipGetLastError());
+        }
+        // what the host needs for the text records: the walks in slot order, their text offsets, the bases
+        {
+            std::vector<EdgeRec> recs(n_rec);
+            std::vector<uint32_t> order(n_rec);
+            std::vector<unsigned long long> bb(n_rec);
+            out.text.resize(total_bases);
+            P2_HIP_GOTO(hipMemcpyAsync(recs.data(), d_recs, n_rec * sizeof(EdgeRec), hipMemcpyDeviceToHost, st));
+            P2_HIP_GOTO(hipMemcpyAsync(order.data(), d_order, n_rec * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+            P2_HIP_GOTO(hipMemcpyAsync(bb.data(), d_base_before, n_rec * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            if (total_bases) P2_HIP_GOTO(hipMemcpyAsync(&out.text[0], d_text, total_bases, hipMemcpyDeviceToHost, st));
+            P2_HIP_GOTO(hipMemcpyAsync(cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, st));
+            P2_HIP_GOTO(hipStreamSynchronize(st));
+            if (cnt[3]) { pg_set_error("edges: a walk did not repeat itself"); rc = PG_EINVAL; goto done; }
+            out.recs.resize(n_rec);
+            for (uint64_t i = 0; i < n_rec; i++) {
+                const EdgeRec& r = recs[order[i]];
+                P2EdgeRec& o = out.recs[i];
+                o.length = r.length; o.bal = (r.flags >> 6) & 1; o.sum = r.sum; o.text_off = bb[i];
+                for (int k = 0; k < 4; k++) { o.first_kmer[k] = r.first_kmer[k]; o.last_kmer[k] = r.last_kmer[k]; }
+            }
+        }
+    }
+    out.n_ids = (long long)total_ids;
+done:
+    hipFree(d_list); hipFree(d_cnt); hipFree(d_key); hipFree(d_key2); hipFree(d_ids); hipFree(d_bases); hipFree(d_id_before); hipFree(d_base_before);
+    hipFree(d_idx); hipFree(d_order); hipFree(d_recs); hipFree(d_text); hipFree(d_tmp);
+    return rc;
 }
 
 void p2_destroy(P2Device* d) { p2_free(d); }
 
 int p2_add_packed(P2Device* d, const uint64_t* words, const uint64_t* word_off, const int32_t* lens, uint64_t n_reads, uint64_t n_words,
                   uint32_t* walks_out, uint16_t* walk_len_out) {
+    if (!d->reads_ready) { pg_set_error("pass 2: p2_begin_reads was not called"); return PG_ESTATE; }
     if (!n_reads) return PG_OK;
     P2_HIP(hipSetDevice(d->device));
     if (n_words + 8 > d->cap_words) {

@@ -315,10 +315,14 @@ def test_device_pass2_matches_reference(golden, tmp_path, name):
         want = golden["md5"][t]
         for reps in (False, True):
             pre = str(tmp_path / (t + ("_R" if reps else "")))
+            # without -R: host edges + device pass 2; with -R: the edges come from the device too (pg_graph_begin)
             nv, ne, na = api.host_pregraph_files(rec, last, codes, None, K, P, pre, mer127=bool(m), cut_single=(D == 0), a_gb=a,
-                                                 max_read_len=c["L"], batches=3, resolve_repeats=reps, device=0, packed=reps)
+                                                 max_read_len=c["L"], batches=3, resolve_repeats=reps, device=0, packed=reps,
+                                                 device_edges=reps)
             assert md5_file(pre + ".preArc") == want["preArc"], (t, reps)
             assert md5_file(pre + ".vertex") == want["vertex"], (t, reps)
+            assert md5_file(pre + ".preGraphBasic") == want["preGraphBasic"], (t, reps)
+            assert md5_gz_text(pre + ".edge.gz") == want["edge"], (t, reps)
             if reps:
                 assert md5_file(pre + ".path") == want["path"], t
                 assert md5_file(pre + ".markOnEdge") == want["markOnEdge"], t
@@ -344,8 +348,10 @@ def test_device_pass2_on_reader_corner_cases(golden, tmp_path):
         o.close()
         for packed in (False, True):
             pre = str(tmp_path / (name + ("_pk" if packed else "")))
-            api.host_pregraph_files(rec, last, codes, lens, K, P, pre, max_read_len=mrl, device=0, packed=packed, batches=2)
+            api.host_pregraph_files(rec, last, codes, lens, K, P, pre, max_read_len=mrl, device=0, packed=packed, batches=2,
+                                    device_edges=packed)
             assert md5_file(pre + ".preArc") == golden["md5"][name]["preArc"], (name, packed)
+            assert md5_gz_text(pre + ".edge.gz") == golden["md5"][name]["edge"], (name, packed)
 
 
 @pytest.mark.parametrize("K,m", [(31, 0), (127, 1)])
