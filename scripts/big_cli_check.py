@@ -20,23 +20,31 @@ def main():
     ap.add_argument("--err", type=float, default=0.004)
     ap.add_argument("--kmer", type=int, default=31)
     ap.add_argument("--sets", type=int, default=8)
+    ap.add_argument("--expect", default="", help="result.json of an earlier run with the same arguments: only the default engine runs and its md5s are compared")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
     fq, cfg = os.path.join(a.out, "reads.fq"), os.path.join(a.out, "lib.cfg")
     write_fastq_fast(fq, gpu_codes(a.genome, a.reads, a.read_len, a.err, 7))
     synth.write_config(cfg, fq, a.read_len)
     res = {"workload": vars(a)}
-    for tag, env in (("partitions", {}), ("global_set", {"PG_ENGINE": "1"})):
+    runs = (("partitions", {}), ("global_set", {"PG_ENGINE": "1"}))
+    if a.expect:
+        runs = runs[:1]
+    for tag, env in runs:
         t = time.time()
         r = subprocess.run([api.binary(False), "pregraph", "-s", cfg, "-K", str(a.kmer), "-o", os.path.join(a.out, tag), "-p", str(a.sets)],
                            capture_output=True, text=True, env=dict(os.environ, PG_HOST_VERBOSE="1", **env))
         res[tag] = {"wall_s": time.time() - t, "rc": r.returncode,
-                    "log": [l for l in r.stderr.splitlines() if "[cli]" in l or "node(s) allocated" in l or "edge(s)" in l or "pre-arc" in l or "again" in l]}
+                    "log": [l for l in r.stderr.splitlines() if "[cli]" in l or "Time spent on" in l or "node(s) allocated" in l or "edge(s)" in l or "pre-arc" in l or "again" in l]}
         if r.returncode == 0:
             res[tag]["md5"] = md5s(os.path.join(a.out, tag))
         else:
             res[tag]["stderr_tail"] = r.stderr[-1500:]
-    res["engines_agree"] = res["partitions"].get("md5") is not None and res["partitions"].get("md5") == res["global_set"].get("md5")
+    if a.expect:
+        want = json.load(open(a.expect))["partitions"]["md5"]
+        res["same_as_expected"] = res["partitions"].get("md5") == want
+    else:
+        res["engines_agree"] = res["partitions"].get("md5") is not None and res["partitions"].get("md5") == res["global_set"].get("md5")
     for f in os.listdir(a.out):
         if f not in ("result.json",):
             os.remove(os.path.join(a.out, f))

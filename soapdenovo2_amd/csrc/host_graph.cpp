@@ -247,30 +247,49 @@ struct HSet {
         const uint64_t old = size;
         if (n > array.n) array.reset(n, old);
         for (uint64_t i = old; i < n; i++) array[i].seq.w[0] = EMPTY;
-        std::vector<uint8_t> placed(n, 0);
-        std::vector<uint8_t>& pending = occ;          // 1 = old element not moved yet
+        // one state byte a slot: 0 free, 1 old element not moved yet, 2 placed.  The old slots are visited in index
+        // order (that order is what the reference's layout depends on), but the home slot of the element AHEAD slots
+        // further on is computed and prefetched now, so the cache misses of consecutive re-homings overlap.
+        enum : uint8_t { FREE = 0, PENDING = 1, PLACED = 2 };
+        std::vector<uint8_t> st(n, FREE);
+        for (uint64_t i = 0; i < old; i++) st[i] = occ[i] ? PENDING : FREE;
         size = n;
         max = (uint64_t)((float)n * lf);
+        constexpr uint64_t AHEAD = 24;
+        uint64_t ring[AHEAD];
+        auto look = [&](uint64_t j) {
+            if (j < old && st[j] == PENDING) {
+                const uint64_t h = home(array[j].seq);
+                ring[j % AHEAD] = h;
+                __builtin_prefetch(&st[h], 1);
+                __builtin_prefetch(&array[h], 1);
+            }
+        };
+        for (uint64_t j = 0; j < std::min<uint64_t>(AHEAD, old); j++) look(j);
         for (uint64_t i = 0; i < old; i++) {
-            if (!pending[i]) continue;
+            const bool mine = st[i] == PENDING;
+            uint64_t hc = mine ? ring[i % AHEAD] : 0;
+            look(i + AHEAD);                                      // reuses ring slot i % AHEAD, read just above
+            if (!mine) continue;
             HNode<NW> cur = array[i];
-            pending[i] = 0;
+            st[i] = FREE;
             for (;;) {
-                uint64_t hc = home(cur.seq);
-                while (placed[hc]) { if (++hc == size) hc = 0; }
-                placed[hc] = 1;
-                if (hc < old && pending[hc]) {
+                while (st[hc] == PLACED) { if (++hc == size) hc = 0; }
+                const bool kick = st[hc] == PENDING;              // an old element still sits there: it goes next
+                st[hc] = PLACED;
+                if (kick) {
                     std::swap(cur, array[hc]);
-                    pending[hc] = 0;
+                    hc = home(cur.seq);
                 } else {
                     array[hc] = cur;
                     break;
                 }
             }
         }
+        occ.assign(n, 0);
+        for (uint64_t i = 0; i < n; i++) occ[i] = st[i] == PLACED;
         for (uint64_t i = 0; i < old; i++)
-            if (!placed[i]) array[i].seq.w[0] = EMPTY;             // vacated and not reused
-        occ.swap(placed);
+            if (!occ[i]) array[i].seq.w[0] = EMPTY;               // vacated and not reused
     }
     // the growth test of put_kmerset (newhash.c:477) for a static (-a) pool only raises the load factor
     void before_put(bool static_pool) {
