@@ -9,6 +9,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <time.h>
 #include <unistd.h>
@@ -381,16 +382,33 @@ int run(int argc, char** argv, bool mer127) {
 
     // ---- export the distinct k-mers and hand over to the host stages
     const int rw = (mer127 ? 4 : 2) + 2;
-    std::vector<uint64_t> records((size_t)n_distinct * rw);
+    // the host copy of the records: plain anonymous memory on huge pages, never value-initialised (several GB)
+    struct HostRecords {
+        uint64_t* p = nullptr; size_t bytes = 0, words = 0;
+        void alloc(size_t n_words) {
+            words = n_words;
+            const size_t HP = (size_t)2 << 20;
+            bytes = (n_words * sizeof(uint64_t) + HP - 1) / HP * HP + HP;
+            void* q = mmap(nullptr, bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+            if (q == MAP_FAILED) { fprintf(stderr, "out of memory (%zu bytes for the node records)\n", bytes); exit(-1); }
+            madvise(q, bytes, MADV_HUGEPAGE);
+            p = (uint64_t*)q;
+        }
+        void release() { if (p) munmap(p, bytes); p = nullptr; bytes = words = 0; }
+        uint64_t* data() { return p; }
+        size_t size() const { return words; }
+        ~HostRecords() { release(); }
+    } records;
+    records.alloc((size_t)n_distinct * rw + 1);
     if (n_distinct) {
         uint64_t* d_rec = nullptr;
-        HIP_OK(hipMalloc((void**)&d_rec, records.size() * sizeof(uint64_t)));
+        HIP_OK(hipMalloc((void**)&d_rec, (size_t)n_distinct * rw * sizeof(uint64_t)));
         uint64_t got = 0;
         if (pg_export(ctx, d_rec, n_distinct, &got, nullptr) != PG_OK) die("pg_export");
         if (got != n_distinct) { fprintf(stderr, "export count mismatch\n"); exit(-1); }
         // replay order (set, first occurrence) on the device; beyond 2^31 records the host sorts instead
         if (n_distinct < 0x7fffffffULL && pg_sort_records(d_rec, n_distinct, mer127 ? 1 : 0, nullptr) != PG_OK) die("pg_sort_records");
-        HIP_OK(hipMemcpy(records.data(), d_rec, records.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(records.data(), d_rec, (size_t)n_distinct * rw * sizeof(uint64_t), hipMemcpyDeviceToHost));
         hipFree(d_rec);
     }
     pg_destroy(ctx);
@@ -408,7 +426,7 @@ int run(int argc, char** argv, bool mer127) {
     if (!graph) die("pg_host_graph_begin");
     if (o.reps && pg_host_graph_resolve_repeats(graph, 1) != PG_OK) die("pg_host_graph_resolve_repeats");
     if (!host_pass2 && pg_graph_use_device(graph, device) != PG_OK) die("pg_graph_use_device");
-    { std::vector<uint64_t>().swap(records); }
+    records.release();
     fprintf(stderr, "Time spent on removing tips and constructing edges: %ds.\n\n", (int)(time(nullptr) - t0));
     lap("layout + tips + edges");
 

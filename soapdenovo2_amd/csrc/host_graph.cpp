@@ -544,8 +544,26 @@ struct Graph {
                 if (fpos > pos) later.push(fpos);
             }
         };
-        for (Chunk& ck : chunks)
-            for (Cand& cd : ck.c) {
+        // the replay is serial and every step touches a handful of random cache lines (start node, stop node, their
+        // "touched" bytes): flatten the candidates and prefetch those lines a few steps ahead
+        std::vector<Cand*> flat;
+        for (Chunk& ck : chunks) for (Cand& cd : ck.c) flat.push_back(&cd);
+        auto warm = [&](const Cand& cd) {
+            const int cs = (int)(cd.pos >> 40);
+            const uint64_t slot = cd.pos & ((1ULL << 40) - 1);
+            __builtin_prefetch(&sets[cs].array[slot], 1);
+            __builtin_prefetch(&touched[cs][slot], 1);
+            if (cd.d.far) {
+                __builtin_prefetch(cd.d.far, 1);
+                __builtin_prefetch(&touched[cd.d.far_set][(size_t)(cd.d.far - sets[cd.d.far_set].array.data())], 1);
+            }
+        };
+        constexpr size_t WARM = 12;
+        for (size_t i = 0; i < std::min(WARM, flat.size()); i++) warm(*flat[i]);
+        for (size_t fi = 0; fi < flat.size(); fi++) {
+            if (fi + WARM < flat.size()) warm(*flat[fi + WARM]);
+            {
+                Cand& cd = *flat[fi];
                 while (!later.empty() && later.top() < cd.pos) {
                     const uint64_t p = later.top();
                     while (!later.empty() && later.top() == p) later.pop();
@@ -554,6 +572,7 @@ struct Graph {
                 while (!later.empty() && later.top() == cd.pos) later.pop();     // already on the list: visited once
                 visit(cd.pos, &cd.d);
             }
+        }
         while (!later.empty()) {
             const uint64_t p = later.top();
             while (!later.empty() && later.top() == p) later.pop();

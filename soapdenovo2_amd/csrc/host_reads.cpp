@@ -11,6 +11,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/stat.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <thread>
@@ -332,11 +333,41 @@ long long stream_reads_parallel(const InputFile& in, ReadSink& sink, bool fastq,
         for (auto& th : pool) th.join();
         deliver(nt);
     };
+    // a regular file is read with a few preads side by side (one thread copying out of the page cache is slower than the
+    // parsers); a pipe (.gz) is read as it comes
+    uint64_t file_off = 0;
+    auto read_window = [&](char* dst, size_t want) -> size_t {
+        if (src.piped) return fread(dst, 1, want, src.fp);
+        const int fd = fileno(src.fp);
+        const int parts = 4;
+        size_t got_part[parts] = {0, 0, 0, 0};
+        auto body = [&](int t) {
+            const size_t lo = want * t / parts, hi = want * (t + 1) / parts;
+            size_t done = 0;
+            while (lo + done < hi) {
+                const ssize_t r = pread(fd, dst + lo + done, hi - lo - done, (off_t)(file_off + lo + done));
+                if (r <= 0) break;
+                done += (size_t)r;
+            }
+            got_part[t] = done;
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < parts; t++) pool.emplace_back(body, t);
+        body(0);
+        for (auto& th : pool) th.join();
+        size_t total = 0;
+        for (int t = 0; t < parts; t++) {                       // a short part means the file ended inside it
+            total += got_part[t];
+            if (got_part[t] < want * (t + 1) / parts - want * t / parts) break;
+        }
+        file_off += total;
+        return total;
+    };
     // two windows: while the threads parse one, the next stretch of the file is read into the other
     std::vector<char> next_win;
     size_t got = 0;
     win.resize(window_chunks * CHUNK);
-    got = fread(win.data(), 1, window_chunks * CHUNK, src.fp);
+    got = read_window(win.data(), window_chunks * CHUNK);
     for (;;) {
         if (got == 0) {
             // the file ended on a chunk boundary: the reference parses its previous buffer again and loses the tail it
@@ -376,7 +407,7 @@ long long stream_reads_parallel(const InputFile& in, ReadSink& sink, bool fastq,
         next_win.resize(tail + window_chunks * CHUNK);
         memcpy(next_win.data(), win.data() + begin, tail);
         size_t next_got = 0;
-        std::thread reader([&]() { next_got = fread(next_win.data() + tail, 1, window_chunks * CHUNK, src.fp); });
+        std::thread reader([&]() { next_got = read_window(next_win.data() + tail, window_chunks * CHUNK); });
         parse_all();
         reader.join();
         win.swap(next_win);
