@@ -492,6 +492,8 @@ struct Graph {
         for (int si = 0; si < (int)sets.size(); si++)
             for (uint64_t lo = 0; lo < sets[si].size; lo += STEP) chunks.push_back(Chunk{si, lo, std::min<uint64_t>(sets[si].size, lo + STEP), {}});
         auto startable = [thin](const HNode<NW>& n) { return !(n.B & (B_LINEAR | B_DELETED)) && (!thin || (n.B & B_SINGLE)); };
+        auto nowt = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+        const double tt0 = nowt();
         {
             std::atomic<size_t> next{0};
             auto body = [&]() {
@@ -513,6 +515,7 @@ struct Graph {
             body();
             for (auto& th : pool) th.join();
         }
+        const double tt1 = nowt();
         // nodes changed during this scan (one byte a slot; only the slots of clipped tips' ends are ever set)
         std::vector<std::vector<uint8_t>> touched(sets.size());
         for (size_t si = 0; si < sets.size(); si++) touched[si].assign(sets[si].size, 0);
@@ -578,7 +581,9 @@ struct Graph {
             while (!later.empty() && later.top() == p) later.pop();
             visit(p, nullptr);
         }
-        if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "tip scan: %lld removed, %lld walked again, %lld decided again\n", removed, rewalked, redecided);
+        if (getenv("PG_HOST_VERBOSE"))
+            fprintf(stderr, "tip scan: %lld removed, %lld walked again, %lld decided again; walks %.2fs, replay %.2fs (%d threads)\n", removed, rewalked,
+                    redecided, tt1 - tt0, nowt() - tt1, nt);
         return removed;
     }
 

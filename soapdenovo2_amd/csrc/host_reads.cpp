@@ -14,6 +14,7 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
 #include <thread>
 
 namespace pg {
@@ -335,6 +336,7 @@ long long stream_reads_parallel(const InputFile& in, ReadSink& sink, bool fastq,
     };
     // a regular file is read with a few preads side by side (one thread copying out of the page cache is slower than the
     // parsers); a pipe (.gz) is read as it comes
+    double t_parse = 0, t_wait = 0;
     uint64_t file_off = 0;
     auto read_window = [&](char* dst, size_t want) -> size_t {
         if (src.piped) return fread(dst, 1, want, src.fp);
@@ -407,14 +409,19 @@ long long stream_reads_parallel(const InputFile& in, ReadSink& sink, bool fastq,
         next_win.resize(tail + window_chunks * CHUNK);
         memcpy(next_win.data(), win.data() + begin, tail);
         size_t next_got = 0;
+        const auto tr0 = std::chrono::steady_clock::now();
         std::thread reader([&]() { next_got = read_window(next_win.data() + tail, window_chunks * CHUNK); });
         parse_all();
+        const auto tr1 = std::chrono::steady_clock::now();
         reader.join();
+        t_parse += std::chrono::duration<double>(tr1 - tr0).count();
+        t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr1).count();
         win.swap(next_win);
         carry = tail;
         got = next_got;
     }
     src.close();
+    if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "reader: %.2fs parsing + handing over, %.2fs more waiting for the file (%d threads)\n", t_parse, t_wait, nt);
     return n_records;
 }
 

@@ -166,20 +166,38 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_tiled_kernel(ReadsArg a, E2
         const uint32_t* sv = v0 + r * np;
         uint32_t x0 = (j >= 0 && j < np) ? sv[j] : 0xFFFFFFFFu;
         uint32_t x1 = (j + 64 < np) ? sv[j + 64] : 0xFFFFFFFFu;
-        uint32_t x2 = (j + 128 < np) ? sv[j + 128] : 0xFFFFFFFFu;
-        auto shifted_min = [&](int d) {                             // x_i[l] = min(x_i[l], value d positions further on)
-            const int srcl = (lane + d) & 63;
-            const bool wrap = lane + d >= 64;
-            const uint32_t a0 = __shfl(x0, srcl, 64), a1 = __shfl(x1, srcl, 64), a2 = __shfl(x2, srcl, 64);
-            x0 = min(x0, wrap ? a1 : a0);
-            x1 = min(x1, wrap ? a2 : a1);
-            x2 = min(x2, wrap ? 0xFFFFFFFFu : a2);
-        };
-        for (int k = 0; k < lv && k < 6; k++) shifted_min(1 << k);
-        if (lv >= 7) { x0 = min(x0, x1); x1 = min(x1, x2); }      // a step of 64 is the next register (w >= 128 only)
-        uint32_t mv = x0;                                           // min over [j, j + span)
-        {
+        uint32_t mv;
+        if (w <= 65) {
+            // a window of at most 65 m-mers never reaches past j + 127: two registers a lane
+            for (int k = 0; k < lv; k++) {
+                const int d = 1 << k;
+                const int srcl = (lane + d) & 63;
+                const bool wrap = lane + d >= 64;
+                const uint32_t a0 = __shfl(x0, srcl, 64), a1 = __shfl(x1, srcl, 64);
+                x0 = min(x0, wrap ? a1 : a0);
+                x1 = min(x1, wrap ? 0xFFFFFFFFu : a1);
+            }
+            mv = x0;                                                // min over [j, j + span)
             const int sft = w - span;                               // the rest of the window: [j + w - span, j + w)
+            if (sft > 0) {
+                const int srcl = (lane + sft) & 63;
+                const uint32_t a0 = __shfl(x0, srcl, 64), a1 = __shfl(x1, srcl, 64);
+                mv = min(x0, lane + sft >= 64 ? a1 : a0);
+            }
+        } else {
+            uint32_t x2 = (j + 128 < np) ? sv[j + 128] : 0xFFFFFFFFu;
+            for (int k = 0; k < lv && k < 6; k++) {
+                const int d = 1 << k;
+                const int srcl = (lane + d) & 63;
+                const bool wrap = lane + d >= 64;
+                const uint32_t a0 = __shfl(x0, srcl, 64), a1 = __shfl(x1, srcl, 64), a2 = __shfl(x2, srcl, 64);
+                x0 = min(x0, wrap ? a1 : a0);
+                x1 = min(x1, wrap ? a2 : a1);
+                x2 = min(x2, wrap ? 0xFFFFFFFFu : a2);
+            }
+            if (lv >= 7) { x0 = min(x0, x1); x1 = min(x1, x2); }  // a step of 64 is the next register (w >= 128 only)
+            mv = x0;
+            const int sft = w - span;
             if (sft > 0) {
                 const int d = sft & 63;
                 const int srcl = (lane + d) & 63;
