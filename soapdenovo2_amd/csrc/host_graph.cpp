@@ -341,6 +341,11 @@ template <int NW>
 struct Graph {
     int K, P;
     int n_threads = 0;             // host threads for the parallel scans (0 = all)
+    // with the sets mirrored in HBM the tip walks run there (pass2_kernels.hip: tip_walk_kernel); the host keeps the
+    // order-dependent replay and sends the nodes it changed back
+    P2Device* tip_dev = nullptr;
+    std::vector<uint64_t> set_base;   // global slot of every set's slot 0 (+ the total)
+    int tip_error = PG_OK;
     Kmer<NW> filter;
     uint32_t bias;
     const uint32_t* crc;
@@ -494,7 +499,32 @@ struct Graph {
         auto startable = [thin](const HNode<NW>& n) { return !(n.B & (B_LINEAR | B_DELETED)) && (!thin || (n.B & B_SINGLE)); };
         auto nowt = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         const double tt0 = nowt();
-        {
+        std::vector<Cand> from_device;
+        if (tip_dev) {
+            std::vector<P2TipWalk> walks;
+            const int rc = p2_tip_walks(tip_dev, cut_len, thin, walks);
+            if (rc) { tip_error = rc; return 0; }
+            from_device.resize(walks.size());
+            auto body = [&](int t) {
+                for (size_t i = walks.size() * t / nt; i < walks.size() * (t + 1) / nt; i++) {
+                    const P2TipWalk& w = walks[i];
+                    const int si = (int)(std::upper_bound(set_base.begin(), set_base.end(), (uint64_t)w.pos) - set_base.begin()) - 1;
+                    Cand& c = from_device[i];
+                    c.pos = ((uint64_t)si << 40) | (w.pos - set_base[si]);
+                    c.d = TipDecision();
+                    if (w.far != ~0ULL) {
+                        const int fs = (int)(std::upper_bound(set_base.begin(), set_base.end(), (uint64_t)w.far) - set_base.begin()) - 1;
+                        c.d.far = &sets[fs].array[w.far - set_base[fs]];
+                        c.d.far_set = fs; c.d.first = (int)w.first; c.d.far_smaller = w.far_smaller != 0;
+                        tip_decide(c.d, thin);
+                    }
+                }
+            };
+            std::vector<std::thread> pool;
+            for (int t = 1; t < nt; t++) pool.emplace_back(body, t);
+            body(0);
+            for (auto& th : pool) th.join();
+        } else {
             std::atomic<size_t> next{0};
             auto body = [&]() {
                 for (;;) {
@@ -522,6 +552,7 @@ struct Graph {
         auto is_touched = [&](int set, const HNode<NW>* n) { return touched[set][(size_t)(n - sets[set].array.data())] != 0; };
         std::priority_queue<uint64_t, std::vector<uint64_t>, std::greater<uint64_t>> later;
         long long removed = 0, rewalked = 0, redecided = 0;
+        std::vector<uint64_t> changed;                              // global slots of the nodes this scan changed
         auto node_at = [&](uint64_t pos) -> HNode<NW>& { return sets[pos >> 40].array[pos & ((1ULL << 40) - 1)]; };
         auto visit = [&](uint64_t pos, const TipDecision* spec) {
             HNode<NW>& n = node_at(pos);
@@ -542,6 +573,7 @@ struct Graph {
             touched[nset][pos & ((1ULL << 40) - 1)] = 1;
             const uint64_t fslot = (uint64_t)(d.far - sets[d.far_set].array.data());
             touched[d.far_set][fslot] = 1;
+            if (tip_dev) { changed.push_back(set_base[nset] + (pos & ((1ULL << 40) - 1))); changed.push_back(set_base[d.far_set] + fslot); }
             if (d.action != 1) {
                 const uint64_t fpos = ((uint64_t)d.far_set << 40) | fslot;
                 if (fpos > pos) later.push(fpos);
@@ -551,6 +583,7 @@ struct Graph {
         // "touched" bytes): flatten the candidates and prefetch those lines a few steps ahead
         std::vector<Cand*> flat;
         for (Chunk& ck : chunks) for (Cand& cd : ck.c) flat.push_back(&cd);
+        for (Cand& cd : from_device) flat.push_back(&cd);
         auto warm = [&](const Cand& cd) {
             const int cs = (int)(cd.pos >> 40);
             const uint64_t slot = cd.pos & ((1ULL << 40) - 1);
@@ -581,6 +614,16 @@ struct Graph {
             while (!later.empty() && later.top() == p) later.pop();
             visit(p, nullptr);
         }
+        if (tip_dev && !changed.empty()) {                          // bring the device copy up to date
+            std::vector<uint64_t> ab(changed.size());
+            for (size_t i = 0; i < changed.size(); i++) {
+                const int si = (int)(std::upper_bound(set_base.begin(), set_base.end(), changed[i]) - set_base.begin()) - 1;
+                const HNode<NW>& n = sets[si].array[changed[i] - set_base[si]];
+                ab[i] = (uint64_t)n.A | ((uint64_t)n.B << 32);
+            }
+            const int rc = p2_mirror_nodes(tip_dev, changed.data(), ab.data(), changed.size());
+            if (rc) { tip_error = rc; return removed; }
+        }
         if (getenv("PG_HOST_VERBOSE"))
             fprintf(stderr, "tip scan: %lld removed, %lld walked again, %lld decided again; walks %.2fs, replay %.2fs (%d threads)\n", removed, rewalked,
                     redecided, tt1 - tt0, nowt() - tt1, nt);
@@ -595,6 +638,7 @@ struct Graph {
         tip_scan(cut, true, tips);
         fprintf(stderr, "Total %lld tip(s) removed.\n", tips);
         remark_linear();
+        if (tip_dev && !tip_error) tip_error = p2_remark_linear(tip_dev);
     }
     // removeMinorTips (cutTipPreGraph.c:414-488)
     void remove_minor_tips() {
@@ -605,10 +649,11 @@ struct Graph {
         for (;;) {
             const long long removed = tip_scan(cut, false, tips);
             fprintf(stderr, "%lld tip(s) removed in cycle %d.\n", removed, round++);
-            if (!removed) break;
+            if (!removed || tip_error) break;
         }
         fprintf(stderr, "Total %lld tip(s) removed.\n", tips);
         remark_linear();
+        if (tip_dev && !tip_error) tip_error = p2_remark_linear(tip_dev);
     }
 };
 
@@ -992,7 +1037,24 @@ static int construct_edges(Graph<NW>& g, const std::string& prefix, int n_thread
 
 // output_vertex (output_pregraph.c:50-86)
 template <int NW>
+static int write_vertex_file(Graph<NW>& g, const std::string& prefix, int& num_vt, bool quiet);
+static int write_basic_file(const std::string& prefix, int num_vt, int K, int num_ed, int max_read_len) {
+    FILE* fp = fopen((prefix + ".preGraphBasic").c_str(), "w");
+    if (!fp) { pg_set_error("cannot open " + prefix + ".preGraphBasic"); return PG_EIO; }
+    fprintf(fp, "VERTEX %d K %d\n", num_vt, K);
+    fprintf(fp, "\nEDGEs %d\n", num_ed);
+    fprintf(fp, "\nMaxReadLen %d MinReadLen %d MaxNameLen %d\n", max_read_len, 0, 256);
+    fclose(fp);
+    return PG_OK;
+}
+template <int NW>
 static int write_vertex(Graph<NW>& g, const std::string& prefix, int num_ed, int max_read_len, int& num_vt) {
+    int rc = write_vertex_file<NW>(g, prefix, num_vt, false);
+    if (rc) return rc;
+    return write_basic_file(prefix, num_vt, g.K, num_ed, max_read_len);
+}
+template <int NW>
+static int write_vertex_file(Graph<NW>& g, const std::string& prefix, int& num_vt, bool quiet) {
     FILE* fp = fopen((prefix + ".vertex").c_str(), "w");
     if (!fp) { pg_set_error("cannot open " + prefix + ".vertex"); return PG_EIO; }
     std::vector<char> big(1 << 22);
@@ -1042,14 +1104,8 @@ static int write_vertex(Graph<NW>& g, const std::string& prefix, int num_ed, int
         if (!r.text.empty()) fwrite(r.text.data(), 1, r.text.size(), fp);
     fputc('\n', fp);
     fclose(fp);
-    fprintf(stderr, "%d vertex(es) output.\n", cnt);
+    if (!quiet) fprintf(stderr, "%d vertex(es) output.\n", cnt);
     num_vt = cnt;
-    fp = fopen((prefix + ".preGraphBasic").c_str(), "w");
-    if (!fp) { pg_set_error("cannot open " + prefix + ".preGraphBasic"); return PG_EIO; }
-    fprintf(fp, "VERTEX %d K %d\n", cnt, g.K);
-    fprintf(fp, "\nEDGEs %d\n", num_ed);
-    fprintf(fp, "\nMaxReadLen %d MinReadLen %d MaxNameLen %d\n", max_read_len, 0, 256);
-    fclose(fp);
     return PG_OK;
 }
 
@@ -1392,7 +1448,11 @@ struct GraphHandle : GraphHandleBase {
     std::vector<uint32_t> dev_walks;
     std::vector<uint16_t> dev_walk_len;
 
-    ~GraphHandle() override { if (path_fp) fclose(path_fp); if (dev) p2_destroy(dev); }
+    ~GraphHandle() override {
+        if (vertex_thread.joinable()) vertex_thread.join();
+        if (path_fp) fclose(path_fp);
+        if (dev) p2_destroy(dev);
+    }
     int use_device(int device) override {
         if (dev_edges) {                             // the sets live on the device, tagged there: pass 2 stays there
             if (device == dev_id) return PG_OK;
@@ -1405,12 +1465,24 @@ struct GraphHandle : GraphHandleBase {
     }
     int max_nk() const { return std::max(1, max_read_len - g.K + 1); }
     // edges on the device (pass2_kernels.hip: eb_*): upload the sets, build, then format output_1edge's text here
-    int dev_build_edges(int device, int n_threads, int& edge_c, long long& records_c, long long& extra_nodes) {
+    // the k-mer sets into HBM as they are now (after the layout replay: the tips then walk on the device copy)
+    int dev_open(int device) {
         dev_on = true; dev_id = device;
         P2Sets sets;
-        for (int si = 0; si < g.P; si++) { sets.nodes[si] = g.sets[si].array.data(); sets.size[si] = g.sets[si].size; }
+        g.set_base.assign((size_t)g.P + 1, 0);
+        for (int si = 0; si < g.P; si++) {
+            sets.nodes[si] = g.sets[si].array.data(); sets.size[si] = g.sets[si].size;
+            g.set_base[si + 1] = g.set_base[si] + g.sets[si].size;
+        }
         dev = p2_open(dev_id, g.K, NW, g.P, sets, max_nk());
         if (!dev) return PG_ENODEV;
+        g.tip_dev = dev;
+        return PG_OK;
+    }
+    int dev_build_edges(int device, int n_threads, int& edge_c, long long& records_c, long long& extra_nodes) {
+        start_vertex_writer();
+        if (!dev) { const int rc0 = dev_open(device); if (rc0) return rc0; }
+        g.tip_dev = nullptr;                         // the device copy is about to be tagged: no more tip walks on it
         P2Edges ed;
         int rc = p2_build_edges(dev, ed);
         if (rc) return rc;
@@ -1467,6 +1539,15 @@ struct GraphHandle : GraphHandleBase {
         return PG_OK;
     }
     bool dev_edges = false;
+    // with the edges on the device nothing changes the host copy of the sets after the tips: <prefix>.vertex is written
+    // by a background thread while the GPU builds edges and threads reads
+    std::thread vertex_thread;
+    int vertex_rc = PG_OK, vertex_count = 0;
+    bool vertex_started = false;
+    void start_vertex_writer() {
+        vertex_started = true;
+        vertex_thread = std::thread([this]() { vertex_rc = write_vertex_file<NW>(g, prefix, vertex_count, true); });
+    }
     int dev_begin() {
         if (dev_ready) return PG_OK;
         if (dev) {                                   // opened for the edges: the (K+1)-mer table is on the device already
@@ -1742,6 +1823,13 @@ struct GraphHandle : GraphHandleBase {
         fprintf(stderr, "Reads alignment done, %lld read(s) deleted, %lld pre-arc(s) added.\n", reads_deleted, arc_count);
         fprintf(stderr, "Time spent on threading reads: %.1fs, on folding pre-arcs: %.1fs.\n", t_thread, t_fold);
         if (n_arcs) *n_arcs = arc_count;
+        if (vertex_started) {
+            if (vertex_thread.joinable()) vertex_thread.join();
+            if (vertex_rc) return vertex_rc;
+            num_vt = vertex_count;
+            fprintf(stderr, "%d vertex(es) output.\n", num_vt);
+            return write_basic_file(prefix, num_vt, g.K, num_ed, max_read_len);
+        }
         return write_vertex<NW>(g, prefix, num_ed, max_read_len, num_vt);
     }
 };
@@ -1757,8 +1845,10 @@ static GraphHandleBase* graph_begin(const uint64_t* records, uint64_t n, const u
     if (replay_layout<NW>(h->g, records, n, set_last_put, K, P, a_gb, n_threads) != PG_OK) { delete h; return nullptr; }
     fprintf(stderr, "Time spent on rebuilding the k-mer set layout: %.1fs.\n", now() - t0);
     t0 = now();
+    if (device >= 0 && !getenv("SOAPDENOVO2_AMD_TIPS_HOST") && h->dev_open(device) != PG_OK) { delete h; return nullptr; }
     if (cut_single) h->g.remove_single_tips();
     h->g.remove_minor_tips();
+    if (h->g.tip_error) { delete h; return nullptr; }
     fprintf(stderr, "Time spent on removing tips: %.1fs.\n\n", now() - t0);
     t0 = now();
     int edge_c = 0;

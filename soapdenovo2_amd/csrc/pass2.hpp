@@ -42,6 +42,14 @@ int p2_set_patch(P2Device* d, const uint64_t* patch_keys, const uint32_t* patch_
 int p2_build_edges(P2Device* d, P2Edges& out);
 int p2_begin_reads(P2Device* d, uint32_t num_ed, bool reps);
 
+// one dead-end start and where its walk over linear nodes stopped (global slots = set base + slot; far = ~0: the walk
+// was longer than the cut-off)
+struct P2TipWalk { unsigned long long pos, far; uint32_t first, far_smaller; };
+// the tip walks of one scan in slot order; afterwards the host sends back the nodes it changed and re-marks
+int p2_tip_walks(P2Device* d, int cut_len, bool thin, std::vector<P2TipWalk>& out);
+int p2_mirror_nodes(P2Device* d, const uint64_t* slots, const uint64_t* ab, uint64_t n);
+int p2_remark_linear(P2Device* d);
+
 // patch table: open addressing over `patch_cap` (a power of two) entries, NW key words + (id, twin) an entry, id 0 =
 // empty, slot = kmer_mix(key) & (cap - 1), linear probing
 P2Device* p2_create(int device, int K, int nw, int n_sets, const P2Sets& sets, const uint64_t* patch_keys, const uint32_t* patch_val,

@@ -459,6 +459,85 @@ __global__ __launch_bounds__(256) void eb_apply(P2Params p, uint64_t* nodes_rw, 
     }
 }
 
+
+// =====================================================================================================================
+// Tip walks on the device (the read-only half of clipTipFromNode, cutTipPreGraph.c:43-346).  A lane per slot: a dead-end,
+// non-linear, non-deleted node (with `thin`: a frequency-one node) walks over linear nodes to the node it stops at.  The
+// order-dependent half -- deciding and clipping in slot order -- stays on the host, which mirrors the nodes it changed
+// back into the device copy (tip_mirror) and re-marks linear nodes on both sides (tip_remark).
+// =====================================================================================================================
+__device__ inline int count_arcs(uint32_t w24) { return (int)((w24 & 63u) != 0) + (int)(((w24 >> 6) & 63u) != 0) + (int)(((w24 >> 12) & 63u) != 0) + (int)(((w24 >> 18) & 63u) != 0); }
+
+template <int NW>
+__global__ __launch_bounds__(256) void tip_walk_kernel(P2Params p, uint64_t n_slots, int cut_len, int thin, P2TipWalk* out, uint64_t cap,
+                                                       unsigned long long* n_out, unsigned long long* errors) {
+    __shared__ uint32_t crc_tab[256];
+    __shared__ uint64_t set_geo[2 * P2_MAX_SETS];
+    crc_tab[threadIdx.x] = crc32_table_entry(threadIdx.x);
+    if (threadIdx.x < p.P) { set_geo[2 * threadIdx.x] = p.set_base[threadIdx.x]; set_geo[2 * threadIdx.x + 1] = p.set_size[threadIdx.x]; }
+    __syncthreads();
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_slots) return;
+    const uint64_t* nd = p.nodes + i * (NW + 1);
+    if (nd[0] == P2_EMPTY) return;
+    const uint64_t ab0 = nd[NW];
+    const uint32_t A0 = (uint32_t)ab0, B0 = (uint32_t)(ab0 >> 32);
+    if (B0 & (B_LINEAR | B_DELETED)) return;
+    if (thin && !(B0 & B_SINGLE)) return;
+    const int in = count_arcs(A0), outn = count_arcs(B0);
+    const bool fwd = in == 0 && outn == 1, bwd = in == 1 && outn == 0;
+    if (!fwd && !bwd) return;
+    const int K = p.K;
+    const Kmer<NW> filter = kmer_filter<NW>(K);
+    Kmer<NW> seq;
+#pragma unroll
+    for (int k = 0; k < NW; k++) seq.w[k] = nd[k];
+    Kmer<NW> prev = fwd ? seq : kmer_rc<NW>(seq, K);
+    int ch;
+    if (fwd) { for (ch = 0; ch < 4; ch++) if ((B0 >> (6 * ch)) & 63) break; }
+    else { for (ch = 0; ch < 4; ch++) if ((A0 >> (6 * ch)) & 63) break; ch ^= 2; }
+    P2TipWalk w;
+    w.pos = i; w.far = ~0ULL; w.first = 0; w.far_smaller = 0;
+    int count = 1;
+    Kmer<NW> cur = kmer_next<NW>(prev, ch, filter);
+    uint64_t slot, ab;
+    bool smaller;
+    if (!walk_step<NW>(p, cur, K, crc_tab, set_geo, slot, ab, smaller)) { atomicAdd(errors, 1ULL); return; }
+    bool reached = true;
+    while ((uint32_t)(ab >> 32) & B_LINEAR) {
+        count++;
+        if (thin && !((uint32_t)(ab >> 32) & B_SINGLE)) break;
+        if (count > cut_len) { reached = false; break; }
+        prev = cur;
+        cur = kmer_next<NW>(cur, linear_out(ab, smaller), filter);
+        if (!walk_step<NW>(p, cur, K, crc_tab, set_geo, slot, ab, smaller)) { atomicAdd(errors, 1ULL); return; }
+    }
+    if (reached) { w.far = slot; w.first = (uint32_t)kmer_first<NW>(prev, K); w.far_smaller = smaller ? 1u : 0u; }
+    const unsigned long long at = atomicAdd(n_out, 1ULL);
+    if (at < cap) out[at] = w;
+}
+
+__global__ void tip_keys(const P2TipWalk* w, uint64_t n, unsigned long long* key, uint32_t* idx) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) { key[i] = w[i].pos; idx[i] = (uint32_t)i; }
+}
+__global__ void tip_gather(const P2TipWalk* w, const uint32_t* order, uint64_t n, P2TipWalk* out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = w[order[i]];
+}
+__global__ void tip_mirror(uint64_t* nodes, int nw1, const uint64_t* slots, const uint64_t* ab, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) nodes[slots[i] * nw1 + nw1 - 1] = ab[i];
+}
+// Mark1in1outNode (cutTipPreGraph.c:532-564): a live non-linear node with one arc each way becomes linear
+__global__ void tip_remark(uint64_t* nodes, int nw1, uint64_t n_slots) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t* nd = nodes + i * nw1;
+        if (nd[0] == P2_EMPTY) continue;
+        const uint64_t ab = nd[nw1 - 1];
+        const uint32_t A = (uint32_t)ab, B = (uint32_t)(ab >> 32);
+        if (B & (B_DELETED | B_LINEAR)) continue;
+        if (count_arcs(A) == 1 && count_arcs(B) == 1) nd[nw1 - 1] = ab | ((uint64_t)B_LINEAR << 32);
+    }
+}
+
 // the occupied slots of the pre-arc table, densely (order does not matter: the host sorts)
 __global__ void p2_compact_arcs(const unsigned long long* key, const unsigned int* cnt, const unsigned long long* first, uint64_t cap,
                                 P2Arc* out, unsigned long long* n_out) {
@@ -594,13 +673,89 @@ P2Device* p2_create(int device, int K, int nw, int n_sets, const P2Sets& sets, c
     return d;
 }
 
-// ---- edges ------------------------------------------------------------------------------------------------------------
+
 #define P2_HIP_GOTO(call)                                                                                    \
     do {                                                                                                     \
         hipError_t e_ = (call);                                                                              \
         if (e_ != hipSuccess) { pg_set_error(std::string("edges: ") + #call + ": " + hipGetErrorString(e_)); rc = PG_ENODEV; goto done; } \
     } while (0)
 
+// ---- tips ---------------------------------------------------------------------------------------------------------------
+int p2_tip_walks(P2Device* d, int cut_len, bool thin, std::vector<P2TipWalk>& out) {
+    int rc = PG_OK;
+    hipStream_t st = d->stream;
+    P2TipWalk *d_w = nullptr, *d_sorted = nullptr;
+    unsigned long long *d_cnt = nullptr, *d_key = nullptr, *d_key2 = nullptr;
+    uint32_t *d_idx = nullptr, *d_order = nullptr;
+    void* d_tmp = nullptr;
+    size_t tmp_bytes = 0;
+    unsigned long long cnt[2] = {0, 0};
+    uint64_t cap = d->n_slots / 8 + 4096;                 // dead ends are a small share of the slots; retried when short
+    out.clear();
+    if (hipSetDevice(d->device) != hipSuccess) { pg_set_error("tips: hipSetDevice failed"); return PG_ENODEV; }
+    if (d->n_slots / 256 >= 0x7FFFFFFFULL) { pg_set_error("tips: too many slots for one launch"); return PG_EINVAL; }
+    P2_HIP_GOTO(hipMalloc((void**)&d_cnt, 2 * sizeof(unsigned long long)));
+    for (int attempt = 0; attempt < 2; attempt++) {
+        hipFree(d_w); d_w = nullptr;
+        P2_HIP_GOTO(hipMalloc((void**)&d_w, cap * sizeof(P2TipWalk)));
+        P2_HIP_GOTO(hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), st));
+        if (d->n_slots) {
+            const dim3 grid((unsigned)((d->n_slots + 255) / 256));
+            if (d->nw == 2) hipLaunchKernelGGL(tip_walk_kernel<2>, grid, dim3(256), 0, st, d->prm, d->n_slots, cut_len, thin ? 1 : 0, d_w, cap, d_cnt, d_cnt + 1);
+            else hipLaunchKernelGGL(tip_walk_kernel<4>, grid, dim3(256), 0, st, d->prm, d->n_slots, cut_len, thin ? 1 : 0, d_w, cap, d_cnt, d_cnt + 1);
+            P2_HIP_GOTO(hipGetLastError());
+        }
+        P2_HIP_GOTO(hipMemcpyAsync(cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, st));
+        P2_HIP_GOTO(hipStreamSynchronize(st));
+        if (cnt[1]) { pg_set_error("Kmer is not found while clipping a tip."); rc = PG_EINVAL; goto done; }
+        if (cnt[0] <= cap) break;
+        cap = cnt[0];
+    }
+    if (cnt[0] > cap) { pg_set_error("tips: walk buffer too small"); rc = PG_ENOMEM; goto done; }
+    if (cnt[0] >= 0x7FFFFFFFULL) { pg_set_error("tips: more than 2^31 - 1 dead ends"); rc = PG_EINVAL; goto done; }
+    if (cnt[0]) {
+        const uint64_t n = cnt[0];
+        P2_HIP_GOTO(hipMalloc((void**)&d_key, n * sizeof(unsigned long long)));
+        P2_HIP_GOTO(hipMalloc((void**)&d_key2, n * sizeof(unsigned long long)));
+        P2_HIP_GOTO(hipMalloc((void**)&d_idx, n * sizeof(uint32_t)));
+        P2_HIP_GOTO(hipMalloc((void**)&d_order, n * sizeof(uint32_t)));
+        P2_HIP_GOTO(hipMalloc((void**)&d_sorted, n * sizeof(P2TipWalk)));
+        hipLaunchKernelGGL(tip_keys, dim3(1024), dim3(256), 0, st, d_w, n, d_key, d_idx);
+        P2_HIP_GOTO(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_key, d_key2, d_idx, d_order, (int)n, 0, 64, st));
+        P2_HIP_GOTO(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
+        P2_HIP_GOTO(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_key, d_key2, d_idx, d_order, (int)n, 0, 64, st));
+        hipLaunchKernelGGL(tip_gather, dim3(1024), dim3(256), 0, st, d_w, d_order, n, d_sorted);
+        out.resize(n);
+        P2_HIP_GOTO(hipMemcpyAsync(out.data(), d_sorted, n * sizeof(P2TipWalk), hipMemcpyDeviceToHost, st));
+        P2_HIP_GOTO(hipStreamSynchronize(st));
+    }
+done:
+    hipFree(d_w); hipFree(d_sorted); hipFree(d_cnt); hipFree(d_key); hipFree(d_key2); hipFree(d_idx); hipFree(d_order); hipFree(d_tmp);
+    return rc;
+}
+
+int p2_mirror_nodes(P2Device* d, const uint64_t* slots, const uint64_t* ab, uint64_t n) {
+    if (!n) return PG_OK;
+    P2_HIP(hipSetDevice(d->device));
+    uint64_t *d_s = nullptr, *d_ab = nullptr;
+    P2_HIP(hipMalloc((void**)&d_s, n * sizeof(uint64_t)));
+    P2_HIP(hipMalloc((void**)&d_ab, n * sizeof(uint64_t)));
+    P2_HIP(hipMemcpyAsync(d_s, slots, n * sizeof(uint64_t), hipMemcpyHostToDevice, d->stream));
+    P2_HIP(hipMemcpyAsync(d_ab, ab, n * sizeof(uint64_t), hipMemcpyHostToDevice, d->stream));
+    hipLaunchKernelGGL(tip_mirror, dim3(1024), dim3(256), 0, d->stream, d->d_nodes, d->nw + 1, d_s, d_ab, n);
+    P2_HIP(hipStreamSynchronize(d->stream));
+    hipFree(d_s); hipFree(d_ab);
+    return PG_OK;
+}
+
+int p2_remark_linear(P2Device* d) {
+    P2_HIP(hipSetDevice(d->device));
+    hipLaunchKernelGGL(tip_remark, dim3(4096), dim3(256), 0, d->stream, d->d_nodes, d->nw + 1, d->n_slots);
+    P2_HIP(hipStreamSynchronize(d->stream));
+    return PG_OK;
+}
+
+// ---- edges ------------------------------------------------------------------------------------------------------------
 int p2_build_edges(P2Device* d, P2Edges& out) {
     int rc = PG_OK;
     const int NW1 = d->nw + 1;
