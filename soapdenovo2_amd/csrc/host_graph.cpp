@@ -1484,8 +1484,10 @@ struct GraphHandle : GraphHandleBase {
         if (!dev) { const int rc0 = dev_open(device); if (rc0) return rc0; }
         g.tip_dev = nullptr;                         // the device copy is about to be tagged: no more tip walks on it
         P2Edges ed;
+        const double te0 = now();
         int rc = p2_build_edges(dev, ed);
         if (rc) return rc;
+        const double te1 = now();
         edge_c = (int)ed.n_ids; records_c = (long long)ed.recs.size(); extra_nodes = ed.n_len1;
         dev_edges = true;
         // text records, one gzip member per range of edges, formatted and deflated by all host threads
@@ -1536,6 +1538,7 @@ struct GraphHandle : GraphHandleBase {
             if (!m.empty()) { any = true; if (fwrite(m.data(), 1, m.size(), fp) != m.size()) { fclose(fp); pg_set_error("short write on " + prefix + ".edge.gz"); return PG_EIO; } }
         if (!any) { std::vector<uint8_t> e; ParallelEdgeBuilder<NW>::gz_member(std::string(), e); fwrite(e.data(), 1, e.size(), fp); }
         fclose(fp);
+        if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "edges: device (walk, sort, tag, download) %.2fs, text + deflate + file %.2fs\n", te1 - te0, now() - te1);
         return PG_OK;
     }
     bool dev_edges = false;

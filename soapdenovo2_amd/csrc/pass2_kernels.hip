@@ -390,6 +390,17 @@ __global__ void eb_sizes(const EdgeRec* recs, const uint32_t* order, uint64_t n,
     }
 }
 
+// what the host formats, in slot order
+__global__ void eb_export(const EdgeRec* recs, const uint32_t* order, const unsigned long long* base_before, uint64_t n, P2EdgeRec* out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const EdgeRec& r = recs[order[i]];
+        P2EdgeRec o;
+        o.length = r.length; o.bal = (r.flags >> 6) & 1; o.sum = r.sum; o.text_off = base_before[i];
+        for (int k = 0; k < 4; k++) { o.first_kmer[k] = r.first_kmer[k]; o.last_kmer[k] = r.last_kmer[k]; }
+        out[i] = o;
+    }
+}
+
 template <int NW>
 __global__ __launch_bounds__(256) void eb_apply(P2Params p, uint64_t* nodes_rw, const EdgeRec* recs, const uint32_t* order, uint64_t n,
                                                 const unsigned long long* id_before, const unsigned long long* base_before, char* text,
@@ -764,6 +775,7 @@ int p2_build_edges(P2Device* d, P2Edges& out) {
                        *d_id_before = nullptr, *d_base_before = nullptr;
     uint32_t *d_idx = nullptr, *d_order = nullptr;
     EdgeRec* d_recs = nullptr;
+    P2EdgeRec* d_export = nullptr;
     char* d_text = nullptr;
     void* d_tmp = nullptr;
     size_t tmp_bytes = 0, tmp2 = 0;
@@ -839,32 +851,25 @@ int p2_build_edges(P2Device* d, P2Edges& out) {
                                     d->d_patch_keys, d->d_patch_val, patch_cap - 1, d_cnt + 3);
             P2_HIP_GOTO(hipGetLastError());
         }
-        // what the host needs for the text records: the walks in slot order, their text offsets, the bases
+        // what the host needs for the text records: the walks in slot order with their text offsets, and the bases
         {
-            std::vector<EdgeRec> recs(n_rec);
-            std::vector<uint32_t> order(n_rec);
-            std::vector<unsigned long long> bb(n_rec);
+            P2EdgeRec* d_out = nullptr;
+            P2_HIP_GOTO(hipMalloc((void**)&d_out, n_rec * sizeof(P2EdgeRec)));
+            d_export = d_out;
+            hipLaunchKernelGGL(eb_export, dim3(2048), dim3(256), 0, st, d_recs, d_order, d_base_before, n_rec, d_out);
+            out.recs.resize(n_rec);
             out.text.resize(total_bases);
-            P2_HIP_GOTO(hipMemcpyAsync(recs.data(), d_recs, n_rec * sizeof(EdgeRec), hipMemcpyDeviceToHost, st));
-            P2_HIP_GOTO(hipMemcpyAsync(order.data(), d_order, n_rec * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-            P2_HIP_GOTO(hipMemcpyAsync(bb.data(), d_base_before, n_rec * sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+            P2_HIP_GOTO(hipMemcpyAsync(out.recs.data(), d_out, n_rec * sizeof(P2EdgeRec), hipMemcpyDeviceToHost, st));
             if (total_bases) P2_HIP_GOTO(hipMemcpyAsync(&out.text[0], d_text, total_bases, hipMemcpyDeviceToHost, st));
             P2_HIP_GOTO(hipMemcpyAsync(cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, st));
             P2_HIP_GOTO(hipStreamSynchronize(st));
             if (cnt[3]) { pg_set_error("edges: a walk did not repeat itself"); rc = PG_EINVAL; goto done; }
-            out.recs.resize(n_rec);
-            for (uint64_t i = 0; i < n_rec; i++) {
-                const EdgeRec& r = recs[order[i]];
-                P2EdgeRec& o = out.recs[i];
-                o.length = r.length; o.bal = (r.flags >> 6) & 1; o.sum = r.sum; o.text_off = bb[i];
-                for (int k = 0; k < 4; k++) { o.first_kmer[k] = r.first_kmer[k]; o.last_kmer[k] = r.last_kmer[k]; }
-            }
         }
     }
     out.n_ids = (long long)total_ids;
 done:
     hipFree(d_list); hipFree(d_cnt); hipFree(d_key); hipFree(d_key2); hipFree(d_ids); hipFree(d_bases); hipFree(d_id_before); hipFree(d_base_before);
-    hipFree(d_idx); hipFree(d_order); hipFree(d_recs); hipFree(d_text); hipFree(d_tmp);
+    hipFree(d_idx); hipFree(d_order); hipFree(d_recs); hipFree(d_export); hipFree(d_text); hipFree(d_tmp);
     return rc;
 }
 
