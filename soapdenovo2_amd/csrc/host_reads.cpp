@@ -15,6 +15,10 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <mutex>
 #include <thread>
 
 namespace pg {
@@ -293,9 +297,11 @@ void parse_range(const InputFile& in, bool fastq, const char* buf, size_t size, 
     }
 }
 
-long long stream_reads_parallel(const InputFile& in, ReadSink& sink, bool fastq, int nt, size_t window_chunks) {
+// `on_run` gets the packed reads of a stretch of the file, in file order; returning false stops the stream early
+typedef std::function<bool(PackedRun&)> RunFn;
+long long stream_file_parallel(const InputFile& in, const std::string& path, bool fastq, int nt, size_t window_chunks, const RunFn& on_run) {
     Source src;
-    src.open(in.path1);
+    src.open(path);
     std::vector<char> win;
     std::vector<size_t> cuts;
     std::vector<std::pair<size_t, size_t>> bufs;
@@ -305,11 +311,12 @@ long long stream_reads_parallel(const InputFile& in, ReadSink& sink, bool fastq,
     size_t carry = 0;
     bool any = false;
     long long n_records = 0;
+    bool stopped = false;
     auto deliver = [&](int used) {
-        for (int t = 0; t < used; t++) {
+        for (int t = 0; t < used && !stopped; t++) {
             PackedRun& r = runs[t];
             n_records += r.records;
-            if (!r.lens.empty()) sink.on_packed(r.words.data(), r.lens.data(), r.lens.size(), r.min_len, r.max_len);
+            if (!r.lens.empty() && !on_run(r)) stopped = true;
         }
     };
     auto parse_all = [&]() {
@@ -375,13 +382,14 @@ long long stream_reads_parallel(const InputFile& in, ReadSink& sink, bool fastq,
             // the file ended on a chunk boundary: the reference parses its previous buffer again and loses the tail it
             // had cached (prlHashReads.c:873-877)
             fprintf(stderr, "Warning : aio_return zero, the size of input file must be N * 32768.\n");
-            if (any) {
+            if (any && !stopped) {
                 runs[0].clear();
                 parse_range(in, fastq, last_buf.data(), last_buf.size(), codes[0], runs[0]);
                 deliver(1);
             }
             break;
         }
+        if (stopped) break;
         any = true;
         const size_t n_full = got / CHUNK, rem = got % CHUNK;
         cuts.assign(n_full, 0);
@@ -404,6 +412,7 @@ long long stream_reads_parallel(const InputFile& in, ReadSink& sink, bool fastq,
         }
         if (rem) bufs.emplace_back(begin, carry + got);       // the short last chunk goes out whole, behind the cached tail
         if (rem) { parse_all(); break; }
+        if (stopped) break;
         last_buf.assign(win.data() + bufs.back().first, bufs.back().second - bufs.back().first);
         const size_t tail = carry + got - begin;
         next_win.resize(tail + window_chunks * CHUNK);
@@ -422,6 +431,88 @@ long long stream_reads_parallel(const InputFile& in, ReadSink& sink, bool fastq,
     }
     src.close();
     if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "reader: %.2fs parsing + handing over, %.2fs more waiting for the file (%d threads)\n", t_parse, t_wait, nt);
+    return n_records;
+}
+
+long long stream_reads_parallel(const InputFile& in, ReadSink& sink, bool fastq, int nt, size_t window_chunks) {
+    return stream_file_parallel(in, in.path1, fastq, nt, window_chunks, [&](PackedRun& r) {
+        sink.on_packed(r.words.data(), r.lens.data(), r.lens.size(), r.min_len, r.max_len);
+        return true;
+    });
+}
+
+// Mate files (f1/f2, q1/q2): the reference takes one read from file 1, one from file 2, and so on, stops when file 2
+// is used up and fails when file 1 runs dry first (prlHashReads.c:464-609).  Each file is parsed by its own group of
+// threads into a short queue of runs; the caller's thread interleaves them read by read.
+struct RunQueue {
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<PackedRun> q;
+    bool done = false, cancel = false;
+    bool push(PackedRun& r) {                            // producer; false = the consumer went away
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return q.size() < 4 || cancel; });
+        if (cancel) return false;
+        q.emplace_back();
+        std::swap(q.back(), r);
+        cv.notify_all();
+        return true;
+    }
+    bool pop(PackedRun& r) {                             // consumer; false = the stream is over
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return !q.empty() || done; });
+        if (q.empty()) return false;
+        std::swap(r, q.front());
+        q.pop_front();
+        cv.notify_all();
+        return true;
+    }
+    void finish() { std::lock_guard<std::mutex> lk(m); done = true; cv.notify_all(); }
+    void stop() { std::lock_guard<std::mutex> lk(m); cancel = true; cv.notify_all(); }
+};
+
+long long stream_mates_parallel(const InputFile& in, ReadSink& sink, bool fastq, int nt, size_t window_chunks) {
+    RunQueue qa, qb;
+    const int nta = std::max(1, nt / 2), ntb = std::max(1, nt - nta);
+    std::thread ta([&]() { stream_file_parallel(in, in.path1, fastq, nta, window_chunks, [&](PackedRun& r) { return qa.push(r); }); qa.finish(); });
+    std::thread tb([&]() { stream_file_parallel(in, in.path2, fastq, ntb, window_chunks, [&](PackedRun& r) { return qb.push(r); }); qb.finish(); });
+    PackedRun a, b, out;
+    size_t ia = 0, ib = 0, wa = 0, wb = 0;               // next read and its first word in the current runs
+    bool have_a = false, have_b = false;
+    long long n_records = 0;
+    auto next_a = [&]() { while (!have_a || ia >= a.lens.size()) { if (!qa.pop(a)) { have_a = false; return false; } have_a = true; ia = 0; wa = 0; } return true; };
+    auto next_b = [&]() { while (!have_b || ib >= b.lens.size()) { if (!qb.pop(b)) { have_b = false; return false; } have_b = true; ib = 0; wb = 0; } return true; };
+    auto take = [&](PackedRun& r, size_t& i, size_t& w) {
+        const int len = r.lens[i];
+        const size_t nw = ((size_t)len + 31) / 32;
+        out.words.insert(out.words.end(), r.words.begin() + (long)w, r.words.begin() + (long)(w + nw));
+        out.lens.push_back(len);
+        out.min_len = std::min(out.min_len, len); out.max_len = std::max(out.max_len, len);
+        i++; w += nw; n_records++;
+    };
+    auto flush = [&]() {
+        if (!out.lens.empty()) sink.on_packed(out.words.data(), out.lens.data(), out.lens.size(), out.min_len, out.max_len);
+        out.clear();
+    };
+    bool fail = false;
+    for (;;) {
+        const bool more_a = next_a(), more_b = next_b();
+        if (!more_a && !more_b) break;
+        if (!more_a) { fail = true; break; }             // file 1 ran dry while file 2 still has reads
+        take(a, ia, wa);
+        if (!more_b) { fail = true; break; }             // ... and the other way round, after file 1's read went out
+        take(b, ib, wb);
+        if (out.lens.size() >= (1u << 18)) flush();
+        if (!next_b()) break;                            // file 2 used up: the reference stops here
+    }
+    flush();
+    qa.stop(); qb.stop();
+    ta.join(); tb.join();
+    if (fail) {
+        fprintf(stderr, "readseqInLib return error! please make sure input file is correct fastq/fasta file \n");
+        fprintf(stderr, "invalid data left in buffer:\n\n");
+        exit(-1);
+    }
     return n_records;
 }
 
@@ -451,7 +542,18 @@ long long stream_reads(const InputFile& in, ReadSink& sink) {
         n_records++;
         sink.on_read(codes.data(), n);
     };
+    int par_threads = host_threads(0);
+    if (const char* e = getenv("SOAPDENOVO2_AMD_PARSE_THREADS")) { const int v = atoi(e); if (v > 0) par_threads = v; }
+    size_t par_window = 4096;                                    // 128 MiB of text at a time
+    if (const char* e = getenv("SOAPDENOVO2_AMD_PARSE_WINDOW")) { const long v = atol(e); if (v > 0) par_window = (size_t)v; }
+    size_t par_min_bytes = (size_t)8 << 20;
+    if (const char* e = getenv("SOAPDENOVO2_AMD_PARSE_PARALLEL_MIN")) par_min_bytes = (size_t)atol(e);
+    auto is_big = [&](const std::string& path) {
+        struct stat st;
+        return stat(path.c_str(), &st) != 0 || (size_t)st.st_size >= par_min_bytes || !S_ISREG(st.st_mode);
+    };
     if (in.type == 1 || in.type == 2) {
+        if (par_threads > 1 && is_big(in.path1)) return stream_mates_parallel(in, sink, fastq, par_threads, par_window);
         // mate files: reads alternate file 1, file 2, ... (prlHashReads.c:464-609)
         ChunkStream s1(in.path1, fastq), s2(in.path2, fastq);
         bool ok1 = s1.next(), ok2 = s2.next();
@@ -475,17 +577,8 @@ long long stream_reads(const InputFile& in, ReadSink& sink) {
         }
         return n_records;
     }
-    {   // single file: all host threads, unless the file is small (or SOAPDENOVO2_AMD_PARSE_THREADS=1)
-        int nt = host_threads(0);
-        if (const char* e = getenv("SOAPDENOVO2_AMD_PARSE_THREADS")) { const int v = atoi(e); if (v > 0) nt = v; }
-        size_t window = 4096;                                    // 128 MiB of text at a time
-        if (const char* e = getenv("SOAPDENOVO2_AMD_PARSE_WINDOW")) { const long v = atol(e); if (v > 0) window = (size_t)v; }
-        size_t min_bytes = (size_t)8 << 20;
-        if (const char* e = getenv("SOAPDENOVO2_AMD_PARSE_PARALLEL_MIN")) min_bytes = (size_t)atol(e);
-        struct stat st;
-        const bool big = stat(in.path1.c_str(), &st) != 0 || (size_t)st.st_size >= min_bytes || !S_ISREG(st.st_mode);
-        if (nt > 1 && big) return stream_reads_parallel(in, sink, fastq, nt, window);
-    }
+    // single file: all host threads, unless the file is small (or SOAPDENOVO2_AMD_PARSE_THREADS=1)
+    if (par_threads > 1 && is_big(in.path1)) return stream_reads_parallel(in, sink, fastq, par_threads, par_window);
     ChunkStream s(in.path1, fastq);
     while (s.next()) {
         size_t start = 0;

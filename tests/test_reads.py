@@ -73,3 +73,31 @@ def test_parallel_reader_delivers_the_same_reads(tmp_path, threads, window):
         assert got[2] == want[2] and got[3] == want[3], cfg
         assert np.array_equal(got[1], want[1]), cfg
         assert np.array_equal(got[0], want[0]), cfg
+
+
+def test_parallel_mate_reader_stops_with_file_two(tmp_path):
+    """q1 longer than q2: the reference stops when file 2 is used up; the multi-threaded mate reader must do the same."""
+    import os
+    import numpy as np
+    a = synth.reads_codes(20000, 1500, 80, 0.004, 21)
+    b = synth.reads_codes(20000, 1100, 80, 0.004, 22)
+    p = lambda f: os.path.abspath(os.path.join(str(tmp_path), f))
+    synth.write_fastq(p("m_1.fq"), a, name_prefix="a")
+    synth.write_fastq(p("m_2.fq"), b, name_prefix="b")
+    cfg = p("m.cfg")
+    open(cfg, "w").write(f"max_rd_len=80\n[LIB]\navg_ins=300\nasm_flags=3\nq1={p('m_1.fq')}\nq2={p('m_2.fq')}\n")
+    os.environ["SOAPDENOVO2_AMD_PARSE_THREADS"] = "1"
+    try:
+        want = api.host_read_all(cfg, 31)
+    finally:
+        del os.environ["SOAPDENOVO2_AMD_PARSE_THREADS"]
+    knobs = {"SOAPDENOVO2_AMD_PARSE_PARALLEL_MIN": "0", "SOAPDENOVO2_AMD_PARSE_THREADS": "4", "SOAPDENOVO2_AMD_PARSE_WINDOW": "2"}
+    os.environ.update(knobs)
+    try:
+        got = api.host_read_all(cfg, 31)
+    finally:
+        for k in knobs:
+            del os.environ[k]
+    assert want[2] == 2200 and got[2] == want[2]
+    assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
+    assert np.array_equal(got[0][0::2], a[:1100]) and np.array_equal(got[0][1::2], b)
