@@ -46,18 +46,6 @@ PG_HD Kmer<NW> canonical_occurrence(const uint64_t* rd, int j, int len, int K,
     return bal;
 }
 
-// The same decision for a forward / reverse-complement pair that is already at hand (rolling walks).
-template <int NW>
-PG_HD Kmer<NW> canonical_pair(const Kmer<NW>& word, const Kmer<NW>& bal, int prev, int next, Occurrence& occ) {
-    if (kmer_less<NW>(word, bal)) {
-        occ.left = prev; occ.right = next;
-        return word;
-    }
-    occ.left = next < 4 ? (next ^ 2) : 4;
-    occ.right = prev < 4 ? (prev ^ 2) : 4;
-    return bal;
-}
-
 // advance a forward / reverse-complement pair by one base b (nextKmer / prevKmer, kmer.c:696-718)
 template <int NW>
 PG_HD void kmer_roll(Kmer<NW>& word, Kmer<NW>& bal, int b, int K, const Kmer<NW>& filter) {
