@@ -391,3 +391,25 @@ def test_cli_falls_back_to_the_global_set_on_a_skewed_partition(golden, tmp_path
     for ext in ("kmerFreq", "preGraphBasic", "vertex", "preArc"):
         assert md5_file(pre + "." + ext) == want[ext], ext
     assert md5_gz_text(pre + ".edge.gz") == want["edge"]
+
+
+@pytest.mark.parametrize("opts", [["-K", "30"], ["-K", "11"], ["-K", "65"], ["-K", "25", "-p", "1"], ["-K", "31", "-d", "2", "-R", "-p", "5"],
+                                  ["-K", "41", "-a", "1", "-p", "3"]])
+def test_cli_option_semantics_against_the_reference_binary(tmp_path, opts):
+    """Option handling that leaks into the bytes (even K -> K + 1, K < 13 -> 13, K > 63 -> 63, -p 1, -d with -R, -a):
+    the executable and the reference binary (oracle/_ref travels with the snapshot) on the same small input."""
+    from soapdenovo2_amd import api, synth
+    ref = os.path.join(ROOT, "oracle", "_ref", "SOAPdenovo-63mer")
+    if not os.path.exists(ref):
+        pytest.skip("reference binary not built")
+    cfg = synth.make_case(str(tmp_path), "opt", 25000, 5000, 90, 0.006, 1234)
+    outs = {}
+    for tag, binary in (("amd", api.binary(False)), ("ref", ref)):
+        pre = str(tmp_path / tag)
+        r = subprocess.run([binary, "pregraph", "-s", cfg, "-o", pre] + opts, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0, (tag, r.stderr[-1500:])
+        outs[tag] = pre
+    exts = ["kmerFreq", "preGraphBasic", "vertex", "preArc"] + (["path", "markOnEdge"] if "-R" in opts else [])
+    for ext in exts:
+        assert md5_file(outs["amd"] + "." + ext) == md5_file(outs["ref"] + "." + ext), (opts, ext)
+    assert md5_gz_text(outs["amd"] + ".edge.gz") == md5_gz_text(outs["ref"] + ".edge.gz"), opts
