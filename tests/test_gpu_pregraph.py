@@ -413,3 +413,26 @@ def test_cli_option_semantics_against_the_reference_binary(tmp_path, opts):
     for ext in exts:
         assert md5_file(outs["amd"] + "." + ext) == md5_file(outs["ref"] + "." + ext), (opts, ext)
     assert md5_gz_text(outs["amd"] + ".edge.gz") == md5_gz_text(outs["ref"] + ".edge.gz"), opts
+
+
+@pytest.mark.parametrize("kind", ["empty", "all_short"])
+def test_cli_degenerate_inputs_against_the_reference_binary(tmp_path, kind):
+    """No read at all / no read of K + 1 bases: both binaries must finish and write the same (empty) graph."""
+    from soapdenovo2_amd import api, synth
+    ref = os.path.join(ROOT, "oracle", "_ref", "SOAPdenovo-63mer")
+    if not os.path.exists(ref):
+        pytest.skip("reference binary not built")
+    fq = str(tmp_path / "d.fq")
+    if kind == "empty":
+        open(fq, "w").close()
+    else:
+        synth.write_fastq(fq, synth.reads_codes(5000, 300, 25, 0.0, 3))
+    cfg = str(tmp_path / "d.cfg")
+    open(cfg, "w").write(f"max_rd_len=100\n[LIB]\navg_ins=200\nasm_flags=3\nq={fq}\n")
+    for tag, binary in (("amd", api.binary(False)), ("ref", ref)):
+        r = subprocess.run([binary, "pregraph", "-s", cfg, "-K", "31", "-o", str(tmp_path / tag), "-p", "2"], stdout=subprocess.DEVNULL,
+                           stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0, (tag, r.stderr[-1500:])
+    for ext in ("kmerFreq", "preGraphBasic", "vertex", "preArc"):
+        assert md5_file(str(tmp_path / ("amd." + ext))) == md5_file(str(tmp_path / ("ref." + ext))), ext
+    assert md5_gz_text(str(tmp_path / "amd.edge.gz")) == md5_gz_text(str(tmp_path / "ref.edge.gz"))
