@@ -323,11 +323,16 @@ __device__ __forceinline__ bool lds_put(LdsSet<NW, SLOTS>& t, const Key63<NW>& k
     constexpr int KW = E2Cfg<NW>::KW;
     uint32_t h = (uint32_t)hash & (SLOTS - 1);
     for (int probes = 0; probes < K2_MAXPROBE; probes++) {
+        // all key words of the slot are fetched together (one LDS round trip for the usual case, a hit); only a word
+        // that is still empty goes through the claiming CAS
+        unsigned long long seen[KW];
+#pragma unroll
+        for (int i = 0; i < KW; i++) seen[i] = t.key[i][h];
         bool mine = true;
 #pragma unroll
         for (int i = 0; i < KW; i++) {
             if (!mine) break;
-            unsigned long long cur = t.key[i][h];
+            unsigned long long cur = seen[i];
             if (cur == L_EMPTY) {
                 const unsigned long long old = atomicCAS(&t.key[i][h], L_EMPTY, (unsigned long long)key.w[i]);
                 cur = old == L_EMPTY ? (unsigned long long)key.w[i] : old;
