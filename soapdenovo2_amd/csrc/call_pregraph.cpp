@@ -316,14 +316,14 @@ int run(int argc, char** argv, bool mer127) {
             est_kmers += (uint64_t)bases;
         }
     if (o.a_gb == 0) {
-        // the export array: room for one distinct k-mer per 16 occurrences (it is enlarged and the partitions are
+        // the export array: room for one distinct k-mer per 6 occurrences (it is enlarged and the partitions are
         // counted again when that is too little), but never more than a third of the device memory -- the record pool
         // needs the rest
         size_t free_b = 0, total_b = 0;
         HIP_OK(hipSetDevice(device));
         HIP_OK(hipMemGetInfo(&free_b, &total_b));
         const double rec_bytes = (mer127 ? 6 : 4) * 8.0;
-        while (log2_slots < 34 && (double)((uint64_t)1 << log2_slots) * 0.7 < (double)est_kmers / 16.0 &&
+        while (log2_slots < 34 && (double)((uint64_t)1 << log2_slots) * 0.7 < (double)est_kmers / 6.0 &&
                (double)((uint64_t)2 << log2_slots) * 0.7 * rec_bytes <= (double)total_b / 3.0)
             log2_slots++;
     }
