@@ -7,7 +7,7 @@ CXX     ?= g++
 CXXFLAGS := -O3 -std=c++17 -fPIC -Wall -Wno-unknown-pragmas -Wno-unused-function -Wno-unused-result -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value
 HOSTOBJ := $(CSRC)/host_graph.o $(CSRC)/host_reads.o $(CSRC)/call_pregraph.o
-DEVOBJ  := $(CSRC)/pregraph_kernels.o $(CSRC)/partition_kernels.o $(CSRC)/pass2_kernels.o $(CSRC)/sort_records.o
+DEVOBJ  := $(CSRC)/pregraph_kernels.o $(CSRC)/partition_kernels.o $(CSRC)/graph_kernels.o $(CSRC)/sort_records.o
 HDRS    := $(wildcard $(CSRC)/*.hpp) include/soapdenovo2_amd.h
 
 all: $(OUT)/libsoapdenovo2_amd.so $(OUT)/bin/SOAPdenovo-63mer $(OUT)/bin/SOAPdenovo-127mer

@@ -1,4 +1,4 @@
-// pass2.hpp -- seam between the host graph (host_graph.cpp, g++) and the device pass 2 (pass2_kernels.hip, hipcc).
+// graph_dev.hpp -- seam between the host graph (host_graph.cpp, g++) and the device stages (graph_kernels.hip, hipcc).
 #pragma once
 #include <stdint.h>
 

@@ -1,11 +1,13 @@
-// pass2_kernels.hip -- pass 2 of pregraph on the device: every read is threaded through the finished edges and the
-// pre-arcs are accumulated in HBM (prlRead2edge, standardPregraph/prlRead2path.c:786-1370).
+// graph_kernels.hip -- the graph stages of pregraph that run on the device, on one copy of the k-mer sets in HBM:
+//   tip_*   the walks of tip clipping                 (clipTipFromNode, cutTipPreGraph.c:43-346)
+//   eb_*    edge construction                         (make_edge / stringBeads / merge_linearV2, node2edge.c:61-649)
+//   p2_*    pass 2: read threading and the pre-arcs   (prlRead2edge, prlRead2path.c:786-1370)
+// The sets come over exactly as the host's layout replay left them (slot arrays in the reference's own layout, an empty
+// slot carries an impossible key), so every lookup is the reference's: set = signext(crc32) % thrd_num, slot = key mod
+// size, linear probing (newhash.c:277-318).
 //
-// What the reference does with a 100 M-k-mer buffer and thrd_num threads per batch (chopKmer4read, searchKmer,
-// parse1read, search1kmerPlus, thread_add1preArc, recordPathBin) is one kernel here, one lane per read:
-//   * the k-mer sets come over exactly as the host stages left them (slot arrays in the reference's own layout,
-//     an empty slot carries an impossible key), so a lookup is the reference's: set = signext(crc32) % thrd_num,
-//     slot = key mod size, linear probing (newhash.c:277-318);
+// Pass 2, one lane per read: what the reference does with a 100 M-k-mer buffer and thrd_num threads per batch
+// (chopKmer4read, searchKmer, parse1read, search1kmerPlus, thread_add1preArc, recordPathBin) is one kernel:
 //   * parse1read's little state machine (prlRead2path.c:598-745) runs in registers; the (K+1)-mers of branch-to-branch
 //     steps are resolved on the spot in a device copy of KmerSetsPatch;
 //   * a pre-arc list is ordered by the first time each target was met (new targets go to the head,
@@ -28,7 +30,7 @@
 #include "device_ctx.hpp"
 #include "extract.hpp"
 #include "kmer.hpp"
-#include "pass2.hpp"
+#include "graph_dev.hpp"
 
 namespace pg {
 

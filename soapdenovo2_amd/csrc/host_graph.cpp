@@ -32,7 +32,7 @@
 
 #include "kmer.hpp"
 #include "host_graph.hpp"
-#include "pass2.hpp"
+#include "graph_dev.hpp"
 #include "../../include/soapdenovo2_amd.h"
 
 namespace pg {
@@ -341,7 +341,7 @@ template <int NW>
 struct Graph {
     int K, P;
     int n_threads = 0;             // host threads for the parallel scans (0 = all)
-    // with the sets mirrored in HBM the tip walks run there (pass2_kernels.hip: tip_walk_kernel); the host keeps the
+    // with the sets mirrored in HBM the tip walks run there (graph_kernels.hip: tip_walk_kernel); the host keeps the
     // order-dependent replay and sends the nodes it changed back
     P2Device* tip_dev = nullptr;
     std::vector<uint64_t> set_base;   // global slot of every set's slot 0 (+ the total)
@@ -1441,7 +1441,7 @@ struct GraphHandle : GraphHandleBase {
     std::vector<Scratch> scratch;
     static double now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
-    // pass 2 on a HIP device (pass2_kernels.hip) instead of the host threads
+    // pass 2 on a HIP device (graph_kernels.hip) instead of the host threads
     bool dev_on = false;
     int dev_id = 0;
     P2Device* dev = nullptr;
@@ -1464,7 +1464,7 @@ struct GraphHandle : GraphHandleBase {
         return PG_OK;
     }
     int max_nk() const { return std::max(1, max_read_len - g.K + 1); }
-    // edges on the device (pass2_kernels.hip: eb_*): upload the sets, build, then format output_1edge's text here
+    // edges on the device (graph_kernels.hip: eb_*): upload the sets, build, then format output_1edge's text here
     // the k-mer sets into HBM as they are now (after the layout replay: the tips then walk on the device copy)
     int dev_open(int device) {
         dev_on = true; dev_id = device;

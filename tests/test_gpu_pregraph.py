@@ -302,7 +302,7 @@ def test_cli_reader_corner_cases(golden, tmp_path):
 
 @pytest.mark.parametrize("name", ["t6k_k31", "t8k_k63", "t6k_k127", "t5k_k24", "m60k_k63"])
 def test_device_pass2_matches_reference(golden, tmp_path, name):
-    """pg_graph_use_device: read -> edge threading and the pre-arc table on the GPU (pass2_kernels.hip), fed with the
+    """pg_graph_use_device: read -> edge threading and the pre-arc table on the GPU (graph_kernels.hip), fed with the
     oracle's pass-1 records: .preArc, and with -R .path / .markOnEdge, byte for byte as the reference wrote them."""
     from conftest import case_codes, oracle_records
     from soapdenovo2_amd import api
