@@ -408,17 +408,36 @@ int run(int argc, char** argv, bool mer127) {
         size_t size() const { return words; }
         ~HostRecords() { release(); }
     } records;
-    records.alloc((size_t)n_distinct * rw + 1);
+    // Records in replay order stay on the device and are pulled set by set, chunk by chunk, while the layout is rebuilt
+    // (pg_graph_begin_streamed); beyond 2^31 records, or with SOAPDENOVO2_AMD_STREAM_RECORDS=0, they are downloaded whole.
+    bool stream_records = n_distinct > 0 && n_distinct < 0x7fffffffULL;
+    if (const char* e = getenv("SOAPDENOVO2_AMD_STREAM_RECORDS")) stream_records = stream_records && atoi(e) != 0;
+    uint64_t* d_rec = nullptr;
+    std::vector<uint64_t> per_set(o.sets, 0);
     if (n_distinct) {
-        uint64_t* d_rec = nullptr;
         HIP_OK(hipMalloc((void**)&d_rec, (size_t)n_distinct * rw * sizeof(uint64_t)));
         uint64_t got = 0;
         if (pg_export(ctx, d_rec, n_distinct, &got, nullptr) != PG_OK) die("pg_export");
         if (got != n_distinct) { fprintf(stderr, "export count mismatch\n"); exit(-1); }
         // replay order (set, first occurrence) on the device; beyond 2^31 records the host sorts instead
         if (n_distinct < 0x7fffffffULL && pg_sort_records(d_rec, n_distinct, mer127 ? 1 : 0, nullptr) != PG_OK) die("pg_sort_records");
-        HIP_OK(hipMemcpy(records.data(), d_rec, (size_t)n_distinct * rw * sizeof(uint64_t), hipMemcpyDeviceToHost));
-        hipFree(d_rec);
+        if (stream_records) {
+            // where every set starts: binary search over the sorted tags (a few hundred 8-byte copies)
+            auto set_of_record = [&](uint64_t i) { uint64_t tag = 0; HIP_OK(hipMemcpy(&tag, d_rec + i * rw + rw - 1, sizeof tag, hipMemcpyDeviceToHost)); return tag >> 56; };
+            std::vector<uint64_t> start(o.sets + 1, n_distinct);
+            start[0] = 0;
+            for (int sidx = 1; sidx < o.sets; sidx++) {               // first record whose set id is >= sidx
+                uint64_t lo = start[sidx - 1], hi = n_distinct;
+                while (lo < hi) { const uint64_t mid = (lo + hi) / 2; if (set_of_record(mid) >= (uint64_t)sidx) hi = mid; else lo = mid + 1; }
+                start[sidx] = lo;
+            }
+            for (int sidx = 0; sidx < o.sets; sidx++) per_set[sidx] = start[sidx + 1] - start[sidx];
+        } else {
+            records.alloc((size_t)n_distinct * rw + 1);
+            HIP_OK(hipMemcpy(records.data(), d_rec, (size_t)n_distinct * rw * sizeof(uint64_t), hipMemcpyDeviceToHost));
+            hipFree(d_rec);
+            d_rec = nullptr;
+        }
     }
     pg_destroy(ctx);
     lap("export + download records");
@@ -430,8 +449,20 @@ int run(int argc, char** argv, bool mer127) {
     if (const char* e = getenv("SOAPDENOVO2_AMD_EDGES")) host_edges = strcmp(e, "host") == 0;
     if (const char* e = getenv("SOAPDENOVO2_AMD_PASS2")) host_pass2 = strcmp(e, "host") == 0;
     if (host_pass2) host_edges = true;                               // host pass 2 needs the host copy of the sets tagged
-    pg_graph* graph = pg_graph_begin(records.data(), n_distinct, set_last.data(), K, mer127 ? 1 : 0, o.sets, o.delow == 0, o.a_gb,
-                                     max_read_len, 0, o.prefix.c_str(), host_edges ? -1 : device);
+    struct Fetch {
+        const uint64_t* d_rec; int rw, device;
+        static int call(void* user, uint64_t first, uint64_t n, uint64_t* dst) {
+            const Fetch* f = (const Fetch*)user;
+            if (hipSetDevice(f->device) != hipSuccess) return PG_ENODEV;
+            return hipMemcpy(dst, f->d_rec + first * f->rw, n * f->rw * sizeof(uint64_t), hipMemcpyDeviceToHost) == hipSuccess ? PG_OK : PG_ENODEV;
+        }
+    } fetch{d_rec, rw, device};
+    pg_graph* graph = stream_records
+        ? pg_graph_begin_streamed(&Fetch::call, &fetch, n_distinct, per_set.data(), set_last.data(), K, mer127 ? 1 : 0, o.sets, o.delow == 0, o.a_gb,
+                                  max_read_len, 0, o.prefix.c_str(), host_edges ? -1 : device)
+        : pg_graph_begin(records.data(), n_distinct, set_last.data(), K, mer127 ? 1 : 0, o.sets, o.delow == 0, o.a_gb,
+                         max_read_len, 0, o.prefix.c_str(), host_edges ? -1 : device);
+    if (d_rec) { hipFree(d_rec); d_rec = nullptr; }
     if (!graph) die("pg_host_graph_begin");
     if (o.reps && pg_host_graph_resolve_repeats(graph, 1) != PG_OK) die("pg_host_graph_resolve_repeats");
     if (!host_pass2 && pg_graph_use_device(graph, device) != PG_OK) die("pg_graph_use_device");

@@ -1238,6 +1238,83 @@ static int replay_layout(Graph<NW>& g, const uint64_t* records, uint64_t n, cons
     return PG_OK;
 }
 
+// The same replay for records that are still on the device, already in replay order (pg_sort_records): every set's
+// worker pulls its stretch chunk by chunk through `fetch` (a device-to-host copy) and inserts while the other workers'
+// copies are in flight, so neither a host copy of all records nor a separate download phase is needed.
+typedef int (*pg_fetch_fn)(void* user, uint64_t first_record, uint64_t n_records, uint64_t* dst);
+template <int NW>
+static int replay_streamed(Graph<NW>& g, pg_fetch_fn fetch, void* user, uint64_t n, const uint64_t* per_set_count, const uint64_t* set_last_put,
+                           int K, int P, int a_gb, int n_threads) {
+    constexpr int RW = NW + 2;
+    g.K = K; g.P = P; g.filter = kmer_filter<NW>(K); g.bias = set_bias((uint32_t)P); g.crc = host_crc_table();
+    host_crc8_init();
+    g.n_threads = n_threads;
+    g.sets.clear();
+    g.sets.resize(P);
+    std::vector<uint64_t> first(P + 1, 0);
+    for (int s = 0; s < P; s++) first[s + 1] = first[s] + per_set_count[s];
+    if (first[P] != n) { pg_set_error("per-set counts do not add up to the record count"); return PG_EINVAL; }
+    const uint64_t init_size = ref_initial_set_size(a_gb, P, NW == 4);
+    const bool verbose = getenv("PG_HOST_VERBOSE") != nullptr;
+    auto nowf = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    std::atomic<int> next{0}, failed{0};
+    auto worker = [&]() {
+        const uint64_t CHUNK = (uint64_t)1 << 21;                           // records a copy (64 / 96 MiB)
+        HugeArray<uint64_t> buf;
+        for (;;) {
+            const int s = next.fetch_add(1);
+            if (s >= P) break;
+            const double ts0 = nowf();
+            double t_fetch = 0;
+            HSet<NW>& hs = g.sets[s];
+            const uint64_t cnt_all = per_set_count[s];
+            hs.init(init_size, HSet<NW>::final_size(init_size, cnt_all + 1, a_gb != 0));
+            if (cnt_all && !buf.p) buf.reset(std::min(CHUNK, cnt_all) * RW + 8);
+            uint64_t last_ord = 0, prev_tag = 0;
+            for (uint64_t at = 0; at < cnt_all && !failed.load(); at += CHUNK) {
+                const int64_t cnt = (int64_t)std::min(CHUNK, cnt_all - at);
+                const double tf0 = nowf();
+                if (fetch(user, first[s] + at, (uint64_t)cnt, buf.data()) != PG_OK) { failed.store(1); break; }
+                t_fetch += nowf() - tf0;
+                const uint64_t* recs = buf.data();
+                constexpr int AHEAD = 16;
+                uint64_t ring_home[AHEAD], ring_size[AHEAD];
+                for (int i = 0; i < AHEAD; i++) ring_size[i] = 0;
+                auto key_of = [&](int64_t i) { Kmer<NW> k; for (int w = 0; w < NW; w++) k.w[w] = recs[i * RW + w]; return k; };
+                for (int64_t i = 0; i < std::min<int64_t>(cnt, AHEAD); i++) { ring_home[i] = hs.home(key_of(i)); ring_size[i] = hs.size; hs.prefetch_put(ring_home[i]); }
+                for (int64_t i = 0; i < cnt; i++) {
+                    const uint64_t* rec = recs + i * RW;
+                    const uint64_t tag = rec[NW + 1];
+                    if ((tag >> PG_ORD_BITS) != (uint64_t)s || (tag < prev_tag && (at || i))) { failed.store(2); break; }   // not in replay order
+                    prev_tag = tag;
+                    HNode<NW> nd;
+                    for (int w = 0; w < NW; w++) nd.seq.w[w] = rec[w];
+                    nd.A = (uint32_t)rec[NW];
+                    nd.B = (uint32_t)(rec[NW] >> 32);
+                    hs.before_put(a_gb != 0);
+                    const int slot = (int)(i % AHEAD);
+                    hs.put_new_at(nd, ring_size[slot] == hs.size ? ring_home[slot] : hs.home(nd.seq));
+                    if (i + AHEAD < cnt) { ring_home[slot] = hs.home(key_of(i + AHEAD)); ring_size[slot] = hs.size; hs.prefetch_put(ring_home[slot]); }
+                    last_ord = tag & PG_ORD_MASK;
+                }
+            }
+            // a duplicate put that arrived after the set's last new key still ran the growth test (newhash.c:477)
+            if (cnt_all && set_last_put && set_last_put[s] > last_ord + 1) hs.before_put(a_gb != 0);
+            if (verbose) fprintf(stderr, "replay set %d: %llu keys, copies %.2fs, inserts %.2fs (of which growing %.2fs)\n", s, (unsigned long long)cnt_all, t_fetch,
+                                 nowf() - ts0 - t_fetch, hs.t_grow);
+        }
+    };
+    int nt = pick_threads(n_threads);
+    nt = std::max(1, std::min(nt, P));
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; t++) pool.emplace_back(worker);
+    worker();
+    for (auto& t : pool) t.join();
+    if (failed.load() == 2) { pg_set_error("streamed records are not ordered by (set, ordinal)"); return PG_EINVAL; }
+    if (failed.load()) return PG_ENODEV;
+    return PG_OK;
+}
+
 template <int NW>
 static int layout_only(const uint64_t* records, uint64_t n, const uint64_t* set_last_put, int P, int a_gb, uint64_t* out_slot,
                        uint64_t* out_size) {
@@ -1839,13 +1916,16 @@ struct GraphHandle : GraphHandleBase {
 
 template <int NW>
 static GraphHandleBase* graph_begin(const uint64_t* records, uint64_t n, const uint64_t* set_last_put, int K, int P, int cut_single,
-                                    int a_gb, int max_read_len, int n_threads, const char* prefix_c, int device) {
+                                    int a_gb, int max_read_len, int n_threads, const char* prefix_c, int device,
+                                    pg_fetch_fn fetch = nullptr, void* fetch_user = nullptr, const uint64_t* per_set_count = nullptr) {
     GraphHandle<NW>* h = new GraphHandle<NW>();
     h->prefix = prefix_c;
     h->max_read_len = max_read_len;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t0 = now();
-    if (replay_layout<NW>(h->g, records, n, set_last_put, K, P, a_gb, n_threads) != PG_OK) { delete h; return nullptr; }
+    const int rc_replay = fetch ? replay_streamed<NW>(h->g, fetch, fetch_user, n, per_set_count, set_last_put, K, P, a_gb, n_threads)
+                                : replay_layout<NW>(h->g, records, n, set_last_put, K, P, a_gb, n_threads);
+    if (rc_replay != PG_OK) { delete h; return nullptr; }
     fprintf(stderr, "Time spent on rebuilding the k-mer set layout: %.1fs.\n", now() - t0);
     t0 = now();
     if (device >= 0 && !getenv("SOAPDENOVO2_AMD_TIPS_HOST") && h->dev_open(device) != PG_OK) { delete h; return nullptr; }
@@ -1930,6 +2010,17 @@ extern "C" pg_graph* pg_graph_begin(const uint64_t* records, uint64_t n_records,
 extern "C" int pg_host_graph_resolve_repeats(pg_graph* g, int on) {
     if (!g) { pg_set_error("null argument"); return PG_EINVAL; }
     return ((pg::GraphHandleBase*)g)->resolve_repeats(on);
+}
+extern "C" pg_graph* pg_graph_begin_streamed(int (*fetch)(void*, uint64_t, uint64_t, uint64_t*), void* user, uint64_t n_records,
+                                             const uint64_t* per_set_count, const uint64_t* set_last_put, int K, int mer127, int n_sets,
+                                             int cut_single, int a_gb, int max_read_len, int n_threads, const char* prefix, int device) {
+    if (!fetch || !per_set_count || !prefix) { pg_set_error("null argument"); return nullptr; }
+    const int maxK = mer127 ? 127 : 63;
+    if (K < 13 || K > maxK || !(K & 1)) { pg_set_error("K must be odd and within 13.." + std::to_string(maxK)); return nullptr; }
+    if (n_sets < 1 || n_sets > 255) { pg_set_error("n_sets must be 1..255"); return nullptr; }
+    pg::GraphHandleBase* h = mer127 ? pg::graph_begin<4>(nullptr, n_records, set_last_put, K, n_sets, cut_single, a_gb, max_read_len, n_threads, prefix, device, fetch, user, per_set_count)
+                                    : pg::graph_begin<2>(nullptr, n_records, set_last_put, K, n_sets, cut_single, a_gb, max_read_len, n_threads, prefix, device, fetch, user, per_set_count);
+    return (pg_graph*)h;
 }
 extern "C" int pg_graph_use_device(pg_graph* g, int device) {
     if (!g) { pg_set_error("null argument"); return PG_EINVAL; }
