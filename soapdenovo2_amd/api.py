@@ -39,6 +39,10 @@ def build(verbose: bool = False) -> None:
         raise PgError("build failed:\n" + (out.stdout or "") + (out.stderr or ""))
 
 
+# int fetch(void *user, uint64_t first_record, uint64_t n_records, uint64_t *dst)  (pg_graph_begin_streamed)
+FETCH_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p)
+
+
 def lib() -> C.CDLL:
     """Load the shared library (import torch first when torch is used in the same process, so that both
     share torch's HIP runtime)."""
@@ -65,6 +69,9 @@ def lib() -> C.CDLL:
     L.pg_host_graph_begin.argtypes = [u64p, C.c_uint64, u64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p]
     L.pg_graph_begin.restype = C.c_void_p
     L.pg_graph_begin.argtypes = [u64p, C.c_uint64, u64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]
+    L.pg_graph_begin_streamed.restype = C.c_void_p
+    L.pg_graph_begin_streamed.argtypes = [FETCH_FN, C.c_void_p, C.c_uint64, u64p, u64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_int, C.c_char_p, C.c_int]
     L.pg_host_graph_add_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int]
     L.pg_host_graph_finish.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]
     L.pg_host_graph_resolve_repeats.argtypes = [C.c_void_p, C.c_int]
@@ -188,12 +195,24 @@ def host_build_graph(records: np.ndarray, set_last_put, K: int, n_sets: int, pre
 def host_pregraph_files(records: np.ndarray, set_last_put, codes: np.ndarray, lens, K: int, n_sets: int, prefix: str,
                         mer127: bool = False, cut_single: bool = True, a_gb: int = 0, max_read_len: int = 100, n_threads: int = 0,
                         batches: int = 1, resolve_repeats: bool = False, packed: bool = False,
-                        device: int = -1, device_edges: bool = False):
+                        device: int = -1, device_edges: bool = False, streamed: bool = False):
     """All host stages incl. pass 2: writes .edge.gz .preArc .vertex .preGraphBasic (and, with resolve_repeats, the
     reference's -R files .path and .markOnEdge); returns (n_vertex, n_edge, n_prearc)."""
     records = np.ascontiguousarray(records, dtype=np.uint64)
     slp = np.ascontiguousarray(set_last_put, dtype=np.uint64)
-    if device_edges:                     # edges (and then pass 2) on HIP device `device`
+    if streamed:                         # records handed over through the fetch callback, in replay order
+        rw = records.shape[1]
+        order = np.argsort(records[:, rw - 1], kind="stable")
+        srt = np.ascontiguousarray(records[order])
+        per_set = np.bincount((srt[:, rw - 1] >> np.uint64(56)).astype(np.int64), minlength=n_sets).astype(np.uint64)
+
+        def _fetch(user, first, n, dst):
+            C.memmove(dst, srt[first:].ctypes.data, n * rw * 8)
+            return 0
+        cb = FETCH_FN(_fetch)
+        h = lib().pg_graph_begin_streamed(cb, None, srt.shape[0], per_set.ctypes.data, slp.ctypes.data, K, int(mer127), n_sets, int(cut_single),
+                                          a_gb, max_read_len, n_threads, prefix.encode(), device if device_edges else -1)
+    elif device_edges:                   # edges (and then pass 2) on HIP device `device`
         h = lib().pg_graph_begin(records.ctypes.data, records.shape[0], slp.ctypes.data, K, int(mer127), n_sets, int(cut_single),
                                  a_gb, max_read_len, n_threads, prefix.encode(), device)
     else:

@@ -102,3 +102,22 @@ def test_host_stages_do_not_depend_on_thread_count(golden, tmp_path, n_threads):
         for ext in ("preArc", "vertex", "preGraphBasic", "path", "markOnEdge"):
             assert md5_file(pre + "." + ext) == want[ext], (ext, n_threads, serial)
         assert md5_gz_text(pre + ".edge.gz") == want["edge"], (n_threads, serial)
+
+
+@pytest.mark.parametrize("name", ["t6k_k31", "t6k_k127", "m60k_k63"])
+def test_streamed_records_give_the_same_graph(golden, tmp_path, name):
+    """pg_graph_begin_streamed: records handed over in replay order through a fetch callback (what the executable does
+    with the device-sorted records) -- same layout, same files, incl. the -a pools and the trailing-duplicate growth."""
+    c = golden["cases"][name]
+    codes = case_codes(c)
+    for run in c["runs"]:
+        P, D, a, m = run
+        t = case_tag(name, run)
+        rec, last, K = oracle_records(codes, c["K"], P, D=D, mer127=bool(m), a_gb=a, prefix=str(tmp_path / ("o_" + t)))
+        pre = str(tmp_path / t)
+        api.host_pregraph_files(rec, last, codes, None, K, P, pre, mer127=bool(m), cut_single=(D == 0), a_gb=a, max_read_len=c["L"],
+                                streamed=True)
+        want = golden["md5"][t]
+        assert md5_file(pre + ".vertex") == want["vertex"], t
+        assert md5_file(pre + ".preArc") == want["preArc"], t
+        assert md5_gz_text(pre + ".edge.gz") == want["edge"], t
