@@ -128,7 +128,8 @@ pg_graph *pg_graph_begin(const uint64_t *records, uint64_t n_records, const uint
                          int n_sets, int cut_single, int a_gb, int max_read_len, int n_threads, const char *prefix, int device);
 /* pg_graph_begin for records that are still in device memory, in replay order (pg_sort_records): per_set_count[s] records
  * of set s follow one another; fetch(user, first_record, n_records, dst) copies a stretch of them to host memory (a
- * hipMemcpy in the caller's hands, called from several threads) and returns PG_OK.  Every set's worker pulls and inserts
+ * hipMemcpy in the caller's hands, called from several threads) and returns PG_OK; a call with n_records = 0 tells the
+ * caller that the calling thread will not ask again (e.g. to un-register its destination buffer).  Every set's worker pulls and inserts
  * chunk by chunk, so the download overlaps the layout replay and no host copy of all records is needed. */
 pg_graph *pg_graph_begin_streamed(int (*fetch)(void *user, uint64_t first_record, uint64_t n_records, uint64_t *dst), void *user,
                                   uint64_t n_records, const uint64_t *per_set_count, const uint64_t *set_last_put, int K,

@@ -36,7 +36,7 @@ def main():
         r = subprocess.run([api.binary(False), "pregraph", "-s", cfg, "-K", str(a.kmer), "-o", os.path.join(a.out, tag), "-p", str(a.sets)],
                            capture_output=True, text=True, env=dict(os.environ, PG_HOST_VERBOSE="1", **env))
         res[tag] = {"wall_s": time.time() - t, "rc": r.returncode,
-                    "log": [l for l in r.stderr.splitlines() if "[cli]" in l or "Time spent on" in l or "node(s) allocated" in l or "edge(s)" in l or "pre-arc" in l or "again" in l]}
+                    "log": [l for l in r.stderr.splitlines() if "[cli]" in l or "Time spent on" in l or "replay set" in l or "node(s) allocated" in l or "edge(s)" in l or "pre-arc" in l or "again" in l]}
         if r.returncode == 0:
             res[tag]["md5"] = md5s(os.path.join(a.out, tag))
         else:

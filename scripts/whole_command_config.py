@@ -85,7 +85,7 @@ def main():
                        capture_output=True, text=True, env=dict(os.environ, PG_HOST_VERBOSE="1"))
     res["amd_wall_s"] = time.time() - t
     res["amd_rc"] = r.returncode
-    res["amd_log"] = [l for l in r.stderr.splitlines() if "Time spent" in l or "node(s) allocated" in l or "read(s) processed" in l or "edge(s)" in l or "pre-arc" in l or "tip scan" in l or "[cli]" in l or "edges:" in l or "replay set 0" in l or "reader:" in l]
+    res["amd_log"] = [l for l in r.stderr.splitlines() if "Time spent" in l or "node(s) allocated" in l or "read(s) processed" in l or "edge(s)" in l or "pre-arc" in l or "tip scan" in l or "[cli]" in l or "edges:" in l or "replay set" in l or "reader:" in l]
     if r.returncode == 0:
         res["amd_md5"] = md5s(os.path.join(a.out, "amd"))
     ref = os.path.join(ROOT, "oracle", "_ref", "SOAPdenovo-63mer")

@@ -1303,6 +1303,7 @@ static int replay_streamed(Graph<NW>& g, pg_fetch_fn fetch, void* user, uint64_t
             if (verbose) fprintf(stderr, "replay set %d: %llu keys, copies %.2fs, inserts %.2fs (of which growing %.2fs)\n", s, (unsigned long long)cnt_all, t_fetch,
                                  nowf() - ts0 - t_fetch, hs.t_grow);
         }
+        fetch(user, 0, 0, nullptr);                                       // this thread will not ask again
     };
     int nt = pick_threads(n_threads);
     nt = std::max(1, std::min(nt, P));
