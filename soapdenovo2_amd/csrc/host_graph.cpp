@@ -343,6 +343,7 @@ struct Graph {
     int n_threads = 0;             // host threads for the parallel scans (0 = all)
     // with the sets mirrored in HBM the tip walks run there (graph_kernels.hip: tip_walk_kernel); the host keeps the
     // order-dependent replay and sends the nodes it changed back
+    std::vector<HugeArray<uint8_t>> touched_map;   // tip scans: one byte a slot, set while a scan runs
     P2Device* tip_dev = nullptr;
     std::vector<uint64_t> set_base;   // global slot of every set's slot 0 (+ the total)
     int tip_error = PG_OK;
@@ -547,10 +548,50 @@ struct Graph {
         }
         const double tt1 = nowt();
         // nodes changed during this scan (one byte a slot; only the slots of clipped tips' ends are ever set)
-        std::vector<std::vector<uint8_t>> touched(sets.size());
-        for (size_t si = 0; si < sets.size(); si++) touched[si].assign(sets[si].size, 0);
+        // (kept across the scans of a run on huge pages and wiped entry by entry afterwards: a fresh zeroed map per scan
+        // costs more than the replay itself on a large graph)
+        if (touched_map.size() != sets.size()) {
+            touched_map.clear();
+            touched_map.resize(sets.size());
+            for (size_t si = 0; si < sets.size(); si++) touched_map[si].reset(sets[si].size + 1);
+        }
+        std::vector<HugeArray<uint8_t>>& touched = touched_map;
+        std::vector<uint64_t> touched_list;
         auto is_touched = [&](int set, const HNode<NW>* n) { return touched[set][(size_t)(n - sets[set].array.data())] != 0; };
-        std::priority_queue<uint64_t, std::vector<uint64_t>, std::greater<uint64_t>> later;
+        // positions to come back to, smallest first.  Millions of them are pending at a time on a large graph, so they wait
+        // unsorted in buckets of 65536 slots and only the bucket the scan is in is kept as a heap.
+        struct LaterQueue {
+            typedef std::priority_queue<uint64_t, std::vector<uint64_t>, std::greater<uint64_t>> Heap;
+            std::vector<std::vector<uint64_t>> bucket;
+            std::vector<size_t> first;                  // first bucket of every set
+            Heap heap;                                  // the pending positions of bucket `cur`
+            size_t cur = 0, pending = 0;
+            size_t index(uint64_t pos) const { return first[pos >> 40] + (size_t)((pos & ((1ULL << 40) - 1)) >> 16); }
+            void push(uint64_t pos) {
+                const size_t b = index(pos);
+                pending++;
+                if (b == cur) { heap.push(pos); return; }
+                if (b < cur) {                          // the heap had run ahead of the scan: put it back
+                    while (!heap.empty()) { bucket[cur].push_back(heap.top()); heap.pop(); }
+                    cur = b;
+                    heap.push(pos);
+                    return;
+                }
+                bucket[b].push_back(pos);
+            }
+            void settle() {
+                while (heap.empty()) {
+                    if (!bucket[cur].empty()) { for (uint64_t x : bucket[cur]) heap.push(x); std::vector<uint64_t>().swap(bucket[cur]); }
+                    else cur++;
+                }
+            }
+            bool empty() const { return pending == 0; }
+            uint64_t top() { settle(); return heap.top(); }
+            void pop() { settle(); heap.pop(); pending--; }
+        } later;
+        later.first.assign(sets.size() + 1, 0);
+        for (size_t si = 0; si < sets.size(); si++) later.first[si + 1] = later.first[si] + (size_t)((sets[si].size >> 16) + 1);
+        later.bucket.resize(later.first[sets.size()] + 1);
         long long removed = 0, rewalked = 0, redecided = 0;
         std::vector<uint64_t> changed;                              // global slots of the nodes this scan changed
         auto node_at = [&](uint64_t pos) -> HNode<NW>& { return sets[pos >> 40].array[pos & ((1ULL << 40) - 1)]; };
@@ -573,6 +614,8 @@ struct Graph {
             touched[nset][pos & ((1ULL << 40) - 1)] = 1;
             const uint64_t fslot = (uint64_t)(d.far - sets[d.far_set].array.data());
             touched[d.far_set][fslot] = 1;
+            touched_list.push_back(pos);
+            touched_list.push_back(((uint64_t)d.far_set << 40) | fslot);
             if (tip_dev) { changed.push_back(set_base[nset] + (pos & ((1ULL << 40) - 1))); changed.push_back(set_base[d.far_set] + fslot); }
             if (d.action != 1) {
                 const uint64_t fpos = ((uint64_t)d.far_set << 40) | fslot;
@@ -614,6 +657,7 @@ struct Graph {
             while (!later.empty() && later.top() == p) later.pop();
             visit(p, nullptr);
         }
+        for (uint64_t tp : touched_list) touched[tp >> 40][tp & ((1ULL << 40) - 1)] = 0;
         if (tip_dev && !changed.empty()) {                          // bring the device copy up to date
             std::vector<uint64_t> ab(changed.size());
             for (size_t i = 0; i < changed.size(); i++) {
