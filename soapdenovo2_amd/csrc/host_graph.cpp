@@ -660,10 +660,18 @@ struct Graph {
         for (uint64_t tp : touched_list) touched[tp >> 40][tp & ((1ULL << 40) - 1)] = 0;
         if (tip_dev && !changed.empty()) {                          // bring the device copy up to date
             std::vector<uint64_t> ab(changed.size());
-            for (size_t i = 0; i < changed.size(); i++) {
-                const int si = (int)(std::upper_bound(set_base.begin(), set_base.end(), changed[i]) - set_base.begin()) - 1;
-                const HNode<NW>& n = sets[si].array[changed[i] - set_base[si]];
-                ab[i] = (uint64_t)n.A | ((uint64_t)n.B << 32);
+            {   // the present counter words of those nodes (random reads: all threads)
+                auto body = [&](int t) {
+                    for (size_t i = changed.size() * t / nt; i < changed.size() * (t + 1) / nt; i++) {
+                        const int si = (int)(std::upper_bound(set_base.begin(), set_base.end(), changed[i]) - set_base.begin()) - 1;
+                        const HNode<NW>& n = sets[si].array[changed[i] - set_base[si]];
+                        ab[i] = (uint64_t)n.A | ((uint64_t)n.B << 32);
+                    }
+                };
+                std::vector<std::thread> pool;
+                for (int t = 1; t < nt; t++) pool.emplace_back(body, t);
+                body(0);
+                for (auto& th : pool) th.join();
             }
             const int rc = p2_mirror_nodes(tip_dev, changed.data(), ab.data(), changed.size());
             if (rc) { tip_error = rc; return removed; }
