@@ -792,21 +792,27 @@ int p2_build_edges(P2Device* d, P2Edges& out) {
     P2_HIP_GOTO(hipMemcpyAsync(cnt, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     P2_HIP_GOTO(hipStreamSynchronize(st));
     n_list = cnt[0];
-    // a vertex has at most eight arcs and every chain is kept from one of its two ends (palindromes aside, which are few)
-    cap_rec = n_list * 5 + 1024;
-    P2_HIP_GOTO(hipMalloc((void**)&d_recs, cap_rec * sizeof(EdgeRec)));
-    if (n_list) {
-        const dim3 grid((unsigned)((n_list * 8 + 255) / 256));
-        if (n_list * 8 / 256 >= 0x7FFFFFFFULL) { pg_set_error("edges: too many vertices for one launch"); rc = PG_EINVAL; goto done; }
-        if (d->nw == 2) hipLaunchKernelGGL(eb_walk<2>, grid, dim3(256), 0, st, d->prm, d_list, n_list, d_recs, cap_rec, d_cnt + 1, d_cnt + 2, d_cnt + 3);
-        else hipLaunchKernelGGL(eb_walk<4>, grid, dim3(256), 0, st, d->prm, d_list, n_list, d_recs, cap_rec, d_cnt + 1, d_cnt + 2, d_cnt + 3);
-        P2_HIP_GOTO(hipGetLastError());
+    // a vertex has at most eight arcs and every chain is kept from one of its two ends (palindromes aside, which are few):
+    // room for five walks a vertex, and a second go with room for all eight should that ever be short
+    if (n_list * 8 / 256 >= 0x7FFFFFFFULL) { pg_set_error("edges: too many vertices for one launch"); rc = PG_EINVAL; goto done; }
+    for (int attempt = 0; attempt < 2; attempt++) {
+        cap_rec = n_list * (attempt ? 8 : 5) + 1024;
+        hipFree(d_recs); d_recs = nullptr;
+        P2_HIP_GOTO(hipMalloc((void**)&d_recs, cap_rec * sizeof(EdgeRec)));
+        P2_HIP_GOTO(hipMemsetAsync(d_cnt + 1, 0, 3 * sizeof(unsigned long long), st));
+        if (n_list) {
+            const dim3 grid((unsigned)((n_list * 8 + 255) / 256));
+            if (d->nw == 2) hipLaunchKernelGGL(eb_walk<2>, grid, dim3(256), 0, st, d->prm, d_list, n_list, d_recs, cap_rec, d_cnt + 1, d_cnt + 2, d_cnt + 3);
+            else hipLaunchKernelGGL(eb_walk<4>, grid, dim3(256), 0, st, d->prm, d_list, n_list, d_recs, cap_rec, d_cnt + 1, d_cnt + 2, d_cnt + 3);
+            P2_HIP_GOTO(hipGetLastError());
+        }
+        P2_HIP_GOTO(hipMemcpyAsync(cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, st));
+        P2_HIP_GOTO(hipStreamSynchronize(st));
+        if (cnt[3]) { pg_set_error("Kmer is not found while building an edge."); rc = PG_EINVAL; goto done; }
+        n_rec = cnt[1];
+        if (n_rec <= cap_rec) break;
     }
-    P2_HIP_GOTO(hipMemcpyAsync(cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, st));
-    P2_HIP_GOTO(hipStreamSynchronize(st));
-    if (cnt[3]) { pg_set_error("Kmer is not found while building an edge."); rc = PG_EINVAL; goto done; }
-    n_rec = cnt[1];
-    if (n_rec > cap_rec) { pg_set_error("edges: more walks than expected (SOAPDENOVO2_AMD_EDGES=host builds them on the host)"); rc = PG_ENOMEM; goto done; }
+    if (n_rec > cap_rec) { pg_set_error("edges: more walks than arcs"); rc = PG_EINVAL; goto done; }
     if (n_rec >= 0x7FFFFFFFULL) { pg_set_error("edges: more than 2^31 - 1 edge records"); rc = PG_EINVAL; goto done; }
     while (patch_cap < 2 * cnt[2] + 2) patch_cap <<= 1;
     hipFree(d->d_patch_keys); hipFree(d->d_patch_val);
