@@ -1,5 +1,5 @@
-// host_graph.cpp -- host stages after pass 1: rebuild the reference's k-mer-set layout from the device's
-// distinct k-mers, then tip clipping, edge construction and the writers.
+// host_graph.cpp -- the graph stages after pass 1, host side: rebuild the reference's k-mer-set layout from the
+// device's distinct k-mers, then tip clipping, edge construction, pass 2 (read threading, pre-arcs) and the writers.
 //
 // Why a layout replay: .vertex and .edge.gz are emitted by walking KmerSets[0..P-1] slot by slot
 // (node2edge.c:383-406, output_pregraph.c:60-75) and tip clipping mutates nodes in that order
@@ -8,8 +8,17 @@
 // (newhash.c:340-528), which depends only on the per-set sequence of distinct keys in first-occurrence
 // order.  The device provides that order (first-occurrence ordinal per key, set id), this file replays it.
 //
-// Everything here is plain C++ (no HIP), templated on NW = words per k-mer (2 = 63-mer binary flavour,
-// 4 = 127-mer flavour).
+// Who does what:
+//   layout replay     here, one thread per set (sequential by construction); records pulled from the device in chunks
+//   tips              walks: graph_kernels.hip (or Graph::tip_walk on all host threads); the order-dependent clipping
+//                     is replayed here in slot order (Graph::tip_scan)
+//   edges             graph_kernels.hip (GraphHandle::dev_build_edges formats the text), or ParallelEdgeBuilder /
+//                     EdgeBuilder on the host
+//   pass 2            graph_kernels.hip (GraphHandle::dev_add_packed / dev_finish), or ReadThreader + PreArcs on the host
+//   writers           .vertex / .preGraphBasic / .edge.gz / .preArc / .path / .markOnEdge
+// The host forms exist for the CPU-only ABI (pg_host_*), the tests that need no GPU and A/B runs; the executable uses the
+// device forms.  Templated on NW = words per k-mer (2 = 63-mer binary flavour, 4 = 127-mer flavour); no HIP in this file
+// (the device stages sit behind graph_dev.hpp).
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
