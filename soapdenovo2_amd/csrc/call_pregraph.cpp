@@ -119,6 +119,70 @@ Options parse_args(int argc, char** argv, bool mer127) {      // initenv, pregra
 
 // Pass 1 driver: reads -> 2-bit packed pinned batches -> hipMemcpyAsync -> pg_count_reads.  Two batches in
 // flight so parsing overlaps the copy + kernel of the previous batch.
+// The accepted reads, 2 bits a base, as pass 1 saw them: pass 2 threads the same reads again (prlRead2edge) and a second
+// go at pass 1 (global-set engine) replays them.  Blocks of 256 MiB on huge pages, whole reads per block, nothing is ever
+// moved or value-initialised.
+struct KeptReads {
+    struct Block {
+        uint64_t* words = nullptr; size_t cap = 0, used = 0, bytes = 0;
+        std::vector<int32_t> lens;
+    };
+    static constexpr size_t BLOCK_WORDS = (size_t)1 << 25;
+    std::vector<Block> blocks;
+    size_t total_bytes = 0;
+    KeptReads() {}
+    KeptReads(const KeptReads&) = delete;
+    KeptReads& operator=(const KeptReads&) = delete;
+    ~KeptReads() { clear(); }
+    void clear() {
+        for (Block& b : blocks) if (b.words) munmap(b.words, b.bytes);
+        blocks.clear();
+        total_bytes = 0;
+    }
+    void swap(KeptReads& o) { blocks.swap(o.blocks); std::swap(total_bytes, o.total_bytes); }
+    size_t reads() const { size_t n = 0; for (const Block& b : blocks) n += b.lens.size(); return n; }
+    bool new_block(size_t min_words) {
+        Block b;
+        b.cap = std::max(BLOCK_WORDS, min_words);
+        b.bytes = b.cap * sizeof(uint64_t);
+        void* q = mmap(nullptr, b.bytes, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+        if (q == MAP_FAILED) return false;
+        madvise(q, b.bytes, MADV_HUGEPAGE);
+        b.words = (uint64_t*)q;
+        b.lens.reserve(b.cap / 4);
+        blocks.push_back(std::move(b));
+        return true;
+    }
+    // n whole reads, nw words in all, back to back; false = out of memory
+    bool append(const uint64_t* w, size_t nw, const int32_t* lens, size_t n) {
+        size_t r = 0, at = 0;
+        while (r < n) {
+            if (blocks.empty() || blocks.back().used == blocks.back().cap) { if (!new_block(0)) return false; }
+            Block& b = blocks.back();
+            size_t take = 0, take_words = 0;
+            if (b.used + (nw - at) <= b.cap) { take = n - r; take_words = nw - at; }            // the rest fits
+            else {
+                while (r + take < n) {
+                    const size_t rw = ((size_t)lens[r + take] + 31) / 32;
+                    if (b.used + take_words + rw > b.cap) break;
+                    take_words += rw; take++;
+                }
+                if (take == 0) {                               // not even one read: this block is done
+                    const size_t rw = ((size_t)lens[r] + 31) / 32;
+                    if (!new_block(rw)) return false;
+                    continue;
+                }
+            }
+            memcpy(b.words + b.used, w + at, take_words * sizeof(uint64_t));
+            b.lens.insert(b.lens.end(), lens + r, lens + r + take);
+            b.used += take_words;
+            total_bytes += take_words * sizeof(uint64_t) + take * sizeof(int32_t);
+            r += take; at += take_words;
+        }
+        return true;
+    }
+};
+
 class Pass1 : public pg::ReadSink {
 public:
     Pass1(pg_ctx* ctx, int K, size_t max_words, size_t max_reads)
@@ -212,22 +276,18 @@ public:
     hipStream_t stream() const { return stream_; }
     // the packed reads kept for pass 2, or nothing when they outgrew the budget (then the files are parsed again)
     void keep_reads(size_t budget_bytes) { keep_ = budget_bytes > 0; keep_budget_ = budget_bytes; }
-    bool take_kept(std::vector<uint64_t>& words, std::vector<int32_t>& lens) {
+    bool take_kept(KeptReads& out) {
         if (!keep_) return false;
-        words.swap(kept_words_); lens.swap(kept_lens_);
+        out.swap(kept_);
         return true;
     }
 
 private:
     void keep_append(const uint64_t* w, size_t nw, const int32_t* lens, size_t n) {
-        if ((kept_words_.size() + nw) * sizeof(uint64_t) + (kept_lens_.size() + n) * sizeof(int32_t) > keep_budget_) {
-            keep_ = false;
-            std::vector<uint64_t>().swap(kept_words_);
-            std::vector<int32_t>().swap(kept_lens_);
-            return;
+        if (kept_.total_bytes + nw * sizeof(uint64_t) + n * sizeof(int32_t) > keep_budget_ || !kept_.append(w, nw, lens, n)) {
+            keep_ = false;                                       // over the budget: pass 2 parses the files again
+            kept_.clear();
         }
-        kept_words_.insert(kept_words_.end(), w, w + nw);
-        kept_lens_.insert(kept_lens_.end(), lens, lens + n);
     }
     struct Buf {
         uint64_t *h_words, *h_off, *h_base, *d_words, *d_off, *d_base;
@@ -263,8 +323,7 @@ private:
     bool failed_ = false;
     bool keep_ = false;
     size_t keep_budget_ = 0;
-    std::vector<uint64_t> kept_words_;
-    std::vector<int32_t> kept_lens_;
+    KeptReads kept_;
     pg_ctx* ctx_;
     int K_;
     size_t max_words_, max_reads_;
@@ -329,8 +388,7 @@ int run(int argc, char** argv, bool mer127) {
     }
     size_t keep_budget = (size_t)sysconf(_SC_PHYS_PAGES) * (size_t)sysconf(_SC_PAGE_SIZE) / 4;
     if (const char* e = getenv("SOAPDENOVO2_AMD_KEEP_READS_GB")) keep_budget = (size_t)(atof(e) * 1073741824.0);
-    std::vector<uint64_t> kept_words;
-    std::vector<int32_t> kept_lens;
+    KeptReads kept;
     bool have_kept = false;
     long long n_records = 0;
     uint64_t total_kmers = 0;
@@ -357,15 +415,17 @@ int run(int argc, char** argv, bool mer127) {
                     n_records += pg::stream_reads(f, p1);
                 }
             } else if (have_kept) {
-                int mn = 0x7fffffff, mx = 0;
-                for (int32_t l : kept_lens) { mn = std::min(mn, (int)l); mx = std::max(mx, (int)l); }
-                if (!kept_lens.empty()) p1.on_packed(kept_words.data(), kept_lens.data(), kept_lens.size(), mn, mx);
+                for (const KeptReads::Block& kb : kept.blocks) {
+                    int mn = 0x7fffffff, mx = 0;
+                    for (int32_t l : kb.lens) { mn = std::min(mn, (int)l); mx = std::max(mx, (int)l); }
+                    if (!kb.lens.empty()) p1.on_packed(kb.words, kb.lens.data(), kb.lens.size(), mn, mx);
+                }
             } else {
                 for (const pg::InputFile& f : files) pg::stream_reads(f, p1);
             }
             ok = p1.finish_ok();
             total_kmers = p1.total_kmers();
-            if (attempt == 0) have_kept = p1.take_kept(kept_words, kept_lens);
+            if (attempt == 0) have_kept = p1.take_kept(kept);
         }
         lap("parse + scatter (pass 1)");
         // ---- -d filter, linear marking, .kmerFreq (deLowCov / Mark1in1outNode / freqStat); with the partition engine
@@ -492,12 +552,15 @@ int run(int argc, char** argv, bool mer127) {
     t0 = time(nullptr);
     if (have_kept) {
         fprintf(stderr, "In file: %s, max seq len %d, max name len %d.\n", o.config.c_str(), max_read_len, 256);
-        const uint64_t total = kept_lens.size(), step = (uint64_t)1 << 22;
-        uint64_t word_at = 0;
-        for (uint64_t lo = 0; lo < total; lo += step) {
-            const uint64_t n = std::min(step, total - lo);
-            if (pg_host_graph_add_packed(graph, kept_words.data() + word_at, kept_lens.data() + lo, n, 0) != PG_OK) die("pg_host_graph_add_packed");
-            for (uint64_t r = lo; r < lo + n; r++) word_at += pg_packed_words((uint32_t)kept_lens[r]);
+        const uint64_t step = (uint64_t)1 << 22;
+        for (const KeptReads::Block& kb : kept.blocks) {
+            const uint64_t total = kb.lens.size();
+            uint64_t word_at = 0;
+            for (uint64_t lo = 0; lo < total; lo += step) {
+                const uint64_t n = std::min(step, total - lo);
+                if (pg_host_graph_add_packed(graph, kb.words + word_at, kb.lens.data() + lo, n, 0) != PG_OK) die("pg_host_graph_add_packed");
+                for (uint64_t r = lo; r < lo + n; r++) word_at += pg_packed_words((uint32_t)kb.lens[r]);
+            }
         }
         fprintf(stderr, "%lld read(s) processed.\n", n_records);
     } else {
