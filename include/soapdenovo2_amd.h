@@ -46,7 +46,10 @@ const char *pg_version(void);
  *   pregraph -s configFile -o outputGraph [-K kmer -p n_sets -a initMemoryAssumption -d KmerFreqCutoff -R]
  * -p is the number of k-mer sets ("threads" in the reference); it fixes the order of .vertex/.edge.gz and
  * is honoured as such regardless of how many GPUs or host threads do the work.
- * Writes <o>.kmerFreq <o>.preGraphBasic <o>.vertex <o>.edge.gz <o>.preArc (-R is accepted; .path / .markOnEdge are not written yet).
+ * -p must be within 1..255 (the reference keeps thread ids in an `unsigned char`, prlHashReads.c:66-126; larger
+ * values misbehave there and are refused here).
+ * Writes <o>.kmerFreq <o>.preGraphBasic <o>.vertex <o>.edge.gz <o>.preArc, and with -R also <o>.path and
+ * <o>.markOnEdge (recordPathBin / output_arcs, prlRead2path.c:435-543).
  * Returns 0; fatal errors print to stderr and exit(), as the reference does (check.c:31,96).
  * call_pregraph        = behaviour of the SOAPdenovo-63mer binary (K <= 63, two hex words per k-mer)
  * call_pregraph_127mer = behaviour of the SOAPdenovo-127mer binary (K <= 127, four hex words)

@@ -2,8 +2,8 @@
 //
 // Mirrors standardPregraph/pregraph.c:62-220 (call_pregraph, initenv): same getopt string, same K clamp, same
 // phase order and stderr phase lines, same output files.  Pass 1 runs on the GPU through the pg_* device
-// operators (there is no CPU fallback); the k-mer-set layout replay, tip clipping and edge construction run
-// on the host (host_graph.cpp).
+// operators (there is no CPU fallback); the k-mer-set layout replay runs on the host threads, the tip walks, the
+// edge construction and pass 2 on the GPU (host_graph.cpp drives graph_kernels.hip), the writers on the host.
 #include <getopt.h>
 #include <stdint.h>
 #include <stdio.h>
@@ -358,12 +358,6 @@ int run(int argc, char** argv, bool mer127) {
 
     int device = 0;
     if (const char* e = getenv("SOAPDENOVO2_AMD_DEVICE")) device = atoi(e);
-    // initial device-set size: from -a (24 / 40 bytes per node as the reference assumes) or 2^24 slots; it grows
-    int log2_slots = 24;
-    if (o.a_gb > 0) {
-        const double nodes = (double)o.a_gb * 1073741824.0 / (mer127 ? 40 : 24);
-        while (log2_slots < 36 && (double)((uint64_t)1 << log2_slots) * 0.7 < nodes) log2_slots++;
-    }
     // how much is coming: bases ~ half the bytes of a FASTQ file, all of a FASTA file (x4 behind gzip)
     uint64_t est_kmers = 0;
     for (const pg::InputFile& f : files)
@@ -374,10 +368,12 @@ int run(int argc, char** argv, bool mer127) {
             if (path->size() > 3 && path->compare(path->size() - 3, 3, ".gz") == 0) bases *= 4.0;
             est_kmers += (uint64_t)bases;
         }
-    if (o.a_gb == 0) {
-        // the export array: room for one distinct k-mer per 6 occurrences (it is enlarged and the partitions are
-        // counted again when that is too little), but never more than a third of the device memory -- the record pool
-        // needs the rest
+    // The device export array: room for one distinct k-mer per 6 occurrences (it is enlarged and the partitions are
+    // counted again when that is too little), but never more than a third of the device memory -- the record pool needs
+    // the rest.  -a only presizes the reference's HOST k-mer sets (prlHashReads.c:369-390) and is used for exactly that
+    // in the layout replay; it does not size anything on the device.
+    int log2_slots = 24;
+    {
         size_t free_b = 0, total_b = 0;
         HIP_OK(hipSetDevice(device));
         HIP_OK(hipMemGetInfo(&free_b, &total_b));

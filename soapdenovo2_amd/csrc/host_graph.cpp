@@ -300,10 +300,14 @@ struct HSet {
         for (uint64_t i = 0; i < old; i++)
             if (!occ[i]) array[i].seq.w[0] = EMPTY;               // vacated and not reused
     }
-    // the growth test of put_kmerset (newhash.c:477) for a static (-a) pool only raises the load factor
+    // the growth test of put_kmerset (newhash.c:477) for a static (-a) pool only raises the load factor: the reference
+    // compares its float load_factor with the double 0.88 (newhash.c:355), which stays true after the assignment, so its
+    // "Static memory pool exploded" exit is never taken and a pool that fills up makes put_kmerset probe forever.  Here a
+    // full pool is reported instead (`full`), the callers fail with that message.
+    bool full = false;
     void before_put(bool static_pool) {
         if (count + 1 <= max) return;
-        if (static_pool) { lf = 0.88f; max = (uint64_t)((float)size * lf); return; }
+        if (static_pool) { lf = 0.88f; max = (uint64_t)((float)size * lf); if (count >= size) full = true; return; }
         grow();
     }
     void put_new(const HNode<NW>& nd, bool static_pool) {
@@ -1225,7 +1229,7 @@ static int replay_layout(Graph<NW>& g, const uint64_t* records, uint64_t n, cons
     if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "replay: bucketing done\n");
     const bool verbose = getenv("PG_HOST_VERBOSE") != nullptr;
     auto nowf = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
-    std::atomic<int> next{0};
+    std::atomic<int> next{0}, pool_full{0};
     auto worker = [&]() {
         for (;;) {
             const int s = next.fetch_add(1);
@@ -1278,6 +1282,7 @@ static int replay_layout(Graph<NW>& g, const uint64_t* records, uint64_t n, cons
                 nd.A = (uint32_t)rec[NW];
                 nd.B = (uint32_t)(rec[NW] >> 32);
                 hs.before_put(a_gb != 0);
+                if (hs.full) { pool_full.store(1); break; }
                 const int slot = (int)(i % AHEAD);
                 hs.put_new_at(nd, ring_size[slot] == hs.size ? ring_home[slot] : hs.home(nd.seq));
                 if (i + 2 * AHEAD < cnt) __builtin_prefetch(records + lo[i + 2 * AHEAD].idx * RW);
@@ -1296,6 +1301,7 @@ static int replay_layout(Graph<NW>& g, const uint64_t* records, uint64_t n, cons
     for (int t = 1; t < nt; t++) pool.emplace_back(worker);
     worker();
     for (auto& t : pool) t.join();
+    if (pool_full.load()) { pg_set_error("-- Static memory pool exploded, please define a larger value. --"); return PG_ENOMEM; }
     return PG_OK;
 }
 
@@ -1330,7 +1336,12 @@ static int replay_streamed(Graph<NW>& g, pg_fetch_fn fetch, void* user, uint64_t
             HSet<NW>& hs = g.sets[s];
             const uint64_t cnt_all = per_set_count[s];
             hs.init(init_size, HSet<NW>::final_size(init_size, cnt_all + 1, a_gb != 0));
-            if (cnt_all && !buf.p) buf.reset(std::min(CHUNK, cnt_all) * RW + 8);
+            // one buffer per worker, re-used from set to set: a later, larger set needs a larger one (the caller has the
+            // old range page-locked, so it is told to let go first)
+            if (cnt_all && buf.n < std::min(CHUNK, cnt_all) * RW + 8) {
+                if (buf.p) fetch(user, 0, 0, nullptr);
+                buf.reset(std::min(CHUNK, cnt_all) * RW + 8);
+            }
             uint64_t last_ord = 0, prev_tag = 0;
             for (uint64_t at = 0; at < cnt_all && !failed.load(); at += CHUNK) {
                 const int64_t cnt = (int64_t)std::min(CHUNK, cnt_all - at);
@@ -1353,6 +1364,7 @@ static int replay_streamed(Graph<NW>& g, pg_fetch_fn fetch, void* user, uint64_t
                     nd.A = (uint32_t)rec[NW];
                     nd.B = (uint32_t)(rec[NW] >> 32);
                     hs.before_put(a_gb != 0);
+                    if (hs.full) { failed.store(3); break; }
                     const int slot = (int)(i % AHEAD);
                     hs.put_new_at(nd, ring_size[slot] == hs.size ? ring_home[slot] : hs.home(nd.seq));
                     if (i + AHEAD < cnt) { ring_home[slot] = hs.home(key_of(i + AHEAD)); ring_size[slot] = hs.size; hs.prefetch_put(ring_home[slot]); }
@@ -1373,6 +1385,7 @@ static int replay_streamed(Graph<NW>& g, pg_fetch_fn fetch, void* user, uint64_t
     worker();
     for (auto& t : pool) t.join();
     if (failed.load() == 2) { pg_set_error("streamed records are not ordered by (set, ordinal)"); return PG_EINVAL; }
+    if (failed.load() == 3) { pg_set_error("-- Static memory pool exploded, please define a larger value. --"); return PG_ENOMEM; }
     if (failed.load()) return PG_ENODEV;
     return PG_OK;
 }

@@ -131,7 +131,12 @@ struct Source {
             piped = true;
         } else fp = fopen(name.c_str(), "r");
         if (!fp) { fprintf(stderr, "Cannot open %s. Now exit to system...\n", name.c_str()); exit(-1); }
+        // a FIFO / process substitution cannot be read with pread(): take it as it comes, like a pipe
+        struct stat st;
+        if (!piped && fstat(fileno(fp), &st) == 0 && !S_ISREG(st.st_mode)) unseekable = true;
     }
+    bool unseekable = false;
+    bool sequential() const { return piped || unseekable; }
     void close() { if (fp) { if (piped) pclose(fp); else fclose(fp); fp = nullptr; } }
 };
 
@@ -409,7 +414,7 @@ long long stream_file_parallel(const InputFile& in, const std::string& path, boo
     double t_parse = 0, t_wait = 0;
     uint64_t file_off = 0;
     auto read_window = [&](char* dst, size_t want) -> size_t {
-        if (src.piped) return fread(dst, 1, want, src.fp);
+        if (src.sequential()) return fread(dst, 1, want, src.fp);
         const int fd = fileno(src.fp);
         const int parts = 4;
         size_t got_part[parts] = {0, 0, 0, 0};

@@ -201,7 +201,7 @@ PG_HD uint32_t set_of_crc(uint32_t crc, uint32_t P, uint32_t bias) {
 }
 inline uint32_t set_bias(uint32_t P) { return (uint32_t)(0xFFFFFFFF00000000ULL % P); }
 
-// device-table slot hash (free design; the reference layout is rebuilt on the host, see layout_replay.cpp)
+// device-table slot hash (free design; the reference layout is rebuilt by replay_layout / replay_streamed, host_graph.cpp)
 template <int NW>
 PG_HD uint64_t kmer_mix(const Kmer<NW>& a) {
     uint64_t h = 0x9E3779B97F4A7C15ULL;

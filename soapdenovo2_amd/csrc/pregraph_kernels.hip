@@ -7,7 +7,7 @@
 // saturating total, `single`) is an order-independent reduction; only the slot inside the reference's
 // table depends on arrival order.  So the device keeps its own hash set (free layout) plus, per k-mer, the
 // 64-bit ordinal of its first occurrence (atomic min) and, per reference set, the ordinal of the last put;
-// the host replays the reference layout from those (layout_replay.cpp).
+// the host replays the reference layout from those (replay_layout / replay_streamed, host_graph.cpp).
 //
 // Device set: open addressing, linear probing, power-of-two capacity, one slot =
 //   NW = 2:  { key[2], cnt, ord }            32 B, two slots per 64-B line

@@ -83,3 +83,4 @@ def test_growth_on_trailing_duplicate():
     # without the last-put information the replay cannot know about the trailing duplicate
     slots2, sizes2 = api.host_replay_layout(rec, np.zeros(1, dtype=np.uint64), 1)
     assert sizes2[0] == 1031
+
