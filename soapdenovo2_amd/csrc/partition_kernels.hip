@@ -5,13 +5,14 @@
 // formulation, chosen because a DRAM-resident set is capped by the chip's random-atomic rate (~24 G ops/s,
 // profiles/r01_membench_random_access.log) at ~13 % of the HBM roofline:
 //
-//   K1  skm_scatter_kernel   one lane per read: cut the read into super-k-mers by minimizer partition
-//                            (skm.hpp), append each as a fixed-size record to its partition's stream
-//                            (streams = chains of 1.5 KB chunks from one pool; one atomic per record, not per
-//                            k-mer: ~20x fewer, and the write side is plain 48-byte stores).
+//   K1  skm_scatter_seg_kernel  (uniform-length batches; skm_scatter_kernel = one lane per read for ragged ones)
+//                            cut the reads into super-k-mers by minimizer partition (skm.hpp, skm_tile.hpp), append each
+//                            as a fixed-size record to its partition's stream (streams = chains of 6 KB chunks from one
+//                            pool; one atomic per record, not per k-mer: ~20x fewer, and the write side is plain
+//                            48-byte stores).
 //   K2  skm_count_kernel     one workgroup per partition (persistent grid): expand the partition's records
-//                            back into k-mer occurrences and insert them into a set that lives in LDS
-//                            (64 KB, word-wise CAS claim from the all-ones pattern, 63-bit key words), then
+//                            back into k-mer occurrences (occ32.hpp) and insert them into a set that lives in LDS
+//                            (120 KB, word-wise CAS claim from the all-ones pattern, 63-bit key words), then
 //                            finalize (-d filter, linear flag, coverage histogram: prlHashReads.c:953-1132)
 //                            and emit the distinct k-mers as export records.  All occurrences of a k-mer
 //                            are in ONE partition, so its LDS result is final: no global table at all.
@@ -27,6 +28,8 @@
 
 #include "device_ctx.hpp"
 #include "extract.hpp"
+#include "occ32.hpp"
+#include "skm_tile.hpp"
 #include "../../include/soapdenovo2_amd.h"
 
 namespace pg {
@@ -41,7 +44,7 @@ template <> struct E2Cfg<4> { static constexpr int PW = 7, KW = 5; };    // 5 ke
 
 struct E2Dev {
     SkmGeom g;
-    uint32_t rpc, maxc;
+    uint32_t rpc, maxc, rpc_log2;        // records per chunk: a power of two
     uint64_t pool_chunks;
     uint32_t* cursor;
     uint32_t* chunk_tbl;
@@ -67,7 +70,7 @@ struct ReadsArg {
 // with q % rpc == 0 drew its number before any lane with a later number of that chunk, so its publish is already
 // issued (same or earlier instruction of this wave, or an independent wave).  The wait is bounded anyway.
 __device__ __forceinline__ uint64_t* record_slot(const E2Dev& e, uint32_t pid, uint32_t q, DevCounters* ctr, int rw) {
-    const uint32_t ci = q / e.rpc, ri = q % e.rpc;
+    const uint32_t ci = q >> e.rpc_log2, ri = q & (e.rpc - 1);
     if (ci >= e.maxc) { atomicOr(&ctr->e2_flags, F_CHUNKS); return nullptr; }
     uint32_t* t = e.chunk_tbl + (uint64_t)pid * e.maxc + ci;
     if (ri == 0) {
@@ -111,139 +114,85 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_kernel(ReadsArg a, E2Dev e,
     });
 }
 
-// Tiled K1 for uniform-length reads: no data-dependent control flow per k-mer.  A workgroup takes R reads:
-//   A  every m-mer value of the tile into LDS (one lane per m-mer position, 32-bit values)
-//   B  sliding-window minimum by doubling: V_k[p] = min(V_{k-1}[p], V_{k-1}[p + 2^(k-1)]), window = two overlapping V_lv
-//   C  partition of every k-mer; D  run starts (a local rule, skm.hpp) and run lengths -> compact item list in LDS
-//   E  one lane per run: reserve a record slot in the partition's stream, build the record from the staged words,
-//      store it with 16-byte writes.
-// Only E touches global memory besides the coalesced tile load.  Index arithmetic is 32-bit with multiply-high
-// reciprocals (the GPU has neither an integer divider nor a 64-bit multiplier).
-struct TileArg { int R, np, lv; uint32_t inv_np, inv_kpr, inv_wpr; };
 // multi-GPU: instead of appending to the local partition streams, records go to per-owner send regions (owner =
 // partition mod n_owners), `cap` records each, with the partition id alongside; cursor[o] counts what owner o gets.
 struct RouteArg { uint64_t* recs; uint32_t* pids; unsigned long long* cursor; uint64_t cap; int n_owners; };
 __device__ __forceinline__ uint32_t fastdiv(uint32_t i, uint32_t inv) { return __umulhi(i, inv); }
+// i / d for small i with inv = ceil(2^32 / d); d = 1 has no 32-bit reciprocal
+__device__ __forceinline__ uint32_t fastdiv1(uint32_t i, uint32_t d, uint32_t inv) { return d == 1 ? i : __umulhi(i, inv); }
 
-template <int NW, bool ROUTE>
-__global__ __launch_bounds__(BLOCK) void skm_scatter_tiled_kernel(ReadsArg a, E2Dev e, DevCounters* ctr, TileArg ta, RouteArg ro) {
+// Tiled K1 for uniform-length reads: every thread does a short serial piece of work on consecutive positions
+// (skm_tile.hpp).  (Round 1 had one lane per k-mer and a log-step sliding minimum by wave shuffles: ~480 vector
+// instructions per read, profiles/r01_pmc_sq_bench20M_engine2.json; this form measures 1.65x faster,
+// profiles/r02_k1k2_rewrite_ab.json.)
+//   load  the tile's reads as dword strings (hi dword of every 64-bit word first)
+//   A     thread = (read, 16 positions): m-mer values from two dwords, compile-time funnel shifts
+//   B     thread = (read, S k-mers): window minima with w + S reads (suffix / core / prefix), partition ids, run-start bits
+//   D     thread = the same segment: one LDS atomic reserves its items, every start bit finds the next start
+//   E     one lane per run: slot in the partition's stream (or the owner's send region), record from the dword string
+// Lanes of a wave take different reads (read index fastest), so the row stride -- forced odd -- is the bank stride.
+struct SegArg { int R, np, npad, wsd, nseg, nca; uint32_t inv_R, inv_wpr; };
+
+template <int NW, bool ROUTE, int S>
+__global__ __launch_bounds__(BLOCK) void skm_scatter_seg_kernel(ReadsArg a, E2Dev e, DevCounters* ctr, SegArg sa, RouteArg ro) {
     constexpr int PW = E2Cfg<NW>::PW, RW = PW + 1;
     extern __shared__ __align__(16) unsigned char smem_raw[];
-    const int R = ta.R, np = ta.np, lv = ta.lv;
-    const int wpr = (int)a.wpr, kpr = (int)a.kpr, ws = wpr + 1, len = (int)a.uniform_len;
-    const int nch = (kpr + 62) / 63;                               // 63-k-mer chunks per read (one wave each)
-    uint64_t* words = (uint64_t*)smem_raw;                       // R * ws
-    unsigned long long* masks = (unsigned long long*)(words + (size_t)R * ws);   // R * nch: run-start bits
-    uint32_t* v0 = (uint32_t*)(masks + (size_t)R * nch);          // R * np: m-mer values
-    uint32_t* pids = v0 + (size_t)R * np;                         // R * kpr
-    uint32_t* items = pids + (size_t)R * kpr;                     // R * kpr  (r << 24 | j << 12 | n)
+    const int R = sa.R, np = sa.np, npad = sa.npad, wsd = sa.wsd, nseg = sa.nseg, nca = sa.nca;
+    const int wpr = (int)a.wpr, kpr = (int)a.kpr, len = (int)a.uniform_len;
+    uint32_t* dw = (uint32_t*)smem_raw;                           // R * wsd   dword strings
+    uint32_t* v0 = dw + (size_t)R * wsd;                          // R * npad  m-mer values; the item list after B
+    uint32_t* pids = v0 + (size_t)R * npad;                       // R * kpr
+    uint32_t* smask = pids + (size_t)R * kpr;                     // R * nseg  run-start bits
+    uint32_t* ranks = smask + (size_t)R * nseg;                   // R * kpr   (ROUTE only)
+    uint32_t* items = v0;
     __shared__ unsigned int n_items;
     const uint64_t r0 = (uint64_t)blockIdx.x * R;
     const int nr = (int)min((uint64_t)R, a.n_reads - r0);
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     if (threadIdx.x == 0) n_items = 0;
     for (int i = threadIdx.x; i < nr * wpr; i += BLOCK) {
-        const int r = (int)fastdiv(i, ta.inv_wpr), k = i - r * wpr;
-        words[r * ws + k] = a.packed[r0 * wpr + i];
+        const int r = (int)fastdiv1(i, wpr, sa.inv_wpr), k = i - r * wpr;
+        const uint64_t wd = a.packed[r0 * wpr + i];
+        *(uint2*)(dw + r * wsd + 2 * k) = make_uint2((uint32_t)(wd >> 32), (uint32_t)wd);
     }
-    for (int r = threadIdx.x; r < nr; r += BLOCK) words[r * ws + wpr] = 0;
+    for (int r = threadIdx.x; r < nr; r += BLOCK)
+        for (int k = 2 * wpr; k < wsd; k++) dw[r * wsd + k] = 0;
     __syncthreads();
     const int m = e.g.m, w = e.g.w;
-    for (int i = threadIdx.x; i < nr * np; i += BLOCK) {
-        const int r = (int)fastdiv(i, ta.inv_np), p = i - r * np;
-        v0[i] = mmer_value(words + r * ws, p, m);
+    // tasks are numbered over the full tile (read index fastest), a short last tile just leaves lanes idle
+    for (int t = threadIdx.x; t < R * nca; t += BLOCK) {
+        const int c = (int)fastdiv1(t, R, sa.inv_R), r = t - c * R;
+        if (r < nr) tile_mmer_chunk(dw + r * wsd, c, np, m, v0 + r * npad);
     }
     __syncthreads();
-    const int span = 1 << lv;                                      // doubling reaches min over [p, p + span), span <= w
-    const int nmax = e.g.nmax;
-    // B + C in registers, one wave per chunk of 63 k-mers of a read: lane l holds k-mer j = 63 c - 1 + l (lane 0 only
-    // supplies the predecessor of lane 1) and the m-mer values at j, j + 64, j + 128.  The sliding minimum over the
-    // w m-mers of a k-mer is lv doubling steps of "min with the value d lanes up" (shuffles, no LDS pass, no barrier),
-    // then one more shifted min for the remainder of the window; the ballot of the run starts IS the bit mask.
-    for (int wi = wave; wi < nr * nch; wi += BLOCK / 64) {
-        const int r = wi / nch, c = wi - r * nch;
-        const int j = 63 * c - 1 + lane;
-        const uint32_t* sv = v0 + r * np;
-        uint32_t x0 = (j >= 0 && j < np) ? sv[j] : 0xFFFFFFFFu;
-        uint32_t x1 = (j + 64 < np) ? sv[j + 64] : 0xFFFFFFFFu;
-        uint32_t mv;
-        if (w <= 65) {
-            // a window of at most 65 m-mers never reaches past j + 127: two registers a lane
-            for (int k = 0; k < lv; k++) {
-                const int d = 1 << k;
-                const int srcl = (lane + d) & 63;
-                const bool wrap = lane + d >= 64;
-                const uint32_t a0 = __shfl(x0, srcl, 64), a1 = __shfl(x1, srcl, 64);
-                x0 = min(x0, wrap ? a1 : a0);
-                x1 = min(x1, wrap ? 0xFFFFFFFFu : a1);
-            }
-            mv = x0;                                                // min over [j, j + span)
-            const int sft = w - span;                               // the rest of the window: [j + w - span, j + w)
-            if (sft > 0) {
-                const int srcl = (lane + sft) & 63;
-                const uint32_t a0 = __shfl(x0, srcl, 64), a1 = __shfl(x1, srcl, 64);
-                mv = min(x0, lane + sft >= 64 ? a1 : a0);
-            }
-        } else {
-            uint32_t x2 = (j + 128 < np) ? sv[j + 128] : 0xFFFFFFFFu;
-            for (int k = 0; k < lv && k < 6; k++) {
-                const int d = 1 << k;
-                const int srcl = (lane + d) & 63;
-                const bool wrap = lane + d >= 64;
-                const uint32_t a0 = __shfl(x0, srcl, 64), a1 = __shfl(x1, srcl, 64), a2 = __shfl(x2, srcl, 64);
-                x0 = min(x0, wrap ? a1 : a0);
-                x1 = min(x1, wrap ? a2 : a1);
-                x2 = min(x2, wrap ? 0xFFFFFFFFu : a2);
-            }
-            if (lv >= 7) { x0 = min(x0, x1); x1 = min(x1, x2); }  // a step of 64 is the next register (w >= 128 only)
-            mv = x0;
-            const int sft = w - span;
-            if (sft > 0) {
-                const int d = sft & 63;
-                const int srcl = (lane + d) & 63;
-                const bool wrap = lane + d >= 64;
-                const uint32_t a0 = __shfl(x0, srcl, 64), a1 = __shfl(x1, srcl, 64), a2 = __shfl(x2, srcl, 64);
-                mv = sft >= 64 ? min(x0, wrap ? a2 : a1) : min(x0, wrap ? a1 : a0);
-            }
-        }
-        const bool valid = lane > 0 ? (j < kpr) : false;
-        const uint32_t pid = skm_partition(mv, e.g.log2_parts);
-        const uint32_t prev = __shfl_up(pid, 1, 64);
-        if (valid) pids[r * kpr + j] = pid;
-        const bool start = valid && (j == 0 || pid != prev || j % nmax == 0);
-        const unsigned long long mk = __ballot(start);
-        if (lane == 0) masks[wi] = mk;
+    for (int t = threadIdx.x; t < R * nseg; t += BLOCK) {
+        const int seg = (int)fastdiv1(t, R, sa.inv_R), r = t - seg * R;
+        if (r >= nr) continue;
+        const int j0 = seg * S, cnt = min(S, kpr - j0);
+        uint32_t pid[S];
+        const uint32_t mk = tile_segment<S>(v0 + r * npad, j0, cnt, w, e.g.nmax, e.g.log2_parts, pid);
+        smask[r * nseg + seg] = mk;
+#pragma unroll
+        for (int i = 0; i < S; i++) if (i < cnt) pids[r * kpr + j0 + i] = pid[i];
     }
-    __syncthreads();
-    // D: every run start finds the next start in the bit masks (no per-lane walk) and queues one item
-    for (int wi = wave; wi < nr * nch; wi += BLOCK / 64) {
-        const int r = wi / nch, c = wi - r * nch;
-        const int j = 63 * c - 1 + lane;
-        const unsigned long long mk = masks[wi];
-        const bool start = (mk >> lane) & 1ULL;
-        uint32_t item = 0;
-        if (start) {
-            int next = kpr;
-            const unsigned long long above = lane < 63 ? (mk >> (lane + 1)) : 0ULL;
-            if (above) next = j + __ffsll((long long)above);
-            else {
-                for (int cc = c + 1; cc < nch; cc++) {
-                    const unsigned long long mm = masks[r * nch + cc];
-                    if (mm) { next = 63 * cc - 1 + __ffsll((long long)mm) - 1; break; }
-                }
+    __syncthreads();                                              // v0 is dead from here: the item list takes its place
+    for (int t = threadIdx.x; t < R * nseg; t += BLOCK) {
+        const int seg = (int)fastdiv1(t, R, sa.inv_R), r = t - seg * R;
+        uint32_t mk = r < nr ? smask[r * nseg + seg] : 0u;
+        if (mk) {
+            unsigned int at = atomicAdd(&n_items, (unsigned int)__popc(mk));
+            while (mk) {
+                const int i = __ffs((int)mk) - 1;
+                mk &= mk - 1;
+                const int j = seg * S + i;
+                const int nxt = tile_next_start(smask + r * nseg, seg, nseg, S, i, kpr);
+                items[at++] = ((uint32_t)r << 24) | ((uint32_t)j << 12) | (uint32_t)(nxt - j);
             }
-            item = ((uint32_t)r << 24) | ((uint32_t)j << 12) | (uint32_t)(next - j);
         }
-        unsigned int base = 0;
-        if (lane == 0 && mk) base = atomicAdd(&n_items, (unsigned int)__popcll(mk));
-        base = __shfl(base, 0, 64);
-        if (start) items[base + __popcll(mk & ((1ULL << lane) - 1))] = item;
     }
     __syncthreads();
     const int total = (int)n_items;
     __shared__ unsigned int ocnt[256];
     __shared__ unsigned long long obase[256];
-    uint32_t* ranks = v0;                                          // the m-mer values are dead by now
     if (ROUTE) {
         ocnt[threadIdx.x] = 0;
         __syncthreads();
@@ -274,7 +223,7 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_tiled_kernel(ReadsArg a, E2
         }
         if (!out) continue;
         uint64_t rec[RW];
-        skm_make_record<PW>(words + r * ws, len, j0, n, a.ord_base + (r0 + (uint64_t)r) * (uint64_t)kpr, e.g, rec);
+        tile_make_record<PW>(dw + r * wsd, len, j0, n, a.ord_base + (r0 + (uint64_t)r) * (uint64_t)kpr, e.g.K, rec);
         ulonglong2* o2 = (ulonglong2*)out;
 #pragma unroll
         for (int k = 0; k < RW / 2; k++) o2[k] = make_ulonglong2(rec[2 * k], rec[2 * k + 1]);
@@ -314,36 +263,61 @@ struct LdsSet {
     unsigned int cnt[9][SLOTS];
 };
 
-// Returns false when the set is too full (a probe sequence longer than MAXPROBE): the caller aborts the attempt and
+// A put gives up when the set is too full (a probe sequence longer than MAXPROBE): the caller aborts the attempt and
 // splits the key range.  No shared key counter on this path -- a same-address LDS atomic per new key serialises the
 // whole workgroup; the keys are counted once, at emit time.
 constexpr int K2_MAXPROBE = 48;
+
+__device__ __forceinline__ const uint64_t* record_ptr(const E2Dev& e, uint32_t pid, uint32_t i, int rw) {
+    const uint32_t c = e.chunk_tbl[(uint64_t)pid * e.maxc + (i >> e.rpc_log2)];
+    if (c == 0 || c == 0xFFFFFFFFu) return nullptr;  // pool ran dry in K1 (flagged there; the run fails in e2_count)
+    return e.pool + ((uint64_t)(c - 1) * e.rpc + (i & (e.rpc - 1))) * (uint64_t)rw;
+}
+
+// ---- K2 ------------------------------------------------------------------------------------------------------------
+// One workgroup per partition (persistent grid).  The partition's records are taken WIN at a time: staged into LDS with
+// coalesced 16-byte copies (so the per-occurrence work never waits on global memory), flattened through a prefix sum of
+// their k-mer counts so every lane gets an equal contiguous share of occurrences, expanded and inserted into the LDS
+// set.  If the set overflows, the attempt is dropped and the key range is split on a hash bit.  Then the set is
+// finalised (-d filter, linear flag, coverage histogram: prlHashReads.c:953-1132) and emitted as export records.
+// The per-occurrence path (round 1 spent ~360 vector instructions on it, profiles/r01_pmc_sq_bench20M_engine2.json):
+//   * records are staged as dword strings (hi dword first), a k-mer occurrence is cut out by occ_extract (occ32.hpp):
+//     six dword reads, funnel shifts, bit reversal -- 32-bit operations throughout, shift amounts that depend on K
+//     alone are wave-uniform;
+//   * the slot hash is three 32-bit multiplies instead of three 64-bit ones;
+//   * no per-lane cache of "the current record": (offset pair, header) are simply read again every step, so the step is
+//     straight-line code -- with 64 lanes a wave crossed a record boundary on nearly every step anyway and paid for the
+//     divergent refill each time;
+//   * the first record of a lane's share comes from a table the flatten step fills (one lane per record writes the lanes
+//     whose share starts inside it) instead of a 9-step binary search per lane and window;
+//   * the put counter is gone: every put adds to exactly one of L[0..3] / "no left neighbour", so puts = their sum, and
+//     the first-occurrence ordinal is only sent through atomicMin when it is smaller than the value just read with the key
+//     (a hot k-mer's lanes hit the same word: same-address LDS atomics serialise, same-address reads broadcast).
 template <int NW, int SLOTS>
-__device__ __forceinline__ bool lds_put(LdsSet<NW, SLOTS>& t, const Key63<NW>& key, uint64_t hash, int left, int right, uint64_t ord) {
+__device__ __forceinline__ bool lds_put(LdsSet<NW, SLOTS>& t, const uint64_t (&kw)[E2Cfg<NW>::KW], uint32_t hash, uint32_t left, uint32_t right,
+                                         uint64_t ord) {
     constexpr int KW = E2Cfg<NW>::KW;
-    uint32_t h = (uint32_t)hash & (SLOTS - 1);
+    uint32_t h = hash & (SLOTS - 1);
     for (int probes = 0; probes < K2_MAXPROBE; probes++) {
-        // all key words of the slot are fetched together (one LDS round trip for the usual case, a hit); only a word
-        // that is still empty goes through the claiming CAS
         unsigned long long seen[KW];
 #pragma unroll
         for (int i = 0; i < KW; i++) seen[i] = t.key[i][h];
+        const unsigned long long so = t.ord[h];
         bool mine = true;
 #pragma unroll
         for (int i = 0; i < KW; i++) {
             if (!mine) break;
             unsigned long long cur = seen[i];
             if (cur == L_EMPTY) {
-                const unsigned long long old = atomicCAS(&t.key[i][h], L_EMPTY, (unsigned long long)key.w[i]);
-                cur = old == L_EMPTY ? (unsigned long long)key.w[i] : old;
+                const unsigned long long old = atomicCAS(&t.key[i][h], L_EMPTY, (unsigned long long)kw[i]);
+                cur = old == L_EMPTY ? (unsigned long long)kw[i] : old;
             }
-            mine = cur == key.w[i];
+            mine = cur == kw[i];
         }
         if (mine) {
-            if (left < 4) atomicAdd(&t.cnt[left][h], 1u);
+            atomicAdd(&t.cnt[left < 4 ? left : 8][h], 1u);           // exactly one of L[0..3] / "none" per put
             if (right < 4) atomicAdd(&t.cnt[4 + right][h], 1u);
-            atomicAdd(&t.cnt[8][h], 1u);
-            atomicMin(&t.ord[h], (unsigned long long)ord);
+            if (ord < so) atomicMin(&t.ord[h], (unsigned long long)ord);
             return true;
         }
         h = (h + 1) & (SLOTS - 1);
@@ -351,23 +325,17 @@ __device__ __forceinline__ bool lds_put(LdsSet<NW, SLOTS>& t, const Key63<NW>& k
     return false;
 }
 
-__device__ __forceinline__ const uint64_t* record_ptr(const E2Dev& e, uint32_t pid, uint32_t i, int rw) {
-    const uint32_t c = e.chunk_tbl[(uint64_t)pid * e.maxc + i / e.rpc];
-    if (c == 0 || c == 0xFFFFFFFFu) return nullptr;  // pool ran dry in K1 (flagged there; the run fails in e2_count)
-    return e.pool + ((uint64_t)(c - 1) * e.rpc + i % e.rpc) * (uint64_t)rw;
-}
-
-// K2.  One workgroup per partition (persistent grid).  The partition's records are taken WIN at a time: staged into
-// LDS with coalesced 16-byte copies (so the per-occurrence work never waits on global memory), flattened through a
-// prefix sum of their k-mer counts so every lane gets an equal contiguous share of occurrences, expanded and inserted
-// into the LDS set.  If the set overflows, the attempt is dropped and the key range is split on a hash bit.
 template <int NW, int SLOTS, int THREADS, int WIN>
-__global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetParams sp, DevCounters* ctr, int dbg) {
-    constexpr int PW = E2Cfg<NW>::PW, RW = PW + 1, KW = E2Cfg<NW>::KW, NWAVE = THREADS / 64, PIECES = RW / 2;
+__global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetParams sp, OccConst oc, DevCounters* ctr, int dbg) {
+    constexpr int PW = E2Cfg<NW>::PW, RW = PW + 1, KW = E2Cfg<NW>::KW, NWAVE = THREADS / 64, PIECES = RW / 2, N2 = 2 * NW;
+    constexpr int RD = 2 * RW;                                            // dwords a record
+    constexpr int PAD = 16;                                               // readable dwords in front of record 0 (a window reaches back 2 NW + 2)
     static_assert(WIN <= THREADS, "one record per lane in the flatten step");
+    static_assert(PAD % 4 == 0 && PAD >= 2 * NW + 2, "front padding");
     __shared__ LdsSet<NW, SLOTS> set;
-    __shared__ __align__(16) uint64_t recs[WIN * RW + 8];                 // + readable padding for the window loads
+    __shared__ __align__(16) uint32_t rl[PAD + WIN * RD + 8];             // records as dword strings: [hdr hi, hdr lo, payload hi, lo, ...]
     __shared__ unsigned int noff[WIN + 1];                                // exclusive prefix sum of the records' k-mer counts
+    __shared__ unsigned short first_rec[THREADS];                         // record in which lane l's share starts
     __shared__ uint32_t crc_tab[256];
     __shared__ unsigned int hist[256];
     constexpr int STRIPES = (SLOTS + THREADS - 1) / THREADS;
@@ -375,15 +343,14 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     __shared__ unsigned int chunk_ids[256];                                // this partition's chunk list (maxc <= 256)
     __shared__ unsigned long long out_base;
     for (int i = threadIdx.x; i < 256; i += THREADS) { crc_tab[i] = crc32_table_entry(i); hist[i] = 0; }
-    if (threadIdx.x < 8) recs[WIN * RW + threadIdx.x] = 0;
-    const Kmer<NW> filter = kmer_filter<NW>(e.g.K);
+    if (threadIdx.x < PAD) rl[threadIdx.x] = 0;
+    if (threadIdx.x < 8) rl[PAD + WIN * RD + threadIdx.x] = 0;
     const int K = e.g.K;
     const uint32_t parts = 1u << e.g.log2_parts;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long my_records = 0;
     unsigned long long tp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
 #define K2_TICK(i) do { if (dbg & 2) { const unsigned long long tn_ = clock64(); tp[i] += tn_ - tlast; tlast = tn_; } } while (0)
-    // the next partition's record count and chunk list are fetched while the current one is processed
     uint32_t pf_nrec = 0, pf_cid = 0;
     if (blockIdx.x < parts) {
         pf_nrec = e.cursor[blockIdx.x];
@@ -419,63 +386,81 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
             __syncthreads();
             K2_TICK(1);
             const uint32_t mask = cur_mask, val = cur_val;
-            volatile unsigned int* abort_flag = &aborted;
             for (uint32_t w0 = 0; w0 < usable; w0 += WIN) {
                 const uint32_t wn = min((uint32_t)WIN, usable - w0);
-                // stage the window's records: 16 bytes per lane and step, consecutive lanes -> consecutive pieces
+                // stage the window's records: 16 bytes per lane and step, each 64-bit word stored high dword first
                 for (uint32_t pc = threadIdx.x; pc < wn * PIECES; pc += THREADS) {
                     const uint32_t ri = pc / PIECES, part = pc - ri * PIECES;
-                    const uint32_t gi = w0 + ri, cid = chunk_ids[gi / e.rpc];
+                    const uint32_t gi = w0 + ri, cid = chunk_ids[gi >> e.rpc_log2];
                     ulonglong2 v = make_ulonglong2(0, 0);
                     if (cid != 0 && cid != 0xFFFFFFFFu)
-                        v = ((const ulonglong2*)(e.pool + ((uint64_t)(cid - 1) * e.rpc + gi % e.rpc) * (uint64_t)RW))[part];
-                    ((ulonglong2*)recs)[pc] = v;
+                        v = ((const ulonglong2*)(e.pool + ((uint64_t)(cid - 1) * e.rpc + (gi & (e.rpc - 1))) * (uint64_t)RW))[part];
+                    ((uint4*)(rl + PAD))[pc] = make_uint4((uint32_t)(v.x >> 32), (uint32_t)v.x, (uint32_t)(v.y >> 32), (uint32_t)v.y);
                 }
                 __syncthreads();
                 K2_TICK(2);
-                // flatten: occurrence idx -> (record, t)
+                // flatten: occurrence idx -> (record, t); every lane gets `share` consecutive occurrences
+                uint32_t total_occ, share;
                 {
-                    const unsigned int n = threadIdx.x < wn ? (unsigned int)skm_n(recs[threadIdx.x * RW]) : 0u;
+                    const unsigned int n = threadIdx.x < wn ? ((rl[PAD + threadIdx.x * RD + 1] >> 2) & 0xFFFFu) : 0u;
                     unsigned int incl = n;
 #pragma unroll
                     for (int d = 1; d < 64; d <<= 1) { const unsigned int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
                     if (lane == 63) wave_cnt[0][wave] = incl;
                     __syncthreads();
-                    unsigned int base = 0;
+                    unsigned int base = 0, tot = 0;
 #pragma unroll
-                    for (int wv = 0; wv < NWAVE; wv++) if (wv < wave) base += wave_cnt[0][wv];
-                    if (threadIdx.x < wn) noff[threadIdx.x] = base + incl - n;
-                    if (threadIdx.x == THREADS - 1) noff[wn] = base + incl;       // lanes past wn contributed 0
+                    for (int wv = 0; wv < NWAVE; wv++) { const unsigned int cw = wave_cnt[0][wv]; if (wv < wave) base += cw; tot += cw; }
+                    total_occ = tot;
+                    share = (tot + THREADS - 1) / THREADS;
+                    if (threadIdx.x < wn) {
+                        const unsigned int o_lo = base + incl - n, o_hi = base + incl;
+                        noff[threadIdx.x] = o_lo;
+                        // lanes whose share starts inside this record: l * share in [o_lo, o_hi)
+                        const float inv = 1.0f / (float)share;
+                        auto div_up = [&](unsigned int x) {                        // ceil(x / share), x < 2^16
+                            unsigned int q = (unsigned int)((float)x * inv);
+                            if (q * share > x) q--;
+                            if ((q + 1) * share <= x) q++;
+                            return q + (q * share < x ? 1u : 0u);
+                        };
+                        const unsigned int l0 = div_up(o_lo), l1 = min((unsigned int)THREADS, div_up(o_hi));
+                        for (unsigned int l = l0; l < l1; l++) first_rec[l] = (unsigned short)threadIdx.x;
+                    }
+                    if (threadIdx.x == THREADS - 1) noff[wn] = tot;
                 }
                 __syncthreads();
                 K2_TICK(3);
-                if (!*abort_flag) {
-                    const uint32_t total_occ = noff[wn];
-                    const uint32_t share = (total_occ + THREADS - 1) / THREADS;
-                    const uint32_t idx0 = min(total_occ, threadIdx.x * share), idx1 = min(total_occ, idx0 + share);
-                    if (idx0 < idx1) {
-                        uint32_t lo = 0, hi = wn - 1;                             // first record of this lane's share
-                        while (lo < hi) { const uint32_t mid = (lo + hi + 1) >> 1; if (noff[mid] <= idx0) lo = mid; else hi = mid - 1; }
-                        uint32_t r = lo, next_off = noff[r + 1], roff = 0;
-                        const uint64_t* rec = recs;
-                        uint64_t hdr = 0;
-                        int hl = 0, nb = 0;
-                        bool fresh = true;
-                        for (uint32_t idx = idx0; idx < idx1; idx++) {
-                            while (idx >= next_off) { r++; next_off = noff[r + 1]; fresh = true; }
-                            if (fresh) {
-                                rec = recs + r * RW;
-                                hdr = rec[0];
-                                hl = skm_has_left(hdr); nb = skm_record_bases(hdr, K); roff = noff[r];
-                                fresh = false;
-                                if (*abort_flag) break;
-                            }
-                            Occurrence occ;
-                            const Kmer<NW> key = canonical_occurrence<NW>(rec + 1, hl + (int)(idx - roff), nb, K, filter, occ);
-                            const uint64_t hh = kmer_mix<NW>(key);
-                            if (((uint32_t)(hh >> 32) & mask) != val) continue;
+                if (!__hip_atomic_load(&aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                    uint32_t idx = min(total_occ, threadIdx.x * share);
+                    const uint32_t idx1 = min(total_occ, idx + share);
+                    if (idx < idx1) {
+                        uint32_t r = first_rec[threadIdx.x];
+                        uint32_t o_hi = noff[r + 1];
+                        for (; idx < idx1; idx++) {
+                            r += idx >= o_hi ? 1u : 0u;
+                            const uint32_t o_lo = noff[r];
+                            o_hi = noff[r + 1];
+                            const uint32_t* rec = rl + PAD + r * RD;
+                            const uint32_t h_hi = rec[0], h_lo = rec[1];
+                            const uint32_t t = idx - o_lo;
+                            const uint32_t hl = (h_lo >> 1) & 1u, hr = h_lo & 1u, n = (h_lo >> 2) & 0xFFFFu;
+                            uint32_t f[N2], rc[N2], prev, next;
+                            occ_extract<NW>(rec + 2, (int)(hl + t), K, oc, f, rc, prev, next);
+                            const bool lt = occ_less<N2>(f, rc);
+                            const bool hasprev = (hl + t) != 0, hasnext = t + 1 < n + hr;
+                            const uint32_t pv = hasprev ? prev : 4u, nx = hasnext ? next : 4u;          // x ^ 2 keeps "none" (bit 2) set
+                            const uint32_t left = lt ? pv : (nx ^ 2u), right = lt ? nx : (pv ^ 2u);
+                            uint32_t c[N2];
+#pragma unroll
+                            for (int q = 0; q < N2; q++) c[q] = lt ? f[q] : rc[q];
+                            const uint32_t hh = occ_hash<N2>(c);
+                            if (((hh >> 11) & mask) != val) continue;
                             if (dbg & 1) { if (hh == 0x1234) aborted = 1; continue; }      // measurement aid: extraction only
-                            if (!lds_put<NW, SLOTS>(set, key63_from_kmer<NW>(key), hh, occ.left, occ.right, skm_ord(hdr) + (uint64_t)(idx - roff))) {
+                            uint64_t kw[KW];
+                            occ_key63<NW>(c, kw);
+                            const uint64_t ord = ((((uint64_t)h_hi << 32) | h_lo) >> SKM_ORD_SHIFT) + t;
+                            if (!lds_put<NW, SLOTS>(set, kw, hh, left, right, ord)) {
                                 aborted = 1;
                                 break;
                             }
@@ -483,7 +468,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     }
                 }
                 K2_TICK(4);
-                __syncthreads();                                                  // recs / noff are rewritten by the next window
+                __syncthreads();                                                  // rl / noff are rewritten by the next window
                 K2_TICK(5);
             }
             if (aborted) {
@@ -491,7 +476,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 // too many distinct keys for the LDS set: split this key range on the next hash bit and redo both halves
                 if (threadIdx.x == 0) {
                     const uint32_t bit = mask + 1;                                    // masks are 2^k - 1
-                    if (bit >= (1u << 24) || sp_top + 2 > 40) atomicOr(&ctr->e2_flags, F_SPLIT);
+                    if (bit >= (1u << 20) || sp_top + 2 > 40) atomicOr(&ctr->e2_flags, F_SPLIT);
                     else {
                         s_mask[sp_top] = mask | bit; s_val[sp_top] = val; sp_top++;
                         s_mask[sp_top] = mask | bit; s_val[sp_top] = val | bit; sp_top++;
@@ -504,10 +489,14 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
             // issued as soon as the live slots are counted so that its latency hides behind the node finalisation.
             bool live[STRIPES];
             unsigned long long bal[STRIPES];
+            unsigned int puts_of[STRIPES];
 #pragma unroll
             for (int st = 0; st < STRIPES; st++) {
                 const int si = st * THREADS + threadIdx.x;
-                live[st] = si < SLOTS && set.cnt[8][si] != 0;          // a put is only counted once every key word is claimed
+                unsigned int puts = 0;
+                if (si < SLOTS) puts = set.cnt[0][si] + set.cnt[1][si] + set.cnt[2][si] + set.cnt[3][si] + set.cnt[8][si];
+                puts_of[st] = puts;
+                live[st] = puts != 0;                                     // a put is only counted once every key word is claimed
                 bal[st] = __ballot(live[st]);
                 if (lane == 0) wave_cnt[st][wave] = (unsigned int)__popcll(bal[st]);
             }
@@ -534,7 +523,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 cov_bin[st] = 0;                                          // 0 = not live (a live node has cov >= 1)
                 if (live[st]) {
                     const int si = st * THREADS + threadIdx.x;
-                    const unsigned int puts = set.cnt[8][si];
+                    const unsigned int puts = puts_of[st];
                     Key63<NW> k63;
 #pragma unroll
                     for (int w = 0; w < KW; w++) k63.w[w] = set.key[w][si];
@@ -558,8 +547,6 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     rec_out[st][NW] = (uint64_t)A | ((uint64_t)B << 32);
                     rec_out[st][NW + 1] = ((uint64_t)sid << PG_ORD_BITS) | (set.ord[si] & PG_ORD_MASK);
                 }
-                // coverage histogram: most nodes of a partition share one or two coverage values (1 for error k-mers),
-                // so count those per wave instead of hammering one LDS word
                 const unsigned long long ones = __ballot(cov_bin[st] == 1);
                 if (lane == 0 && ones) atomicAdd(&hist[1], (unsigned int)__popcll(ones));
                 if (cov_bin[st] > 1) atomicAdd(&hist[cov_bin[st]], 1u);
@@ -630,7 +617,8 @@ __global__ __launch_bounds__(BLOCK) void skm_lastput_kernel(E2Dev e, SetParams s
 
 static E2Dev dev_view(const pg_ctx* c) {
     const E2& s = c->e2;
-    return E2Dev{s.g, s.rpc, s.maxc, s.pool_chunks, s.cursor, s.chunk_tbl, s.pool, s.out, s.out_capacity};
+    uint32_t lg = 0; while ((1u << lg) < s.rpc) lg++;
+    return E2Dev{s.g, s.rpc, s.maxc, lg, s.pool_chunks, s.cursor, s.chunk_tbl, s.pool, s.out, s.out_capacity};
 }
 
 int e2_create(pg_ctx* c) {
@@ -641,6 +629,7 @@ int e2_create(pg_ctx* c) {
     if (const char* v = getenv("PG_LOG2_PARTS")) s.log2_parts = std::max(4, std::min(24, atoi(v)));
     s.g = skm_geometry(c->K, s.log2_parts, c->NW);
     s.rpc = 128;
+    if (const char* v = getenv("PG_RPC")) { const int q = atoi(v); if (q == 16 || q == 32 || q == 64 || q == 128) s.rpc = (uint32_t)q; }
     const uint64_t parts = (uint64_t)1 << s.log2_parts;
     const uint64_t rec_bytes = (uint64_t)s.g.rw * 8, chunk_bytes = rec_bytes * s.rpc;
     size_t free_b = 0, total_b = 0;
@@ -733,28 +722,42 @@ static int e2_ensure_pool(pg_ctx* c, uint64_t n_reads, uint64_t n_kmers, hipStre
     return PG_OK;
 }
 
+template <int NW, bool ROUTE>
+static void launch_seg_s(int S, dim3 grid, size_t smem, hipStream_t st, const ReadsArg& a, const E2Dev& e, DevCounters* ctr, const SegArg& sa, const RouteArg& ro) {
+    switch (S) {
+        case 7: hipLaunchKernelGGL((skm_scatter_seg_kernel<NW, ROUTE, 7>), grid, dim3(BLOCK), smem, st, a, e, ctr, sa, ro); break;
+        case 9: hipLaunchKernelGGL((skm_scatter_seg_kernel<NW, ROUTE, 9>), grid, dim3(BLOCK), smem, st, a, e, ctr, sa, ro); break;
+        case 11: hipLaunchKernelGGL((skm_scatter_seg_kernel<NW, ROUTE, 11>), grid, dim3(BLOCK), smem, st, a, e, ctr, sa, ro); break;
+        case 13: hipLaunchKernelGGL((skm_scatter_seg_kernel<NW, ROUTE, 13>), grid, dim3(BLOCK), smem, st, a, e, ctr, sa, ro); break;
+        default: hipLaunchKernelGGL((skm_scatter_seg_kernel<NW, ROUTE, 15>), grid, dim3(BLOCK), smem, st, a, e, ctr, sa, ro); break;
+    }
+}
+
 // launch the tiled K1; returns PG_OK / an error, or 1 when the reads are too long for a tile (caller falls back)
 static int launch_tiled(pg_ctx* c, const ReadsArg& a, const RouteArg* route, hipStream_t st) {
-    const int np = (int)a.uniform_len - c->e2.g.m + 1;
-    const size_t per_read = (size_t)(a.wpr + 1) * 8 + (size_t)((a.kpr + 62) / 63) * 8 + (size_t)np * 4 + (size_t)a.kpr * 8;
-    int R = (int)std::min<size_t>(8, (56 * 1024) / per_read);          // small tiles: many resident workgroups hide the LDS / atomic latency
-    if (const char* v = getenv("PG_K1_R")) R = std::max(1, std::min(atoi(v), (int)((56 * 1024) / per_read)));
+    const SkmGeom& g = c->e2.g;
+    const int kpr = (int)a.kpr, wpr = (int)a.wpr, np = (int)a.uniform_len - g.m + 1;
+    int S = tile_pick_segment(kpr, g.w);
+    if (const char* v = getenv("PG_K1_S")) { const int q = atoi(v); if (q >= 7 && q <= 15 && (q & 1) && (q <= g.w || q == 7)) S = q; }
+    const int nseg = (kpr + S - 1) / S, nca = (np + 15) / 16, npad = np | 1, wsd = (2 * wpr + 3) | 1;
+    const size_t per_read = (size_t)(wsd + npad + kpr + nseg + (route ? kpr : 0)) * 4;
+    int R = std::min<int>(128, std::max(1, BLOCK / nseg));                     // one pass of phase B per tile
+    R = (int)std::min<size_t>((size_t)R, (60 * 1024) / per_read);
+    if (const char* v = getenv("PG_K1_R")) R = std::max(1, std::min(atoi(v), (int)std::min<size_t>(128, (60 * 1024) / per_read)));
     if (R < 1) return 1;
-    int lv = 0;
-    while ((2 << lv) <= c->e2.g.w) lv++;
     const uint64_t grid = (a.n_reads + R - 1) / R;
     if (grid > 0x7FFFFFFFULL) { pg_set_error("batch too large for one launch"); return PG_EINVAL; }
-    const size_t smem = per_read * R;
     auto inv = [](uint32_t d) { return (uint32_t)(((1ULL << 32) + d - 1) / d); };
-    TileArg ta{R, np, lv, inv((uint32_t)np), inv(a.kpr), inv(a.wpr)};
+    SegArg sa{R, np, npad, wsd, nseg, nca, inv((uint32_t)R), inv(a.wpr)};
     RouteArg ro{nullptr, nullptr, nullptr, 0, 1};
     if (route) ro = *route;
+    const size_t smem = per_read * R;
     if (c->NW == 2) {
-        if (route) hipLaunchKernelGGL((skm_scatter_tiled_kernel<2, true>), dim3((unsigned)grid), dim3(BLOCK), smem, st, a, dev_view(c), c->ctr, ta, ro);
-        else hipLaunchKernelGGL((skm_scatter_tiled_kernel<2, false>), dim3((unsigned)grid), dim3(BLOCK), smem, st, a, dev_view(c), c->ctr, ta, ro);
+        if (route) launch_seg_s<2, true>(S, dim3((unsigned)grid), smem, st, a, dev_view(c), c->ctr, sa, ro);
+        else launch_seg_s<2, false>(S, dim3((unsigned)grid), smem, st, a, dev_view(c), c->ctr, sa, ro);
     } else {
-        if (route) hipLaunchKernelGGL((skm_scatter_tiled_kernel<4, true>), dim3((unsigned)grid), dim3(BLOCK), smem, st, a, dev_view(c), c->ctr, ta, ro);
-        else hipLaunchKernelGGL((skm_scatter_tiled_kernel<4, false>), dim3((unsigned)grid), dim3(BLOCK), smem, st, a, dev_view(c), c->ctr, ta, ro);
+        if (route) launch_seg_s<4, true>(S, dim3((unsigned)grid), smem, st, a, dev_view(c), c->ctr, sa, ro);
+        else launch_seg_s<4, false>(S, dim3((unsigned)grid), smem, st, a, dev_view(c), c->ctr, sa, ro);
     }
     E2_TRY(hipGetLastError());
     c->e2.counted = false;
@@ -841,12 +844,18 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     if (const char* v = getenv("PG_K2CFG")) cfg = atoi(v);
     // cfg 0: 2048-slot set, 1024 lanes, 512-record windows  -> ~150 KB LDS, one workgroup per CU
     // cfg 1: 1024-slot set,  512 lanes, 256-record windows  ->  ~77 KB LDS, two workgroups per CU
-    if (c->NW == 2) {
-        if (cfg == 0) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, c->ctr, dbg);
-        else hipLaunchKernelGGL((skm_count_kernel<2, 1024, 512, 256>), dim3(grid), dim3(512), 0, st, dev_view(c), delow, sp, c->ctr, dbg);
-    } else {
-        if (cfg == 0) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, c->ctr, dbg);
-        else hipLaunchKernelGGL((skm_count_kernel<4, 512, 512, 256>), dim3(grid), dim3(512), 0, st, dev_view(c), delow, sp, c->ctr, dbg);
+    {
+        const OccConst oc = occ_const(c->K, c->NW);
+        // cfg 2: 512-slot set, 256 lanes, 128-record windows -> ~38 KB LDS, four workgroups per CU (meant for 4x the partitions)
+        if (c->NW == 2) {
+            if (cfg == 0) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
+            else if (cfg == 1) hipLaunchKernelGGL((skm_count_kernel<2, 1024, 512, 256>), dim3(grid), dim3(512), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
+            else hipLaunchKernelGGL((skm_count_kernel<2, 512, 256, 128>), dim3(grid * 2), dim3(256), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
+        } else {
+            if (cfg == 0) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
+            else if (cfg == 1) hipLaunchKernelGGL((skm_count_kernel<4, 512, 512, 256>), dim3(grid), dim3(512), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
+            else hipLaunchKernelGGL((skm_count_kernel<4, 256, 256, 128>), dim3(grid * 2), dim3(256), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
+        }
     }
     E2_TRY(hipGetLastError());
     if (want_last_put) {

@@ -74,19 +74,19 @@ PG_HD uint32_t rev2bit32(uint32_t x) {
     return __builtin_bswap32(x);
 #endif
 }
+// Order of the m-mers = order of this hash of the canonical m-mer (not lexicographic: poly-A would win every window).
+// A bijection of the 32-bit value, so distinct m-mers never tie; one xor and one 32-bit multiply -- it runs once per base
+// of every read, and only the order matters (the partition id re-hashes the winning value, skm_partition).
+PG_HD uint32_t mmer_hash(uint32_t canon) { return (canon ^ 0x5BD1E995u) * 0x9E3779B1u; }
 PG_HD uint32_t mmer_value(const uint64_t* rd, int p, int m) {          // m <= 16: an m-mer is at most 32 bits
     const uint32_t fwd = (uint32_t)(bits_at(rd, 2 * p) >> (64 - 2 * m));
     const uint32_t rc = rev2bit32(fwd ^ 0xAAAAAAAAu) >> (32 - 2 * m);
-    uint32_t x = fwd < rc ? fwd : rc;
-    x ^= x >> 16;                          // order m-mers by a hash, not lexicographically (poly-A would win everywhere)
-    x *= 0x85EBCA6Bu;
-    x ^= x >> 13;
-    x *= 0xC2B2AE35u;
-    x ^= x >> 16;
-    return x;
+    return mmer_hash(fwd < rc ? fwd : rc);
 }
 PG_HD uint32_t skm_partition(uint32_t minval, int log2_parts) {
-    return (uint32_t)(minval * 0x9E3779B1u) >> (32 - log2_parts);
+    uint32_t x = minval * 0x85EBCA6Bu;            // the minimum of a window is a small number: spread it over all bits
+    x ^= x >> 15;
+    return (uint32_t)(x * 0xC2B2AE35u) >> (32 - log2_parts);
 }
 
 // ---- cutting a read into runs ------------------------------------------------------------------------------

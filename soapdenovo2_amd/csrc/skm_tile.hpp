@@ -1,0 +1,146 @@
+// skm_tile.hpp -- the per-thread pieces of the tiled super-k-mer cutter (K1, partition_kernels.hip), host + device.
+//
+// skm_split_read (skm.hpp) is the reference formulation: one serial walk per read.  The tiled kernel computes the same
+// runs for a tile of uniform-length reads with every thread doing a short serial piece of work on consecutive positions
+// (no per-k-mer shuffles, no per-k-mer control flow):
+//
+//   A  tile_mmer_chunk      16 consecutive m-mer values of a read from two dwords of its base string
+//   B  tile_segment<S>      the sliding-window minima of S consecutive k-mers (+ their predecessor) with w + S reads:
+//                           all S + 1 windows share the core [last k-mer, first k-mer + w), so
+//                           min(window j) = min(suffix-min up to the core, core, prefix-min behind the core);
+//                           then partition ids and the run-start bits of the S k-mers
+//   D  tile_next_start      where the run that starts at a given bit ends (the next start bit, in this or a later segment)
+//   E  tile_make_record<PW> the record of a run from the dword string
+//
+// Everything here is plain inline code shared with the CPU harness (tests/emu_skm.cpp), which runs the same phases serially
+// and compares the records with skm_split_read + skm_make_record.
+#pragma once
+#include "skm.hpp"
+#include "occ32.hpp"
+
+namespace pg {
+
+// 32 bits of a dword string (first base in the top bits of dword 0) starting at bit `bit` >= 0; d[bit/32 + 1] readable
+PG_HD uint32_t dw_bits32(const uint32_t* d, int bit) {
+    const int k = bit >> 5;
+    const uint32_t o = (uint32_t)bit & 31u;
+    const uint32_t x = alignbit32(d[k], d[k + 1], 32u - o);
+    return o ? x : d[k];
+}
+
+// hashed canonical m-mer from its 16-base window x (m-mer in the top 2m bits); same value as mmer_value(rd, p, m)
+PG_HD uint32_t mmer_from_window(uint32_t x, int m) {
+    const uint32_t fwd = x >> (32 - 2 * m);
+    uint32_t rc = rc_dword(x);
+    if (m < 16) rc &= (1u << (2 * m)) - 1u;
+    return mmer_hash(fwd < rc ? fwd : rc);
+}
+
+// A: m-mer values at positions 16 c .. 16 c + 15 (those below np) of one read; row = its dword string, out = its value row
+PG_HD void tile_mmer_chunk(const uint32_t* row, int c, int np, int m, uint32_t* out) {
+    const uint32_t d0 = row[c], d1 = row[c + 1];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const int p = 16 * c + i;
+        const uint32_t x = i ? alignbit32(d0, d1, (uint32_t)(32 - 2 * i)) : d0;
+        if (p < np) out[p] = mmer_from_window(x, m);
+    }
+}
+
+// B: k-mers j0 .. j0 + cnt - 1 of a read (cnt <= S <= w), v = the read's m-mer values, w m-mers a k-mer.
+// Returns the run-start bits (bit i = k-mer j0 + i starts a run: first k-mer, partition change, or a multiple of nmax)
+// and the partition ids in pid_out[0 .. cnt).
+template <int S>
+PG_HD uint32_t tile_segment(const uint32_t* v, int j0, int cnt, int w, int nmax, int log2_parts, uint32_t* pid_out) {
+    // window q = k-mer j0 - 1 + q, q = 0 .. cnt: q = 0 is the predecessor of the segment's first k-mer (none when j0 = 0),
+    // wanted only for the partition comparison.  All indices below are compile-time, so the arrays stay in registers.
+    const int jl = j0 - 1, jh = j0 + cnt - 1;
+    const bool has_pred = j0 > 0;
+    uint32_t suf[S + 1], pre[S + 1];
+    suf[S] = 0xFFFFFFFFu;                                          // suf[q] = min over positions [jl + q, jh)
+#pragma unroll
+    for (int q = S - 1; q >= 0; q--) {
+        const bool in = q < cnt && (q > 0 || has_pred);
+        const uint32_t x = in ? v[jl + q] : 0xFFFFFFFFu;
+        suf[q] = in ? (x < suf[q + 1] ? x : suf[q + 1]) : 0xFFFFFFFFu;
+    }
+    uint32_t core = 0xFFFFFFFFu;                                   // positions [jh, jl + w): inside every window (cnt <= S <= w)
+    for (int p = jh; p < jl + w; p++) { const uint32_t x = v[p]; core = x < core ? x : core; }
+    pre[0] = 0xFFFFFFFFu;                                          // pre[q] = min over positions [jl + w, jl + q + w)
+#pragma unroll
+    for (int q = 1; q <= S; q++) {
+        const bool in = q <= cnt;
+        const uint32_t x = in ? v[jl + w + q - 1] : 0xFFFFFFFFu;
+        pre[q] = x < pre[q - 1] ? x : pre[q - 1];
+    }
+    uint32_t mask = 0, prev_pid = 0;
+    int next_cut = 0;                                              // first multiple of nmax >= j0
+    while (next_cut < j0) next_cut += nmax;
+#pragma unroll
+    for (int q = 0; q <= S; q++) {
+        if (q <= cnt) {
+            uint32_t mv = suf[q] < core ? suf[q] : core;
+            mv = pre[q] < mv ? pre[q] : mv;
+            const uint32_t pid = skm_partition(mv, log2_parts);    // (q = 0 without a predecessor: a junk value nobody compares with)
+            if (q >= 1) {
+                const int j = j0 + q - 1;
+                bool start = j == 0 || pid != prev_pid;
+                if (j == next_cut) { start = true; next_cut += nmax; }
+                if (start) mask |= 1u << (q - 1);
+                pid_out[q - 1] = pid;
+            }
+            prev_pid = pid;
+        }
+    }
+    return mask;
+}
+
+// D: end of the run that starts at bit i of segment `seg`: the next start bit of the read (segments seg .. nseg - 1, S
+// k-mers each), or kpr.  masks = the read's segment masks.
+PG_HD int tile_next_start(const uint32_t* masks, int seg, int nseg, int S, int i, int kpr) {
+    const uint32_t own = masks[seg];
+    const uint32_t above = i < 31 ? (own >> (i + 1)) : 0u;
+    if (above) return seg * S + i + __builtin_ffs((int)above);
+    for (int sg = seg + 1; sg < nseg; sg++) {
+        const uint32_t mk = masks[sg];
+        if (mk) return sg * S + __builtin_ffs((int)mk) - 1;
+    }
+    return kpr;
+}
+
+// E: the record of the run [j0, j0 + n) of a read of `len` bases given as a dword string (two zero dwords behind it).
+// Same words as skm_make_record (skm.hpp).
+template <int PW>
+PG_HD void tile_make_record(const uint32_t* row, int len, int j0, int n, uint64_t ord0, int K, uint64_t* rec) {
+    const int has_left = j0 > 0, has_right = (j0 + n - 1 + K) < len;
+    const int b0 = j0 - has_left;
+    const int nb = n + K - 1 + has_left + has_right;
+    rec[0] = skm_header(ord0 + (uint64_t)j0, n, has_left, has_right);
+#pragma unroll
+    for (int i = 0; i < PW; i++) {
+        const int first = 32 * i;
+        uint64_t v = 0;
+        if (first < nb) {
+            const int bit = 2 * (b0 + first);
+            v = ((uint64_t)dw_bits32(row, bit) << 32) | dw_bits32(row, bit + 32);
+            const int valid = nb - first;
+            if (valid < 32) v &= ~0ULL << (64 - 2 * valid);
+        }
+        rec[1 + i] = v;
+    }
+}
+
+// segment length for a read geometry: odd (the m-mer rows are read with stride S between lanes), <= w, least padding
+inline int tile_pick_segment(int kpr, int w) {
+    int best = 7;
+    double best_eff = -1;
+    for (int s = 7; s <= 15; s += 2) {
+        if (s > w && s != 7) continue;
+        const int nseg = (kpr + s - 1) / s;
+        const double eff = (double)kpr / (double)(nseg * s) - 0.002 * (15 - s);   // ties: the longer segment (fewer reads per k-mer)
+        if (eff > best_eff) { best_eff = eff; best = s; }
+    }
+    return best;
+}
+
+}  // namespace pg

@@ -10,6 +10,7 @@
 #include <array>
 #include "../soapdenovo2_amd/csrc/skm.hpp"
 #include "../soapdenovo2_amd/csrc/extract.hpp"
+#include "../soapdenovo2_amd/csrc/occ32.hpp"
 
 using namespace pg;
 
@@ -51,11 +52,32 @@ static int64_t run(const uint64_t* packed, int64_t n_reads, int len, int K, int 
             const uint64_t h = rec[0];
             const int n = skm_n(h), hl = skm_has_left(h), nb = skm_record_bases(h, K);
             int t = 0, bad = 0;
+            // the counting kernel's 32-bit extraction (occ32.hpp) on the record laid out as it is in LDS: dwords in string
+            // order, readable a window's length before the payload (here: junk, as the previous record would be)
+            constexpr int N2 = 2 * NW, PADD = 2 * NW + 4;
+            std::vector<uint32_t> dws(PADD + 2 * (size_t)g.pw + 4, 0xDEADBEEFu);
+            for (int w = 0; w < g.pw; w++) { dws[PADD + 2 * w] = (uint32_t)(rec[1 + w] >> 32); dws[PADD + 2 * w + 1] = (uint32_t)rec[1 + w]; }
+            const OccConst oc = occ_const(K, NW);
             skm_expand_record<NW>(rec, K, filter, [&](const Kmer<NW>& key, int left, int right, uint64_t ord) {
                 // the rolling expansion must agree with the window extraction of extract.hpp position by position
                 Occurrence occ;
                 Kmer<NW> ref = canonical_occurrence<NW>(rec + 1, hl + t, nb, K, filter, occ);
                 if (!kmer_eq<NW>(ref, key) || occ.left != left || occ.right != right || ord != skm_ord(h) + (uint64_t)t) bad = 1;
+                {
+                    uint32_t f[N2], rc[N2], prev, next, c[N2];
+                    occ_extract<NW>(dws.data() + PADD, hl + t, K, oc, f, rc, prev, next);
+                    const bool lt = occ_less<N2>(f, rc);
+                    const bool hasprev = hl + t > 0, hasnext = t < n - 1 + skm_has_right(h);
+                    const int l32 = lt ? (hasprev ? (int)prev : 4) : (hasnext ? (int)(next ^ 2) : 4);
+                    const int r32 = lt ? (hasnext ? (int)next : 4) : (hasprev ? (int)(prev ^ 2) : 4);
+                    for (int q = 0; q < N2; q++) c[q] = lt ? f[q] : rc[q];
+                    for (int q = 0; q < NW; q++) if (key.w[q] != (((uint64_t)c[2 * q] << 32) | c[2 * q + 1])) bad = 6;
+                    if (l32 != left || r32 != right) bad = 7;
+                    uint64_t kw[KeyWords<NW>::value];
+                    occ_key63<NW>(c, kw);
+                    Key63<NW> want = key63_from_kmer<NW>(key);
+                    for (int q = 0; q < KeyWords<NW>::value; q++) if (kw[q] != want.w[q]) bad = 8;
+                }
                 t++;
                 // the 63-bit re-cut used by the LDS set must round-trip
                 Kmer<NW> back = kmer_from_key63<NW>(key63_from_kmer<NW>(key));
@@ -94,3 +116,69 @@ extern "C" int64_t emu_skm_count(const uint64_t* packed, int64_t n_reads, int le
     return mer127 ? run<4>(packed, n_reads, len, K, log2_parts, out, cap, n_records, max_part_distinct)
                   : run<2>(packed, n_reads, len, K, log2_parts, out, cap, n_records, max_part_distinct);
 }
+
+// ---- the tiled cutter (csrc/skm_tile.hpp) run serially: phases A, B, D, E over tiles of R reads, compared run for run
+// and word for word with skm_split_read + skm_make_record.  Returns 0 or a negative code.
+#include "../soapdenovo2_amd/csrc/skm_tile.hpp"
+
+template <int NW, int S>
+static int64_t tile_check(const uint64_t* packed, int64_t n_reads, int len, int K, int log2_parts, int R) {
+    constexpr int PW = NW == 2 ? 5 : 7, RW = PW + 1;
+    const SkmGeom g = skm_geometry(K, log2_parts, NW);
+    const int wpr = (len + 31) / 32, kpr = len - K + 1, np = len - g.m + 1, npad = np | 1;
+    const int wsd = (2 * wpr + 3) | 1, nseg = (kpr + S - 1) / S, nca = (np + 15) / 16;
+    if (S > g.w && S != 7) return -100;
+    int64_t checked = 0;
+    for (int64_t r0 = 0; r0 < n_reads; r0 += R) {
+        const int nr = (int)std::min<int64_t>(R, n_reads - r0);
+        std::vector<uint32_t> dw((size_t)nr * wsd, 0), v0((size_t)nr * npad, 0xABABABABu), pids((size_t)nr * kpr, 0), masks((size_t)nr * nseg, 0);
+        for (int r = 0; r < nr; r++)
+            for (int k = 0; k < wpr; k++) {
+                const uint64_t wd = packed[(r0 + r) * wpr + k];
+                dw[(size_t)r * wsd + 2 * k] = (uint32_t)(wd >> 32); dw[(size_t)r * wsd + 2 * k + 1] = (uint32_t)wd;
+            }
+        for (int t = 0; t < nr * nca; t++) { const int c = t / nr, r = t % nr; tile_mmer_chunk(dw.data() + (size_t)r * wsd, c, np, g.m, v0.data() + (size_t)r * npad); }
+        for (int r = 0; r < nr; r++)                                // phase A against the 64-bit formulation
+            for (int p = 0; p < np; p++) if (v0[(size_t)r * npad + p] != mmer_value(packed + (r0 + r) * wpr, p, g.m)) return -101;
+        for (int t = 0; t < nr * nseg; t++) {
+            const int seg = t / nr, r = t % nr, j0 = seg * S, cnt = std::min(S, kpr - j0);
+            uint32_t pid[S];
+            masks[(size_t)r * nseg + seg] = tile_segment<S>(v0.data() + (size_t)r * npad, j0, cnt, g.w, g.nmax, log2_parts, pid);
+            for (int i = 0; i < cnt; i++) pids[(size_t)r * kpr + j0 + i] = pid[i];
+        }
+        for (int r = 0; r < nr; r++) {
+            struct Run { int j0, n; uint32_t pid; };
+            std::vector<Run> got, want;
+            for (int seg = 0; seg < nseg; seg++) {
+                uint32_t mk = masks[(size_t)r * nseg + seg];
+                while (mk) {
+                    const int i = __builtin_ffs((int)mk) - 1;
+                    mk &= mk - 1;
+                    const int j = seg * S + i, nxt = tile_next_start(masks.data() + (size_t)r * nseg, seg, nseg, S, i, kpr);
+                    got.push_back(Run{j, nxt - j, pids[(size_t)r * kpr + j]});
+                }
+            }
+            const uint64_t* rd = packed + (r0 + r) * wpr;
+            skm_split_read(rd, len, g, [&](int j0, int n, uint32_t pid) { want.push_back(Run{j0, n, pid}); });
+            if (got.size() != want.size()) return -102;
+            for (size_t q = 0; q < got.size(); q++) {
+                if (got[q].j0 != want[q].j0 || got[q].n != want[q].n || got[q].pid != want[q].pid) return -103;
+                uint64_t a[RW], b[RW];
+                const uint64_t ord0 = (uint64_t)(r0 + r) * (uint64_t)kpr + 12345;
+                tile_make_record<PW>(dw.data() + (size_t)r * wsd, len, got[q].j0, got[q].n, ord0, K, a);
+                skm_make_record<PW>(rd, len, want[q].j0, want[q].n, ord0, g, b);
+                for (int k = 0; k < RW; k++) if (a[k] != b[k]) return -104;
+                checked++;
+            }
+        }
+    }
+    return checked;
+}
+
+extern "C" int64_t emu_tile_check(const uint64_t* packed, int64_t n_reads, int len, int K, int mer127, int log2_parts, int S, int R) {
+#define TC(NWV, SV) case SV: return tile_check<NWV, SV>(packed, n_reads, len, K, log2_parts, R);
+    if (mer127) switch (S) { TC(4, 7) TC(4, 9) TC(4, 11) TC(4, 13) TC(4, 15) default: return -99; }
+    switch (S) { TC(2, 7) TC(2, 9) TC(2, 11) TC(2, 13) TC(2, 15) default: return -99; }
+#undef TC
+}
+extern "C" int emu_tile_pick_segment(int kpr, int w) { return tile_pick_segment(kpr, w); }

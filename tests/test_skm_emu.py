@@ -46,3 +46,24 @@ def test_partition_logic_matches_oracle(golden, emu, tmp_path, name, m127, log2_
     reads, kpr = codes.shape[0], codes.shape[1] - K + 1
     assert reads <= nrec.value <= reads * kpr
     print(name, "records/read", nrec.value / reads, "max distinct in a partition", maxd.value)
+
+
+@pytest.mark.parametrize("name,m127", [("t6k_k31", False), ("t8k_k63", False), ("t8k_k63", True), ("t6k_k127", True), ("t5k_k24", False)])
+def test_tiled_cutter_matches_serial_walk(golden, emu, name, m127):
+    """K1's tile formulation (csrc/skm_tile.hpp: m-mer chunks, segment minima, start bits, next start, record build) run
+    serially on the CPU gives exactly the runs and records of skm_split_read + skm_make_record, for every segment length."""
+    c = golden["cases"][name]
+    codes = case_codes(c)[:1500]
+    K = c["K"] | 1
+    packed = api.pack_reads_uniform(codes)
+    emu.emu_tile_check.restype = C.c_int64
+    emu.emu_tile_check.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    m = max(7, min(16, K - 6))
+    w = K - m + 1
+    for S in (7, 9, 11, 13, 15):
+        if S > w and S != 7:
+            continue
+        for R in (1, 5, 32):
+            n = emu.emu_tile_check(packed.ctypes.data, codes.shape[0], codes.shape[1], K, int(m127), 9, S, R)
+            assert n >= codes.shape[0], (S, R, n)
+    assert emu.emu_tile_pick_segment(88, 48) == 11
