@@ -6,8 +6,8 @@ OUT     := soapdenovo2_amd
 CXX     ?= g++
 CXXFLAGS := -O3 -std=c++17 -fPIC -Wall -Wno-unknown-pragmas -Wno-unused-function -Wno-unused-result -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value
-HOSTOBJ := $(CSRC)/host_graph.o $(CSRC)/host_reads.o $(CSRC)/call_pregraph.o
-DEVOBJ  := $(CSRC)/pregraph_kernels.o $(CSRC)/partition_kernels.o $(CSRC)/graph_kernels.o $(CSRC)/sort_records.o
+HOSTOBJ := $(CSRC)/host_graph.o $(CSRC)/host_reads.o $(CSRC)/call_pregraph.o $(CSRC)/host_skm.o
+DEVOBJ  := $(CSRC)/pregraph_kernels.o $(CSRC)/partition_kernels.o $(CSRC)/graph_kernels.o $(CSRC)/sort_records.o $(CSRC)/exchange.o
 HDRS    := $(wildcard $(CSRC)/*.hpp) include/soapdenovo2_amd.h
 
 all: $(OUT)/libsoapdenovo2_amd.so $(OUT)/bin/SOAPdenovo-63mer $(OUT)/bin/SOAPdenovo-127mer
@@ -18,7 +18,7 @@ $(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
 $(OUT)/libsoapdenovo2_amd.so: $(HOSTOBJ) $(DEVOBJ)
-	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $^ -lz -lpthread
+	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $^ -lz -lpthread -ldl
 
 $(OUT)/bin/SOAPdenovo-63mer: $(CSRC)/main.cpp $(OUT)/libsoapdenovo2_amd.so
 	@mkdir -p $(OUT)/bin

@@ -4,8 +4,14 @@
     python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run)
 
 One step = one full pass of the hot path over the workload: empty the k-mer set, then extract and insert every
-k-mer occurrence of every read (for N > 1: extract + route by owner, RCCL all-to-all, insert).  Reads are
-generated on the GPU before the timed region and stay resident in HBM; FASTQ parsing and PCIe are not in `value`.
+k-mer occurrence of every read -- exactly the device work `call_pregraph` does for pass 1: K1 per batch (for N > 1:
+pg_count_reads_sharded = cut + route by owner, RCCL all-to-all, append) and pg_finalize (K2: count every partition,
+-d filter, linear marks, coverage histogram).  Reads are generated on the GPU before the timed region and stay
+resident in HBM; FASTQ parsing and PCIe are not in `value`.  Next to it, measured once outside the timed steps and
+reported in the same JSON line: the export + sort hand-over, a PCIe-inclusive pass (pinned host batches, copies
+overlapped with the kernels), and `whole_command` -- the `SOAPdenovo-63mer pregraph` executable on a FASTQ prefix of
+the same read distribution written to local disk, its stages, and byte equality of its five files with the
+reference binary's (oracle/_ref), whose own timings are the `cpu_baseline`.
 Workload = BASELINE.json configs[2] ("C. elegans-scale 200M x 150 bp synthetic, K=63, 1xMI355X"), the
 configuration the metric (K = 63) is quoted on; per-GPU work is fixed as N grows (weak scaling).
 Prints ONE JSON line on rank 0.
@@ -54,40 +60,74 @@ def gen_packed_reads(torch, dev, genome_len, n_reads, read_len, err, seed, chunk
     return out
 
 
-def cpu_baseline(args, cores):
-    """The reference's own pthreaded pregraph (oracle/_ref, built from /root/reference by oracle/Makefile.ref)
-    timed on this box's host cores on a bounded sample of the same read distribution; pass-1 time is the
-    reference's own 'Time spent on hashing reads' line."""
-    from soapdenovo2_amd import synth
-    ref = os.path.join(ROOT, "oracle", "_ref", "SOAPdenovo-63mer")
-    n = args.cpu_sample_reads
-    with tempfile.TemporaryDirectory() as td:
-        g = min(args.genome, 20_000_000)
-        cfg = synth.make_case(td, "cpu", g, n, args.read_len, args.err, args.seed + 1)
+def md5_outputs(prefix):
+    import gzip
+    import hashlib
+    out = {}
+    for ext in ("kmerFreq", "preGraphBasic", "vertex", "preArc"):
+        out[ext] = hashlib.md5(open(f"{prefix}.{ext}", "rb").read()).hexdigest()
+    h = hashlib.md5()
+    with gzip.open(prefix + ".edge.gz", "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 24), b""):
+            h.update(chunk)
+    out["edge"] = h.hexdigest()
+    return out
+
+
+def whole_command(args, cores):
+    """The `pregraph` executable end to end on a FASTQ prefix of the benchmarked read distribution (local disk), next to the
+    reference's pthreaded pregraph (oracle/_ref, built from /root/reference by oracle/Makefile.ref) on the same file and the
+    same host cores.  Returns (whole_command, cpu_baseline)."""
+    from soapdenovo2_amd import api, synth
+    ref = os.path.join(ROOT, "oracle", "_ref", "SOAPdenovo-127mer" if args.kmer > 63 else "SOAPdenovo-63mer")
+    mine = api.binary(args.kmer > 63)
+    n = args.whole_reads
+    td = tempfile.mkdtemp(prefix="pgbench_", dir=os.environ.get("PG_BENCH_TMP"))
+    try:
+        t0 = time.time()
+        codes = synth.gpu_reads_codes(args.genome, n, args.read_len, args.err, args.seed + 1)
+        fq, cfg = os.path.join(td, "reads.fq"), os.path.join(td, "lib.cfg")
+        synth.write_fastq_fast(fq, codes)
+        del codes
+        synth.write_config(cfg, fq, args.read_len)
+        t_gen = time.time() - t0
+        wc = {"workload": f"first {n} reads of the benchmarked distribution ({args.read_len} bp, genome {args.genome}, err {args.err}) as FASTQ on local disk, "
+                          f"K={args.kmer}, -p {args.sets}", "reads": n, "fastq_bytes": os.path.getsize(fq), "generate_s": round(t_gen, 1)}
+        base = [ "pregraph", "-s", cfg, "-K", str(args.kmer), "-p", str(args.sets)]
+        t0 = time.time()
+        out = subprocess.run([mine] + base + ["-o", os.path.join(td, "amd")], capture_output=True, text=True, env=dict(os.environ, PG_HOST_VERBOSE="1"))
+        wall = time.time() - t0
+        wc.update({"rc": out.returncode, "wall_s": wall, "reads_per_sec": n / wall if out.returncode == 0 else None,
+                   "stages_s": {m.group(1): float(m.group(2)) for m in re.finditer(r"\[cli\] ([^:]+): ([0-9.]+)s", out.stderr)}})
+        m = re.search(r"(\d+) node\(s\) allocated", out.stderr)
+        if m:
+            wc["distinct_kmers"] = int(m.group(1))
+        if out.returncode != 0:
+            wc["stderr_tail"] = out.stderr[-800:]
+        cpu = None
         if os.path.exists(ref):
             t0 = time.time()
-            out = subprocess.run([ref, "pregraph", "-s", cfg, "-K", str(args.kmer), "-o", os.path.join(td, "o"), "-p", str(cores)],
-                                 capture_output=True, text=True)
-            wall = time.time() - t0
-            m = re.search(r"Time spent on hashing reads: (\d+)s", out.stderr)
-            m2 = re.search(r"Time spent on pre-graph construction: (\d+)s", out.stderr)
-            sec = float(m.group(1)) if m else None
-            if not sec:
-                sec = float(m2.group(1)) if m2 and float(m2.group(1)) > 0 else wall
-            return {"value": n / sec, "unit": "reads/s", "cores": cores, "kind": "reference",
-                    "sample": f"{n} reads x {args.read_len} bp, genome {g}, err {args.err}, K={args.kmer}, -p {cores}; "
-                              f"pass 1 {sec:.0f} s of {wall:.0f} s whole command"}
-        # fall back to the single-threaded C restatement
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        from oracle_binding import Oracle
-        codes = synth.reads_codes(g, n // 8, args.read_len, args.err, args.seed + 1)
-        o = Oracle(args.kmer, P=8, max_read_len=args.read_len)
-        t0 = time.time()
-        o.add_reads(codes)
-        sec = time.time() - t0
-        o.close()
-        return {"value": (n // 8) / sec, "unit": "reads/s", "cores": 1, "kind": "port",
-                "sample": f"{n // 8} reads x {args.read_len} bp, K={args.kmer}, oracle/pregraph_oracle.c pass 1"}
+            r = subprocess.run([ref, "pregraph", "-s", cfg, "-K", str(args.kmer), "-p", str(cores), "-o", os.path.join(td, "ref")], capture_output=True, text=True)
+            rwall = time.time() - t0
+            m1 = re.search(r"Time spent on hashing reads: (\d+)s", r.stderr)
+            sec = float(m1.group(1)) if m1 and float(m1.group(1)) > 0 else rwall
+            cpu = {"value": n / sec, "unit": "reads/s", "cores": cores, "kind": "reference",
+                   "sample": f"{n} reads x {args.read_len} bp, genome {args.genome}, err {args.err}, K={args.kmer}, -p {cores}: pass 1 ('Time spent on hashing "
+                             f"reads') {sec:.0f} s of {rwall:.0f} s whole command", "whole_command_reads_per_sec": n / rwall}
+            wc["reference_wall_s"] = rwall
+            wc["reference_threads"] = cores
+            wc["speedup_vs_reference"] = rwall / wall if out.returncode == 0 else None
+            # (-p fixes the order of .vertex / .edge.gz, so the reference runs at the same -p as the executable: one run serves
+            #  as the CPU baseline and as the byte-for-byte check)
+            refp = os.path.join(td, "ref") if r.returncode == 0 else None
+            if refp and out.returncode == 0:
+                a, b = md5_outputs(os.path.join(td, "amd")), md5_outputs(refp)
+                wc["files_identical_to_reference"] = a == b
+                wc["md5"] = a
+        return wc, cpu
+    finally:
+        import shutil
+        shutil.rmtree(td, ignore_errors=True)
 
 
 def main():
@@ -105,8 +145,10 @@ def main():
     ap.add_argument("--mer127", action="store_true", help="four-word k-mers (the SOAPdenovo-127mer flavour); implied by --kmer > 63")
     ap.add_argument("--batch-reads", type=int, default=16_000_000)
     ap.add_argument("--log2-slots", type=int, default=0, help="0 = size from the expected distinct count")
-    ap.add_argument("--cpu-sample-reads", type=int, default=2_000_000)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--whole-reads", type=int, default=4_000_000, help="reads of the whole-command / CPU-baseline FASTQ (0 = skip both)")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the whole-command run and the reference run (kernel work only)")
+    ap.add_argument("--no-extras", action="store_true", help="skip the export + sort and the PCIe-inclusive measurements")
+    ap.add_argument("--exchange", default="lib", help="N > 1: lib = pg_count_reads_sharded (librccl through the C ABI), torch = torch.distributed all_to_all")
     ap.add_argument("--engine", type=int, default=2, help="2 = super-k-mer partitions counted in LDS (default), 1 = one DRAM-resident set")
     ap.add_argument("--comm", default="nccl", help="nccl (RCCL over xGMI) or gloo (test only: exchange staged through the host)")
     ap.add_argument("--share-gpu", action="store_true", help="test only: every rank uses cuda:0")
@@ -138,6 +180,28 @@ def main():
             o = torch.empty(out_t.shape, dtype=out_t.dtype)
             dist.all_to_all_single(o, in_t.cpu(), out_splits, in_splits)
             out_t.copy_(o)
+
+    # N > 1: the library's own communicator (librccl through the C ABI): rank 0 makes the id, torch's store carries it
+    comm, exchange = None, "none"
+    if world > 1 and args.engine == 2:
+        exchange = args.exchange
+        if args.comm != "nccl" or args.share_gpu:
+            exchange = "torch"                                   # RCCL refuses ranks that share a GPU (test set-ups only)
+        if exchange == "lib":
+            ok = 1
+            try:
+                box = [api.Comm.unique_id() if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                comm = api.Comm.rccl(world, rank, local, box[0])
+            except Exception as e:                               # e.g. librccl missing: say so and use torch's RCCL
+                print(f"[bench rank {rank}] pg_comm_create failed ({e}); falling back to torch.distributed", file=sys.stderr)
+                ok = 0
+            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 0:
+                if comm is not None:
+                    comm.close()
+                comm, exchange = None, "torch (fallback)"
 
     K, L, P = args.kmer, args.read_len, args.sets
     kpr = L - K + 1
@@ -174,8 +238,12 @@ def main():
                 if timed:
                     e1.record()
                     ev.append((e0, e1, n))
+            elif engine == 2 and comm is not None:
+                # partition engine across GPUs: owner(partition) = partition mod world; super-k-mer records travel.
+                # One collective call of the library per batch: cut + route, counts, records (ncclSend/ncclRecv group), append.
+                kc.count_sharded(comm, view, n, L, ord0 + lo * kpr)
             elif engine == 2:
-                # partition engine across GPUs: owner(partition) = partition mod world; super-k-mer records travel
+                # the same steps spelled out with torch.distributed as the transport
                 rw = kc.record_words()
                 cap = int(n * (2.0 * kpr / (kpr_w + 1) + 1) * 1.5 / world) + 1024
                 recs, parts, counts = kc.skm_route(view, n, L, ord0 + lo * kpr, world, cap)
@@ -236,6 +304,61 @@ def main():
         dist.all_reduce(t)
         distinct = int(t.item())
 
+    # ---- outside the timed steps (N = 1): the hand-over call_pregraph does after pass 1, and a PCIe-inclusive pass
+    extras = {}
+    if world == 1 and engine == 2 and not args.no_extras:
+        # (a) export + sort: distinct k-mers into (set, first ordinal) order for the layout replay (pg_export + pg_sort_records)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        rw_e = kc.nw + 2
+        d = torch.empty(max(distinct, 1) * rw_e, dtype=torch.int64, device=dev)
+        got = __import__("ctypes").c_uint64(0)
+        api._check(api.lib().pg_export(kc.h, d.data_ptr(), distinct, __import__("ctypes").byref(got), kc._stream()), "pg_export")
+        sort_ok = distinct < (1 << 31)
+        if sort_ok:
+            api._check(api.lib().pg_sort_records(d.data_ptr(), distinct, int(mer127), kc._stream()), "pg_sort_records")
+        torch.cuda.synchronize()
+        extras["export_sort_ms"] = (time.perf_counter() - t0) * 1e3
+        extras["export_sorted_on_device"] = bool(sort_ok)
+        del d
+        # (b) per-set counts + the decision about the last put (what call_pregraph runs instead of K3)
+        t0 = time.perf_counter()
+        cnts = kc.set_counts()
+        need = bool(api.lib().pg_host_last_put_matters(cnts.ctypes.data, P, 0, int(mer127)))
+        extras["set_counts_ms"] = (time.perf_counter() - t0) * 1e3
+        extras["last_put_needed"] = need
+        t0 = time.perf_counter()
+        kc.last_put()
+        extras["last_put_kernel_ms"] = (time.perf_counter() - t0) * 1e3          # paid only when needed
+        # (c) one pass with the batches coming from pinned host memory: two device buffers, copies on their own stream
+        nb = min(args.batch_reads, n_reads)
+        host = torch.empty(nb * wpr + 8, dtype=torch.int64).pin_memory()
+        host.copy_(packed[: nb * wpr + 8])
+        dbuf = [torch.empty(nb * wpr + 8, dtype=torch.int64, device=dev) for _ in range(2)]
+        cstream = torch.cuda.Stream()
+        copied = [torch.cuda.Event() for _ in range(2)]
+        used = [torch.cuda.Event() for _ in range(2)]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        kc.reset()
+        for i, (lo, n) in enumerate(batches):
+            b = i & 1
+            with torch.cuda.stream(cstream):
+                if i >= 2:
+                    cstream.wait_event(used[b])
+                dbuf[b][: n * wpr + 8].copy_(host[: n * wpr + 8], non_blocking=True)
+                copied[b].record(cstream)
+            torch.cuda.current_stream().wait_event(copied[b])
+            kc.count_uniform(dbuf[b], n, L, ord0 + lo * kpr)
+            used[b].record(torch.cuda.current_stream())
+        kc.finalize(0, want_last_put=False)
+        torch.cuda.synchronize()
+        dt_h = time.perf_counter() - t0
+        extras["pcie_inclusive_ms_per_pass"] = dt_h * 1e3
+        extras["pcie_inclusive_reads_per_sec"] = n_reads / dt_h
+        extras["pcie_note"] = f"every batch ({nb} reads, {nb * wpr * 8 / 1e6:.0f} MB packed) copied from pinned host memory, double-buffered on a copy stream"
+        del host, dbuf
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         total_reads = n_reads * world
@@ -252,8 +375,13 @@ def main():
                        "engine": engine,
                        "parallelism": ("single GPU, " + ("super-k-mer partitions counted in LDS" if engine == 2 else "fused extract+insert into one DRAM set"))
                        if world == 1 else (f"partition-owner (partition mod {world}), super-k-mer records over RCCL all-to-all" if engine == 2
-                                           else f"set-id owner, k-mer records over RCCL all-to-all x{world}")},
+                                           else f"set-id owner, k-mer records over RCCL all-to-all x{world}"),
+                       "exchange": {"lib": "pg_count_reads_sharded (librccl ncclSend/ncclRecv group through the C ABI)", "none": None}.get(exchange, exchange)},
         }
+        if comm is not None:
+            rec["config"]["exchange_stats_rank0"] = comm.stats()
+        if extras:
+            rec["pass1_hand_over"] = extras
         if world == 1 and ev:
             slot_b = 80 if mer127 else 48
             bytes_per_read = kpr * slot_b + (L + 3) // 4          # node read + node write per occurrence + packed read
@@ -269,7 +397,7 @@ def main():
                 launches, avg_ms, per_launch = len(ev), sum(dur) / len(dur) * 1e3, sum(alg) / len(alg)
                 extra = {}
             else:
-                # Partition engine: two kernels share the pass.  K1 (skm_scatter_tiled_kernel) reads the packed reads and
+                # Partition engine: two kernels share the pass.  K1 (skm_scatter_seg_kernel) reads the packed reads and
                 # writes super-k-mer records; K2 (skm_count_kernel) reads the records, counts every partition in LDS and writes
                 # the distinct k-mers.  `achieved` follows the contract: SURVEY.md 8d's algorithmic bytes per read (one node
                 # read + one node write per k-mer occurrence + the packed read) x the reads one launch of the dominant kernel
@@ -281,7 +409,7 @@ def main():
                 k1_s, k2_s = sum(dur) / args.steps, sum(dur2) / args.steps
                 alg_pass = n_reads * bytes_per_read
                 if k1_s >= k2_s:
-                    kernel, achieved = f"skm_scatter_tiled_kernel<{nwk}>", alg_pass / k1_s / 1e9
+                    kernel, achieved = f"skm_scatter_seg_kernel<{nwk}>", alg_pass / k1_s / 1e9
                     launches, avg_ms, per_launch = len(ev), sum(dur) / len(dur) * 1e3, alg_pass / len(batches)
                 else:
                     kernel, achieved = f"skm_count_kernel<{nwk}>", alg_pass / k2_s / 1e9
@@ -305,15 +433,29 @@ def main():
                         traffic = tj.get(kn + "_bytes_per_launch")
                 except Exception:
                     traffic = None
+            # `bound` names the roofline the contract prices this path against (HBM bytes of a hash-table
+            # formulation).  The kernel itself moves 0.15x those bytes and is limited elsewhere, see `limiter`.
+            limiter = ("LDS atomics on the partition's hot k-mers (same-address adds serialise) + the latency of the short per-partition phases "
+                       "(stage, prefix sum, emit) between workgroup barriers; vector ALU ~45 % busy, HBM ~7 % of peak "
+                       "(profiles/r02_k2_phase_cycles_20M.txt, DESIGN.md 3.2)") if engine == 2 else "random-atomic rate of the DRAM-resident set"
             rec["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                                "traffic": traffic, "kernel": kernel, "launches": launches, "avg_launch_ms": avg_ms,
-                               "algorithmic_bytes_per_launch": per_launch, **extra}
-            if not args.no_cpu_baseline:
-                # the reference's workers each scan the whole k-mer buffer (prlHashReads.c:79-90), so its pass 1 stops
-                # scaling long before a 100+-core host is used up: cap -p at 16 and say so
-                rec["cpu_baseline"] = cpu_baseline(args, min(os.cpu_count() or 1, 16))
+                               "algorithmic_bytes_per_launch": per_launch, "limiter": limiter, **extra}
+            if not args.no_cpu_baseline and args.whole_reads > 0:
+                # the reference's workers each scan the whole k-mer buffer (prlHashReads.c:79-90), so its pass 1 stops scaling
+                # long before a 100+-core host is used up (-p 256 was slower than -p 16 in round 1); it runs at the same -p as
+                # the executable, which also makes its files comparable byte for byte
+                kc.close()                                            # the executable wants the GPU memory
+                del packed
+                torch.cuda.empty_cache()
+                wc, cpu = whole_command(args, args.sets)
+                rec["whole_command"] = wc
+                if cpu:
+                    rec["cpu_baseline"] = cpu
         print(json.dumps(rec), flush=True)
     kc.close()
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 

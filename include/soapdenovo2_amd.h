@@ -153,6 +153,14 @@ int pg_host_replay_layout(const uint64_t *records, uint64_t n_records, const uin
                           int n_sets, int a_gb, uint64_t *out_slot /* [n_records] */,
                           uint64_t *out_set_size /* [n_sets], may be NULL */);
 
+/* Host twins of the multi-GPU routing step (no GPU; tests and tools): cut a uniform-length batch of packed reads into
+ * super-k-mer records exactly as pg_skm_route does -- records_out[i * W ..] (W = 6 / 8 words), tags_out[i] = partition << 8
+ * | owner with owner = partition mod n_owners -- and expand records back into k-mer occurrences, rows of
+ * (key words..., left, right, ordinal); left / right = base code or 4 for none.  Return the count, or -1. */
+int64_t pg_host_skm_cut(const uint64_t *packed, uint64_t n_reads, uint32_t read_len, int K, int mer127, int log2_parts, uint64_t ord_base,
+                        int n_owners, uint64_t *records_out, uint64_t *tags_out, uint64_t capacity);
+int64_t pg_host_skm_expand(const uint64_t *records, uint64_t n_records, int K, int mer127, uint64_t *out, uint64_t capacity);
+
 /* Write <prefix>.kmerFreq from the 256-bin coverage histogram (freqStat, prlHashReads.c:1104-1132). */
 int pg_host_write_kmerfreq(const uint64_t hist[256], const char *prefix);
 
@@ -248,11 +256,69 @@ int pg_finalize(pg_ctx *ctx, int delow, uint64_t hist_out[256], uint64_t *set_la
  * pg_distinct() records; order is unspecified.  *n_out (host) receives the count.  Synchronises. */
 int pg_export(pg_ctx *ctx, uint64_t *d_records, uint64_t capacity, uint64_t *n_out, void *stream);
 
+/* Partition engine, after pg_finalize(..., set_last_put_out = NULL, ...): the number of distinct k-mers per reference set
+ * (out[256]), and the per-set last put computed on demand.  The layout replay needs the last put only when a set's count sits
+ * exactly at a growth threshold of the reference's size schedule (pg_host_last_put_matters on the counts, summed over the
+ * ranks in a multi-GPU run); otherwise that second expansion of every record is skipped and zeros are handed over. */
+int pg_set_counts(pg_ctx *ctx, uint64_t out[256], void *stream);
+int pg_last_put(pg_ctx *ctx, uint64_t *set_last_put_out, void *stream);
+/* 1 when, for some set, a duplicate put arriving after its last new key would grow the reference's table (newhash.c:477). */
+int pg_host_last_put_matters(const uint64_t *set_counts, int n_sets, int a_gb, int mer127);
+
+/* Partition engine: the export array itself instead of a copy of it (the caller owns *d_records_out and frees it with
+ * hipFree); everything else the context holds on the device is released, the context can only be destroyed afterwards. */
+int pg_export_take(pg_ctx *ctx, uint64_t **d_records_out, uint64_t *n_out);
+
 /* Order exported records (device memory, on the current device) by their last word, i.e. by k-mer set and then by
  * first-occurrence ordinal: the order in which the layout replay of pg_host_build_graph / pg_host_graph_begin inserts
  * them (put_kmerset order, newhash.c:473-528).  Records handed over in this order are inserted as they lie; otherwise
  * the host buckets and sorts them itself.  n_records < 2^31.  Synchronises. */
 int pg_sort_records(uint64_t *d_records, uint64_t n_records, int mer127, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * 4. Multi-GPU pass 1.  The reference hands every k-mer to the set it hashes to through shared memory
+ *    (each of its `thrd_num` workers scans the whole buffer for `hashBanBuffer[i] % thrd_num == id`,
+ *    standardPregraph/prlHashReads.c:79-90).  Across GPUs the unit that travels is the super-k-mer record and
+ *    owner(record) = minimizer partition mod n_ranks; a rank counts the partitions it owns with no further exchange.
+ *    A communicator has one rank per GPU: one per process (PG_COMM_RCCL: the 128-byte id made by rank 0 travels out of
+ *    band, e.g. through the torch.distributed store) or several in one process, one host thread each
+ *    (pg_comm_create_local; PG_COMM_RCCL when every rank has its own device, PG_COMM_P2P -- peer copies between the
+ *    ranks' buffers -- when ranks share a device or on request).  Every call below is collective: all ranks make it,
+ *    in the same order.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct pg_comm pg_comm;
+#define PG_COMM_RCCL 0   /* ncclSend / ncclRecv in one group: a direct all-to-all over xGMI */
+#define PG_COMM_P2P 1    /* one process: barrier + peer-to-peer copies */
+int pg_comm_unique_id(uint8_t id[128]);
+pg_comm *pg_comm_create(int n_ranks, int rank, int device, const uint8_t id[128]);
+/* transport: PG_COMM_RCCL, PG_COMM_P2P, or -1 = RCCL when the devices are pairwise distinct (SOAPDENOVO2_AMD_EXCHANGE=p2p|rccl
+ * overrides), else P2P.  out[n_ranks] receives the ranks' communicators. */
+int pg_comm_create_local(int n_ranks, const int *devices, int transport, pg_comm **out);
+void pg_comm_destroy(pg_comm *comm);
+int pg_comm_rank(const pg_comm *comm);
+int pg_comm_size(const pg_comm *comm);
+int pg_comm_transport(const pg_comm *comm);
+/* out[0] rounds, out[1] records sent, out[2] records received, out[3] records per owner region */
+int pg_comm_stats(const pg_comm *comm, uint64_t out[4]);
+
+/* d_send_counts[o] goes to rank o, d_recv_counts[q] comes from rank q (device memory, n_ranks words each). */
+int pg_exchange_counts(pg_comm *comm, const uint64_t *d_send_counts, uint64_t *d_recv_counts, void *stream);
+/* Variable all-to-all of the records pg_skm_route wrote (owner o's at d_send_records + o * capacity_per_owner * rec_words,
+ * ids at d_send_parts + o * capacity_per_owner).  send_counts / recv_counts are host arrays (what pg_exchange_counts moved);
+ * what rank q sent lands behind what ranks < q sent. */
+int pg_exchange_records(pg_comm *comm, const uint64_t *d_send_records, const uint32_t *d_send_parts, uint64_t capacity_per_owner,
+                        int rec_words, const uint64_t *send_counts, const uint64_t *recv_counts, uint64_t *d_recv_records,
+                        uint32_t *d_recv_parts, void *stream);
+/* In-place sum over the ranks (the 256-bin coverage histogram behind .kmerFreq, prlHashReads.c:1104-1132). */
+int pg_exchange_allreduce_u64(pg_comm *comm, uint64_t *d_buf, uint64_t n, void *stream);
+/* Every rank's exported records on rank `root`, rank after rank (d_out / capacity / n_out matter on the root only). */
+int pg_exchange_gather_records(pg_comm *comm, const uint64_t *d_records, uint64_t n_local, int rec_words, int root, uint64_t *d_out,
+                               uint64_t capacity, uint64_t *n_out, void *stream);
+/* One batch of pass 1 on all ranks: pg_skm_route (ragged batches too: d_word_off / d_kmer_base as in pg_count_reads), the count
+ * and record exchange, pg_skm_ingest.  A rank with nothing to contribute in a round calls it with n_reads = 0.  The send and
+ * receive regions live in the communicator and grow as needed.  After the last round: pg_finalize on every rank. */
+int pg_count_reads_sharded(pg_ctx *ctx, pg_comm *comm, const uint64_t *d_packed, const uint64_t *d_word_off, const uint64_t *d_kmer_base,
+                           uint64_t n_reads, uint32_t uniform_len, uint64_t n_kmers, uint64_t ord_base, void *stream);
 
 #ifdef __cplusplus
 }

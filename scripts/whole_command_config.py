@@ -13,39 +13,11 @@ sys.path.insert(0, ROOT)
 from soapdenovo2_amd import synth, api
 
 
-def write_fastq_fast(path, codes):
-    n, L = codes.shape
-    names = np.char.zfill(np.arange(n).astype("U9"), 9).astype("S9").view(np.uint8).reshape(n, 9)
-    rec = np.empty((n, 2 + 9 + 1 + L + 3 + L + 1), dtype=np.uint8)
-    rec[:, 0] = ord("@"); rec[:, 1] = ord("r"); rec[:, 2:11] = names; rec[:, 11] = 10
-    rec[:, 12:12 + L] = np.frombuffer(b"ACTG", dtype=np.uint8)[codes]
-    rec[:, 12 + L] = 10; rec[:, 13 + L] = ord("+"); rec[:, 14 + L] = 10
-    rec[:, 15 + L:15 + 2 * L] = ord("I"); rec[:, 15 + 2 * L] = 10
-    blob = rec.tobytes()
-    if len(blob) % 32768 == 0:
-        blob = blob[:-1] + b" \n"
-    open(path, "wb").write(blob)
+write_fastq_fast = synth.write_fastq_fast
 
 
-def gpu_codes(genome_len, n_reads, read_len, err, seed, chunk=2_000_000):
-    """same read model as synth.reads_codes, drawn with torch on the GPU (numpy takes minutes at 10 M reads)"""
-    import torch
-    dev = torch.device("cuda", 0)
-    g = torch.Generator(device=dev); g.manual_seed(seed)
-    genome = torch.randint(0, 4, (genome_len,), dtype=torch.uint8, device=dev, generator=g)
-    ar = torch.arange(read_len, device=dev, dtype=torch.int64)
-    out = np.empty((n_reads, read_len), dtype=np.uint8)
-    for lo in range(0, n_reads, chunk):
-        n = min(chunk, n_reads - lo)
-        starts = torch.randint(0, genome_len - read_len, (n,), device=dev, generator=g, dtype=torch.int64)
-        reads = genome[starts[:, None] + ar[None, :]]
-        flip = torch.rand(n, device=dev, generator=g) < 0.5
-        reads = torch.where(flip[:, None], torch.flip(reads, dims=[1]) ^ 2, reads)
-        mask = torch.rand(reads.shape, device=dev, generator=g) < err
-        shift = torch.randint(1, 4, reads.shape, device=dev, generator=g, dtype=torch.uint8)
-        reads = torch.where(mask, (reads + shift) & 3, reads)
-        out[lo:lo + n] = reads.cpu().numpy()
-    return out
+def gpu_codes(genome_len, n_reads, read_len, err, seed):
+    return synth.gpu_reads_codes(genome_len, n_reads, read_len, err, seed)
 
 
 def md5s(prefix):

@@ -106,6 +106,29 @@ def lib() -> C.CDLL:
     L.pg_stats.argtypes = [C.c_void_p, u64p]
     L.pg_finalize.argtypes = [C.c_void_p, C.c_int, u64p, u64p, C.c_void_p]
     L.pg_export.argtypes = [C.c_void_p, u64p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]
+    L.pg_export_take.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.pg_set_counts.argtypes = [C.c_void_p, u64p, C.c_void_p]
+    L.pg_last_put.argtypes = [C.c_void_p, u64p, C.c_void_p]
+    L.pg_host_last_put_matters.argtypes = [u64p, C.c_int, C.c_int, C.c_int]
+    # multi-GPU exchange (include/soapdenovo2_amd.h, section 4)
+    L.pg_comm_unique_id.argtypes = [C.c_void_p]
+    L.pg_comm_create.restype = C.c_void_p
+    L.pg_comm_create.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p]
+    L.pg_comm_create_local.argtypes = [C.c_int, C.c_void_p, C.c_int, C.c_void_p]
+    L.pg_comm_destroy.argtypes = [C.c_void_p]
+    L.pg_comm_rank.argtypes = [C.c_void_p]
+    L.pg_comm_size.argtypes = [C.c_void_p]
+    L.pg_comm_transport.argtypes = [C.c_void_p]
+    L.pg_comm_stats.argtypes = [C.c_void_p, u64p]
+    L.pg_exchange_counts.argtypes = [C.c_void_p, u64p, u64p, C.c_void_p]
+    L.pg_exchange_records.argtypes = [C.c_void_p, u64p, u64p, C.c_uint64, C.c_int, u64p, u64p, u64p, u64p, C.c_void_p]
+    L.pg_exchange_allreduce_u64.argtypes = [C.c_void_p, u64p, C.c_uint64, C.c_void_p]
+    L.pg_exchange_gather_records.argtypes = [C.c_void_p, u64p, C.c_uint64, C.c_int, C.c_int, u64p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]
+    L.pg_count_reads_sharded.argtypes = [C.c_void_p, C.c_void_p, u64p, u64p, u64p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p]
+    L.pg_host_skm_cut.restype = C.c_int64
+    L.pg_host_skm_cut.argtypes = [u64p, C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, u64p, u64p, C.c_uint64]
+    L.pg_host_skm_expand.restype = C.c_int64
+    L.pg_host_skm_expand.argtypes = [u64p, C.c_uint64, C.c_int, C.c_int, u64p, C.c_uint64]
     _lib = L
     return L
 
@@ -114,6 +137,9 @@ EXPORTED_SYMBOLS = [
     "pg_last_error", "pg_version", "call_pregraph", "call_pregraph_127mer", "pg_packed_words", "pg_pack_read",
     "pg_host_build_graph", "pg_host_graph_begin", "pg_host_graph_add_reads", "pg_host_graph_finish", "pg_host_graph_resolve_repeats", "pg_host_graph_add_packed", "pg_graph_use_device", "pg_sort_records", "pg_expect_kmers", "pg_create_sized", "pg_graph_begin", "pg_graph_begin_streamed", "pg_host_read_all", "pg_host_replay_layout", "pg_host_write_kmerfreq", "pg_create", "pg_create_engine", "pg_destroy", "pg_reset", "pg_set_autogrow", "pg_count_reads", "pg_route_count",
     "pg_route_scatter", "pg_count_records", "pg_skm_route", "pg_skm_ingest", "pg_distinct", "pg_stats", "pg_table_info", "pg_finalize", "pg_export",
+    "pg_export_take", "pg_set_counts", "pg_last_put", "pg_host_last_put_matters", "pg_comm_unique_id", "pg_comm_create", "pg_comm_create_local", "pg_comm_destroy", "pg_comm_rank", "pg_comm_size",
+    "pg_comm_transport", "pg_comm_stats", "pg_exchange_counts", "pg_exchange_records", "pg_exchange_allreduce_u64",
+    "pg_exchange_gather_records", "pg_count_reads_sharded", "pg_host_skm_cut", "pg_host_skm_expand",
 ]
 
 
@@ -276,6 +302,94 @@ def host_write_kmerfreq(hist: np.ndarray, prefix: str) -> None:
 # ---------------------------------------------------------------------------------------------------------
 # device operators (torch tensors carry the device memory; the kernels are the library's)
 # ---------------------------------------------------------------------------------------------------------
+PG_COMM_RCCL, PG_COMM_P2P = 0, 1
+
+
+class Comm:
+    """One rank of a pass-1 communicator (pg_comm_*): `Comm.rccl(n, rank, device, id)` for one rank per process,
+    `Comm.local(devices)` for several ranks (host threads) in this process."""
+
+    def __init__(self, handle, owner=True):
+        self.h = handle
+        self.owner = owner
+
+    @staticmethod
+    def unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        _check(lib().pg_comm_unique_id(C.addressof(buf)), "pg_comm_unique_id")
+        return bytes(buf)
+
+    @staticmethod
+    def rccl(n_ranks: int, rank: int, device: int, uid: bytes) -> "Comm":
+        buf = (C.c_uint8 * 128).from_buffer_copy(uid)
+        h = lib().pg_comm_create(n_ranks, rank, device, C.addressof(buf))
+        if not h:
+            raise PgError("pg_comm_create failed: " + lib().pg_last_error().decode())
+        return Comm(h)
+
+    @staticmethod
+    def local(devices: Sequence[int], transport: int = -1):
+        n = len(devices)
+        dv = (C.c_int * n)(*devices)
+        out = (C.c_void_p * n)()
+        _check(lib().pg_comm_create_local(n, C.addressof(dv), transport, C.addressof(out)), "pg_comm_create_local")
+        return [Comm(out[i]) for i in range(n)]
+
+    @property
+    def rank(self) -> int:
+        return lib().pg_comm_rank(self.h)
+
+    @property
+    def size(self) -> int:
+        return lib().pg_comm_size(self.h)
+
+    @property
+    def transport(self) -> str:
+        return "rccl" if lib().pg_comm_transport(self.h) == PG_COMM_RCCL else "p2p"
+
+    def stats(self) -> dict:
+        out = np.zeros(4, dtype=np.uint64)
+        _check(lib().pg_comm_stats(self.h, out.ctypes.data), "pg_comm_stats")
+        return {"rounds": int(out[0]), "sent_records": int(out[1]), "recv_records": int(out[2]), "cap": int(out[3])}
+
+    def allreduce_u64(self, d_tensor, stream=None) -> None:
+        _check(lib().pg_exchange_allreduce_u64(self.h, d_tensor.data_ptr(), d_tensor.numel(), stream), "pg_exchange_allreduce_u64")
+
+    def close(self) -> None:
+        if self.h and self.owner:
+            lib().pg_comm_destroy(self.h)
+        self.h = None
+
+
+def host_skm_cut(packed: np.ndarray, n_reads: int, read_len: int, K: int, mer127: bool, log2_parts: int, ord_base: int, n_owners: int):
+    """Host twin of pg_skm_route (the same inline code the kernels run, skm.hpp): the batch's super-k-mer records and, per
+    record, partition << 8 | owner.  -> (records [n, W] uint64, tags [n] uint64)."""
+    nw = 4 if mer127 else 2
+    W = 6 if nw == 2 else 8
+    cap = n_reads * (read_len - K + 1)
+    recs = np.zeros((cap, W), dtype=np.uint64)
+    tags = np.zeros(cap, dtype=np.uint64)
+    packed = np.ascontiguousarray(packed, dtype=np.uint64)
+    n = lib().pg_host_skm_cut(packed.ctypes.data, n_reads, read_len, K, int(mer127), log2_parts, ord_base, n_owners, recs.ctypes.data,
+                              tags.ctypes.data, cap)
+    if n < 0:
+        raise PgError("pg_host_skm_cut failed: " + lib().pg_last_error().decode())
+    return recs[:n], tags[:n]
+
+
+def host_skm_expand(records: np.ndarray, K: int, mer127: bool):
+    """Host twin of the record expansion of K2: every k-mer occurrence of the records as rows
+    (key words..., left, right, ordinal)."""
+    nw = 4 if mer127 else 2
+    records = np.ascontiguousarray(records, dtype=np.uint64)
+    cap = int(((records[:, 0] >> np.uint64(2)) & np.uint64(0xFFFF)).sum()) if len(records) else 0
+    out = np.zeros((max(cap, 1), nw + 3), dtype=np.uint64)
+    n = lib().pg_host_skm_expand(records.ctypes.data, records.shape[0], K, int(mer127), out.ctypes.data, cap)
+    if n < 0:
+        raise PgError("pg_host_skm_expand failed: " + lib().pg_last_error().decode())
+    return out[:n]
+
+
 class KmerCounter:
     """Pass-1 counting context on one GPU (pg_create ... pg_export)."""
 
@@ -339,6 +453,12 @@ class KmerCounter:
     def count_records(self, d_records, n_records: int) -> None:
         _check(lib().pg_count_records(self.h, d_records.data_ptr(), n_records, self._stream()), "pg_count_records")
 
+    def count_sharded(self, comm: "Comm", d_packed, n_reads: int, read_len: int, ord_base: int = 0, stream=None) -> None:
+        """One round of multi-GPU pass 1 (collective over comm): cut, all-to-all, append.  d_packed may be None with n_reads = 0."""
+        st = stream if stream is not None else self._stream()
+        _check(lib().pg_count_reads_sharded(self.h, comm.h, d_packed.data_ptr() if d_packed is not None else None, None, None, n_reads,
+                                            read_len if n_reads else 0, 0, ord_base, st), "pg_count_reads_sharded")
+
     def set_autogrow(self, on: bool) -> None:
         _check(lib().pg_set_autogrow(self.h, int(on)), "pg_set_autogrow")
 
@@ -361,6 +481,16 @@ class KmerCounter:
         _check(lib().pg_finalize(self.h, delow, hist.ctypes.data, last.ctypes.data if want_last_put else None, self._stream()),
                "pg_finalize")
         return hist, last
+
+    def set_counts(self) -> np.ndarray:
+        out = np.zeros(256, dtype=np.uint64)
+        _check(lib().pg_set_counts(self.h, out.ctypes.data, self._stream()), "pg_set_counts")
+        return out[: self.P]
+
+    def last_put(self) -> np.ndarray:
+        out = np.zeros(self.P, dtype=np.uint64)
+        _check(lib().pg_last_put(self.h, out.ctypes.data, self._stream()), "pg_last_put")
+        return out
 
     def stats(self) -> dict:
         out = np.zeros(8, dtype=np.uint64)

@@ -15,7 +15,11 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include <hip/hip_runtime_api.h>
@@ -183,32 +187,28 @@ struct KeptReads {
     }
 };
 
-class Pass1 : public pg::ReadSink {
+// Pass 1 driver, common part: accepted reads -> 2-bit packed batches in pinned host buffers.  What happens to a full
+// batch is the backend's business (submit): one GPU takes batch after batch (Pass1), several GPUs take a round of one
+// batch each and exchange (ShardedPass1).
+class BatchFiller : public pg::ReadSink {
 public:
-    Pass1(pg_ctx* ctx, int K, size_t max_words, size_t max_reads)
-        : ctx_(ctx), K_(K), max_words_(max_words), max_reads_(max_reads) {
-        HIP_OK(hipStreamCreate(&stream_));
-        for (int i = 0; i < 2; i++) {
-            Buf& b = buf_[i];
+    struct Buf {
+        uint64_t *h_words = nullptr, *h_off = nullptr, *h_base = nullptr;
+        size_t n_reads = 0, n_words = 0;
+        uint64_t n_kmers = 0, ord_base = 0;
+        int first_len = 0;
+        bool uniform = true;
+    };
+    BatchFiller(int K, size_t max_words, size_t max_reads, int n_bufs) : K_(K), max_words_(max_words), max_reads_(max_reads), buf_(n_bufs) {
+        for (Buf& b : buf_) {
             HIP_OK(hipHostMalloc((void**)&b.h_words, (max_words_ + 8) * sizeof(uint64_t), hipHostMallocDefault));
             HIP_OK(hipHostMalloc((void**)&b.h_off, max_reads_ * sizeof(uint64_t), hipHostMallocDefault));
             HIP_OK(hipHostMalloc((void**)&b.h_base, (max_reads_ + 1) * sizeof(uint64_t), hipHostMallocDefault));
-            HIP_OK(hipMalloc((void**)&b.d_words, (max_words_ + 8) * sizeof(uint64_t)));
-            HIP_OK(hipMalloc((void**)&b.d_off, max_reads_ * sizeof(uint64_t)));
-            HIP_OK(hipMalloc((void**)&b.d_base, (max_reads_ + 1) * sizeof(uint64_t)));
-            HIP_OK(hipEventCreateWithFlags(&b.done, hipEventDisableTiming));
-            b.busy = false;
         }
         reset(buf_[0]);
     }
-    ~Pass1() {
-        for (int i = 0; i < 2; i++) {
-            Buf& b = buf_[i];
-            hipHostFree(b.h_words); hipHostFree(b.h_off); hipHostFree(b.h_base);
-            hipFree(b.d_words); hipFree(b.d_off); hipFree(b.d_base);
-            hipEventDestroy(b.done);
-        }
-        hipStreamDestroy(stream_);
+    ~BatchFiller() override {
+        for (Buf& b : buf_) { hipHostFree(b.h_words); hipHostFree(b.h_off); hipHostFree(b.h_base); }
     }
     void on_read(const uint8_t* codes, int len) override {
         if (len < K_ + 1) return;                               // prlHashReads.c:642
@@ -270,10 +270,8 @@ public:
             at += nw;
         }
     }
-    void finish() { submit(); HIP_OK(hipStreamSynchronize(stream_)); }
-    bool finish_ok() { finish(); return !failed_; }
+    virtual bool finish_ok() = 0;
     uint64_t total_kmers() const { return ord_; }
-    hipStream_t stream() const { return stream_; }
     // the packed reads kept for pass 2, or nothing when they outgrew the budget (then the files are parsed again)
     void keep_reads(size_t budget_bytes) { keep_ = budget_bytes > 0; keep_budget_ = budget_bytes; }
     bool take_kept(KeptReads& out) {
@@ -282,6 +280,23 @@ public:
         return true;
     }
 
+protected:
+    // the batch in buf_[cur_] is complete: take it, and leave cur_ on a buffer that may be filled
+    virtual void submit() = 0;
+    void seal(Buf& b) {                                             // the last touches before a batch leaves the host
+        for (int i = 0; i < 8; i++) b.h_words[b.n_words + i] = 0;   // readable padding for the window loads
+        b.h_base[b.n_reads] = b.n_kmers;
+        b.ord_base = ord_;
+        ord_ += b.n_kmers;
+    }
+    void reset(Buf& b) { b.n_reads = 0; b.n_words = 0; b.n_kmers = 0; b.first_len = 0; b.uniform = true; }
+    int K_;
+    size_t max_words_, max_reads_;
+    std::vector<Buf> buf_;
+    int cur_ = 0;
+    uint64_t ord_ = 0;
+    long long accepted_ = 0;
+
 private:
     void keep_append(const uint64_t* w, size_t nw, const int32_t* lens, size_t n) {
         if (kept_.total_bytes + nw * sizeof(uint64_t) + n * sizeof(int32_t) > keep_budget_ || !kept_.append(w, nw, lens, n)) {
@@ -289,49 +304,168 @@ private:
             kept_.clear();
         }
     }
-    struct Buf {
-        uint64_t *h_words, *h_off, *h_base, *d_words, *d_off, *d_base;
-        size_t n_reads, n_words;
-        uint64_t n_kmers;
-        int first_len;
-        bool uniform, busy;
-        hipEvent_t done;
-    };
-    void reset(Buf& b) { b.n_reads = 0; b.n_words = 0; b.n_kmers = 0; b.first_len = 0; b.uniform = true; }
-    void submit() {
-        Buf& b = buf_[cur_];
-        if (b.n_reads) {
-            for (int i = 0; i < 8; i++) b.h_words[b.n_words + i] = 0;          // readable padding for the window loads
-            b.h_base[b.n_reads] = b.n_kmers;
-            HIP_OK(hipMemcpyAsync(b.d_words, b.h_words, (b.n_words + 8) * sizeof(uint64_t), hipMemcpyHostToDevice, stream_));
-            if (!b.uniform) {
-                HIP_OK(hipMemcpyAsync(b.d_off, b.h_off, b.n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, stream_));
-                HIP_OK(hipMemcpyAsync(b.d_base, b.h_base, (b.n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream_));
-            }
-            if (!failed_ && pg_count_reads(ctx_, b.d_words, b.uniform ? nullptr : b.d_off, b.uniform ? nullptr : b.d_base, b.n_reads,
-                                           b.uniform ? (uint32_t)b.first_len : 0u, b.n_kmers, ord_, stream_) != PG_OK)
-                failed_ = true;                                     // the caller decides (finish_ok)
-            HIP_OK(hipEventRecord(b.done, stream_));
-            b.busy = true;
-            ord_ += b.n_kmers;
-        }
-        cur_ ^= 1;
-        Buf& n = buf_[cur_];
-        if (n.busy) { HIP_OK(hipEventSynchronize(n.done)); n.busy = false; }
-        reset(n);
-    }
-    bool failed_ = false;
     bool keep_ = false;
     size_t keep_budget_ = 0;
     KeptReads kept_;
+};
+
+// One GPU: hipMemcpyAsync + pg_count_reads, two batches in flight so parsing overlaps the copy + kernel of the previous one.
+class Pass1 : public BatchFiller {
+public:
+    Pass1(pg_ctx* ctx, int K, size_t max_words, size_t max_reads) : BatchFiller(K, max_words, max_reads, 2), ctx_(ctx) {
+        HIP_OK(hipStreamCreate(&stream_));
+        for (int i = 0; i < 2; i++) {
+            Dev& d = dev_[i];
+            HIP_OK(hipMalloc((void**)&d.d_words, (max_words_ + 8) * sizeof(uint64_t)));
+            HIP_OK(hipMalloc((void**)&d.d_off, max_reads_ * sizeof(uint64_t)));
+            HIP_OK(hipMalloc((void**)&d.d_base, (max_reads_ + 1) * sizeof(uint64_t)));
+            HIP_OK(hipEventCreateWithFlags(&d.done, hipEventDisableTiming));
+            d.busy = false;
+        }
+    }
+    ~Pass1() override {
+        for (int i = 0; i < 2; i++) {
+            Dev& d = dev_[i];
+            hipFree(d.d_words); hipFree(d.d_off); hipFree(d.d_base);
+            hipEventDestroy(d.done);
+        }
+        hipStreamDestroy(stream_);
+    }
+    bool finish_ok() override { submit(); HIP_OK(hipStreamSynchronize(stream_)); return !failed_; }
+
+private:
+    struct Dev { uint64_t *d_words, *d_off, *d_base; hipEvent_t done; bool busy; };
+    void submit() override {
+        Buf& b = buf_[cur_];
+        Dev& d = dev_[cur_];
+        if (b.n_reads) {
+            seal(b);
+            HIP_OK(hipMemcpyAsync(d.d_words, b.h_words, (b.n_words + 8) * sizeof(uint64_t), hipMemcpyHostToDevice, stream_));
+            if (!b.uniform) {
+                HIP_OK(hipMemcpyAsync(d.d_off, b.h_off, b.n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, stream_));
+                HIP_OK(hipMemcpyAsync(d.d_base, b.h_base, (b.n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream_));
+            }
+            if (!failed_ && pg_count_reads(ctx_, d.d_words, b.uniform ? nullptr : d.d_off, b.uniform ? nullptr : d.d_base, b.n_reads,
+                                           b.uniform ? (uint32_t)b.first_len : 0u, b.n_kmers, b.ord_base, stream_) != PG_OK)
+                failed_ = true;                                     // the caller decides (finish_ok)
+            HIP_OK(hipEventRecord(d.done, stream_));
+            d.busy = true;
+        }
+        cur_ ^= 1;
+        if (dev_[cur_].busy) { HIP_OK(hipEventSynchronize(dev_[cur_].done)); dev_[cur_].busy = false; }
+        reset(buf_[cur_]);
+    }
+    bool failed_ = false;
     pg_ctx* ctx_;
-    int K_;
-    size_t max_words_, max_reads_;
-    Buf buf_[2];
-    int cur_ = 0;
-    uint64_t ord_ = 0;
-    long long accepted_ = 0;
+    Dev dev_[2];
     hipStream_t stream_;
+};
+
+// Several GPUs (SOAPDENOVO2_AMD_DEVICES=0,1,...): batches are dealt to the ranks in turn, a round = one batch per rank.
+// One host thread per rank copies its batch to its GPU and runs pg_count_reads_sharded -- cut, all-to-all, append
+// (exchange.hip) -- while this thread fills the next round's buffers.  Every k-mer keeps the ordinal it has in the
+// reference's read order, so nothing downstream depends on which GPU counted it.
+class ShardedPass1 : public BatchFiller {
+public:
+    ShardedPass1(const std::vector<pg_ctx*>& ctxs, const std::vector<pg_comm*>& comms, const std::vector<int>& devices, int K, size_t max_words,
+                 size_t max_reads)
+        : BatchFiller(K, max_words, max_reads, 2 * (int)ctxs.size()), n_((int)ctxs.size()), ctx_(ctxs), comm_(comms), device_(devices) {
+        posted_.assign(2, 0);
+        for (int r = 0; r < n_; r++) workers_.emplace_back([this, r] { worker(r); });
+    }
+    ~ShardedPass1() override { stop(); }
+    bool finish_ok() override {
+        if (buf_[cur_].n_reads) submit();
+        if (cur_ % n_ != 0) {                                      // a partly dealt round: the other ranks take part empty-handed
+            while (cur_ % n_ != 0) { seal(buf_[cur_]); cur_++; }
+            post_round((cur_ - 1) / n_);
+        }
+        wait_all();
+        stop();
+        return !failed_.load();
+    }
+
+private:
+    void submit() override {
+        Buf& b = buf_[cur_];
+        if (!b.n_reads) return;                                    // nothing to hand over: keep filling this buffer
+        seal(b);
+        const int set = cur_ / n_;
+        if (cur_ % n_ == n_ - 1) post_round(set);
+        cur_ = (cur_ + 1) % (2 * n_);
+        if (cur_ % n_ == 0) wait_set_free(cur_ / n_);             // the set we are about to fill: its last round must be done
+        reset(buf_[cur_]);
+    }
+    void post_round(int set) {
+        std::lock_guard<std::mutex> lk(mu_);
+        rounds_posted_++;
+        posted_[set] = rounds_posted_;                              // round number (1-based) now waiting in this set
+        cv_.notify_all();
+    }
+    void wait_set_free(int set) {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return posted_[set] == 0 || rounds_done_ >= posted_[set]; });
+        for (int r = 0; r < n_; r++) reset(buf_[set * n_ + r]);
+    }
+    void wait_all() {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return rounds_done_ >= rounds_posted_; });
+    }
+    void stop() {
+        { std::lock_guard<std::mutex> lk(mu_); stop_ = true; cv_.notify_all(); }
+        for (auto& t : workers_) if (t.joinable()) t.join();
+        workers_.clear();
+    }
+    void worker(int r) {
+        HIP_OK(hipSetDevice(device_[r]));
+        hipStream_t st;
+        HIP_OK(hipStreamCreate(&st));
+        uint64_t *d_words, *d_off, *d_base;
+        HIP_OK(hipMalloc((void**)&d_words, (max_words_ + 8) * sizeof(uint64_t)));
+        HIP_OK(hipMalloc((void**)&d_off, max_reads_ * sizeof(uint64_t)));
+        HIP_OK(hipMalloc((void**)&d_base, (max_reads_ + 1) * sizeof(uint64_t)));
+        for (uint64_t round = 1;; round++) {
+            int set = -1;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_.wait(lk, [&] { return stop_ || rounds_posted_ >= round; });
+                if (rounds_posted_ < round) break;                  // stopped with nothing left
+                set = (int)((round - 1) & 1);                       // rounds alternate between the two buffer sets
+            }
+            const Buf& b = buf_[set * n_ + r];
+            if (b.n_reads) {
+                HIP_OK(hipMemcpyAsync(d_words, b.h_words, (b.n_words + 8) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+                if (!b.uniform) {
+                    HIP_OK(hipMemcpyAsync(d_off, b.h_off, b.n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+                    HIP_OK(hipMemcpyAsync(d_base, b.h_base, (b.n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
+                }
+            }
+            if (pg_count_reads_sharded(ctx_[r], comm_[r], d_words, b.uniform ? nullptr : d_off, b.uniform ? nullptr : d_base, b.n_reads,
+                                       (b.uniform && b.n_reads) ? (uint32_t)b.first_len : 0u, b.n_kmers, b.ord_base, st) != PG_OK) {
+                fprintf(stderr, "rank %d: pg_count_reads_sharded: %s\n", r, pg_last_error());
+                failed_.store(true);
+            }
+            HIP_OK(hipStreamSynchronize(st));
+            {
+                std::lock_guard<std::mutex> lk(mu_);
+                if (++done_in_round_ == n_) { done_in_round_ = 0; rounds_done_++; cv_.notify_all(); }
+            }
+        }
+        hipFree(d_words); hipFree(d_off); hipFree(d_base);
+        hipStreamDestroy(st);
+    }
+    int n_;
+    std::vector<pg_ctx*> ctx_;
+    std::vector<pg_comm*> comm_;
+    std::vector<int> device_;
+    std::vector<std::thread> workers_;
+    std::mutex mu_;
+    std::condition_variable cv_;
+    std::vector<uint64_t> posted_;            // per buffer set: the round waiting in it (0 = none yet)
+    uint64_t rounds_posted_ = 0, rounds_done_ = 0;
+    int done_in_round_ = 0;
+    bool stop_ = false;
+    std::atomic<bool> failed_{false};
 };
 
 int run(int argc, char** argv, bool mer127) {
@@ -356,8 +490,23 @@ int run(int argc, char** argv, bool mer127) {
             (int)cfg.libs.size(), max_read_len, 256);
     std::vector<pg::InputFile> files = pg::input_order(cfg, max_read_len);
 
+    // SOAPDENOVO2_AMD_DEVICES=0,1,2,...: pass 1 sharded over these GPUs (one rank each; an ordinal may repeat, which puts
+    // several ranks on one GPU -- how the N-rank path is tested on a 1-GPU box); everything after pass 1 runs on the first.
     int device = 0;
     if (const char* e = getenv("SOAPDENOVO2_AMD_DEVICE")) device = atoi(e);
+    std::vector<int> devices;
+    if (const char* e = getenv("SOAPDENOVO2_AMD_DEVICES")) {
+        for (const char* q = e; *q;) {
+            char* end = nullptr;
+            const long v = strtol(q, &end, 10);
+            if (end == q) break;
+            devices.push_back((int)v);
+            q = *end == ',' ? end + 1 : end;
+            if (end == q && *q) break;
+        }
+        if (!devices.empty()) device = devices[0];
+    }
+    const int n_ranks = devices.size() > 1 ? (int)devices.size() : 1;
     // how much is coming: bases ~ half the bytes of a FASTQ file, all of a FASTA file (x4 behind gzip)
     uint64_t est_kmers = 0;
     for (const pg::InputFile& f : files)
@@ -382,6 +531,9 @@ int run(int argc, char** argv, bool mer127) {
                (double)((uint64_t)2 << log2_slots) * 0.7 * rec_bytes <= (double)total_b / 3.0)
             log2_slots++;
     }
+    // a pass-1 batch: 64 MiB of packed reads / 2 M reads (SOAPDENOVO2_AMD_BATCH_READS: smaller batches, for tests)
+    size_t batch_words = (size_t)1 << 23, batch_reads = (size_t)1 << 21;
+    if (const char* e = getenv("SOAPDENOVO2_AMD_BATCH_READS")) { const long v = atol(e); if (v > 0) { batch_reads = (size_t)v; batch_words = std::min(batch_words, batch_reads * 160 + 64); } }
     size_t keep_budget = (size_t)sysconf(_SC_PHYS_PAGES) * (size_t)sysconf(_SC_PAGE_SIZE) / 4;
     if (const char* e = getenv("SOAPDENOVO2_AMD_KEEP_READS_GB")) keep_budget = (size_t)(atof(e) * 1073741824.0);
     KeptReads kept;
@@ -392,6 +544,101 @@ int run(int argc, char** argv, bool mer127) {
     std::vector<uint64_t> set_last(o.sets, 0);
     uint64_t n_distinct = 0;
     pg_ctx* ctx = nullptr;
+    uint64_t* d_rec = nullptr;                                     // the distinct k-mers of pass 1, on `device`
+    int engine_used = 2;
+    if (n_ranks > 1) {
+        // ---- pass 1 on n_ranks GPUs: cut + all-to-all + append per batch, then every rank counts its own partitions
+        std::vector<pg_ctx*> ctxs(n_ranks, nullptr);
+        std::vector<pg_comm*> comms(n_ranks, nullptr);
+        if (pg_comm_create_local(n_ranks, devices.data(), -1, comms.data()) != PG_OK) die("pg_comm_create_local");
+        fprintf(stderr, "%d k-mer set(s), pass 1 on %d rank(s) (HIP devices", o.sets, n_ranks);
+        for (int r = 0; r < n_ranks; r++) fprintf(stderr, " %d", devices[r]);
+        fprintf(stderr, "), records exchanged by %s.\n", pg_comm_transport(comms[0]) == PG_COMM_RCCL ? "RCCL all-to-all" : "peer copies");
+        int shared = 1;                                            // ranks on one device share its memory
+        for (int r = 0; r < n_ranks; r++) { int c = 0; for (int q = 0; q < n_ranks; q++) c += devices[q] == devices[r]; shared = std::max(shared, c); }
+        int ls = log2_slots;
+        for (int sft = n_ranks * shared; sft > 1 && ls > 20; sft >>= 1) ls--;
+        for (int r = 0; r < n_ranks; r++) {
+            ctxs[r] = pg_create_sized(devices[r], K, mer127 ? 1 : 0, o.sets, ls, 2, est_kmers / (uint64_t)n_ranks + 1);
+            if (!ctxs[r]) die("pg_create");
+        }
+        {
+            ShardedPass1 p1(ctxs, comms, devices, K, batch_words, batch_reads);
+            p1.keep_reads(keep_budget);
+            for (const pg::InputFile& f : files) {
+                fprintf(stderr, "Import reads from file:\n %s\n", f.path1.c_str());
+                if (!f.path2.empty()) fprintf(stderr, "Import reads from file:\n %s\n", f.path2.c_str());
+                n_records += pg::stream_reads(f, p1);
+            }
+            if (!p1.finish_ok()) { fprintf(stderr, "pass 1 failed on a rank\n"); exit(-1); }
+            total_kmers = p1.total_kmers();
+            have_kept = p1.take_kept(kept);
+        }
+        lap("parse + scatter + exchange (pass 1)");
+        // count: all ranks at once; the coverage histogram is summed over the ranks (all-reduce), the per-set last put is
+        // the latest over the ranks, the distinct k-mers are gathered on rank 0's GPU
+        const int rw1 = (mer127 ? 4 : 2) + 2;
+        std::vector<std::vector<uint64_t>> last(n_ranks, std::vector<uint64_t>(o.sets, 0));
+        std::vector<uint64_t> n_r(n_ranks, 0);
+        std::vector<uint64_t*> d_r(n_ranks, nullptr);
+        std::vector<std::string> err(n_ranks);
+        uint64_t n_all = 0;
+        {
+            std::vector<std::thread> th;
+            std::mutex mu;
+            std::condition_variable cv;
+            int counted = 0;
+            for (int r = 0; r < n_ranks; r++)
+                th.emplace_back([&, r] {
+                    uint64_t h[512];                                  // coverage histogram | distinct k-mers per set
+                    uint64_t* d_h = nullptr;
+                    auto fail = [&](const char* what) { err[r] = std::string(what) + ": " + pg_last_error(); };
+                    bool ok = pg_finalize(ctxs[r], o.delow, h, nullptr, nullptr) == PG_OK;
+                    if (!ok) fail("pg_finalize");
+                    if (ok && pg_set_counts(ctxs[r], h + 256, nullptr) != PG_OK) { ok = false; fail("pg_set_counts"); }
+                    if (!ok) memset(h, 0, sizeof h);
+                    // the collectives below are entered by every rank, failed or not
+                    if (hipSetDevice(devices[r]) != hipSuccess || hipMalloc((void**)&d_h, sizeof h) != hipSuccess ||
+                        hipMemcpy(d_h, h, sizeof h, hipMemcpyHostToDevice) != hipSuccess) { fprintf(stderr, "rank %d: no device memory\n", r); exit(-1); }
+                    if (pg_exchange_allreduce_u64(comms[r], d_h, 512, nullptr) != PG_OK && ok) { ok = false; fail("pg_exchange_allreduce_u64"); }
+                    HIP_OK(hipMemcpy(h, d_h, sizeof h, hipMemcpyDeviceToHost));
+                    if (r == 0) memcpy(hist, h, 256 * sizeof(uint64_t));
+                    hipFree(d_h);
+                    // every rank sees the same totals, so all of them take the same decision about the last put
+                    if (ok && pg_host_last_put_matters(h + 256, o.sets, o.a_gb, mer127 ? 1 : 0) && pg_last_put(ctxs[r], last[r].data(), nullptr) != PG_OK) { ok = false; fail("pg_last_put"); }
+                    if (ok && pg_export_take(ctxs[r], &d_r[r], &n_r[r]) != PG_OK) { ok = false; fail("pg_export_take"); }
+                    if (!ok) { n_r[r] = 0; d_r[r] = nullptr; }
+                    // rank 0 sizes the gathered array once every rank knows its count
+                    {
+                        std::unique_lock<std::mutex> lk(mu);
+                        if (++counted == n_ranks) {
+                            for (int q = 0; q < n_ranks; q++) n_all += n_r[q];
+                            if (n_all) { HIP_OK(hipSetDevice(device)); HIP_OK(hipMalloc((void**)&d_rec, (size_t)n_all * rw1 * sizeof(uint64_t))); }
+                            HIP_OK(hipSetDevice(devices[r]));
+                            cv.notify_all();
+                        } else cv.wait(lk, [&] { return counted == n_ranks; });
+                    }
+                    uint64_t got = 0;
+                    if (pg_exchange_gather_records(comms[r], d_r[r], n_r[r], rw1, 0, d_rec, n_all, &got, nullptr) != PG_OK && ok) fail("pg_exchange_gather_records");
+                    if (d_r[r]) hipFree(d_r[r]);
+                    pg_destroy(ctxs[r]);
+                });
+            for (auto& t : th) t.join();
+        }
+        for (int r = 0; r < n_ranks; r++) if (!err[r].empty()) { fprintf(stderr, "rank %d: %s\n", r, err[r].c_str()); exit(-1); }
+        for (int r = 0; r < n_ranks; r++) {
+            for (int sidx = 0; sidx < o.sets; sidx++) set_last[sidx] = std::max(set_last[sidx], last[r][sidx]);
+            if (verbose) {
+                uint64_t cs[4];
+                pg_comm_stats(comms[r], cs);
+                fprintf(stderr, "[cli] rank %d (device %d): %llu distinct k-mers, %llu rounds, %llu records sent, %llu received\n", r, devices[r],
+                        (unsigned long long)n_r[r], (unsigned long long)cs[0], (unsigned long long)cs[1], (unsigned long long)cs[2]);
+            }
+            pg_comm_destroy(comms[r]);
+        }
+        n_distinct = n_all;
+        HIP_OK(hipSetDevice(device));
+    } else {
     // Pass 1 on the partition engine; should one partition outgrow its chunk list (one minimizer owning a huge share of
     // the input) the reads go through the global-set engine instead -- slower, indifferent to skew, same result.
     int engine = 2;
@@ -402,7 +649,7 @@ int run(int argc, char** argv, bool mer127) {
         if (attempt == 0) fprintf(stderr, "%d k-mer set(s) on HIP device %d.\n", o.sets, device);
         bool ok = true;
         {
-            Pass1 p1(ctx, K, (size_t)1 << 23, (size_t)1 << 21);     // 64 MiB of packed reads / 2 M reads per batch
+            Pass1 p1(ctx, K, batch_words, batch_reads);
             if (attempt == 0) {
                 p1.keep_reads(keep_budget);
                 for (const pg::InputFile& f : files) {
@@ -426,13 +673,21 @@ int run(int argc, char** argv, bool mer127) {
         lap("parse + scatter (pass 1)");
         // ---- -d filter, linear marking, .kmerFreq (deLowCov / Mark1in1outNode / freqStat); with the partition engine
         // this is also where the partitions are counted, so the node count is known only afterwards
-        if (ok && pg_finalize(ctx, o.delow, hist, set_last.data(), nullptr) != PG_OK) ok = false;
+        if (ok && pg_finalize(ctx, o.delow, hist, engine == 2 ? nullptr : set_last.data(), nullptr) != PG_OK) ok = false;
         if (ok && pg_distinct(ctx, &n_distinct, nullptr) != PG_OK) ok = false;
-        if (ok) break;
+        if (ok && engine == 2) {
+            // the per-set last put costs a second expansion of every record and matters only when a set ends exactly at a
+            // growth threshold of the reference's size schedule (newhash.c:477): ask first
+            uint64_t per[256];
+            if (pg_set_counts(ctx, per, nullptr) != PG_OK) ok = false;
+            else if (pg_host_last_put_matters(per, o.sets, o.a_gb, mer127 ? 1 : 0) && pg_last_put(ctx, set_last.data(), nullptr) != PG_OK) ok = false;
+        }
+        if (ok) { engine_used = engine; break; }
         if (engine != 2 || attempt > 0) die("pass 1");
         fprintf(stderr, "Partition engine gave up (%s); counting again with the global k-mer set.\n", pg_last_error());
         pg_destroy(ctx);
         engine = 1;
+    }
     }
     lap("count partitions (finalize)");
     time_t t1 = time(nullptr);
@@ -468,13 +723,19 @@ int run(int argc, char** argv, bool mer127) {
     // (pg_graph_begin_streamed); beyond 2^31 records, or with SOAPDENOVO2_AMD_STREAM_RECORDS=0, they are downloaded whole.
     bool stream_records = n_distinct > 0 && n_distinct < 0x7fffffffULL;
     if (const char* e = getenv("SOAPDENOVO2_AMD_STREAM_RECORDS")) stream_records = stream_records && atoi(e) != 0;
-    uint64_t* d_rec = nullptr;
     std::vector<uint64_t> per_set(o.sets, 0);
     if (n_distinct) {
-        HIP_OK(hipMalloc((void**)&d_rec, (size_t)n_distinct * rw * sizeof(uint64_t)));
-        uint64_t got = 0;
-        if (pg_export(ctx, d_rec, n_distinct, &got, nullptr) != PG_OK) die("pg_export");
-        if (got != n_distinct) { fprintf(stderr, "export count mismatch\n"); exit(-1); }
+        if (ctx) {
+            // the partition engine hands its export array over as it is and frees its streams (no second copy in HBM);
+            // the global-set engine compacts its table into a fresh array
+            uint64_t got = 0;
+            if (engine_used == 2) { if (pg_export_take(ctx, &d_rec, &got) != PG_OK) die("pg_export_take"); }
+            else {
+                HIP_OK(hipMalloc((void**)&d_rec, (size_t)n_distinct * rw * sizeof(uint64_t)));
+                if (pg_export(ctx, d_rec, n_distinct, &got, nullptr) != PG_OK) die("pg_export");
+            }
+            if (got != n_distinct) { fprintf(stderr, "export count mismatch\n"); exit(-1); }
+        }
         // replay order (set, first occurrence) on the device; beyond 2^31 records the host sorts instead
         if (n_distinct < 0x7fffffffULL && pg_sort_records(d_rec, n_distinct, mer127 ? 1 : 0, nullptr) != PG_OK) die("pg_sort_records");
         if (stream_records) {
@@ -495,7 +756,7 @@ int run(int argc, char** argv, bool mer127) {
             d_rec = nullptr;
         }
     }
-    pg_destroy(ctx);
+    if (ctx) pg_destroy(ctx);
     lap("export + download records");
 
     // ---- tips + edges (removeSingleTips / removeMinorTips / kmer2edges), graph kept for pass 2

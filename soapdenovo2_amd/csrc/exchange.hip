@@ -1,0 +1,468 @@
+// exchange.hip -- multi-GPU pass 1: the all-to-all that brings every k-mer occurrence to the GPU owning it.
+//
+// The reference fans k-mers out to its `thrd_num` sets through shared memory (every worker scans the whole buffer and keeps
+// `hashBanBuffer[i] % thrd_num == id`, standardPregraph/prlHashReads.c:79-90).  Here the unit that travels is the
+// super-k-mer record (~19 k-mers in 48 bytes) and owner(record) = minimizer partition mod n_ranks, so all occurrences of a
+// k-mer meet on one GPU and each rank counts its own partitions with no further communication (partition_kernels.hip).
+//
+// Two transports behind one interface:
+//   PG_COMM_RCCL  ncclSend / ncclRecv inside one group = a direct all-to-all over xGMI (every pair talks over its own
+//                 link; nothing is relayed through a ring).  One rank per process (bench.py under torch.distributed.run,
+//                 the id travels through its store) or one rank per host thread of one process (call_pregraph with
+//                 SOAPDENOVO2_AMD_DEVICES=0,1,...).  librccl is loaded with dlopen at first use, so single-GPU users and
+//                 the CPU-only ABI tests never need it.
+//   PG_COMM_P2P   one process only: ranks meet at a barrier, publish their send buffers and pull their share with
+//                 peer-to-peer copies (SDMA over xGMI).  Also works when several ranks share one device, which RCCL
+//                 refuses -- that is how the N-rank path is exercised on a 1-GPU box.
+#include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <mutex>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "device_ctx.hpp"
+#include "../../include/soapdenovo2_amd.h"
+
+namespace {
+
+#define X_TRY(expr)                                                                            \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) {                                                                \
+            pg_set_error(std::string(#expr) + ": " + hipGetErrorString(e_));                   \
+            return (e_ == hipErrorOutOfMemory) ? PG_ENOMEM : PG_ENODEV;                        \
+        }                                                                                      \
+    } while (0)
+
+// ---- librccl, resolved at run time -----------------------------------------------------------------------------
+struct Rccl {
+    void* lib = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    std::string why;
+    bool load() {
+        if (lib) return true;
+        const char* names[] = {getenv("SOAPDENOVO2_AMD_RCCL"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char* n : names) {
+            if (!n || !*n) continue;
+            lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+            if (lib) break;
+            why = dlerror();
+        }
+        if (!lib) return false;
+        auto sym = [&](const char* s) { void* p = dlsym(lib, s); if (!p) why = std::string("missing symbol ") + s; return p; };
+        GetUniqueId = (decltype(GetUniqueId))sym("ncclGetUniqueId");
+        CommInitRank = (decltype(CommInitRank))sym("ncclCommInitRank");
+        CommDestroy = (decltype(CommDestroy))sym("ncclCommDestroy");
+        GroupStart = (decltype(GroupStart))sym("ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))sym("ncclGroupEnd");
+        Send = (decltype(Send))sym("ncclSend");
+        Recv = (decltype(Recv))sym("ncclRecv");
+        AllReduce = (decltype(AllReduce))sym("ncclAllReduce");
+        GetErrorString = (decltype(GetErrorString))sym("ncclGetErrorString");
+        if (!GetUniqueId || !CommInitRank || !CommDestroy || !GroupStart || !GroupEnd || !Send || !Recv || !AllReduce || !GetErrorString) {
+            dlclose(lib); lib = nullptr; return false;
+        }
+        return true;
+    }
+};
+Rccl g_rccl;
+std::mutex g_rccl_mu;
+bool rccl_ready() { std::lock_guard<std::mutex> lk(g_rccl_mu); return g_rccl.load(); }
+
+#define N_TRY(expr)                                                                            \
+    do {                                                                                       \
+        ncclResult_t r_ = (expr);                                                              \
+        if (r_ != ncclSuccess) {                                                               \
+            pg_set_error(std::string(#expr) + ": " + g_rccl.GetErrorString(r_));               \
+            return PG_ENODEV;                                                                  \
+        }                                                                                      \
+    } while (0)
+
+// ---- in-process group: a reusable barrier and one mailbox per rank ------------------------------------------------
+struct LocalGroup {
+    int n = 0, refs = 0;
+    std::mutex m;
+    std::condition_variable cv;
+    int waiting = 0;
+    uint64_t gen = 0;
+    std::vector<const void*> a, b;         // published pointers (device memory of the publishing rank)
+    std::vector<uint64_t> v;               // published scalar
+    std::vector<int> device;
+    void barrier() {
+        std::unique_lock<std::mutex> lk(m);
+        const uint64_t g = gen;
+        if (++waiting == n) { waiting = 0; gen++; cv.notify_all(); }
+        else cv.wait(lk, [&] { return gen != g; });
+    }
+};
+
+}  // namespace
+
+struct pg_comm {
+    int n = 1, rank = 0, device = 0, transport = PG_COMM_P2P;
+    ncclComm_t nccl = nullptr;
+    LocalGroup* grp = nullptr;
+    // working buffers of pg_count_reads_sharded / pg_exchange_gather_records (device memory on `device`)
+    uint64_t* d_send_recs = nullptr;
+    uint32_t* d_send_parts = nullptr;
+    uint64_t cap = 0;                      // records per owner region
+    int rw = 0;
+    uint64_t* d_counts = nullptr;          // [n] records for owner o / [n] received from rank q
+    uint64_t* d_rcounts = nullptr;
+    uint64_t* d_recv_recs = nullptr;
+    uint32_t* d_recv_parts = nullptr;
+    uint64_t recv_cap = 0;
+    std::vector<uint64_t> h_counts, h_rcounts;
+    uint64_t sent_records = 0, recv_records = 0, rounds = 0;
+};
+
+namespace {
+
+int comm_alloc_small(pg_comm* c) {
+    X_TRY(hipSetDevice(c->device));
+    X_TRY(hipMalloc((void**)&c->d_counts, sizeof(uint64_t) * (size_t)c->n));
+    X_TRY(hipMalloc((void**)&c->d_rcounts, sizeof(uint64_t) * (size_t)c->n));
+    c->h_counts.assign(c->n, 0);
+    c->h_rcounts.assign(c->n, 0);
+    return PG_OK;
+}
+
+// every rank sends k words to every rank: d_send[o * k ..] goes to rank o, d_recv[q * k ..] comes from rank q
+int alltoall_words(pg_comm* c, const uint64_t* d_send, uint64_t* d_recv, uint64_t k, hipStream_t st) {
+    if (c->n == 1) { X_TRY(hipMemcpyAsync(d_recv, d_send, k * 8, hipMemcpyDeviceToDevice, st)); return PG_OK; }
+    if (c->transport == PG_COMM_RCCL) {
+        X_TRY(hipMemcpyAsync(d_recv + (uint64_t)c->rank * k, d_send + (uint64_t)c->rank * k, k * 8, hipMemcpyDeviceToDevice, st));
+        N_TRY(g_rccl.GroupStart());
+        for (int p = 0; p < c->n; p++) {
+            if (p == c->rank) continue;
+            N_TRY(g_rccl.Send(d_send + (uint64_t)p * k, k, ncclUint64, p, c->nccl, st));
+            N_TRY(g_rccl.Recv(d_recv + (uint64_t)p * k, k, ncclUint64, p, c->nccl, st));
+        }
+        N_TRY(g_rccl.GroupEnd());
+        return PG_OK;
+    }
+    LocalGroup* g = c->grp;
+    X_TRY(hipStreamSynchronize(st));                           // what we publish must be complete
+    g->a[c->rank] = d_send;
+    g->barrier();
+    for (int q = 0; q < c->n; q++)
+        X_TRY(hipMemcpyAsync(d_recv + (uint64_t)q * k, (const uint64_t*)g->a[q] + (uint64_t)c->rank * k, k * 8, hipMemcpyDefault, st));
+    X_TRY(hipStreamSynchronize(st));
+    g->barrier();                                               // everybody has pulled: the send buffers may change again
+    return PG_OK;
+}
+
+}  // namespace
+
+extern "C" int pg_comm_unique_id(uint8_t id[128]) {
+    if (!id) { pg_set_error("null argument"); return PG_EINVAL; }
+    if (!rccl_ready()) { pg_set_error("librccl could not be loaded: " + g_rccl.why); return PG_ENODEV; }
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is 128 bytes");
+    ncclUniqueId u;
+    N_TRY(g_rccl.GetUniqueId(&u));
+    memcpy(id, &u, 128);
+    return PG_OK;
+}
+
+extern "C" pg_comm* pg_comm_create(int n_ranks, int rank, int device, const uint8_t id[128]) {
+    if (n_ranks < 1 || n_ranks > 256 || rank < 0 || rank >= n_ranks || !id) { pg_set_error("pg_comm_create: bad arguments"); return nullptr; }
+    if (!rccl_ready()) { pg_set_error("librccl could not be loaded: " + g_rccl.why); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { pg_set_error("pg_comm_create: hipSetDevice failed"); return nullptr; }
+    pg_comm* c = new pg_comm();
+    c->n = n_ranks; c->rank = rank; c->device = device; c->transport = PG_COMM_RCCL;
+    ncclUniqueId u;
+    memcpy(&u, id, 128);
+    ncclResult_t r = g_rccl.CommInitRank(&c->nccl, n_ranks, u, rank);
+    if (r != ncclSuccess) { pg_set_error(std::string("ncclCommInitRank: ") + g_rccl.GetErrorString(r)); delete c; return nullptr; }
+    if (comm_alloc_small(c) != PG_OK) { pg_comm_destroy(c); return nullptr; }
+    return c;
+}
+
+extern "C" int pg_comm_create_local(int n_ranks, const int* devices, int transport, pg_comm** out) {
+    if (n_ranks < 1 || n_ranks > 256 || !devices || !out) { pg_set_error("pg_comm_create_local: bad arguments"); return PG_EINVAL; }
+    bool distinct = true;
+    for (int i = 0; i < n_ranks; i++) for (int j = 0; j < i; j++) distinct = distinct && devices[i] != devices[j];
+    if (transport < 0) {
+        transport = (distinct && n_ranks > 1) ? PG_COMM_RCCL : PG_COMM_P2P;
+        if (const char* e = getenv("SOAPDENOVO2_AMD_EXCHANGE")) {
+            if (!strcmp(e, "p2p")) transport = PG_COMM_P2P;
+            else if (!strcmp(e, "rccl")) transport = PG_COMM_RCCL;
+        }
+    }
+    if (transport == PG_COMM_RCCL && !distinct && n_ranks > 1) { pg_set_error("RCCL needs one device per rank; ranks sharing a device use the p2p transport"); return PG_EINVAL; }
+    for (int i = 0; i < n_ranks; i++) out[i] = nullptr;
+    if (transport == PG_COMM_RCCL) {
+        uint8_t id[128];
+        int rc = pg_comm_unique_id(id);
+        if (rc) return rc;
+        std::vector<std::string> errs(n_ranks);
+        std::vector<std::thread> th;
+        for (int i = 0; i < n_ranks; i++)                       // ncclCommInitRank is collective: all ranks at once
+            th.emplace_back([&, i] { out[i] = pg_comm_create(n_ranks, i, devices[i], id); if (!out[i]) errs[i] = pg_last_error(); });
+        for (auto& t : th) t.join();
+        for (int i = 0; i < n_ranks; i++)
+            if (!out[i]) {
+                pg_set_error(errs[i]);
+                for (int j = 0; j < n_ranks; j++) { pg_comm_destroy(out[j]); out[j] = nullptr; }
+                return PG_ENODEV;
+            }
+        return PG_OK;
+    }
+    LocalGroup* g = new LocalGroup();
+    g->n = n_ranks; g->refs = n_ranks;
+    g->a.assign(n_ranks, nullptr); g->b.assign(n_ranks, nullptr); g->v.assign(n_ranks, 0);
+    g->device.assign(devices, devices + n_ranks);
+    for (int i = 0; i < n_ranks; i++) {
+        pg_comm* c = new pg_comm();
+        c->n = n_ranks; c->rank = i; c->device = devices[i]; c->transport = PG_COMM_P2P; c->grp = g;
+        out[i] = c;
+        if (comm_alloc_small(c) != PG_OK) {
+            const std::string why = pg_last_error();
+            for (int j = 0; j <= i; j++) { pg_comm_destroy(out[j]); out[j] = nullptr; }
+            for (int j = i + 1; j < n_ranks; j++) if (--g->refs == 0) delete g;
+            pg_set_error(why);
+            return PG_ENOMEM;
+        }
+        for (int j = 0; j < i; j++)                              // direct peer copies where the fabric allows them
+            if (devices[j] != devices[i]) {
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, devices[i], devices[j]) == hipSuccess && can) {
+                    (void)hipSetDevice(devices[i]); (void)hipDeviceEnablePeerAccess(devices[j], 0);
+                    (void)hipSetDevice(devices[j]); (void)hipDeviceEnablePeerAccess(devices[i], 0);
+                    (void)hipGetLastError();
+                }
+            }
+    }
+    return PG_OK;
+}
+
+extern "C" void pg_comm_destroy(pg_comm* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->nccl) g_rccl.CommDestroy(c->nccl);
+    for (void* p : {(void*)c->d_send_recs, (void*)c->d_send_parts, (void*)c->d_counts, (void*)c->d_rcounts, (void*)c->d_recv_recs, (void*)c->d_recv_parts})
+        if (p) (void)hipFree(p);
+    if (c->grp) {
+        bool last;
+        { std::lock_guard<std::mutex> lk(c->grp->m); last = --c->grp->refs == 0; }
+        if (last) delete c->grp;
+    }
+    delete c;
+}
+
+extern "C" int pg_comm_rank(const pg_comm* c) { return c ? c->rank : -1; }
+extern "C" int pg_comm_size(const pg_comm* c) { return c ? c->n : 0; }
+extern "C" int pg_comm_transport(const pg_comm* c) { return c ? c->transport : -1; }
+
+extern "C" int pg_exchange_counts(pg_comm* c, const uint64_t* d_send_counts, uint64_t* d_recv_counts, void* stream) {
+    if (!c || !d_send_counts || !d_recv_counts) { pg_set_error("null argument"); return PG_EINVAL; }
+    X_TRY(hipSetDevice(c->device));
+    return alltoall_words(c, d_send_counts, d_recv_counts, 1, (hipStream_t)stream);
+}
+
+extern "C" int pg_exchange_allreduce_u64(pg_comm* c, uint64_t* d_buf, uint64_t n, void* stream) {
+    if (!c || (!d_buf && n)) { pg_set_error("null argument"); return PG_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    X_TRY(hipSetDevice(c->device));
+    if (c->n == 1 || n == 0) return PG_OK;
+    if (c->transport == PG_COMM_RCCL) { N_TRY(g_rccl.AllReduce(d_buf, d_buf, n, ncclUint64, ncclSum, c->nccl, st)); return PG_OK; }
+    LocalGroup* g = c->grp;
+    X_TRY(hipStreamSynchronize(st));
+    g->a[c->rank] = d_buf;
+    g->barrier();
+    std::vector<uint64_t> sum(n, 0), tmp(n);
+    for (int q = 0; q < c->n; q++) {
+        X_TRY(hipMemcpy(tmp.data(), g->a[q], n * 8, hipMemcpyDefault));
+        for (uint64_t i = 0; i < n; i++) sum[i] += tmp[i];
+    }
+    g->barrier();                                               // every rank has read every buffer
+    X_TRY(hipMemcpy(d_buf, sum.data(), n * 8, hipMemcpyHostToDevice));
+    return PG_OK;
+}
+
+// Variable all-to-all of super-k-mer records and their partition ids.  Sender side: owner o's records lie at
+// d_send_recs + o * cap * rw, its ids at d_send_parts + o * cap, send_counts[o] of them.  Receiver side: what rank q sent
+// lands behind what ranks < q sent (recv_counts[] as exchanged by pg_exchange_counts), densely.
+extern "C" int pg_exchange_records(pg_comm* c, const uint64_t* d_send_recs, const uint32_t* d_send_parts, uint64_t cap, int rw,
+                                   const uint64_t* send_counts, const uint64_t* recv_counts, uint64_t* d_recv_recs, uint32_t* d_recv_parts,
+                                   void* stream) {
+    if (!c || !send_counts || !recv_counts) { pg_set_error("null argument"); return PG_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    X_TRY(hipSetDevice(c->device));
+    std::vector<uint64_t> off(c->n + 1, 0);
+    for (int q = 0; q < c->n; q++) off[q + 1] = off[q] + recv_counts[q];
+    if (c->transport == PG_COMM_RCCL || c->n == 1) {
+        const int me = c->rank;
+        if (send_counts[me]) {
+            X_TRY(hipMemcpyAsync(d_recv_recs + off[me] * rw, d_send_recs + (uint64_t)me * cap * rw, send_counts[me] * (uint64_t)rw * 8, hipMemcpyDeviceToDevice, st));
+            X_TRY(hipMemcpyAsync(d_recv_parts + off[me], d_send_parts + (uint64_t)me * cap, send_counts[me] * 4, hipMemcpyDeviceToDevice, st));
+        }
+        if (c->n == 1) return PG_OK;
+        N_TRY(g_rccl.GroupStart());
+        for (int p = 0; p < c->n; p++) {
+            if (p == me) continue;
+            if (send_counts[p]) {
+                N_TRY(g_rccl.Send(d_send_recs + (uint64_t)p * cap * rw, send_counts[p] * (uint64_t)rw, ncclUint64, p, c->nccl, st));
+                N_TRY(g_rccl.Send(d_send_parts + (uint64_t)p * cap, send_counts[p], ncclUint32, p, c->nccl, st));
+            }
+            if (recv_counts[p]) {
+                N_TRY(g_rccl.Recv(d_recv_recs + off[p] * rw, recv_counts[p] * (uint64_t)rw, ncclUint64, p, c->nccl, st));
+                N_TRY(g_rccl.Recv(d_recv_parts + off[p], recv_counts[p], ncclUint32, p, c->nccl, st));
+            }
+        }
+        N_TRY(g_rccl.GroupEnd());
+        return PG_OK;
+    }
+    LocalGroup* g = c->grp;
+    X_TRY(hipStreamSynchronize(st));
+    g->a[c->rank] = d_send_recs; g->b[c->rank] = d_send_parts; g->v[c->rank] = cap;
+    g->barrier();
+    for (int q = 0; q < c->n; q++) {
+        if (!recv_counts[q]) continue;
+        const uint64_t qcap = g->v[q];
+        X_TRY(hipMemcpyAsync(d_recv_recs + off[q] * rw, (const uint64_t*)g->a[q] + (uint64_t)c->rank * qcap * rw, recv_counts[q] * (uint64_t)rw * 8, hipMemcpyDefault, st));
+        X_TRY(hipMemcpyAsync(d_recv_parts + off[q], (const uint32_t*)g->b[q] + (uint64_t)c->rank * qcap, recv_counts[q] * 4, hipMemcpyDefault, st));
+    }
+    X_TRY(hipStreamSynchronize(st));
+    g->barrier();
+    return PG_OK;
+}
+
+// One batch of pass 1 on n ranks (collective: every rank calls it once per round, with n_reads = 0 when it has nothing):
+// cut the batch into records grouped by owner, exchange counts, exchange records, append what arrived to the local partition
+// streams.  After the last round every rank runs pg_finalize on its own partitions.
+extern "C" int pg_count_reads_sharded(pg_ctx* ctx, pg_comm* c, const uint64_t* d_packed, const uint64_t* d_word_off, const uint64_t* d_kmer_base,
+                                      uint64_t n_reads, uint32_t uniform_len, uint64_t n_kmers, uint64_t ord_base, void* stream) {
+    if (!ctx || !c || (n_reads && !d_packed)) { pg_set_error("null argument"); return PG_EINVAL; }
+    if (ctx->engine != 2) { pg_set_error("pg_count_reads_sharded needs the partition engine"); return PG_ESTATE; }
+    if (ctx->finalized) { pg_set_error("pg_count_reads_sharded after pg_finalize"); return PG_ESTATE; }
+    if (ctx->device != c->device) { pg_set_error("context and communicator live on different devices"); return PG_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    X_TRY(hipSetDevice(c->device));
+    const int n = c->n, rw = ctx->e2.g.rw;
+    if (uniform_len) n_kmers = n_reads * (uint64_t)(uniform_len - ctx->K + 1);
+    // a read of k k-mers makes about 2k / (w + 1) + 1 records; twice that, spread over n owners, plus slack
+    const uint64_t est = 2 * n_kmers / (uint64_t)(ctx->e2.g.w + 1) + n_reads;
+    const uint64_t want_cap = 2 * est / (uint64_t)n + 4096;
+    if (want_cap > c->cap || rw != c->rw) {
+        // (the previous round ended with every rank's pulls / receives complete, so nobody reads the old regions any more)
+        X_TRY(hipStreamSynchronize(st));
+        if (c->d_send_recs) (void)hipFree(c->d_send_recs);
+        if (c->d_send_parts) (void)hipFree(c->d_send_parts);
+        c->d_send_recs = nullptr; c->d_send_parts = nullptr;
+        c->cap = want_cap + want_cap / 4; c->rw = rw;
+        X_TRY(hipMalloc((void**)&c->d_send_recs, c->cap * (uint64_t)n * rw * 8));
+        X_TRY(hipMalloc((void**)&c->d_send_parts, c->cap * (uint64_t)n * 4));
+    }
+    int rc = pg::e2_route(ctx, d_packed, d_word_off, d_kmer_base, n_reads, uniform_len, ord_base, n, c->d_send_recs, c->d_send_parts, c->cap,
+                          c->d_counts, st);
+    int first_err = rc;
+    const std::string first_why = rc ? pg_last_error() : "";
+    if (rc) X_TRY(hipMemsetAsync(c->d_counts, 0, sizeof(uint64_t) * (size_t)n, st));   // take part in the round anyway
+    // an owner region that overflowed: the kernel dropped what did not fit (and flagged the context); tell the receivers
+    // the number that is really there
+    X_TRY(hipMemcpyAsync(c->h_counts.data(), c->d_counts, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+    X_TRY(hipStreamSynchronize(st));
+    bool clamped = false;
+    for (int q = 0; q < n; q++) {
+        if (c->h_counts[q] > c->cap) { c->h_counts[q] = c->cap; clamped = true; }
+        c->sent_records += c->h_counts[q];
+    }
+    if (clamped) {
+        if (!first_err) { first_err = PG_ENOMEM; pg_set_error("pg_count_reads_sharded: an owner's send region overflowed"); }
+        X_TRY(hipMemcpyAsync(c->d_counts, c->h_counts.data(), sizeof(uint64_t) * (size_t)n, hipMemcpyHostToDevice, st));
+    }
+    rc = alltoall_words(c, c->d_counts, c->d_rcounts, 1, st);
+    if (rc) return rc;
+    X_TRY(hipMemcpyAsync(c->h_rcounts.data(), c->d_rcounts, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost, st));
+    X_TRY(hipStreamSynchronize(st));
+    uint64_t total_in = 0;
+    for (int q = 0; q < n; q++) total_in += c->h_rcounts[q];
+    if (total_in > c->recv_cap) {
+        if (c->d_recv_recs) (void)hipFree(c->d_recv_recs);
+        if (c->d_recv_parts) (void)hipFree(c->d_recv_parts);
+        c->d_recv_recs = nullptr; c->d_recv_parts = nullptr;
+        c->recv_cap = total_in + total_in / 4 + 4096;
+        X_TRY(hipMalloc((void**)&c->d_recv_recs, c->recv_cap * (uint64_t)rw * 8));
+        X_TRY(hipMalloc((void**)&c->d_recv_parts, c->recv_cap * 4));
+    }
+    rc = pg_exchange_records(c, c->d_send_recs, c->d_send_parts, c->cap, rw, c->h_counts.data(), c->h_rcounts.data(), c->d_recv_recs, c->d_recv_parts, st);
+    if (rc) return rc;
+    c->recv_records += total_in;
+    c->rounds++;
+    rc = pg::e2_ingest(ctx, c->d_recv_recs, c->d_recv_parts, total_in, st);
+    if (rc) return rc;
+    ctx->batches++;
+    if (first_err) { if (!first_why.empty()) pg_set_error(first_why); return first_err; }
+    return PG_OK;
+}
+
+// All ranks' exported records on rank `root` (rank order), for the stages that work on the whole graph.
+extern "C" int pg_exchange_gather_records(pg_comm* c, const uint64_t* d_records, uint64_t n_local, int rec_words, int root, uint64_t* d_out,
+                                          uint64_t capacity, uint64_t* n_out, void* stream) {
+    if (!c || root < 0 || root >= c->n || (n_local && !d_records)) { pg_set_error("bad argument"); return PG_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    X_TRY(hipSetDevice(c->device));
+    std::vector<uint64_t> mine(c->n, n_local);
+    X_TRY(hipMemcpyAsync(c->d_counts, mine.data(), sizeof(uint64_t) * (size_t)c->n, hipMemcpyHostToDevice, st));
+    int rc = alltoall_words(c, c->d_counts, c->d_rcounts, 1, st);
+    if (rc) return rc;
+    X_TRY(hipMemcpyAsync(c->h_rcounts.data(), c->d_rcounts, sizeof(uint64_t) * (size_t)c->n, hipMemcpyDeviceToHost, st));
+    X_TRY(hipStreamSynchronize(st));
+    std::vector<uint64_t> off(c->n + 1, 0);
+    for (int q = 0; q < c->n; q++) off[q + 1] = off[q] + c->h_rcounts[q];
+    if (n_out) *n_out = off[c->n];
+    const bool is_root = c->rank == root;
+    int err = PG_OK;
+    if (is_root && (off[c->n] > capacity || (off[c->n] && !d_out))) { pg_set_error("pg_exchange_gather_records: capacity too small"); err = PG_EINVAL; }
+    if (c->transport == PG_COMM_RCCL || c->n == 1) {
+        if (is_root && !err && n_local) X_TRY(hipMemcpyAsync(d_out + off[root] * rec_words, d_records, n_local * (uint64_t)rec_words * 8, hipMemcpyDeviceToDevice, st));
+        if (c->n > 1) {
+            // a root without room still has to take what is sent to it: it receives into nothing only if nothing is sent, so
+            // on error it drains into a scratch allocation
+            uint64_t* sink = d_out;
+            if (is_root && err) { X_TRY(hipMalloc((void**)&sink, std::max<uint64_t>(off[c->n], 1) * (uint64_t)rec_words * 8)); }
+            N_TRY(g_rccl.GroupStart());
+            if (!is_root && n_local) N_TRY(g_rccl.Send(d_records, n_local * (uint64_t)rec_words, ncclUint64, root, c->nccl, st));
+            if (is_root)
+                for (int q = 0; q < c->n; q++)
+                    if (q != root && c->h_rcounts[q]) N_TRY(g_rccl.Recv(sink + off[q] * rec_words, c->h_rcounts[q] * (uint64_t)rec_words, ncclUint64, q, c->nccl, st));
+            N_TRY(g_rccl.GroupEnd());
+            X_TRY(hipStreamSynchronize(st));
+            if (sink != d_out) (void)hipFree(sink);
+        }
+        return err;
+    }
+    LocalGroup* g = c->grp;
+    X_TRY(hipStreamSynchronize(st));
+    g->a[c->rank] = d_records;
+    g->barrier();
+    if (is_root && !err)
+        for (int q = 0; q < c->n; q++)
+            if (c->h_rcounts[q]) X_TRY(hipMemcpyAsync(d_out + off[q] * rec_words, g->a[q], c->h_rcounts[q] * (uint64_t)rec_words * 8, hipMemcpyDefault, st));
+    X_TRY(hipStreamSynchronize(st));
+    g->barrier();
+    return err;
+}
+
+extern "C" int pg_comm_stats(const pg_comm* c, uint64_t out[4]) {
+    if (!c || !out) { pg_set_error("null argument"); return PG_EINVAL; }
+    out[0] = c->rounds; out[1] = c->sent_records; out[2] = c->recv_records; out[3] = c->cap;
+    return PG_OK;
+}

@@ -1390,6 +1390,18 @@ static int replay_streamed(Graph<NW>& g, pg_fetch_fn fetch, void* user, uint64_t
     return PG_OK;
 }
 
+// After the n distinct keys of a set are in, one more put (a duplicate: nothing is inserted) still runs the growth test of
+// newhash.c:477; it changes the layout exactly when the table would grow, i.e. when n sits at the threshold of its size.
+extern "C" int pg_host_last_put_matters(const uint64_t* set_counts, int n_sets, int a_gb, int mer127) {
+    if (!set_counts || a_gb != 0) return 0;                         // static pools never grow
+    const uint64_t init = ref_initial_set_size(0, n_sets, mer127);
+    for (int s = 0; s < n_sets; s++) {
+        const uint64_t n = set_counts[s];
+        if (n && HSet<2>::final_size(init, n + 1, false) != HSet<2>::final_size(init, n, false)) return 1;
+    }
+    return 0;
+}
+
 template <int NW>
 static int layout_only(const uint64_t* records, uint64_t n, const uint64_t* set_last_put, int P, int a_gb, uint64_t* out_slot,
                        uint64_t* out_size) {

@@ -89,8 +89,13 @@ __device__ __forceinline__ uint64_t* record_slot(const E2Dev& e, uint32_t pid, u
     return e.pool + ((uint64_t)(c - 1) * e.rpc + ri) * (uint64_t)rw;
 }
 
-template <int NW>
-__global__ __launch_bounds__(BLOCK) void skm_scatter_kernel(ReadsArg a, E2Dev e, DevCounters* ctr) {
+// multi-GPU: instead of appending to the local partition streams, records go to per-owner send regions (owner =
+// partition mod n_owners), `cap` records each, with the partition id alongside; cursor[o] counts what owner o gets.
+struct RouteArg { uint64_t* recs; uint32_t* pids; unsigned long long* cursor; uint64_t cap; int n_owners; };
+
+// one lane per read: any mix of read lengths (the tiled kernel below takes the uniform batches)
+template <int NW, bool ROUTE>
+__global__ __launch_bounds__(BLOCK) void skm_scatter_kernel(ReadsArg a, E2Dev e, DevCounters* ctr, RouteArg ro) {
     constexpr int PW = E2Cfg<NW>::PW, RW = PW + 1;
     const uint64_t r = (uint64_t)blockIdx.x * BLOCK + threadIdx.x;
     if (r >= a.n_reads) return;
@@ -104,8 +109,17 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_kernel(ReadsArg a, E2Dev e,
         rd = a.packed + a.word_off[r]; len = (int)(a.kmer_base[r + 1] - kb) + e.g.K - 1; ord0 = a.ord_base + kb;
     }
     skm_split_read(rd, len, e.g, [&](int j0, int n, uint32_t pid) {
-        const uint32_t q = atomicAdd(&e.cursor[pid], 1u);
-        uint64_t* dst = record_slot(e, pid, q, ctr, RW);
+        uint64_t* dst;
+        if (ROUTE) {
+            const uint32_t o = pid % (uint32_t)ro.n_owners;
+            const unsigned long long at = atomicAdd(&ro.cursor[o], 1ULL);
+            if (at >= ro.cap) { atomicOr(&ctr->e2_flags, F_POOL); return; }
+            ro.pids[(uint64_t)o * ro.cap + at] = pid;
+            dst = ro.recs + ((uint64_t)o * ro.cap + at) * RW;
+        } else {
+            const uint32_t q = atomicAdd(&e.cursor[pid], 1u);
+            dst = record_slot(e, pid, q, ctr, RW);
+        }
         if (!dst) return;
         uint64_t rec[RW];
         skm_make_record<PW>(rd, len, j0, n, ord0, e.g, rec);
@@ -114,9 +128,6 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_kernel(ReadsArg a, E2Dev e,
     });
 }
 
-// multi-GPU: instead of appending to the local partition streams, records go to per-owner send regions (owner =
-// partition mod n_owners), `cap` records each, with the partition id alongside; cursor[o] counts what owner o gets.
-struct RouteArg { uint64_t* recs; uint32_t* pids; unsigned long long* cursor; uint64_t cap; int n_owners; };
 __device__ __forceinline__ uint32_t fastdiv(uint32_t i, uint32_t inv) { return __umulhi(i, inv); }
 // i / d for small i with inv = ceil(2^32 / d); d = 1 has no 32-bit reciprocal
 __device__ __forceinline__ uint32_t fastdiv1(uint32_t i, uint32_t d, uint32_t inv) { return d == 1 ? i : __umulhi(i, inv); }
@@ -603,6 +614,17 @@ __global__ __launch_bounds__(BLOCK) void skm_lastput_kernel(E2Dev e, SetParams s
     if (threadIdx.x < sp.P && set_last[threadIdx.x]) atomicMax(&ctr->set_last[threadIdx.x], set_last[threadIdx.x]);
 }
 
+// distinct k-mers per reference set, from the export array (the set id is the top byte of a record's last word)
+__global__ __launch_bounds__(BLOCK) void set_count_kernel(const uint64_t* out, uint64_t n, int rw, DevCounters* ctr) {
+    __shared__ unsigned int cnt[256];
+    cnt[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK)
+        atomicAdd(&cnt[out[i * rw + rw - 1] >> PG_ORD_BITS], 1u);
+    __syncthreads();
+    if (cnt[threadIdx.x]) atomicAdd(&ctr->set_last[threadIdx.x], (unsigned long long)cnt[threadIdx.x]);
+}
+
 // =========================================================================================================
 // host side of engine 2
 // =========================================================================================================
@@ -765,18 +787,41 @@ static int launch_tiled(pg_ctx* c, const ReadsArg& a, const RouteArg* route, hip
 }
 
 // multi-GPU step 1: cut a uniform batch into records grouped by owner (partition mod n_owners)
-int e2_route(pg_ctx* c, const uint64_t* d_packed, uint64_t n_reads, uint32_t uniform_len, uint64_t ord_base, int n_owners,
-             uint64_t* d_recs, uint32_t* d_pids, uint64_t cap, uint64_t* d_counts, hipStream_t st) {
-    if (!uniform_len || uniform_len >= 4096) { pg_set_error("pg_skm_route needs a uniform-length batch"); return PG_EINVAL; }
+static int launch_serial(pg_ctx* c, const ReadsArg& a, const RouteArg* route, hipStream_t st) {
+    const uint64_t grid = (a.n_reads + BLOCK - 1) / BLOCK;
+    if (grid > 0x7FFFFFFFULL) { pg_set_error("batch too large for one launch"); return PG_EINVAL; }
+    RouteArg ro{nullptr, nullptr, nullptr, 0, 1};
+    if (route) ro = *route;
+    if (c->NW == 2) {
+        if (route) hipLaunchKernelGGL((skm_scatter_kernel<2, true>), dim3((unsigned)grid), dim3(BLOCK), 0, st, a, dev_view(c), c->ctr, ro);
+        else hipLaunchKernelGGL((skm_scatter_kernel<2, false>), dim3((unsigned)grid), dim3(BLOCK), 0, st, a, dev_view(c), c->ctr, ro);
+    } else {
+        if (route) hipLaunchKernelGGL((skm_scatter_kernel<4, true>), dim3((unsigned)grid), dim3(BLOCK), 0, st, a, dev_view(c), c->ctr, ro);
+        else hipLaunchKernelGGL((skm_scatter_kernel<4, false>), dim3((unsigned)grid), dim3(BLOCK), 0, st, a, dev_view(c), c->ctr, ro);
+    }
+    E2_TRY(hipGetLastError());
+    c->e2.counted = false;
+    return PG_OK;
+}
+
+// multi-GPU step 1: cut a batch into records grouped by owner (partition mod n_owners).  Uniform batches go through the
+// tiled kernel, ragged ones (d_word_off / d_kmer_base given) through the one-lane-per-read kernel.
+int e2_route(pg_ctx* c, const uint64_t* d_packed, const uint64_t* d_word_off, const uint64_t* d_kmer_base, uint64_t n_reads,
+             uint32_t uniform_len, uint64_t ord_base, int n_owners, uint64_t* d_recs, uint32_t* d_pids, uint64_t cap, uint64_t* d_counts,
+             hipStream_t st) {
+    if (!uniform_len && (!d_word_off || !d_kmer_base)) { pg_set_error("pg_skm_route: a ragged batch needs d_word_off and d_kmer_base"); return PG_EINVAL; }
     if ((ord_base >> (64 - SKM_ORD_SHIFT)) != 0) { pg_set_error("ordinal exceeds the 46 bits of a super-k-mer header"); return PG_EINVAL; }
     ReadsArg a;
-    a.packed = d_packed; a.word_off = nullptr; a.kmer_base = nullptr; a.n_reads = n_reads; a.uniform_len = uniform_len;
-    a.kpr = uniform_len - c->K + 1; a.wpr = (uniform_len + 31) / 32; a.ord_base = ord_base;
+    a.packed = d_packed; a.word_off = d_word_off; a.kmer_base = d_kmer_base; a.n_reads = n_reads; a.uniform_len = uniform_len;
+    a.kpr = uniform_len ? uniform_len - c->K + 1 : 0; a.wpr = uniform_len ? (uniform_len + 31) / 32 : 0; a.ord_base = ord_base;
     E2_TRY(hipMemsetAsync(d_counts, 0, sizeof(uint64_t) * n_owners, st));
+    if (n_reads == 0) return PG_OK;
     RouteArg ro{d_recs, d_pids, (unsigned long long*)d_counts, cap, n_owners};
-    int rc = launch_tiled(c, a, &ro, st);
-    if (rc == 1) { pg_set_error("reads too long for the tiled kernel"); return PG_EINVAL; }
-    return rc;
+    if (uniform_len && uniform_len < 4096 && (int)a.kpr < 4096) {
+        int rc = launch_tiled(c, a, &ro, st);
+        if (rc != 1) return rc;
+    }
+    return launch_serial(c, a, &ro, st);
 }
 
 // multi-GPU step 2: take records another rank cut for this rank's partitions
@@ -818,12 +863,51 @@ int e2_scatter(pg_ctx* c, const uint64_t* d_packed, const uint64_t* d_word_off, 
         int rc = launch_tiled(c, a, nullptr, st);
         if (rc != 1) return rc;
     }
-    const uint64_t grid = (n_reads + BLOCK - 1) / BLOCK;
-    if (grid > 0x7FFFFFFFULL) { pg_set_error("batch too large for one launch"); return PG_EINVAL; }
-    if (c->NW == 2) hipLaunchKernelGGL(skm_scatter_kernel<2>, dim3((unsigned)grid), dim3(BLOCK), 0, st, a, dev_view(c), c->ctr);
-    else hipLaunchKernelGGL(skm_scatter_kernel<4>, dim3((unsigned)grid), dim3(BLOCK), 0, st, a, dev_view(c), c->ctr);
+    return launch_serial(c, a, nullptr, st);
+}
+
+// K3: per reference set, 1 + the ordinal of the last k-mer occurrence routed to it -> ctr->set_last (the streams must still exist)
+static int e2_last_put_launch(pg_ctx* c, hipStream_t st) {
+    E2& s = c->e2;
+    if (!s.pool) { pg_set_error("the partition streams are gone (pg_export_take)"); return PG_ESTATE; }
+    const SetParams sp{(uint32_t)c->P, set_bias((uint32_t)c->P)};
+    int n_cu = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) n_cu = prop.multiProcessorCount;
+    const unsigned grid = std::min<unsigned>(1u << s.log2_parts, (unsigned)n_cu * 8u);
+    E2_TRY(hipMemsetAsync(c->ctr->set_last, 0, sizeof(unsigned long long) * 256, st));
+    if (c->NW == 2) hipLaunchKernelGGL(skm_lastput_kernel<2>, dim3(grid), dim3(BLOCK), 0, st, dev_view(c), sp, c->ctr);
+    else hipLaunchKernelGGL(skm_lastput_kernel<4>, dim3(grid), dim3(BLOCK), 0, st, dev_view(c), sp, c->ctr);
     E2_TRY(hipGetLastError());
-    c->e2.counted = false;
+    return PG_OK;
+}
+int e2_last_put(pg_ctx* c, uint64_t* out, hipStream_t st) {
+    int rc = e2_last_put_launch(c, st);
+    if (rc) return rc;
+    E2_TRY(hipStreamSynchronize(st));
+    unsigned long long h[256];
+    E2_TRY(hipMemcpy(h, c->ctr->set_last, sizeof h, hipMemcpyDeviceToHost));
+    for (int i = 0; i < c->P; i++) out[i] = h[i];
+    return PG_OK;
+}
+// distinct k-mers per reference set (after e2_count); uses ctr->set_last as scratch
+int e2_set_counts(pg_ctx* c, uint64_t out[256], hipStream_t st) {
+    E2& s = c->e2;
+    if (!s.counted || !s.out) { pg_set_error("pg_set_counts: call pg_finalize first"); return PG_ESTATE; }
+    unsigned long long n = 0;
+    E2_TRY(hipMemcpy(&n, &c->ctr->n_export, sizeof n, hipMemcpyDeviceToHost));
+    unsigned long long keep[256], h[256];
+    E2_TRY(hipMemcpy(keep, c->ctr->set_last, sizeof keep, hipMemcpyDeviceToHost));
+    E2_TRY(hipMemsetAsync(c->ctr->set_last, 0, sizeof keep, st));
+    if (n) {
+        const unsigned grid = (unsigned)std::min<uint64_t>((n + BLOCK - 1) / BLOCK, 256u * 16u);
+        hipLaunchKernelGGL(set_count_kernel, dim3(grid), dim3(BLOCK), 0, st, s.out, (uint64_t)n, c->NW + 2, c->ctr);
+        E2_TRY(hipGetLastError());
+    }
+    E2_TRY(hipStreamSynchronize(st));
+    E2_TRY(hipMemcpy(h, c->ctr->set_last, sizeof h, hipMemcpyDeviceToHost));
+    E2_TRY(hipMemcpy(c->ctr->set_last, keep, sizeof keep, hipMemcpyHostToDevice));
+    for (int i = 0; i < 256; i++) out[i] = h[i];
     return PG_OK;
 }
 
@@ -859,10 +943,8 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     }
     E2_TRY(hipGetLastError());
     if (want_last_put) {
-        E2_TRY(hipMemsetAsync(c->ctr->set_last, 0, sizeof(unsigned long long) * 256, st));
-        if (c->NW == 2) hipLaunchKernelGGL(skm_lastput_kernel<2>, dim3(grid), dim3(BLOCK), 0, st, dev_view(c), sp, c->ctr);
-        else hipLaunchKernelGGL(skm_lastput_kernel<4>, dim3(grid), dim3(BLOCK), 0, st, dev_view(c), sp, c->ctr);
-        E2_TRY(hipGetLastError());
+        int rc = e2_last_put_launch(c, st);
+        if (rc) return rc;
     }
     E2_TRY(hipStreamSynchronize(st));
     DevCounters h;

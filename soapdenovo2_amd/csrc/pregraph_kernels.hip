@@ -789,8 +789,9 @@ extern "C" int pg_skm_route(pg_ctx* c, const uint64_t* d_packed, uint64_t n_read
     if (c->engine != 2) { g_err = "pg_skm_route needs the partition engine"; return PG_ESTATE; }
     if (n_owners < 1 || n_owners > 256) { g_err = "bad n_owners"; return PG_EINVAL; }
     HIP_TRY(hipSetDevice(c->device));
-    return e2_route(c, d_packed, n_reads, uniform_len, ord_base, n_owners, d_send_records, d_send_parts, capacity_per_owner, d_counts,
-                    (hipStream_t)stream);
+    if (!uniform_len) { g_err = "pg_skm_route needs a uniform-length batch (pg_count_reads_sharded takes ragged ones)"; return PG_EINVAL; }
+    return e2_route(c, d_packed, nullptr, nullptr, n_reads, uniform_len, ord_base, n_owners, d_send_records, d_send_parts, capacity_per_owner,
+                    d_counts, (hipStream_t)stream);
 }
 
 extern "C" int pg_skm_ingest(pg_ctx* c, const uint64_t* d_records, const uint32_t* d_parts, uint64_t n_records, void* stream) {
@@ -867,6 +868,41 @@ extern "C" int pg_finalize(pg_ctx* c, int delow, uint64_t hist_out[256], uint64_
     for (int i = 0; i < 256; i++) hist_out[i] = h.hist[i];
     if (set_last_put_out) for (int i = 0; i < c->P; i++) set_last_put_out[i] = h.set_last[i];
     c->finalized = true;
+    return PG_OK;
+}
+
+// Partition engine: the per-set last put on demand (K3 is a second expansion of every record, and the layout replay needs
+// its answer only when some set ends exactly at a growth threshold: pg_host_last_put_matters), and the per-set counts
+// that decision is taken from.
+extern "C" int pg_set_counts(pg_ctx* c, uint64_t out[256], void* stream) {
+    if (!c || !out) { g_err = "null argument"; return PG_EINVAL; }
+    if (c->engine != 2) { g_err = "pg_set_counts needs the partition engine"; return PG_ESTATE; }
+    HIP_TRY(hipSetDevice(c->device));
+    return e2_set_counts(c, out, (hipStream_t)stream);
+}
+extern "C" int pg_last_put(pg_ctx* c, uint64_t* set_last_put_out, void* stream) {
+    if (!c || !set_last_put_out) { g_err = "null argument"; return PG_EINVAL; }
+    if (c->engine != 2) { g_err = "pg_last_put needs the partition engine (the global-set engine returns it from pg_finalize)"; return PG_ESTATE; }
+    HIP_TRY(hipSetDevice(c->device));
+    return e2_last_put(c, set_last_put_out, (hipStream_t)stream);
+}
+
+// Partition engine only: hand the export array itself over (no copy) and let go of everything else the context holds on
+// the device -- the record pool, the chunk table, the cursors.  The caller owns *d_records_out (hipFree) from here on; the
+// context can only be destroyed afterwards.  Halves the device memory needed at the hand-over to the graph stages.
+extern "C" int pg_export_take(pg_ctx* c, uint64_t** d_records_out, uint64_t* n_out) {
+    if (!c || !d_records_out || !n_out) { g_err = "null argument"; return PG_EINVAL; }
+    if (c->engine != 2) { g_err = "pg_export_take needs the partition engine"; return PG_ESTATE; }
+    if (!c->e2.counted) { g_err = "pg_export_take: call pg_finalize first"; return PG_ESTATE; }
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long n = 0;
+    HIP_TRY(hipMemcpy(&n, &c->ctr->n_export, sizeof n, hipMemcpyDeviceToHost));
+    *d_records_out = c->e2.out;
+    *n_out = n;
+    c->e2.out = nullptr;
+    c->e2.out_capacity = 0;
+    e2_destroy(c);                                       // frees what is left (pool, tables); the context is spent
+    c->e2.counted = false;
     return PG_OK;
 }
 

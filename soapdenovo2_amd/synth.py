@@ -54,6 +54,46 @@ def write_fastq(path: str, codes: np.ndarray, name_prefix: str = "r") -> None:
         f.write(blob)
 
 
+def write_fastq_fast(path: str, codes: np.ndarray) -> None:
+    """write_fastq for millions of reads: fixed-width names (`@r000000123`), one numpy block, no Python loop."""
+    n, L = codes.shape
+    names = np.char.zfill(np.arange(n).astype("U9"), 9).astype("S9").view(np.uint8).reshape(n, 9)
+    rec = np.empty((n, 2 + 9 + 1 + L + 3 + L + 1), dtype=np.uint8)
+    rec[:, 0] = ord("@"); rec[:, 1] = ord("r"); rec[:, 2:11] = names; rec[:, 11] = 10
+    rec[:, 12:12 + L] = _ASCII[codes]
+    rec[:, 12 + L] = 10; rec[:, 13 + L] = ord("+"); rec[:, 14 + L] = 10
+    rec[:, 15 + L:15 + 2 * L] = ord("I"); rec[:, 15 + 2 * L] = 10
+    blob = rec.tobytes()
+    if len(blob) % 32768 == 0:                 # the reference drops the tail of such a file (prlHashReads.c:873-877): avoid the size
+        blob = blob[:-1] + b" \n"
+    with open(path, "wb") as f:
+        f.write(blob)
+
+
+def gpu_reads_codes(genome_len: int, n_reads: int, read_len: int, err: float, seed: int, device: int = 0, chunk: int = 2_000_000) -> np.ndarray:
+    """The read model of reads_codes drawn with torch on a GPU (numpy takes minutes at 10 M reads); a different random
+    stream, so the reads differ from reads_codes' for the same seed."""
+    import torch
+    dev = torch.device("cuda", device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    genome = torch.randint(0, 4, (genome_len,), dtype=torch.uint8, device=dev, generator=g)
+    ar = torch.arange(read_len, device=dev, dtype=torch.int64)
+    out = np.empty((n_reads, read_len), dtype=np.uint8)
+    for lo in range(0, n_reads, chunk):
+        n = min(chunk, n_reads - lo)
+        starts = torch.randint(0, genome_len - read_len, (n,), device=dev, generator=g, dtype=torch.int64)
+        reads = genome[starts[:, None] + ar[None, :]]
+        flip = torch.rand(n, device=dev, generator=g) < 0.5
+        reads = torch.where(flip[:, None], torch.flip(reads, dims=[1]) ^ 2, reads)
+        if err > 0:
+            mask = torch.rand(reads.shape, device=dev, generator=g) < err
+            shift = torch.randint(1, 4, reads.shape, device=dev, generator=g, dtype=torch.uint8)
+            reads = torch.where(mask, (reads + shift) & 3, reads)
+        out[lo:lo + n] = reads.cpu().numpy()
+    return out
+
+
 def write_fasta(path: str, codes: np.ndarray, name_prefix: str = "r") -> None:
     n, L = codes.shape
     chunks = [b">" + name_prefix.encode() + str(i).encode() + b"\n" + _ASCII[codes[i]].tobytes() + b"\n"

@@ -1,103 +1,101 @@
-"""The N > 1 exchange logic on CPU (gloo, world size 2): the owner partition + variable-size all-to-all that
-bench.py / a multi-GPU pregraph run perform around pg_route_scatter / pg_count_records.  The device kernels are
-stood in by the oracle (occurrence records of each rank's reads); what is tested is that after the exchange every
-rank holds exactly the occurrences of the reference sets it owns, and that per-rank reduction + union equals the
-single-process result."""
+"""The N > 1 pass-1 path on CPU (gloo, world sizes 2 and 3) through the library's own routing code.
+
+Each rank cuts its share of the reads into super-k-mer records with pg_host_skm_cut -- the host twin of pg_skm_route: the
+same inline functions the kernels run (csrc/skm.hpp), owner = minimizer partition mod world -- the records travel through
+a variable-size all-to-all (what pg_exchange_records does over RCCL), and every rank expands what it received with
+pg_host_skm_expand.  Checked: every k-mer occurrence of the input arrives exactly once; all occurrences of a canonical
+k-mer meet on ONE rank; the per-rank reduction (saturating counters, first ordinal) put together equals the oracle's
+single-process records bit for bit.  The oracle is the checker; nothing here restates the routing."""
 import os
 import sys
 
 import numpy as np
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from conftest import ROOT, case_codes, oracle_records
+from conftest import ROOT, oracle_records
+
+CASES = {"k21": (3000, 400, 60, 0.01, 77, 21, False), "k63": (4000, 300, 150, 0.005, 5, 63, False), "k127": (6000, 120, 250, 0.004, 9, 127, True)}
 
 
-def _occurrences(codes, K, P, ord_base):
-    """(key_hi, key_lo, meta, set) per k-mer occurrence, via the oracle one read at a time."""
-    from oracle_binding import Oracle
-    o = Oracle(K, P=P, max_read_len=codes.shape[1])
-    recs = []
-    L = codes.shape[1]
-    kpr = L - K + 1
-    # brute force in numpy (small inputs): canonical k-mer + flanks per position, as SURVEY.md A.1
-    def val(seq):
-        v = 0
-        for c in seq:
-            v = (v << 2) | int(c)
-        return v
-    from oracle_binding import lib
-    for r in range(codes.shape[0]):
-        s = codes[r]
-        for j in range(kpr):
-            w = val(s[j:j + K])
-            rc = val([(int(c) ^ 2) for c in s[j:j + K][::-1]])
-            if w <= rc:
-                key, left, right = w, (int(s[j - 1]) if j > 0 else 4), (int(s[j + K]) if j < L - K else 4)
-            else:
-                key, left, right = rc, ((int(s[j + K]) ^ 2) if j < L - K else 4), ((int(s[j - 1]) ^ 2) if j > 0 else 4)
-            recs.append((key >> 64, key & ((1 << 64) - 1), ((ord_base + r * kpr + j) << 6) | (left << 3) | right))
-    o.close()
-    return recs
+def _reduce(occ, nw):
+    """occurrence rows (key words, left, right, ord) -> records (key words, cnt word, first ordinal) with the reference's
+    saturating counters (newhash.c:74-140)."""
+    if len(occ) == 0:
+        return np.zeros((0, nw + 2), dtype=np.uint64)
+    keys = occ[:, :nw]
+    order = np.lexsort([keys[:, i] for i in range(nw - 1, -1, -1)])
+    occ = occ[order]
+    keys = occ[:, :nw]
+    new = np.ones(len(occ), dtype=bool)
+    new[1:] = (keys[1:] != keys[:-1]).any(axis=1)
+    gid = np.cumsum(new) - 1
+    n = int(gid[-1]) + 1
+    out = np.zeros((n, nw + 2), dtype=np.uint64)
+    out[:, :nw] = keys[new]
+    puts = np.bincount(gid, minlength=n)
+    A = (np.minimum(puts, 255).astype(np.uint64) << np.uint64(24))
+    B = np.where(puts == 1, np.uint64(1 << 27), np.uint64(0))
+    for c in range(4):
+        l = np.minimum(np.bincount(gid, weights=(occ[:, nw] == c), minlength=n).astype(np.uint64), 63)
+        r = np.minimum(np.bincount(gid, weights=(occ[:, nw + 1] == c), minlength=n).astype(np.uint64), 63)
+        A |= l << np.uint64(6 * c)
+        B |= r << np.uint64(6 * c)
+    out[:, nw] = A | (B << np.uint64(32))
+    first = np.full(n, np.iinfo(np.uint64).max, dtype=np.uint64)
+    np.minimum.at(first, gid, occ[:, nw + 2])
+    out[:, nw + 1] = first
+    return out
 
 
-def _crc_set(hi, lo, P):
-    import zlib
-    # hash_kmer = CRC-32 with register init 0 and a final xor (hashFunction.c:123-131); zlib xors its start value, so
-    # passing 0xFFFFFFFF starts the register at 0, and zlib applies the final xor itself
-    crc = zlib.crc32(int(hi).to_bytes(8, "little") + int(lo).to_bytes(8, "little"), 0xFFFFFFFF) & 0xFFFFFFFF
-    v = crc if crc < 0x80000000 else crc + 0xFFFFFFFF00000000
-    return v % P
-
-
-def _worker(rank, world, port, tmp, K, P):
+def _worker(rank, world, port, tmp, case):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-    from soapdenovo2_amd import synth
-    codes = synth.reads_codes(3000, 60, 60, 0.01, 77)
-    per = codes.shape[0] // world
-    mine = codes[rank * per:(rank + 1) * per]
-    kpr = codes.shape[1] - K + 1
-    recs = _occurrences(mine, K, P, rank * per * kpr)
-    owner = [_crc_set(h, l, P) % world for h, l, _ in recs]
-    send = [[r for r, o in zip(recs, owner) if o == d] for d in range(world)]
-    send_counts = torch.tensor([len(x) for x in send], dtype=torch.int64)
+    from soapdenovo2_amd import api, synth
+    G, N, L, err, seed, K, m127 = CASES[case]
+    codes = synth.reads_codes(G, N, L, err, seed)
+    bounds = np.linspace(0, N, world + 1).astype(int)
+    lo, hi = int(bounds[rank]), int(bounds[rank + 1])
+    kpr = L - K + 1
+    packed = api.pack_reads_uniform(codes[lo:hi])
+    recs, tags = api.host_skm_cut(packed, hi - lo, L, K, m127, 7, lo * kpr, world)
+    owner = (tags & np.uint64(0xFF)).astype(np.int64)
+    assert ((tags >> np.uint64(8)).astype(np.int64) % world == owner).all()
+    W = recs.shape[1]
+    order = np.argsort(owner, kind="stable")                  # grouped by owner, as pg_skm_route writes them
+    recs, owner = recs[order], owner[order]
+    send_counts = torch.from_numpy(np.bincount(owner, minlength=world).astype(np.int64))
     recv_counts = torch.empty_like(send_counts)
     dist.all_to_all_single(recv_counts, send_counts)
-    flat = [w for part in send for r in part for w in r]
-    # uint64 payload travels as int64
-    out = torch.from_numpy(np.array(flat, dtype=np.uint64).view(np.int64)) if flat else torch.empty(0, dtype=torch.int64)
-    inp = torch.empty(int(recv_counts.sum()) * 3, dtype=torch.int64)
-    dist.all_to_all_single(inp, out, [int(c) * 3 for c in recv_counts], [int(c) * 3 for c in send_counts])
-    got = inp.numpy().view(np.uint64).reshape(-1, 3)
-    np.save(os.path.join(tmp, f"recv{rank}.npy"), got)
+    out = torch.from_numpy(recs.view(np.int64).reshape(-1).copy())
+    inp = torch.empty(int(recv_counts.sum()) * W, dtype=torch.int64)
+    dist.all_to_all_single(inp, out, [int(c) * W for c in recv_counts], [int(c) * W for c in send_counts])
+    got = inp.numpy().view(np.uint64).reshape(-1, W)
+    occ = api.host_skm_expand(got, K, m127)
+    np.save(os.path.join(tmp, f"occ{rank}.npy"), occ)
     dist.barrier()
     dist.destroy_process_group()
 
 
-def test_owner_exchange_world2(tmp_path):
-    K, P, world = 21, 4, 2
-    port = 29500 + os.getpid() % 2000
-    mp.spawn(_worker, args=(world, port, str(tmp_path), K, P), nprocs=world, join=True)
+@pytest.mark.parametrize("case,world", [("k21", 2), ("k63", 2), ("k63", 3), ("k127", 2)])
+def test_partition_owner_exchange(tmp_path, case, world):
     from soapdenovo2_amd import synth
-    codes = synth.reads_codes(3000, 60, 60, 0.01, 77)
-    want, last, _ = oracle_records(codes, K, P, prefix=str(tmp_path / "o"))
-    parts = [np.load(str(tmp_path / f"recv{r}.npy")) for r in range(world)]
-    assert sum(len(p) for p in parts) == codes.shape[0] * (codes.shape[1] - K + 1)
-    seen = {}
-    for r, p in enumerate(parts):
-        for hi, lo, meta in p:
-            s = _crc_set(int(hi), int(lo), P)
-            assert s % world == r                          # every occurrence landed on the owner of its set
-            k = (int(hi), int(lo))
-            ordv = int(meta) >> 6
-            c, first = seen.get(k, (0, 1 << 62))
-            seen[k] = (c + 1, min(first, ordv))
-    assert len(seen) == want.shape[0]
-    for row in want:
-        c, first = seen[(int(row[0]), int(row[1]))]
-        assert min(c, 255) == (int(row[2]) & 0xFFFFFFFF) >> 24            # total coverage
-        assert first == int(row[3]) & ((1 << 56) - 1)                      # first-occurrence ordinal
-        assert int(row[3]) >> 56 == _crc_set(int(row[0]), int(row[1]), P)  # set id
+    G, N, L, err, seed, K, m127 = CASES[case]
+    port = 29500 + (os.getpid() * 7 + world * 13 + len(case)) % 2000
+    mp.spawn(_worker, args=(world, port, str(tmp_path), case), nprocs=world, join=True)
+    codes = synth.reads_codes(G, N, L, err, seed)
+    want, _, _ = oracle_records(codes, K, 1, mer127=m127, prefix=str(tmp_path / "o"))
+    nw = 4 if m127 else 2
+    parts = [np.load(str(tmp_path / f"occ{r}.npy")) for r in range(world)]
+    assert sum(len(p) for p in parts) == N * (L - K + 1)                    # every occurrence arrived, once
+    per_rank = [_reduce(p, nw) for p in parts]
+    got = np.concatenate(per_rank)
+    key = lambda r: r[np.lexsort([r[:, i] for i in range(nw - 1, -1, -1)])]
+    g, w = key(got), key(want).copy()
+    assert g.shape == w.shape                                                # no k-mer on two ranks
+    w[:, nw + 1] &= np.uint64((1 << 56) - 1)                                # the oracle's set id (P = 1: zero anyway)
+    w[:, nw] &= np.uint64(~(1 << (32 + 24)) & 0xFFFFFFFFFFFFFFFF)           # ... and the linear flag of finish_count
+    assert (g == w).all()

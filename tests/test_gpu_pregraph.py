@@ -437,3 +437,192 @@ def test_cli_degenerate_inputs_against_the_reference_binary(tmp_path, kind):
     for ext in ("kmerFreq", "preGraphBasic", "vertex", "preArc"):
         assert md5_file(str(tmp_path / ("amd." + ext))) == md5_file(str(tmp_path / ("ref." + ext))), ext
     assert md5_gz_text(str(tmp_path / "amd.edge.gz")) == md5_gz_text(str(tmp_path / "ref.edge.gz"))
+
+
+# ---- multi-GPU pass 1 through product code (exchange.hip), ranks sharing the one GPU of the test box --------------------
+def _sharded_records(codes, K, P, n_ranks, mer127=False, batches=5, transport=-1, rccl_world1=False):
+    """n_ranks ranks (host threads) on cuda:0: batches are dealt to the ranks in turn, a round = one batch per rank (the last
+    round leaves ranks empty-handed), every rank runs pg_count_reads_sharded per round and pg_finalize at the end."""
+    import threading
+    import torch
+    from soapdenovo2_amd import api
+    n, L = codes.shape
+    kpr = L - K + 1
+    if rccl_world1:
+        comms = [api.Comm.rccl(1, 0, 0, api.Comm.unique_id())]
+    else:
+        comms = api.Comm.local([0] * n_ranks, transport)
+    kcs = [api.KmerCounter(K, n_sets=P, mer127=mer127, log2_slots=18, engine=2) for _ in range(n_ranks)]
+    bounds = np.linspace(0, n, batches + 1).astype(int)
+    rounds = (batches + n_ranks - 1) // n_ranks
+    packed = [torch.from_numpy(api.pack_reads_uniform(codes[bounds[b]:bounds[b + 1]]).view(np.int64)).cuda() for b in range(batches)]
+    out, errs = [None] * n_ranks, []
+
+    def rank_main(r):
+        try:
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                for rd in range(rounds):
+                    b = rd * n_ranks + r
+                    if b < batches:
+                        kcs[r].count_sharded(comms[r], packed[b], int(bounds[b + 1] - bounds[b]), L, int(bounds[b]) * kpr)
+                    else:
+                        kcs[r].count_sharded(comms[r], None, 0, L, 0)
+                hist, last = kcs[r].finalize(0)
+                d_h = torch.from_numpy(hist.view(np.int64)).cuda()
+                comms[r].allreduce_u64(d_h, C_void(st))
+                st.synchronize()
+                out[r] = (kcs[r].export(), d_h.cpu().numpy().view(np.uint64), last, comms[r].stats(), comms[r].transport)
+        except Exception as e:                                   # a dead rank would leave the others at a barrier
+            errs.append((r, e))
+            os._exit(17)
+
+    import ctypes
+    C_void = lambda s: ctypes.c_void_p(s.cuda_stream)
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(n_ranks)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not errs, errs
+    for kc in kcs:
+        kc.close()
+    for c in comms:
+        c.close()
+    return out
+
+
+@pytest.mark.parametrize("name,P,m,n_ranks", [("m60k_k63", 8, False, 2), ("m60k_k63", 8, False, 3), ("t8k_k63", 5, True, 3),
+                                               ("t6k_k127", 3, True, 2), ("t6k_k31", 7, False, 3)])
+def test_sharded_pass1_ranks_on_one_gpu(golden, tmp_path, name, P, m, n_ranks):
+    c = golden["cases"][name]
+    codes = case_codes(c)
+    want, last_want, K = oracle_records(codes, c["K"], P, mer127=m, prefix=str(tmp_path / "o"))
+    out = _sharded_records(codes, K, P, n_ranks, mer127=m)
+    nw = 4 if m else 2
+    got = np.concatenate([o[0] for o in out])
+    assert got.shape == want.shape                                                   # no k-mer counted on two ranks
+    assert (_sorted(got, nw) == _sorted(want, nw)).all()
+    assert (np.maximum.reduce([o[2] for o in out]) == last_want).all()
+    freq = [int(x) for x in open(str(tmp_path / "o.kmerFreq")).read().split()]
+    for o in out:
+        assert [int(x) for x in o[1][1:]] == freq                                    # every rank holds the all-reduced histogram
+        assert o[4] == "p2p" and o[3]["rounds"] == (5 + n_ranks - 1) // n_ranks
+    assert sum(o[3]["sent_records"] for o in out) == sum(o[3]["recv_records"] for o in out) > 0
+    assert all(len(o[0]) > 0 for o in out)
+
+
+def test_sharded_pass1_rccl_single_rank(golden, tmp_path):
+    """The RCCL transport on the one GPU there is: a world of one rank -- librccl is loaded, a communicator is made from a
+    unique id, the (self) exchange and the all-reduce run through it."""
+    c = golden["cases"]["t8k_k63"]
+    codes = case_codes(c)
+    want, last_want, K = oracle_records(codes, c["K"], 4, prefix=str(tmp_path / "o"))
+    out = _sharded_records(codes, K, 4, 1, rccl_world1=True)
+    assert out[0][4] == "rccl"
+    assert (_sorted(out[0][0], 2) == _sorted(want, 2)).all()
+    assert (out[0][2] == last_want).all()
+
+
+@pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
+@pytest.mark.parametrize("name", ["m60k_k63", "t6k_k127", "t5k_k24"])
+def test_cli_sharded_matches_reference_files(golden, tmp_path, name, devices):
+    """`pregraph` with pass 1 sharded over several ranks (SOAPDENOVO2_AMD_DEVICES, here all on GPU 0): the five files (and
+    the -R pair) equal the reference's byte for byte, as with one rank."""
+    from soapdenovo2_amd import synth
+    c = golden["cases"][name]
+    cfg = synth.make_case(str(tmp_path), name, c["G"], c["N"], c["L"], c["err"], c["seed"])
+    for run in c["runs"]:
+        P, D, a, m = run
+        t = case_tag(name, run)
+        pre = str(tmp_path / t)
+        env = dict(PARALLEL_PARSE, SOAPDENOVO2_AMD_DEVICES=devices, PG_HOST_VERBOSE="1", SOAPDENOVO2_AMD_BATCH_READS="7000")
+        log = _run_cli(cfg, c["K"], pre, P, D, a, m, R=True, extra_env=env)
+        assert f"pass 1 on {len(devices.split(','))} rank(s)" in log
+        want = golden["md5"][t]
+        for ext in ("kmerFreq", "preGraphBasic", "vertex", "preArc", "path", "markOnEdge"):
+            assert md5_file(pre + "." + ext) == want[ext], (t, ext)
+        assert md5_gz_text(pre + ".edge.gz") == want["edge"], t
+
+
+def test_cli_sharded_reader_corner_cases(golden, tmp_path):
+    """Ragged / truncated / mate-file inputs through the sharded pass 1 (the one-lane-per-read cutter with routing)."""
+    from soapdenovo2_amd import synth
+    for name in synth.QUIRK_CASES:
+        cfg = synth.make_quirk_case(str(tmp_path), name)
+        pre = str(tmp_path / (name + "_sh"))
+        _run_cli(cfg, 31, pre, 3, 0, 0, 0, extra_env={"SOAPDENOVO2_AMD_DEVICES": "0,0,0", "SOAPDENOVO2_AMD_BATCH_READS": "300"})
+        want = golden["md5"][name]
+        for ext in ("kmerFreq", "preGraphBasic", "vertex", "preArc"):
+            assert md5_file(pre + "." + ext) == want[ext], (name, ext)
+        assert md5_gz_text(pre + ".edge.gz") == want["edge"], name
+
+
+def _threshold_reads(K=31, target=793):
+    """Reads (all K + 1 bases) with exactly `target` distinct k-mers in one set (1031 slots * 0.77f -> max 793), then pure
+    duplicates: the reference grows the set on the duplicate (newhash.c:477 tests before it probes)."""
+    from oracle_binding import Oracle
+    rng = np.random.default_rng(9)
+    o = Oracle(K, P=1, max_read_len=K + 2)
+    reads = []
+    while o.L.oracle_node_count(o.h) + 2 <= target:
+        r = rng.integers(0, 4, size=(1, K + 1), dtype=np.uint8)
+        o.add_reads(r)
+        reads.append(r[0])
+    while o.L.oracle_node_count(o.h) < target:
+        r = np.concatenate([reads[0][1:], rng.integers(0, 4, size=1, dtype=np.uint8)])[None, :]
+        o.add_reads(r)
+        reads.append(r[0])
+    assert o.L.oracle_node_count(o.h) == target
+    o.close()
+    return reads
+
+
+@pytest.mark.parametrize("tail", ["duplicate", "none"])
+def test_cli_last_put_on_demand(tmp_path, tail):
+    """The per-set last put is computed only when a set ends exactly at a growth threshold (pg_host_last_put_matters): with
+    793 distinct k-mers in the single set a trailing duplicate read grows the reference's table and changes .vertex order;
+    without it the table stays.  Both against the reference binary, with one rank and with three."""
+    from soapdenovo2_amd import api, synth
+    ref = os.path.join(ROOT, "oracle", "_ref", "SOAPdenovo-63mer")
+    if not os.path.exists(ref):
+        pytest.skip("reference binary not built")
+    reads = _threshold_reads()
+    if tail == "duplicate":
+        reads = reads + [reads[0]]
+    fa = str(tmp_path / "t.fa")
+    synth.write_fasta(fa, np.stack(reads))
+    cfg = str(tmp_path / "t.cfg")
+    open(cfg, "w").write(f"max_rd_len=100\n[LIB]\navg_ins=200\nasm_flags=3\nf={fa}\n")
+    outs = {}
+    for tag, binary, env in (("amd", api.binary(False), {}), ("amd3", api.binary(False), {"SOAPDENOVO2_AMD_DEVICES": "0,0,0", "SOAPDENOVO2_AMD_BATCH_READS": "100"}),
+                             ("ref", ref, {})):
+        pre = str(tmp_path / tag)
+        r = subprocess.run([binary, "pregraph", "-s", cfg, "-K", "31", "-o", pre, "-p", "1"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True,
+                           env=dict(os.environ, **env))
+        assert r.returncode == 0, (tag, r.stderr[-1500:])
+        outs[tag] = pre
+    for tag in ("amd", "amd3"):
+        for ext in ("kmerFreq", "preGraphBasic", "vertex", "preArc"):
+            assert md5_file(outs[tag] + "." + ext) == md5_file(outs["ref"] + "." + ext), (tag, tail, ext)
+        assert md5_gz_text(outs[tag] + ".edge.gz") == md5_gz_text(outs["ref"] + ".edge.gz"), (tag, tail)
+
+
+def test_set_counts_and_last_put_calls(golden, tmp_path):
+    import torch
+    from soapdenovo2_amd import api
+    c = golden["cases"]["t8k_k63"]
+    codes = case_codes(c)
+    P = 5
+    want, last_want, K = oracle_records(codes, c["K"], P, prefix=str(tmp_path / "o"))
+    kc = api.KmerCounter(K, n_sets=P, log2_slots=18, engine=2)
+    packed = torch.from_numpy(api.pack_reads_uniform(codes).view(np.int64)).cuda()
+    kc.count_uniform(packed, codes.shape[0], codes.shape[1], 0)
+    kc.finalize(0, want_last_put=False)
+    counts = kc.set_counts()
+    assert (counts == np.bincount((want[:, 3] >> np.uint64(56)).astype(int), minlength=P)).all()
+    assert (kc.last_put() == last_want).all()
+    kc.close()
+    assert api.lib().pg_host_last_put_matters(np.array([793], dtype=np.uint64).ctypes.data, 1, 0, 0) == 1
+    assert api.lib().pg_host_last_put_matters(np.array([792], dtype=np.uint64).ctypes.data, 1, 0, 0) == 0
+    assert api.lib().pg_host_last_put_matters(np.array([793], dtype=np.uint64).ctypes.data, 1, 1, 0) == 0

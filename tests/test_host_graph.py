@@ -84,3 +84,14 @@ def test_growth_on_trailing_duplicate():
     slots2, sizes2 = api.host_replay_layout(rec, np.zeros(1, dtype=np.uint64), 1)
     assert sizes2[0] == 1031
 
+
+def test_last_put_matters_only_at_a_growth_threshold():
+    """pg_host_last_put_matters: 1031 slots * 0.77f -> max 793, so a trailing duplicate grows a growable set holding
+    exactly 793 keys (and nothing else does); -a pools never grow."""
+    L = api.lib()
+    u = lambda *v: np.array(v, dtype=np.uint64).ctypes.data
+    assert L.pg_host_last_put_matters(u(793), 1, 0, 0) == 1
+    assert L.pg_host_last_put_matters(u(792), 1, 0, 0) == 0
+    assert L.pg_host_last_put_matters(u(794), 1, 0, 0) == 0
+    assert L.pg_host_last_put_matters(u(10, 500, 793), 3, 0, 0) == 1
+    assert L.pg_host_last_put_matters(u(793), 1, 2, 0) == 0
