@@ -809,13 +809,16 @@ static int launch_serial(pg_ctx* c, const ReadsArg& a, const RouteArg* route, hi
 int e2_route(pg_ctx* c, const uint64_t* d_packed, const uint64_t* d_word_off, const uint64_t* d_kmer_base, uint64_t n_reads,
              uint32_t uniform_len, uint64_t ord_base, int n_owners, uint64_t* d_recs, uint32_t* d_pids, uint64_t cap, uint64_t* d_counts,
              hipStream_t st) {
+    if (n_reads == 0) {                                          // a rank without reads in this round: nothing for anybody
+        E2_TRY(hipMemsetAsync(d_counts, 0, sizeof(uint64_t) * n_owners, st));
+        return PG_OK;
+    }
     if (!uniform_len && (!d_word_off || !d_kmer_base)) { pg_set_error("pg_skm_route: a ragged batch needs d_word_off and d_kmer_base"); return PG_EINVAL; }
     if ((ord_base >> (64 - SKM_ORD_SHIFT)) != 0) { pg_set_error("ordinal exceeds the 46 bits of a super-k-mer header"); return PG_EINVAL; }
     ReadsArg a;
     a.packed = d_packed; a.word_off = d_word_off; a.kmer_base = d_kmer_base; a.n_reads = n_reads; a.uniform_len = uniform_len;
     a.kpr = uniform_len ? uniform_len - c->K + 1 : 0; a.wpr = uniform_len ? (uniform_len + 31) / 32 : 0; a.ord_base = ord_base;
     E2_TRY(hipMemsetAsync(d_counts, 0, sizeof(uint64_t) * n_owners, st));
-    if (n_reads == 0) return PG_OK;
     RouteArg ro{d_recs, d_pids, (unsigned long long*)d_counts, cap, n_owners};
     if (uniform_len && uniform_len < 4096 && (int)a.kpr < 4096) {
         int rc = launch_tiled(c, a, &ro, st);

@@ -474,7 +474,10 @@ def _sharded_records(codes, K, P, n_ranks, mer127=False, batches=5, transport=-1
                 st.synchronize()
                 out[r] = (kcs[r].export(), d_h.cpu().numpy().view(np.uint64), last, comms[r].stats(), comms[r].transport)
         except Exception as e:                                   # a dead rank would leave the others at a barrier
-            errs.append((r, e))
+            import sys
+            import traceback
+            traceback.print_exc()
+            sys.stderr.flush()
             os._exit(17)
 
     import ctypes
