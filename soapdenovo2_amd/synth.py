@@ -33,6 +33,53 @@ def reads_codes(genome_len: int, n_reads: int, read_len: int, err: float, seed: 
     return np.ascontiguousarray(reads)
 
 
+def genome_model(model: str, genome_len: int, seed: int, K: int):
+    """Haplotypes to draw reads from.  "uniform": one random sequence.  "diploid": a second haplotype that differs by
+    pairs of SNPs K + 2 apart (two branch nodes joined by a single (K+1)-mer: the length-1 edges of node2edge.c:481-542).
+    "repeat": one haplotype with segments longer than K copied to other places (branching inside long shared stretches)."""
+    rng = np.random.default_rng(seed + 7919)
+    a = rng.integers(0, 4, size=genome_len, dtype=np.uint8)
+    if model == "uniform":
+        return [a]
+    if model == "diploid":
+        b = a.copy()
+        step = max(8 * K, 1500)
+        for p in range(2 * K, genome_len - 4 * K, step):
+            for q in (p, p + K + 2):
+                b[q] = (b[q] + 1 + rng.integers(0, 3)) & 3
+        return [a, b]
+    if model == "repeat":
+        seg = 2 * K + 40
+        for i in range(6):
+            src = int(rng.integers(0, genome_len - seg))
+            dst = int(rng.integers(0, genome_len - seg))
+            a[dst:dst + seg] = a[src:src + seg]
+            if i % 2:                                   # an inverted copy: the reverse strand of the same stretch
+                a[dst:dst + seg] = (a[src:src + seg][::-1] ^ 2)
+        return [a]
+    raise ValueError(model)
+
+
+def reads_codes_model(model: str, genome_len: int, n_reads: int, read_len: int, err: float, seed: int, K: int) -> np.ndarray:
+    """reads_codes over the haplotypes of genome_model (each read picks a haplotype at random)."""
+    if model == "uniform":
+        return reads_codes(genome_len, n_reads, read_len, err, seed)
+    haps = genome_model(model, genome_len, seed, K)
+    rng = np.random.default_rng(seed)
+    starts = rng.integers(0, genome_len - read_len, size=n_reads, dtype=np.int64)
+    which = rng.integers(0, len(haps), size=n_reads)
+    flip = rng.random(n_reads) < 0.5
+    idx = starts[:, None] + np.arange(read_len, dtype=np.int64)[None, :]
+    reads = np.stack(haps)[which[:, None], idx]
+    rc = (reads[:, ::-1] ^ 2).astype(np.uint8)
+    reads = np.where(flip[:, None], rc, reads)
+    if err > 0:
+        mask = rng.random(reads.shape) < err
+        shift = rng.integers(1, 4, size=reads.shape, dtype=np.uint8)
+        reads = np.where(mask, (reads + shift) & 3, reads).astype(np.uint8)
+    return np.ascontiguousarray(reads.astype(np.uint8))
+
+
 def write_fastq(path: str, codes: np.ndarray, name_prefix: str = "r") -> None:
     """Write reads as single-end FASTQ (`@r<i>`, quality 'I' x L).
 
@@ -114,10 +161,10 @@ def write_config(path: str, fastq: str, max_rd_len: int, key: str = "q", avg_ins
 
 
 def make_case(outdir: str, name: str, genome_len: int, n_reads: int, read_len: int, err: float,
-              seed: int, fmt: str = "fastq") -> str:
+              seed: int, fmt: str = "fastq", model: str = "uniform", K: int = 0) -> str:
     """Generate <outdir>/<name>.fq (or .fa) + <name>.cfg; return the config path."""
     os.makedirs(outdir, exist_ok=True)
-    codes = reads_codes(genome_len, n_reads, read_len, err, seed)
+    codes = reads_codes_model(model, genome_len, n_reads, read_len, err, seed, K)
     if fmt == "fastq":
         data = os.path.join(outdir, name + ".fq")
         write_fastq(data, codes)
@@ -199,9 +246,26 @@ def make_quirk_case(outdir: str, name: str) -> str:
         open(p(name + "_2.fa"), "wb").write(b"".join(b">s%d/2\n" % i + _ASCII[d[i]].tobytes() + b"\n" for i in range(400)))
         open(cfg, "w").write(f"max_rd_len=90\n[LIB]\navg_ins=300\nreverse_seq=0\nasm_flags=3\n"
                              f"q1={p(name + '_1.fq')}\nq2={p(name + '_2.fq')}\nf1={p(name + '_1.fa')}\nf2={p(name + '_2.fa')}\n")
+    elif name == "rq_gz":
+        # gzip-compressed inputs: the reference reads them through popen("gzip -dc ...") (readseq1by1.c:676-714)
+        import gzip
+        a = reads_codes(20000, 1500, 100, 0.004, 111)
+        b = reads_codes(20000, 700, 100, 0.004, 112)
+        with gzip.GzipFile(p(name + ".fq.gz"), "wb", mtime=0) as f:
+            f.write(b"".join(_fastq_blob(list(a), [b"z%d" % i for i in range(1500)])))
+        with gzip.GzipFile(p(name + ".fa.gz"), "wb", mtime=0) as f:
+            f.write(b"".join(b">g%d\n" % i + _ASCII[b[i]].tobytes() + b"\n" for i in range(700)))
+        open(cfg, "w").write(f"max_rd_len=100\n[LIB]\navg_ins=200\nasm_flags=3\nq={p(name + '.fq.gz')}\nf={p(name + '.fa.gz')}\n")
+    elif name == "rq_p":
+        # p=: both mates of a pair in one FASTA file, one after the other (lib.c:130-506 type 3), next to a plain q= file
+        a = reads_codes(20000, 1200, 90, 0.004, 113)
+        b = reads_codes(20000, 500, 90, 0.004, 114)
+        open(p(name + "_pairs.fa"), "wb").write(b"".join(b">m%d/%d\n" % (i // 2, 1 + i % 2) + _ASCII[a[i]].tobytes() + b"\n" for i in range(1200)))
+        open(p(name + ".fq"), "wb").write(b"".join(_fastq_blob(list(b), [b"s%d" % i for i in range(500)])))
+        open(cfg, "w").write(f"max_rd_len=90\n[LIB]\navg_ins=250\nreverse_seq=0\nasm_flags=3\np={p(name + '_pairs.fa')}\nq={p(name + '.fq')}\n")
     else:
         raise ValueError(name)
     return cfg
 
 
-QUIRK_CASES = ["rq_32k", "rq_trunc", "rq_ragged", "rq_pair"]
+QUIRK_CASES = ["rq_32k", "rq_trunc", "rq_ragged", "rq_pair", "rq_gz", "rq_p"]

@@ -51,7 +51,13 @@ def md5_gz_text(path):
 
 def case_codes(case):
     from soapdenovo2_amd import synth
-    return synth.reads_codes(case["G"], case["N"], case["L"], case["err"], case["seed"])
+    return synth.reads_codes_model(case.get("model", "uniform"), case["G"], case["N"], case["L"], case["err"], case["seed"], case["K"])
+
+
+def case_config(case, outdir, name):
+    """FASTQ + config of a golden case, as tests/golden/make_golden.py wrote them for the reference."""
+    from soapdenovo2_amd import synth
+    return synth.make_case(outdir, name, case["G"], case["N"], case["L"], case["err"], case["seed"], model=case.get("model", "uniform"), K=case["K"])
 
 
 def oracle_records(codes, K, P, D=0, mer127=False, a_gb=0, prefix=None):

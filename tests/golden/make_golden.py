@@ -22,6 +22,11 @@ CASES = {
     "t5k_k24":  dict(G=20000, N=5000, L=80, err=0.01, seed=12, K=24, runs=[(8,0,0,0)], full=[]),
     "m100k_k31": dict(G=500000, N=100000, L=100, err=0.005, seed=7, K=31, runs=[(8,0,0,0)], full=[]),
     "m60k_k63": dict(G=400000, N=60000, L=150, err=0.002, seed=8, K=63, runs=[(8,0,0,0), (8,0,0,1)], full=[]),
+    # structured genomes (synth.genome_model): two haplotypes with SNP pairs K + 2 apart -> length-1 edges, i.e. the
+    # (K+1)-mer table of node2edge.c:481-542 and, at K = 127, the `char` length overflow of kmer.c:532; repeats longer than K
+    "d8k_k127": dict(G=40000, N=8000, L=250, err=0.001, seed=21, K=127, model="diploid", runs=[(3,0,0,1), (8,0,0,1)], full=[]),
+    "r8k_k127": dict(G=40000, N=8000, L=250, err=0.001, seed=22, K=127, model="repeat", runs=[(3,0,0,1)], full=[]),
+    "d8k_k63":  dict(G=40000, N=8000, L=150, err=0.002, seed=23, K=63, model="diploid", runs=[(5,0,0,0), (5,0,0,1)], full=[]),
 }
 EXTS = ("kmerFreq", "preGraphBasic", "vertex", "edge", "preArc")
 
@@ -35,7 +40,7 @@ def main():
     digests = {}
     with tempfile.TemporaryDirectory() as td:
         for name, c in CASES.items():
-            cfg = synth.make_case(td, name, c["G"], c["N"], c["L"], c["err"], c["seed"])
+            cfg = synth.make_case(td, name, c["G"], c["N"], c["L"], c["err"], c["seed"], model=c.get("model", "uniform"), K=c["K"])
             for run in c["runs"]:
                 P, D, a, m = run
                 t = tag(name, run)
@@ -59,6 +64,7 @@ def main():
                     digests[t][e] = hashlib.md5(open(f"{preR}.{e}", "rb").read()).hexdigest()
                 subprocess.run([binary, "contig", "-g", preR, "-R"], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
                 digests[t]["contigR"] = hashlib.md5(open(preR + ".contig", "rb").read()).hexdigest()
+                digests[t]["length1_edges"] = sum(1 for l in gzip.open(pre + ".edge.gz", "rt") if l.startswith(">length 1,"))
                 if list(run) in [list(r) for r in c["full"]]:
                     for e in EXTS:
                         if e == "edge":

@@ -6,7 +6,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ROOT, case_codes, case_tag, md5_file, md5_gz_text, oracle_records
+from conftest import ROOT, case_codes, case_config, case_tag, md5_file, md5_gz_text, oracle_records
 
 pytestmark = pytest.mark.gpu
 
@@ -44,7 +44,8 @@ def _gpu_records(codes, K, P, mer127=False, D=0, log2_slots=20, batches=1, engin
 
 @pytest.mark.parametrize("engine", ENGINES)
 @pytest.mark.parametrize("name,P,m,D", [("t6k_k31", 8, False, 0), ("t6k_k31", 7, False, 1), ("t8k_k63", 2, False, 0),
-                                        ("t8k_k63", 5, True, 0), ("t6k_k127", 3, True, 0), ("t5k_k24", 8, False, 0)])
+                                        ("t8k_k63", 5, True, 0), ("t6k_k127", 3, True, 0), ("t5k_k24", 8, False, 0),
+                                        ("d8k_k127", 3, True, 0), ("d8k_k63", 5, False, 0)])
 def test_count_matches_oracle(golden, tmp_path, name, P, m, D, engine):
     c = golden["cases"][name]
     codes = case_codes(c)
@@ -193,12 +194,12 @@ def _run_cli(cfg, K, prefix, P, D, a, m, engine=None, R=False, extra_env=None):
 
 
 @pytest.mark.parametrize("engine", ENGINES)
-@pytest.mark.parametrize("name", ["t6k_k31", "t8k_k63", "t6k_k127", "t5k_k24", "m100k_k31", "m60k_k63"])
+@pytest.mark.parametrize("name", ["t6k_k31", "t8k_k63", "t6k_k127", "t5k_k24", "m100k_k31", "m60k_k63", "d8k_k127", "r8k_k127", "d8k_k63"])
 def test_cli_matches_reference_files(golden, tmp_path, name, engine):
     """`SOAPdenovo-63mer|127mer pregraph -s cfg -K k -o pfx -p n [-d -a]` end to end against the reference's files."""
     from soapdenovo2_amd import synth
     c = golden["cases"][name]
-    cfg = synth.make_case(str(tmp_path), name, c["G"], c["N"], c["L"], c["err"], c["seed"])
+    cfg = case_config(c, str(tmp_path), name)
     for run in c["runs"]:
         P, D, a, m = run
         t = case_tag(name, run)
@@ -301,7 +302,7 @@ def test_cli_reader_corner_cases(golden, tmp_path):
         assert md5_file(pre + ".preArc") == want["preArc"], name
 
 
-@pytest.mark.parametrize("name", ["t6k_k31", "t8k_k63", "t6k_k127", "t5k_k24", "m60k_k63"])
+@pytest.mark.parametrize("name", ["t6k_k31", "t8k_k63", "t6k_k127", "t5k_k24", "m60k_k63", "d8k_k127", "r8k_k127", "d8k_k63"])
 def test_device_pass2_matches_reference(golden, tmp_path, name):
     """pg_graph_use_device: read -> edge threading and the pre-arc table on the GPU (graph_kernels.hip), fed with the
     oracle's pass-1 records: .preArc, and with -R .path / .markOnEdge, byte for byte as the reference wrote them."""
@@ -528,13 +529,13 @@ def test_sharded_pass1_rccl_single_rank(golden, tmp_path):
 
 
 @pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
-@pytest.mark.parametrize("name", ["m60k_k63", "t6k_k127", "t5k_k24"])
+@pytest.mark.parametrize("name", ["m60k_k63", "t6k_k127", "t5k_k24", "d8k_k127"])
 def test_cli_sharded_matches_reference_files(golden, tmp_path, name, devices):
     """`pregraph` with pass 1 sharded over several ranks (SOAPDENOVO2_AMD_DEVICES, here all on GPU 0): the five files (and
     the -R pair) equal the reference's byte for byte, as with one rank."""
     from soapdenovo2_amd import synth
     c = golden["cases"][name]
-    cfg = synth.make_case(str(tmp_path), name, c["G"], c["N"], c["L"], c["err"], c["seed"])
+    cfg = case_config(c, str(tmp_path), name)
     for run in c["runs"]:
         P, D, a, m = run
         t = case_tag(name, run)

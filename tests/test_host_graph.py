@@ -9,7 +9,7 @@ import pytest
 from conftest import case_codes, case_tag, md5_file, md5_gz_text, oracle_records
 from soapdenovo2_amd import api
 
-CASES = ["t6k_k31", "t8k_k63", "t6k_k127", "t5k_k24", "m60k_k63"]
+CASES = ["t6k_k31", "t8k_k63", "t6k_k127", "t5k_k24", "m60k_k63", "d8k_k127", "r8k_k127", "d8k_k63"]
 
 
 @pytest.mark.parametrize("name", CASES)

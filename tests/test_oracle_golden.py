@@ -6,7 +6,7 @@ import pytest
 from conftest import GOLDEN, case_codes, case_tag, md5_file
 from oracle_binding import run_oracle
 
-SMALL = ["t6k_k31", "t8k_k63", "t6k_k127", "t5k_k24"]
+SMALL = ["t6k_k31", "t8k_k63", "t6k_k127", "t5k_k24", "d8k_k127", "r8k_k127", "d8k_k63"]
 
 
 def _cases(golden, names):

@@ -8,7 +8,7 @@ from conftest import case_codes, case_tag, md5_file, md5_gz_text, oracle_records
 from soapdenovo2_amd import api
 
 
-@pytest.mark.parametrize("name", ["t6k_k31", "t8k_k63", "t6k_k127", "t5k_k24", "m60k_k63"])
+@pytest.mark.parametrize("name", ["t6k_k31", "t8k_k63", "t6k_k127", "t5k_k24", "m60k_k63", "d8k_k127", "r8k_k127", "d8k_k63"])
 def test_prearc_matches_reference(golden, tmp_path, name):
     c = golden["cases"][name]
     codes = case_codes(c)
