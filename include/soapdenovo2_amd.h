@@ -268,11 +268,14 @@ int pg_host_last_put_matters(const uint64_t *set_counts, int n_sets, int a_gb, i
 /* Partition engine: the export array itself instead of a copy of it (the caller owns *d_records_out and frees it with
  * hipFree); everything else the context holds on the device is released, the context can only be destroyed afterwards. */
 int pg_export_take(pg_ctx *ctx, uint64_t **d_records_out, uint64_t *n_out);
+void pg_device_free(void *d_ptr);   /* hipFree, for callers that do not link the HIP runtime */
 
 /* Order exported records (device memory, on the current device) by their last word, i.e. by k-mer set and then by
  * first-occurrence ordinal: the order in which the layout replay of pg_host_build_graph / pg_host_graph_begin inserts
  * them (put_kmerset order, newhash.c:473-528).  Records handed over in this order are inserted as they lie; otherwise
- * the host buckets and sorts them itself.  n_records < 2^31.  Synchronises. */
+ * the host buckets and sorts them itself.  Any n_records that fits: rocPRIM's radix sort with 64-bit sizes, the
+ * permutation kept as 64-bit indices beyond 2^32 - 1 records (PG_SORT_WIDE=1 forces that flavour); needs about 2.5x the
+ * records' bytes of free device memory.  Synchronises. */
 int pg_sort_records(uint64_t *d_records, uint64_t n_records, int mer127, void *stream);
 
 /* ------------------------------------------------------------------------------------------------

@@ -107,6 +107,7 @@ def lib() -> C.CDLL:
     L.pg_finalize.argtypes = [C.c_void_p, C.c_int, u64p, u64p, C.c_void_p]
     L.pg_export.argtypes = [C.c_void_p, u64p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]
     L.pg_export_take.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.pg_device_free.argtypes = [C.c_void_p]
     L.pg_set_counts.argtypes = [C.c_void_p, u64p, C.c_void_p]
     L.pg_last_put.argtypes = [C.c_void_p, u64p, C.c_void_p]
     L.pg_host_last_put_matters.argtypes = [u64p, C.c_int, C.c_int, C.c_int]
@@ -137,7 +138,7 @@ EXPORTED_SYMBOLS = [
     "pg_last_error", "pg_version", "call_pregraph", "call_pregraph_127mer", "pg_packed_words", "pg_pack_read",
     "pg_host_build_graph", "pg_host_graph_begin", "pg_host_graph_add_reads", "pg_host_graph_finish", "pg_host_graph_resolve_repeats", "pg_host_graph_add_packed", "pg_graph_use_device", "pg_sort_records", "pg_expect_kmers", "pg_create_sized", "pg_graph_begin", "pg_graph_begin_streamed", "pg_host_read_all", "pg_host_replay_layout", "pg_host_write_kmerfreq", "pg_create", "pg_create_engine", "pg_destroy", "pg_reset", "pg_set_autogrow", "pg_count_reads", "pg_route_count",
     "pg_route_scatter", "pg_count_records", "pg_skm_route", "pg_skm_ingest", "pg_distinct", "pg_stats", "pg_table_info", "pg_finalize", "pg_export",
-    "pg_export_take", "pg_set_counts", "pg_last_put", "pg_host_last_put_matters", "pg_comm_unique_id", "pg_comm_create", "pg_comm_create_local", "pg_comm_destroy", "pg_comm_rank", "pg_comm_size",
+    "pg_export_take", "pg_device_free", "pg_set_counts", "pg_last_put", "pg_host_last_put_matters", "pg_comm_unique_id", "pg_comm_create", "pg_comm_create_local", "pg_comm_destroy", "pg_comm_rank", "pg_comm_size",
     "pg_comm_transport", "pg_comm_stats", "pg_exchange_counts", "pg_exchange_records", "pg_exchange_allreduce_u64",
     "pg_exchange_gather_records", "pg_count_reads_sharded", "pg_host_skm_cut", "pg_host_skm_expand",
 ]
@@ -359,6 +360,11 @@ class Comm:
         if self.h and self.owner:
             lib().pg_comm_destroy(self.h)
         self.h = None
+
+
+def hip_free(ptr) -> None:
+    """hipFree of a device pointer the library handed over (pg_export_take)."""
+    lib().pg_device_free(ptr)
 
 
 def host_skm_cut(packed: np.ndarray, n_reads: int, read_len: int, K: int, mer127: bool, log2_parts: int, ord_base: int, n_owners: int):

@@ -720,8 +720,8 @@ int run(int argc, char** argv, bool mer127) {
         ~HostRecords() { release(); }
     } records;
     // Records in replay order stay on the device and are pulled set by set, chunk by chunk, while the layout is rebuilt
-    // (pg_graph_begin_streamed); beyond 2^31 records, or with SOAPDENOVO2_AMD_STREAM_RECORDS=0, they are downloaded whole.
-    bool stream_records = n_distinct > 0 && n_distinct < 0x7fffffffULL;
+    // (pg_graph_begin_streamed); with SOAPDENOVO2_AMD_STREAM_RECORDS=0 they are downloaded whole.
+    bool stream_records = n_distinct > 0;
     if (const char* e = getenv("SOAPDENOVO2_AMD_STREAM_RECORDS")) stream_records = stream_records && atoi(e) != 0;
     std::vector<uint64_t> per_set(o.sets, 0);
     if (n_distinct) {
@@ -736,8 +736,8 @@ int run(int argc, char** argv, bool mer127) {
             }
             if (got != n_distinct) { fprintf(stderr, "export count mismatch\n"); exit(-1); }
         }
-        // replay order (set, first occurrence) on the device; beyond 2^31 records the host sorts instead
-        if (n_distinct < 0x7fffffffULL && pg_sort_records(d_rec, n_distinct, mer127 ? 1 : 0, nullptr) != PG_OK) die("pg_sort_records");
+        // replay order (set, first occurrence) on the device
+        if (pg_sort_records(d_rec, n_distinct, mer127 ? 1 : 0, nullptr) != PG_OK) die("pg_sort_records");
         if (stream_records) {
             // where every set starts: binary search over the sorted tags (a few hundred 8-byte copies)
             auto set_of_record = [&](uint64_t i) { uint64_t tag = 0; HIP_OK(hipMemcpy(&tag, d_rec + i * rw + rw - 1, sizeof tag, hipMemcpyDeviceToHost)); return tag >> 56; };

@@ -360,6 +360,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     const uint32_t parts = 1u << e.g.log2_parts;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long my_records = 0;
+    bool dirty = true;                                                   // the LDS set needs a full wipe before the next attempt
     unsigned long long tp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
 #define K2_TICK(i) do { if (dbg & 2) { const unsigned long long tn_ = clock64(); tp[i] += tn_ - tlast; tlast = tn_; } } while (0)
     uint32_t pf_nrec = 0, pf_cid = 0;
@@ -387,12 +388,15 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
         while (sp_top > 0) {
             __syncthreads();
             if (threadIdx.x == 0) { sp_top--; cur_mask = s_mask[sp_top]; cur_val = s_val[sp_top]; aborted = 0; }
-            for (int i = threadIdx.x; i < SLOTS; i += THREADS) {
+            if (dirty) {                                              // (the emit below leaves the set empty: it wipes what it reads)
+                for (int i = threadIdx.x; i < SLOTS; i += THREADS) {
 #pragma unroll
-                for (int q = 0; q < KW; q++) set.key[q][i] = L_EMPTY;
-                set.ord[i] = L_EMPTY;
+                    for (int q = 0; q < KW; q++) set.key[q][i] = L_EMPTY;
+                    set.ord[i] = L_EMPTY;
 #pragma unroll
-                for (int q = 0; q < 9; q++) set.cnt[q][i] = 0;
+                    for (int q = 0; q < 9; q++) set.cnt[q][i] = 0;
+                }
+                dirty = false;
             }
             __syncthreads();
             K2_TICK(1);
@@ -484,6 +488,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
             }
             if (aborted) {
                 if (dbg & 2) tp[9]++;
+                dirty = true;
                 // too many distinct keys for the LDS set: split this key range on the next hash bit and redo both halves
                 if (threadIdx.x == 0) {
                     const uint32_t bit = mask + 1;                                    // masks are 2^k - 1
@@ -496,29 +501,23 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 __syncthreads();
                 continue;
             }
-            // ---- emit: finalize every stored node and append it to the export array.  One global atomic per attempt,
-            // issued as soon as the live slots are counted so that its latency hides behind the node finalisation.
+            // ---- emit: finalize every stored node and append it to the export array.  The set is a quarter full on average,
+            // so the live slots are first listed (rank = wave prefix sums over the ballots) and then worked on by dense waves:
+            // lane i takes the i-th live slot, writes export record out_base + i and wipes the slot behind it, which is all
+            // the clearing the next attempt needs.  One global atomic per attempt.
+            unsigned short* live_list = (unsigned short*)rl;              // the record window is idle during the emit
             bool live[STRIPES];
             unsigned long long bal[STRIPES];
-            unsigned int puts_of[STRIPES];
 #pragma unroll
             for (int st = 0; st < STRIPES; st++) {
                 const int si = st * THREADS + threadIdx.x;
                 unsigned int puts = 0;
                 if (si < SLOTS) puts = set.cnt[0][si] + set.cnt[1][si] + set.cnt[2][si] + set.cnt[3][si] + set.cnt[8][si];
-                puts_of[st] = puts;
                 live[st] = puts != 0;                                     // a put is only counted once every key word is claimed
                 bal[st] = __ballot(live[st]);
                 if (lane == 0) wave_cnt[st][wave] = (unsigned int)__popcll(bal[st]);
             }
             __syncthreads();
-            if (threadIdx.x == 0) {
-                unsigned int tot = 0;
-                for (int st = 0; st < STRIPES; st++) for (int wv = 0; wv < NWAVE; wv++) tot += wave_cnt[st][wv];
-                out_base = atomicAdd(&ctr->n_export, (unsigned long long)tot);
-            }
-            uint64_t rec_out[STRIPES][NW + 2];
-            unsigned int off[STRIPES], cov_bin[STRIPES];
             unsigned int running = 0;
 #pragma unroll
             for (int st = 0; st < STRIPES; st++) {
@@ -529,21 +528,46 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     if (wv < wave) before += cw;
                     total += cw;
                 }
-                off[st] = running + before + (unsigned int)__popcll(bal[st] & ((1ULL << lane) - 1));
+                if (live[st]) live_list[running + before + (unsigned int)__popcll(bal[st] & ((1ULL << lane) - 1))] = (unsigned short)(st * THREADS + threadIdx.x);
                 running += total;
-                cov_bin[st] = 0;                                          // 0 = not live (a live node has cov >= 1)
-                if (live[st]) {
-                    const int si = st * THREADS + threadIdx.x;
-                    const unsigned int puts = puts_of[st];
+            }
+            const unsigned int n_live = running;
+            K2_TICK(6);
+            __syncthreads();                                              // the list is complete
+            K2_TICK(7);
+            // The export slots come from one global counter every workgroup of the grid adds to: its answer takes a while.
+            // Thread 0 asks now and looks at the answer only after its share of the finalisation (the records are staged in
+            // LDS meanwhile and go out afterwards as whole 16-byte pieces, coalesced).
+            unsigned long long ticket = 0;
+            if (threadIdx.x == 0) ticket = atomicAdd(&ctr->n_export, (unsigned long long)n_live);
+            constexpr unsigned int LIST_WORDS = SLOTS * 2 / 8;            // the list's share of rl, in 64-bit words
+            constexpr unsigned int STAGE_CAP = ((PAD + WIN * RD + 8) * 4 - SLOTS * 2) / ((NW + 2) * 8) / 64 * 64;
+            static_assert(STAGE_CAP >= 64, "staging area");
+            uint64_t* stage = (uint64_t*)rl + LIST_WORDS;
+            for (unsigned int c0 = 0; c0 < n_live; c0 += STAGE_CAP) {
+                const unsigned int cn = min(STAGE_CAP, n_live - c0);
+                for (unsigned int i = threadIdx.x; i < cn; i += THREADS) {
+                    const int si = live_list[c0 + i];
+                    unsigned int cl[4], cr[4];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) { cl[c] = set.cnt[c][si]; cr[c] = set.cnt[4 + c][si]; }
+                    const unsigned int puts = cl[0] + cl[1] + cl[2] + cl[3] + set.cnt[8][si];
                     Key63<NW> k63;
 #pragma unroll
                     for (int w = 0; w < KW; w++) k63.w[w] = set.key[w][si];
+                    const unsigned long long first = set.ord[si];
+                    // wipe the slot
+#pragma unroll
+                    for (int w = 0; w < KW; w++) set.key[w][si] = L_EMPTY;
+                    set.ord[si] = L_EMPTY;
+#pragma unroll
+                    for (int q = 0; q < 9; q++) set.cnt[q][si] = 0;
                     const Kmer<NW> key = kmer_from_key63<NW>(k63);
                     uint32_t A = min(puts, 255u) << 24, B = puts == 1 ? B_SINGLE : 0u;
                     int nin = 0, nout = 0;
 #pragma unroll
                     for (int c = 0; c < 4; c++) {                               // saturate, then thread_delow + thread_mark
-                        uint32_t l = min(set.cnt[c][si], 63u), r = min(set.cnt[4 + c][si], 63u);
+                        uint32_t l = min(cl[c], 63u), r = min(cr[c], 63u);
                         if (D > 0 && l <= (uint32_t)D) l = 0;
                         if (D > 0 && r <= (uint32_t)D) r = 0;
                         A |= l << (6 * c); B |= r << (6 * c);
@@ -551,31 +575,28 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     }
                     if (D > 0 && nin == 0 && nout == 0) B |= B_DELETED;
                     if (nin == 1 && nout == 1) B |= B_LINEAR;
-                    cov_bin[st] = A >> 24;
+                    const uint32_t cov = A >> 24;
                     const uint32_t sid = set_of_crc(kmer_crc32<NW>(key, crc_tab), sp.P, sp.bias);
+                    // coverage histogram: most nodes of a partition share one or two coverage values (1 for error k-mers), so
+                    // count those per wave instead of hammering one LDS word
+                    const unsigned long long ones = __ballot(cov == 1);
+                    if (lane == __ffsll((long long)ones) - 1) atomicAdd(&hist[1], (unsigned int)__popcll(ones));
+                    if (cov > 1) atomicAdd(&hist[cov], 1u);
+                    uint64_t* o = stage + (size_t)i * (NW + 2);
 #pragma unroll
-                    for (int w = 0; w < NW; w++) rec_out[st][w] = key.w[w];
-                    rec_out[st][NW] = (uint64_t)A | ((uint64_t)B << 32);
-                    rec_out[st][NW + 1] = ((uint64_t)sid << PG_ORD_BITS) | (set.ord[si] & PG_ORD_MASK);
+                    for (int w = 0; w < NW; w++) o[w] = key.w[w];
+                    o[NW] = (uint64_t)A | ((uint64_t)B << 32);
+                    o[NW + 1] = ((uint64_t)sid << PG_ORD_BITS) | (first & PG_ORD_MASK);
                 }
-                const unsigned long long ones = __ballot(cov_bin[st] == 1);
-                if (lane == 0 && ones) atomicAdd(&hist[1], (unsigned int)__popcll(ones));
-                if (cov_bin[st] > 1) atomicAdd(&hist[cov_bin[st]], 1u);
-            }
-            K2_TICK(6);
-            __syncthreads();                                              // out_base is in; the set may be cleared after this
-            K2_TICK(7);
-            const unsigned long long ob = out_base;
-#pragma unroll
-            for (int st = 0; st < STRIPES; st++) {
-                if (live[st]) {
-                    const uint64_t pos = ob + off[st];
-                    if (pos < e.out_capacity) {
-                        uint64_t* o = e.out + pos * (NW + 2);
-#pragma unroll
-                        for (int w = 0; w < NW + 2; w++) o[w] = rec_out[st][w];
-                    } else atomicOr(&ctr->e2_flags, F_OUT);
-                }
+                if (threadIdx.x == 0 && c0 == 0) out_base = ticket;
+                __syncthreads();
+                const unsigned long long ob = out_base + c0;
+                if (ob + cn <= e.out_capacity) {
+                    ulonglong2* dst = (ulonglong2*)(e.out + ob * (NW + 2));           // (NW + 2) * 8 is a multiple of 16
+                    const ulonglong2* src = (const ulonglong2*)stage;
+                    for (unsigned int q = threadIdx.x; q < cn * ((NW + 2) / 2); q += THREADS) dst[q] = src[q];
+                } else if (threadIdx.x == 0) atomicOr(&ctr->e2_flags, F_OUT);
+                if (c0 + STAGE_CAP < n_live) __syncthreads();                     // the staging area is filled again
             }
             K2_TICK(8);
         }

@@ -906,6 +906,9 @@ extern "C" int pg_export_take(pg_ctx* c, uint64_t** d_records_out, uint64_t* n_o
     return PG_OK;
 }
 
+// hipFree for callers that do not link the HIP runtime themselves (what pg_export_take hands over)
+extern "C" void pg_device_free(void* d_ptr) { if (d_ptr) (void)hipFree(d_ptr); }
+
 extern "C" int pg_export(pg_ctx* c, uint64_t* d_records, uint64_t capacity, uint64_t* n_out, void* stream) {
     if (!c || !d_records || !n_out) { g_err = "null argument"; return PG_EINVAL; }
     hipStream_t st = (hipStream_t)stream;

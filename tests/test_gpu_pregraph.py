@@ -356,11 +356,14 @@ def test_device_pass2_on_reader_corner_cases(golden, tmp_path):
             assert md5_gz_text(pre + ".edge.gz") == golden["md5"][name]["edge"], (name, packed)
 
 
-@pytest.mark.parametrize("K,m", [(31, 0), (127, 1)])
-def test_sort_records_is_replay_order(K, m):
-    """pg_sort_records: exported records ordered by (set, first ordinal) -- the same multiset, sorted by the last word."""
+@pytest.mark.parametrize("K,m,wide", [(31, 0, False), (127, 1, False), (31, 0, True), (127, 1, True)])
+def test_sort_records_is_replay_order(K, m, wide, monkeypatch):
+    """pg_sort_records: exported records ordered by (set, first ordinal) -- the same multiset, sorted by the last word.
+    wide: the flavour for more than 2^32 - 1 records (64-bit permutation indices), forced on a small input."""
     import torch
     from soapdenovo2_amd import api, synth
+    if wide:
+        monkeypatch.setenv("PG_SORT_WIDE", "1")
     L, n = 150, 40000
     codes = synth.reads_codes(50000, n, L, 0.004, 77)
     packed = torch.from_numpy(api.pack_reads_uniform(codes).view(np.int64)).cuda()
@@ -630,3 +633,55 @@ def test_set_counts_and_last_put_calls(golden, tmp_path):
     assert api.lib().pg_host_last_put_matters(np.array([793], dtype=np.uint64).ctypes.data, 1, 0, 0) == 1
     assert api.lib().pg_host_last_put_matters(np.array([792], dtype=np.uint64).ctypes.data, 1, 0, 0) == 0
     assert api.lib().pg_host_last_put_matters(np.array([793], dtype=np.uint64).ctypes.data, 1, 1, 0) == 0
+
+
+# ---- the drop-in, proven: the reference's own executable with its pregraph stage replaced by the library ------------------
+@pytest.mark.parametrize("flavour,K", [("63", 31), ("127", 75)])
+def test_linked_into_the_reference_all_pipeline(tmp_path, flavour, K):
+    """oracle/_ref/SOAPdenovo-*mer-amd = the reference's objects minus pregraph.o prlHashReads.o cutTipPreGraph.o node2edge.o
+    output_pregraph.o prlRead2path.o, linked against libsoapdenovo2_amd.so (oracle/Makefile.ref, target `linkin`).  Its
+    `all` pipeline calls call_pregraph in-process (standardPregraph/main.c:341) and then runs the reference's unchanged
+    contig / map / scaff stages on what the GPU wrote: every output must equal the all-reference run's."""
+    from soapdenovo2_amd import synth
+    ref = os.path.join(ROOT, "oracle", "_ref", f"SOAPdenovo-{flavour}mer")
+    amd = ref + "-amd"
+    if not (os.path.exists(ref) and os.path.exists(amd)):
+        pytest.skip("reference / link-in binaries not built")
+    cfg = synth.make_case(str(tmp_path), "all", 30000, 6000, 100, 0.005, 20260926)
+    outs = {}
+    for tag, binary in (("ref", ref), ("amd", amd)):
+        d = tmp_path / tag
+        d.mkdir()
+        r = subprocess.run([binary, "all", "-s", cfg, "-K", str(K), "-o", str(d / "o"), "-p", "4", "-R"], stdout=subprocess.DEVNULL, stderr=subprocess.PIPE,
+                           text=True, cwd=str(d))
+        assert r.returncode == 0, (tag, r.stderr[-1500:])
+        outs[tag] = str(d / "o")
+    assert "HIP device" in r.stderr                                  # the pregraph stage of the second run was ours
+    for ext in ("kmerFreq", "preGraphBasic", "vertex", "preArc", "path", "markOnEdge", "contig", "ContigIndex", "Arc", "updated.edge", "scafSeq", "scaf"):
+        assert md5_file(outs["amd"] + "." + ext) == md5_file(outs["ref"] + "." + ext), ext
+    assert md5_gz_text(outs["amd"] + ".edge.gz") == md5_gz_text(outs["ref"] + ".edge.gz")
+
+
+def test_call_pregraph_twice_in_one_process(golden, tmp_path):
+    """The boundary is a function, not a process (the reference's pipeline() calls it in-process and carries on): two calls in
+    one process -- getopt state reset, no device or host state carried over -- then one of the 127-mer flavour."""
+    code = r'''
+import sys
+sys.path.insert(0, sys.argv[1])
+from soapdenovo2_amd import api
+cfg, out = sys.argv[2], sys.argv[3]
+for i, (m, K) in enumerate(((False, 31), (False, 31), (True, 31))):
+    rc = api.call_pregraph(["-s", cfg, "-K", str(K), "-o", f"{out}/r{i}", "-p", "8", "-R"], mer127=m, in_process=True)
+    assert rc == 0
+print("three calls done")
+'''
+    c = golden["cases"]["t6k_k31"]
+    cfg = case_config(c, str(tmp_path), "t6k_k31")
+    r = subprocess.run([os.sys.executable, "-c", code, ROOT, cfg, str(tmp_path)], capture_output=True, text=True)
+    assert r.returncode == 0 and "three calls done" in r.stdout, r.stderr[-1500:]
+    want = golden["md5"]["t6k_k31_p8_d0_a0_63"]
+    for i in (0, 1):
+        for ext in ("kmerFreq", "preGraphBasic", "vertex", "preArc", "path", "markOnEdge"):
+            assert md5_file(str(tmp_path / f"r{i}.{ext}")) == want[ext], (i, ext)
+        assert md5_gz_text(str(tmp_path / f"r{i}.edge.gz")) == want["edge"], i
+    assert md5_file(str(tmp_path / "r2.kmerFreq")) == want["kmerFreq"]          # same counts through the four-word path
