@@ -306,7 +306,7 @@ __device__ __forceinline__ const uint64_t* record_ptr(const E2Dev& e, uint32_t p
 //     (a hot k-mer's lanes hit the same word: same-address LDS atomics serialise, same-address reads broadcast).
 template <int NW, int SLOTS>
 __device__ __forceinline__ bool lds_put(LdsSet<NW, SLOTS>& t, const uint64_t (&kw)[E2Cfg<NW>::KW], uint32_t hash, uint32_t left, uint32_t right,
-                                         uint64_t ord) {
+                                         uint64_t ord, uint32_t copies) {
     constexpr int KW = E2Cfg<NW>::KW;
     uint32_t h = hash & (SLOTS - 1);
     for (int probes = 0; probes < K2_MAXPROBE; probes++) {
@@ -326,8 +326,8 @@ __device__ __forceinline__ bool lds_put(LdsSet<NW, SLOTS>& t, const uint64_t (&k
             mine = cur == kw[i];
         }
         if (mine) {
-            atomicAdd(&t.cnt[left < 4 ? left : 8][h], 1u);           // exactly one of L[0..3] / "none" per put
-            if (right < 4) atomicAdd(&t.cnt[4 + right][h], 1u);
+            atomicAdd(&t.cnt[left < 4 ? left : 8][h], copies);       // exactly one of L[0..3] / "none" per put
+            if (right < 4) atomicAdd(&t.cnt[4 + right][h], copies);
             if (ord < so) atomicMin(&t.ord[h], (unsigned long long)ord);
             return true;
         }
@@ -344,16 +344,24 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     static_assert(WIN <= THREADS, "one record per lane in the flatten step");
     static_assert(PAD % 4 == 0 && PAD >= 2 * NW + 2, "front padding");
     __shared__ LdsSet<NW, SLOTS> set;
-    __shared__ __align__(16) uint32_t rl[PAD + WIN * RD + 8];             // records as dword strings: [hdr hi, hdr lo, payload hi, lo, ...]
-    __shared__ unsigned int noff[WIN + 1];                                // exclusive prefix sum of the records' k-mer counts
-    __shared__ unsigned short first_rec[THREADS];                         // record in which lane l's share starts
-    __shared__ uint32_t crc_tab[256];
+    __shared__ __align__(16) uint32_t rl[PAD + WIN * RD + 8];             // records: [hdr lo, hdr hi, payload as a dword string: hi, lo, hi, lo, ...]
+    // one scratch area, two lives: the record-dedupe table (DT slots), then the flattening tables
+    constexpr int DT = 2 * WIN;                                           // open addressing over the window's records, <= 50 % full
+    constexpr int FL_WORDS = (DT > WIN + 1 + THREADS / 2 ? DT : WIN + 1 + THREADS / 2) + 2;
+    __shared__ __align__(8) unsigned int fl_raw[FL_WORDS];
+    unsigned int* const dtab = fl_raw;                                    // record index + 1 of the slot's first taker, 0 = free
+    unsigned int* const noff = fl_raw;                                    // [n_rep + 1] exclusive prefix sum of the representatives' k-mer counts
+    unsigned short* const first_rec = (unsigned short*)(fl_raw + WIN + 1);   // [THREADS] representative in which lane l's share starts
+    __shared__ unsigned int dcount[WIN];                                  // copies of a representative record in the window
+    __shared__ unsigned short repidx[WIN];                                // representatives, in window order
+    __shared__ uint32_t crc_tab[4 * 256];                                 // CRC-32 sliced by four (kmer.hpp)
     __shared__ unsigned int hist[256];
     constexpr int STRIPES = (SLOTS + THREADS - 1) / THREADS;
     __shared__ unsigned int aborted, sp_top, s_mask[40], s_val[40], cur_mask, cur_val, wave_cnt[STRIPES][NWAVE];
     __shared__ unsigned int chunk_ids[256];                                // this partition's chunk list (maxc <= 256)
     __shared__ unsigned long long out_base;
-    for (int i = threadIdx.x; i < 256; i += THREADS) { crc_tab[i] = crc32_table_entry(i); hist[i] = 0; }
+    for (int i = threadIdx.x; i < 1024; i += THREADS) crc_tab[i] = crc32_slice_entry(i >> 8, i & 255);
+    for (int i = threadIdx.x; i < 256; i += THREADS) hist[i] = 0;
     if (threadIdx.x < PAD) rl[threadIdx.x] = 0;
     if (threadIdx.x < 8) rl[PAD + WIN * RD + threadIdx.x] = 0;
     const int K = e.g.K;
@@ -403,22 +411,66 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
             const uint32_t mask = cur_mask, val = cur_val;
             for (uint32_t w0 = 0; w0 < usable; w0 += WIN) {
                 const uint32_t wn = min((uint32_t)WIN, usable - w0);
-                // stage the window's records: 16 bytes per lane and step, each 64-bit word stored high dword first
+                // stage the window's records: 16 bytes per lane and step; the header word as it is, every payload word high
+                // dword first (a string of dwords)
                 for (uint32_t pc = threadIdx.x; pc < wn * PIECES; pc += THREADS) {
                     const uint32_t ri = pc / PIECES, part = pc - ri * PIECES;
                     const uint32_t gi = w0 + ri, cid = chunk_ids[gi >> e.rpc_log2];
                     ulonglong2 v = make_ulonglong2(0, 0);
                     if (cid != 0 && cid != 0xFFFFFFFFu)
                         v = ((const ulonglong2*)(e.pool + ((uint64_t)(cid - 1) * e.rpc + (gi & (e.rpc - 1))) * (uint64_t)RW))[part];
-                    ((uint4*)(rl + PAD))[pc] = make_uint4((uint32_t)(v.x >> 32), (uint32_t)v.x, (uint32_t)(v.y >> 32), (uint32_t)v.y);
+                    const uint32_t x0 = part ? (uint32_t)(v.x >> 32) : (uint32_t)v.x, x1 = part ? (uint32_t)v.x : (uint32_t)(v.x >> 32);
+                    ((uint4*)(rl + PAD))[pc] = make_uint4(x0, x1, (uint32_t)(v.y >> 32), (uint32_t)v.y);
                 }
+                for (int i = threadIdx.x; i < DT; i += THREADS) dtab[i] = 0;
+                for (int i = threadIdx.x; i < WIN; i += THREADS) dcount[i] = 1;
                 __syncthreads();
                 K2_TICK(2);
-                // flatten: occurrence idx -> (record, t); every lane gets `share` consecutive occurrences
+                // dedupe: at high coverage most records of a partition are exact copies of one another (every read that covers a
+                // super-k-mer completely cuts out the same bases with the same flanks).  Copies are found through a small hash
+                // table over the window; the first taker of a slot represents the others, which add to its count and lower its
+                // first ordinal (the header word: equal records differ in nothing else, so the smaller header is the smaller
+                // ordinal).  Only representatives are expanded, each occurrence counting `copies` times: the same sums, the
+                // same minima, about half the work.
+                bool is_rep = threadIdx.x < wn;
+                if (is_rep && !(dbg & 4)) {
+                    const uint32_t* me = rl + PAD + threadIdx.x * RD;
+                    uint32_t w[RD - 1];
+                    w[0] = me[0] & ((1u << SKM_ORD_SHIFT) - 1);            // n, has_left, has_right
+#pragma unroll
+                    for (int q = 1; q < RD - 1; q++) w[q] = me[q + 1];
+                    uint32_t hsh = 0x9E3779B1u;                               // rotate-xor fold, one multiplicative finish
+#pragma unroll
+                    for (int q = 0; q < RD - 1; q++) hsh = alignbit32(hsh, hsh, 27u) ^ w[q];
+                    hsh *= 0x85EBCA6Bu;
+                    hsh ^= hsh >> 15;
+                    uint32_t sl = hsh & (DT - 1);
+                    for (int probes = 0; probes < DT; probes++) {
+                        unsigned int v = dtab[sl];
+                        if (v == 0) {
+                            const unsigned int old = atomicCAS(&dtab[sl], 0u, threadIdx.x + 1u);
+                            if (old == 0) break;                              // first of its kind: it represents the rest
+                            v = old;
+                        }
+                        const uint32_t* it = rl + PAD + (v - 1) * RD;
+                        bool same = (it[0] & ((1u << SKM_ORD_SHIFT) - 1)) == w[0];
+#pragma unroll
+                        for (int q = 1; q < RD - 1; q++) same = same && it[q + 1] == w[q];
+                        if (same) {
+                            atomicAdd(&dcount[v - 1], 1u);
+                            atomicMin((unsigned long long*)it, *(const unsigned long long*)me);
+                            is_rep = false;
+                            break;
+                        }
+                        sl = (sl + 1) & (DT - 1);
+                    }
+                }
+                __syncthreads();                                                  // dtab is dead from here, counts and minima are final
+                // flatten: occurrence idx -> (representative, t); every lane gets `share` consecutive occurrences
                 uint32_t total_occ, share;
                 {
-                    const unsigned int n = threadIdx.x < wn ? ((rl[PAD + threadIdx.x * RD + 1] >> 2) & 0xFFFFu) : 0u;
-                    unsigned int incl = n;
+                    const unsigned int n = is_rep ? ((rl[PAD + threadIdx.x * RD] >> 2) & 0xFFFFu) : 0u;
+                    unsigned int incl = n | (is_rep ? 1u << 20 : 0u);         // k-mers below bit 20, representatives above
 #pragma unroll
                     for (int d = 1; d < 64; d <<= 1) { const unsigned int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
                     if (lane == 63) wave_cnt[0][wave] = incl;
@@ -426,11 +478,15 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     unsigned int base = 0, tot = 0;
 #pragma unroll
                     for (int wv = 0; wv < NWAVE; wv++) { const unsigned int cw = wave_cnt[0][wv]; if (wv < wave) base += cw; tot += cw; }
+                    const unsigned int n_rep = tot >> 20;
+                    tot &= (1u << 20) - 1;
                     total_occ = tot;
                     share = (tot + THREADS - 1) / THREADS;
-                    if (threadIdx.x < wn) {
-                        const unsigned int o_lo = base + incl - n, o_hi = base + incl;
-                        noff[threadIdx.x] = o_lo;
+                    if (is_rep) {
+                        const unsigned int upto = base + incl, k = (upto >> 20) - 1;            // this representative's rank
+                        const unsigned int o_hi = upto & ((1u << 20) - 1), o_lo = o_hi - n;
+                        noff[k] = o_lo;
+                        repidx[k] = (unsigned short)threadIdx.x;
                         // lanes whose share starts inside this record: l * share in [o_lo, o_hi)
                         const float inv = 1.0f / (float)share;
                         auto div_up = [&](unsigned int x) {                        // ceil(x / share), x < 2^16
@@ -440,9 +496,9 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                             return q + (q * share < x ? 1u : 0u);
                         };
                         const unsigned int l0 = div_up(o_lo), l1 = min((unsigned int)THREADS, div_up(o_hi));
-                        for (unsigned int l = l0; l < l1; l++) first_rec[l] = (unsigned short)threadIdx.x;
+                        for (unsigned int l = l0; l < l1; l++) first_rec[l] = (unsigned short)k;
                     }
-                    if (threadIdx.x == THREADS - 1) noff[wn] = tot;
+                    if (threadIdx.x == THREADS - 1) noff[n_rep] = tot;
                 }
                 __syncthreads();
                 K2_TICK(3);
@@ -450,14 +506,16 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     uint32_t idx = min(total_occ, threadIdx.x * share);
                     const uint32_t idx1 = min(total_occ, idx + share);
                     if (idx < idx1) {
-                        uint32_t r = first_rec[threadIdx.x];
-                        uint32_t o_hi = noff[r + 1];
+                        uint32_t k = first_rec[threadIdx.x];
+                        uint32_t o_hi = noff[k + 1];
                         for (; idx < idx1; idx++) {
-                            r += idx >= o_hi ? 1u : 0u;
-                            const uint32_t o_lo = noff[r];
-                            o_hi = noff[r + 1];
+                            k += idx >= o_hi ? 1u : 0u;
+                            const uint32_t o_lo = noff[k];
+                            o_hi = noff[k + 1];
+                            const uint32_t r = repidx[k];
                             const uint32_t* rec = rl + PAD + r * RD;
-                            const uint32_t h_hi = rec[0], h_lo = rec[1];
+                            const uint32_t h_lo = rec[0], h_hi = rec[1];
+                            const uint32_t copies = dcount[r];
                             const uint32_t t = idx - o_lo;
                             const uint32_t hl = (h_lo >> 1) & 1u, hr = h_lo & 1u, n = (h_lo >> 2) & 0xFFFFu;
                             uint32_t f[N2], rc[N2], prev, next;
@@ -475,7 +533,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                             uint64_t kw[KW];
                             occ_key63<NW>(c, kw);
                             const uint64_t ord = ((((uint64_t)h_hi << 32) | h_lo) >> SKM_ORD_SHIFT) + t;
-                            if (!lds_put<NW, SLOTS>(set, kw, hh, left, right, ord)) {
+                            if (!lds_put<NW, SLOTS>(set, kw, hh, left, right, ord, copies)) {
                                 aborted = 1;
                                 break;
                             }
@@ -576,7 +634,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     if (D > 0 && nin == 0 && nout == 0) B |= B_DELETED;
                     if (nin == 1 && nout == 1) B |= B_LINEAR;
                     const uint32_t cov = A >> 24;
-                    const uint32_t sid = set_of_crc(kmer_crc32<NW>(key, crc_tab), sp.P, sp.bias);
+                    const uint32_t sid = set_of_crc(kmer_crc32_sliced<NW>(key, crc_tab), sp.P, sp.bias);
                     // coverage histogram: most nodes of a partition share one or two coverage values (1 for error k-mers), so
                     // count those per wave instead of hammering one LDS word
                     const unsigned long long ones = __ballot(cov == 1);

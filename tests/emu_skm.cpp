@@ -182,3 +182,19 @@ extern "C" int64_t emu_tile_check(const uint64_t* packed, int64_t n_reads, int l
 #undef TC
 }
 extern "C" int emu_tile_pick_segment(int kpr, int w) { return tile_pick_segment(kpr, w); }
+
+// the sliced CRC of kmer.hpp against the byte-wise one
+extern "C" int emu_crc_check(int n) {
+    uint32_t t1[256], t4[1024];
+    for (int i = 0; i < 256; i++) t1[i] = crc32_table_entry(i);
+    for (int i = 0; i < 1024; i++) t4[i] = crc32_slice_entry(i >> 8, i & 255);
+    uint64_t x = 0x9E3779B97F4A7C15ULL;
+    for (int i = 0; i < n; i++) {
+        Kmer<2> a; Kmer<4> b;
+        for (int q = 0; q < 2; q++) { x = x * 6364136223846793005ULL + 1442695040888963407ULL; a.w[q] = x; }
+        for (int q = 0; q < 4; q++) { x = x * 6364136223846793005ULL + 1442695040888963407ULL; b.w[q] = x; }
+        if (kmer_crc32<2>(a, t1) != kmer_crc32_sliced<2>(a, t4)) return 1;
+        if (kmer_crc32<4>(b, t1) != kmer_crc32_sliced<4>(b, t4)) return 2;
+    }
+    return 0;
+}

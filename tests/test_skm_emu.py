@@ -67,3 +67,7 @@ def test_tiled_cutter_matches_serial_walk(golden, emu, name, m127):
             n = emu.emu_tile_check(packed.ctypes.data, codes.shape[0], codes.shape[1], K, int(m127), 9, S, R)
             assert n >= codes.shape[0], (S, R, n)
     assert emu.emu_tile_pick_segment(88, 48) == 11
+
+
+def test_sliced_crc_equals_bytewise(emu):
+    assert emu.emu_crc_check(20000) == 0
