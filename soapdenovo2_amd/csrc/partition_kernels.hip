@@ -724,8 +724,9 @@ static E2Dev dev_view(const pg_ctx* c) {
 
 int e2_create(pg_ctx* c) {
     E2& s = c->e2;
-    // partitions: expected distinct / ~1000 so a partition usually fits the LDS set in one attempt
-    s.log2_parts = std::max(8, std::min(23, c->log2_slots - 11));
+    // partitions: expected distinct / ~1000 so a partition usually fits the LDS set in one attempt; a quarter of that for the
+    // 127-mer flavour (a 1024-slot set, five key words to claim per new k-mer: measured best, profiles/r02_bench_k127.json)
+    s.log2_parts = std::max(8, std::min(23, c->log2_slots - (c->NW == 4 ? 9 : 11)));
     if (c->hint_log2_parts >= 0) s.log2_parts = std::max(8, std::min(23, c->hint_log2_parts));
     if (const char* v = getenv("PG_LOG2_PARTS")) s.log2_parts = std::max(4, std::min(24, atoi(v)));
     s.g = skm_geometry(c->K, s.log2_parts, c->NW);

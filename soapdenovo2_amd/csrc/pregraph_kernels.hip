@@ -500,9 +500,9 @@ extern "C" pg_ctx* pg_create(int device, int K, int mer127, int n_sets, int log2
     return pg_create_engine(device, K, mer127, n_sets, log2_slots, engine);
 }
 
-static int parts_for_kmers(uint64_t total_kmers) {
+static int parts_for_kmers(uint64_t total_kmers, int nw) {
     int lp = 8;
-    while (lp < 23 && ((uint64_t)8192 << lp) < total_kmers) lp++;
+    while (lp < 23 && ((uint64_t)(nw == 4 ? 2048 : 8192) << lp) < total_kmers) lp++;      // the 127-mer LDS set holds half as many keys, and likes them sparse
     return lp;
 }
 extern "C" pg_ctx* pg_create_sized(int device, int K, int mer127, int n_sets, int log2_slots, int engine, uint64_t expected_kmers);
@@ -524,7 +524,7 @@ extern "C" pg_ctx* pg_create_sized(int device, int K, int mer127, int n_sets, in
     c->ub_distinct = 0; c->finalized = false; c->autogrow = true; c->slots = nullptr; c->ctr = nullptr;
     c->variant = 1;
     c->engine = engine;
-    if (expected_kmers) { c->hint_kmers = expected_kmers; c->hint_log2_parts = parts_for_kmers(expected_kmers); }
+    if (expected_kmers) { c->hint_kmers = expected_kmers; c->hint_log2_parts = parts_for_kmers(expected_kmers, c->NW); }
     if (const char* v = getenv("PG_VARIANT")) c->variant = atoi(v);
     if (engine == 2) {
         if (hipMalloc(&c->ctr, sizeof(DevCounters)) != hipSuccess) { g_err = "pg_create: hipMalloc failed"; delete c; return nullptr; }
@@ -549,7 +549,7 @@ extern "C" int pg_expect_kmers(pg_ctx* c, uint64_t total_kmers) {
     if (!c) { g_err = "null context"; return PG_EINVAL; }
     if (c->engine != 2) return PG_OK;
     if (c->batches) { g_err = "pg_expect_kmers: batches were already counted"; return PG_ESTATE; }
-    const int lp = parts_for_kmers(total_kmers);
+    const int lp = parts_for_kmers(total_kmers, c->NW);
     if (lp == c->e2.log2_parts) return PG_OK;
     HIP_TRY(hipSetDevice(c->device));
     const int old = c->hint_log2_parts;
