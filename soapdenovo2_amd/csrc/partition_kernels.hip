@@ -142,7 +142,7 @@ __device__ __forceinline__ uint32_t fastdiv1(uint32_t i, uint32_t d, uint32_t in
 //   D     thread = the same segment: one LDS atomic reserves its items, every start bit finds the next start
 //   E     one lane per run: slot in the partition's stream (or the owner's send region), record from the dword string
 // Lanes of a wave take different reads (read index fastest), so the row stride -- forced odd -- is the bank stride.
-struct SegArg { int R, np, npad, wsd, nseg, nca; uint32_t inv_R, inv_wpr; };
+struct SegArg { int R, np, npad, wsd, nseg, nca; uint32_t inv_R, inv_wpr; int dbg; };   // dbg (PG_K1DBG, measurement aid): 1 = no record stores, 2 = no slot reservation either
 
 template <int NW, bool ROUTE, int S>
 __global__ __launch_bounds__(BLOCK) void skm_scatter_seg_kernel(ReadsArg a, E2Dev e, DevCounters* ctr, SegArg sa, RouteArg ro) {
@@ -222,6 +222,11 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_seg_kernel(ReadsArg a, E2De
         const int r = (int)(pk >> 24), j0 = (int)((pk >> 12) & 0xFFF), n = (int)(pk & 0xFFF);
         const uint32_t pid = pids[r * kpr + j0];
         uint64_t* out;
+        uint32_t q = 0;
+        // the returned atomic on the partition's cursor is asked first and looked at after the record is built
+        if (!ROUTE && !(sa.dbg & 2)) q = atomicAdd(&e.cursor[pid], 1u);
+        uint64_t rec[RW];
+        tile_make_record<PW>(dw + r * wsd, len, j0, n, a.ord_base + (r0 + (uint64_t)r) * (uint64_t)kpr, e.g.K, rec);
         if (ROUTE) {
             const uint32_t o = pid % (uint32_t)ro.n_owners;
             const unsigned long long at = obase[o] + ranks[it];
@@ -229,12 +234,11 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_seg_kernel(ReadsArg a, E2De
             ro.pids[(uint64_t)o * ro.cap + at] = pid;
             out = ro.recs + ((uint64_t)o * ro.cap + at) * RW;
         } else {
-            const uint32_t q = atomicAdd(&e.cursor[pid], 1u);
+            if (sa.dbg & 2) { if (pid == 0xFFFFFFFFu || rec[0] == 0x1234567) atomicOr(&ctr->e2_flags, F_POOL); continue; }
             out = record_slot(e, pid, q, ctr, RW);
         }
         if (!out) continue;
-        uint64_t rec[RW];
-        tile_make_record<PW>(dw + r * wsd, len, j0, n, a.ord_base + (r0 + (uint64_t)r) * (uint64_t)kpr, e.g.K, rec);
+        if (sa.dbg & 1) { if (rec[0] == 0x1234567 && rec[1] == 77) atomicOr(&ctr->e2_flags, F_POOL); continue; }
         ulonglong2* o2 = (ulonglong2*)out;
 #pragma unroll
         for (int k = 0; k < RW / 2; k++) o2[k] = make_ulonglong2(rec[2 * k], rec[2 * k + 1]);
@@ -353,7 +357,6 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     unsigned int* const noff = fl_raw;                                    // [n_rep + 1] exclusive prefix sum of the representatives' k-mer counts
     unsigned short* const first_rec = (unsigned short*)(fl_raw + WIN + 1);   // [THREADS] representative in which lane l's share starts
     __shared__ unsigned int dcount[WIN];                                  // copies of a representative record in the window
-    __shared__ unsigned short repidx[WIN];                                // representatives, in window order
     __shared__ uint32_t crc_tab[4 * 256];                                 // CRC-32 sliced by four (kmer.hpp)
     __shared__ unsigned int hist[256];
     constexpr int STRIPES = (SLOTS + THREADS - 1) / THREADS;
@@ -469,7 +472,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 // flatten: occurrence idx -> (representative, t); every lane gets `share` consecutive occurrences
                 uint32_t total_occ, share;
                 {
-                    const unsigned int n = is_rep ? ((rl[PAD + threadIdx.x * RD] >> 2) & 0xFFFFu) : 0u;
+                    const unsigned int n = is_rep ? ((rl[PAD + threadIdx.x * RD] >> 2) & 0x7Fu) : 0u;
                     unsigned int incl = n | (is_rep ? 1u << 20 : 0u);         // k-mers below bit 20, representatives above
 #pragma unroll
                     for (int d = 1; d < 64; d <<= 1) { const unsigned int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
@@ -482,11 +485,25 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     tot &= (1u << 20) - 1;
                     total_occ = tot;
                     share = (tot + THREADS - 1) / THREADS;
+                    // Representatives move to the front of the window (rank k -> record slot k: k <= its old place, everybody has
+                    // read before anybody writes), with the copy count in the idle bits of the LDS header (a record has at most
+                    // 96 k-mers, the count field is 16 bits wide): the occurrence loop then finds offsets, header and count of
+                    // rank k in one round trip.
+                    uint32_t mine[RD];
+                    if (is_rep) {
+                        const uint32_t* me = rl + PAD + threadIdx.x * RD;
+#pragma unroll
+                        for (int q = 0; q < RD; q++) mine[q] = me[q];
+                        mine[0] = (mine[0] & ~0x3FE00u) | ((dcount[threadIdx.x] - 1u) << 9);   // n < 128 keeps bits 2..8, copies - 1 <= 511
+                    }
+                    __syncthreads();
                     if (is_rep) {
                         const unsigned int upto = base + incl, k = (upto >> 20) - 1;            // this representative's rank
                         const unsigned int o_hi = upto & ((1u << 20) - 1), o_lo = o_hi - n;
                         noff[k] = o_lo;
-                        repidx[k] = (unsigned short)threadIdx.x;
+                        uint32_t* to = rl + PAD + k * RD;
+#pragma unroll
+                        for (int q = 0; q < RD; q++) to[q] = mine[q];
                         // lanes whose share starts inside this record: l * share in [o_lo, o_hi)
                         const float inv = 1.0f / (float)share;
                         auto div_up = [&](unsigned int x) {                        // ceil(x / share), x < 2^16
@@ -512,12 +529,11 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                             k += idx >= o_hi ? 1u : 0u;
                             const uint32_t o_lo = noff[k];
                             o_hi = noff[k + 1];
-                            const uint32_t r = repidx[k];
-                            const uint32_t* rec = rl + PAD + r * RD;
+                            const uint32_t* rec = rl + PAD + k * RD;
                             const uint32_t h_lo = rec[0], h_hi = rec[1];
-                            const uint32_t copies = dcount[r];
+                            const uint32_t copies = ((h_lo >> 9) & 0x1FFu) + 1u;
                             const uint32_t t = idx - o_lo;
-                            const uint32_t hl = (h_lo >> 1) & 1u, hr = h_lo & 1u, n = (h_lo >> 2) & 0xFFFFu;
+                            const uint32_t hl = (h_lo >> 1) & 1u, hr = h_lo & 1u, n = (h_lo >> 2) & 0x7Fu;
                             uint32_t f[N2], rc[N2], prev, next;
                             occ_extract<NW>(rec + 2, (int)(hl + t), K, oc, f, rc, prev, next);
                             const bool lt = occ_less<N2>(f, rc);
@@ -569,9 +585,9 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
 #pragma unroll
             for (int st = 0; st < STRIPES; st++) {
                 const int si = st * THREADS + threadIdx.x;
-                unsigned int puts = 0;
-                if (si < SLOTS) puts = set.cnt[0][si] + set.cnt[1][si] + set.cnt[2][si] + set.cnt[3][si] + set.cnt[8][si];
-                live[st] = puts != 0;                                     // a put is only counted once every key word is claimed
+                // every put of this attempt is complete (barrier), so a slot whose first key word is taken holds a whole key
+                // and at least one put
+                live[st] = si < SLOTS && set.key[0][si] != L_EMPTY;
                 bal[st] = __ballot(live[st]);
                 if (lane == 0) wave_cnt[st][wave] = (unsigned int)__popcll(bal[st]);
             }
@@ -850,7 +866,9 @@ static int launch_tiled(pg_ctx* c, const ReadsArg& a, const RouteArg* route, hip
     const uint64_t grid = (a.n_reads + R - 1) / R;
     if (grid > 0x7FFFFFFFULL) { pg_set_error("batch too large for one launch"); return PG_EINVAL; }
     auto inv = [](uint32_t d) { return (uint32_t)(((1ULL << 32) + d - 1) / d); };
-    SegArg sa{R, np, npad, wsd, nseg, nca, inv((uint32_t)R), inv(a.wpr)};
+    int k1dbg = 0;
+    if (const char* v = getenv("PG_K1DBG")) k1dbg = atoi(v);
+    SegArg sa{R, np, npad, wsd, nseg, nca, inv((uint32_t)R), inv(a.wpr), k1dbg};
     RouteArg ro{nullptr, nullptr, nullptr, 0, 1};
     if (route) ro = *route;
     const size_t smem = per_read * R;

