@@ -198,8 +198,38 @@ struct HSet {
     float lf = 0.77f;
 
     // home slot (modular, newhash.c:36-57): exact 128-bit modulus for NW = 2; the 127-mer build reduces the
-    // key in 32-bit chunks, which is a true modulus only while size < 2^32 -- restated as is
+    // key in 32-bit chunks, which is a true modulus only while size < 2^32 -- restated as is.
+    // While size < 2^32 (always, short of ~3 G keys a set) every reduction is a Barrett step with the reciprocal kept
+    // beside the size: a multiply-high, a multiply and two corrections instead of a division.  In the in-place rehash the
+    // home of a kicked element sits on the critical path in front of a cache miss, and a 128-by-64 division has ~4x the
+    // latency of this.
+    uint64_t bar_m = 0, bar_c64 = 0;                               // floor(2^64 / size), 2^64 mod size
+    void set_size(uint64_t sz) {
+        size = sz;
+        bar_m = sz > 1 ? (uint64_t)((((unsigned __int128)1) << 64) / sz) : 0;
+        bar_c64 = sz > 1 ? (uint64_t)((((unsigned __int128)1) << 64) % sz) : 0;
+    }
+    uint64_t bred(uint64_t x) const {                              // x mod size, size < 2^32
+        const uint64_t q = (uint64_t)(((unsigned __int128)x * bar_m) >> 64);
+        uint64_t r = x - q * size;
+        if (r >= size) r -= size;
+        if (r >= size) r -= size;
+        return r;
+    }
     uint64_t home(const Kmer<NW>& k) const {
+        if (size > 1 && size < (1ULL << 32)) {
+            if (NW == 2) {                                            // (hi mod p) * (2^64 mod p) + (lo mod p), all below 2^64
+                uint64_t r = bred(bred(k.w[0]) * bar_c64) + bred(k.w[1]);
+                if (r >= size) r -= size;
+                return r;
+            }
+            uint64_t t = bred(k.w[0]);
+            for (int i = 1; i < NW; i++) {
+                t = bred(t << 32 | (k.w[i] >> 32));
+                t = bred(t << 32 | (k.w[i] & 0xffffffffULL));
+            }
+            return t;
+        }
         if (NW == 2) {
 #if defined(__x86_64__)
             // (hi * 2^64 + lo) % size as two 64-bit divisions (the generic 128-bit modulus is a slow library call)
@@ -236,7 +266,7 @@ struct HSet {
     }
     // `capacity` slots are reserved up front (untouched pages cost nothing) so that growing never has to move the array
     void init(uint64_t sz, uint64_t capacity = 0) {
-        size = sz; count = 0; lf = 0.77f;
+        set_size(sz); count = 0; lf = 0.77f;
         max = (uint64_t)((float)size * lf);
         array.reset(std::max(size, capacity));
         for (uint64_t i = 0; i < size; i++) array[i].seq.w[0] = EMPTY;
@@ -262,7 +292,7 @@ struct HSet {
         enum : uint8_t { FREE = 0, PENDING = 1, PLACED = 2 };
         std::vector<uint8_t> st(n, FREE);
         for (uint64_t i = 0; i < old; i++) st[i] = occ[i] ? PENDING : FREE;
-        size = n;
+        set_size(n);
         max = (uint64_t)((float)n * lf);
         constexpr uint64_t AHEAD = 24;
         uint64_t ring[AHEAD];
