@@ -268,6 +268,9 @@ int pg_host_last_put_matters(const uint64_t *set_counts, int n_sets, int a_gb, i
 /* Partition engine: the export array itself instead of a copy of it (the caller owns *d_records_out and frees it with
  * hipFree); everything else the context holds on the device is released, the context can only be destroyed afterwards. */
 int pg_export_take(pg_ctx *ctx, uint64_t **d_records_out, uint64_t *n_out);
+/* The same, with the record pool handed over too (*d_workspace_out, hipFree it when done): scratch memory for
+ * pg_sort_records_ws, so that the hand-over needs no large allocation (hipMalloc right after a big hipFree takes seconds). */
+int pg_export_take_ws(pg_ctx *ctx, uint64_t **d_records_out, uint64_t *n_out, void **d_workspace_out, uint64_t *workspace_bytes_out);
 void pg_device_free(void *d_ptr);   /* hipFree, for callers that do not link the HIP runtime */
 
 /* Order exported records (device memory, on the current device) by their last word, i.e. by k-mer set and then by
@@ -277,6 +280,9 @@ void pg_device_free(void *d_ptr);   /* hipFree, for callers that do not link the
  * permutation kept as 64-bit indices beyond 2^32 - 1 records (PG_SORT_WIDE=1 forces that flavour); needs about 2.5x the
  * records' bytes of free device memory.  Synchronises. */
 int pg_sort_records(uint64_t *d_records, uint64_t n_records, int mer127, void *stream);
+/* The same on caller-provided scratch memory (used when it holds the keys, indices and the permuted copy: about 2.5x the
+ * records' bytes; otherwise the call allocates what is missing). */
+int pg_sort_records_ws(uint64_t *d_records, uint64_t n_records, int mer127, void *d_workspace, uint64_t workspace_bytes, void *stream);
 
 /* ------------------------------------------------------------------------------------------------
  * 4. Multi-GPU pass 1.  The reference hands every k-mer to the set it hashes to through shared memory

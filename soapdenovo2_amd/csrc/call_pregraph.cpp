@@ -724,20 +724,22 @@ int run(int argc, char** argv, bool mer127) {
     bool stream_records = n_distinct > 0;
     if (const char* e = getenv("SOAPDENOVO2_AMD_STREAM_RECORDS")) stream_records = stream_records && atoi(e) != 0;
     std::vector<uint64_t> per_set(o.sets, 0);
+    void* d_ws = nullptr;
+    uint64_t ws_bytes = 0;
     if (n_distinct) {
         if (ctx) {
             // the partition engine hands its export array over as it is and frees its streams (no second copy in HBM);
             // the global-set engine compacts its table into a fresh array
             uint64_t got = 0;
-            if (engine_used == 2) { if (pg_export_take(ctx, &d_rec, &got) != PG_OK) die("pg_export_take"); }
+            if (engine_used == 2) { if (pg_export_take_ws(ctx, &d_rec, &got, &d_ws, &ws_bytes) != PG_OK) die("pg_export_take"); }
             else {
                 HIP_OK(hipMalloc((void**)&d_rec, (size_t)n_distinct * rw * sizeof(uint64_t)));
                 if (pg_export(ctx, d_rec, n_distinct, &got, nullptr) != PG_OK) die("pg_export");
             }
             if (got != n_distinct) { fprintf(stderr, "export count mismatch\n"); exit(-1); }
         }
-        // replay order (set, first occurrence) on the device
-        if (pg_sort_records(d_rec, n_distinct, mer127 ? 1 : 0, nullptr) != PG_OK) die("pg_sort_records");
+        // replay order (set, first occurrence) on the device, in the memory pass 1 is done with
+        if (pg_sort_records_ws(d_rec, n_distinct, mer127 ? 1 : 0, d_ws, ws_bytes, nullptr) != PG_OK) die("pg_sort_records");
         if (stream_records) {
             // where every set starts: binary search over the sorted tags (a few hundred 8-byte copies)
             auto set_of_record = [&](uint64_t i) { uint64_t tag = 0; HIP_OK(hipMemcpy(&tag, d_rec + i * rw + rw - 1, sizeof tag, hipMemcpyDeviceToHost)); return tag >> 56; };
@@ -757,6 +759,7 @@ int run(int argc, char** argv, bool mer127) {
         }
     }
     if (ctx) pg_destroy(ctx);
+    if (d_ws) { (void)hipFree(d_ws); d_ws = nullptr; }            // the graph stages want the room
     lap("export + download records");
 
     // ---- tips + edges (removeSingleTips / removeMinorTips / kmer2edges), graph kept for pass 2

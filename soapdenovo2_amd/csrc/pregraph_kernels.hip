@@ -890,7 +890,7 @@ extern "C" int pg_last_put(pg_ctx* c, uint64_t* set_last_put_out, void* stream) 
 // Partition engine only: hand the export array itself over (no copy) and let go of everything else the context holds on
 // the device -- the record pool, the chunk table, the cursors.  The caller owns *d_records_out (hipFree) from here on; the
 // context can only be destroyed afterwards.  Halves the device memory needed at the hand-over to the graph stages.
-extern "C" int pg_export_take(pg_ctx* c, uint64_t** d_records_out, uint64_t* n_out) {
+extern "C" int pg_export_take_ws(pg_ctx* c, uint64_t** d_records_out, uint64_t* n_out, void** d_workspace_out, uint64_t* workspace_bytes_out) {
     if (!c || !d_records_out || !n_out) { g_err = "null argument"; return PG_EINVAL; }
     if (c->engine != 2) { g_err = "pg_export_take needs the partition engine"; return PG_ESTATE; }
     if (!c->e2.counted) { g_err = "pg_export_take: call pg_finalize first"; return PG_ESTATE; }
@@ -901,10 +901,16 @@ extern "C" int pg_export_take(pg_ctx* c, uint64_t** d_records_out, uint64_t* n_o
     *n_out = n;
     c->e2.out = nullptr;
     c->e2.out_capacity = 0;
+    if (d_workspace_out && workspace_bytes_out) {           // the record pool changes hands as well, as scratch memory
+        *d_workspace_out = c->e2.pool;
+        *workspace_bytes_out = c->e2.pool_chunks * (uint64_t)c->e2.rpc * (uint64_t)c->e2.g.rw * 8;
+        c->e2.pool = nullptr;
+    }
     e2_destroy(c);                                       // frees what is left (pool, tables); the context is spent
     c->e2.counted = false;
     return PG_OK;
 }
+extern "C" int pg_export_take(pg_ctx* c, uint64_t** d_records_out, uint64_t* n_out) { return pg_export_take_ws(c, d_records_out, n_out, nullptr, nullptr); }
 
 // hipFree for callers that do not link the HIP runtime themselves (what pg_export_take hands over)
 extern "C" void pg_device_free(void* d_ptr) { if (d_ptr) (void)hipFree(d_ptr); }

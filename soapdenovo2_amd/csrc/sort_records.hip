@@ -56,7 +56,7 @@ __global__ void sr_gather(const uint64_t* __restrict__ rec, const Idx* __restric
     } while (0)
 
 template <int RW, typename Idx>
-static int sort_impl(uint64_t* d_records, uint64_t n, hipStream_t stream) {
+static int sort_impl(uint64_t* d_records, uint64_t n, void* d_ws, size_t ws_bytes, hipStream_t stream) {
     int rc = PG_OK;
     const bool verbose = getenv("PG_SORT_VERBOSE") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
@@ -69,6 +69,8 @@ static int sort_impl(uint64_t* d_records, uint64_t n, hipStream_t stream) {
     unsigned long long h_max = 0;
     size_t tmp_bytes = 0;
     int ord_bits = 1;
+    bool own_work = true, own_sorted = true;
+    size_t work_bytes = 0, sorted_bytes = 0;
     const size_t a16 = 255;
     const size_t key_bytes = (n * sizeof(uint64_t) + a16) & ~a16, idx_bytes = (n * sizeof(Idx) + a16) & ~a16;
     uint64_t *tag_in, *tag_out;
@@ -81,7 +83,14 @@ static int sort_impl(uint64_t* d_records, uint64_t n, hipStream_t stream) {
     while (ord_bits < 56 && (h_max >> ord_bits)) ord_bits++;
     SR_HIP((rocprim::radix_sort_pairs<rocprim::default_config, uint64_t*, uint64_t*, Idx*, Idx*, size_t>(
         nullptr, tmp_bytes, nullptr, nullptr, nullptr, nullptr, (size_t)n, 0u, (unsigned)(ord_bits + 8), stream)));
-    SR_HIP(hipMalloc((void**)&work, 2 * key_bytes + 2 * idx_bytes + tmp_bytes + 256));
+    // the caller's workspace (call_pregraph hands over the record pool pass 1 is done with) saves two large hipMalloc /
+    // hipFree pairs, which take seconds right after a big hipFree
+    work_bytes = (2 * key_bytes + 2 * idx_bytes + tmp_bytes + 511) & ~(size_t)255;
+    sorted_bytes = n * RW * sizeof(uint64_t);
+    own_work = !d_ws || ws_bytes < work_bytes + 256;
+    own_sorted = own_work || ws_bytes < work_bytes + sorted_bytes + 512;
+    if (own_work) SR_HIP(hipMalloc((void**)&work, work_bytes));
+    else work = (unsigned char*)(((uintptr_t)d_ws + 255) & ~(uintptr_t)255);
     tag_in = (uint64_t*)work; tag_out = (uint64_t*)(work + key_bytes);
     idx_in = (Idx*)(work + 2 * key_bytes); idx_out = (Idx*)(work + 2 * key_bytes + idx_bytes);
     lap("max ordinal + work allocation");
@@ -90,21 +99,24 @@ static int sort_impl(uint64_t* d_records, uint64_t n, hipStream_t stream) {
     SR_HIP((rocprim::radix_sort_pairs<rocprim::default_config, uint64_t*, uint64_t*, Idx*, Idx*, size_t>(
         work + 2 * key_bytes + 2 * idx_bytes, tmp_bytes, tag_in, tag_out, idx_in, idx_out, (size_t)n, 0u, (unsigned)(ord_bits + 8), stream)));
     lap("radix sort of the tags");
-    SR_HIP(hipMalloc((void**)&sorted, n * RW * sizeof(uint64_t)));
+    if (own_sorted) SR_HIP(hipMalloc((void**)&sorted, sorted_bytes));
+    else sorted = (uint64_t*)(work + work_bytes);
     hipLaunchKernelGGL((sr_gather<RW, Idx>), dim3(8192), dim3(256), 0, stream, d_records, idx_out, n, sorted);
     SR_HIP(hipGetLastError());
     SR_HIP(hipMemcpyAsync(d_records, sorted, n * RW * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream));
     SR_HIP(hipStreamSynchronize(stream));
     lap("gather + copy back");
 done:
-    (void)hipFree(work); (void)hipFree(sorted); (void)hipFree(d_max);
+    if (own_work) (void)hipFree(work);
+    if (own_sorted) (void)hipFree(sorted);
+    (void)hipFree(d_max);
     lap("free");
     return rc;
 }
 
 }  // namespace pg
 
-extern "C" int pg_sort_records(uint64_t* d_records, uint64_t n, int mer127, void* stream_v) {
+extern "C" int pg_sort_records_ws(uint64_t* d_records, uint64_t n, int mer127, void* d_workspace, uint64_t workspace_bytes, void* stream_v) {
     using namespace pg;
     if (!n) return PG_OK;
     if (!d_records) { pg_set_error("pg_sort_records: null records"); return PG_EINVAL; }
@@ -112,6 +124,10 @@ extern "C" int pg_sort_records(uint64_t* d_records, uint64_t n, int mer127, void
     // 32-bit record indices while they suffice; PG_SORT_WIDE=1 forces the 64-bit flavour (tests)
     bool wide = n > 0xFFFFFFFFULL;
     if (const char* e = getenv("PG_SORT_WIDE")) wide = wide || atoi(e) != 0;
-    if (mer127) return wide ? sort_impl<6, uint64_t>(d_records, n, stream) : sort_impl<6, uint32_t>(d_records, n, stream);
-    return wide ? sort_impl<4, uint64_t>(d_records, n, stream) : sort_impl<4, uint32_t>(d_records, n, stream);
+    if (mer127) return wide ? sort_impl<6, uint64_t>(d_records, n, d_workspace, workspace_bytes, stream) : sort_impl<6, uint32_t>(d_records, n, d_workspace, workspace_bytes, stream);
+    return wide ? sort_impl<4, uint64_t>(d_records, n, d_workspace, workspace_bytes, stream) : sort_impl<4, uint32_t>(d_records, n, d_workspace, workspace_bytes, stream);
+}
+
+extern "C" int pg_sort_records(uint64_t* d_records, uint64_t n, int mer127, void* stream_v) {
+    return pg_sort_records_ws(d_records, n, mer127, nullptr, 0, stream_v);
 }
