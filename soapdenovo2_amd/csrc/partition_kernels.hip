@@ -372,11 +372,14 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long my_records = 0;
     bool dirty = true;                                                   // the LDS set needs a full wipe before the next attempt
-    unsigned long long tp[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
+    unsigned long long tp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
 #define K2_TICK(i) do { if (dbg & 2) { const unsigned long long tn_ = clock64(); tp[i] += tn_ - tlast; tlast = tn_; } } while (0)
     uint32_t pf_nrec = 0, pf_cid = 0;
+    // (the record count is the same for every lane, which would make it a scalar load -- and scalar loads are waited for at
+    //  the very next barrier together with the LDS traffic (lgkmcnt); through a vector register it stays in flight until used)
+    auto peek_cursor = [&](uint32_t p) { const uint32_t* q = e.cursor + p; asm volatile("" : "+v"(q)); return *q; };
     if (blockIdx.x < parts) {
-        pf_nrec = e.cursor[blockIdx.x];
+        pf_nrec = peek_cursor(blockIdx.x);
         if (threadIdx.x < e.maxc) pf_cid = e.chunk_tbl[(uint64_t)blockIdx.x * e.maxc + threadIdx.x];
     }
     for (uint32_t pid = blockIdx.x; pid < parts; pid += gridDim.x) {
@@ -384,7 +387,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
         {
             const uint32_t nxt = pid + gridDim.x;
             if (nxt < parts) {
-                pf_nrec = e.cursor[nxt];
+                pf_nrec = peek_cursor(nxt);
                 if (threadIdx.x < e.maxc) pf_cid = e.chunk_tbl[(uint64_t)nxt * e.maxc + threadIdx.x];
             }
         }
@@ -468,6 +471,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                         sl = (sl + 1) & (DT - 1);
                     }
                 }
+                K2_TICK(10);
                 __syncthreads();                                                  // dtab is dead from here, counts and minima are final
                 // flatten: occurrence idx -> (representative, t); every lane gets `share` consecutive occurrences
                 uint32_t total_occ, share;
@@ -663,6 +667,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     o[NW + 1] = ((uint64_t)sid << PG_ORD_BITS) | (first & PG_ORD_MASK);
                 }
                 if (threadIdx.x == 0 && c0 == 0) out_base = ticket;
+                K2_TICK(11);
                 __syncthreads();
                 const unsigned long long ob = out_base + c0;
                 if (ob + cn <= e.out_capacity) {
@@ -678,7 +683,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     __syncthreads();
     for (int i = threadIdx.x; i < 256; i += THREADS) if (hist[i]) atomicAdd(&ctr->hist[i], (unsigned long long)hist[i]);
     if (threadIdx.x == 0 && my_records) atomicAdd(&ctr->n_records, my_records);
-    if ((dbg & 2) && threadIdx.x == 0) for (int i = 0; i < 10; i++) atomicAdd(&ctr->phase[i], tp[i]);
+    if ((dbg & 2) && threadIdx.x == 0) for (int i = 0; i < 12; i++) atomicAdd(&ctr->phase[i], tp[i]);
 #undef K2_TICK
 }
 
@@ -1067,11 +1072,12 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     if (h.e2_flags & F_OUT) { pg_set_error("partition engine: more distinct k-mers than the export array holds (raise log2_slots)"); return PG_ENOMEM; }
     if (h.e2_flags & F_SPLIT) { pg_set_error("partition engine: a partition could not be split to fit the LDS set"); return PG_ENOMEM; }
     if (dbg & 2) {
-        static const char* names[10] = {"meta+sync", "clear", "stage", "flatten", "occurrences (own share)", "wait for the slowest lane",
-                                        "emit: count+atomic+finalise", "emit: wait for the atomic", "emit: writes", "dropped attempts"};
+        static const char* names[12] = {"meta+sync", "clear (after a dropped attempt) + barrier", "stage", "barrier + flatten + compaction", "occurrences (own share)",
+                                        "wait for the slowest lane", "emit: list the live slots", "emit: barrier", "emit: barrier + coalesced copy out", "dropped attempts",
+                                        "dedupe (hash, probe, compare)", "emit: finalise into the staging area"};
         unsigned long long tot = 0;
-        for (int i = 0; i < 9; i++) tot += h.phase[i];
-        for (int i = 0; i < 10; i++) fprintf(stderr, "K2 phase %-32s %14llu  %5.1f%%\n", names[i], h.phase[i], i < 9 ? 100.0 * h.phase[i] / (double)(tot ? tot : 1) : 0.0);
+        for (int i = 0; i < 12; i++) if (i != 9) tot += h.phase[i];
+        for (int i = 0; i < 12; i++) fprintf(stderr, "K2 phase %-40s %14llu  %5.1f%%\n", names[i], h.phase[i], i != 9 ? 100.0 * h.phase[i] / (double)(tot ? tot : 1) : 0.0);
     }
     s.counted = true;
     return PG_OK;
