@@ -152,8 +152,9 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_seg_kernel(ReadsArg a, E2De
     const int wpr = (int)a.wpr, kpr = (int)a.kpr, len = (int)a.uniform_len;
     uint32_t* dw = (uint32_t*)smem_raw;                           // R * wsd   dword strings
     uint32_t* v0 = dw + (size_t)R * wsd;                          // R * npad  m-mer values; the item list after B
-    uint32_t* pids = v0 + (size_t)R * npad;                       // R * kpr
-    uint32_t* smask = pids + (size_t)R * kpr;                     // R * nseg  run-start bits
+    const int kpad = nseg * S;                                    // partition ids: whole segments, so a segment stores all S of its ids
+    uint32_t* pids = v0 + (size_t)R * npad;                       // R * kpad
+    uint32_t* smask = pids + (size_t)R * kpad;                    // R * nseg  run-start bits
     uint32_t* ranks = smask + (size_t)R * nseg;                   // R * kpr   (ROUTE only)
     uint32_t* items = v0;
     __shared__ unsigned int n_items;
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_seg_kernel(ReadsArg a, E2De
     // tasks are numbered over the full tile (read index fastest), a short last tile just leaves lanes idle
     for (int t = threadIdx.x; t < R * nca; t += BLOCK) {
         const int c = (int)fastdiv1(t, R, sa.inv_R), r = t - c * R;
-        if (r < nr) tile_mmer_chunk(dw + r * wsd, c, np, m, v0 + r * npad);
+        if (r < nr) tile_mmer_chunk(dw + r * wsd, c, m, v0 + r * npad);
     }
     __syncthreads();
     for (int t = threadIdx.x; t < R * nseg; t += BLOCK) {
@@ -180,10 +181,10 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_seg_kernel(ReadsArg a, E2De
         if (r >= nr) continue;
         const int j0 = seg * S, cnt = min(S, kpr - j0);
         uint32_t pid[S];
-        const uint32_t mk = tile_segment<S>(v0 + r * npad, j0, cnt, w, e.g.nmax, e.g.log2_parts, pid);
+        const uint32_t mk = tile_segment<S>(v0 + r * npad, np, j0, cnt, w, e.g.nmax, e.g.log2_parts, pid);
         smask[r * nseg + seg] = mk;
 #pragma unroll
-        for (int i = 0; i < S; i++) if (i < cnt) pids[r * kpr + j0 + i] = pid[i];
+        for (int i = 0; i < S; i++) pids[r * kpad + j0 + i] = pid[i];
     }
     __syncthreads();                                              // v0 is dead from here: the item list takes its place
     for (int t = threadIdx.x; t < R * nseg; t += BLOCK) {
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_seg_kernel(ReadsArg a, E2De
         __syncthreads();
         for (int it = threadIdx.x; it < total; it += BLOCK) {
             const uint32_t pk = items[it];
-            const uint32_t pid = pids[(int)(pk >> 24) * kpr + (int)((pk >> 12) & 0xFFF)];
+            const uint32_t pid = pids[(int)(pk >> 24) * kpad + (int)((pk >> 12) & 0xFFF)];
             ranks[it] = atomicAdd(&ocnt[pid % (uint32_t)ro.n_owners], 1u);
         }
         __syncthreads();
@@ -220,7 +221,7 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_seg_kernel(ReadsArg a, E2De
     for (int it = threadIdx.x; it < total; it += BLOCK) {
         const uint32_t pk = items[it];
         const int r = (int)(pk >> 24), j0 = (int)((pk >> 12) & 0xFFF), n = (int)(pk & 0xFFF);
-        const uint32_t pid = pids[r * kpr + j0];
+        const uint32_t pid = pids[r * kpad + j0];
         uint64_t* out;
         uint32_t q = 0;
         // the returned atomic on the partition's cursor is asked first and looked at after the record is built
@@ -862,8 +863,8 @@ static int launch_tiled(pg_ctx* c, const ReadsArg& a, const RouteArg* route, hip
     const int kpr = (int)a.kpr, wpr = (int)a.wpr, np = (int)a.uniform_len - g.m + 1;
     int S = tile_pick_segment(kpr, g.w);
     if (const char* v = getenv("PG_K1_S")) { const int q = atoi(v); if (q >= 7 && q <= 15 && (q & 1) && (q <= g.w || q == 7)) S = q; }
-    const int nseg = (kpr + S - 1) / S, nca = (np + 15) / 16, npad = np | 1, wsd = (2 * wpr + 3) | 1;
-    const size_t per_read = (size_t)(wsd + npad + kpr + nseg + (route ? kpr : 0)) * 4;
+    const int nseg = (kpr + S - 1) / S, nca = (np + 15) / 16, npad = (16 * nca) | 1, wsd = (2 * wpr + 3) | 1;   // value rows: whole 16-position chunks, odd stride
+    const size_t per_read = (size_t)(wsd + npad + nseg * S + nseg + (route ? kpr : 0)) * 4;
     int R = std::min<int>(128, std::max(1, BLOCK / nseg));                     // one pass of phase B per tile
     R = (int)std::min<size_t>((size_t)R, (60 * 1024) / per_read);
     if (const char* v = getenv("PG_K1_R")) R = std::max(1, std::min(atoi(v), (int)std::min<size_t>(128, (60 * 1024) / per_read)));

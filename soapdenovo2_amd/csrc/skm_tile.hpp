@@ -36,61 +36,66 @@ PG_HD uint32_t mmer_from_window(uint32_t x, int m) {
     return mmer_hash(fwd < rc ? fwd : rc);
 }
 
-// A: m-mer values at positions 16 c .. 16 c + 15 (those below np) of one read; row = its dword string, out = its value row
-PG_HD void tile_mmer_chunk(const uint32_t* row, int c, int np, int m, uint32_t* out) {
+// A: m-mer values at positions 16 c .. 16 c + 15 of one read; row = its dword string (two readable dwords behind it),
+// out = its value row, which has room for 16 * ceil(np / 16) values: positions >= np get junk nobody reads, and the
+// sixteen stores need no bound test.
+PG_HD void tile_mmer_chunk(const uint32_t* row, int c, int m, uint32_t* out) {
     const uint32_t d0 = row[c], d1 = row[c + 1];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        const int p = 16 * c + i;
         const uint32_t x = i ? alignbit32(d0, d1, (uint32_t)(32 - 2 * i)) : d0;
-        if (p < np) out[p] = mmer_from_window(x, m);
+        out[16 * c + i] = mmer_from_window(x, m);
     }
 }
 
-// B: k-mers j0 .. j0 + cnt - 1 of a read (cnt <= S <= w), v = the read's m-mer values, w m-mers a k-mer.
+// B: k-mers j0 .. j0 + cnt - 1 of a read (cnt <= S <= w), v = the read's m-mer values (np of them), w m-mers a k-mer.
 // Returns the run-start bits (bit i = k-mer j0 + i starts a run: first k-mer, partition change, or a multiple of nmax)
-// and the partition ids in pid_out[0 .. cnt).
+// and the partition ids in pid_out[0 .. S) (those at cnt and above are junk).
+// Straight-line on purpose: every load address is clamped into the row instead of being skipped, every "does this window
+// exist" is a select -- a wave runs 64 segments in lockstep, and the branchy form spent more instructions on exec masks
+// than on minima.
 template <int S>
-PG_HD uint32_t tile_segment(const uint32_t* v, int j0, int cnt, int w, int nmax, int log2_parts, uint32_t* pid_out) {
+PG_HD uint32_t tile_segment(const uint32_t* v, int np, int j0, int cnt, int w, int nmax, int log2_parts, uint32_t* pid_out) {
     // window q = k-mer j0 - 1 + q, q = 0 .. cnt: q = 0 is the predecessor of the segment's first k-mer (none when j0 = 0),
     // wanted only for the partition comparison.  All indices below are compile-time, so the arrays stay in registers.
     const int jl = j0 - 1, jh = j0 + cnt - 1;
-    const bool has_pred = j0 > 0;
     uint32_t suf[S + 1], pre[S + 1];
     suf[S] = 0xFFFFFFFFu;                                          // suf[q] = min over positions [jl + q, jh)
 #pragma unroll
     for (int q = S - 1; q >= 0; q--) {
-        const bool in = q < cnt && (q > 0 || has_pred);
-        const uint32_t x = in ? v[jl + q] : 0xFFFFFFFFu;
-        suf[q] = in ? (x < suf[q + 1] ? x : suf[q + 1]) : 0xFFFFFFFFu;
+        const int at = jl + q;
+        const uint32_t x = v[at < 0 ? 0 : at];                     // (at <= jh - 1 < np whenever it counts; S <= w keeps it in the row anyway)
+        const bool in = q < cnt && at >= 0;
+        const uint32_t mn = x < suf[q + 1] ? x : suf[q + 1];
+        suf[q] = in ? mn : 0xFFFFFFFFu;
     }
     uint32_t core = 0xFFFFFFFFu;                                   // positions [jh, jl + w): inside every window (cnt <= S <= w)
     for (int p = jh; p < jl + w; p++) { const uint32_t x = v[p]; core = x < core ? x : core; }
     pre[0] = 0xFFFFFFFFu;                                          // pre[q] = min over positions [jl + w, jl + q + w)
 #pragma unroll
     for (int q = 1; q <= S; q++) {
-        const bool in = q <= cnt;
-        const uint32_t x = in ? v[jl + w + q - 1] : 0xFFFFFFFFu;
-        pre[q] = x < pre[q - 1] ? x : pre[q - 1];
+        const int at = jl + w + q - 1;
+        const uint32_t x = v[at < np ? at : np - 1];
+        const uint32_t xx = q <= cnt ? x : 0xFFFFFFFFu;
+        pre[q] = xx < pre[q - 1] ? xx : pre[q - 1];
     }
     uint32_t mask = 0, prev_pid = 0;
     int next_cut = 0;                                              // first multiple of nmax >= j0
     while (next_cut < j0) next_cut += nmax;
 #pragma unroll
     for (int q = 0; q <= S; q++) {
-        if (q <= cnt) {
-            uint32_t mv = suf[q] < core ? suf[q] : core;
-            mv = pre[q] < mv ? pre[q] : mv;
-            const uint32_t pid = skm_partition(mv, log2_parts);    // (q = 0 without a predecessor: a junk value nobody compares with)
-            if (q >= 1) {
-                const int j = j0 + q - 1;
-                bool start = j == 0 || pid != prev_pid;
-                if (j == next_cut) { start = true; next_cut += nmax; }
-                if (start) mask |= 1u << (q - 1);
-                pid_out[q - 1] = pid;
-            }
-            prev_pid = pid;
+        uint32_t mv = suf[q] < core ? suf[q] : core;
+        mv = pre[q] < mv ? pre[q] : mv;
+        const uint32_t pid = skm_partition(mv, log2_parts);        // (q = 0 without a predecessor, q > cnt: junk nobody uses)
+        if (q >= 1) {
+            const int j = j0 + q - 1;
+            const bool cut = j == next_cut;
+            const bool start = (j == 0 || pid != prev_pid || cut) && q <= cnt;
+            next_cut += cut ? nmax : 0;
+            mask |= start ? 1u << (q - 1) : 0u;
+            pid_out[q - 1] = pid;
         }
+        prev_pid = pid;
     }
     return mask;
 }

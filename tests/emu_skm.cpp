@@ -125,8 +125,8 @@ template <int NW, int S>
 static int64_t tile_check(const uint64_t* packed, int64_t n_reads, int len, int K, int log2_parts, int R) {
     constexpr int PW = NW == 2 ? 5 : 7, RW = PW + 1;
     const SkmGeom g = skm_geometry(K, log2_parts, NW);
-    const int wpr = (len + 31) / 32, kpr = len - K + 1, np = len - g.m + 1, npad = np | 1;
-    const int wsd = (2 * wpr + 3) | 1, nseg = (kpr + S - 1) / S, nca = (np + 15) / 16;
+    const int wpr = (len + 31) / 32, kpr = len - K + 1, np = len - g.m + 1;
+    const int wsd = (2 * wpr + 3) | 1, nseg = (kpr + S - 1) / S, nca = (np + 15) / 16, npad = (16 * nca) | 1;
     if (S > g.w && S != 7) return -100;
     int64_t checked = 0;
     for (int64_t r0 = 0; r0 < n_reads; r0 += R) {
@@ -137,13 +137,13 @@ static int64_t tile_check(const uint64_t* packed, int64_t n_reads, int len, int 
                 const uint64_t wd = packed[(r0 + r) * wpr + k];
                 dw[(size_t)r * wsd + 2 * k] = (uint32_t)(wd >> 32); dw[(size_t)r * wsd + 2 * k + 1] = (uint32_t)wd;
             }
-        for (int t = 0; t < nr * nca; t++) { const int c = t / nr, r = t % nr; tile_mmer_chunk(dw.data() + (size_t)r * wsd, c, np, g.m, v0.data() + (size_t)r * npad); }
+        for (int t = 0; t < nr * nca; t++) { const int c = t / nr, r = t % nr; tile_mmer_chunk(dw.data() + (size_t)r * wsd, c, g.m, v0.data() + (size_t)r * npad); }
         for (int r = 0; r < nr; r++)                                // phase A against the 64-bit formulation
             for (int p = 0; p < np; p++) if (v0[(size_t)r * npad + p] != mmer_value(packed + (r0 + r) * wpr, p, g.m)) return -101;
         for (int t = 0; t < nr * nseg; t++) {
             const int seg = t / nr, r = t % nr, j0 = seg * S, cnt = std::min(S, kpr - j0);
             uint32_t pid[S];
-            masks[(size_t)r * nseg + seg] = tile_segment<S>(v0.data() + (size_t)r * npad, j0, cnt, g.w, g.nmax, log2_parts, pid);
+            masks[(size_t)r * nseg + seg] = tile_segment<S>(v0.data() + (size_t)r * npad, np, j0, cnt, g.w, g.nmax, log2_parts, pid);
             for (int i = 0; i < cnt; i++) pids[(size_t)r * kpr + j0 + i] = pid[i];
         }
         for (int r = 0; r < nr; r++) {
