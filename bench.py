@@ -220,6 +220,10 @@ def main():
     engine = args.engine
     mer127 = args.mer127 or K > 63
     kc = api.KmerCounter(K, n_sets=P, mer127=mer127, log2_slots=log2_slots, device=local, engine=engine)
+    if world > 1 and engine == 2:
+        # the partition count follows the whole job: a partition holds what ALL ranks send to it (every rank must cut with the
+        # same geometry); the export array (log2_slots) follows this rank's share
+        api._check(api.lib().pg_expect_kmers(kc.h, n_kmers * world), "pg_expect_kmers")
     kc.set_autogrow(False)
     wpr = (L + 31) // 32
     batches = [(lo, min(args.batch_reads, n_reads - lo)) for lo in range(0, n_reads, args.batch_reads)]
@@ -345,23 +349,24 @@ def main():
         kc.last_put()
         extras["last_put_kernel_ms"] = (time.perf_counter() - t0) * 1e3          # paid only when needed
         # (a) export + sort: the distinct k-mers in (set, first ordinal) order for the layout replay, as call_pregraph hands
-        # them over: pg_export_take (the export array itself, the record pool is freed) + pg_sort_records.  Last, because the
+        # them over: pg_export_take_ws (the export array itself, and the record pool as scratch) + pg_sort_records_ws.  Last, because the
         # context is spent afterwards.
         import ctypes
         st_snapshot = kc.stats()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        ptr, got = ctypes.c_void_p(0), ctypes.c_uint64(0)
-        api._check(api.lib().pg_export_take(kc.h, ctypes.byref(ptr), ctypes.byref(got)), "pg_export_take")
-        sort_ok = got.value < (1 << 31)
-        if sort_ok and got.value:
-            api._check(api.lib().pg_sort_records(ptr, got.value, int(mer127), kc._stream()), "pg_sort_records")
+        ptr, got, ws, ws_bytes = ctypes.c_void_p(0), ctypes.c_uint64(0), ctypes.c_void_p(0), ctypes.c_uint64(0)
+        api._check(api.lib().pg_export_take_ws(kc.h, ctypes.byref(ptr), ctypes.byref(got), ctypes.byref(ws), ctypes.byref(ws_bytes)), "pg_export_take_ws")
+        sort_ok = True
+        if got.value:       # sorted inside the record pool pass 1 is done with: no allocation on the way
+            api._check(api.lib().pg_sort_records_ws(ptr, got.value, int(mer127), ws, ws_bytes, kc._stream()), "pg_sort_records_ws")
         torch.cuda.synchronize()
         extras["export_sort_ms"] = (time.perf_counter() - t0) * 1e3
         extras["export_sorted_on_device"] = bool(sort_ok)
         assert got.value == distinct
         torch.cuda.synchronize()
         api.hip_free(ptr)
+        api.hip_free(ws)
 
     if rank == 0:
         ms = dt / args.steps * 1e3

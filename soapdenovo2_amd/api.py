@@ -107,6 +107,8 @@ def lib() -> C.CDLL:
     L.pg_finalize.argtypes = [C.c_void_p, C.c_int, u64p, u64p, C.c_void_p]
     L.pg_export.argtypes = [C.c_void_p, u64p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p]
     L.pg_export_take.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.pg_export_take_ws.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.pg_sort_records_ws.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
     L.pg_device_free.argtypes = [C.c_void_p]
     L.pg_set_counts.argtypes = [C.c_void_p, u64p, C.c_void_p]
     L.pg_last_put.argtypes = [C.c_void_p, u64p, C.c_void_p]

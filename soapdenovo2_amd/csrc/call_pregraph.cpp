@@ -559,7 +559,9 @@ int run(int argc, char** argv, bool mer127) {
         int ls = log2_slots;
         for (int sft = n_ranks * shared; sft > 1 && ls > 20; sft >>= 1) ls--;
         for (int r = 0; r < n_ranks; r++) {
-            ctxs[r] = pg_create_sized(devices[r], K, mer127 ? 1 : 0, o.sets, ls, 2, est_kmers / (uint64_t)n_ranks + 1);
+            // the partition count follows the WHOLE input (every rank cuts with the same geometry, and a partition holds what all
+            // ranks send to it); the export array follows this rank's share
+            ctxs[r] = pg_create_sized(devices[r], K, mer127 ? 1 : 0, o.sets, ls, 2, est_kmers + 1);
             if (!ctxs[r]) die("pg_create");
         }
         {
