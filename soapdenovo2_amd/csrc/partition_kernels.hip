@@ -748,8 +748,8 @@ int e2_create(pg_ctx* c) {
     E2& s = c->e2;
     // partitions: expected distinct / ~1000 so a partition usually fits the LDS set in one attempt; a quarter of that for the
     // 127-mer flavour (a 1024-slot set, five key words to claim per new k-mer: measured best, profiles/r02_bench_k127.json)
-    s.log2_parts = std::max(8, std::min(23, c->log2_slots - (c->NW == 4 ? 9 : 11)));
-    if (c->hint_log2_parts >= 0) s.log2_parts = std::max(8, std::min(23, c->hint_log2_parts));
+    s.log2_parts = std::max(8, std::min(24, c->log2_slots - (c->NW == 4 ? 9 : 11)));
+    if (c->hint_log2_parts >= 0) s.log2_parts = std::max(8, std::min(24, c->hint_log2_parts));
     if (const char* v = getenv("PG_LOG2_PARTS")) s.log2_parts = std::max(4, std::min(24, atoi(v)));
     s.g = skm_geometry(c->K, s.log2_parts, c->NW);
     s.rpc = 128;
@@ -772,9 +772,9 @@ int e2_create(pg_ctx* c) {
     pool_bytes = std::min<uint64_t>(pool_bytes, (budget - out_bytes) * 9 / 10);
     s.pool_chunks = pool_bytes / chunk_bytes;
     if (s.pool_chunks < parts + 16) { pg_set_error("partition engine: record pool too small for the partition count"); return PG_ENOMEM; }
-    // chunk table: up to 2^28 entries in total, at least enough for an even spread x8
+    // chunk table: up to 2^29 entries in total (2 GB), at least enough for an even spread x8
     const uint64_t even = (s.pool_chunks + parts - 1) / parts;
-    s.maxc = (uint32_t)std::max<uint64_t>(8, std::min<uint64_t>(std::min<uint64_t>(256, ((uint64_t)1 << 28) / parts), even * 16));
+    s.maxc = (uint32_t)std::max<uint64_t>(8, std::min<uint64_t>(std::min<uint64_t>(256, ((uint64_t)1 << 29) / parts), even * 16));
     E2_TRY(hipMalloc(&s.cursor, parts * sizeof(uint32_t)));
     E2_TRY(hipMalloc(&s.chunk_tbl, parts * s.maxc * sizeof(uint32_t)));
     E2_TRY(hipMalloc(&s.pool, s.pool_chunks * chunk_bytes + 64));
@@ -833,7 +833,7 @@ static int e2_ensure_pool(pg_ctx* c, uint64_t n_reads, uint64_t n_kmers, hipStre
     s.pool_chunks = fresh_chunks;
     // a longer chunk list per partition too, if the table allows (rebuild with the wider stride)
     const uint64_t even = (fresh_chunks + parts - 1) / parts;
-    const uint32_t want = (uint32_t)std::max<uint64_t>(s.maxc, std::min<uint64_t>(std::min<uint64_t>(256, ((uint64_t)1 << 28) / parts), even * 16));
+    const uint32_t want = (uint32_t)std::max<uint64_t>(s.maxc, std::min<uint64_t>(std::min<uint64_t>(256, ((uint64_t)1 << 29) / parts), even * 16));
     if (want > s.maxc) {
         uint32_t* tbl = nullptr;
         E2_TRY(hipMalloc(&tbl, parts * want * sizeof(uint32_t)));

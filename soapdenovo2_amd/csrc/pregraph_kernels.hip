@@ -502,7 +502,7 @@ extern "C" pg_ctx* pg_create(int device, int K, int mer127, int n_sets, int log2
 
 static int parts_for_kmers(uint64_t total_kmers, int nw) {
     int lp = 8;
-    while (lp < 23 && ((uint64_t)(nw == 4 ? 2048 : 8192) << lp) < total_kmers) lp++;      // the 127-mer LDS set holds half as many keys, and likes them sparse
+    while (lp < 24 && ((uint64_t)(nw == 4 ? 2048 : 8192) << lp) < total_kmers) lp++;      // the 127-mer LDS set holds half as many keys, and likes them sparse
     return lp;
 }
 extern "C" pg_ctx* pg_create_sized(int device, int K, int mer127, int n_sets, int log2_slots, int engine, uint64_t expected_kmers);
