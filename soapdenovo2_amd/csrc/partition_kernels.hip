@@ -266,7 +266,8 @@ __global__ __launch_bounds__(BLOCK) void skm_ingest_kernel(const uint64_t* recs,
 
 // ---- the LDS set ---------------------------------------------------------------------------------------------
 // Struct of arrays, so lanes that hit different slots hit different banks: key[KW][SLOTS] (63-bit words), ord[SLOTS],
-// cnt[9][SLOTS] (u32: L[4], R[4], puts).  Keys and ord start as ~0, counters as 0.  A slot is claimed key word by key
+// cnt[5][SLOTS] (L0|L1<<16, L2|L3<<16, R0|R1<<16, R2|R3<<16, puts without a left neighbour).  Keys and ord start as ~0,
+// counters as 0.  A slot is claimed key word by key
 // word: an empty word is taken with CAS(~0 -> mine), a word holding something else means another key owns the slot.
 // Counting is plain atomic adds, saturated when the node is emitted: a sum of +1's clipped at the end equals the
 // reference's saturating increments (newhash.c:74-106) and, unlike a CAS on packed counters, needs no retry when many
@@ -276,8 +277,10 @@ struct LdsSet {
     static constexpr int KW = E2Cfg<NW>::KW;
     unsigned long long key[KW][SLOTS];
     unsigned long long ord[SLOTS];
-    unsigned int cnt[9][SLOTS];
+    unsigned int cnt[5][SLOTS];       // 16-bit halves: a window adds at most WIN * nmax <= 512 * 127 to a field, and fields are
+                                      // clipped to 255 between the windows of a partition (k2_clip_counters)
 };
+__device__ __forceinline__ unsigned int clip_halves_255(unsigned int x) { return min(x & 0xFFFFu, 255u) | (min(x >> 16, 255u) << 16); }
 
 // A put gives up when the set is too full (a probe sequence longer than MAXPROBE): the caller aborts the attempt and
 // splits the key range.  No shared key counter on this path -- a same-address LDS atomic per new key serialises the
@@ -331,8 +334,9 @@ __device__ __forceinline__ bool lds_put(LdsSet<NW, SLOTS>& t, const uint64_t (&k
             mine = cur == kw[i];
         }
         if (mine) {
-            atomicAdd(&t.cnt[left < 4 ? left : 8][h], copies);       // exactly one of L[0..3] / "none" per put
-            if (right < 4) atomicAdd(&t.cnt[4 + right][h], copies);
+            // exactly one of L[0..3] / "none" per put
+            atomicAdd(&t.cnt[left < 4 ? left >> 1 : 4][h], left < 4 ? copies << ((left & 1u) * 16u) : copies);
+            if (right < 4) atomicAdd(&t.cnt[2 + (right >> 1)][h], copies << ((right & 1u) * 16u));
             if (ord < so) atomicMin(&t.ord[h], (unsigned long long)ord);
             return true;
         }
@@ -341,15 +345,26 @@ __device__ __forceinline__ bool lds_put(LdsSet<NW, SLOTS>& t, const uint64_t (&k
     return false;
 }
 
-template <int NW, int SLOTS, int THREADS, int WIN>
+// A workgroup barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global access of the
+// wave (s_waitcnt vmcnt(0)): K2's global stores (export records) are never read back by the kernel and its global loads are
+// waited for where their registers are used, so draining them at each of the ~15 barriers of a partition only serialises
+// memory latency with the LDS phases.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+template <int NW, int SLOTS, int THREADS, int WIN, bool TIMERS>
 __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetParams sp, OccConst oc, DevCounters* ctr, int dbg) {
     constexpr int PW = E2Cfg<NW>::PW, RW = PW + 1, KW = E2Cfg<NW>::KW, NWAVE = THREADS / 64, PIECES = RW / 2, N2 = 2 * NW;
     constexpr int RD = 2 * RW;                                            // dwords a record
     constexpr int PAD = 16;                                               // readable dwords in front of record 0 (a window reaches back 2 NW + 2)
     static_assert(WIN <= THREADS, "one record per lane in the flatten step");
     static_assert(PAD % 4 == 0 && PAD >= 2 * NW + 2, "front padding");
+    static_assert(SLOTS % THREADS == 0, "whole stripes");
+    constexpr int RL_WORDS = PAD + WIN * RD + 8;
     __shared__ LdsSet<NW, SLOTS> set;
-    __shared__ __align__(16) uint32_t rl[PAD + WIN * RD + 8];             // records: [hdr lo, hdr hi, payload as a dword string: hi, lo, hi, lo, ...]
+    // two record windows: [hdr lo, hdr hi, payload as a dword string: hi, lo, hi, lo, ...].  While one partition's nodes are
+    // emitted (the emit keeps its slot list and its staging area in that partition's dead window), the next partition's
+    // first window arrives in the other buffer.
+    __shared__ __align__(16) uint32_t rl2[2][RL_WORDS];
     // one scratch area, two lives: the record-dedupe table (DT slots), then the flattening tables
     constexpr int DT = 2 * WIN;                                           // open addressing over the window's records, <= 50 % full
     constexpr int FL_WORDS = (DT > WIN + 1 + THREADS / 2 ? DT : WIN + 1 + THREADS / 2) + 2;
@@ -360,21 +375,267 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     __shared__ unsigned int dcount[WIN];                                  // copies of a representative record in the window
     __shared__ uint32_t crc_tab[4 * 256];                                 // CRC-32 sliced by four (kmer.hpp)
     __shared__ unsigned int hist[256];
-    constexpr int STRIPES = (SLOTS + THREADS - 1) / THREADS;
-    __shared__ unsigned int aborted, sp_top, s_mask[40], s_val[40], cur_mask, cur_val, wave_cnt[STRIPES][NWAVE];
-    __shared__ unsigned int chunk_ids[256];                                // this partition's chunk list (maxc <= 256)
+    constexpr int MAXSTRIPES = SLOTS / THREADS;
+    __shared__ unsigned int aborted, s_mask[40], s_val[40], wave_cnt_e[MAXSTRIPES][NWAVE], wave_cnt_f[NWAVE], s_nlive, s_tot;
+    __shared__ unsigned int chunk_ids2[2][256];                           // the partitions' chunk lists (maxc <= 256)
     __shared__ unsigned long long out_base;
     for (int i = threadIdx.x; i < 1024; i += THREADS) crc_tab[i] = crc32_slice_entry(i >> 8, i & 255);
     for (int i = threadIdx.x; i < 256; i += THREADS) hist[i] = 0;
-    if (threadIdx.x < PAD) rl[threadIdx.x] = 0;
-    if (threadIdx.x < 8) rl[PAD + WIN * RD + threadIdx.x] = 0;
+    if (threadIdx.x < 2 * PAD) rl2[threadIdx.x / PAD][threadIdx.x % PAD] = 0;
+    if (threadIdx.x < 16) rl2[threadIdx.x >> 3][PAD + WIN * RD + (threadIdx.x & 7)] = 0;
     const int K = e.g.K;
     const uint32_t parts = 1u << e.g.log2_parts;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long my_records = 0;
     bool dirty = true;                                                   // the LDS set needs a full wipe before the next attempt
-    unsigned long long tp[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, tlast = clock64();
-#define K2_TICK(i) do { if (dbg & 2) { const unsigned long long tn_ = clock64(); tp[i] += tn_ - tlast; tlast = tn_; } } while (0)
+    unsigned long long tp[TIMERS ? 12 : 1] = {0}, tlast = TIMERS ? clock64() : 0;      // phase timers: their own instantiation (PG_DBG & 2), 25 registers
+    // Every barrier of this kernel orders LDS traffic only (lds_barrier): its global stores are never read back and its
+    // global loads are waited for where their registers are used.
+#define K2_SYNC() lds_barrier()
+#define K2_TICK(i) do { if (TIMERS) { const unsigned long long tn_ = clock64(); tp[(i) * TIMERS] += tn_ - tlast; tlast = tn_; } } while (0)
+
+    // ---- prepare a window: stage -> dedupe -> flatten.  Written as barrier-free steps for a group of GS lanes (gtid = lane
+    // index in the group, gwave = wave index in the group); the caller puts a barrier between the steps.
+    struct Prep { bool is_rep; unsigned int n, incl; };
+    // stage the window's records: 16 bytes per lane and step; the header word as it is, every payload word high dword first
+    auto p_stage = [&](auto gs_, int gtid, int nb, uint32_t w0, uint32_t wn) {
+        constexpr int GS = decltype(gs_)::value;
+        uint32_t* const rlb = rl2[nb];
+        const unsigned int* const cids = chunk_ids2[nb];
+        for (uint32_t pc = gtid; pc < wn * PIECES; pc += GS) {
+            const uint32_t ri = pc / PIECES, part = pc - ri * PIECES;
+            const uint32_t gi = w0 + ri, cid = cids[gi >> e.rpc_log2];
+            ulonglong2 v = make_ulonglong2(0, 0);
+            if (cid != 0 && cid != 0xFFFFFFFFu)
+                v = ((const ulonglong2*)(e.pool + ((uint64_t)(cid - 1) * e.rpc + (gi & (e.rpc - 1))) * (uint64_t)RW))[part];
+            const uint32_t x0 = part ? (uint32_t)(v.x >> 32) : (uint32_t)v.x, x1 = part ? (uint32_t)v.x : (uint32_t)(v.x >> 32);
+            ((uint4*)(rlb + PAD))[pc] = make_uint4(x0, x1, (uint32_t)(v.y >> 32), (uint32_t)v.y);
+        }
+        for (int i = gtid; i < DT; i += GS) dtab[i] = 0;
+        for (int i = gtid; i < WIN; i += GS) dcount[i] = 1;
+    };
+    // the same in two halves with the memory latency in between: ask (16 bytes a lane from global memory straight into LDS,
+    // lane l of a wave to wave base + 16 l: the staging layout but for the dword order), and later turn the dwords round in
+    // place, every lane the pieces it asked for
+    auto p_stage_async = [&](int nb, uint32_t wn) {
+        uint32_t* const rlb = rl2[nb];
+        const unsigned int* const cids = chunk_ids2[nb];
+        for (uint32_t p0 = 0; p0 < wn * PIECES; p0 += THREADS) {
+            const uint32_t pc = p0 + threadIdx.x;
+            if (pc < wn * PIECES) {
+                const uint32_t ri = pc / PIECES, part = pc - ri * PIECES;
+                const uint32_t cid = cids[ri >> e.rpc_log2];
+                if (cid != 0 && cid != 0xFFFFFFFFu) {
+                    const ulonglong2* src = (const ulonglong2*)(e.pool + ((uint64_t)(cid - 1) * e.rpc + (ri & (e.rpc - 1))) * (uint64_t)RW) + part;
+                    __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)(rlb + PAD + (p0 + wave * 64) * 4), 16, 0, 0);
+                }
+            }
+        }
+    };
+    auto p_unpack = [&](int nb, uint32_t wn) {
+        uint32_t* const rlb = rl2[nb];
+        const unsigned int* const cids = chunk_ids2[nb];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        for (uint32_t pc = threadIdx.x; pc < wn * PIECES; pc += THREADS) {
+            const uint32_t ri = pc / PIECES, part = pc - ri * PIECES;
+            const uint32_t cid = cids[ri >> e.rpc_log2];
+            uint4 v = ((const uint4*)(rlb + PAD))[pc];                       // lo, hi, lo, hi
+            if (cid == 0 || cid == 0xFFFFFFFFu) v = make_uint4(0, 0, 0, 0);
+            ((uint4*)(rlb + PAD))[pc] = make_uint4(part ? v.y : v.x, part ? v.x : v.y, v.w, v.z);
+        }
+        for (int i = threadIdx.x; i < DT; i += THREADS) dtab[i] = 0;
+        for (int i = threadIdx.x; i < WIN; i += THREADS) dcount[i] = 1;
+    };
+    // dedupe: at high coverage most records of a partition are exact copies of one another (every read that covers a
+    // super-k-mer completely cuts out the same bases with the same flanks).  Copies are found through a small hash table over
+    // the window; the first taker of a slot represents the others, which add to its count and lower its first ordinal (the
+    // header word: equal records differ in nothing else, so the smaller header is the smaller ordinal).  Only
+    // representatives are expanded, each occurrence counting `copies` times: the same sums, the same minima, about half the
+    // work.
+    auto p_dedupe = [&](int gtid, int nb, uint32_t wn, Prep& ps) {
+        uint32_t* const rlb = rl2[nb];
+        bool is_rep = (uint32_t)gtid < wn;
+        if (is_rep && !(dbg & 4)) {
+            const uint32_t* me = rlb + PAD + gtid * RD;
+            uint32_t w[RD - 1];
+            w[0] = me[0] & ((1u << SKM_ORD_SHIFT) - 1);                    // n, has_left, has_right
+#pragma unroll
+            for (int q = 1; q < RD - 1; q++) w[q] = me[q + 1];
+            uint32_t hsh = 0x9E3779B1u;                                       // rotate-xor fold, one multiplicative finish
+#pragma unroll
+            for (int q = 0; q < RD - 1; q++) hsh = alignbit32(hsh, hsh, 27u) ^ w[q];
+            hsh *= 0x85EBCA6Bu;
+            hsh ^= hsh >> 15;
+            uint32_t sl = hsh & (DT - 1);
+            for (int probes = 0; probes < DT; probes++) {
+                unsigned int v = dtab[sl];
+                if (v == 0) {
+                    const unsigned int old = atomicCAS(&dtab[sl], 0u, (unsigned int)gtid + 1u);
+                    if (old == 0) break;                                      // first of its kind: it represents the rest
+                    v = old;
+                }
+                const uint32_t* it = rlb + PAD + (v - 1) * RD;
+                bool same = (it[0] & ((1u << SKM_ORD_SHIFT) - 1)) == w[0];
+#pragma unroll
+                for (int q = 1; q < RD - 1; q++) same = same && it[q + 1] == w[q];
+                if (same) {
+                    atomicAdd(&dcount[v - 1], 1u);
+                    atomicMin((unsigned long long*)it, *(const unsigned long long*)me);
+                    is_rep = false;
+                    break;
+                }
+                sl = (sl + 1) & (DT - 1);
+            }
+        }
+        ps.is_rep = is_rep;
+    };
+    // flatten: occurrence idx -> (representative, t); every lane of the workgroup gets `share` consecutive occurrences
+    auto p_flat1 = [&](int gtid, int gwave, int nb, Prep& ps) {
+        ps.n = ps.is_rep ? ((rl2[nb][PAD + gtid * RD] >> 2) & 0x7Fu) : 0u;
+        unsigned int incl = ps.n | (ps.is_rep ? 1u << 20 : 0u);                // k-mers below bit 20, representatives above
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const unsigned int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+        if (lane == 63) wave_cnt_f[gwave] = incl;
+        ps.incl = incl;
+    };
+    // the offsets table: entry k = first occurrence index of the k-th representative | its place in the window << 16 (at
+    // most 512 * 127 < 2^16 occurrences a window); the representative's copy count goes into the idle bits of its LDS header
+    // (a record has at most 127 k-mers, the count field is 16 bits wide), so the occurrence loop finds offsets, place,
+    // header and count in two dependent round trips
+    auto p_flat2 = [&](auto gs_, int gtid, int gwave, int nb, Prep& ps) {
+        constexpr int GW = decltype(gs_)::value / 64;
+        unsigned int base = 0, tot = 0;
+#pragma unroll
+        for (int wv = 0; wv < GW; wv++) { const unsigned int cw = wave_cnt_f[wv]; if (wv < gwave) base += cw; tot += cw; }
+        const unsigned int n_rep = tot >> 20;
+        tot &= (1u << 20) - 1;
+        const unsigned int share = (tot + THREADS - 1) / THREADS;
+        if (ps.is_rep) {
+            uint32_t* me = rl2[nb] + PAD + gtid * RD;
+            me[0] = (me[0] & ~0x3FE00u) | ((dcount[gtid] - 1u) << 9);                // n < 128 keeps bits 2..8, copies - 1 <= 511
+            const unsigned int upto = base + ps.incl, k = (upto >> 20) - 1;          // this representative's rank
+            const unsigned int o_hi = upto & ((1u << 20) - 1), o_lo = o_hi - ps.n;
+            noff[k] = o_lo | ((unsigned int)gtid << 16);
+            // lanes whose share starts inside this record: l * share in [o_lo, o_hi)
+            const float inv = 1.0f / (float)share;
+            auto div_up = [&](unsigned int x) {                                // ceil(x / share), x < 2^16
+                unsigned int q = (unsigned int)((float)x * inv);
+                if (q * share > x) q--;
+                if ((q + 1) * share <= x) q++;
+                return q + (q * share < x ? 1u : 0u);
+            };
+            const unsigned int l0 = div_up(o_lo), l1 = min((unsigned int)THREADS, div_up(o_hi));
+            for (unsigned int l = l0; l < l1; l++) first_rec[l] = (unsigned short)k;
+        }
+        if (gtid == 0) { noff[n_rep] = tot; s_tot = tot; }
+    };
+
+    // ---- emit: finalize every stored node and append it to the export array.  The set is a quarter full on average, so
+    // the live slots are first listed (rank = wave prefix sums over the ballots) and then worked on by dense waves: lane i
+    // takes the i-th live slot, finalises it into a staging area (the -d filter, the linear flag, the coverage histogram:
+    // prlHashReads.c:953-1132) and wipes the slot behind it, which is all the clearing the next attempt needs; the staged
+    // records go out as whole 16-byte pieces, coalesced.  One global atomic per attempt.  Barrier-free steps as above; `sb` =
+    // the window buffer whose storage the list and the staging area borrow.
+    struct Emit { bool live[MAXSTRIPES]; unsigned long long bal[MAXSTRIPES]; };
+    constexpr unsigned int LIST_WORDS = SLOTS * 2 / 8;                    // the list's share of the buffer, in 64-bit words
+    constexpr unsigned int STAGE_CAP = (RL_WORDS * 4 - SLOTS * 2) / ((NW + 2) * 8) / 64 * 64;
+    static_assert(STAGE_CAP >= 64, "staging area");
+    auto e_list1 = [&](auto gs_, int gtid, int gwave, Emit& es) {
+        constexpr int GS = decltype(gs_)::value, STR = SLOTS / GS;
+#pragma unroll
+        for (int st = 0; st < STR; st++) {
+            // every put of this attempt is complete (barrier), so a slot whose first key word is taken holds a whole key and
+            // at least one put
+            es.live[st] = set.key[0][st * GS + gtid] != L_EMPTY;
+            es.bal[st] = __ballot(es.live[st]);
+            if (lane == 0) wave_cnt_e[st][gwave] = (unsigned int)__popcll(es.bal[st]);
+        }
+    };
+    auto e_list2 = [&](auto gs_, int gtid, int gwave, int sb, Emit& es) {
+        constexpr int GS = decltype(gs_)::value, STR = SLOTS / GS, GW = GS / 64;
+        unsigned short* live_list = (unsigned short*)rl2[sb];
+        unsigned int running = 0;
+#pragma unroll
+        for (int st = 0; st < STR; st++) {
+            unsigned int before = 0, total = 0;
+#pragma unroll
+            for (int wv = 0; wv < GW; wv++) {
+                const unsigned int cw = wave_cnt_e[st][wv];
+                if (wv < gwave) before += cw;
+                total += cw;
+            }
+            if (es.live[st]) live_list[running + before + (unsigned int)__popcll(es.bal[st] & ((1ULL << lane) - 1))] = (unsigned short)(st * GS + gtid);
+            running += total;
+        }
+        if (gtid == 0) s_nlive = running;
+    };
+    auto e_final = [&](auto gs_, int gtid, int sb, unsigned int c0, unsigned int cn, unsigned int n_live) {
+        constexpr int GS = decltype(gs_)::value;
+        const unsigned short* live_list = (const unsigned short*)rl2[sb];
+        uint64_t* stage = (uint64_t*)rl2[sb] + LIST_WORDS;
+        // The export slots come from one global counter every workgroup of the grid adds to: its answer takes a while.  The
+        // group's first lane asks now and looks at the answer only after its share of the finalisation.
+        unsigned long long ticket = 0;
+        if (gtid == 0 && c0 == 0) ticket = atomicAdd(&ctr->n_export, (unsigned long long)n_live);
+        for (unsigned int i = gtid; i < cn; i += GS) {
+            const int si = live_list[c0 + i];
+            unsigned int cl[4], cr[4];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const unsigned int lw = set.cnt[c][si], rw2 = set.cnt[2 + c][si];
+                cl[2 * c] = lw & 0xFFFFu; cl[2 * c + 1] = lw >> 16;
+                cr[2 * c] = rw2 & 0xFFFFu; cr[2 * c + 1] = rw2 >> 16;
+            }
+            const unsigned int puts = cl[0] + cl[1] + cl[2] + cl[3] + set.cnt[4][si];
+            Key63<NW> k63;
+#pragma unroll
+            for (int w = 0; w < KW; w++) k63.w[w] = set.key[w][si];
+            const unsigned long long first = set.ord[si];
+            // wipe the slot
+#pragma unroll
+            for (int w = 0; w < KW; w++) set.key[w][si] = L_EMPTY;
+            set.ord[si] = L_EMPTY;
+#pragma unroll
+            for (int q = 0; q < 5; q++) set.cnt[q][si] = 0;
+            const Kmer<NW> key = kmer_from_key63<NW>(k63);
+            uint32_t A = min(puts, 255u) << 24, B = puts == 1 ? B_SINGLE : 0u;
+            int nin = 0, nout = 0;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {                                       // saturate, then thread_delow + thread_mark
+                uint32_t l = min(cl[c], 63u), r = min(cr[c], 63u);
+                if (D > 0 && l <= (uint32_t)D) l = 0;
+                if (D > 0 && r <= (uint32_t)D) r = 0;
+                A |= l << (6 * c); B |= r << (6 * c);
+                nin += l > 0; nout += r > 0;
+            }
+            if (D > 0 && nin == 0 && nout == 0) B |= B_DELETED;
+            if (nin == 1 && nout == 1) B |= B_LINEAR;
+            const uint32_t cov = A >> 24;
+            const uint32_t sid = set_of_crc(kmer_crc32_sliced<NW>(key, crc_tab), sp.P, sp.bias);
+            // coverage histogram: most nodes of a partition share one or two coverage values (1 for error k-mers), so count
+            // those per wave instead of hammering one LDS word
+            const unsigned long long ones = __ballot(cov == 1);
+            if (lane == __ffsll((long long)ones) - 1) atomicAdd(&hist[1], (unsigned int)__popcll(ones));
+            if (cov > 1) atomicAdd(&hist[cov], 1u);
+            uint64_t* o = stage + (size_t)i * (NW + 2);
+#pragma unroll
+            for (int w = 0; w < NW; w++) o[w] = key.w[w];
+            o[NW] = (uint64_t)A | ((uint64_t)B << 32);
+            o[NW + 1] = ((uint64_t)sid << PG_ORD_BITS) | (first & PG_ORD_MASK);
+        }
+        if (gtid == 0 && c0 == 0) out_base = ticket;
+    };
+    auto e_copy = [&](auto gs_, int gtid, int sb, unsigned int c0, unsigned int cn) {
+        constexpr int GS = decltype(gs_)::value;
+        const unsigned long long ob = out_base + c0;
+        if (ob + cn <= e.out_capacity) {
+            ulonglong2* dst = (ulonglong2*)(e.out + ob * (NW + 2));               // (NW + 2) * 8 is a multiple of 16
+            const ulonglong2* src = (const ulonglong2*)((const uint64_t*)rl2[sb] + LIST_WORDS);
+            for (unsigned int q = gtid; q < cn * ((NW + 2) / 2); q += GS) dst[q] = src[q];
+        } else if (gtid == 0) atomicOr(&ctr->e2_flags, F_OUT);
+    };
+    const std::integral_constant<int, THREADS> whole{};
+
     uint32_t pf_nrec = 0, pf_cid = 0;
     // (the record count is the same for every lane, which would make it a scalar load -- and scalar loads are waited for at
     //  the very next barrier together with the LDS traffic (lgkmcnt); through a vector register it stays in flight until used)
@@ -383,158 +644,74 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
         pf_nrec = peek_cursor(blockIdx.x);
         if (threadIdx.x < e.maxc) pf_cid = e.chunk_tbl[(uint64_t)blockIdx.x * e.maxc + threadIdx.x];
     }
+    int b = 0;                                                            // the current partition's window buffer
+    bool staged = false;                                                  // its first window is already on its way into rl2[b] (asked for by the previous emit)
     for (uint32_t pid = blockIdx.x; pid < parts; pid += gridDim.x) {
         const uint32_t nrec = pf_nrec, my_cid = pf_cid;
-        {
-            const uint32_t nxt = pid + gridDim.x;
-            if (nxt < parts) {
-                pf_nrec = peek_cursor(nxt);
-                if (threadIdx.x < e.maxc) pf_cid = e.chunk_tbl[(uint64_t)nxt * e.maxc + threadIdx.x];
-            }
+        const uint32_t nxt = pid + gridDim.x;
+        if (nxt < parts) {
+            pf_nrec = peek_cursor(nxt);
+            if (threadIdx.x < e.maxc) pf_cid = e.chunk_tbl[(uint64_t)nxt * e.maxc + threadIdx.x];
         }
         const uint32_t usable = min(nrec, e.maxc * e.rpc);               // an overfull partition was flagged by K1
         my_records += usable;
-        if (usable == 0) continue;
-        __syncthreads();
-        if (threadIdx.x < e.maxc) chunk_ids[threadIdx.x] = my_cid;
-        if (threadIdx.x == 0) { sp_top = 1; s_mask[0] = 0; s_val[0] = 0; }
-        __syncthreads();
+        if (usable == 0) continue;                                        // (never one that was asked for)
+        if (!staged) {
+            K2_SYNC();                                                    // the previous partition's last readers of this chunk list
+            if (threadIdx.x < e.maxc) chunk_ids2[b][threadIdx.x] = my_cid;
+        }
         K2_TICK(0);
-        while (sp_top > 0) {
-            __syncthreads();
-            if (threadIdx.x == 0) { sp_top--; cur_mask = s_mask[sp_top]; cur_val = s_val[sp_top]; aborted = 0; }
-            if (dirty) {                                              // (the emit below leaves the set empty: it wipes what it reads)
+        // key ranges still to count: (mask, val) on the slot hash; the stack pointer lives in a register of every lane
+        int top = 0;
+        uint32_t mask = 0, val = 0;
+        bool window_ready = false;                                        // rl2[b] holds window 0, prepared
+        bool raw = staged;                                                // ... or window 0 as global_load_lds left it
+        staged = false;
+        for (;;) {
+            if (threadIdx.x == 0) aborted = 0;
+            if (dirty) {                                                  // (an emit leaves the set empty: it wipes what it reads)
                 for (int i = threadIdx.x; i < SLOTS; i += THREADS) {
 #pragma unroll
                     for (int q = 0; q < KW; q++) set.key[q][i] = L_EMPTY;
                     set.ord[i] = L_EMPTY;
 #pragma unroll
-                    for (int q = 0; q < 9; q++) set.cnt[q][i] = 0;
+                    for (int q = 0; q < 5; q++) set.cnt[q][i] = 0;
                 }
                 dirty = false;
             }
-            __syncthreads();
+            K2_SYNC();
             K2_TICK(1);
-            const uint32_t mask = cur_mask, val = cur_val;
             for (uint32_t w0 = 0; w0 < usable; w0 += WIN) {
                 const uint32_t wn = min((uint32_t)WIN, usable - w0);
-                // stage the window's records: 16 bytes per lane and step; the header word as it is, every payload word high
-                // dword first (a string of dwords)
-                for (uint32_t pc = threadIdx.x; pc < wn * PIECES; pc += THREADS) {
-                    const uint32_t ri = pc / PIECES, part = pc - ri * PIECES;
-                    const uint32_t gi = w0 + ri, cid = chunk_ids[gi >> e.rpc_log2];
-                    ulonglong2 v = make_ulonglong2(0, 0);
-                    if (cid != 0 && cid != 0xFFFFFFFFu)
-                        v = ((const ulonglong2*)(e.pool + ((uint64_t)(cid - 1) * e.rpc + (gi & (e.rpc - 1))) * (uint64_t)RW))[part];
-                    const uint32_t x0 = part ? (uint32_t)(v.x >> 32) : (uint32_t)v.x, x1 = part ? (uint32_t)v.x : (uint32_t)(v.x >> 32);
-                    ((uint4*)(rl + PAD))[pc] = make_uint4(x0, x1, (uint32_t)(v.y >> 32), (uint32_t)v.y);
+                if (!(window_ready && w0 == 0)) {
+                    Prep ps;
+                    if (raw && w0 == 0) p_unpack(b, wn); else p_stage(whole, threadIdx.x, b, w0, wn);
+                    raw = false;
+                    K2_SYNC();
+                    K2_TICK(2);
+                    p_dedupe(threadIdx.x, b, wn, ps);
+                    K2_TICK(10);
+                    K2_SYNC();                                            // dtab is dead from here, counts and minima are final
+                    p_flat1(threadIdx.x, wave, b, ps);
+                    K2_SYNC();
+                    p_flat2(whole, threadIdx.x, wave, b, ps);
+                    K2_SYNC();
+                    K2_TICK(3);
                 }
-                for (int i = threadIdx.x; i < DT; i += THREADS) dtab[i] = 0;
-                for (int i = threadIdx.x; i < WIN; i += THREADS) dcount[i] = 1;
-                __syncthreads();
-                K2_TICK(2);
-                // dedupe: at high coverage most records of a partition are exact copies of one another (every read that covers a
-                // super-k-mer completely cuts out the same bases with the same flanks).  Copies are found through a small hash
-                // table over the window; the first taker of a slot represents the others, which add to its count and lower its
-                // first ordinal (the header word: equal records differ in nothing else, so the smaller header is the smaller
-                // ordinal).  Only representatives are expanded, each occurrence counting `copies` times: the same sums, the
-                // same minima, about half the work.
-                bool is_rep = threadIdx.x < wn;
-                if (is_rep && !(dbg & 4)) {
-                    const uint32_t* me = rl + PAD + threadIdx.x * RD;
-                    uint32_t w[RD - 1];
-                    w[0] = me[0] & ((1u << SKM_ORD_SHIFT) - 1);            // n, has_left, has_right
-#pragma unroll
-                    for (int q = 1; q < RD - 1; q++) w[q] = me[q + 1];
-                    uint32_t hsh = 0x9E3779B1u;                               // rotate-xor fold, one multiplicative finish
-#pragma unroll
-                    for (int q = 0; q < RD - 1; q++) hsh = alignbit32(hsh, hsh, 27u) ^ w[q];
-                    hsh *= 0x85EBCA6Bu;
-                    hsh ^= hsh >> 15;
-                    uint32_t sl = hsh & (DT - 1);
-                    for (int probes = 0; probes < DT; probes++) {
-                        unsigned int v = dtab[sl];
-                        if (v == 0) {
-                            const unsigned int old = atomicCAS(&dtab[sl], 0u, threadIdx.x + 1u);
-                            if (old == 0) break;                              // first of its kind: it represents the rest
-                            v = old;
-                        }
-                        const uint32_t* it = rl + PAD + (v - 1) * RD;
-                        bool same = (it[0] & ((1u << SKM_ORD_SHIFT) - 1)) == w[0];
-#pragma unroll
-                        for (int q = 1; q < RD - 1; q++) same = same && it[q + 1] == w[q];
-                        if (same) {
-                            atomicAdd(&dcount[v - 1], 1u);
-                            atomicMin((unsigned long long*)it, *(const unsigned long long*)me);
-                            is_rep = false;
-                            break;
-                        }
-                        sl = (sl + 1) & (DT - 1);
-                    }
-                }
-                K2_TICK(10);
-                __syncthreads();                                                  // dtab is dead from here, counts and minima are final
-                // flatten: occurrence idx -> (representative, t); every lane gets `share` consecutive occurrences
-                uint32_t total_occ, share;
-                {
-                    const unsigned int n = is_rep ? ((rl[PAD + threadIdx.x * RD] >> 2) & 0x7Fu) : 0u;
-                    unsigned int incl = n | (is_rep ? 1u << 20 : 0u);         // k-mers below bit 20, representatives above
-#pragma unroll
-                    for (int d = 1; d < 64; d <<= 1) { const unsigned int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
-                    if (lane == 63) wave_cnt[0][wave] = incl;
-                    __syncthreads();
-                    unsigned int base = 0, tot = 0;
-#pragma unroll
-                    for (int wv = 0; wv < NWAVE; wv++) { const unsigned int cw = wave_cnt[0][wv]; if (wv < wave) base += cw; tot += cw; }
-                    const unsigned int n_rep = tot >> 20;
-                    tot &= (1u << 20) - 1;
-                    total_occ = tot;
-                    share = (tot + THREADS - 1) / THREADS;
-                    // Representatives move to the front of the window (rank k -> record slot k: k <= its old place, everybody has
-                    // read before anybody writes), with the copy count in the idle bits of the LDS header (a record has at most
-                    // 96 k-mers, the count field is 16 bits wide): the occurrence loop then finds offsets, header and count of
-                    // rank k in one round trip.
-                    uint32_t mine[RD];
-                    if (is_rep) {
-                        const uint32_t* me = rl + PAD + threadIdx.x * RD;
-#pragma unroll
-                        for (int q = 0; q < RD; q++) mine[q] = me[q];
-                        mine[0] = (mine[0] & ~0x3FE00u) | ((dcount[threadIdx.x] - 1u) << 9);   // n < 128 keeps bits 2..8, copies - 1 <= 511
-                    }
-                    __syncthreads();
-                    if (is_rep) {
-                        const unsigned int upto = base + incl, k = (upto >> 20) - 1;            // this representative's rank
-                        const unsigned int o_hi = upto & ((1u << 20) - 1), o_lo = o_hi - n;
-                        noff[k] = o_lo;
-                        uint32_t* to = rl + PAD + k * RD;
-#pragma unroll
-                        for (int q = 0; q < RD; q++) to[q] = mine[q];
-                        // lanes whose share starts inside this record: l * share in [o_lo, o_hi)
-                        const float inv = 1.0f / (float)share;
-                        auto div_up = [&](unsigned int x) {                        // ceil(x / share), x < 2^16
-                            unsigned int q = (unsigned int)((float)x * inv);
-                            if (q * share > x) q--;
-                            if ((q + 1) * share <= x) q++;
-                            return q + (q * share < x ? 1u : 0u);
-                        };
-                        const unsigned int l0 = div_up(o_lo), l1 = min((unsigned int)THREADS, div_up(o_hi));
-                        for (unsigned int l = l0; l < l1; l++) first_rec[l] = (unsigned short)k;
-                    }
-                    if (threadIdx.x == THREADS - 1) noff[n_rep] = tot;
-                }
-                __syncthreads();
-                K2_TICK(3);
+                window_ready = usable <= WIN;                             // a single window stays good for the other key ranges
+                const uint32_t total_occ = s_tot, share = (total_occ + THREADS - 1) / THREADS;
+                const uint32_t* const rl = rl2[b];
                 if (!__hip_atomic_load(&aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
                     uint32_t idx = min(total_occ, threadIdx.x * share);
                     const uint32_t idx1 = min(total_occ, idx + share);
                     if (idx < idx1) {
                         uint32_t k = first_rec[threadIdx.x];
-                        uint32_t o_hi = noff[k + 1];
+                        uint32_t o_hi = noff[k + 1] & 0xFFFFu;
                         for (; idx < idx1; idx++) {
                             k += idx >= o_hi ? 1u : 0u;
-                            const uint32_t o_lo = noff[k];
-                            o_hi = noff[k + 1];
-                            const uint32_t* rec = rl + PAD + k * RD;
+                            const uint32_t nk = noff[k], o_lo = nk & 0xFFFFu;
+                            o_hi = noff[k + 1] & 0xFFFFu;
+                            const uint32_t* rec = rl + PAD + (nk >> 16) * RD;
                             const uint32_t h_lo = rec[0], h_hi = rec[1];
                             const uint32_t copies = ((h_lo >> 9) & 0x1FFu) + 1u;
                             const uint32_t t = idx - o_lo;
@@ -562,130 +739,73 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     }
                 }
                 K2_TICK(4);
-                __syncthreads();                                                  // rl / noff are rewritten by the next window
+                // the next partition's chunk list, for the prepare that runs beside this partition's last emit
+                if (threadIdx.x < e.maxc) chunk_ids2[b ^ 1][threadIdx.x] = pf_cid;
+                K2_SYNC();                                                  // the window and its tables are rewritten by the next one
+                if (w0 + WIN < usable) {                                    // more windows add to these counters: keep the halves small
+                    for (int i = threadIdx.x; i < SLOTS; i += THREADS) {    // (they saturate at 63 / 255 in the end anyway)
+#pragma unroll
+                        for (int q = 0; q < 4; q++) set.cnt[q][i] = clip_halves_255(set.cnt[q][i]);
+                    }
+                }
                 K2_TICK(5);
             }
-            if (aborted) {
-                if (dbg & 2) tp[9]++;
+            if (aborted) {                                                // (read behind the window loop's last barrier: the same for every lane)
+                if (TIMERS) tp[9 * TIMERS]++;
                 dirty = true;
                 // too many distinct keys for the LDS set: split this key range on the next hash bit and redo both halves
-                if (threadIdx.x == 0) {
-                    const uint32_t bit = mask + 1;                                    // masks are 2^k - 1
-                    if (bit >= (1u << 20) || sp_top + 2 > 40) atomicOr(&ctr->e2_flags, F_SPLIT);
-                    else {
-                        s_mask[sp_top] = mask | bit; s_val[sp_top] = val; sp_top++;
-                        s_mask[sp_top] = mask | bit; s_val[sp_top] = val | bit; sp_top++;
+                const uint32_t bit = mask + 1;                            // masks are 2^k - 1
+                if (bit >= (1u << 20) || top + 2 > 40) {
+                    if (threadIdx.x == 0) atomicOr(&ctr->e2_flags, F_SPLIT);
+                } else {
+                    if (threadIdx.x == 0) {
+                        s_mask[top] = mask | bit; s_val[top] = val;
+                        s_mask[top + 1] = mask | bit; s_val[top + 1] = val | bit;
                     }
+                    top += 2;
                 }
-                __syncthreads();
-                continue;
-            }
-            // ---- emit: finalize every stored node and append it to the export array.  The set is a quarter full on average,
-            // so the live slots are first listed (rank = wave prefix sums over the ballots) and then worked on by dense waves:
-            // lane i takes the i-th live slot, writes export record out_base + i and wipes the slot behind it, which is all
-            // the clearing the next attempt needs.  One global atomic per attempt.
-            unsigned short* live_list = (unsigned short*)rl;              // the record window is idle during the emit
-            bool live[STRIPES];
-            unsigned long long bal[STRIPES];
-#pragma unroll
-            for (int st = 0; st < STRIPES; st++) {
-                const int si = st * THREADS + threadIdx.x;
-                // every put of this attempt is complete (barrier), so a slot whose first key word is taken holds a whole key
-                // and at least one put
-                live[st] = si < SLOTS && set.key[0][si] != L_EMPTY;
-                bal[st] = __ballot(live[st]);
-                if (lane == 0) wave_cnt[st][wave] = (unsigned int)__popcll(bal[st]);
-            }
-            __syncthreads();
-            unsigned int running = 0;
-#pragma unroll
-            for (int st = 0; st < STRIPES; st++) {
-                unsigned int before = 0, total = 0;
-#pragma unroll
-                for (int wv = 0; wv < NWAVE; wv++) {
-                    const unsigned int cw = wave_cnt[st][wv];
-                    if (wv < wave) before += cw;
-                    total += cw;
-                }
-                if (live[st]) live_list[running + before + (unsigned int)__popcll(bal[st] & ((1ULL << lane) - 1))] = (unsigned short)(st * THREADS + threadIdx.x);
-                running += total;
-            }
-            const unsigned int n_live = running;
-            K2_TICK(6);
-            __syncthreads();                                              // the list is complete
-            K2_TICK(7);
-            // The export slots come from one global counter every workgroup of the grid adds to: its answer takes a while.
-            // Thread 0 asks now and looks at the answer only after its share of the finalisation (the records are staged in
-            // LDS meanwhile and go out afterwards as whole 16-byte pieces, coalesced).
-            unsigned long long ticket = 0;
-            if (threadIdx.x == 0) ticket = atomicAdd(&ctr->n_export, (unsigned long long)n_live);
-            constexpr unsigned int LIST_WORDS = SLOTS * 2 / 8;            // the list's share of rl, in 64-bit words
-            constexpr unsigned int STAGE_CAP = ((PAD + WIN * RD + 8) * 4 - SLOTS * 2) / ((NW + 2) * 8) / 64 * 64;
-            static_assert(STAGE_CAP >= 64, "staging area");
-            uint64_t* stage = (uint64_t*)rl + LIST_WORDS;
-            for (unsigned int c0 = 0; c0 < n_live; c0 += STAGE_CAP) {
-                const unsigned int cn = min(STAGE_CAP, n_live - c0);
-                for (unsigned int i = threadIdx.x; i < cn; i += THREADS) {
-                    const int si = live_list[c0 + i];
-                    unsigned int cl[4], cr[4];
-#pragma unroll
-                    for (int c = 0; c < 4; c++) { cl[c] = set.cnt[c][si]; cr[c] = set.cnt[4 + c][si]; }
-                    const unsigned int puts = cl[0] + cl[1] + cl[2] + cl[3] + set.cnt[8][si];
-                    Key63<NW> k63;
-#pragma unroll
-                    for (int w = 0; w < KW; w++) k63.w[w] = set.key[w][si];
-                    const unsigned long long first = set.ord[si];
-                    // wipe the slot
-#pragma unroll
-                    for (int w = 0; w < KW; w++) set.key[w][si] = L_EMPTY;
-                    set.ord[si] = L_EMPTY;
-#pragma unroll
-                    for (int q = 0; q < 9; q++) set.cnt[q][si] = 0;
-                    const Kmer<NW> key = kmer_from_key63<NW>(k63);
-                    uint32_t A = min(puts, 255u) << 24, B = puts == 1 ? B_SINGLE : 0u;
-                    int nin = 0, nout = 0;
-#pragma unroll
-                    for (int c = 0; c < 4; c++) {                               // saturate, then thread_delow + thread_mark
-                        uint32_t l = min(cl[c], 63u), r = min(cr[c], 63u);
-                        if (D > 0 && l <= (uint32_t)D) l = 0;
-                        if (D > 0 && r <= (uint32_t)D) r = 0;
-                        A |= l << (6 * c); B |= r << (6 * c);
-                        nin += l > 0; nout += r > 0;
+            } else {
+                const uint32_t usable_next = nxt < parts ? min(pf_nrec, e.maxc * e.rpc) : 0u;
+                // The last emit of a partition borrows its own window (dead now) and, first of all, asks for the next partition's
+                // first window: global_load_lds copies 16 bytes a lane straight into the other buffer, no registers, so the
+                // loads fly during the whole emit (p_stage_async / p_unpack).  Earlier emits (more key ranges to come) borrow
+                // the other buffer, and a single-window partition keeps its prepared window for the remaining ranges.
+                const bool ahead = top == 0 && usable_next > 0 && !(dbg & 16);
+                const int sb = top == 0 ? b : b ^ 1;
+                if (ahead) { p_stage_async(b ^ 1, min((uint32_t)WIN, usable_next)); staged = true; }
+                {
+                    Emit es;
+                    e_list1(whole, threadIdx.x, wave, es);
+                    K2_SYNC();
+                    e_list2(whole, threadIdx.x, wave, sb, es);
+                    K2_SYNC();
+                    K2_TICK(6);
+                    const unsigned int n_live = s_nlive;
+                    for (unsigned int c0 = 0; c0 < n_live; c0 += STAGE_CAP) {
+                        const unsigned int cn = min(STAGE_CAP, n_live - c0);
+                        e_final(whole, threadIdx.x, sb, c0, cn, n_live);
+                        K2_TICK(11);
+                        K2_SYNC();
+                        e_copy(whole, threadIdx.x, sb, c0, cn);
+                        K2_SYNC();                                        // the staging area is filled again, or the buffer staged into
                     }
-                    if (D > 0 && nin == 0 && nout == 0) B |= B_DELETED;
-                    if (nin == 1 && nout == 1) B |= B_LINEAR;
-                    const uint32_t cov = A >> 24;
-                    const uint32_t sid = set_of_crc(kmer_crc32_sliced<NW>(key, crc_tab), sp.P, sp.bias);
-                    // coverage histogram: most nodes of a partition share one or two coverage values (1 for error k-mers), so
-                    // count those per wave instead of hammering one LDS word
-                    const unsigned long long ones = __ballot(cov == 1);
-                    if (lane == __ffsll((long long)ones) - 1) atomicAdd(&hist[1], (unsigned int)__popcll(ones));
-                    if (cov > 1) atomicAdd(&hist[cov], 1u);
-                    uint64_t* o = stage + (size_t)i * (NW + 2);
-#pragma unroll
-                    for (int w = 0; w < NW; w++) o[w] = key.w[w];
-                    o[NW] = (uint64_t)A | ((uint64_t)B << 32);
-                    o[NW + 1] = ((uint64_t)sid << PG_ORD_BITS) | (first & PG_ORD_MASK);
+                    K2_TICK(8);
                 }
-                if (threadIdx.x == 0 && c0 == 0) out_base = ticket;
-                K2_TICK(11);
-                __syncthreads();
-                const unsigned long long ob = out_base + c0;
-                if (ob + cn <= e.out_capacity) {
-                    ulonglong2* dst = (ulonglong2*)(e.out + ob * (NW + 2));           // (NW + 2) * 8 is a multiple of 16
-                    const ulonglong2* src = (const ulonglong2*)stage;
-                    for (unsigned int q = threadIdx.x; q < cn * ((NW + 2) / 2); q += THREADS) dst[q] = src[q];
-                } else if (threadIdx.x == 0) atomicOr(&ctr->e2_flags, F_OUT);
-                if (c0 + STAGE_CAP < n_live) __syncthreads();                     // the staging area is filled again
             }
-            K2_TICK(8);
+            if (top == 0) break;
+            K2_SYNC();                                                    // the pushed ranges are visible
+            top--;
+            mask = s_mask[top];
+            val = s_val[top];
         }
+        if (staged) b ^= 1;
     }
-    __syncthreads();
+    K2_SYNC();
     for (int i = threadIdx.x; i < 256; i += THREADS) if (hist[i]) atomicAdd(&ctr->hist[i], (unsigned long long)hist[i]);
     if (threadIdx.x == 0 && my_records) atomicAdd(&ctr->n_records, my_records);
-    if ((dbg & 2) && threadIdx.x == 0) for (int i = 0; i < 12; i++) atomicAdd(&ctr->phase[i], tp[i]);
+    if (TIMERS && threadIdx.x == 0) for (int i = 0; i < 12; i++) atomicAdd(&ctr->phase[i], tp[i * TIMERS]);
 #undef K2_TICK
+#undef K2_SYNC
 }
 
 // per reference set: 1 + ordinal of the last k-mer occurrence routed to it (see host_graph.cpp, before_put)
@@ -1039,13 +1159,15 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
         const OccConst oc = occ_const(c->K, c->NW);
         // cfg 2: 512-slot set, 256 lanes, 128-record windows -> ~38 KB LDS, four workgroups per CU (meant for 4x the partitions)
         if (c->NW == 2) {
-            if (cfg == 0) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
-            else if (cfg == 1) hipLaunchKernelGGL((skm_count_kernel<2, 1024, 512, 256>), dim3(grid), dim3(512), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
-            else hipLaunchKernelGGL((skm_count_kernel<2, 512, 256, 128>), dim3(grid * 2), dim3(256), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
+            if (cfg == 0 && (dbg & 2)) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, true>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
+            else if (cfg == 0) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
+            else if (cfg == 1) hipLaunchKernelGGL((skm_count_kernel<2, 1024, 512, 256, false>), dim3(grid), dim3(512), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
+            else hipLaunchKernelGGL((skm_count_kernel<2, 512, 256, 128, false>), dim3(grid * 2), dim3(256), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
         } else {
-            if (cfg == 0) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
-            else if (cfg == 1) hipLaunchKernelGGL((skm_count_kernel<4, 512, 512, 256>), dim3(grid), dim3(512), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
-            else hipLaunchKernelGGL((skm_count_kernel<4, 256, 256, 128>), dim3(grid * 2), dim3(256), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
+            if (cfg == 0 && (dbg & 2)) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, true>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
+            else if (cfg == 0) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
+            else if (cfg == 1) hipLaunchKernelGGL((skm_count_kernel<4, 512, 512, 256, false>), dim3(grid), dim3(512), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
+            else hipLaunchKernelGGL((skm_count_kernel<4, 256, 256, 128, false>), dim3(grid * 2), dim3(256), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
         }
     }
     E2_TRY(hipGetLastError());
