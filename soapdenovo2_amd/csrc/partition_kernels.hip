@@ -398,10 +398,10 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     // index in the group, gwave = wave index in the group); the caller puts a barrier between the steps.
     struct Prep { bool is_rep; unsigned int n, incl; };
     // stage the window's records: 16 bytes per lane and step; the header word as it is, every payload word high dword first
-    auto p_stage = [&](auto gs_, int gtid, int nb, uint32_t w0, uint32_t wn) {
+    auto p_stage = [&](auto gs_, int gtid, int nb, int cl, uint32_t w0, uint32_t wn) {
         constexpr int GS = decltype(gs_)::value;
         uint32_t* const rlb = rl2[nb];
-        const unsigned int* const cids = chunk_ids2[nb];
+        const unsigned int* const cids = chunk_ids2[cl];
         for (uint32_t pc = gtid; pc < wn * PIECES; pc += GS) {
             const uint32_t ri = pc / PIECES, part = pc - ri * PIECES;
             const uint32_t gi = w0 + ri, cid = cids[gi >> e.rpc_log2];
@@ -417,28 +417,28 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     // the same in two halves with the memory latency in between: ask (16 bytes a lane from global memory straight into LDS,
     // lane l of a wave to wave base + 16 l: the staging layout but for the dword order), and later turn the dwords round in
     // place, every lane the pieces it asked for
-    auto p_stage_async = [&](int nb, uint32_t wn) {
+    auto p_stage_async = [&](int nb, int cl, uint32_t w0, uint32_t wn) {
         uint32_t* const rlb = rl2[nb];
-        const unsigned int* const cids = chunk_ids2[nb];
+        const unsigned int* const cids = chunk_ids2[cl];
         for (uint32_t p0 = 0; p0 < wn * PIECES; p0 += THREADS) {
             const uint32_t pc = p0 + threadIdx.x;
             if (pc < wn * PIECES) {
                 const uint32_t ri = pc / PIECES, part = pc - ri * PIECES;
-                const uint32_t cid = cids[ri >> e.rpc_log2];
+                const uint32_t gi = w0 + ri, cid = cids[gi >> e.rpc_log2];
                 if (cid != 0 && cid != 0xFFFFFFFFu) {
-                    const ulonglong2* src = (const ulonglong2*)(e.pool + ((uint64_t)(cid - 1) * e.rpc + (ri & (e.rpc - 1))) * (uint64_t)RW) + part;
+                    const ulonglong2* src = (const ulonglong2*)(e.pool + ((uint64_t)(cid - 1) * e.rpc + (gi & (e.rpc - 1))) * (uint64_t)RW) + part;
                     __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)(rlb + PAD + (p0 + wave * 64) * 4), 16, 0, 0);
                 }
             }
         }
     };
-    auto p_unpack = [&](int nb, uint32_t wn) {
+    auto p_unpack = [&](int nb, int cl, uint32_t w0, uint32_t wn) {
         uint32_t* const rlb = rl2[nb];
-        const unsigned int* const cids = chunk_ids2[nb];
+        const unsigned int* const cids = chunk_ids2[cl];
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         for (uint32_t pc = threadIdx.x; pc < wn * PIECES; pc += THREADS) {
             const uint32_t ri = pc / PIECES, part = pc - ri * PIECES;
-            const uint32_t cid = cids[ri >> e.rpc_log2];
+            const uint32_t cid = cids[(w0 + ri) >> e.rpc_log2];
             uint4 v = ((const uint4*)(rlb + PAD))[pc];                       // lo, hi, lo, hi
             if (cid == 0 || cid == 0xFFFFFFFFu) v = make_uint4(0, 0, 0, 0);
             ((uint4*)(rlb + PAD))[pc] = make_uint4(part ? v.y : v.x, part ? v.x : v.y, v.w, v.z);
@@ -644,7 +644,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
         pf_nrec = peek_cursor(blockIdx.x);
         if (threadIdx.x < e.maxc) pf_cid = e.chunk_tbl[(uint64_t)blockIdx.x * e.maxc + threadIdx.x];
     }
-    int b = 0;                                                            // the current partition's window buffer
+    int b = 0, cl = 0;                                                    // the current window's buffer, the current partition's chunk list
     bool staged = false;                                                  // its first window is already on its way into rl2[b] (asked for by the previous emit)
     for (uint32_t pid = blockIdx.x; pid < parts; pid += gridDim.x) {
         const uint32_t nrec = pf_nrec, my_cid = pf_cid;
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
         if (usable == 0) continue;                                        // (never one that was asked for)
         if (!staged) {
             K2_SYNC();                                                    // the previous partition's last readers of this chunk list
-            if (threadIdx.x < e.maxc) chunk_ids2[b][threadIdx.x] = my_cid;
+            if (threadIdx.x < e.maxc) chunk_ids2[cl][threadIdx.x] = my_cid;
         }
         K2_TICK(0);
         // key ranges still to count: (mask, val) on the slot hash; the stack pointer lives in a register of every lane
@@ -685,7 +685,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 const uint32_t wn = min((uint32_t)WIN, usable - w0);
                 if (!(window_ready && w0 == 0)) {
                     Prep ps;
-                    if (raw && w0 == 0) p_unpack(b, wn); else p_stage(whole, threadIdx.x, b, w0, wn);
+                    if (raw) p_unpack(b, cl, w0, wn); else p_stage(whole, threadIdx.x, b, cl, w0, wn);
                     raw = false;
                     K2_SYNC();
                     K2_TICK(2);
@@ -699,6 +699,9 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     K2_TICK(3);
                 }
                 window_ready = usable <= WIN;                             // a single window stays good for the other key ranges
+                // the partition's next window flies into the other buffer while this one is counted
+                const bool more = w0 + WIN < usable;
+                if (more && !(dbg & 16)) p_stage_async(b ^ 1, cl, w0 + WIN, min((uint32_t)WIN, usable - w0 - WIN));
                 const uint32_t total_occ = s_tot, share = (total_occ + THREADS - 1) / THREADS;
                 const uint32_t* const rl = rl2[b];
                 if (!__hip_atomic_load(&aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
@@ -740,7 +743,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 }
                 K2_TICK(4);
                 // the next partition's chunk list, for the prepare that runs beside this partition's last emit
-                if (threadIdx.x < e.maxc) chunk_ids2[b ^ 1][threadIdx.x] = pf_cid;
+                if (threadIdx.x < e.maxc) chunk_ids2[cl ^ 1][threadIdx.x] = pf_cid;
                 K2_SYNC();                                                  // the window and its tables are rewritten by the next one
                 if (w0 + WIN < usable) {                                    // more windows add to these counters: keep the halves small
                     for (int i = threadIdx.x; i < SLOTS; i += THREADS) {    // (they saturate at 63 / 255 in the end anyway)
@@ -748,6 +751,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                         for (int q = 0; q < 4; q++) set.cnt[q][i] = clip_halves_255(set.cnt[q][i]);
                     }
                 }
+                if (more && !(dbg & 16)) { b ^= 1; raw = true; }
                 K2_TICK(5);
             }
             if (aborted) {                                                // (read behind the window loop's last barrier: the same for every lane)
@@ -772,7 +776,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 // the other buffer, and a single-window partition keeps its prepared window for the remaining ranges.
                 const bool ahead = top == 0 && usable_next > 0 && !(dbg & 16);
                 const int sb = top == 0 ? b : b ^ 1;
-                if (ahead) { p_stage_async(b ^ 1, min((uint32_t)WIN, usable_next)); staged = true; }
+                if (ahead) { p_stage_async(b ^ 1, cl ^ 1, 0u, min((uint32_t)WIN, usable_next)); staged = true; }
                 {
                     Emit es;
                     e_list1(whole, threadIdx.x, wave, es);
@@ -798,7 +802,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
             mask = s_mask[top];
             val = s_val[top];
         }
-        if (staged) b ^= 1;
+        if (staged) { b ^= 1; cl ^= 1; }
     }
     K2_SYNC();
     for (int i = threadIdx.x; i < 256; i += THREADS) if (hist[i]) atomicAdd(&ctr->hist[i], (unsigned long long)hist[i]);
