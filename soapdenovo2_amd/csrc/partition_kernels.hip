@@ -351,6 +351,18 @@ __device__ __forceinline__ bool lds_put(LdsSet<NW, SLOTS>& t, const uint64_t (&k
 // memory latency with the LDS phases.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// inclusive prefix sum over the 64 lanes of a wave on the data-parallel-primitive path: four shifted adds inside each row
+// of 16 lanes, then the row totals broadcast forward -- no LDS round trips (the shuffle form is six ds_bpermute)
+__device__ __forceinline__ unsigned int wave_inclusive_sum(unsigned int x) {
+    x += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, false);   // row_shr:1
+    x += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, false);   // row_shr:2
+    x += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, false);   // row_shr:4
+    x += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, false);   // row_shr:8
+    x += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, false);   // row_bcast:15 into rows 1 and 3
+    x += (unsigned int)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, false);   // row_bcast:31 into rows 2 and 3
+    return x;
+}
+
 template <int NW, int SLOTS, int THREADS, int WIN, bool TIMERS>
 __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetParams sp, OccConst oc, DevCounters* ctr, int dbg) {
     constexpr int PW = E2Cfg<NW>::PW, RW = PW + 1, KW = E2Cfg<NW>::KW, NWAVE = THREADS / 64, PIECES = RW / 2, N2 = 2 * NW;
@@ -493,8 +505,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     auto p_flat1 = [&](int gtid, int gwave, int nb, Prep& ps) {
         ps.n = ps.is_rep ? ((rl2[nb][PAD + gtid * RD] >> 2) & 0x7Fu) : 0u;
         unsigned int incl = ps.n | (ps.is_rep ? 1u << 20 : 0u);                // k-mers below bit 20, representatives above
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) { const unsigned int o = __shfl_up(incl, d, 64); if (lane >= d) incl += o; }
+        incl = wave_inclusive_sum(incl);
         if (lane == 63) wave_cnt_f[gwave] = incl;
         ps.incl = incl;
     };
@@ -656,9 +667,9 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
         const uint32_t usable = min(nrec, e.maxc * e.rpc);               // an overfull partition was flagged by K1
         my_records += usable;
         if (usable == 0) continue;                                        // (never one that was asked for)
-        if (!staged) {
-            K2_SYNC();                                                    // the previous partition's last readers of this chunk list
+        if (!staged) {                                                    // (the list's last readers are at least an emit's barriers back)
             if (threadIdx.x < e.maxc) chunk_ids2[cl][threadIdx.x] = my_cid;
+            K2_SYNC();
         }
         K2_TICK(0);
         // key ranges still to count: (mask, val) on the slot hash; the stack pointer lives in a register of every lane
@@ -668,6 +679,9 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
         bool raw = staged;                                                // ... or window 0 as global_load_lds left it
         staged = false;
         for (;;) {
+            // (no barrier of its own for the flag: whoever read it last did so before the barriers of the emit or of the range
+            //  stack, and whoever sets it next does so behind the barriers of the prepare -- or, for a window kept from the
+            //  previous range, finds the 0 that is there already)
             if (threadIdx.x == 0) aborted = 0;
             if (dirty) {                                                  // (an emit leaves the set empty: it wipes what it reads)
                 for (int i = threadIdx.x; i < SLOTS; i += THREADS) {
@@ -678,8 +692,8 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     for (int q = 0; q < 5; q++) set.cnt[q][i] = 0;
                 }
                 dirty = false;
+                K2_SYNC();
             }
-            K2_SYNC();
             K2_TICK(1);
             for (uint32_t w0 = 0; w0 < usable; w0 += WIN) {
                 const uint32_t wn = min((uint32_t)WIN, usable - w0);
@@ -791,8 +805,8 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                         K2_TICK(11);
                         K2_SYNC();
                         e_copy(whole, threadIdx.x, sb, c0, cn);
-                        K2_SYNC();                                        // the staging area is filled again, or the buffer staged into
-                    }
+                        if (c0 + STAGE_CAP < n_live) K2_SYNC();           // the staging area is filled again (after the last chunk the
+                    }                                                     // buffer's next writer is several barriers away)
                     K2_TICK(8);
                 }
             }
