@@ -444,9 +444,10 @@ def main():
                     traffic = None
             # `bound` names the roofline the contract prices this path against (HBM bytes of a hash-table
             # formulation).  The kernel itself moves 0.15x those bytes and is limited elsewhere, see `limiter`.
-            limiter = ("LDS atomics on the partition's hot k-mers (same-address adds serialise) + the latency of the short per-partition phases "
-                       "(stage, prefix sum, emit) between workgroup barriers; vector ALU ~45 % busy, HBM ~7 % of peak "
-                       "(profiles/r02_k2_phase_cycles_20M.txt, DESIGN.md 3.2)") if engine == 2 else "random-atomic rate of the DRAM-resident set"
+            limiter = ("instruction issue: ~220 vector instructions per read over 4 waves a SIMD (the 88 KB LDS set allows one 1024-lane "
+                       "workgroup per CU), random 8-byte LDS accesses replayed for bank conflicts, nine workgroup barriers per partition; "
+                       "vector ALU ~44 % busy, HBM ~9 % of peak (profiles/r02b_pmc_sq_bench20M.json, profiles/r02b_k2_phase_cycles_20M.txt, "
+                       "DESIGN.md 3.2)") if engine == 2 else "random-atomic rate of the DRAM-resident set"
             rec["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                                "traffic": traffic, "kernel": kernel, "launches": launches, "avg_launch_ms": avg_ms,
                                "algorithmic_bytes_per_launch": per_launch, "limiter": limiter, **extra}

@@ -509,10 +509,10 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
         if (lane == 63) wave_cnt_f[gwave] = incl;
         ps.incl = incl;
     };
-    // the offsets table: entry k = first occurrence index of the k-th representative | its place in the window << 16 (at
-    // most 512 * 127 < 2^16 occurrences a window); the representative's copy count goes into the idle bits of its LDS header
-    // (a record has at most 127 k-mers, the count field is 16 bits wide), so the occurrence loop finds offsets, place,
-    // header and count in two dependent round trips
+    // the offsets table: entry k = first occurrence index of the k-th representative | its place in the window << 16 | its
+    // flank bits << 25 (at most 512 * 127 < 2^16 occurrences a window): all the occurrence loop needs to address the bases
+    // of an occurrence, so the header (ordinal, copy count) is off the critical path.  The representative's copy count goes
+    // into the idle bits of its LDS header (a record has at most 127 k-mers, the count field is 16 bits wide).
     auto p_flat2 = [&](auto gs_, int gtid, int gwave, int nb, Prep& ps) {
         constexpr int GW = decltype(gs_)::value / 64;
         unsigned int base = 0, tot = 0;
@@ -523,10 +523,11 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
         const unsigned int share = (tot + THREADS - 1) / THREADS;
         if (ps.is_rep) {
             uint32_t* me = rl2[nb] + PAD + gtid * RD;
-            me[0] = (me[0] & ~0x3FE00u) | ((dcount[gtid] - 1u) << 9);                // n < 128 keeps bits 2..8, copies - 1 <= 511
+            const uint32_t h0 = me[0];
+            me[0] = (h0 & ~0x3FE00u) | ((dcount[gtid] - 1u) << 9);                   // n < 128 keeps bits 2..8, copies - 1 <= 511
             const unsigned int upto = base + ps.incl, k = (upto >> 20) - 1;          // this representative's rank
             const unsigned int o_hi = upto & ((1u << 20) - 1), o_lo = o_hi - ps.n;
-            noff[k] = o_lo | ((unsigned int)gtid << 16);
+            noff[k] = o_lo | ((unsigned int)gtid << 16) | ((h0 & 3u) << 25);          // bit 25 = has_right, bit 26 = has_left
             // lanes whose share starts inside this record: l * share in [o_lo, o_hi)
             const float inv = 1.0f / (float)share;
             auto div_up = [&](unsigned int x) {                                // ceil(x / share), x < 2^16
@@ -723,16 +724,16 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     const uint32_t idx1 = min(total_occ, idx + share);
                     if (idx < idx1) {
                         uint32_t k = first_rec[threadIdx.x];
-                        uint32_t o_hi = noff[k + 1] & 0xFFFFu;
+                        uint32_t nk = noff[k], nk1 = noff[k + 1];              // idx lies inside representative k
                         for (; idx < idx1; idx++) {
-                            k += idx >= o_hi ? 1u : 0u;
-                            const uint32_t nk = noff[k], o_lo = nk & 0xFFFFu;
-                            o_hi = noff[k + 1] & 0xFFFFu;
-                            const uint32_t* rec = rl + PAD + (nk >> 16) * RD;
-                            const uint32_t h_lo = rec[0], h_hi = rec[1];
-                            const uint32_t copies = ((h_lo >> 9) & 0x1FFu) + 1u;
+                            const uint32_t o_lo = nk & 0xFFFFu, o_hi = nk1 & 0xFFFFu;
+                            const uint32_t* rec = rl + PAD + ((nk >> 16) & 0x1FFu) * RD;
+                            const uint32_t hl = (nk >> 26) & 1u, hr = (nk >> 25) & 1u, n = o_hi - o_lo;
                             const uint32_t t = idx - o_lo;
-                            const uint32_t hl = (h_lo >> 1) & 1u, hr = h_lo & 1u, n = (h_lo >> 2) & 0x7Fu;
+                            // the table entries of the next occurrence, asked for before this one is worked on
+                            k += idx + 1 >= o_hi ? 1u : 0u;
+                            nk = noff[k];
+                            nk1 = noff[k + 1];
                             uint32_t f[N2], rc[N2], prev, next;
                             occ_extract<NW>(rec + 2, (int)(hl + t), K, oc, f, rc, prev, next);
                             const bool lt = occ_less<N2>(f, rc);
@@ -747,6 +748,8 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                             if (dbg & 1) { if (hh == 0x1234) aborted = 1; continue; }      // measurement aid: extraction only
                             uint64_t kw[KW];
                             occ_key63<NW>(c, kw);
+                            const uint32_t h_lo = rec[0], h_hi = rec[1];
+                            const uint32_t copies = ((h_lo >> 9) & 0x1FFu) + 1u;
                             const uint64_t ord = ((((uint64_t)h_hi << 32) | h_lo) >> SKM_ORD_SHIFT) + t;
                             if (!lds_put<NW, SLOTS>(set, kw, hh, left, right, ord, copies)) {
                                 aborted = 1;
@@ -1213,8 +1216,8 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     if (h.e2_flags & F_OUT) { pg_set_error("partition engine: more distinct k-mers than the export array holds (raise log2_slots)"); return PG_ENOMEM; }
     if (h.e2_flags & F_SPLIT) { pg_set_error("partition engine: a partition could not be split to fit the LDS set"); return PG_ENOMEM; }
     if (dbg & 2) {
-        static const char* names[12] = {"meta+sync", "clear (after a dropped attempt) + barrier", "stage", "barrier + flatten + compaction", "occurrences (own share)",
-                                        "wait for the slowest lane", "emit: list the live slots", "emit: barrier", "emit: barrier + coalesced copy out", "dropped attempts",
+        static const char* names[12] = {"partition header", "clear after a dropped attempt", "window: unpack / stage + barrier", "barrier + flatten (prefix sum, tables) + barriers", "occurrences (thread 0's share)",
+                                        "wait for the slowest wave + barrier", "emit: ask for the next window, list the live slots", "-", "emit: barrier + coalesced copy out", "dropped attempts (count)",
                                         "dedupe (hash, probe, compare)", "emit: finalise into the staging area"};
         unsigned long long tot = 0;
         for (int i = 0; i < 12; i++) if (i != 9) tot += h.phase[i];
