@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--kmer", type=int, default=31)
     ap.add_argument("--sets", type=int, default=8)
     ap.add_argument("--single", action="store_true", help="only the default engine, no comparison")
+    ap.add_argument("--variant", action="append", default=[], help="extra run of the default engine with these variables, e.g. PG_NO_THP=1,PG_GROW_VERBOSE=1")
     ap.add_argument("--expect", default="", help="result.json of an earlier run with the same arguments: only the default engine runs and its md5s are compared")
     a = ap.parse_args()
     os.makedirs(a.out, exist_ok=True)
@@ -31,14 +32,17 @@ def main():
     runs = (("partitions", {}), ("global_set", {"PG_ENGINE": "1"}))
     if a.expect or a.single:
         runs = runs[:1]
-    for tag, env in runs:
+    for v in a.variant:
+        runs = runs + ((v, dict(kv.split("=", 1) for kv in v.split(","))),)
+    for ri, (tag, env) in enumerate(runs):
+        pre = tag if tag in ("partitions", "global_set") else "variant%d" % ri
         t = time.time()
-        r = subprocess.run([api.binary(False), "pregraph", "-s", cfg, "-K", str(a.kmer), "-o", os.path.join(a.out, tag), "-p", str(a.sets)],
+        r = subprocess.run([api.binary(False), "pregraph", "-s", cfg, "-K", str(a.kmer), "-o", os.path.join(a.out, pre), "-p", str(a.sets)],
                            capture_output=True, text=True, env=dict(os.environ, PG_HOST_VERBOSE="1", **env))
         res[tag] = {"wall_s": time.time() - t, "rc": r.returncode,
-                    "log": [l for l in r.stderr.splitlines() if "[cli]" in l or "Time spent on" in l or "replay set" in l or "node(s) allocated" in l or "edge(s)" in l or "pre-arc" in l or "again" in l]}
+                    "log": [l for l in r.stderr.splitlines() if "[cli]" in l or "Time spent on" in l or "replay set" in l or "node(s) allocated" in l or "edge(s)" in l or "pre-arc" in l or "again" in l or l.startswith("grow ")]}
         if r.returncode == 0:
-            res[tag]["md5"] = md5s(os.path.join(a.out, tag))
+            res[tag]["md5"] = md5s(os.path.join(a.out, pre))
         else:
             res[tag]["stderr_tail"] = r.stderr[-1500:]
     if a.expect and os.path.exists(a.expect):

@@ -286,37 +286,61 @@ struct HSet {
         const uint64_t old = size;
         if (n > array.n) array.reset(n, old);
         for (uint64_t i = old; i < n; i++) array[i].seq.w[0] = EMPTY;
-        // one state byte a slot: 0 free, 1 old element not moved yet, 2 placed.  The old slots are visited in index
-        // order (that order is what the reference's layout depends on), but the home slot of the element AHEAD slots
-        // further on is computed and prefetched now, so the cache misses of consecutive re-homings overlap.
-        enum : uint8_t { FREE = 0, PENDING = 1, PLACED = 2 };
-        std::vector<uint8_t> st(n, FREE);
-        for (uint64_t i = 0; i < old; i++) st[i] = occ[i] ? PENDING : FREE;
+        // one state byte a slot: 0 free, 1 placed, 2 old element not moved yet -- the occupancy bytes themselves, shifted
+        // for the duration of the move (so there is no pass to build them and none to turn them back).  The old slots are
+        // visited in index order (that order is what the reference's layout depends on); the cache misses are taken
+        // ahead of time in two steps: LOOK_FAR slots ahead the home of the element is computed and its state byte and slot are
+        // prefetched; LOOK_NEAR slots ahead that state byte is looked at, and if an unmoved old element sits there -- it will
+        // be kicked out and re-homed next (a fifth of all moves), a home that depends on a slot not read yet -- its own
+        // home is computed and prefetched too.
+        enum : uint8_t { FREE = 0, PLACED = 1, PENDING = 2 };
+        std::vector<uint8_t> st = std::move(occ);
+        st.resize(n, FREE);
+        for (uint64_t i = 0; i < old; i++) st[i] <<= 1;
         set_size(n);
         max = (uint64_t)((float)n * lf);
-        constexpr uint64_t AHEAD = 24;
-        uint64_t ring[AHEAD];
-        auto look = [&](uint64_t j) {
+        constexpr uint64_t LOOK_NEAR = 16, LOOK_FAR = 40;
+        uint64_t ring[LOOK_FAR];
+        auto look_far = [&](uint64_t j) {
             if (j < old && st[j] == PENDING) {
                 const uint64_t h = home(array[j].seq);
-                ring[j % AHEAD] = h;
+                ring[j % LOOK_FAR] = h;
                 __builtin_prefetch(&st[h], 1);
                 __builtin_prefetch(&array[h], 1);
+                __builtin_prefetch((const char*)&array[h] + sizeof(HNode<NW>) - 1, 1);   // (a slot may straddle two lines)
             }
         };
-        for (uint64_t j = 0; j < std::min<uint64_t>(AHEAD, old); j++) look(j);
+        auto look_near = [&](uint64_t j) {
+            if (j < old && st[j] == PENDING) {
+                const uint64_t h = ring[j % LOOK_FAR];
+                if (st[h] == PENDING && h != j) {
+                    const uint64_t h2 = home(array[h].seq);
+                    __builtin_prefetch(&st[h2], 1);
+                    __builtin_prefetch(&array[h2], 1);
+                    __builtin_prefetch((const char*)&array[h2] + sizeof(HNode<NW>) - 1, 1);
+                }
+            }
+        };
+        const auto tg1 = std::chrono::steady_clock::now();
+        uint64_t n_kick = 0, n_moved = 0;
+        for (uint64_t j = 0; j < std::min<uint64_t>(LOOK_FAR, old); j++) look_far(j);
+        for (uint64_t j = 0; j < std::min<uint64_t>(LOOK_NEAR, old); j++) look_near(j);
         for (uint64_t i = 0; i < old; i++) {
             const bool mine = st[i] == PENDING;
-            uint64_t hc = mine ? ring[i % AHEAD] : 0;
-            look(i + AHEAD);                                      // reuses ring slot i % AHEAD, read just above
+            uint64_t hc = mine ? ring[i % LOOK_FAR] : 0;
+            look_far(i + LOOK_FAR);                                    // reuses ring slot i % LOOK_FAR, read just above
+            look_near(i + LOOK_NEAR);
             if (!mine) continue;
             HNode<NW> cur = array[i];
             st[i] = FREE;
+            array[i].seq.w[0] = EMPTY;                            // vacated (whoever lands here later overwrites it)
             for (;;) {
                 while (st[hc] == PLACED) { if (++hc == size) hc = 0; }
                 const bool kick = st[hc] == PENDING;              // an old element still sits there: it goes next
                 st[hc] = PLACED;
+                n_moved++;
                 if (kick) {
+                    n_kick++;
                     std::swap(cur, array[hc]);
                     hc = home(cur.seq);
                 } else {
@@ -325,10 +349,12 @@ struct HSet {
                 }
             }
         }
-        occ.assign(n, 0);
-        for (uint64_t i = 0; i < n; i++) occ[i] = st[i] == PLACED;
-        for (uint64_t i = 0; i < old; i++)
-            if (!occ[i]) array[i].seq.w[0] = EMPTY;               // vacated and not reused
+        occ = std::move(st);
+        if (getenv("PG_GROW_VERBOSE")) {
+            auto d = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
+            fprintf(stderr, "grow %llu -> %llu: prepare %.3fs, re-home %.3fs (%llu moved, %llu kicks)\n", (unsigned long long)old, (unsigned long long)n, d(tg0, tg1),
+                    d(tg1, std::chrono::steady_clock::now()), (unsigned long long)n_moved, (unsigned long long)n_kick);
+        }
     }
     // the growth test of put_kmerset (newhash.c:477) for a static (-a) pool only raises the load factor: the reference
     // compares its float load_factor with the double 0.88 (newhash.c:355), which stays true after the assignment, so its
@@ -344,7 +370,11 @@ struct HSet {
         before_put(static_pool);
         put_new_at(nd, home(nd.seq));
     }
-    void prefetch_put(uint64_t hc) const { __builtin_prefetch(&array[hc], 1); __builtin_prefetch(&occ[hc], 1); }
+    void prefetch_put(uint64_t hc) const {
+        __builtin_prefetch(&array[hc], 1);
+        __builtin_prefetch((const char*)&array[hc] + sizeof(HNode<NW>) - 1, 1);      // (a slot may straddle two lines)
+        __builtin_prefetch(&occ[hc], 1);
+    }
     void put_new_at(const HNode<NW>& nd, uint64_t hc) {                 // the caller ran before_put
         while (occ[hc]) { if (++hc == size) hc = 0; }
         occ[hc] = 1;
