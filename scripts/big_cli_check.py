@@ -28,6 +28,7 @@ def main():
     fq, cfg = os.path.join(a.out, "reads.fq"), os.path.join(a.out, "lib.cfg")
     write_fastq_fast(fq, gpu_codes(a.genome, a.reads, a.read_len, a.err, 7))
     synth.write_config(cfg, fq, a.read_len)
+    os.sync()                                       # the generator's write-back is not part of the commands being timed
     res = {"workload": vars(a)}
     runs = (("partitions", {}), ("global_set", {"PG_ENGINE": "1"}))
     if a.expect or a.single:
@@ -38,9 +39,9 @@ def main():
         pre = tag if tag in ("partitions", "global_set") else "variant%d" % ri
         t = time.time()
         r = subprocess.run([api.binary(False), "pregraph", "-s", cfg, "-K", str(a.kmer), "-o", os.path.join(a.out, pre), "-p", str(a.sets)],
-                           capture_output=True, text=True, env=dict(os.environ, PG_HOST_VERBOSE="1", **env))
+                           capture_output=True, text=True, env={**os.environ, "PG_HOST_VERBOSE": "1", **env})
         res[tag] = {"wall_s": time.time() - t, "rc": r.returncode,
-                    "log": [l for l in r.stderr.splitlines() if "[cli]" in l or "Time spent on" in l or "replay set" in l or "node(s) allocated" in l or "edge(s)" in l or "pre-arc" in l or "again" in l or l.startswith("grow ")]}
+                    "log": [l for l in r.stderr.splitlines() if "[cli]" in l or "Time spent on" in l or "replay set" in l or "node(s) allocated" in l or "edge(s)" in l or "pre-arc" in l or "again" in l or l.startswith("grow ") or l.startswith("reader:")]}
         if r.returncode == 0:
             res[tag]["md5"] = md5s(os.path.join(a.out, pre))
         else:

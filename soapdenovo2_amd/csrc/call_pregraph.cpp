@@ -219,7 +219,7 @@ public:
         if (keep_) { const int32_t l32 = len; keep_append(b->h_words + b->n_words, nw, &l32, 1); }   // pass 2 threads the same reads again
         b->h_off[b->n_reads] = b->n_words;
         b->h_base[b->n_reads] = b->n_kmers;
-        if (b->n_reads == 0) b->first_len = len; else if (len != b->first_len) b->uniform = false;
+        note_length(b, len);
         b->n_words += nw;
         b->n_kmers += (uint64_t)(len - K_ + 1);
         b->n_reads++;
@@ -239,11 +239,12 @@ public:
                 take = std::min(take, (max_words_ - b->n_words) / wpr);
                 if (take == 0) { submit(); continue; }
                 memcpy(b->h_words + b->n_words, words + at, take * wpr * sizeof(uint64_t));
-                if (b->n_reads == 0) b->first_len = len; else if (len != b->first_len) b->uniform = false;
-                for (size_t i = 0; i < take; i++) {
-                    b->h_off[b->n_reads + i] = b->n_words + i * wpr;
-                    b->h_base[b->n_reads + i] = b->n_kmers + i * kpr;
-                }
+                note_length(b, len);
+                if (!b->uniform)                                    // (a uniform batch goes to the device without index arrays)
+                    for (size_t i = 0; i < take; i++) {
+                        b->h_off[b->n_reads + i] = b->n_words + i * wpr;
+                        b->h_base[b->n_reads + i] = b->n_kmers + i * kpr;
+                    }
                 if (keep_) keep_append(words + at, take * wpr, lens + r, take);
                 b->n_words += take * wpr; b->n_kmers += take * kpr; b->n_reads += take;
                 accepted_ += (long long)take;
@@ -261,7 +262,7 @@ public:
                 if (keep_) keep_append(words + at, nw, &lens[r], 1);
                 b->h_off[b->n_reads] = b->n_words;
                 b->h_base[b->n_reads] = b->n_kmers;
-                if (b->n_reads == 0) b->first_len = len; else if (len != b->first_len) b->uniform = false;
+                note_length(b, len);
                 b->n_words += nw;
                 b->n_kmers += (uint64_t)(len - K_ + 1);
                 b->n_reads++;
@@ -269,6 +270,16 @@ public:
             }
             at += nw;
         }
+    }
+    // first read of a batch, or a read of another length: from then on the batch needs its index arrays, and the block
+    // copies above did not fill them while every read had the same length
+    void note_length(Buf* b, int len) {
+        if (b->n_reads == 0) { b->first_len = len; return; }
+        if (!b->uniform || len == b->first_len) return;
+        const size_t wpr = pg_packed_words((uint32_t)b->first_len);
+        const uint64_t kpr = (uint64_t)(b->first_len - K_ + 1);
+        for (size_t i = 0; i < b->n_reads; i++) { b->h_off[i] = i * wpr; b->h_base[i] = i * kpr; }
+        b->uniform = false;
     }
     virtual bool finish_ok() = 0;
     uint64_t total_kmers() const { return ord_; }

@@ -373,21 +373,22 @@ long long stream_file_parallel(const InputFile& in, const std::string& path, boo
     std::vector<char> win;
     std::vector<size_t> cuts;
     std::vector<std::pair<size_t, size_t>> bufs;
-    std::vector<PackedRun> runs(nt);
+    // two sets of runs: while the caller's thread hands one window's runs over (copies into the batch buffers: serial, and
+    // about as long as the parsing itself once a dozen threads parse), the threads already cut and parse the next window
+    std::vector<PackedRun> run_sets[2] = {std::vector<PackedRun>(nt), std::vector<PackedRun>(nt)};
     std::vector<std::vector<uint8_t>> codes(nt, std::vector<uint8_t>((size_t)std::max(in.max_read_len, 1) + 8));
     std::string last_buf;                                   // the buffer parsed last, for the N x 32768 rerun
     size_t carry = 0;
-    bool any = false;
     long long n_records = 0;
     bool stopped = false;
-    auto deliver = [&](int used) {
+    auto deliver = [&](std::vector<PackedRun>& runs, int used) {
         for (int t = 0; t < used && !stopped; t++) {
             PackedRun& r = runs[t];
             n_records += r.records;
             if (!r.lens.empty() && !on_run(r)) stopped = true;
         }
     };
-    auto parse_all = [&]() {
+    auto parse_all = [&](std::vector<PackedRun>& runs) {
         // contiguous groups of buffers of about equal size, one per thread
         size_t total = 0;
         for (auto& b : bufs) total += b.second - b.first;
@@ -407,11 +408,10 @@ long long stream_file_parallel(const InputFile& in, const std::string& path, boo
         for (int t = 1; t < nt; t++) pool.emplace_back(body, t);
         body(0);
         for (auto& th : pool) th.join();
-        deliver(nt);
     };
     // a regular file is read with a few preads side by side (one thread copying out of the page cache is slower than the
     // parsers); a pipe (.gz) is read as it comes
-    double t_parse = 0, t_wait = 0;
+    double t_parse = 0, t_hand = 0;
     uint64_t file_off = 0;
     auto read_window = [&](char* dst, size_t want) -> size_t {
         if (src.sequential()) return fread(dst, 1, want, src.fp);
@@ -445,20 +445,11 @@ long long stream_file_parallel(const InputFile& in, const std::string& path, boo
     size_t got = 0;
     win.resize(window_chunks * CHUNK);
     got = read_window(win.data(), window_chunks * CHUNK);
-    for (;;) {
-        if (got == 0) {
-            // the file ended on a chunk boundary: the reference parses its previous buffer again and loses the tail it
-            // had cached (prlHashReads.c:873-877)
-            fprintf(stderr, "Warning : aio_return zero, the size of input file must be N * 32768.\n");
-            if (any && !stopped) {
-                runs[0].clear();
-                parse_range(in, fastq, last_buf.data(), last_buf.size(), codes[0], runs[0]);
-                deliver(1);
-            }
-            break;
-        }
-        if (stopped) break;
-        any = true;
+    // One window (`win`, `carry` cached bytes + `got` fresh ones, got > 0): cut, parse into `runs`, and meanwhile read the
+    // next window; leaves win / carry / got describing that next window.  Returns true when this window ended the file
+    // inside a chunk (nothing follows).
+    auto cut_and_parse = [&](std::vector<PackedRun>& runs) -> bool {
+        const auto tr0 = std::chrono::steady_clock::now();
         const size_t n_full = got / CHUNK, rem = got % CHUNK;
         cuts.assign(n_full, 0);
         {
@@ -478,27 +469,59 @@ long long stream_file_parallel(const InputFile& in, const std::string& path, boo
             bufs.emplace_back(begin, end);
             begin = end;
         }
-        if (rem) bufs.emplace_back(begin, carry + got);       // the short last chunk goes out whole, behind the cached tail
-        if (rem) { parse_all(); break; }
-        if (stopped) break;
+        if (rem) {                                             // the short last chunk goes out whole, behind the cached tail
+            bufs.emplace_back(begin, carry + got);
+            parse_all(runs);
+            t_parse += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
+            return true;
+        }
         last_buf.assign(win.data() + bufs.back().first, bufs.back().second - bufs.back().first);
         const size_t tail = carry + got - begin;
         next_win.resize(tail + window_chunks * CHUNK);
         memcpy(next_win.data(), win.data() + begin, tail);
         size_t next_got = 0;
-        const auto tr0 = std::chrono::steady_clock::now();
         std::thread reader([&]() { next_got = read_window(next_win.data() + tail, window_chunks * CHUNK); });
-        parse_all();
-        const auto tr1 = std::chrono::steady_clock::now();
+        parse_all(runs);
         reader.join();
-        t_parse += std::chrono::duration<double>(tr1 - tr0).count();
-        t_wait += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr1).count();
         win.swap(next_win);
         carry = tail;
         got = next_got;
+        t_parse += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
+        return false;
+    };
+    if (got == 0) {
+        // (an empty file: the reference warns as well, and has no previous buffer to parse again)
+        fprintf(stderr, "Warning : aio_return zero, the size of input file must be N * 32768.\n");
+    } else {
+        int cur = 0;
+        bool last = cut_and_parse(run_sets[0]);
+        for (;;) {
+            // run_sets[cur] holds a parsed window; the next one, if there is one, is cut and parsed by the threads while
+            // this thread hands the runs over
+            const bool more = !last && got != 0;
+            bool next_last = false;
+            std::thread ahead;
+            if (more) ahead = std::thread([&, cur]() { next_last = cut_and_parse(run_sets[cur ^ 1]); });
+            const auto th0 = std::chrono::steady_clock::now();
+            deliver(run_sets[cur], nt);
+            t_hand += std::chrono::duration<double>(std::chrono::steady_clock::now() - th0).count();
+            if (ahead.joinable()) ahead.join();
+            if (last || stopped) break;
+            if (!more) {
+                // the file ended on a chunk boundary: the reference parses its previous buffer again and loses the tail it
+                // had cached (prlHashReads.c:873-877)
+                fprintf(stderr, "Warning : aio_return zero, the size of input file must be N * 32768.\n");
+                run_sets[0][0].clear();
+                parse_range(in, fastq, last_buf.data(), last_buf.size(), codes[0], run_sets[0][0]);
+                deliver(run_sets[0], 1);
+                break;
+            }
+            cur ^= 1;
+            last = next_last;
+        }
     }
     src.close();
-    if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "reader: %.2fs parsing + handing over, %.2fs more waiting for the file (%d threads)\n", t_parse, t_wait, nt);
+    if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "reader: %.2fs cutting + parsing (with the next window's read), %.2fs handing over beside it (%d threads)\n", t_parse, t_hand, nt);
     return n_records;
 }
 
