@@ -146,6 +146,10 @@ int pg_host_graph_add_packed(pg_graph *g, const uint64_t *words, const int32_t *
 int pg_host_graph_add_reads(pg_graph *g, const uint8_t *codes, const int32_t *lens, uint64_t n_reads, uint64_t stride,
                             int n_threads);
 int pg_host_graph_finish(pg_graph *g, int *out_num_vertex, int *out_num_edge, long long *out_num_prearc);
+/* A caller whose process ends right after call_pregraph (the stand-alone executable) says so: the k-mer sets -- tens of
+ * gigabytes at scale, seconds to unmap -- are then left to the kernel's exit path instead of being released page by page.
+ * Default 0: everything is released before pg_host_graph_finish / call_pregraph return (the `all` pipeline goes on). */
+void pg_process_exits_after_this(int yes);
 
 /* The layout replay alone (init_kmerset / put_kmerset / encap_kmerset, newhash.c:200-233,340-528): for every
  * record the slot it occupies in its reference k-mer set, and per set the final table size. */

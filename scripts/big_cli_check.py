@@ -42,6 +42,7 @@ def main():
                            capture_output=True, text=True, env={**os.environ, "PG_HOST_VERBOSE": "1", **env})
         res[tag] = {"wall_s": time.time() - t, "rc": r.returncode,
                     "log": [l for l in r.stderr.splitlines() if "[cli]" in l or "Time spent on" in l or "replay set" in l or "node(s) allocated" in l or "edge(s)" in l or "pre-arc" in l or "again" in l or l.startswith("grow ") or l.startswith("reader:")]}
+        open(os.path.join(os.path.dirname(a.out.rstrip("/")) or ".", "stderr_%s.txt" % pre), "w").write(r.stderr)
         if r.returncode == 0:
             res[tag]["md5"] = md5s(os.path.join(a.out, pre))
         else:

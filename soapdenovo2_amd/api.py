@@ -138,7 +138,7 @@ def lib() -> C.CDLL:
 
 EXPORTED_SYMBOLS = [
     "pg_last_error", "pg_version", "call_pregraph", "call_pregraph_127mer", "pg_packed_words", "pg_pack_read",
-    "pg_host_build_graph", "pg_host_graph_begin", "pg_host_graph_add_reads", "pg_host_graph_finish", "pg_host_graph_resolve_repeats", "pg_host_graph_add_packed", "pg_graph_use_device", "pg_sort_records", "pg_expect_kmers", "pg_create_sized", "pg_graph_begin", "pg_graph_begin_streamed", "pg_host_read_all", "pg_host_replay_layout", "pg_host_write_kmerfreq", "pg_create", "pg_create_engine", "pg_destroy", "pg_reset", "pg_set_autogrow", "pg_count_reads", "pg_route_count",
+    "pg_host_build_graph", "pg_host_graph_begin", "pg_host_graph_add_reads", "pg_host_graph_finish", "pg_process_exits_after_this", "pg_host_graph_resolve_repeats", "pg_host_graph_add_packed", "pg_graph_use_device", "pg_sort_records", "pg_expect_kmers", "pg_create_sized", "pg_graph_begin", "pg_graph_begin_streamed", "pg_host_read_all", "pg_host_replay_layout", "pg_host_write_kmerfreq", "pg_create", "pg_create_engine", "pg_destroy", "pg_reset", "pg_set_autogrow", "pg_count_reads", "pg_route_count",
     "pg_route_scatter", "pg_count_records", "pg_skm_route", "pg_skm_ingest", "pg_distinct", "pg_stats", "pg_table_info", "pg_finalize", "pg_export",
     "pg_export_take", "pg_export_take_ws", "pg_sort_records_ws", "pg_device_free", "pg_set_counts", "pg_last_put", "pg_host_last_put_matters", "pg_comm_unique_id", "pg_comm_create", "pg_comm_create_local", "pg_comm_destroy", "pg_comm_rank", "pg_comm_size",
     "pg_comm_transport", "pg_comm_stats", "pg_exchange_counts", "pg_exchange_records", "pg_exchange_allreduce_u64",

@@ -485,6 +485,8 @@ int run(int argc, char** argv, bool mer127) {
     auto nowf = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
     double tv = nowf();
     auto lap = [&](const char* what) { if (verbose) { const double t = nowf(); fprintf(stderr, "[cli] %s: %.2fs\n", what, t - tv); tv = t; } };
+    const double t_begin = tv;
+    auto mark = [&](const char* what) { if (verbose) fprintf(stderr, "[cli]   at %.2fs: %s\n", nowf() - t_begin, what); };
     fprintf(stderr, "\n********************\nPregraph\n********************\n\n");
     Options o = parse_args(argc, argv, mer127);
     int K = o.K;                                                   // pregraph.c:71-97
@@ -657,12 +659,15 @@ int run(int argc, char** argv, bool mer127) {
     int engine = 2;
     if (const char* e = getenv("PG_ENGINE")) engine = atoi(e);
     for (int attempt = 0;; attempt++) {
+        mark("input files sized");
         ctx = pg_create_sized(device, K, mer127 ? 1 : 0, o.sets, log2_slots, engine, est_kmers);
         if (!ctx) die("pg_create");
+        mark("device context created (HIP start-up, record pool, export array)");
         if (attempt == 0) fprintf(stderr, "%d k-mer set(s) on HIP device %d.\n", o.sets, device);
         bool ok = true;
         {
             Pass1 p1(ctx, K, batch_words, batch_reads);
+            mark("pinned batch buffers allocated");
             if (attempt == 0) {
                 p1.keep_reads(keep_budget);
                 for (const pg::InputFile& f : files) {
@@ -679,7 +684,9 @@ int run(int argc, char** argv, bool mer127) {
             } else {
                 for (const pg::InputFile& f : files) pg::stream_reads(f, p1);
             }
+            mark("files read");
             ok = p1.finish_ok();
+            mark("last batch cut on the device");
             total_kmers = p1.total_kmers();
             if (attempt == 0) have_kept = p1.take_kept(kept);
         }

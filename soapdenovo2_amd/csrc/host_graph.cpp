@@ -1045,7 +1045,10 @@ struct ParallelEdgeBuilder {
     static bool gz_member(const std::string& text, std::vector<uint8_t>& out) {
         z_stream z;
         memset(&z, 0, sizeof(z));
-        if (deflateInit2(&z, Z_DEFAULT_COMPRESSION, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+        // level 1: <prefix>.edge.gz is a multi-member gzip file here anyway (never the reference's bytes, always its text), the
+        // later stages only gzread it, and at level 6 the deflate was most of the edge stage's host time
+        static const int level = getenv("SOAPDENOVO2_AMD_GZIP_LEVEL") ? std::max(1, std::min(9, atoi(getenv("SOAPDENOVO2_AMD_GZIP_LEVEL")))) : 1;
+        if (deflateInit2(&z, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
         out.resize(deflateBound(&z, (uLong)text.size()) + 64);
         z.next_in = (Bytef*)text.data(); z.avail_in = (uInt)text.size();
         z.next_out = out.data(); z.avail_out = (uInt)out.size();
@@ -1632,6 +1635,7 @@ struct PreArcs {
 // The graph kept alive between edge construction and pass 2.
 struct GraphHandleBase {
     virtual ~GraphHandleBase() {}
+    virtual void shutdown() = 0;
     virtual int add_reads(const uint8_t* codes, const int32_t* lens, uint64_t n, uint64_t stride, int n_threads) = 0;
     virtual int add_packed(const uint64_t* words, const int32_t* lens, uint64_t n, int n_threads) = 0;
     virtual int finish(long long* n_arcs) = 0;
@@ -1672,10 +1676,12 @@ struct GraphHandle : GraphHandleBase {
     std::vector<uint32_t> dev_walks;
     std::vector<uint16_t> dev_walk_len;
 
-    ~GraphHandle() override {
+    ~GraphHandle() override { shutdown(); }
+    // everything but the memory: threads, files, the device copy
+    void shutdown() override {
         if (vertex_thread.joinable()) vertex_thread.join();
-        if (path_fp) fclose(path_fp);
-        if (dev) p2_destroy(dev);
+        if (path_fp) { fclose(path_fp); path_fp = nullptr; }
+        if (dev) { p2_destroy(dev); dev = nullptr; }
     }
     int use_device(int device) override {
         if (dev_edges) {                             // the sets live on the device, tagged there: pass 2 stays there
@@ -1773,7 +1779,16 @@ struct GraphHandle : GraphHandleBase {
     bool vertex_started = false;
     void start_vertex_writer() {
         vertex_started = true;
-        vertex_thread = std::thread([this]() { vertex_rc = write_vertex_file<NW>(g, prefix, vertex_count, true); });
+        vertex_thread = std::thread([this]() {
+            const double tv0 = now();
+            vertex_rc = write_vertex_file<NW>(g, prefix, vertex_count, true);
+            const double tv1 = now();
+            // <prefix>.vertex was the last reader of the host copy of the k-mer sets (the edges were built on the device copy,
+            // pass 2 threads the reads there): tens of gigabytes go back now, beside pass 2, instead of at the very end
+            for (auto& hs : g.sets) { hs.array.release(); std::vector<uint8_t>().swap(hs.occ); }
+            for (auto& tm : g.touched_map) tm.release();
+            if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "vertex writer: %.2fs, host k-mer sets released: %.2fs (beside the edges and pass 2)\n", tv1 - tv0, now() - tv1);
+        });
     }
     int dev_begin() {
         if (dev_ready) return PG_OK;
@@ -2051,7 +2066,9 @@ struct GraphHandle : GraphHandleBase {
         fprintf(stderr, "Time spent on threading reads: %.1fs, on folding pre-arcs: %.1fs.\n", t_thread, t_fold);
         if (n_arcs) *n_arcs = arc_count;
         if (vertex_started) {
+            const double tw0 = now();
             if (vertex_thread.joinable()) vertex_thread.join();
+            if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "finish: waited %.2fs for the vertex writer\n", now() - tw0);
             if (vertex_rc) return vertex_rc;
             num_vt = vertex_count;
             fprintf(stderr, "%d vertex(es) output.\n", num_vt);
@@ -2076,6 +2093,7 @@ static GraphHandleBase* graph_begin(const uint64_t* records, uint64_t n, const u
     fprintf(stderr, "Time spent on rebuilding the k-mer set layout: %.1fs.\n", now() - t0);
     t0 = now();
     if (device >= 0 && !getenv("SOAPDENOVO2_AMD_TIPS_HOST") && h->dev_open(device) != PG_OK) { delete h; return nullptr; }
+    if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "k-mer sets uploaded to the device: %.2fs\n", now() - t0);
     if (cut_single) h->g.remove_single_tips();
     h->g.remove_minor_tips();
     if (h->g.tip_error) { delete h; return nullptr; }
@@ -2181,13 +2199,29 @@ extern "C" int pg_host_graph_add_reads(pg_graph* g, const uint8_t* codes, const 
     if (!g || (!codes && n_reads)) { pg_set_error("null argument"); return PG_EINVAL; }
     return ((pg::GraphHandleBase*)g)->add_reads(codes, lens, n_reads, stride, n_threads);
 }
+static bool g_process_exits_next = false;
+extern "C" void pg_process_exits_after_this(int yes) { g_process_exits_next = yes != 0; }
+
 extern "C" int pg_host_graph_finish(pg_graph* g, int* out_num_vertex, int* out_num_edge, long long* out_num_prearc) {
     if (!g) { pg_set_error("null argument"); return PG_EINVAL; }
     pg::GraphHandleBase* h = (pg::GraphHandleBase*)g;
     int rc = h->finish(out_num_prearc);
     if (out_num_vertex) *out_num_vertex = h->num_vt;
     if (out_num_edge) *out_num_edge = h->num_ed;
-    delete h;
+    // Unmapping tens of gigabytes of k-mer sets takes seconds (page by page, with TLB shoot-downs to every core a worker
+    // ran on); a process that is about to exit leaves that to the kernel's exit path, which has none of it to do.
+    if (getenv("PG_HOST_VERBOSE")) {                       // resident memory, and how much of it sits on huge pages
+        if (FILE* fp = fopen("/proc/self/smaps_rollup", "r")) {
+            char line[256];
+            while (fgets(line, sizeof line, fp))
+                if (!strncmp(line, "Rss:", 4) || !strncmp(line, "AnonHugePages:", 14)) fprintf(stderr, "memory at the end: %s", line);
+            fclose(fp);
+        }
+    }
+    const auto td0 = std::chrono::steady_clock::now();
+    if (g_process_exits_next) h->shutdown();
+    else delete h;
+    if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "graph released: %.2fs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - td0).count());
     return rc;
 }
 

@@ -16,6 +16,7 @@ static void usage(void) {
 int main(int argc, char** argv) {
     if (argc < 2) { usage(); return 1; }
     if (strcmp(argv[1], "pregraph") == 0) {
+        pg_process_exits_after_this(1);              // nothing follows in this process: big tables are left to the exit path
 #ifdef PG_MER127
         return call_pregraph_127mer(argc - 1, argv + 1);
 #else
