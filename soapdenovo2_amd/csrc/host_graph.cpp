@@ -1782,14 +1782,13 @@ struct GraphHandle : GraphHandleBase {
         vertex_thread = std::thread([this]() {
             const double tv0 = now();
             vertex_rc = write_vertex_file<NW>(g, prefix, vertex_count, true);
-            const double tv1 = now();
-            // <prefix>.vertex was the last reader of the host copy of the k-mer sets (the edges were built on the device copy,
-            // pass 2 threads the reads there): tens of gigabytes go back now, beside pass 2, instead of at the very end
-            for (auto& hs : g.sets) { hs.array.release(); std::vector<uint8_t>().swap(hs.occ); }
-            for (auto& tm : g.touched_map) tm.release();
-            if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "vertex writer: %.2fs, host k-mer sets released: %.2fs (beside the edges and pass 2)\n", tv1 - tv0, now() - tv1);
+            if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "vertex writer: %.2fs (beside the edges)\n", now() - tv0);
         });
     }
+    // (Releasing the host copy of the sets as soon as <prefix>.vertex is written -- nothing reads it after that in device mode --
+    // was tried, beside the edge text and beside pass 2: an munmap of tens of gigabytes holds the address-space lock for over a
+    // second, and whatever else allocates, frees or page-faults meanwhile waits for it; the stage it ran beside grew by as much
+    // as the end of the process shrank.)
     int dev_begin() {
         if (dev_ready) return PG_OK;
         if (dev) {                                   // opened for the edges: the (K+1)-mer table is on the device already
