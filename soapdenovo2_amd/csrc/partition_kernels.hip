@@ -705,10 +705,11 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     K2_SYNC();
                     K2_TICK(2);
                     p_dedupe(threadIdx.x, b, wn, ps);
+                    // (a lane knows whether it represents its record as soon as its own probe ends, and a header's k-mer
+                    //  count is the same in every copy: the wave prefix needs no barrier in front of it)
+                    p_flat1(threadIdx.x, wave, b, ps);
                     K2_TICK(10);
                     K2_SYNC();                                            // dtab is dead from here, counts and minima are final
-                    p_flat1(threadIdx.x, wave, b, ps);
-                    K2_SYNC();
                     p_flat2(whole, threadIdx.x, wave, b, ps);
                     K2_SYNC();
                     K2_TICK(3);
