@@ -1171,7 +1171,9 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     int n_cu = 256;
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) n_cu = prop.multiProcessorCount;
-    const unsigned grid = std::min<unsigned>(parts, (unsigned)n_cu * 8u);           // persistent workgroups, x8 per CU for balance
+    unsigned per_cu = 2;                                                            // persistent workgroups: two per CU measured best (1 .. 32 tried; every start of a workgroup builds its tables and wipes the set)
+    if (const char* v = getenv("PG_K2_WG_PER_CU")) per_cu = (unsigned)std::max(1, atoi(v));
+    const unsigned grid = std::min<unsigned>(parts, (unsigned)n_cu * per_cu);
     int dbg = 0, cfg = 0;
     if (const char* v = getenv("PG_DBG")) dbg = atoi(v);
     if (const char* v = getenv("PG_K2CFG")) cfg = atoi(v);
