@@ -416,7 +416,6 @@ struct Graph {
     int n_threads = 0;             // host threads for the parallel scans (0 = all)
     // with the sets mirrored in HBM the tip walks run there (graph_kernels.hip: tip_walk_kernel); the host keeps the
     // order-dependent replay and sends the nodes it changed back
-    std::vector<HugeArray<uint8_t>> touched_map;   // tip scans: one byte a slot, set while a scan runs
     P2Device* tip_dev = nullptr;
     std::vector<uint64_t> set_base;   // global slot of every set's slot 0 (+ the total)
     int tip_error = PG_OK;
@@ -478,6 +477,26 @@ struct Graph {
         for (int t = 1; t < nt; t++) pool.emplace_back(body);
         body();
         for (auto& th : pool) th.join();
+    }
+
+    // The same marking after a round of tip clipping: only the ends of clipped tips changed their arcs since the last
+    // marking, so only they can have become 1-in-1-out; every other node is marked (or not) as it was.
+    std::vector<uint64_t> phase_touched;           // set << 40 | slot of every node the scans of this phase changed
+    void remark_touched() {
+        int nt = pick_threads(n_threads);
+        if (nt < 1) nt = 1;
+        auto body = [&](int t) {
+            for (size_t i = phase_touched.size() * t / nt; i < phase_touched.size() * (t + 1) / nt; i++) {
+                HNode<NW>& n = sets[phase_touched[i] >> 40].array[phase_touched[i] & ((1ULL << 40) - 1)];
+                if (n.B & (B_DELETED | B_LINEAR)) continue;
+                if (n_in(n) == 1 && n_out(n) == 1) __atomic_fetch_or(&n.B, B_LINEAR, __ATOMIC_RELAXED);   // (a node may be listed twice)
+            }
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; t++) pool.emplace_back(body, t);
+        body(0);
+        for (auto& th : pool) th.join();
+        std::vector<uint64_t>().swap(phase_touched);
     }
 
     // clipTipFromNode (cutTipPreGraph.c:43-346), split into the read-only walk and the mutation it decides on, so
@@ -620,17 +639,12 @@ struct Graph {
             for (auto& th : pool) th.join();
         }
         const double tt1 = nowt();
-        // nodes changed during this scan (one byte a slot; only the slots of clipped tips' ends are ever set)
-        // (kept across the scans of a run on huge pages and wiped entry by entry afterwards: a fresh zeroed map per scan
-        // costs more than the replay itself on a large graph)
-        if (touched_map.size() != sets.size()) {
-            touched_map.clear();
-            touched_map.resize(sets.size());
-            for (size_t si = 0; si < sets.size(); si++) touched_map[si].reset(sets[si].size + 1);
-        }
-        std::vector<HugeArray<uint8_t>>& touched = touched_map;
+        // nodes changed during this scan: a spare bit of the node itself (only the ends of clipped tips ever get it; cleared
+        // again from the list below before anything else looks at the word).  A byte map beside the sets did the same with
+        // two more cache misses per candidate in a loop that is nothing but cache misses.
+        constexpr uint32_t B_TOUCHED = 1u << 26;
         std::vector<uint64_t> touched_list;
-        auto is_touched = [&](int set, const HNode<NW>* n) { return touched[set][(size_t)(n - sets[set].array.data())] != 0; };
+        auto is_touched = [&](int, const HNode<NW>* n) { return (n->B & B_TOUCHED) != 0; };
         // positions to come back to, smallest first.  Millions of them are pending at a time on a large graph, so they wait
         // unsorted in buckets of 65536 slots and only the bucket the scan is in is kept as a heap.
         struct LaterQueue {
@@ -684,9 +698,9 @@ struct Graph {
             } else { d = tip_evaluate(n, cut_len, thin); rewalked++; }
             if (!tip_apply(n, d, tips)) return;
             removed++;
-            touched[nset][pos & ((1ULL << 40) - 1)] = 1;
+            n.B |= B_TOUCHED;
             const uint64_t fslot = (uint64_t)(d.far - sets[d.far_set].array.data());
-            touched[d.far_set][fslot] = 1;
+            d.far->B |= B_TOUCHED;
             touched_list.push_back(pos);
             touched_list.push_back(((uint64_t)d.far_set << 40) | fslot);
             if (tip_dev) { changed.push_back(set_base[nset] + (pos & ((1ULL << 40) - 1))); changed.push_back(set_base[d.far_set] + fslot); }
@@ -704,11 +718,7 @@ struct Graph {
             const int cs = (int)(cd.pos >> 40);
             const uint64_t slot = cd.pos & ((1ULL << 40) - 1);
             __builtin_prefetch(&sets[cs].array[slot], 1);
-            __builtin_prefetch(&touched[cs][slot], 1);
-            if (cd.d.far) {
-                __builtin_prefetch(cd.d.far, 1);
-                __builtin_prefetch(&touched[cd.d.far_set][(size_t)(cd.d.far - sets[cd.d.far_set].array.data())], 1);
-            }
+            if (cd.d.far) __builtin_prefetch(cd.d.far, 1);
         };
         constexpr size_t WARM = 12;
         for (size_t i = 0; i < std::min(WARM, flat.size()); i++) warm(*flat[i]);
@@ -730,7 +740,8 @@ struct Graph {
             while (!later.empty() && later.top() == p) later.pop();
             visit(p, nullptr);
         }
-        for (uint64_t tp : touched_list) touched[tp >> 40][tp & ((1ULL << 40) - 1)] = 0;
+        for (uint64_t tp : touched_list) node_at(tp).B &= ~B_TOUCHED;
+        phase_touched.insert(phase_touched.end(), touched_list.begin(), touched_list.end());
         if (tip_dev && !changed.empty()) {                          // bring the device copy up to date
             std::vector<uint64_t> ab(changed.size());
             {   // the present counter words of those nodes (random reads: all threads)
@@ -762,7 +773,7 @@ struct Graph {
         fprintf(stderr, "Start to remove frequency-one-kmer tips shorter than %d.\n", cut);
         tip_scan(cut, true, tips);
         fprintf(stderr, "Total %lld tip(s) removed.\n", tips);
-        remark_linear();
+        remark_touched();
         if (tip_dev && !tip_error) tip_error = p2_remark_linear(tip_dev);
     }
     // removeMinorTips (cutTipPreGraph.c:414-488)
@@ -777,7 +788,7 @@ struct Graph {
             if (!removed || tip_error) break;
         }
         fprintf(stderr, "Total %lld tip(s) removed.\n", tips);
-        remark_linear();
+        remark_touched();
         if (tip_dev && !tip_error) tip_error = p2_remark_linear(tip_dev);
     }
 };
