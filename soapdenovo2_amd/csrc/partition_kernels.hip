@@ -267,8 +267,8 @@ __global__ __launch_bounds__(BLOCK) void skm_ingest_kernel(const uint64_t* recs,
 // ---- the LDS set ---------------------------------------------------------------------------------------------
 // Struct of arrays, so lanes that hit different slots hit different banks: key[KW][SLOTS] (63-bit words), ord[SLOTS],
 // cnt[5][SLOTS] (L0|L1<<16, L2|L3<<16, R0|R1<<16, R2|R3<<16, puts without a left neighbour).  Keys and ord start as ~0,
-// counters as 0.  A slot is claimed key word by key
-// word: an empty word is taken with CAS(~0 -> mine), a word holding something else means another key owns the slot.
+// counters as 0.  A slot is claimed key word by key word: an empty word is taken with CAS(~0 -> mine), a word holding
+// something else means another key owns the slot.
 // Counting is plain atomic adds, saturated when the node is emitted: a sum of +1's clipped at the end equals the
 // reference's saturating increments (newhash.c:74-106) and, unlike a CAS on packed counters, needs no retry when many
 // lanes hit one hot k-mer.  `single` = exactly one put (newhash.c:127,511).
@@ -278,13 +278,13 @@ struct LdsSet {
     unsigned long long key[KW][SLOTS];
     unsigned long long ord[SLOTS];
     unsigned int cnt[5][SLOTS];       // 16-bit halves: a window adds at most WIN * nmax <= 512 * 127 to a field, and fields are
-                                      // clipped to 255 between the windows of a partition (k2_clip_counters)
+                                      // clipped to 255 between the windows of a partition (clip_halves_255)
 };
 __device__ __forceinline__ unsigned int clip_halves_255(unsigned int x) { return min(x & 0xFFFFu, 255u) | (min(x >> 16, 255u) << 16); }
 
 // A put gives up when the set is too full (a probe sequence longer than MAXPROBE): the caller aborts the attempt and
-// splits the key range.  No shared key counter on this path -- a same-address LDS atomic per new key serialises the
-// whole workgroup; the keys are counted once, at emit time.
+// splits the key range.  No shared key counter and no list of claimed slots on this path: measured again in round 2 (one
+// wave-aggregated LDS atomic per step that claims a slot), the put loop lost more than the emit's listing phase costs.
 constexpr int K2_MAXPROBE = 48;
 
 __device__ __forceinline__ const uint64_t* record_ptr(const E2Dev& e, uint32_t pid, uint32_t i, int rw) {
@@ -294,19 +294,20 @@ __device__ __forceinline__ const uint64_t* record_ptr(const E2Dev& e, uint32_t p
 }
 
 // ---- K2 ------------------------------------------------------------------------------------------------------------
-// One workgroup per partition (persistent grid).  The partition's records are taken WIN at a time: staged into LDS with
-// coalesced 16-byte copies (so the per-occurrence work never waits on global memory), flattened through a prefix sum of
-// their k-mer counts so every lane gets an equal contiguous share of occurrences, expanded and inserted into the LDS
-// set.  If the set overflows, the attempt is dropped and the key range is split on a hash bit.  Then the set is
-// finalised (-d filter, linear flag, coverage histogram: prlHashReads.c:953-1132) and emitted as export records.
+// One workgroup per partition (persistent grid).  The partition's records are taken WIN at a time.  A window arrives in LDS
+// by global_load_lds one window ahead (while the previous window is counted, or the previous partition emitted), exact
+// copies of a record are merged (dedupe), the representatives' k-mer counts go through a prefix sum so that every lane
+// gets an equal contiguous share of occurrences, and the occurrences are expanded and inserted into the LDS set.  If the
+// set overflows, the attempt is dropped and the key range is split on a hash bit.  Then the set is finalised (-d filter,
+// linear flag, coverage histogram: prlHashReads.c:953-1132) and emitted as export records.
 // The per-occurrence path (round 1 spent ~360 vector instructions on it, profiles/r01_pmc_sq_bench20M_engine2.json):
 //   * records are staged as dword strings (hi dword first), a k-mer occurrence is cut out by occ_extract (occ32.hpp):
 //     six dword reads, funnel shifts, bit reversal -- 32-bit operations throughout, shift amounts that depend on K
 //     alone are wave-uniform;
 //   * the slot hash is three 32-bit multiplies instead of three 64-bit ones;
-//   * no per-lane cache of "the current record": (offset pair, header) are simply read again every step, so the step is
-//     straight-line code -- with 64 lanes a wave crossed a record boundary on nearly every step anyway and paid for the
-//     divergent refill each time;
+//   * no per-lane cache of "the current record": the offset-table entries (first occurrence | place in the window | flank
+//     bits) are simply read again every step, one step ahead of their use, so the step is straight-line code -- with 64
+//     lanes a wave crossed a record boundary on nearly every step anyway and paid for the divergent refill each time;
 //   * the first record of a lane's share comes from a table the flatten step fills (one lane per record writes the lanes
 //     whose share starts inside it) instead of a 9-step binary search per lane and window;
 //   * the put counter is gone: every put adds to exactly one of L[0..3] / "no left neighbour", so puts = their sum, and
