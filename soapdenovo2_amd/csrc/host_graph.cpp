@@ -712,6 +712,13 @@ struct Graph {
         // the replay is serial and every step touches a handful of random cache lines (start node, stop node, their
         // "touched" bytes): flatten the candidates and prefetch those lines a few steps ahead
         std::vector<Cand*> flat;
+        {
+            size_t n_cand = from_device.size();
+            for (Chunk& ck : chunks) n_cand += ck.c.size();
+            flat.reserve(n_cand);
+            touched_list.reserve(2 * n_cand);                   // (most candidates are clipped: no regrowing copies in the loop)
+            if (tip_dev) changed.reserve(2 * n_cand);
+        }
         for (Chunk& ck : chunks) for (Cand& cd : ck.c) flat.push_back(&cd);
         for (Cand& cd : from_device) flat.push_back(&cd);
         auto warm = [&](const Cand& cd) {
