@@ -263,9 +263,21 @@ def make_quirk_case(outdir: str, name: str) -> str:
         open(p(name + "_pairs.fa"), "wb").write(b"".join(b">m%d/%d\n" % (i // 2, 1 + i % 2) + _ASCII[a[i]].tobytes() + b"\n" for i in range(1200)))
         open(p(name + ".fq"), "wb").write(b"".join(_fastq_blob(list(b), [b"s%d" % i for i in range(500)])))
         open(cfg, "w").write(f"max_rd_len=90\n[LIB]\navg_ins=250\nreverse_seq=0\nasm_flags=3\np={p(name + '_pairs.fa')}\nq={p(name + '.fq')}\n")
+    elif name == "rq_tie":
+        # three libs, two of them with the same avg_ins: the reference orders libs with qsort (lib.c:505), whose order
+        # among equals is the C library's business (glibc's merge sort keeps the file order); a third lib sorts in front
+        a = reads_codes(20000, 700, 100, 0.004, 115)
+        b = reads_codes(20000, 500, 100, 0.004, 116)
+        c = reads_codes(20000, 300, 100, 0.004, 117)
+        for tag, codes in (("a", a), ("b", b), ("c", c)):
+            open(p(f"{name}_{tag}.fq"), "wb").write(b"".join(_fastq_blob(list(codes), [b"%s%d" % (tag.encode(), i) for i in range(len(codes))])))
+        open(cfg, "w").write(
+            f"max_rd_len=100\n[LIB]\navg_ins=300\nasm_flags=3\nrank=1\nq={p(name + '_a.fq')}\n"
+            f"[LIB]\navg_ins=300\nasm_flags=3\nrank=2\nq={p(name + '_b.fq')}\n"
+            f"[LIB]\navg_ins=200\nasm_flags=3\nrank=3\nq={p(name + '_c.fq')}\n")
     else:
         raise ValueError(name)
     return cfg
 
 
-QUIRK_CASES = ["rq_32k", "rq_trunc", "rq_ragged", "rq_pair", "rq_gz", "rq_p"]
+QUIRK_CASES = ["rq_32k", "rq_trunc", "rq_ragged", "rq_pair", "rq_gz", "rq_p", "rq_tie"]

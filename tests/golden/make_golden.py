@@ -17,16 +17,16 @@ CASES = {
     "t6k_k31":  dict(G=30000, N=6000, L=100, err=0.005, seed=20260926, K=31,
                      runs=[(1,0,0,0), (8,0,0,0), (7,0,0,0), (3,1,0,0), (2,0,1,0)], full=[(1,0,0,0), (8,0,0,0)]),
     "t8k_k63":  dict(G=40000, N=8000, L=150, err=0.003, seed=3, K=63,
-                     runs=[(2,0,0,0), (8,0,0,0), (2,0,0,1)], full=[(2,0,0,0)]),
-    "t6k_k127": dict(G=40000, N=6000, L=250, err=0.002, seed=5, K=127, runs=[(3,0,0,1)], full=[]),
+                     runs=[(2,0,0,0), (8,0,0,0), (2,0,0,1), (2,0,1,0), (2,0,1,1), (3,1,0,0), (3,2,0,1)], full=[(2,0,0,0)]),
+    "t6k_k127": dict(G=40000, N=6000, L=250, err=0.002, seed=5, K=127, runs=[(3,0,0,1), (3,0,1,1), (3,1,0,1)], full=[]),
     "t5k_k24":  dict(G=20000, N=5000, L=80, err=0.01, seed=12, K=24, runs=[(8,0,0,0)], full=[]),
     "m100k_k31": dict(G=500000, N=100000, L=100, err=0.005, seed=7, K=31, runs=[(8,0,0,0)], full=[]),
     "m60k_k63": dict(G=400000, N=60000, L=150, err=0.002, seed=8, K=63, runs=[(8,0,0,0), (8,0,0,1)], full=[]),
     # structured genomes (synth.genome_model): two haplotypes with SNP pairs K + 2 apart -> length-1 edges, i.e. the
     # (K+1)-mer table of node2edge.c:481-542 and, at K = 127, the `char` length overflow of kmer.c:532; repeats longer than K
-    "d8k_k127": dict(G=40000, N=8000, L=250, err=0.001, seed=21, K=127, model="diploid", runs=[(3,0,0,1), (8,0,0,1)], full=[]),
+    "d8k_k127": dict(G=40000, N=8000, L=250, err=0.001, seed=21, K=127, model="diploid", runs=[(3,0,0,1), (8,0,0,1), (3,1,0,1)], full=[]),
     "r8k_k127": dict(G=40000, N=8000, L=250, err=0.001, seed=22, K=127, model="repeat", runs=[(3,0,0,1)], full=[]),
-    "d8k_k63":  dict(G=40000, N=8000, L=150, err=0.002, seed=23, K=63, model="diploid", runs=[(5,0,0,0), (5,0,0,1)], full=[]),
+    "d8k_k63":  dict(G=40000, N=8000, L=150, err=0.002, seed=23, K=63, model="diploid", runs=[(5,0,0,0), (5,0,0,1), (5,1,0,0), (4,0,1,1)], full=[]),
 }
 EXTS = ("kmerFreq", "preGraphBasic", "vertex", "edge", "preArc")
 

@@ -26,7 +26,7 @@ def test_prearc_matches_reference(golden, tmp_path, name):
         assert md5_file(pre + ".vertex") == want["vertex"], t
         assert md5_file(pre + ".preGraphBasic") == want["preGraphBasic"], t
         assert md5_gz_text(pre + ".edge.gz") == want["edge"], t
-        assert na > 0
+        assert na > 0 or D > 0                                             # (-d leaves an error-free 40 kb genome as a single chain)
 
 
 def test_prearc_on_reader_corner_cases(golden, tmp_path):
