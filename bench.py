@@ -229,6 +229,7 @@ def main():
     wpr = (L + 31) // 32
     batches = [(lo, min(args.batch_reads, n_reads - lo)) for lo in range(0, n_reads, args.batch_reads)]
     ord0 = rank * n_kmers
+    ord0_last = ord0 + n_kmers                     # 1 + the ordinal of the last k-mer occurrence of this rank's reads
     ev, ev2 = [], []
 
     def step(timed):
@@ -280,7 +281,7 @@ def main():
         if timed:
             f0, f1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             f0.record()
-        kc.finalize(0, want_last_put=False)
+        kc._last_hist, _ = kc.finalize(0, want_last_put=False)
         if timed:
             f1.record()
             ev2.append((f0, f1))
@@ -304,10 +305,38 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     distinct = kc.distinct()                       # also raises if the set overflowed
+    # ---- conservation check on the TIMED result (milliseconds; every rank, summed): the coverage histogram adds up to the
+    # distinct k-mers, the nodes' coverage fields add up to the k-mer occurrences that went in (exact while no node
+    # saturates at 255, a lower bound otherwise), the latest put any set saw is the last k-mer of the last read
+    hist_t, _ = kc._last_hist, None
+    chk = kc.checksum() if engine == 2 else None
+    cons_local = [int(hist_t.sum()), int((hist_t * np.arange(256, dtype=np.uint64)).sum()), int(hist_t[255]),
+                  int(chk[6]) if chk is not None else -1, int(chk[7]) if chk is not None else -1, distinct]
     if world > 1:
-        t = torch.tensor([distinct], dtype=torch.int64, device=dev)
+        t = torch.tensor(cons_local, dtype=torch.int64, device=dev)
         dist.all_reduce(t)
-        distinct = int(t.item())
+        cons_local = [int(x) for x in t.tolist()]
+        distinct = cons_local[5]
+    last_timed = kc.last_put() if engine == 2 else None           # K3: a second expansion of every record (untimed)
+    max_last = int(last_timed.max()) if last_timed is not None else -1
+    if world > 1 and last_timed is not None:
+        t = torch.tensor([max_last], dtype=torch.int64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        max_last = int(t.item())
+    total_kmers = n_kmers * world
+    conservation = {
+        "checked_on": "the result of the last timed step",
+        "histogram_sum": cons_local[0], "distinct": distinct, "histogram_sum_equals_distinct": cons_local[0] == distinct,
+        "kmer_occurrences_in": total_kmers, "sum_of_coverage_histogram": cons_local[1], "saturated_nodes": cons_local[2],
+        "occurrences_conserved": (cons_local[1] == total_kmers) if cons_local[2] == 0 else (cons_local[1] <= total_kmers),
+        "occurrence_check": "exact (no node saturated)" if cons_local[2] == 0 else "lower bound (saturated nodes count 255)",
+        "sum_of_exported_coverage_fields": cons_local[3] if cons_local[3] >= 0 else None,
+        "export_agrees_with_histogram": (cons_local[3] == cons_local[1] and cons_local[4] == cons_local[2]) if cons_local[3] >= 0 else None,
+        "max_last_put": max_last if max_last >= 0 else None,
+        "max_last_put_equals_last_ordinal_plus_1": (max_last == ord0_last) if max_last >= 0 and world == 1 else None,
+    }
+    conservation["ok"] = all(v is not False for v in conservation.values())
+    digest_timed = [int(x) for x in chk[:6]] if chk is not None else None
 
     # ---- outside the timed steps (N = 1): the hand-over call_pregraph does after pass 1, and a PCIe-inclusive pass
     extras, st_snapshot = {}, None
@@ -336,6 +365,9 @@ def main():
         kc.finalize(0, want_last_put=False)
         torch.cuda.synchronize()
         dt_h = time.perf_counter() - t0
+        # the same reads through other buffers in other batch boundaries' timing: the digest of the distinct k-mers must not move
+        conservation["digest_equal_resident_vs_pcie_pass"] = [int(x) for x in kc.checksum()[:6]] == digest_timed
+        conservation["ok"] = conservation["ok"] and conservation["digest_equal_resident_vs_pcie_pass"]
         extras["pcie_inclusive_ms_per_pass"] = dt_h * 1e3
         extras["pcie_inclusive_reads_per_sec"] = n_reads / dt_h
         extras["pcie_note"] = f"the packed reads ({n_reads * wpr * 8 / 1e9:.1f} GB) start in pinned host memory; batches of {nb} reads are copied on a second stream into two device buffers while the previous batch is cut"
@@ -376,7 +408,7 @@ def main():
             "metric": f"pregraph_pass1_reads_per_sec_K{K}", "value": total_reads / (dt / args.steps), "unit": "reads/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
-            "distinct_kmers_per_sec": distinct / (dt / args.steps),
+            "distinct_kmers_per_sec": distinct / (dt / args.steps), "conservation": conservation,
             "kmer_occurrences_per_sec": n_kmers * world / (dt / args.steps),
             "config": {"workload": f"C. elegans-scale synthetic: {n_reads} reads/GPU x {L} bp, genome {args.genome} bp, err {args.err}, "
                                    f"K={K}, -p {P} sets (BASELINE.json configs[2])",
@@ -384,7 +416,8 @@ def main():
                        "distinct_kmers": distinct, "table_slots_log2": log2_slots,
                        "engine": engine,
                        "parallelism": ("single GPU, " + ("super-k-mer partitions counted in LDS" if engine == 2 else "fused extract+insert into one DRAM set"))
-                       if world == 1 else (f"partition-owner (partition mod {world}), super-k-mer records over RCCL all-to-all" if engine == 2
+                       if world == 1 else (f"owner(record) = minimizer partition mod {world} (a hash of the k-mer's minimizer -- NOT north_star's high-bit key range: "
+                                            f"the first base of a canonical k-mer is skewed 7:5:3:1, SURVEY.md 8e), super-k-mer records over RCCL all-to-all" if engine == 2
                                            else f"set-id owner, k-mer records over RCCL all-to-all x{world}"),
                        "exchange": {"lib": "pg_count_reads_sharded (librccl ncclSend/ncclRecv group through the C ABI)", "none": None}.get(exchange, exchange)},
         }
@@ -431,8 +464,8 @@ def main():
                          "moved_bytes_per_step": k1_bytes + k2_bytes, "moved_over_algorithmic": (k1_bytes + k2_bytes) / alg_pass,
                          "records_per_read": st["records"] / n_reads, "record_bytes": st["unit_bytes"], "partitions": st["parts_or_slots"]}
             if os.path.exists(tf):
-                # PMC bytes (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes) are kept per read in profiles/pmc_traffic.json
-                # (measured on the 20 M-read variant of this workload) and scaled to the reads of one launch
+                # PMC bytes (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes over this command at its full 200 M reads) are kept
+                # per read in profiles/pmc_traffic.json and scaled to the reads of one launch of the dominant kernel
                 try:
                     tj = json.load(open(tf))
                     kn = kernel.split("<")[0]
@@ -449,8 +482,13 @@ def main():
                        "workgroup per CU), random 8-byte LDS accesses replayed for bank conflicts, nine workgroup barriers per partition; "
                        "vector ALU ~44 % busy, HBM ~9 % of peak (profiles/r02b_pmc_sq_bench20M.json, profiles/r02b_k2_phase_cycles_20M.txt, "
                        "DESIGN.md 3.2)") if engine == 2 else "random-atomic rate of the DRAM-resident set"
-            rec["roofline"] = {"bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                               "traffic": traffic, "kernel": kernel, "launches": launches, "avg_launch_ms": avg_ms,
+            # what the counters say about the same launch: PMC bytes / launch time against the same peak (never `frac`)
+            counter_frac = (traffic / (avg_ms * 1e-3) / 1e9 / 8000.0) if traffic else None
+            rec["roofline"] = {"bound": "hbm", "bound_note": "hbm-equivalent (contract): SURVEY.md 8d prices the path as a hash table in HBM; this formulation "
+                                                             "moves a fraction of those bytes (see traffic / hbm_counter_frac) and is limited as `limiter_bound` says",
+                               "limiter_bound": "valu-issue/lds" if engine == 2 else "random-atomic rate",
+                               "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                               "traffic": traffic, "hbm_counter_frac": counter_frac, "kernel": kernel, "launches": launches, "avg_launch_ms": avg_ms,
                                "algorithmic_bytes_per_launch": per_launch, "limiter": limiter, **extra}
             if not args.no_cpu_baseline and args.whole_reads > 0:
                 # the reference's workers each scan the whole k-mer buffer (prlHashReads.c:79-90), so its pass 1 stops scaling

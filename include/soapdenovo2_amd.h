@@ -276,6 +276,15 @@ int pg_export_take(pg_ctx *ctx, uint64_t **d_records_out, uint64_t *n_out);
  * pg_sort_records_ws, so that the hand-over needs no large allocation (hipMalloc right after a big hipFree takes seconds). */
 int pg_export_take_ws(pg_ctx *ctx, uint64_t **d_records_out, uint64_t *n_out, void **d_workspace_out, uint64_t *workspace_bytes_out);
 void pg_device_free(void *d_ptr);   /* hipFree, for callers that do not link the HIP runtime */
+/* A read-only look at the partition engine's export array after pg_finalize (no copy; valid until the next pg_reset,
+ * pg_export_take or pg_destroy). */
+int pg_export_peek(pg_ctx *ctx, const uint64_t **d_records_out, uint64_t *n_out);
+/* Order-independent digest of a device array of records (rec_words = nw + 2 words each): out[0 .. rec_words) the column
+ * sums mod 2^64, out[6] the sum of the coverage fields (bits 31:24 of cnt: min(puts, 255), newhash.c:95-103), out[7] the
+ * number of saturated ones.  Equal digests from two passes over the same reads -- whatever the batching, the engine, the
+ * number of GPUs -- and out[6] == the k-mer occurrences that went in when out[7] == 0: the conservation check bench.py
+ * prints with its timed result.  Synchronises. */
+int pg_records_checksum(const uint64_t *d_records, uint64_t n_records, int rec_words, uint64_t out[8], void *stream);
 
 /* Order exported records (device memory, on the current device) by their last word, i.e. by k-mer set and then by
  * first-occurrence ordinal: the order in which the layout replay of pg_host_build_graph / pg_host_graph_begin inserts
@@ -332,6 +341,18 @@ int pg_exchange_gather_records(pg_comm *comm, const uint64_t *d_records, uint64_
  * receive regions live in the communicator and grow as needed.  After the last round: pg_finalize on every rank. */
 int pg_count_reads_sharded(pg_ctx *ctx, pg_comm *comm, const uint64_t *d_packed, const uint64_t *d_word_off, const uint64_t *d_kmer_base,
                            uint64_t n_reads, uint32_t uniform_len, uint64_t n_kmers, uint64_t ord_base, void *stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * 5. Test hooks.  The device graph stages (csrc/dev_graph.hpp, csrc/dev_tips.hpp) are written once over a backend; these
+ *    entry points run the SAME function objects on host threads instead of HIP lanes, so that the CPU-only tests can
+ *    compare them with the sequential host stages.  Not a fallback: nothing in the product path calls them.
+ * ------------------------------------------------------------------------------------------------ */
+/* layout of static (-a) k-mer sets, SURVEY.md App. C "K6" (put_kmerset into a table that never grows, newhash.c:353-366,
+ * 473-528): records sorted by (set, ordinal), per_set_count[s] of them per set; nodes_out = n_sets * set_size slots of
+ * nw + 1 words (key words, cnt), empty slots with all-ones in their first word.  Returns PG_OK, 1 = unsuited (a set that
+ * fills its pool or holds >= 2^32 keys: the caller replays on the host), or PG_E*. */
+int pg_host_emu_layout_static(const uint64_t *records, const uint64_t *per_set_count, int n_sets, uint64_t set_size, int mer127,
+                              int n_threads, uint64_t *nodes_out);
 
 #ifdef __cplusplus
 }

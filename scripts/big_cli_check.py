@@ -1,62 +1,108 @@
 #!/usr/bin/env python3
-"""Larger-than-golden check of the executable (run on the GPU box): one synthetic FASTQ through the default partition engine
-and through the global-set engine (PG_ENGINE=1); both must write the same five files.  Prints timings and md5s.
+"""Larger-than-golden check of the executable: one synthetic FASTQ (scripts/synth_fastq.cpp: bytes that depend on the arguments
+only, so the same file can be made wherever the reference binary has the memory and the time to run) through
+`SOAPdenovo-63mer|127mer pregraph`, md5s compared with the reference's.
 
-    python scripts/big_cli_check.py --reads 30000000 --read-len 100 --genome 15000000 --kmer 31
+    # where the reference fits (this takes the reference tens of minutes; no GPU needed):
+    python scripts/big_cli_check.py --reference --reads 60000000 --out /tmp/big60 --save profiles/r03_ref_60M_K63.json
+    # on the GPU box:
+    python scripts/big_cli_check.py --reads 60000000 --expect profiles/r03_ref_60M_K63.json --out gpurun_out/big60
+
+Without --expect the run is refused: a big run whose files are compared with nothing proves nothing (--unverified says so
+explicitly and marks the result).  Exit code 1 when the md5s differ or the command fails.
 """
-import argparse, json, os, subprocess, sys, time
+import argparse, gzip, hashlib, json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from soapdenovo2_amd import synth, api
-from scripts.whole_command_config import write_fastq_fast, gpu_codes, md5s
+GEN = os.path.join(ROOT, "soapdenovo2_amd", "bin", "synth_fastq")
+KEEP = ("[cli]", "Time spent on", "replay set", "node(s) allocated", "edge(s)", "pre-arc", "again", "reader:", "tip scan", "edges:", "layout", "vertex")
+
+
+def md5s(prefix):
+    out = {}
+    for ext in ("kmerFreq", "preGraphBasic", "vertex", "preArc"):
+        h = hashlib.md5()
+        with open(f"{prefix}.{ext}", "rb") as f:
+            for chunk in iter(lambda: f.read(1 << 24), b""):
+                h.update(chunk)
+        out[ext] = h.hexdigest()
+    h = hashlib.md5()
+    with gzip.open(prefix + ".edge.gz", "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 24), b""):
+            h.update(chunk)
+    out["edge"] = h.hexdigest()
+    return out
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--out", default="gpurun_out/big")
     ap.add_argument("--reads", type=int, default=30_000_000)
-    ap.add_argument("--read-len", type=int, default=100)
-    ap.add_argument("--genome", type=int, default=15_000_000)
-    ap.add_argument("--err", type=float, default=0.004)
-    ap.add_argument("--kmer", type=int, default=31)
+    ap.add_argument("--read-len", type=int, default=150)
+    ap.add_argument("--genome", type=int, default=100_000_000)
+    ap.add_argument("--err", type=float, default=0.001)
+    ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--kmer", type=int, default=63)
     ap.add_argument("--sets", type=int, default=8)
-    ap.add_argument("--single", action="store_true", help="only the default engine, no comparison")
-    ap.add_argument("--variant", action="append", default=[], help="extra run of the default engine with these variables, e.g. PG_NO_THP=1,PG_GROW_VERBOSE=1")
-    ap.add_argument("--expect", default="", help="result.json of an earlier run with the same arguments: only the default engine runs and its md5s are compared")
+    ap.add_argument("--a-gb", type=int, default=0, help="the reference's -a (0 = growable sets)")
+    ap.add_argument("--reference", action="store_true", help="run oracle/_ref instead of the executable and --save its md5s")
+    ap.add_argument("--save", default="", help="with --reference: where the expectation goes")
+    ap.add_argument("--expect", default="", help="JSON written by --reference --save for the same arguments")
+    ap.add_argument("--unverified", action="store_true", help="run without an expectation (the result says so)")
+    ap.add_argument("--env", action="append", default=[], help="NAME=VALUE for the command (repeatable)")
+    ap.add_argument("--keep-fastq", action="store_true")
     a = ap.parse_args()
+    key = {k: getattr(a, k) for k in ("reads", "read_len", "genome", "err", "seed", "kmer", "sets", "a_gb")}
+    want = None
+    if not a.reference:
+        if a.expect:
+            e = json.load(open(a.expect))
+            if e.get("workload") != key or not e.get("md5"):
+                sys.exit(f"{a.expect} holds no md5s for these arguments: {e.get('workload')} vs {key}")
+            want = e["md5"]
+        elif not a.unverified:
+            sys.exit("no --expect: refusing a run that is compared with nothing (--unverified to insist)")
     os.makedirs(a.out, exist_ok=True)
-    fq, cfg = os.path.join(a.out, "reads.fq"), os.path.join(a.out, "lib.cfg")
-    write_fastq_fast(fq, gpu_codes(a.genome, a.reads, a.read_len, a.err, 7))
-    synth.write_config(cfg, fq, a.read_len)
-    os.sync()                                       # the generator's write-back is not part of the commands being timed
-    res = {"workload": vars(a)}
-    runs = (("partitions", {}), ("global_set", {"PG_ENGINE": "1"}))
-    if a.expect or a.single:
-        runs = runs[:1]
-    for v in a.variant:
-        runs = runs + ((v, dict(kv.split("=", 1) for kv in v.split(","))),)
-    for ri, (tag, env) in enumerate(runs):
-        pre = tag if tag in ("partitions", "global_set") else "variant%d" % ri
-        t = time.time()
-        r = subprocess.run([api.binary(False), "pregraph", "-s", cfg, "-K", str(a.kmer), "-o", os.path.join(a.out, pre), "-p", str(a.sets)],
-                           capture_output=True, text=True, env={**os.environ, "PG_HOST_VERBOSE": "1", **env})
-        res[tag] = {"wall_s": time.time() - t, "rc": r.returncode,
-                    "log": [l for l in r.stderr.splitlines() if "[cli]" in l or "Time spent on" in l or "replay set" in l or "node(s) allocated" in l or "edge(s)" in l or "pre-arc" in l or "again" in l or l.startswith("grow ") or l.startswith("reader:")]}
-        open(os.path.join(os.path.dirname(a.out.rstrip("/")) or ".", "stderr_%s.txt" % pre), "w").write(r.stderr)
-        if r.returncode == 0:
-            res[tag]["md5"] = md5s(os.path.join(a.out, pre))
-        else:
-            res[tag]["stderr_tail"] = r.stderr[-1500:]
-    if a.expect and os.path.exists(a.expect):
-        want = json.load(open(a.expect))["partitions"]["md5"]
-        res["same_as_expected"] = res["partitions"].get("md5") == want
-    elif not a.single:
-        res["engines_agree"] = res["partitions"].get("md5") is not None and res["partitions"].get("md5") == res["global_set"].get("md5")
+    fq, cfg = os.path.abspath(os.path.join(a.out, "reads.fq")), os.path.join(a.out, "lib.cfg")
+    t = time.time()
+    if not (a.keep_fastq and os.path.exists(fq)):
+        subprocess.check_call([GEN, fq, str(a.genome), str(a.reads), str(a.read_len), str(a.err), str(a.seed)])
+    open(cfg, "w").write(f"max_rd_len={a.read_len}\n[LIB]\navg_ins=200\nreverse_seq=0\nasm_flags=3\nrank=1\nq={fq}\n")
+    os.sync()
+    res = {"workload": key, "fastq_bytes": os.path.getsize(fq), "generate_s": round(time.time() - t, 1)}
+    mer127 = a.kmer > 63
+    if a.reference:
+        binary = os.path.join(ROOT, "oracle", "_ref", "SOAPdenovo-127mer" if mer127 else "SOAPdenovo-63mer")
+    else:
+        binary = os.path.join(ROOT, "soapdenovo2_amd", "bin", "SOAPdenovo-127mer" if mer127 else "SOAPdenovo-63mer")
+    pre = os.path.join(a.out, "ref" if a.reference else "amd")
+    cmd = [binary, "pregraph", "-s", cfg, "-K", str(a.kmer), "-o", pre, "-p", str(a.sets)] + (["-a", str(a.a_gb)] if a.a_gb else [])
+    env = dict(os.environ, PG_HOST_VERBOSE="1", **dict(kv.split("=", 1) for kv in a.env))
+    t = time.time()
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+    res.update({"command": " ".join(cmd[1:]), "binary": os.path.relpath(binary, ROOT), "wall_s": round(time.time() - t, 2), "rc": r.returncode,
+                "log": [l for l in r.stderr.splitlines() if any(k in l for k in KEEP)]})
+    open(os.path.join(a.out, "stderr.txt"), "w").write(r.stderr)
+    ok = r.returncode == 0
+    if ok:
+        res["md5"] = md5s(pre)
+        if want is not None:
+            res["expect"] = a.expect
+            res["identical_to_reference"] = res["md5"] == want
+            ok = res["identical_to_reference"]
+        elif not a.reference:
+            res["unverified"] = True
+    else:
+        res["stderr_tail"] = r.stderr[-1500:]
     for f in os.listdir(a.out):
-        if f not in ("result.json",):
+        if f not in ("result.json", "stderr.txt") and not (a.keep_fastq and f in ("reads.fq", "lib.cfg")):
             os.remove(os.path.join(a.out, f))
     print(json.dumps(res, indent=1))
     json.dump(res, open(os.path.join(a.out, "result.json"), "w"), indent=1)
+    if a.reference and a.save and ok:
+        json.dump({"workload": key, "md5": res["md5"], "reference_wall_s": res["wall_s"], "log": res["log"],
+                   "made_by": "scripts/big_cli_check.py --reference (oracle/_ref, built from /root/reference by oracle/Makefile.ref)"}, open(a.save, "w"), indent=1)
+    sys.exit(0 if ok else 1)
 
 
 if __name__ == "__main__":

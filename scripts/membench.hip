@@ -1,4 +1,4 @@
-// tools/membench.hip -- random-access ceilings of one MI355X for the access shapes the k-mer set uses.
+// scripts/membench.hip -- random-access ceilings of one MI355X for the access shapes the k-mer set uses.
 // Not product code: a measurement aid for DESIGN.md (what a random-probe hash formulation can reach at most).
 //   ./membench [log2_table_bytes=34] [n_ops_log2=30]
 #include <hip/hip_runtime.h>

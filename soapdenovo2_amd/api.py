@@ -110,6 +110,8 @@ def lib() -> C.CDLL:
     L.pg_export_take_ws.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
     L.pg_sort_records_ws.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
     L.pg_device_free.argtypes = [C.c_void_p]
+    L.pg_export_peek.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)]
+    L.pg_records_checksum.argtypes = [C.c_void_p, C.c_uint64, C.c_int, u64p, C.c_void_p]
     L.pg_set_counts.argtypes = [C.c_void_p, u64p, C.c_void_p]
     L.pg_last_put.argtypes = [C.c_void_p, u64p, C.c_void_p]
     L.pg_host_last_put_matters.argtypes = [u64p, C.c_int, C.c_int, C.c_int]
@@ -132,6 +134,7 @@ def lib() -> C.CDLL:
     L.pg_host_skm_cut.argtypes = [u64p, C.c_uint64, C.c_uint32, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, u64p, u64p, C.c_uint64]
     L.pg_host_skm_expand.restype = C.c_int64
     L.pg_host_skm_expand.argtypes = [u64p, C.c_uint64, C.c_int, C.c_int, u64p, C.c_uint64]
+    L.pg_host_emu_layout_static.argtypes = [u64p, u64p, C.c_int, C.c_uint64, C.c_int, C.c_int, u64p]
     _lib = L
     return L
 
@@ -140,9 +143,10 @@ EXPORTED_SYMBOLS = [
     "pg_last_error", "pg_version", "call_pregraph", "call_pregraph_127mer", "pg_packed_words", "pg_pack_read",
     "pg_host_build_graph", "pg_host_graph_begin", "pg_host_graph_add_reads", "pg_host_graph_finish", "pg_process_exits_after_this", "pg_host_graph_resolve_repeats", "pg_host_graph_add_packed", "pg_graph_use_device", "pg_sort_records", "pg_expect_kmers", "pg_create_sized", "pg_graph_begin", "pg_graph_begin_streamed", "pg_host_read_all", "pg_host_replay_layout", "pg_host_write_kmerfreq", "pg_create", "pg_create_engine", "pg_destroy", "pg_reset", "pg_set_autogrow", "pg_count_reads", "pg_route_count",
     "pg_route_scatter", "pg_count_records", "pg_skm_route", "pg_skm_ingest", "pg_distinct", "pg_stats", "pg_table_info", "pg_finalize", "pg_export",
-    "pg_export_take", "pg_export_take_ws", "pg_sort_records_ws", "pg_device_free", "pg_set_counts", "pg_last_put", "pg_host_last_put_matters", "pg_comm_unique_id", "pg_comm_create", "pg_comm_create_local", "pg_comm_destroy", "pg_comm_rank", "pg_comm_size",
+    "pg_export_take", "pg_export_take_ws", "pg_export_peek", "pg_records_checksum", "pg_sort_records_ws", "pg_device_free", "pg_set_counts", "pg_last_put", "pg_host_last_put_matters", "pg_comm_unique_id", "pg_comm_create", "pg_comm_create_local", "pg_comm_destroy", "pg_comm_rank", "pg_comm_size",
     "pg_comm_transport", "pg_comm_stats", "pg_exchange_counts", "pg_exchange_records", "pg_exchange_allreduce_u64",
     "pg_exchange_gather_records", "pg_count_reads_sharded", "pg_host_skm_cut", "pg_host_skm_expand",
+    "pg_host_emu_layout_static",
 ]
 
 
@@ -505,6 +509,15 @@ class KmerCounter:
         _check(lib().pg_stats(self.h, out.ctypes.data), "pg_stats")
         keys = ["engine", "distinct", "records", "unit_bytes", "pool_used", "pool_chunks", "parts_or_slots", "export_capacity"]
         return {k: int(v) for k, v in zip(keys, out)}
+
+    def checksum(self) -> np.ndarray:
+        """Order-independent digest of the distinct k-mers after finalize (pg_records_checksum on the export array in place):
+        [column sums mod 2^64 (nw + 2 of them, zero-padded to 6), sum of the coverage fields, saturated nodes]."""
+        ptr, n = C.c_void_p(0), C.c_uint64(0)
+        _check(lib().pg_export_peek(self.h, C.byref(ptr), C.byref(n)), "pg_export_peek")
+        out = np.zeros(8, dtype=np.uint64)
+        _check(lib().pg_records_checksum(ptr, n.value, self.nw + 2, out.ctypes.data, self._stream()), "pg_records_checksum")
+        return out
 
     def export(self, sort: bool = False) -> np.ndarray:
         """(n, nw + 2) uint64 records on the host (key words, cnt, set << 56 | first ordinal); with sort=True in the layout

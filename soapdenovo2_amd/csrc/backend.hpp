@@ -1,0 +1,109 @@
+// backend.hpp -- one source for the device graph stages, two ways to run it.
+//
+// The stages after pass 1 that live on the device (k-mer-set layout for -a pools, tip clipping, the sharded regroup) are
+// written once, as templates over a Backend, in dev_graph.hpp: data-parallel steps are function objects called with an
+// index (`be.launch(n, f)`), the primitives between them (radix sort, scans) are the backend's.
+//   HipBackend   (backend_hip.hpp, hipcc only): launch = a kernel whose lane i calls f(i); rocPRIM / hipCUB primitives on
+//                the backend's stream; memory from hipMalloc.  This is what the product runs.
+//   HostBackend  (below, any C++ compiler): launch = host threads each taking a strided share of the indices -- the same
+//                function objects, the same atomics (through the hd_* wrappers), so a data race or an order dependence shows
+//                up in the CPU tests; std:: primitives.  Used by the `-m "not gpu"` tests (pg_host_emu_* in
+//                host_emu.cpp) and nowhere in the product path: there is no CPU fallback, call_pregraph never picks it.
+#pragma once
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <algorithm>
+#include <atomic>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "kmer.hpp"
+
+// attribute of a lambda handed to Backend::launch (PG_HD carries `inline`, which a lambda cannot)
+#if defined(__HIPCC__)
+#define PG_LAMBDA __host__ __device__
+#else
+#define PG_LAMBDA
+#endif
+
+namespace pg {
+
+// ---- atomics on plain words, same spelling on both sides --------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+PG_HD unsigned long long hd_atomic_add(unsigned long long* p, unsigned long long v) { return atomicAdd(p, v); }
+PG_HD unsigned int hd_atomic_add(unsigned int* p, unsigned int v) { return atomicAdd(p, v); }
+PG_HD unsigned long long hd_atomic_min(unsigned long long* p, unsigned long long v) { return atomicMin(p, v); }
+PG_HD unsigned long long hd_atomic_max(unsigned long long* p, unsigned long long v) { return atomicMax(p, v); }
+PG_HD unsigned long long hd_atomic_or(unsigned long long* p, unsigned long long v) { return atomicOr(p, v); }
+PG_HD unsigned long long hd_atomic_and(unsigned long long* p, unsigned long long v) { return atomicAnd(p, v); }
+PG_HD unsigned long long hd_atomic_cas(unsigned long long* p, unsigned long long expected, unsigned long long desired) { return atomicCAS(p, expected, desired); }
+PG_HD unsigned long long hd_atomic_load(const unsigned long long* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#else
+inline unsigned long long hd_atomic_add(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline unsigned int hd_atomic_add(unsigned int* p, unsigned int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline unsigned long long hd_atomic_min(unsigned long long* p, unsigned long long v) {
+    unsigned long long cur = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (v < cur && !__atomic_compare_exchange_n(p, &cur, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return cur;
+}
+inline unsigned long long hd_atomic_max(unsigned long long* p, unsigned long long v) {
+    unsigned long long cur = __atomic_load_n(p, __ATOMIC_RELAXED);
+    while (v > cur && !__atomic_compare_exchange_n(p, &cur, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}
+    return cur;
+}
+inline unsigned long long hd_atomic_or(unsigned long long* p, unsigned long long v) { return __atomic_fetch_or(p, v, __ATOMIC_RELAXED); }
+inline unsigned long long hd_atomic_and(unsigned long long* p, unsigned long long v) { return __atomic_fetch_and(p, v, __ATOMIC_RELAXED); }
+inline unsigned long long hd_atomic_cas(unsigned long long* p, unsigned long long expected, unsigned long long desired) {
+    __atomic_compare_exchange_n(p, &expected, desired, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED);
+    return expected;
+}
+inline unsigned long long hd_atomic_load(const unsigned long long* p) { return __atomic_load_n(p, __ATOMIC_RELAXED); }
+#endif
+
+// ---- the host backend -----------------------------------------------------------------------------------------------------
+struct HostBackend {
+    int n_threads;
+    explicit HostBackend(int threads = 0) : n_threads(threads > 0 ? threads : 4) {}
+    static constexpr bool on_device = false;
+    int error = 0;                                       // allocation failures etc. (PG_E*), sticky
+    std::string error_text;
+
+    template <typename T> T* alloc(size_t n) { return (T*)malloc(std::max<size_t>(n, 1) * sizeof(T)); }
+    void release(void* p) { free(p); }
+    template <typename T> void fill(T* p, size_t n, T v) { for (size_t i = 0; i < n; i++) p[i] = v; }
+    template <typename T> void to_host(T* dst, const T* src, size_t n) { if (n) memcpy((void*)dst, (const void*)src, n * sizeof(T)); }
+    template <typename T> void to_device(T* dst, const T* src, size_t n) { if (n) memcpy((void*)dst, (const void*)src, n * sizeof(T)); }
+    template <typename T> void copy(T* dst, const T* src, size_t n) { if (n) memmove((void*)dst, (const void*)src, n * sizeof(T)); }
+    void sync() {}
+
+    // f(i) for every i in [0, n): thread t takes i = t, t + T, t + 2T, ... so that neighbouring indices run concurrently,
+    // as the lanes of a wavefront do
+    template <typename F> void launch(uint64_t n, F f) {
+        const int T = (int)std::min<uint64_t>((uint64_t)n_threads, std::max<uint64_t>(n, 1));
+        if (T <= 1) { for (uint64_t i = 0; i < n; i++) f(i); return; }
+        std::vector<std::thread> pool;
+        for (int t = 0; t < T; t++) pool.emplace_back([=]() mutable { for (uint64_t i = (uint64_t)t; i < n; i += (uint64_t)T) f(i); });
+        for (auto& th : pool) th.join();
+    }
+    // stable sort of (key, value) pairs by the low `bits` bits of the key
+    template <typename V> void sort_pairs(const uint64_t* kin, uint64_t* kout, const V* vin, V* vout, uint64_t n, int bits) {
+        std::vector<uint64_t> idx(n);
+        for (uint64_t i = 0; i < n; i++) idx[i] = i;
+        const uint64_t mask = bits >= 64 ? ~0ULL : ((1ULL << bits) - 1);
+        std::stable_sort(idx.begin(), idx.end(), [&](uint64_t a, uint64_t b) { return (kin[a] & mask) < (kin[b] & mask); });
+        for (uint64_t i = 0; i < n; i++) { kout[i] = kin[idx[i]]; vout[i] = vin[idx[i]]; }
+    }
+    void inclusive_max(const long long* in, long long* out, uint64_t n) {
+        long long m = 0;
+        for (uint64_t i = 0; i < n; i++) { m = i ? std::max(m, in[i]) : in[i]; out[i] = m; }
+    }
+    void exclusive_sum(const unsigned long long* in, unsigned long long* out, uint64_t n) {
+        unsigned long long s = 0;
+        for (uint64_t i = 0; i < n; i++) { const unsigned long long v = in[i]; out[i] = s; s += v; }
+    }
+};
+
+}  // namespace pg

@@ -1,0 +1,100 @@
+// backend_hip.hpp -- the backend the product runs the device graph stages on (see backend.hpp): one HIP device, one stream.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
+
+#include <string>
+
+#include "backend.hpp"
+#include "../../include/soapdenovo2_amd.h"
+
+namespace pg {
+
+// lane i of the grid calls f(i); grid-stride, so any n fits one launch
+template <typename F>
+__global__ __launch_bounds__(256) void be_launch_kernel(uint64_t n, F f) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) f(i);
+}
+template <typename T>
+__global__ __launch_bounds__(256) void be_fill_kernel(T* p, uint64_t n, T v) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) p[i] = v;
+}
+struct BeMaxLL { __host__ __device__ long long operator()(long long a, long long b) const { return a > b ? a : b; } };
+
+struct HipBackend {
+    int device;
+    hipStream_t stream;
+    static constexpr bool on_device = true;
+    int error = 0;
+    std::string error_text;
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0;
+    HipBackend(int device_, hipStream_t stream_) : device(device_), stream(stream_) { (void)hipSetDevice(device); }
+    HipBackend(const HipBackend&) = delete;
+    HipBackend& operator=(const HipBackend&) = delete;
+    ~HipBackend() { if (tmp) (void)hipFree(tmp); }
+
+    bool ok(hipError_t e, const char* what) {
+        if (e == hipSuccess) return true;
+        if (!error) { error = e == hipErrorOutOfMemory ? PG_ENOMEM : PG_ENODEV; error_text = std::string(what) + ": " + hipGetErrorString(e); }
+        return false;
+    }
+    template <typename T> T* alloc(size_t n) {
+        void* p = nullptr;
+        (void)hipSetDevice(device);
+        if (!ok(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)), "hipMalloc")) return nullptr;
+        return (T*)p;
+    }
+    void release(void* p) { if (p) (void)hipFree(p); }
+    template <typename T> void fill(T* p, size_t n, T v) {
+        if (!n || error) return;
+        const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 1u << 16);
+        hipLaunchKernelGGL(be_fill_kernel<T>, dim3(grid), dim3(256), 0, stream, p, (uint64_t)n, v);
+        ok(hipGetLastError(), "fill");
+    }
+    template <typename T> void to_host(T* dst, const T* src, size_t n) { if (n && !error) { ok(hipMemcpyAsync((void*)dst, (const void*)src, n * sizeof(T), hipMemcpyDeviceToHost, stream), "copy to host"); ok(hipStreamSynchronize(stream), "sync"); } }
+    template <typename T> void to_device(T* dst, const T* src, size_t n) { if (n && !error) { ok(hipMemcpyAsync((void*)dst, (const void*)src, n * sizeof(T), hipMemcpyHostToDevice, stream), "copy to device"); ok(hipStreamSynchronize(stream), "sync"); } }
+    template <typename T> void copy(T* dst, const T* src, size_t n) { if (n && !error) ok(hipMemcpyAsync((void*)dst, (const void*)src, n * sizeof(T), hipMemcpyDeviceToDevice, stream), "copy"); }
+    void sync() { if (!error) ok(hipStreamSynchronize(stream), "sync"); }
+
+    template <typename F> void launch(uint64_t n, F f) {
+        if (!n || error) return;
+        const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 1u << 20);
+        hipLaunchKernelGGL(be_launch_kernel<F>, dim3(grid), dim3(256), 0, stream, n, f);
+        ok(hipGetLastError(), "launch");
+    }
+    bool scratch(size_t bytes) {
+        if (bytes <= tmp_bytes) return true;
+        if (tmp) (void)hipFree(tmp);
+        tmp = nullptr; tmp_bytes = 0;
+        if (!ok(hipMalloc(&tmp, bytes), "hipMalloc (scratch)")) return false;
+        tmp_bytes = bytes;
+        return true;
+    }
+    template <typename V> void sort_pairs(const uint64_t* kin, uint64_t* kout, const V* vin, V* vout, uint64_t n, int bits) {
+        if (!n || error) return;
+        size_t need = 0;
+        if (!ok((rocprim::radix_sort_pairs<rocprim::default_config, const uint64_t*, uint64_t*, const V*, V*, size_t>(
+                    nullptr, need, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)bits, stream)), "radix sort (size)")) return;
+        if (!scratch(need)) return;
+        ok((rocprim::radix_sort_pairs<rocprim::default_config, const uint64_t*, uint64_t*, const V*, V*, size_t>(
+               tmp, need, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)bits, stream)), "radix sort");
+    }
+    void inclusive_max(const long long* in, long long* out, uint64_t n) {
+        if (!n || error) return;
+        size_t need = 0;
+        if (!ok(hipcub::DeviceScan::InclusiveScan(nullptr, need, in, out, BeMaxLL(), (size_t)n, stream), "scan (size)")) return;
+        if (!scratch(need)) return;
+        ok(hipcub::DeviceScan::InclusiveScan(tmp, need, in, out, BeMaxLL(), (size_t)n, stream), "scan");
+    }
+    void exclusive_sum(const unsigned long long* in, unsigned long long* out, uint64_t n) {
+        if (!n || error) return;
+        size_t need = 0;
+        if (!ok(hipcub::DeviceScan::ExclusiveSum(nullptr, need, in, out, (size_t)n, stream), "sum (size)")) return;
+        if (!scratch(need)) return;
+        ok(hipcub::DeviceScan::ExclusiveSum(tmp, need, in, out, (size_t)n, stream), "sum");
+    }
+};
+
+}  // namespace pg

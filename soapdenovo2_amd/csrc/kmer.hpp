@@ -147,6 +147,9 @@ PG_HD Kmer<NW> kmer_plus(Kmer<NW> a, int ch) {
 //   B = r_links (4 x 6 bit) | linear << 24 | deleted << 25 | checked << 26 | single << 27 | twin << 28 | inEdge << 30
 constexpr uint32_t B_LINEAR = 1u << 24;
 constexpr uint32_t B_DELETED = 1u << 25;
+// the reference's `checked` bit, never set by pregraph: scratch for the host tip scan ("this scan changed the node");
+// must be 0 in every node outside Graph::tip_scan -- asserted before the nodes are uploaded or written out
+constexpr uint32_t B_TOUCHED = 1u << 26;
 constexpr uint32_t B_SINGLE = 1u << 27;
 constexpr int B_TWIN_SHIFT = 28;
 constexpr int B_INEDGE_SHIFT = 30;

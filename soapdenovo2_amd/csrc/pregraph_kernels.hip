@@ -910,6 +910,17 @@ extern "C" int pg_export_take_ws(pg_ctx* c, uint64_t** d_records_out, uint64_t* 
     c->e2.counted = false;
     return PG_OK;
 }
+// a read-only look at the partition engine's export array (valid until the next pg_reset / pg_export_take / pg_destroy)
+extern "C" int pg_export_peek(pg_ctx* c, const uint64_t** d_records_out, uint64_t* n_out) {
+    if (!c || !d_records_out || !n_out) { g_err = "null argument"; return PG_EINVAL; }
+    if (c->engine != 2 || !c->e2.counted) { g_err = "pg_export_peek: partition engine after pg_finalize only"; return PG_ESTATE; }
+    HIP_TRY(hipSetDevice(c->device));
+    unsigned long long n = 0;
+    HIP_TRY(hipMemcpy(&n, &c->ctr->n_export, sizeof n, hipMemcpyDeviceToHost));
+    *d_records_out = c->e2.out;
+    *n_out = n;
+    return PG_OK;
+}
 extern "C" int pg_export_take(pg_ctx* c, uint64_t** d_records_out, uint64_t* n_out) { return pg_export_take_ws(c, d_records_out, n_out, nullptr, nullptr); }
 
 // hipFree for callers that do not link the HIP runtime themselves (what pg_export_take hands over)

@@ -49,6 +49,25 @@ __global__ void sr_gather(const uint64_t* __restrict__ rec, const Idx* __restric
     }
 }
 
+// order-independent digest of a record array: per-column sums mod 2^64, the sum of the coverage fields and the number of
+// saturated ones -- what a caller compares between two passes over the same reads (any batching, any engine) and against
+// the k-mer occurrences that went in (bench.py's conservation check)
+__global__ __launch_bounds__(256) void sr_checksum(const uint64_t* __restrict__ rec, uint64_t n, int rw, unsigned long long* __restrict__ out) {
+    unsigned long long col[6] = {0, 0, 0, 0, 0, 0}, cov = 0, sat = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const uint64_t* r = rec + i * rw;
+        for (int w = 0; w < rw; w++) col[w] += r[w];
+        const uint32_t c = (uint32_t)(r[rw - 2] >> 24) & 0xFFu;
+        cov += c;
+        sat += c == 255u;
+    }
+    for (int w = 0; w < 8; w++) {
+        unsigned long long v = w < 6 ? col[w] : (w == 6 ? cov : sat);
+        for (int d = 32; d > 0; d >>= 1) v += __shfl_down(v, d, 64);
+        if ((threadIdx.x & 63) == 0 && v) atomicAdd(&out[w], v);
+    }
+}
+
 #define SR_HIP(call)                                                                                     \
     do {                                                                                                 \
         hipError_t e_ = (call);                                                                          \
@@ -130,4 +149,21 @@ extern "C" int pg_sort_records_ws(uint64_t* d_records, uint64_t n, int mer127, v
 
 extern "C" int pg_sort_records(uint64_t* d_records, uint64_t n, int mer127, void* stream_v) {
     return pg_sort_records_ws(d_records, n, mer127, nullptr, 0, stream_v);
+}
+
+extern "C" int pg_records_checksum(const uint64_t* d_records, uint64_t n, int rec_words, uint64_t out[8], void* stream_v) {
+    using namespace pg;
+    if (!out || (!d_records && n) || rec_words < 3 || rec_words > 6) { pg_set_error("pg_records_checksum: bad argument"); return PG_EINVAL; }
+    hipStream_t stream = (hipStream_t)stream_v;
+    int rc = PG_OK;
+    unsigned long long* d = nullptr;
+    SR_HIP(hipMalloc((void**)&d, 8 * sizeof(unsigned long long)));
+    SR_HIP(hipMemsetAsync(d, 0, 8 * sizeof(unsigned long long), stream));
+    if (n) hipLaunchKernelGGL(sr_checksum, dim3(4096), dim3(256), 0, stream, d_records, n, rec_words, d);
+    SR_HIP(hipGetLastError());
+    SR_HIP(hipMemcpyAsync(out, d, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
+    SR_HIP(hipStreamSynchronize(stream));
+done:
+    (void)hipFree(d);
+    return rc;
 }

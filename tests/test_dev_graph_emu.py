@@ -1,0 +1,107 @@
+"""The device graph stages (csrc/dev_graph.hpp, csrc/dev_tips.hpp) run on the HostBackend -- the same function objects the HIP
+kernels run, on host threads -- against a plain model and against the sequential host stages.  No GPU."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from conftest import case_codes, oracle_records
+from soapdenovo2_amd import api
+
+EMPTY = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _fcfs_model(keys, S, nw):
+    """put_kmerset into a table that never grows (newhash.c:487-528): first empty slot at or after key mod size, in arrival order."""
+    table = [None] * S
+    for i, k in enumerate(keys):
+        v = 0
+        for w in k:
+            v = (v << 64) | int(w)
+        h = v % S                                   # exact for the 63-mer modulus; the 127-mer chain of 32-bit chunks is a true modulus while S < 2^32
+        while table[h] is not None:
+            h = (h + 1) % S
+        table[h] = i
+    return table
+
+
+def _emu_layout(rec, per_set, S, nw, threads):
+    P = len(per_set)
+    out = np.zeros((P * S, nw + 1), dtype=np.uint64)
+    cnt = np.array(per_set, dtype=np.uint64)
+    rc = api.lib().pg_host_emu_layout_static(rec.ctypes.data, cnt.ctypes.data, P, S, int(nw == 4), threads, out.ctypes.data)
+    return rc, out
+
+
+@pytest.mark.parametrize("nw", [2, 4])
+@pytest.mark.parametrize("S,n,threads", [(1031, 600, 1), (1031, 1000, 4), (257, 250, 3), (4099, 3000, 8), (97, 96, 2)])
+def test_layout_static_equals_first_come_first_served_probing(nw, S, n, threads):
+    """Random keys, several sets, loads up to 99 %: at these loads the last probe cluster wraps around the end of the table in
+    most sets, which is the rotated-frame path of layout_static."""
+    rng = np.random.default_rng(S * 7 + n + nw)
+    P = 3
+    per_set = [n, 0, max(1, n // 2)]
+    total = sum(per_set)
+    rec = np.zeros((total, nw + 2), dtype=np.uint64)
+    rec[:, :nw] = rng.integers(0, 1 << 62, size=(total, nw), dtype=np.uint64)
+    rec[:, 0] >>= np.uint64(3)                       # K <= 63 / 127 leaves the top bits of word 0 clear
+    # homes concentrated near the end of the table in set 0, so that its last cluster certainly wraps
+    for i in range(per_set[0] // 4):
+        v = 0
+        for w in rec[i, :nw]:
+            v = (v << 64) | int(w)
+        want = S - 1 - (i % 5)
+        v += (want - v % S) % S
+        for w in range(nw - 1, -1, -1):
+            rec[i, w] = np.uint64(v & 0xFFFFFFFFFFFFFFFF); v >>= 64
+    rec[:, nw] = np.arange(total, dtype=np.uint64) + np.uint64(1000)            # cnt: anything recognisable
+    at = 0
+    for s, c in enumerate(per_set):
+        rec[at:at + c, nw + 1] = (np.uint64(s) << np.uint64(56)) | np.arange(c, dtype=np.uint64)
+        at += c
+    rc, out = _emu_layout(rec, per_set, S, nw, threads)
+    assert rc == 0
+    at = 0
+    wrapped = False
+    for s, c in enumerate(per_set):
+        table = _fcfs_model(rec[at:at + c, :nw], S, nw)
+        img = out[s * S:(s + 1) * S]
+        for slot in range(S):
+            if table[slot] is None:
+                assert img[slot, 0] == EMPTY, (s, slot)
+            else:
+                assert (img[slot] == rec[at + table[slot], :nw + 1]).all(), (s, slot)
+        wrapped = wrapped or (c and table[S - 1] is not None and table[0] is not None)
+        at += c
+    assert wrapped
+
+
+def test_layout_static_refuses_a_full_pool():
+    rec = np.zeros((97, 4), dtype=np.uint64)
+    rec[:, 1] = np.arange(97, dtype=np.uint64)
+    rc, _ = _emu_layout(rec, [97], 97, 2, 1)
+    assert rc == 1                                   # unsuited: the caller replays on the host (which reports the exploded pool)
+
+
+@pytest.mark.parametrize("name,P,a,m", [("t6k_k31", 2, 1, False), ("t8k_k63", 2, 1, True), ("t6k_k127", 3, 1, True)])
+def test_layout_static_equals_the_host_replay_on_golden_cases(golden, tmp_path, name, P, a, m):
+    """-a pools of the golden cases: the emulated device layout puts every k-mer into the slot the sequential host replay
+    (pinned slot by slot on the oracle, tests/test_host_graph.py) puts it."""
+    c = golden["cases"][name]
+    codes = case_codes(c)
+    rec, last, K = oracle_records(codes, c["K"], P, mer127=m, a_gb=a, prefix=str(tmp_path / "o"))
+    nw = 4 if m else 2
+    rec = rec[np.argsort(rec[:, nw + 1], kind="stable")]                    # replay order: (set, first ordinal)
+    slots, sizes = api.host_replay_layout(rec, last, P, mer127=m, a_gb=a)
+    S = int(sizes[0])
+    assert all(int(x) == S for x in sizes)
+    per_set = [int(((rec[:, nw + 1] >> np.uint64(56)) == np.uint64(s)).sum()) for s in range(P)]
+    # the image is P * S slots of 24 / 40 bytes: a few GB at -a 1 -- keep the comparison to the occupied slots
+    out = np.zeros((P * S, nw + 1), dtype=np.uint64)
+    cnt = np.array(per_set, dtype=np.uint64)
+    rc = api.lib().pg_host_emu_layout_static(np.ascontiguousarray(rec).ctypes.data, cnt.ctypes.data, P, S, int(m), 4, out.ctypes.data)
+    assert rc == 0
+    sets = (rec[:, nw + 1] >> np.uint64(56)).astype(np.int64)
+    got = out[sets * S + slots.astype(np.int64)]
+    assert (got == rec[:, :nw + 1]).all()
+    assert int((out[:, 0] != EMPTY).sum()) == len(rec)
