@@ -138,6 +138,15 @@ pg_graph *pg_graph_begin_streamed(int (*fetch)(void *user, uint64_t first_record
                                   uint64_t n_records, const uint64_t *per_set_count, const uint64_t *set_last_put, int K,
                                   int mer127, int n_sets, int cut_single, int a_gb, int max_read_len, int n_threads,
                                   const char *prefix, int device);
+/* pg_graph_begin for records that lie in the memory of HIP device `records_device`, in replay order (pg_sort_records), with the
+ * copies in the library's hands.  With -a (a_gb != 0: static pools, which never grow or rehash, newhash.c:353-366) and
+ * device == records_device the k-mer-set layout itself is made on the device (SURVEY.md App. C "K6": first-come-first-served
+ * probing as a sort by home slot + one sweep per probe cluster) and only downloaded; growable sets (a_gb == 0) are replayed
+ * by the host threads, which pull their stretch of records chunk by chunk.  SOAPDENOVO2_AMD_LAYOUT=host keeps the host
+ * replay for -a too (A/B runs). */
+pg_graph *pg_graph_begin_device(const uint64_t *d_records, int records_device, uint64_t n_records, const uint64_t *per_set_count,
+                                const uint64_t *set_last_put, int K, int mer127, int n_sets, int cut_single, int a_gb,
+                                int max_read_len, int n_threads, const char *prefix, int device);
 pg_graph *pg_host_graph_begin(const uint64_t *records, uint64_t n_records, const uint64_t *set_last_put, int K, int mer127,
                               int n_sets, int cut_single, int a_gb, int max_read_len, int n_threads, const char *prefix);
 int pg_host_graph_resolve_repeats(pg_graph *g, int on);

@@ -51,6 +51,8 @@ def main():
     ap.add_argument("--unverified", action="store_true", help="run without an expectation (the result says so)")
     ap.add_argument("--env", action="append", default=[], help="NAME=VALUE for the command (repeatable)")
     ap.add_argument("--keep-fastq", action="store_true")
+    ap.add_argument("--tag", default="", help="suffix of result.json / stderr.txt (several runs into one --out)")
+    ap.add_argument("--rocprof", default="", help="run the command under rocprofv3 with these arguments (e.g. '--kernel-trace --stats'), output next to result.json")
     a = ap.parse_args()
     key = {k: getattr(a, k) for k in ("reads", "read_len", "genome", "err", "seed", "kmer", "sets", "a_gb")}
     want = None
@@ -78,11 +80,18 @@ def main():
     pre = os.path.join(a.out, "ref" if a.reference else "amd")
     cmd = [binary, "pregraph", "-s", cfg, "-K", str(a.kmer), "-o", pre, "-p", str(a.sets)] + (["-a", str(a.a_gb)] if a.a_gb else [])
     env = dict(os.environ, PG_HOST_VERBOSE="1", **dict(kv.split("=", 1) for kv in a.env))
+    cwd = None
+    if a.rocprof:
+        prof_dir = os.path.abspath(os.path.join(a.out, "prof" + a.tag))
+        cmd = ["rocprofv3"] + a.rocprof.split() + ["--output-format", "csv", "-d", prof_dir, "--"] + [os.path.abspath(c) if os.path.exists(c) else c for c in cmd]
+        cmd[cmd.index("-o") + 1] = os.path.abspath(pre)
+        env["TMPDIR"] = "/tmp"
+        cwd = "/tmp"
     t = time.time()
-    r = subprocess.run(cmd, capture_output=True, text=True, env=env)
+    r = subprocess.run(cmd, capture_output=True, text=True, env=env, cwd=cwd)
     res.update({"command": " ".join(cmd[1:]), "binary": os.path.relpath(binary, ROOT), "wall_s": round(time.time() - t, 2), "rc": r.returncode,
                 "log": [l for l in r.stderr.splitlines() if any(k in l for k in KEEP)]})
-    open(os.path.join(a.out, "stderr.txt"), "w").write(r.stderr)
+    open(os.path.join(a.out, f"stderr{a.tag}.txt"), "w").write(r.stderr)
     ok = r.returncode == 0
     if ok:
         res["md5"] = md5s(pre)
@@ -95,10 +104,11 @@ def main():
     else:
         res["stderr_tail"] = r.stderr[-1500:]
     for f in os.listdir(a.out):
-        if f not in ("result.json", "stderr.txt") and not (a.keep_fastq and f in ("reads.fq", "lib.cfg")):
-            os.remove(os.path.join(a.out, f))
+        full = os.path.join(a.out, f)
+        if os.path.isfile(full) and not f.startswith(("result", "stderr")) and not (a.keep_fastq and f in ("reads.fq", "lib.cfg")):
+            os.remove(full)
     print(json.dumps(res, indent=1))
-    json.dump(res, open(os.path.join(a.out, "result.json"), "w"), indent=1)
+    json.dump(res, open(os.path.join(a.out, f"result{a.tag}.json"), "w"), indent=1)
     if a.reference and a.save and ok:
         json.dump({"workload": key, "md5": res["md5"], "reference_wall_s": res["wall_s"], "log": res["log"],
                    "made_by": "scripts/big_cli_check.py --reference (oracle/_ref, built from /root/reference by oracle/Makefile.ref)"}, open(a.save, "w"), indent=1)

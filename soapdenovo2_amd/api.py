@@ -72,6 +72,8 @@ def lib() -> C.CDLL:
     L.pg_graph_begin_streamed.restype = C.c_void_p
     L.pg_graph_begin_streamed.argtypes = [FETCH_FN, C.c_void_p, C.c_uint64, u64p, u64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_int, C.c_char_p, C.c_int]
+    L.pg_graph_begin_device.restype = C.c_void_p
+    L.pg_graph_begin_device.argtypes = [u64p, C.c_int, C.c_uint64, u64p, u64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_char_p, C.c_int]
     L.pg_host_graph_add_reads.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int]
     L.pg_host_graph_finish.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_longlong)]
     L.pg_host_graph_resolve_repeats.argtypes = [C.c_void_p, C.c_int]
@@ -146,7 +148,7 @@ EXPORTED_SYMBOLS = [
     "pg_export_take", "pg_export_take_ws", "pg_export_peek", "pg_records_checksum", "pg_sort_records_ws", "pg_device_free", "pg_set_counts", "pg_last_put", "pg_host_last_put_matters", "pg_comm_unique_id", "pg_comm_create", "pg_comm_create_local", "pg_comm_destroy", "pg_comm_rank", "pg_comm_size",
     "pg_comm_transport", "pg_comm_stats", "pg_exchange_counts", "pg_exchange_records", "pg_exchange_allreduce_u64",
     "pg_exchange_gather_records", "pg_count_reads_sharded", "pg_host_skm_cut", "pg_host_skm_expand",
-    "pg_host_emu_layout_static",
+    "pg_host_emu_layout_static", "pg_graph_begin_device",
 ]
 
 

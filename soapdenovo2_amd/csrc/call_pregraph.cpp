@@ -789,35 +789,10 @@ int run(int argc, char** argv, bool mer127) {
     if (const char* e = getenv("SOAPDENOVO2_AMD_EDGES")) host_edges = strcmp(e, "host") == 0;
     if (const char* e = getenv("SOAPDENOVO2_AMD_PASS2")) host_pass2 = strcmp(e, "host") == 0;
     if (host_pass2) host_edges = true;                               // host pass 2 needs the host copy of the sets tagged
-    struct Fetch {
-        const uint64_t* d_rec; int rw, device;
-        // called from the replay's worker threads: each keeps its own stream and has its chunk buffer page-locked once, so
-        // the copies are plain DMA that run side by side (pageable copies on the null stream queue up behind each other)
-        static int call(void* user, uint64_t first, uint64_t n, uint64_t* dst) {
-            const Fetch* f = (const Fetch*)user;
-            struct PerThread {
-                hipStream_t st = nullptr; void* reg = nullptr; size_t bytes = 0;
-                ~PerThread() { if (reg) hipHostUnregister(reg); if (st) hipStreamDestroy(st); }
-            };
-            static thread_local PerThread t;
-            if (hipSetDevice(f->device) != hipSuccess) return PG_ENODEV;
-            if (n == 0) {                                         // the worker is done: let go of its buffer before it is unmapped
-                if (t.reg) { hipHostUnregister(t.reg); t.reg = nullptr; t.bytes = 0; }
-                return PG_OK;
-            }
-            const size_t bytes = (size_t)n * f->rw * sizeof(uint64_t);
-            if (!t.st && hipStreamCreateWithFlags(&t.st, hipStreamNonBlocking) != hipSuccess) return PG_ENODEV;
-            if (t.reg != (void*)dst || t.bytes < bytes) {
-                if (t.reg) { hipHostUnregister(t.reg); t.reg = nullptr; }
-                if (hipHostRegister(dst, bytes, hipHostRegisterDefault) == hipSuccess) { t.reg = dst; t.bytes = bytes; }
-            }
-            if (hipMemcpyAsync(dst, f->d_rec + first * f->rw, bytes, hipMemcpyDeviceToHost, t.st) != hipSuccess) return PG_ENODEV;
-            return hipStreamSynchronize(t.st) == hipSuccess ? PG_OK : PG_ENODEV;
-        }
-    } fetch{d_rec, rw, device};
+    // records still on the device: with -a the layout is made there (K6), otherwise the replay's workers pull their stretches
     pg_graph* graph = stream_records
-        ? pg_graph_begin_streamed(&Fetch::call, &fetch, n_distinct, per_set.data(), set_last.data(), K, mer127 ? 1 : 0, o.sets, o.delow == 0, o.a_gb,
-                                  max_read_len, 0, o.prefix.c_str(), host_edges ? -1 : device)
+        ? pg_graph_begin_device(d_rec, device, n_distinct, per_set.data(), set_last.data(), K, mer127 ? 1 : 0, o.sets, o.delow == 0, o.a_gb,
+                                max_read_len, 0, o.prefix.c_str(), host_edges ? -1 : device)
         : pg_graph_begin(records.data(), n_distinct, set_last.data(), K, mer127 ? 1 : 0, o.sets, o.delow == 0, o.a_gb,
                          max_read_len, 0, o.prefix.c_str(), host_edges ? -1 : device);
     if (d_rec) { hipFree(d_rec); d_rec = nullptr; }

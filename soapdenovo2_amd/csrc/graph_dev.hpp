@@ -38,6 +38,14 @@ struct P2Edges {
 // step by step: upload the sets; then either the host's (K+1)-mer table (p2_set_patch) or the edges built on the device
 // (p2_build_edges: tags the device copy of the sets and fills the device (K+1)-mer table itself); then p2_begin_reads
 P2Device* p2_open(int device, int K, int nw, int n_sets, const P2Sets& sets, int max_nk);
+// SURVEY.md App. C "K6": static (-a) pools laid out on the device from the records as they lie there sorted by (set, ordinal)
+// (every set has set_size slots); *unsuited = true (and nullptr) when a set fills its pool or holds >= 2^32 keys -- the
+// caller replays on the host then.  p2_download_set: one set's slot array into host memory.  p2_fetch_words: device -> host
+// copies from several host threads at once (n_words = 0: the calling thread is done).
+P2Device* p2_open_layout(int device, int K, int nw, int n_sets, const uint64_t* d_records, const uint64_t* per_set_count, uint64_t set_size,
+                         int max_nk, bool* unsuited);
+int p2_download_set(P2Device* d, int set, void* dst);
+int p2_fetch_words(int device, const uint64_t* d_src, uint64_t n_words, uint64_t* dst);
 int p2_set_patch(P2Device* d, const uint64_t* patch_keys, const uint32_t* patch_val, uint64_t patch_cap);
 int p2_build_edges(P2Device* d, P2Edges& out);
 int p2_begin_reads(P2Device* d, uint32_t num_ed, bool reps);

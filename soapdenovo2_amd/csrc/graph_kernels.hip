@@ -31,6 +31,9 @@
 #include "extract.hpp"
 #include "kmer.hpp"
 #include "graph_dev.hpp"
+#include "graph_lookup.hpp"
+#include "backend_hip.hpp"
+#include "dev_graph.hpp"
 
 namespace pg {
 
@@ -71,31 +74,6 @@ struct P2Params {
     // 4 markers, 5 edge id out of range
     unsigned long long* counters;
 };
-
-// ((r << 32) | chunk) mod d for r < d, exact for any d < 2^63
-__device__ inline uint64_t mod_step32(uint64_t r, uint32_t chunk, uint64_t d) {
-    if (d <= 0x100000000ULL) return ((r << 32) | chunk) % d;
-    for (int b = 31; b >= 0; b--) {
-        r = (r << 1) | ((chunk >> b) & 1u);
-        if (r >= d) r -= d;
-    }
-    return r;
-}
-template <int NW>
-__device__ inline uint64_t home_slot(const Kmer<NW>& k, uint64_t size) {
-    if (NW == 2) {                                   // exact 128-bit modulus (newhash.c:36-57, 63-mer build)
-        uint64_t r = k.w[0] % size;
-        r = mod_step32(r, (uint32_t)(k.w[1] >> 32), size);
-        return mod_step32(r, (uint32_t)k.w[1], size);
-    }
-    uint64_t t = k.w[0] % size;                      // the 127-mer build folds 32-bit chunks in 64-bit arithmetic
-#pragma unroll
-    for (int i = 1; i < NW; i++) {
-        t = (t << 32 | (k.w[i] >> 32)) % size;
-        t = (t << 32 | (k.w[i] & 0xffffffffULL)) % size;
-    }
-    return t;
-}
 
 // search_kmerset, returning the node's global slot (set base + slot), ~0 when absent
 template <int NW>
@@ -589,6 +567,7 @@ struct P2Device {
     uint64_t n_slots = 0;
     bool reads_ready = false;
     hipStream_t stream = nullptr;
+    std::vector<uint64_t> set_sizes;     // host copy of the geometry
 };
 
 static void p2_free(P2Device* d) {
@@ -610,6 +589,7 @@ static int p2_open_impl(P2Device* d, const P2Sets& sets) {
     uint64_t total = 0;
     std::vector<uint64_t> geo(2 * (size_t)d->P);
     for (int s = 0; s < d->P; s++) { geo[s] = total; geo[d->P + s] = sets.size[s]; total += sets.size[s]; }
+    d->set_sizes.assign(sets.size, sets.size + d->P);
     d->n_slots = total;
     P2_HIP(hipMalloc((void**)&d->d_geo, geo.size() * sizeof(uint64_t)));
     P2_HIP(hipMemcpy(d->d_geo, geo.data(), geo.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
@@ -635,6 +615,94 @@ P2Device* p2_open(int device, int K, int nw, int n_sets, const P2Sets& sets, int
     d->device = device; d->K = K; d->nw = nw; d->P = n_sets; d->max_nk = std::max(max_nk, 1);
     if (p2_open_impl(d, sets) != PG_OK) { p2_free(d); return nullptr; }
     return d;
+}
+
+// nodes of an empty image: first key word all-ones, the rest zero
+__global__ void p2_empty_image(uint64_t* nodes, int nw1, uint64_t n_slots) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots * nw1; i += (uint64_t)gridDim.x * blockDim.x)
+        nodes[i] = (i % nw1) ? 0ULL : P2_EMPTY;
+}
+
+// SURVEY.md App. C "K6": the k-mer sets of a static (-a) pool laid out on the device, from the distinct k-mers of pass 1 as
+// they lie there sorted by (set, first ordinal) -- no host replay, no upload (dev_graph.hpp: layout_static)
+P2Device* p2_open_layout(int device, int K, int nw, int n_sets, const uint64_t* d_records, const uint64_t* per_set_count, uint64_t set_size,
+                         int max_nk, bool* unsuited) {
+    *unsuited = false;
+    if (n_sets < 1 || n_sets > P2_MAX_SETS || (nw != 2 && nw != 4)) { pg_set_error("layout: bad arguments"); return nullptr; }
+    P2Device* d = new P2Device();
+    d->device = device; d->K = K; d->nw = nw; d->P = n_sets; d->max_nk = std::max(max_nk, 1);
+    auto fail = [&](const std::string& why) -> P2Device* { if (!why.empty()) pg_set_error(why); p2_free(d); return nullptr; };
+    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&d->stream) != hipSuccess) return fail("layout: no HIP device");
+    memset(&d->prm, 0, sizeof(d->prm));
+    const int NW1 = nw + 1;
+    const uint64_t total = (uint64_t)n_sets * set_size;
+    std::vector<uint64_t> geo(2 * (size_t)n_sets);
+    for (int s = 0; s < n_sets; s++) { geo[s] = (uint64_t)s * set_size; geo[n_sets + s] = set_size; }
+    d->set_sizes.assign(n_sets, set_size);
+    d->n_slots = total;
+    if (hipMalloc((void**)&d->d_geo, geo.size() * sizeof(uint64_t)) != hipSuccess || hipMalloc((void**)&d->d_nodes, total * NW1 * sizeof(uint64_t)) != hipSuccess ||
+        hipMalloc((void**)&d->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess)
+        return fail("layout: out of device memory for the k-mer sets (" + std::to_string(total * NW1 * 8 >> 20) + " MiB)");
+    (void)hipMemcpyAsync(d->d_geo, geo.data(), geo.size() * sizeof(uint64_t), hipMemcpyHostToDevice, d->stream);
+    (void)hipMemsetAsync(d->d_counters, 0, 8 * sizeof(unsigned long long), d->stream);
+    hipLaunchKernelGGL(p2_empty_image, dim3(8192), dim3(256), 0, d->stream, d->d_nodes, NW1, total);
+    int rc;
+    {
+        HipBackend be(device, d->stream);
+        rc = nw == 2 ? layout_static<HipBackend, 2>(be, d_records, per_set_count, n_sets, set_size, d->d_nodes)
+                     : layout_static<HipBackend, 4>(be, d_records, per_set_count, n_sets, set_size, d->d_nodes);
+        if (rc < 0) return fail("layout: " + (be.error_text.empty() ? std::string("failed") : be.error_text));
+    }
+    if (rc == K6_UNSUITED) { *unsuited = true; return fail(""); }
+    if (hipStreamSynchronize(d->stream) != hipSuccess) return fail("layout: kernel failure");
+    P2Params& p = d->prm;
+    p.nodes = d->d_nodes;
+    p.set_base = d->d_geo; p.set_size = d->d_geo + d->P;
+    p.P = (uint32_t)d->P; p.bias = set_bias((uint32_t)d->P); p.K = d->K;
+    p.max_nk = d->max_nk;
+    p.counters = d->d_counters;
+    return d;
+}
+
+// one set's slots, as they are on the device now, into host memory (size * (nw + 1) words)
+int p2_download_set(P2Device* d, int set, void* dst) {
+    P2_HIP(hipSetDevice(d->device));
+    uint64_t first = 0;
+    for (int s = 0; s < set; s++) first += d->set_sizes[s];
+    const size_t bytes = (size_t)d->set_sizes[set] * (d->nw + 1) * sizeof(uint64_t);
+    hipStream_t st = nullptr;
+    P2_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    const bool reg = hipHostRegister(dst, bytes, hipHostRegisterDefault) == hipSuccess;       // plain DMA instead of staged copies
+    hipError_t e = hipMemcpyAsync(dst, d->d_nodes + first * (d->nw + 1), bytes, hipMemcpyDeviceToHost, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    if (reg) (void)hipHostUnregister(dst);
+    (void)hipStreamDestroy(st);
+    if (e != hipSuccess) { pg_set_error(std::string("download of a k-mer set: ") + hipGetErrorString(e)); return PG_ENODEV; }
+    return PG_OK;
+}
+
+// a stretch of device-resident records into host memory; called from the layout replay's worker threads: each keeps its own
+// stream and has its chunk buffer page-locked once, so the copies are plain DMA that run side by side (pageable copies on
+// the null stream queue up behind each other).  n_words = 0: the calling thread will not ask again.
+int p2_fetch_words(int device, const uint64_t* d_src, uint64_t n_words, uint64_t* dst) {
+    struct PerThread {
+        hipStream_t st = nullptr; void* reg = nullptr; size_t bytes = 0;
+        ~PerThread() { if (reg) (void)hipHostUnregister(reg); if (st) (void)hipStreamDestroy(st); }
+    };
+    static thread_local PerThread t;
+    if (hipSetDevice(device) != hipSuccess) return PG_ENODEV;
+    if (n_words == 0) {                                   // let go of the buffer before its owner unmaps it
+        if (t.reg) { (void)hipHostUnregister(t.reg); t.reg = nullptr; t.bytes = 0; }
+        return PG_OK;
+    }
+    const size_t bytes = (size_t)n_words * sizeof(uint64_t);
+    if (!t.st && hipStreamCreateWithFlags(&t.st, hipStreamNonBlocking) != hipSuccess) return PG_ENODEV;
+    if (t.reg != (void*)dst || t.bytes < bytes) {
+        if (t.reg) { (void)hipHostUnregister(t.reg); t.reg = nullptr; }
+        if (hipHostRegister(dst, bytes, hipHostRegisterDefault) == hipSuccess) { t.reg = dst; t.bytes = bytes; }
+    }
+    if (hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, t.st) != hipSuccess) return PG_ENODEV;
+    return hipStreamSynchronize(t.st) == hipSuccess ? PG_OK : PG_ENODEV;
 }
 
 // KmerSetsPatch as the host built it

@@ -272,6 +272,13 @@ struct HSet {
         for (uint64_t i = 0; i < size; i++) array[i].seq.w[0] = EMPTY;
         occ.assign(size, 0);
     }
+    // storage for a layout made elsewhere (the device's K6 layout is downloaded into it): `sz` slots, `n` of them occupied
+    void adopt(uint64_t sz, uint64_t n) {
+        set_size(sz); count = n; lf = 0.77f;
+        max = (uint64_t)((float)size * lf);
+        array.reset(size);
+        occ.assign(size, 0);
+    }
     // encap_kmerset, growable case (newhash.c:368-454): next size, then re-home in place in old-slot order,
     // an element that lands on a not-yet-moved old element kicks it out and that one is placed next
     double t_grow = 0;
@@ -2108,21 +2115,85 @@ struct GraphHandle : GraphHandleBase {
     }
 };
 
+// records that lie in device memory (device `rec_device`, replay order): pulled by the replay's workers chunk by chunk
+struct DeviceRecords { const uint64_t* d_rec; int rw, device; };
+static int fetch_device_records(void* user, uint64_t first, uint64_t n, uint64_t* dst) {
+    const DeviceRecords* f = (const DeviceRecords*)user;
+    return p2_fetch_words(f->device, f->d_rec + first * (uint64_t)f->rw, n * (uint64_t)f->rw, dst);
+}
+
+// SURVEY.md App. C "K6": with -a the sets never grow, and their layout is made on the device from the records as they lie
+// there (graph_kernels.hip: p2_open_layout, dev_graph.hpp: layout_static).  The host copy the tip decisions and the vertex
+// writer still read is a download of that image.  Returns PG_OK, 1 = unsuited (the caller replays on the host), or PG_E*.
+template <int NW>
+static int layout_on_device(GraphHandle<NW>* h, const uint64_t* d_records, const uint64_t* per_set_count, int K, int P, int a_gb, int n_threads,
+                            int device) {
+    Graph<NW>& g = h->g;
+    g.K = K; g.P = P; g.filter = kmer_filter<NW>(K); g.bias = set_bias((uint32_t)P); g.crc = host_crc_table();
+    host_crc8_init();
+    g.n_threads = n_threads;
+    const uint64_t S = ref_initial_set_size(a_gb, P, NW == 4);
+    auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    const double t0 = now();
+    bool unsuited = false;
+    P2Device* dev = p2_open_layout(device, K, NW, P, d_records, per_set_count, S, h->max_nk(), &unsuited);
+    if (!dev) return unsuited ? 1 : PG_ENODEV;
+    const double t1 = now();
+    g.sets.clear();
+    g.sets.resize(P);
+    g.set_base.assign((size_t)P + 1, 0);
+    for (int si = 0; si < P; si++) g.set_base[si + 1] = g.set_base[si] + S;
+    std::atomic<int> next{0}, failed{0};
+    auto worker = [&]() {
+        for (;;) {
+            const int si = next.fetch_add(1);
+            if (si >= P) break;
+            HSet<NW>& hs = g.sets[si];
+            hs.adopt(S, per_set_count[si]);
+            if (p2_download_set(dev, si, hs.array.data()) != PG_OK) { failed.store(1); continue; }
+            for (uint64_t i = 0; i < S; i++) hs.occ[i] = hs.array[i].seq.w[0] != HSet<NW>::EMPTY;
+        }
+    };
+    {
+        const int nt = std::max(1, std::min(pick_threads(n_threads), P));
+        std::vector<std::thread> pool;
+        for (int t = 1; t < nt; t++) pool.emplace_back(worker);
+        worker();
+        for (auto& th : pool) th.join();
+    }
+    if (failed.load()) { p2_destroy(dev); return PG_ENODEV; }
+    h->dev = dev; h->dev_on = true; h->dev_id = device;
+    g.tip_dev = dev;
+    if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "k-mer set layout on the device (K6): %.2fs; host copy downloaded: %.2fs\n", t1 - t0, now() - t1);
+    return PG_OK;
+}
+
 template <int NW>
 static GraphHandleBase* graph_begin(const uint64_t* records, uint64_t n, const uint64_t* set_last_put, int K, int P, int cut_single,
                                     int a_gb, int max_read_len, int n_threads, const char* prefix_c, int device,
-                                    pg_fetch_fn fetch = nullptr, void* fetch_user = nullptr, const uint64_t* per_set_count = nullptr) {
+                                    pg_fetch_fn fetch = nullptr, void* fetch_user = nullptr, const uint64_t* per_set_count = nullptr,
+                                    const uint64_t* d_records = nullptr, int rec_device = -1) {
     GraphHandle<NW>* h = new GraphHandle<NW>();
     h->prefix = prefix_c;
     h->max_read_len = max_read_len;
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t0 = now();
-    const int rc_replay = fetch ? replay_streamed<NW>(h->g, fetch, fetch_user, n, per_set_count, set_last_put, K, P, a_gb, n_threads)
-                                : replay_layout<NW>(h->g, records, n, set_last_put, K, P, a_gb, n_threads);
+    int rc_replay = 1;
+    DeviceRecords dr{d_records, NW + 2, rec_device};
+    if (d_records) {
+        // -a pools: the layout is made where the records are (SOAPDENOVO2_AMD_LAYOUT=host keeps the host replay, for A/B runs)
+        const char* where = getenv("SOAPDENOVO2_AMD_LAYOUT");
+        if (a_gb != 0 && device >= 0 && device == rec_device && !(where && !strcmp(where, "host")) && !getenv("SOAPDENOVO2_AMD_TIPS_HOST"))
+            rc_replay = layout_on_device<NW>(h, d_records, per_set_count, K, P, a_gb, n_threads, device);
+        if (rc_replay == 1) { fetch = &fetch_device_records; fetch_user = &dr; }
+    }
+    if (rc_replay == 1)
+        rc_replay = fetch ? replay_streamed<NW>(h->g, fetch, fetch_user, n, per_set_count, set_last_put, K, P, a_gb, n_threads)
+                          : replay_layout<NW>(h->g, records, n, set_last_put, K, P, a_gb, n_threads);
     if (rc_replay != PG_OK) { delete h; return nullptr; }
     fprintf(stderr, "Time spent on rebuilding the k-mer set layout: %.1fs.\n", now() - t0);
     t0 = now();
-    if (device >= 0 && !getenv("SOAPDENOVO2_AMD_TIPS_HOST") && h->dev_open(device) != PG_OK) { delete h; return nullptr; }
+    if (device >= 0 && !getenv("SOAPDENOVO2_AMD_TIPS_HOST") && !h->dev && h->dev_open(device) != PG_OK) { delete h; return nullptr; }
     if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "k-mer sets uploaded to the device: %.2fs\n", now() - t0);
     if (cut_single) h->g.remove_single_tips();
     h->g.remove_minor_tips();
@@ -2215,6 +2286,19 @@ extern "C" pg_graph* pg_graph_begin_streamed(int (*fetch)(void*, uint64_t, uint6
     if (n_sets < 1 || n_sets > 255) { pg_set_error("n_sets must be 1..255"); return nullptr; }
     pg::GraphHandleBase* h = mer127 ? pg::graph_begin<4>(nullptr, n_records, set_last_put, K, n_sets, cut_single, a_gb, max_read_len, n_threads, prefix, device, fetch, user, per_set_count)
                                     : pg::graph_begin<2>(nullptr, n_records, set_last_put, K, n_sets, cut_single, a_gb, max_read_len, n_threads, prefix, device, fetch, user, per_set_count);
+    return (pg_graph*)h;
+}
+extern "C" pg_graph* pg_graph_begin_device(const uint64_t* d_records, int records_device, uint64_t n_records, const uint64_t* per_set_count,
+                                           const uint64_t* set_last_put, int K, int mer127, int n_sets, int cut_single, int a_gb, int max_read_len,
+                                           int n_threads, const char* prefix, int device) {
+    if ((!d_records && n_records) || !per_set_count || !prefix) { pg_set_error("null argument"); return nullptr; }
+    const int maxK = mer127 ? 127 : 63;
+    if (K < 13 || K > maxK || !(K & 1)) { pg_set_error("K must be odd and within 13.." + std::to_string(maxK)); return nullptr; }
+    if (n_sets < 1 || n_sets > 255) { pg_set_error("n_sets must be 1..255"); return nullptr; }
+    static const uint64_t none = 0;
+    const uint64_t* recs = d_records ? d_records : &none;        // (no records: an address nobody reads)
+    pg::GraphHandleBase* h = mer127 ? pg::graph_begin<4>(nullptr, n_records, set_last_put, K, n_sets, cut_single, a_gb, max_read_len, n_threads, prefix, device, nullptr, nullptr, per_set_count, recs, records_device)
+                                    : pg::graph_begin<2>(nullptr, n_records, set_last_put, K, n_sets, cut_single, a_gb, max_read_len, n_threads, prefix, device, nullptr, nullptr, per_set_count, recs, records_device);
     return (pg_graph*)h;
 }
 extern "C" int pg_graph_use_device(pg_graph* g, int device) {
