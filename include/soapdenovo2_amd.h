@@ -363,6 +363,14 @@ int pg_count_reads_sharded(pg_ctx *ctx, pg_comm *comm, const uint64_t *d_packed,
 int pg_host_emu_layout_static(const uint64_t *records, const uint64_t *per_set_count, int n_sets, uint64_t set_size, int mer127,
                               int n_threads, uint64_t *nodes_out);
 
+/* tip clipping (removeSingleTips / removeMinorTips, cutTipPreGraph.c:363-488) as the device decides it (csrc/dev_tips.hpp: a
+ * fixed point over start decisions, one lane per stop node) next to the sequential host scan, on two copies of the layout
+ * replayed from `records`: out[0], out[1] = tips the sequential scan removed (single, minor); out[2], out[3] = the same from
+ * the emulated device stage; out[4] = nodes whose counter words differ afterwards (must be 0); out[5] = fixed-point rounds;
+ * out[6] = minor cycles. */
+int pg_host_emu_clip_tips(const uint64_t *records, uint64_t n_records, const uint64_t *set_last_put, int K, int mer127, int n_sets,
+                          int cut_single, int a_gb, int n_threads, uint64_t out[8]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -89,7 +89,8 @@ struct HostBackend {
         for (auto& th : pool) th.join();
     }
     // stable sort of (key, value) pairs by the low `bits` bits of the key
-    template <typename V> void sort_pairs(const uint64_t* kin, uint64_t* kout, const V* vin, V* vout, uint64_t n, int bits) {
+    template <typename KT, typename V> void sort_pairs(const KT* kin, KT* kout, const V* vin, V* vout, uint64_t n, int bits) {
+        static_assert(sizeof(KT) == 8, "64-bit keys");
         std::vector<uint64_t> idx(n);
         for (uint64_t i = 0; i < n; i++) idx[i] = i;
         const uint64_t mask = bits >= 64 ? ~0ULL : ((1ULL << bits) - 1);

@@ -72,13 +72,14 @@ struct HipBackend {
         tmp_bytes = bytes;
         return true;
     }
-    template <typename V> void sort_pairs(const uint64_t* kin, uint64_t* kout, const V* vin, V* vout, uint64_t n, int bits) {
+    template <typename KT, typename V> void sort_pairs(const KT* kin, KT* kout, const V* vin, V* vout, uint64_t n, int bits) {
+        static_assert(sizeof(KT) == 8, "64-bit keys");
         if (!n || error) return;
         size_t need = 0;
-        if (!ok((rocprim::radix_sort_pairs<rocprim::default_config, const uint64_t*, uint64_t*, const V*, V*, size_t>(
+        if (!ok((rocprim::radix_sort_pairs<rocprim::default_config, const KT*, KT*, const V*, V*, size_t>(
                     nullptr, need, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)bits, stream)), "radix sort (size)")) return;
         if (!scratch(need)) return;
-        ok((rocprim::radix_sort_pairs<rocprim::default_config, const uint64_t*, uint64_t*, const V*, V*, size_t>(
+        ok((rocprim::radix_sort_pairs<rocprim::default_config, const KT*, KT*, const V*, V*, size_t>(
                tmp, need, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)bits, stream)), "radix sort");
     }
     void inclusive_max(const long long* in, long long* out, uint64_t n) {

@@ -120,7 +120,7 @@ int layout_static(BE& be, const uint64_t* records, const uint64_t* per_set_count
             hk[i] = home_slot<NW>(k, S);
             iv[i] = (uint32_t)i;
         });
-        be.template sort_pairs<uint32_t>(hk, hs, iv, is, n, bits);
+        be.sort_pairs(hk, hs, iv, is, n, bits);
         be.launch(n, [=] PG_LAMBDA(uint64_t j) { v[j] = (long long)hs[j] - (long long)j; });
         be.inclusive_max(v, m, n);
         long long m_last = 0;

@@ -55,6 +55,11 @@ int p2_begin_reads(P2Device* d, uint32_t num_ed, bool reps);
 struct P2TipWalk { unsigned long long pos, far; uint32_t first, far_smaller; };
 // the tip walks of one scan in slot order; afterwards the host sends back the nodes it changed and re-marks
 int p2_tip_walks(P2Device* d, int cut_len, bool thin, std::vector<P2TipWalk>& out);
+// removeSingleTips / removeMinorTips decided on the device (dev_tips.hpp); the counts the reference prints
+struct P2TipTotals { unsigned long long single = 0, minor = 0; int cycles = 0, rounds = 0; std::vector<unsigned long long> per_cycle; };
+int p2_clip_tips(P2Device* d, bool cut_single, P2TipTotals& out);
+// the vertices -- live non-linear nodes -- in slot order, nw key words each (what output_vertex prints)
+int p2_list_vertices(P2Device* d, std::vector<uint64_t>& keys);
 int p2_mirror_nodes(P2Device* d, const uint64_t* slots, const uint64_t* ab, uint64_t n);
 int p2_remark_linear(P2Device* d);
 

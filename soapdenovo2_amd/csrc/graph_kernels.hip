@@ -34,6 +34,7 @@
 #include "graph_lookup.hpp"
 #include "backend_hip.hpp"
 #include "dev_graph.hpp"
+#include "dev_tips.hpp"
 
 namespace pg {
 
@@ -568,6 +569,8 @@ struct P2Device {
     bool reads_ready = false;
     hipStream_t stream = nullptr;
     std::vector<uint64_t> set_sizes;     // host copy of the geometry
+    uint64_t* d_geo3 = nullptr;          // SetsView::geo: per set (first global slot, size, address of slot 0)
+    uint32_t* d_crc = nullptr;           // CRC-32 byte table for the lookups of the backend-generic stages
 };
 
 static void p2_free(P2Device* d) {
@@ -577,6 +580,7 @@ static void p2_free(P2Device* d) {
     hipFree(d->d_arc_key); hipFree(d->d_arc_cnt); hipFree(d->d_arc_first);
     hipFree(d->d_counters); hipFree(d->d_marker);
     hipFree(d->d_words); hipFree(d->d_off); hipFree(d->d_lens); hipFree(d->d_stage); hipFree(d->d_walk_len);
+    hipFree(d->d_geo3); hipFree(d->d_crc);
     if (d->stream) hipStreamDestroy(d->stream);
     delete d;
 }
@@ -834,6 +838,85 @@ int p2_remark_linear(P2Device* d) {
     hipLaunchKernelGGL(tip_remark, dim3(4096), dim3(256), 0, d->stream, d->d_nodes, d->nw + 1, d->n_slots);
     P2_HIP(hipStreamSynchronize(d->stream));
     return PG_OK;
+}
+
+// ---- the sets as the backend-generic stages see them (dev_tips.hpp) ---------------------------------------------------------
+static int p2_sets_view(P2Device* d, SetsView& view, SetsGeo& geo) {
+    P2_HIP(hipSetDevice(d->device));
+    const int NW1 = d->nw + 1;
+    geo.P = d->P; geo.first.clear(); geo.size.clear(); geo.base.clear();
+    std::vector<uint64_t> words(3 * (size_t)d->P);
+    uint64_t first = 0;
+    for (int s = 0; s < d->P; s++) {
+        uint64_t* base = d->d_nodes + first * NW1;
+        geo.first.push_back(first); geo.size.push_back(d->set_sizes[s]); geo.base.push_back(base);
+        words[3 * s] = first; words[3 * s + 1] = d->set_sizes[s]; words[3 * s + 2] = (uint64_t)(uintptr_t)base;
+        first += d->set_sizes[s];
+    }
+    if (!d->d_geo3) {
+        P2_HIP(hipMalloc((void**)&d->d_geo3, words.size() * sizeof(uint64_t)));
+        P2_HIP(hipMalloc((void**)&d->d_crc, 256 * sizeof(uint32_t)));
+        uint32_t tab[256];
+        for (uint32_t i = 0; i < 256; i++) tab[i] = crc32_table_entry(i);
+        P2_HIP(hipMemcpy(d->d_crc, tab, sizeof tab, hipMemcpyHostToDevice));
+    }
+    P2_HIP(hipMemcpy(d->d_geo3, words.data(), words.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    view = SetsView{d->d_geo3, d->d_crc, (uint32_t)d->P, set_bias((uint32_t)d->P), d->K};
+    return PG_OK;
+}
+
+// removeSingleTips + removeMinorTips decided on the device (dev_tips.hpp)
+int p2_clip_tips(P2Device* d, bool cut_single, P2TipTotals& out) {
+    SetsView view;
+    SetsGeo geo;
+    int rc = p2_sets_view(d, view, geo);
+    if (rc) return rc;
+    HipBackend be(d->device, d->stream);
+    TipTotals tot;
+    rc = d->nw == 2 ? clip_tips<HipBackend, 2>(be, view, geo, cut_single, tot) : clip_tips<HipBackend, 4>(be, view, geo, cut_single, tot);
+    if (rc) { pg_set_error(be.error_text.empty() ? "tip clipping on the device failed" : be.error_text); return rc; }
+    out.single = tot.single; out.minor = tot.minor; out.cycles = tot.minor_cycles; out.rounds = tot.rounds;
+    out.per_cycle.assign(tot.per_cycle.begin(), tot.per_cycle.end());
+    return PG_OK;
+}
+
+// the vertices (live non-linear nodes) in slot order, NW key words each (output_vertex, output_pregraph.c:50-86)
+__global__ void vx_gather(const uint64_t* nodes, int nw, const unsigned long long* slots, uint64_t n, uint64_t* out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * nw; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = nodes[slots[i / nw] * (nw + 1) + i % nw];
+}
+int p2_list_vertices(P2Device* d, std::vector<uint64_t>& keys) {
+    int rc = PG_OK;
+    hipStream_t st = d->stream;
+    unsigned long long *d_list = nullptr, *d_sorted = nullptr, *d_cnt = nullptr;
+    uint64_t* d_keys = nullptr;
+    void* d_tmp = nullptr;
+    size_t tmp_bytes = 0;
+    unsigned long long n = 0;
+    int bits = 1;
+    keys.clear();
+    if (hipSetDevice(d->device) != hipSuccess) { pg_set_error("vertices: hipSetDevice failed"); return PG_ENODEV; }
+    P2_HIP_GOTO(hipMalloc((void**)&d_cnt, sizeof(unsigned long long)));
+    P2_HIP_GOTO(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st));
+    P2_HIP_GOTO(hipMalloc((void**)&d_list, std::max<uint64_t>(d->n_slots, 1) * sizeof(unsigned long long)));
+    hipLaunchKernelGGL(eb_list_branch, dim3(4096), dim3(256), 0, st, d->d_nodes, d->nw + 1, d->n_slots, d_list, d_cnt);
+    P2_HIP_GOTO(hipMemcpyAsync(&n, d_cnt, sizeof n, hipMemcpyDeviceToHost, st));
+    P2_HIP_GOTO(hipStreamSynchronize(st));
+    if (n) {
+        while (bits < 64 && (d->n_slots >> bits)) bits++;
+        P2_HIP_GOTO(hipMalloc((void**)&d_sorted, n * sizeof(unsigned long long)));
+        P2_HIP_GOTO(hipMalloc((void**)&d_keys, n * d->nw * sizeof(uint64_t)));
+        P2_HIP_GOTO((rocprim::radix_sort_keys<rocprim::default_config, unsigned long long*, unsigned long long*, size_t>(nullptr, tmp_bytes, d_list, d_sorted, (size_t)n, 0u, (unsigned)bits, st)));
+        P2_HIP_GOTO(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
+        P2_HIP_GOTO((rocprim::radix_sort_keys<rocprim::default_config, unsigned long long*, unsigned long long*, size_t>(d_tmp, tmp_bytes, d_list, d_sorted, (size_t)n, 0u, (unsigned)bits, st)));
+        hipLaunchKernelGGL(vx_gather, dim3(4096), dim3(256), 0, st, d->d_nodes, d->nw, d_sorted, (uint64_t)n, d_keys);
+        keys.resize((size_t)n * d->nw);
+        P2_HIP_GOTO(hipMemcpyAsync(keys.data(), d_keys, keys.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
+        P2_HIP_GOTO(hipStreamSynchronize(st));
+    }
+done:
+    hipFree(d_list); hipFree(d_sorted); hipFree(d_cnt); hipFree(d_keys); hipFree(d_tmp);
+    return rc;
 }
 
 // ---- edges ------------------------------------------------------------------------------------------------------------

@@ -42,6 +42,8 @@
 #include "kmer.hpp"
 #include "host_graph.hpp"
 #include "graph_dev.hpp"
+#include "backend.hpp"
+#include "dev_tips.hpp"
 #include "../../include/soapdenovo2_amd.h"
 
 namespace pg {
@@ -791,6 +793,7 @@ struct Graph {
         fprintf(stderr, "Start to remove frequency-one-kmer tips shorter than %d.\n", cut);
         tip_scan(cut, true, tips);
         fprintf(stderr, "Total %lld tip(s) removed.\n", tips);
+        last_single = tips;
         remark_touched();
         if (tip_dev && !tip_error) tip_error = p2_remark_linear(tip_dev);
     }
@@ -806,9 +809,11 @@ struct Graph {
             if (!removed || tip_error) break;
         }
         fprintf(stderr, "Total %lld tip(s) removed.\n", tips);
+        last_minor = tips;
         remark_touched();
         if (tip_dev && !tip_error) tip_error = p2_remark_linear(tip_dev);
     }
+    long long last_single = 0, last_minor = 0;
 };
 
 // ---- writers -------------------------------------------------------------------------------------------
@@ -1272,6 +1277,40 @@ static int write_vertex_file(Graph<NW>& g, const std::string& prefix, int& num_v
     fclose(fp);
     if (!quiet) fprintf(stderr, "%d vertex(es) output.\n", cnt);
     num_vt = cnt;
+    return PG_OK;
+}
+
+// <prefix>.vertex from the vertices' k-mers in slot order (the device lists them: p2_list_vertices), NW words each
+template <int NW>
+static int write_vertex_keys(const std::string& prefix, const std::vector<uint64_t>& keys, int n_threads, int& num_vt) {
+    FILE* fp = fopen((prefix + ".vertex").c_str(), "w");
+    if (!fp) { pg_set_error("cannot open " + prefix + ".vertex"); return PG_EIO; }
+    const size_t n = keys.size() / NW;
+    const int nt = (int)std::max<size_t>(1, std::min<size_t>((size_t)pick_threads(n_threads), n / 65536 + 1));
+    std::vector<std::string> text(nt);
+    auto body = [&](int t) {
+        std::string& out = text[t];
+        const size_t lo = n * t / nt, hi = n * (t + 1) / nt;
+        out.reserve((hi - lo) * (NW == 2 ? 34 : 68));
+        char tmp[128];
+        for (size_t i = lo; i < hi; i++) {
+            Kmer<NW> k;
+            for (int w = 0; w < NW; w++) k.w[w] = keys[i * NW + w];
+            int len = fmt_kmer<NW>(tmp, k, ' ');
+            if ((i + 1) % 8 == 0) tmp[len++] = '\n';
+            out.append(tmp, (size_t)len);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int t = 1; t < nt; t++) pool.emplace_back(body, t);
+    body(0);
+    for (auto& th : pool) th.join();
+    bool ok = true;
+    for (auto& tx : text) ok = ok && (tx.empty() || fwrite(tx.data(), 1, tx.size(), fp) == tx.size());
+    fputc('\n', fp);
+    fclose(fp);
+    if (!ok) { pg_set_error("short write on " + prefix + ".vertex"); return PG_EIO; }
+    num_vt = (int)n;
     return PG_OK;
 }
 
@@ -1815,8 +1854,40 @@ struct GraphHandle : GraphHandleBase {
     std::thread vertex_thread;
     int vertex_rc = PG_OK, vertex_count = 0;
     bool vertex_started = false;
+    bool sets_on_device_only = false;            // tips were clipped on the device: the host copy of the sets (if any) is stale
+    std::vector<uint64_t> vertex_keys;
+    int dev_clip_tips(bool cut_single) {
+        const int cut = 2 * g.K;
+        P2TipTotals tot;
+        const double t0 = now();
+        const int rc = p2_clip_tips(dev, cut_single, tot);
+        if (rc) return rc;
+        // the reference's banner (cutTipPreGraph.c:363-399, 414-488)
+        if (cut_single) {
+            fprintf(stderr, "Start to remove frequency-one-kmer tips shorter than %d.\n", cut);
+            fprintf(stderr, "Total %llu tip(s) removed.\n", tot.single);
+        }
+        fprintf(stderr, "Start to remove tips with minority links.\n");
+        for (size_t i = 0; i < tot.per_cycle.size(); i++) fprintf(stderr, "%llu tip(s) removed in cycle %d.\n", tot.per_cycle[i], (int)i + 1);
+        fprintf(stderr, "Total %llu tip(s) removed.\n", tot.minor);
+        if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "tips decided on the device: %d scan(s), %d fixed-point round(s), %.2fs\n", (int)tot.per_cycle.size() + (cut_single ? 1 : 0), tot.rounds, now() - t0);
+        sets_on_device_only = true;
+        g.tip_dev = nullptr;
+        return PG_OK;
+    }
     void start_vertex_writer() {
         vertex_started = true;
+        if (sets_on_device_only) {
+            vertex_rc = p2_list_vertices(dev, vertex_keys);
+            if (vertex_rc) return;
+            vertex_thread = std::thread([this]() {
+                const double tv0 = now();
+                vertex_rc = write_vertex_keys<NW>(prefix, vertex_keys, g.n_threads, vertex_count);
+                std::vector<uint64_t>().swap(vertex_keys);
+                if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "vertex writer: %.2fs (beside the edges)\n", now() - tv0);
+            });
+            return;
+        }
         vertex_thread = std::thread([this]() {
             const double tv0 = now();
             vertex_rc = write_vertex_file<NW>(g, prefix, vertex_count, true);
@@ -2127,7 +2198,7 @@ static int fetch_device_records(void* user, uint64_t first, uint64_t n, uint64_t
 // writer still read is a download of that image.  Returns PG_OK, 1 = unsuited (the caller replays on the host), or PG_E*.
 template <int NW>
 static int layout_on_device(GraphHandle<NW>* h, const uint64_t* d_records, const uint64_t* per_set_count, int K, int P, int a_gb, int n_threads,
-                            int device) {
+                            int device, bool host_copy) {
     Graph<NW>& g = h->g;
     g.K = K; g.P = P; g.filter = kmer_filter<NW>(K); g.bias = set_bias((uint32_t)P); g.crc = host_crc_table();
     host_crc8_init();
@@ -2147,7 +2218,7 @@ static int layout_on_device(GraphHandle<NW>* h, const uint64_t* d_records, const
     auto worker = [&]() {
         for (;;) {
             const int si = next.fetch_add(1);
-            if (si >= P) break;
+            if (si >= P || !host_copy) break;
             HSet<NW>& hs = g.sets[si];
             hs.adopt(S, per_set_count[si]);
             if (p2_download_set(dev, si, hs.array.data()) != PG_OK) { failed.store(1); continue; }
@@ -2164,7 +2235,7 @@ static int layout_on_device(GraphHandle<NW>* h, const uint64_t* d_records, const
     if (failed.load()) { p2_destroy(dev); return PG_ENODEV; }
     h->dev = dev; h->dev_on = true; h->dev_id = device;
     g.tip_dev = dev;
-    if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "k-mer set layout on the device (K6): %.2fs; host copy downloaded: %.2fs\n", t1 - t0, now() - t1);
+    if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "k-mer set layout on the device (K6): %.2fs; host copy %s: %.2fs\n", t1 - t0, host_copy ? "downloaded" : "not needed", now() - t1);
     return PG_OK;
 }
 
@@ -2180,11 +2251,13 @@ static GraphHandleBase* graph_begin(const uint64_t* records, uint64_t n, const u
     double t0 = now();
     int rc_replay = 1;
     DeviceRecords dr{d_records, NW + 2, rec_device};
+    // SOAPDENOVO2_AMD_TIPS=replay: round 2's hybrid (walks on the device, decisions replayed by the host in slot order), for A/B runs
+    const bool tips_replay = getenv("SOAPDENOVO2_AMD_TIPS") && !strcmp(getenv("SOAPDENOVO2_AMD_TIPS"), "replay");
     if (d_records) {
         // -a pools: the layout is made where the records are (SOAPDENOVO2_AMD_LAYOUT=host keeps the host replay, for A/B runs)
         const char* where = getenv("SOAPDENOVO2_AMD_LAYOUT");
         if (a_gb != 0 && device >= 0 && device == rec_device && !(where && !strcmp(where, "host")) && !getenv("SOAPDENOVO2_AMD_TIPS_HOST"))
-            rc_replay = layout_on_device<NW>(h, d_records, per_set_count, K, P, a_gb, n_threads, device);
+            rc_replay = layout_on_device<NW>(h, d_records, per_set_count, K, P, a_gb, n_threads, device, /*host_copy=*/tips_replay);
         if (rc_replay == 1) { fetch = &fetch_device_records; fetch_user = &dr; }
     }
     if (rc_replay == 1)
@@ -2195,9 +2268,13 @@ static GraphHandleBase* graph_begin(const uint64_t* records, uint64_t n, const u
     t0 = now();
     if (device >= 0 && !getenv("SOAPDENOVO2_AMD_TIPS_HOST") && !h->dev && h->dev_open(device) != PG_OK) { delete h; return nullptr; }
     if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "k-mer sets uploaded to the device: %.2fs\n", now() - t0);
-    if (cut_single) h->g.remove_single_tips();
-    h->g.remove_minor_tips();
-    if (h->g.tip_error) { delete h; return nullptr; }
+    if (h->dev && !tips_replay) {                // decided on the device (dev_tips.hpp); the host copy of the sets is not touched
+        if (h->dev_clip_tips(cut_single != 0) != PG_OK) { delete h; return nullptr; }
+    } else {
+        if (cut_single) h->g.remove_single_tips();
+        h->g.remove_minor_tips();
+        if (h->g.tip_error) { delete h; return nullptr; }
+    }
     fprintf(stderr, "Time spent on removing tips: %.1fs.\n\n", now() - t0);
     t0 = now();
     int edge_c = 0;
@@ -2345,6 +2422,53 @@ extern "C" int pg_host_replay_layout(const uint64_t* records, uint64_t n_records
     if (n_sets < 1 || n_sets > 255) { pg_set_error("n_sets must be 1..255"); return PG_EINVAL; }
     if (mer127) return pg::layout_only<4>(records, n_records, set_last_put, n_sets, a_gb, out_slot, out_set_size);
     return pg::layout_only<2>(records, n_records, set_last_put, n_sets, a_gb, out_slot, out_set_size);
+}
+
+// Test hook (see include/soapdenovo2_amd.h, section 5): the tip clipping of dev_tips.hpp on the HostBackend next to the
+// sequential host scan, on two copies of the same layout; out = tips removed by either (single, minor), nodes whose counter
+// words differ afterwards, fixed-point rounds, minor cycles.
+template <int NW>
+static int emu_clip_tips(const uint64_t* records, uint64_t n, const uint64_t* set_last_put, int K, int P, int cut_single, int a_gb, int n_threads,
+                         uint64_t out[8]) {
+    using namespace pg;
+    Graph<NW> g1, g2;
+    int rc = replay_layout<NW>(g1, records, n, set_last_put, K, P, a_gb, 1);
+    if (rc) return rc;
+    rc = replay_layout<NW>(g2, records, n, set_last_put, K, P, a_gb, 1);
+    if (rc) return rc;
+    if (cut_single) g1.remove_single_tips();
+    g1.remove_minor_tips();
+    SetsGeo geo;
+    geo.P = P;
+    std::vector<uint64_t> geo_words(3 * (size_t)P);
+    uint64_t first = 0;
+    for (int s = 0; s < P; s++) {
+        geo.first.push_back(first); geo.size.push_back(g2.sets[s].size); geo.base.push_back((uint64_t*)g2.sets[s].array.data());
+        geo_words[3 * s] = first; geo_words[3 * s + 1] = g2.sets[s].size; geo_words[3 * s + 2] = (uint64_t)(uintptr_t)g2.sets[s].array.data();
+        first += g2.sets[s].size;
+    }
+    SetsView view{geo_words.data(), host_crc_table(), (uint32_t)P, set_bias((uint32_t)P), K};
+    HostBackend be(n_threads);
+    TipTotals tot;
+    rc = clip_tips<HostBackend, NW>(be, view, geo, cut_single != 0, tot);
+    if (rc) { pg_set_error(be.error_text.empty() ? "emulated tip clipping failed" : be.error_text); return rc; }
+    uint64_t diff = 0;
+    for (int s = 0; s < P; s++)
+        for (uint64_t i = 0; i < g1.sets[s].size; i++) {
+            if (!g1.sets[s].occ[i]) continue;
+            const HNode<NW>&a = g1.sets[s].array[i], &b = g2.sets[s].array[i];
+            diff += a.A != b.A || a.B != b.B;
+        }
+    out[0] = (uint64_t)g1.last_single; out[1] = (uint64_t)g1.last_minor; out[2] = tot.single; out[3] = tot.minor;
+    out[4] = diff; out[5] = (uint64_t)tot.rounds; out[6] = (uint64_t)tot.minor_cycles; out[7] = 0;
+    return PG_OK;
+}
+extern "C" int pg_host_emu_clip_tips(const uint64_t* records, uint64_t n_records, const uint64_t* set_last_put, int K, int mer127, int n_sets,
+                                     int cut_single, int a_gb, int n_threads, uint64_t out[8]) {
+    if ((!records && n_records) || !out) { pg_set_error("null argument"); return PG_EINVAL; }
+    if (n_sets < 1 || n_sets > 255) { pg_set_error("n_sets must be 1..255"); return PG_EINVAL; }
+    return mer127 ? emu_clip_tips<4>(records, n_records, set_last_put, K, n_sets, cut_single, a_gb, n_threads, out)
+                  : emu_clip_tips<2>(records, n_records, set_last_put, K, n_sets, cut_single, a_gb, n_threads, out);
 }
 
 extern "C" int pg_host_write_kmerfreq(const uint64_t hist[256], const char* prefix) {

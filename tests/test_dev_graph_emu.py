@@ -105,3 +105,24 @@ def test_layout_static_equals_the_host_replay_on_golden_cases(golden, tmp_path, 
     got = out[sets * S + slots.astype(np.int64)]
     assert (got == rec[:, :nw + 1]).all()
     assert int((out[:, 0] != EMPTY).sum()) == len(rec)
+
+
+@pytest.mark.parametrize("threads", [1, 5])
+@pytest.mark.parametrize("name", ["t6k_k31", "t8k_k63", "t6k_k127", "t5k_k24", "m60k_k63", "d8k_k127", "r8k_k127", "d8k_k63", "m100k_k31"])
+def test_device_tip_decisions_equal_the_sequential_scan(golden, tmp_path, name, threads):
+    """removeSingleTips / removeMinorTips as the device decides them (dev_tips.hpp on the HostBackend: the fixed point over start
+    decisions) against the sequential slot-order scan (Graph::tip_scan, pinned on the reference's files by tests/test_host_graph.py):
+    the same tips, and afterwards the same counter words in every node."""
+    c = golden["cases"][name]
+    codes = case_codes(c)
+    for run in c["runs"]:
+        P, D, a, m = run
+        rec, last, K = oracle_records(codes, c["K"], P, D=D, mer127=bool(m), a_gb=a, prefix=str(tmp_path / "o"))
+        rec = np.ascontiguousarray(rec)
+        out = np.zeros(8, dtype=np.uint64)
+        rc = api.lib().pg_host_emu_clip_tips(rec.ctypes.data, len(rec), last.ctypes.data, K, int(bool(m)), P, int(D == 0), a, threads, out.ctypes.data)
+        assert rc == 0, api.lib().pg_last_error()
+        single_seq, minor_seq, single_dev, minor_dev, diff, rounds, cycles = (int(x) for x in out[:7])
+        assert (single_dev, minor_dev) == (single_seq, minor_seq), (name, run)
+        assert diff == 0, (name, run, diff)
+        assert rounds >= cycles >= 1
