@@ -345,9 +345,20 @@ int pg_exchange_allreduce_u64(pg_comm *comm, uint64_t *d_buf, uint64_t n, void *
 /* Every rank's exported records on rank `root`, rank after rank (d_out / capacity / n_out matter on the root only). */
 int pg_exchange_gather_records(pg_comm *comm, const uint64_t *d_records, uint64_t n_local, int rec_words, int root, uint64_t *d_out,
                                uint64_t capacity, uint64_t *n_out, void *stream);
+/* After pass 1 (pg_finalize + pg_export_take on every rank): the distinct k-mers move once more, to owner(set s) = s mod
+ * n_ranks, so that every k-mer set of the reference (KmerSets[s], s = hash_kmer % thrd_num, prlHashReads.c:79-90) lies whole
+ * on one GPU for the layout replay and the set-by-set scans.  Takes ownership of d_records (freed); the
+ * regrouped records come back in a fresh device allocation *d_out (pg_device_free).  Collective; a rank that fails makes
+ * every rank return an error instead of leaving the others waiting. */
+int pg_exchange_regroup_by_set(pg_comm *comm, uint64_t *d_records, uint64_t n_local, int rec_words, uint64_t **d_out, uint64_t *n_out,
+                               void *stream);
+/* out[0] = distinct k-mers this rank held before the regroup, out[1] = after it */
+int pg_comm_regroup_stats(const pg_comm *comm, uint64_t out[2]);
 /* One batch of pass 1 on all ranks: pg_skm_route (ragged batches too: d_word_off / d_kmer_base as in pg_count_reads), the count
  * and record exchange, pg_skm_ingest.  A rank with nothing to contribute in a round calls it with n_reads = 0.  The send and
- * receive regions live in the communicator and grow as needed.  After the last round: pg_finalize on every rank. */
+ * receive regions live in the communicator and grow as needed; a batch that sends one owner more than its region holds (one
+ * minimizer dominating the batch) is cut again with larger regions, all ranks alike.  A rank that fails still finishes the
+ * round's collectives, and every rank returns an error.  After the last round: pg_finalize on every rank. */
 int pg_count_reads_sharded(pg_ctx *ctx, pg_comm *comm, const uint64_t *d_packed, const uint64_t *d_word_off, const uint64_t *d_kmer_base,
                            uint64_t n_reads, uint32_t uniform_len, uint64_t n_kmers, uint64_t ord_base, void *stream);
 

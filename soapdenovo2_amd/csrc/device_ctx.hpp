@@ -74,5 +74,6 @@ int e2_set_counts(pg_ctx* c, uint64_t out[256], hipStream_t st);
 int e2_route(pg_ctx* c, const uint64_t* d_packed, const uint64_t* d_word_off, const uint64_t* d_kmer_base, uint64_t n_reads,
              uint32_t uniform_len, uint64_t ord_base, int n_owners, uint64_t* d_recs, uint32_t* d_pids, uint64_t cap, uint64_t* d_counts,
              hipStream_t st);
+int e2_clear_route_overflow(pg_ctx* c, hipStream_t st);
 int e2_ingest(pg_ctx* c, const uint64_t* d_recs, const uint32_t* d_pids, uint64_t n, hipStream_t st);
 }  // namespace pg

@@ -130,6 +130,7 @@ struct pg_comm {
     uint64_t recv_cap = 0;
     std::vector<uint64_t> h_counts, h_rcounts;
     uint64_t sent_records = 0, recv_records = 0, rounds = 0;
+    uint64_t regrouped_from = 0, regrouped_in = 0;   // distinct k-mers before / after pg_exchange_regroup_by_set
 };
 
 namespace {
@@ -143,29 +144,97 @@ int comm_alloc_small(pg_comm* c) {
     return PG_OK;
 }
 
+// Error discipline of everything collective below: a rank that fails locally still takes part in every barrier / group of the
+// call (with nothing to give), remembers its first error and returns it at the end -- a rank that left early would leave its
+// peers waiting forever in LocalGroup::barrier() or ncclRecv.  Calls that move data in several steps exchange an error word
+// first (agree()), so that all ranks skip the later steps together.
+struct FirstError {
+    int rc = PG_OK;
+    std::string why;
+    void hip(hipError_t e, const char* what) {
+        if (e == hipSuccess || rc) return;
+        rc = e == hipErrorOutOfMemory ? PG_ENOMEM : PG_ENODEV;
+        why = std::string(what) + ": " + hipGetErrorString(e);
+    }
+    void nccl(ncclResult_t r, const char* what) {
+        if (r == ncclSuccess || rc) return;
+        rc = PG_ENODEV;
+        why = std::string(what) + ": " + g_rccl.GetErrorString(r);
+    }
+    void set(int code, const std::string& text) { if (!rc) { rc = code; why = text; } }
+    int done() const { if (rc) pg_set_error(why); return rc; }
+};
+
 // every rank sends k words to every rank: d_send[o * k ..] goes to rank o, d_recv[q * k ..] comes from rank q
 int alltoall_words(pg_comm* c, const uint64_t* d_send, uint64_t* d_recv, uint64_t k, hipStream_t st) {
-    if (c->n == 1) { X_TRY(hipMemcpyAsync(d_recv, d_send, k * 8, hipMemcpyDeviceToDevice, st)); return PG_OK; }
+    FirstError err;
+    if (c->n == 1) { err.hip(hipMemcpyAsync(d_recv, d_send, k * 8, hipMemcpyDeviceToDevice, st), "copy"); return err.done(); }
     if (c->transport == PG_COMM_RCCL) {
-        X_TRY(hipMemcpyAsync(d_recv + (uint64_t)c->rank * k, d_send + (uint64_t)c->rank * k, k * 8, hipMemcpyDeviceToDevice, st));
-        N_TRY(g_rccl.GroupStart());
+        err.hip(hipMemcpyAsync(d_recv + (uint64_t)c->rank * k, d_send + (uint64_t)c->rank * k, k * 8, hipMemcpyDeviceToDevice, st), "copy");
+        err.nccl(g_rccl.GroupStart(), "ncclGroupStart");
         for (int p = 0; p < c->n; p++) {
             if (p == c->rank) continue;
-            N_TRY(g_rccl.Send(d_send + (uint64_t)p * k, k, ncclUint64, p, c->nccl, st));
-            N_TRY(g_rccl.Recv(d_recv + (uint64_t)p * k, k, ncclUint64, p, c->nccl, st));
+            err.nccl(g_rccl.Send(d_send + (uint64_t)p * k, k, ncclUint64, p, c->nccl, st), "ncclSend");
+            err.nccl(g_rccl.Recv(d_recv + (uint64_t)p * k, k, ncclUint64, p, c->nccl, st), "ncclRecv");
         }
-        N_TRY(g_rccl.GroupEnd());
-        return PG_OK;
+        err.nccl(g_rccl.GroupEnd(), "ncclGroupEnd");
+        return err.done();
     }
     LocalGroup* g = c->grp;
-    X_TRY(hipStreamSynchronize(st));                           // what we publish must be complete
+    err.hip(hipStreamSynchronize(st), "sync");                  // what we publish must be complete
     g->a[c->rank] = d_send;
     g->barrier();
     for (int q = 0; q < c->n; q++)
-        X_TRY(hipMemcpyAsync(d_recv + (uint64_t)q * k, (const uint64_t*)g->a[q] + (uint64_t)c->rank * k, k * 8, hipMemcpyDefault, st));
-    X_TRY(hipStreamSynchronize(st));
+        err.hip(hipMemcpyAsync(d_recv + (uint64_t)q * k, (const uint64_t*)g->a[q] + (uint64_t)c->rank * k, k * 8, hipMemcpyDefault, st), "peer copy");
+    err.hip(hipStreamSynchronize(st), "sync");
     g->barrier();                                               // everybody has pulled: the send buffers may change again
-    return PG_OK;
+    return err.done();
+}
+
+// collective: the largest word any rank brings (an error code negated, a capacity, ...); scratch = the communicator's count arrays
+int agree_max(pg_comm* c, uint64_t mine, uint64_t* out, hipStream_t st) {
+    FirstError err;
+    std::vector<uint64_t> h(c->n, mine);
+    err.hip(hipMemcpyAsync(c->d_counts, h.data(), sizeof(uint64_t) * (size_t)c->n, hipMemcpyHostToDevice, st), "copy");
+    const int rc = alltoall_words(c, c->d_counts, c->d_rcounts, 1, st);
+    if (rc) err.set(rc, pg_last_error());
+    err.hip(hipMemcpyAsync(h.data(), c->d_rcounts, sizeof(uint64_t) * (size_t)c->n, hipMemcpyDeviceToHost, st), "copy");
+    err.hip(hipStreamSynchronize(st), "sync");
+    uint64_t m = mine;
+    for (int q = 0; q < c->n; q++) m = std::max(m, h[q]);
+    *out = err.rc ? std::max<uint64_t>(m, 1) : m;
+    return err.done();
+}
+
+// variable all-to-all of bytes: what goes to rank p lies at d_send + send_off[p] (send_cnt[p] bytes); what comes from rank q
+// lands at d_recv + recv_off[q] (recv_cnt[q] bytes).  Host arrays of n entries.
+int alltoallv_bytes(pg_comm* c, const void* d_send, const uint64_t* send_off, const uint64_t* send_cnt, void* d_recv, const uint64_t* recv_off,
+                    const uint64_t* recv_cnt, hipStream_t st) {
+    FirstError err;
+    const int me = c->rank;
+    const char* src = (const char*)d_send;
+    char* dst = (char*)d_recv;
+    if (c->transport == PG_COMM_RCCL || c->n == 1) {
+        if (send_cnt[me]) err.hip(hipMemcpyAsync(dst + recv_off[me], src + send_off[me], send_cnt[me], hipMemcpyDeviceToDevice, st), "copy");
+        if (c->n == 1) return err.done();
+        err.nccl(g_rccl.GroupStart(), "ncclGroupStart");
+        for (int p = 0; p < c->n; p++) {
+            if (p == me) continue;
+            if (send_cnt[p]) err.nccl(g_rccl.Send(src + send_off[p], send_cnt[p], ncclUint8, p, c->nccl, st), "ncclSend");
+            if (recv_cnt[p]) err.nccl(g_rccl.Recv(dst + recv_off[p], recv_cnt[p], ncclUint8, p, c->nccl, st), "ncclRecv");
+        }
+        err.nccl(g_rccl.GroupEnd(), "ncclGroupEnd");
+        return err.done();
+    }
+    LocalGroup* g = c->grp;
+    err.hip(hipStreamSynchronize(st), "sync");
+    g->a[me] = d_send; g->b[me] = send_off;
+    g->barrier();
+    for (int q = 0; q < c->n; q++)
+        if (recv_cnt[q]) err.hip(hipMemcpyAsync(dst + recv_off[q], (const char*)g->a[q] + ((const uint64_t*)g->b[q])[me], recv_cnt[q], hipMemcpyDefault, st), "peer copy");
+    err.hip(hipStreamSynchronize(st), "sync");
+    g->barrier();
+    return err.done();
 }
 
 }  // namespace
@@ -305,43 +374,20 @@ extern "C" int pg_exchange_records(pg_comm* c, const uint64_t* d_send_recs, cons
     if (!c || !send_counts || !recv_counts) { pg_set_error("null argument"); return PG_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     X_TRY(hipSetDevice(c->device));
-    std::vector<uint64_t> off(c->n + 1, 0);
-    for (int q = 0; q < c->n; q++) off[q + 1] = off[q] + recv_counts[q];
-    if (c->transport == PG_COMM_RCCL || c->n == 1) {
-        const int me = c->rank;
-        if (send_counts[me]) {
-            X_TRY(hipMemcpyAsync(d_recv_recs + off[me] * rw, d_send_recs + (uint64_t)me * cap * rw, send_counts[me] * (uint64_t)rw * 8, hipMemcpyDeviceToDevice, st));
-            X_TRY(hipMemcpyAsync(d_recv_parts + off[me], d_send_parts + (uint64_t)me * cap, send_counts[me] * 4, hipMemcpyDeviceToDevice, st));
-        }
-        if (c->n == 1) return PG_OK;
-        N_TRY(g_rccl.GroupStart());
-        for (int p = 0; p < c->n; p++) {
-            if (p == me) continue;
-            if (send_counts[p]) {
-                N_TRY(g_rccl.Send(d_send_recs + (uint64_t)p * cap * rw, send_counts[p] * (uint64_t)rw, ncclUint64, p, c->nccl, st));
-                N_TRY(g_rccl.Send(d_send_parts + (uint64_t)p * cap, send_counts[p], ncclUint32, p, c->nccl, st));
-            }
-            if (recv_counts[p]) {
-                N_TRY(g_rccl.Recv(d_recv_recs + off[p] * rw, recv_counts[p] * (uint64_t)rw, ncclUint64, p, c->nccl, st));
-                N_TRY(g_rccl.Recv(d_recv_parts + off[p], recv_counts[p], ncclUint32, p, c->nccl, st));
-            }
-        }
-        N_TRY(g_rccl.GroupEnd());
-        return PG_OK;
+    const int n = c->n;
+    std::vector<uint64_t> so(n), sc(n), ro(n), rcn(n), so2(n), sc2(n), ro2(n), rc2(n);
+    uint64_t at = 0;
+    for (int q = 0; q < n; q++) {
+        so[q] = (uint64_t)q * cap * rw * 8; sc[q] = send_counts[q] * (uint64_t)rw * 8; ro[q] = at * rw * 8; rcn[q] = recv_counts[q] * (uint64_t)rw * 8;
+        so2[q] = (uint64_t)q * cap * 4; sc2[q] = send_counts[q] * 4; ro2[q] = at * 4; rc2[q] = recv_counts[q] * 4;
+        at += recv_counts[q];
     }
-    LocalGroup* g = c->grp;
-    X_TRY(hipStreamSynchronize(st));
-    g->a[c->rank] = d_send_recs; g->b[c->rank] = d_send_parts; g->v[c->rank] = cap;
-    g->barrier();
-    for (int q = 0; q < c->n; q++) {
-        if (!recv_counts[q]) continue;
-        const uint64_t qcap = g->v[q];
-        X_TRY(hipMemcpyAsync(d_recv_recs + off[q] * rw, (const uint64_t*)g->a[q] + (uint64_t)c->rank * qcap * rw, recv_counts[q] * (uint64_t)rw * 8, hipMemcpyDefault, st));
-        X_TRY(hipMemcpyAsync(d_recv_parts + off[q], (const uint32_t*)g->b[q] + (uint64_t)c->rank * qcap, recv_counts[q] * 4, hipMemcpyDefault, st));
-    }
-    X_TRY(hipStreamSynchronize(st));
-    g->barrier();
-    return PG_OK;
+    // both steps are entered by every rank whatever the first one returned
+    const int e1 = alltoallv_bytes(c, d_send_recs, so.data(), sc.data(), d_recv_recs, ro.data(), rcn.data(), st);
+    const std::string w1 = e1 ? pg_last_error() : "";
+    const int e2 = alltoallv_bytes(c, d_send_parts, so2.data(), sc2.data(), d_recv_parts, ro2.data(), rc2.data(), st);
+    if (e1) { pg_set_error(w1); return e1; }
+    return e2;
 }
 
 // One batch of pass 1 on n ranks (collective: every rank calls it once per round, with n_reads = 0 when it has nothing):
@@ -357,59 +403,183 @@ extern "C" int pg_count_reads_sharded(pg_ctx* ctx, pg_comm* c, const uint64_t* d
     X_TRY(hipSetDevice(c->device));
     const int n = c->n, rw = ctx->e2.g.rw;
     if (uniform_len) n_kmers = n_reads * (uint64_t)(uniform_len - ctx->K + 1);
+    FirstError err;                                             // this rank's first failure; the round is finished regardless
     // a read of k k-mers makes about 2k / (w + 1) + 1 records; twice that, spread over n owners, plus slack
     const uint64_t est = 2 * n_kmers / (uint64_t)(ctx->e2.g.w + 1) + n_reads;
-    const uint64_t want_cap = 2 * est / (uint64_t)n + 4096;
-    if (want_cap > c->cap || rw != c->rw) {
-        // (the previous round ended with every rank's pulls / receives complete, so nobody reads the old regions any more)
-        X_TRY(hipStreamSynchronize(st));
-        if (c->d_send_recs) (void)hipFree(c->d_send_recs);
-        if (c->d_send_parts) (void)hipFree(c->d_send_parts);
-        c->d_send_recs = nullptr; c->d_send_parts = nullptr;
-        c->cap = want_cap + want_cap / 4; c->rw = rw;
-        X_TRY(hipMalloc((void**)&c->d_send_recs, c->cap * (uint64_t)n * rw * 8));
-        X_TRY(hipMalloc((void**)&c->d_send_parts, c->cap * (uint64_t)n * 4));
-    }
-    int rc = pg::e2_route(ctx, d_packed, d_word_off, d_kmer_base, n_reads, uniform_len, ord_base, n, c->d_send_recs, c->d_send_parts, c->cap,
-                          c->d_counts, st);
-    int first_err = rc;
-    const std::string first_why = rc ? pg_last_error() : "";
-    if (rc) X_TRY(hipMemsetAsync(c->d_counts, 0, sizeof(uint64_t) * (size_t)n, st));   // take part in the round anyway
-    // an owner region that overflowed: the kernel dropped what did not fit (and flagged the context); tell the receivers
-    // the number that is really there
-    X_TRY(hipMemcpyAsync(c->h_counts.data(), c->d_counts, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost, st));
-    X_TRY(hipStreamSynchronize(st));
-    bool clamped = false;
-    for (int q = 0; q < n; q++) {
-        if (c->h_counts[q] > c->cap) { c->h_counts[q] = c->cap; clamped = true; }
-        c->sent_records += c->h_counts[q];
-    }
-    if (clamped) {
-        if (!first_err) { first_err = PG_ENOMEM; pg_set_error("pg_count_reads_sharded: an owner's send region overflowed"); }
-        X_TRY(hipMemcpyAsync(c->d_counts, c->h_counts.data(), sizeof(uint64_t) * (size_t)n, hipMemcpyHostToDevice, st));
-    }
-    rc = alltoall_words(c, c->d_counts, c->d_rcounts, 1, st);
-    if (rc) return rc;
-    X_TRY(hipMemcpyAsync(c->h_rcounts.data(), c->d_rcounts, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost, st));
-    X_TRY(hipStreamSynchronize(st));
+    uint64_t want_cap = 2 * est / (uint64_t)n + 4096;
     uint64_t total_in = 0;
+    // A batch dominated by one minimizer (low-complexity reads, adapter dimers, high-copy repeats) can send one owner far
+    // more than its even share: the cut is then repeated with regions as large as the largest count seen (the batch is
+    // still resident).  Whether to repeat is agreed among the ranks, so that all of them take the same number of steps.
+    for (int attempt = 0;; attempt++) {
+        if (!err.rc && (want_cap > c->cap || rw != c->rw)) {
+            // (the previous round ended with every rank's pulls / receives complete, so nobody reads the old regions any more)
+            err.hip(hipStreamSynchronize(st), "sync");
+            if (c->d_send_recs) (void)hipFree(c->d_send_recs);
+            if (c->d_send_parts) (void)hipFree(c->d_send_parts);
+            c->d_send_recs = nullptr; c->d_send_parts = nullptr;
+            c->cap = 0; c->rw = rw;
+            const uint64_t cap = want_cap + want_cap / 4;
+            err.hip(hipMalloc((void**)&c->d_send_recs, cap * (uint64_t)n * rw * 8), "hipMalloc (send region)");
+            if (!err.rc) err.hip(hipMalloc((void**)&c->d_send_parts, cap * (uint64_t)n * 4), "hipMalloc (send region)");
+            if (!err.rc) c->cap = cap;
+        }
+        if (!err.rc) {
+            const int rc = pg::e2_route(ctx, d_packed, d_word_off, d_kmer_base, n_reads, uniform_len, ord_base, n, c->d_send_recs, c->d_send_parts, c->cap,
+                                        c->d_counts, st);
+            if (rc) err.set(rc, pg_last_error());
+        }
+        if (err.rc) (void)hipMemsetAsync(c->d_counts, 0, sizeof(uint64_t) * (size_t)n, st);       // nothing to give, but still in the round
+        err.hip(hipMemcpyAsync(c->h_counts.data(), c->d_counts, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost, st), "copy");
+        err.hip(hipStreamSynchronize(st), "sync");
+        uint64_t largest = 0;
+        for (int q = 0; q < n; q++) largest = std::max(largest, c->h_counts[q]);
+        const bool overflowed = !err.rc && largest > c->cap;
+        // one word per rank: an error outranks a repeat request, which carries the capacity wanted
+        uint64_t verdict = 0;
+        const uint64_t ERR = 1ULL << 62;
+        const int arc = agree_max(c, err.rc ? ERR : (overflowed ? largest : 0), &verdict, st);
+        if (arc) err.set(arc, pg_last_error());
+        if (verdict >= ERR || err.rc) {                             // some rank failed: nobody exchanges records this round
+            err.set(PG_ENODEV, "pg_count_reads_sharded: another rank failed in this round");
+            (void)pg::e2_clear_route_overflow(ctx, st);
+            return err.done();
+        }
+        if (verdict == 0) break;                                    // every owner region held what it was given
+        if (attempt >= 2) { err.set(PG_ENOMEM, "pg_count_reads_sharded: an owner's send region overflowed three times"); return err.done(); }
+        want_cap = std::max(want_cap, verdict + verdict / 8 + 4096); // all ranks grow alike and cut again
+        const int crc = pg::e2_clear_route_overflow(ctx, st);
+        if (crc) err.set(crc, pg_last_error());
+    }
+    for (int q = 0; q < n; q++) c->sent_records += c->h_counts[q];
+    {
+        // (agree_max used the count arrays as its scratch)
+        err.hip(hipMemcpyAsync(c->d_counts, c->h_counts.data(), sizeof(uint64_t) * (size_t)n, hipMemcpyHostToDevice, st), "copy");
+        const int rc = alltoall_words(c, c->d_counts, c->d_rcounts, 1, st);
+        if (rc) err.set(rc, pg_last_error());
+    }
+    err.hip(hipMemcpyAsync(c->h_rcounts.data(), c->d_rcounts, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost, st), "copy");
+    err.hip(hipStreamSynchronize(st), "sync");
     for (int q = 0; q < n; q++) total_in += c->h_rcounts[q];
-    if (total_in > c->recv_cap) {
+    if (!err.rc && total_in > c->recv_cap) {
         if (c->d_recv_recs) (void)hipFree(c->d_recv_recs);
         if (c->d_recv_parts) (void)hipFree(c->d_recv_parts);
         c->d_recv_recs = nullptr; c->d_recv_parts = nullptr;
-        c->recv_cap = total_in + total_in / 4 + 4096;
-        X_TRY(hipMalloc((void**)&c->d_recv_recs, c->recv_cap * (uint64_t)rw * 8));
-        X_TRY(hipMalloc((void**)&c->d_recv_parts, c->recv_cap * 4));
+        c->recv_cap = 0;
+        const uint64_t cap = total_in + total_in / 4 + 4096;
+        err.hip(hipMalloc((void**)&c->d_recv_recs, cap * (uint64_t)rw * 8), "hipMalloc (receive region)");
+        if (!err.rc) err.hip(hipMalloc((void**)&c->d_recv_parts, cap * 4), "hipMalloc (receive region)");
+        if (!err.rc) c->recv_cap = cap;
     }
-    rc = pg_exchange_records(c, c->d_send_recs, c->d_send_parts, c->cap, rw, c->h_counts.data(), c->h_rcounts.data(), c->d_recv_recs, c->d_recv_parts, st);
+    {   // a rank that could not make room says so before anybody sends to it
+        uint64_t verdict = 0;
+        const int arc = agree_max(c, err.rc ? 1 : 0, &verdict, st);
+        if (arc) err.set(arc, pg_last_error());
+        if (verdict || err.rc) { err.set(PG_ENODEV, "pg_count_reads_sharded: another rank failed in this round"); return err.done(); }
+    }
+    int rc = pg_exchange_records(c, c->d_send_recs, c->d_send_parts, c->cap, rw, c->h_counts.data(), c->h_rcounts.data(), c->d_recv_recs, c->d_recv_parts, st);
     if (rc) return rc;
     c->recv_records += total_in;
     c->rounds++;
     rc = pg::e2_ingest(ctx, c->d_recv_recs, c->d_recv_parts, total_in, st);
     if (rc) return rc;
     ctx->batches++;
-    if (first_err) { if (!first_why.empty()) pg_set_error(first_why); return first_err; }
+    return PG_OK;
+}
+
+// ---- the regroup after pass 1 ("reference set id -> GPU") ----------------------------------------------------------
+// Pass 1 leaves every distinct k-mer on the rank that owns its minimizer partition.  Everything after it works on the
+// reference's k-mer sets (KmerSets[s], s = hash_kmer % thrd_num, prlHashReads.c:79-90): the layout replay is per set, and
+// the scans walk the sets in order (node2edge.c:383-406, output_pregraph.c:60-75).  So the distinct k-mers -- and only
+// they: 32 / 48 bytes per k-mer, once -- move a second time, to owner(set s) = s mod n_ranks; from then on a set lives
+// whole on one GPU and no rank holds more than its share of sets.
+__global__ __launch_bounds__(256) void rg_count(const uint64_t* rec, uint64_t n, int rw, int n_ranks, unsigned long long* counts) {
+    __shared__ unsigned int local[256];
+    local[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+        atomicAdd(&local[(unsigned)(rec[i * rw + rw - 1] >> PG_ORD_BITS) % (unsigned)n_ranks], 1u);
+    __syncthreads();
+    if ((int)threadIdx.x < n_ranks && local[threadIdx.x]) atomicAdd(&counts[threadIdx.x], (unsigned long long)local[threadIdx.x]);
+}
+// records grouped by destination: block-aggregated cursors (one returned atomic per block and destination)
+__global__ __launch_bounds__(256) void rg_scatter(const uint64_t* rec, uint64_t n, int rw, int n_ranks, unsigned long long* cursor, uint64_t* out) {
+    __shared__ unsigned int local[256];
+    __shared__ unsigned long long base[256];
+    for (uint64_t i0 = (uint64_t)blockIdx.x * blockDim.x; i0 < n; i0 += (uint64_t)gridDim.x * blockDim.x) {
+        local[threadIdx.x] = 0;
+        __syncthreads();
+        const uint64_t i = i0 + threadIdx.x;
+        unsigned dest = 0, rank_in = 0;
+        if (i < n) { dest = (unsigned)(rec[i * rw + rw - 1] >> PG_ORD_BITS) % (unsigned)n_ranks; rank_in = atomicAdd(&local[dest], 1u); }
+        __syncthreads();
+        if ((int)threadIdx.x < n_ranks && local[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], (unsigned long long)local[threadIdx.x]);
+        __syncthreads();
+        if (i < n) {
+            uint64_t* o = out + (base[dest] + rank_in) * rw;
+            for (int w = 0; w < rw; w++) o[w] = rec[i * rw + w];
+        }
+        __syncthreads();
+    }
+}
+
+extern "C" int pg_exchange_regroup_by_set(pg_comm* c, uint64_t* d_records, uint64_t n_local, int rec_words, uint64_t** d_out, uint64_t* n_out,
+                                          void* stream) {
+    if (!c || !d_out || !n_out || (n_local && !d_records) || rec_words < 3 || rec_words > 6) { pg_set_error("bad argument"); return PG_EINVAL; }
+    hipStream_t st = (hipStream_t)stream;
+    *d_out = nullptr; *n_out = 0;
+    FirstError err;
+    err.hip(hipSetDevice(c->device), "hipSetDevice");
+    const int n = c->n;
+    uint64_t* d_send = nullptr;
+    unsigned long long* d_cur = nullptr;
+    std::vector<uint64_t> scnt(n, 0), soff(n, 0), rcnt(n, 0), roff(n, 0);
+    if (!err.rc) err.hip(hipMalloc((void**)&d_cur, sizeof(unsigned long long) * (size_t)n), "hipMalloc");
+    if (!err.rc && n_local) err.hip(hipMalloc((void**)&d_send, n_local * (uint64_t)rec_words * 8), "hipMalloc (regroup send buffer)");
+    if (!err.rc) {
+        err.hip(hipMemsetAsync(c->d_counts, 0, sizeof(uint64_t) * (size_t)n, st), "memset");
+        if (n_local) hipLaunchKernelGGL(rg_count, dim3((unsigned)std::min<uint64_t>((n_local + 255) / 256, 4096)), dim3(256), 0, st, d_records, n_local, rec_words, n,
+                                        (unsigned long long*)c->d_counts);
+        err.hip(hipGetLastError(), "rg_count");
+        err.hip(hipMemcpyAsync(scnt.data(), c->d_counts, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost, st), "copy");
+        err.hip(hipStreamSynchronize(st), "sync");
+    }
+    if (!err.rc) {
+        for (int q = 1; q < n; q++) soff[q] = soff[q - 1] + scnt[q - 1];
+        err.hip(hipMemcpyAsync(d_cur, soff.data(), sizeof(uint64_t) * (size_t)n, hipMemcpyHostToDevice, st), "copy");
+        if (n_local) hipLaunchKernelGGL(rg_scatter, dim3((unsigned)std::min<uint64_t>((n_local + 255) / 256, 8192)), dim3(256), 0, st, d_records, n_local, rec_words, n, d_cur, d_send);
+        err.hip(hipGetLastError(), "rg_scatter");
+        err.hip(hipStreamSynchronize(st), "sync");
+    }
+    if (d_records) (void)hipFree(d_records);                       // the caller's array has been regrouped into d_send: halve the peak
+    if (err.rc) (void)hipMemsetAsync(c->d_counts, 0, sizeof(uint64_t) * (size_t)n, st);
+    {   // counts (zeros from a rank that failed)
+        const int rc = alltoall_words(c, c->d_counts, c->d_rcounts, 1, st);
+        if (rc) err.set(rc, pg_last_error());
+        err.hip(hipMemcpyAsync(rcnt.data(), c->d_rcounts, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost, st), "copy");
+        err.hip(hipStreamSynchronize(st), "sync");
+    }
+    uint64_t total = 0;
+    for (int q = 0; q < n; q++) { roff[q] = total; total += rcnt[q]; }
+    uint64_t* out = nullptr;
+    if (!err.rc && total) err.hip(hipMalloc((void**)&out, total * (uint64_t)rec_words * 8), "hipMalloc (regrouped records)");
+    uint64_t verdict = 0;
+    {
+        const int arc = agree_max(c, err.rc ? 1 : 0, &verdict, st);
+        if (arc) err.set(arc, pg_last_error());
+    }
+    if (!verdict && !err.rc) {
+        const uint64_t B = (uint64_t)rec_words * 8;
+        for (int q = 0; q < n; q++) { scnt[q] *= B; soff[q] *= B; rcnt[q] *= B; roff[q] *= B; }
+        const int rc = alltoallv_bytes(c, d_send, soff.data(), scnt.data(), out, roff.data(), rcnt.data(), st);
+        if (rc) err.set(rc, pg_last_error());
+        err.hip(hipStreamSynchronize(st), "sync");
+    } else err.set(PG_ENODEV, "pg_exchange_regroup_by_set: another rank failed");
+    if (d_send) (void)hipFree(d_send);
+    if (d_cur) (void)hipFree(d_cur);
+    if (err.rc) { if (out) (void)hipFree(out); return err.done(); }
+    *d_out = out; *n_out = total;
+    c->regrouped_in = total; c->regrouped_from = n_local;
     return PG_OK;
 }
 
@@ -464,5 +634,10 @@ extern "C" int pg_exchange_gather_records(pg_comm* c, const uint64_t* d_records,
 extern "C" int pg_comm_stats(const pg_comm* c, uint64_t out[4]) {
     if (!c || !out) { pg_set_error("null argument"); return PG_EINVAL; }
     out[0] = c->rounds; out[1] = c->sent_records; out[2] = c->recv_records; out[3] = c->cap;
+    return PG_OK;
+}
+extern "C" int pg_comm_regroup_stats(const pg_comm* c, uint64_t out[2]) {
+    if (!c || !out) { pg_set_error("null argument"); return PG_EINVAL; }
+    out[0] = c->regrouped_from; out[1] = c->regrouped_in;
     return PG_OK;
 }

@@ -3,6 +3,7 @@
 #include <stdint.h>
 
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace pg {
@@ -37,7 +38,9 @@ struct P2Edges {
 
 // step by step: upload the sets; then either the host's (K+1)-mer table (p2_set_patch) or the edges built on the device
 // (p2_build_edges: tags the device copy of the sets and fills the device (K+1)-mer table itself); then p2_begin_reads
-P2Device* p2_open(int device, int K, int nw, int n_sets, const P2Sets& sets, int max_nk);
+// upload of the host's sets; set_device (may be null: everything on `device`) puts set s on HIP device set_device[s] of this
+// process, the kernels run on `device` and reach the others' sets through peer mappings
+P2Device* p2_open(int device, int K, int nw, int n_sets, const P2Sets& sets, int max_nk, const int* set_device = nullptr);
 // SURVEY.md App. C "K6": static (-a) pools laid out on the device from the records as they lie there sorted by (set, ordinal)
 // (every set has set_size slots); *unsuited = true (and nullptr) when a set fills its pool or holds >= 2^32 keys -- the
 // caller replays on the host then.  p2_download_set: one set's slot array into host memory.  p2_fetch_words: device -> host
@@ -45,6 +48,12 @@ P2Device* p2_open(int device, int K, int nw, int n_sets, const P2Sets& sets, int
 P2Device* p2_open_layout(int device, int K, int nw, int n_sets, const uint64_t* d_records, const uint64_t* per_set_count, uint64_t set_size,
                          int max_nk, bool* unsuited);
 int p2_download_set(P2Device* d, int set, void* dst);
+// the sharded form of the same: p2_layout_rank lays out the sets ONE rank owns (n_own sets of set_size slots, back to back in
+// a fresh allocation on its device; 1 = unsuited), p2_adopt makes the graph over sets that already lie in device memory
+// (set s: set_size[s] slots at set_ptr[s] on set_device[s]; the allocations in `owned` change hands)
+int p2_layout_rank(int device, int nw, int n_own, const uint64_t* d_records, const uint64_t* own_counts, uint64_t set_size, uint64_t** d_nodes_out);
+P2Device* p2_adopt(int lead_device, int K, int nw, int n_sets, const uint64_t* set_size, const int* set_device, uint64_t* const* set_ptr,
+                   const std::vector<std::pair<int, void*>>& owned, int max_nk);
 int p2_fetch_words(int device, const uint64_t* d_src, uint64_t n_words, uint64_t* dst);
 int p2_set_patch(P2Device* d, const uint64_t* patch_keys, const uint32_t* patch_val, uint64_t patch_cap);
 int p2_build_edges(P2Device* d, P2Edges& out);

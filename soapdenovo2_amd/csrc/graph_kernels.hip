@@ -51,9 +51,8 @@ constexpr uint64_t P2_EMPTY = ~0ULL;
 constexpr int P2_MAX_SETS = 255;
 
 struct P2Params {
-    const uint64_t* nodes;              // all sets back to back, (NW + 1) words a slot: key words, then A | B << 32
-    const uint64_t* set_base;           // first slot of each set (device array, P entries)
-    const uint64_t* set_size;
+    const uint64_t* geo3;               // per set: first global slot, size, address of its slot 0 ((NW + 1) words a slot: key words,
+                                        // then A | B << 32); the sets of one graph may lie on several GPUs of the process
     uint32_t P, bias;
     int K;
     // (K+1)-mer patch table
@@ -76,45 +75,15 @@ struct P2Params {
     unsigned long long* counters;
 };
 
-// search_kmerset, returning the node's global slot (set base + slot), ~0 when absent
-template <int NW>
-__device__ inline uint64_t find_slot(const P2Params& p, const Kmer<NW>& key, const uint32_t* crc_tab, const uint64_t* set_geo) {
-    const uint32_t set = set_of_crc(kmer_crc32<NW>(key, crc_tab), p.P, p.bias);
-    const uint64_t size = set_geo[2 * set + 1], first = set_geo[2 * set];
-    const uint64_t* base = p.nodes + first * (NW + 1);
-    uint64_t hc = home_slot<NW>(key, size);
-    for (uint64_t step = 0; step < size; step++) {
-        const uint64_t* nd = base + hc * (NW + 1);
-        const uint64_t w0 = nd[0];
-        if (w0 == P2_EMPTY) return ~0ULL;
-        bool eq = w0 == key.w[0];
-#pragma unroll
-        for (int i = 1; i < NW; i++) eq = eq && nd[i] == key.w[i];
-        if (eq) return first + hc;
-        if (++hc == size) hc = 0;
-    }
-    return ~0ULL;
-}
-
-// search_kmerset: the node's two counter words, or false
-template <int NW>
-__device__ inline bool find_node(const P2Params& p, const Kmer<NW>& key, const uint32_t* crc_tab, const uint64_t* set_geo, uint64_t& ab) {
-    const uint32_t set = set_of_crc(kmer_crc32<NW>(key, crc_tab), p.P, p.bias);
-    const uint64_t size = set_geo[2 * set + 1];
-    const uint64_t* base = p.nodes + set_geo[2 * set] * (NW + 1);
-    uint64_t hc = home_slot<NW>(key, size);
-    for (uint64_t step = 0; step < size; step++) {
-        const uint64_t* nd = base + hc * (NW + 1);
-        const uint64_t w0 = nd[0];
-        if (w0 == P2_EMPTY) return false;
-        bool eq = w0 == key.w[0];
-#pragma unroll
-        for (int i = 1; i < NW; i++) eq = eq && nd[i] == key.w[i];
-        if (eq) { ab = nd[NW]; return true; }
-        if (++hc == size) hc = 0;
-    }
-    return false;
-}
+// every kernel below starts the same way: CRC table and set geometry into LDS, a SetsView over them (graph_lookup.hpp:
+// sv_find / sv_step / sv_node are the reference's search_kmerset on per-set base addresses)
+#define P2_PROLOGUE(p)                                                                               \
+    __shared__ uint32_t crc_tab[256];                                                                \
+    __shared__ uint64_t set_geo[3 * P2_MAX_SETS];                                                    \
+    crc_tab[threadIdx.x] = crc32_table_entry(threadIdx.x);                                           \
+    for (int q_ = threadIdx.x; q_ < 3 * (int)(p).P; q_ += 256) set_geo[q_] = (p).geo3[q_];           \
+    __syncthreads();                                                                                 \
+    const SetsView sv{set_geo, crc_tab, (p).P, (p).bias, (p).K}
 
 template <int NW>
 __device__ inline uint32_t find_patch(const P2Params& p, const Kmer<NW>& key, bool smaller) {
@@ -158,11 +127,7 @@ __device__ inline void add_prearc(const P2Params& p, uint32_t from, uint32_t to,
 template <int NW>
 __global__ __launch_bounds__(256) void p2_thread_kernel(P2Params p, const uint64_t* __restrict__ words, const uint64_t* __restrict__ word_off,
                                                         const int32_t* __restrict__ lens, uint64_t n_reads, uint64_t first_ordinal) {
-    __shared__ uint32_t crc_tab[256];
-    __shared__ uint64_t set_geo[2 * P2_MAX_SETS];                        // (first slot, size) of every set
-    crc_tab[threadIdx.x] = crc32_table_entry(threadIdx.x);
-    if (threadIdx.x < p.P) { set_geo[2 * threadIdx.x] = p.set_base[threadIdx.x]; set_geo[2 * threadIdx.x + 1] = p.set_size[threadIdx.x]; }
-    __syncthreads();
+    P2_PROLOGUE(p);
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     const int K = p.K;
@@ -188,8 +153,9 @@ __global__ __launch_bounds__(256) void p2_thread_kernel(P2Params p, const uint64
     for (int j = 0; j < nk; j++) {
         if (j) kmer_roll<NW>(word, bal, read_base(rd, j + K - 1), K, filter);
         const bool smaller = kmer_less<NW>(word, bal);
-        uint64_t ab;
-        if (!find_node<NW>(p, smaller ? word : bal, crc_tab, set_geo, ab)) { atomicAdd(&p.counters[1], 1ULL); return; }
+        uint64_t* nd;
+        if (sv_find<NW>(sv, smaller ? word : bal, nd) == ~0ULL) { atomicAdd(&p.counters[1], 1ULL); return; }
+        const uint64_t ab = nd[NW];
         const uint32_t A = (uint32_t)ab, B = (uint32_t)(ab >> 32);
         const bool linear = B & B_LINEAR, in_edge = (B >> B_INEDGE_SHIFT) & 3;
         if ((B & B_DELETED) || (linear && !in_edge)) {                   // deleted, or on a floating loop
@@ -272,50 +238,26 @@ struct WalkState {
     int next_ch;                      // last base of the second node
 };
 
-// the single outgoing base of a linear node in walk orientation (only_out)
-__device__ inline int linear_out(uint64_t ab, bool smaller) {
-    const uint32_t A = (uint32_t)ab, B = (uint32_t)(ab >> 32);
-    int ch;
-    if (smaller) { for (ch = 0; ch < 4; ch++) if ((B >> (6 * ch)) & 63) break; return ch; }
-    for (ch = 0; ch < 4; ch++) if ((A >> (6 * ch)) & 63) break;
-    return ch ^ 2;
-}
-
-// one step: the node of `word`; false = not in the sets
-template <int NW>
-__device__ inline bool walk_step(const P2Params& p, const Kmer<NW>& word, int K, const uint32_t* crc_tab, const uint64_t* set_geo,
-                                 uint64_t& slot, uint64_t& ab, bool& smaller) {
-    const Kmer<NW> bal = kmer_rc<NW>(word, K);
-    smaller = !kmer_less<NW>(bal, word);
-    slot = find_slot<NW>(p, smaller ? word : bal, crc_tab, set_geo);
-    if (slot == ~0ULL) return false;
-    ab = p.nodes[slot * (NW + 1) + NW];
-    return true;
-}
-
-__global__ void eb_list_branch(const uint64_t* nodes, int nw1, uint64_t n_slots, unsigned long long* list, unsigned long long* n_list) {
+// one set's vertices (live non-linear nodes) as global slots, in any order
+__global__ void eb_list_branch(const uint64_t* nodes, int nw1, uint64_t n_slots, uint64_t first, unsigned long long* list, unsigned long long* n_list) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t* nd = nodes + i * nw1;
         if (nd[0] == P2_EMPTY) continue;
         const uint32_t B = (uint32_t)(nd[nw1 - 1] >> 32);
         if (B & (B_LINEAR | B_DELETED)) continue;
-        list[atomicAdd(n_list, 1ULL)] = i;
+        list[atomicAdd(n_list, 1ULL)] = first + i;
     }
 }
 
 template <int NW>
 __global__ __launch_bounds__(256) void eb_walk(P2Params p, const unsigned long long* list, uint64_t n_list, EdgeRec* out, uint64_t cap,
                                                unsigned long long* n_out, unsigned long long* n_len1, unsigned long long* errors) {
-    __shared__ uint32_t crc_tab[256];
-    __shared__ uint64_t set_geo[2 * P2_MAX_SETS];
-    crc_tab[threadIdx.x] = crc32_table_entry(threadIdx.x);
-    if (threadIdx.x < p.P) { set_geo[2 * threadIdx.x] = p.set_base[threadIdx.x]; set_geo[2 * threadIdx.x + 1] = p.set_size[threadIdx.x]; }
-    __syncthreads();
+    P2_PROLOGUE(p);
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_list * 8) return;
     const uint64_t slot0 = list[t >> 3];
     const int order = (int)(t & 7);
-    const uint64_t* nd0 = p.nodes + slot0 * (NW + 1);
+    const uint64_t* nd0 = sv_node<NW>(sv, slot0);
     const uint64_t ab0 = nd0[NW];
     const int ch = order & 3;
     const bool right = order < 4;
@@ -330,8 +272,10 @@ __global__ __launch_bounds__(256) void eb_walk(P2Params p, const unsigned long l
     // stringBeads
     Kmer<NW> prev = first, cur = kmer_next<NW>(first, nextch, filter);
     uint64_t slot, ab;
+    uint64_t* node;
     bool smaller;
-    if (!walk_step<NW>(p, cur, K, crc_tab, set_geo, slot, ab, smaller)) { atomicAdd(errors, 1ULL); return; }
+    if (!sv_step<NW>(sv, cur, slot, node, smaller)) { atomicAdd(errors, 1ULL); return; }
+    ab = node[NW];
     const int next_ch = kmer_last<NW>(cur);
     uint32_t count = 2;
     unsigned long long sum = 0;
@@ -339,8 +283,9 @@ __global__ __launch_bounds__(256) void eb_walk(P2Params p, const unsigned long l
         const uint32_t A = (uint32_t)ab;
         sum += (A & 63) + ((A >> 6) & 63) + ((A >> 12) & 63) + ((A >> 18) & 63);
         prev = cur;
-        cur = kmer_next<NW>(cur, linear_out(ab, smaller), filter);
-        if (!walk_step<NW>(p, cur, K, crc_tab, set_geo, slot, ab, smaller)) { atomicAdd(errors, 1ULL); return; }
+        cur = kmer_next<NW>(cur, linear_out_ab(ab, smaller), filter);
+        if (!sv_step<NW>(sv, cur, slot, node, smaller)) { atomicAdd(errors, 1ULL); return; }
+        ab = node[NW];
         count++;
     }
     const int prev_ch = kmer_first<NW>(prev, K);
@@ -383,14 +328,10 @@ __global__ void eb_export(const EdgeRec* recs, const uint32_t* order, const unsi
 }
 
 template <int NW>
-__global__ __launch_bounds__(256) void eb_apply(P2Params p, uint64_t* nodes_rw, const EdgeRec* recs, const uint32_t* order, uint64_t n,
+__global__ __launch_bounds__(256) void eb_apply(P2Params p, const EdgeRec* recs, const uint32_t* order, uint64_t n,
                                                 const unsigned long long* id_before, const unsigned long long* base_before, char* text,
                                                 uint64_t* patch_keys, uint32_t* patch_val, uint64_t patch_mask, unsigned long long* errors) {
-    __shared__ uint32_t crc_tab[256];
-    __shared__ uint64_t set_geo[2 * P2_MAX_SETS];
-    crc_tab[threadIdx.x] = crc32_table_entry(threadIdx.x);
-    if (threadIdx.x < p.P) { set_geo[2 * threadIdx.x] = p.set_base[threadIdx.x]; set_geo[2 * threadIdx.x + 1] = p.set_size[threadIdx.x]; }
-    __syncthreads();
+    P2_PROLOGUE(p);
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const EdgeRec r = recs[order[i]];
@@ -408,25 +349,28 @@ __global__ __launch_bounds__(256) void eb_apply(P2Params p, uint64_t* nodes_rw, 
     // walk again: bases out, interior nodes tagged (edge id replaces word A, twin / inEdge in word B)
     Kmer<NW> cur = kmer_next<NW>(first, next_ch, filter);
     uint64_t slot, ab;
+    uint64_t* node;
     bool smaller;
     for (uint32_t b = 0; b < r.length; b++) {
-        if (!walk_step<NW>(p, cur, K, crc_tab, set_geo, slot, ab, smaller)) { atomicAdd(errors, 1ULL); return; }
+        if (!sv_step<NW>(sv, cur, slot, node, smaller)) { atomicAdd(errors, 1ULL); return; }
+        ab = node[NW];
         seq[b] = "ACTG"[kmer_last<NW>(cur)];
         if (b + 1 == r.length) break;                               // the far branch node
         const uint32_t A = smaller ? id : id + bal;
         const uint32_t twin = smaller ? bal + 1 : 1 - bal;
         const uint32_t B = ((uint32_t)(ab >> 32) & 0x0FFFFFFFu) | (twin << B_TWIN_SHIFT) | (1u << B_INEDGE_SHIFT);
-        const int out = linear_out(ab, smaller);
-        nodes_rw[slot * (NW + 1) + NW] = (uint64_t)A | ((uint64_t)B << 32);
+        const int out = linear_out_ab(ab, smaller);
+        node[NW] = (uint64_t)A | ((uint64_t)B << 32);
         cur = kmer_next<NW>(cur, out, filter);
     }
     if (slot != r.far_slot) { atomicAdd(errors, 1ULL); return; }
     // dislink2prevUncertain on the far node, dislink2nextUncertain on the start node (64-bit word: A low, B high)
     {
         const int bit = last_smaller ? 6 * prev_ch : 32 + 6 * (prev_ch ^ 2);
-        atomicAnd((unsigned long long*)&nodes_rw[r.far_slot * (NW + 1) + NW], ~(63ULL << bit));
+        // (system scope: the node may lie in another GPU's memory)
+        __hip_atomic_fetch_and((unsigned long long*)(sv_node<NW>(sv, r.far_slot) + NW), ~(63ULL << bit), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const int bit0 = first_smaller ? 32 + 6 * next_ch : 6 * (next_ch ^ 2);
-        atomicAnd((unsigned long long*)&nodes_rw[slot0 * (NW + 1) + NW], ~(63ULL << bit0));
+        __hip_atomic_fetch_and((unsigned long long*)(sv_node<NW>(sv, slot0) + NW), ~(63ULL << bit0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
     if (r.length == 1) {                                            // KmerSetsPatch (node2edge.c:481-542)
         Kmer<NW> last;
@@ -458,25 +402,19 @@ __global__ __launch_bounds__(256) void eb_apply(P2Params p, uint64_t* nodes_rw, 
 // order-dependent half -- deciding and clipping in slot order -- stays on the host, which mirrors the nodes it changed
 // back into the device copy (tip_mirror) and re-marks linear nodes on both sides (tip_remark).
 // =====================================================================================================================
-__device__ inline int count_arcs(uint32_t w24) { return (int)((w24 & 63u) != 0) + (int)(((w24 >> 6) & 63u) != 0) + (int)(((w24 >> 12) & 63u) != 0) + (int)(((w24 >> 18) & 63u) != 0); }
-
 template <int NW>
-__global__ __launch_bounds__(256) void tip_walk_kernel(P2Params p, uint64_t n_slots, int cut_len, int thin, P2TipWalk* out, uint64_t cap,
-                                                       unsigned long long* n_out, unsigned long long* errors) {
-    __shared__ uint32_t crc_tab[256];
-    __shared__ uint64_t set_geo[2 * P2_MAX_SETS];
-    crc_tab[threadIdx.x] = crc32_table_entry(threadIdx.x);
-    if (threadIdx.x < p.P) { set_geo[2 * threadIdx.x] = p.set_base[threadIdx.x]; set_geo[2 * threadIdx.x + 1] = p.set_size[threadIdx.x]; }
-    __syncthreads();
+__global__ __launch_bounds__(256) void tip_walk_kernel(P2Params p, const uint64_t* set_nodes, uint64_t first_slot, uint64_t n_slots, int cut_len, int thin,
+                                                       P2TipWalk* out, uint64_t cap, unsigned long long* n_out, unsigned long long* errors) {
+    P2_PROLOGUE(p);
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_slots) return;
-    const uint64_t* nd = p.nodes + i * (NW + 1);
+    const uint64_t* nd = set_nodes + i * (NW + 1);
     if (nd[0] == P2_EMPTY) return;
     const uint64_t ab0 = nd[NW];
     const uint32_t A0 = (uint32_t)ab0, B0 = (uint32_t)(ab0 >> 32);
     if (B0 & (B_LINEAR | B_DELETED)) return;
     if (thin && !(B0 & B_SINGLE)) return;
-    const int in = count_arcs(A0), outn = count_arcs(B0);
+    const int in = count_arcs24(A0), outn = count_arcs24(B0);
     const bool fwd = in == 0 && outn == 1, bwd = in == 1 && outn == 0;
     if (!fwd && !bwd) return;
     const int K = p.K;
@@ -489,20 +427,23 @@ __global__ __launch_bounds__(256) void tip_walk_kernel(P2Params p, uint64_t n_sl
     if (fwd) { for (ch = 0; ch < 4; ch++) if ((B0 >> (6 * ch)) & 63) break; }
     else { for (ch = 0; ch < 4; ch++) if ((A0 >> (6 * ch)) & 63) break; ch ^= 2; }
     P2TipWalk w;
-    w.pos = i; w.far = ~0ULL; w.first = 0; w.far_smaller = 0;
+    w.pos = first_slot + i; w.far = ~0ULL; w.first = 0; w.far_smaller = 0;
     int count = 1;
     Kmer<NW> cur = kmer_next<NW>(prev, ch, filter);
     uint64_t slot, ab;
+    uint64_t* node;
     bool smaller;
-    if (!walk_step<NW>(p, cur, K, crc_tab, set_geo, slot, ab, smaller)) { atomicAdd(errors, 1ULL); return; }
+    if (!sv_step<NW>(sv, cur, slot, node, smaller)) { atomicAdd(errors, 1ULL); return; }
+    ab = node[NW];
     bool reached = true;
     while ((uint32_t)(ab >> 32) & B_LINEAR) {
         count++;
         if (thin && !((uint32_t)(ab >> 32) & B_SINGLE)) break;
         if (count > cut_len) { reached = false; break; }
         prev = cur;
-        cur = kmer_next<NW>(cur, linear_out(ab, smaller), filter);
-        if (!walk_step<NW>(p, cur, K, crc_tab, set_geo, slot, ab, smaller)) { atomicAdd(errors, 1ULL); return; }
+        cur = kmer_next<NW>(cur, linear_out_ab(ab, smaller), filter);
+        if (!sv_step<NW>(sv, cur, slot, node, smaller)) { atomicAdd(errors, 1ULL); return; }
+        ab = node[NW];
     }
     if (reached) { w.far = slot; w.first = (uint32_t)kmer_first<NW>(prev, K); w.far_smaller = smaller ? 1u : 0u; }
     const unsigned long long at = atomicAdd(n_out, 1ULL);
@@ -515,10 +456,12 @@ __global__ void tip_keys(const P2TipWalk* w, uint64_t n, unsigned long long* key
 __global__ void tip_gather(const P2TipWalk* w, const uint32_t* order, uint64_t n, P2TipWalk* out) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) out[i] = w[order[i]];
 }
-__global__ void tip_mirror(uint64_t* nodes, int nw1, const uint64_t* slots, const uint64_t* ab, uint64_t n) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) nodes[slots[i] * nw1 + nw1 - 1] = ab[i];
+template <int NW>
+__global__ __launch_bounds__(256) void tip_mirror(P2Params p, const uint64_t* slots, const uint64_t* ab, uint64_t n) {
+    P2_PROLOGUE(p);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) sv_node<NW>(sv, slots[i])[NW] = ab[i];
 }
-// Mark1in1outNode (cutTipPreGraph.c:532-564): a live non-linear node with one arc each way becomes linear
+// Mark1in1outNode (cutTipPreGraph.c:532-564) over one set: a live non-linear node with one arc each way becomes linear
 __global__ void tip_remark(uint64_t* nodes, int nw1, uint64_t n_slots) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t* nd = nodes + i * nw1;
@@ -526,7 +469,7 @@ __global__ void tip_remark(uint64_t* nodes, int nw1, uint64_t n_slots) {
         const uint64_t ab = nd[nw1 - 1];
         const uint32_t A = (uint32_t)ab, B = (uint32_t)(ab >> 32);
         if (B & (B_DELETED | B_LINEAR)) continue;
-        if (count_arcs(A) == 1 && count_arcs(B) == 1) nd[nw1 - 1] = ab | ((uint64_t)B_LINEAR << 32);
+        if (count_arcs24(A) == 1 && count_arcs24(B) == 1) nd[nw1 - 1] = ab | ((uint64_t)B_LINEAR << 32);
     }
 }
 
@@ -546,13 +489,20 @@ __global__ void p2_fill_u64(unsigned long long* a, uint64_t n, unsigned long lon
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// The graph on the device.  Kernels are launched on `device` (the lead rank's GPU); the k-mer sets may be spread over
+// several GPUs of the process -- set s on set_dev[s], reached from the lead through peer mappings (xGMI) -- which is how
+// the sharded run keeps every rank at its share of the sets ("reference set id -> GPU").
 struct P2Device {
     int device = 0, K = 0, nw = 2, P = 1, max_nk = 0;
     bool reps = false;
     uint32_t num_ed = 0;
     P2Params prm;
-    uint64_t* d_nodes = nullptr;
-    uint64_t* d_geo = nullptr;          // set_base[P] then set_size[P]
+    std::vector<uint64_t> set_sizes, set_first;      // host copy of the geometry
+    std::vector<int> set_dev;
+    std::vector<uint64_t*> set_ptr;                  // address of every set's slot 0
+    std::vector<std::pair<int, void*>> owned;        // (device, allocation) holding the sets
+    uint64_t* d_geo3 = nullptr;                      // per set (first global slot, size, address of slot 0): P2Params::geo3, SetsView::geo
+    uint32_t* d_crc = nullptr;                       // CRC-32 byte table for the lookups of the backend-generic stages
     uint64_t* d_patch_keys = nullptr;
     uint32_t* d_patch_val = nullptr;
     unsigned long long* d_arc_key = nullptr;
@@ -568,15 +518,13 @@ struct P2Device {
     uint64_t n_slots = 0;
     bool reads_ready = false;
     hipStream_t stream = nullptr;
-    std::vector<uint64_t> set_sizes;     // host copy of the geometry
-    uint64_t* d_geo3 = nullptr;          // SetsView::geo: per set (first global slot, size, address of slot 0)
-    uint32_t* d_crc = nullptr;           // CRC-32 byte table for the lookups of the backend-generic stages
 };
 
 static void p2_free(P2Device* d) {
     if (!d) return;
+    for (auto& o : d->owned) { (void)hipSetDevice(o.first); (void)hipFree(o.second); }
     hipSetDevice(d->device);
-    hipFree(d->d_nodes); hipFree(d->d_geo); hipFree(d->d_patch_keys); hipFree(d->d_patch_val);
+    hipFree(d->d_patch_keys); hipFree(d->d_patch_val);
     hipFree(d->d_arc_key); hipFree(d->d_arc_cnt); hipFree(d->d_arc_first);
     hipFree(d->d_counters); hipFree(d->d_marker);
     hipFree(d->d_words); hipFree(d->d_off); hipFree(d->d_lens); hipFree(d->d_stage); hipFree(d->d_walk_len);
@@ -585,39 +533,93 @@ static void p2_free(P2Device* d) {
     delete d;
 }
 
-static int p2_open_impl(P2Device* d, const P2Sets& sets) {
+// the sets are in place (set_sizes / set_dev / set_ptr filled): geometry to the lead, peer mappings, stream, counters
+static int p2_finish_open(P2Device* d) {
     P2_HIP(hipSetDevice(d->device));
-    P2_HIP(hipStreamCreate(&d->stream));
+    if (!d->stream) P2_HIP(hipStreamCreate(&d->stream));
     memset(&d->prm, 0, sizeof(d->prm));
-    const int NW1 = d->nw + 1;
-    uint64_t total = 0;
-    std::vector<uint64_t> geo(2 * (size_t)d->P);
-    for (int s = 0; s < d->P; s++) { geo[s] = total; geo[d->P + s] = sets.size[s]; total += sets.size[s]; }
-    d->set_sizes.assign(sets.size, sets.size + d->P);
-    d->n_slots = total;
-    P2_HIP(hipMalloc((void**)&d->d_geo, geo.size() * sizeof(uint64_t)));
-    P2_HIP(hipMemcpy(d->d_geo, geo.data(), geo.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-    P2_HIP(hipMalloc((void**)&d->d_nodes, std::max<uint64_t>(total, 1) * NW1 * sizeof(uint64_t)));
-    for (int s = 0; s < d->P; s++)
-        if (sets.size[s])
-            P2_HIP(hipMemcpyAsync(d->d_nodes + geo[s] * NW1, sets.nodes[s], sets.size[s] * NW1 * sizeof(uint64_t), hipMemcpyHostToDevice, d->stream));
+    std::vector<uint64_t> words(3 * (size_t)d->P);
+    d->set_first.assign(d->P, 0);
+    uint64_t first = 0;
+    for (int s = 0; s < d->P; s++) {
+        d->set_first[s] = first;
+        words[3 * s] = first; words[3 * s + 1] = d->set_sizes[s]; words[3 * s + 2] = (uint64_t)(uintptr_t)d->set_ptr[s];
+        first += d->set_sizes[s];
+        if (d->set_dev[s] != d->device) {                    // the lead reads and writes its peers' sets
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, d->device, d->set_dev[s]) != hipSuccess || !can) { pg_set_error("the GPUs holding the k-mer sets cannot map each other's memory"); return PG_ENODEV; }
+            const hipError_t e = hipDeviceEnablePeerAccess(d->set_dev[s], 0);
+            if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { pg_set_error(std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e)); return PG_ENODEV; }
+            (void)hipGetLastError();
+        }
+    }
+    d->n_slots = first;
+    P2_HIP(hipMalloc((void**)&d->d_geo3, words.size() * sizeof(uint64_t)));
+    P2_HIP(hipMemcpy(d->d_geo3, words.data(), words.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    P2_HIP(hipMalloc((void**)&d->d_crc, 256 * sizeof(uint32_t)));
+    {
+        uint32_t tab[256];
+        for (uint32_t i = 0; i < 256; i++) tab[i] = crc32_table_entry(i);
+        P2_HIP(hipMemcpy(d->d_crc, tab, sizeof tab, hipMemcpyHostToDevice));
+    }
     P2_HIP(hipMalloc((void**)&d->d_counters, 8 * sizeof(unsigned long long)));
     P2_HIP(hipMemsetAsync(d->d_counters, 0, 8 * sizeof(unsigned long long), d->stream));
     P2_HIP(hipStreamSynchronize(d->stream));
     P2Params& p = d->prm;
-    p.nodes = d->d_nodes;
-    p.set_base = d->d_geo; p.set_size = d->d_geo + d->P;
+    p.geo3 = d->d_geo3;
     p.P = (uint32_t)d->P; p.bias = set_bias((uint32_t)d->P); p.K = d->K;
     p.max_nk = d->max_nk;
     p.counters = d->d_counters;
     return PG_OK;
 }
 
-P2Device* p2_open(int device, int K, int nw, int n_sets, const P2Sets& sets, int max_nk) {
+// upload: set s goes to set_device[s] (null: everything to `device`); one allocation per device
+static int p2_open_impl(P2Device* d, const P2Sets& sets, const int* set_device) {
+    const int NW1 = d->nw + 1;
+    d->set_sizes.assign(sets.size, sets.size + d->P);
+    d->set_dev.assign(d->P, d->device);
+    d->set_ptr.assign(d->P, nullptr);
+    if (set_device) for (int s = 0; s < d->P; s++) d->set_dev[s] = set_device[s];
+    std::vector<int> devs;
+    for (int s = 0; s < d->P; s++) if (std::find(devs.begin(), devs.end(), d->set_dev[s]) == devs.end()) devs.push_back(d->set_dev[s]);
+    std::vector<hipStream_t> streams;
+    int rc = PG_OK;
+    for (int dev : devs) {
+        uint64_t total = 0;
+        for (int s = 0; s < d->P; s++) if (d->set_dev[s] == dev) total += sets.size[s];
+        uint64_t* base = nullptr;
+        hipStream_t st = nullptr;
+        if (hipSetDevice(dev) != hipSuccess || hipMalloc((void**)&base, std::max<uint64_t>(total, 1) * NW1 * sizeof(uint64_t)) != hipSuccess ||
+            hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
+            pg_set_error("out of device memory for the k-mer sets (" + std::to_string(total * NW1 * 8 >> 20) + " MiB on device " + std::to_string(dev) + ")");
+            if (base) (void)hipFree(base);
+            rc = PG_ENOMEM;
+            break;
+        }
+        d->owned.emplace_back(dev, (void*)base);
+        streams.push_back(st);
+        uint64_t at = 0;
+        for (int s = 0; s < d->P && rc == PG_OK; s++) {
+            if (d->set_dev[s] != dev) continue;
+            d->set_ptr[s] = base + at * NW1;
+            if (sets.size[s] && hipMemcpyAsync(d->set_ptr[s], sets.nodes[s], sets.size[s] * NW1 * sizeof(uint64_t), hipMemcpyHostToDevice, st) != hipSuccess) { pg_set_error("upload of a k-mer set failed"); rc = PG_ENODEV; }
+            at += sets.size[s];
+        }
+    }
+    for (size_t i = 0; i < streams.size(); i++) {                   // the devices' uploads ran side by side
+        (void)hipSetDevice(devs[i]);
+        if (hipStreamSynchronize(streams[i]) != hipSuccess && rc == PG_OK) { pg_set_error("upload of the k-mer sets failed"); rc = PG_ENODEV; }
+        (void)hipStreamDestroy(streams[i]);
+    }
+    if (rc) return rc;
+    return p2_finish_open(d);
+}
+
+P2Device* p2_open(int device, int K, int nw, int n_sets, const P2Sets& sets, int max_nk, const int* set_device) {
     if (n_sets < 1 || n_sets > P2_MAX_SETS || (nw != 2 && nw != 4)) { pg_set_error("pass 2: bad arguments"); return nullptr; }
     P2Device* d = new P2Device();
     d->device = device; d->K = K; d->nw = nw; d->P = n_sets; d->max_nk = std::max(max_nk, 1);
-    if (p2_open_impl(d, sets) != PG_OK) { p2_free(d); return nullptr; }
+    if (p2_open_impl(d, sets, set_device) != PG_OK) { p2_free(d); return nullptr; }
     return d;
 }
 
@@ -627,57 +629,82 @@ __global__ void p2_empty_image(uint64_t* nodes, int nw1, uint64_t n_slots) {
         nodes[i] = (i % nw1) ? 0ULL : P2_EMPTY;
 }
 
-// SURVEY.md App. C "K6": the k-mer sets of a static (-a) pool laid out on the device, from the distinct k-mers of pass 1 as
-// they lie there sorted by (set, first ordinal) -- no host replay, no upload (dev_graph.hpp: layout_static)
+// SURVEY.md App. C "K6", one rank's share: the sets this rank owns (n_own of them, set_size slots each, back to back in a
+// fresh allocation on `device`), laid out from the rank's records as they lie there sorted by (set, first ordinal) -- no host
+// replay, no upload (dev_graph.hpp: layout_static).  PG_OK, 1 = unsuited (nothing allocated), or PG_E*.
+int p2_layout_rank(int device, int nw, int n_own, const uint64_t* d_records, const uint64_t* own_counts, uint64_t set_size, uint64_t** d_nodes_out) {
+    *d_nodes_out = nullptr;
+    if (n_own < 1) return PG_OK;
+    const bool verbose = getenv("PG_HOST_VERBOSE") != nullptr;
+    auto now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
+    const double t0 = now();
+    for (int s = 0; s < n_own; s++) if (own_counts[s] >= set_size || own_counts[s] >= 0xFFFFFFFFULL) return K6_UNSUITED;
+    P2_HIP(hipSetDevice(device));
+    hipStream_t st = nullptr;
+    P2_HIP(hipStreamCreate(&st));
+    const int NW1 = nw + 1;
+    const uint64_t total = (uint64_t)n_own * set_size;
+    uint64_t* nodes = nullptr;
+    if (hipMalloc((void**)&nodes, total * NW1 * sizeof(uint64_t)) != hipSuccess) {
+        (void)hipStreamDestroy(st);
+        pg_set_error("layout: out of device memory for the k-mer sets (" + std::to_string(total * NW1 * 8 >> 20) + " MiB on device " + std::to_string(device) + ")");
+        return PG_ENOMEM;
+    }
+    const double t1 = now();
+    hipLaunchKernelGGL(p2_empty_image, dim3(8192), dim3(256), 0, st, nodes, NW1, total);
+    int rc;
+    std::string why;
+    {
+        HipBackend be(device, st);
+        rc = nw == 2 ? layout_static<HipBackend, 2>(be, d_records, own_counts, n_own, set_size, nodes)
+                     : layout_static<HipBackend, 4>(be, d_records, own_counts, n_own, set_size, nodes);
+        why = be.error_text;
+    }
+    if (rc == PG_OK && hipStreamSynchronize(st) != hipSuccess) { rc = PG_ENODEV; why = "kernel failure"; }
+    (void)hipStreamDestroy(st);
+    if (rc) { (void)hipFree(nodes); if (rc < 0) pg_set_error("layout: " + (why.empty() ? std::string("failed") : why)); return rc; }
+    if (verbose) fprintf(stderr, "K6 on device %d: %d set(s) of %llu slots, allocation %.2fs, layout %.2fs\n", device, n_own, (unsigned long long)set_size, t1 - t0, now() - t1);
+    *d_nodes_out = nodes;
+    return PG_OK;
+}
+
+// the graph over sets that are already in device memory: set s = set_size[s] slots at set_ptr[s] on set_device[s]; the
+// allocations in `owned` (device, pointer) change hands
+P2Device* p2_adopt(int lead_device, int K, int nw, int n_sets, const uint64_t* set_size, const int* set_device, uint64_t* const* set_ptr,
+                   const std::vector<std::pair<int, void*>>& owned, int max_nk) {
+    P2Device* d = new P2Device();
+    d->device = lead_device; d->K = K; d->nw = nw; d->P = n_sets; d->max_nk = std::max(max_nk, 1);
+    d->set_sizes.assign(set_size, set_size + n_sets);
+    d->set_dev.assign(set_device, set_device + n_sets);
+    d->set_ptr.assign(set_ptr, set_ptr + n_sets);
+    d->owned = owned;
+    if (n_sets < 1 || n_sets > P2_MAX_SETS || (nw != 2 && nw != 4)) { pg_set_error("graph: bad arguments"); p2_free(d); return nullptr; }
+    if (p2_finish_open(d) != PG_OK) { p2_free(d); return nullptr; }
+    return d;
+}
+
 P2Device* p2_open_layout(int device, int K, int nw, int n_sets, const uint64_t* d_records, const uint64_t* per_set_count, uint64_t set_size,
                          int max_nk, bool* unsuited) {
     *unsuited = false;
-    if (n_sets < 1 || n_sets > P2_MAX_SETS || (nw != 2 && nw != 4)) { pg_set_error("layout: bad arguments"); return nullptr; }
-    P2Device* d = new P2Device();
-    d->device = device; d->K = K; d->nw = nw; d->P = n_sets; d->max_nk = std::max(max_nk, 1);
-    auto fail = [&](const std::string& why) -> P2Device* { if (!why.empty()) pg_set_error(why); p2_free(d); return nullptr; };
-    if (hipSetDevice(device) != hipSuccess || hipStreamCreate(&d->stream) != hipSuccess) return fail("layout: no HIP device");
-    memset(&d->prm, 0, sizeof(d->prm));
-    const int NW1 = nw + 1;
-    const uint64_t total = (uint64_t)n_sets * set_size;
-    std::vector<uint64_t> geo(2 * (size_t)n_sets);
-    for (int s = 0; s < n_sets; s++) { geo[s] = (uint64_t)s * set_size; geo[n_sets + s] = set_size; }
-    d->set_sizes.assign(n_sets, set_size);
-    d->n_slots = total;
-    if (hipMalloc((void**)&d->d_geo, geo.size() * sizeof(uint64_t)) != hipSuccess || hipMalloc((void**)&d->d_nodes, total * NW1 * sizeof(uint64_t)) != hipSuccess ||
-        hipMalloc((void**)&d->d_counters, 8 * sizeof(unsigned long long)) != hipSuccess)
-        return fail("layout: out of device memory for the k-mer sets (" + std::to_string(total * NW1 * 8 >> 20) + " MiB)");
-    (void)hipMemcpyAsync(d->d_geo, geo.data(), geo.size() * sizeof(uint64_t), hipMemcpyHostToDevice, d->stream);
-    (void)hipMemsetAsync(d->d_counters, 0, 8 * sizeof(unsigned long long), d->stream);
-    hipLaunchKernelGGL(p2_empty_image, dim3(8192), dim3(256), 0, d->stream, d->d_nodes, NW1, total);
-    int rc;
-    {
-        HipBackend be(device, d->stream);
-        rc = nw == 2 ? layout_static<HipBackend, 2>(be, d_records, per_set_count, n_sets, set_size, d->d_nodes)
-                     : layout_static<HipBackend, 4>(be, d_records, per_set_count, n_sets, set_size, d->d_nodes);
-        if (rc < 0) return fail("layout: " + (be.error_text.empty() ? std::string("failed") : be.error_text));
-    }
-    if (rc == K6_UNSUITED) { *unsuited = true; return fail(""); }
-    if (hipStreamSynchronize(d->stream) != hipSuccess) return fail("layout: kernel failure");
-    P2Params& p = d->prm;
-    p.nodes = d->d_nodes;
-    p.set_base = d->d_geo; p.set_size = d->d_geo + d->P;
-    p.P = (uint32_t)d->P; p.bias = set_bias((uint32_t)d->P); p.K = d->K;
-    p.max_nk = d->max_nk;
-    p.counters = d->d_counters;
-    return d;
+    uint64_t* nodes = nullptr;
+    const int rc = p2_layout_rank(device, nw, n_sets, d_records, per_set_count, set_size, &nodes);
+    if (rc == K6_UNSUITED) { *unsuited = true; return nullptr; }
+    if (rc) return nullptr;
+    std::vector<uint64_t> sizes(n_sets, set_size);
+    std::vector<int> devs(n_sets, device);
+    std::vector<uint64_t*> ptrs(n_sets);
+    for (int s = 0; s < n_sets; s++) ptrs[s] = nodes + (uint64_t)s * set_size * (nw + 1);
+    return p2_adopt(device, K, nw, n_sets, sizes.data(), devs.data(), ptrs.data(), {{device, (void*)nodes}}, max_nk);
 }
 
 // one set's slots, as they are on the device now, into host memory (size * (nw + 1) words)
 int p2_download_set(P2Device* d, int set, void* dst) {
-    P2_HIP(hipSetDevice(d->device));
-    uint64_t first = 0;
-    for (int s = 0; s < set; s++) first += d->set_sizes[s];
+    P2_HIP(hipSetDevice(d->set_dev[set]));
     const size_t bytes = (size_t)d->set_sizes[set] * (d->nw + 1) * sizeof(uint64_t);
     hipStream_t st = nullptr;
     P2_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     const bool reg = hipHostRegister(dst, bytes, hipHostRegisterDefault) == hipSuccess;       // plain DMA instead of staged copies
-    hipError_t e = hipMemcpyAsync(dst, d->d_nodes + first * (d->nw + 1), bytes, hipMemcpyDeviceToHost, st);
+    hipError_t e = hipMemcpyAsync(dst, d->set_ptr[set], bytes, hipMemcpyDeviceToHost, st);
     if (e == hipSuccess) e = hipStreamSynchronize(st);
     if (reg) (void)hipHostUnregister(dst);
     (void)hipStreamDestroy(st);
@@ -778,16 +805,17 @@ int p2_tip_walks(P2Device* d, int cut_len, bool thin, std::vector<P2TipWalk>& ou
     uint64_t cap = d->n_slots / 8 + 4096;                 // dead ends are a small share of the slots; retried when short
     out.clear();
     if (hipSetDevice(d->device) != hipSuccess) { pg_set_error("tips: hipSetDevice failed"); return PG_ENODEV; }
-    if (d->n_slots / 256 >= 0x7FFFFFFFULL) { pg_set_error("tips: too many slots for one launch"); return PG_EINVAL; }
+    for (int si = 0; si < d->P; si++) if (d->set_sizes[si] / 256 >= 0x7FFFFFFFULL) { pg_set_error("tips: too many slots for one launch"); return PG_EINVAL; }
     P2_HIP_GOTO(hipMalloc((void**)&d_cnt, 2 * sizeof(unsigned long long)));
     for (int attempt = 0; attempt < 2; attempt++) {
         hipFree(d_w); d_w = nullptr;
         P2_HIP_GOTO(hipMalloc((void**)&d_w, cap * sizeof(P2TipWalk)));
         P2_HIP_GOTO(hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), st));
-        if (d->n_slots) {
-            const dim3 grid((unsigned)((d->n_slots + 255) / 256));
-            if (d->nw == 2) hipLaunchKernelGGL(tip_walk_kernel<2>, grid, dim3(256), 0, st, d->prm, d->n_slots, cut_len, thin ? 1 : 0, d_w, cap, d_cnt, d_cnt + 1);
-            else hipLaunchKernelGGL(tip_walk_kernel<4>, grid, dim3(256), 0, st, d->prm, d->n_slots, cut_len, thin ? 1 : 0, d_w, cap, d_cnt, d_cnt + 1);
+        for (int si = 0; si < d->P; si++) {
+            if (!d->set_sizes[si]) continue;
+            const dim3 grid((unsigned)((d->set_sizes[si] + 255) / 256));
+            if (d->nw == 2) hipLaunchKernelGGL(tip_walk_kernel<2>, grid, dim3(256), 0, st, d->prm, d->set_ptr[si], d->set_first[si], d->set_sizes[si], cut_len, thin ? 1 : 0, d_w, cap, d_cnt, d_cnt + 1);
+            else hipLaunchKernelGGL(tip_walk_kernel<4>, grid, dim3(256), 0, st, d->prm, d->set_ptr[si], d->set_first[si], d->set_sizes[si], cut_len, thin ? 1 : 0, d_w, cap, d_cnt, d_cnt + 1);
             P2_HIP_GOTO(hipGetLastError());
         }
         P2_HIP_GOTO(hipMemcpyAsync(cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, st));
@@ -827,7 +855,8 @@ int p2_mirror_nodes(P2Device* d, const uint64_t* slots, const uint64_t* ab, uint
     P2_HIP(hipMalloc((void**)&d_ab, n * sizeof(uint64_t)));
     P2_HIP(hipMemcpyAsync(d_s, slots, n * sizeof(uint64_t), hipMemcpyHostToDevice, d->stream));
     P2_HIP(hipMemcpyAsync(d_ab, ab, n * sizeof(uint64_t), hipMemcpyHostToDevice, d->stream));
-    hipLaunchKernelGGL(tip_mirror, dim3(1024), dim3(256), 0, d->stream, d->d_nodes, d->nw + 1, d_s, d_ab, n);
+    if (d->nw == 2) hipLaunchKernelGGL(tip_mirror<2>, dim3(1024), dim3(256), 0, d->stream, d->prm, d_s, d_ab, n);
+    else hipLaunchKernelGGL(tip_mirror<4>, dim3(1024), dim3(256), 0, d->stream, d->prm, d_s, d_ab, n);
     P2_HIP(hipStreamSynchronize(d->stream));
     hipFree(d_s); hipFree(d_ab);
     return PG_OK;
@@ -835,7 +864,8 @@ int p2_mirror_nodes(P2Device* d, const uint64_t* slots, const uint64_t* ab, uint
 
 int p2_remark_linear(P2Device* d) {
     P2_HIP(hipSetDevice(d->device));
-    hipLaunchKernelGGL(tip_remark, dim3(4096), dim3(256), 0, d->stream, d->d_nodes, d->nw + 1, d->n_slots);
+    for (int si = 0; si < d->P; si++)
+        if (d->set_sizes[si]) hipLaunchKernelGGL(tip_remark, dim3(4096), dim3(256), 0, d->stream, d->set_ptr[si], d->nw + 1, d->set_sizes[si]);
     P2_HIP(hipStreamSynchronize(d->stream));
     return PG_OK;
 }
@@ -843,24 +873,7 @@ int p2_remark_linear(P2Device* d) {
 // ---- the sets as the backend-generic stages see them (dev_tips.hpp) ---------------------------------------------------------
 static int p2_sets_view(P2Device* d, SetsView& view, SetsGeo& geo) {
     P2_HIP(hipSetDevice(d->device));
-    const int NW1 = d->nw + 1;
-    geo.P = d->P; geo.first.clear(); geo.size.clear(); geo.base.clear();
-    std::vector<uint64_t> words(3 * (size_t)d->P);
-    uint64_t first = 0;
-    for (int s = 0; s < d->P; s++) {
-        uint64_t* base = d->d_nodes + first * NW1;
-        geo.first.push_back(first); geo.size.push_back(d->set_sizes[s]); geo.base.push_back(base);
-        words[3 * s] = first; words[3 * s + 1] = d->set_sizes[s]; words[3 * s + 2] = (uint64_t)(uintptr_t)base;
-        first += d->set_sizes[s];
-    }
-    if (!d->d_geo3) {
-        P2_HIP(hipMalloc((void**)&d->d_geo3, words.size() * sizeof(uint64_t)));
-        P2_HIP(hipMalloc((void**)&d->d_crc, 256 * sizeof(uint32_t)));
-        uint32_t tab[256];
-        for (uint32_t i = 0; i < 256; i++) tab[i] = crc32_table_entry(i);
-        P2_HIP(hipMemcpy(d->d_crc, tab, sizeof tab, hipMemcpyHostToDevice));
-    }
-    P2_HIP(hipMemcpy(d->d_geo3, words.data(), words.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
+    geo.P = d->P; geo.first = d->set_first; geo.size = d->set_sizes; geo.base = d->set_ptr;
     view = SetsView{d->d_geo3, d->d_crc, (uint32_t)d->P, set_bias((uint32_t)d->P), d->K};
     return PG_OK;
 }
@@ -881,9 +894,11 @@ int p2_clip_tips(P2Device* d, bool cut_single, P2TipTotals& out) {
 }
 
 // the vertices (live non-linear nodes) in slot order, NW key words each (output_vertex, output_pregraph.c:50-86)
-__global__ void vx_gather(const uint64_t* nodes, int nw, const unsigned long long* slots, uint64_t n, uint64_t* out) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * nw; i += (uint64_t)gridDim.x * blockDim.x)
-        out[i] = nodes[slots[i / nw] * (nw + 1) + i % nw];
+template <int NW>
+__global__ __launch_bounds__(256) void vx_gather(P2Params p, const unsigned long long* slots, uint64_t n, uint64_t* out) {
+    P2_PROLOGUE(p);
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * NW; i += (uint64_t)gridDim.x * blockDim.x)
+        out[i] = sv_node<NW>(sv, slots[i / NW])[i % NW];
 }
 int p2_list_vertices(P2Device* d, std::vector<uint64_t>& keys) {
     int rc = PG_OK;
@@ -899,7 +914,8 @@ int p2_list_vertices(P2Device* d, std::vector<uint64_t>& keys) {
     P2_HIP_GOTO(hipMalloc((void**)&d_cnt, sizeof(unsigned long long)));
     P2_HIP_GOTO(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st));
     P2_HIP_GOTO(hipMalloc((void**)&d_list, std::max<uint64_t>(d->n_slots, 1) * sizeof(unsigned long long)));
-    hipLaunchKernelGGL(eb_list_branch, dim3(4096), dim3(256), 0, st, d->d_nodes, d->nw + 1, d->n_slots, d_list, d_cnt);
+    for (int si = 0; si < d->P; si++)
+        if (d->set_sizes[si]) hipLaunchKernelGGL(eb_list_branch, dim3(4096), dim3(256), 0, st, d->set_ptr[si], d->nw + 1, d->set_sizes[si], d->set_first[si], d_list, d_cnt);
     P2_HIP_GOTO(hipMemcpyAsync(&n, d_cnt, sizeof n, hipMemcpyDeviceToHost, st));
     P2_HIP_GOTO(hipStreamSynchronize(st));
     if (n) {
@@ -909,7 +925,8 @@ int p2_list_vertices(P2Device* d, std::vector<uint64_t>& keys) {
         P2_HIP_GOTO((rocprim::radix_sort_keys<rocprim::default_config, unsigned long long*, unsigned long long*, size_t>(nullptr, tmp_bytes, d_list, d_sorted, (size_t)n, 0u, (unsigned)bits, st)));
         P2_HIP_GOTO(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
         P2_HIP_GOTO((rocprim::radix_sort_keys<rocprim::default_config, unsigned long long*, unsigned long long*, size_t>(d_tmp, tmp_bytes, d_list, d_sorted, (size_t)n, 0u, (unsigned)bits, st)));
-        hipLaunchKernelGGL(vx_gather, dim3(4096), dim3(256), 0, st, d->d_nodes, d->nw, d_sorted, (uint64_t)n, d_keys);
+        if (d->nw == 2) hipLaunchKernelGGL(vx_gather<2>, dim3(4096), dim3(256), 0, st, d->prm, d_sorted, (uint64_t)n, d_keys);
+        else hipLaunchKernelGGL(vx_gather<4>, dim3(4096), dim3(256), 0, st, d->prm, d_sorted, (uint64_t)n, d_keys);
         keys.resize((size_t)n * d->nw);
         P2_HIP_GOTO(hipMemcpyAsync(keys.data(), d_keys, keys.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         P2_HIP_GOTO(hipStreamSynchronize(st));
@@ -939,7 +956,8 @@ int p2_build_edges(P2Device* d, P2Edges& out) {
     P2_HIP_GOTO(hipMalloc((void**)&d_cnt, 4 * sizeof(unsigned long long)));
     P2_HIP_GOTO(hipMemsetAsync(d_cnt, 0, 4 * sizeof(unsigned long long), st));
     P2_HIP_GOTO(hipMalloc((void**)&d_list, std::max<uint64_t>(d->n_slots, 1) * sizeof(unsigned long long)));
-    hipLaunchKernelGGL(eb_list_branch, dim3(4096), dim3(256), 0, st, d->d_nodes, NW1, d->n_slots, d_list, d_cnt);
+    for (int si = 0; si < d->P; si++)
+        if (d->set_sizes[si]) hipLaunchKernelGGL(eb_list_branch, dim3(4096), dim3(256), 0, st, d->set_ptr[si], NW1, d->set_sizes[si], d->set_first[si], d_list, d_cnt);
     P2_HIP_GOTO(hipMemcpyAsync(cnt, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
     P2_HIP_GOTO(hipStreamSynchronize(st));
     n_list = cnt[0];
@@ -1004,9 +1022,9 @@ int p2_build_edges(P2Device* d, P2Edges& out) {
         P2_HIP_GOTO(hipMalloc((void**)&d_text, std::max<unsigned long long>(total_bases, 1)));
         {
             const dim3 grid((unsigned)((n_rec + 255) / 256));
-            if (d->nw == 2) hipLaunchKernelGGL(eb_apply<2>, grid, dim3(256), 0, st, d->prm, d->d_nodes, d_recs, d_order, n_rec, d_id_before, d_base_before, d_text,
+            if (d->nw == 2) hipLaunchKernelGGL(eb_apply<2>, grid, dim3(256), 0, st, d->prm, d_recs, d_order, n_rec, d_id_before, d_base_before, d_text,
                                                d->d_patch_keys, d->d_patch_val, patch_cap - 1, d_cnt + 3);
-            else hipLaunchKernelGGL(eb_apply<4>, grid, dim3(256), 0, st, d->prm, d->d_nodes, d_recs, d_order, n_rec, d_id_before, d_base_before, d_text,
+            else hipLaunchKernelGGL(eb_apply<4>, grid, dim3(256), 0, st, d->prm, d_recs, d_order, n_rec, d_id_before, d_base_before, d_text,
                                     d->d_patch_keys, d->d_patch_val, patch_cap - 1, d_cnt + 3);
             P2_HIP_GOTO(hipGetLastError());
         }

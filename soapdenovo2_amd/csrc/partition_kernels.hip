@@ -35,7 +35,7 @@
 namespace pg {
 
 constexpr uint64_t L_EMPTY = ~0ULL;
-constexpr unsigned long long F_POOL = 1, F_CHUNKS = 2, F_OUT = 4, F_SPLIT = 8;
+constexpr unsigned long long F_POOL = 1, F_CHUNKS = 2, F_OUT = 4, F_SPLIT = 8, F_ROUTE = 16;   // F_ROUTE: an owner's send region overflowed (multi-GPU cut)
 
 template <int NW> struct E2Cfg;
 // LDS slot = KW key words | ord | 10 x u32 counters (L[4], R[4], puts, spare)
@@ -113,7 +113,7 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_kernel(ReadsArg a, E2Dev e,
         if (ROUTE) {
             const uint32_t o = pid % (uint32_t)ro.n_owners;
             const unsigned long long at = atomicAdd(&ro.cursor[o], 1ULL);
-            if (at >= ro.cap) { atomicOr(&ctr->e2_flags, F_POOL); return; }
+            if (at >= ro.cap) { atomicOr(&ctr->e2_flags, F_ROUTE); return; }
             ro.pids[(uint64_t)o * ro.cap + at] = pid;
             dst = ro.recs + ((uint64_t)o * ro.cap + at) * RW;
         } else {
@@ -231,7 +231,7 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_seg_kernel(ReadsArg a, E2De
         if (ROUTE) {
             const uint32_t o = pid % (uint32_t)ro.n_owners;
             const unsigned long long at = obase[o] + ranks[it];
-            if (at >= ro.cap) { atomicOr(&ctr->e2_flags, F_POOL); continue; }
+            if (at >= ro.cap) { atomicOr(&ctr->e2_flags, F_ROUTE); continue; }
             ro.pids[(uint64_t)o * ro.cap + at] = pid;
             out = ro.recs + ((uint64_t)o * ro.cap + at) * RW;
         } else {
@@ -1074,6 +1074,14 @@ int e2_route(pg_ctx* c, const uint64_t* d_packed, const uint64_t* d_word_off, co
     return launch_serial(c, a, &ro, st);
 }
 
+// the cut of a batch is about to be repeated with larger owner regions (pg_count_reads_sharded): forget the overflow
+__global__ void e2_clear_flag_kernel(DevCounters* ctr, unsigned long long bit) { atomicAnd(&ctr->e2_flags, ~bit); }
+int e2_clear_route_overflow(pg_ctx* c, hipStream_t st) {
+    hipLaunchKernelGGL(e2_clear_flag_kernel, dim3(1), dim3(1), 0, st, c->ctr, F_ROUTE);
+    E2_TRY(hipGetLastError());
+    return PG_OK;
+}
+
 // multi-GPU step 2: take records another rank cut for this rank's partitions
 int e2_ingest(pg_ctx* c, const uint64_t* d_recs, const uint32_t* d_pids, uint64_t n, hipStream_t st) {
     if (n == 0) return PG_OK;
@@ -1203,6 +1211,7 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     E2_TRY(hipStreamSynchronize(st));
     DevCounters h;
     E2_TRY(hipMemcpy(&h, c->ctr, sizeof h, hipMemcpyDeviceToHost));
+    if (h.e2_flags & F_ROUTE) { pg_set_error("partition engine: an owner's send region overflowed and the cut was not repeated"); return PG_ENOMEM; }
     if (h.e2_flags & F_POOL) { pg_set_error("partition engine: record pool exhausted (raise log2_slots or PG_POOL_MB)"); return PG_ENOMEM; }
     if (h.e2_flags & F_CHUNKS) { pg_set_error("partition engine: one partition outgrew its chunk list (heavily skewed minimizers)"); return PG_ENOMEM; }
     if ((h.e2_flags & F_OUT) && c->autogrow && !(h.e2_flags & (F_POOL | F_CHUNKS | F_SPLIT))) {
