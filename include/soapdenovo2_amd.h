@@ -147,6 +147,15 @@ pg_graph *pg_graph_begin_streamed(int (*fetch)(void *user, uint64_t first_record
 pg_graph *pg_graph_begin_device(const uint64_t *d_records, int records_device, uint64_t n_records, const uint64_t *per_set_count,
                                 const uint64_t *set_last_put, int K, int mer127, int n_sets, int cut_single, int a_gb,
                                 int max_read_len, int n_threads, const char *prefix, int device);
+/* The sharded form ("reference set id -> GPU"): rank r of n_ranks holds, in the memory of HIP device devices[r], the
+ * records of the k-mer sets s with s mod n_ranks == r (what pg_exchange_regroup_by_set leaves there), sorted by (set, ordinal)
+ * (pg_sort_records); n_records[r] of them; per_set_count[s] over all sets.  Every set's layout is made where its records are --
+ * -a: on its rank's GPU (K6); growable sets: by the host threads, pulling from that GPU -- and the set then lives on that GPU
+ * only: no rank ever holds more than its share of the sets.  The tip, edge and pass-2 kernels run on devices[0] and reach the
+ * other ranks' sets through peer mappings (all ranks belong to this process). */
+pg_graph *pg_graph_begin_sharded(int n_ranks, const int *devices, const uint64_t *const *d_records, const uint64_t *n_records,
+                                 const uint64_t *per_set_count, const uint64_t *set_last_put, int K, int mer127, int n_sets,
+                                 int cut_single, int a_gb, int max_read_len, int n_threads, const char *prefix);
 pg_graph *pg_host_graph_begin(const uint64_t *records, uint64_t n_records, const uint64_t *set_last_put, int K, int mer127,
                               int n_sets, int cut_single, int a_gb, int max_read_len, int n_threads, const char *prefix);
 int pg_host_graph_resolve_repeats(pg_graph *g, int on);
@@ -173,6 +182,10 @@ int pg_host_replay_layout(const uint64_t *records, uint64_t n_records, const uin
 int64_t pg_host_skm_cut(const uint64_t *packed, uint64_t n_reads, uint32_t read_len, int K, int mer127, int log2_parts, uint64_t ord_base,
                         int n_owners, uint64_t *records_out, uint64_t *tags_out, uint64_t capacity);
 int64_t pg_host_skm_expand(const uint64_t *records, uint64_t n_records, int K, int mer127, uint64_t *out, uint64_t capacity);
+
+/* Host twin of the grouping step of pg_exchange_regroup_by_set (no GPU; tests): counts_out[q] = records whose reference set is
+ * owned by rank q (set s -> rank s mod n_ranks), grouped_out = the records grouped by that rank, in their order. */
+int pg_host_regroup_plan(const uint64_t *records, uint64_t n_records, int rec_words, int n_ranks, uint64_t *counts_out, uint64_t *grouped_out);
 
 /* Write <prefix>.kmerFreq from the 256-bin coverage histogram (freqStat, prlHashReads.c:1104-1132). */
 int pg_host_write_kmerfreq(const uint64_t hist[256], const char *prefix);

@@ -558,6 +558,8 @@ int run(int argc, char** argv, bool mer127) {
     uint64_t n_distinct = 0;
     pg_ctx* ctx = nullptr;
     uint64_t* d_rec = nullptr;                                     // the distinct k-mers of pass 1, on `device`
+    std::vector<uint64_t*> sh_rec;                                 // sharded run: per rank, the k-mers of the sets it owns (replay order), on its GPU
+    std::vector<uint64_t> sh_n, sh_per_set;
     int engine_used = 2;
     if (n_ranks > 1) {
         // ---- pass 1 on n_ranks GPUs: cut + all-to-all + append per batch, then every rank counts its own partitions
@@ -590,24 +592,24 @@ int run(int argc, char** argv, bool mer127) {
             have_kept = p1.take_kept(kept);
         }
         lap("parse + scatter + exchange (pass 1)");
-        // count: all ranks at once; the coverage histogram is summed over the ranks (all-reduce), the per-set last put is
-        // the latest over the ranks, the distinct k-mers are gathered on rank 0's GPU
+        // count: all ranks at once; the coverage histogram and the per-set counts are summed over the ranks (all-reduce), the
+        // per-set last put is the latest over the ranks.  Then the distinct k-mers move to the rank that owns their reference
+        // set (set s -> rank s mod n_ranks) and are put in replay order there: from here on a k-mer set lives whole
+        // on one GPU and nothing is gathered anywhere.
         const int rw1 = (mer127 ? 4 : 2) + 2;
         std::vector<std::vector<uint64_t>> last(n_ranks, std::vector<uint64_t>(o.sets, 0));
-        std::vector<uint64_t> n_r(n_ranks, 0);
-        std::vector<uint64_t*> d_r(n_ranks, nullptr);
+        std::vector<uint64_t> n_before(n_ranks, 0);
         std::vector<std::string> err(n_ranks);
-        uint64_t n_all = 0;
+        sh_rec.assign(n_ranks, nullptr);
+        sh_n.assign(n_ranks, 0);
+        sh_per_set.assign(o.sets, 0);
         {
             std::vector<std::thread> th;
-            std::mutex mu;
-            std::condition_variable cv;
-            int counted = 0;
             for (int r = 0; r < n_ranks; r++)
                 th.emplace_back([&, r] {
                     uint64_t h[512];                                  // coverage histogram | distinct k-mers per set
                     uint64_t* d_h = nullptr;
-                    auto fail = [&](const char* what) { err[r] = std::string(what) + ": " + pg_last_error(); };
+                    auto fail = [&](const char* what) { if (err[r].empty()) err[r] = std::string(what) + ": " + pg_last_error(); };
                     bool ok = pg_finalize(ctxs[r], o.delow, h, nullptr, nullptr) == PG_OK;
                     if (!ok) fail("pg_finalize");
                     if (ok && pg_set_counts(ctxs[r], h + 256, nullptr) != PG_OK) { ok = false; fail("pg_set_counts"); }
@@ -617,37 +619,35 @@ int run(int argc, char** argv, bool mer127) {
                         hipMemcpy(d_h, h, sizeof h, hipMemcpyHostToDevice) != hipSuccess) { fprintf(stderr, "rank %d: no device memory\n", r); exit(-1); }
                     if (pg_exchange_allreduce_u64(comms[r], d_h, 512, nullptr) != PG_OK && ok) { ok = false; fail("pg_exchange_allreduce_u64"); }
                     HIP_OK(hipMemcpy(h, d_h, sizeof h, hipMemcpyDeviceToHost));
-                    if (r == 0) memcpy(hist, h, 256 * sizeof(uint64_t));
+                    if (r == 0) { memcpy(hist, h, 256 * sizeof(uint64_t)); for (int sidx = 0; sidx < o.sets; sidx++) sh_per_set[sidx] = h[256 + sidx]; }
                     hipFree(d_h);
                     // every rank sees the same totals, so all of them take the same decision about the last put
                     if (ok && pg_host_last_put_matters(h + 256, o.sets, o.a_gb, mer127 ? 1 : 0) && pg_last_put(ctxs[r], last[r].data(), nullptr) != PG_OK) { ok = false; fail("pg_last_put"); }
-                    if (ok && pg_export_take(ctxs[r], &d_r[r], &n_r[r]) != PG_OK) { ok = false; fail("pg_export_take"); }
-                    if (!ok) { n_r[r] = 0; d_r[r] = nullptr; }
-                    // rank 0 sizes the gathered array once every rank knows its count
-                    {
-                        std::unique_lock<std::mutex> lk(mu);
-                        if (++counted == n_ranks) {
-                            for (int q = 0; q < n_ranks; q++) n_all += n_r[q];
-                            if (n_all) { HIP_OK(hipSetDevice(device)); HIP_OK(hipMalloc((void**)&d_rec, (size_t)n_all * rw1 * sizeof(uint64_t))); }
-                            HIP_OK(hipSetDevice(devices[r]));
-                            cv.notify_all();
-                        } else cv.wait(lk, [&] { return counted == n_ranks; });
-                    }
-                    uint64_t got = 0;
-                    if (pg_exchange_gather_records(comms[r], d_r[r], n_r[r], rw1, 0, d_rec, n_all, &got, nullptr) != PG_OK && ok) fail("pg_exchange_gather_records");
-                    if (d_r[r]) hipFree(d_r[r]);
-                    pg_destroy(ctxs[r]);
+                    uint64_t* d_mine = nullptr;
+                    uint64_t n_mine = 0;
+                    if (ok && pg_export_take(ctxs[r], &d_mine, &n_mine) != PG_OK) { ok = false; fail("pg_export_take"); }
+                    if (!ok) { n_mine = 0; d_mine = nullptr; }
+                    n_before[r] = n_mine;
+                    pg_destroy(ctxs[r]);                              // the record pool and the tables: the regroup and the sort want the room
+                    uint64_t* d_g = nullptr;
+                    uint64_t n_g = 0;
+                    if (pg_exchange_regroup_by_set(comms[r], d_mine, n_mine, rw1, &d_g, &n_g, nullptr) != PG_OK) { ok = false; fail("pg_exchange_regroup_by_set"); }
+                    if (ok && n_g && (hipSetDevice(devices[r]) != hipSuccess || pg_sort_records(d_g, n_g, mer127 ? 1 : 0, nullptr) != PG_OK)) { ok = false; fail("pg_sort_records"); }
+                    sh_rec[r] = d_g; sh_n[r] = n_g;
                 });
             for (auto& t : th) t.join();
         }
         for (int r = 0; r < n_ranks; r++) if (!err[r].empty()) { fprintf(stderr, "rank %d: %s\n", r, err[r].c_str()); exit(-1); }
+        uint64_t n_all = 0;
+        for (int r = 0; r < n_ranks; r++) n_all += sh_n[r];
         for (int r = 0; r < n_ranks; r++) {
             for (int sidx = 0; sidx < o.sets; sidx++) set_last[sidx] = std::max(set_last[sidx], last[r][sidx]);
             if (verbose) {
                 uint64_t cs[4];
                 pg_comm_stats(comms[r], cs);
-                fprintf(stderr, "[cli] rank %d (device %d): %llu distinct k-mers, %llu rounds, %llu records sent, %llu received\n", r, devices[r],
-                        (unsigned long long)n_r[r], (unsigned long long)cs[0], (unsigned long long)cs[1], (unsigned long long)cs[2]);
+                fprintf(stderr, "[cli] rank %d (device %d): %llu distinct k-mers after pass 1, %llu of %llu after the regroup by set; %llu rounds, %llu records sent, %llu received\n",
+                        r, devices[r], (unsigned long long)n_before[r], (unsigned long long)sh_n[r], (unsigned long long)n_all, (unsigned long long)cs[0],
+                        (unsigned long long)cs[1], (unsigned long long)cs[2]);
             }
             pg_comm_destroy(comms[r]);
         }
@@ -746,7 +746,7 @@ int run(int argc, char** argv, bool mer127) {
     std::vector<uint64_t> per_set(o.sets, 0);
     void* d_ws = nullptr;
     uint64_t ws_bytes = 0;
-    if (n_distinct) {
+    if (n_distinct && n_ranks == 1) {
         if (ctx) {
             // the partition engine hands its export array over as it is and frees its streams (no second copy in HBM);
             // the global-set engine compacts its table into a fresh array
@@ -790,12 +790,17 @@ int run(int argc, char** argv, bool mer127) {
     if (const char* e = getenv("SOAPDENOVO2_AMD_PASS2")) host_pass2 = strcmp(e, "host") == 0;
     if (host_pass2) host_edges = true;                               // host pass 2 needs the host copy of the sets tagged
     // records still on the device: with -a the layout is made there (K6), otherwise the replay's workers pull their stretches
-    pg_graph* graph = stream_records
+    pg_graph* graph = n_ranks > 1
+        ? pg_graph_begin_sharded(n_ranks, devices.data(), sh_rec.data(), sh_n.data(), sh_per_set.data(), set_last.data(), K, mer127 ? 1 : 0, o.sets, o.delow == 0,
+                                 o.a_gb, max_read_len, 0, o.prefix.c_str())
+        : stream_records
         ? pg_graph_begin_device(d_rec, device, n_distinct, per_set.data(), set_last.data(), K, mer127 ? 1 : 0, o.sets, o.delow == 0, o.a_gb,
                                 max_read_len, 0, o.prefix.c_str(), host_edges ? -1 : device)
         : pg_graph_begin(records.data(), n_distinct, set_last.data(), K, mer127 ? 1 : 0, o.sets, o.delow == 0, o.a_gb,
                          max_read_len, 0, o.prefix.c_str(), host_edges ? -1 : device);
     if (d_rec) { hipFree(d_rec); d_rec = nullptr; }
+    for (int r = 0; r < (int)sh_rec.size(); r++) if (sh_rec[r]) { (void)hipSetDevice(devices[r]); hipFree(sh_rec[r]); sh_rec[r] = nullptr; }
+    (void)hipSetDevice(device);
     if (!graph) die("pg_host_graph_begin");
     if (o.reps && pg_host_graph_resolve_repeats(graph, 1) != PG_OK) die("pg_host_graph_resolve_repeats");
     if (!host_pass2 && pg_graph_use_device(graph, device) != PG_OK) die("pg_graph_use_device");

@@ -407,6 +407,7 @@ extern "C" int pg_count_reads_sharded(pg_ctx* ctx, pg_comm* c, const uint64_t* d
     // a read of k k-mers makes about 2k / (w + 1) + 1 records; twice that, spread over n owners, plus slack
     const uint64_t est = 2 * n_kmers / (uint64_t)(ctx->e2.g.w + 1) + n_reads;
     uint64_t want_cap = 2 * est / (uint64_t)n + 4096;
+    if (const char* e = getenv("PG_ROUTE_CAP")) { const long v = atol(e); if (v > 0) want_cap = std::max<uint64_t>(c->cap * 4 / 5, (uint64_t)v); }   // tests: start small, exercise the repeat
     uint64_t total_in = 0;
     // A batch dominated by one minimizer (low-complexity reads, adapter dimers, high-copy repeats) can send one owner far
     // more than its even share: the cut is then repeated with regions as large as the largest count seen (the batch is

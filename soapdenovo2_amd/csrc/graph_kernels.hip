@@ -717,8 +717,9 @@ int p2_download_set(P2Device* d, int set, void* dst) {
 // the null stream queue up behind each other).  n_words = 0: the calling thread will not ask again.
 int p2_fetch_words(int device, const uint64_t* d_src, uint64_t n_words, uint64_t* dst) {
     struct PerThread {
-        hipStream_t st = nullptr; void* reg = nullptr; size_t bytes = 0;
-        ~PerThread() { if (reg) (void)hipHostUnregister(reg); if (st) (void)hipStreamDestroy(st); }
+        std::vector<std::pair<int, hipStream_t>> st;      // one stream per device this thread has pulled from (a worker's sets may lie on several)
+        void* reg = nullptr; size_t bytes = 0;
+        ~PerThread() { if (reg) (void)hipHostUnregister(reg); for (auto& q : st) { (void)hipSetDevice(q.first); (void)hipStreamDestroy(q.second); } }
     };
     static thread_local PerThread t;
     if (hipSetDevice(device) != hipSuccess) return PG_ENODEV;
@@ -727,14 +728,21 @@ int p2_fetch_words(int device, const uint64_t* d_src, uint64_t n_words, uint64_t
         return PG_OK;
     }
     const size_t bytes = (size_t)n_words * sizeof(uint64_t);
-    if (!t.st && hipStreamCreateWithFlags(&t.st, hipStreamNonBlocking) != hipSuccess) return PG_ENODEV;
+    hipStream_t st = nullptr;
+    for (auto& q : t.st) if (q.first == device) st = q.second;
+    if (!st) {
+        if (hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) return PG_ENODEV;
+        t.st.emplace_back(device, st);
+    }
     if (t.reg != (void*)dst || t.bytes < bytes) {
         if (t.reg) { (void)hipHostUnregister(t.reg); t.reg = nullptr; }
-        if (hipHostRegister(dst, bytes, hipHostRegisterDefault) == hipSuccess) { t.reg = dst; t.bytes = bytes; }
+        if (hipHostRegister(dst, bytes, hipHostRegisterPortable) == hipSuccess) { t.reg = dst; t.bytes = bytes; }
     }
-    if (hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, t.st) != hipSuccess) return PG_ENODEV;
-    return hipStreamSynchronize(t.st) == hipSuccess ? PG_OK : PG_ENODEV;
+    if (hipMemcpyAsync(dst, d_src, bytes, hipMemcpyDeviceToHost, st) != hipSuccess) return PG_ENODEV;
+    return hipStreamSynchronize(st) == hipSuccess ? PG_OK : PG_ENODEV;
 }
+
+void pg_device_free_on(int device, void* d_ptr) { if (d_ptr) { (void)hipSetDevice(device); (void)hipFree(d_ptr); } }
 
 // KmerSetsPatch as the host built it
 int p2_set_patch(P2Device* d, const uint64_t* patch_keys, const uint32_t* patch_val, uint64_t patch_cap) {

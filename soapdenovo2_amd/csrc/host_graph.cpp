@@ -1773,6 +1773,7 @@ struct GraphHandle : GraphHandleBase {
     int max_nk() const { return std::max(1, max_read_len - g.K + 1); }
     // edges on the device (graph_kernels.hip: eb_*): upload the sets, build, then format output_1edge's text here
     // the k-mer sets into HBM as they are now (after the layout replay: the tips then walk on the device copy)
+    std::vector<int> set_devices;                // sharded run: the HIP device every set lives on (empty: all on dev_id)
     int dev_open(int device) {
         dev_on = true; dev_id = device;
         P2Sets sets;
@@ -1781,7 +1782,7 @@ struct GraphHandle : GraphHandleBase {
             sets.nodes[si] = g.sets[si].array.data(); sets.size[si] = g.sets[si].size;
             g.set_base[si + 1] = g.set_base[si] + g.sets[si].size;
         }
-        dev = p2_open(dev_id, g.K, NW, g.P, sets, max_nk());
+        dev = p2_open(dev_id, g.K, NW, g.P, sets, max_nk(), set_devices.empty() ? nullptr : set_devices.data());
         if (!dev) return PG_ENODEV;
         g.tip_dev = dev;
         return PG_OK;
@@ -2239,11 +2240,68 @@ static int layout_on_device(GraphHandle<NW>* h, const uint64_t* d_records, const
     return PG_OK;
 }
 
+// The sharded form ("reference set id -> GPU"): rank r of n_ranks holds the records of the sets s with
+// s mod n_ranks == r, sorted by (set, ordinal), in the memory of its own GPU.
+struct ShardedRecords {
+    int n_ranks = 0, rw = 0;
+    std::vector<int> devices;
+    std::vector<const uint64_t*> d_rec;
+    std::vector<uint64_t> first_global;          // [P + 1] index of every set's first record in set order
+    std::vector<uint64_t> local_off;             // [P] index of the set's first record in its rank's array
+};
+static int fetch_sharded_records(void* user, uint64_t first, uint64_t n, uint64_t* dst) {
+    const ShardedRecords* f = (const ShardedRecords*)user;
+    if (n == 0) return p2_fetch_words(f->devices[0], nullptr, 0, nullptr);
+    const int s = (int)(std::upper_bound(f->first_global.begin(), f->first_global.end(), first) - f->first_global.begin()) - 1;   // a stretch never spans sets
+    const int r = s % f->n_ranks;
+    return p2_fetch_words(f->devices[r], f->d_rec[r] + (f->local_off[s] + (first - f->first_global[s])) * (uint64_t)f->rw, n * (uint64_t)f->rw, dst);
+}
+// K6 on every rank for the sets it owns, then one graph over all of them (the lead = rank 0's GPU runs the kernels)
+template <int NW>
+static int layout_on_ranks(GraphHandle<NW>* h, const ShardedRecords& sr, const uint64_t* per_set_count, int K, int P, int a_gb, int n_threads) {
+    Graph<NW>& g = h->g;
+    g.K = K; g.P = P; g.filter = kmer_filter<NW>(K); g.bias = set_bias((uint32_t)P); g.crc = host_crc_table();
+    host_crc8_init();
+    g.n_threads = n_threads;
+    const uint64_t S = ref_initial_set_size(a_gb, P, NW == 4);
+    const int N = sr.n_ranks;
+    std::vector<uint64_t*> nodes(N, nullptr);
+    std::vector<int> rcs(N, PG_OK);
+    std::vector<std::string> why(N);
+    std::vector<std::thread> pool;
+    for (int r = 0; r < N; r++)
+        pool.emplace_back([&, r] {
+            std::vector<uint64_t> own;
+            for (int s = r; s < P; s += N) own.push_back(per_set_count[s]);
+            rcs[r] = p2_layout_rank(sr.devices[r], NW, (int)own.size(), sr.d_rec[r], own.data(), S, &nodes[r]);
+            if (rcs[r] < 0) why[r] = pg_last_error();
+        });
+    for (auto& t : pool) t.join();
+    int rc = PG_OK;
+    for (int r = 0; r < N; r++) if (rcs[r] && rc <= 0) { rc = rcs[r] < 0 ? rcs[r] : (rc ? rc : 1); if (rcs[r] < 0) pg_set_error(why[r]); }
+    std::vector<std::pair<int, void*>> owned;
+    for (int r = 0; r < N; r++) if (nodes[r]) owned.emplace_back(sr.devices[r], (void*)nodes[r]);
+    if (rc) { for (auto& o : owned) pg_device_free_on(o.first, o.second); return rc; }
+    std::vector<uint64_t> sizes(P, S);
+    std::vector<int> devs(P);
+    std::vector<uint64_t*> ptrs(P);
+    for (int s = 0; s < P; s++) { devs[s] = sr.devices[s % N]; ptrs[s] = nodes[s % N] + (uint64_t)(s / N) * S * (NW + 1); }
+    P2Device* dev = p2_adopt(sr.devices[0], K, NW, P, sizes.data(), devs.data(), ptrs.data(), owned, h->max_nk());
+    if (!dev) return PG_ENODEV;
+    g.sets.clear();
+    g.sets.resize(P);
+    g.set_base.assign((size_t)P + 1, 0);
+    for (int si = 0; si < P; si++) g.set_base[si + 1] = g.set_base[si] + S;
+    h->dev = dev; h->dev_on = true; h->dev_id = sr.devices[0];
+    h->set_devices = devs;
+    return PG_OK;
+}
+
 template <int NW>
 static GraphHandleBase* graph_begin(const uint64_t* records, uint64_t n, const uint64_t* set_last_put, int K, int P, int cut_single,
                                     int a_gb, int max_read_len, int n_threads, const char* prefix_c, int device,
                                     pg_fetch_fn fetch = nullptr, void* fetch_user = nullptr, const uint64_t* per_set_count = nullptr,
-                                    const uint64_t* d_records = nullptr, int rec_device = -1) {
+                                    const uint64_t* d_records = nullptr, int rec_device = -1, const ShardedRecords* sharded = nullptr) {
     GraphHandle<NW>* h = new GraphHandle<NW>();
     h->prefix = prefix_c;
     h->max_read_len = max_read_len;
@@ -2259,6 +2317,14 @@ static GraphHandleBase* graph_begin(const uint64_t* records, uint64_t n, const u
         if (a_gb != 0 && device >= 0 && device == rec_device && !(where && !strcmp(where, "host")) && !getenv("SOAPDENOVO2_AMD_TIPS_HOST"))
             rc_replay = layout_on_device<NW>(h, d_records, per_set_count, K, P, a_gb, n_threads, device, /*host_copy=*/tips_replay);
         if (rc_replay == 1) { fetch = &fetch_device_records; fetch_user = &dr; }
+    }
+    if (sharded) {
+        const char* where = getenv("SOAPDENOVO2_AMD_LAYOUT");
+        h->set_devices.resize(P);
+        for (int si = 0; si < P; si++) h->set_devices[si] = sharded->devices[si % sharded->n_ranks];
+        if (a_gb != 0 && !(where && !strcmp(where, "host")) && !tips_replay && !getenv("SOAPDENOVO2_AMD_TIPS_HOST"))
+            rc_replay = layout_on_ranks<NW>(h, *sharded, per_set_count, K, P, a_gb, n_threads);
+        if (rc_replay == 1) { fetch = &fetch_sharded_records; fetch_user = (void*)sharded; }
     }
     if (rc_replay == 1)
         rc_replay = fetch ? replay_streamed<NW>(h->g, fetch, fetch_user, n, per_set_count, set_last_put, K, P, a_gb, n_threads)
@@ -2376,6 +2442,34 @@ extern "C" pg_graph* pg_graph_begin_device(const uint64_t* d_records, int record
     const uint64_t* recs = d_records ? d_records : &none;        // (no records: an address nobody reads)
     pg::GraphHandleBase* h = mer127 ? pg::graph_begin<4>(nullptr, n_records, set_last_put, K, n_sets, cut_single, a_gb, max_read_len, n_threads, prefix, device, nullptr, nullptr, per_set_count, recs, records_device)
                                     : pg::graph_begin<2>(nullptr, n_records, set_last_put, K, n_sets, cut_single, a_gb, max_read_len, n_threads, prefix, device, nullptr, nullptr, per_set_count, recs, records_device);
+    return (pg_graph*)h;
+}
+extern "C" pg_graph* pg_graph_begin_sharded(int n_ranks, const int* devices, const uint64_t* const* d_records, const uint64_t* n_records,
+                                            const uint64_t* per_set_count, const uint64_t* set_last_put, int K, int mer127, int n_sets, int cut_single,
+                                            int a_gb, int max_read_len, int n_threads, const char* prefix) {
+    if (n_ranks < 1 || !devices || !d_records || !n_records || !per_set_count || !prefix) { pg_set_error("null argument"); return nullptr; }
+    const int maxK = mer127 ? 127 : 63;
+    if (K < 13 || K > maxK || !(K & 1)) { pg_set_error("K must be odd and within 13.." + std::to_string(maxK)); return nullptr; }
+    if (n_sets < 1 || n_sets > 255) { pg_set_error("n_sets must be 1..255"); return nullptr; }
+    pg::ShardedRecords sr;
+    sr.n_ranks = n_ranks; sr.rw = (mer127 ? 4 : 2) + 2;
+    sr.devices.assign(devices, devices + n_ranks);
+    sr.d_rec.assign(d_records, d_records + n_ranks);
+    sr.first_global.assign((size_t)n_sets + 1, 0);
+    sr.local_off.assign(n_sets, 0);
+    std::vector<uint64_t> held(n_ranks, 0);
+    uint64_t total = 0;
+    for (int s = 0; s < n_sets; s++) {
+        sr.first_global[s] = total;
+        sr.local_off[s] = held[s % n_ranks];
+        held[s % n_ranks] += per_set_count[s];
+        total += per_set_count[s];
+    }
+    sr.first_global[n_sets] = total;
+    for (int r = 0; r < n_ranks; r++)
+        if (held[r] != n_records[r]) { pg_set_error("pg_graph_begin_sharded: rank " + std::to_string(r) + " does not hold exactly the records of its sets"); return nullptr; }
+    pg::GraphHandleBase* h = mer127 ? pg::graph_begin<4>(nullptr, total, set_last_put, K, n_sets, cut_single, a_gb, max_read_len, n_threads, prefix, devices[0], nullptr, nullptr, per_set_count, nullptr, -1, &sr)
+                                    : pg::graph_begin<2>(nullptr, total, set_last_put, K, n_sets, cut_single, a_gb, max_read_len, n_threads, prefix, devices[0], nullptr, nullptr, per_set_count, nullptr, -1, &sr);
     return (pg_graph*)h;
 }
 extern "C" int pg_graph_use_device(pg_graph* g, int device) {

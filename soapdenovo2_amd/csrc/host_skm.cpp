@@ -65,3 +65,20 @@ extern "C" int64_t pg_host_skm_expand(const uint64_t* records, uint64_t n_record
     if ((!records && n_records) || !out) { pg_set_error("pg_host_skm_expand: bad argument"); return -1; }
     return mer127 ? expand<4>(records, n_records, K, out, capacity) : expand<2>(records, n_records, K, out, capacity);
 }
+
+// host twin of the regroup's grouping step (exchange.hip: rg_count / rg_scatter): the rank every record goes to -- the owner
+// of its reference set, set s -> rank s mod n_ranks -- the counts per destination, and the records grouped by destination
+// (order within a destination as they lay); what the gloo tests move through torch.distributed
+extern "C" int pg_host_regroup_plan(const uint64_t* records, uint64_t n_records, int rec_words, int n_ranks, uint64_t* counts_out, uint64_t* grouped_out) {
+    if ((!records && n_records) || !counts_out || !grouped_out || rec_words < 3 || rec_words > 6 || n_ranks < 1 || n_ranks > 256) { pg_set_error("pg_host_regroup_plan: bad argument"); return PG_EINVAL; }
+    for (int q = 0; q < n_ranks; q++) counts_out[q] = 0;
+    for (uint64_t i = 0; i < n_records; i++) counts_out[(records[i * rec_words + rec_words - 1] >> PG_ORD_BITS) % (uint64_t)n_ranks]++;
+    uint64_t at[256], run = 0;
+    for (int q = 0; q < n_ranks; q++) { at[q] = run; run += counts_out[q]; }
+    for (uint64_t i = 0; i < n_records; i++) {
+        const uint64_t d = (records[i * rec_words + rec_words - 1] >> PG_ORD_BITS) % (uint64_t)n_ranks;
+        for (int w = 0; w < rec_words; w++) grouped_out[at[d] * rec_words + w] = records[i * rec_words + w];
+        at[d]++;
+    }
+    return PG_OK;
+}

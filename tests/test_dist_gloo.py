@@ -99,3 +99,50 @@ def test_partition_owner_exchange(tmp_path, case, world):
     w[:, nw + 1] &= np.uint64((1 << 56) - 1)                                # the oracle's set id (P = 1: zero anyway)
     w[:, nw] &= np.uint64(~(1 << (32 + 24)) & 0xFFFFFFFFFFFFFFFF)           # ... and the linear flag of finish_count
     assert (g == w).all()
+
+
+# ---- the regroup after pass 1: distinct k-mers to the rank that owns their reference set (set s -> rank s mod world) ----------
+def _regroup_worker(rank, world, port, tmp, P):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from soapdenovo2_amd import api
+    full = np.load(os.path.join(tmp, "records.npy"))
+    mine = np.ascontiguousarray(full[rank::world])                   # any split of the distinct k-mers will do for pass 1's owners
+    rw = full.shape[1]
+    counts = np.zeros(world, dtype=np.uint64)
+    grouped = np.zeros_like(mine)
+    assert api.lib().pg_host_regroup_plan(mine.ctypes.data, len(mine), rw, world, counts.ctypes.data, grouped.ctypes.data) == 0
+    send_counts = torch.from_numpy(counts.astype(np.int64))
+    recv_counts = torch.empty_like(send_counts)
+    dist.all_to_all_single(recv_counts, send_counts)
+    inp = torch.empty(int(recv_counts.sum()) * rw, dtype=torch.int64)
+    dist.all_to_all_single(inp, torch.from_numpy(grouped.view(np.int64).reshape(-1).copy()), [int(c) * rw for c in recv_counts], [int(c) * rw for c in send_counts])
+    got = inp.numpy().view(np.uint64).reshape(-1, rw)
+    np.save(os.path.join(tmp, f"regrouped{rank}.npy"), got)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,P", [(2, 8), (3, 8), (3, 5)])
+def test_regroup_by_set_owner(tmp_path, world, P):
+    """Every rank ends up with exactly the k-mers of the sets it owns, nobody holds more than its share of sets, nothing is
+    lost or doubled -- through pg_host_regroup_plan, the host twin of the device grouping step."""
+    from soapdenovo2_amd import synth
+    codes = synth.reads_codes(20000, 3000, 100, 0.005, 41)
+    rec, _, _ = oracle_records(codes, 31, P, prefix=str(tmp_path / "o"))
+    rec = rec[np.random.default_rng(1).permutation(len(rec))]
+    np.save(str(tmp_path / "records.npy"), rec)
+    port = 31500 + (os.getpid() * 5 + world * 17 + P) % 2000
+    mp.spawn(_regroup_worker, args=(world, port, str(tmp_path), P), nprocs=world, join=True)
+    parts = [np.load(str(tmp_path / f"regrouped{r}.npy")) for r in range(world)]
+    nw = rec.shape[1] - 2
+    sets_all = (rec[:, nw + 1] >> np.uint64(56)).astype(np.int64)
+    for r, p in enumerate(parts):
+        s = (p[:, nw + 1] >> np.uint64(56)).astype(np.int64)
+        assert (s % world == r).all()
+        assert len(p) == int((sets_all % world == r).sum())              # its sets, whole
+        assert len(p) <= -(-P // world) * np.bincount(sets_all, minlength=P).max()
+    got = np.concatenate(parts)
+    key = lambda a: a[np.lexsort([a[:, i] for i in range(a.shape[1] - 1, -1, -1)])]
+    assert (key(got) == key(rec)).all()

@@ -545,11 +545,35 @@ def test_cli_sharded_matches_reference_files(golden, tmp_path, name, devices):
         pre = str(tmp_path / t)
         env = dict(PARALLEL_PARSE, SOAPDENOVO2_AMD_DEVICES=devices, PG_HOST_VERBOSE="1", SOAPDENOVO2_AMD_BATCH_READS="7000")
         log = _run_cli(cfg, c["K"], pre, P, D, a, m, R=True, extra_env=env)
-        assert f"pass 1 on {len(devices.split(','))} rank(s)" in log
+        n_ranks = len(devices.split(','))
+        assert f"pass 1 on {n_ranks} rank(s)" in log
+        # after the regroup every rank holds the k-mers of its own sets and no more (set s -> rank s mod n_ranks): nothing is gathered
+        import re
+        held = [(int(m.group(1)), int(m.group(2)), int(m.group(3))) for m in re.finditer(r"rank (\d+) \(device \d+\): \d+ distinct k-mers after pass 1, (\d+) of (\d+) after the regroup", log)]
+        assert len(held) == n_ranks and sum(h[1] for h in held) == held[0][2] > 0
+        share = -(-P // n_ranks) / P                                       # the largest number of sets a rank owns / all sets
+        assert max(h[1] for h in held) <= share * held[0][2] * 1.25 + 64, held
         want = golden["md5"][t]
         for ext in ("kmerFreq", "preGraphBasic", "vertex", "preArc", "path", "markOnEdge"):
             assert md5_file(pre + "." + ext) == want[ext], (t, ext)
         assert md5_gz_text(pre + ".edge.gz") == want["edge"], t
+
+
+def test_cli_sharded_repeats_the_cut_when_an_owner_region_overflows(golden, tmp_path):
+    """Send regions that start far too small (PG_ROUTE_CAP): every round's cut overflows, the ranks agree on a larger capacity and
+    cut again -- the files do not change."""
+    name = "m60k_k63"
+    c = golden["cases"][name]
+    cfg = case_config(c, str(tmp_path), name)
+    P, D, a, m = c["runs"][0]
+    t = case_tag(name, c["runs"][0])
+    pre = str(tmp_path / t)
+    env = dict(PARALLEL_PARSE, SOAPDENOVO2_AMD_DEVICES="0,0,0", PG_HOST_VERBOSE="1", SOAPDENOVO2_AMD_BATCH_READS="7000", PG_ROUTE_CAP="50")
+    _run_cli(cfg, c["K"], pre, P, D, a, m, extra_env=env)
+    want = golden["md5"][t]
+    for ext in ("kmerFreq", "preGraphBasic", "vertex", "preArc"):
+        assert md5_file(pre + "." + ext) == want[ext], (t, ext)
+    assert md5_gz_text(pre + ".edge.gz") == want["edge"], t
 
 
 def test_cli_sharded_reader_corner_cases(golden, tmp_path):
