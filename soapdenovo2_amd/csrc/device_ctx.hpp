@@ -33,7 +33,10 @@ struct E2 {
     SkmGeom g;
     int log2_parts = 0;
     uint32_t rpc = 128;           // records per chunk
-    uint32_t maxc = 0;            // chunk-table entries per partition
+    uint32_t rs = 0;              // words from one record to the next (>= g.rw; 8 = every 48-byte record in its own 64-byte line)
+    uint32_t direct = 0;          // the first `direct` chunks of every partition lie at computed addresses (chunk c of partition p
+                                  // = pool chunk c * parts + p): no table entry, no pool atomic, nobody waits for a published id
+    uint32_t maxc = 0;            // chunk-table entries per partition (the chunks after the direct ones)
     uint64_t pool_chunks = 0;
     uint32_t* cursor = nullptr;   // [parts] records appended
     uint32_t* chunk_tbl = nullptr;// [parts * maxc] chunk id + 1, 0 = not allocated

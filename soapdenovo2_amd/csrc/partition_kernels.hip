@@ -45,6 +45,7 @@ template <> struct E2Cfg<4> { static constexpr int PW = 7, KW = 5; };    // 5 ke
 struct E2Dev {
     SkmGeom g;
     uint32_t rpc, maxc, rpc_log2;        // records per chunk: a power of two
+    uint32_t rs, direct;                 // record stride in words; chunks per partition at computed addresses (device_ctx.hpp)
     uint64_t pool_chunks;
     uint32_t* cursor;
     uint32_t* chunk_tbl;
@@ -69,12 +70,16 @@ struct ReadsArg {
 // "publish if first" and THEN the wait loop, and a publisher never waits for anything before its store.  The lane
 // with q % rpc == 0 drew its number before any lane with a later number of that chunk, so its publish is already
 // issued (same or earlier instruction of this wave, or an independent wave).  The wait is bounded anyway.
-__device__ __forceinline__ uint64_t* record_slot(const E2Dev& e, uint32_t pid, uint32_t q, DevCounters* ctr, int rw) {
-    const uint32_t ci = q >> e.rpc_log2, ri = q & (e.rpc - 1);
+__device__ __forceinline__ uint64_t* record_slot(const E2Dev& e, uint32_t pid, uint32_t q, DevCounters* ctr, int) {
+    uint32_t ci = q >> e.rpc_log2;
+    const uint32_t ri = q & (e.rpc - 1);
+    if (ci < e.direct)                                             // chunk ci of partition pid has a fixed place: pool chunk ci * parts + pid
+        return e.pool + ((((uint64_t)ci << e.g.log2_parts) + pid) * e.rpc + ri) * (uint64_t)e.rs;
+    ci -= e.direct;
     if (ci >= e.maxc) { atomicOr(&ctr->e2_flags, F_CHUNKS); return nullptr; }
     uint32_t* t = e.chunk_tbl + (uint64_t)pid * e.maxc + ci;
     if (ri == 0) {
-        const unsigned long long nc = atomicAdd(&ctr->pool_next, 1ULL) + 1;
+        const unsigned long long nc = ((unsigned long long)e.direct << e.g.log2_parts) + atomicAdd(&ctr->pool_next, 1ULL) + 1;
         const uint32_t id = nc > e.pool_chunks ? 0xFFFFFFFFu : (uint32_t)nc;     // 0xFFFFFFFF = "pool exhausted", releases the waiters too
         if (nc > e.pool_chunks) atomicOr(&ctr->e2_flags, F_POOL);
         __hip_atomic_store(t, id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -86,7 +91,13 @@ __device__ __forceinline__ uint64_t* record_slot(const E2Dev& e, uint32_t pid, u
     }
     if (c == 0) { atomicOr(&ctr->e2_flags, F_POOL); return nullptr; }
     if (c == 0xFFFFFFFFu) return nullptr;
-    return e.pool + ((uint64_t)(c - 1) * e.rpc + ri) * (uint64_t)rw;
+    return e.pool + ((uint64_t)(c - 1) * e.rpc + ri) * (uint64_t)e.rs;
+}
+// the pool chunk (id, 1-based; 0 / 0xFFFFFFFF = none) that holds chunk `ci` of partition pid
+__device__ __forceinline__ uint32_t chunk_id_of(const E2Dev& e, uint32_t pid, uint32_t ci) {
+    if (ci < e.direct) return (uint32_t)((((uint64_t)ci << e.g.log2_parts) + pid) + 1);
+    ci -= e.direct;
+    return ci < e.maxc ? e.chunk_tbl[(uint64_t)pid * e.maxc + ci] : 0u;
 }
 
 // multi-GPU: instead of appending to the local partition streams, records go to per-owner send regions (owner =
@@ -287,10 +298,10 @@ __device__ __forceinline__ unsigned int clip_halves_255(unsigned int x) { return
 // wave-aggregated LDS atomic per step that claims a slot), the put loop lost more than the emit's listing phase costs.
 constexpr int K2_MAXPROBE = 48;
 
-__device__ __forceinline__ const uint64_t* record_ptr(const E2Dev& e, uint32_t pid, uint32_t i, int rw) {
-    const uint32_t c = e.chunk_tbl[(uint64_t)pid * e.maxc + (i >> e.rpc_log2)];
+__device__ __forceinline__ const uint64_t* record_ptr(const E2Dev& e, uint32_t pid, uint32_t i, int) {
+    const uint32_t c = chunk_id_of(e, pid, i >> e.rpc_log2);
     if (c == 0 || c == 0xFFFFFFFFu) return nullptr;  // pool ran dry in K1 (flagged there; the run fails in e2_count)
-    return e.pool + ((uint64_t)(c - 1) * e.rpc + (i & (e.rpc - 1))) * (uint64_t)rw;
+    return e.pool + ((uint64_t)(c - 1) * e.rpc + (i & (e.rpc - 1))) * (uint64_t)e.rs;
 }
 
 // ---- K2 ------------------------------------------------------------------------------------------------------------
@@ -390,7 +401,8 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     __shared__ unsigned int hist[256];
     constexpr int MAXSTRIPES = SLOTS / THREADS;
     __shared__ unsigned int aborted, s_mask[40], s_val[40], wave_cnt_e[MAXSTRIPES][NWAVE], wave_cnt_f[NWAVE], s_nlive, s_tot;
-    __shared__ unsigned int chunk_ids2[2][256];                           // the partitions' chunk lists (maxc <= 256)
+    __shared__ unsigned int chunk_ids2[2][256];                           // the partitions' chunk lists (direct + maxc <= 256)
+    const uint32_t nchunks = e.direct + e.maxc;
     __shared__ unsigned long long out_base;
     for (int i = threadIdx.x; i < 1024; i += THREADS) crc_tab[i] = crc32_slice_entry(i >> 8, i & 255);
     for (int i = threadIdx.x; i < 256; i += THREADS) hist[i] = 0;
@@ -420,7 +432,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
             const uint32_t gi = w0 + ri, cid = cids[gi >> e.rpc_log2];
             ulonglong2 v = make_ulonglong2(0, 0);
             if (cid != 0 && cid != 0xFFFFFFFFu)
-                v = ((const ulonglong2*)(e.pool + ((uint64_t)(cid - 1) * e.rpc + (gi & (e.rpc - 1))) * (uint64_t)RW))[part];
+                v = ((const ulonglong2*)(e.pool + ((uint64_t)(cid - 1) * e.rpc + (gi & (e.rpc - 1))) * (uint64_t)e.rs))[part];
             const uint32_t x0 = part ? (uint32_t)(v.x >> 32) : (uint32_t)v.x, x1 = part ? (uint32_t)v.x : (uint32_t)(v.x >> 32);
             ((uint4*)(rlb + PAD))[pc] = make_uint4(x0, x1, (uint32_t)(v.y >> 32), (uint32_t)v.y);
         }
@@ -439,7 +451,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 const uint32_t ri = pc / PIECES, part = pc - ri * PIECES;
                 const uint32_t gi = w0 + ri, cid = cids[gi >> e.rpc_log2];
                 if (cid != 0 && cid != 0xFFFFFFFFu) {
-                    const ulonglong2* src = (const ulonglong2*)(e.pool + ((uint64_t)(cid - 1) * e.rpc + (gi & (e.rpc - 1))) * (uint64_t)RW) + part;
+                    const ulonglong2* src = (const ulonglong2*)(e.pool + ((uint64_t)(cid - 1) * e.rpc + (gi & (e.rpc - 1))) * (uint64_t)e.rs) + part;
                     __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)(rlb + PAD + (p0 + wave * 64) * 4), 16, 0, 0);
                 }
             }
@@ -655,7 +667,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     auto peek_cursor = [&](uint32_t p) { const uint32_t* q = e.cursor + p; asm volatile("" : "+v"(q)); return *q; };
     if (blockIdx.x < parts) {
         pf_nrec = peek_cursor(blockIdx.x);
-        if (threadIdx.x < e.maxc) pf_cid = e.chunk_tbl[(uint64_t)blockIdx.x * e.maxc + threadIdx.x];
+        if (threadIdx.x < nchunks) pf_cid = chunk_id_of(e, blockIdx.x, threadIdx.x);
     }
     int b = 0, cl = 0;                                                    // the current window's buffer, the current partition's chunk list
     bool staged = false;                                                  // its first window is already on its way into rl2[b] (asked for by the previous emit)
@@ -664,13 +676,13 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
         const uint32_t nxt = pid + gridDim.x;
         if (nxt < parts) {
             pf_nrec = peek_cursor(nxt);
-            if (threadIdx.x < e.maxc) pf_cid = e.chunk_tbl[(uint64_t)nxt * e.maxc + threadIdx.x];
+            if (threadIdx.x < nchunks) pf_cid = chunk_id_of(e, nxt, threadIdx.x);
         }
-        const uint32_t usable = min(nrec, e.maxc * e.rpc);               // an overfull partition was flagged by K1
+        const uint32_t usable = min(nrec, nchunks * e.rpc);              // an overfull partition was flagged by K1
         my_records += usable;
         if (usable == 0) continue;                                        // (never one that was asked for)
         if (!staged) {                                                    // (the list's last readers are at least an emit's barriers back)
-            if (threadIdx.x < e.maxc) chunk_ids2[cl][threadIdx.x] = my_cid;
+            if (threadIdx.x < nchunks) chunk_ids2[cl][threadIdx.x] = my_cid;
             K2_SYNC();
         }
         K2_TICK(0);
@@ -762,7 +774,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 }
                 K2_TICK(4);
                 // the next partition's chunk list, for the prepare that runs beside this partition's last emit
-                if (threadIdx.x < e.maxc) chunk_ids2[cl ^ 1][threadIdx.x] = pf_cid;
+                if (threadIdx.x < nchunks) chunk_ids2[cl ^ 1][threadIdx.x] = pf_cid;
                 K2_SYNC();                                                  // the window and its tables are rewritten by the next one
                 if (w0 + WIN < usable) {                                    // more windows add to these counters: keep the halves small
                     for (int i = threadIdx.x; i < SLOTS; i += THREADS) {    // (they saturate at 63 / 255 in the end anyway)
@@ -788,7 +800,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     top += 2;
                 }
             } else {
-                const uint32_t usable_next = nxt < parts ? min(pf_nrec, e.maxc * e.rpc) : 0u;
+                const uint32_t usable_next = nxt < parts ? min(pf_nrec, nchunks * e.rpc) : 0u;
                 // The last emit of a partition borrows its own window (dead now) and, first of all, asks for the next partition's
                 // first window: global_load_lds copies 16 bytes a lane straight into the other buffer, no registers, so the
                 // loads fly during the whole emit (p_stage_async / p_unpack).  Earlier emits (more key ranges to come) borrow
@@ -844,7 +856,7 @@ __global__ __launch_bounds__(BLOCK) void skm_lastput_kernel(E2Dev e, SetParams s
     const int K = e.g.K;
     const uint32_t parts = 1u << e.g.log2_parts;
     for (uint32_t pid = blockIdx.x; pid < parts; pid += gridDim.x) {
-        const uint32_t usable = min(e.cursor[pid], e.maxc * e.rpc);
+        const uint32_t usable = min(e.cursor[pid], (e.direct + e.maxc) * e.rpc);
         for (uint32_t i = threadIdx.x; i < usable; i += BLOCK) {
             const uint64_t* rec = record_ptr(e, pid, i, RW);
             if (!rec) continue;
@@ -884,7 +896,7 @@ __global__ __launch_bounds__(BLOCK) void set_count_kernel(const uint64_t* out, u
 static E2Dev dev_view(const pg_ctx* c) {
     const E2& s = c->e2;
     uint32_t lg = 0; while ((1u << lg) < s.rpc) lg++;
-    return E2Dev{s.g, s.rpc, s.maxc, lg, s.pool_chunks, s.cursor, s.chunk_tbl, s.pool, s.out, s.out_capacity};
+    return E2Dev{s.g, s.rpc, s.maxc, lg, s.rs, s.direct, s.pool_chunks, s.cursor, s.chunk_tbl, s.pool, s.out, s.out_capacity};
 }
 
 int e2_create(pg_ctx* c) {
@@ -898,7 +910,19 @@ int e2_create(pg_ctx* c) {
     s.rpc = 128;
     if (const char* v = getenv("PG_RPC")) { const int q = atoi(v); if (q == 16 || q == 32 || q == 64 || q == 128) s.rpc = (uint32_t)q; }
     const uint64_t parts = (uint64_t)1 << s.log2_parts;
-    const uint64_t rec_bytes = (uint64_t)s.g.rw * 8, chunk_bytes = rec_bytes * s.rpc;
+    // record slots: PG_REC_STRIDE=8 gives every 48-byte record of the two-word flavour its own 64-byte line (whole-line writes
+    // in K1; the four-word flavour's records are 64 bytes anyway)
+    s.rs = (uint32_t)s.g.rw;
+    if (const char* v = getenv("PG_REC_STRIDE")) { const int q = atoi(v); if (q >= s.g.rw && q <= 16 && (q & 1) == 0) s.rs = (uint32_t)q; }
+    const uint64_t rec_bytes = (uint64_t)s.rs * 8, chunk_bytes = rec_bytes * s.rpc;
+    // PG_DIRECT_CHUNKS=M: the first M chunks of every partition at computed addresses (M * parts chunks set aside up front);
+    // -1 = about 1.25x the mean partition when the input size is known
+    s.direct = 0;
+    if (const char* v = getenv("PG_DIRECT_CHUNKS")) {
+        int q = atoi(v);
+        if (q < 0 && c->hint_kmers) q = (int)(((double)c->hint_kmers * 2.0 / (double)(s.g.w + 1) / (double)parts * 1.25 + (double)s.rpc - 1) / (double)s.rpc);
+        s.direct = (uint32_t)std::max(0, std::min(q, 192));
+    }
     size_t free_b = 0, total_b = 0;
     E2_TRY(hipMemGetInfo(&free_b, &total_b));
     // export array: what a set of 2^log2_slots slots would hold at 70 % load
@@ -912,12 +936,14 @@ int e2_create(pg_ctx* c) {
     if (const char* v = getenv("PG_POOL_MB")) pool_bytes = (uint64_t)atoll(v) << 20;
     const uint64_t budget = (uint64_t)(free_b * 0.85);
     if (out_bytes + parts * 8 > budget) { pg_set_error("partition engine: export array does not fit in device memory"); return PG_ENOMEM; }
+    pool_bytes += (uint64_t)s.direct * parts * chunk_bytes;
     pool_bytes = std::min<uint64_t>(pool_bytes, (budget - out_bytes) * 9 / 10);
     s.pool_chunks = pool_bytes / chunk_bytes;
-    if (s.pool_chunks < parts + 16) { pg_set_error("partition engine: record pool too small for the partition count"); return PG_ENOMEM; }
+    if (s.pool_chunks < (uint64_t)s.direct * parts + parts + 16) { pg_set_error("partition engine: record pool too small for the partition count"); return PG_ENOMEM; }
+    if ((((uint64_t)s.direct + 1) << s.log2_parts) >= 0xFFFFFFFFULL || s.pool_chunks >= 0xFFFFFFFFULL) s.pool_chunks = std::min<uint64_t>(s.pool_chunks, 0xFFFFFFF0ULL);   // chunk ids are 32 bits
     // chunk table: up to 2^29 entries in total (2 GB), at least enough for an even spread x8
-    const uint64_t even = (s.pool_chunks + parts - 1) / parts;
-    s.maxc = (uint32_t)std::max<uint64_t>(8, std::min<uint64_t>(std::min<uint64_t>(256, ((uint64_t)1 << 29) / parts), even * 16));
+    const uint64_t even = (s.pool_chunks - (uint64_t)s.direct * parts + parts - 1) / parts;
+    s.maxc = (uint32_t)std::max<uint64_t>(8, std::min<uint64_t>(std::min<uint64_t>(256 - s.direct, ((uint64_t)1 << 29) / parts), even * 16));
     E2_TRY(hipMalloc(&s.cursor, parts * sizeof(uint32_t)));
     E2_TRY(hipMalloc(&s.chunk_tbl, parts * s.maxc * sizeof(uint32_t)));
     E2_TRY(hipMalloc(&s.pool, s.pool_chunks * chunk_bytes + 64));
@@ -957,26 +983,28 @@ static int e2_ensure_pool(pg_ctx* c, uint64_t n_reads, uint64_t n_kmers, hipStre
     const uint64_t parts = (uint64_t)1 << s.log2_parts;
     const uint64_t est_records = 4 * (2 * n_kmers / (uint64_t)(s.g.w + 1) + n_reads) + 64;
     s.est_chunks += est_records / s.rpc + 1;
-    const uint64_t need = s.est_chunks + parts + 16;
+    const uint64_t fixed = (uint64_t)s.direct * parts;                 // chunks at computed addresses: always there, never handed out
+    const uint64_t need = s.est_chunks + parts + 16 + fixed;
     if (need <= s.pool_chunks) return PG_OK;
     // the estimate is loose: look at what was really handed out
     E2_TRY(hipStreamSynchronize(st));
     unsigned long long used = 0;
     E2_TRY(hipMemcpy(&used, &c->ctr->pool_next, sizeof used, hipMemcpyDeviceToHost));
     s.est_chunks = used + est_records / s.rpc + 1;
-    const uint64_t need2 = s.est_chunks + parts + 16;
+    const uint64_t need2 = s.est_chunks + parts + 16 + fixed;
     if (need2 <= s.pool_chunks) return PG_OK;
-    const uint64_t chunk_bytes = (uint64_t)s.g.rw * 8 * s.rpc;
-    const uint64_t fresh_chunks = std::max(need2 * 2, s.pool_chunks * 2);
+    const uint64_t chunk_bytes = (uint64_t)s.rs * 8 * s.rpc;
+    const uint64_t fresh_chunks = std::max(need2 * 2 - fixed, s.pool_chunks * 2 - fixed);
+    if (fresh_chunks >= 0xFFFFFFF0ULL) { pg_set_error("partition engine: more than 2^32 record chunks"); return PG_ENOMEM; }
     uint64_t* fresh = nullptr;
     E2_TRY(hipMalloc(&fresh, fresh_chunks * chunk_bytes + 64));
-    E2_TRY(hipMemcpy(fresh, s.pool, std::min<uint64_t>(used, s.pool_chunks) * chunk_bytes, hipMemcpyDeviceToDevice));
+    E2_TRY(hipMemcpy(fresh, s.pool, std::min<uint64_t>(fixed + used, s.pool_chunks) * chunk_bytes, hipMemcpyDeviceToDevice));
     E2_TRY(hipFree(s.pool));
     s.pool = fresh;
     s.pool_chunks = fresh_chunks;
     // a longer chunk list per partition too, if the table allows (rebuild with the wider stride)
     const uint64_t even = (fresh_chunks + parts - 1) / parts;
-    const uint32_t want = (uint32_t)std::max<uint64_t>(s.maxc, std::min<uint64_t>(std::min<uint64_t>(256, ((uint64_t)1 << 29) / parts), even * 16));
+    const uint32_t want = (uint32_t)std::max<uint64_t>(s.maxc, std::min<uint64_t>(std::min<uint64_t>(256 - s.direct, ((uint64_t)1 << 29) / parts), even * 16));
     if (want > s.maxc) {
         uint32_t* tbl = nullptr;
         E2_TRY(hipMalloc(&tbl, parts * want * sizeof(uint32_t)));
@@ -1088,7 +1116,7 @@ int e2_ingest(pg_ctx* c, const uint64_t* d_recs, const uint32_t* d_pids, uint64_
     E2& s = c->e2;
     if (c->autogrow) {                       // room for n more records (+ one open chunk per partition is already counted)
         s.est_chunks += n / s.rpc + 1;
-        if (s.est_chunks + ((uint64_t)1 << s.log2_parts) + 16 > s.pool_chunks) {
+        if (s.est_chunks + ((uint64_t)1 << s.log2_parts) + 16 + ((uint64_t)s.direct << s.log2_parts) > s.pool_chunks) {
             int rc = e2_ensure_pool(c, 0, 0, st);
             if (rc) return rc;
         }

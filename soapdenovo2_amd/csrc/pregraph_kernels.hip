@@ -812,7 +812,7 @@ extern "C" int pg_stats(pg_ctx* c, uint64_t out[8]) {
     out[1] = c->engine == 2 ? h.n_export : h.n_distinct;
     if (c->engine == 2) {
         out[2] = h.n_records;
-        out[3] = (uint64_t)c->e2.g.rw * 8;
+        out[3] = (uint64_t)c->e2.rs * 8;
         out[4] = h.pool_next;
         out[5] = c->e2.pool_chunks;
         out[6] = (uint64_t)1 << c->e2.log2_parts;
@@ -903,7 +903,7 @@ extern "C" int pg_export_take_ws(pg_ctx* c, uint64_t** d_records_out, uint64_t* 
     c->e2.out_capacity = 0;
     if (d_workspace_out && workspace_bytes_out) {           // the record pool changes hands as well, as scratch memory
         *d_workspace_out = c->e2.pool;
-        *workspace_bytes_out = c->e2.pool_chunks * (uint64_t)c->e2.rpc * (uint64_t)c->e2.g.rw * 8;
+        *workspace_bytes_out = c->e2.pool_chunks * (uint64_t)c->e2.rpc * (uint64_t)c->e2.rs * 8;
         c->e2.pool = nullptr;
     }
     e2_destroy(c);                                       // frees what is left (pool, tables); the context is spent
