@@ -60,7 +60,7 @@ extern "C" int pg_host_read_all(const char* config, int K, uint8_t* codes_out, i
     pg::LibConfig cfg = pg::parse_lib_config(config);
     const int mrl = cfg.max_rd_len ? cfg.max_rd_len : 100;
     long long rec = 0;
-    for (const pg::InputFile& f : pg::input_order(cfg, mrl)) rec += pg::stream_reads(f, sink);
+    for (pg::InputFile f : pg::input_order(cfg, mrl)) { f.keep_len = K + 1; rec += pg::stream_reads(f, sink); }
     if (n_records) *n_records = (uint64_t)rec;
     if (n_accepted) *n_accepted = sink.n;
     if (max_read_len_out) *max_read_len_out = mrl;
@@ -502,6 +502,7 @@ int run(int argc, char** argv, bool mer127) {
     fprintf(stderr, "In %s, %d lib(s), maximum read length %d, maximum name length %d.\n\n", o.config.c_str(),
             (int)cfg.libs.size(), max_read_len, 256);
     std::vector<pg::InputFile> files = pg::input_order(cfg, max_read_len);
+    for (pg::InputFile& f : files) f.keep_len = K + 1;                        // (BAM: prlHashReads.c:437 keeps reads of K + 1 bases and more)
 
     // SOAPDENOVO2_AMD_DEVICES=0,1,2,...: pass 1 sharded over these GPUs (one rank each; an ordinal may repeat, which puts
     // several ranks on one GPU -- how the N-rank path is tested on a 1-GPU box); everything after pass 1 runs on the first.
@@ -528,6 +529,7 @@ int run(int argc, char** argv, bool mer127) {
             if (path->empty() || stat(path->c_str(), &st) != 0) continue;
             double bases = (double)st.st_size * ((f.type == 2 || f.type == 6) ? 0.5 : 1.0);
             if (path->size() > 3 && path->compare(path->size() - 3, 3, ".gz") == 0) bases *= 4.0;
+            if (f.type == 4) bases *= 3.0;                              // BAM: 4-bit bases + qualities, deflated
             est_kmers += (uint64_t)bases;
         }
     // The device export array: room for one distinct k-mer per 6 occurrences (it is enlarged and the partitions are

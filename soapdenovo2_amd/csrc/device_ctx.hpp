@@ -20,11 +20,17 @@ struct DevCounters {
     unsigned long long set_last[256];
     unsigned long long n_export;
     // partition engine
-    unsigned long long pool_next;      // chunks handed out
+    unsigned long long pool_next;      // (unused since the hand-out counters were split: pool_sub)
     unsigned long long e2_flags;       // bit 0 pool exhausted, bit 1 partition chunk list full, bit 2 output full, bit 3 split exhausted
     unsigned long long n_records;      // super-k-mer records written
     unsigned long long phase[12];      // PG_DBG=2: cycles of workgroup thread 0 per K2 phase (measurement aid)
+    // Chunks of the record pool are handed out by POOL_SUBS counters, one 64-byte line each, picked by the partition id: a
+    // single counter took every chunk request of the chip -- 7 M returned atomics on one address per 200 M reads, and one
+    // address serves about 88 of them per microsecond (MI355X_MICROARCH.md, "dequeue"): that alone was K1's 84 ms.
+    // Sub-pool s owns the chunks s + 1, s + 1 + POOL_SUBS, ... (interleaved, so a pool that grows keeps every id valid).
+    unsigned long long pool_sub[1024 * 8];
 };
+constexpr uint32_t POOL_SUBS = 1024;
 
 struct SetParams { uint32_t P, bias; };
 

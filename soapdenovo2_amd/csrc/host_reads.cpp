@@ -12,6 +12,7 @@
 #include <string.h>
 #include <sys/stat.h>
 #include <unistd.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <chrono>
@@ -104,7 +105,7 @@ std::vector<InputFile> input_order(const LibConfig& cfg, int max_all) {
         if (L.asm_flag != 1 && L.asm_flag != 3) continue;              // asm_ctg == 1 (prlHashReads.c:308,406)
         const int mrl = L.rd_len_cutoff > 0 ? std::min(L.rd_len_cutoff, max_all) : max_all;
         auto add = [&](int type, const std::string& a, const std::string& b) {
-            out.push_back(InputFile{(int)i, type, a, b, mrl, L.reverse});
+            out.push_back(InputFile{(int)i, type, a, b, mrl, L.reverse, L.asm_flag, 0});
         };
         for (size_t j = 0; j < L.f1.size(); j++) add(1, L.f1[j], L.f2[j]);
         for (size_t j = 0; j < L.q1.size(); j++) add(2, L.q1[j], L.q2[j]);
@@ -620,8 +621,86 @@ void ReadSink::on_packed(const uint64_t* words, const int32_t* lens, size_t n, i
     }
 }
 
+// ---- b=: BAM (read1seqbam / read1seqInLibBam, readseq1by1.c:449-592,1248-1280; the loops of prlHashReads.c:408-455 and
+// prlRead2path.c:902-960).  An own reader over zlib: a BAM file is a series of gzip members (BGZF), which gzread() inflates
+// one after the other; inside, the header and then records of block_size bytes (SAM/BAM specification 4.2).  What the
+// reference makes of a record: the SEQ column of its SAM text ("=ACMGRSVTWYHKDBN" per 4-bit code; letters go through
+// base2int, '=' and '*' are no letters and vanish), cut to the lib's read length, reverse_seq applied.
+//   asm_flags = 1: records with the QC-fail flag (0x200) are skipped.
+//   otherwise:     records pair up two by two (no names are looked at); a pair with a QC-fail mate is "taken back": the second
+//                  mate is not delivered and the LAST KEPT READ of the buffer -- the first mate if it was long enough to be
+//                  kept, else whatever was kept before it -- is removed again (prlHashReads.c:414-426).  Hence the one-read
+//                  delay line below: a read long enough to be kept is handed to the sink only when the next one arrives.
+//                  (The reference indexes lenBuffer[read_c - 1] even when its buffer is empty -- a pair taken back right
+//                  after a full buffer of reads was flushed -- which reads in front of the array; here nothing is removed
+//                  then.  The pairing state carries over from one BAM file to the next, as the reference's static does.)
+static int g_bam_pair_state = -3;                                   // `state`, readseq1by1.c:44
+
+static long long stream_bam(const InputFile& in, ReadSink& sink) {
+    gzFile fp = gzopen(in.path1.c_str(), "rb");
+    if (!fp) { fprintf(stderr, "Cannot open %s. Now exit to system...\n", in.path1.c_str()); exit(-1); }
+    gzbuffer(fp, 1 << 20);
+    auto need = [&](void* dst, size_t n) { return gzread(fp, dst, (unsigned)n) == (int)n; };
+    auto skip = [&](size_t n) { char tmp[4096]; while (n) { const size_t k = std::min(n, sizeof tmp); if (!need(tmp, k)) return false; n -= k; } return true; };
+    char magic[4];
+    int32_t l_text = 0, n_ref = 0;
+    bool ok = need(magic, 4) && !memcmp(magic, "BAM\1", 4) && need(&l_text, 4) && l_text >= 0 && skip((size_t)l_text) && need(&n_ref, 4) && n_ref >= 0;
+    for (int32_t r = 0; ok && r < n_ref; r++) {
+        int32_t l_name = 0, l_ref = 0;
+        ok = need(&l_name, 4) && l_name >= 0 && skip((size_t)l_name) && need(&l_ref, 4);
+    }
+    if (!ok) { fprintf(stderr, "Cannot read the header.\n"); exit(-1); }
+    const int max_len = std::max(in.max_read_len, 1);
+    std::vector<uint8_t> codes((size_t)max_len + 8), held((size_t)max_len + 8), rec;
+    int held_len = -1;                                               // a kept-length read waiting for its successor
+    long long n_records = 0;
+    static const char nt16[] = "=ACMGRSVTWYHKDBN";
+    for (;;) {
+        int32_t block = 0;
+        if (!need(&block, 4) || block < 32) break;                   // end of file (or a truncated one: samread < 0 ends the file too)
+        rec.resize((size_t)block);
+        if (!need(rec.data(), (size_t)block)) break;
+        const uint32_t l_read_name = rec[8];
+        uint16_t n_cigar, flag;
+        int32_t l_seq;
+        memcpy(&n_cigar, rec.data() + 12, 2); memcpy(&flag, rec.data() + 14, 2); memcpy(&l_seq, rec.data() + 16, 4);
+        const size_t seq_at = 32 + (size_t)l_read_name + 4 * (size_t)n_cigar;
+        if (l_seq < 0 || seq_at + ((size_t)l_seq + 1) / 2 > (size_t)block) break;
+        int type = 0;
+        if (flag & 0x0200) {
+            if (in.asm_flag == 1) continue;                          // not a good read: on to the next record
+            switch (g_bam_pair_state) { case -3: g_bam_pair_state = -2; break; case -2: g_bam_pair_state = 0; break; case -1: g_bam_pair_state = 2; break; default: g_bam_pair_state = -3; }
+        } else {
+            switch (g_bam_pair_state) { case -3: g_bam_pair_state = -1; break; case -2: g_bam_pair_state = 1; break; case -1: g_bam_pair_state = 3; break; default: g_bam_pair_state = -3; }
+        }
+        // the SEQ column: l_seq characters ("*" when there are none), the first max_read_len of them looked at
+        int n = 0;
+        const int look = std::min(l_seq == 0 ? 1 : (int)l_seq, max_len);
+        for (int j = 0; j < look && l_seq > 0; j++) {
+            const char ch = nt16[(rec[seq_at + (size_t)(j >> 1)] >> ((~j & 1) << 2)) & 0xf];
+            if (ch >= 'A' && ch <= 'Z') codes[n++] = (uint8_t)base_code(ch);
+        }
+        if (g_bam_pair_state == 3) g_bam_pair_state = -3;
+        else if (g_bam_pair_state == 0 || g_bam_pair_state == 1 || g_bam_pair_state == 2) { g_bam_pair_state = -3; type = -1; }
+        if (in.reverse) reverse_complement(codes.data(), n);
+        if (type == -1) {                                            // the pair is taken back (prlHashReads.c:412-426)
+            n_records--;
+            held_len = -1;
+            continue;
+        }
+        n_records++;
+        if (n < std::max(in.keep_len, 1)) { sink.on_read(codes.data(), n); continue; }      // nobody keeps it: order does not matter
+        if (held_len >= 0) sink.on_read(held.data(), held_len);
+        held.swap(codes);
+        held_len = n;
+    }
+    if (held_len >= 0) sink.on_read(held.data(), held_len);
+    gzclose(fp);
+    return n_records;
+}
+
 long long stream_reads(const InputFile& in, ReadSink& sink) {
-    if (in.type == 4) { fprintf(stderr, "BAM input (b=) is not supported by this build.\n"); exit(-1); }
+    if (in.type == 4) return stream_bam(in, sink);
     const bool fastq = (in.type == 2 || in.type == 6);
     std::vector<uint8_t> codes((size_t)std::max(in.max_read_len, 1) + 8);
     long long n_records = 0;

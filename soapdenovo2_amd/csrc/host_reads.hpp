@@ -31,6 +31,9 @@ struct InputFile {
     std::string path1, path2;
     int max_read_len;    // min(rd_len_cutoff, max_rd_len) or max_rd_len (openNextFile, prlHashReads.c:921-928)
     int reverse;
+    int asm_flag = 3;    // BAM only: 1 = QC-fail records (flag 0x200) are skipped one by one, else pairs with one are taken back
+    int keep_len = 0;    // BAM only: the length from which the caller keeps a read (K + 1, prlHashReads.c:437): a pair that is
+                         // taken back takes the last KEPT read with it (prlHashReads.c:414-426), so the reader has to know
 };
 std::vector<InputFile> input_order(const LibConfig& cfg, int max_read_len_all);
 

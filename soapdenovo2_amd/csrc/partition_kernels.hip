@@ -25,6 +25,7 @@
 #include <stdlib.h>
 #include <string>
 #include <algorithm>
+#include <vector>
 
 #include "device_ctx.hpp"
 #include "extract.hpp"
@@ -79,7 +80,8 @@ __device__ __forceinline__ uint64_t* record_slot(const E2Dev& e, uint32_t pid, u
     if (ci >= e.maxc) { atomicOr(&ctr->e2_flags, F_CHUNKS); return nullptr; }
     uint32_t* t = e.chunk_tbl + (uint64_t)pid * e.maxc + ci;
     if (ri == 0) {
-        const unsigned long long nc = ((unsigned long long)e.direct << e.g.log2_parts) + atomicAdd(&ctr->pool_next, 1ULL) + 1;
+        const uint32_t nsub = min(POOL_SUBS, 1u << e.g.log2_parts), sub = pid & (nsub - 1);      // (every sub-pool serves as many partitions)
+        const unsigned long long nc = ((unsigned long long)e.direct << e.g.log2_parts) + atomicAdd(&ctr->pool_sub[sub * 8], 1ULL) * nsub + sub + 1;
         const uint32_t id = nc > e.pool_chunks ? 0xFFFFFFFFu : (uint32_t)nc;     // 0xFFFFFFFF = "pool exhausted", releases the waiters too
         if (nc > e.pool_chunks) atomicOr(&ctr->e2_flags, F_POOL);
         __hip_atomic_store(t, id, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -988,8 +990,13 @@ static int e2_ensure_pool(pg_ctx* c, uint64_t n_reads, uint64_t n_kmers, hipStre
     if (need <= s.pool_chunks) return PG_OK;
     // the estimate is loose: look at what was really handed out
     E2_TRY(hipStreamSynchronize(st));
-    unsigned long long used = 0;
-    E2_TRY(hipMemcpy(&used, &c->ctr->pool_next, sizeof used, hipMemcpyDeviceToHost));
+    unsigned long long used = 0;                                      // as if every sub-pool were as full as the fullest
+    {
+        std::vector<unsigned long long> subs(POOL_SUBS * 8);
+        E2_TRY(hipMemcpy(subs.data(), c->ctr->pool_sub, subs.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        for (uint32_t q = 0; q < POOL_SUBS; q++) used = std::max(used, subs[q * 8]);
+        used *= std::min<uint64_t>(POOL_SUBS, parts);
+    }
     s.est_chunks = used + est_records / s.rpc + 1;
     const uint64_t need2 = s.est_chunks + parts + 16 + fixed;
     if (need2 <= s.pool_chunks) return PG_OK;

@@ -813,7 +813,8 @@ extern "C" int pg_stats(pg_ctx* c, uint64_t out[8]) {
     if (c->engine == 2) {
         out[2] = h.n_records;
         out[3] = (uint64_t)c->e2.rs * 8;
-        out[4] = h.pool_next;
+        out[4] = 0;
+        for (uint32_t q = 0; q < POOL_SUBS; q++) out[4] += h.pool_sub[q * 8];
         out[5] = c->e2.pool_chunks;
         out[6] = (uint64_t)1 << c->e2.log2_parts;
         out[7] = c->e2.out_capacity;

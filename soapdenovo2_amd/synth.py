@@ -275,9 +275,61 @@ def make_quirk_case(outdir: str, name: str) -> str:
             f"max_rd_len=100\n[LIB]\navg_ins=300\nasm_flags=3\nrank=1\nq={p(name + '_a.fq')}\n"
             f"[LIB]\navg_ins=300\nasm_flags=3\nrank=2\nq={p(name + '_b.fq')}\n"
             f"[LIB]\navg_ins=200\nasm_flags=3\nrank=3\nq={p(name + '_c.fq')}\n")
+    elif name == "rq_bam":
+        # b=: unaligned BAM (readseq1by1.c:449-592).  Lib 1 (asm_flags=3): records pair up two by two and a pair with a
+        # QC-fail mate (flag 0x200) is taken back; lib 2 (asm_flags=1): QC-fail records are skipped one by one.  IUPAC codes,
+        # '=' and an empty sequence in between; reverse_seq on the second lib.
+        a = reads_codes(20000, 1400, 100, 0.004, 118)
+        b = reads_codes(20000, 600, 100, 0.004, 119)
+        rng = np.random.default_rng(120)
+        def records(codes, qc_every, weird_every):
+            out = []
+            for i, c in enumerate(codes):
+                seq = _ASCII[c].tobytes().decode()
+                if weird_every and i % weird_every == 3:
+                    seq = seq[:10] + "N" + seq[11:20] + "M" + seq[21:30] + "=" + seq[31:]
+                if weird_every and i % (weird_every * 7) == 5:
+                    seq = ""
+                flag = 0x4 | 0x1 | (0x40 if i % 2 == 0 else 0x80)
+                if qc_every and (i % qc_every) in (2, 7):
+                    flag |= 0x200
+                out.append((b"pair%d/%d" % (i // 2, 1 + i % 2), flag, seq))
+            return out
+        write_bam(p(name + "_1.bam"), records(a, 37, 53))
+        write_bam(p(name + "_2.bam"), records(b, 11, 0))
+        open(cfg, "w").write(f"max_rd_len=90\n[LIB]\navg_ins=200\nreverse_seq=0\nasm_flags=3\nb={p(name + '_1.bam')}\n"
+                             f"[LIB]\navg_ins=300\nreverse_seq=1\nasm_flags=1\nb={p(name + '_2.bam')}\n")
     else:
         raise ValueError(name)
     return cfg
 
 
-QUIRK_CASES = ["rq_32k", "rq_trunc", "rq_ragged", "rq_pair", "rq_gz", "rq_p", "rq_tie"]
+def write_bam(path: str, records) -> None:
+    """A minimal unaligned BAM file: records = [(name bytes, flag, sequence str)], qualities 0xFF, no references.  BGZF blocks of
+    <= 60000 bytes with the 'BC' extra field and the empty end-of-file block (SAM/BAM specification, sections 4.1, 4.2)."""
+    import struct, zlib
+    nt16 = {c: i for i, c in enumerate("=ACMGRSVTWYHKDBN")}
+    text = b"@HD\tVN:1.0\tSO:unsorted\n"
+    body = bytearray(b"BAM\1" + struct.pack("<i", len(text)) + text + struct.pack("<i", 0))
+    for name, flag, seq in records:
+        l = len(seq)
+        packed = bytearray((l + 1) // 2)
+        for i, ch in enumerate(seq):
+            packed[i // 2] |= nt16[ch] << (4 if i % 2 == 0 else 0)
+        rec = struct.pack("<iiBBHHHiiii", -1, -1, len(name) + 1, 0, 4680, 0, flag, l, -1, -1, 0) + name + b"\0" + bytes(packed) + b"\xff" * l
+        body += struct.pack("<i", len(rec)) + rec
+    out = bytearray()
+    def block(data):
+        comp = zlib.compressobj(6, zlib.DEFLATED, -15)
+        raw = comp.compress(bytes(data)) + comp.flush()
+        bsize = len(raw) + 25
+        return (b"\x1f\x8b\x08\x04\0\0\0\0\0\xff\x06\0BC\x02\0" + struct.pack("<H", bsize) + raw
+                + struct.pack("<II", zlib.crc32(bytes(data)) & 0xFFFFFFFF, len(data)))
+    for lo in range(0, len(body), 60000):
+        out += block(body[lo:lo + 60000])
+    out += block(b"")
+    with open(path, "wb") as f:
+        f.write(out)
+
+
+QUIRK_CASES = ["rq_32k", "rq_trunc", "rq_ragged", "rq_pair", "rq_gz", "rq_p", "rq_tie", "rq_bam"]
