@@ -88,6 +88,11 @@ void pg_pack_read(const uint8_t *codes, uint32_t len, uint64_t *words_out);
 int pg_host_read_all(const char *config, int K, uint8_t *codes_out, int32_t *lens_out, uint64_t capacity_reads,
                      uint64_t stride, uint64_t *n_records, uint64_t *n_accepted, int *max_read_len_out);
 
+/* BAM inputs (b=): the reader pairs records up two by two and takes pairs with a QC-fail mate back (readseq1by1.c:449-592);
+ * the pairing state is a static of the reference (readseq1by1.c:44) that outlives files, passes and calls -- mirrored here.
+ * set != 0 stores `value` (-3 = as in a fresh process); returns the state. */
+int pg_host_bam_pair_state(int set, int value);
+
 /* Build the reference's k-mer-set layout from the distinct k-mers of pass 1 and run everything after it:
  * [-d] is assumed already applied to `records` by pg_finalize; this replays put_kmerset/encap_kmerset slot
  * placement (newhash.c:340-528) for n_sets sets, then removeSingleTips/removeMinorTips, kmer2edges and

@@ -150,7 +150,7 @@ EXPORTED_SYMBOLS = [
     "pg_export_take", "pg_export_take_ws", "pg_export_peek", "pg_records_checksum", "pg_sort_records_ws", "pg_device_free", "pg_set_counts", "pg_last_put", "pg_host_last_put_matters", "pg_comm_unique_id", "pg_comm_create", "pg_comm_create_local", "pg_comm_destroy", "pg_comm_rank", "pg_comm_size",
     "pg_comm_transport", "pg_comm_stats", "pg_exchange_counts", "pg_exchange_records", "pg_exchange_allreduce_u64",
     "pg_exchange_gather_records", "pg_count_reads_sharded", "pg_host_skm_cut", "pg_host_skm_expand",
-    "pg_host_emu_layout_static", "pg_graph_begin_device", "pg_host_emu_clip_tips", "pg_exchange_regroup_by_set", "pg_comm_regroup_stats", "pg_graph_begin_sharded", "pg_host_regroup_plan",
+    "pg_host_emu_layout_static", "pg_graph_begin_device", "pg_host_emu_clip_tips", "pg_exchange_regroup_by_set", "pg_comm_regroup_stats", "pg_graph_begin_sharded", "pg_host_regroup_plan", "pg_host_bam_pair_state",
 ]
 
 
@@ -281,16 +281,24 @@ def host_pregraph_files(records: np.ndarray, set_last_put, codes: np.ndarray, le
     return nv.value, ne.value, na.value
 
 
-def host_read_all(config: str, K: int):
-    """All reads the reference would hand to pass 1, in its order: (codes [n, stride] uint8, lens int32, n_records, max_rd_len)."""
+def host_read_all(config: str, K: int, bam_state: int = -3):
+    """All reads the reference would hand to a pass over the inputs, in its order: (codes [n, stride] uint8, lens int32, n_records,
+    max_rd_len).  bam_state: the BAM reader's pairing state the pass starts with (-3 = pass 1 of a fresh process; for pass 2 hand in
+    host_bam_state() as pass 1 left it -- the reference's static carries over, readseq1by1.c:44)."""
     nrec, nacc, mrl = C.c_uint64(0), C.c_uint64(0), C.c_int(0)
+    lib().pg_host_bam_pair_state(1, bam_state)
     _check(lib().pg_host_read_all(config.encode(), K, None, None, 0, 0, C.byref(nrec), C.byref(nacc), C.byref(mrl)), "pg_host_read_all")
+    lib().pg_host_bam_pair_state(1, bam_state)
     n, stride = nacc.value, max(mrl.value, 1)
     codes = np.zeros((max(n, 1), stride), dtype=np.uint8)
     lens = np.zeros(max(n, 1), dtype=np.int32)
     _check(lib().pg_host_read_all(config.encode(), K, codes.ctypes.data, lens.ctypes.data, n, stride, C.byref(nrec), C.byref(nacc),
                                   C.byref(mrl)), "pg_host_read_all")
     return codes[:n], lens[:n], nrec.value, mrl.value
+
+
+def host_bam_state() -> int:
+    return int(lib().pg_host_bam_pair_state(0, 0))
 
 
 def host_replay_layout(records: np.ndarray, set_last_put, n_sets: int, mer127: bool = False, a_gb: int = 0):

@@ -635,6 +635,12 @@ void ReadSink::on_packed(const uint64_t* words, const int32_t* lens, size_t n, i
 //                  after a full buffer of reads was flushed -- which reads in front of the array; here nothing is removed
 //                  then.  The pairing state carries over from one BAM file to the next, as the reference's static does.)
 static int g_bam_pair_state = -3;                                   // `state`, readseq1by1.c:44
+// The state is a static of the reference and so outlives a file, a pass and a call: an input with an odd number of good
+// records leaves a first mate dangling, and pass 2 -- which reads the files again -- then pairs the records up one off from
+// pass 1 and takes other pairs back (the golden case rq_bam does exactly that).  Mirrored: call_pregraph parses BAM inputs a
+// second time for pass 2 instead of replaying the reads it kept, and nothing here resets the state.  Tools that look at one
+// pass on its own get and set it through pg_host_bam_pair_state.
+int bam_pair_state(bool set, int value) { if (set) g_bam_pair_state = value; return g_bam_pair_state; }
 
 static long long stream_bam(const InputFile& in, ReadSink& sink) {
     gzFile fp = gzopen(in.path1.c_str(), "rb");

@@ -56,5 +56,7 @@ int host_threads(int n_threads);
 // Returns the number of records parsed ("read(s) processed" in the reference's log counts these).
 // Reads are delivered untruncated by K; the caller drops reads shorter than K + 1 (prlHashReads.c:642).
 long long stream_reads(const InputFile& in, ReadSink& sink);
+// the BAM reader's pairing state (the reference's static `state`, readseq1by1.c:44); set = true stores `value` first
+int bam_pair_state(bool set, int value);
 
 }  // namespace pg

@@ -37,6 +37,12 @@ def test_prearc_on_reader_corner_cases(golden, tmp_path):
     for name in synth.QUIRK_CASES:
         cfg = synth.make_quirk_case(str(tmp_path), name)
         codes, lens, _, mrl = api.host_read_all(cfg, K)
+        # (BAM: the reference's pairing state outlives pass 1, so pass 2 starts with whatever pass 1 left; the fixture has an even
+        #  number of good records, which leaves it where it began)
+        codes2, lens2 = codes, lens
+        if name == "rq_bam":
+            codes2, lens2, _, _ = api.host_read_all(cfg, K, bam_state=api.host_bam_state())
+            assert api.host_bam_state() == -3 and (lens2 == lens).all() and (codes2 == codes).all()
         o = Oracle(K, P=P, max_read_len=mrl)
         o.add_reads(codes, lens=lens)
         o.finish_count(str(tmp_path / ("o_" + name)))
@@ -48,10 +54,10 @@ def test_prearc_on_reader_corner_cases(golden, tmp_path):
         last = np.array(o.set_last_put(), dtype=np.uint64)
         o.close()
         pre = str(tmp_path / name)
-        api.host_pregraph_files(rec, last, codes, lens, K, P, pre, max_read_len=mrl)
+        api.host_pregraph_files(rec, last, codes2, lens2, K, P, pre, max_read_len=mrl)
         assert md5_file(pre + ".preArc") == golden["md5"][name]["preArc"], name
         # the same reads handed over 2-bit packed (pg_host_graph_add_packed: what the executable keeps from pass 1)
-        api.host_pregraph_files(rec, last, codes, lens, K, P, pre + "_pk", max_read_len=mrl, packed=True, batches=3)
+        api.host_pregraph_files(rec, last, codes2, lens2, K, P, pre + "_pk", max_read_len=mrl, packed=True, batches=3)
         assert md5_file(pre + "_pk.preArc") == golden["md5"][name]["preArc"], name
 
 
