@@ -161,6 +161,12 @@ pg_graph *pg_graph_begin_device(const uint64_t *d_records, int records_device, u
 pg_graph *pg_graph_begin_sharded(int n_ranks, const int *devices, const uint64_t *const *d_records, const uint64_t *n_records,
                                  const uint64_t *per_set_count, const uint64_t *set_last_put, int K, int mer127, int n_sets,
                                  int cut_single, int a_gb, int max_read_len, int n_threads, const char *prefix);
+/* Device memory the caller is done with, offered to the graph stages for reuse (one block per device): with -a, pg_graph_begin_device
+ * lays the k-mer sets out inside it when it is large enough instead of allocating -- a hipMalloc of tens of gigabytes right behind
+ * a hipFree of as much takes seconds.  After pg_graph_begin_* the caller withdraws the offer: a non-null result is still the
+ * caller's to free, null means the block was taken over (and is freed with the graph). */
+int pg_device_scratch_offer(int device, void *d_ptr, uint64_t bytes);
+void *pg_device_scratch_withdraw(int device);
 pg_graph *pg_host_graph_begin(const uint64_t *records, uint64_t n_records, const uint64_t *set_last_put, int K, int mer127,
                               int n_sets, int cut_single, int a_gb, int max_read_len, int n_threads, const char *prefix);
 int pg_host_graph_resolve_repeats(pg_graph *g, int on);

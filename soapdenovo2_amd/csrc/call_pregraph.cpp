@@ -788,7 +788,11 @@ int run(int argc, char** argv, bool mer127) {
         }
     }
     if (ctx) pg_destroy(ctx);
-    if (d_ws) { (void)hipFree(d_ws); d_ws = nullptr; }            // the graph stages want the room
+    // pass 1's record pool: with -a the k-mer sets are laid out inside it (no allocation of that size behind a free of that
+    // size: seconds); otherwise it goes now -- the host replay gives the driver the time
+    bool ws_offered = false;
+    if (d_ws && o.a_gb != 0 && stream_records && pg_device_scratch_offer(device, d_ws, ws_bytes) == PG_OK) ws_offered = true;
+    else if (d_ws) { (void)hipFree(d_ws); d_ws = nullptr; }
     lap("export + download records");
 
     // ---- tips + edges (removeSingleTips / removeMinorTips / kmer2edges), graph kept for pass 2
@@ -807,6 +811,7 @@ int run(int argc, char** argv, bool mer127) {
                                 max_read_len, 0, o.prefix.c_str(), host_edges ? -1 : device)
         : pg_graph_begin(records.data(), n_distinct, set_last.data(), K, mer127 ? 1 : 0, o.sets, o.delow == 0, o.a_gb,
                          max_read_len, 0, o.prefix.c_str(), host_edges ? -1 : device);
+    if (ws_offered) { if (void* back = pg_device_scratch_withdraw(device)) (void)hipFree(back); d_ws = nullptr; }
     if (d_rec) { hipFree(d_rec); d_rec = nullptr; }
     for (int r = 0; r < (int)sh_rec.size(); r++) if (sh_rec[r]) { (void)hipSetDevice(devices[r]); hipFree(sh_rec[r]); sh_rec[r] = nullptr; }
     (void)hipSetDevice(device);

@@ -51,7 +51,8 @@ int p2_download_set(P2Device* d, int set, void* dst);
 // the sharded form of the same: p2_layout_rank lays out the sets ONE rank owns (n_own sets of set_size slots, back to back in
 // a fresh allocation on its device; 1 = unsuited), p2_adopt makes the graph over sets that already lie in device memory
 // (set s: set_size[s] slots at set_ptr[s] on set_device[s]; the allocations in `owned` change hands)
-int p2_layout_rank(int device, int nw, int n_own, const uint64_t* d_records, const uint64_t* own_counts, uint64_t set_size, uint64_t** d_nodes_out);
+int p2_layout_rank(int device, int nw, int n_own, const uint64_t* d_records, const uint64_t* own_counts, uint64_t set_size, uint64_t** d_nodes_out,
+                   void** alloc_out = nullptr);      // *alloc_out = what to hipFree in the end (the image may sit inside a block taken over)
 P2Device* p2_adopt(int lead_device, int K, int nw, int n_sets, const uint64_t* set_size, const int* set_device, uint64_t* const* set_ptr,
                    const std::vector<std::pair<int, void*>>& owned, int max_nk);
 int p2_fetch_words(int device, const uint64_t* d_src, uint64_t n_words, uint64_t* dst);

@@ -23,6 +23,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -629,11 +630,41 @@ __global__ void p2_empty_image(uint64_t* nodes, int nw1, uint64_t n_slots) {
         nodes[i] = (i % nw1) ? 0ULL : P2_EMPTY;
 }
 
+// Device memory a caller is done with and offers for reuse (pg_device_scratch_offer): a hipMalloc of tens of gigabytes right
+// behind a hipFree of as much takes seconds on this stack, so pass 1's record pool becomes the k-mer set image instead of being
+// freed and allocated anew.  One block per device; whoever takes it owns it.
+namespace {
+struct Offered { int device; void* ptr; uint64_t bytes; };
+std::vector<Offered> g_offered;
+std::mutex g_offered_mu;
+void* take_offered(int device, uint64_t need) {
+    std::lock_guard<std::mutex> lk(g_offered_mu);
+    for (size_t i = 0; i < g_offered.size(); i++)
+        if (g_offered[i].device == device && g_offered[i].bytes >= need + 256) { void* p = g_offered[i].ptr; g_offered.erase(g_offered.begin() + i); return p; }
+    return nullptr;
+}
+}  // namespace
+extern "C" int pg_device_scratch_offer(int device, void* d_ptr, uint64_t bytes) {
+    if (!d_ptr) return PG_EINVAL;
+    std::lock_guard<std::mutex> lk(g_offered_mu);
+    for (auto& o : g_offered) if (o.device == device) return PG_ESTATE;       // one block per device
+    g_offered.push_back(Offered{device, d_ptr, bytes});
+    return PG_OK;
+}
+extern "C" void* pg_device_scratch_withdraw(int device) {
+    std::lock_guard<std::mutex> lk(g_offered_mu);
+    for (size_t i = 0; i < g_offered.size(); i++)
+        if (g_offered[i].device == device) { void* p = g_offered[i].ptr; g_offered.erase(g_offered.begin() + i); return p; }
+    return nullptr;
+}
+
 // SURVEY.md App. C "K6", one rank's share: the sets this rank owns (n_own of them, set_size slots each, back to back in a
 // fresh allocation on `device`), laid out from the rank's records as they lie there sorted by (set, first ordinal) -- no host
 // replay, no upload (dev_graph.hpp: layout_static).  PG_OK, 1 = unsuited (nothing allocated), or PG_E*.
-int p2_layout_rank(int device, int nw, int n_own, const uint64_t* d_records, const uint64_t* own_counts, uint64_t set_size, uint64_t** d_nodes_out) {
+int p2_layout_rank(int device, int nw, int n_own, const uint64_t* d_records, const uint64_t* own_counts, uint64_t set_size, uint64_t** d_nodes_out,
+                   void** alloc_out) {
     *d_nodes_out = nullptr;
+    if (alloc_out) *alloc_out = nullptr;
     if (n_own < 1) return PG_OK;
     const bool verbose = getenv("PG_HOST_VERBOSE") != nullptr;
     auto now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
@@ -645,7 +676,9 @@ int p2_layout_rank(int device, int nw, int n_own, const uint64_t* d_records, con
     const int NW1 = nw + 1;
     const uint64_t total = (uint64_t)n_own * set_size;
     uint64_t* nodes = nullptr;
-    if (hipMalloc((void**)&nodes, total * NW1 * sizeof(uint64_t)) != hipSuccess) {
+    void* block = take_offered(device, total * NW1 * sizeof(uint64_t));        // memory pass 1 is done with, if it was offered and is large enough
+    if (block) nodes = (uint64_t*)(((uintptr_t)block + 255) & ~(uintptr_t)255);
+    else if (hipMalloc((void**)&nodes, total * NW1 * sizeof(uint64_t)) != hipSuccess) {
         (void)hipStreamDestroy(st);
         pg_set_error("layout: out of device memory for the k-mer sets (" + std::to_string(total * NW1 * 8 >> 20) + " MiB on device " + std::to_string(device) + ")");
         return PG_ENOMEM;
@@ -662,9 +695,11 @@ int p2_layout_rank(int device, int nw, int n_own, const uint64_t* d_records, con
     }
     if (rc == PG_OK && hipStreamSynchronize(st) != hipSuccess) { rc = PG_ENODEV; why = "kernel failure"; }
     (void)hipStreamDestroy(st);
-    if (rc) { (void)hipFree(nodes); if (rc < 0) pg_set_error("layout: " + (why.empty() ? std::string("failed") : why)); return rc; }
-    if (verbose) fprintf(stderr, "K6 on device %d: %d set(s) of %llu slots, allocation %.2fs, layout %.2fs\n", device, n_own, (unsigned long long)set_size, t1 - t0, now() - t1);
+    if (rc) { (void)hipFree(block ? block : (void*)nodes); if (rc < 0) pg_set_error("layout: " + (why.empty() ? std::string("failed") : why)); return rc; }
+    if (verbose) fprintf(stderr, "K6 on device %d: %d set(s) of %llu slots, %s %.2fs, layout %.2fs\n", device, n_own, (unsigned long long)set_size,
+                         block ? "memory taken over from pass 1" : "allocation", t1 - t0, now() - t1);
     *d_nodes_out = nodes;
+    if (alloc_out) *alloc_out = block ? block : (void*)nodes;
     return PG_OK;
 }
 
@@ -687,14 +722,15 @@ P2Device* p2_open_layout(int device, int K, int nw, int n_sets, const uint64_t* 
                          int max_nk, bool* unsuited) {
     *unsuited = false;
     uint64_t* nodes = nullptr;
-    const int rc = p2_layout_rank(device, nw, n_sets, d_records, per_set_count, set_size, &nodes);
+    void* alloc = nullptr;
+    const int rc = p2_layout_rank(device, nw, n_sets, d_records, per_set_count, set_size, &nodes, &alloc);
     if (rc == K6_UNSUITED) { *unsuited = true; return nullptr; }
     if (rc) return nullptr;
     std::vector<uint64_t> sizes(n_sets, set_size);
     std::vector<int> devs(n_sets, device);
     std::vector<uint64_t*> ptrs(n_sets);
     for (int s = 0; s < n_sets; s++) ptrs[s] = nodes + (uint64_t)s * set_size * (nw + 1);
-    return p2_adopt(device, K, nw, n_sets, sizes.data(), devs.data(), ptrs.data(), {{device, (void*)nodes}}, max_nk);
+    return p2_adopt(device, K, nw, n_sets, sizes.data(), devs.data(), ptrs.data(), {{device, alloc}}, max_nk);
 }
 
 // one set's slots, as they are on the device now, into host memory (size * (nw + 1) words)

@@ -2266,6 +2266,7 @@ static int layout_on_ranks(GraphHandle<NW>* h, const ShardedRecords& sr, const u
     const uint64_t S = ref_initial_set_size(a_gb, P, NW == 4);
     const int N = sr.n_ranks;
     std::vector<uint64_t*> nodes(N, nullptr);
+    std::vector<void*> allocs(N, nullptr);
     std::vector<int> rcs(N, PG_OK);
     std::vector<std::string> why(N);
     std::vector<std::thread> pool;
@@ -2273,14 +2274,14 @@ static int layout_on_ranks(GraphHandle<NW>* h, const ShardedRecords& sr, const u
         pool.emplace_back([&, r] {
             std::vector<uint64_t> own;
             for (int s = r; s < P; s += N) own.push_back(per_set_count[s]);
-            rcs[r] = p2_layout_rank(sr.devices[r], NW, (int)own.size(), sr.d_rec[r], own.data(), S, &nodes[r]);
+            rcs[r] = p2_layout_rank(sr.devices[r], NW, (int)own.size(), sr.d_rec[r], own.data(), S, &nodes[r], &allocs[r]);
             if (rcs[r] < 0) why[r] = pg_last_error();
         });
     for (auto& t : pool) t.join();
     int rc = PG_OK;
     for (int r = 0; r < N; r++) if (rcs[r] && rc <= 0) { rc = rcs[r] < 0 ? rcs[r] : (rc ? rc : 1); if (rcs[r] < 0) pg_set_error(why[r]); }
     std::vector<std::pair<int, void*>> owned;
-    for (int r = 0; r < N; r++) if (nodes[r]) owned.emplace_back(sr.devices[r], (void*)nodes[r]);
+    for (int r = 0; r < N; r++) if (nodes[r]) owned.emplace_back(sr.devices[r], allocs[r]);
     if (rc) { for (auto& o : owned) pg_device_free_on(o.first, o.second); return rc; }
     std::vector<uint64_t> sizes(P, S);
     std::vector<int> devs(P);

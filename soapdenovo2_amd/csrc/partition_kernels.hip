@@ -377,7 +377,10 @@ __device__ __forceinline__ unsigned int wave_inclusive_sum(unsigned int x) {
     return x;
 }
 
-template <int NW, int SLOTS, int THREADS, int WIN, bool TIMERS>
+// VT: the occurrences of a window are cut into VT * THREADS equal shares ("virtual lanes"); a wave takes 64 of them at a time
+// from a counter in LDS until none are left.  VT = 1 is the static split (lane l takes share l); with more shares than lanes a
+// wave that finishes early -- shorter probe sequences, fewer lost CAS -- takes the next tile instead of waiting at the barrier.
+template <int NW, int SLOTS, int THREADS, int WIN, bool TIMERS, int VT = 1>
 __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetParams sp, OccConst oc, DevCounters* ctr, int dbg) {
     constexpr int PW = E2Cfg<NW>::PW, RW = PW + 1, KW = E2Cfg<NW>::KW, NWAVE = THREADS / 64, PIECES = RW / 2, N2 = 2 * NW;
     constexpr int RD = 2 * RW;                                            // dwords a record
@@ -393,11 +396,13 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     __shared__ __align__(16) uint32_t rl2[2][RL_WORDS];
     // one scratch area, two lives: the record-dedupe table (DT slots), then the flattening tables
     constexpr int DT = 2 * WIN;                                           // open addressing over the window's records, <= 50 % full
-    constexpr int FL_WORDS = (DT > WIN + 1 + THREADS / 2 ? DT : WIN + 1 + THREADS / 2) + 2;
+    constexpr int VL = VT * THREADS;                                      // virtual lanes
+    constexpr int FL_WORDS = (DT > WIN + 1 + VL / 2 ? DT : WIN + 1 + VL / 2) + 2;
     __shared__ __align__(8) unsigned int fl_raw[FL_WORDS];
     unsigned int* const dtab = fl_raw;                                    // record index + 1 of the slot's first taker, 0 = free
     unsigned int* const noff = fl_raw;                                    // [n_rep + 1] exclusive prefix sum of the representatives' k-mer counts
-    unsigned short* const first_rec = (unsigned short*)(fl_raw + WIN + 1);   // [THREADS] representative in which lane l's share starts
+    unsigned short* const first_rec = (unsigned short*)(fl_raw + WIN + 1);   // [VL] representative in which virtual lane l's share starts
+    __shared__ unsigned int tile_ctr;                                     // next tile of 64 virtual lanes (VT > 1)
     __shared__ unsigned int dcount[WIN];                                  // copies of a representative record in the window
     __shared__ uint32_t crc_tab[4 * 256];                                 // CRC-32 sliced by four (kmer.hpp)
     __shared__ unsigned int hist[256];
@@ -535,7 +540,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
         for (int wv = 0; wv < GW; wv++) { const unsigned int cw = wave_cnt_f[wv]; if (wv < gwave) base += cw; tot += cw; }
         const unsigned int n_rep = tot >> 20;
         tot &= (1u << 20) - 1;
-        const unsigned int share = (tot + THREADS - 1) / THREADS;
+        const unsigned int share = (tot + VL - 1) / VL;
         if (ps.is_rep) {
             uint32_t* me = rl2[nb] + PAD + gtid * RD;
             const uint32_t h0 = me[0];
@@ -551,10 +556,10 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 if ((q + 1) * share <= x) q++;
                 return q + (q * share < x ? 1u : 0u);
             };
-            const unsigned int l0 = div_up(o_lo), l1 = min((unsigned int)THREADS, div_up(o_hi));
+            const unsigned int l0 = div_up(o_lo), l1 = min((unsigned int)VL, div_up(o_hi));
             for (unsigned int l = l0; l < l1; l++) first_rec[l] = (unsigned short)k;
         }
-        if (gtid == 0) { noff[n_rep] = tot; s_tot = tot; }
+        if (gtid == 0) { noff[n_rep] = tot; s_tot = tot; tile_ctr = NWAVE; }
     };
 
     // ---- emit: finalize every stored node and append it to the export array.  The set is a quarter full on average, so
@@ -733,13 +738,17 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 // the partition's next window flies into the other buffer while this one is counted
                 const bool more = w0 + WIN < usable;
                 if (more && !(dbg & 16)) p_stage_async(b ^ 1, cl, w0 + WIN, min((uint32_t)WIN, usable - w0 - WIN));
-                const uint32_t total_occ = s_tot, share = (total_occ + THREADS - 1) / THREADS;
+                const uint32_t total_occ = s_tot, share = (total_occ + VL - 1) / VL;
                 const uint32_t* const rl = rl2[b];
                 if (!__hip_atomic_load(&aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                    uint32_t idx = min(total_occ, threadIdx.x * share);
+                  // (VT > 1) tiles of 64 virtual lanes: the wave's first one is its own number, the next ones come off the counter
+                  for (uint32_t tile = (uint32_t)wave;;) {
+                    const uint32_t vlane = VT == 1 ? threadIdx.x : tile * 64u + (uint32_t)lane;
+                    if (VT > 1 && tile * 64u * share >= total_occ) break;
+                    uint32_t idx = min(total_occ, vlane * share);
                     const uint32_t idx1 = min(total_occ, idx + share);
                     if (idx < idx1) {
-                        uint32_t k = first_rec[threadIdx.x];
+                        uint32_t k = first_rec[vlane];
                         uint32_t nk = noff[k], nk1 = noff[k + 1];              // idx lies inside representative k
                         for (; idx < idx1; idx++) {
                             const uint32_t o_lo = nk & 0xFFFFu, o_hi = nk1 & 0xFFFFu;
@@ -773,6 +782,11 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                             }
                         }
                     }
+                    if (VT == 1) break;
+                    unsigned int nt = 0;
+                    if (lane == 0) nt = atomicAdd(&tile_ctr, 1u);
+                    tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)nt);
+                  }
                 }
                 K2_TICK(4);
                 // the next partition's chunk list, for the prepare that runs beside this partition's last emit
@@ -1218,7 +1232,8 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     unsigned per_cu = 2;                                                            // persistent workgroups: two per CU measured best (1 .. 32 tried; every start of a workgroup builds its tables and wipes the set)
     if (const char* v = getenv("PG_K2_WG_PER_CU")) per_cu = (unsigned)std::max(1, atoi(v));
     const unsigned grid = std::min<unsigned>(parts, (unsigned)n_cu * per_cu);
-    int dbg = 0, cfg = 0;
+    int dbg = 0, cfg = 0, vt = 1;
+    if (const char* v = getenv("PG_K2_VT")) vt = atoi(v);                 // 1 = static shares, 2 / 4 = tiles of virtual lanes taken dynamically
     if (const char* v = getenv("PG_DBG")) dbg = atoi(v);
     if (const char* v = getenv("PG_K2CFG")) cfg = atoi(v);
     // cfg 0: 2048-slot set, 1024 lanes, 512-record windows  -> ~150 KB LDS, one workgroup per CU
@@ -1228,11 +1243,15 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
         // cfg 2: 512-slot set, 256 lanes, 128-record windows -> ~38 KB LDS, four workgroups per CU (meant for 4x the partitions)
         if (c->NW == 2) {
             if (cfg == 0 && (dbg & 2)) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, true>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
+            else if (cfg == 0 && vt == 4) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 4>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
+            else if (cfg == 0 && vt == 2) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 2>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
             else if (cfg == 0) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
             else if (cfg == 1) hipLaunchKernelGGL((skm_count_kernel<2, 1024, 512, 256, false>), dim3(grid), dim3(512), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
             else hipLaunchKernelGGL((skm_count_kernel<2, 512, 256, 128, false>), dim3(grid * 2), dim3(256), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
         } else {
             if (cfg == 0 && (dbg & 2)) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, true>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
+            else if (cfg == 0 && vt == 4) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false, 4>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
+            else if (cfg == 0 && vt == 2) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false, 2>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
             else if (cfg == 0) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
             else if (cfg == 1) hipLaunchKernelGGL((skm_count_kernel<4, 512, 512, 256, false>), dim3(grid), dim3(512), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
             else hipLaunchKernelGGL((skm_count_kernel<4, 256, 256, 128, false>), dim3(grid * 2), dim3(256), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
