@@ -221,9 +221,10 @@ def main():
     engine = args.engine
     mer127 = args.mer127 or K > 63
     kc = api.KmerCounter(K, n_sets=P, mer127=mer127, log2_slots=log2_slots, device=local, engine=engine)
-    if world > 1 and engine == 2:
-        # the partition count follows the whole job: a partition holds what ALL ranks send to it (every rank must cut with the
-        # same geometry); the export array (log2_slots) follows this rank's share
+    if engine == 2:
+        # the input size is known up front, as call_pregraph knows it from the file sizes: the partition count and the record
+        # pool follow it.  N > 1: it follows the whole job -- a partition holds what ALL ranks send to it (every rank must cut
+        # with the same geometry); the export array (log2_slots) follows this rank's share
         api._check(api.lib().pg_expect_kmers(kc.h, n_kmers * world), "pg_expect_kmers")
     kc.set_autogrow(False)
     wpr = (L + 31) // 32

@@ -273,19 +273,34 @@ int tip_scan(BE& be, const SetsView& view, const SetsGeo& geo, int cut_len, bool
     const uint64_t n_slots = geo.n_slots();
     unsigned long long* counters = be.template alloc<unsigned long long>(12);
     be.fill(counters, 12, 0ULL);
-    // ---- S0's dead ends
-    for_each_slot<BE, NW>(be, geo, [=] PG_LAMBDA(uint64_t* nd, uint64_t) {
-        if (nd[0] == SV_EMPTY) return;
-        const uint64_t ab = nd[NW];
-        if (ab_startable(ab, thin) && ab_dead_end(ab)) hd_atomic_add(&counters[0], 1ULL);
-    });
+    // ---- S0's dead ends: one scan over the sets lists them (room for one slot in eight, a second scan with the exact room
+    //      should that ever be short)
     unsigned long long h_cnt[12];
-    be.to_host(h_cnt, counters, 12);
-    if (be.error) { be.release(counters); return be.error; }
+    uint64_t list_cap = n_slots / 8 + 65536;
+    unsigned long long* cand_list = nullptr;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        cand_list = be.template alloc<unsigned long long>(list_cap);
+        be.fill(counters, 12, 0ULL);
+        const uint64_t cap_now = list_cap;
+        unsigned long long* const list_now = cand_list;
+        for_each_slot<BE, NW>(be, geo, [=] PG_LAMBDA(uint64_t* nd, uint64_t g) {
+            if (nd[0] == SV_EMPTY) return;
+            const uint64_t ab = nd[NW];
+            if (!(ab_startable(ab, thin) && ab_dead_end(ab))) return;
+            const unsigned long long i = hd_atomic_add(&counters[0], 1ULL);
+            if (i < cap_now) list_now[i] = g;
+        });
+        be.to_host(h_cnt, counters, 12);
+        if (be.error) { be.release(cand_list); be.release(counters); return be.error; }
+        if (h_cnt[0] <= list_cap) break;
+        be.release(cand_list);
+        cand_list = nullptr;
+        list_cap = h_cnt[0];
+    }
     const uint64_t n_init = h_cnt[0];
-    if (!n_init) { be.release(counters); return PG_OK; }
+    if (!n_init || !cand_list) { be.release(cand_list); be.release(counters); return n_init ? PG_ENOMEM : PG_OK; }
     const uint64_t cap = n_init + n_init / 4 + 65536;
-    if (cap >= 0xFFFFFFFFULL) { be.release(counters); be.error_text = "tips: more than 2^32 dead ends"; return PG_EINVAL; }
+    if (cap >= 0xFFFFFFFFULL) { be.release(cand_list); be.release(counters); be.error_text = "tips: more than 2^32 dead ends"; return PG_EINVAL; }
     TipState t;
     t.view = view; t.cut_len = cut_len; t.thin = thin ? 1 : 0;
     int bits = 1;
@@ -326,25 +341,27 @@ int tip_scan(BE& be, const SetsView& view, const SetsGeo& geo, int cut_len, bool
         be.release(t.c_slot); be.release(t.c_ab); be.release(t.c_started); be.release(t.c_prev); be.release(t.c_far); be.release(t.c_flags);
         be.release(t.c_dir); be.release(t.c_first); be.release(t.c_action); be.release(t.cmap.key); be.release(t.cmap.val);
         be.release(t.bl.key); be.release(t.bl.val); be.release(t.bl_ab); be.release(k1); be.release(k2); be.release(v1); be.release(v2);
-        be.release(spawn); be.release(counters);
+        be.release(spawn); be.release(counters); be.release(cand_list);
     };
     if (be.error) { cleanup(); return be.error; }
     be.fill(t.cmap.key, map_cap, 0ULL);
     be.fill(t.bl.key, 2 * bl_cap, 0ULL);
     be.fill(counters, 12, 0ULL);
-    {   // the candidate list (any order: the arrivals are sorted by time below) and its index
+    {   // the candidates (any order: the arrivals are sorted by time below) and their index
         const TipState tt = t;
-        for_each_slot<BE, NW>(be, geo, [=] PG_LAMBDA(uint64_t* nd, uint64_t g) {
-            if (nd[0] == SV_EMPTY) return;
-            const uint64_t ab = nd[NW];
-            if (!(ab_startable(ab, tt.thin != 0) && ab_dead_end(ab))) return;
-            const unsigned long long i = hd_atomic_add(&tt.counters[0], 1ULL);
+        const unsigned long long* const list_now = cand_list;
+        be.launch(n_init, [=] PG_LAMBDA(uint64_t i) {
+            const uint64_t g = list_now[i], ab = sv_node<NW>(tt.view, g)[NW];
             tt.c_slot[i] = g; tt.c_ab[i] = ab; tt.c_started[i] = 1u; tt.c_prev[i] = ab; tt.c_flags[i] = 0; tt.c_action[i] = 0; tt.c_far[i] = TIP_NONE;
             bool created;
             const uint64_t h = slotmap_claim(tt.cmap, g, created);
             tt.cmap.val[h] = i;
         });
+        be.fill(counters, 12, 0ULL);
     }
+    be.sync();
+    be.release(cand_list);
+    cand_list = nullptr;
     bool any_bl = false;
     unsigned long long bl_digest_prev = 0;
     for (int round = 0;; round++) {

@@ -413,6 +413,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     __shared__ unsigned long long out_base;
     for (int i = threadIdx.x; i < 1024; i += THREADS) crc_tab[i] = crc32_slice_entry(i >> 8, i & 255);
     for (int i = threadIdx.x; i < 256; i += THREADS) hist[i] = 0;
+    if (threadIdx.x == 0) tile_ctr = NWAVE;
     if (threadIdx.x < 2 * PAD) rl2[threadIdx.x / PAD][threadIdx.x % PAD] = 0;
     if (threadIdx.x < 16) rl2[threadIdx.x >> 3][PAD + WIN * RD + (threadIdx.x & 7)] = 0;
     const int K = e.g.K;
@@ -744,7 +745,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                   // (VT > 1) tiles of 64 virtual lanes: the wave's first one is its own number, the next ones come off the counter
                   for (uint32_t tile = (uint32_t)wave;;) {
                     const uint32_t vlane = VT == 1 ? threadIdx.x : tile * 64u + (uint32_t)lane;
-                    if (VT > 1 && tile * 64u * share >= total_occ) break;
+                    if (VT > 1 && (tile * 64u * share >= total_occ || __hip_atomic_load(&aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) break;
                     uint32_t idx = min(total_occ, vlane * share);
                     const uint32_t idx1 = min(total_occ, idx + share);
                     if (idx < idx1) {
@@ -792,6 +793,9 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 // the next partition's chunk list, for the prepare that runs beside this partition's last emit
                 if (threadIdx.x < nchunks) chunk_ids2[cl ^ 1][threadIdx.x] = pf_cid;
                 K2_SYNC();                                                  // the window and its tables are rewritten by the next one
+                // (every wave is past the tile loop: the counter starts over for the next occurrence phase -- the next window,
+                //  or the same window again for another key range -- which is at least one barrier away)
+                if (VT > 1 && threadIdx.x == 0) tile_ctr = NWAVE;
                 if (w0 + WIN < usable) {                                    // more windows add to these counters: keep the halves small
                     for (int i = threadIdx.x; i < SLOTS; i += THREADS) {    // (they saturate at 63 / 255 in the end anyway)
 #pragma unroll
@@ -934,10 +938,16 @@ int e2_create(pg_ctx* c) {
     // PG_DIRECT_CHUNKS=M: the first M chunks of every partition at computed addresses (M * parts chunks set aside up front);
     // -1 = about 1.25x the mean partition when the input size is known
     s.direct = 0;
-    if (const char* v = getenv("PG_DIRECT_CHUNKS")) {
-        int q = atoi(v);
-        if (q < 0 && c->hint_kmers) q = (int)(((double)c->hint_kmers * 2.0 / (double)(s.g.w + 1) / (double)parts * 1.25 + (double)s.rpc - 1) / (double)s.rpc);
-        s.direct = (uint32_t)std::max(0, std::min(q, 192));
+    {
+        // default: with the input size known, room for 1.25x the mean partition at computed addresses (at most eight chunks a
+        // partition and a quarter of the device memory); PG_DIRECT_CHUNKS=M sets it, 0 switches it off
+        int q = c->hint_kmers ? (int)(((double)c->hint_kmers * 2.0 / (double)(s.g.w + 1) / (double)parts * 1.25 + (double)s.rpc - 1) / (double)s.rpc) : 0;
+        q = std::min(q, 8);
+        if (const char* v = getenv("PG_DIRECT_CHUNKS")) { const int e = atoi(v); if (e >= 0) q = std::min(e, 192); }
+        size_t free_b0 = 0, total_b0 = 0;
+        if (hipMemGetInfo(&free_b0, &total_b0) == hipSuccess)
+            while (q > 0 && (uint64_t)q * parts * chunk_bytes > total_b0 / 4) q--;
+        s.direct = (uint32_t)std::max(0, q);
     }
     size_t free_b = 0, total_b = 0;
     E2_TRY(hipMemGetInfo(&free_b, &total_b));
@@ -948,7 +958,7 @@ int e2_create(pg_ctx* c) {
     // 20 k-mers); default = as much as a set of 2^log2_slots 64-byte slots, capped by what is free
     uint64_t pool_bytes = ((uint64_t)1 << c->log2_slots) * 64 + parts * chunk_bytes * 2;
     if (c->hint_kmers)                       // known input size: 2 / (w + 1) records a k-mer, half as much again, it grows
-        pool_bytes = (uint64_t)((double)c->hint_kmers * 3.0 / (double)(s.g.w + 1)) * rec_bytes + parts * chunk_bytes * 2 + ((uint64_t)64 << 20);
+        pool_bytes = (uint64_t)((double)c->hint_kmers * (s.direct ? 1.5 : 3.0) / (double)(s.g.w + 1)) * rec_bytes + parts * chunk_bytes * 2 + ((uint64_t)64 << 20);
     if (const char* v = getenv("PG_POOL_MB")) pool_bytes = (uint64_t)atoll(v) << 20;
     const uint64_t budget = (uint64_t)(free_b * 0.85);
     if (out_bytes + parts * 8 > budget) { pg_set_error("partition engine: export array does not fit in device memory"); return PG_ENOMEM; }

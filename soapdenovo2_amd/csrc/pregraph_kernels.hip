@@ -550,7 +550,7 @@ extern "C" int pg_expect_kmers(pg_ctx* c, uint64_t total_kmers) {
     if (c->engine != 2) return PG_OK;
     if (c->batches) { g_err = "pg_expect_kmers: batches were already counted"; return PG_ESTATE; }
     const int lp = parts_for_kmers(total_kmers, c->NW);
-    if (lp == c->e2.log2_parts) return PG_OK;
+    if (lp == c->e2.log2_parts && c->hint_kmers == total_kmers) return PG_OK;
     HIP_TRY(hipSetDevice(c->device));
     const int old = c->hint_log2_parts;
     const uint64_t old_kmers = c->hint_kmers;
