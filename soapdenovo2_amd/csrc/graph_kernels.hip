@@ -519,6 +519,8 @@ struct P2Device {
     uint64_t n_slots = 0;
     bool reads_ready = false;
     hipStream_t stream = nullptr;
+    unsigned long long* d_vlist = nullptr;           // the vertices' global slots as p2_list_vertices left them (the edge builder starts from the same list)
+    uint64_t n_vlist = 0;
 };
 
 static void p2_free(P2Device* d) {
@@ -529,7 +531,7 @@ static void p2_free(P2Device* d) {
     hipFree(d->d_arc_key); hipFree(d->d_arc_cnt); hipFree(d->d_arc_first);
     hipFree(d->d_counters); hipFree(d->d_marker);
     hipFree(d->d_words); hipFree(d->d_off); hipFree(d->d_lens); hipFree(d->d_stage); hipFree(d->d_walk_len);
-    hipFree(d->d_geo3); hipFree(d->d_crc);
+    hipFree(d->d_geo3); hipFree(d->d_crc); hipFree(d->d_vlist);
     if (d->stream) hipStreamDestroy(d->stream);
     delete d;
 }
@@ -974,6 +976,9 @@ int p2_list_vertices(P2Device* d, std::vector<uint64_t>& keys) {
         keys.resize((size_t)n * d->nw);
         P2_HIP_GOTO(hipMemcpyAsync(keys.data(), d_keys, keys.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         P2_HIP_GOTO(hipStreamSynchronize(st));
+        hipFree(d->d_vlist);
+        d->d_vlist = d_sorted; d->n_vlist = n;                     // the edges are built from these very nodes: no second scan of the sets
+        d_sorted = nullptr;
     }
 done:
     hipFree(d_list); hipFree(d_sorted); hipFree(d_cnt); hipFree(d_keys); hipFree(d_tmp);
@@ -999,12 +1004,17 @@ int p2_build_edges(P2Device* d, P2Edges& out) {
     if (hipSetDevice(d->device) != hipSuccess) { pg_set_error("edges: hipSetDevice failed"); return PG_ENODEV; }
     P2_HIP_GOTO(hipMalloc((void**)&d_cnt, 4 * sizeof(unsigned long long)));
     P2_HIP_GOTO(hipMemsetAsync(d_cnt, 0, 4 * sizeof(unsigned long long), st));
-    P2_HIP_GOTO(hipMalloc((void**)&d_list, std::max<uint64_t>(d->n_slots, 1) * sizeof(unsigned long long)));
-    for (int si = 0; si < d->P; si++)
-        if (d->set_sizes[si]) hipLaunchKernelGGL(eb_list_branch, dim3(4096), dim3(256), 0, st, d->set_ptr[si], NW1, d->set_sizes[si], d->set_first[si], d_list, d_cnt);
-    P2_HIP_GOTO(hipMemcpyAsync(cnt, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-    P2_HIP_GOTO(hipStreamSynchronize(st));
-    n_list = cnt[0];
+    if (d->d_vlist) {                                            // listed for <prefix>.vertex a moment ago (nothing changed a flag since)
+        d_list = d->d_vlist; d->d_vlist = nullptr;
+        n_list = d->n_vlist;
+    } else {
+        P2_HIP_GOTO(hipMalloc((void**)&d_list, std::max<uint64_t>(d->n_slots, 1) * sizeof(unsigned long long)));
+        for (int si = 0; si < d->P; si++)
+            if (d->set_sizes[si]) hipLaunchKernelGGL(eb_list_branch, dim3(4096), dim3(256), 0, st, d->set_ptr[si], NW1, d->set_sizes[si], d->set_first[si], d_list, d_cnt);
+        P2_HIP_GOTO(hipMemcpyAsync(cnt, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
+        P2_HIP_GOTO(hipStreamSynchronize(st));
+        n_list = cnt[0];
+    }
     // a vertex has at most eight arcs and every chain is kept from one of its two ends (palindromes aside, which are few):
     // room for five walks a vertex, and a second go with room for all eight should that ever be short
     if (n_list * 8 / 256 >= 0x7FFFFFFFULL) { pg_set_error("edges: too many vertices for one launch"); rc = PG_EINVAL; goto done; }

@@ -1242,8 +1242,8 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     unsigned per_cu = 2;                                                            // persistent workgroups: two per CU measured best (1 .. 32 tried; every start of a workgroup builds its tables and wipes the set)
     if (const char* v = getenv("PG_K2_WG_PER_CU")) per_cu = (unsigned)std::max(1, atoi(v));
     const unsigned grid = std::min<unsigned>(parts, (unsigned)n_cu * per_cu);
-    int dbg = 0, cfg = 0, vt = 1;
-    if (const char* v = getenv("PG_K2_VT")) vt = atoi(v);                 // 1 = static shares, 2 / 4 = tiles of virtual lanes taken dynamically
+    int dbg = 0, cfg = 0, vt = 4;                                         // tiles of virtual lanes taken dynamically: K2 177.8 -> 168.7 ms at K = 63, 269 -> 232 ms at K = 127 (profiles/r03h_*)
+    if (const char* v = getenv("PG_K2_VT")) vt = atoi(v);                 // 1 = static shares (round 2), 2 / 4 = tiles
     if (const char* v = getenv("PG_DBG")) dbg = atoi(v);
     if (const char* v = getenv("PG_K2CFG")) cfg = atoi(v);
     // cfg 0: 2048-slot set, 1024 lanes, 512-record windows  -> ~150 KB LDS, one workgroup per CU
