@@ -398,6 +398,13 @@ int pg_count_reads_sharded(pg_ctx *ctx, pg_comm *comm, const uint64_t *d_packed,
 int pg_host_emu_layout_static(const uint64_t *records, const uint64_t *per_set_count, int n_sets, uint64_t set_size, int mer127,
                               int n_threads, uint64_t *nodes_out);
 
+/* layout of growable (-a 0) k-mer sets as the device computes it (csrc/dev_rehash.hpp: encap_kmerset's in-place rehash as a fixed
+ * point over insertion times, newhash.c:340-528): records sorted by (set, ordinal); out_slot[i] = slot of record i in its set,
+ * out_set_size[s] = final size, out_rounds[s] = fixed-point rounds; out_nodes (optional, nodes_cap_slots slots of 3 / 5 words): the
+ * sets' image back to back, word 0 of an empty slot all ones.  To be compared with pg_host_replay_layout. */
+int pg_host_emu_layout_growable(const uint64_t *records, uint64_t n_records, const uint64_t *set_last_put, int mer127, int n_sets,
+                                int n_threads, uint64_t *out_slot, uint64_t *out_set_size, uint64_t *out_rounds, uint64_t *out_nodes,
+                                uint64_t nodes_cap_slots);
 /* tip clipping (removeSingleTips / removeMinorTips, cutTipPreGraph.c:363-488) as the device decides it (csrc/dev_tips.hpp: a
  * fixed point over start decisions, one lane per stop node) next to the sequential host scan, on two copies of the layout
  * replayed from `records`: out[0], out[1] = tips the sequential scan removed (single, minor); out[2], out[3] = the same from

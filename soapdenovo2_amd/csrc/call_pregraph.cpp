@@ -788,10 +788,10 @@ int run(int argc, char** argv, bool mer127) {
         }
     }
     if (ctx) pg_destroy(ctx);
-    // pass 1's record pool: with -a the k-mer sets are laid out inside it (no allocation of that size behind a free of that
-    // size: seconds); otherwise it goes now -- the host replay gives the driver the time
+    // pass 1's record pool: the k-mer sets are laid out inside it (no allocation of that size behind a free of that size:
+    // seconds); when the records go to the host it goes now -- the host replay gives the driver the time
     bool ws_offered = false;
-    if (d_ws && o.a_gb != 0 && stream_records && pg_device_scratch_offer(device, d_ws, ws_bytes) == PG_OK) ws_offered = true;
+    if (d_ws && stream_records && pg_device_scratch_offer(device, d_ws, ws_bytes) == PG_OK) ws_offered = true;
     else if (d_ws) { (void)hipFree(d_ws); d_ws = nullptr; }
     lap("export + download records");
 

@@ -1,0 +1,319 @@
+// dev_rehash.hpp -- the layout of a GROWABLE k-mer set (-a 0) on the device: put_kmerset with encap_kmerset's in-place
+// rehash (newhash.c:340-528), the slot every k-mer ends up in.  Written over a Backend (backend.hpp), like dev_graph.hpp.
+//
+// A growable set lives through a handful of sizes (ref_sizes.hpp: grow_schedule).  At one size it is first-come-first-served
+// linear probing -- dev_graph.hpp shows that this is one sweep per probe cluster in which a slot takes the earliest-arrived
+// pending key -- and the only question is what "arrived" means for the keys that were already there when the set grew:
+//
+//   encap_kmerset walks the OLD slots in index order; the element of slot i, if it has not moved yet, is taken out and
+//   inserted at (key mod new size), probing over slots that hold already-MOVED elements only; if it comes to rest on a slot
+//   whose old element has not moved yet, it takes the slot and that element is inserted next, and so on (newhash.c:403-452).
+//
+// So every element has an insertion TIME (origin slot of its chain, depth in the chain): (j, 0) for the element of old slot j
+// if the walk finds it in place, (i, d + 1) if the element that was inserted at time (i, d) came to rest on slot j first.  The
+// keys that arrive after the growth come later than all of them, in arrival order.  With the times known the new layout is the
+// same sweep as for a static pool.  The times depend on the layout (who rests on slot j?) and the layout on the times -- but
+// only forwards: an element can only be kicked by one that was inserted EARLIER.  Hence a fixed point from above: start with
+// T(e_j) = (j, 0), sweep, look at every old slot j -- if its new occupant y is another element with T(y) < (j, 0), then e_j was
+// kicked: T(e_j) = T(y) + one level -- and sweep again the probe clusters that hold an element whose time changed, until none
+// does.  Why it ends at the reference's layout: (1) no time is ever EARLIER than the true one -- a slot of a
+// first-come-first-served table fills no earlier when every key arrives no earlier, so the occupant of slot j in a round comes no
+// earlier than the true one, and an element that truly stays in place is never taken for kicked; (2) by (1) the elements with the
+// k earliest true times, once they carry them, make the first k steps of a round's sweep the true ones, so the (k+1)-th finds its
+// true kicker (or nobody) on its slot and has its true time from the next round on.  Both need a round's times to be read as a
+// whole (two arrays, swapped) -- updated in place, an element can get a time derived from one that has changed since.  Chains are
+// a dozen levels deep (a fifth of the moves are kicks), a set settles in 5 - 10 rounds a size, and a round after the first touches
+// a fraction of the clusters.
+// Which slots are occupied, the clusters and the wrap-around frame depend on the homes alone and are computed once per size.
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+#include "backend.hpp"
+#include "graph_lookup.hpp"
+#include "ref_sizes.hpp"
+#include "../../include/soapdenovo2_amd.h"
+
+namespace pg {
+
+constexpr int RH_DEPTH_BITS = 22;                  // time = origin << 22 | depth
+constexpr uint32_t RH_NONE = 0xFFFFFFFFu;
+
+// one probe cluster: the slots of frame [hs[j], ...) take the pending element with the smallest time
+struct RhSweep {
+    const uint64_t* hs;                 // homes in the frame, sorted
+    const uint32_t* is;                 // elements in the same order
+    const long long* m;                 // prefix maximum of hs[j] - j
+    const unsigned long long* T;        // time of every element
+    unsigned int* dirty;                // per sorted position: sweep the cluster that starts here
+    unsigned long long* heap_t;
+    uint32_t* heap_e;
+    unsigned long long* slot_new;       // table slot of every element
+    uint32_t* owner;                    // element resting on table slot j, for j < n_owner (RH_NONE: nobody)
+    uint64_t n, S, origin, n_owner;
+    PG_HD void operator()(uint64_t j) const {
+        if (j && m[j] <= m[j - 1]) return;                          // not the first key of a cluster
+        if (!dirty[j]) return;
+        dirty[j] = 0;
+        unsigned long long* ht = heap_t + j;
+        uint32_t* he = heap_e + j;
+        uint64_t hn = 0, nxt = j, p = hs[j];
+        for (;;) {
+            while (nxt < n && hs[nxt] <= p) {
+                const uint32_t e = is[nxt++];
+                const unsigned long long t = T[e];
+                uint64_t c = hn++;
+                while (c) { const uint64_t par = (c - 1) >> 1; if (ht[par] <= t) break; ht[c] = ht[par]; he[c] = he[par]; c = par; }
+                ht[c] = t; he[c] = e;
+            }
+            if (!hn) return;
+            const uint32_t first = he[0];
+            hn--;
+            const unsigned long long lt = ht[hn];
+            const uint32_t le = he[hn];
+            if (hn) {
+                uint64_t c = 0;
+                for (;;) {
+                    uint64_t ch = 2 * c + 1;
+                    if (ch >= hn) break;
+                    if (ch + 1 < hn && ht[ch + 1] < ht[ch]) ch++;
+                    if (ht[ch] >= lt) break;
+                    ht[c] = ht[ch]; he[c] = he[ch]; c = ch;
+                }
+                ht[c] = lt; he[c] = le;
+            }
+            uint64_t slot = p + origin;
+            if (slot >= S) slot -= S;
+            slot_new[first] = slot;
+            if (slot < n_owner) owner[slot] = first;
+            p++;
+        }
+    }
+};
+
+// scratch for one set at a time, sized for the largest
+template <class BE>
+struct RhWork {
+    uint64_t *hk = nullptr, *hs = nullptr, *hr = nullptr;
+    uint32_t *iv = nullptr, *is = nullptr, *ir = nullptr, *pos_of = nullptr, *heap_e = nullptr, *owner = nullptr;
+    long long *v = nullptr, *m = nullptr, *cs = nullptr;
+    unsigned long long *T = nullptr, *T2 = nullptr, *heap_t = nullptr, *slot_prev = nullptr, *scal = nullptr;
+    unsigned int* dirty = nullptr;
+    uint64_t cap = 0, owner_cap = 0;
+    bool reserve(BE& be, uint64_t n, uint64_t n_owner) {
+        n = std::max<uint64_t>(n, 1);
+        cap = n; owner_cap = std::max<uint64_t>(n_owner, 1);
+        hk = be.template alloc<uint64_t>(n); hs = be.template alloc<uint64_t>(n); hr = be.template alloc<uint64_t>(n);
+        iv = be.template alloc<uint32_t>(n); is = be.template alloc<uint32_t>(n); ir = be.template alloc<uint32_t>(n);
+        v = be.template alloc<long long>(n); m = be.template alloc<long long>(n);
+        cs = be.template alloc<long long>(n);                          // cluster start (sorted position) of every sorted position
+        pos_of = be.template alloc<uint32_t>(n);                       // sorted position of every element
+        T = be.template alloc<unsigned long long>(n); T2 = be.template alloc<unsigned long long>(n);
+        dirty = be.template alloc<unsigned int>(n);
+        heap_t = be.template alloc<unsigned long long>(n); heap_e = be.template alloc<uint32_t>(n);
+        slot_prev = be.template alloc<unsigned long long>(n);
+        owner = be.template alloc<uint32_t>(owner_cap);
+        scal = be.template alloc<unsigned long long>(4);
+        return !be.error;
+    }
+    void release(BE& be) {
+        be.release(hk); be.release(hs); be.release(hr); be.release(iv); be.release(is); be.release(ir); be.release(v); be.release(m); be.release(cs);
+        be.release(pos_of); be.release(T); be.release(T2); be.release(dirty); be.release(heap_t); be.release(heap_e); be.release(slot_prev); be.release(owner); be.release(scal);
+        *this = RhWork();
+    }
+    // bytes a key / an old slot (for the caller's memory planning)
+    static constexpr uint64_t bytes_per_key = 8 * 3 + 4 * 3 + 8 * 3 + 4 + 8 * 2 + 4 + 8 + 4 + 8;
+};
+// the largest old size a schedule's growths walk over
+inline uint64_t grow_owner_slots(const std::vector<GrowEpoch>& sched) {
+    uint64_t c = 0;
+    for (size_t e = 1; e < sched.size(); e++) c = std::max(c, sched[e - 1].size);
+    return c;
+}
+
+// the slots of a growable set's n keys (arrival order = record order) after put_kmerset's whole history (sched: grow_schedule
+// of the set).  slots_out: backend memory, n entries.  *rounds_out += fixed-point rounds.  wk: reserved for >= n keys and the
+// schedule's grow_owner_slots.
+template <class BE, int NW>
+int layout_growable(BE& be, RhWork<BE>& wk, const uint64_t* rec, uint64_t n, const std::vector<GrowEpoch>& sched, unsigned long long* slots_out,
+                    int* rounds_out) {
+    constexpr int RW = NW + 2;
+    if (!n) return PG_OK;
+    if (n >= 0xFFFFFFF0ULL) { be.error_text = "layout_growable: more than 2^32 keys in a set"; return PG_EINVAL; }
+    if (n > wk.cap || grow_owner_slots(sched) > wk.owner_cap) { be.error_text = "layout_growable: scratch too small"; return PG_EINVAL; }
+    uint64_t *hk = wk.hk, *hs = wk.hs, *hr = wk.hr;
+    uint32_t *iv = wk.iv, *is = wk.is, *ir = wk.ir, *pos_of = wk.pos_of, *heap_e = wk.heap_e, *owner = wk.owner;
+    long long *v = wk.v, *m = wk.m, *cs = wk.cs;
+    unsigned long long *T = wk.T, *Tn = wk.T2, *heap_t = wk.heap_t, *slot_prev = wk.slot_prev, *scal = wk.scal;
+    unsigned int* dirty = wk.dirty;
+    unsigned long long* slot_new = slots_out;
+    int rc = PG_OK;
+    for (size_t ei = 0; ei < sched.size() && !be.error && rc == PG_OK; ei++) {
+        const GrowEpoch ep = sched[ei];
+        const uint64_t S = ep.size, M = ep.n_end, n_old = ep.n_old;
+        const uint64_t s_prev = ei ? sched[ei - 1].size : 0;
+        if (!M) continue;
+        if ((s_prev + M) >> (63 - RH_DEPTH_BITS)) { rc = PG_EINVAL; be.error_text = "layout_growable: set too large for the time encoding"; break; }
+        int bits = 1;
+        while (bits < 64 && (S >> bits)) bits++;
+        // ---- homes at this size, sorted; occupied slots, clusters, the frame in which nothing wraps
+        be.launch(M, [=] PG_LAMBDA(uint64_t i) {
+            Kmer<NW> k;
+#pragma unroll
+            for (int w = 0; w < NW; w++) k.w[w] = rec[i * RW + w];
+            hk[i] = home_slot<NW>(k, S);
+            iv[i] = (uint32_t)i;
+        });
+        be.sort_pairs(hk, hs, iv, is, M, bits);
+        be.launch(M, [=] PG_LAMBDA(uint64_t j) { v[j] = (long long)hs[j] - (long long)j; });
+        be.inclusive_max(v, m, M);
+        long long m_last = 0;
+        be.to_host(&m_last, m + (M - 1), 1);
+        if (be.error) break;
+        const uint64_t q_last = (uint64_t)((long long)(M - 1) + m_last);
+        const uint64_t* hs_use = hs;
+        const uint32_t* is_use = is;
+        uint64_t origin = 0;
+        if (q_last >= S) {                                           // the last cluster wraps (dev_graph.hpp, step 3)
+            const uint64_t W = q_last - (S - 1);
+            be.launch(1, [=] PG_LAMBDA(uint64_t) {
+                uint64_t seen = 0, prev_end = 0, e = 0;
+                bool found = false;
+                for (uint64_t j = 0; j < M && !found; j++) {
+                    const uint64_t q = (uint64_t)((long long)j + m[j]);
+                    if (q >= S) break;
+                    const uint64_t gap = q - prev_end;
+                    if (seen + gap >= W + 1) { e = prev_end + (W + 1 - seen) - 1; found = true; }
+                    seen += gap;
+                    prev_end = q + 1;
+                }
+                if (!found) e = prev_end + (W + 1 - seen) - 1;
+                const uint64_t o = e + 1 == S ? 0 : e + 1;
+                uint64_t lo = 0, hi = M;
+                while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (hs[mid] >= o) hi = mid; else lo = mid + 1; }
+                scal[0] = o; scal[1] = lo;
+            });
+            unsigned long long orot[2] = {0, 0};
+            be.to_host(orot, scal, 2);
+            if (be.error) break;
+            origin = orot[0];
+            const uint64_t r = orot[1] % M, o = origin;
+            be.launch(M, [=] PG_LAMBDA(uint64_t j) {
+                const uint64_t src = j + r >= M ? j + r - M : j + r;
+                const uint64_t h = hs[src];
+                hr[j] = h >= o ? h - o : h + S - o;
+                ir[j] = is[src];
+                v[j] = (long long)hr[j] - (long long)j;
+            });
+            be.inclusive_max(v, m, M);
+            be.to_host(&m_last, m + (M - 1), 1);
+            if (be.error) break;
+            if ((uint64_t)((long long)(M - 1) + m_last) >= S) { rc = PG_EINVAL; be.error_text = "layout_growable: the rotated frame still wraps"; break; }
+            hs_use = hr; is_use = ir;
+        }
+        // ---- where every element sits in the sorted order, and the cluster it belongs to; times; everything to be swept
+        {
+            const uint32_t* isu = is_use;
+            const long long* mm = m;
+            be.launch(M, [=] PG_LAMBDA(uint64_t j) {
+                pos_of[isu[j]] = (uint32_t)j;
+                v[j] = (j == 0 || mm[j] > mm[j - 1]) ? (long long)j : 0;
+                dirty[j] = 1u;
+            });
+            be.inclusive_max(v, cs, M);
+            const unsigned long long* sp = slot_prev;
+            be.launch(M, [=] PG_LAMBDA(uint64_t i) {
+                T[i] = Tn[i] = (i < n_old ? sp[i] : (unsigned long long)(s_prev + (i - n_old))) << RH_DEPTH_BITS;
+            });
+            if (n_old) be.fill(owner, (size_t)s_prev, RH_NONE);
+        }
+        // ---- the fixed point
+        for (int round = 0;; round++) {
+            if (round > 10000) { rc = PG_EINVAL; be.error_text = "layout_growable: the fixed point did not settle"; break; }
+            if (rounds_out) (*rounds_out)++;
+            be.launch(M, RhSweep{hs_use, is_use, m, T, dirty, heap_t, heap_e, slot_new, owner, M, S, origin, n_old ? s_prev : 0});
+            if (!n_old) break;                                        // nobody was there before: arrival order is all there is
+            be.fill(scal, 1, 0ULL);
+            {
+                // every old element's time from the layout just made.  Jacobi: this round's times are read, the next round's
+                // written -- with times read while they change an element could come out EARLIER than it truly is, and the
+                // argument above (times never fall below the true ones) would not hold
+                const unsigned long long* sp = slot_prev;
+                const unsigned long long* Tc = T;
+                unsigned long long* Tw = Tn;
+                const long long* csp = cs;
+                be.launch(n_old, [=] PG_LAMBDA(uint64_t i) {
+                    const unsigned long long j = sp[i];
+                    const unsigned long long natural = j << RH_DEPTH_BITS;
+                    const uint32_t y = owner[j];
+                    unsigned long long t = natural;
+                    if (y != RH_NONE && y != (uint32_t)i) {
+                        const unsigned long long ty = Tc[y];
+                        if (ty < natural) t = ty + 1;                  // y came to rest on slot j before the walk reached it: e_j went next
+                    }
+                    Tw[i] = t;
+                    if (t != Tc[i]) {
+                        dirty[csp[pos_of[i]]] = 1u;
+                        hd_atomic_add(&scal[0], 1ULL);
+                    }
+                });
+                unsigned long long* sw = T; T = Tn; Tn = sw;
+            }
+            unsigned long long changed = 0;
+            be.to_host(&changed, scal, 1);
+            if (be.error || !changed) break;
+        }
+        if (ei + 1 < sched.size()) be.copy(slot_prev, slot_new, M);
+    }
+    be.sync();
+    if (be.error) return be.error;
+    return rc;
+}
+
+// P growable sets: records sorted by (set, ordinal) in backend memory; per_set_count, trailing (a duplicate put arrived after
+// the set's last new key), set_first_slot (the set's slot 0 in `nodes`, in slots) on the host.  nodes (optional): the image,
+// every slot's first word preset to SV_EMPTY -- a key's record words 0..NW go to its slot.  slots_all (optional, backend memory,
+// one entry a record): the slot within the set.
+template <class BE, int NW>
+int layout_growable_sets(BE& be, const uint64_t* records, const uint64_t* per_set_count, const unsigned char* trailing, int P, uint64_t init_size,
+                         const uint64_t* set_first_slot, uint64_t* nodes, unsigned long long* slots_all, uint64_t* rounds_out) {
+    constexpr int RW = NW + 2;
+    uint64_t n_max = 0, owner_max = 0;
+    std::vector<std::vector<GrowEpoch>> sched(P);
+    for (int s = 0; s < P; s++) {
+        sched[s] = grow_schedule(per_set_count[s], trailing && trailing[s], init_size);
+        n_max = std::max(n_max, per_set_count[s]);
+        owner_max = std::max(owner_max, grow_owner_slots(sched[s]));
+    }
+    if (!n_max) return PG_OK;
+    RhWork<BE> wk;
+    unsigned long long* slots_tmp = slots_all ? nullptr : be.template alloc<unsigned long long>(n_max);
+    int rc = wk.reserve(be, n_max, owner_max) ? PG_OK : PG_ENOMEM;
+    uint64_t first = 0;
+    for (int s = 0; s < P && rc == PG_OK && !be.error; s++) {
+        const uint64_t n = per_set_count[s];
+        const uint64_t* rec = records + first * RW;
+        unsigned long long* slots = slots_all ? slots_all + first : slots_tmp;
+        first += n;
+        if (!n) continue;
+        int rounds = 0;
+        rc = layout_growable<BE, NW>(be, wk, rec, n, sched[s], slots, &rounds);
+        if (rounds_out) rounds_out[s] = (uint64_t)rounds;
+        if (rc != PG_OK || !nodes) continue;
+        uint64_t* set_nodes = nodes + set_first_slot[s] * (uint64_t)(NW + 1);
+        be.launch(n, [=] PG_LAMBDA(uint64_t i) {
+            const uint64_t* r = rec + i * RW;
+            uint64_t* nd = set_nodes + slots[i] * (uint64_t)(NW + 1);
+#pragma unroll
+            for (int w = 0; w <= NW; w++) nd[w] = r[w];
+        });
+    }
+    be.sync();
+    wk.release(be);
+    be.release(slots_tmp);
+    if (be.error) return be.error;
+    return rc;
+}
+
+}  // namespace pg

@@ -53,6 +53,10 @@ int p2_download_set(P2Device* d, int set, void* dst);
 // (set s: set_size[s] slots at set_ptr[s] on set_device[s]; the allocations in `owned` change hands)
 int p2_layout_rank(int device, int nw, int n_own, const uint64_t* d_records, const uint64_t* own_counts, uint64_t set_size, uint64_t** d_nodes_out,
                    void** alloc_out = nullptr);      // *alloc_out = what to hipFree in the end (the image may sit inside a block taken over)
+// growable (-a 0) sets: set i of the rank ends with sizes_out[i] slots (the reference's growth schedule), the sets lie back to
+// back; own_trailing[i]: a duplicate put arrived after the set's last new key (it still runs the growth test)
+int p2_layout_rank_growable(int device, int nw, int n_own, const uint64_t* d_records, const uint64_t* own_counts, const unsigned char* own_trailing,
+                            uint64_t init_size, uint64_t* sizes_out, uint64_t** d_nodes_out, void** alloc_out = nullptr);
 P2Device* p2_adopt(int lead_device, int K, int nw, int n_sets, const uint64_t* set_size, const int* set_device, uint64_t* const* set_ptr,
                    const std::vector<std::pair<int, void*>>& owned, int max_nk);
 int p2_fetch_words(int device, const uint64_t* d_src, uint64_t n_words, uint64_t* dst);

@@ -35,6 +35,7 @@
 #include "graph_lookup.hpp"
 #include "backend_hip.hpp"
 #include "dev_graph.hpp"
+#include "dev_rehash.hpp"
 #include "dev_tips.hpp"
 
 namespace pg {
@@ -700,6 +701,61 @@ int p2_layout_rank(int device, int nw, int n_own, const uint64_t* d_records, con
     if (rc) { (void)hipFree(block ? block : (void*)nodes); if (rc < 0) pg_set_error("layout: " + (why.empty() ? std::string("failed") : why)); return rc; }
     if (verbose) fprintf(stderr, "K6 on device %d: %d set(s) of %llu slots, %s %.2fs, layout %.2fs\n", device, n_own, (unsigned long long)set_size,
                          block ? "memory taken over from pass 1" : "allocation", t1 - t0, now() - t1);
+    *d_nodes_out = nodes;
+    if (alloc_out) *alloc_out = block ? block : (void*)nodes;
+    return PG_OK;
+}
+
+// The same for GROWABLE sets (-a 0): every set ends at the size the reference's growth schedule gives it for its key count
+// (sizes_out), and every key in the slot the whole history of in-place rehashes leaves it in (dev_rehash.hpp: layout_growable).
+// The sets lie back to back in one allocation, set i at sizes_out[0] + ... + sizes_out[i - 1] slots.
+int p2_layout_rank_growable(int device, int nw, int n_own, const uint64_t* d_records, const uint64_t* own_counts, const unsigned char* own_trailing,
+                            uint64_t init_size, uint64_t* sizes_out, uint64_t** d_nodes_out, void** alloc_out) {
+    *d_nodes_out = nullptr;
+    if (alloc_out) *alloc_out = nullptr;
+    if (n_own < 1) return PG_OK;
+    const bool verbose = getenv("PG_HOST_VERBOSE") != nullptr;
+    auto now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
+    const double t0 = now();
+    std::vector<uint64_t> first_slot((size_t)n_own + 1, 0);
+    for (int s = 0; s < n_own; s++) {
+        if (own_counts[s] >= 0xFFFFFFF0ULL) return K6_UNSUITED;
+        sizes_out[s] = grow_schedule(own_counts[s], own_trailing && own_trailing[s], init_size).back().size;
+        first_slot[s + 1] = first_slot[s] + sizes_out[s];
+    }
+    P2_HIP(hipSetDevice(device));
+    hipStream_t st = nullptr;
+    P2_HIP(hipStreamCreate(&st));
+    const int NW1 = nw + 1;
+    const uint64_t total = first_slot[n_own];
+    uint64_t* nodes = nullptr;
+    void* block = take_offered(device, total * NW1 * sizeof(uint64_t));
+    if (block) nodes = (uint64_t*)(((uintptr_t)block + 255) & ~(uintptr_t)255);
+    else if (hipMalloc((void**)&nodes, total * NW1 * sizeof(uint64_t)) != hipSuccess) {
+        (void)hipStreamDestroy(st);
+        pg_set_error("layout: out of device memory for the k-mer sets (" + std::to_string(total * NW1 * 8 >> 20) + " MiB on device " + std::to_string(device) + ")");
+        return PG_ENOMEM;
+    }
+    const double t1 = now();
+    hipLaunchKernelGGL(p2_empty_image, dim3(8192), dim3(256), 0, st, nodes, NW1, total);
+    int rc;
+    std::string why;
+    std::vector<uint64_t> rounds((size_t)n_own, 0);
+    {
+        HipBackend be(device, st);
+        rc = nw == 2 ? layout_growable_sets<HipBackend, 2>(be, d_records, own_counts, own_trailing, n_own, init_size, first_slot.data(), nodes, nullptr, rounds.data())
+                     : layout_growable_sets<HipBackend, 4>(be, d_records, own_counts, own_trailing, n_own, init_size, first_slot.data(), nodes, nullptr, rounds.data());
+        why = be.error_text;
+    }
+    if (rc == PG_OK && hipStreamSynchronize(st) != hipSuccess) { rc = PG_ENODEV; why = "kernel failure"; }
+    (void)hipStreamDestroy(st);
+    if (rc) { (void)hipFree(block ? block : (void*)nodes); pg_set_error("layout: " + (why.empty() ? std::string("failed") : why)); return rc < 0 ? rc : PG_ENODEV; }
+    if (verbose) {
+        uint64_t r_all = 0;
+        for (uint64_t r : rounds) r_all += r;
+        fprintf(stderr, "growable sets on device %d: %d set(s), %llu slots in all, %s %.2fs, layout %.2fs (%llu rounds over all sizes)\n", device, n_own,
+                (unsigned long long)total, block ? "memory taken over from pass 1" : "allocation", t1 - t0, now() - t1, (unsigned long long)r_all);
+    }
     *d_nodes_out = nodes;
     if (alloc_out) *alloc_out = block ? block : (void*)nodes;
     return PG_OK;

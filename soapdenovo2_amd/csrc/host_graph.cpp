@@ -44,6 +44,8 @@
 #include "graph_dev.hpp"
 #include "backend.hpp"
 #include "dev_tips.hpp"
+#include "ref_sizes.hpp"
+#include "dev_rehash.hpp"
 #include "../../include/soapdenovo2_amd.h"
 
 namespace pg {
@@ -120,22 +122,7 @@ const uint32_t* host_crc_table() {
     return g_crc_tab;
 }
 
-// ---- the reference's size schedule (newhash.c:142-185) ----------------------------------------------
-// is_prime_kh tests odd divisors 3 <= i < (u64)sqrt((float)n) -- strict '<' and a float sqrt, so squares of
-// primes pass; table sizes must come from exactly this function.
-static bool ref_is_prime(uint64_t n) {
-    if (n < 4) return true;
-    if ((n & 1) == 0) return false;
-    const uint64_t lim = (uint64_t)sqrt((float)n);
-    for (uint64_t i = 3; i < lim; i += 2)
-        if (n % i == 0) return false;
-    return true;
-}
-static uint64_t ref_next_prime(uint64_t n) {
-    if ((n & 1) == 0) n++;
-    while (!ref_is_prime(n)) n += 2;
-    return n;
-}
+// (the reference's size schedule: ref_sizes.hpp)
 uint64_t ref_initial_set_size(int a_gb, int n_sets, int mer127) {     // prlHashReads.c:369-390 + init_kmerset
     uint64_t init = 1024;
     if (a_gb) {
@@ -2194,12 +2181,33 @@ static int fetch_device_records(void* user, uint64_t first, uint64_t n, uint64_t
     return p2_fetch_words(f->device, f->d_rec + first * (uint64_t)f->rw, n * (uint64_t)f->rw, dst);
 }
 
-// SURVEY.md App. C "K6": with -a the sets never grow, and their layout is made on the device from the records as they lie
-// there (graph_kernels.hip: p2_open_layout, dev_graph.hpp: layout_static).  The host copy the tip decisions and the vertex
-// writer still read is a download of that image.  Returns PG_OK, 1 = unsuited (the caller replays on the host), or PG_E*.
+// a duplicate put arrived after set s's last new key? (it still ran the growth test, newhash.c:477) -- set_last_put against the
+// ordinal of the set's last record, which lies on `device`
 template <int NW>
-static int layout_on_device(GraphHandle<NW>* h, const uint64_t* d_records, const uint64_t* per_set_count, int K, int P, int a_gb, int n_threads,
-                            int device, bool host_copy) {
+static int trailing_puts(int device, const uint64_t* d_records, const uint64_t* counts, int n_sets, const uint64_t* last_put /*per set, may be null*/,
+                         std::vector<unsigned char>& out) {
+    out.assign((size_t)n_sets, 0);
+    uint64_t first = 0;
+    int rc = PG_OK;
+    for (int s = 0; s < n_sets && rc == PG_OK; s++) {
+        first += counts[s];
+        if (!counts[s] || !last_put || !last_put[s]) continue;
+        uint64_t tag = 0;
+        rc = p2_fetch_words(device, d_records + (first - 1) * (uint64_t)(NW + 2) + NW + 1, 1, &tag);
+        if (rc == PG_OK) out[s] = last_put[s] > (tag & PG_ORD_MASK) + 1;
+    }
+    (void)p2_fetch_words(device, nullptr, 0, nullptr);
+    return rc;
+}
+
+// SURVEY.md App. C "K6": the layout of the k-mer sets is made on the device from the records as they lie there
+// (graph_kernels.hip: p2_layout_rank / p2_layout_rank_growable) -- with -a the sets never grow (dev_graph.hpp: layout_static),
+// without they end at the size the reference's growth schedule gives them and every key where the in-place rehashes leave it
+// (dev_rehash.hpp: layout_growable).  The host copy (SOAPDENOVO2_AMD_TIPS=replay only) is a download of that image.
+// Returns PG_OK, 1 = unsuited (the caller replays on the host), or PG_E*.
+template <int NW>
+static int layout_on_device(GraphHandle<NW>* h, const uint64_t* d_records, const uint64_t* per_set_count, const uint64_t* set_last_put, int K, int P,
+                            int a_gb, int n_threads, int device, bool host_copy) {
     Graph<NW>& g = h->g;
     g.K = K; g.P = P; g.filter = kmer_filter<NW>(K); g.bias = set_bias((uint32_t)P); g.crc = host_crc_table();
     host_crc8_init();
@@ -2207,23 +2215,40 @@ static int layout_on_device(GraphHandle<NW>* h, const uint64_t* d_records, const
     const uint64_t S = ref_initial_set_size(a_gb, P, NW == 4);
     auto now = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     const double t0 = now();
-    bool unsuited = false;
-    P2Device* dev = p2_open_layout(device, K, NW, P, d_records, per_set_count, S, h->max_nk(), &unsuited);
-    if (!dev) return unsuited ? 1 : PG_ENODEV;
+    std::vector<uint64_t> sizes((size_t)P, S);
+    P2Device* dev = nullptr;
+    if (a_gb != 0) {
+        bool unsuited = false;
+        dev = p2_open_layout(device, K, NW, P, d_records, per_set_count, S, h->max_nk(), &unsuited);
+        if (!dev) return unsuited ? 1 : PG_ENODEV;
+    } else {
+        std::vector<unsigned char> trailing;
+        if (trailing_puts<NW>(device, d_records, per_set_count, P, set_last_put, trailing) != PG_OK) return PG_ENODEV;
+        uint64_t* nodes = nullptr;
+        void* alloc = nullptr;
+        const int rc = p2_layout_rank_growable(device, NW, P, d_records, per_set_count, trailing.data(), S, sizes.data(), &nodes, &alloc);
+        if (rc) return rc;
+        std::vector<int> devs((size_t)P, device);
+        std::vector<uint64_t*> ptrs((size_t)P);
+        uint64_t at = 0;
+        for (int si = 0; si < P; si++) { ptrs[si] = nodes + at * (NW + 1); at += sizes[si]; }
+        dev = p2_adopt(device, K, NW, P, sizes.data(), devs.data(), ptrs.data(), {{device, alloc}}, h->max_nk());
+        if (!dev) return PG_ENODEV;
+    }
     const double t1 = now();
     g.sets.clear();
     g.sets.resize(P);
     g.set_base.assign((size_t)P + 1, 0);
-    for (int si = 0; si < P; si++) g.set_base[si + 1] = g.set_base[si] + S;
+    for (int si = 0; si < P; si++) g.set_base[si + 1] = g.set_base[si] + sizes[si];
     std::atomic<int> next{0}, failed{0};
     auto worker = [&]() {
         for (;;) {
             const int si = next.fetch_add(1);
             if (si >= P || !host_copy) break;
             HSet<NW>& hs = g.sets[si];
-            hs.adopt(S, per_set_count[si]);
+            hs.adopt(sizes[si], per_set_count[si]);
             if (p2_download_set(dev, si, hs.array.data()) != PG_OK) { failed.store(1); continue; }
-            for (uint64_t i = 0; i < S; i++) hs.occ[i] = hs.array[i].seq.w[0] != HSet<NW>::EMPTY;
+            for (uint64_t i = 0; i < sizes[si]; i++) hs.occ[i] = hs.array[i].seq.w[0] != HSet<NW>::EMPTY;
         }
     };
     {
@@ -2236,7 +2261,8 @@ static int layout_on_device(GraphHandle<NW>* h, const uint64_t* d_records, const
     if (failed.load()) { p2_destroy(dev); return PG_ENODEV; }
     h->dev = dev; h->dev_on = true; h->dev_id = device;
     g.tip_dev = dev;
-    if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "k-mer set layout on the device (K6): %.2fs; host copy %s: %.2fs\n", t1 - t0, host_copy ? "downloaded" : "not needed", now() - t1);
+    if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "k-mer set layout on the device (%s): %.2fs; host copy %s: %.2fs\n", a_gb ? "static pools" : "growable sets", t1 - t0,
+                                           host_copy ? "downloaded" : "not needed", now() - t1);
     return PG_OK;
 }
 
@@ -2258,7 +2284,8 @@ static int fetch_sharded_records(void* user, uint64_t first, uint64_t n, uint64_
 }
 // K6 on every rank for the sets it owns, then one graph over all of them (the lead = rank 0's GPU runs the kernels)
 template <int NW>
-static int layout_on_ranks(GraphHandle<NW>* h, const ShardedRecords& sr, const uint64_t* per_set_count, int K, int P, int a_gb, int n_threads) {
+static int layout_on_ranks(GraphHandle<NW>* h, const ShardedRecords& sr, const uint64_t* per_set_count, const uint64_t* set_last_put, int K, int P, int a_gb,
+                           int n_threads) {
     Graph<NW>& g = h->g;
     g.K = K; g.P = P; g.filter = kmer_filter<NW>(K); g.bias = set_bias((uint32_t)P); g.crc = host_crc_table();
     host_crc8_init();
@@ -2269,12 +2296,21 @@ static int layout_on_ranks(GraphHandle<NW>* h, const ShardedRecords& sr, const u
     std::vector<void*> allocs(N, nullptr);
     std::vector<int> rcs(N, PG_OK);
     std::vector<std::string> why(N);
+    std::vector<uint64_t> sizes(P, S);
     std::vector<std::thread> pool;
     for (int r = 0; r < N; r++)
         pool.emplace_back([&, r] {
-            std::vector<uint64_t> own;
-            for (int s = r; s < P; s += N) own.push_back(per_set_count[s]);
-            rcs[r] = p2_layout_rank(sr.devices[r], NW, (int)own.size(), sr.d_rec[r], own.data(), S, &nodes[r], &allocs[r]);
+            std::vector<uint64_t> own, own_last, own_sizes;
+            for (int s = r; s < P; s += N) { own.push_back(per_set_count[s]); own_last.push_back(set_last_put ? set_last_put[s] : 0); }
+            if (a_gb != 0) rcs[r] = p2_layout_rank(sr.devices[r], NW, (int)own.size(), sr.d_rec[r], own.data(), S, &nodes[r], &allocs[r]);
+            else {
+                std::vector<unsigned char> trailing;
+                own_sizes.assign(own.size(), 0);
+                rcs[r] = trailing_puts<NW>(sr.devices[r], sr.d_rec[r], own.data(), (int)own.size(), own_last.data(), trailing);
+                if (rcs[r] == PG_OK)
+                    rcs[r] = p2_layout_rank_growable(sr.devices[r], NW, (int)own.size(), sr.d_rec[r], own.data(), trailing.data(), S, own_sizes.data(), &nodes[r], &allocs[r]);
+                for (size_t i = 0; i < own.size(); i++) sizes[r + (int)i * N] = own_sizes[i];
+            }
             if (rcs[r] < 0) why[r] = pg_last_error();
         });
     for (auto& t : pool) t.join();
@@ -2283,16 +2319,16 @@ static int layout_on_ranks(GraphHandle<NW>* h, const ShardedRecords& sr, const u
     std::vector<std::pair<int, void*>> owned;
     for (int r = 0; r < N; r++) if (nodes[r]) owned.emplace_back(sr.devices[r], allocs[r]);
     if (rc) { for (auto& o : owned) pg_device_free_on(o.first, o.second); return rc; }
-    std::vector<uint64_t> sizes(P, S);
     std::vector<int> devs(P);
     std::vector<uint64_t*> ptrs(P);
-    for (int s = 0; s < P; s++) { devs[s] = sr.devices[s % N]; ptrs[s] = nodes[s % N] + (uint64_t)(s / N) * S * (NW + 1); }
+    std::vector<uint64_t> rank_at(N, 0);                                 // slots of the rank's earlier sets
+    for (int s = 0; s < P; s++) { devs[s] = sr.devices[s % N]; ptrs[s] = nodes[s % N] + rank_at[s % N] * (NW + 1); rank_at[s % N] += sizes[s]; }
     P2Device* dev = p2_adopt(sr.devices[0], K, NW, P, sizes.data(), devs.data(), ptrs.data(), owned, h->max_nk());
     if (!dev) return PG_ENODEV;
     g.sets.clear();
     g.sets.resize(P);
     g.set_base.assign((size_t)P + 1, 0);
-    for (int si = 0; si < P; si++) g.set_base[si + 1] = g.set_base[si] + S;
+    for (int si = 0; si < P; si++) g.set_base[si + 1] = g.set_base[si] + sizes[si];
     h->dev = dev; h->dev_on = true; h->dev_id = sr.devices[0];
     h->set_devices = devs;
     return PG_OK;
@@ -2313,18 +2349,18 @@ static GraphHandleBase* graph_begin(const uint64_t* records, uint64_t n, const u
     // SOAPDENOVO2_AMD_TIPS=replay: round 2's hybrid (walks on the device, decisions replayed by the host in slot order), for A/B runs
     const bool tips_replay = getenv("SOAPDENOVO2_AMD_TIPS") && !strcmp(getenv("SOAPDENOVO2_AMD_TIPS"), "replay");
     if (d_records) {
-        // -a pools: the layout is made where the records are (SOAPDENOVO2_AMD_LAYOUT=host keeps the host replay, for A/B runs)
+        // the layout is made where the records are (SOAPDENOVO2_AMD_LAYOUT=host keeps the host replay, for A/B runs)
         const char* where = getenv("SOAPDENOVO2_AMD_LAYOUT");
-        if (a_gb != 0 && device >= 0 && device == rec_device && !(where && !strcmp(where, "host")) && !getenv("SOAPDENOVO2_AMD_TIPS_HOST"))
-            rc_replay = layout_on_device<NW>(h, d_records, per_set_count, K, P, a_gb, n_threads, device, /*host_copy=*/tips_replay);
+        if (device >= 0 && device == rec_device && !(where && !strcmp(where, "host")) && !getenv("SOAPDENOVO2_AMD_TIPS_HOST"))
+            rc_replay = layout_on_device<NW>(h, d_records, per_set_count, set_last_put, K, P, a_gb, n_threads, device, /*host_copy=*/tips_replay);
         if (rc_replay == 1) { fetch = &fetch_device_records; fetch_user = &dr; }
     }
     if (sharded) {
         const char* where = getenv("SOAPDENOVO2_AMD_LAYOUT");
         h->set_devices.resize(P);
         for (int si = 0; si < P; si++) h->set_devices[si] = sharded->devices[si % sharded->n_ranks];
-        if (a_gb != 0 && !(where && !strcmp(where, "host")) && !tips_replay && !getenv("SOAPDENOVO2_AMD_TIPS_HOST"))
-            rc_replay = layout_on_ranks<NW>(h, *sharded, per_set_count, K, P, a_gb, n_threads);
+        if (!(where && !strcmp(where, "host")) && !tips_replay && !getenv("SOAPDENOVO2_AMD_TIPS_HOST"))
+            rc_replay = layout_on_ranks<NW>(h, *sharded, per_set_count, set_last_put, K, P, a_gb, n_threads);
         if (rc_replay == 1) { fetch = &fetch_sharded_records; fetch_user = (void*)sharded; }
     }
     if (rc_replay == 1)
@@ -2564,6 +2600,44 @@ extern "C" int pg_host_emu_clip_tips(const uint64_t* records, uint64_t n_records
     if (n_sets < 1 || n_sets > 255) { pg_set_error("n_sets must be 1..255"); return PG_EINVAL; }
     return mer127 ? emu_clip_tips<4>(records, n_records, set_last_put, K, n_sets, cut_single, a_gb, n_threads, out)
                   : emu_clip_tips<2>(records, n_records, set_last_put, K, n_sets, cut_single, a_gb, n_threads, out);
+}
+
+// Test hook: the layout of growable sets as the device computes it (dev_rehash.hpp on the HostBackend) -- per record its slot,
+// per set the final size and the fixed-point rounds, optionally the node image (sets back to back, NW + 1 words a slot, empty
+// slots = all ones in word 0) -- to be compared with pg_host_replay_layout.  Records sorted by (set, ordinal).
+template <int NW>
+static int emu_layout_growable(const uint64_t* records, uint64_t n, const uint64_t* set_last_put, int P, int n_threads, uint64_t* out_slot,
+                               uint64_t* out_size, uint64_t* out_rounds, uint64_t* out_nodes, uint64_t nodes_cap_slots) {
+    using namespace pg;
+    constexpr int RW = NW + 2;
+    HostBackend be(n_threads);
+    const uint64_t init = ref_initial_set_size(0, P, NW == 4);
+    std::vector<uint64_t> cnt(P, 0), first_slot(P + 1, 0);
+    std::vector<unsigned char> trailing(P, 0);
+    uint64_t at = 0;
+    for (int s = 0; s < P; s++) {
+        while (at + cnt[s] < n && (int)(records[(at + cnt[s]) * RW + NW + 1] >> PG_ORD_BITS) == s) cnt[s]++;
+        trailing[s] = cnt[s] && set_last_put && set_last_put[s] > (records[(at + cnt[s] - 1) * RW + NW + 1] & PG_ORD_MASK) + 1;
+        const uint64_t fsize = grow_schedule(cnt[s], trailing[s] != 0, init).back().size;
+        if (out_size) out_size[s] = fsize;
+        first_slot[s + 1] = first_slot[s] + fsize;
+        at += cnt[s];
+    }
+    if (at != n) { pg_set_error("records are not sorted by set"); return PG_EINVAL; }
+    if (out_nodes) {
+        if (nodes_cap_slots < first_slot[P]) { pg_set_error("node image too small"); return PG_EINVAL; }
+        for (uint64_t i = 0; i < first_slot[P]; i++) { out_nodes[i * (NW + 1)] = ~0ULL; for (int w = 1; w <= NW; w++) out_nodes[i * (NW + 1) + w] = 0; }
+    }
+    const int rc = layout_growable_sets<HostBackend, NW>(be, records, cnt.data(), trailing.data(), P, init, first_slot.data(), out_nodes,
+                                                         (unsigned long long*)out_slot, out_rounds);
+    if (rc) pg_set_error(be.error_text.empty() ? "layout_growable failed" : be.error_text);
+    return rc;
+}
+extern "C" int pg_host_emu_layout_growable(const uint64_t* records, uint64_t n_records, const uint64_t* set_last_put, int mer127, int n_sets, int n_threads,
+                                           uint64_t* out_slot, uint64_t* out_set_size, uint64_t* out_rounds, uint64_t* out_nodes, uint64_t nodes_cap_slots) {
+    if ((!records && n_records) || !out_slot) { pg_set_error("null argument"); return PG_EINVAL; }
+    return mer127 ? emu_layout_growable<4>(records, n_records, set_last_put, n_sets, n_threads, out_slot, out_set_size, out_rounds, out_nodes, nodes_cap_slots)
+                  : emu_layout_growable<2>(records, n_records, set_last_put, n_sets, n_threads, out_slot, out_set_size, out_rounds, out_nodes, nodes_cap_slots);
 }
 
 extern "C" int pg_host_write_kmerfreq(const uint64_t hist[256], const char* prefix) {

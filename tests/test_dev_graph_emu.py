@@ -126,3 +126,54 @@ def test_device_tip_decisions_equal_the_sequential_scan(golden, tmp_path, name, 
         assert (single_dev, minor_dev) == (single_seq, minor_seq), (name, run)
         assert diff == 0, (name, run, diff)
         assert rounds >= cycles >= 1
+
+
+def _growable_vs_replay(rec, last, P, m, threads):
+    nw = 4 if m else 2
+    rec = np.ascontiguousarray(rec[np.argsort(rec[:, nw + 1], kind="stable")])
+    want_slots, want_sizes = api.host_replay_layout(rec, last, P, mer127=m, a_gb=0)
+    slots = np.zeros(len(rec), dtype=np.uint64)
+    sizes = np.zeros(P, dtype=np.uint64)
+    rounds = np.zeros(P, dtype=np.uint64)
+    cap = int(sum(int(x) for x in want_sizes)) + 7
+    nodes = np.zeros((cap, nw + 1), dtype=np.uint64)
+    rc = api.lib().pg_host_emu_layout_growable(rec.ctypes.data, len(rec), last.ctypes.data, int(m), P, threads, slots.ctypes.data, sizes.ctypes.data,
+                                               rounds.ctypes.data, nodes.ctypes.data, cap)
+    assert rc == 0, api.lib().pg_last_error()
+    assert [int(x) for x in sizes] == [int(x) for x in want_sizes]
+    bad = np.nonzero(slots != want_slots)[0]
+    assert len(bad) == 0, (len(bad), bad[:5], slots[bad[:5]], want_slots[bad[:5]])
+    # the image: every record's key and payload word in its slot, everything else empty
+    base = np.concatenate([[0], np.cumsum(want_sizes.astype(np.uint64))]).astype(np.uint64)
+    at = base[(rec[:, nw + 1] >> np.uint64(api.PG_ORD_BITS)).astype(np.int64)] + slots
+    assert (nodes[at.astype(np.int64)] == rec[:, : nw + 1]).all()
+    filled = np.zeros(cap, dtype=bool)
+    filled[at.astype(np.int64)] = True
+    assert (nodes[:cap - 7][~filled[:cap - 7], 0] == np.uint64(0xFFFFFFFFFFFFFFFF)).all() and int(filled.sum()) == len(rec)
+    return rounds
+
+
+@pytest.mark.parametrize("name,P,m", [("t6k_k31", 7, False), ("t8k_k63", 3, True), ("m60k_k63", 8, False), ("t6k_k127", 3, True), ("m100k_k31", 2, False)])
+def test_layout_growable_equals_the_host_replay(golden, tmp_path, name, P, m):
+    """The growable (-a 0) sets' layout as the device computes it -- the in-place rehash as a fixed point over insertion times,
+    dev_rehash.hpp on the HostBackend -- puts every k-mer into the slot the sequential host replay puts it (which is pinned slot by
+    slot on the oracle and through the golden files on the reference)."""
+    c = golden["cases"][name]
+    codes = case_codes(c)
+    rec, last, K = oracle_records(codes, c["K"], P, mer127=m, prefix=str(tmp_path / "o"))
+    rounds = _growable_vs_replay(rec, last, P, m, threads=4)
+    assert int(rounds.max()) >= 2
+
+
+def test_layout_growable_random_keys_and_the_trailing_duplicate():
+    """Random keys (no genome structure), set sizes right at the growth thresholds, with and without a duplicate put behind the
+    last new key (newhash.c:477 tests the growth before it probes)."""
+    rng = np.random.default_rng(77)
+    for n in (1, 5, 793, 794, 795, 1590, 1591, 5000, 40000):
+        for trailing in (False, True):
+            rec = np.zeros((n, 4), dtype=np.uint64)
+            rec[:, :2] = rng.integers(0, 1 << 62, size=(n, 2), dtype=np.uint64)
+            rec[:, 0] >>= np.uint64(3)
+            rec[:, 3] = np.arange(n, dtype=np.uint64) * np.uint64(3)
+            last = np.array([int(rec[-1, 3]) + (5 if trailing else 1)], dtype=np.uint64)
+            _growable_vs_replay(rec, last, 1, False, threads=3)

@@ -709,3 +709,30 @@ print("three calls done")
             assert md5_file(str(tmp_path / f"r{i}.{ext}")) == want[ext], (i, ext)
         assert md5_gz_text(str(tmp_path / f"r{i}.edge.gz")) == want["edge"], i
     assert md5_file(str(tmp_path / "r2.kmerFreq")) == want["kmerFreq"]          # same counts through the four-word path
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("layout", ["device", "host"])
+@pytest.mark.parametrize("name", ["t8k_k63", "m60k_k63", "d8k_k127", "m100k_k31"])
+def test_cli_layout_on_the_device_and_on_the_host(golden, tmp_path, name, layout):
+    """The k-mer sets' layout is made on the device by default -- growable sets (-a 0) through the fixed point over the in-place
+    rehashes' insertion times (dev_rehash.hpp), -a pools through one sweep (dev_graph.hpp); SOAPDENOVO2_AMD_LAYOUT=host keeps the
+    sequential host replay.  Same files either way."""
+    c = golden["cases"][name]
+    cfg = case_config(c, str(tmp_path), name)
+    for run in c["runs"]:
+        P, D, a, m = run
+        t = case_tag(name, run)
+        pre = str(tmp_path / t)
+        env = dict(PARALLEL_PARSE, PG_HOST_VERBOSE="1")
+        if layout == "host":
+            env["SOAPDENOVO2_AMD_LAYOUT"] = "host"
+        log = _run_cli(cfg, c["K"], pre, P, D, a, m, extra_env=env)
+        on_device = "k-mer set layout on the device" in log
+        assert on_device == (layout == "device"), log[-3000:]
+        if layout == "device" and not a:
+            assert "growable sets on device" in log
+        want = golden["md5"][t]
+        for ext in ("kmerFreq", "preGraphBasic", "vertex", "preArc"):
+            assert md5_file(pre + "." + ext) == want[ext], (t, ext)
+        assert md5_gz_text(pre + ".edge.gz") == want["edge"], t
