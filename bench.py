@@ -132,51 +132,65 @@ def whole_command(args, cores):
 
 
 def big_command(args):
-    """The executable on the 60 M-read FASTQ of scripts/synth_fastq.cpp (bytes that depend on the arguments only) with -a 16 -- static
-    pools: the k-mer-set layout is made on the device (SURVEY.md App. C "K6") -- compared with the md5s of the REFERENCE's own run
-    on the same file, which took it a quarter of an hour in the build container and is committed (profiles/r03_ref_60M_K63_a16.json)."""
-    exp_path = os.path.join(ROOT, "profiles", "r03_ref_60M_K63_a16.json")
+    """The executable on the 60 M-read FASTQ of scripts/synth_fastq.cpp (bytes that depend on the arguments only), once with -a 16
+    (static pools) and once with the default growable sets -- either way the k-mer-set layout is made on the device (SURVEY.md
+    App. C "K6": dev_graph.hpp / dev_rehash.hpp) -- compared with the md5s of the REFERENCE's own runs on the same file, which took it
+    a quarter of an hour each in the build container and are committed (profiles/r03_ref_60M_K63*.json).
+    Returns {"whole_command_60M_a16": {...}, "whole_command_60M": {...}}."""
+    exps = [("whole_command_60M_a16", "r03_ref_60M_K63_a16.json"), ("whole_command_60M", "r03_ref_60M_K63.json")]
     gen = os.path.join(ROOT, "soapdenovo2_amd", "bin", "synth_fastq")
-    if not (os.path.exists(exp_path) and os.path.exists(gen)):
+    exps = [(k, os.path.join(ROOT, "profiles", f)) for k, f in exps if os.path.exists(os.path.join(ROOT, "profiles", f))]
+    if not exps or not os.path.exists(gen):
         return None
-    exp = json.load(open(exp_path))
-    w = exp["workload"]
+    w = json.load(open(exps[0][1]))["workload"]
     if args.kmer != w["kmer"] or args.sets != w["sets"]:
         return None
     from soapdenovo2_amd import api
     td = tempfile.mkdtemp(prefix="pgbig_", dir=os.environ.get("PG_BENCH_TMP"))
+    res = {}
     try:
         if shutil_free_gb(td) < w["reads"] * (2 * w["read_len"] + 20) / 1e9 + 4:
-            return {"skipped": "not enough room for the FASTQ in " + td}
+            return {exps[0][0]: {"skipped": "not enough room for the FASTQ in " + td}}
         fq, cfg = os.path.join(td, "reads.fq"), os.path.join(td, "lib.cfg")
         t0 = time.time()
         subprocess.check_call([gen, fq, str(w["genome"]), str(w["reads"]), str(w["read_len"]), str(w["err"]), str(w["seed"])])
         open(cfg, "w").write(f"max_rd_len={w['read_len']}\n[LIB]\navg_ins=200\nreverse_seq=0\nasm_flags=3\nrank=1\nq={fq}\n")
         os.sync()
-        out = {"workload": f"{w['reads']} reads x {w['read_len']} bp, genome {w['genome']}, err {w['err']} (scripts/synth_fastq.cpp, seed {w['seed']}), "
-                           f"K={w['kmer']}, -p {w['sets']} -a {w['a_gb']}", "reads": w["reads"], "fastq_bytes": os.path.getsize(fq), "generate_s": round(time.time() - t0, 1)}
-        pre = os.path.join(td, "amd")
-        t0 = time.time()
-        r = subprocess.run([api.binary(False), "pregraph", "-s", cfg, "-K", str(w["kmer"]), "-o", pre, "-p", str(w["sets"]), "-a", str(w["a_gb"])],
-                           capture_output=True, text=True, env=dict(os.environ, PG_HOST_VERBOSE="1"))
-        wall = time.time() - t0
-        out.update({"rc": r.returncode, "wall_s": wall, "reads_per_sec": w["reads"] / wall if r.returncode == 0 else None,
-                    "stages_s": {m.group(1): float(m.group(2)) for m in re.finditer(r"\[cli\] ([^:]+): ([0-9.]+)s", r.stderr)}})
-        m = re.search(r"Time spent on rebuilding the k-mer set layout: ([0-9.]+)s", r.stderr)
-        if m:
-            out["layout_s"] = float(m.group(1))
-        m = re.search(r"tips decided on the device: (\d+) scan\(s\), (\d+) fixed-point round\(s\), ([0-9.]+)s", r.stderr)
-        if m:
-            out["tips"] = {"scans": int(m.group(1)), "rounds": int(m.group(2)), "seconds": float(m.group(3))}
-        if r.returncode == 0:
-            got = md5_outputs(pre)
-            out["md5"] = got
-            out["files_identical_to_reference"] = got == exp["md5"]
-            out["reference_wall_s"] = exp.get("reference_wall_s")
-            out["expectation"] = "profiles/r03_ref_60M_K63_a16.json (oracle/_ref/SOAPdenovo-63mer pregraph -p 8 -a 16 on the same file, build container)"
-        else:
-            out["stderr_tail"] = r.stderr[-800:]
-        return out
+        gen_s = round(time.time() - t0, 1)
+        for key, exp_path in exps:
+            exp = json.load(open(exp_path))
+            w = exp["workload"]
+            out = {"workload": f"{w['reads']} reads x {w['read_len']} bp, genome {w['genome']}, err {w['err']} (scripts/synth_fastq.cpp, seed {w['seed']}), "
+                               f"K={w['kmer']}, -p {w['sets']} -a {w['a_gb']}", "reads": w["reads"], "fastq_bytes": os.path.getsize(fq), "generate_s": gen_s}
+            pre = os.path.join(td, "amd" + key[-4:])
+            t0 = time.time()
+            r = subprocess.run([api.binary(False), "pregraph", "-s", cfg, "-K", str(w["kmer"]), "-o", pre, "-p", str(w["sets"])] + (["-a", str(w["a_gb"])] if w["a_gb"] else []),
+                               capture_output=True, text=True, env=dict(os.environ, PG_HOST_VERBOSE="1"))
+            wall = time.time() - t0
+            out.update({"rc": r.returncode, "wall_s": wall, "reads_per_sec": w["reads"] / wall if r.returncode == 0 else None,
+                        "stages_s": {m.group(1): float(m.group(2)) for m in re.finditer(r"\[cli\] ([^:]+): ([0-9.]+)s", r.stderr)}})
+            m = re.search(r"Time spent on rebuilding the k-mer set layout: ([0-9.]+)s", r.stderr)
+            if m:
+                out["layout_s"] = float(m.group(1))
+            out["layout_on_device"] = "k-mer set layout on the device" in r.stderr
+            m = re.search(r"tips decided on the device: (\d+) scan\(s\), (\d+) fixed-point round\(s\), ([0-9.]+)s", r.stderr)
+            if m:
+                out["tips"] = {"scans": int(m.group(1)), "rounds": int(m.group(2)), "seconds": float(m.group(3))}
+            if r.returncode == 0:
+                got = md5_outputs(pre)
+                out["md5"] = got
+                out["files_identical_to_reference"] = got == exp["md5"]
+                out["reference_wall_s"] = exp.get("reference_wall_s")
+                out["expectation"] = f"profiles/{os.path.basename(exp_path)} (oracle/_ref/SOAPdenovo-63mer pregraph -p {w['sets']}" + (f" -a {w['a_gb']}" if w["a_gb"] else "") + " on the same file, build container)"
+                for ext in ("kmerFreq", "preGraphBasic", "vertex", "preArc", "edge.gz"):
+                    try:
+                        os.remove(pre + "." + ext)
+                    except OSError:
+                        pass
+            else:
+                out["stderr_tail"] = r.stderr[-800:]
+            res[key] = out
+        return res
     finally:
         import shutil
         shutil.rmtree(td, ignore_errors=True)
@@ -562,7 +576,7 @@ def main():
                 if not args.no_big:
                     big = big_command(args)
                     if big:
-                        rec["whole_command_60M_a16"] = big
+                        rec.update(big)
         print(json.dumps(rec), flush=True)
     kc.close()
     if comm is not None:
