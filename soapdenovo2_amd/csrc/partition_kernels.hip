@@ -1252,14 +1252,14 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
         const OccConst oc = occ_const(c->K, c->NW);
         // cfg 2: 512-slot set, 256 lanes, 128-record windows -> ~38 KB LDS, four workgroups per CU (meant for 4x the partitions)
         if (c->NW == 2) {
-            if (cfg == 0 && (dbg & 2)) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, true>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
+            if (cfg == 0 && (dbg & 2)) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, true, 4>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
             else if (cfg == 0 && vt == 4) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 4>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
             else if (cfg == 0 && vt == 2) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 2>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
             else if (cfg == 0) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
             else if (cfg == 1) hipLaunchKernelGGL((skm_count_kernel<2, 1024, 512, 256, false>), dim3(grid), dim3(512), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
             else hipLaunchKernelGGL((skm_count_kernel<2, 512, 256, 128, false>), dim3(grid * 2), dim3(256), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
         } else {
-            if (cfg == 0 && (dbg & 2)) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, true>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
+            if (cfg == 0 && (dbg & 2)) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, true, 4>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
             else if (cfg == 0 && vt == 4) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false, 4>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
             else if (cfg == 0 && vt == 2) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false, 2>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
             else if (cfg == 0) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
