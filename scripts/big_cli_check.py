@@ -55,13 +55,14 @@ def main():
     ap.add_argument("--rocprof", default="", help="run the command under rocprofv3 with these arguments (e.g. '--kernel-trace --stats'), output next to result.json")
     a = ap.parse_args()
     key = {k: getattr(a, k) for k in ("reads", "read_len", "genome", "err", "seed", "kmer", "sets", "a_gb")}
-    want = None
+    want, want_kind = None, None
     if not a.reference:
         if a.expect:
             e = json.load(open(a.expect))
             if e.get("workload") != key or not e.get("md5"):
                 sys.exit(f"{a.expect} holds no md5s for these arguments: {e.get('workload')} vs {key}")
             want = e["md5"]
+            want_kind = e.get("kind", "reference")
         elif not a.unverified:
             sys.exit("no --expect: refusing a run that is compared with nothing (--unverified to insist)")
     os.makedirs(a.out, exist_ok=True)
@@ -97,8 +98,10 @@ def main():
         res["md5"] = md5s(pre)
         if want is not None:
             res["expect"] = a.expect
-            res["identical_to_reference"] = res["md5"] == want
-            ok = res["identical_to_reference"]
+            # an expectation made by the reference itself, or ("kind": "self") by an earlier run of this executable
+            verdict = "identical_to_reference" if want_kind == "reference" else "identical_to_earlier_run"
+            res[verdict] = res["md5"] == want
+            ok = res[verdict]
         elif not a.reference:
             res["unverified"] = True
     else:

@@ -35,6 +35,7 @@ namespace pg {
 #if defined(__HIP_DEVICE_COMPILE__)
 PG_HD unsigned long long hd_atomic_add(unsigned long long* p, unsigned long long v) { return atomicAdd(p, v); }
 PG_HD unsigned int hd_atomic_add(unsigned int* p, unsigned int v) { return atomicAdd(p, v); }
+PG_HD unsigned int hd_atomic_exch(unsigned int* p, unsigned int v) { return atomicExch(p, v); }
 PG_HD unsigned long long hd_atomic_min(unsigned long long* p, unsigned long long v) { return atomicMin(p, v); }
 PG_HD unsigned long long hd_atomic_max(unsigned long long* p, unsigned long long v) { return atomicMax(p, v); }
 PG_HD unsigned long long hd_atomic_or(unsigned long long* p, unsigned long long v) { return atomicOr(p, v); }
@@ -44,6 +45,7 @@ PG_HD unsigned long long hd_atomic_load(const unsigned long long* p) { return __
 #else
 inline unsigned long long hd_atomic_add(unsigned long long* p, unsigned long long v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline unsigned int hd_atomic_add(unsigned int* p, unsigned int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
+inline unsigned int hd_atomic_exch(unsigned int* p, unsigned int v) { return __atomic_exchange_n(p, v, __ATOMIC_RELAXED); }
 inline unsigned long long hd_atomic_min(unsigned long long* p, unsigned long long v) {
     unsigned long long cur = __atomic_load_n(p, __ATOMIC_RELAXED);
     while (v < cur && !__atomic_compare_exchange_n(p, &cur, v, true, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) {}

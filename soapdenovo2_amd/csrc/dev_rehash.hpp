@@ -21,9 +21,11 @@
 // earlier than the true one, and an element that truly stays in place is never taken for kicked; (2) by (1) the elements with the
 // k earliest true times, once they carry them, make the first k steps of a round's sweep the true ones, so the (k+1)-th finds its
 // true kicker (or nobody) on its slot and has its true time from the next round on.  Both need a round's times to be read as a
-// whole (two arrays, swapped) -- updated in place, an element can get a time derived from one that has changed since.  Chains are
-// a dozen levels deep (a fifth of the moves are kicks), a set settles in 5 - 10 rounds a size, and a round after the first touches
-// a fraction of the clusters.
+// whole: the sweep only READS times and lists the changes it finds (old element, new time); they are applied between the rounds.
+// (A first version updated the times in place while other lanes read them and livelocked on the host backend's four threads.)
+// A round costs what changed: the sweep runs over a list of the clusters that hold an element whose time changed, and the only old
+// elements whose time can change are those whose old slot lies in such a cluster -- the sweep meets them on its way.  Chains are a
+// dozen levels deep (a fifth of the moves are kicks), a set settles in 20 - 30 rounds a size, all but the first few tiny.
 // Which slots are occupied, the clusters and the wrap-around frame depend on the homes alone and are computed once per size.
 #pragma once
 #include <stdint.h>
@@ -40,21 +42,27 @@ namespace pg {
 constexpr int RH_DEPTH_BITS = 22;                  // time = origin << 22 | depth
 constexpr uint32_t RH_NONE = 0xFFFFFFFFu;
 
-// one probe cluster: the slots of frame [hs[j], ...) take the pending element with the smallest time
+// one probe cluster: the slots of frame [hs[j], ...) take the pending element with the smallest time; the old element of every
+// slot met on the way is given the time the slot's new occupant implies -- if that is not the time it has, onto the change list
 struct RhSweep {
     const uint64_t* hs;                 // homes in the frame, sorted
     const uint32_t* is;                 // elements in the same order
     const long long* m;                 // prefix maximum of hs[j] - j
-    const unsigned long long* T;        // time of every element
-    unsigned int* dirty;                // per sorted position: sweep the cluster that starts here
+    const unsigned long long* T;        // time of every element (read only here)
+    unsigned int* dirty;                // per sorted position: the cluster that starts here is on the list
+    const uint32_t* list;               // cluster starts to sweep (null: every cluster, lane = sorted position)
     unsigned long long* heap_t;
     uint32_t* heap_e;
     unsigned long long* slot_new;       // table slot of every element
-    uint32_t* owner;                    // element resting on table slot j, for j < n_owner (RH_NONE: nobody)
-    uint64_t n, S, origin, n_owner;
-    PG_HD void operator()(uint64_t j) const {
-        if (j && m[j] <= m[j - 1]) return;                          // not the first key of a cluster
-        if (!dirty[j]) return;
+    const uint32_t* elem_prev;          // element that sat on table slot j before the growth, for j < n_prev (RH_NONE: nobody)
+    uint32_t* chg_e;                    // changes: element, time
+    unsigned long long* chg_t;
+    unsigned long long* n_chg;
+    uint64_t n, S, origin, n_prev;
+    PG_HD void operator()(uint64_t lane) const {
+        uint64_t j = lane;
+        if (list) j = list[lane];
+        else if (j && m[j] <= m[j - 1]) return;                     // not the first key of a cluster
         dirty[j] = 0;
         unsigned long long* ht = heap_t + j;
         uint32_t* he = heap_e + j;
@@ -69,6 +77,7 @@ struct RhSweep {
             }
             if (!hn) return;
             const uint32_t first = he[0];
+            const unsigned long long t_first = ht[0];
             hn--;
             const unsigned long long lt = ht[hn];
             const uint32_t le = he[hn];
@@ -86,7 +95,18 @@ struct RhSweep {
             uint64_t slot = p + origin;
             if (slot >= S) slot -= S;
             slot_new[first] = slot;
-            if (slot < n_owner) owner[slot] = first;
+            if (slot < n_prev) {
+                const uint32_t e = elem_prev[slot];
+                if (e != RH_NONE) {
+                    const unsigned long long natural = (unsigned long long)slot << RH_DEPTH_BITS;
+                    unsigned long long t = natural;
+                    if (e != first && t_first < natural) t = t_first + 1;   // `first` came to rest here before the walk reached the slot: e went next
+                    if (t != T[e]) {
+                        const unsigned long long at = hd_atomic_add(n_chg, 1ULL);
+                        chg_e[at] = e; chg_t[at] = t;
+                    }
+                }
+            }
             p++;
         }
     }
@@ -96,9 +116,9 @@ struct RhSweep {
 template <class BE>
 struct RhWork {
     uint64_t *hk = nullptr, *hs = nullptr, *hr = nullptr;
-    uint32_t *iv = nullptr, *is = nullptr, *ir = nullptr, *pos_of = nullptr, *heap_e = nullptr, *owner = nullptr;
+    uint32_t *iv = nullptr, *is = nullptr, *ir = nullptr, *pos_of = nullptr, *heap_e = nullptr, *elem_prev = nullptr, *chg_e = nullptr, *list_a = nullptr, *list_b = nullptr;
     long long *v = nullptr, *m = nullptr, *cs = nullptr;
-    unsigned long long *T = nullptr, *T2 = nullptr, *heap_t = nullptr, *slot_prev = nullptr, *scal = nullptr;
+    unsigned long long *T = nullptr, *chg_t = nullptr, *heap_t = nullptr, *slot_prev = nullptr, *scal = nullptr;
     unsigned int* dirty = nullptr;
     uint64_t cap = 0, owner_cap = 0;
     bool reserve(BE& be, uint64_t n, uint64_t n_owner) {
@@ -109,21 +129,24 @@ struct RhWork {
         v = be.template alloc<long long>(n); m = be.template alloc<long long>(n);
         cs = be.template alloc<long long>(n);                          // cluster start (sorted position) of every sorted position
         pos_of = be.template alloc<uint32_t>(n);                       // sorted position of every element
-        T = be.template alloc<unsigned long long>(n); T2 = be.template alloc<unsigned long long>(n);
+        T = be.template alloc<unsigned long long>(n);
+        chg_e = be.template alloc<uint32_t>(n); chg_t = be.template alloc<unsigned long long>(n);      // at most one change an old element a round
+        list_a = be.template alloc<uint32_t>(n); list_b = be.template alloc<uint32_t>(n);             // cluster starts to sweep, this round's and the next's
         dirty = be.template alloc<unsigned int>(n);
         heap_t = be.template alloc<unsigned long long>(n); heap_e = be.template alloc<uint32_t>(n);
         slot_prev = be.template alloc<unsigned long long>(n);
-        owner = be.template alloc<uint32_t>(owner_cap);
+        elem_prev = be.template alloc<uint32_t>(owner_cap);
         scal = be.template alloc<unsigned long long>(4);
         return !be.error;
     }
     void release(BE& be) {
         be.release(hk); be.release(hs); be.release(hr); be.release(iv); be.release(is); be.release(ir); be.release(v); be.release(m); be.release(cs);
-        be.release(pos_of); be.release(T); be.release(T2); be.release(dirty); be.release(heap_t); be.release(heap_e); be.release(slot_prev); be.release(owner); be.release(scal);
+        be.release(pos_of); be.release(T); be.release(chg_e); be.release(chg_t); be.release(list_a); be.release(list_b); be.release(dirty); be.release(heap_t); be.release(heap_e);
+        be.release(slot_prev); be.release(elem_prev); be.release(scal);
         *this = RhWork();
     }
     // bytes a key / an old slot (for the caller's memory planning)
-    static constexpr uint64_t bytes_per_key = 8 * 3 + 4 * 3 + 8 * 3 + 4 + 8 * 2 + 4 + 8 + 4 + 8;
+    static constexpr uint64_t bytes_per_key = 8 * 3 + 4 * 3 + 8 * 3 + 4 + 8 + 12 + 8 + 4 + 8 + 4 + 8;
 };
 // the largest old size a schedule's growths walk over
 inline uint64_t grow_owner_slots(const std::vector<GrowEpoch>& sched) {
@@ -143,9 +166,9 @@ int layout_growable(BE& be, RhWork<BE>& wk, const uint64_t* rec, uint64_t n, con
     if (n >= 0xFFFFFFF0ULL) { be.error_text = "layout_growable: more than 2^32 keys in a set"; return PG_EINVAL; }
     if (n > wk.cap || grow_owner_slots(sched) > wk.owner_cap) { be.error_text = "layout_growable: scratch too small"; return PG_EINVAL; }
     uint64_t *hk = wk.hk, *hs = wk.hs, *hr = wk.hr;
-    uint32_t *iv = wk.iv, *is = wk.is, *ir = wk.ir, *pos_of = wk.pos_of, *heap_e = wk.heap_e, *owner = wk.owner;
+    uint32_t *iv = wk.iv, *is = wk.is, *ir = wk.ir, *pos_of = wk.pos_of, *heap_e = wk.heap_e, *elem_prev = wk.elem_prev, *chg_e = wk.chg_e;
     long long *v = wk.v, *m = wk.m, *cs = wk.cs;
-    unsigned long long *T = wk.T, *Tn = wk.T2, *heap_t = wk.heap_t, *slot_prev = wk.slot_prev, *scal = wk.scal;
+    unsigned long long *T = wk.T, *chg_t = wk.chg_t, *heap_t = wk.heap_t, *slot_prev = wk.slot_prev, *scal = wk.scal;
     unsigned int* dirty = wk.dirty;
     unsigned long long* slot_new = slots_out;
     int rc = PG_OK;
@@ -219,50 +242,48 @@ int layout_growable(BE& be, RhWork<BE>& wk, const uint64_t* rec, uint64_t n, con
             be.launch(M, [=] PG_LAMBDA(uint64_t j) {
                 pos_of[isu[j]] = (uint32_t)j;
                 v[j] = (j == 0 || mm[j] > mm[j - 1]) ? (long long)j : 0;
-                dirty[j] = 1u;
+                dirty[j] = 0u;
             });
             be.inclusive_max(v, cs, M);
             const unsigned long long* sp = slot_prev;
             be.launch(M, [=] PG_LAMBDA(uint64_t i) {
-                T[i] = Tn[i] = (i < n_old ? sp[i] : (unsigned long long)(s_prev + (i - n_old))) << RH_DEPTH_BITS;
+                T[i] = (i < n_old ? sp[i] : (unsigned long long)(s_prev + (i - n_old))) << RH_DEPTH_BITS;
             });
-            if (n_old) be.fill(owner, (size_t)s_prev, RH_NONE);
-        }
-        // ---- the fixed point
-        for (int round = 0;; round++) {
-            if (round > 10000) { rc = PG_EINVAL; be.error_text = "layout_growable: the fixed point did not settle"; break; }
-            if (rounds_out) (*rounds_out)++;
-            be.launch(M, RhSweep{hs_use, is_use, m, T, dirty, heap_t, heap_e, slot_new, owner, M, S, origin, n_old ? s_prev : 0});
-            if (!n_old) break;                                        // nobody was there before: arrival order is all there is
-            be.fill(scal, 1, 0ULL);
-            {
-                // every old element's time from the layout just made.  Jacobi: this round's times are read, the next round's
-                // written -- with times read while they change an element could come out EARLIER than it truly is, and the
-                // argument above (times never fall below the true ones) would not hold
-                const unsigned long long* sp = slot_prev;
-                const unsigned long long* Tc = T;
-                unsigned long long* Tw = Tn;
-                const long long* csp = cs;
-                be.launch(n_old, [=] PG_LAMBDA(uint64_t i) {
-                    const unsigned long long j = sp[i];
-                    const unsigned long long natural = j << RH_DEPTH_BITS;
-                    const uint32_t y = owner[j];
-                    unsigned long long t = natural;
-                    if (y != RH_NONE && y != (uint32_t)i) {
-                        const unsigned long long ty = Tc[y];
-                        if (ty < natural) t = ty + 1;                  // y came to rest on slot j before the walk reached it: e_j went next
-                    }
-                    Tw[i] = t;
-                    if (t != Tc[i]) {
-                        dirty[csp[pos_of[i]]] = 1u;
-                        hd_atomic_add(&scal[0], 1ULL);
-                    }
-                });
-                unsigned long long* sw = T; T = Tn; Tn = sw;
+            if (n_old) {
+                be.fill(elem_prev, (size_t)s_prev, RH_NONE);
+                be.launch(n_old, [=] PG_LAMBDA(uint64_t i) { elem_prev[sp[i]] = (uint32_t)i; });
             }
-            unsigned long long changed = 0;
-            be.to_host(&changed, scal, 1);
-            if (be.error || !changed) break;
+        }
+        // ---- the fixed point: sweep (every cluster first, then the listed ones), apply the changes it found, list their clusters
+        uint32_t* list_cur = nullptr;
+        uint32_t* list_next = wk.list_a;
+        uint64_t n_list = M;
+        for (int round = 0;; round++) {
+            if (round > 100000) { rc = PG_EINVAL; be.error_text = "layout_growable: the fixed point did not settle"; break; }
+            if (rounds_out) (*rounds_out)++;
+            be.fill(scal, 2, 0ULL);
+            be.launch(n_list, RhSweep{hs_use, is_use, m, T, dirty, list_cur, heap_t, heap_e, slot_new, elem_prev, chg_e, chg_t, scal, M, S, origin, n_old ? s_prev : 0});
+            if (!n_old) break;                                        // nobody was there before: arrival order is all there is
+            unsigned long long n_chg = 0;
+            be.to_host(&n_chg, scal, 1);
+            if (be.error || !n_chg) break;
+            {
+                const long long* csp = cs;
+                uint32_t* ln = list_next;
+                unsigned long long* n_dirty = scal + 1;
+                be.launch(n_chg, [=] PG_LAMBDA(uint64_t c) {
+                    const uint32_t e = chg_e[c];
+                    T[e] = chg_t[c];
+                    const uint32_t start = (uint32_t)csp[pos_of[e]];
+                    if (hd_atomic_exch(&dirty[start], 1u) == 0u) ln[hd_atomic_add(n_dirty, 1ULL)] = start;
+                });
+            }
+            unsigned long long n_dirty_h = 0;
+            be.to_host(&n_dirty_h, scal + 1, 1);
+            if (be.error) break;
+            n_list = n_dirty_h;
+            list_cur = list_next;
+            list_next = list_cur == wk.list_a ? wk.list_b : wk.list_a;
         }
         if (ei + 1 < sched.size()) be.copy(slot_prev, slot_new, M);
     }
