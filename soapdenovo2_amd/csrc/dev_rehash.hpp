@@ -29,6 +29,8 @@
 // Which slots are occupied, the clusters and the wrap-around frame depend on the homes alone and are computed once per size.
 #pragma once
 #include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -282,6 +284,7 @@ int layout_growable(BE& be, RhWork<BE>& wk, const uint64_t* rec, uint64_t n, con
             be.to_host(&n_dirty_h, scal + 1, 1);
             if (be.error) break;
             n_list = n_dirty_h;
+            if (getenv("PG_RH_DEBUG")) fprintf(stderr, "rh size %llu keys %llu round %d: %llu time changes, %llu clusters to sweep again\n", (unsigned long long)S, (unsigned long long)M, round, n_chg, n_dirty_h);
             list_cur = list_next;
             list_next = list_cur == wk.list_a ? wk.list_b : wk.list_a;
         }
@@ -292,17 +295,25 @@ int layout_growable(BE& be, RhWork<BE>& wk, const uint64_t* rec, uint64_t n, con
     return rc;
 }
 
+// scratch bytes one call of layout_growable_sets takes for sets of at most n_max keys that grow out of at most owner_max slots
+inline uint64_t growable_scratch_bytes(uint64_t n_max, uint64_t owner_max) { return (RhWork<int>::bytes_per_key + 8) * n_max + 4 * owner_max + (1u << 20); }
+
 // P growable sets: records sorted by (set, ordinal) in backend memory; per_set_count, trailing (a duplicate put arrived after
 // the set's last new key), set_first_slot (the set's slot 0 in `nodes`, in slots) on the host.  nodes (optional): the image,
 // every slot's first word preset to SV_EMPTY -- a key's record words 0..NW go to its slot.  slots_all (optional, backend memory,
 // one entry a record): the slot within the set.
 template <class BE, int NW>
 int layout_growable_sets(BE& be, const uint64_t* records, const uint64_t* per_set_count, const unsigned char* trailing, int P, uint64_t init_size,
-                         const uint64_t* set_first_slot, uint64_t* nodes, unsigned long long* slots_all, uint64_t* rounds_out) {
+                         const uint64_t* set_first_slot, uint64_t* nodes, unsigned long long* slots_all, uint64_t* rounds_out, int s_begin = 0, int s_step = 1) {
+    // (s_begin, s_step: this call lays out the sets s_begin, s_begin + s_step, ... -- a round of the fixed point is a handful of
+    //  small dependent launches, so the caller runs several calls side by side, each on its own backend / stream)
     constexpr int RW = NW + 2;
     uint64_t n_max = 0, owner_max = 0;
     std::vector<std::vector<GrowEpoch>> sched(P);
+    std::vector<uint64_t> first_of((size_t)P + 1, 0);
     for (int s = 0; s < P; s++) {
+        first_of[s + 1] = first_of[s] + per_set_count[s];
+        if (s < s_begin || (s - s_begin) % s_step) continue;
         sched[s] = grow_schedule(per_set_count[s], trailing && trailing[s], init_size);
         n_max = std::max(n_max, per_set_count[s]);
         owner_max = std::max(owner_max, grow_owner_slots(sched[s]));
@@ -311,12 +322,10 @@ int layout_growable_sets(BE& be, const uint64_t* records, const uint64_t* per_se
     RhWork<BE> wk;
     unsigned long long* slots_tmp = slots_all ? nullptr : be.template alloc<unsigned long long>(n_max);
     int rc = wk.reserve(be, n_max, owner_max) ? PG_OK : PG_ENOMEM;
-    uint64_t first = 0;
-    for (int s = 0; s < P && rc == PG_OK && !be.error; s++) {
-        const uint64_t n = per_set_count[s];
+    for (int s = s_begin; s < P && rc == PG_OK && !be.error; s += s_step) {
+        const uint64_t n = per_set_count[s], first = first_of[s];
         const uint64_t* rec = records + first * RW;
         unsigned long long* slots = slots_all ? slots_all + first : slots_tmp;
-        first += n;
         if (!n) continue;
         int rounds = 0;
         rc = layout_growable<BE, NW>(be, wk, rec, n, sched[s], slots, &rounds);

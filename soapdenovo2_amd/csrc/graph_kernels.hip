@@ -25,6 +25,7 @@
 #include <algorithm>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/soapdenovo2_amd.h"
@@ -738,23 +739,53 @@ int p2_layout_rank_growable(int device, int nw, int n_own, const uint64_t* d_rec
     }
     const double t1 = now();
     hipLaunchKernelGGL(p2_empty_image, dim3(8192), dim3(256), 0, st, nodes, NW1, total);
-    int rc;
+    int rc = PG_OK;
     std::string why;
     std::vector<uint64_t> rounds((size_t)n_own, 0);
+    // A round of a set's fixed point is a handful of small dependent launches and two reads of a counter: latency, not work.
+    // Several sets side by side, each on its own stream, as many as the free memory holds scratch for (SOAPDENOVO2_AMD_LAYOUT_LANES)
+    int lanes = 1;
     {
-        HipBackend be(device, st);
-        rc = nw == 2 ? layout_growable_sets<HipBackend, 2>(be, d_records, own_counts, own_trailing, n_own, init_size, first_slot.data(), nodes, nullptr, rounds.data())
-                     : layout_growable_sets<HipBackend, 4>(be, d_records, own_counts, own_trailing, n_own, init_size, first_slot.data(), nodes, nullptr, rounds.data());
-        why = be.error_text;
+        uint64_t n_max = 0, owner_max = 0;
+        for (int s = 0; s < n_own; s++) {
+            n_max = std::max(n_max, own_counts[s]);
+            owner_max = std::max(owner_max, grow_owner_slots(grow_schedule(own_counts[s], own_trailing && own_trailing[s], init_size)));
+        }
+        size_t free_b = 0, total_b = 0;
+        const uint64_t one = growable_scratch_bytes(n_max, owner_max);
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) lanes = (int)std::min<uint64_t>(8, (uint64_t)((double)free_b * 0.85) / std::max<uint64_t>(one, 1));
+        if (const char* v = getenv("SOAPDENOVO2_AMD_LAYOUT_LANES")) lanes = atoi(v);
+        lanes = std::max(1, std::min(lanes, n_own));
     }
-    if (rc == PG_OK && hipStreamSynchronize(st) != hipSuccess) { rc = PG_ENODEV; why = "kernel failure"; }
+    if (hipStreamSynchronize(st) != hipSuccess) { rc = PG_ENODEV; why = "kernel failure"; }      // the image is empty before anybody writes to it
+    if (rc == PG_OK) {
+        std::vector<int> rcs((size_t)lanes, PG_OK);
+        std::vector<std::string> whys((size_t)lanes);
+        auto lane = [&](int t) {
+            hipStream_t ls = nullptr;
+            if (hipSetDevice(device) != hipSuccess || hipStreamCreateWithFlags(&ls, hipStreamNonBlocking) != hipSuccess) { rcs[t] = PG_ENODEV; whys[t] = "no stream"; return; }
+            {
+                HipBackend be(device, ls);
+                rcs[t] = nw == 2 ? layout_growable_sets<HipBackend, 2>(be, d_records, own_counts, own_trailing, n_own, init_size, first_slot.data(), nodes, nullptr, rounds.data(), t, lanes)
+                                 : layout_growable_sets<HipBackend, 4>(be, d_records, own_counts, own_trailing, n_own, init_size, first_slot.data(), nodes, nullptr, rounds.data(), t, lanes);
+                whys[t] = be.error_text;
+            }
+            if (rcs[t] == PG_OK && hipStreamSynchronize(ls) != hipSuccess) { rcs[t] = PG_ENODEV; whys[t] = "kernel failure"; }
+            (void)hipStreamDestroy(ls);
+        };
+        std::vector<std::thread> pool;
+        for (int t = 1; t < lanes; t++) pool.emplace_back(lane, t);
+        lane(0);
+        for (auto& th : pool) th.join();
+        for (int t = 0; t < lanes; t++) if (rcs[t] && !rc) { rc = rcs[t]; why = whys[t]; }
+    }
     (void)hipStreamDestroy(st);
     if (rc) { (void)hipFree(block ? block : (void*)nodes); pg_set_error("layout: " + (why.empty() ? std::string("failed") : why)); return rc < 0 ? rc : PG_ENODEV; }
     if (verbose) {
         uint64_t r_all = 0;
         for (uint64_t r : rounds) r_all += r;
-        fprintf(stderr, "growable sets on device %d: %d set(s), %llu slots in all, %s %.2fs, layout %.2fs (%llu rounds over all sizes)\n", device, n_own,
-                (unsigned long long)total, block ? "memory taken over from pass 1" : "allocation", t1 - t0, now() - t1, (unsigned long long)r_all);
+        fprintf(stderr, "growable sets on device %d: %d set(s), %llu slots in all, %s %.2fs, layout %.2fs (%llu rounds over all sizes, %d set(s) side by side)\n", device, n_own,
+                (unsigned long long)total, block ? "memory taken over from pass 1" : "allocation", t1 - t0, now() - t1, (unsigned long long)r_all, lanes);
     }
     *d_nodes_out = nodes;
     if (alloc_out) *alloc_out = block ? block : (void*)nodes;
