@@ -4,6 +4,9 @@
 #include <hipcub/hipcub.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
 
+#include <string.h>
+#include <time.h>
+
 #include <string>
 
 #include "backend.hpp"
@@ -30,10 +33,16 @@ struct HipBackend {
     std::string error_text;
     void* tmp = nullptr;
     size_t tmp_bytes = 0;
-    HipBackend(int device_, hipStream_t stream_) : device(device_), stream(stream_) { (void)hipSetDevice(device); }
+    void* pinned = nullptr;                       // 256 bytes of page-locked host memory: the fixed points read a counter or two per round
+    double t_readback = 0;                        // seconds spent in small read-backs (copy + wait), for the verbose lines
+    unsigned long long n_readback = 0;
+    HipBackend(int device_, hipStream_t stream_) : device(device_), stream(stream_) {
+        (void)hipSetDevice(device);
+        if (hipHostMalloc(&pinned, 256, hipHostMallocDefault) != hipSuccess) pinned = nullptr;
+    }
     HipBackend(const HipBackend&) = delete;
     HipBackend& operator=(const HipBackend&) = delete;
-    ~HipBackend() { if (tmp) (void)hipFree(tmp); }
+    ~HipBackend() { if (tmp) (void)hipFree(tmp); if (pinned) (void)hipHostFree(pinned); }
 
     bool ok(hipError_t e, const char* what) {
         if (e == hipSuccess) return true;
@@ -53,7 +62,21 @@ struct HipBackend {
         hipLaunchKernelGGL(be_fill_kernel<T>, dim3(grid), dim3(256), 0, stream, p, (uint64_t)n, v);
         ok(hipGetLastError(), "fill");
     }
-    template <typename T> void to_host(T* dst, const T* src, size_t n) { if (n && !error) { ok(hipMemcpyAsync((void*)dst, (const void*)src, n * sizeof(T), hipMemcpyDeviceToHost, stream), "copy to host"); ok(hipStreamSynchronize(stream), "sync"); } }
+    template <typename T> void to_host(T* dst, const T* src, size_t n) {
+        if (!n || error) return;
+        if (pinned && n * sizeof(T) <= 256) {                             // a pageable destination goes through a staging kernel and a second copy
+            struct timespec a, b;
+            clock_gettime(CLOCK_MONOTONIC, &a);
+            if (ok(hipMemcpyAsync(pinned, (const void*)src, n * sizeof(T), hipMemcpyDeviceToHost, stream), "copy to host") && ok(hipStreamSynchronize(stream), "sync"))
+                memcpy((void*)dst, pinned, n * sizeof(T));
+            clock_gettime(CLOCK_MONOTONIC, &b);
+            t_readback += (double)(b.tv_sec - a.tv_sec) + 1e-9 * (double)(b.tv_nsec - a.tv_nsec);
+            n_readback++;
+            return;
+        }
+        ok(hipMemcpyAsync((void*)dst, (const void*)src, n * sizeof(T), hipMemcpyDeviceToHost, stream), "copy to host");
+        ok(hipStreamSynchronize(stream), "sync");
+    }
     template <typename T> void to_device(T* dst, const T* src, size_t n) { if (n && !error) { ok(hipMemcpyAsync((void*)dst, (const void*)src, n * sizeof(T), hipMemcpyHostToDevice, stream), "copy to device"); ok(hipStreamSynchronize(stream), "sync"); } }
     template <typename T> void copy(T* dst, const T* src, size_t n) { if (n && !error) ok(hipMemcpyAsync((void*)dst, (const void*)src, n * sizeof(T), hipMemcpyDeviceToDevice, stream), "copy"); }
     void sync() { if (!error) ok(hipStreamSynchronize(stream), "sync"); }

@@ -31,6 +31,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <time.h>
 
 #include <vector>
 
@@ -174,8 +175,11 @@ int layout_growable(BE& be, RhWork<BE>& wk, const uint64_t* rec, uint64_t n, con
     unsigned int* dirty = wk.dirty;
     unsigned long long* slot_new = slots_out;
     int rc = PG_OK;
+    const bool rh_debug = getenv("PG_RH_DEBUG") != nullptr;
+    auto rh_now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
     for (size_t ei = 0; ei < sched.size() && !be.error && rc == PG_OK; ei++) {
         const GrowEpoch ep = sched[ei];
+        const double t_epoch = rh_debug ? rh_now() : 0.0;
         const uint64_t S = ep.size, M = ep.n_end, n_old = ep.n_old;
         const uint64_t s_prev = ei ? sched[ei - 1].size : 0;
         if (!M) continue;
@@ -256,6 +260,7 @@ int layout_growable(BE& be, RhWork<BE>& wk, const uint64_t* rec, uint64_t n, con
                 be.launch(n_old, [=] PG_LAMBDA(uint64_t i) { elem_prev[sp[i]] = (uint32_t)i; });
             }
         }
+        if (rh_debug) { be.sync(); fprintf(stderr, "rh size %llu keys %llu: sort, clusters, times ready %.3f ms since the size began\n", (unsigned long long)S, (unsigned long long)M, 1e3 * (rh_now() - t_epoch)); }
         // ---- the fixed point: sweep (every cluster first, then the listed ones), apply the changes it found, list their clusters
         uint32_t* list_cur = nullptr;
         uint32_t* list_next = wk.list_a;
@@ -284,7 +289,8 @@ int layout_growable(BE& be, RhWork<BE>& wk, const uint64_t* rec, uint64_t n, con
             be.to_host(&n_dirty_h, scal + 1, 1);
             if (be.error) break;
             n_list = n_dirty_h;
-            if (getenv("PG_RH_DEBUG")) fprintf(stderr, "rh size %llu keys %llu round %d: %llu time changes, %llu clusters to sweep again\n", (unsigned long long)S, (unsigned long long)M, round, n_chg, n_dirty_h);
+            if (rh_debug) fprintf(stderr, "rh size %llu keys %llu round %d: %llu time changes, %llu clusters to sweep again, %.3f ms since the size began\n", (unsigned long long)S,
+                                  (unsigned long long)M, round, n_chg, n_dirty_h, 1e3 * (rh_now() - t_epoch));
             list_cur = list_next;
             list_next = list_cur == wk.list_a ? wk.list_b : wk.list_a;
         }

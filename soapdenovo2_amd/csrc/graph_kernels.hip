@@ -769,6 +769,7 @@ int p2_layout_rank_growable(int device, int nw, int n_own, const uint64_t* d_rec
                 rcs[t] = nw == 2 ? layout_growable_sets<HipBackend, 2>(be, d_records, own_counts, own_trailing, n_own, init_size, first_slot.data(), nodes, nullptr, rounds.data(), t, lanes)
                                  : layout_growable_sets<HipBackend, 4>(be, d_records, own_counts, own_trailing, n_own, init_size, first_slot.data(), nodes, nullptr, rounds.data(), t, lanes);
                 whys[t] = be.error_text;
+                if (verbose) fprintf(stderr, "growable layout, lane %d: %llu read-backs of a counter, %.2fs waiting for them\n", t, be.n_readback, be.t_readback);
             }
             if (rcs[t] == PG_OK && hipStreamSynchronize(ls) != hipSuccess) { rcs[t] = PG_ENODEV; whys[t] = "kernel failure"; }
             (void)hipStreamDestroy(ls);
