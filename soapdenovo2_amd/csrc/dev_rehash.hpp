@@ -44,6 +44,7 @@ namespace pg {
 
 constexpr int RH_DEPTH_BITS = 22;                  // time = origin << 22 | depth
 constexpr uint32_t RH_NONE = 0xFFFFFFFFu;
+constexpr unsigned long long RH_NO_TIME = ~0ULL;
 
 // one probe cluster: the slots of frame [hs[j], ...) take the pending element with the smallest time; the old element of every
 // slot met on the way is given the time the slot's new occupant implies -- if that is not the time it has, onto the change list
@@ -51,13 +52,14 @@ struct RhSweep {
     const uint64_t* hs;                 // homes in the frame, sorted
     const uint32_t* is;                 // elements in the same order
     const long long* m;                 // prefix maximum of hs[j] - j
-    const unsigned long long* T;        // time of every element (read only here)
+    const unsigned long long* Ts;       // time of every element, in the sorted order (read only here)
+    const unsigned long long* T_old;    // per table slot j < n_prev: the time of the element that sat there before the growth (RH_NO_TIME: nobody)
     unsigned int* dirty;                // per sorted position: the cluster that starts here is on the list
     const uint32_t* list;               // cluster starts to sweep (null: every cluster, lane = sorted position)
     unsigned long long* heap_t;
     uint32_t* heap_e;
     unsigned long long* slot_new;       // table slot of every element
-    const uint32_t* elem_prev;          // element that sat on table slot j before the growth, for j < n_prev (RH_NONE: nobody)
+    const uint32_t* elem_prev;          // ... and which element that is
     uint32_t* chg_e;                    // changes: element, time
     unsigned long long* chg_t;
     unsigned long long* n_chg;
@@ -72,8 +74,8 @@ struct RhSweep {
         uint64_t hn = 0, nxt = j, p = hs[j];
         for (;;) {
             while (nxt < n && hs[nxt] <= p) {
+                const unsigned long long t = Ts[nxt];
                 const uint32_t e = is[nxt++];
-                const unsigned long long t = T[e];
                 uint64_t c = hn++;
                 while (c) { const uint64_t par = (c - 1) >> 1; if (ht[par] <= t) break; ht[c] = ht[par]; he[c] = he[par]; c = par; }
                 ht[c] = t; he[c] = e;
@@ -99,14 +101,16 @@ struct RhSweep {
             if (slot >= S) slot -= S;
             slot_new[first] = slot;
             if (slot < n_prev) {
-                const uint32_t e = elem_prev[slot];
-                if (e != RH_NONE) {
+                // (times are unique, so "the slot's old element came to rest on it itself" is t_first == told; everything the
+                //  sweep reads lies in the order it walks: sorted position or slot)
+                const unsigned long long told = T_old[slot];
+                if (told != RH_NO_TIME) {
                     const unsigned long long natural = (unsigned long long)slot << RH_DEPTH_BITS;
                     unsigned long long t = natural;
-                    if (e != first && t_first < natural) t = t_first + 1;   // `first` came to rest here before the walk reached the slot: e went next
-                    if (t != T[e]) {
+                    if (t_first != told && t_first < natural) t = t_first + 1;   // `first` came to rest here before the walk reached the slot: the old element went next
+                    if (t != told) {
                         const unsigned long long at = hd_atomic_add(n_chg, 1ULL);
-                        chg_e[at] = e; chg_t[at] = t;
+                        chg_e[at] = elem_prev[slot]; chg_t[at] = t;
                     }
                 }
             }
@@ -121,7 +125,7 @@ struct RhWork {
     uint64_t *hk = nullptr, *hs = nullptr, *hr = nullptr;
     uint32_t *iv = nullptr, *is = nullptr, *ir = nullptr, *pos_of = nullptr, *heap_e = nullptr, *elem_prev = nullptr, *chg_e = nullptr, *list_a = nullptr, *list_b = nullptr;
     long long *v = nullptr, *m = nullptr, *cs = nullptr;
-    unsigned long long *T = nullptr, *chg_t = nullptr, *heap_t = nullptr, *slot_prev = nullptr, *scal = nullptr;
+    unsigned long long *Ts = nullptr, *T_old = nullptr, *chg_t = nullptr, *heap_t = nullptr, *slot_prev = nullptr, *scal = nullptr;
     unsigned int* dirty = nullptr;
     uint64_t cap = 0, owner_cap = 0;
     bool reserve(BE& be, uint64_t n, uint64_t n_owner) {
@@ -132,19 +136,19 @@ struct RhWork {
         v = be.template alloc<long long>(n); m = be.template alloc<long long>(n);
         cs = be.template alloc<long long>(n);                          // cluster start (sorted position) of every sorted position
         pos_of = be.template alloc<uint32_t>(n);                       // sorted position of every element
-        T = be.template alloc<unsigned long long>(n);
+        Ts = be.template alloc<unsigned long long>(n);
         chg_e = be.template alloc<uint32_t>(n); chg_t = be.template alloc<unsigned long long>(n);      // at most one change an old element a round
         list_a = be.template alloc<uint32_t>(n); list_b = be.template alloc<uint32_t>(n);             // cluster starts to sweep, this round's and the next's
         dirty = be.template alloc<unsigned int>(n);
         heap_t = be.template alloc<unsigned long long>(n); heap_e = be.template alloc<uint32_t>(n);
         slot_prev = be.template alloc<unsigned long long>(n);
-        elem_prev = be.template alloc<uint32_t>(owner_cap);
+        elem_prev = be.template alloc<uint32_t>(owner_cap); T_old = be.template alloc<unsigned long long>(owner_cap);
         scal = be.template alloc<unsigned long long>(4);
         return !be.error;
     }
     void release(BE& be) {
         be.release(hk); be.release(hs); be.release(hr); be.release(iv); be.release(is); be.release(ir); be.release(v); be.release(m); be.release(cs);
-        be.release(pos_of); be.release(T); be.release(chg_e); be.release(chg_t); be.release(list_a); be.release(list_b); be.release(dirty); be.release(heap_t); be.release(heap_e);
+        be.release(pos_of); be.release(Ts); be.release(T_old); be.release(chg_e); be.release(chg_t); be.release(list_a); be.release(list_b); be.release(dirty); be.release(heap_t); be.release(heap_e);
         be.release(slot_prev); be.release(elem_prev); be.release(scal);
         *this = RhWork();
     }
@@ -171,7 +175,7 @@ int layout_growable(BE& be, RhWork<BE>& wk, const uint64_t* rec, uint64_t n, con
     uint64_t *hk = wk.hk, *hs = wk.hs, *hr = wk.hr;
     uint32_t *iv = wk.iv, *is = wk.is, *ir = wk.ir, *pos_of = wk.pos_of, *heap_e = wk.heap_e, *elem_prev = wk.elem_prev, *chg_e = wk.chg_e;
     long long *v = wk.v, *m = wk.m, *cs = wk.cs;
-    unsigned long long *T = wk.T, *chg_t = wk.chg_t, *heap_t = wk.heap_t, *slot_prev = wk.slot_prev, *scal = wk.scal;
+    unsigned long long *Ts = wk.Ts, *T_old = wk.T_old, *chg_t = wk.chg_t, *heap_t = wk.heap_t, *slot_prev = wk.slot_prev, *scal = wk.scal;
     unsigned int* dirty = wk.dirty;
     unsigned long long* slot_new = slots_out;
     int rc = PG_OK;
@@ -252,13 +256,15 @@ int layout_growable(BE& be, RhWork<BE>& wk, const uint64_t* rec, uint64_t n, con
             });
             be.inclusive_max(v, cs, M);
             const unsigned long long* sp = slot_prev;
-            be.launch(M, [=] PG_LAMBDA(uint64_t i) {
-                T[i] = (i < n_old ? sp[i] : (unsigned long long)(s_prev + (i - n_old))) << RH_DEPTH_BITS;
-            });
             if (n_old) {
                 be.fill(elem_prev, (size_t)s_prev, RH_NONE);
-                be.launch(n_old, [=] PG_LAMBDA(uint64_t i) { elem_prev[sp[i]] = (uint32_t)i; });
+                be.fill(T_old, (size_t)s_prev, RH_NO_TIME);
             }
+            be.launch(M, [=] PG_LAMBDA(uint64_t i) {
+                const unsigned long long t = (i < n_old ? sp[i] : (unsigned long long)(s_prev + (i - n_old))) << RH_DEPTH_BITS;
+                Ts[pos_of[i]] = t;
+                if (i < n_old) { elem_prev[sp[i]] = (uint32_t)i; T_old[sp[i]] = t; }
+            });
         }
         if (rh_debug) { be.sync(); fprintf(stderr, "rh size %llu keys %llu: sort, clusters, times ready %.3f ms since the size began\n", (unsigned long long)S, (unsigned long long)M, 1e3 * (rh_now() - t_epoch)); }
         // ---- the fixed point: sweep (every cluster first, then the listed ones), apply the changes it found, list their clusters
@@ -269,19 +275,22 @@ int layout_growable(BE& be, RhWork<BE>& wk, const uint64_t* rec, uint64_t n, con
             if (round > 100000) { rc = PG_EINVAL; be.error_text = "layout_growable: the fixed point did not settle"; break; }
             if (rounds_out) (*rounds_out)++;
             be.fill(scal, 2, 0ULL);
-            be.launch(n_list, RhSweep{hs_use, is_use, m, T, dirty, list_cur, heap_t, heap_e, slot_new, elem_prev, chg_e, chg_t, scal, M, S, origin, n_old ? s_prev : 0});
+            be.launch(n_list, RhSweep{hs_use, is_use, m, Ts, T_old, dirty, list_cur, heap_t, heap_e, slot_new, elem_prev, chg_e, chg_t, scal, M, S, origin, n_old ? s_prev : 0});
             if (!n_old) break;                                        // nobody was there before: arrival order is all there is
             unsigned long long n_chg = 0;
             be.to_host(&n_chg, scal, 1);
             if (be.error || !n_chg) break;
             {
                 const long long* csp = cs;
+                const unsigned long long* sp2 = slot_prev;
                 uint32_t* ln = list_next;
                 unsigned long long* n_dirty = scal + 1;
                 be.launch(n_chg, [=] PG_LAMBDA(uint64_t c) {
                     const uint32_t e = chg_e[c];
-                    T[e] = chg_t[c];
-                    const uint32_t start = (uint32_t)csp[pos_of[e]];
+                    const uint32_t pos = pos_of[e];
+                    Ts[pos] = chg_t[c];
+                    T_old[sp2[e]] = chg_t[c];
+                    const uint32_t start = (uint32_t)csp[pos];
                     if (hd_atomic_exch(&dirty[start], 1u) == 0u) ln[hd_atomic_add(n_dirty, 1ULL)] = start;
                 });
             }
@@ -302,7 +311,7 @@ int layout_growable(BE& be, RhWork<BE>& wk, const uint64_t* rec, uint64_t n, con
 }
 
 // scratch bytes one call of layout_growable_sets takes for sets of at most n_max keys that grow out of at most owner_max slots
-inline uint64_t growable_scratch_bytes(uint64_t n_max, uint64_t owner_max) { return (RhWork<int>::bytes_per_key + 8) * n_max + 4 * owner_max + (1u << 20); }
+inline uint64_t growable_scratch_bytes(uint64_t n_max, uint64_t owner_max) { return (RhWork<int>::bytes_per_key + 8) * n_max + 12 * owner_max + (1u << 20); }
 
 // P growable sets: records sorted by (set, ordinal) in backend memory; per_set_count, trailing (a duplicate put arrived after
 // the set's last new key), set_first_slot (the set's slot 0 in `nodes`, in slots) on the host.  nodes (optional): the image,
