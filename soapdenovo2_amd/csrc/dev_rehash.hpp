@@ -69,33 +69,56 @@ struct RhSweep {
         if (list) j = list[lane];
         else if (j && m[j] <= m[j - 1]) return;                     // not the first key of a cluster
         dirty[j] = 0;
+        // the pending elements: the RF earliest wait in registers (sorted; all-ones = free), the rest in a heap whose storage is
+        // the cluster's own stretch of the heap arrays -- most clusters never touch it, and a heap in memory is a chain of
+        // dependent round trips per element
+        constexpr int RF = 6;
+        unsigned long long rt[RF];
+        uint32_t re[RF];
+#pragma unroll
+        for (int i = 0; i < RF; i++) { rt[i] = RH_NO_TIME; re[i] = 0; }
         unsigned long long* ht = heap_t + j;
         uint32_t* he = heap_e + j;
         uint64_t hn = 0, nxt = j, p = hs[j];
         for (;;) {
             while (nxt < n && hs[nxt] <= p) {
-                const unsigned long long t = Ts[nxt];
-                const uint32_t e = is[nxt++];
-                uint64_t c = hn++;
-                while (c) { const uint64_t par = (c - 1) >> 1; if (ht[par] <= t) break; ht[c] = ht[par]; he[c] = he[par]; c = par; }
-                ht[c] = t; he[c] = e;
-            }
-            if (!hn) return;
-            const uint32_t first = he[0];
-            const unsigned long long t_first = ht[0];
-            hn--;
-            const unsigned long long lt = ht[hn];
-            const uint32_t le = he[hn];
-            if (hn) {
-                uint64_t c = 0;
-                for (;;) {
-                    uint64_t ch = 2 * c + 1;
-                    if (ch >= hn) break;
-                    if (ch + 1 < hn && ht[ch + 1] < ht[ch]) ch++;
-                    if (ht[ch] >= lt) break;
-                    ht[c] = ht[ch]; he[c] = he[ch]; c = ch;
+                unsigned long long t = Ts[nxt];
+                uint32_t e = is[nxt++];
+#pragma unroll
+                for (int i = 0; i < RF; i++)                         // into the sorted registers; what falls out at the end is the latest of them
+                    if (t < rt[i]) { const unsigned long long xt = rt[i]; const uint32_t xe = re[i]; rt[i] = t; re[i] = e; t = xt; e = xe; }
+                if (t != RH_NO_TIME) {
+                    uint64_t c = hn++;
+                    while (c) { const uint64_t par = (c - 1) >> 1; if (ht[par] <= t) break; ht[c] = ht[par]; he[c] = he[par]; c = par; }
+                    ht[c] = t; he[c] = e;
                 }
-                ht[c] = lt; he[c] = le;
+            }
+            uint32_t first;
+            unsigned long long t_first;
+            if (hn && ht[0] < rt[0]) {                              // (an element that fell out of full registers can be earlier than one that came later)
+                first = he[0];
+                t_first = ht[0];
+                hn--;
+                const unsigned long long lt = ht[hn];
+                const uint32_t le = he[hn];
+                if (hn) {
+                    uint64_t c = 0;
+                    for (;;) {
+                        uint64_t ch = 2 * c + 1;
+                        if (ch >= hn) break;
+                        if (ch + 1 < hn && ht[ch + 1] < ht[ch]) ch++;
+                        if (ht[ch] >= lt) break;
+                        ht[c] = ht[ch]; he[c] = he[ch]; c = ch;
+                    }
+                    ht[c] = lt; he[c] = le;
+                }
+            } else {
+                if (rt[0] == RH_NO_TIME) return;                    // nothing pending: the next key starts its own cluster
+                first = re[0];
+                t_first = rt[0];
+#pragma unroll
+                for (int i = 0; i + 1 < RF; i++) { rt[i] = rt[i + 1]; re[i] = re[i + 1]; }
+                rt[RF - 1] = RH_NO_TIME;
             }
             uint64_t slot = p + origin;
             if (slot >= S) slot -= S;
