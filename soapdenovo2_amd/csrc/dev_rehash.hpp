@@ -60,15 +60,18 @@ struct RhSweep {
     uint32_t* heap_e;
     unsigned long long* slot_new;       // table slot of every element
     const uint32_t* elem_prev;          // ... and which element that is
-    uint32_t* chg_e;                    // changes: element, time
-    unsigned long long* chg_t;
-    unsigned long long* n_chg;
+    uint32_t* chg_e;                    // changes (element, time): a cluster's go into ITS stretch of these arrays (it places as many
+    unsigned long long* chg_t;          //   elements as it has, and every placement changes at most one old element), chg_n[start] of them --
+    uint32_t* chg_n;                    //   one counter for all of them would be a returned atomic on one address inside the loop
+    unsigned long long* n_chg;          // their number over the round
     uint64_t n, S, origin, n_prev;
+    int only_dirty;                     // (list == null) skip the clusters whose flag is down
     PG_HD void operator()(uint64_t lane) const {
         uint64_t j = lane;
         if (list) j = list[lane];
-        else if (j && m[j] <= m[j - 1]) return;                     // not the first key of a cluster
+        else if ((j && m[j] <= m[j - 1]) || (only_dirty && !dirty[j])) return;     // not the first key of a cluster / nothing changed in it
         dirty[j] = 0;
+        uint32_t n_found = 0;
         // the pending elements: the RF earliest wait in registers (sorted; all-ones = free), the rest in a heap whose storage is
         // the cluster's own stretch of the heap arrays -- most clusters never touch it, and a heap in memory is a chain of
         // dependent round trips per element
@@ -113,7 +116,7 @@ struct RhSweep {
                     ht[c] = lt; he[c] = le;
                 }
             } else {
-                if (rt[0] == RH_NO_TIME) return;                    // nothing pending: the next key starts its own cluster
+                if (rt[0] == RH_NO_TIME) break;                     // nothing pending: the next key starts its own cluster
                 first = re[0];
                 t_first = rt[0];
 #pragma unroll
@@ -132,13 +135,54 @@ struct RhSweep {
                     unsigned long long t = natural;
                     if (t_first != told && t_first < natural) t = t_first + 1;   // `first` came to rest here before the walk reached the slot: the old element went next
                     if (t != told) {
-                        const unsigned long long at = hd_atomic_add(n_chg, 1ULL);
-                        chg_e[at] = elem_prev[slot]; chg_t[at] = t;
+                        chg_e[j + n_found] = elem_prev[slot]; chg_t[j + n_found] = t;
+                        n_found++;
                     }
                 }
             }
             p++;
         }
+        chg_n[j] = n_found;
+        if (n_found) hd_atomic_add(n_chg, (unsigned long long)n_found);
+    }
+};
+
+// between two sweeps: the changes a cluster's sweep found are applied -- the times where the next sweep reads them (by sorted
+// position, by old slot) -- and the clusters of the changed elements flagged; with want_list they are listed as well (few changes:
+// the next sweep runs over the list; many: over all positions, looking at the flags -- a list would be built by an atomic each)
+struct RhApply {
+    const uint32_t* list;               // clusters swept this round (null: all positions)
+    uint32_t* chg_n;
+    const uint32_t* chg_e;
+    const unsigned long long* chg_t;
+    const uint32_t* pos_of;
+    const long long* cs;
+    const unsigned long long* slot_prev;
+    unsigned long long* Ts;
+    unsigned long long* T_old;
+    unsigned int* dirty;
+    uint32_t* list_next;
+    unsigned long long* n_dirty;
+    int want_list;
+    PG_HD void operator()(uint64_t lane) const {
+        const uint64_t j = list ? list[lane] : lane;
+        const uint32_t k = chg_n[j];
+        if (!k) return;
+        chg_n[j] = 0;
+        uint32_t fresh = 0;
+        for (uint32_t i = 0; i < k; i++) {
+            const uint32_t e = chg_e[j + i];
+            const unsigned long long t = chg_t[j + i];
+            const uint32_t pos = pos_of[e];
+            Ts[pos] = t;
+            T_old[slot_prev[e]] = t;
+            const uint32_t start = (uint32_t)cs[pos];
+            if (hd_atomic_exch(&dirty[start], 1u) == 0u) {
+                if (want_list) list_next[hd_atomic_add(n_dirty, 1ULL)] = start;
+                else fresh++;
+            }
+        }
+        if (fresh) hd_atomic_add(n_dirty, (unsigned long long)fresh);
     }
 };
 
@@ -146,7 +190,7 @@ struct RhSweep {
 template <class BE>
 struct RhWork {
     uint64_t *hk = nullptr, *hs = nullptr, *hr = nullptr;
-    uint32_t *iv = nullptr, *is = nullptr, *ir = nullptr, *pos_of = nullptr, *heap_e = nullptr, *elem_prev = nullptr, *chg_e = nullptr, *list_a = nullptr, *list_b = nullptr;
+    uint32_t *iv = nullptr, *is = nullptr, *ir = nullptr, *pos_of = nullptr, *heap_e = nullptr, *elem_prev = nullptr, *chg_e = nullptr, *chg_n = nullptr, *list_a = nullptr, *list_b = nullptr;
     long long *v = nullptr, *m = nullptr, *cs = nullptr;
     unsigned long long *Ts = nullptr, *T_old = nullptr, *chg_t = nullptr, *heap_t = nullptr, *slot_prev = nullptr, *scal = nullptr;
     unsigned int* dirty = nullptr;
@@ -160,7 +204,7 @@ struct RhWork {
         cs = be.template alloc<long long>(n);                          // cluster start (sorted position) of every sorted position
         pos_of = be.template alloc<uint32_t>(n);                       // sorted position of every element
         Ts = be.template alloc<unsigned long long>(n);
-        chg_e = be.template alloc<uint32_t>(n); chg_t = be.template alloc<unsigned long long>(n);      // at most one change an old element a round
+        chg_e = be.template alloc<uint32_t>(n); chg_t = be.template alloc<unsigned long long>(n); chg_n = be.template alloc<uint32_t>(n);
         list_a = be.template alloc<uint32_t>(n); list_b = be.template alloc<uint32_t>(n);             // cluster starts to sweep, this round's and the next's
         dirty = be.template alloc<unsigned int>(n);
         heap_t = be.template alloc<unsigned long long>(n); heap_e = be.template alloc<uint32_t>(n);
@@ -171,12 +215,12 @@ struct RhWork {
     }
     void release(BE& be) {
         be.release(hk); be.release(hs); be.release(hr); be.release(iv); be.release(is); be.release(ir); be.release(v); be.release(m); be.release(cs);
-        be.release(pos_of); be.release(Ts); be.release(T_old); be.release(chg_e); be.release(chg_t); be.release(list_a); be.release(list_b); be.release(dirty); be.release(heap_t); be.release(heap_e);
+        be.release(pos_of); be.release(Ts); be.release(T_old); be.release(chg_e); be.release(chg_t); be.release(chg_n); be.release(list_a); be.release(list_b); be.release(dirty); be.release(heap_t); be.release(heap_e);
         be.release(slot_prev); be.release(elem_prev); be.release(scal);
         *this = RhWork();
     }
     // bytes a key / an old slot (for the caller's memory planning)
-    static constexpr uint64_t bytes_per_key = 8 * 3 + 4 * 3 + 8 * 3 + 4 + 8 + 12 + 8 + 4 + 8 + 4 + 8;
+    static constexpr uint64_t bytes_per_key = 8 * 3 + 4 * 3 + 8 * 3 + 4 + 8 + 16 + 8 + 4 + 8 + 4 + 8;
 };
 // the largest old size a schedule's growths walk over
 inline uint64_t grow_owner_slots(const std::vector<GrowEpoch>& sched) {
@@ -196,7 +240,7 @@ int layout_growable(BE& be, RhWork<BE>& wk, const uint64_t* rec, uint64_t n, con
     if (n >= 0xFFFFFFF0ULL) { be.error_text = "layout_growable: more than 2^32 keys in a set"; return PG_EINVAL; }
     if (n > wk.cap || grow_owner_slots(sched) > wk.owner_cap) { be.error_text = "layout_growable: scratch too small"; return PG_EINVAL; }
     uint64_t *hk = wk.hk, *hs = wk.hs, *hr = wk.hr;
-    uint32_t *iv = wk.iv, *is = wk.is, *ir = wk.ir, *pos_of = wk.pos_of, *heap_e = wk.heap_e, *elem_prev = wk.elem_prev, *chg_e = wk.chg_e;
+    uint32_t *iv = wk.iv, *is = wk.is, *ir = wk.ir, *pos_of = wk.pos_of, *heap_e = wk.heap_e, *elem_prev = wk.elem_prev, *chg_e = wk.chg_e, *chg_n = wk.chg_n;
     long long *v = wk.v, *m = wk.m, *cs = wk.cs;
     unsigned long long *Ts = wk.Ts, *T_old = wk.T_old, *chg_t = wk.chg_t, *heap_t = wk.heap_t, *slot_prev = wk.slot_prev, *scal = wk.scal;
     unsigned int* dirty = wk.dirty;
@@ -276,6 +320,7 @@ int layout_growable(BE& be, RhWork<BE>& wk, const uint64_t* rec, uint64_t n, con
                 pos_of[isu[j]] = (uint32_t)j;
                 v[j] = (j == 0 || mm[j] > mm[j - 1]) ? (long long)j : 0;
                 dirty[j] = 0u;
+                chg_n[j] = 0u;
             });
             be.inclusive_max(v, cs, M);
             const unsigned long long* sp = slot_prev;
@@ -291,40 +336,34 @@ int layout_growable(BE& be, RhWork<BE>& wk, const uint64_t* rec, uint64_t n, con
         }
         if (rh_debug) { be.sync(); fprintf(stderr, "rh size %llu keys %llu: sort, clusters, times ready %.3f ms since the size began\n", (unsigned long long)S, (unsigned long long)M, 1e3 * (rh_now() - t_epoch)); }
         // ---- the fixed point: sweep (every cluster first, then the listed ones), apply the changes it found, list their clusters
-        uint32_t* list_cur = nullptr;
+        const uint32_t* list_cur = nullptr;                           // null: the sweep runs over all positions
         uint32_t* list_next = wk.list_a;
-        uint64_t n_list = M;
+        uint64_t n_list = 0;
+        const uint64_t list_max = std::max<uint64_t>(1024, M >> 10);  // more changes than this: flags and a sweep over all positions cost less than a list
         for (int round = 0;; round++) {
             if (round > 100000) { rc = PG_EINVAL; be.error_text = "layout_growable: the fixed point did not settle"; break; }
             if (rounds_out) (*rounds_out)++;
             be.fill(scal, 2, 0ULL);
-            be.launch(n_list, RhSweep{hs_use, is_use, m, Ts, T_old, dirty, list_cur, heap_t, heap_e, slot_new, elem_prev, chg_e, chg_t, scal, M, S, origin, n_old ? s_prev : 0});
+            be.launch(list_cur ? n_list : M, RhSweep{hs_use, is_use, m, Ts, T_old, dirty, list_cur, heap_t, heap_e, slot_new, elem_prev, chg_e, chg_t, chg_n, scal, M, S, origin,
+                                                     n_old ? s_prev : 0, round > 0});
             if (!n_old) break;                                        // nobody was there before: arrival order is all there is
             unsigned long long n_chg = 0;
             be.to_host(&n_chg, scal, 1);
             if (be.error || !n_chg) break;
-            {
-                const long long* csp = cs;
-                const unsigned long long* sp2 = slot_prev;
-                uint32_t* ln = list_next;
-                unsigned long long* n_dirty = scal + 1;
-                be.launch(n_chg, [=] PG_LAMBDA(uint64_t c) {
-                    const uint32_t e = chg_e[c];
-                    const uint32_t pos = pos_of[e];
-                    Ts[pos] = chg_t[c];
-                    T_old[sp2[e]] = chg_t[c];
-                    const uint32_t start = (uint32_t)csp[pos];
-                    if (hd_atomic_exch(&dirty[start], 1u) == 0u) ln[hd_atomic_add(n_dirty, 1ULL)] = start;
-                });
-            }
+            const bool want_list = n_chg <= list_max;
+            be.launch(list_cur ? n_list : M, RhApply{list_cur, chg_n, chg_e, chg_t, pos_of, cs, slot_prev, Ts, T_old, dirty, list_next, scal + 1, want_list});
             unsigned long long n_dirty_h = 0;
             be.to_host(&n_dirty_h, scal + 1, 1);
             if (be.error) break;
-            n_list = n_dirty_h;
             if (rh_debug) fprintf(stderr, "rh size %llu keys %llu round %d: %llu time changes, %llu clusters to sweep again, %.3f ms since the size began\n", (unsigned long long)S,
                                   (unsigned long long)M, round, n_chg, n_dirty_h, 1e3 * (rh_now() - t_epoch));
-            list_cur = list_next;
-            list_next = list_cur == wk.list_a ? wk.list_b : wk.list_a;
+            if (want_list) {
+                n_list = n_dirty_h;
+                list_cur = list_next;
+                list_next = list_cur == wk.list_a ? wk.list_b : wk.list_a;
+            } else {
+                list_cur = nullptr;
+            }
         }
         if (ei + 1 < sched.size()) be.copy(slot_prev, slot_new, M);
     }
