@@ -148,8 +148,8 @@ struct RhSweep {
 };
 
 // between two sweeps: the changes a cluster's sweep found are applied -- the times where the next sweep reads them (by sorted
-// position, by old slot) -- and the clusters of the changed elements flagged; with want_list they are listed as well (few changes:
-// the next sweep runs over the list; many: over all positions, looking at the flags -- a list would be built by an atomic each)
+// position, by old slot) -- and the clusters of the changed elements flagged; with want_list they are listed as well, by an atomic
+// each (few changes; many: the caller makes the list from the flags)
 struct RhApply {
     const uint32_t* list;               // clusters swept this round (null: all positions)
     uint32_t* chg_n;
@@ -339,7 +339,7 @@ int layout_growable(BE& be, RhWork<BE>& wk, const uint64_t* rec, uint64_t n, con
         const uint32_t* list_cur = nullptr;                           // null: the sweep runs over all positions
         uint32_t* list_next = wk.list_a;
         uint64_t n_list = 0;
-        const uint64_t list_max = std::max<uint64_t>(1024, M >> 10);  // more changes than this: flags and a sweep over all positions cost less than a list
+        const uint64_t list_max = std::max<uint64_t>(1024, M >> 10);  // more changes than this: the list is made from the flags by a prefix sum, not by an atomic a cluster
         for (int round = 0;; round++) {
             if (round > 100000) { rc = PG_EINVAL; be.error_text = "layout_growable: the fixed point did not settle"; break; }
             if (rounds_out) (*rounds_out)++;
@@ -357,13 +357,20 @@ int layout_growable(BE& be, RhWork<BE>& wk, const uint64_t* rec, uint64_t n, con
             if (be.error) break;
             if (rh_debug) fprintf(stderr, "rh size %llu keys %llu round %d: %llu time changes, %llu clusters to sweep again, %.3f ms since the size began\n", (unsigned long long)S,
                                   (unsigned long long)M, round, n_chg, n_dirty_h, 1e3 * (rh_now() - t_epoch));
-            if (want_list) {
-                n_list = n_dirty_h;
-                list_cur = list_next;
-                list_next = list_cur == wk.list_a ? wk.list_b : wk.list_a;
-            } else {
-                list_cur = nullptr;
+            if (!want_list) {
+                // many clusters: the list by a prefix sum over the flags (a sweep over all positions that looks at the flags would
+                // run with a few live lanes a wave; listed clusters fill the waves)
+                unsigned long long* f64 = (unsigned long long*)hk;      // (the unsorted homes are done with)
+                unsigned long long* at64 = (unsigned long long*)v;      // (so are the scans' inputs)
+                unsigned int* dd = dirty;
+                uint32_t* ln = list_next;
+                be.launch(M, [=] PG_LAMBDA(uint64_t j) { f64[j] = dd[j] ? 1ULL : 0ULL; });
+                be.exclusive_sum(f64, at64, M);
+                be.launch(M, [=] PG_LAMBDA(uint64_t j) { if (dd[j]) ln[at64[j]] = (uint32_t)j; });
             }
+            n_list = n_dirty_h;
+            list_cur = list_next;
+            list_next = list_cur == wk.list_a ? wk.list_b : wk.list_a;
         }
         if (ei + 1 < sched.size()) be.copy(slot_prev, slot_new, M);
     }
