@@ -8,8 +8,10 @@
 // straddle a 32 KiB chunk, a file whose size is a multiple of 32768).
 #include "host_reads.hpp"
 
+#include <fcntl.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/mman.h>
 #include <sys/stat.h>
 #include <unistd.h>
 #include <zlib.h>
@@ -372,8 +374,20 @@ long long stream_file_parallel(const InputFile& in, const std::string& path, boo
     Source src;
     src.open(path);
     std::vector<char> win;
+    const char* wdata = nullptr;                             // where the current window (cached tail, then fresh bytes) starts
     std::vector<size_t> cuts;
     std::vector<std::pair<size_t, size_t>> bufs;
+    // A regular file is mapped and parsed where the page cache holds it (SOAPDENOVO2_AMD_READER=copy: read into buffers, as a pipe
+    // is): the copy out of the page cache cost as much processor time as the parsing.  Windows, cuts and buffers are the same.
+    const char* map = nullptr;
+    size_t map_len = 0;
+    if (!src.sequential() && !(getenv("SOAPDENOVO2_AMD_READER") && !strcmp(getenv("SOAPDENOVO2_AMD_READER"), "copy"))) {
+        struct stat st;
+        if (fstat(fileno(src.fp), &st) == 0 && st.st_size > 0) {
+            void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(src.fp), 0);
+            if (m != MAP_FAILED) { map = (const char*)m; map_len = (size_t)st.st_size; (void)madvise(m, map_len, MADV_SEQUENTIAL); }
+        }
+    }
     // two sets of runs: while the caller's thread hands one window's runs over (copies into the batch buffers: serial, and
     // about as long as the parsing itself once a dozen threads parse), the threads already cut and parse the next window
     std::vector<PackedRun> run_sets[2] = {std::vector<PackedRun>(nt), std::vector<PackedRun>(nt)};
@@ -403,7 +417,7 @@ long long stream_file_parallel(const InputFile& in, const std::string& path, boo
         }
         auto body = [&](int t) {
             runs[t].clear();
-            for (size_t i = first[t]; i < first[t + 1]; i++) parse_range(in, fastq, win.data() + bufs[i].first, bufs[i].second - bufs[i].first, codes[t], runs[t]);
+            for (size_t i = first[t]; i < first[t + 1]; i++) parse_range(in, fastq, wdata + bufs[i].first, bufs[i].second - bufs[i].first, codes[t], runs[t]);
         };
         std::vector<std::thread> pool;
         for (int t = 1; t < nt; t++) pool.emplace_back(body, t);
@@ -412,7 +426,8 @@ long long stream_file_parallel(const InputFile& in, const std::string& path, boo
     };
     // a regular file is read with a few preads side by side (one thread copying out of the page cache is slower than the
     // parsers); a pipe (.gz) is read as it comes
-    double t_parse = 0, t_hand = 0;
+    double t_parse = 0, t_hand = 0, t_cut = 0, t_read = 0, t_pa = 0;
+    auto nowd = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     uint64_t file_off = 0;
     auto read_window = [&](char* dst, size_t want) -> size_t {
         if (src.sequential()) return fread(dst, 1, want, src.fp);
@@ -444,25 +459,35 @@ long long stream_file_parallel(const InputFile& in, const std::string& path, boo
     // two windows: while the threads parse one, the next stretch of the file is read into the other
     std::vector<char> next_win;
     size_t got = 0;
-    win.resize(window_chunks * CHUNK);
-    got = read_window(win.data(), window_chunks * CHUNK);
+    auto map_window = [&](uint64_t off) -> size_t {            // the mapped file's next window: nothing moves, the kernel is told to read ahead
+        const size_t n = off < map_len ? std::min(window_chunks * CHUNK, map_len - (size_t)off) : 0;
+        if (n) (void)posix_fadvise(fileno(src.fp), (off_t)off, (off_t)std::min(2 * window_chunks * CHUNK, map_len - (size_t)off), POSIX_FADV_WILLNEED);
+        return n;
+    };
+    if (map) got = map_window(0);
+    else {
+        win.resize(window_chunks * CHUNK);
+        got = read_window(win.data(), window_chunks * CHUNK);
+    }
     // One window (`win`, `carry` cached bytes + `got` fresh ones, got > 0): cut, parse into `runs`, and meanwhile read the
     // next window; leaves win / carry / got describing that next window.  Returns true when this window ended the file
     // inside a chunk (nothing follows).
     auto cut_and_parse = [&](std::vector<PackedRun>& runs) -> bool {
         const auto tr0 = std::chrono::steady_clock::now();
         const size_t n_full = got / CHUNK, rem = got % CHUNK;
+        wdata = map ? map + file_off - carry : win.data();     // (mapped: file_off = where the window's fresh bytes start)
         cuts.assign(n_full, 0);
         {
             auto body = [&](int t) {
                 for (size_t i = n_full * t / nt; i < n_full * (t + 1) / nt; i++)
-                    cuts[i] = fastq ? fastq_cut(win.data() + carry + i * CHUNK, CHUNK) : fasta_cut(win.data() + carry + i * CHUNK, CHUNK);
+                    cuts[i] = fastq ? fastq_cut(wdata + carry + i * CHUNK, CHUNK) : fasta_cut(wdata + carry + i * CHUNK, CHUNK);
             };
             std::vector<std::thread> pool;
             for (int t = 1; t < nt; t++) pool.emplace_back(body, t);
             body(0);
             for (auto& th : pool) th.join();
         }
+        t_cut += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
         bufs.clear();
         size_t begin = 0;
         for (size_t i = 0; i < n_full; i++) {
@@ -476,13 +501,24 @@ long long stream_file_parallel(const InputFile& in, const std::string& path, boo
             t_parse += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
             return true;
         }
-        last_buf.assign(win.data() + bufs.back().first, bufs.back().second - bufs.back().first);
+        last_buf.assign(wdata + bufs.back().first, bufs.back().second - bufs.back().first);
         const size_t tail = carry + got - begin;
+        if (map) {
+            const double a = nowd();
+            parse_all(runs);
+            t_pa += nowd() - a;
+            (void)madvise((void*)(map + ((file_off - carry) & ~(size_t)4095)), ((carry + got - tail) & ~(size_t)4095), MADV_DONTNEED);   // parsed: the mapping lets go of it
+            file_off += got;
+            carry = tail;
+            got = map_window(file_off);
+            t_parse += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
+            return false;
+        }
         next_win.resize(tail + window_chunks * CHUNK);
         memcpy(next_win.data(), win.data() + begin, tail);
         size_t next_got = 0;
-        std::thread reader([&]() { next_got = read_window(next_win.data() + tail, window_chunks * CHUNK); });
-        parse_all(runs);
+        std::thread reader([&]() { const double a = nowd(); next_got = read_window(next_win.data() + tail, window_chunks * CHUNK); t_read += nowd() - a; });
+        { const double a = nowd(); parse_all(runs); t_pa += nowd() - a; }
         reader.join();
         win.swap(next_win);
         carry = tail;
@@ -521,8 +557,9 @@ long long stream_file_parallel(const InputFile& in, const std::string& path, boo
             last = next_last;
         }
     }
+    if (map) (void)munmap((void*)map, map_len);
     src.close();
-    if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "reader: %.2fs cutting + parsing (with the next window's read), %.2fs handing over beside it (%d threads)\n", t_parse, t_hand, nt);
+    if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "reader: %.2fs cutting + parsing (with the next window's read), %.2fs handing over beside it (%d threads); of the first: cuts %.2fs, parsing %.2fs, the read beside it %.2fs\n", t_parse, t_hand, nt, t_cut, t_pa, t_read);
     return n_records;
 }
 

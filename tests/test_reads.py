@@ -46,18 +46,20 @@ def test_config_errors_exit_like_the_reference(tmp_path):
     assert r.returncode != 0 and "Cannot open /nonexistent.fq" in r.stderr
 
 
+@pytest.mark.parametrize("reader", ["map", "copy"])
 @pytest.mark.parametrize("threads,window", [(3, 2), (5, 1), (2, 64)])
-def test_parallel_reader_delivers_the_same_reads(tmp_path, threads, window):
+def test_parallel_reader_delivers_the_same_reads(tmp_path, threads, window, reader):
     """Single files are parsed by all host threads (windows of 32 KiB chunks, cuts and buffers in parallel): same reads,
     same order, same record count as the sequential chunk emulation -- on the corner cases (N x 32768 file, ragged reads,
-    truncation, two libs, lower case / N / '.') and on plain FASTQ / FASTA, with tiny windows to cross window borders."""
+    truncation, two libs, lower case / N / '.') and on plain FASTQ / FASTA, with tiny windows to cross window borders.
+    Both for the mapped file (parsed where the page cache holds it) and for windows copied into buffers (what a pipe gets)."""
     import os
     import numpy as np
     cfgs = [(synth.make_quirk_case(str(tmp_path), name), 31) for name in synth.QUIRK_CASES]
     for fmt in ("fastq", "fasta"):
         cfgs.append((synth.make_case(str(tmp_path), "p_" + fmt, 30000, 4000, 90, 0.01, 9, fmt=fmt), 25))
     knobs = {"SOAPDENOVO2_AMD_PARSE_PARALLEL_MIN": "0", "SOAPDENOVO2_AMD_PARSE_THREADS": str(threads),
-             "SOAPDENOVO2_AMD_PARSE_WINDOW": str(window)}
+             "SOAPDENOVO2_AMD_PARSE_WINDOW": str(window), "SOAPDENOVO2_AMD_READER": reader}
     for cfg, K in cfgs:
         os.environ["SOAPDENOVO2_AMD_PARSE_THREADS"] = "1"
         try:
