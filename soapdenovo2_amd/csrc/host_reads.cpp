@@ -377,11 +377,13 @@ long long stream_file_parallel(const InputFile& in, const std::string& path, boo
     const char* wdata = nullptr;                             // where the current window (cached tail, then fresh bytes) starts
     std::vector<size_t> cuts;
     std::vector<std::pair<size_t, size_t>> bufs;
-    // A regular file is mapped and parsed where the page cache holds it (SOAPDENOVO2_AMD_READER=copy: read into buffers, as a pipe
-    // is): the copy out of the page cache cost as much processor time as the parsing.  Windows, cuts and buffers are the same.
+    // SOAPDENOVO2_AMD_READER=map: a regular file is mapped and parsed where the page cache holds it instead of being read into
+    // buffers (which a pipe always is).  Windows, cuts and buffers are the same.  Not the default: it halves the reader's time on
+    // an 8-core box, but on the GPU box (256 hardware threads, 16 granted) the page faults cost more than the four copying
+    // threads they replace (19 GB: 2.6 - 2.7 s against 2.0 - 2.3 s).
     const char* map = nullptr;
     size_t map_len = 0;
-    if (!src.sequential() && !(getenv("SOAPDENOVO2_AMD_READER") && !strcmp(getenv("SOAPDENOVO2_AMD_READER"), "copy"))) {
+    if (!src.sequential() && getenv("SOAPDENOVO2_AMD_READER") && !strcmp(getenv("SOAPDENOVO2_AMD_READER"), "map")) {
         struct stat st;
         if (fstat(fileno(src.fp), &st) == 0 && st.st_size > 0) {
             void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(src.fp), 0);
