@@ -753,7 +753,9 @@ int p2_layout_rank_growable(int device, int nw, int n_own, const uint64_t* d_rec
         }
         size_t free_b = 0, total_b = 0;
         const uint64_t one = growable_scratch_bytes(n_max, owner_max);
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) lanes = (int)std::min<uint64_t>(8, (uint64_t)((double)free_b * 0.85) / std::max<uint64_t>(one, 1));
+        // (two: 1.15 s -> 1.0 s at 60 M reads; eight bought another 0.05 s for four times the scratch -- and a fresh process pays for its
+        //  allocations by the gigabyte)
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) lanes = (int)std::min<uint64_t>(2, (uint64_t)((double)free_b * 0.85) / std::max<uint64_t>(one, 1));
         if (const char* v = getenv("SOAPDENOVO2_AMD_LAYOUT_LANES")) lanes = atoi(v);
         lanes = std::max(1, std::min(lanes, n_own));
     }
