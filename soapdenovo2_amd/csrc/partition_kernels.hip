@@ -155,7 +155,7 @@ __device__ __forceinline__ uint32_t fastdiv1(uint32_t i, uint32_t d, uint32_t in
 //   D     thread = the same segment: one LDS atomic reserves its items, every start bit finds the next start
 //   E     one lane per run: slot in the partition's stream (or the owner's send region), record from the dword string
 // Lanes of a wave take different reads (read index fastest), so the row stride -- forced odd -- is the bank stride.
-struct SegArg { int R, np, npad, wsd, nseg, nca; uint32_t inv_R, inv_wpr; int dbg; int stage_off, items_cap; };   // stage_off (dwords from the start of the dynamic LDS, 16-byte aligned; 0 = none): where phase E stages records when the tile has at most items_cap of them   // dbg (PG_K1DBG, measurement aid): 1 = no record stores, 2 = no slot reservation either
+struct SegArg { int R, np, npad, wsd, nseg, nca; uint32_t inv_R, inv_wpr; int dbg; };   // dbg (PG_K1DBG, measurement aid): 1 = no record stores, 2 = no slot reservation either
 
 template <int NW, bool ROUTE, int S>
 __global__ __launch_bounds__(BLOCK) void skm_scatter_seg_kernel(ReadsArg a, E2Dev e, DevCounters* ctr, SegArg sa, RouteArg ro) {
@@ -231,68 +231,31 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_seg_kernel(ReadsArg a, E2De
             obase[threadIdx.x] = atomicAdd(&ro.cursor[threadIdx.x], (unsigned long long)ocnt[threadIdx.x]);
         __syncthreads();
     }
-    // E.  A lane's record is RW / 2 pieces of 16 bytes; stored by the lane itself they are RW / 2 separate write requests to one
-    // line (the counters show 32 bytes written per 16-byte store: 2 x the record's bytes).  So the records of a wave go through LDS
-    // and four neighbouring lanes store one record with ONE instruction -- one request a record.  The staging area lies behind the
-    // item list in the (dead) value rows; a tile with more items than fit in front of it stores lane by lane.
-    const bool staged = sa.stage_off != 0 && total <= sa.items_cap;
-    constexpr int RW2 = 2 * RW;                                           // dwords a record
-    uint32_t* const stg_rec = (uint32_t*)smem_raw + sa.stage_off + (threadIdx.x >> 6) * (64 * RW2 + 128);
-    unsigned long long* const stg_ptr = (unsigned long long*)(stg_rec + 64 * RW2);
-    const int lane = threadIdx.x & 63;
-    for (int base = 0; base < total; base += BLOCK) {
-        const int it = base + (int)threadIdx.x;
-        uint64_t* out = nullptr;
+    for (int it = threadIdx.x; it < total; it += BLOCK) {
+        const uint32_t pk = items[it];
+        const int r = (int)(pk >> 24), j0 = (int)((pk >> 12) & 0xFFF), n = (int)(pk & 0xFFF);
+        const uint32_t pid = pids[r * kpad + j0];
+        uint64_t* out;
+        uint32_t q = 0;
+        // the returned atomic on the partition's cursor is asked first and looked at after the record is built
+        if (!ROUTE && !(sa.dbg & 2)) q = atomicAdd(&e.cursor[pid], 1u);
         uint64_t rec[RW];
-        if (it < total) {
-            const uint32_t pk = items[it];
-            const int r = (int)(pk >> 24), j0 = (int)((pk >> 12) & 0xFFF), n = (int)(pk & 0xFFF);
-            const uint32_t pid = pids[r * kpad + j0];
-            uint32_t q = 0;
-            // the returned atomic on the partition's cursor is asked first and looked at after the record is built
-            if (!ROUTE && !(sa.dbg & 2)) q = atomicAdd(&e.cursor[pid], 1u);
-            tile_make_record<PW>(dw + r * wsd, len, j0, n, a.ord_base + (r0 + (uint64_t)r) * (uint64_t)kpr, e.g.K, rec);
-            if (ROUTE) {
-                const uint32_t o = pid % (uint32_t)ro.n_owners;
-                const unsigned long long at = obase[o] + ranks[it];
-                if (at >= ro.cap) atomicOr(&ctr->e2_flags, F_ROUTE);
-                else {
-                    ro.pids[(uint64_t)o * ro.cap + at] = pid;
-                    out = ro.recs + ((uint64_t)o * ro.cap + at) * RW;
-                }
-            } else if (sa.dbg & 2) {
-                if (pid == 0xFFFFFFFFu || rec[0] == 0x1234567) atomicOr(&ctr->e2_flags, F_POOL);
-            } else {
-                out = record_slot(e, pid, q, ctr, RW);
-            }
-            if (out && (sa.dbg & 1)) { if (rec[0] == 0x1234567 && rec[1] == 77) atomicOr(&ctr->e2_flags, F_POOL); out = nullptr; }
+        tile_make_record<PW>(dw + r * wsd, len, j0, n, a.ord_base + (r0 + (uint64_t)r) * (uint64_t)kpr, e.g.K, rec);
+        if (ROUTE) {
+            const uint32_t o = pid % (uint32_t)ro.n_owners;
+            const unsigned long long at = obase[o] + ranks[it];
+            if (at >= ro.cap) { atomicOr(&ctr->e2_flags, F_ROUTE); continue; }
+            ro.pids[(uint64_t)o * ro.cap + at] = pid;
+            out = ro.recs + ((uint64_t)o * ro.cap + at) * RW;
+        } else {
+            if (sa.dbg & 2) { if (pid == 0xFFFFFFFFu || rec[0] == 0x1234567) atomicOr(&ctr->e2_flags, F_POOL); continue; }
+            out = record_slot(e, pid, q, ctr, RW);
         }
-        if (!staged) {
-            if (out) {
-                ulonglong2* o2 = (ulonglong2*)out;
+        if (!out) continue;
+        if (sa.dbg & 1) { if (rec[0] == 0x1234567 && rec[1] == 77) atomicOr(&ctr->e2_flags, F_POOL); continue; }
+        ulonglong2* o2 = (ulonglong2*)out;
 #pragma unroll
-                for (int k = 0; k < RW / 2; k++) o2[k] = make_ulonglong2(rec[2 * k], rec[2 * k + 1]);
-            }
-            continue;
-        }
-        // (the waves of a workgroup run the same number of rounds -- `base` is uniform -- and every lane of a wave gets here)
-        {
-            ulonglong2* mine = (ulonglong2*)(stg_rec + lane * RW2);
-#pragma unroll
-            for (int k = 0; k < RW / 2; k++) mine[k] = make_ulonglong2(rec[2 * k], rec[2 * k + 1]);
-            stg_ptr[lane] = (unsigned long long)(uintptr_t)out;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-#pragma unroll
-        for (int rd = 0; rd < 4; rd++) {
-            const int src = rd * 16 + (lane >> 2), k = lane & 3;
-            ulonglong2* dst = (ulonglong2*)(uintptr_t)stg_ptr[src];
-            if (dst && k < RW / 2) dst[k] = *(const ulonglong2*)(stg_rec + src * RW2 + 4 * k);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();                                  // the next round overwrites the staging area
+        for (int k = 0; k < RW / 2; k++) o2[k] = make_ulonglong2(rec[2 * k], rec[2 * k + 1]);
     }
 }
 
@@ -1113,16 +1076,7 @@ static int launch_tiled(pg_ctx* c, const ReadsArg& a, const RouteArg* route, hip
     auto inv = [](uint32_t d) { return (uint32_t)(((1ULL << 32) + d - 1) / d); };
     int k1dbg = 0;
     if (const char* v = getenv("PG_K1DBG")) k1dbg = atoi(v);
-    // phase E's staging area: behind the item list, inside the value rows (R * npad dwords from dword R * wsd on); PG_K1_STAGE=0: off
-    int stage_off = 0, items_cap = 0;
-    {
-        const int rw2 = 2 * (c->NW == 2 ? 6 : 8), need = (BLOCK / 64) * (64 * rw2 + 128);
-        const int v0 = R * wsd, v_end = v0 + R * npad;
-        const int off = (v_end - need) & ~3;                                    // 16-byte aligned (the dynamic LDS starts aligned)
-        if (off > v0 + 64) { stage_off = off; items_cap = off - v0; }
-        if (const char* v = getenv("PG_K1_STAGE")) if (atoi(v) == 0) stage_off = 0;
-    }
-    SegArg sa{R, np, npad, wsd, nseg, nca, inv((uint32_t)R), inv(a.wpr), k1dbg, stage_off, items_cap};
+    SegArg sa{R, np, npad, wsd, nseg, nca, inv((uint32_t)R), inv(a.wpr), k1dbg};
     RouteArg ro{nullptr, nullptr, nullptr, 0, 1};
     if (route) ro = *route;
     const size_t smem = per_read * R;
