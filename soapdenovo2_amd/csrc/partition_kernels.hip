@@ -1069,6 +1069,13 @@ static int launch_tiled(pg_ctx* c, const ReadsArg& a, const RouteArg* route, hip
     const size_t per_read = (size_t)(wsd + npad + nseg * S + nseg + (route ? kpr : 0)) * 4;
     int R = std::min<int>(128, std::max(1, BLOCK / nseg));                     // one pass of phase B per tile
     R = (int)std::min<size_t>((size_t)R, (60 * 1024) / per_read);
+    // ... and about 25 KB of LDS a tile, i.e. five workgroups a CU: measured at 150 bp (profiles/r03v_k1_tile_sizes.json), K = 63
+    // (1016 B a read): 12 / 16 / 20 / 24 / 28 / 32 / 56 reads -> 84.7 / 73.6 / 65.9 / 59.5 - 61.1 / 61.6 / 66.8 - 67.3 / 108.9 ms per
+    // 200 M reads; K = 127 (760 B a read): 16 / 24 / 32 / 48 / 80 -> 57.7 / 42.1 / 38.1 / 41.4 / 54.3 ms
+    {
+        const int r_lds = (int)(((25 * 1024) / per_read) & ~(size_t)7);
+        if (r_lds >= 8) R = std::min(R, r_lds);
+    }
     if (const char* v = getenv("PG_K1_R")) R = std::max(1, std::min(atoi(v), (int)std::min<size_t>(128, (60 * 1024) / per_read)));
     if (R < 1) return 1;
     const uint64_t grid = (a.n_reads + R - 1) / R;
