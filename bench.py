@@ -550,9 +550,9 @@ def main():
                     traffic = None
             # `bound` names the roofline the contract prices this path against (HBM bytes of a hash-table
             # formulation).  The kernel itself moves 0.15x those bytes and is limited elsewhere, see `limiter`.
-            limiter = ("instruction issue: ~220 vector instructions per read over 4 waves a SIMD (the 88 KB LDS set allows one 1024-lane "
+            limiter = ("instruction issue: ~230 vector instructions per read over 4 waves a SIMD (the 88 KB LDS set allows one 1024-lane "
                        "workgroup per CU), random 8-byte LDS accesses replayed for bank conflicts, nine workgroup barriers per partition; "
-                       "vector ALU ~44 % busy, HBM ~9 % of peak (profiles/r02b_pmc_sq_bench20M.json, profiles/r02b_k2_phase_cycles_20M.txt, "
+                       "vector ALU ~44 % busy, HBM ~9 % of peak (profiles/r03j_pmc_sq_bench20M.json, profiles/r03j_k2_phase_cycles_20M_k63.txt, "
                        "DESIGN.md 3.2)") if engine == 2 else "random-atomic rate of the DRAM-resident set"
             # what the counters say about the same launch: PMC bytes / launch time against the same peak (never `frac`)
             counter_frac = (traffic / (avg_ms * 1e-3) / 1e9 / 8000.0) if traffic else None
