@@ -376,6 +376,11 @@ int pg_exchange_gather_records(pg_comm *comm, const uint64_t *d_records, uint64_
  * every rank return an error instead of leaving the others waiting. */
 int pg_exchange_regroup_by_set(pg_comm *comm, uint64_t *d_records, uint64_t n_local, int rec_words, uint64_t **d_out, uint64_t *n_out,
                                void *stream);
+/* the same inside a workspace (the record pool pass 1 is done with, pg_export_take_ws): the send buffer is its front and, when both
+ * fit, the regrouped records its tail (*out_in_workspace = 1: they are freed with the workspace); d_records stays the caller's.
+ * Nothing of that size is allocated or released, which costs a fresh process seconds. */
+int pg_exchange_regroup_by_set_ws(pg_comm *comm, uint64_t *d_records, uint64_t n_local, int rec_words, void *d_workspace,
+                                  uint64_t workspace_bytes, uint64_t **d_out, uint64_t *n_out, int *out_in_workspace, void *stream);
 /* out[0] = distinct k-mers this rank held before the regroup, out[1] = after it */
 int pg_comm_regroup_stats(const pg_comm *comm, uint64_t out[2]);
 /* One batch of pass 1 on all ranks: pg_skm_route (ragged batches too: d_word_off / d_kmer_base as in pg_count_reads), the count

@@ -569,6 +569,11 @@ int run(int argc, char** argv, bool mer127) {
     uint64_t* d_rec = nullptr;                                     // the distinct k-mers of pass 1, on `device`
     std::vector<uint64_t*> sh_rec;                                 // sharded run: per rank, the k-mers of the sets it owns (replay order), on its GPU
     std::vector<uint64_t> sh_n, sh_per_set;
+    // ... the record pool each rank's pass 1 is done with (regroup, sort and, as an offered block, the k-mer sets' layout work inside
+    // it: no allocation of that size behind a release of that size), how much of its front is free, what is to be released in the end
+    std::vector<void*> sh_ws, sh_mine;
+    std::vector<uint64_t> sh_ws_front;
+    std::vector<char> sh_in_ws, sh_offered;
     int engine_used = 2;
     if (n_ranks > 1) {
         // ---- pass 1 on n_ranks GPUs: cut + all-to-all + append per batch, then every rank counts its own partitions
@@ -611,6 +616,7 @@ int run(int argc, char** argv, bool mer127) {
         std::vector<std::string> err(n_ranks);
         sh_rec.assign(n_ranks, nullptr);
         sh_n.assign(n_ranks, 0);
+        sh_ws.assign(n_ranks, nullptr); sh_mine.assign(n_ranks, nullptr); sh_ws_front.assign(n_ranks, 0); sh_in_ws.assign(n_ranks, 0); sh_offered.assign(n_ranks, 0);
         sh_per_set.assign(o.sets, 0);
         {
             std::vector<std::thread> th;
@@ -634,15 +640,20 @@ int run(int argc, char** argv, bool mer127) {
                     if (ok && pg_host_last_put_matters(h + 256, o.sets, o.a_gb, mer127 ? 1 : 0) && pg_last_put(ctxs[r], last[r].data(), nullptr) != PG_OK) { ok = false; fail("pg_last_put"); }
                     uint64_t* d_mine = nullptr;
                     uint64_t n_mine = 0;
-                    if (ok && pg_export_take(ctxs[r], &d_mine, &n_mine) != PG_OK) { ok = false; fail("pg_export_take"); }
+                    void* d_ws = nullptr;
+                    uint64_t ws_bytes = 0;
+                    if (ok && pg_export_take_ws(ctxs[r], &d_mine, &n_mine, &d_ws, &ws_bytes) != PG_OK) { ok = false; fail("pg_export_take"); }
                     if (!ok) { n_mine = 0; d_mine = nullptr; }
                     n_before[r] = n_mine;
-                    pg_destroy(ctxs[r]);                              // the record pool and the tables: the regroup and the sort want the room
+                    pg_destroy(ctxs[r]);                              // the tables; the record pool stays as the workspace of what follows
                     uint64_t* d_g = nullptr;
                     uint64_t n_g = 0;
-                    if (pg_exchange_regroup_by_set(comms[r], d_mine, n_mine, rw1, &d_g, &n_g, nullptr) != PG_OK) { ok = false; fail("pg_exchange_regroup_by_set"); }
-                    if (ok && n_g && (hipSetDevice(devices[r]) != hipSuccess || pg_sort_records(d_g, n_g, mer127 ? 1 : 0, nullptr) != PG_OK)) { ok = false; fail("pg_sort_records"); }
+                    int in_ws = 0;
+                    if (pg_exchange_regroup_by_set_ws(comms[r], d_mine, n_mine, rw1, d_ws, ws_bytes, &d_g, &n_g, &in_ws, nullptr) != PG_OK) { ok = false; fail("pg_exchange_regroup_by_set"); }
+                    const uint64_t front = in_ws ? (uint64_t)((char*)d_g - (char*)d_ws) : ws_bytes;
+                    if (ok && n_g && (hipSetDevice(devices[r]) != hipSuccess || pg_sort_records_ws(d_g, n_g, mer127 ? 1 : 0, d_ws, front, nullptr) != PG_OK)) { ok = false; fail("pg_sort_records"); }
                     sh_rec[r] = d_g; sh_n[r] = n_g;
+                    sh_ws[r] = d_ws; sh_ws_front[r] = front; sh_in_ws[r] = (char)in_ws; sh_mine[r] = d_ws ? (void*)d_mine : nullptr;   // (without a workspace the regroup has released d_mine)
                 });
             for (auto& t : th) t.join();
         }
@@ -803,6 +814,8 @@ int run(int argc, char** argv, bool mer127) {
     if (const char* e = getenv("SOAPDENOVO2_AMD_PASS2")) host_pass2 = strcmp(e, "host") == 0;
     if (host_pass2) host_edges = true;                               // host pass 2 needs the host copy of the sets tagged
     // records still on the device: with -a the layout is made there (K6), otherwise the replay's workers pull their stretches
+    for (int r = 0; r < (int)sh_ws.size(); r++)                      // one block a device (ranks that share a GPU in test set-ups: the first one's)
+        if (sh_ws[r] && sh_ws_front[r] && pg_device_scratch_offer(devices[r], sh_ws[r], sh_ws_front[r]) == PG_OK) sh_offered[r] = 1;
     pg_graph* graph = n_ranks > 1
         ? pg_graph_begin_sharded(n_ranks, devices.data(), sh_rec.data(), sh_n.data(), sh_per_set.data(), set_last.data(), K, mer127 ? 1 : 0, o.sets, o.delow == 0,
                                  o.a_gb, max_read_len, 0, o.prefix.c_str())
@@ -813,7 +826,16 @@ int run(int argc, char** argv, bool mer127) {
                          max_read_len, 0, o.prefix.c_str(), host_edges ? -1 : device);
     if (ws_offered) { if (void* back = pg_device_scratch_withdraw(device)) (void)hipFree(back); d_ws = nullptr; }
     if (d_rec) { hipFree(d_rec); d_rec = nullptr; }
-    for (int r = 0; r < (int)sh_rec.size(); r++) if (sh_rec[r]) { (void)hipSetDevice(devices[r]); hipFree(sh_rec[r]); sh_rec[r] = nullptr; }
+    for (int r = 0; r < (int)sh_rec.size(); r++) {
+        (void)hipSetDevice(devices[r]);
+        // the pool: offered and still there -> ours to release; offered and gone -> a layout laid its k-mer sets out in it and the
+        // graph owns it now (the records in its tail are done with either way)
+        if (sh_offered[r]) { if (void* back = pg_device_scratch_withdraw(devices[r])) hipFree(back); }
+        else if (sh_ws[r]) hipFree(sh_ws[r]);
+        if (sh_rec[r] && !sh_in_ws[r]) hipFree(sh_rec[r]);
+        sh_rec[r] = nullptr;
+        if (sh_mine[r]) hipFree(sh_mine[r]);
+    }
     (void)hipSetDevice(device);
     if (!graph) die("pg_host_graph_begin");
     if (o.reps && pg_host_graph_resolve_repeats(graph, 1) != PG_OK) die("pg_host_graph_resolve_repeats");

@@ -524,19 +524,27 @@ __global__ __launch_bounds__(256) void rg_scatter(const uint64_t* rec, uint64_t 
     }
 }
 
-extern "C" int pg_exchange_regroup_by_set(pg_comm* c, uint64_t* d_records, uint64_t n_local, int rec_words, uint64_t** d_out, uint64_t* n_out,
-                                          void* stream) {
+// With a workspace (the record pool pass 1 is done with, pg_export_take_ws): the send buffer is the workspace's front, the
+// regrouped records its tail when both fit (*out_in_workspace = 1: not to be freed on their own), and d_records stays the
+// caller's -- no allocation and no release of that size, both of which cost a fresh process seconds.  Without: as before (the
+// input array is released as soon as it has been copied, the result is an allocation of its own).
+extern "C" int pg_exchange_regroup_by_set_ws(pg_comm* c, uint64_t* d_records, uint64_t n_local, int rec_words, void* d_workspace, uint64_t workspace_bytes,
+                                             uint64_t** d_out, uint64_t* n_out, int* out_in_workspace, void* stream) {
     if (!c || !d_out || !n_out || (n_local && !d_records) || rec_words < 3 || rec_words > 6) { pg_set_error("bad argument"); return PG_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     *d_out = nullptr; *n_out = 0;
+    if (out_in_workspace) *out_in_workspace = 0;
     FirstError err;
     err.hip(hipSetDevice(c->device), "hipSetDevice");
     const int n = c->n;
     uint64_t* d_send = nullptr;
     unsigned long long* d_cur = nullptr;
+    const uint64_t send_bytes = (n_local * (uint64_t)rec_words * 8 + 255) & ~255ULL;
+    const bool send_in_ws = d_workspace && out_in_workspace && send_bytes <= workspace_bytes;
     std::vector<uint64_t> scnt(n, 0), soff(n, 0), rcnt(n, 0), roff(n, 0);
     if (!err.rc) err.hip(hipMalloc((void**)&d_cur, sizeof(unsigned long long) * (size_t)n), "hipMalloc");
-    if (!err.rc && n_local) err.hip(hipMalloc((void**)&d_send, n_local * (uint64_t)rec_words * 8), "hipMalloc (regroup send buffer)");
+    if (send_in_ws) d_send = (uint64_t*)d_workspace;
+    else if (!err.rc && n_local) err.hip(hipMalloc((void**)&d_send, n_local * (uint64_t)rec_words * 8), "hipMalloc (regroup send buffer)");
     if (!err.rc) {
         err.hip(hipMemsetAsync(c->d_counts, 0, sizeof(uint64_t) * (size_t)n, st), "memset");
         if (n_local) hipLaunchKernelGGL(rg_count, dim3((unsigned)std::min<uint64_t>((n_local + 255) / 256, 4096)), dim3(256), 0, st, d_records, n_local, rec_words, n,
@@ -552,7 +560,7 @@ extern "C" int pg_exchange_regroup_by_set(pg_comm* c, uint64_t* d_records, uint6
         err.hip(hipGetLastError(), "rg_scatter");
         err.hip(hipStreamSynchronize(st), "sync");
     }
-    if (d_records) (void)hipFree(d_records);                       // the caller's array has been regrouped into d_send: halve the peak
+    if (d_records && !(d_workspace && out_in_workspace)) (void)hipFree(d_records);   // the caller's array has been regrouped into d_send: halve the peak
     if (err.rc) (void)hipMemsetAsync(c->d_counts, 0, sizeof(uint64_t) * (size_t)n, st);
     {   // counts (zeros from a rank that failed)
         const int rc = alltoall_words(c, c->d_counts, c->d_rcounts, 1, st);
@@ -563,7 +571,15 @@ extern "C" int pg_exchange_regroup_by_set(pg_comm* c, uint64_t* d_records, uint6
     uint64_t total = 0;
     for (int q = 0; q < n; q++) { roff[q] = total; total += rcnt[q]; }
     uint64_t* out = nullptr;
-    if (!err.rc && total) err.hip(hipMalloc((void**)&out, total * (uint64_t)rec_words * 8), "hipMalloc (regrouped records)");
+    bool out_in_ws = false;
+    if (send_in_ws && total) {
+        const uint64_t out_bytes = total * (uint64_t)rec_words * 8;
+        if (out_bytes + 256 <= workspace_bytes) {
+            const uint64_t off = (workspace_bytes - out_bytes) & ~255ULL;
+            if (off >= send_bytes) { out = (uint64_t*)((char*)d_workspace + off); out_in_ws = true; }
+        }
+    }
+    if (!err.rc && total && !out) err.hip(hipMalloc((void**)&out, total * (uint64_t)rec_words * 8), "hipMalloc (regrouped records)");
     uint64_t verdict = 0;
     {
         const int arc = agree_max(c, err.rc ? 1 : 0, &verdict, st);
@@ -576,12 +592,17 @@ extern "C" int pg_exchange_regroup_by_set(pg_comm* c, uint64_t* d_records, uint6
         if (rc) err.set(rc, pg_last_error());
         err.hip(hipStreamSynchronize(st), "sync");
     } else err.set(PG_ENODEV, "pg_exchange_regroup_by_set: another rank failed");
-    if (d_send) (void)hipFree(d_send);
+    if (d_send && !send_in_ws) (void)hipFree(d_send);
     if (d_cur) (void)hipFree(d_cur);
-    if (err.rc) { if (out) (void)hipFree(out); return err.done(); }
+    if (err.rc) { if (out && !out_in_ws) (void)hipFree(out); return err.done(); }
     *d_out = out; *n_out = total;
+    if (out_in_workspace) *out_in_workspace = out_in_ws ? 1 : 0;
     c->regrouped_in = total; c->regrouped_from = n_local;
     return PG_OK;
+}
+extern "C" int pg_exchange_regroup_by_set(pg_comm* c, uint64_t* d_records, uint64_t n_local, int rec_words, uint64_t** d_out, uint64_t* n_out,
+                                          void* stream) {
+    return pg_exchange_regroup_by_set_ws(c, d_records, n_local, rec_words, nullptr, 0, d_out, n_out, nullptr, stream);
 }
 
 // All ranks' exported records on rank `root` (rank order), for the stages that work on the whole graph.
