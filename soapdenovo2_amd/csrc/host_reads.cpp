@@ -247,9 +247,72 @@ static int parse_fastq_scan(const char* buf, size_t end, size_t& start, int max_
     }
     return 0;
 }
+#if defined(__x86_64__)
+#include <immintrin.h>
+// The usual record once more, 32 characters at a time: the sequence line is converted while its end is looked for, and any
+// character that is not a letter in front of that end (a digit, '@', NUL, '.', CR ...) sends the record to the scalar forms
+// below (-1), which remain the definition.  Reads nothing behind `end`.
+__attribute__((target("avx2"))) static int parse_fastq_avx2(const char* buf, size_t end, size_t& start, int max_len, uint8_t* out) {
+    if (!(start < end && buf[start] == '@')) return -1;
+    const char* e1 = (const char*)memchr(buf + start, '\n', end - start);           // end of the name line
+    if (!e1) return -1;
+    const char* s = e1 + 1;
+    const char* lim = buf + end;
+    const __m256i nl = _mm256_set1_epi8('\n'), c20 = _mm256_set1_epi8(0x20), ca = _mm256_set1_epi8((char)('a' - 128)),
+                  c26 = _mm256_set1_epi8((char)(26 - 128)), c3 = _mm256_set1_epi8(3);
+    size_t sl = 0;
+    for (;;) {
+        if (s + sl + 32 > lim) return -1;                                             // (the last record of a buffer: scalar)
+        const __m256i v = _mm256_loadu_si256((const __m256i*)(s + sl));
+        const uint32_t m_nl = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, nl));
+        // letter: ((v | 0x20) - 'a') < 26, compared as signed bytes after a shift by 128
+        const __m256i x = _mm256_sub_epi8(_mm256_or_si256(v, c20), ca);
+        const uint32_t m_ok = (uint32_t)_mm256_movemask_epi8(_mm256_cmpgt_epi8(c26, x));
+        const uint32_t before = m_nl ? ((m_nl & (0u - m_nl)) - 1u) : 0xFFFFFFFFu;     // the characters in front of the line's end
+        if ((~m_ok) & before) return -1;
+        if ((long)sl < (long)max_len) {
+            // base2int: (c & 6) >> 1; 16-bit shift, the bit that crosses a byte is masked off
+            const __m256i code = _mm256_and_si256(_mm256_srli_epi16(v, 1), c3);
+            uint8_t tmp[32];
+            _mm256_storeu_si256((__m256i*)tmp, code);
+            const size_t room = (size_t)max_len - sl;
+            memcpy(out + sl, tmp, room < 32 ? room : 32);                             // (`out` holds max_len + 8: whole blocks would overrun it)
+        }
+        if (m_nl) { sl += (size_t)__builtin_ctz(m_nl); break; }
+        sl += 32;
+    }
+    const char* e2 = s + sl;                                                          // the sequence line's '\n'
+    const int n = (int)(sl < (size_t)max_len ? sl : (size_t)max_len);
+    // the '+' line ends at the next '\n' (usually "+\n"); the quality line is skipped by the sequence's length
+    size_t qi;
+    if (e2 + 1 < lim && e2[1] == '\n') qi = (size_t)(e2 + 1 - buf);
+    else if (e2 + 2 < lim && e2[2] == '\n') qi = (size_t)(e2 + 2 - buf);
+    else {
+        const char* q = e2 + 1 < lim ? (const char*)memchr(e2 + 1, '\n', (size_t)(lim - (e2 + 1))) : nullptr;
+        qi = q ? (size_t)(q - buf) : end;
+    }
+    start = qi + 2 + sl;
+    return n;
+}
+#endif
+// SOAPDENOVO2_AMD_PARSE_SIMD=0 keeps the scalar forms (looked at on every call: the tests switch it inside one process)
+static bool simd_parse_on() {
+#if defined(__x86_64__)
+    static const bool have = [] { __builtin_cpu_init(); return __builtin_cpu_supports("avx2") != 0; }();
+    if (!have) return false;
+    const char* e = getenv("SOAPDENOVO2_AMD_PARSE_SIMD");
+    return !(e && e[0] == '0');
+#else
+    return false;
+#endif
+}
+
 // The same scan for the usual record -- it starts on its '@' and its sequence line holds no '@' -- with the line ends
 // found by memchr; anything else goes through the character-by-character scan above.
-int parse_fastq(const char* buf, size_t end, size_t& start, int max_len, uint8_t* out) {
+int parse_fastq(const char* buf, size_t end, size_t& start, int max_len, uint8_t* out, bool simd) {
+#if defined(__x86_64__)
+    if (simd) { const int r = parse_fastq_avx2(buf, end, start, max_len, out); if (r >= 0) return r; }
+#endif
     if (start < end && buf[start] == '@') {
         const char* e1 = (const char*)memchr(buf + start, '\n', end - start);           // end of the name line
         if (!e1) return 0;
@@ -354,8 +417,9 @@ struct PackedRun {
 
 void parse_range(const InputFile& in, bool fastq, const char* buf, size_t size, std::vector<uint8_t>& codes, PackedRun& out) {
     size_t start = 0;
+    const bool simd = simd_parse_on();
     while (start < size) {
-        const int n = fastq ? parse_fastq(buf, size, start, in.max_read_len, codes.data()) : parse_fasta(buf, size, start, in.max_read_len, codes.data());
+        const int n = fastq ? parse_fastq(buf, size, start, in.max_read_len, codes.data(), simd) : parse_fasta(buf, size, start, in.max_read_len, codes.data());
         if (n < 1) bad_record(buf, size, start);
         if (in.reverse) reverse_complement(codes.data(), n);
         out.records++;
@@ -750,7 +814,7 @@ long long stream_reads(const InputFile& in, ReadSink& sink) {
     std::vector<uint8_t> codes((size_t)std::max(in.max_read_len, 1) + 8);
     long long n_records = 0;
     auto parse = [&](const std::string& buf, size_t& start) {
-        const int n = fastq ? parse_fastq(buf.data(), buf.size(), start, in.max_read_len, codes.data())
+        const int n = fastq ? parse_fastq(buf.data(), buf.size(), start, in.max_read_len, codes.data(), /*simd=*/false)    // (the chunk emulation stays on the scalar definition)
                             : parse_fasta(buf.data(), buf.size(), start, in.max_read_len, codes.data());
         if (n < 1) bad_record(buf, start);
         if (in.reverse) reverse_complement(codes.data(), n);

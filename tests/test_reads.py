@@ -103,3 +103,48 @@ def test_parallel_mate_reader_stops_with_file_two(tmp_path):
     assert want[2] == 2200 and got[2] == want[2]
     assert np.array_equal(got[0], want[0]) and np.array_equal(got[1], want[1])
     assert np.array_equal(got[0][0::2], a[:1100]) and np.array_equal(got[0][1::2], b)
+
+
+def test_simd_fastq_parse_equals_the_scalar_definition(tmp_path):
+    """The AVX2 form of the usual FASTQ record (sequence line converted while its end is looked for) hands every record it does
+    not fully understand to the scalar forms: same reads with SOAPDENOVO2_AMD_PARSE_SIMD=0, and the same as the sequential chunk
+    emulation (always scalar) -- on records with lower case, N, '.', digits, CR LF, reads longer than max_rd_len, reads shorter
+    than a vector, '+' lines that repeat the name and quality lines that begin with '@'."""
+    import os
+    import numpy as np
+    rng = np.random.default_rng(5)
+    lines = []
+    for i in range(60000):
+        kind = int(rng.integers(0, 12))
+        n = int(rng.integers(1, 40)) if kind == 0 else int(rng.integers(60, 181))
+        seq = "".join("ACGT"[c] for c in rng.integers(0, 4, size=n))
+        if kind == 1:
+            seq = seq.lower()
+        elif kind == 2:
+            seq = seq[: n // 2] + "N" + seq[n // 2 + 1:]
+        elif kind == 3:
+            seq = seq[: n // 3] + "." + seq[n // 3 + 1:]
+        elif kind == 4:
+            seq = seq[: n // 3] + "7" + seq[n // 3 + 1:]
+        eol = "\r\n" if kind == 5 else "\n"
+        plus = "+" + ("r%d" % i if kind == 6 else "")
+        qual = ("@" if kind == 7 else "I") + "I" * (n - 1)
+        lines.append("@r%d some text%s%s%s%s%s%s%s" % (i, eol, seq, eol, plus, eol, qual, eol))
+    fq = tmp_path / "w.fq"
+    fq.write_text("".join(lines), newline="")
+    cfg = tmp_path / "w.cfg"
+    cfg.write_text(f"max_rd_len=150\n[LIB]\navg_ins=200\nasm_flags=3\nq={fq}\n")
+    knobs = {"SOAPDENOVO2_AMD_PARSE_PARALLEL_MIN": "0", "SOAPDENOVO2_AMD_PARSE_THREADS": "3", "SOAPDENOVO2_AMD_PARSE_WINDOW": "7"}
+    got = {}
+    for tag, extra in (("seq", {"SOAPDENOVO2_AMD_PARSE_THREADS": "1"}), ("scalar", dict(knobs, SOAPDENOVO2_AMD_PARSE_SIMD="0")), ("simd", knobs)):
+        os.environ.update(extra)
+        try:
+            got[tag] = api.host_read_all(str(cfg), 31)
+        finally:
+            for k in extra:
+                del os.environ[k]
+    assert got["seq"][2] == 60000
+    for tag in ("scalar", "simd"):
+        assert got[tag][2] == got["seq"][2] and got[tag][3] == got["seq"][3], tag
+        assert np.array_equal(got[tag][1], got["seq"][1]), tag
+        assert np.array_equal(got[tag][0], got["seq"][0]), tag
