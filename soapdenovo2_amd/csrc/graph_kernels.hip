@@ -783,7 +783,15 @@ int p2_layout_rank_growable(int device, int nw, int n_own, const uint64_t* d_rec
         for (int t = 0; t < lanes; t++) if (rcs[t] && !rc) { rc = rcs[t]; why = whys[t]; }
     }
     (void)hipStreamDestroy(st);
-    if (rc) { (void)hipFree(block ? block : (void*)nodes); pg_set_error("layout: " + (why.empty() ? std::string("failed") : why)); return rc < 0 ? rc : PG_ENODEV; }
+    if (rc) {
+        (void)hipFree(block ? block : (void*)nodes);
+        if (rc == PG_ENOMEM) {                                            // no room for the scratch beside the image: the sequential host replay needs none
+            fprintf(stderr, "growable sets on device %d: out of device memory for the layout's scratch; replaying on the host\n", device);
+            return K6_UNSUITED;
+        }
+        pg_set_error("layout: " + (why.empty() ? std::string("failed") : why));
+        return rc < 0 ? rc : PG_ENODEV;
+    }
     if (verbose) {
         uint64_t r_all = 0;
         for (uint64_t r : rounds) r_all += r;
