@@ -45,8 +45,8 @@ struct OccConst {
     int prev_q, prev_r;     // `prev` = (window dword [ND - 1 - prev_q] >> prev_r) & 3
     int rc_sd, rc_sb;       // the reversed register moves down by 32 rc_sd + rc_sb bits
 };
-inline OccConst occ_const(int K, int nw) {
-    OccConst c;
+constexpr OccConst occ_const(int K, int nw) {            // (constexpr: a kernel instantiated for one K folds the switches of occ_extract away)
+    OccConst c{};
     int bits = 2 * K;
     for (int i = 2 * nw - 1; i >= 0; i--) { c.flt[i] = bits >= 32 ? 0xFFFFFFFFu : (bits > 0 ? ((1u << bits) - 1u) : 0u); bits -= 32; }
     for (int i = 2 * nw; i < 8; i++) c.flt[i] = 0;

@@ -380,7 +380,9 @@ __device__ __forceinline__ unsigned int wave_inclusive_sum(unsigned int x) {
 // VT: the occurrences of a window are cut into VT * THREADS equal shares ("virtual lanes"); a wave takes 64 of them at a time
 // from a counter in LDS until none are left.  VT = 1 is the static split (lane l takes share l); with more shares than lanes a
 // wave that finishes early -- shorter probe sequences, fewer lost CAS -- takes the next tile instead of waiting at the barrier.
-template <int NW, int SLOTS, int THREADS, int WIN, bool TIMERS, int VT = 1>
+// KS: the kernel for ONE k-mer length (0 = any): the K-only shift amounts of occ_extract become immediates and its two wave-uniform
+// switches -- a dozen scalar branches an occurrence -- go away.
+template <int NW, int SLOTS, int THREADS, int WIN, bool TIMERS, int VT = 1, int KS = 0>
 __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetParams sp, OccConst oc, DevCounters* ctr, int dbg) {
     constexpr int PW = E2Cfg<NW>::PW, RW = PW + 1, KW = E2Cfg<NW>::KW, NWAVE = THREADS / 64, PIECES = RW / 2, N2 = 2 * NW;
     constexpr int RD = 2 * RW;                                            // dwords a record
@@ -761,7 +763,10 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                             nk = noff[k];
                             nk1 = noff[k + 1];
                             uint32_t f[N2], rc[N2], prev, next;
-                            occ_extract<NW>(rec + 2, (int)(hl + t), K, oc, f, rc, prev, next);
+                            if constexpr (KS != 0) {
+                                constexpr OccConst ock = occ_const(KS, NW);
+                                occ_extract<NW>(rec + 2, (int)(hl + t), KS, ock, f, rc, prev, next);
+                            } else occ_extract<NW>(rec + 2, (int)(hl + t), K, oc, f, rc, prev, next);
                             const bool lt = occ_less<N2>(f, rc);
                             const bool hasprev = (hl + t) != 0, hasnext = t + 1 < n + hr;
                             const uint32_t pv = hasprev ? prev : 4u, nx = hasnext ? next : 4u;          // x ^ 2 keeps "none" (bit 2) set
@@ -1253,6 +1258,8 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     if (const char* v = getenv("PG_K2_VT")) vt = atoi(v);                 // 1 = static shares (round 2), 2 / 4 = tiles
     if (const char* v = getenv("PG_DBG")) dbg = atoi(v);
     if (const char* v = getenv("PG_K2CFG")) cfg = atoi(v);
+    bool ks = true;                                                       // the instantiations for K = 31 / 63 / 127 (PG_K2_KS=0: the general kernel)
+    if (const char* v = getenv("PG_K2_KS")) ks = atoi(v) != 0;
     // cfg 0: 2048-slot set, 1024 lanes, 512-record windows  -> ~150 KB LDS, one workgroup per CU
     // cfg 1: 1024-slot set,  512 lanes, 256-record windows  ->  ~77 KB LDS, two workgroups per CU
     {
@@ -1260,6 +1267,8 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
         // cfg 2: 512-slot set, 256 lanes, 128-record windows -> ~38 KB LDS, four workgroups per CU (meant for 4x the partitions)
         if (c->NW == 2) {
             if (cfg == 0 && (dbg & 2)) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, true, 4>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
+            else if (cfg == 0 && vt == 4 && ks && c->K == 63) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 4, 63>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
+            else if (cfg == 0 && vt == 4 && ks && c->K == 31) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 4, 31>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
             else if (cfg == 0 && vt == 4) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 4>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
             else if (cfg == 0 && vt == 2) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 2>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
             else if (cfg == 0) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
@@ -1267,6 +1276,7 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
             else hipLaunchKernelGGL((skm_count_kernel<2, 512, 256, 128, false>), dim3(grid * 2), dim3(256), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
         } else {
             if (cfg == 0 && (dbg & 2)) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, true, 4>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
+            else if (cfg == 0 && vt == 4 && ks && c->K == 127) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false, 4, 127>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
             else if (cfg == 0 && vt == 4) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false, 4>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
             else if (cfg == 0 && vt == 2) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false, 2>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
             else if (cfg == 0) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
