@@ -157,7 +157,9 @@ __device__ __forceinline__ uint32_t fastdiv1(uint32_t i, uint32_t d, uint32_t in
 // Lanes of a wave take different reads (read index fastest), so the row stride -- forced odd -- is the bank stride.
 struct SegArg { int R, np, npad, wsd, nseg, nca; uint32_t inv_R, inv_wpr; int dbg; };   // dbg (PG_K1DBG, measurement aid): 1 = no record stores, 2 = no slot reservation either
 
-template <int NW, bool ROUTE, int S>
+// W: the window length (m-mers a k-mer) at compile time, with 16-mers (0: whatever the geometry says) -- the loops of phase B
+// unroll into loads with immediate offsets, phase A loses its shifts by 32 - 2m.
+template <int NW, bool ROUTE, int S, int W = 0>
 __global__ __launch_bounds__(BLOCK) void skm_scatter_seg_kernel(ReadsArg a, E2Dev e, DevCounters* ctr, SegArg sa, RouteArg ro) {
     constexpr int PW = E2Cfg<NW>::PW, RW = PW + 1;
     extern __shared__ __align__(16) unsigned char smem_raw[];
@@ -182,11 +184,11 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_seg_kernel(ReadsArg a, E2De
     for (int r = threadIdx.x; r < nr; r += BLOCK)
         for (int k = 2 * wpr; k < wsd; k++) dw[r * wsd + k] = 0;
     __syncthreads();
-    const int m = e.g.m, w = e.g.w;
+    const int m = W ? 16 : e.g.m, w = W ? W : e.g.w;
     // tasks are numbered over the full tile (read index fastest), a short last tile just leaves lanes idle
     for (int t = threadIdx.x; t < R * nca; t += BLOCK) {
         const int c = (int)fastdiv1(t, R, sa.inv_R), r = t - c * R;
-        if (r < nr) tile_mmer_chunk(dw + r * wsd, c, m, v0 + r * npad);
+        if (r < nr) tile_mmer_chunk<(W ? 16 : 0)>(dw + r * wsd, c, m, v0 + r * npad);
     }
     __syncthreads();
     for (int t = threadIdx.x; t < R * nseg; t += BLOCK) {
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_seg_kernel(ReadsArg a, E2De
         if (r >= nr) continue;
         const int j0 = seg * S, cnt = min(S, kpr - j0);
         uint32_t pid[S];
-        const uint32_t mk = tile_segment<S>(v0 + r * npad, np, j0, cnt, w, e.g.nmax, e.g.log2_parts, pid);
+        const uint32_t mk = tile_segment<S, W>(v0 + r * npad, np, j0, cnt, w, e.g.nmax, e.g.log2_parts, pid);
         smask[r * nseg + seg] = mk;
 #pragma unroll
         for (int i = 0; i < S; i++) pids[r * kpad + j0 + i] = pid[i];
@@ -383,7 +385,8 @@ __device__ __forceinline__ unsigned int wave_inclusive_sum(unsigned int x) {
 // KS: the kernel for ONE k-mer length (0 = any): the K-only shift amounts of occ_extract become immediates and its two wave-uniform
 // switches -- a dozen scalar branches an occurrence -- go away.
 template <int NW, int SLOTS, int THREADS, int WIN, bool TIMERS, int VT = 1, int KS = 0>
-__global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetParams sp, OccConst oc, DevCounters* ctr, int dbg) {
+__global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetParams sp, OccConst oc, DevCounters* ctr, int dbg_arg) {
+    const int dbg = KS == 0 ? dbg_arg : 0;                               // the measurement switches (PG_DBG) live in the general kernel only
     constexpr int PW = E2Cfg<NW>::PW, RW = PW + 1, KW = E2Cfg<NW>::KW, NWAVE = THREADS / 64, PIECES = RW / 2, N2 = 2 * NW;
     constexpr int RD = 2 * RW;                                            // dwords a record
     constexpr int PAD = 16;                                               // readable dwords in front of record 0 (a window reaches back 2 NW + 2)
@@ -1053,15 +1056,26 @@ static int e2_ensure_pool(pg_ctx* c, uint64_t n_reads, uint64_t n_kmers, hipStre
     return PG_OK;
 }
 
-template <int NW, bool ROUTE>
+template <int NW, bool ROUTE, int W>
 static void launch_seg_s(int S, dim3 grid, size_t smem, hipStream_t st, const ReadsArg& a, const E2Dev& e, DevCounters* ctr, const SegArg& sa, const RouteArg& ro) {
     switch (S) {
-        case 7: hipLaunchKernelGGL((skm_scatter_seg_kernel<NW, ROUTE, 7>), grid, dim3(BLOCK), smem, st, a, e, ctr, sa, ro); break;
-        case 9: hipLaunchKernelGGL((skm_scatter_seg_kernel<NW, ROUTE, 9>), grid, dim3(BLOCK), smem, st, a, e, ctr, sa, ro); break;
-        case 11: hipLaunchKernelGGL((skm_scatter_seg_kernel<NW, ROUTE, 11>), grid, dim3(BLOCK), smem, st, a, e, ctr, sa, ro); break;
-        case 13: hipLaunchKernelGGL((skm_scatter_seg_kernel<NW, ROUTE, 13>), grid, dim3(BLOCK), smem, st, a, e, ctr, sa, ro); break;
-        default: hipLaunchKernelGGL((skm_scatter_seg_kernel<NW, ROUTE, 15>), grid, dim3(BLOCK), smem, st, a, e, ctr, sa, ro); break;
+        case 7: hipLaunchKernelGGL((skm_scatter_seg_kernel<NW, ROUTE, 7, W>), grid, dim3(BLOCK), smem, st, a, e, ctr, sa, ro); break;
+        case 9: hipLaunchKernelGGL((skm_scatter_seg_kernel<NW, ROUTE, 9, W>), grid, dim3(BLOCK), smem, st, a, e, ctr, sa, ro); break;
+        case 11: hipLaunchKernelGGL((skm_scatter_seg_kernel<NW, ROUTE, 11, W>), grid, dim3(BLOCK), smem, st, a, e, ctr, sa, ro); break;
+        case 13: hipLaunchKernelGGL((skm_scatter_seg_kernel<NW, ROUTE, 13, W>), grid, dim3(BLOCK), smem, st, a, e, ctr, sa, ro); break;
+        default: hipLaunchKernelGGL((skm_scatter_seg_kernel<NW, ROUTE, 15, W>), grid, dim3(BLOCK), smem, st, a, e, ctr, sa, ro); break;
     }
+}
+// the instantiations with the window length at compile time: K = 63 (48 16-mers a k-mer) and K = 31 (16) in the two-word flavour,
+// K = 127 (112) in the four-word one; every other geometry runs the general kernel (PG_K1_W=0: always)
+template <int NW, bool ROUTE>
+static void launch_seg(int S, int m, int w, dim3 grid, size_t smem, hipStream_t st, const ReadsArg& a, const E2Dev& e, DevCounters* ctr, const SegArg& sa, const RouteArg& ro) {
+    bool fixed = m == 16 && S <= w;
+    if (const char* v = getenv("PG_K1_W")) fixed = fixed && atoi(v) != 0;
+    if (fixed && NW == 2 && w == 48) launch_seg_s<NW, ROUTE, 48>(S, grid, smem, st, a, e, ctr, sa, ro);
+    else if (fixed && NW == 2 && w == 16) launch_seg_s<NW, ROUTE, 16>(S, grid, smem, st, a, e, ctr, sa, ro);
+    else if (fixed && NW == 4 && w == 112) launch_seg_s<NW, ROUTE, 112>(S, grid, smem, st, a, e, ctr, sa, ro);
+    else launch_seg_s<NW, ROUTE, 0>(S, grid, smem, st, a, e, ctr, sa, ro);
 }
 
 // launch the tiled K1; returns PG_OK / an error, or 1 when the reads are too long for a tile (caller falls back)
@@ -1093,11 +1107,11 @@ static int launch_tiled(pg_ctx* c, const ReadsArg& a, const RouteArg* route, hip
     if (route) ro = *route;
     const size_t smem = per_read * R;
     if (c->NW == 2) {
-        if (route) launch_seg_s<2, true>(S, dim3((unsigned)grid), smem, st, a, dev_view(c), c->ctr, sa, ro);
-        else launch_seg_s<2, false>(S, dim3((unsigned)grid), smem, st, a, dev_view(c), c->ctr, sa, ro);
+        if (route) launch_seg<2, true>(S, g.m, g.w, dim3((unsigned)grid), smem, st, a, dev_view(c), c->ctr, sa, ro);
+        else launch_seg<2, false>(S, g.m, g.w, dim3((unsigned)grid), smem, st, a, dev_view(c), c->ctr, sa, ro);
     } else {
-        if (route) launch_seg_s<4, true>(S, dim3((unsigned)grid), smem, st, a, dev_view(c), c->ctr, sa, ro);
-        else launch_seg_s<4, false>(S, dim3((unsigned)grid), smem, st, a, dev_view(c), c->ctr, sa, ro);
+        if (route) launch_seg<4, true>(S, g.m, g.w, dim3((unsigned)grid), smem, st, a, dev_view(c), c->ctr, sa, ro);
+        else launch_seg<4, false>(S, g.m, g.w, dim3((unsigned)grid), smem, st, a, dev_view(c), c->ctr, sa, ro);
     }
     E2_TRY(hipGetLastError());
     c->e2.counted = false;
@@ -1260,6 +1274,7 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     if (const char* v = getenv("PG_K2CFG")) cfg = atoi(v);
     bool ks = true;                                                       // the instantiations for K = 31 / 63 / 127 (PG_K2_KS=0: the general kernel)
     if (const char* v = getenv("PG_K2_KS")) ks = atoi(v) != 0;
+    if (dbg) ks = false;
     // cfg 0: 2048-slot set, 1024 lanes, 512-record windows  -> ~150 KB LDS, one workgroup per CU
     // cfg 1: 1024-slot set,  512 lanes, 256-record windows  ->  ~77 KB LDS, two workgroups per CU
     {

@@ -6,7 +6,7 @@
 //
 //   A  tile_mmer_chunk      16 consecutive m-mer values of a read from two dwords of its base string
 //   B  tile_segment<S>      the sliding-window minima of S consecutive k-mers (+ their predecessor) with w + S reads:
-//                           all S + 1 windows share the core [last k-mer, first k-mer + w), so
+//                           all S + 1 windows share the core [first k-mer + S - 1, first k-mer - 1 + w), so
 //                           min(window j) = min(suffix-min up to the core, core, prefix-min behind the core);
 //                           then partition ids and the run-start bits of the S k-mers
 //   D  tile_next_start      where the run that starts at a given bit ends (the next start bit, in this or a later segment)
@@ -38,13 +38,14 @@ PG_HD uint32_t mmer_from_window(uint32_t x, int m) {
 
 // A: m-mer values at positions 16 c .. 16 c + 15 of one read; row = its dword string (two readable dwords behind it),
 // out = its value row, which has room for 16 * ceil(np / 16) values: positions >= np get junk nobody reads, and the
-// sixteen stores need no bound test.
+// sixteen stores need no bound test.  M: the m-mer length at compile time (0: `m`).
+template <int M = 0>
 PG_HD void tile_mmer_chunk(const uint32_t* row, int c, int m, uint32_t* out) {
     const uint32_t d0 = row[c], d1 = row[c + 1];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
         const uint32_t x = i ? alignbit32(d0, d1, (uint32_t)(32 - 2 * i)) : d0;
-        out[16 * c + i] = mmer_from_window(x, m);
+        out[16 * c + i] = mmer_from_window(x, M ? M : m);
     }
 }
 
@@ -53,24 +54,32 @@ PG_HD void tile_mmer_chunk(const uint32_t* row, int c, int m, uint32_t* out) {
 // and the partition ids in pid_out[0 .. S) (those at cnt and above are junk).
 // Straight-line on purpose: every load address is clamped into the row instead of being skipped, every "does this window
 // exist" is a select -- a wave runs 64 segments in lockstep, and the branchy form spent more instructions on exec masks
-// than on minima.
-template <int S>
-PG_HD uint32_t tile_segment(const uint32_t* v, int np, int j0, int cnt, int w, int nmax, int log2_parts, uint32_t* pid_out) {
+// than on minima.  The three parts are cut at places that depend on the segment's FIRST k-mer alone (not on cnt): window q
+// = k-mer j0 - 1 + q is  [j0 - 1 + q, J)  +  [J, j0 - 1 + w)  +  [j0 - 1 + w, j0 - 1 + q + w)  with J = j0 + S - 1, so the
+// middle part has w - S positions for every lane and, with W = w at compile time, all three loops unroll into loads with
+// immediate offsets.
+template <int S, int W = 0>
+PG_HD uint32_t tile_segment(const uint32_t* v, int np, int j0, int cnt, int w_rt, int nmax, int log2_parts, uint32_t* pid_out) {
     // window q = k-mer j0 - 1 + q, q = 0 .. cnt: q = 0 is the predecessor of the segment's first k-mer (none when j0 = 0),
     // wanted only for the partition comparison.  All indices below are compile-time, so the arrays stay in registers.
-    const int jl = j0 - 1, jh = j0 + cnt - 1;
+    const int w = W ? W : w_rt;
+    const int jl = j0 - 1, J = j0 + S - 1;
     uint32_t suf[S + 1], pre[S + 1];
-    suf[S] = 0xFFFFFFFFu;                                          // suf[q] = min over positions [jl + q, jh)
+    suf[S] = 0xFFFFFFFFu;                                          // suf[q] = min over positions [jl + q, J)   (J - 1 < np: S <= w)
 #pragma unroll
     for (int q = S - 1; q >= 0; q--) {
         const int at = jl + q;
-        const uint32_t x = v[at < 0 ? 0 : at];                     // (at <= jh - 1 < np whenever it counts; S <= w keeps it in the row anyway)
-        const bool in = q < cnt && at >= 0;
+        const uint32_t x = v[at < 0 ? 0 : at];
         const uint32_t mn = x < suf[q + 1] ? x : suf[q + 1];
-        suf[q] = in ? mn : 0xFFFFFFFFu;
+        suf[q] = at >= 0 ? mn : 0xFFFFFFFFu;                       // (at < 0: q = 0 of the read's first segment, a window nobody uses)
     }
-    uint32_t core = 0xFFFFFFFFu;                                   // positions [jh, jl + w): inside every window (cnt <= S <= w)
-    for (int p = jh; p < jl + w; p++) { const uint32_t x = v[p]; core = x < core ? x : core; }
+    uint32_t core = 0xFFFFFFFFu;                                   // positions [J, jl + w): inside every window of the segment
+    if (W) {
+#pragma unroll
+        for (int i = 0; i < (W ? W - S : 0); i++) { const uint32_t x = v[J + i]; core = x < core ? x : core; }
+    } else {
+        for (int p = J; p < jl + w; p++) { const uint32_t x = v[p]; core = x < core ? x : core; }
+    }
     pre[0] = 0xFFFFFFFFu;                                          // pre[q] = min over positions [jl + w, jl + q + w)
 #pragma unroll
     for (int q = 1; q <= S; q++) {

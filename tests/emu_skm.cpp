@@ -137,7 +137,11 @@ static int64_t tile_check(const uint64_t* packed, int64_t n_reads, int len, int 
                 const uint64_t wd = packed[(r0 + r) * wpr + k];
                 dw[(size_t)r * wsd + 2 * k] = (uint32_t)(wd >> 32); dw[(size_t)r * wsd + 2 * k + 1] = (uint32_t)wd;
             }
-        for (int t = 0; t < nr * nca; t++) { const int c = t / nr, r = t % nr; tile_mmer_chunk(dw.data() + (size_t)r * wsd, c, g.m, v0.data() + (size_t)r * npad); }
+        for (int t = 0; t < nr * nca; t++) {
+            const int c = t / nr, r = t % nr;
+            if (g.m == 16 && (t & 1)) tile_mmer_chunk<16>(dw.data() + (size_t)r * wsd, c, g.m, v0.data() + (size_t)r * npad);      // (both forms; every position is compared below)
+            else tile_mmer_chunk(dw.data() + (size_t)r * wsd, c, g.m, v0.data() + (size_t)r * npad);
+        }
         for (int r = 0; r < nr; r++)                                // phase A against the 64-bit formulation
             for (int p = 0; p < np; p++) if (v0[(size_t)r * npad + p] != mmer_value(packed + (r0 + r) * wpr, p, g.m)) return -101;
         for (int t = 0; t < nr * nseg; t++) {
@@ -145,6 +149,18 @@ static int64_t tile_check(const uint64_t* packed, int64_t n_reads, int len, int 
             uint32_t pid[S];
             masks[(size_t)r * nseg + seg] = tile_segment<S>(v0.data() + (size_t)r * npad, np, j0, cnt, g.w, g.nmax, log2_parts, pid);
             for (int i = 0; i < cnt; i++) pids[(size_t)r * kpr + j0 + i] = pid[i];
+            // the instantiations with the window length at compile time (what the kernel runs for K = 31 / 63 / 127): same bits, same ids
+            uint32_t pid2[S];
+            uint32_t mk2 = masks[(size_t)r * nseg + seg];
+            bool have = true;
+            if (g.w == 48 && S <= 48) mk2 = tile_segment<S, 48>(v0.data() + (size_t)r * npad, np, j0, cnt, g.w, g.nmax, log2_parts, pid2);
+            else if (g.w == 112 && S <= 112) mk2 = tile_segment<S, 112>(v0.data() + (size_t)r * npad, np, j0, cnt, g.w, g.nmax, log2_parts, pid2);
+            else if (g.w == 16 && S <= 16) mk2 = tile_segment<S, 16>(v0.data() + (size_t)r * npad, np, j0, cnt, g.w, g.nmax, log2_parts, pid2);
+            else have = false;
+            if (have) {
+                if (mk2 != masks[(size_t)r * nseg + seg]) return -105;
+                for (int i = 0; i < cnt; i++) if (pid2[i] != pid[i]) return -106;
+            }
         }
         for (int r = 0; r < nr; r++) {
             struct Run { int j0, n; uint32_t pid; };
