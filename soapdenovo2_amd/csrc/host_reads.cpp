@@ -407,7 +407,9 @@ static PackFn pick_pack() {
 }
 static const PackFn g_pack = pick_pack();
 
-struct PackedRun {
+// (one cache line pair to itself: the parsing threads' runs lie next to each other in a vector, and every record moves the
+//  vectors' end pointers and the counters -- unaligned, two threads shared a line and the reader stopped scaling at two threads)
+struct alignas(128) PackedRun {
     std::vector<uint64_t> words;
     std::vector<int32_t> lens;
     long long records = 0;
@@ -415,7 +417,15 @@ struct PackedRun {
     void clear() { words.clear(); lens.clear(); records = 0; min_len = 0x7fffffff; max_len = 0; }
 };
 
-void parse_range(const InputFile& in, bool fastq, const char* buf, size_t size, std::vector<uint8_t>& codes, PackedRun& out) {
+// the one-byte-a-base buffer of a parsing thread: written for every base of every read, so it keeps 128 bytes of distance from its
+// neighbours' (the threads' buffers used to be 160-byte heap blocks side by side: two threads shared a cache line, and eight threads
+// parsed no faster than one -- scripts/parse_bench.cpp)
+struct CodeBuf {
+    std::vector<uint8_t> raw;
+    explicit CodeBuf(size_t n = 0) : raw(n + 256) {}
+    uint8_t* data() { return (uint8_t*)(((uintptr_t)raw.data() + 127) & ~(uintptr_t)127); }
+};
+void parse_range(const InputFile& in, bool fastq, const char* buf, size_t size, CodeBuf& codes, PackedRun& out) {
     size_t start = 0;
     const bool simd = simd_parse_on();
     while (start < size) {
@@ -431,6 +441,56 @@ void parse_range(const InputFile& in, bool fastq, const char* buf, size_t size, 
         out.max_len = std::max(out.max_len, n);
     }
 }
+
+// Threads that live as long as the file is streamed: body(t) for t = 0 .. n - 1, t = 0 on the calling thread.  (A window of the
+// file is parsed in some 15 ms; threads created per window start on their creator's processor and are spread by the scheduler's
+// balancer only ticks later -- sixteen of them parsed a window hardly faster than three: scripts/parse_bench.cpp shows the same
+// with short jobs.  Threads that sleep between windows stay where they were.)
+class WorkerPool {
+    int n;
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv_start, cv_done;
+    const std::function<void(int)>* job = nullptr;
+    uint64_t gen = 0;
+    int pending = 0;
+    bool stop = false;
+    void worker(int t) {
+        uint64_t seen = 0;
+        for (;;) {
+            const std::function<void(int)>* j;
+            {
+                std::unique_lock<std::mutex> lk(m);
+                cv_start.wait(lk, [&] { return stop || gen != seen; });
+                if (stop) return;
+                seen = gen;
+                j = job;
+            }
+            (*j)(t);
+            {
+                std::lock_guard<std::mutex> lk(m);
+                if (--pending == 0) cv_done.notify_all();
+            }
+        }
+    }
+public:
+    explicit WorkerPool(int n_) : n(std::max(1, n_)) { for (int t = 1; t < n; t++) th.emplace_back([this, t] { worker(t); }); }
+    WorkerPool(const WorkerPool&) = delete;
+    WorkerPool& operator=(const WorkerPool&) = delete;
+    ~WorkerPool() {
+        { std::lock_guard<std::mutex> lk(m); stop = true; }
+        cv_start.notify_all();
+        for (auto& t : th) t.join();
+    }
+    void run(const std::function<void(int)>& body) {        // one caller at a time
+        if (n > 1) {
+            { std::lock_guard<std::mutex> lk(m); job = &body; pending = n - 1; gen++; }
+            cv_start.notify_all();
+        }
+        body(0);
+        if (n > 1) { std::unique_lock<std::mutex> lk(m); cv_done.wait(lk, [&] { return pending == 0; }); }
+    }
+};
 
 // `on_run` gets the packed reads of a stretch of the file, in file order; returning false stops the stream early
 typedef std::function<bool(PackedRun&)> RunFn;
@@ -457,7 +517,8 @@ long long stream_file_parallel(const InputFile& in, const std::string& path, boo
     // two sets of runs: while the caller's thread hands one window's runs over (copies into the batch buffers: serial, and
     // about as long as the parsing itself once a dozen threads parse), the threads already cut and parse the next window
     std::vector<PackedRun> run_sets[2] = {std::vector<PackedRun>(nt), std::vector<PackedRun>(nt)};
-    std::vector<std::vector<uint8_t>> codes(nt, std::vector<uint8_t>((size_t)std::max(in.max_read_len, 1) + 8));
+    std::vector<CodeBuf> codes(nt, CodeBuf((size_t)std::max(in.max_read_len, 1) + 8));
+    WorkerPool workers(nt), readers(4);
     std::string last_buf;                                   // the buffer parsed last, for the N x 32768 rerun
     size_t carry = 0;
     long long n_records = 0;
@@ -481,14 +542,10 @@ long long stream_file_parallel(const InputFile& in, const std::string& path, boo
             while (bi < bufs.size() && acc < want) { acc += bufs[bi].second - bufs[bi].first; bi++; }
             first[t] = bi;
         }
-        auto body = [&](int t) {
+        workers.run([&](int t) {
             runs[t].clear();
             for (size_t i = first[t]; i < first[t + 1]; i++) parse_range(in, fastq, wdata + bufs[i].first, bufs[i].second - bufs[i].first, codes[t], runs[t]);
-        };
-        std::vector<std::thread> pool;
-        for (int t = 1; t < nt; t++) pool.emplace_back(body, t);
-        body(0);
-        for (auto& th : pool) th.join();
+        });
     };
     // a regular file is read with a few preads side by side (one thread copying out of the page cache is slower than the
     // parsers); a pipe (.gz) is read as it comes
@@ -500,7 +557,7 @@ long long stream_file_parallel(const InputFile& in, const std::string& path, boo
         const int fd = fileno(src.fp);
         const int parts = 4;
         size_t got_part[parts] = {0, 0, 0, 0};
-        auto body = [&](int t) {
+        readers.run([&](int t) {
             const size_t lo = want * t / parts, hi = want * (t + 1) / parts;
             size_t done = 0;
             while (lo + done < hi) {
@@ -509,11 +566,7 @@ long long stream_file_parallel(const InputFile& in, const std::string& path, boo
                 done += (size_t)r;
             }
             got_part[t] = done;
-        };
-        std::vector<std::thread> pool;
-        for (int t = 1; t < parts; t++) pool.emplace_back(body, t);
-        body(0);
-        for (auto& th : pool) th.join();
+        });
         size_t total = 0;
         for (int t = 0; t < parts; t++) {                       // a short part means the file ended inside it
             total += got_part[t];
@@ -544,14 +597,10 @@ long long stream_file_parallel(const InputFile& in, const std::string& path, boo
         wdata = map ? map + file_off - carry : win.data();     // (mapped: file_off = where the window's fresh bytes start)
         cuts.assign(n_full, 0);
         {
-            auto body = [&](int t) {
+            workers.run([&](int t) {
                 for (size_t i = n_full * t / nt; i < n_full * (t + 1) / nt; i++)
                     cuts[i] = fastq ? fastq_cut(wdata + carry + i * CHUNK, CHUNK) : fasta_cut(wdata + carry + i * CHUNK, CHUNK);
-            };
-            std::vector<std::thread> pool;
-            for (int t = 1; t < nt; t++) pool.emplace_back(body, t);
-            body(0);
-            for (auto& th : pool) th.join();
+            });
         }
         t_cut += std::chrono::duration<double>(std::chrono::steady_clock::now() - tr0).count();
         bufs.clear();
