@@ -814,6 +814,7 @@ int run(int argc, char** argv, bool mer127) {
     if (const char* e = getenv("SOAPDENOVO2_AMD_PASS2")) host_pass2 = strcmp(e, "host") == 0;
     if (host_pass2) host_edges = true;                               // host pass 2 needs the host copy of the sets tagged
     // records still on the device: with -a the layout is made there (K6), otherwise the replay's workers pull their stretches
+    (void)pg_host_edge_file_in_background(getenv("SOAPDENOVO2_AMD_EDGE_FILE_INLINE") ? 0 : 1);    // <o>.edge.gz is formatted and deflated beside pass 2
     for (int r = 0; r < (int)sh_ws.size(); r++)                      // one block a device (ranks that share a GPU in test set-ups: the first one's)
         if (sh_ws[r] && sh_ws_front[r] && pg_device_scratch_offer(devices[r], sh_ws[r], sh_ws_front[r]) == PG_OK) sh_offered[r] = 1;
     pg_graph* graph = n_ranks > 1
@@ -824,6 +825,7 @@ int run(int argc, char** argv, bool mer127) {
                                 max_read_len, 0, o.prefix.c_str(), host_edges ? -1 : device)
         : pg_graph_begin(records.data(), n_distinct, set_last.data(), K, mer127 ? 1 : 0, o.sets, o.delow == 0, o.a_gb,
                          max_read_len, 0, o.prefix.c_str(), host_edges ? -1 : device);
+    (void)pg_host_edge_file_in_background(0);                         // (the decision was taken while the edges were built; other callers in this process keep the default)
     if (ws_offered) { if (void* back = pg_device_scratch_withdraw(device)) (void)hipFree(back); d_ws = nullptr; }
     if (d_rec) { hipFree(d_rec); d_rec = nullptr; }
     for (int r = 0; r < (int)sh_rec.size(); r++) {

@@ -52,6 +52,7 @@ namespace pg {
 
 static uint32_t g_crc_tab[256];
 static std::atomic<bool> g_crc_ready{false};
+static std::atomic<int> g_edge_file_in_background{0};     // pg_host_edge_file_in_background
 // host threads for the parallel stages: the caller's count, else SOAPDENOVO2_AMD_HOST_THREADS, else every hardware thread
 int host_threads(int n_threads);
 static int pick_threads(int n_threads) { return host_threads(n_threads); }
@@ -1743,6 +1744,7 @@ struct GraphHandle : GraphHandleBase {
     ~GraphHandle() override { shutdown(); }
     // everything but the memory: threads, files, the device copy
     void shutdown() override {
+        if (edge_thread.joinable()) edge_thread.join();
         if (vertex_thread.joinable()) vertex_thread.join();
         if (path_fp) { fclose(path_fp); path_fp = nullptr; }
         if (dev) { p2_destroy(dev); dev = nullptr; }
@@ -1785,6 +1787,34 @@ struct GraphHandle : GraphHandleBase {
         const double te1 = now();
         edge_c = (int)ed.n_ids; records_c = (long long)ed.recs.size(); extra_nodes = ed.n_len1;
         dev_edges = true;
+        // <prefix>.edge.gz is text made from what the device handed back; nothing that follows reads it.  A caller that said so
+        // (pg_host_edge_file_in_background: call_pregraph) gets it written beside pass 2 and waits for it in finish.
+        if (g_edge_file_in_background.load()) {
+            auto* held = new P2Edges(std::move(ed));
+            edge_started = true;
+            edge_thread = std::thread([this, held, n_threads, te0, te1] {
+                edge_rc = write_edge_file(*held, n_threads, te0, te1);
+                if (edge_rc) edge_err = pg_last_error();
+                delete held;
+            });
+            return PG_OK;
+        }
+        return write_edge_file(ed, n_threads, te0, te1);
+    }
+    std::thread edge_thread;
+    bool edge_started = false;
+    int edge_rc = PG_OK;
+    std::string edge_err;
+    int join_edge_writer() {
+        if (!edge_started) return PG_OK;
+        const double tw0 = now();
+        if (edge_thread.joinable()) edge_thread.join();
+        if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "finish: waited %.2fs for the edge file\n", now() - tw0);
+        edge_started = false;
+        if (edge_rc) pg_set_error(edge_err);
+        return edge_rc;
+    }
+    int write_edge_file(const P2Edges& ed, int n_threads, double te0, double te1) {
         // text records, one gzip member per range of edges, formatted and deflated by all host threads
         const size_t STEP = 1 << 15, n_chunks = (ed.recs.size() + STEP - 1) / STEP;
         std::vector<std::vector<uint8_t>> gz(n_chunks);
@@ -2161,6 +2191,7 @@ struct GraphHandle : GraphHandleBase {
         fprintf(stderr, "Reads alignment done, %lld read(s) deleted, %lld pre-arc(s) added.\n", reads_deleted, arc_count);
         fprintf(stderr, "Time spent on threading reads: %.1fs, on folding pre-arcs: %.1fs.\n", t_thread, t_fold);
         if (n_arcs) *n_arcs = arc_count;
+        { const int erc = join_edge_writer(); if (erc) return erc; }
         if (vertex_started) {
             const double tw0 = now();
             if (vertex_thread.joinable()) vertex_thread.join();
@@ -2452,6 +2483,10 @@ extern "C" pg_graph* pg_graph_begin(const uint64_t* records, uint64_t n_records,
     pg::GraphHandleBase* h = mer127 ? pg::graph_begin<4>(records, n_records, set_last_put, K, n_sets, cut_single, a_gb, max_read_len, n_threads, prefix, device)
                                     : pg::graph_begin<2>(records, n_records, set_last_put, K, n_sets, cut_single, a_gb, max_read_len, n_threads, prefix, device);
     return (pg_graph*)h;
+}
+extern "C" int pg_host_edge_file_in_background(int on) {
+    pg::g_edge_file_in_background.store(on ? 1 : 0);
+    return PG_OK;
 }
 extern "C" int pg_host_graph_resolve_repeats(pg_graph* g, int on) {
     if (!g) { pg_set_error("null argument"); return PG_EINVAL; }
