@@ -177,6 +177,10 @@ pg_graph *pg_host_graph_begin(const uint64_t *records, uint64_t n_records, const
 int pg_host_graph_resolve_repeats(pg_graph *g, int on);
 int pg_graph_use_device(pg_graph *g, int device);
 int pg_host_graph_add_packed(pg_graph *g, const uint64_t *words, const int32_t *lens, uint64_t n_reads, int n_threads);
+/* the same for reads that are already in the memory of HIP device `device` (the graph's own: pg_graph_use_device), all of
+ * read_len bases, packed back to back, 8 readable words behind the last -- what pass 1 leaves there when it keeps its batches;
+ * no copy, no index arrays.  Not for -R runs (the walks of a read come back through the host path). */
+int pg_graph_add_packed_device(pg_graph *g, const uint64_t *d_words, uint64_t n_reads, int read_len, int device);
 int pg_host_graph_add_reads(pg_graph *g, const uint8_t *codes, const int32_t *lens, uint64_t n_reads, uint64_t stride,
                             int n_threads);
 int pg_host_graph_finish(pg_graph *g, int *out_num_vertex, int *out_num_edge, long long *out_num_prearc);

@@ -191,6 +191,43 @@ struct KeptReads {
     }
 };
 
+// Reads kept for pass 2 in DEVICE memory: while every read so far has one length, the batches pass 1 has uploaded anyway are
+// copied on (device to device) into chunks of 1 GiB, one segment a batch; pass 2 threads them where they are
+// (pg_graph_add_packed_device) -- no copy back, no index arrays.  The first read of another length moves everything into the host
+// store (KeptReads), which then goes on as before.
+struct DevKept {
+    struct Seg { uint64_t* d; uint64_t n_reads; };
+    static constexpr size_t CHUNK_WORDS = (size_t)1 << 27;
+    std::vector<void*> chunks;
+    std::vector<Seg> segs;
+    size_t used_in_last = 0, total_bytes = 0;
+    int len = 0, device = 0;
+    DevKept() {}
+    DevKept(const DevKept&) = delete;
+    DevKept& operator=(const DevKept&) = delete;
+    ~DevKept() { clear(); }
+    void clear() {
+        for (void* c : chunks) (void)hipFree(c);
+        chunks.clear(); segs.clear(); used_in_last = 0; total_bytes = 0; len = 0;
+    }
+    void swap(DevKept& o) { chunks.swap(o.chunks); segs.swap(o.segs); std::swap(used_in_last, o.used_in_last); std::swap(total_bytes, o.total_bytes); std::swap(len, o.len); std::swap(device, o.device); }
+    // room for n_words words (<= CHUNK_WORDS); nullptr = no device memory
+    uint64_t* take(size_t n_words) {
+        if (n_words > CHUNK_WORDS) return nullptr;
+        if (chunks.empty() || used_in_last + n_words > CHUNK_WORDS) {
+            void* c = nullptr;
+            if (hipMalloc(&c, CHUNK_WORDS * sizeof(uint64_t)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            chunks.push_back(c);
+            used_in_last = 0;
+        }
+        uint64_t* p = (uint64_t*)chunks.back() + used_in_last;
+        used_in_last += n_words;
+        total_bytes += n_words * sizeof(uint64_t);
+        return p;
+    }
+};
+
+
 // Pass 1 driver, common part: accepted reads -> 2-bit packed batches in pinned host buffers.  What happens to a full
 // batch is the backend's business (submit): one GPU takes batch after batch (Pass1), several GPUs take a round of one
 // batch each and exchange (ShardedPass1).
@@ -220,6 +257,7 @@ public:
         Buf* b = &buf_[cur_];
         if (b->n_reads == max_reads_ || b->n_words + nw > max_words_) { submit(); b = &buf_[cur_]; }
         pg_pack_read(codes, (uint32_t)len, b->h_words + b->n_words);
+        if (keep_ && dev_keep_) dev_keep_to_host();
         if (keep_) { const int32_t l32 = len; keep_append(b->h_words + b->n_words, nw, &l32, 1); }   // pass 2 threads the same reads again
         b->h_off[b->n_reads] = b->n_words;
         b->h_base[b->n_reads] = b->n_kmers;
@@ -249,7 +287,10 @@ public:
                         b->h_off[b->n_reads + i] = b->n_words + i * wpr;
                         b->h_base[b->n_reads + i] = b->n_kmers + i * kpr;
                     }
-                if (keep_) keep_append(words + at, take * wpr, lens + r, take);
+                if (keep_) {
+                    if (dev_keep_ && (dev_len_ == 0 || dev_len_ == len)) dev_len_ = len;      // kept when the batch is on the device (submit)
+                    else { if (dev_keep_) dev_keep_to_host(); if (keep_) keep_append(words + at, take * wpr, lens + r, take); }
+                }
                 b->n_words += take * wpr; b->n_kmers += take * kpr; b->n_reads += take;
                 accepted_ += (long long)take;
                 at += take * wpr; r += take;
@@ -263,6 +304,7 @@ public:
                 Buf* b = &buf_[cur_];
                 if (b->n_reads == max_reads_ || b->n_words + nw > max_words_) { submit(); b = &buf_[cur_]; }
                 memcpy(b->h_words + b->n_words, words + at, nw * sizeof(uint64_t));
+                if (keep_ && dev_keep_) { dev_keep_to_host(); b = &buf_[cur_]; }
                 if (keep_) keep_append(words + at, nw, &lens[r], 1);
                 b->h_off[b->n_reads] = b->n_words;
                 b->h_base[b->n_reads] = b->n_kmers;
@@ -289,6 +331,36 @@ public:
     uint64_t total_kmers() const { return ord_; }
     // the packed reads kept for pass 2, or nothing when they outgrew the budget (then the files are parsed again)
     void keep_reads(size_t budget_bytes) { keep_ = budget_bytes > 0; keep_budget_ = budget_bytes; }
+    // ... on the device while they are of one length (single-GPU pass 1 only; see DevKept)
+    void keep_reads_on_device(size_t budget_bytes) { dev_keep_ = keep_ && budget_bytes > 0; dev_budget_ = budget_bytes; }
+    bool take_dev_kept(DevKept& out) {
+        if (!dev_keep_) return false;
+        dev_kept_.len = dev_len_;
+        out.swap(dev_kept_);
+        return !out.segs.empty();
+    }
+    // everything kept on the device so far, and the reads waiting in the batch being filled, into the host store; from here on
+    // the host store is the only one
+    virtual void dev_keep_to_host() {
+        if (!dev_keep_) return;
+        dev_keep_ = false;
+        const size_t wpr = dev_len_ ? pg_packed_words((uint32_t)dev_len_) : 0;
+        std::vector<uint64_t> tmp;
+        std::vector<int32_t> ls;
+        (void)hipDeviceSynchronize();
+        for (const DevKept::Seg& sg : dev_kept_.segs) {
+            tmp.resize(sg.n_reads * wpr);
+            ls.assign(sg.n_reads, (int32_t)dev_len_);
+            if (hipMemcpy(tmp.data(), sg.d, tmp.size() * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) { keep_ = false; kept_.clear(); break; }
+            if (keep_) keep_append(tmp.data(), tmp.size(), ls.data(), sg.n_reads);
+        }
+        dev_kept_.clear();
+        const Buf& b = buf_[cur_];
+        if (keep_ && b.n_reads && wpr) {                          // (filled by the one-length block copies alone while the device kept them)
+            ls.assign(b.n_reads, (int32_t)dev_len_);
+            keep_append(b.h_words, b.n_reads * wpr, ls.data(), b.n_reads);
+        }
+    }
     bool take_kept(KeptReads& out) {
         if (!keep_) return false;
         out.swap(kept_);
@@ -322,6 +394,13 @@ private:
     bool keep_ = false;
     size_t keep_budget_ = 0;
     KeptReads kept_;
+
+protected:
+    void keep_host(const uint64_t* w, size_t nw, const int32_t* lens, size_t n) { if (keep_) keep_append(w, nw, lens, n); }
+    bool dev_keep_ = false;
+    int dev_len_ = 0;
+    size_t dev_budget_ = 0;
+    DevKept dev_kept_;
 };
 
 // One GPU: hipMemcpyAsync + pg_count_reads, two batches in flight so parsing overlaps the copy + kernel of the previous one.
@@ -363,6 +442,20 @@ private:
             if (!failed_ && pg_count_reads(ctx_, d.d_words, b.uniform ? nullptr : d.d_off, b.uniform ? nullptr : d.d_base, b.n_reads,
                                            b.uniform ? (uint32_t)b.first_len : 0u, b.n_kmers, b.ord_base, stream_) != PG_OK)
                 failed_ = true;                                     // the caller decides (finish_ok)
+            if (dev_keep_) {                                        // the batch is of one length (or dev_keep_ would be off): it stays on the device for pass 2
+                uint64_t* dst = dev_kept_.total_bytes + (b.n_words + 8) * sizeof(uint64_t) <= dev_budget_ ? dev_kept_.take(b.n_words + 8) : nullptr;
+                if (dst && hipMemcpyAsync(dst, d.d_words, (b.n_words + 8) * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream_) == hipSuccess)
+                    dev_kept_.segs.push_back(DevKept::Seg{dst, b.n_reads});
+                else {                                              // no room: this batch and all before it go to the host store
+                    const size_t wpr = pg_packed_words((uint32_t)dev_len_);
+                    std::vector<int32_t> ls(b.n_reads, (int32_t)dev_len_);
+                    Buf hold = b;                                   // (dev_keep_to_host looks at buf_[cur_]: make it see an empty batch, this one is appended below)
+                    b.n_reads = 0;
+                    dev_keep_to_host();
+                    b = hold;
+                    keep_host(b.h_words, b.n_reads * wpr, ls.data(), b.n_reads);
+                }
+            }
             HIP_OK(hipEventRecord(d.done, stream_));
             d.busy = true;
         }
@@ -560,6 +653,17 @@ int run(int argc, char** argv, bool mer127) {
     if (const char* e = getenv("SOAPDENOVO2_AMD_KEEP_READS_GB")) keep_budget = (size_t)(atof(e) * 1073741824.0);
     KeptReads kept;
     bool have_kept = false;
+    // ... on the device instead, while the reads are of one length and pass 2 runs there without -R (SOAPDENOVO2_AMD_KEEP_ON_HOST=1: never)
+    DevKept devkept;
+    size_t dev_keep_budget = 0;
+    {
+        const char* e2 = getenv("SOAPDENOVO2_AMD_PASS2");
+        const char* e1 = getenv("SOAPDENOVO2_AMD_EDGES");
+        const bool host_side = (e2 && !strcmp(e2, "host")) || (e1 && !strcmp(e1, "host"));
+        size_t free_b = 0, total_b = 0;
+        if (!o.reps && !host_side && !getenv("SOAPDENOVO2_AMD_KEEP_ON_HOST") && keep_budget > 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+            dev_keep_budget = total_b / 8;
+    }
     long long n_records = 0;
     uint64_t total_kmers = 0;
     uint64_t hist[256];
@@ -690,6 +794,7 @@ int run(int argc, char** argv, bool mer127) {
             mark("pinned batch buffers allocated");
             if (attempt == 0) {
                 p1.keep_reads(keep_budget);
+                p1.keep_reads_on_device(dev_keep_budget);
                 for (const pg::InputFile& f : files) {
                     fprintf(stderr, "Import reads from file:\n %s\n", f.path1.c_str());
                     if (!f.path2.empty()) fprintf(stderr, "Import reads from file:\n %s\n", f.path2.c_str());
@@ -708,7 +813,11 @@ int run(int argc, char** argv, bool mer127) {
             ok = p1.finish_ok();
             mark("last batch cut on the device");
             total_kmers = p1.total_kmers();
-            if (attempt == 0) have_kept = p1.take_kept(kept);
+            if (attempt == 0) {
+                (void)p1.take_dev_kept(devkept);                   // (the batch still being filled went out with finish_ok)
+                devkept.device = device;
+                have_kept = p1.take_kept(kept);
+            }
         }
         lap("parse + scatter (pass 1)");
         // ---- -d filter, linear marking, .kmerFreq (deLowCov / Mark1in1outNode / freqStat); with the partition engine
@@ -727,6 +836,19 @@ int run(int argc, char** argv, bool mer127) {
         fprintf(stderr, "Partition engine gave up (%s); counting again with the global k-mer set.\n", pg_last_error());
         pg_destroy(ctx);
         engine = 1;
+        if (!devkept.segs.empty()) {                               // the second attempt is fed from the host store
+            const size_t wpr = pg_packed_words((uint32_t)devkept.len);
+            std::vector<uint64_t> tmp;
+            std::vector<int32_t> ls;
+            for (const DevKept::Seg& sg : devkept.segs) {
+                tmp.resize(sg.n_reads * wpr);
+                ls.assign(sg.n_reads, (int32_t)devkept.len);
+                if (hipMemcpy(tmp.data(), sg.d, tmp.size() * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess || !kept.append(tmp.data(), tmp.size(), ls.data(), sg.n_reads)) {
+                    have_kept = false; kept.clear(); break;
+                }
+            }
+            devkept.clear();
+        }
     }
     }
     lap("count partitions (finalize)");
@@ -848,7 +970,14 @@ int run(int argc, char** argv, bool mer127) {
 
     // ---- pass 2 (prlRead2edge): the reads again, in the same order, threaded through the edges -> .preArc
     t0 = time(nullptr);
-    if (have_kept) {
+    if (have_kept && !devkept.segs.empty() && !host_pass2) {
+        // the reads of pass 1 are still on the device (one length, one segment a batch): threaded where they are
+        fprintf(stderr, "In file: %s, max seq len %d, max name len %d.\n", o.config.c_str(), max_read_len, 256);
+        for (const DevKept::Seg& sg : devkept.segs)
+            if (pg_graph_add_packed_device(graph, sg.d, sg.n_reads, devkept.len, devkept.device) != PG_OK) die("pg_graph_add_packed_device");
+        devkept.clear();
+        fprintf(stderr, "%lld read(s) processed.\n", n_records);
+    } else if (have_kept) {
         fprintf(stderr, "In file: %s, max seq len %d, max name len %d.\n", o.config.c_str(), max_read_len, 256);
         const uint64_t step = (uint64_t)1 << 22;
         for (const KeptReads::Block& kb : kept.blocks) {

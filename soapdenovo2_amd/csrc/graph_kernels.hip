@@ -129,15 +129,15 @@ __device__ inline void add_prearc(const P2Params& p, uint32_t from, uint32_t to,
 // one lane = one read (chopKmer4read + searchKmer + parse1read + search1kmerPlus + thread_add1preArc + recordPathBin)
 template <int NW>
 __global__ __launch_bounds__(256) void p2_thread_kernel(P2Params p, const uint64_t* __restrict__ words, const uint64_t* __restrict__ word_off,
-                                                        const int32_t* __restrict__ lens, uint64_t n_reads, uint64_t first_ordinal) {
+                                                        const int32_t* __restrict__ lens, uint64_t n_reads, uint64_t first_ordinal, int uniform_len) {
     P2_PROLOGUE(p);
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     const int K = p.K;
-    const int len = lens[r];
+    const int len = uniform_len ? uniform_len : lens[r];                 // (uniform_len: reads of one length back to back, no index arrays)
     if (p.walk_len) p.walk_len[r] = 0;
     if (len < K + 1) return;                                             // prlRead2path.c:1103
-    const uint64_t* rd = words + word_off[r];
+    const uint64_t* rd = words + (uniform_len ? r * (uint64_t)((uniform_len + 31) / 32) : word_off[r]);
     const Kmer<NW> filter = kmer_filter<NW>(K);
     const int nk = len - K + 1;
     uint32_t* row = p.stage ? p.stage + r * (uint64_t)p.max_nk : nullptr;
@@ -1234,13 +1234,33 @@ int p2_add_packed(P2Device* d, const uint64_t* words, const uint64_t* word_off, 
     p.stage = d->reps ? d->d_stage : nullptr;
     p.walk_len = d->reps ? d->d_walk_len : nullptr;
     const dim3 grid((unsigned)((n_reads + 255) / 256)), block(256);
-    if (d->nw == 2) hipLaunchKernelGGL(p2_thread_kernel<2>, grid, block, 0, d->stream, p, d->d_words, d->d_off, d->d_lens, n_reads, d->ordinal);
-    else hipLaunchKernelGGL(p2_thread_kernel<4>, grid, block, 0, d->stream, p, d->d_words, d->d_off, d->d_lens, n_reads, d->ordinal);
+    if (d->nw == 2) hipLaunchKernelGGL(p2_thread_kernel<2>, grid, block, 0, d->stream, p, d->d_words, d->d_off, d->d_lens, n_reads, d->ordinal, 0);
+    else hipLaunchKernelGGL(p2_thread_kernel<4>, grid, block, 0, d->stream, p, d->d_words, d->d_off, d->d_lens, n_reads, d->ordinal, 0);
     P2_HIP(hipGetLastError());
     if (d->reps && walks_out && walk_len_out) {
         P2_HIP(hipMemcpyAsync(walks_out, d->d_stage, n_reads * (size_t)d->max_nk * sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
         P2_HIP(hipMemcpyAsync(walk_len_out, d->d_walk_len, n_reads * sizeof(uint16_t), hipMemcpyDeviceToHost, d->stream));
     }
+    P2_HIP(hipStreamSynchronize(d->stream));
+    d->ordinal += n_reads;
+    return PG_OK;
+}
+
+// the same for reads that are on the graph's lead device already (pass 1 left them there): n_reads reads of read_len bases, packed
+// back to back, 8 readable words behind the last; no -R walks on this path
+int p2_add_packed_device(P2Device* d, const uint64_t* d_words, uint64_t n_reads, int read_len) {
+    if (!d->reads_ready) { pg_set_error("pass 2: p2_begin_reads was not called"); return PG_ESTATE; }
+    if (d->reps) { pg_set_error("pass 2: device-resident reads are not for -R runs"); return PG_ESTATE; }
+    if (!n_reads) return PG_OK;
+    if (read_len < 1 || !d_words) { pg_set_error("pass 2: bad argument"); return PG_EINVAL; }
+    P2_HIP(hipSetDevice(d->device));
+    P2Params p = d->prm;
+    p.stage = nullptr;
+    p.walk_len = nullptr;
+    const dim3 grid((unsigned)((n_reads + 255) / 256)), block(256);
+    if (d->nw == 2) hipLaunchKernelGGL(p2_thread_kernel<2>, grid, block, 0, d->stream, p, d_words, (const uint64_t*)nullptr, (const int32_t*)nullptr, n_reads, d->ordinal, read_len);
+    else hipLaunchKernelGGL(p2_thread_kernel<4>, grid, block, 0, d->stream, p, d_words, (const uint64_t*)nullptr, (const int32_t*)nullptr, n_reads, d->ordinal, read_len);
+    P2_HIP(hipGetLastError());
     P2_HIP(hipStreamSynchronize(d->stream));
     d->ordinal += n_reads;
     return PG_OK;

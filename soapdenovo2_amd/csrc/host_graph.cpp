@@ -1703,6 +1703,7 @@ struct GraphHandleBase {
     virtual void shutdown() = 0;
     virtual int add_reads(const uint8_t* codes, const int32_t* lens, uint64_t n, uint64_t stride, int n_threads) = 0;
     virtual int add_packed(const uint64_t* words, const int32_t* lens, uint64_t n, int n_threads) = 0;
+    virtual int add_packed_device(const uint64_t* d_words, uint64_t n, int read_len, int device) = 0;
     virtual int finish(long long* n_arcs) = 0;
     virtual int resolve_repeats(int on) = 0;
     virtual int use_device(int device) = 0;
@@ -2076,6 +2077,20 @@ struct GraphHandle : GraphHandleBase {
         });
     }
     // reads packed 2 bits a base, 32 bases a word, first base in the top bits (pg_pack_read), back to back
+    // reads that pass 1 left on the device (one length, back to back): threaded where they are
+    int add_packed_device(const uint64_t* d_words, uint64_t n, int read_len, int device) override {
+        if (!dev_on || device != dev_id) { pg_set_error("pg_graph_add_packed_device: the graph is not on that device (pg_graph_use_device first)"); return PG_ESTATE; }
+        if (path_fp) { pg_set_error("pg_graph_add_packed_device: not with -R (the walks come back through the host path)"); return PG_ESTATE; }
+        if (read_len - g.K + 1 > max_nk()) { pg_set_error("a read is longer than the maximum read length given at pg_host_graph_begin"); return PG_EINVAL; }
+        const double t0 = now();
+        int rc = dev_begin();
+        if (rc) return rc;
+        rc = p2_add_packed_device(dev, d_words, n, read_len);
+        if (rc) return rc;
+        reads_seen += (long long)n;
+        t_thread += now() - t0;
+        return PG_OK;
+    }
     int add_packed(const uint64_t* words, const int32_t* lens, uint64_t n, int n_threads) override {
         if (dev_on) return dev_add_packed(words, lens, n);
         std::vector<uint64_t> off(n + 1, 0);
@@ -2551,6 +2566,10 @@ extern "C" int pg_graph_use_device(pg_graph* g, int device) {
 extern "C" int pg_host_graph_add_packed(pg_graph* g, const uint64_t* words, const int32_t* lens, uint64_t n_reads, int n_threads) {
     if (!g || ((!words || !lens) && n_reads)) { pg_set_error("null argument"); return PG_EINVAL; }
     return ((pg::GraphHandleBase*)g)->add_packed(words, lens, n_reads, n_threads);
+}
+extern "C" int pg_graph_add_packed_device(pg_graph* g, const uint64_t* d_words, uint64_t n_reads, int read_len, int device) {
+    if (!g || (!d_words && n_reads) || read_len < 1) { pg_set_error("bad argument"); return PG_EINVAL; }
+    return ((pg::GraphHandleBase*)g)->add_packed_device(d_words, n_reads, read_len, device);
 }
 extern "C" int pg_host_graph_add_reads(pg_graph* g, const uint8_t* codes, const int32_t* lens, uint64_t n_reads, uint64_t stride, int n_threads) {
     if (!g || (!codes && n_reads)) { pg_set_error("null argument"); return PG_EINVAL; }
