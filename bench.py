@@ -172,6 +172,14 @@ def big_command(args):
             m = re.search(r"Time spent on rebuilding the k-mer set layout: ([0-9.]+)s", r.stderr)
             if m:
                 out["layout_s"] = float(m.group(1))
+            # how long the process waited for its device context (HIP start-up + the record pool's allocation): 0.1 s on an idle GPU,
+            # seconds when another process has just released its memory -- part of wall_s and of the pass-1 stage either way
+            m0, m1 = re.search(r"at ([0-9.]+)s: input files sized", r.stderr), re.search(r"at ([0-9.]+)s: device context created", r.stderr)
+            if m0 and m1:
+                out["device_context_s"] = round(float(m1.group(1)) - float(m0.group(1)), 2)
+            m = re.search(r"reader: ([0-9.]+)s cutting \+ parsing", r.stderr)
+            if m:
+                out["reader_s"] = float(m.group(1))
             out["layout_on_device"] = "k-mer set layout on the device" in r.stderr
             m = re.search(r"tips decided on the device: (\d+) scan\(s\), (\d+) fixed-point round\(s\), ([0-9.]+)s", r.stderr)
             if m:
