@@ -736,3 +736,26 @@ def test_cli_layout_on_the_device_and_on_the_host(golden, tmp_path, name, layout
         for ext in ("kmerFreq", "preGraphBasic", "vertex", "preArc"):
             assert md5_file(pre + "." + ext) == want[ext], (t, ext)
         assert md5_gz_text(pre + ".edge.gz") == want["edge"], t
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("toggle", [{"PG_K2_KS": "0", "PG_K1_W": "0"}, {"SOAPDENOVO2_AMD_KEEP_ON_HOST": "1"}, {"SOAPDENOVO2_AMD_EDGE_FILE_INLINE": "1"},
+                                    {"SOAPDENOVO2_AMD_PARSE_SIMD": "0", "SOAPDENOVO2_AMD_READER": "map"}, {"SOAPDENOVO2_AMD_LAYOUT_LANES": "1"}],
+                         ids=["general-kernels", "reads-kept-on-host", "edge-file-inline", "scalar-mapped-reader", "one-layout-lane"])
+@pytest.mark.parametrize("name", ["m60k_k63", "t6k_k127"])
+def test_cli_round3_switches_do_not_change_the_files(golden, tmp_path, name, toggle):
+    """What round 3 made the default has a switch back, and the files do not depend on it: the K2 / K1 kernels instantiated for one K
+    against the general ones, the reads of pass 1 kept on the device against the host store, <o>.edge.gz written beside pass 2 against
+    before it, the AVX2 record and the copied windows of the reader against the scalar record on the mapped file, two growable sets
+    laid out side by side against one."""
+    c = golden["cases"][name]
+    cfg = case_config(c, str(tmp_path), name)
+    for run in c["runs"]:
+        P, D, a, m = run
+        t = case_tag(name, run)
+        pre = str(tmp_path / t)
+        _run_cli(cfg, c["K"], pre, P, D, a, m, extra_env=dict(PARALLEL_PARSE, **toggle))
+        want = golden["md5"][t]
+        for ext in ("kmerFreq", "preGraphBasic", "vertex", "preArc"):
+            assert md5_file(pre + "." + ext) == want[ext], (t, ext, toggle)
+        assert md5_gz_text(pre + ".edge.gz") == want["edge"], (t, toggle)
