@@ -12,92 +12,6 @@
 #include "backend.hpp"
 #include "../../include/soapdenovo2_amd.h"
 
-#include <mutex>
-#include <unordered_map>
-#include <vector>
-
-namespace pg {
-
-// Device blocks the graph stages are done with are kept and handed out again (layout scratch -> tip scratch -> vertex list ->
-// edge builder -> pre-arc table) instead of going back to the driver: an allocation behind a release of tens of gigabytes costs
-// the process ~0.1 s a gigabyte (the 200 M-read command spent 1.3 s of its edge stage there).  Everything this translation
-// unit allocates and releases goes through here (the two macros below); a pointer that was not allocated here is released
-// the plain way.  p2_device_cache_flush() gives the kept blocks back (after pass 2 is set up, and with the graph).
-// SOAPDENOVO2_AMD_DEVICE_CACHE=0: plain hipMalloc / hipFree.
-namespace devcache {
-struct Block { void* p; size_t bytes; int device; };
-inline std::mutex& mu() { static std::mutex m; return m; }
-inline std::unordered_map<void*, std::pair<size_t, int>>& live() { static std::unordered_map<void*, std::pair<size_t, int>> m; return m; }
-inline std::vector<Block>& kept() { static std::vector<Block> v; return v; }
-inline bool on() { static const bool v = [] { const char* e = getenv("SOAPDENOVO2_AMD_DEVICE_CACHE"); return !(e && e[0] == '0'); }(); return v; }
-inline void flush(int device = -1) {
-    std::vector<Block> go;
-    {
-        std::lock_guard<std::mutex> lk(mu());
-        std::vector<Block>& k = kept();
-        for (size_t i = 0; i < k.size();)
-            if (device < 0 || k[i].device == device) { go.push_back(k[i]); k[i] = k.back(); k.pop_back(); } else i++;
-    }
-    if (go.empty()) return;
-    int cur = 0;
-    (void)hipGetDevice(&cur);
-    for (const Block& b : go) { (void)hipSetDevice(b.device); (void)hipFree(b.p); }
-    (void)hipSetDevice(cur);
-}
-inline hipError_t cached_malloc(void** out, size_t bytes) {
-    if (!on()) return hipMalloc(out, bytes);
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    {
-        std::lock_guard<std::mutex> lk(mu());
-        std::vector<Block>& k = kept();
-        size_t best = k.size();
-        const size_t most = std::max<size_t>(4 * bytes, bytes + ((size_t)64 << 20));
-        for (size_t i = 0; i < k.size(); i++)
-            if (k[i].device == dev && k[i].bytes >= bytes && k[i].bytes <= most && (best == k.size() || k[i].bytes < k[best].bytes)) best = i;
-        if (best != k.size()) {
-            *out = k[best].p;
-            live()[k[best].p] = {k[best].bytes, dev};
-            k[best] = k.back();
-            k.pop_back();
-            return hipSuccess;
-        }
-    }
-    hipError_t e = hipMalloc(out, bytes);
-    if (e != hipSuccess) {                                   // what is kept may be what is missing
-        (void)hipGetLastError();
-        flush(dev);
-        e = hipMalloc(out, bytes);
-    }
-    if (e == hipSuccess) { std::lock_guard<std::mutex> lk(mu()); live()[*out] = {bytes, dev}; }
-    return e;
-}
-inline hipError_t cached_free(void* p) {
-    if (!p) return hipSuccess;
-    if (!on()) return hipFree(p);
-    Block b{p, 0, 0};
-    {
-        std::lock_guard<std::mutex> lk(mu());
-        auto it = live().find(p);
-        if (it == live().end()) { b.p = nullptr; }
-        else { b.bytes = it->second.first; b.device = it->second.second; live().erase(it); }
-    }
-    if (!b.p) return hipFree(p);                             // not from here (a caller's block): the plain way
-    int cur = 0;                                             // hipFree waits for the device; whoever relied on that still can
-    (void)hipGetDevice(&cur);
-    if (cur != b.device) (void)hipSetDevice(b.device);
-    (void)hipDeviceSynchronize();
-    if (cur != b.device) (void)hipSetDevice(cur);
-    std::lock_guard<std::mutex> lk(mu());
-    kept().push_back(b);
-    return hipSuccess;
-}
-}  // namespace devcache
-}  // namespace pg
-// (after every header that has its own uses of the two names)
-#define hipMalloc(p, n) ::pg::devcache::cached_malloc((void**)(p), (size_t)(n))
-#define hipFree(p) ::pg::devcache::cached_free((void*)(p))
-
 namespace pg {
 
 // lane i of the grid calls f(i); grid-stride, so any n fits one launch

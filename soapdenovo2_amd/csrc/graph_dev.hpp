@@ -88,7 +88,6 @@ void p2_destroy(P2Device* d);
 int p2_add_packed(P2Device* d, const uint64_t* words, const uint64_t* word_off, const int32_t* lens, uint64_t n_reads, uint64_t n_words,
                   uint32_t* walks_out, uint16_t* walk_len_out);
 int p2_add_packed_device(P2Device* d, const uint64_t* d_words, uint64_t n_reads, int read_len);      // reads already on the lead device, one length, back to back
-void p2_device_cache_flush();                      // the device blocks the graph stages keep for reuse (backend_hip.hpp: devcache) go back to the driver
 int p2_finish(P2Device* d, P2Result& out);
 
 }  // namespace pg

@@ -536,7 +536,6 @@ static void p2_free(P2Device* d) {
     hipFree(d->d_geo3); hipFree(d->d_crc); hipFree(d->d_vlist);
     if (d->stream) hipStreamDestroy(d->stream);
     delete d;
-    devcache::flush();                                       // what the stages kept for reuse goes back with the graph
 }
 
 // the sets are in place (set_sizes / set_dev / set_ptr filled): geometry to the lead, peer mappings, stream, counters
@@ -1267,10 +1266,7 @@ int p2_add_packed_device(P2Device* d, const uint64_t* d_words, uint64_t n_reads,
     return PG_OK;
 }
 
-void p2_device_cache_flush() { devcache::flush(); }
-
 int p2_finish(P2Device* d, P2Result& out) {
-    devcache::flush();                                       // no stage after this one allocates much: the kept blocks go back now
     P2_HIP(hipSetDevice(d->device));
     unsigned long long c[8];
     P2_HIP(hipMemcpy(c, d->d_counters, sizeof(c), hipMemcpyDeviceToHost));
