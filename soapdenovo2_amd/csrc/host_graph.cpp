@@ -1778,7 +1778,9 @@ struct GraphHandle : GraphHandleBase {
         return PG_OK;
     }
     int dev_build_edges(int device, int n_threads, int& edge_c, long long& records_c, long long& extra_nodes) {
+        const double tv0 = now();
         start_vertex_writer();
+        if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "vertex list from the device: %.2fs\n", now() - tv0);
         if (!dev) { const int rc0 = dev_open(device); if (rc0) return rc0; }
         g.tip_dev = nullptr;                         // the device copy is about to be tagged: no more tip walks on it
         P2Edges ed;
