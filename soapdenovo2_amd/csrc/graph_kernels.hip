@@ -242,13 +242,16 @@ struct WalkState {
 };
 
 // one set's vertices (live non-linear nodes) as global slots, in any order
-__global__ void eb_list_branch(const uint64_t* nodes, int nw1, uint64_t n_slots, uint64_t first, unsigned long long* list, unsigned long long* n_list) {
+// (cap: room in `list`; what does not fit is still counted, so the caller can come again with a list that holds them all)
+__global__ void eb_list_branch(const uint64_t* nodes, int nw1, uint64_t n_slots, uint64_t first, unsigned long long* list, unsigned long long* n_list,
+                               unsigned long long cap) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t* nd = nodes + i * nw1;
         if (nd[0] == P2_EMPTY) continue;
         const uint32_t B = (uint32_t)(nd[nw1 - 1] >> 32);
         if (B & (B_LINEAR | B_DELETED)) continue;
-        list[atomicAdd(n_list, 1ULL)] = first + i;
+        const unsigned long long at = atomicAdd(n_list, 1ULL);
+        if (at < cap) list[at] = first + i;
     }
 }
 
@@ -1056,12 +1059,21 @@ int p2_list_vertices(P2Device* d, std::vector<uint64_t>& keys) {
     keys.clear();
     if (hipSetDevice(d->device) != hipSuccess) { pg_set_error("vertices: hipSetDevice failed"); return PG_ENODEV; }
     P2_HIP_GOTO(hipMalloc((void**)&d_cnt, sizeof(unsigned long long)));
-    P2_HIP_GOTO(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st));
-    P2_HIP_GOTO(hipMalloc((void**)&d_list, std::max<uint64_t>(d->n_slots, 1) * sizeof(unsigned long long)));
-    for (int si = 0; si < d->P; si++)
-        if (d->set_sizes[si]) hipLaunchKernelGGL(eb_list_branch, dim3(4096), dim3(256), 0, st, d->set_ptr[si], d->nw + 1, d->set_sizes[si], d->set_first[si], d_list, d_cnt);
-    P2_HIP_GOTO(hipMemcpyAsync(&n, d_cnt, sizeof n, hipMemcpyDeviceToHost, st));
-    P2_HIP_GOTO(hipStreamSynchronize(st));
+    // a list for one slot in 32 (a vertex is a node that is not linear: one in a few hundred); should there be more, the scan says
+    // how many and runs again -- a list for every slot was a 17 GB allocation at 200 M reads, 1.4 s
+    for (unsigned long long cap = std::max<unsigned long long>(d->n_slots / 32, 1 << 20);;) {
+        cap = std::min<unsigned long long>(cap, std::max<unsigned long long>(d->n_slots, 1));
+        P2_HIP_GOTO(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st));
+        P2_HIP_GOTO(hipMalloc((void**)&d_list, cap * sizeof(unsigned long long)));
+        for (int si = 0; si < d->P; si++)
+            if (d->set_sizes[si]) hipLaunchKernelGGL(eb_list_branch, dim3(4096), dim3(256), 0, st, d->set_ptr[si], d->nw + 1, d->set_sizes[si], d->set_first[si], d_list, d_cnt, cap);
+        P2_HIP_GOTO(hipMemcpyAsync(&n, d_cnt, sizeof n, hipMemcpyDeviceToHost, st));
+        P2_HIP_GOTO(hipStreamSynchronize(st));
+        if (n <= cap) break;
+        hipFree(d_list);
+        d_list = nullptr;
+        cap = n;
+    }
     if (n) {
         while (bits < 64 && (d->n_slots >> bits)) bits++;
         P2_HIP_GOTO(hipMalloc((void**)&d_sorted, n * sizeof(unsigned long long)));
@@ -1108,7 +1120,7 @@ int p2_build_edges(P2Device* d, P2Edges& out) {
     } else {
         P2_HIP_GOTO(hipMalloc((void**)&d_list, std::max<uint64_t>(d->n_slots, 1) * sizeof(unsigned long long)));
         for (int si = 0; si < d->P; si++)
-            if (d->set_sizes[si]) hipLaunchKernelGGL(eb_list_branch, dim3(4096), dim3(256), 0, st, d->set_ptr[si], NW1, d->set_sizes[si], d->set_first[si], d_list, d_cnt);
+            if (d->set_sizes[si]) hipLaunchKernelGGL(eb_list_branch, dim3(4096), dim3(256), 0, st, d->set_ptr[si], NW1, d->set_sizes[si], d->set_first[si], d_list, d_cnt, (unsigned long long)std::max<uint64_t>(d->n_slots, 1));
         P2_HIP_GOTO(hipMemcpyAsync(cnt, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
         P2_HIP_GOTO(hipStreamSynchronize(st));
         n_list = cnt[0];
