@@ -177,3 +177,22 @@ def test_layout_growable_random_keys_and_the_trailing_duplicate():
             rec[:, 3] = np.arange(n, dtype=np.uint64) * np.uint64(3)
             last = np.array([int(rec[-1, 3]) + (5 if trailing else 1)], dtype=np.uint64)
             _growable_vs_replay(rec, last, 1, False, threads=3)
+
+
+def test_layout_growable_random_keys_four_words():
+    """The same with four-word keys (the 127-mer flavour: other initial size, chained 32-bit modulus for the home slot), several
+    sets of different sizes in one call."""
+    rng = np.random.default_rng(177)
+    P = 3
+    counts = [30000, 7, 12345]
+    recs = []
+    for s, n in enumerate(counts):
+        r = np.zeros((n, 6), dtype=np.uint64)
+        r[:, :4] = rng.integers(0, 1 << 62, size=(n, 4), dtype=np.uint64)
+        r[:, 0] >>= np.uint64(3)
+        r[:, 5] = (np.arange(n, dtype=np.uint64) * np.uint64(2)) | (np.uint64(s) << np.uint64(api.PG_ORD_BITS))
+        recs.append(r)
+    rec = np.concatenate(recs)
+    last = np.array([2 * n + 3 for n in counts], dtype=np.uint64)        # every set saw a duplicate put after its last new key
+    rounds = _growable_vs_replay(rec, last, P, True, threads=4)
+    assert int(rounds[0]) > int(rounds[1])
