@@ -295,6 +295,41 @@ __attribute__((target("avx2"))) static int parse_fastq_avx2(const char* buf, siz
     return n;
 }
 #endif
+#if defined(__x86_64__)
+// The usual FASTA record (a '>' line, then the sequence on one line) the same way; -1 = not the usual record, the scalar
+// form below decides.
+__attribute__((target("avx2"))) static int parse_fasta_avx2(const char* buf, size_t end, size_t& start, int max_len, uint8_t* out) {
+    if (!(start < end && buf[start] == '>')) return -1;
+    const char* e1 = (const char*)memchr(buf + start, '\n', end - start);           // end of the name line
+    if (!e1) return -1;
+    const char* s = e1 + 1;
+    const char* lim = buf + end;
+    const __m256i nl = _mm256_set1_epi8('\n'), c20 = _mm256_set1_epi8(0x20), ca = _mm256_set1_epi8((char)('a' - 128)),
+                  c26 = _mm256_set1_epi8((char)(26 - 128)), c3 = _mm256_set1_epi8(3);
+    size_t sl = 0;
+    for (;;) {
+        if (s + sl + 32 > lim) return -1;
+        const __m256i v = _mm256_loadu_si256((const __m256i*)(s + sl));
+        const uint32_t m_nl = (uint32_t)_mm256_movemask_epi8(_mm256_cmpeq_epi8(v, nl));
+        const __m256i x = _mm256_sub_epi8(_mm256_or_si256(v, c20), ca);
+        const uint32_t m_ok = (uint32_t)_mm256_movemask_epi8(_mm256_cmpgt_epi8(c26, x));
+        const uint32_t before = m_nl ? ((m_nl & (0u - m_nl)) - 1u) : 0xFFFFFFFFu;
+        if ((~m_ok) & before) return -1;                                              // ('>' in the sequence line starts a record over: scalar)
+        if ((long)sl < (long)max_len) {
+            const __m256i code = _mm256_and_si256(_mm256_srli_epi16(v, 1), c3);
+            uint8_t tmp[32];
+            _mm256_storeu_si256((__m256i*)tmp, code);
+            const size_t room = (size_t)max_len - sl;
+            memcpy(out + sl, tmp, room < 32 ? room : 32);
+        }
+        if (m_nl) { sl += (size_t)__builtin_ctz(m_nl); break; }
+        sl += 32;
+    }
+    if (sl == 0) return -1;                                                           // (an empty sequence line: the scalar form reports it)
+    start = (size_t)(s + sl - buf) + 1;
+    return (int)(sl < (size_t)max_len ? sl : (size_t)max_len);
+}
+#endif
 // SOAPDENOVO2_AMD_PARSE_SIMD=0 keeps the scalar forms (looked at on every call: the tests switch it inside one process)
 static bool simd_parse_on() {
 #if defined(__x86_64__)
@@ -331,7 +366,10 @@ int parse_fastq(const char* buf, size_t end, size_t& start, int max_len, uint8_t
 }
 
 // readseqInBuf (readseq1by1.c:138-209): next record of a FASTA buffer (single-line sequences)
-int parse_fasta(const char* buf, size_t end, size_t& start, int max_len, uint8_t* out) {
+int parse_fasta(const char* buf, size_t end, size_t& start, int max_len, uint8_t* out, bool simd) {
+#if defined(__x86_64__)
+    if (simd) { const int r = parse_fasta_avx2(buf, end, start, max_len, out); if (r >= 0) return r; }
+#endif
     long p = -1;
     for (size_t m = start; m < end; m++) {
         const char c = buf[m];
@@ -429,7 +467,7 @@ void parse_range(const InputFile& in, bool fastq, const char* buf, size_t size, 
     size_t start = 0;
     const bool simd = simd_parse_on();
     while (start < size) {
-        const int n = fastq ? parse_fastq(buf, size, start, in.max_read_len, codes.data(), simd) : parse_fasta(buf, size, start, in.max_read_len, codes.data());
+        const int n = fastq ? parse_fastq(buf, size, start, in.max_read_len, codes.data(), simd) : parse_fasta(buf, size, start, in.max_read_len, codes.data(), simd);
         if (n < 1) bad_record(buf, size, start);
         if (in.reverse) reverse_complement(codes.data(), n);
         out.records++;
@@ -865,7 +903,7 @@ long long stream_reads(const InputFile& in, ReadSink& sink) {
     long long n_records = 0;
     auto parse = [&](const std::string& buf, size_t& start) {
         const int n = fastq ? parse_fastq(buf.data(), buf.size(), start, in.max_read_len, codes.data(), /*simd=*/false)    // (the chunk emulation stays on the scalar definition)
-                            : parse_fasta(buf.data(), buf.size(), start, in.max_read_len, codes.data());
+                            : parse_fasta(buf.data(), buf.size(), start, in.max_read_len, codes.data(), /*simd=*/false);
         if (n < 1) bad_record(buf, start);
         if (in.reverse) reverse_complement(codes.data(), n);
         n_records++;

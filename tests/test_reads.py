@@ -148,3 +148,48 @@ def test_simd_fastq_parse_equals_the_scalar_definition(tmp_path):
         assert got[tag][2] == got["seq"][2] and got[tag][3] == got["seq"][3], tag
         assert np.array_equal(got[tag][1], got["seq"][1]), tag
         assert np.array_equal(got[tag][0], got["seq"][0]), tag
+
+
+def test_simd_fasta_parse_equals_the_scalar_definition(tmp_path):
+    """The same for FASTA (a '>' line, the sequence on one line): lower case, N, '.', digits, CR LF, long and
+    very short reads.  (A sequence broken over two lines and a '>' inside a name (the 32 KiB chunks are cut at the last '>') are
+    errors to the reference -- "invalid data left in buffer" -- and to this reader.)"""
+    import os
+    import numpy as np
+    rng = np.random.default_rng(6)
+    lines = []
+    n_rec = 0
+    for i in range(50000):
+        kind = int(rng.integers(0, 12))
+        n = int(rng.integers(1, 40)) if kind == 0 else int(rng.integers(60, 181))
+        seq = "".join("ACGT"[c] for c in rng.integers(0, 4, size=n))
+        if kind == 1:
+            seq = seq.lower()
+        elif kind == 2:
+            seq = seq[: n // 2] + "N" + seq[n // 2 + 1:]
+        elif kind == 3:
+            seq = seq[: n // 3] + "." + seq[n // 3 + 1:]
+        elif kind == 4:
+            seq = seq[: n // 3] + "7" + seq[n // 3 + 1:]
+        eol = "\r\n" if kind == 5 else "\n"
+        name = ">r%d" % i + (" some text" if kind == 6 else "")
+        lines.append(name + eol + seq + eol)
+        n_rec += 1
+    fa = tmp_path / "w.fa"
+    fa.write_text("".join(lines), newline="")
+    cfg = tmp_path / "w.cfg"
+    cfg.write_text(f"max_rd_len=150\n[LIB]\navg_ins=200\nasm_flags=3\nf={fa}\n")
+    knobs = {"SOAPDENOVO2_AMD_PARSE_PARALLEL_MIN": "0", "SOAPDENOVO2_AMD_PARSE_THREADS": "3", "SOAPDENOVO2_AMD_PARSE_WINDOW": "5"}
+    got = {}
+    for tag, extra in (("seq", {"SOAPDENOVO2_AMD_PARSE_THREADS": "1"}), ("scalar", dict(knobs, SOAPDENOVO2_AMD_PARSE_SIMD="0")), ("simd", knobs)):
+        os.environ.update(extra)
+        try:
+            got[tag] = api.host_read_all(str(cfg), 31)
+        finally:
+            for k in extra:
+                del os.environ[k]
+    assert got["seq"][2] == n_rec
+    for tag in ("scalar", "simd"):
+        assert got[tag][2] == got["seq"][2] and got[tag][3] == got["seq"][3], tag
+        assert np.array_equal(got[tag][1], got["seq"][1]), tag
+        assert np.array_equal(got[tag][0], got["seq"][0]), tag
