@@ -89,7 +89,8 @@ int pg_host_read_all(const char *config, int K, uint8_t *codes_out, int32_t *len
                      uint64_t stride, uint64_t *n_records, uint64_t *n_accepted, int *max_read_len_out);
 
 /* BAM inputs (b=): the reader pairs records up two by two and takes pairs with a QC-fail mate back (readseq1by1.c:449-592);
- * the pairing state is a static of the reference (readseq1by1.c:44) that outlives files, passes and calls -- mirrored here.
+ * the pairing state is a static of the reference (readseq1by1.c:44) which it puts back to -3 at every end of file
+ * (readseq1by1.c:584-587) -- mirrored here, so every file and both passes start pairing afresh.
  * set != 0 stores `value` (-3 = as in a fresh process); returns the state. */
 int pg_host_bam_pair_state(int set, int value);
 

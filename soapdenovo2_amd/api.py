@@ -282,14 +282,11 @@ def host_pregraph_files(records: np.ndarray, set_last_put, codes: np.ndarray, le
     return nv.value, ne.value, na.value
 
 
-def host_read_all(config: str, K: int, bam_state: int = -3):
+def host_read_all(config: str, K: int):
     """All reads the reference would hand to a pass over the inputs, in its order: (codes [n, stride] uint8, lens int32, n_records,
-    max_rd_len).  bam_state: the BAM reader's pairing state the pass starts with (-3 = pass 1 of a fresh process; for pass 2 hand in
-    host_bam_state() as pass 1 left it -- the reference's static carries over, readseq1by1.c:44)."""
+    max_rd_len).  (The BAM reader's pairing state is back at -3 after every file, readseq1by1.c:584-587: each pass sees the same reads.)"""
     nrec, nacc, mrl = C.c_uint64(0), C.c_uint64(0), C.c_int(0)
-    lib().pg_host_bam_pair_state(1, bam_state)
     _check(lib().pg_host_read_all(config.encode(), K, None, None, 0, 0, C.byref(nrec), C.byref(nacc), C.byref(mrl)), "pg_host_read_all")
-    lib().pg_host_bam_pair_state(1, bam_state)
     n, stride = nacc.value, max(mrl.value, 1)
     codes = np.zeros((max(n, 1), stride), dtype=np.uint8)
     lens = np.zeros(max(n, 1), dtype=np.int32)

@@ -647,9 +647,6 @@ int run(int argc, char** argv, bool mer127) {
     size_t batch_words = (size_t)1 << 23, batch_reads = (size_t)1 << 21;
     if (const char* e = getenv("SOAPDENOVO2_AMD_BATCH_READS")) { const long v = atol(e); if (v > 0) { batch_reads = (size_t)v; batch_words = std::min(batch_words, batch_reads * 160 + 64); } }
     size_t keep_budget = (size_t)sysconf(_SC_PHYS_PAGES) * (size_t)sysconf(_SC_PAGE_SIZE) / 4;
-    // a BAM input is parsed again for pass 2, as the reference does: its pairing state carries over from pass 1, so pass 2 may
-    // see other reads than pass 1 did (host_reads.cpp)
-    for (const pg::InputFile& f : files) if (f.type == 4) keep_budget = 0;
     if (const char* e = getenv("SOAPDENOVO2_AMD_KEEP_READS_GB")) keep_budget = (size_t)(atof(e) * 1073741824.0);
     KeptReads kept;
     bool have_kept = false;

@@ -820,17 +820,19 @@ void ReadSink::on_packed(const uint64_t* words, const int32_t* lens, size_t n, i
 //   asm_flags = 1: records with the QC-fail flag (0x200) are skipped.
 //   otherwise:     records pair up two by two (no names are looked at); a pair with a QC-fail mate is "taken back": the second
 //                  mate is not delivered and the LAST KEPT READ of the buffer -- the first mate if it was long enough to be
-//                  kept, else whatever was kept before it -- is removed again (prlHashReads.c:414-426).  Hence the one-read
-//                  delay line below: a read long enough to be kept is handed to the sink only when the next one arrives.
+//                  kept, else whatever was kept before it -- is removed again (prlHashReads.c:414-426).  Hence the delay
+//                  line below: reads long enough to be kept wait in a short queue (BAM_HOLD deep) before they reach the
+//                  sink, so that several pairs taken back in a row, each with a first mate too short to be kept, can each
+//                  remove one earlier kept read as the reference's read_c-- does.
 //                  (The reference indexes lenBuffer[read_c - 1] even when its buffer is empty -- a pair taken back right
 //                  after a full buffer of reads was flushed -- which reads in front of the array; here nothing is removed
-//                  then.  The pairing state carries over from one BAM file to the next, as the reference's static does.)
-static int g_bam_pair_state = -3;                                   // `state`, readseq1by1.c:44
-// The state is a static of the reference and so outlives a file, a pass and a call: an input with an odd number of good
-// records leaves a first mate dangling, and pass 2 -- which reads the files again -- then pairs the records up one off from
-// pass 1 and takes other pairs back (the golden case rq_bam does exactly that).  Mirrored: call_pregraph parses BAM inputs a
-// second time for pass 2 instead of replaying the reads it kept, and nothing here resets the state.  Tools that look at one
-// pass on its own get and set it through pg_host_bam_pair_state.
+//                  then.)
+// `state` (readseq1by1.c:44) is a static, but the reference puts it back to -3 whenever samread() reports the end of a file
+// (`if (readstate < 0) state = -3;`, readseq1by1.c:584-587): a file with an odd number of records leaves its last record as a
+// first mate without a second, and the next file -- and pass 2, which reads the files again -- starts pairing afresh.  So both
+// passes see the same reads and call_pregraph may replay the reads it kept.  pg_host_bam_pair_state stays for tools that want
+// to look at or force the state.
+static int g_bam_pair_state = -3;
 int bam_pair_state(bool set, int value) { if (set) g_bam_pair_state = value; return g_bam_pair_state; }
 
 static long long stream_bam(const InputFile& in, ReadSink& sink) {
@@ -848,8 +850,11 @@ static long long stream_bam(const InputFile& in, ReadSink& sink) {
     }
     if (!ok) { fprintf(stderr, "Cannot read the header.\n"); exit(-1); }
     const int max_len = std::max(in.max_read_len, 1);
-    std::vector<uint8_t> codes((size_t)max_len + 8), held((size_t)max_len + 8), rec;
-    int held_len = -1;                                               // a kept-length read waiting for its successor
+    constexpr int BAM_HOLD = 256;
+    const size_t row = (size_t)max_len + 8;
+    std::vector<uint8_t> codes(row), held(row * BAM_HOLD), rec;
+    int held_len[BAM_HOLD];
+    int held_head = 0, held_n = 0;                                   // kept-length reads waiting: ring of rows, oldest at held_head
     long long n_records = 0;
     static const char nt16[] = "=ACMGRSVTWYHKDBN";
     for (;;) {
@@ -882,16 +887,23 @@ static long long stream_bam(const InputFile& in, ReadSink& sink) {
         if (in.reverse) reverse_complement(codes.data(), n);
         if (type == -1) {                                            // the pair is taken back (prlHashReads.c:412-426)
             n_records--;
-            held_len = -1;
+            if (held_n > 0) held_n--;                                // the last kept read goes again (read_c--)
             continue;
         }
         n_records++;
         if (n < std::max(in.keep_len, 1)) { sink.on_read(codes.data(), n); continue; }      // nobody keeps it: order does not matter
-        if (held_len >= 0) sink.on_read(held.data(), held_len);
-        held.swap(codes);
-        held_len = n;
+        if (held_n == BAM_HOLD) {
+            sink.on_read(held.data() + row * (size_t)held_head, held_len[held_head]);
+            held_head = (held_head + 1) % BAM_HOLD;
+            held_n--;
+        }
+        const int at = (held_head + held_n) % BAM_HOLD;
+        memcpy(held.data() + row * (size_t)at, codes.data(), (size_t)n);
+        held_len[at] = n;
+        held_n++;
     }
-    if (held_len >= 0) sink.on_read(held.data(), held_len);
+    g_bam_pair_state = -3;                                           // end of file, or a truncated one: readseq1by1.c:584-587
+    for (; held_n > 0; held_n--, held_head = (held_head + 1) % BAM_HOLD) sink.on_read(held.data() + row * (size_t)held_head, held_len[held_head]);
     gzclose(fp);
     return n_records;
 }

@@ -280,10 +280,7 @@ def make_quirk_case(outdir: str, name: str) -> str:
         # QC-fail mate (flag 0x200) is taken back; lib 2 (asm_flags=1): QC-fail records are skipped one by one.  IUPAC codes,
         # '=' and an empty sequence in between; reverse_seq on the second lib.
         a = reads_codes(20000, 1400, 100, 0.004, 118)
-        b = reads_codes(20000, 602, 100, 0.004, 119)      # 602: an even number of good records.  The reference's pairing state is a static
-        # that outlives pass 1 (readseq1by1.c:44); an odd count would leave a mate dangling, pass 2 would pair the records up one
-        # off, take other pairs back and meet k-mers pass 1 never stored -- where the reference goes on with an uninitialised
-        # node pointer (searchKmer, prlRead2path.c:348-368).  Nothing to pin there.
+        b = reads_codes(20000, 602, 100, 0.004, 119)
         def records(codes, qc_every, weird_every):
             out = []
             for i, c in enumerate(codes):
@@ -301,6 +298,30 @@ def make_quirk_case(outdir: str, name: str) -> str:
         write_bam(p(name + "_2.bam"), records(b, 11, 0))
         open(cfg, "w").write(f"max_rd_len=90\n[LIB]\navg_ins=200\nreverse_seq=0\nasm_flags=3\nb={p(name + '_1.bam')}\n"
                              f"[LIB]\navg_ins=300\nreverse_seq=1\nasm_flags=1\nb={p(name + '_2.bam')}\n")
+    elif name == "rq_bam_odd":
+        # two BAM files in one lib (asm_flags=3), the first with an ODD number of records: its last record is a first mate
+        # without a second when the file ends, where the reference puts the pairing state back (readseq1by1.c:584-587), so the
+        # second file pairs from its first record on -- and its second record is a QC-fail.  Also: runs of pairs taken back whose
+        # first mates are too short to be kept (each removes one earlier kept read, prlHashReads.c:414-426), reads of mixed lengths.
+        a = reads_codes(20000, 701, 100, 0.004, 120)
+        b = reads_codes(20000, 904, 100, 0.004, 121)
+        def records(codes, qc, short):
+            out = []
+            for i, c in enumerate(codes):
+                seq = _ASCII[c].tobytes().decode()
+                if i in short:
+                    seq = seq[:20]                          # shorter than K + 1 = 32: not kept
+                flag = 0x4 | 0x1 | (0x40 if i % 2 == 0 else 0x80)
+                if i in qc:
+                    flag |= 0x200
+                out.append((b"pair%d/%d" % (i // 2, 1 + i % 2), flag, seq))
+            return out
+        qa = {9, 40, 41, 77, 300, 523}
+        qb = {1, 101, 103, 105, 401, 640, 641, 642, 900}
+        sb = {100, 102, 104, 400}                          # three pairs in a row: short first mate + QC-fail second mate
+        write_bam(p(name + "_1.bam"), records(a, qa, set()))
+        write_bam(p(name + "_2.bam"), records(b, qb, sb))
+        open(cfg, "w").write(f"max_rd_len=100\n[LIB]\navg_ins=200\nreverse_seq=0\nasm_flags=3\nb={p(name + '_1.bam')}\nb={p(name + '_2.bam')}\n")
     else:
         raise ValueError(name)
     return cfg
@@ -334,4 +355,4 @@ def write_bam(path: str, records) -> None:
         f.write(out)
 
 
-QUIRK_CASES = ["rq_32k", "rq_trunc", "rq_ragged", "rq_pair", "rq_gz", "rq_p", "rq_tie", "rq_bam"]
+QUIRK_CASES = ["rq_32k", "rq_trunc", "rq_ragged", "rq_pair", "rq_gz", "rq_p", "rq_tie", "rq_bam", "rq_bam_odd"]

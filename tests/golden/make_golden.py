@@ -5,6 +5,7 @@ so these files ARE the parity pin.  Only data is stored: input parameters (cases
 files for the small cases, and md5 digests for the larger ones.
 
     python tests/golden/make_golden.py
+    python tests/golden/make_golden.py --quirk rq_bam_odd     # add / refresh one reader corner case, everything else stays
 """
 import gzip, hashlib, json, os, shutil, subprocess, sys, tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -38,8 +39,10 @@ def tag(name, run):
 
 def main():
     digests = {}
+    only_quirks = [sys.argv[i + 1] for i, a in enumerate(sys.argv[:-1]) if a == "--quirk"]
+    old = json.load(open(os.path.join(HERE, "cases.json"))) if only_quirks else None
     with tempfile.TemporaryDirectory() as td:
-        for name, c in CASES.items():
+        for name, c in ({} if only_quirks else CASES).items():
             cfg = synth.make_case(td, name, c["G"], c["N"], c["L"], c["err"], c["seed"], model=c.get("model", "uniform"), K=c["K"])
             for run in c["runs"]:
                 P, D, a, m = run
@@ -76,7 +79,7 @@ def main():
         # reader corner cases: K = 31, -p 3; also pin the reference's "read(s) processed" count
         import re
         quirks = {}
-        for name in synth.QUIRK_CASES:
+        for name in (only_quirks or synth.QUIRK_CASES):
             cfg = synth.make_quirk_case(td, name)
             pre = os.path.join(td, name)
             binary = os.path.join(ROOT, "oracle", "_ref", "SOAPdenovo-63mer")
@@ -88,6 +91,10 @@ def main():
             m2 = re.search(r"(\d+) node\(s\) allocated, (\d+) kmer\(s\) in reads", out.stderr)
             quirks[name] = {"reads_processed": int(m.group(1)), "nodes": int(m2.group(1)), "kmers": int(m2.group(2))}
             print("golden", name, quirks[name], flush=True)
+    if old is not None:
+        old["md5"].update(digests)
+        old["quirks"].update(quirks)
+        digests, quirks = old["md5"], old["quirks"]
     cases = {k: {kk: vv for kk, vv in v.items()} for k, v in CASES.items()}
     json.dump({"cases": cases, "md5": digests, "quirks": quirks}, open(os.path.join(HERE, "cases.json"), "w"), indent=1, sort_keys=True)
 

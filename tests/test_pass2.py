@@ -37,11 +37,12 @@ def test_prearc_on_reader_corner_cases(golden, tmp_path):
     for name in synth.QUIRK_CASES:
         cfg = synth.make_quirk_case(str(tmp_path), name)
         codes, lens, _, mrl = api.host_read_all(cfg, K)
-        # (BAM: the reference's pairing state outlives pass 1, so pass 2 starts with whatever pass 1 left; the fixture has an even
-        #  number of good records, which leaves it where it began)
+        # (BAM: the reference puts its pairing state back at every end of file, readseq1by1.c:584-587, so a second pass over the
+        #  inputs -- rq_bam_odd leaves a first mate dangling at the end of its first file -- sees the reads of the first)
         codes2, lens2 = codes, lens
-        if name == "rq_bam":
-            codes2, lens2, _, _ = api.host_read_all(cfg, K, bam_state=api.host_bam_state())
+        if name.startswith("rq_bam"):
+            assert api.host_bam_state() == -3
+            codes2, lens2, _, _ = api.host_read_all(cfg, K)
             assert api.host_bam_state() == -3 and (lens2 == lens).all() and (codes2 == codes).all()
         o = Oracle(K, P=P, max_read_len=mrl)
         o.add_reads(codes, lens=lens)
