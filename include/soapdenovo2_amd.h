@@ -164,7 +164,8 @@ pg_graph *pg_graph_begin_sharded(int n_ranks, const int *devices, const uint64_t
                                  int cut_single, int a_gb, int max_read_len, int n_threads, const char *prefix);
 /* <prefix>.edge.gz written beside pass 2 (on != 0): the graph stages that build edges on the device return once the device has
  * handed the edges back, a background thread formats and deflates the text, and pg_host_graph_finish (or destroying the graph)
- * waits for it.  Process-wide; off by default, so a caller that reads the file right after pg_graph_begin* finds it complete.
+ * waits for it and reports its error.  A choice of the calling thread for the graphs it begins (graphs of other threads are not
+ * touched); off by default, so a caller that reads the file right after pg_graph_begin* finds it complete.
  * call_pregraph turns it on (output_1edge, node2edge.c:88-110, has no reader before the process ends). */
 int pg_host_edge_file_in_background(int on);
 /* Device memory the caller is done with, offered to the graph stages for reuse (one block per device): with -a, pg_graph_begin_device

@@ -61,6 +61,7 @@ P2Device* p2_adopt(int lead_device, int K, int nw, int n_sets, const uint64_t* s
                    const std::vector<std::pair<int, void*>>& owned, int max_nk);
 int p2_fetch_words(int device, const uint64_t* d_src, uint64_t n_words, uint64_t* dst);
 void pg_device_free_on(int device, void* d_ptr);      // hipFree on that device
+void pg_device_release_layout(int device, void* d_ptr);   // a layout's allocation given up: re-offered if it was a taken-over block, freed otherwise
 int p2_set_patch(P2Device* d, const uint64_t* patch_keys, const uint32_t* patch_val, uint64_t patch_cap);
 int p2_build_edges(P2Device* d, P2Edges& out);
 int p2_begin_reads(P2Device* d, uint32_t num_ed, bool reps);

@@ -528,9 +528,10 @@ struct P2Device {
     uint64_t n_vlist = 0;
 };
 
+namespace { void forget_taken(void* ptr); }       // (the offered-block bookkeeping further down)
 static void p2_free(P2Device* d) {
     if (!d) return;
-    for (auto& o : d->owned) { (void)hipSetDevice(o.first); (void)hipFree(o.second); }
+    for (auto& o : d->owned) { forget_taken(o.second); (void)hipSetDevice(o.first); (void)hipFree(o.second); }
     hipSetDevice(d->device);
     hipFree(d->d_patch_keys); hipFree(d->d_patch_val);
     hipFree(d->d_arc_key); hipFree(d->d_arc_cnt); hipFree(d->d_arc_first);
@@ -639,16 +640,36 @@ __global__ void p2_empty_image(uint64_t* nodes, int nw1, uint64_t n_slots) {
 
 // Device memory a caller is done with and offers for reuse (pg_device_scratch_offer): a hipMalloc of tens of gigabytes right
 // behind a hipFree of as much takes seconds on this stack, so pass 1's record pool becomes the k-mer set image instead of being
-// freed and allocated anew.  One block per device; whoever takes it owns it.
+// freed and allocated anew.  One block per device; whoever takes it AND SUCCEEDS owns it.  A taker that fails or finds itself
+// unsuited hands the block back (the caller may still have live data in the same allocation -- call_pregraph keeps the
+// regrouped records in the pool's tail, and the host replay that follows an unsuited layout reads them), so a taken block is
+// remembered until its new owner releases it.
 namespace {
 struct Offered { int device; void* ptr; uint64_t bytes; };
-std::vector<Offered> g_offered;
+std::vector<Offered> g_offered, g_taken;
 std::mutex g_offered_mu;
 void* take_offered(int device, uint64_t need) {
     std::lock_guard<std::mutex> lk(g_offered_mu);
     for (size_t i = 0; i < g_offered.size(); i++)
-        if (g_offered[i].device == device && g_offered[i].bytes >= need + 256) { void* p = g_offered[i].ptr; g_offered.erase(g_offered.begin() + i); return p; }
+        if (g_offered[i].device == device && g_offered[i].bytes >= need + 256) {
+            void* p = g_offered[i].ptr;
+            g_taken.push_back(g_offered[i]);
+            g_offered.erase(g_offered.begin() + i);
+            return p;
+        }
     return nullptr;
+}
+// a taken block goes back on offer (true), or the pointer was never one (false)
+bool hand_back_offered(void* ptr) {
+    std::lock_guard<std::mutex> lk(g_offered_mu);
+    for (size_t i = 0; i < g_taken.size(); i++)
+        if (g_taken[i].ptr == ptr) { g_offered.push_back(g_taken[i]); g_taken.erase(g_taken.begin() + i); return true; }
+    return false;
+}
+// the new owner frees the block itself: nothing to remember any more
+void forget_taken(void* ptr) {
+    std::lock_guard<std::mutex> lk(g_offered_mu);
+    for (size_t i = 0; i < g_taken.size(); i++) if (g_taken[i].ptr == ptr) { g_taken.erase(g_taken.begin() + i); return; }
 }
 }  // namespace
 extern "C" int pg_device_scratch_offer(int device, void* d_ptr, uint64_t bytes) {
@@ -702,7 +723,11 @@ int p2_layout_rank(int device, int nw, int n_own, const uint64_t* d_records, con
     }
     if (rc == PG_OK && hipStreamSynchronize(st) != hipSuccess) { rc = PG_ENODEV; why = "kernel failure"; }
     (void)hipStreamDestroy(st);
-    if (rc) { (void)hipFree(block ? block : (void*)nodes); if (rc < 0) pg_set_error("layout: " + (why.empty() ? std::string("failed") : why)); return rc; }
+    if (rc) {
+        if (block) hand_back_offered(block); else (void)hipFree(nodes);            // only what was allocated here is freed here
+        if (rc < 0) pg_set_error("layout: " + (why.empty() ? std::string("failed") : why));
+        return rc;
+    }
     if (verbose) fprintf(stderr, "K6 on device %d: %d set(s) of %llu slots, %s %.2fs, layout %.2fs\n", device, n_own, (unsigned long long)set_size,
                          block ? "memory taken over from pass 1" : "allocation", t1 - t0, now() - t1);
     *d_nodes_out = nodes;
@@ -787,7 +812,7 @@ int p2_layout_rank_growable(int device, int nw, int n_own, const uint64_t* d_rec
     }
     (void)hipStreamDestroy(st);
     if (rc) {
-        (void)hipFree(block ? block : (void*)nodes);
+        if (block) hand_back_offered(block); else (void)hipFree(nodes);            // only what was allocated here is freed here
         if (rc == PG_ENOMEM) {                                            // no room for the scratch beside the image: the sequential host replay needs none
             fprintf(stderr, "growable sets on device %d: out of device memory for the layout's scratch; replaying on the host\n", device);
             return K6_UNSUITED;
@@ -882,6 +907,8 @@ int p2_fetch_words(int device, const uint64_t* d_src, uint64_t n_words, uint64_t
 }
 
 void pg_device_free_on(int device, void* d_ptr) { if (d_ptr) { (void)hipSetDevice(device); (void)hipFree(d_ptr); } }
+// a layout's allocation that is not going to be used after all: back on offer if it was taken over from a caller, freed otherwise
+void pg_device_release_layout(int device, void* d_ptr) { if (d_ptr && !hand_back_offered(d_ptr)) pg_device_free_on(device, d_ptr); }
 
 // KmerSetsPatch as the host built it
 int p2_set_patch(P2Device* d, const uint64_t* patch_keys, const uint32_t* patch_val, uint64_t patch_cap) {

@@ -52,7 +52,7 @@ namespace pg {
 
 static uint32_t g_crc_tab[256];
 static std::atomic<bool> g_crc_ready{false};
-static std::atomic<int> g_edge_file_in_background{0};     // pg_host_edge_file_in_background
+static thread_local int g_edge_file_in_background = 0;    // pg_host_edge_file_in_background: the calling thread's choice for the graphs it begins
 // host threads for the parallel stages: the caller's count, else SOAPDENOVO2_AMD_HOST_THREADS, else every hardware thread
 int host_threads(int n_threads);
 static int pick_threads(int n_threads) { return host_threads(n_threads); }
@@ -1745,7 +1745,8 @@ struct GraphHandle : GraphHandleBase {
     ~GraphHandle() override { shutdown(); }
     // everything but the memory: threads, files, the device copy
     void shutdown() override {
-        if (edge_thread.joinable()) edge_thread.join();
+        // a graph given up before finish(): the edge writer's verdict has no caller to go to any more -- say it at least
+        if (join_edge_writer() != PG_OK) fprintf(stderr, "%s.edge.gz was not written: %s\n", prefix.c_str(), edge_err.c_str());
         if (vertex_thread.joinable()) vertex_thread.join();
         if (path_fp) { fclose(path_fp); path_fp = nullptr; }
         if (dev) { p2_destroy(dev); dev = nullptr; }
@@ -1792,7 +1793,7 @@ struct GraphHandle : GraphHandleBase {
         dev_edges = true;
         // <prefix>.edge.gz is text made from what the device handed back; nothing that follows reads it.  A caller that said so
         // (pg_host_edge_file_in_background: call_pregraph) gets it written beside pass 2 and waits for it in finish.
-        if (g_edge_file_in_background.load()) {
+        if (g_edge_file_in_background) {
             auto* held = new P2Edges(std::move(ed));
             edge_started = true;
             edge_thread = std::thread([this, held, n_threads, te0, te1] {
@@ -2193,6 +2194,14 @@ struct GraphHandle : GraphHandleBase {
         return PG_OK;
     }
     int finish(long long* n_arcs) override {
+        // whatever else goes wrong, the background edge writer is waited for and its error is not lost (the first error wins)
+        const int rc = finish_files(n_arcs);
+        const std::string why = rc ? pg_last_error() : std::string();
+        const int erc = join_edge_writer();
+        if (rc) pg_set_error(why);
+        return rc ? rc : erc;
+    }
+    int finish_files(long long* n_arcs) {
         int rc = dev_on ? dev_finish() : arcs.write(prefix + ".preArc");
         if (rc) return rc;
         const long long arc_count = dev_on ? dev_arc_count : arcs.count();
@@ -2346,10 +2355,15 @@ static int layout_on_ranks(GraphHandle<NW>* h, const ShardedRecords& sr, const u
     std::vector<std::string> why(N);
     std::vector<uint64_t> sizes(P, S);
     std::vector<std::thread> pool;
+    // (test hook: SOAPDENOVO2_AMD_TEST_UNSUITED_RANK=r makes rank r report "unsuited" -- as a set of >= 2^32 keys or a pool filled to
+    //  the last slot would -- so that the path "some ranks laid out, one did not, everybody replays on the host" can be walked with
+    //  small inputs)
+    const int forced_unsuited = getenv("SOAPDENOVO2_AMD_TEST_UNSUITED_RANK") ? atoi(getenv("SOAPDENOVO2_AMD_TEST_UNSUITED_RANK")) : -1;
     for (int r = 0; r < N; r++)
         pool.emplace_back([&, r] {
             std::vector<uint64_t> own, own_last, own_sizes;
             for (int s = r; s < P; s += N) { own.push_back(per_set_count[s]); own_last.push_back(set_last_put ? set_last_put[s] : 0); }
+            if (r == forced_unsuited) { rcs[r] = 1; return; }                 // (1 = K6_UNSUITED, dev_graph.hpp)
             if (a_gb != 0) rcs[r] = p2_layout_rank(sr.devices[r], NW, (int)own.size(), sr.d_rec[r], own.data(), S, &nodes[r], &allocs[r]);
             else {
                 std::vector<unsigned char> trailing;
@@ -2366,7 +2380,9 @@ static int layout_on_ranks(GraphHandle<NW>* h, const ShardedRecords& sr, const u
     for (int r = 0; r < N; r++) if (rcs[r] && rc <= 0) { rc = rcs[r] < 0 ? rcs[r] : (rc ? rc : 1); if (rcs[r] < 0) pg_set_error(why[r]); }
     std::vector<std::pair<int, void*>> owned;
     for (int r = 0; r < N; r++) if (nodes[r]) owned.emplace_back(sr.devices[r], allocs[r]);
-    if (rc) { for (auto& o : owned) pg_device_free_on(o.first, o.second); return rc; }
+    // another rank is unsuited or failed: the host replay that may follow reads every rank's records, and those may lie in the
+    // tail of the very block a successful rank laid its sets out in -- such a block goes back on offer, it is not freed here
+    if (rc) { for (auto& o : owned) pg_device_release_layout(o.first, o.second); return rc; }
     std::vector<int> devs(P);
     std::vector<uint64_t*> ptrs(P);
     std::vector<uint64_t> rank_at(N, 0);                                 // slots of the rank's earlier sets
@@ -2502,7 +2518,7 @@ extern "C" pg_graph* pg_graph_begin(const uint64_t* records, uint64_t n_records,
     return (pg_graph*)h;
 }
 extern "C" int pg_host_edge_file_in_background(int on) {
-    pg::g_edge_file_in_background.store(on ? 1 : 0);
+    pg::g_edge_file_in_background = on ? 1 : 0;
     return PG_OK;
 }
 extern "C" int pg_host_graph_resolve_repeats(pg_graph* g, int on) {

@@ -559,6 +559,27 @@ def test_cli_sharded_matches_reference_files(golden, tmp_path, name, devices):
         assert md5_gz_text(pre + ".edge.gz") == want["edge"], t
 
 
+@pytest.mark.parametrize("name,run_i", [("m60k_k63", 0), ("t6k_k127", 1)])
+def test_cli_sharded_one_rank_unsuited_replays_on_the_host(golden, tmp_path, name, run_i):
+    """One rank reports its sets unsuited for the device layout while the others have already laid theirs out INSIDE the record
+    pools they took over (the regrouped records lie in the tail of the same allocation): the taken blocks go back on offer, none is
+    freed, and the host replay reads every rank's records (graph_kernels.hip p2_layout_rank*, host_graph.cpp
+    layout_on_ranks).  Growable sets and -a pools."""
+    c = golden["cases"][name]
+    cfg = case_config(c, str(tmp_path), name)
+    run = c["runs"][run_i]
+    P, D, a, m = run
+    t = case_tag(name, run)
+    pre = str(tmp_path / t)
+    env = dict(PARALLEL_PARSE, SOAPDENOVO2_AMD_DEVICES="0,0,0", PG_HOST_VERBOSE="1", SOAPDENOVO2_AMD_BATCH_READS="7000", SOAPDENOVO2_AMD_TEST_UNSUITED_RANK="1")
+    log = _run_cli(cfg, c["K"], pre, P, D, a, m, extra_env=env)
+    assert "replay set" in log                                             # the host replay ran
+    want = golden["md5"][t]
+    for ext in ("kmerFreq", "preGraphBasic", "vertex", "preArc"):
+        assert md5_file(pre + "." + ext) == want[ext], (t, ext)
+    assert md5_gz_text(pre + ".edge.gz") == want["edge"], t
+
+
 def test_cli_sharded_repeats_the_cut_when_an_owner_region_overflows(golden, tmp_path):
     """Send regions that start far too small (PG_ROUTE_CAP): every round's cut overflows, the ranks agree on a larger capacity and
     cut again -- the files do not change."""
