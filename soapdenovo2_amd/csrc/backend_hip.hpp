@@ -1,7 +1,7 @@
 // backend_hip.hpp -- the backend the product runs the device graph stages on (see backend.hpp): one HIP device, one stream.
 #pragma once
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_scan.hpp>
 #include <rocprim/device/device_radix_sort.hpp>
 
 #include <string.h>
@@ -108,16 +108,16 @@ struct HipBackend {
     void inclusive_max(const long long* in, long long* out, uint64_t n) {
         if (!n || error) return;
         size_t need = 0;
-        if (!ok(hipcub::DeviceScan::InclusiveScan(nullptr, need, in, out, BeMaxLL(), (size_t)n, stream), "scan (size)")) return;
+        if (!ok(rocprim::inclusive_scan(nullptr, need, in, out, (size_t)n, BeMaxLL(), stream), "scan (size)")) return;
         if (!scratch(need)) return;
-        ok(hipcub::DeviceScan::InclusiveScan(tmp, need, in, out, BeMaxLL(), (size_t)n, stream), "scan");
+        ok(rocprim::inclusive_scan(tmp, need, in, out, (size_t)n, BeMaxLL(), stream), "scan");
     }
     void exclusive_sum(const unsigned long long* in, unsigned long long* out, uint64_t n) {
         if (!n || error) return;
         size_t need = 0;
-        if (!ok(hipcub::DeviceScan::ExclusiveSum(nullptr, need, in, out, (size_t)n, stream), "sum (size)")) return;
+        if (!ok(rocprim::exclusive_scan(nullptr, need, in, out, 0ULL, (size_t)n, rocprim::plus<unsigned long long>(), stream), "sum (size)")) return;
         if (!scratch(need)) return;
-        ok(hipcub::DeviceScan::ExclusiveSum(tmp, need, in, out, (size_t)n, stream), "sum");
+        ok(rocprim::exclusive_scan(tmp, need, in, out, 0ULL, (size_t)n, rocprim::plus<unsigned long long>(), stream), "sum");
     }
 };
 

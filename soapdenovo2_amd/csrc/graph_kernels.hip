@@ -17,7 +17,8 @@
 //     counts are atomic adds (saturated to 255 when written).
 // All integer work, HBM-latency bound (one random 24/40-byte probe per k-mer); nothing here is shaped for MFMA.
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
 #include <stdint.h>
 #include <stdio.h>
 #include <string.h>
@@ -1008,9 +1009,9 @@ int p2_tip_walks(P2Device* d, int cut_len, bool thin, std::vector<P2TipWalk>& ou
         P2_HIP_GOTO(hipMalloc((void**)&d_order, n * sizeof(uint32_t)));
         P2_HIP_GOTO(hipMalloc((void**)&d_sorted, n * sizeof(P2TipWalk)));
         hipLaunchKernelGGL(tip_keys, dim3(1024), dim3(256), 0, st, d_w, n, d_key, d_idx);
-        P2_HIP_GOTO(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_key, d_key2, d_idx, d_order, (int)n, 0, 64, st));
+        P2_HIP_GOTO((rocprim::radix_sort_pairs<rocprim::default_config, unsigned long long*, unsigned long long*, uint32_t*, uint32_t*, size_t>(nullptr, tmp_bytes, d_key, d_key2, d_idx, d_order, (size_t)n, 0u, 64u, st)));
         P2_HIP_GOTO(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
-        P2_HIP_GOTO(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_key, d_key2, d_idx, d_order, (int)n, 0, 64, st));
+        P2_HIP_GOTO((rocprim::radix_sort_pairs<rocprim::default_config, unsigned long long*, unsigned long long*, uint32_t*, uint32_t*, size_t>(d_tmp, tmp_bytes, d_key, d_key2, d_idx, d_order, (size_t)n, 0u, 64u, st)));
         hipLaunchKernelGGL(tip_gather, dim3(1024), dim3(256), 0, st, d_w, d_order, n, d_sorted);
         out.resize(n);
         P2_HIP_GOTO(hipMemcpyAsync(out.data(), d_sorted, n * sizeof(P2TipWalk), hipMemcpyDeviceToHost, st));
@@ -1194,14 +1195,14 @@ int p2_build_edges(P2Device* d, P2Edges& out) {
         P2_HIP_GOTO(hipMalloc((void**)&d_id_before, n_rec * sizeof(unsigned long long)));
         P2_HIP_GOTO(hipMalloc((void**)&d_base_before, n_rec * sizeof(unsigned long long)));
         hipLaunchKernelGGL(eb_keys, dim3(2048), dim3(256), 0, st, d_recs, n_rec, d_key, d_idx);
-        P2_HIP_GOTO(hipcub::DeviceRadixSort::SortPairs(nullptr, tmp_bytes, d_key, d_key2, d_idx, d_order, (int)n_rec, 0, 64, st));
-        P2_HIP_GOTO(hipcub::DeviceScan::ExclusiveSum(nullptr, tmp2, d_ids, d_id_before, (int)n_rec, st));
+        P2_HIP_GOTO((rocprim::radix_sort_pairs<rocprim::default_config, unsigned long long*, unsigned long long*, uint32_t*, uint32_t*, size_t>(nullptr, tmp_bytes, d_key, d_key2, d_idx, d_order, (size_t)n_rec, 0u, 64u, st)));
+        P2_HIP_GOTO((rocprim::exclusive_scan<rocprim::default_config, unsigned long long*, unsigned long long*, unsigned long long, rocprim::plus<unsigned long long>>(nullptr, tmp2, d_ids, d_id_before, 0ULL, (size_t)n_rec, rocprim::plus<unsigned long long>(), st)));
         tmp_bytes = std::max(tmp_bytes, tmp2);
         P2_HIP_GOTO(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
-        P2_HIP_GOTO(hipcub::DeviceRadixSort::SortPairs(d_tmp, tmp_bytes, d_key, d_key2, d_idx, d_order, (int)n_rec, 0, 64, st));
+        P2_HIP_GOTO((rocprim::radix_sort_pairs<rocprim::default_config, unsigned long long*, unsigned long long*, uint32_t*, uint32_t*, size_t>(d_tmp, tmp_bytes, d_key, d_key2, d_idx, d_order, (size_t)n_rec, 0u, 64u, st)));
         hipLaunchKernelGGL(eb_sizes, dim3(2048), dim3(256), 0, st, d_recs, d_order, n_rec, d_ids, d_bases);
-        P2_HIP_GOTO(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_ids, d_id_before, (int)n_rec, st));
-        P2_HIP_GOTO(hipcub::DeviceScan::ExclusiveSum(d_tmp, tmp_bytes, d_bases, d_base_before, (int)n_rec, st));
+        P2_HIP_GOTO((rocprim::exclusive_scan<rocprim::default_config, unsigned long long*, unsigned long long*, unsigned long long, rocprim::plus<unsigned long long>>(d_tmp, tmp_bytes, d_ids, d_id_before, 0ULL, (size_t)n_rec, rocprim::plus<unsigned long long>(), st)));
+        P2_HIP_GOTO((rocprim::exclusive_scan<rocprim::default_config, unsigned long long*, unsigned long long*, unsigned long long, rocprim::plus<unsigned long long>>(d_tmp, tmp_bytes, d_bases, d_base_before, 0ULL, (size_t)n_rec, rocprim::plus<unsigned long long>(), st)));
         P2_HIP_GOTO(hipMemcpyAsync(&last_ids, d_ids + n_rec - 1, sizeof(last_ids), hipMemcpyDeviceToHost, st));
         P2_HIP_GOTO(hipMemcpyAsync(&last_bases, d_bases + n_rec - 1, sizeof(last_bases), hipMemcpyDeviceToHost, st));
         P2_HIP_GOTO(hipMemcpyAsync(&last_idb, d_id_before + n_rec - 1, sizeof(last_idb), hipMemcpyDeviceToHost, st));
