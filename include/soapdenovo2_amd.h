@@ -429,6 +429,11 @@ int pg_host_emu_layout_growable(const uint64_t *records, uint64_t n_records, con
 int pg_host_emu_clip_tips(const uint64_t *records, uint64_t n_records, const uint64_t *set_last_put, int K, int mer127, int n_sets,
                           int cut_single, int a_gb, int n_threads, uint64_t out[8]);
 
+/* key mod size (newhash.c:36-57: the exact 128-bit modulus of the 63-mer build, the 32-bit chunks folded in 64-bit arithmetic of
+ * the 127-mer build) as the graph stages' lookups and both device layouts compute it: by a precomputed reciprocal of the size
+ * instead of the compiler's 64-bit `%` (csrc/graph_lookup.hpp: ModConst, rem128).  keys = n x (mer127 ? 4 : 2) words. */
+int pg_host_emu_home_slots(const uint64_t *keys, uint64_t n, int mer127, uint64_t size, uint64_t *out);
+
 #ifdef __cplusplus
 }
 #endif

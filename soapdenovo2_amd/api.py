@@ -140,6 +140,7 @@ def lib() -> C.CDLL:
     L.pg_host_regroup_plan.argtypes = [u64p, C.c_uint64, C.c_int, C.c_int, u64p, u64p]
     L.pg_host_emu_clip_tips.argtypes = [u64p, C.c_uint64, u64p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, u64p]
     L.pg_host_emu_layout_static.argtypes = [u64p, u64p, C.c_int, C.c_uint64, C.c_int, C.c_int, u64p]
+    L.pg_host_emu_home_slots.argtypes = [u64p, C.c_uint64, C.c_int, C.c_uint64, u64p]
     _lib = L
     return L
 
@@ -151,7 +152,7 @@ EXPORTED_SYMBOLS = [
     "pg_export_take", "pg_export_take_ws", "pg_export_peek", "pg_records_checksum", "pg_sort_records_ws", "pg_device_free", "pg_set_counts", "pg_last_put", "pg_host_last_put_matters", "pg_comm_unique_id", "pg_comm_create", "pg_comm_create_local", "pg_comm_destroy", "pg_comm_rank", "pg_comm_size",
     "pg_comm_transport", "pg_comm_stats", "pg_exchange_counts", "pg_exchange_records", "pg_exchange_allreduce_u64",
     "pg_exchange_gather_records", "pg_count_reads_sharded", "pg_host_skm_cut", "pg_host_skm_expand",
-    "pg_host_emu_layout_static", "pg_graph_begin_device", "pg_host_emu_clip_tips", "pg_exchange_regroup_by_set", "pg_comm_regroup_stats", "pg_graph_begin_sharded", "pg_host_regroup_plan", "pg_host_bam_pair_state", "pg_device_scratch_offer", "pg_device_scratch_withdraw", "pg_host_emu_layout_growable", "pg_exchange_regroup_by_set_ws", "pg_host_edge_file_in_background", "pg_graph_add_packed_device",
+    "pg_host_emu_layout_static", "pg_graph_begin_device", "pg_host_emu_clip_tips", "pg_exchange_regroup_by_set", "pg_comm_regroup_stats", "pg_graph_begin_sharded", "pg_host_regroup_plan", "pg_host_bam_pair_state", "pg_device_scratch_offer", "pg_device_scratch_withdraw", "pg_host_emu_layout_growable", "pg_exchange_regroup_by_set_ws", "pg_host_edge_file_in_background", "pg_graph_add_packed_device", "pg_host_emu_home_slots",
 ]
 
 

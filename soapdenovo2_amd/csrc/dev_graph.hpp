@@ -113,11 +113,12 @@ int layout_static(BE& be, const uint64_t* records, const uint64_t* per_set_count
         uint64_t* set_nodes = nodes + (uint64_t)s * S * (NW + 1);
         first += n;
         if (!n) continue;
+        const ModConst mc = make_modconst(S);
         be.launch(n, [=] PG_LAMBDA(uint64_t i) {
             Kmer<NW> k;
 #pragma unroll
             for (int w = 0; w < NW; w++) k.w[w] = rec[i * RW + w];
-            hk[i] = home_slot<NW>(k, S);
+            hk[i] = home_slot<NW>(k, mc);
             iv[i] = (uint32_t)i;
         });
         be.sort_pairs(hk, hs, iv, is, n, bits);

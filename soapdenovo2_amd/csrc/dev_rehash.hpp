@@ -258,11 +258,12 @@ int layout_growable(BE& be, RhWork<BE>& wk, const uint64_t* rec, uint64_t n, con
         int bits = 1;
         while (bits < 64 && (S >> bits)) bits++;
         // ---- homes at this size, sorted; occupied slots, clusters, the frame in which nothing wraps
+        const ModConst mc = make_modconst(S);
         be.launch(M, [=] PG_LAMBDA(uint64_t i) {
             Kmer<NW> k;
 #pragma unroll
             for (int w = 0; w < NW; w++) k.w[w] = rec[i * RW + w];
-            hk[i] = home_slot<NW>(k, S);
+            hk[i] = home_slot<NW>(k, mc);
             iv[i] = (uint32_t)i;
         });
         be.sort_pairs(hk, hs, iv, is, M, bits);

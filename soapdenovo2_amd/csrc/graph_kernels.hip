@@ -55,8 +55,9 @@ constexpr uint64_t P2_EMPTY = ~0ULL;
 constexpr int P2_MAX_SETS = 255;
 
 struct P2Params {
-    const uint64_t* geo3;               // per set: first global slot, size, address of its slot 0 ((NW + 1) words a slot: key words,
-                                        // then A | B << 32); the sets of one graph may lie on several GPUs of the process
+    const uint64_t* geo3;               // per set (SV_GEO words): first global slot, size, address of its slot 0 ((NW + 1) words a slot: key
+                                        // words, then A | B << 32), the size's reciprocal (graph_lookup.hpp: ModConst); the sets of one graph may
+                                        // lie on several GPUs of the process
     uint32_t P, bias;
     int K;
     // (K+1)-mer patch table
@@ -83,9 +84,9 @@ struct P2Params {
 // sv_find / sv_step / sv_node are the reference's search_kmerset on per-set base addresses)
 #define P2_PROLOGUE(p)                                                                               \
     __shared__ uint32_t crc_tab[256];                                                                \
-    __shared__ uint64_t set_geo[3 * P2_MAX_SETS];                                                    \
+    __shared__ uint64_t set_geo[SV_GEO * P2_MAX_SETS];                                               \
     crc_tab[threadIdx.x] = crc32_table_entry(threadIdx.x);                                           \
-    for (int q_ = threadIdx.x; q_ < 3 * (int)(p).P; q_ += 256) set_geo[q_] = (p).geo3[q_];           \
+    for (int q_ = threadIdx.x; q_ < SV_GEO * (int)(p).P; q_ += 256) set_geo[q_] = (p).geo3[q_];      \
     __syncthreads();                                                                                 \
     const SetsView sv{set_geo, crc_tab, (p).P, (p).bias, (p).K}
 
@@ -548,12 +549,14 @@ static int p2_finish_open(P2Device* d) {
     P2_HIP(hipSetDevice(d->device));
     if (!d->stream) P2_HIP(hipStreamCreate(&d->stream));
     memset(&d->prm, 0, sizeof(d->prm));
-    std::vector<uint64_t> words(3 * (size_t)d->P);
+    std::vector<uint64_t> words(SV_GEO * (size_t)d->P);
     d->set_first.assign(d->P, 0);
     uint64_t first = 0;
     for (int s = 0; s < d->P; s++) {
         d->set_first[s] = first;
-        words[3 * s] = first; words[3 * s + 1] = d->set_sizes[s]; words[3 * s + 2] = (uint64_t)(uintptr_t)d->set_ptr[s];
+        const ModConst mc = make_modconst(d->set_sizes[s]);
+        words[SV_GEO * s] = first; words[SV_GEO * s + 1] = d->set_sizes[s]; words[SV_GEO * s + 2] = (uint64_t)(uintptr_t)d->set_ptr[s];
+        words[SV_GEO * s + 3] = mc.v; words[SV_GEO * s + 4] = mc.s;
         first += d->set_sizes[s];
         if (d->set_dev[s] != d->device) {                    // the lead reads and writes its peers' sets
             int can = 0;

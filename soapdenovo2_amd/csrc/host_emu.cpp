@@ -27,3 +27,15 @@ extern "C" int pg_host_emu_layout_static(const uint64_t* records, const uint64_t
     if (rc < 0) pg_set_error(be.error_text.empty() ? "pg_host_emu_layout_static failed" : be.error_text);
     return rc;
 }
+
+// key mod size with the precomputed reciprocal (graph_lookup.hpp: ModConst, rem128, home_slot), as every lookup of the graph stages and
+// both layouts compute it; keys = n x (mer127 ? 4 : 2) words, out[n]
+extern "C" int pg_host_emu_home_slots(const uint64_t* keys, uint64_t n, int mer127, uint64_t size, uint64_t* out) {
+    if (!keys || !out || size < 1 || (size >> 63)) { pg_set_error("pg_host_emu_home_slots: bad argument"); return PG_EINVAL; }
+    const pg::ModConst mc = pg::make_modconst(size);
+    for (uint64_t i = 0; i < n; i++) {
+        if (mer127) { pg::Kmer<4> k; for (int w = 0; w < 4; w++) k.w[w] = keys[4 * i + w]; out[i] = pg::home_slot<4>(k, mc); }
+        else { pg::Kmer<2> k; for (int w = 0; w < 2; w++) k.w[w] = keys[2 * i + w]; out[i] = pg::home_slot<2>(k, mc); }
+    }
+    return PG_OK;
+}

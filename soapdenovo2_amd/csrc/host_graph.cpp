@@ -2643,11 +2643,13 @@ static int emu_clip_tips(const uint64_t* records, uint64_t n, const uint64_t* se
     g1.remove_minor_tips();
     SetsGeo geo;
     geo.P = P;
-    std::vector<uint64_t> geo_words(3 * (size_t)P);
+    std::vector<uint64_t> geo_words(SV_GEO * (size_t)P);
     uint64_t first = 0;
     for (int s = 0; s < P; s++) {
         geo.first.push_back(first); geo.size.push_back(g2.sets[s].size); geo.base.push_back((uint64_t*)g2.sets[s].array.data());
-        geo_words[3 * s] = first; geo_words[3 * s + 1] = g2.sets[s].size; geo_words[3 * s + 2] = (uint64_t)(uintptr_t)g2.sets[s].array.data();
+        const ModConst mc = make_modconst(g2.sets[s].size);
+        geo_words[SV_GEO * s] = first; geo_words[SV_GEO * s + 1] = g2.sets[s].size; geo_words[SV_GEO * s + 2] = (uint64_t)(uintptr_t)g2.sets[s].array.data();
+        geo_words[SV_GEO * s + 3] = mc.v; geo_words[SV_GEO * s + 4] = mc.s;
         first += g2.sets[s].size;
     }
     SetsView view{geo_words.data(), host_crc_table(), (uint32_t)P, set_bias((uint32_t)P), K};

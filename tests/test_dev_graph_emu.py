@@ -196,3 +196,34 @@ def test_layout_growable_random_keys_four_words():
     last = np.array([2 * n + 3 for n in counts], dtype=np.uint64)        # every set saw a duplicate put after its last new key
     rounds = _growable_vs_replay(rec, last, P, True, threads=4)
     assert int(rounds[0]) > int(rounds[1])
+
+
+@pytest.mark.parametrize("mer127", [False, True])
+def test_home_slot_by_reciprocal_equals_the_reference_modulus(mer127):
+    """key mod size through the precomputed reciprocal (graph_lookup.hpp: rem128) against Python's integers: the exact 128-bit
+    modulus of the 63-mer build, and the 127-mer build's 32-bit chunks folded in 64-bit arithmetic -- whose `t << 32` overflows
+    once a set is larger than 2^32 slots (newhash.c:36-57); sizes from 1 to 2^63 - 1, keys incl. the extremes."""
+    rng = np.random.default_rng(11)
+    nw = 4 if mer127 else 2
+    M = (1 << 64) - 1
+    sizes = [1, 2, 3, 1031, 16777213, (1 << 32) - 1, 1 << 32, (1 << 32) + 15, 4294967311 * 3, (1 << 40) + 9, (1 << 62) + 1, (1 << 63) - 1, (1 << 63) - 25]
+    sizes += [int(x) for x in rng.integers(1, 1 << 62, size=20)] + [int(x) for x in rng.integers(1, 1 << 34, size=20)]
+    keys = rng.integers(0, 1 << 63, size=(4000, nw), dtype=np.uint64) * np.uint64(2) + rng.integers(0, 2, size=(4000, nw), dtype=np.uint64)
+    keys[0] = 0
+    keys[1] = M
+    keys[2, :] = [M if i % 2 else 0 for i in range(nw)]
+    keys = np.ascontiguousarray(keys)
+    out = np.zeros(len(keys), dtype=np.uint64)
+    for size in sizes:
+        api._check(api.lib().pg_host_emu_home_slots(keys.ctypes.data, len(keys), int(mer127), size, out.ctypes.data), "pg_host_emu_home_slots")
+        for i in range(0, len(keys), 7 if size > 5 else 1):
+            w = [int(x) for x in keys[i]]
+            if not mer127:
+                want = ((w[0] << 64) | w[1]) % size
+            else:
+                t = w[0] % size
+                for x in w[1:]:
+                    t = (((t << 32) & M) | (x >> 32)) % size
+                    t = (((t << 32) & M) | (x & 0xFFFFFFFF)) % size
+                want = t
+            assert int(out[i]) == want, (size, w)
