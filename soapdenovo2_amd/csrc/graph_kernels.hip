@@ -128,11 +128,25 @@ __device__ inline void add_prearc(const P2Params& p, uint32_t from, uint32_t to,
     atomicAdd(&p.counters[2], 1ULL);
 }
 
-// one lane = one read (chopKmer4read + searchKmer + parse1read + search1kmerPlus + thread_add1preArc + recordPathBin)
-template <int NW>
+// one lane = one read (chopKmer4read + searchKmer + parse1read + search1kmerPlus + thread_add1preArc + recordPathBin).
+// The read is taken BL k-mers at a time, in two phases.  LOOK UP: roll the BL k-mers, and for each the canonical form, its set
+// (CRC-32 sliced by four: four independent table reads a step instead of a chain of sixteen), its home slot (key mod size by
+// the set's precomputed reciprocal) -- then ask for all BL home slots at once and look at them together; the probes that did
+// not end at their home slot (linear probing, newhash.c:277-318) go round again, together.  A lane so has BL random 24 / 40-byte
+// probes of the sets in flight instead of one: the kernel waits for memory, and with one probe a lane it ran at a sixth of the
+// rate HBM serves random lines at (profiles/r03_graph_kernels_60M.csv).  THREAD: parse1read's state machine (prlRead2path.c:
+// 598-745) over the BL counter words, in read order, exactly as before.  (The reference looks every k-mer of its buffer up
+// before it threads any read, prlRead2path.c:159-248: a k-mer behind the point where the state machine gives a read up is
+// looked up there too.)
+template <int NW, int BL>
 __global__ __launch_bounds__(256) void p2_thread_kernel(P2Params p, const uint64_t* __restrict__ words, const uint64_t* __restrict__ word_off,
                                                         const int32_t* __restrict__ lens, uint64_t n_reads, uint64_t first_ordinal, int uniform_len) {
-    P2_PROLOGUE(p);
+    static_assert(BL >= 1 && BL <= 8, "set ids of a block are packed into one 64-bit word");
+    __shared__ uint32_t crc4[4 * 256];
+    __shared__ uint64_t set_geo[SV_GEO * P2_MAX_SETS];
+    for (int i = threadIdx.x; i < 1024; i += 256) crc4[i] = crc32_slice_entry(i >> 8, i & 255);
+    for (int i = threadIdx.x; i < SV_GEO * (int)p.P; i += 256) set_geo[i] = p.geo3[i];
+    __syncthreads();
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     const int K = p.K;
@@ -155,48 +169,100 @@ __global__ __launch_bounds__(256) void p2_thread_kernel(P2Params p, const uint64
     int n_items = 0;             // items pushed since the last restart
     int n_valid = -1;            // index of the first unresolved item (id 0), -1 while there is none
     uint32_t last_id = 0;        // id of the latest item
-    for (int j = 0; j < nk; j++) {
-        if (j) kmer_roll<NW>(word, bal, read_base(rd, j + K - 1), K, filter);
-        const bool smaller = kmer_less<NW>(word, bal);
-        uint64_t* nd;
-        if (sv_find<NW>(sv, smaller ? word : bal, nd) == ~0ULL) { atomicAdd(&p.counters[1], 1ULL); return; }
-        const uint64_t ab = nd[NW];
-        const uint32_t A = (uint32_t)ab, B = (uint32_t)(ab >> 32);
-        const bool linear = B & B_LINEAR, in_edge = (B >> B_INEDGE_SHIFT) & 3;
-        if ((B & B_DELETED) || (linear && !in_edge)) {                   // deleted, or on a floating loop
-            if (retain < 2) { retain = 0; n_items = 0; n_valid = -1; continue; }
-            break;
-        }
-        uint32_t id = 0;
-        bool push = false;
-        if (linear) {
-            const uint32_t twin = (B >> B_TWIN_SHIFT) & 3;
-            id = smaller ? A : A + twin - 1;
-            if (retain == 0 || is_prev) { push = true; is_prev = false; }
-            else if (id != last_id) push = true;
-        } else {
-            if (is_prev) {                                               // branch node after branch node: a length-1 edge
-                const Kmer<NW> plus = kmer_plus<NW>(prev_k, kmer_last<NW>(word));
-                const Kmer<NW> bal_plus = rc_plus<NW>(plus, K);
-                const bool sm = kmer_less<NW>(plus, bal_plus);
-                id = find_patch<NW>(p, sm ? plus : bal_plus, sm);
-                push = true;
+    bool stop = false;
+    for (int j0 = 0; j0 < nk && !stop; j0 += BL) {
+        const int nb = min(BL, nk - j0);
+        // ---- look up
+        Kmer<NW> ck[BL];
+        uint64_t hc[BL], abv[BL];
+        uint64_t setq = 0;                                               // the probes' set ids, a byte each
+        uint32_t smaller_mask = 0;
+#pragma unroll
+        for (int q = 0; q < BL; q++) {
+            if (q < nb) {
+                if (j0 + q) kmer_roll<NW>(word, bal, read_base(rd, j0 + q + K - 1), K, filter);
+                const bool sm = kmer_less<NW>(word, bal);
+                ck[q] = sm ? word : bal;
+                smaller_mask |= (sm ? 1u : 0u) << q;
+                const uint32_t s = set_of_crc(kmer_crc32_sliced<NW>(ck[q], crc4), p.P, p.bias);
+                setq |= (uint64_t)s << (8 * q);
+                hc[q] = home_slot<NW>(ck[q], ModConst{set_geo[SV_GEO * s + 1], set_geo[SV_GEO * s + 3], (uint32_t)set_geo[SV_GEO * s + 4]});
+            } else {                                                     // behind the read's last k-mer: probe 0 once more (nobody looks)
+                ck[q] = ck[0]; hc[q] = hc[0];
+                setq |= (setq & 0xff) << (8 * q);
             }
-            is_prev = true;
-            prev_k = word;
+            abv[q] = 0;
         }
-        if (!push) continue;
-        retain++;
-        // thread_add1preArc walks the items pairwise up to the first unresolved one (prlRead2path.c:405-424); an item is
-        // never taken back once two are retained, so the pair can go out as soon as its second half is known
-        if (n_items >= 1 && n_valid < 0 && id != 0) {
-            if (last_id >= p.id_end || id >= p.id_end) atomicAdd(&p.counters[5], 1ULL);
-            else add_prearc(p, last_id, id, seq0 | (unsigned)(n_items - 1));
+        uint32_t pend = (1u << nb) - 1u;
+        for (bool first = true; pend; first = false) {
+            uint64_t d[BL][NW + 1];
+#pragma unroll
+            for (int q = 0; q < BL; q++)
+                if (first || ((pend >> q) & 1u)) {                       // (the first round asks for everything, unconditionally)
+                    const uint32_t s = (uint32_t)(setq >> (8 * q)) & 0xff;
+                    const uint64_t* nd = (const uint64_t*)(uintptr_t)set_geo[SV_GEO * s + 2] + hc[q] * (NW + 1);
+#pragma unroll
+                    for (int i = 0; i <= NW; i++) d[q][i] = nd[i];
+                }
+#pragma unroll
+            for (int q = 0; q < BL; q++)
+                if ((pend >> q) & 1u) {
+                    if (d[q][0] == SV_EMPTY) { atomicAdd(&p.counters[1], 1ULL); return; }      // not in the sets
+                    bool eq = true;
+#pragma unroll
+                    for (int i = 0; i < NW; i++) eq = eq && d[q][i] == ck[q].w[i];
+                    if (eq) { abv[q] = d[q][NW]; pend &= ~(1u << q); }
+                    else {
+                        const uint32_t s = (uint32_t)(setq >> (8 * q)) & 0xff;
+                        if (++hc[q] == set_geo[SV_GEO * s + 1]) hc[q] = 0;
+                    }
+                }
         }
-        if (id == 0 && n_valid < 0) n_valid = n_items;
-        if (row && n_items < p.max_nk) row[n_items] = id;
-        last_id = id;
-        n_items++;
+        // ---- thread
+#pragma unroll
+        for (int q = 0; q < BL; q++) {
+            if (q >= nb || stop) continue;
+            const bool smaller = (smaller_mask >> q) & 1u;
+            const uint64_t ab = abv[q];
+            const uint32_t A = (uint32_t)ab, B = (uint32_t)(ab >> 32);
+            const bool linear = B & B_LINEAR, in_edge = (B >> B_INEDGE_SHIFT) & 3;
+            if ((B & B_DELETED) || (linear && !in_edge)) {                   // deleted, or on a floating loop
+                if (retain < 2) { retain = 0; n_items = 0; n_valid = -1; }
+                else stop = true;
+                continue;
+            }
+            uint32_t id = 0;
+            bool push = false;
+            if (linear) {
+                const uint32_t twin = (B >> B_TWIN_SHIFT) & 3;
+                id = smaller ? A : A + twin - 1;
+                if (retain == 0 || is_prev) { push = true; is_prev = false; }
+                else if (id != last_id) push = true;
+            } else {
+                const Kmer<NW> wq = smaller ? ck[q] : kmer_rc<NW>(ck[q], K);    // the k-mer as the read spells it
+                if (is_prev) {                                               // branch node after branch node: a length-1 edge
+                    const Kmer<NW> plus = kmer_plus<NW>(prev_k, kmer_last<NW>(wq));
+                    const Kmer<NW> bal_plus = rc_plus<NW>(plus, K);
+                    const bool sm = kmer_less<NW>(plus, bal_plus);
+                    id = find_patch<NW>(p, sm ? plus : bal_plus, sm);
+                    push = true;
+                }
+                is_prev = true;
+                prev_k = wq;
+            }
+            if (!push) continue;
+            retain++;
+            // thread_add1preArc walks the items pairwise up to the first unresolved one (prlRead2path.c:405-424); an item is
+            // never taken back once two are retained, so the pair can go out as soon as its second half is known
+            if (n_items >= 1 && n_valid < 0 && id != 0) {
+                if (last_id >= p.id_end || id >= p.id_end) atomicAdd(&p.counters[5], 1ULL);
+                else add_prearc(p, last_id, id, seq0 | (unsigned)(n_items - 1));
+            }
+            if (id == 0 && n_valid < 0) n_valid = n_items;
+            if (row && n_items < p.max_nk) row[n_items] = id;
+            last_id = id;
+            n_items++;
+        }
     }
     if (retain < 1) atomicAdd(&p.counters[0], 1ULL);
     if (retain < 2 || !row) return;
@@ -209,6 +275,22 @@ __global__ __launch_bounds__(256) void p2_thread_kernel(P2Params p, const uint64
         if (e < p.id_end) atomicAdd(&p.marker[e], 1u); else atomicAdd(&p.counters[5], 1ULL);
     }
     atomicAdd(&p.counters[4], (unsigned long long)upto);
+}
+// probes a lane keeps in flight (SOAPDENOVO2_AMD_P2_BLOCK = 1: one at a time, for A/B runs)
+static int p2_block() { static const int v = [] { const char* e = getenv("SOAPDENOVO2_AMD_P2_BLOCK"); return e ? atoi(e) : 0; }(); return v; }
+static void p2_launch_thread_kernel(int nw, dim3 grid, hipStream_t st, const P2Params& p, const uint64_t* words, const uint64_t* word_off, const int32_t* lens,
+                                    uint64_t n_reads, uint64_t first_ordinal, int uniform_len) {
+    const int bl = p2_block();
+    const dim3 block(256);
+    if (nw == 2) {
+        if (bl == 1) hipLaunchKernelGGL((p2_thread_kernel<2, 1>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len);
+        else if (bl == 4) hipLaunchKernelGGL((p2_thread_kernel<2, 4>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len);
+        else hipLaunchKernelGGL((p2_thread_kernel<2, 8>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len);
+    } else {
+        if (bl == 1) hipLaunchKernelGGL((p2_thread_kernel<4, 1>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len);
+        else if (bl == 8) hipLaunchKernelGGL((p2_thread_kernel<4, 8>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len);
+        else hipLaunchKernelGGL((p2_thread_kernel<4, 4>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len);
+    }
 }
 
 
@@ -1276,9 +1358,8 @@ int p2_add_packed(P2Device* d, const uint64_t* words, const uint64_t* word_off, 
     P2Params p = d->prm;
     p.stage = d->reps ? d->d_stage : nullptr;
     p.walk_len = d->reps ? d->d_walk_len : nullptr;
-    const dim3 grid((unsigned)((n_reads + 255) / 256)), block(256);
-    if (d->nw == 2) hipLaunchKernelGGL(p2_thread_kernel<2>, grid, block, 0, d->stream, p, d->d_words, d->d_off, d->d_lens, n_reads, d->ordinal, 0);
-    else hipLaunchKernelGGL(p2_thread_kernel<4>, grid, block, 0, d->stream, p, d->d_words, d->d_off, d->d_lens, n_reads, d->ordinal, 0);
+    const dim3 grid((unsigned)((n_reads + 255) / 256));
+    p2_launch_thread_kernel(d->nw, grid, d->stream, p, d->d_words, d->d_off, d->d_lens, n_reads, d->ordinal, 0);
     P2_HIP(hipGetLastError());
     if (d->reps && walks_out && walk_len_out) {
         P2_HIP(hipMemcpyAsync(walks_out, d->d_stage, n_reads * (size_t)d->max_nk * sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
@@ -1300,9 +1381,8 @@ int p2_add_packed_device(P2Device* d, const uint64_t* d_words, uint64_t n_reads,
     P2Params p = d->prm;
     p.stage = nullptr;
     p.walk_len = nullptr;
-    const dim3 grid((unsigned)((n_reads + 255) / 256)), block(256);
-    if (d->nw == 2) hipLaunchKernelGGL(p2_thread_kernel<2>, grid, block, 0, d->stream, p, d_words, (const uint64_t*)nullptr, (const int32_t*)nullptr, n_reads, d->ordinal, read_len);
-    else hipLaunchKernelGGL(p2_thread_kernel<4>, grid, block, 0, d->stream, p, d_words, (const uint64_t*)nullptr, (const int32_t*)nullptr, n_reads, d->ordinal, read_len);
+    const dim3 grid((unsigned)((n_reads + 255) / 256));
+    p2_launch_thread_kernel(d->nw, grid, d->stream, p, d_words, nullptr, nullptr, n_reads, d->ordinal, read_len);
     P2_HIP(hipGetLastError());
     P2_HIP(hipStreamSynchronize(d->stream));
     d->ordinal += n_reads;

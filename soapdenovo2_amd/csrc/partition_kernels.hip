@@ -382,11 +382,18 @@ __device__ __forceinline__ unsigned int wave_inclusive_sum(unsigned int x) {
 // VT: the occurrences of a window are cut into VT * THREADS equal shares ("virtual lanes"); a wave takes 64 of them at a time
 // from a counter in LDS until none are left.  VT = 1 is the static split (lane l takes share l); with more shares than lanes a
 // wave that finishes early -- shorter probe sequences, fewer lost CAS -- takes the next tile instead of waiting at the barrier.
+// VT = 0: no shares at all -- occurrence idx of the window goes to lane idx mod 64 of whichever wave takes tile idx / 64 (the same
+// counter).  The flatten step then only marks where every representative's occurrences start (one bit an occurrence: sbits) and
+// which representative is running at each tile's first occurrence (tile_rep0); a lane finds its representative with a population
+// count over its tile's 64 start bits.  The table "share -> first representative" (first_rec: every representative wrote the ~19
+// shares that start inside it, a loop of up to 64 steps a wave) is gone, and so is the inner loop over a share.
 // KS: the kernel for ONE k-mer length (0 = any): the K-only shift amounts of occ_extract become immediates and its two wave-uniform
 // switches -- a dozen scalar branches an occurrence -- go away.
 template <int NW, int SLOTS, int THREADS, int WIN, bool TIMERS, int VT = 1, int KS = 0>
-__global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetParams sp, OccConst oc, DevCounters* ctr, int dbg_arg) {
+__global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetParams sp, OccConst oc, DevCounters* ctr, int dbg_arg, int opt) {
     const int dbg = KS == 0 ? dbg_arg : 0;                               // the measurement switches (PG_DBG) live in the general kernel only
+    // opt (PG_K2_OPT, wave-uniform): bit 0 = the emit lists the live slots through one returned LDS atomic a wave and stripe (the
+    // export order is unspecified anyway) instead of exact ranks from a table of per-wave counts behind a second barrier
     constexpr int PW = E2Cfg<NW>::PW, RW = PW + 1, KW = E2Cfg<NW>::KW, NWAVE = THREADS / 64, PIECES = RW / 2, N2 = 2 * NW;
     constexpr int RD = 2 * RW;                                            // dwords a record
     constexpr int PAD = 16;                                               // readable dwords in front of record 0 (a window reaches back 2 NW + 2)
@@ -401,12 +408,17 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     __shared__ __align__(16) uint32_t rl2[2][RL_WORDS];
     // one scratch area, two lives: the record-dedupe table (DT slots), then the flattening tables
     constexpr int DT = 2 * WIN;                                           // open addressing over the window's records, <= 50 % full
-    constexpr int VL = VT * THREADS;                                      // virtual lanes
-    constexpr int FL_WORDS = (DT > WIN + 1 + VL / 2 ? DT : WIN + 1 + VL / 2) + 2;
+    constexpr int VL = (VT ? VT : 1) * THREADS;                           // virtual lanes
+    constexpr int SB_WORDS = (WIN * 127 + 31) / 32 + 2;                   // VT = 0: a start bit per occurrence of a window (<= WIN * 127)
+    constexpr int SB_AT = ((DT > WIN + 1 + WIN ? DT : WIN + 1 + WIN) + 1) & ~1;      //         behind the dedupe table and behind tile_rep0; read 64 bits at a time
+    constexpr int FL_WORDS = VT == 0 ? SB_AT + SB_WORDS : (DT > WIN + 1 + VL / 2 ? DT : WIN + 1 + VL / 2) + 2;
+    static_assert(VT != 0 || WIN * 127 / 64 + 1 <= 2 * WIN, "tile_rep0 holds a short per tile");
     __shared__ __align__(8) unsigned int fl_raw[FL_WORDS];
     unsigned int* const dtab = fl_raw;                                    // record index + 1 of the slot's first taker, 0 = free
     unsigned int* const noff = fl_raw;                                    // [n_rep + 1] exclusive prefix sum of the representatives' k-mer counts
     unsigned short* const first_rec = (unsigned short*)(fl_raw + WIN + 1);   // [VL] representative in which virtual lane l's share starts
+    unsigned short* const tile_rep0 = (unsigned short*)(fl_raw + WIN + 1);   // VT = 0: [tiles] the representative running at occurrence 64 * tile (lives in the dead dedupe table)
+    unsigned int* const sbits = fl_raw + SB_AT;                              // VT = 0: bit idx = occurrence idx is the first of its representative
     __shared__ unsigned int tile_ctr;                                     // next tile of 64 virtual lanes (VT > 1)
     __shared__ unsigned int dcount[WIN];                                  // copies of a representative record in the window
     __shared__ uint32_t crc_tab[4 * 256];                                 // CRC-32 sliced by four (kmer.hpp)
@@ -451,6 +463,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
         }
         for (int i = gtid; i < DT; i += GS) dtab[i] = 0;
         for (int i = gtid; i < WIN; i += GS) dcount[i] = 1;
+        if (VT == 0) for (int i = gtid; i < SB_WORDS; i += GS) sbits[i] = 0;
     };
     // the same in two halves with the memory latency in between: ask (16 bytes a lane from global memory straight into LDS,
     // lane l of a wave to wave base + 16 l: the staging layout but for the dword order), and later turn the dwords round in
@@ -483,6 +496,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
         }
         for (int i = threadIdx.x; i < DT; i += THREADS) dtab[i] = 0;
         for (int i = threadIdx.x; i < WIN; i += THREADS) dcount[i] = 1;
+        if (VT == 0) for (int i = threadIdx.x; i < SB_WORDS; i += THREADS) sbits[i] = 0;
     };
     // dedupe: at high coverage most records of a partition are exact copies of one another (every read that covers a
     // super-k-mer completely cuts out the same bases with the same flanks).  Copies are found through a small hash table over
@@ -554,6 +568,11 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
             const unsigned int upto = base + ps.incl, k = (upto >> 20) - 1;          // this representative's rank
             const unsigned int o_hi = upto & ((1u << 20) - 1), o_lo = o_hi - ps.n;
             noff[k] = o_lo | ((unsigned int)gtid << 16) | ((h0 & 3u) << 25);          // bit 25 = has_right, bit 26 = has_left
+            if constexpr (VT == 0) {
+                atomicOr(&sbits[o_lo >> 5], 1u << (o_lo & 31u));
+                // the tiles whose first occurrence lies in this representative (at most two more: a record has <= 127 k-mers)
+                for (unsigned int t = (o_lo + 63u) >> 6; (t << 6) < o_hi; t++) tile_rep0[t] = (unsigned short)k;
+            } else {
             // lanes whose share starts inside this record: l * share in [o_lo, o_hi)
             const float inv = 1.0f / (float)share;
             auto div_up = [&](unsigned int x) {                                // ceil(x / share), x < 2^16
@@ -564,6 +583,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
             };
             const unsigned int l0 = div_up(o_lo), l1 = min((unsigned int)VL, div_up(o_hi));
             for (unsigned int l = l0; l < l1; l++) first_rec[l] = (unsigned short)k;
+            }
         }
         if (gtid == 0) { noff[n_rep] = tot; s_tot = tot; tile_ctr = NWAVE; }
     };
@@ -606,6 +626,21 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
             running += total;
         }
         if (gtid == 0) s_nlive = running;
+    };
+    // the same list in any order: a wave reserves room for its live slots of a stripe with one returned atomic on s_nlive (zeroed
+    // in front of the barrier that ends the occurrence phase)
+    auto e_list_any = [&](auto gs_, int gtid, int sb) {
+        constexpr int GS = decltype(gs_)::value, STR = SLOTS / GS;
+        unsigned short* live_list = (unsigned short*)rl2[sb];
+#pragma unroll
+        for (int st = 0; st < STR; st++) {
+            const bool live = set.key[0][st * GS + gtid] != L_EMPTY;
+            const unsigned long long bal = __ballot(live);
+            unsigned int base = 0;
+            if (lane == 0 && bal) base = atomicAdd(&s_nlive, (unsigned int)__popcll(bal));
+            base = (unsigned int)__builtin_amdgcn_readfirstlane((int)base);
+            if (live) live_list[base + (unsigned int)__popcll(bal & ((1ULL << lane) - 1))] = (unsigned short)(st * GS + gtid);
+        }
     };
     auto e_final = [&](auto gs_, int gtid, int sb, unsigned int c0, unsigned int cn, unsigned int n_live) {
         constexpr int GS = decltype(gs_)::value;
@@ -744,27 +779,35 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 // the partition's next window flies into the other buffer while this one is counted
                 const bool more = w0 + WIN < usable;
                 if (more && !(dbg & 16)) p_stage_async(b ^ 1, cl, w0 + WIN, min((uint32_t)WIN, usable - w0 - WIN));
-                const uint32_t total_occ = s_tot, share = (total_occ + VL - 1) / VL;
+                const uint32_t total_occ = s_tot, share = VT == 0 ? 1u : (total_occ + VL - 1) / VL;
                 const uint32_t* const rl = rl2[b];
                 if (!__hip_atomic_load(&aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
                   // (VT > 1) tiles of 64 virtual lanes: the wave's first one is its own number, the next ones come off the counter
                   for (uint32_t tile = (uint32_t)wave;;) {
                     const uint32_t vlane = VT == 1 ? threadIdx.x : tile * 64u + (uint32_t)lane;
-                    if (VT > 1 && (tile * 64u * share >= total_occ || __hip_atomic_load(&aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) break;
+                    if (VT != 1 && (tile * 64u * share >= total_occ || __hip_atomic_load(&aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) break;
                     uint32_t idx = min(total_occ, vlane * share);
                     const uint32_t idx1 = min(total_occ, idx + share);
                     if (idx < idx1) {
-                        uint32_t k = first_rec[vlane];
+                        uint32_t k;
+                        if constexpr (VT == 0) {
+                            // the representative running at the tile's first occurrence + the starts among the tile's occurrences 1 .. lane
+                            const unsigned long long tb = *(const unsigned long long*)(sbits + 2 * tile);
+                            const unsigned long long upto = lane == 63 ? ~0ULL : (2ULL << lane) - 1ULL;
+                            k = (uint32_t)tile_rep0[tile] + (uint32_t)__popcll(tb & upto & ~1ULL);
+                        } else k = first_rec[vlane];
                         uint32_t nk = noff[k], nk1 = noff[k + 1];              // idx lies inside representative k
                         for (; idx < idx1; idx++) {
                             const uint32_t o_lo = nk & 0xFFFFu, o_hi = nk1 & 0xFFFFu;
                             const uint32_t* rec = rl + PAD + ((nk >> 16) & 0x1FFu) * RD;
                             const uint32_t hl = (nk >> 26) & 1u, hr = (nk >> 25) & 1u, n = o_hi - o_lo;
                             const uint32_t t = idx - o_lo;
-                            // the table entries of the next occurrence, asked for before this one is worked on
-                            k += idx + 1 >= o_hi ? 1u : 0u;
-                            nk = noff[k];
-                            nk1 = noff[k + 1];
+                            if constexpr (VT != 0) {
+                                // the table entries of the next occurrence, asked for before this one is worked on
+                                k += idx + 1 >= o_hi ? 1u : 0u;
+                                nk = noff[k];
+                                nk1 = noff[k + 1];
+                            }
                             uint32_t f[N2], rc[N2], prev, next;
                             if constexpr (KS != 0) {
                                 constexpr OccConst ock = occ_const(KS, NW);
@@ -800,10 +843,11 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 K2_TICK(4);
                 // the next partition's chunk list, for the prepare that runs beside this partition's last emit
                 if (threadIdx.x < nchunks) chunk_ids2[cl ^ 1][threadIdx.x] = pf_cid;
+                if (threadIdx.x == 0) s_nlive = 0;                          // (e_list_any adds to it; its last readers are a barrier back)
                 K2_SYNC();                                                  // the window and its tables are rewritten by the next one
                 // (every wave is past the tile loop: the counter starts over for the next occurrence phase -- the next window,
                 //  or the same window again for another key range -- which is at least one barrier away)
-                if (VT > 1 && threadIdx.x == 0) tile_ctr = NWAVE;
+                if (VT != 1 && threadIdx.x == 0) tile_ctr = NWAVE;
                 if (w0 + WIN < usable) {                                    // more windows add to these counters: keep the halves small
                     for (int i = threadIdx.x; i < SLOTS; i += THREADS) {    // (they saturate at 63 / 255 in the end anyway)
 #pragma unroll
@@ -837,11 +881,16 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 const int sb = top == 0 ? b : b ^ 1;
                 if (ahead) { p_stage_async(b ^ 1, cl ^ 1, 0u, min((uint32_t)WIN, usable_next)); staged = true; }
                 {
-                    Emit es;
-                    e_list1(whole, threadIdx.x, wave, es);
-                    K2_SYNC();
-                    e_list2(whole, threadIdx.x, wave, sb, es);
-                    K2_SYNC();
+                    if (opt & 1) {
+                        e_list_any(whole, threadIdx.x, sb);
+                        K2_SYNC();
+                    } else {
+                        Emit es;
+                        e_list1(whole, threadIdx.x, wave, es);
+                        K2_SYNC();
+                        e_list2(whole, threadIdx.x, wave, sb, es);
+                        K2_SYNC();
+                    }
                     K2_TICK(6);
                     const unsigned int n_live = s_nlive;
                     for (unsigned int c0 = 0; c0 < n_live; c0 += STAGE_CAP) {
@@ -1272,6 +1321,8 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     if (const char* v = getenv("PG_K2_VT")) vt = atoi(v);                 // 1 = static shares (round 2), 2 / 4 = tiles
     if (const char* v = getenv("PG_DBG")) dbg = atoi(v);
     if (const char* v = getenv("PG_K2CFG")) cfg = atoi(v);
+    int k2opt = 0;
+    if (const char* v = getenv("PG_K2_OPT")) k2opt = atoi(v);
     bool ks = true;                                                       // the instantiations for K = 31 / 63 / 127 (PG_K2_KS=0: the general kernel)
     if (const char* v = getenv("PG_K2_KS")) ks = atoi(v) != 0;
     if (dbg) ks = false;
@@ -1281,22 +1332,27 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
         const OccConst oc = occ_const(c->K, c->NW);
         // cfg 2: 512-slot set, 256 lanes, 128-record windows -> ~38 KB LDS, four workgroups per CU (meant for 4x the partitions)
         if (c->NW == 2) {
-            if (cfg == 0 && (dbg & 2)) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, true, 4>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
-            else if (cfg == 0 && vt == 4 && ks && c->K == 63) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 4, 63>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
-            else if (cfg == 0 && vt == 4 && ks && c->K == 31) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 4, 31>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
-            else if (cfg == 0 && vt == 4) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 4>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
-            else if (cfg == 0 && vt == 2) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 2>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
-            else if (cfg == 0) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
-            else if (cfg == 1) hipLaunchKernelGGL((skm_count_kernel<2, 1024, 512, 256, false>), dim3(grid), dim3(512), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
-            else hipLaunchKernelGGL((skm_count_kernel<2, 512, 256, 128, false>), dim3(grid * 2), dim3(256), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
+            if (cfg == 0 && (dbg & 2)) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, true, 4>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
+            else if (cfg == 0 && vt == 0 && ks && c->K == 63) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 0, 63>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
+            else if (cfg == 0 && vt == 0 && ks && c->K == 31) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 0, 31>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
+            else if (cfg == 0 && vt == 0) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 0>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
+            else if (cfg == 0 && vt == 4 && ks && c->K == 63) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 4, 63>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
+            else if (cfg == 0 && vt == 4 && ks && c->K == 31) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 4, 31>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
+            else if (cfg == 0 && vt == 4) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 4>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
+            else if (cfg == 0 && vt == 2) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 2>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
+            else if (cfg == 0) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
+            else if (cfg == 1) hipLaunchKernelGGL((skm_count_kernel<2, 1024, 512, 256, false>), dim3(grid), dim3(512), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
+            else hipLaunchKernelGGL((skm_count_kernel<2, 512, 256, 128, false>), dim3(grid * 2), dim3(256), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
         } else {
-            if (cfg == 0 && (dbg & 2)) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, true, 4>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
-            else if (cfg == 0 && vt == 4 && ks && c->K == 127) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false, 4, 127>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
-            else if (cfg == 0 && vt == 4) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false, 4>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
-            else if (cfg == 0 && vt == 2) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false, 2>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
-            else if (cfg == 0) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
-            else if (cfg == 1) hipLaunchKernelGGL((skm_count_kernel<4, 512, 512, 256, false>), dim3(grid), dim3(512), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
-            else hipLaunchKernelGGL((skm_count_kernel<4, 256, 256, 128, false>), dim3(grid * 2), dim3(256), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg);
+            if (cfg == 0 && (dbg & 2)) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, true, 4>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
+            else if (cfg == 0 && vt == 0 && ks && c->K == 127) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false, 0, 127>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
+            else if (cfg == 0 && vt == 0) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false, 0>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
+            else if (cfg == 0 && vt == 4 && ks && c->K == 127) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false, 4, 127>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
+            else if (cfg == 0 && vt == 4) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false, 4>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
+            else if (cfg == 0 && vt == 2) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false, 2>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
+            else if (cfg == 0) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
+            else if (cfg == 1) hipLaunchKernelGGL((skm_count_kernel<4, 512, 512, 256, false>), dim3(grid), dim3(512), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
+            else hipLaunchKernelGGL((skm_count_kernel<4, 256, 256, 128, false>), dim3(grid * 2), dim3(256), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
         }
     }
     E2_TRY(hipGetLastError());
