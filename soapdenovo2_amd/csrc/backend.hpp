@@ -81,6 +81,22 @@ struct HostBackend {
     template <typename T> void copy(T* dst, const T* src, size_t n) { if (n) memmove((void*)dst, (const void*)src, n * sizeof(T)); }
     void sync() {}
 
+    // ---- places: where the k-mer sets live.  A sharded run keeps set s on the GPU of the rank that owns it; the steps that look at
+    // one set at a time (the scans over all slots) run at the set's place, with their own lists and counters there, and hand the
+    // lead a gathered result.  On the host every place is this memory; `places` > 1 only makes the CPU tests walk the same
+    // bookkeeping (per-place lists, gathers) the sharded device run walks.
+    int places = 1;
+    int n_places() const { return places; }
+    int place_of_set(int s) const { return s % places; }
+    template <typename T> T* alloc_at(int, size_t n) { return alloc<T>(n); }
+    void release_at(int, void* p) { release(p); }
+    template <typename T> void fill_at(int, T* p, size_t n, T v) { fill(p, n, v); }
+    template <typename T> void to_host_at(int, T* dst, const T* src, size_t n) { to_host(dst, src, n); }
+    template <typename T> void gather_at(int, T* dst_lead, const T* src_place, size_t n) { copy(dst_lead, src_place, n); }
+    template <typename F> void launch_at(int, uint64_t n, F f) { launch(n, f); }
+    void sync_places() {}
+    uint64_t launches_at[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // (kept for symmetry with the device backend's per-place launch counts)
+
     // f(i) for every i in [0, n): thread t takes i = t, t + T, t + 2T, ... so that neighbouring indices run concurrently,
     // as the lanes of a wavefront do
     template <typename F> void launch(uint64_t n, F f) {

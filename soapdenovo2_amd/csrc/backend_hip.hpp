@@ -8,6 +8,7 @@
 #include <time.h>
 
 #include <string>
+#include <vector>
 
 #include "backend.hpp"
 #include "../../include/soapdenovo2_amd.h"
@@ -38,7 +39,59 @@ struct HipBackend {
     unsigned long long n_readback = 0;
     HipBackend(int device_, hipStream_t stream_) : device(device_), stream(stream_) {
         (void)hipSetDevice(device);
-        if (hipHostMalloc(&pinned, 256, hipHostMallocDefault) != hipSuccess) pinned = nullptr;
+        if (hipHostMalloc(&pinned, 256, hipHostMallocPortable) != hipSuccess) pinned = nullptr;
+    }
+    // ---- places (backend.hpp): place p = a device of this process with a stream of its own; set s lives at set_place[s].  Empty:
+    // one place, the lead itself.  A step launched at a place runs on that GPU, on memory allocated there; the caller orders it
+    // against the lead's stream with sync() / sync_places() (kernel boundaries are also where writes through a peer mapping become
+    // visible to the memory's owner).
+    struct Place { int device; hipStream_t stream; };
+    std::vector<Place> place;
+    std::vector<int> set_place;
+    std::vector<uint64_t> launches_at;            // launches per place, for the verbose lines and the tests
+    void use_places(const std::vector<Place>& pl, const std::vector<int>& of_set) { place = pl; set_place = of_set; launches_at.assign(pl.size(), 0); }
+    int n_places() const { return place.empty() ? 1 : (int)place.size(); }
+    int place_of_set(int s) const { return place.empty() || s >= (int)set_place.size() ? 0 : set_place[s]; }
+    int dev_at(int pl) const { return place.empty() ? device : place[pl].device; }
+    hipStream_t stream_at(int pl) const { return place.empty() ? stream : place[pl].stream; }
+    template <typename T> T* alloc_at(int pl, size_t n) {
+        void* p = nullptr;
+        (void)hipSetDevice(dev_at(pl));
+        const bool good = ok(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)), "hipMalloc (at a place)");
+        (void)hipSetDevice(device);
+        return good ? (T*)p : nullptr;
+    }
+    void release_at(int pl, void* p) { if (p) { (void)hipSetDevice(dev_at(pl)); (void)hipFree(p); (void)hipSetDevice(device); } }
+    template <typename T> void fill_at(int pl, T* p, size_t n, T v) {
+        if (!n || error) return;
+        (void)hipSetDevice(dev_at(pl));
+        const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 1u << 16);
+        hipLaunchKernelGGL(be_fill_kernel<T>, dim3(grid), dim3(256), 0, stream_at(pl), p, (uint64_t)n, v);
+        ok(hipGetLastError(), "fill (at a place)");
+        (void)hipSetDevice(device);
+    }
+    template <typename T> void to_host_at(int pl, T* dst, const T* src, size_t n) {
+        if (!n || error) return;
+        (void)hipSetDevice(dev_at(pl));
+        if (ok(hipMemcpyAsync((void*)dst, (const void*)src, n * sizeof(T), hipMemcpyDeviceToHost, stream_at(pl)), "copy to host (from a place)")) ok(hipStreamSynchronize(stream_at(pl)), "sync");
+        (void)hipSetDevice(device);
+    }
+    // what a place listed, into the lead's memory (a peer copy on the lead's stream; the place's stream has been waited for)
+    template <typename T> void gather_at(int, T* dst_lead, const T* src_place, size_t n) {
+        if (n && !error) ok(hipMemcpyAsync((void*)dst_lead, (const void*)src_place, n * sizeof(T), hipMemcpyDefault, stream), "gather from a place");
+    }
+    template <typename F> void launch_at(int pl, uint64_t n, F f) {
+        if (!n || error) return;
+        (void)hipSetDevice(dev_at(pl));
+        const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 1u << 20);
+        hipLaunchKernelGGL(be_launch_kernel<F>, dim3(grid), dim3(256), 0, stream_at(pl), n, f);
+        ok(hipGetLastError(), "launch (at a place)");
+        if (pl < (int)launches_at.size()) launches_at[pl]++;
+        (void)hipSetDevice(device);
+    }
+    void sync_places() {
+        for (int pl = 0; pl < n_places() && !error; pl++) { (void)hipSetDevice(dev_at(pl)); ok(hipStreamSynchronize(stream_at(pl)), "sync (a place)"); }
+        (void)hipSetDevice(device);
     }
     HipBackend(const HipBackend&) = delete;
     HipBackend& operator=(const HipBackend&) = delete;

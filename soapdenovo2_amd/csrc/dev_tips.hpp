@@ -243,25 +243,29 @@ struct SetsGeo {
     uint64_t n_slots() const { return P ? first[P - 1] + size[P - 1] : 0; }
 };
 
-// f(node address, global slot) for every slot of every set: one launch per set, lane = slot
+// f(node address, global slot) for every slot of every set: one launch per set, lane = slot, AT THE SET'S PLACE (the GPU that
+// holds it: the reference gives every set one owner for its scans too, cutTipPreGraph.c:603-639).  The caller has waited for
+// the lead's stream (be.sync()) and waits for the places afterwards (be.sync_places()).
 template <class BE, int NW, class F>
 void for_each_slot(BE& be, const SetsGeo& geo, F f) {
     for (int s = 0; s < geo.P; s++) {
         uint64_t* base = geo.base[s];
         const uint64_t first = geo.first[s];
-        be.launch(geo.size[s], [=] PG_LAMBDA(uint64_t i) { f(base + i * (NW + 1), first + i); });
+        be.launch_at(be.place_of_set(s), geo.size[s], [=] PG_LAMBDA(uint64_t i) { f(base + i * (NW + 1), first + i); });
     }
 }
 
 // Mark1in1outNode (cutTipPreGraph.c:532-564): a live non-linear node with one arc each way becomes linear
 template <class BE, int NW>
 void remark_linear(BE& be, const SetsGeo& geo) {
+    be.sync();
     for_each_slot<BE, NW>(be, geo, [=] PG_LAMBDA(uint64_t* nd, uint64_t) {
         if (nd[0] == SV_EMPTY) return;
         const uint64_t ab = nd[NW];
         if (ab_flag(ab, B_DELETED | B_LINEAR)) return;
         if (ab_in(ab) == 1 && ab_out(ab) == 1) nd[NW] = ab | ((uint64_t)B_LINEAR << 32);
     });
+    be.sync_places();
 }
 
 // One scan of removeSingleTips (thin) / removeMinorTips over all sets.  Returns PG_OK or PG_E*; *removed = tips clipped,
@@ -273,29 +277,66 @@ int tip_scan(BE& be, const SetsView& view, const SetsGeo& geo, int cut_len, bool
     const uint64_t n_slots = geo.n_slots();
     unsigned long long* counters = be.template alloc<unsigned long long>(12);
     be.fill(counters, 12, 0ULL);
-    // ---- S0's dead ends: one scan over the sets lists them (room for one slot in eight, a second scan with the exact room
-    //      should that ever be short)
+    // ---- S0's dead ends: one scan over the sets lists them -- every set at its place, into a list and a counter of that place
+    //      (room for one slot in eight, a second scan with the exact room should that ever be short); the lead gathers the lists
     unsigned long long h_cnt[12];
-    uint64_t list_cap = n_slots / 8 + 65536;
+    for (int q = 0; q < 12; q++) h_cnt[q] = 0;
     unsigned long long* cand_list = nullptr;
-    for (int attempt = 0; attempt < 2; attempt++) {
-        cand_list = be.template alloc<unsigned long long>(list_cap);
-        be.fill(counters, 12, 0ULL);
-        const uint64_t cap_now = list_cap;
-        unsigned long long* const list_now = cand_list;
-        for_each_slot<BE, NW>(be, geo, [=] PG_LAMBDA(uint64_t* nd, uint64_t g) {
-            if (nd[0] == SV_EMPTY) return;
-            const uint64_t ab = nd[NW];
-            if (!(ab_startable(ab, thin) && ab_dead_end(ab))) return;
-            const unsigned long long i = hd_atomic_add(&counters[0], 1ULL);
-            if (i < cap_now) list_now[i] = g;
-        });
-        be.to_host(h_cnt, counters, 12);
-        if (be.error) { be.release(cand_list); be.release(counters); return be.error; }
-        if (h_cnt[0] <= list_cap) break;
-        be.release(cand_list);
-        cand_list = nullptr;
-        list_cap = h_cnt[0];
+    {
+        const int NPL = be.n_places();
+        std::vector<uint64_t> pl_slots(NPL, 0), pl_cap(NPL, 0), pl_n(NPL, 0);
+        std::vector<unsigned long long*> pl_list(NPL, nullptr), pl_cnt(NPL, nullptr);
+        for (int s = 0; s < geo.P; s++) pl_slots[be.place_of_set(s)] += geo.size[s];
+        for (int pl = 0; pl < NPL; pl++) { pl_cap[pl] = pl_slots[pl] / 8 + 65536; pl_cnt[pl] = be.template alloc_at<unsigned long long>(pl, 1); }
+        be.sync();                                                   // what the lead wrote into the sets so far is in place
+        for (int attempt = 0; attempt < 2 && !be.error; attempt++) {
+            bool short_of_room = false;
+            for (int pl = 0; pl < NPL; pl++) {
+                if (pl_list[pl]) continue;                               // (listed completely in the first attempt)
+                pl_list[pl] = be.template alloc_at<unsigned long long>(pl, pl_cap[pl]);
+                be.fill_at(pl, pl_cnt[pl], 1, 0ULL);
+            }
+            for (int s = 0; s < geo.P && !be.error; s++) {
+                const int pl = be.place_of_set(s);
+                if (pl_n[pl]) continue;
+                uint64_t* base = geo.base[s];
+                const uint64_t first = geo.first[s], cap_now = pl_cap[pl];
+                unsigned long long* const list_now = pl_list[pl];
+                unsigned long long* const cnt_now = pl_cnt[pl];
+                be.launch_at(pl, geo.size[s], [=] PG_LAMBDA(uint64_t i) {
+                    const uint64_t* nd = base + i * (NW + 1);
+                    if (nd[0] == SV_EMPTY) return;
+                    const uint64_t ab = nd[NW];
+                    if (!(ab_startable(ab, thin) && ab_dead_end(ab))) return;
+                    const unsigned long long j = hd_atomic_add(cnt_now, 1ULL);
+                    if (j < cap_now) list_now[j] = first + i;
+                });
+            }
+            for (int pl = 0; pl < NPL && !be.error; pl++) {
+                if (pl_n[pl]) continue;
+                unsigned long long got = 0;
+                be.to_host_at(pl, &got, pl_cnt[pl], 1);
+                if (got > pl_cap[pl]) { be.release_at(pl, pl_list[pl]); pl_list[pl] = nullptr; pl_cap[pl] = got; short_of_room = true; }
+                else pl_n[pl] = got ? got : ~0ULL;                      // (~0: listed, nothing found)
+            }
+            if (!short_of_room) break;
+        }
+        uint64_t total = 0;
+        bool complete = !be.error;
+        for (int pl = 0; pl < NPL; pl++) { if (!pl_n[pl]) complete = false; else if (pl_n[pl] != ~0ULL) total += pl_n[pl]; }
+        if (complete && total) {
+            cand_list = be.template alloc<unsigned long long>(total);
+            uint64_t at = 0;
+            for (int pl = 0; pl < NPL && cand_list; pl++) {
+                if (pl_n[pl] == ~0ULL) continue;
+                be.gather_at(pl, cand_list + at, pl_list[pl], pl_n[pl]);
+                at += pl_n[pl];
+            }
+            be.sync();
+        }
+        for (int pl = 0; pl < NPL; pl++) { be.release_at(pl, pl_list[pl]); be.release_at(pl, pl_cnt[pl]); }
+        if (be.error || !complete) { be.release(cand_list); be.release(counters); return be.error ? be.error : PG_ENOMEM; }
+        h_cnt[0] = total;
     }
     const uint64_t n_init = h_cnt[0];
     if (!n_init || !cand_list) { be.release(cand_list); be.release(counters); return n_init ? PG_ENOMEM : PG_OK; }

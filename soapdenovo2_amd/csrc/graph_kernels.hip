@@ -276,20 +276,23 @@ __global__ __launch_bounds__(256) void p2_thread_kernel(P2Params p, const uint64
     }
     atomicAdd(&p.counters[4], (unsigned long long)upto);
 }
-// probes a lane keeps in flight (SOAPDENOVO2_AMD_P2_BLOCK = 1: one at a time, for A/B runs)
-static int p2_block() { static const int v = [] { const char* e = getenv("SOAPDENOVO2_AMD_P2_BLOCK"); return e ? atoi(e) : 0; }(); return v; }
+// probes a lane keeps in flight (SOAPDENOVO2_AMD_P2_BLOCK).  Measured at 60 M reads (profiles/r04a_p2_block_ab.csv): 1 -> 222.7 ms, 4 -> 230.9 ms,
+// 8 -> 304.9 ms (round 3's kernel: 272.6 ms).  One probe a lane with 58 registers (eight waves a SIMD) already keeps the memory
+// system at the rate it serves random lines at -- 23.7 G lookups/s x ~1.6 lines a lookup (a 24-byte slot straddles two 64-byte
+// lines one time in four, a lookup probes 1.75 slots on average) = 38 G lines/s, the ceiling profiles/r01_membench_random_access.log
+// measured -- so more probes a lane only cost registers, i.e. waves.  What the round bought came from the sliced CRC and the reciprocal.
+static int p2_block() { static const int v = [] { const char* e = getenv("SOAPDENOVO2_AMD_P2_BLOCK"); return e ? atoi(e) : 1; }(); return v; }
 static void p2_launch_thread_kernel(int nw, dim3 grid, hipStream_t st, const P2Params& p, const uint64_t* words, const uint64_t* word_off, const int32_t* lens,
                                     uint64_t n_reads, uint64_t first_ordinal, int uniform_len) {
     const int bl = p2_block();
     const dim3 block(256);
     if (nw == 2) {
-        if (bl == 1) hipLaunchKernelGGL((p2_thread_kernel<2, 1>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len);
+        if (bl == 8) hipLaunchKernelGGL((p2_thread_kernel<2, 8>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len);
         else if (bl == 4) hipLaunchKernelGGL((p2_thread_kernel<2, 4>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len);
-        else hipLaunchKernelGGL((p2_thread_kernel<2, 8>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len);
+        else hipLaunchKernelGGL((p2_thread_kernel<2, 1>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len);
     } else {
-        if (bl == 1) hipLaunchKernelGGL((p2_thread_kernel<4, 1>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len);
-        else if (bl == 8) hipLaunchKernelGGL((p2_thread_kernel<4, 8>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len);
-        else hipLaunchKernelGGL((p2_thread_kernel<4, 4>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len);
+        if (bl == 4) hipLaunchKernelGGL((p2_thread_kernel<4, 4>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len);
+        else hipLaunchKernelGGL((p2_thread_kernel<4, 1>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len);
     }
 }
 

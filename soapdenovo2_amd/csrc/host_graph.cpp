@@ -2654,6 +2654,7 @@ static int emu_clip_tips(const uint64_t* records, uint64_t n, const uint64_t* se
     }
     SetsView view{geo_words.data(), host_crc_table(), (uint32_t)P, set_bias((uint32_t)P), K};
     HostBackend be(n_threads);
+    if (const char* e = getenv("PG_EMU_PLACES")) be.places = std::max(1, atoi(e));     // the per-place lists and gathers of a sharded run, on one memory
     TipTotals tot;
     rc = clip_tips<HostBackend, NW>(be, view, geo, cut_single != 0, tot);
     if (rc) { pg_set_error(be.error_text.empty() ? "emulated tip clipping failed" : be.error_text); return rc; }

@@ -1317,11 +1317,12 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     unsigned per_cu = 2;                                                            // persistent workgroups: two per CU measured best (1 .. 32 tried; every start of a workgroup builds its tables and wipes the set)
     if (const char* v = getenv("PG_K2_WG_PER_CU")) per_cu = (unsigned)std::max(1, atoi(v));
     const unsigned grid = std::min<unsigned>(parts, (unsigned)n_cu * per_cu);
-    int dbg = 0, cfg = 0, vt = 4;                                         // tiles of virtual lanes taken dynamically: K2 177.8 -> 168.7 ms at K = 63, 269 -> 232 ms at K = 127 (profiles/r03h_*)
-    if (const char* v = getenv("PG_K2_VT")) vt = atoi(v);                 // 1 = static shares (round 2), 2 / 4 = tiles
+    int dbg = 0, cfg = 0, vt = 0;                                         // 0 = occurrences dealt 64 at a time, representative by population count over start bits (round 4:
+                                                                          // K2 162.9 -> 154.3 ms at K = 63, profiles/r04a_k2_vt0_opt1_ab.json)
+    if (const char* v = getenv("PG_K2_VT")) vt = atoi(v);                 // 1 = static shares (round 2), 2 / 4 = tiles of virtual lanes with a share table (round 3: 177.8 -> 168.7 ms)
     if (const char* v = getenv("PG_DBG")) dbg = atoi(v);
     if (const char* v = getenv("PG_K2CFG")) cfg = atoi(v);
-    int k2opt = 0;
+    int k2opt = 1;                                                        // bit 0: live slots listed in any order (162.9 -> 157.0 ms; with vt = 0: 148.9 ms)
     if (const char* v = getenv("PG_K2_OPT")) k2opt = atoi(v);
     bool ks = true;                                                       // the instantiations for K = 31 / 63 / 127 (PG_K2_KS=0: the general kernel)
     if (const char* v = getenv("PG_K2_KS")) ks = atoi(v) != 0;
@@ -1332,7 +1333,8 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
         const OccConst oc = occ_const(c->K, c->NW);
         // cfg 2: 512-slot set, 256 lanes, 128-record windows -> ~38 KB LDS, four workgroups per CU (meant for 4x the partitions)
         if (c->NW == 2) {
-            if (cfg == 0 && (dbg & 2)) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, true, 4>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
+            if (cfg == 0 && (dbg & 2) && vt == 0) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, true, 0>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
+            else if (cfg == 0 && (dbg & 2)) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, true, 4>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
             else if (cfg == 0 && vt == 0 && ks && c->K == 63) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 0, 63>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
             else if (cfg == 0 && vt == 0 && ks && c->K == 31) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 0, 31>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
             else if (cfg == 0 && vt == 0) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 0>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
@@ -1344,7 +1346,8 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
             else if (cfg == 1) hipLaunchKernelGGL((skm_count_kernel<2, 1024, 512, 256, false>), dim3(grid), dim3(512), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
             else hipLaunchKernelGGL((skm_count_kernel<2, 512, 256, 128, false>), dim3(grid * 2), dim3(256), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
         } else {
-            if (cfg == 0 && (dbg & 2)) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, true, 4>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
+            if (cfg == 0 && (dbg & 2) && vt == 0) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, true, 0>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
+            else if (cfg == 0 && (dbg & 2)) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, true, 4>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
             else if (cfg == 0 && vt == 0 && ks && c->K == 127) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false, 0, 127>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
             else if (cfg == 0 && vt == 0) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false, 0>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
             else if (cfg == 0 && vt == 4 && ks && c->K == 127) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false, 4, 127>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);

@@ -107,12 +107,14 @@ def test_layout_static_equals_the_host_replay_on_golden_cases(golden, tmp_path, 
     assert int((out[:, 0] != EMPTY).sum()) == len(rec)
 
 
-@pytest.mark.parametrize("threads", [1, 5])
+@pytest.mark.parametrize("threads,places", [(1, 1), (5, 1), (5, 3)])
 @pytest.mark.parametrize("name", ["t6k_k31", "t8k_k63", "t6k_k127", "t5k_k24", "m60k_k63", "d8k_k127", "r8k_k127", "d8k_k63", "m100k_k31"])
-def test_device_tip_decisions_equal_the_sequential_scan(golden, tmp_path, name, threads):
+def test_device_tip_decisions_equal_the_sequential_scan(golden, tmp_path, name, threads, places, monkeypatch):
     """removeSingleTips / removeMinorTips as the device decides them (dev_tips.hpp on the HostBackend: the fixed point over start
     decisions) against the sequential slot-order scan (Graph::tip_scan, pinned on the reference's files by tests/test_host_graph.py):
-    the same tips, and afterwards the same counter words in every node."""
+    the same tips, and afterwards the same counter words in every node.  places = 3: the scans over the sets run "where the set
+    lives" with a list and a counter per place that the lead gathers, as in a sharded run (backend.hpp)."""
+    monkeypatch.setenv("PG_EMU_PLACES", str(places))
     c = golden["cases"][name]
     codes = case_codes(c)
     for run in c["runs"]:
