@@ -976,7 +976,8 @@ int run(int argc, char** argv, bool mer127) {
         fprintf(stderr, "%lld read(s) processed.\n", n_records);
     } else if (have_kept) {
         fprintf(stderr, "In file: %s, max seq len %d, max name len %d.\n", o.config.c_str(), max_read_len, 256);
-        const uint64_t step = (uint64_t)1 << 22;
+        // a pass-2 batch: what a pass-1 batch was (a sharded graph deals them to its lanes in turn, graph_kernels.hip: P2Lane)
+        const uint64_t step = std::min<uint64_t>((uint64_t)1 << 22, (uint64_t)batch_reads);
         for (const KeptReads::Block& kb : kept.blocks) {
             const uint64_t total = kb.lens.size();
             uint64_t word_at = 0;

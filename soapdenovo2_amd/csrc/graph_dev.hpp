@@ -21,6 +21,7 @@ struct P2Result {
     std::vector<P2Arc> arcs;
     std::vector<unsigned int> marker;                             // per edge id, unsaturated (-R only)
     long long reads_deleted = 0, markers = 0;
+    int lanes = 1;                                                // > 1: a (from, to) pair may come from several lanes -- merge by sum and minimum
 };
 
 // one edge record as the device built it, in the reference's order (the host formats output_1edge's text from it)
@@ -88,7 +89,10 @@ void p2_destroy(P2Device* d);
 // max_nk ids (walks_out) with their lengths (walk_len_out, 0 = the read has no recorded walk)
 int p2_add_packed(P2Device* d, const uint64_t* words, const uint64_t* word_off, const int32_t* lens, uint64_t n_reads, uint64_t n_words,
                   uint32_t* walks_out, uint16_t* walk_len_out);
-int p2_add_packed_device(P2Device* d, const uint64_t* d_words, uint64_t n_reads, int read_len);      // reads already on the lead device, one length, back to back
+int p2_add_packed_device(P2Device* d, const uint64_t* d_words, uint64_t n_reads, int read_len, int device);   // reads already on a lane's device, one length, back to back
+// the ranks of a sharded run (lane 0 = the lead's device): the per-set scans run on the owner's lane (set s -> lane s mod n_lanes),
+// pass 2 deals its read batches to the lanes in turn, each with a pre-arc table of its own
+int p2_use_lanes(P2Device* d, const int* lane_devices, int n_lanes);
 int p2_finish(P2Device* d, P2Result& out);
 
 }  // namespace pg

@@ -585,8 +585,38 @@ __global__ void p2_fill_u64(unsigned long long* a, uint64_t n, unsigned long lon
 // The graph on the device.  Kernels are launched on `device` (the lead rank's GPU); the k-mer sets may be spread over
 // several GPUs of the process -- set s on set_dev[s], reached from the lead through peer mappings (xGMI) -- which is how
 // the sharded run keeps every rank at its share of the sets ("reference set id -> GPU").
+// One lane of the graph stages = one rank of a sharded run: a GPU of the process with a stream of its own.  The scans over the
+// slots of a set run on the lane that owns the set (set s -> lane s mod n_lanes, the rank that laid it out; the reference gives
+// every set one owner for its scans as well, prlHashReads.c:79-90, cutTipPreGraph.c:603-639), and pass 2 deals its read batches
+// to the lanes in turn (every read has one worker, prlRead2path.c:248), each lane with its own pre-arc table, counters and
+// batch buffers against the peer-mapped sets.  A pre-arc list is a multiplicity and a first-met order (prlRead2path.c:388-403):
+// the lanes' tables merge by sum and minimum.  Lane 0 is the lead (its tables are the P2Device's own).
+struct P2Lane {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool tables = false;                             // the pass-2 tables below exist
+    P2Params prm;
+    uint64_t* d_geo3 = nullptr;                      // copies on this lane's device (lane 0 and lanes on the lead's device: the lead's own)
+    uint64_t* d_patch_keys = nullptr;
+    uint32_t* d_patch_val = nullptr;
+    bool own_geo = false, own_patch = false;
+    unsigned long long* d_arc_key = nullptr;
+    unsigned int* d_arc_cnt = nullptr;
+    unsigned long long* d_arc_first = nullptr;
+    unsigned long long* d_counters = nullptr;
+    unsigned int* d_marker = nullptr;
+    uint64_t* d_words = nullptr; size_t cap_words = 0;
+    uint64_t* d_off = nullptr; int32_t* d_lens = nullptr; size_t cap_reads = 0;
+    uint32_t* d_stage = nullptr; uint16_t* d_walk_len = nullptr; size_t cap_stage_reads = 0;
+    hipEvent_t copied = nullptr;
+    uint64_t reads = 0, batches = 0, scans = 0;      // what the lane did (PG_HOST_VERBOSE; asserted by the sharded tests)
+};
+
 struct P2Device {
     int device = 0, K = 0, nw = 2, P = 1, max_nk = 0;
+    std::vector<P2Lane> lanes;                       // lanes[0] = the lead
+    std::vector<int> set_lane;                       // the lane that owns set s
+    unsigned next_lane = 0;
     bool reps = false;
     uint32_t num_ed = 0;
     P2Params prm;
@@ -598,15 +628,7 @@ struct P2Device {
     uint32_t* d_crc = nullptr;                       // CRC-32 byte table for the lookups of the backend-generic stages
     uint64_t* d_patch_keys = nullptr;
     uint32_t* d_patch_val = nullptr;
-    unsigned long long* d_arc_key = nullptr;
-    unsigned int* d_arc_cnt = nullptr;
-    unsigned long long* d_arc_first = nullptr;
-    unsigned long long* d_counters = nullptr;
-    unsigned int* d_marker = nullptr;
-    // batch buffers (grown on demand)
-    uint64_t* d_words = nullptr; size_t cap_words = 0;
-    uint64_t* d_off = nullptr; int32_t* d_lens = nullptr; size_t cap_reads = 0;
-    uint32_t* d_stage = nullptr; uint16_t* d_walk_len = nullptr; size_t cap_stage_reads = 0;
+    unsigned long long* d_counters = nullptr;        // the lead's counters of the stages in front of pass 2
     uint64_t ordinal = 0;
     uint64_t n_slots = 0;
     bool reads_ready = false;
@@ -619,11 +641,21 @@ namespace { void forget_taken(void* ptr); }       // (the offered-block bookkeep
 static void p2_free(P2Device* d) {
     if (!d) return;
     for (auto& o : d->owned) { forget_taken(o.second); (void)hipSetDevice(o.first); (void)hipFree(o.second); }
+    for (size_t l = 0; l < d->lanes.size(); l++) {
+        P2Lane& ln = d->lanes[l];
+        (void)hipSetDevice(ln.device);
+        if (ln.own_geo) hipFree(ln.d_geo3);
+        if (ln.own_patch) { hipFree(ln.d_patch_keys); hipFree(ln.d_patch_val); }
+        hipFree(ln.d_arc_key); hipFree(ln.d_arc_cnt); hipFree(ln.d_arc_first);
+        if (l) hipFree(ln.d_counters);
+        hipFree(ln.d_marker);
+        hipFree(ln.d_words); hipFree(ln.d_off); hipFree(ln.d_lens); hipFree(ln.d_stage); hipFree(ln.d_walk_len);
+        if (ln.copied) (void)hipEventDestroy(ln.copied);
+        if (l && ln.stream) (void)hipStreamDestroy(ln.stream);
+    }
     hipSetDevice(d->device);
     hipFree(d->d_patch_keys); hipFree(d->d_patch_val);
-    hipFree(d->d_arc_key); hipFree(d->d_arc_cnt); hipFree(d->d_arc_first);
-    hipFree(d->d_counters); hipFree(d->d_marker);
-    hipFree(d->d_words); hipFree(d->d_off); hipFree(d->d_lens); hipFree(d->d_stage); hipFree(d->d_walk_len);
+    hipFree(d->d_counters);
     hipFree(d->d_geo3); hipFree(d->d_crc); hipFree(d->d_vlist);
     if (d->stream) hipStreamDestroy(d->stream);
     delete d;
@@ -668,6 +700,45 @@ static int p2_finish_open(P2Device* d) {
     p.P = (uint32_t)d->P; p.bias = set_bias((uint32_t)d->P); p.K = d->K;
     p.max_nk = d->max_nk;
     p.counters = d->d_counters;
+    // one lane until the caller names the ranks (p2_use_lanes)
+    d->lanes.assign(1, P2Lane());
+    d->lanes[0].device = d->device; d->lanes[0].stream = d->stream;
+    d->set_lane.assign(d->P, 0);
+    return PG_OK;
+}
+
+// the two devices can map each other's memory, and `from` has done so
+static int p2_peer(int from, int to) {
+    if (from == to) return PG_OK;
+    int can = 0;
+    if (hipDeviceCanAccessPeer(&can, from, to) != hipSuccess || !can) { pg_set_error("the GPUs of the sharded graph cannot map each other's memory"); return PG_ENODEV; }
+    P2_HIP(hipSetDevice(from));
+    const hipError_t e = hipDeviceEnablePeerAccess(to, 0);
+    (void)hipGetLastError();
+    if (e != hipSuccess && e != hipErrorPeerAccessAlreadyEnabled) { pg_set_error(std::string("hipDeviceEnablePeerAccess: ") + hipGetErrorString(e)); return PG_ENODEV; }
+    return PG_OK;
+}
+// The ranks of a sharded run, lane 0 = the lead's device: from here on the per-set scans run on the owner's lane and pass 2 deals
+// its batches to all of them.  Every lane maps every set's device (it probes all sets) and the lead maps every lane (it gathers
+// their lists).  Ranks may share a device (test set-ups on one GPU): they are lanes of their own all the same.
+int p2_use_lanes(P2Device* d, const int* lane_devices, int n_lanes) {
+    if (n_lanes < 1 || !lane_devices || lane_devices[0] != d->device) { pg_set_error("graph lanes: lane 0 is the lead device"); return PG_EINVAL; }
+    if (d->lanes.size() != 1 || d->reads_ready) { pg_set_error("graph lanes: already set"); return PG_ESTATE; }
+    for (int l = 1; l < n_lanes; l++) {
+        P2Lane ln;
+        ln.device = lane_devices[l];
+        P2_HIP(hipSetDevice(ln.device));
+        P2_HIP(hipStreamCreateWithFlags(&ln.stream, hipStreamNonBlocking));
+        d->lanes.push_back(ln);
+    }
+    for (int l = 0; l < n_lanes; l++) {
+        for (int s = 0; s < d->P; s++) { const int rc = p2_peer(lane_devices[l], d->set_dev[s]); if (rc) return rc; }
+        int rc = p2_peer(d->device, lane_devices[l]);
+        if (!rc) rc = p2_peer(lane_devices[l], d->device);
+        if (rc) return rc;
+    }
+    for (int s = 0; s < d->P; s++) d->set_lane[s] = s % n_lanes;
+    P2_HIP(hipSetDevice(d->device));
     return PG_OK;
 }
 
@@ -1013,7 +1084,8 @@ int p2_set_patch(P2Device* d, const uint64_t* patch_keys, const uint32_t* patch_
     return PG_OK;
 }
 
-// the pre-arc table and, with -R, the marker counts
+// the pre-arc table and, with -R, the marker counts: one of each per lane; lanes on another device than the lead's get their own
+// copy of the set geometry and of the (K+1)-mer table (a few MB: every probe of them would otherwise cross xGMI)
 int p2_begin_reads(P2Device* d, uint32_t num_ed, bool reps) {
     P2_HIP(hipSetDevice(d->device));
     if (!d->d_patch_val) { pg_set_error("pass 2: no (K+1)-mer table yet"); return PG_ESTATE; }
@@ -1021,21 +1093,44 @@ int p2_begin_reads(P2Device* d, uint32_t num_ed, bool reps) {
     // every edge has a handful of successors: eight slots an edge id keep the load low; the kernel counts overflows
     uint64_t arc_cap = 1 << 16;
     while (arc_cap < (uint64_t)d->num_ed * 8) arc_cap <<= 1;
-    P2_HIP(hipMalloc((void**)&d->d_arc_key, arc_cap * sizeof(unsigned long long)));
-    P2_HIP(hipMalloc((void**)&d->d_arc_cnt, arc_cap * sizeof(unsigned int)));
-    P2_HIP(hipMalloc((void**)&d->d_arc_first, arc_cap * sizeof(unsigned long long)));
-    P2_HIP(hipMemsetAsync(d->d_arc_key, 0, arc_cap * sizeof(unsigned long long), d->stream));
-    P2_HIP(hipMemsetAsync(d->d_arc_cnt, 0, arc_cap * sizeof(unsigned int), d->stream));
-    hipLaunchKernelGGL(p2_fill_u64, dim3(1024), dim3(256), 0, d->stream, d->d_arc_first, arc_cap, ~0ULL);
-    P2_HIP(hipMemsetAsync(d->d_counters, 0, 8 * sizeof(unsigned long long), d->stream));
-    if (d->reps) {
-        P2_HIP(hipMalloc((void**)&d->d_marker, ((size_t)d->num_ed + 1) * sizeof(unsigned int)));
-        P2_HIP(hipMemsetAsync(d->d_marker, 0, ((size_t)d->num_ed + 1) * sizeof(unsigned int), d->stream));
+    const uint64_t patch_cap = d->prm.patch_mask + 1;
+    for (size_t l = 0; l < d->lanes.size(); l++) {
+        P2Lane& ln = d->lanes[l];
+        P2_HIP(hipSetDevice(ln.device));
+        ln.prm = d->prm;
+        if (ln.device != d->device) {
+            const size_t gb = (size_t)SV_GEO * d->P * sizeof(uint64_t), kb = patch_cap * d->nw * sizeof(uint64_t), vb = patch_cap * 2 * sizeof(uint32_t);
+            P2_HIP(hipMalloc((void**)&ln.d_geo3, gb)); ln.own_geo = true;
+            P2_HIP(hipMalloc((void**)&ln.d_patch_keys, kb)); ln.own_patch = true;
+            P2_HIP(hipMalloc((void**)&ln.d_patch_val, vb));
+            P2_HIP(hipMemcpyPeerAsync(ln.d_geo3, ln.device, d->d_geo3, d->device, gb, ln.stream));
+            P2_HIP(hipMemcpyPeerAsync(ln.d_patch_keys, ln.device, d->d_patch_keys, d->device, kb, ln.stream));
+            P2_HIP(hipMemcpyPeerAsync(ln.d_patch_val, ln.device, d->d_patch_val, d->device, vb, ln.stream));
+            ln.prm.geo3 = ln.d_geo3; ln.prm.patch_keys = ln.d_patch_keys; ln.prm.patch_val = ln.d_patch_val;
+        }
+        if (l == 0) ln.d_counters = d->d_counters;
+        else P2_HIP(hipMalloc((void**)&ln.d_counters, 8 * sizeof(unsigned long long)));
+        P2_HIP(hipMalloc((void**)&ln.d_arc_key, arc_cap * sizeof(unsigned long long)));
+        P2_HIP(hipMalloc((void**)&ln.d_arc_cnt, arc_cap * sizeof(unsigned int)));
+        P2_HIP(hipMalloc((void**)&ln.d_arc_first, arc_cap * sizeof(unsigned long long)));
+        P2_HIP(hipMemsetAsync(ln.d_arc_key, 0, arc_cap * sizeof(unsigned long long), ln.stream));
+        P2_HIP(hipMemsetAsync(ln.d_arc_cnt, 0, arc_cap * sizeof(unsigned int), ln.stream));
+        hipLaunchKernelGGL(p2_fill_u64, dim3(1024), dim3(256), 0, ln.stream, ln.d_arc_first, arc_cap, ~0ULL);
+        P2_HIP(hipMemsetAsync(ln.d_counters, 0, 8 * sizeof(unsigned long long), ln.stream));
+        if (d->reps) {
+            P2_HIP(hipMalloc((void**)&ln.d_marker, ((size_t)d->num_ed + 1) * sizeof(unsigned int)));
+            P2_HIP(hipMemsetAsync(ln.d_marker, 0, ((size_t)d->num_ed + 1) * sizeof(unsigned int), ln.stream));
+        }
+        P2_HIP(hipEventCreateWithFlags(&ln.copied, hipEventDisableTiming));
+        P2_HIP(hipStreamSynchronize(ln.stream));
+        P2Params& p = ln.prm;
+        p.counters = ln.d_counters;
+        p.arc_key = ln.d_arc_key; p.arc_cnt = ln.d_arc_cnt; p.arc_first = ln.d_arc_first; p.arc_mask = arc_cap - 1;
+        p.marker = ln.d_marker; p.id_end = d->num_ed + 1;
+        ln.tables = true;
     }
-    P2_HIP(hipStreamSynchronize(d->stream));
-    P2Params& p = d->prm;
-    p.arc_key = d->d_arc_key; p.arc_cnt = d->d_arc_cnt; p.arc_first = d->d_arc_first; p.arc_mask = arc_cap - 1;
-    p.marker = d->d_marker; p.id_end = d->num_ed + 1;
+    P2_HIP(hipSetDevice(d->device));
+    d->prm = d->lanes[0].prm;
     d->reads_ready = true;
     return PG_OK;
 }
@@ -1127,9 +1222,16 @@ int p2_mirror_nodes(P2Device* d, const uint64_t* slots, const uint64_t* ab, uint
 
 int p2_remark_linear(P2Device* d) {
     P2_HIP(hipSetDevice(d->device));
-    for (int si = 0; si < d->P; si++)
-        if (d->set_sizes[si]) hipLaunchKernelGGL(tip_remark, dim3(4096), dim3(256), 0, d->stream, d->set_ptr[si], d->nw + 1, d->set_sizes[si]);
     P2_HIP(hipStreamSynchronize(d->stream));
+    for (int si = 0; si < d->P; si++) {
+        if (!d->set_sizes[si]) continue;
+        P2Lane& ln = d->lanes[d->set_lane[si]];                      // every set on the lane that owns it
+        P2_HIP(hipSetDevice(ln.device));
+        hipLaunchKernelGGL(tip_remark, dim3(4096), dim3(256), 0, ln.stream, d->set_ptr[si], d->nw + 1, d->set_sizes[si]);
+        ln.scans++;
+    }
+    for (auto& ln : d->lanes) { P2_HIP(hipSetDevice(ln.device)); P2_HIP(hipStreamSynchronize(ln.stream)); }
+    P2_HIP(hipSetDevice(d->device));
     return PG_OK;
 }
 
@@ -1148,9 +1250,15 @@ int p2_clip_tips(P2Device* d, bool cut_single, P2TipTotals& out) {
     int rc = p2_sets_view(d, view, geo);
     if (rc) return rc;
     HipBackend be(d->device, d->stream);
+    if (d->lanes.size() > 1) {                                       // the scans over a set's slots run on the lane that owns the set
+        std::vector<HipBackend::Place> pl;
+        for (auto& ln : d->lanes) pl.push_back(HipBackend::Place{ln.device, ln.stream});
+        be.use_places(pl, d->set_lane);
+    }
     TipTotals tot;
     rc = d->nw == 2 ? clip_tips<HipBackend, 2>(be, view, geo, cut_single, tot) : clip_tips<HipBackend, 4>(be, view, geo, cut_single, tot);
     if (rc) { pg_set_error(be.error_text.empty() ? "tip clipping on the device failed" : be.error_text); return rc; }
+    for (size_t l = 0; l < be.launches_at.size() && l < d->lanes.size(); l++) d->lanes[l].scans += be.launches_at[l];
     out.single = tot.single; out.minor = tot.minor; out.cycles = tot.minor_cycles; out.rounds = tot.rounds;
     out.per_cycle.assign(tot.per_cycle.begin(), tot.per_cycle.end());
     return PG_OK;
@@ -1163,6 +1271,70 @@ __global__ __launch_bounds__(256) void vx_gather(P2Params p, const unsigned long
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n * NW; i += (uint64_t)gridDim.x * blockDim.x)
         out[i] = sv_node<NW>(sv, slots[i / NW])[i % NW];
 }
+// The vertices of every set, listed ON THE LANE THAT OWNS THE SET into a list and a counter of that lane (room for one slot in 32
+// -- a vertex is a node that is not linear: one in a few hundred; a lane that runs short says how many and scans again), then
+// gathered into one list on the lead (*d_list_out, *n_out; any order).  A list for every slot was a 17 GB allocation at 200 M reads.
+static int p2_list_branch_nodes(P2Device* d, unsigned long long** d_list_out, unsigned long long* n_out) {
+    *d_list_out = nullptr; *n_out = 0;
+    const int NL = (int)d->lanes.size();
+    std::vector<unsigned long long*> l_list(NL, nullptr), l_cnt(NL, nullptr);
+    std::vector<unsigned long long> l_cap(NL, 0), l_n(NL, 0), l_slots(NL, 0);
+    std::vector<char> l_done(NL, 0);
+    int rc = PG_OK;
+    unsigned long long total = 0, at = 0;
+    unsigned long long* d_list = nullptr;
+    for (int s = 0; s < d->P; s++) l_slots[d->set_lane[s]] += d->set_sizes[s];
+    if (hipSetDevice(d->device) != hipSuccess || hipStreamSynchronize(d->stream) != hipSuccess) { pg_set_error("vertices: the lead's stream failed"); return PG_ENODEV; }
+    for (int l = 0; l < NL; l++) l_cap[l] = std::min<unsigned long long>(std::max<unsigned long long>(l_slots[l] / 32, 1 << 20), std::max<unsigned long long>(l_slots[l], 1));
+    for (int attempt = 0; attempt < 2; attempt++) {
+        for (int l = 0; l < NL; l++) {
+            if (l_done[l] || !l_slots[l]) { l_done[l] = 1; continue; }
+            P2Lane& ln = d->lanes[l];
+            P2_HIP_GOTO(hipSetDevice(ln.device));
+            if (!l_cnt[l]) P2_HIP_GOTO(hipMalloc((void**)&l_cnt[l], sizeof(unsigned long long)));
+            P2_HIP_GOTO(hipMalloc((void**)&l_list[l], l_cap[l] * sizeof(unsigned long long)));
+            P2_HIP_GOTO(hipMemsetAsync(l_cnt[l], 0, sizeof(unsigned long long), ln.stream));
+            for (int si = 0; si < d->P; si++)
+                if (d->set_lane[si] == l && d->set_sizes[si]) {
+                    hipLaunchKernelGGL(eb_list_branch, dim3(4096), dim3(256), 0, ln.stream, d->set_ptr[si], d->nw + 1, d->set_sizes[si], d->set_first[si], l_list[l], l_cnt[l], l_cap[l]);
+                    ln.scans++;
+                }
+            P2_HIP_GOTO(hipGetLastError());
+        }
+        bool again = false;
+        for (int l = 0; l < NL; l++) {
+            if (l_done[l]) continue;
+            P2Lane& ln = d->lanes[l];
+            P2_HIP_GOTO(hipSetDevice(ln.device));
+            P2_HIP_GOTO(hipMemcpyAsync(&l_n[l], l_cnt[l], sizeof(unsigned long long), hipMemcpyDeviceToHost, ln.stream));
+            P2_HIP_GOTO(hipStreamSynchronize(ln.stream));
+            if (l_n[l] <= l_cap[l]) { l_done[l] = 1; continue; }
+            hipFree(l_list[l]); l_list[l] = nullptr;
+            l_cap[l] = l_n[l]; l_n[l] = 0;
+            again = true;
+        }
+        if (!again) break;
+    }
+    for (int l = 0; l < NL; l++) total += l_n[l];
+    P2_HIP_GOTO(hipSetDevice(d->device));
+    if (total) {
+        P2_HIP_GOTO(hipMalloc((void**)&d_list, total * sizeof(unsigned long long)));
+        for (int l = 0; l < NL; l++) {
+            if (!l_n[l]) continue;
+            P2_HIP_GOTO(hipMemcpyAsync(d_list + at, l_list[l], l_n[l] * sizeof(unsigned long long), hipMemcpyDefault, d->stream));
+            at += l_n[l];
+        }
+        P2_HIP_GOTO(hipStreamSynchronize(d->stream));
+    }
+    *d_list_out = d_list; d_list = nullptr;
+    *n_out = total;
+done:
+    for (int l = 0; l < NL; l++) { (void)hipSetDevice(d->lanes[l].device); hipFree(l_list[l]); hipFree(l_cnt[l]); }
+    (void)hipSetDevice(d->device);
+    hipFree(d_list);
+    return rc;
+}
+
 int p2_list_vertices(P2Device* d, std::vector<uint64_t>& keys) {
     int rc = PG_OK;
     hipStream_t st = d->stream;
@@ -1174,22 +1346,8 @@ int p2_list_vertices(P2Device* d, std::vector<uint64_t>& keys) {
     int bits = 1;
     keys.clear();
     if (hipSetDevice(d->device) != hipSuccess) { pg_set_error("vertices: hipSetDevice failed"); return PG_ENODEV; }
-    P2_HIP_GOTO(hipMalloc((void**)&d_cnt, sizeof(unsigned long long)));
-    // a list for one slot in 32 (a vertex is a node that is not linear: one in a few hundred); should there be more, the scan says
-    // how many and runs again -- a list for every slot was a 17 GB allocation at 200 M reads, 1.4 s
-    for (unsigned long long cap = std::max<unsigned long long>(d->n_slots / 32, 1 << 20);;) {
-        cap = std::min<unsigned long long>(cap, std::max<unsigned long long>(d->n_slots, 1));
-        P2_HIP_GOTO(hipMemsetAsync(d_cnt, 0, sizeof(unsigned long long), st));
-        P2_HIP_GOTO(hipMalloc((void**)&d_list, cap * sizeof(unsigned long long)));
-        for (int si = 0; si < d->P; si++)
-            if (d->set_sizes[si]) hipLaunchKernelGGL(eb_list_branch, dim3(4096), dim3(256), 0, st, d->set_ptr[si], d->nw + 1, d->set_sizes[si], d->set_first[si], d_list, d_cnt, cap);
-        P2_HIP_GOTO(hipMemcpyAsync(&n, d_cnt, sizeof n, hipMemcpyDeviceToHost, st));
-        P2_HIP_GOTO(hipStreamSynchronize(st));
-        if (n <= cap) break;
-        hipFree(d_list);
-        d_list = nullptr;
-        cap = n;
-    }
+    rc = p2_list_branch_nodes(d, &d_list, &n);
+    if (rc) goto done;
     if (n) {
         while (bits < 64 && (d->n_slots >> bits)) bits++;
         P2_HIP_GOTO(hipMalloc((void**)&d_sorted, n * sizeof(unsigned long long)));
@@ -1214,7 +1372,6 @@ done:
 // ---- edges ------------------------------------------------------------------------------------------------------------
 int p2_build_edges(P2Device* d, P2Edges& out) {
     int rc = PG_OK;
-    const int NW1 = d->nw + 1;
     hipStream_t st = d->stream;
     unsigned long long *d_list = nullptr, *d_cnt = nullptr, *d_key = nullptr, *d_key2 = nullptr, *d_ids = nullptr, *d_bases = nullptr,
                        *d_id_before = nullptr, *d_base_before = nullptr;
@@ -1234,12 +1391,10 @@ int p2_build_edges(P2Device* d, P2Edges& out) {
         d_list = d->d_vlist; d->d_vlist = nullptr;
         n_list = d->n_vlist;
     } else {
-        P2_HIP_GOTO(hipMalloc((void**)&d_list, std::max<uint64_t>(d->n_slots, 1) * sizeof(unsigned long long)));
-        for (int si = 0; si < d->P; si++)
-            if (d->set_sizes[si]) hipLaunchKernelGGL(eb_list_branch, dim3(4096), dim3(256), 0, st, d->set_ptr[si], NW1, d->set_sizes[si], d->set_first[si], d_list, d_cnt, (unsigned long long)std::max<uint64_t>(d->n_slots, 1));
-        P2_HIP_GOTO(hipMemcpyAsync(cnt, d_cnt, sizeof(unsigned long long), hipMemcpyDeviceToHost, st));
-        P2_HIP_GOTO(hipStreamSynchronize(st));
-        n_list = cnt[0];
+        unsigned long long n_listed = 0;
+        rc = p2_list_branch_nodes(d, &d_list, &n_listed);
+        if (rc) goto done;
+        n_list = n_listed;
     }
     // a vertex has at most eight arcs and every chain is kept from one of its two ends (palindromes aside, which are few):
     // room for five walks a vertex, and a second go with room for all eight should that ever be short
@@ -1332,95 +1487,136 @@ done:
 
 void p2_destroy(P2Device* d) { p2_free(d); }
 
+// One batch of reads goes to the next lane in turn.  Without -R the call returns as soon as the batch has left the host buffers
+// (the lane threads it while the caller fetches the next batch for the next lane); with -R the walks come back, so it waits.
 int p2_add_packed(P2Device* d, const uint64_t* words, const uint64_t* word_off, const int32_t* lens, uint64_t n_reads, uint64_t n_words,
                   uint32_t* walks_out, uint16_t* walk_len_out) {
     if (!d->reads_ready) { pg_set_error("pass 2: p2_begin_reads was not called"); return PG_ESTATE; }
     if (!n_reads) return PG_OK;
-    P2_HIP(hipSetDevice(d->device));
-    if (n_words + 8 > d->cap_words) {
-        hipFree(d->d_words);
-        d->cap_words = (n_words + 8) * 5 / 4;
-        P2_HIP(hipMalloc((void**)&d->d_words, d->cap_words * sizeof(uint64_t)));
+    P2Lane& ln = d->lanes[d->next_lane++ % d->lanes.size()];
+    P2_HIP(hipSetDevice(ln.device));
+    if (n_words + 8 > ln.cap_words || n_reads > ln.cap_reads || (d->reps && n_reads > ln.cap_stage_reads)) P2_HIP(hipStreamSynchronize(ln.stream));   // nobody reads the buffers that go
+    if (n_words + 8 > ln.cap_words) {
+        hipFree(ln.d_words);
+        ln.cap_words = (n_words + 8) * 5 / 4;
+        P2_HIP(hipMalloc((void**)&ln.d_words, ln.cap_words * sizeof(uint64_t)));
     }
-    if (n_reads > d->cap_reads) {
-        hipFree(d->d_off); hipFree(d->d_lens);
-        d->cap_reads = n_reads * 5 / 4;
-        P2_HIP(hipMalloc((void**)&d->d_off, d->cap_reads * sizeof(uint64_t)));
-        P2_HIP(hipMalloc((void**)&d->d_lens, d->cap_reads * sizeof(int32_t)));
+    if (n_reads > ln.cap_reads) {
+        hipFree(ln.d_off); hipFree(ln.d_lens);
+        ln.cap_reads = n_reads * 5 / 4;
+        P2_HIP(hipMalloc((void**)&ln.d_off, ln.cap_reads * sizeof(uint64_t)));
+        P2_HIP(hipMalloc((void**)&ln.d_lens, ln.cap_reads * sizeof(int32_t)));
     }
-    if (d->reps && n_reads > d->cap_stage_reads) {
-        hipFree(d->d_stage); hipFree(d->d_walk_len);
-        d->cap_stage_reads = n_reads;
-        P2_HIP(hipMalloc((void**)&d->d_stage, d->cap_stage_reads * (size_t)d->max_nk * sizeof(uint32_t)));
-        P2_HIP(hipMalloc((void**)&d->d_walk_len, d->cap_stage_reads * sizeof(uint16_t)));
+    if (d->reps && n_reads > ln.cap_stage_reads) {
+        hipFree(ln.d_stage); hipFree(ln.d_walk_len);
+        ln.cap_stage_reads = n_reads;
+        P2_HIP(hipMalloc((void**)&ln.d_stage, ln.cap_stage_reads * (size_t)d->max_nk * sizeof(uint32_t)));
+        P2_HIP(hipMalloc((void**)&ln.d_walk_len, ln.cap_stage_reads * sizeof(uint16_t)));
     }
-    P2_HIP(hipMemcpyAsync(d->d_words, words, n_words * sizeof(uint64_t), hipMemcpyHostToDevice, d->stream));
-    P2_HIP(hipMemsetAsync(d->d_words + n_words, 0, 8 * sizeof(uint64_t), d->stream));      // readable padding for the window loads
-    P2_HIP(hipMemcpyAsync(d->d_off, word_off, n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, d->stream));
-    P2_HIP(hipMemcpyAsync(d->d_lens, lens, n_reads * sizeof(int32_t), hipMemcpyHostToDevice, d->stream));
-    P2Params p = d->prm;
-    p.stage = d->reps ? d->d_stage : nullptr;
-    p.walk_len = d->reps ? d->d_walk_len : nullptr;
+    // (the copies are ordered behind the lane's previous batch by its stream: that batch read the same buffers)
+    P2_HIP(hipMemcpyAsync(ln.d_words, words, n_words * sizeof(uint64_t), hipMemcpyHostToDevice, ln.stream));
+    P2_HIP(hipMemsetAsync(ln.d_words + n_words, 0, 8 * sizeof(uint64_t), ln.stream));      // readable padding for the window loads
+    P2_HIP(hipMemcpyAsync(ln.d_off, word_off, n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, ln.stream));
+    P2_HIP(hipMemcpyAsync(ln.d_lens, lens, n_reads * sizeof(int32_t), hipMemcpyHostToDevice, ln.stream));
+    P2_HIP(hipEventRecord(ln.copied, ln.stream));
+    P2Params p = ln.prm;
+    p.stage = d->reps ? ln.d_stage : nullptr;
+    p.walk_len = d->reps ? ln.d_walk_len : nullptr;
     const dim3 grid((unsigned)((n_reads + 255) / 256));
-    p2_launch_thread_kernel(d->nw, grid, d->stream, p, d->d_words, d->d_off, d->d_lens, n_reads, d->ordinal, 0);
+    p2_launch_thread_kernel(d->nw, grid, ln.stream, p, ln.d_words, ln.d_off, ln.d_lens, n_reads, d->ordinal, 0);
     P2_HIP(hipGetLastError());
     if (d->reps && walks_out && walk_len_out) {
-        P2_HIP(hipMemcpyAsync(walks_out, d->d_stage, n_reads * (size_t)d->max_nk * sizeof(uint32_t), hipMemcpyDeviceToHost, d->stream));
-        P2_HIP(hipMemcpyAsync(walk_len_out, d->d_walk_len, n_reads * sizeof(uint16_t), hipMemcpyDeviceToHost, d->stream));
-    }
-    P2_HIP(hipStreamSynchronize(d->stream));
+        P2_HIP(hipMemcpyAsync(walks_out, ln.d_stage, n_reads * (size_t)d->max_nk * sizeof(uint32_t), hipMemcpyDeviceToHost, ln.stream));
+        P2_HIP(hipMemcpyAsync(walk_len_out, ln.d_walk_len, n_reads * sizeof(uint16_t), hipMemcpyDeviceToHost, ln.stream));
+        P2_HIP(hipStreamSynchronize(ln.stream));
+    } else P2_HIP(hipEventSynchronize(ln.copied));                 // the caller's buffers are its own again
     d->ordinal += n_reads;
+    ln.reads += n_reads; ln.batches++;
+    P2_HIP(hipSetDevice(d->device));
     return PG_OK;
 }
 
-// the same for reads that are on the graph's lead device already (pass 1 left them there): n_reads reads of read_len bases, packed
-// back to back, 8 readable words behind the last; no -R walks on this path
-int p2_add_packed_device(P2Device* d, const uint64_t* d_words, uint64_t n_reads, int read_len) {
+// the same for reads that lie on a lane's device already (pass 1 left them there): n_reads reads of read_len bases, packed back to
+// back, 8 readable words behind the last; no -R walks on this path.  Calls arrive in read order (the ordinal is the call order).
+int p2_add_packed_device(P2Device* d, const uint64_t* d_words, uint64_t n_reads, int read_len, int device) {
     if (!d->reads_ready) { pg_set_error("pass 2: p2_begin_reads was not called"); return PG_ESTATE; }
     if (d->reps) { pg_set_error("pass 2: device-resident reads are not for -R runs"); return PG_ESTATE; }
     if (!n_reads) return PG_OK;
     if (read_len < 1 || !d_words) { pg_set_error("pass 2: bad argument"); return PG_EINVAL; }
-    P2_HIP(hipSetDevice(d->device));
-    P2Params p = d->prm;
+    P2Lane* ln = nullptr;
+    for (size_t q = 0; q < d->lanes.size() && !ln; q++) {          // the next lane in turn among those on that device
+        P2Lane& c = d->lanes[(d->next_lane + q) % d->lanes.size()];
+        if (c.device == device) { ln = &c; d->next_lane = (unsigned)((d->next_lane + q + 1) % d->lanes.size()); }
+    }
+    if (!ln) { pg_set_error("pass 2: no lane of the graph runs on the device the reads lie on"); return PG_EINVAL; }
+    P2_HIP(hipSetDevice(ln->device));
+    P2Params p = ln->prm;
     p.stage = nullptr;
     p.walk_len = nullptr;
     const dim3 grid((unsigned)((n_reads + 255) / 256));
-    p2_launch_thread_kernel(d->nw, grid, d->stream, p, d_words, nullptr, nullptr, n_reads, d->ordinal, read_len);
+    p2_launch_thread_kernel(d->nw, grid, ln->stream, p, d_words, nullptr, nullptr, n_reads, d->ordinal, read_len);
     P2_HIP(hipGetLastError());
-    P2_HIP(hipStreamSynchronize(d->stream));
+    P2_HIP(hipStreamSynchronize(ln->stream));                       // (the caller may release the reads)
     d->ordinal += n_reads;
+    ln->reads += n_reads; ln->batches++;
+    P2_HIP(hipSetDevice(d->device));
     return PG_OK;
 }
 
 int p2_finish(P2Device* d, P2Result& out) {
-    P2_HIP(hipSetDevice(d->device));
-    unsigned long long c[8];
-    P2_HIP(hipMemcpy(c, d->d_counters, sizeof(c), hipMemcpyDeviceToHost));
+    unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<unsigned long long> lane_arcs(d->lanes.size(), 0);
+    for (size_t l = 0; l < d->lanes.size(); l++) {
+        P2Lane& ln = d->lanes[l];
+        if (!ln.tables) continue;
+        P2_HIP(hipSetDevice(ln.device));
+        P2_HIP(hipStreamSynchronize(ln.stream));
+        unsigned long long cl[8];
+        P2_HIP(hipMemcpy(cl, ln.d_counters, sizeof(cl), hipMemcpyDeviceToHost));
+        for (int q = 0; q < 8; q++) c[q] += cl[q];
+        lane_arcs[l] = cl[3];
+    }
+    if (getenv("PG_HOST_VERBOSE"))
+        for (size_t l = 0; l < d->lanes.size(); l++)
+            fprintf(stderr, "graph lane %zu (device %d): pass 2 threaded %llu read(s) in %llu batch(es), %llu distinct pre-arc(s); %llu per-set scan(s) ran here\n", l, d->lanes[l].device,
+                    (unsigned long long)d->lanes[l].reads, (unsigned long long)d->lanes[l].batches, lane_arcs[l], (unsigned long long)d->lanes[l].scans);
     if (c[1]) { pg_set_error("pass 2: " + std::to_string(c[1]) + " k-mer(s) of the reads are not in the sets"); return PG_EINVAL; }
     if (c[2]) { pg_set_error("pass 2: pre-arc table overflow"); return PG_ENOMEM; }
     if (c[5]) { pg_set_error("pass 2: edge id out of range"); return PG_EINVAL; }
     out.reads_deleted = (long long)c[0];
     out.markers = (long long)c[4];
-    const uint64_t cap = d->prm.arc_mask + 1;
-    const size_t n_arcs = (size_t)c[3];
+    out.lanes = (int)d->lanes.size();
+    const size_t n_arcs = (size_t)c[3];                            // (a pair met on several lanes is counted by each: the caller merges)
     out.arcs.assign(n_arcs, P2Arc{0, 0, 0, 0});
-    if (n_arcs) {
-        P2Arc* d_arcs = nullptr;
-        P2_HIP(hipMalloc((void**)&d_arcs, n_arcs * sizeof(P2Arc)));
-        P2_HIP(hipMemsetAsync(d->d_counters + 6, 0, sizeof(unsigned long long), d->stream));
-        hipLaunchKernelGGL(p2_compact_arcs, dim3(2048), dim3(256), 0, d->stream, d->d_arc_key, d->d_arc_cnt, d->d_arc_first, cap, d_arcs, d->d_counters + 6);
-        P2_HIP(hipMemcpyAsync(out.arcs.data(), d_arcs, n_arcs * sizeof(P2Arc), hipMemcpyDeviceToHost, d->stream));
-        unsigned long long got = 0;
-        P2_HIP(hipMemcpyAsync(&got, d->d_counters + 6, sizeof(got), hipMemcpyDeviceToHost, d->stream));
-        P2_HIP(hipStreamSynchronize(d->stream));
-        hipFree(d_arcs);
-        if (got != n_arcs) { pg_set_error("pass 2: pre-arc table is inconsistent"); return PG_EINVAL; }
-    }
     out.marker.clear();
-    if (d->reps) {
-        out.marker.resize((size_t)d->num_ed + 1);
-        P2_HIP(hipMemcpy(out.marker.data(), d->d_marker, out.marker.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
+    if (d->reps) out.marker.assign((size_t)d->num_ed + 1, 0u);
+    size_t at = 0;
+    for (size_t l = 0; l < d->lanes.size(); l++) {
+        P2Lane& ln = d->lanes[l];
+        if (!ln.tables) continue;
+        P2_HIP(hipSetDevice(ln.device));
+        const uint64_t cap = ln.prm.arc_mask + 1;
+        const size_t n_l = (size_t)lane_arcs[l];
+        if (n_l) {
+            P2Arc* d_arcs = nullptr;
+            P2_HIP(hipMalloc((void**)&d_arcs, n_l * sizeof(P2Arc)));
+            P2_HIP(hipMemsetAsync(ln.d_counters + 6, 0, sizeof(unsigned long long), ln.stream));
+            hipLaunchKernelGGL(p2_compact_arcs, dim3(2048), dim3(256), 0, ln.stream, ln.d_arc_key, ln.d_arc_cnt, ln.d_arc_first, cap, d_arcs, ln.d_counters + 6);
+            P2_HIP(hipMemcpyAsync(out.arcs.data() + at, d_arcs, n_l * sizeof(P2Arc), hipMemcpyDeviceToHost, ln.stream));
+            unsigned long long got = 0;
+            P2_HIP(hipMemcpyAsync(&got, ln.d_counters + 6, sizeof(got), hipMemcpyDeviceToHost, ln.stream));
+            P2_HIP(hipStreamSynchronize(ln.stream));
+            hipFree(d_arcs);
+            if (got != n_l) { pg_set_error("pass 2: pre-arc table is inconsistent"); return PG_EINVAL; }
+            at += n_l;
+        }
+        if (d->reps) {
+            std::vector<unsigned int> m((size_t)d->num_ed + 1);
+            P2_HIP(hipMemcpy(m.data(), ln.d_marker, m.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
+            for (size_t e = 0; e < m.size(); e++) out.marker[e] += m[e];
+        }
     }
+    P2_HIP(hipSetDevice(d->device));
     return PG_OK;
 }
 

@@ -1765,6 +1765,7 @@ struct GraphHandle : GraphHandleBase {
     // edges on the device (graph_kernels.hip: eb_*): upload the sets, build, then format output_1edge's text here
     // the k-mer sets into HBM as they are now (after the layout replay: the tips then walk on the device copy)
     std::vector<int> set_devices;                // sharded run: the HIP device every set lives on (empty: all on dev_id)
+    std::vector<int> lane_devices;               // sharded run: the ranks' devices, lane 0 = the lead (graph_kernels.hip: P2Lane)
     int dev_open(int device) {
         dev_on = true; dev_id = device;
         P2Sets sets;
@@ -1775,6 +1776,7 @@ struct GraphHandle : GraphHandleBase {
         }
         dev = p2_open(dev_id, g.K, NW, g.P, sets, max_nk(), set_devices.empty() ? nullptr : set_devices.data());
         if (!dev) return PG_ENODEV;
+        if (lane_devices.size() > 1 && lane_devices[0] == dev_id && p2_use_lanes(dev, lane_devices.data(), (int)lane_devices.size()) != PG_OK) { p2_destroy(dev); dev = nullptr; return PG_ENODEV; }
         g.tip_dev = dev;
         return PG_OK;
     }
@@ -2012,9 +2014,23 @@ struct GraphHandle : GraphHandleBase {
             for (const P2Arc& a : res.arcs) sorted[cur[(size_t)((uint64_t)a.from * nt / n_from)]++] = a;
         }
         std::vector<std::string> text(nt);
+        const bool merge = res.lanes > 1;
+        std::vector<size_t> merged_n(nt, 0);
         auto body = [&](int t) {
             P2Arc* lo = sorted.data() + start[t];
             P2Arc* hi = sorted.data() + start[t + 1];
+            if (merge) {
+                // several lanes threaded the reads: a (from, to) pair may have an entry from each -- multiplicities add up, the first
+                // meeting is the earliest (thread_add1preArc counts and keeps the list order of the first insertion, prlRead2path.c:388-403)
+                std::sort(lo, hi, [](const P2Arc& a, const P2Arc& b) { return a.from != b.from ? a.from < b.from : a.to < b.to; });
+                P2Arc* w = lo;
+                for (P2Arc* a = lo; a != hi; ++a) {
+                    if (w != lo && w[-1].from == a->from && w[-1].to == a->to) { w[-1].mult += a->mult; w[-1].first = std::min(w[-1].first, a->first); }
+                    else *w++ = *a;
+                }
+                hi = w;
+            }
+            merged_n[t] = (size_t)(hi - lo);
             std::sort(lo, hi, [](const P2Arc& a, const P2Arc& b) { return a.from != b.from ? a.from < b.from : a.first > b.first; });
             std::string& out = text[t];
             out.reserve((size_t)(hi - lo) * 12);
@@ -2038,7 +2054,8 @@ struct GraphHandle : GraphHandleBase {
         for (int t = 0; t < nt; t++)
             if (!text[t].empty() && fwrite(text[t].data(), 1, text[t].size(), fp) != text[t].size()) { fclose(fp); pg_set_error("short write on " + prefix + ".preArc"); return PG_EIO; }
         fclose(fp);
-        dev_arc_count = (long long)res.arcs.size();
+        dev_arc_count = 0;
+        for (int t = 0; t < nt; t++) dev_arc_count += (long long)merged_n[t];
         if (path_fp) for (size_t e = 0; e < marker.size() && e < res.marker.size(); e++) marker[e] = (uint8_t)std::min(255u, res.marker[e]);
         t_fold += now() - t0;
         return PG_OK;
@@ -2082,13 +2099,13 @@ struct GraphHandle : GraphHandleBase {
     // reads packed 2 bits a base, 32 bases a word, first base in the top bits (pg_pack_read), back to back
     // reads that pass 1 left on the device (one length, back to back): threaded where they are
     int add_packed_device(const uint64_t* d_words, uint64_t n, int read_len, int device) override {
-        if (!dev_on || device != dev_id) { pg_set_error("pg_graph_add_packed_device: the graph is not on that device (pg_graph_use_device first)"); return PG_ESTATE; }
+        if (!dev_on) { pg_set_error("pg_graph_add_packed_device: the graph is not on a device (pg_graph_use_device first)"); return PG_ESTATE; }
         if (path_fp) { pg_set_error("pg_graph_add_packed_device: not with -R (the walks come back through the host path)"); return PG_ESTATE; }
         if (read_len - g.K + 1 > max_nk()) { pg_set_error("a read is longer than the maximum read length given at pg_host_graph_begin"); return PG_EINVAL; }
         const double t0 = now();
         int rc = dev_begin();
         if (rc) return rc;
-        rc = p2_add_packed_device(dev, d_words, n, read_len);
+        rc = p2_add_packed_device(dev, d_words, n, read_len, device);      // (a lane of the graph on that device, or an error)
         if (rc) return rc;
         reads_seen += (long long)n;
         t_thread += now() - t0;
@@ -2389,6 +2406,8 @@ static int layout_on_ranks(GraphHandle<NW>* h, const ShardedRecords& sr, const u
     for (int s = 0; s < P; s++) { devs[s] = sr.devices[s % N]; ptrs[s] = nodes[s % N] + rank_at[s % N] * (NW + 1); rank_at[s % N] += sizes[s]; }
     P2Device* dev = p2_adopt(sr.devices[0], K, NW, P, sizes.data(), devs.data(), ptrs.data(), owned, h->max_nk());
     if (!dev) return PG_ENODEV;
+    // the ranks become the lanes of the graph: per-set scans on the owner, pass 2's batches dealt to all of them
+    if (p2_use_lanes(dev, sr.devices.data(), N) != PG_OK) { p2_destroy(dev); return PG_ENODEV; }
     g.sets.clear();
     g.sets.resize(P);
     g.set_base.assign((size_t)P + 1, 0);
@@ -2423,6 +2442,7 @@ static GraphHandleBase* graph_begin(const uint64_t* records, uint64_t n, const u
         const char* where = getenv("SOAPDENOVO2_AMD_LAYOUT");
         h->set_devices.resize(P);
         for (int si = 0; si < P; si++) h->set_devices[si] = sharded->devices[si % sharded->n_ranks];
+        h->lane_devices = sharded->devices;
         if (!(where && !strcmp(where, "host")) && !tips_replay && !getenv("SOAPDENOVO2_AMD_TIPS_HOST"))
             rc_replay = layout_on_ranks<NW>(h, *sharded, per_set_count, set_last_put, K, P, a_gb, n_threads);
         if (rc_replay == 1) { fetch = &fetch_sharded_records; fetch_user = (void*)sharded; }

@@ -553,6 +553,17 @@ def test_cli_sharded_matches_reference_files(golden, tmp_path, name, devices):
         assert len(held) == n_ranks and sum(h[1] for h in held) == held[0][2] > 0
         share = -(-P // n_ranks) / P                                       # the largest number of sets a rank owns / all sets
         assert max(h[1] for h in held) <= share * held[0][2] * 1.25 + 64, held
+        # the graph stages' COMPUTE is sharded too: every rank is a lane of the graph -- pass 2 deals its read batches to the lanes in
+        # turn (each threads about 1 / n_ranks of the reads against the peer-mapped sets, own pre-arc table, merged at the end) and the
+        # scans over a set's slots run on the lane that owns the set
+        lanes = [(int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4))) for m in
+                 re.finditer(r"graph lane (\d+) \(device \d+\): pass 2 threaded (\d+) read\(s\) in (\d+) batch\(es\), \d+ distinct pre-arc\(s\); (\d+) per-set scan", log)]
+        assert [l[0] for l in lanes] == list(range(n_ranks)), log[-3000:]
+        n_reads = sum(l[1] for l in lanes)
+        assert n_reads == c["N"] and all(l[2] >= 1 for l in lanes)
+        assert max(l[1] for l in lanes) <= n_reads / n_ranks + 2 * 7000, lanes
+        owners = min(P, n_ranks)
+        assert sum(1 for l in lanes if l[3] > 0) == owners, lanes              # a lane that owns a set scanned it; a lane that owns none scanned nothing
         want = golden["md5"][t]
         for ext in ("kmerFreq", "preGraphBasic", "vertex", "preArc", "path", "markOnEdge"):
             assert md5_file(pre + "." + ext) == want[ext], (t, ext)
