@@ -132,81 +132,143 @@ def whole_command(args, cores):
 
 
 def big_command(args):
-    """The executable on the 60 M-read FASTQ of scripts/synth_fastq.cpp (bytes that depend on the arguments only), once with -a 16
-    (static pools) and once with the default growable sets -- either way the k-mer-set layout is made on the device (SURVEY.md
-    App. C "K6": dev_graph.hpp / dev_rehash.hpp) -- compared with the md5s of the REFERENCE's own runs on the same file, which took it
-    a quarter of an hour each in the build container and are committed (profiles/r03_ref_60M_K63*.json).
-    Returns {"whole_command_60M_a16": {...}, "whole_command_60M": {...}}."""
-    exps = [("whole_command_60M_a16", "r03_ref_60M_K63_a16.json"), ("whole_command_60M", "r03_ref_60M_K63.json")]
+    """The executable on FASTQ files of scripts/synth_fastq.cpp (bytes that depend on the arguments only), compared with the md5s of the
+    REFERENCE's own runs on the same files, which took it a quarter of an hour to an hour each in the build container and are committed
+    (profiles/r0*_ref_*.json): 60 M reads at K = 63 with -a 16 (static pools) and with the default growable sets -- either way the
+    k-mer-set layout is made on the device (SURVEY.md App. C "K6": dev_graph.hpp / dev_rehash.hpp); 20 M reads at K = 127 (the
+    SOAPdenovo-127mer flavour, configs[4]'s path); configs[2] at its full 200 M reads with -a 40.
+    Returns {"whole_command_60M_a16": {...}, "whole_command_60M": {...}, "whole_command_k127_20M": {...}, "whole_command_200M_a40": {...}}."""
+    groups = [[("whole_command_60M_a16", "r03_ref_60M_K63_a16.json"), ("whole_command_60M", "r03_ref_60M_K63.json")],
+              [("whole_command_k127_20M", "r04_ref_20M_K127.json")],
+              [("whole_command_200M_a40", "r04_ref_200M_K63_a40.json")]]
     gen = os.path.join(ROOT, "soapdenovo2_amd", "bin", "synth_fastq")
-    exps = [(k, os.path.join(ROOT, "profiles", f)) for k, f in exps if os.path.exists(os.path.join(ROOT, "profiles", f))]
-    if not exps or not os.path.exists(gen):
-        return None
-    w = json.load(open(exps[0][1]))["workload"]
-    if args.kmer != w["kmer"] or args.sets != w["sets"]:
+    if not os.path.exists(gen):
         return None
     from soapdenovo2_amd import api
-    td = tempfile.mkdtemp(prefix="pgbig_", dir=os.environ.get("PG_BENCH_TMP"))
     res = {}
-    try:
-        if shutil_free_gb(td) < w["reads"] * (2 * w["read_len"] + 20) / 1e9 + 4:
-            return {exps[0][0]: {"skipped": "not enough room for the FASTQ in " + td}}
-        fq, cfg = os.path.join(td, "reads.fq"), os.path.join(td, "lib.cfg")
-        t0 = time.time()
-        subprocess.check_call([gen, fq, str(w["genome"]), str(w["reads"]), str(w["read_len"]), str(w["err"]), str(w["seed"])])
-        open(cfg, "w").write(f"max_rd_len={w['read_len']}\n[LIB]\navg_ins=200\nreverse_seq=0\nasm_flags=3\nrank=1\nq={fq}\n")
-        os.sync()
-        gen_s = round(time.time() - t0, 1)
-        for key, exp_path in exps:
-            exp = json.load(open(exp_path))
-            w = exp["workload"]
-            out = {"workload": f"{w['reads']} reads x {w['read_len']} bp, genome {w['genome']}, err {w['err']} (scripts/synth_fastq.cpp, seed {w['seed']}), "
-                               f"K={w['kmer']}, -p {w['sets']} -a {w['a_gb']}", "reads": w["reads"], "fastq_bytes": os.path.getsize(fq), "generate_s": gen_s}
-            pre = os.path.join(td, "amd" + key[-4:])
+    for group in groups:
+        exps = [(k, os.path.join(ROOT, "profiles", f)) for k, f in group if os.path.exists(os.path.join(ROOT, "profiles", f))]
+        if not exps:
+            continue
+        w = json.load(open(exps[0][1]))["workload"]
+        if args.sets != w["sets"]:
+            continue
+        td = tempfile.mkdtemp(prefix="pgbig_", dir=os.environ.get("PG_BENCH_TMP"))
+        try:
+            if shutil_free_gb(td) < w["reads"] * (2 * w["read_len"] + 20) / 1e9 + 8:
+                res[exps[0][0]] = {"skipped": "not enough room for the FASTQ in " + td}
+                continue
+            fq, cfg = os.path.join(td, "reads.fq"), os.path.join(td, "lib.cfg")
             t0 = time.time()
-            r = subprocess.run([api.binary(False), "pregraph", "-s", cfg, "-K", str(w["kmer"]), "-o", pre, "-p", str(w["sets"])] + (["-a", str(w["a_gb"])] if w["a_gb"] else []),
-                               capture_output=True, text=True, env=dict(os.environ, PG_HOST_VERBOSE="1"))
-            wall = time.time() - t0
-            out.update({"rc": r.returncode, "wall_s": wall, "reads_per_sec": w["reads"] / wall if r.returncode == 0 else None,
-                        "stages_s": {m.group(1): float(m.group(2)) for m in re.finditer(r"\[cli\] ([^:]+): ([0-9.]+)s", r.stderr)}})
-            m = re.search(r"Time spent on rebuilding the k-mer set layout: ([0-9.]+)s", r.stderr)
-            if m:
-                out["layout_s"] = float(m.group(1))
-            # how long the process waited for its device context (HIP start-up + the record pool's allocation): 0.1 s on an idle GPU,
-            # seconds when another process has just released its memory -- part of wall_s and of the pass-1 stage either way
-            m0, m1 = re.search(r"at ([0-9.]+)s: input files sized", r.stderr), re.search(r"at ([0-9.]+)s: device context created", r.stderr)
-            if m0 and m1:
-                out["device_context_s"] = round(float(m1.group(1)) - float(m0.group(1)), 2)
-            m = re.search(r"reader: ([0-9.]+)s cutting \+ parsing", r.stderr)
-            if m:
-                out["reader_s"] = float(m.group(1))
-            out["layout_on_device"] = "k-mer set layout on the device" in r.stderr
-            m = re.search(r"tips decided on the device: (\d+) scan\(s\), (\d+) fixed-point round\(s\), ([0-9.]+)s", r.stderr)
-            if m:
-                out["tips"] = {"scans": int(m.group(1)), "rounds": int(m.group(2)), "seconds": float(m.group(3))}
-            if r.returncode == 0:
-                got = md5_outputs(pre)
-                out["md5"] = got
-                out["files_identical_to_reference"] = got == exp["md5"]
-                out["reference_wall_s"] = exp.get("reference_wall_s")
-                out["expectation"] = f"profiles/{os.path.basename(exp_path)} (oracle/_ref/SOAPdenovo-63mer pregraph -p {w['sets']}" + (f" -a {w['a_gb']}" if w["a_gb"] else "") + " on the same file, build container)"
-                for ext in ("kmerFreq", "preGraphBasic", "vertex", "preArc", "edge.gz"):
-                    try:
-                        os.remove(pre + "." + ext)
-                    except OSError:
-                        pass
-            else:
-                out["stderr_tail"] = r.stderr[-800:]
-            res[key] = out
-        return res
-    finally:
-        import shutil
-        shutil.rmtree(td, ignore_errors=True)
+            subprocess.check_call([gen, fq, str(w["genome"]), str(w["reads"]), str(w["read_len"]), str(w["err"]), str(w["seed"])])
+            open(cfg, "w").write(f"max_rd_len={w['read_len']}\n[LIB]\navg_ins=200\nreverse_seq=0\nasm_flags=3\nrank=1\nq={fq}\n")
+            os.sync()
+            gen_s = round(time.time() - t0, 1)
+            for key, exp_path in exps:
+                exp = json.load(open(exp_path))
+                w = exp["workload"]
+                mer127 = w["kmer"] > 63
+                out = {"workload": f"{w['reads']} reads x {w['read_len']} bp, genome {w['genome']}, err {w['err']} (scripts/synth_fastq.cpp, seed {w['seed']}), "
+                                   f"K={w['kmer']}, -p {w['sets']} -a {w['a_gb']}", "reads": w["reads"], "fastq_bytes": os.path.getsize(fq), "generate_s": gen_s}
+                pre = os.path.join(td, "amd_" + key)
+                t0 = time.time()
+                r = subprocess.run([api.binary(mer127), "pregraph", "-s", cfg, "-K", str(w["kmer"]), "-o", pre, "-p", str(w["sets"])] + (["-a", str(w["a_gb"])] if w["a_gb"] else []),
+                                   capture_output=True, text=True, env=dict(os.environ, PG_HOST_VERBOSE="1"))
+                wall = time.time() - t0
+                out.update({"rc": r.returncode, "wall_s": wall, "reads_per_sec": w["reads"] / wall if r.returncode == 0 else None,
+                            "stages_s": {m.group(1): float(m.group(2)) for m in re.finditer(r"\[cli\] ([^:]+): ([0-9.]+)s", r.stderr)}})
+                m = re.search(r"Time spent on rebuilding the k-mer set layout: ([0-9.]+)s", r.stderr)
+                if m:
+                    out["layout_s"] = float(m.group(1))
+                # how long the process waited for its device context (HIP start-up + the record pool's allocation): 0.1 s on an idle GPU,
+                # seconds when another process has just released its memory -- part of wall_s and of the pass-1 stage either way
+                m0, m1 = re.search(r"at ([0-9.]+)s: input files sized", r.stderr), re.search(r"at ([0-9.]+)s: device context created", r.stderr)
+                if m0 and m1:
+                    out["device_context_s"] = round(float(m1.group(1)) - float(m0.group(1)), 2)
+                m = re.search(r"reader: ([0-9.]+)s cutting \+ parsing", r.stderr)
+                if m:
+                    out["reader_s"] = float(m.group(1))
+                out["layout_on_device"] = "k-mer set layout on the device" in r.stderr
+                m = re.search(r"tips decided on the device: (\d+) scan\(s\), (\d+) fixed-point round\(s\), ([0-9.]+)s", r.stderr)
+                if m:
+                    out["tips"] = {"scans": int(m.group(1)), "rounds": int(m.group(2)), "seconds": float(m.group(3))}
+                if r.returncode == 0:
+                    got = md5_outputs(pre)
+                    out["md5"] = got
+                    out["files_identical_to_reference"] = got == exp["md5"]
+                    out["reference_wall_s"] = exp.get("reference_wall_s")
+                    out["expectation"] = (f"profiles/{os.path.basename(exp_path)} (oracle/_ref/SOAPdenovo-{'127' if mer127 else '63'}mer pregraph -p {w['sets']}"
+                                          + (f" -a {w['a_gb']}" if w["a_gb"] else "") + " on the same file, build container)")
+                    for ext in ("kmerFreq", "preGraphBasic", "vertex", "preArc", "edge.gz"):
+                        try:
+                            os.remove(pre + "." + ext)
+                        except OSError:
+                            pass
+                else:
+                    out["stderr_tail"] = r.stderr[-800:]
+                res[key] = out
+        except Exception as e:                                       # a leg that cannot run says so; the bench line still comes out
+            res[exps[0][0]] = {"skipped": f"{type(e).__name__}: {e}"}
+        finally:
+            import shutil
+            shutil.rmtree(td, ignore_errors=True)
+    return res or None
 
 
 def shutil_free_gb(path):
     import shutil
     return shutil.disk_usage(path).free / 1e9
+
+
+def pass_k127(torch, api, packed, n_reads, L, P, genome, err, batch_reads, device):
+    """configs[4]'s path on the same resident reads: pass 1 with the four-word k-mers of the SOAPdenovo-127mer flavour (K = 127:
+    prlHashReads.c:374-378, kmer.c:532), timed like the headline pass (1 warm-up, 2 timed passes, inputs resident), with the same
+    conservation check on the timed result.  Its algorithmic bytes: 80 B per k-mer occurrence (40-byte node read + write) + the packed read."""
+    K = 127
+    kpr = L - K + 1
+    if kpr < 1:
+        return None
+    n_kmers = n_reads * kpr
+    expected = min(n_kmers, genome + n_reads * L * err * min(K, kpr))
+    log2_slots = 20
+    while (1 << log2_slots) * 0.6 < expected:
+        log2_slots += 1
+    kc = api.KmerCounter(K, n_sets=P, mer127=True, log2_slots=log2_slots, device=device, engine=2)
+    try:
+        api._check(api.lib().pg_expect_kmers(kc.h, n_kmers), "pg_expect_kmers")
+        kc.set_autogrow(False)
+        wpr = (L + 31) // 32
+        batches = [(lo, min(batch_reads, n_reads - lo)) for lo in range(0, n_reads, batch_reads)]
+        ev = []
+        hist = None
+        steps = 2
+        for it in range(1 + steps):
+            kc.reset()
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            e[0].record()
+            for lo, n in batches:
+                kc.count_uniform(packed[lo * wpr:], n, L, lo * kpr)
+            e[1].record()
+            hist, _ = kc.finalize(0, want_last_put=False)
+            e[2].record()
+            if it:
+                ev.append(e)
+        torch.cuda.synchronize()
+        k1 = sum(e[0].elapsed_time(e[1]) for e in ev) / steps
+        k2 = sum(e[1].elapsed_time(e[2]) for e in ev) / steps
+        distinct = kc.distinct()
+        cov = int((hist * np.arange(256, dtype=np.uint64)).sum())
+        sat = int(hist[255])
+        bytes_per_read = kpr * 80 + (L + 3) // 4
+        ok = int(hist.sum()) == distinct and (cov == n_kmers if sat == 0 else cov <= n_kmers)
+        return {"workload": f"the same {n_reads} resident reads x {L} bp, K=127 (four-word k-mers, {kpr} k-mers a read), -p {P}",
+                "ms_per_pass": k1 + k2, "reads_per_sec": n_reads / ((k1 + k2) * 1e-3), "k1_scatter_ms": k1, "k2_count_ms": k2, "distinct_kmers": distinct,
+                "algorithmic_bytes_per_read": bytes_per_read, "roofline_frac_k2": n_reads * bytes_per_read / (k2 * 1e-3) / 1e9 / 8000.0,
+                "roofline_frac_both_kernels": n_reads * bytes_per_read / ((k1 + k2) * 1e-3) / 1e9 / 8000.0,
+                "conservation": {"histogram_sum_equals_distinct": int(hist.sum()) == distinct, "kmer_occurrences_in": n_kmers, "sum_of_coverage_histogram": cov,
+                                 "saturated_nodes": sat, "ok": ok}}
+    finally:
+        kc.close()
 
 
 def main():
@@ -228,6 +290,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the whole-command run and the reference run (kernel work only)")
     ap.add_argument("--no-big", action="store_true", help="skip the 60 M-read -a 16 command (19 GB of FASTQ on local disk, ~25 s)")
     ap.add_argument("--no-extras", action="store_true", help="skip the export + sort and the PCIe-inclusive measurements")
+    ap.add_argument("--no-k127", action="store_true", help="skip the K = 127 pass over the same reads (the `k127` entry of the line)")
     ap.add_argument("--exchange", default="lib", help="N > 1: lib = pg_count_reads_sharded (librccl through the C ABI), torch = torch.distributed all_to_all")
     ap.add_argument("--engine", type=int, default=2, help="2 = super-k-mer partitions counted in LDS (default), 1 = one DRAM-resident set")
     ap.add_argument("--comm", default="nccl", help="nccl (RCCL over xGMI) or gloo (test only: exchange staged through the host)")
@@ -265,8 +328,17 @@ def main():
     comm, exchange = None, "none"
     if world > 1 and args.engine == 2:
         exchange = args.exchange
-        if args.comm != "nccl" or args.share_gpu:
-            exchange = "torch"                                   # RCCL refuses ranks that share a GPU (test set-ups only)
+        if (args.comm != "nccl" or args.share_gpu) and exchange == "lib":
+            # RCCL refuses ranks that share a GPU (test set-ups only): the library's own sharded pass -- the same pipelined
+            # pg_count_reads_sharded, the same routing, flags and appends -- over a transport that stages the exchange through the
+            # host and torch.distributed's gloo all-to-all (pg_comm_create_host)
+            def host_a2a(send, so, sc, recv, ro, rc):
+                assert all(so[i] + sc[i] == so[i + 1] for i in range(world - 1)) and all(ro[i] + rc[i] == ro[i + 1] for i in range(world - 1))
+                st_ = torch.frombuffer(send, dtype=torch.uint8)[so[0]: so[0] + sum(sc)] if sum(sc) else torch.empty(0, dtype=torch.uint8)
+                rt_ = torch.frombuffer(recv, dtype=torch.uint8)[ro[0]: ro[0] + sum(rc)] if sum(rc) else torch.empty(0, dtype=torch.uint8)
+                dist.all_to_all_single(rt_, st_, list(rc), list(sc))
+            comm = api.Comm.host(world, rank, local, host_a2a)
+            exchange = "lib-host"
         if exchange == "lib":
             ok = 1
             try:
@@ -393,11 +465,13 @@ def main():
     for _ in range(args.warmup):
         step(False)
     barrier()
+    pipe0 = comm.pipeline_stats() if comm is not None else None
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step(True)
     barrier()
     dt = time.perf_counter() - t0
+    pipe1 = comm.pipeline_stats() if comm is not None else None
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -499,6 +573,17 @@ def main():
         api.hip_free(ptr)
         api.hip_free(ws)
 
+    k127 = None
+    if world == 1 and engine == 2 and K <= 63 and L >= 128 and not args.no_extras and not args.no_k127:
+        st_final = st_snapshot if extras else kc.stats()
+        kc.close()                                              # (its pools go; the 127-mer pass makes its own)
+        torch.cuda.empty_cache()
+        try:
+            k127 = pass_k127(torch, api, packed, n_reads, L, P, args.genome, args.err, args.batch_reads, local)
+        except Exception as e:
+            k127 = {"error": f"{type(e).__name__}: {e}"}
+    else:
+        st_final = None
     if rank == 0:
         ms = dt / args.steps * 1e3
         total_reads = n_reads * world
@@ -515,12 +600,24 @@ def main():
                        "engine": engine,
                        "parallelism": ("single GPU, " + ("super-k-mer partitions counted in LDS" if engine == 2 else "fused extract+insert into one DRAM set"))
                        if world == 1 else (f"owner(record) = minimizer partition mod {world} (a hash of the k-mer's minimizer -- NOT north_star's high-bit key range: "
-                                            f"the first base of a canonical k-mer is skewed 7:5:3:1, SURVEY.md 8e), super-k-mer records over RCCL all-to-all" if engine == 2
+                                            f"the first base of a canonical k-mer is skewed 7:5:3:1, SURVEY.md 8e), super-k-mer records in a direct all-to-all; "
+                                            f"after pass 1: owner(distinct k-mer) = reference set id mod {world}" if engine == 2
                                            else f"set-id owner, k-mer records over RCCL all-to-all x{world}"),
-                       "exchange": {"lib": "pg_count_reads_sharded (librccl ncclSend/ncclRecv group through the C ABI)", "none": None}.get(exchange, exchange)},
+                       "exchange": {"lib": "pg_count_reads_sharded (librccl ncclSend/ncclRecv group through the C ABI)",
+                                    "lib-host": "pg_count_reads_sharded over pg_comm_create_host (test transport: staged through the host, gloo all-to-all)",
+                                    "none": None}.get(exchange, exchange)},
         }
         if comm is not None:
             rec["config"]["exchange_stats_rank0"] = comm.stats()
+            d = {k: pipe1[k] - pipe0[k] for k in ("exchange_ms", "bytes_sent", "host_waits", "repeated_cuts", "rounds")}
+            # (rank 0's numbers; the ranks cut equal batches of one read distribution)
+            rec["exchange_ms"] = d["exchange_ms"] / args.steps           # device time of the record exchanges per step (events on the exchange stream)
+            rec["bytes_sent_per_rank"] = d["bytes_sent"] / args.steps    # to the other ranks, per step
+            rec["exchange"] = {"transport": comm.transport, "rounds_per_step": d["rounds"] / args.steps, "host_waits_per_round": d["host_waits"] / max(d["rounds"], 1),
+                               "repeated_cuts": d["repeated_cuts"], "owner_region_records": pipe1["owner_region_records"],
+                               "exchange_GBps_per_rank": (d["bytes_sent"] / 1e9) / (d["exchange_ms"] / 1e3) if d["exchange_ms"] > 0 else None,
+                               "exchange_over_step": d["exchange_ms"] / args.steps / ms,
+                               "overlap": "round i's records travel on their own stream while batch i + 1 is cut and round i - 1 is appended (exchange.hip)"}
         if extras:
             rec["pass1_hand_over"] = extras
         if world == 1 and ev:
@@ -543,7 +640,7 @@ def main():
                 # the distinct k-mers.  `achieved` follows the contract: SURVEY.md 8d's algorithmic bytes per read (one node
                 # read + one node write per k-mer occurrence + the packed read) x the reads one launch of the dominant kernel
                 # processes / its duration.  The bytes that formulation really moves (passes x record bytes) are listed too.
-                st = st_snapshot if extras else kc.stats()
+                st = st_final if st_final is not None else (st_snapshot if extras else kc.stats())
                 rec_bytes = st["records"] * st["unit_bytes"]
                 k1_bytes = n_reads * wpr * 8 + rec_bytes
                 k2_bytes = rec_bytes + distinct * (kc.nw + 2) * 8
@@ -582,12 +679,35 @@ def main():
                        "DESIGN.md 3.2)") if engine == 2 else "random-atomic rate of the DRAM-resident set"
             # what the counters say about the same launch: PMC bytes / launch time against the same peak (never `frac`)
             counter_frac = (traffic / (avg_ms * 1e-3) / 1e9 / 8000.0) if traffic else None
+            if engine == 2:
+                # The formulation's OWN rooflines ("a sort/partition formulation should instead count passes x record
+                # bytes and say so"): (1) memory -- the bytes it cannot avoid moving (packed reads in, super-k-mer records out; records
+                # back in, distinct k-mers out) at HBM peak against the time of both kernels; (2) instruction issue, its declared
+                # limiter -- the wave-level vector instructions K2 issues (SQ_INSTS_VALU of a committed PMC pass, per read) against
+                # what 256 CUs x 4 SIMDs issue at 2.4 GHz with four cycles a wave64 instruction.
+                floor_ms = (k1_bytes + k2_bytes) / 8000e9 * 1e3
+                extra["own_formulation"] = {"definition": "passes x record bytes: reads in + records out (K1), records in + distinct k-mers out (K2)",
+                                            "bytes_per_step": k1_bytes + k2_bytes, "bytes_per_read": (k1_bytes + k2_bytes) / n_reads,
+                                            "hbm_floor_ms": floor_ms, "frac_of_hbm_both_kernels": floor_ms / ((k1_s + k2_s) * 1e3),
+                                            "k2_frac_of_hbm": (k2_bytes / 8000e9) / k2_s}
+                try:
+                    tj = json.load(open(tf))
+                    ipr = tj.get("skm_count_kernel_valu_insts_per_read_K127" if mer127 else "skm_count_kernel_valu_insts_per_read")
+                    if ipr:
+                        issue_peak = 256 * 4 * 2.4e9 / 4
+                        extra["valu_issue_frac"] = ipr * n_reads / issue_peak / k2_s
+                        extra["valu_issue_note"] = (f"{ipr:.0f} wave-level vector instructions per read (SQ_INSTS_VALU, {tj.get('sq_source', 'profiles/')}) x reads / "
+                                                    f"{issue_peak / 1e9:.0f} G wave instructions/s / K2's time")
+                except Exception:
+                    pass
             rec["roofline"] = {"bound": "hbm", "bound_note": "hbm-equivalent (contract): SURVEY.md 8d prices the path as a hash table in HBM; this formulation "
                                                              "moves a fraction of those bytes (see traffic / hbm_counter_frac) and is limited as `limiter_bound` says",
                                "limiter_bound": "valu-issue/lds" if engine == 2 else "random-atomic rate",
                                "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                                "traffic": traffic, "hbm_counter_frac": counter_frac, "kernel": kernel, "launches": launches, "avg_launch_ms": avg_ms,
                                "algorithmic_bytes_per_launch": per_launch, "limiter": limiter, **extra}
+            if k127 is not None:
+                rec["k127"] = k127
             rec.update(commands)                                      # whole_command, cpu_baseline, whole_command_60M*: run before the pass (above)
         print(json.dumps(rec), flush=True)
     kc.close()

@@ -355,6 +355,8 @@ int pg_sort_records_ws(uint64_t *d_records, uint64_t n_records, int mer127, void
 typedef struct pg_comm pg_comm;
 #define PG_COMM_RCCL 0   /* ncclSend / ncclRecv in one group: a direct all-to-all over xGMI */
 #define PG_COMM_P2P 1    /* one process: barrier + peer-to-peer copies */
+#define PG_COMM_HOST 2   /* the caller's all-to-all over host buffers (pg_comm_create_host): ranks in several processes without RCCL
+                            between them, e.g. sharing one GPU under torch.distributed / gloo; staged through the host, for tests */
 int pg_comm_unique_id(uint8_t id[128]);
 pg_comm *pg_comm_create(int n_ranks, int rank, int device, const uint8_t id[128]);
 /* transport: PG_COMM_RCCL, PG_COMM_P2P, or -1 = RCCL when the devices are pairwise distinct (SOAPDENOVO2_AMD_EXCHANGE=p2p|rccl
@@ -366,6 +368,18 @@ int pg_comm_size(const pg_comm *comm);
 int pg_comm_transport(const pg_comm *comm);
 /* out[0] rounds, out[1] records sent, out[2] records received, out[3] records per owner region */
 int pg_comm_stats(const pg_comm *comm, uint64_t out[4]);
+/* the pipeline of pg_count_reads_sharded: out[0] device microseconds spent in the record exchanges (events on the exchange stream),
+ * [1] bytes sent to other ranks, [2] host waits (one a round), [3] cuts repeated with larger owner regions, [4] rounds, [5] records per
+ * owner region */
+int pg_comm_pipeline_stats(const pg_comm *comm, uint64_t out[8]);
+/* A variable all-to-all over HOST buffers brought by the caller: what goes to rank p lies at send + send_off[p] (send_cnt[p] bytes), what
+ * comes from rank q lands at recv + recv_off[q] (recv_cnt[q] bytes); arrays of n_ranks entries; returns 0 when done.  Collective. */
+typedef int (*pg_host_alltoallv_fn)(void *user, const void *send, const uint64_t *send_off, const uint64_t *send_cnt, void *recv,
+                                    const uint64_t *recv_off, const uint64_t *recv_cnt);
+pg_comm *pg_comm_create_host(int n_ranks, int rank, int device, pg_host_alltoallv_fn fn, void *user);
+/* Appends what pg_count_reads_sharded still has in flight (its last round travels when the call returns) to the partition streams of
+ * ctx and waits for it.  pg_finalize / pg_reset / pg_destroy do this by themselves; callers that look at the streams otherwise use it. */
+int pg_comm_flush(pg_ctx *ctx, pg_comm *comm, void *stream);
 
 /* d_send_counts[o] goes to rank o, d_recv_counts[q] comes from rank q (device memory, n_ranks words each). */
 int pg_exchange_counts(pg_comm *comm, const uint64_t *d_send_counts, uint64_t *d_recv_counts, void *stream);

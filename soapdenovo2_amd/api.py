@@ -127,6 +127,10 @@ def lib() -> C.CDLL:
     L.pg_comm_size.argtypes = [C.c_void_p]
     L.pg_comm_transport.argtypes = [C.c_void_p]
     L.pg_comm_stats.argtypes = [C.c_void_p, u64p]
+    L.pg_comm_pipeline_stats.argtypes = [C.c_void_p, u64p]
+    L.pg_comm_create_host.restype = C.c_void_p
+    L.pg_comm_create_host.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.pg_comm_flush.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     L.pg_exchange_counts.argtypes = [C.c_void_p, u64p, u64p, C.c_void_p]
     L.pg_exchange_records.argtypes = [C.c_void_p, u64p, u64p, C.c_uint64, C.c_int, u64p, u64p, u64p, u64p, C.c_void_p]
     L.pg_exchange_allreduce_u64.argtypes = [C.c_void_p, u64p, C.c_uint64, C.c_void_p]
@@ -152,7 +156,7 @@ EXPORTED_SYMBOLS = [
     "pg_export_take", "pg_export_take_ws", "pg_export_peek", "pg_records_checksum", "pg_sort_records_ws", "pg_device_free", "pg_set_counts", "pg_last_put", "pg_host_last_put_matters", "pg_comm_unique_id", "pg_comm_create", "pg_comm_create_local", "pg_comm_destroy", "pg_comm_rank", "pg_comm_size",
     "pg_comm_transport", "pg_comm_stats", "pg_exchange_counts", "pg_exchange_records", "pg_exchange_allreduce_u64",
     "pg_exchange_gather_records", "pg_count_reads_sharded", "pg_host_skm_cut", "pg_host_skm_expand",
-    "pg_host_emu_layout_static", "pg_graph_begin_device", "pg_host_emu_clip_tips", "pg_exchange_regroup_by_set", "pg_comm_regroup_stats", "pg_graph_begin_sharded", "pg_host_regroup_plan", "pg_host_bam_pair_state", "pg_device_scratch_offer", "pg_device_scratch_withdraw", "pg_host_emu_layout_growable", "pg_exchange_regroup_by_set_ws", "pg_host_edge_file_in_background", "pg_graph_add_packed_device", "pg_host_emu_home_slots",
+    "pg_host_emu_layout_static", "pg_graph_begin_device", "pg_host_emu_clip_tips", "pg_exchange_regroup_by_set", "pg_comm_regroup_stats", "pg_graph_begin_sharded", "pg_host_regroup_plan", "pg_host_bam_pair_state", "pg_device_scratch_offer", "pg_device_scratch_withdraw", "pg_host_emu_layout_growable", "pg_exchange_regroup_by_set_ws", "pg_host_edge_file_in_background", "pg_graph_add_packed_device", "pg_host_emu_home_slots", "pg_comm_pipeline_stats", "pg_comm_create_host", "pg_comm_flush",
 ]
 
 
@@ -320,7 +324,8 @@ def host_write_kmerfreq(hist: np.ndarray, prefix: str) -> None:
 # ---------------------------------------------------------------------------------------------------------
 # device operators (torch tensors carry the device memory; the kernels are the library's)
 # ---------------------------------------------------------------------------------------------------------
-PG_COMM_RCCL, PG_COMM_P2P = 0, 1
+PG_COMM_RCCL, PG_COMM_P2P, PG_COMM_HOST = 0, 1, 2
+HOST_A2A_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_void_p, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64))
 
 
 class Comm:
@@ -330,6 +335,34 @@ class Comm:
     def __init__(self, handle, owner=True):
         self.h = handle
         self.owner = owner
+        self._keep = None
+
+    @staticmethod
+    def host(n_ranks: int, rank: int, device: int, alltoallv) -> "Comm":
+        """One rank per process, the variable all-to-all brought by the caller (pg_comm_create_host): alltoallv(send: bytes-like
+        view, send_off, send_cnt, recv: writable view, recv_off, recv_cnt) over HOST memory, lists of n_ranks byte offsets / counts.
+        For ranks that cannot talk RCCL (e.g. several processes on one GPU under gloo): exchange staged through the host."""
+        def thunk(_user, send, soff, scnt, recv, roff, rcnt):
+            try:
+                so, sc = [int(soff[i]) for i in range(n_ranks)], [int(scnt[i]) for i in range(n_ranks)]
+                ro, rc = [int(roff[i]) for i in range(n_ranks)], [int(rcnt[i]) for i in range(n_ranks)]
+                s_len = max([o + c for o, c in zip(so, sc)] + [0])
+                r_len = max([o + c for o, c in zip(ro, rc)] + [0])
+                sv = (C.c_char * max(s_len, 1)).from_address(send)
+                rv = (C.c_char * max(r_len, 1)).from_address(recv)
+                alltoallv(memoryview(sv).cast("B"), so, sc, memoryview(rv).cast("B"), ro, rc)
+                return 0
+            except Exception as e:                                   # an exception must not unwind through the C frames
+                import sys, traceback
+                traceback.print_exc(file=sys.stderr)
+                return 1
+        fn = HOST_A2A_FN(thunk)
+        h = lib().pg_comm_create_host(n_ranks, rank, device, C.cast(fn, C.c_void_p), None)
+        if not h:
+            raise PgError("pg_comm_create_host failed: " + lib().pg_last_error().decode())
+        c = Comm(h)
+        c._keep = fn                                                 # the callback lives as long as the communicator
+        return c
 
     @staticmethod
     def unique_id() -> bytes:
@@ -363,7 +396,17 @@ class Comm:
 
     @property
     def transport(self) -> str:
-        return "rccl" if lib().pg_comm_transport(self.h) == PG_COMM_RCCL else "p2p"
+        return {PG_COMM_RCCL: "rccl", PG_COMM_P2P: "p2p", PG_COMM_HOST: "host"}[lib().pg_comm_transport(self.h)]
+
+    def pipeline_stats(self) -> dict:
+        out = np.zeros(8, dtype=np.uint64)
+        _check(lib().pg_comm_pipeline_stats(self.h, out.ctypes.data), "pg_comm_pipeline_stats")
+        return {"exchange_ms": int(out[0]) / 1000.0, "bytes_sent": int(out[1]), "host_waits": int(out[2]), "repeated_cuts": int(out[3]), "rounds": int(out[4]),
+                "owner_region_records": int(out[5])}
+
+    def flush(self, counter, stream=None) -> None:
+        """What the last round of counter.count_sharded left in flight is appended to its partition streams (pg_finalize does it too)."""
+        _check(lib().pg_comm_flush(counter.h, self.h, stream if stream is not None else counter._stream()), "pg_comm_flush")
 
     def stats(self) -> dict:
         out = np.zeros(4, dtype=np.uint64)

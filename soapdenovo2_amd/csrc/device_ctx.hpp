@@ -68,7 +68,13 @@ struct pg_ctx {
     uint64_t hint_kmers = 0;     // engine 2: k-mer occurrences to come, 0 = unknown (sizes the record pool)
     uint64_t batches = 0;        // batches taken since create / reset
     pg::E2 e2;
+    // the sharded pass 1 (exchange.hip) keeps its last round's records in flight when it returns: whatever consumes the partition
+    // streams next (pg_finalize, pg_reset, pg_destroy, ...) has them appended first
+    int (*pending_drain)(pg_ctx*, void* user, hipStream_t st) = nullptr;
+    void (*pending_detach)(pg_ctx*, void* user) = nullptr;       // the context goes away: whoever holds it forgets it
+    void* pending_user = nullptr;
 };
+inline int pg_ctx_drain(pg_ctx* c, hipStream_t st) { return c && c->pending_drain ? c->pending_drain(c, c->pending_user, st) : 0; }
 
 // engine 2 entry points (partition_kernels.hip)
 namespace pg {

@@ -131,6 +131,31 @@ struct pg_comm {
     std::vector<uint64_t> h_counts, h_rcounts;
     uint64_t sent_records = 0, recv_records = 0, rounds = 0;
     uint64_t regrouped_from = 0, regrouped_in = 0;   // distinct k-mers before / after pg_exchange_regroup_by_set
+    // PG_COMM_HOST: the caller's all-to-all over host buffers (bench.py over gloo: ranks in several processes that share a GPU)
+    pg_host_alltoallv_fn host_a2a = nullptr;
+    void* host_user = nullptr;
+    std::vector<char> h_stage_s, h_stage_r;
+    // ---- the pipeline of pg_count_reads_sharded: two slots (send region + receive region each), the exchange of round i on
+    // its own stream while the caller's stream cuts round i + 1 and appends round i - 1
+    struct Slot {
+        uint64_t* d_send_recs = nullptr; uint32_t* d_send_parts = nullptr;
+        uint64_t* d_recv_recs = nullptr; uint32_t* d_recv_parts = nullptr;
+        hipEvent_t routed = nullptr, exchanged = nullptr, t0 = nullptr, t1 = nullptr;
+        uint64_t total_in = 0;
+        bool pending = false;                 // exchanged (or on its way), not yet appended to the partition streams
+        bool timed = false;                   // t0 / t1 hold an exchange that has not been added to exchange_ms yet
+        bool used = false;                    // `exchanged` has been recorded at least once
+    } slot[2];
+    uint64_t pipe_cap = 0;                    // records per owner region (both slots)
+    int pipe_rw = 0;
+    hipStream_t xstream = nullptr;            // the exchange's stream
+    uint64_t* d_pairs = nullptr;              // [2 n] what this rank tells rank o: (records for o, this rank's largest region | error flag)
+    uint64_t* d_rpairs = nullptr;             // [2 n] the same from every rank
+    uint64_t* h_pairs = nullptr;              // pinned: [4 n] = own pairs, received pairs
+    uint64_t round_no = 0;
+    double exchange_ms = 0;                   // device time of the record exchanges (events on the exchange stream)
+    uint64_t host_syncs = 0, repeats = 0, bytes_sent = 0;
+    pg_ctx* pipe_ctx = nullptr;
 };
 
 namespace {
@@ -321,12 +346,21 @@ extern "C" int pg_comm_create_local(int n_ranks, const int* devices, int transpo
     return PG_OK;
 }
 
+namespace { void pipe_free(pg_comm* c); }
 extern "C" void pg_comm_destroy(pg_comm* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->nccl) g_rccl.CommDestroy(c->nccl);
     for (void* p : {(void*)c->d_send_recs, (void*)c->d_send_parts, (void*)c->d_counts, (void*)c->d_rcounts, (void*)c->d_recv_recs, (void*)c->d_recv_parts})
         if (p) (void)hipFree(p);
+    if (c->xstream) (void)hipStreamSynchronize(c->xstream);
+    if (c->pipe_ctx && c->pipe_ctx->pending_user == c) { c->pipe_ctx->pending_drain = nullptr; c->pipe_ctx->pending_detach = nullptr; c->pipe_ctx->pending_user = nullptr; }
+    pipe_free(c);
+    for (auto& sl : c->slot) for (hipEvent_t e : {sl.routed, sl.exchanged, sl.t0, sl.t1}) if (e) (void)hipEventDestroy(e);
+    if (c->d_pairs) (void)hipFree(c->d_pairs);
+    if (c->d_rpairs) (void)hipFree(c->d_rpairs);
+    if (c->h_pairs) (void)hipHostFree(c->h_pairs);
+    if (c->xstream) (void)hipStreamDestroy(c->xstream);
     if (c->grp) {
         bool last;
         { std::lock_guard<std::mutex> lk(c->grp->m); last = --c->grp->refs == 0; }
@@ -390,102 +424,305 @@ extern "C" int pg_exchange_records(pg_comm* c, const uint64_t* d_send_recs, cons
     return e2;
 }
 
-// One batch of pass 1 on n ranks (collective: every rank calls it once per round, with n_reads = 0 when it has nothing):
-// cut the batch into records grouped by owner, exchange counts, exchange records, append what arrived to the local partition
-// streams.  After the last round every rank runs pg_finalize on its own partitions.
+// ---- pass 1 on n ranks, pipelined -------------------------------------------------------------------------------------------
+// One call = one round (collective: every rank calls it once per round, with n_reads = 0 when it has nothing).  Round i:
+//   caller's stream:   cut batch i into records grouped by owner (send region of slot i & 1); pack (count, largest) pairs
+//   exchange stream:   [behind the records of round i - 1]  pairs all-to-all (2 words a peer)           --> ONE host wait a round
+//   host:              every rank's counts and flags: an error anywhere ends the round for all; a region that overflowed
+//                      anywhere makes all ranks grow alike and cut again
+//   caller's stream:   append round i - 1 (its records arrived while batch i was cut)
+//   exchange stream:   records + partition ids of round i, variable all-to-all, no host wait
+// so the records of a round travel while the next batch is cut and the previous one is appended; the last round is appended
+// by whatever consumes the partition streams next (pg_finalize) or by pg_comm_flush.  The reference's fan-out through shared
+// memory has no serial section either (prlHashReads.c:79-90).  Receive regions hold n x cap records -- what n full send
+// regions could bring -- so a round never has to size them; they grow with the send regions, all ranks alike.
+// A rank that fails still goes through the round's collective steps (with nothing to give) and says so in its flag word.
+namespace {
+
+constexpr uint64_t PIPE_ERR = 1ULL << 62;
+
+__global__ void pack_pairs_kernel(const uint64_t* counts, int n, uint64_t floor, uint64_t flag_or, uint64_t* pairs) {
+    uint64_t largest = floor;
+    for (int q = 0; q < n; q++) largest = counts[q] > largest ? counts[q] : largest;
+    for (int o = threadIdx.x; o < n; o += blockDim.x) { pairs[2 * o] = counts[o]; pairs[2 * o + 1] = largest | flag_or; }
+}
+
+void pipe_free(pg_comm* c) {
+    for (auto& sl : c->slot) {
+        for (void* p : {(void*)sl.d_send_recs, (void*)sl.d_send_parts, (void*)sl.d_recv_recs, (void*)sl.d_recv_parts}) if (p) (void)hipFree(p);
+        sl.d_send_recs = nullptr; sl.d_send_parts = nullptr; sl.d_recv_recs = nullptr; sl.d_recv_parts = nullptr;
+    }
+    c->pipe_cap = 0;
+}
+int pipe_alloc(pg_comm* c, uint64_t cap, int rw, FirstError& err) {
+    pipe_free(c);
+    const uint64_t n = (uint64_t)c->n;
+    for (auto& sl : c->slot) {
+        err.hip(hipMalloc((void**)&sl.d_send_recs, cap * n * rw * 8), "hipMalloc (send region)");
+        err.hip(hipMalloc((void**)&sl.d_send_parts, cap * n * 4), "hipMalloc (send region)");
+        err.hip(hipMalloc((void**)&sl.d_recv_recs, cap * n * rw * 8), "hipMalloc (receive region)");
+        err.hip(hipMalloc((void**)&sl.d_recv_parts, cap * n * 4), "hipMalloc (receive region)");
+    }
+    if (err.rc) { pipe_free(c); return err.rc; }
+    c->pipe_cap = cap; c->pipe_rw = rw;
+    return PG_OK;
+}
+int pipe_init(pg_comm* c, FirstError& err) {
+    if (c->xstream) return PG_OK;
+    err.hip(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking), "hipStreamCreate");
+    for (auto& sl : c->slot) {
+        err.hip(hipEventCreateWithFlags(&sl.routed, hipEventDisableTiming), "hipEventCreate");
+        err.hip(hipEventCreateWithFlags(&sl.exchanged, hipEventDisableTiming), "hipEventCreate");
+        err.hip(hipEventCreate(&sl.t0), "hipEventCreate");
+        err.hip(hipEventCreate(&sl.t1), "hipEventCreate");
+    }
+    err.hip(hipMalloc((void**)&c->d_pairs, sizeof(uint64_t) * 2 * (size_t)c->n), "hipMalloc");
+    err.hip(hipMalloc((void**)&c->d_rpairs, sizeof(uint64_t) * 2 * (size_t)c->n), "hipMalloc");
+    err.hip(hipHostMalloc((void**)&c->h_pairs, sizeof(uint64_t) * 4 * (size_t)c->n, hipHostMallocPortable), "hipHostMalloc");
+    return err.rc;
+}
+// the exchange of a slot has been timed: add it up (its events are complete: the caller waited for something behind them)
+void pipe_collect_time(pg_comm* c, pg_comm::Slot& sl) {
+    if (!sl.timed) return;
+    float ms = 0;
+    if (hipEventElapsedTime(&ms, sl.t0, sl.t1) == hipSuccess) c->exchange_ms += (double)ms;
+    sl.timed = false;
+}
+// append what a slot received to the partition streams (caller's stream, behind the slot's exchange)
+int pipe_ingest(pg_comm* c, pg_ctx* ctx, pg_comm::Slot& sl, hipStream_t st) {
+    if (!sl.pending) return PG_OK;
+    sl.pending = false;
+    if (hipStreamWaitEvent(st, sl.exchanged, 0) != hipSuccess) { pg_set_error("hipStreamWaitEvent failed"); return PG_ENODEV; }
+    const int rc = pg::e2_ingest(ctx, sl.d_recv_recs, sl.d_recv_parts, sl.total_in, st);
+    if (rc) return rc;
+    c->recv_records += sl.total_in;
+    ctx->batches++;
+    return PG_OK;
+}
+// everything in flight lands and is appended; the streams are idle afterwards
+int pipe_drain(pg_comm* c, pg_ctx* ctx, hipStream_t st) {
+    FirstError err;
+    err.hip(hipSetDevice(c->device), "hipSetDevice");
+    for (int k = 0; k < 2; k++) {
+        pg_comm::Slot& sl = c->slot[(c->round_no + (uint64_t)k) & 1];       // the older round first
+        if (sl.pending && ctx) { const int rc = pipe_ingest(c, ctx, sl, st); if (rc) err.set(rc, pg_last_error()); }
+        sl.pending = false;
+    }
+    if (c->xstream) err.hip(hipStreamSynchronize(c->xstream), "sync");
+    err.hip(hipStreamSynchronize(st), "sync");
+    for (auto& sl : c->slot) pipe_collect_time(c, sl);
+    return err.done();
+}
+int pipe_drain_hook(pg_ctx* ctx, void* user, hipStream_t st) { return pipe_drain((pg_comm*)user, ctx, st); }
+void pipe_detach_hook(pg_ctx* ctx, void* user) { pg_comm* c = (pg_comm*)user; if (c && c->pipe_ctx == ctx) c->pipe_ctx = nullptr; }
+
+// the pairs of this round: every rank's (records for me, its largest region | flags) into h_pairs[2n ..], own pairs into h_pairs[0 ..]
+int pipe_exchange_pairs(pg_comm* c, hipStream_t st, pg_comm::Slot& sl, FirstError& err) {
+    const int n = c->n;
+    const size_t bytes = sizeof(uint64_t) * 2 * (size_t)n;
+    if (c->transport == PG_COMM_RCCL || n == 1) {
+        // on the exchange stream, behind the previous round's records and behind this round's cut
+        err.hip(hipStreamWaitEvent(c->xstream, sl.routed, 0), "hipStreamWaitEvent");
+        if (n == 1) err.hip(hipMemcpyAsync(c->d_rpairs, c->d_pairs, bytes, hipMemcpyDeviceToDevice, c->xstream), "copy");
+        else { const int rc = alltoall_words(c, c->d_pairs, c->d_rpairs, 2, c->xstream); if (rc) err.set(rc, pg_last_error()); }
+        err.hip(hipMemcpyAsync(c->h_pairs, c->d_pairs, bytes, hipMemcpyDeviceToHost, c->xstream), "copy");
+        err.hip(hipMemcpyAsync(c->h_pairs + 2 * n, c->d_rpairs, bytes, hipMemcpyDeviceToHost, c->xstream), "copy");
+        err.hip(hipStreamSynchronize(c->xstream), "sync");
+        c->host_syncs++;
+        return err.rc;
+    }
+    // one process (mailbox of the group) or the caller's all-to-all: the pairs travel through host memory
+    err.hip(hipMemcpyAsync(c->h_pairs, c->d_pairs, bytes, hipMemcpyDeviceToHost, st), "copy");
+    err.hip(hipStreamSynchronize(st), "sync");
+    c->host_syncs++;
+    if (c->transport == PG_COMM_HOST) {
+        std::vector<uint64_t> off(n), cnt(n, 16);
+        for (int q = 0; q < n; q++) off[q] = 16 * (uint64_t)q;
+        if (c->host_a2a(c->host_user, c->h_pairs, off.data(), cnt.data(), c->h_pairs + 2 * n, off.data(), cnt.data()) != 0) err.set(PG_ENODEV, "the caller's all-to-all failed");
+        return err.rc;
+    }
+    LocalGroup* g = c->grp;
+    g->a[c->rank] = c->h_pairs;
+    g->barrier();
+    for (int q = 0; q < n; q++) { const uint64_t* theirs = (const uint64_t*)g->a[q]; c->h_pairs[2 * n + 2 * q] = theirs[2 * c->rank]; c->h_pairs[2 * n + 2 * q + 1] = theirs[2 * c->rank + 1]; }
+    g->barrier();
+    return err.rc;
+}
+
+// records + partition ids of the slot, variable all-to-all on the exchange stream; nobody waits for it here
+int pipe_exchange_records(pg_comm* c, pg_comm::Slot& sl, int rw, hipStream_t st, FirstError& err) {
+    const int n = c->n, me = c->rank;
+    const uint64_t cap = c->pipe_cap;
+    std::vector<uint64_t> so(n), sc(n), ro(n), rcn(n), so2(n), sc2(n), ro2(n), rc2(n);
+    uint64_t at = 0;
+    for (int q = 0; q < n; q++) {
+        so[q] = (uint64_t)q * cap * rw * 8; sc[q] = c->h_counts[q] * (uint64_t)rw * 8; ro[q] = at * rw * 8; rcn[q] = c->h_rcounts[q] * (uint64_t)rw * 8;
+        so2[q] = (uint64_t)q * cap * 4; sc2[q] = c->h_counts[q] * 4; ro2[q] = at * 4; rc2[q] = c->h_rcounts[q] * 4;
+        at += c->h_rcounts[q];
+    }
+    sl.total_in = at;
+    hipStream_t xs = c->xstream;
+    // behind this round's cut -- and with it behind the append of two rounds ago, which read this slot's receive region
+    err.hip(hipStreamWaitEvent(xs, sl.routed, 0), "hipStreamWaitEvent");
+    if (c->transport == PG_COMM_RCCL || n == 1) {
+        err.hip(hipEventRecord(sl.t0, xs), "hipEventRecord");
+        int rc = alltoallv_bytes(c, sl.d_send_recs, so.data(), sc.data(), sl.d_recv_recs, ro.data(), rcn.data(), xs);
+        if (rc) err.set(rc, pg_last_error());
+        rc = alltoallv_bytes(c, sl.d_send_parts, so2.data(), sc2.data(), sl.d_recv_parts, ro2.data(), rc2.data(), xs);
+        if (rc) err.set(rc, pg_last_error());
+        err.hip(hipEventRecord(sl.t1, xs), "hipEventRecord");
+    } else if (c->transport == PG_COMM_HOST) {
+        // staged through the host and the caller's all-to-all (test set-ups): device -> host, exchange, host -> device; blocking
+        uint64_t s_bytes = 0, r_bytes = 0;
+        std::vector<uint64_t> hso(n), hro(n), hsc(n), hrc(n);
+        for (int q = 0; q < n; q++) { hso[q] = s_bytes; hsc[q] = sc[q] + sc2[q]; s_bytes += hsc[q]; hro[q] = r_bytes; hrc[q] = rcn[q] + rc2[q]; r_bytes += hrc[q]; }
+        c->h_stage_s.resize(s_bytes + 8); c->h_stage_r.resize(r_bytes + 8);
+        err.hip(hipStreamWaitEvent(xs, sl.routed, 0), "hipStreamWaitEvent");
+        err.hip(hipEventRecord(sl.t0, xs), "hipEventRecord");
+        for (int q = 0; q < n; q++) {
+            if (sc[q]) err.hip(hipMemcpyAsync(c->h_stage_s.data() + hso[q], (const char*)sl.d_send_recs + so[q], sc[q], hipMemcpyDeviceToHost, xs), "copy");
+            if (sc2[q]) err.hip(hipMemcpyAsync(c->h_stage_s.data() + hso[q] + sc[q], (const char*)sl.d_send_parts + so2[q], sc2[q], hipMemcpyDeviceToHost, xs), "copy");
+        }
+        err.hip(hipStreamSynchronize(xs), "sync");
+        if (c->host_a2a(c->host_user, c->h_stage_s.data(), hso.data(), hsc.data(), c->h_stage_r.data(), hro.data(), hrc.data()) != 0) err.set(PG_ENODEV, "the caller's all-to-all failed");
+        for (int q = 0; q < n; q++) {
+            if (rcn[q]) err.hip(hipMemcpyAsync((char*)sl.d_recv_recs + ro[q], c->h_stage_r.data() + hro[q], rcn[q], hipMemcpyHostToDevice, xs), "copy");
+            if (rc2[q]) err.hip(hipMemcpyAsync((char*)sl.d_recv_parts + ro2[q], c->h_stage_r.data() + hro[q] + rcn[q], rc2[q], hipMemcpyHostToDevice, xs), "copy");
+        }
+        err.hip(hipEventRecord(sl.t1, xs), "hipEventRecord");
+        err.hip(hipStreamSynchronize(xs), "sync");                  // (the staging buffers are reused by the next round)
+    } else {
+        // one process: every rank has cut (the pairs' barrier came after each rank waited for its own cut); publish the regions and
+        // pull -- asynchronously, on the exchange stream
+        LocalGroup* g = c->grp;
+        struct Pub { const void* recs; const void* parts; uint64_t cap; };
+        Pub mine{sl.d_send_recs, sl.d_send_parts, cap};
+        g->a[me] = &mine;
+        g->b[me] = c->h_counts.data();
+        g->barrier();
+        err.hip(hipEventRecord(sl.t0, xs), "hipEventRecord");
+        for (int q = 0; q < n; q++) {
+            const Pub* theirs = (const Pub*)g->a[q];
+            if (rcn[q]) err.hip(hipMemcpyAsync((char*)sl.d_recv_recs + ro[q], (const char*)theirs->recs + (uint64_t)me * theirs->cap * rw * 8, rcn[q], hipMemcpyDefault, xs), "peer copy");
+            if (rc2[q]) err.hip(hipMemcpyAsync((char*)sl.d_recv_parts + ro2[q], (const char*)theirs->parts + (uint64_t)me * theirs->cap * 4, rc2[q], hipMemcpyDefault, xs), "peer copy");
+        }
+        err.hip(hipEventRecord(sl.t1, xs), "hipEventRecord");
+        g->barrier();                                               // (`mine` is on this stack)
+    }
+    err.hip(hipEventRecord(sl.exchanged, xs), "hipEventRecord");
+    sl.used = true; sl.timed = true; sl.pending = true;
+    for (int q = 0; q < n; q++) { c->sent_records += c->h_counts[q]; if (q != me) c->bytes_sent += sc[q] + sc2[q]; }
+    (void)st;
+    return err.rc;
+}
+
+}  // namespace
+
 extern "C" int pg_count_reads_sharded(pg_ctx* ctx, pg_comm* c, const uint64_t* d_packed, const uint64_t* d_word_off, const uint64_t* d_kmer_base,
                                       uint64_t n_reads, uint32_t uniform_len, uint64_t n_kmers, uint64_t ord_base, void* stream) {
     if (!ctx || !c || (n_reads && !d_packed)) { pg_set_error("null argument"); return PG_EINVAL; }
     if (ctx->engine != 2) { pg_set_error("pg_count_reads_sharded needs the partition engine"); return PG_ESTATE; }
     if (ctx->finalized) { pg_set_error("pg_count_reads_sharded after pg_finalize"); return PG_ESTATE; }
     if (ctx->device != c->device) { pg_set_error("context and communicator live on different devices"); return PG_EINVAL; }
+    if (c->pipe_ctx && c->pipe_ctx != ctx) { pg_set_error("the communicator is in use by another context (pg_comm_flush it first)"); return PG_ESTATE; }
     hipStream_t st = (hipStream_t)stream;
     X_TRY(hipSetDevice(c->device));
     const int n = c->n, rw = ctx->e2.g.rw;
     if (uniform_len) n_kmers = n_reads * (uint64_t)(uniform_len - ctx->K + 1);
     FirstError err;                                             // this rank's first failure; the round is finished regardless
+    pipe_init(c, err);
+    c->pipe_ctx = ctx;
+    ctx->pending_drain = &pipe_drain_hook; ctx->pending_detach = &pipe_detach_hook; ctx->pending_user = c;
     // a read of k k-mers makes about 2k / (w + 1) + 1 records; twice that, spread over n owners, plus slack
     const uint64_t est = 2 * n_kmers / (uint64_t)(ctx->e2.g.w + 1) + n_reads;
-    uint64_t want_cap = 2 * est / (uint64_t)n + 4096;
-    if (const char* e = getenv("PG_ROUTE_CAP")) { const long v = atol(e); if (v > 0) want_cap = std::max<uint64_t>(c->cap * 4 / 5, (uint64_t)v); }   // tests: start small, exercise the repeat
-    uint64_t total_in = 0;
-    // A batch dominated by one minimizer (low-complexity reads, adapter dimers, high-copy repeats) can send one owner far
-    // more than its even share: the cut is then repeated with regions as large as the largest count seen (the batch is
-    // still resident).  Whether to repeat is agreed among the ranks, so that all of them take the same number of steps.
+    uint64_t want_cap = n_reads ? 2 * est / (uint64_t)n + 4096 : 0;
+    if (const char* e = getenv("PG_ROUTE_CAP")) { const long v = atol(e); if (v > 0 && n_reads) want_cap = std::max<uint64_t>(c->pipe_cap * 4 / 5, (uint64_t)v); }   // tests: start small, exercise the repeat
+    pg_comm::Slot& sl = c->slot[c->round_no & 1];
+    pg_comm::Slot& prev = c->slot[(c->round_no & 1) ^ 1];
+    const bool one_process = c->transport == PG_COMM_P2P && n > 1;
+    if (c->pipe_cap && rw != c->pipe_rw) {                          // (a communicator that served the other k-mer width before)
+        (void)pipe_drain(c, ctx, st);
+        pipe_free(c);
+        for (auto& q : c->slot) q.used = false;
+    }
+    // The owner regions have ONE size on all ranks (a receive region holds what n full send regions can bring), and it only ever
+    // changes by agreement: every rank packs the largest count of its cut -- or the size it would like, when its batch asks for
+    // more than the regions hold (the first round: there are none yet) -- into its flag word, and when the largest word of the
+    // round exceeds the regions, all ranks drain what is in flight, grow to the same size and cut again (the batch is still
+    // resident).  A batch dominated by one minimizer (low-complexity reads, adapter dimers, high-copy repeats) sends one owner far
+    // more than its even share: same path.
     for (int attempt = 0;; attempt++) {
-        if (!err.rc && (want_cap > c->cap || rw != c->rw)) {
-            // (the previous round ended with every rank's pulls / receives complete, so nobody reads the old regions any more)
-            err.hip(hipStreamSynchronize(st), "sync");
-            if (c->d_send_recs) (void)hipFree(c->d_send_recs);
-            if (c->d_send_parts) (void)hipFree(c->d_send_parts);
-            c->d_send_recs = nullptr; c->d_send_parts = nullptr;
-            c->cap = 0; c->rw = rw;
-            const uint64_t cap = want_cap + want_cap / 4;
-            err.hip(hipMalloc((void**)&c->d_send_recs, cap * (uint64_t)n * rw * 8), "hipMalloc (send region)");
-            if (!err.rc) err.hip(hipMalloc((void**)&c->d_send_parts, cap * (uint64_t)n * 4), "hipMalloc (send region)");
-            if (!err.rc) c->cap = cap;
+        // the slot's send region was last read by the exchange of two rounds ago
+        if (sl.used) err.hip(hipStreamWaitEvent(st, sl.exchanged, 0), "hipStreamWaitEvent");
+        if (one_process && sl.used) {                             // ... by the PEERS' pulls of two rounds ago: all of them are done?
+            err.hip(hipEventSynchronize(sl.exchanged), "hipEventSynchronize");
+            c->grp->barrier();
         }
-        if (!err.rc) {
-            const int rc = pg::e2_route(ctx, d_packed, d_word_off, d_kmer_base, n_reads, uniform_len, ord_base, n, c->d_send_recs, c->d_send_parts, c->cap,
+        pipe_collect_time(c, sl);
+        const bool can_cut = !err.rc && c->pipe_cap != 0;
+        if (can_cut) {
+            const int rc = pg::e2_route(ctx, d_packed, d_word_off, d_kmer_base, n_reads, uniform_len, ord_base, n, sl.d_send_recs, sl.d_send_parts, c->pipe_cap,
                                         c->d_counts, st);
             if (rc) err.set(rc, pg_last_error());
         }
-        if (err.rc) (void)hipMemsetAsync(c->d_counts, 0, sizeof(uint64_t) * (size_t)n, st);       // nothing to give, but still in the round
-        err.hip(hipMemcpyAsync(c->h_counts.data(), c->d_counts, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost, st), "copy");
-        err.hip(hipStreamSynchronize(st), "sync");
-        uint64_t largest = 0;
-        for (int q = 0; q < n; q++) largest = std::max(largest, c->h_counts[q]);
-        const bool overflowed = !err.rc && largest > c->cap;
-        // one word per rank: an error outranks a repeat request, which carries the capacity wanted
-        uint64_t verdict = 0;
-        const uint64_t ERR = 1ULL << 62;
-        const int arc = agree_max(c, err.rc ? ERR : (overflowed ? largest : 0), &verdict, st);
-        if (arc) err.set(arc, pg_last_error());
-        if (verdict >= ERR || err.rc) {                             // some rank failed: nobody exchanges records this round
+        if (!can_cut || err.rc) (void)hipMemsetAsync(c->d_counts, 0, sizeof(uint64_t) * (size_t)n, st);   // nothing to give, but still in the round
+        const uint64_t wish = (!err.rc && want_cap > c->pipe_cap) ? want_cap : 0;
+        hipLaunchKernelGGL(pack_pairs_kernel, dim3(1), dim3(64), 0, st, c->d_counts, n, wish, err.rc ? PIPE_ERR : 0ULL, c->d_pairs);
+        err.hip(hipGetLastError(), "pack");
+        err.hip(hipEventRecord(sl.routed, st), "hipEventRecord");
+        pipe_exchange_pairs(c, st, sl, err);
+        // ---- what everybody said
+        uint64_t verdict = 0, largest_all = 0;
+        for (int q = 0; q < n; q++) {
+            c->h_counts[q] = c->h_pairs[2 * q];
+            c->h_rcounts[q] = c->h_pairs[2 * n + 2 * q];
+            const uint64_t f = c->h_pairs[2 * n + 2 * q + 1];
+            verdict |= f & PIPE_ERR;
+            largest_all = std::max(largest_all, f & ~PIPE_ERR);
+        }
+        if (verdict || err.rc) {                                    // some rank failed: nobody exchanges records this round
             err.set(PG_ENODEV, "pg_count_reads_sharded: another rank failed in this round");
             (void)pg::e2_clear_route_overflow(ctx, st);
+            (void)pipe_drain(c, ctx, st);
             return err.done();
         }
-        if (verdict == 0) break;                                    // every owner region held what it was given
-        if (attempt >= 2) { err.set(PG_ENOMEM, "pg_count_reads_sharded: an owner's send region overflowed three times"); return err.done(); }
-        want_cap = std::max(want_cap, verdict + verdict / 8 + 4096); // all ranks grow alike and cut again
-        const int crc = pg::e2_clear_route_overflow(ctx, st);
-        if (crc) err.set(crc, pg_last_error());
+        if (largest_all <= c->pipe_cap) break;                      // every owner region held what it was given (and nobody wants more)
+        if (attempt >= 3) { err.set(PG_ENOMEM, "pg_count_reads_sharded: an owner's send region overflowed three times"); (void)pipe_drain(c, ctx, st); return err.done(); }
+        // all ranks grow alike and cut again: first everything in flight lands (nobody pulls from or sends into the old regions)
+        c->repeats += c->pipe_cap ? 1 : 0;
+        { const int rc = pipe_drain(c, ctx, st); if (rc) err.set(rc, pg_last_error()); }
+        if (one_process) c->grp->barrier();
+        for (auto& q : c->slot) q.used = false;
+        if (c->pipe_cap) { const int crc = pg::e2_clear_route_overflow(ctx, st); if (crc) err.set(crc, pg_last_error()); }
+        pipe_alloc(c, largest_all + largest_all / 4 + 4096, rw, err);   // (a function of the agreed word alone: the same on every rank)
     }
-    for (int q = 0; q < n; q++) c->sent_records += c->h_counts[q];
-    {
-        // (agree_max used the count arrays as its scratch)
-        err.hip(hipMemcpyAsync(c->d_counts, c->h_counts.data(), sizeof(uint64_t) * (size_t)n, hipMemcpyHostToDevice, st), "copy");
-        const int rc = alltoall_words(c, c->d_counts, c->d_rcounts, 1, st);
-        if (rc) err.set(rc, pg_last_error());
-    }
-    err.hip(hipMemcpyAsync(c->h_rcounts.data(), c->d_rcounts, sizeof(uint64_t) * (size_t)n, hipMemcpyDeviceToHost, st), "copy");
-    err.hip(hipStreamSynchronize(st), "sync");
-    for (int q = 0; q < n; q++) total_in += c->h_rcounts[q];
-    if (!err.rc && total_in > c->recv_cap) {
-        if (c->d_recv_recs) (void)hipFree(c->d_recv_recs);
-        if (c->d_recv_parts) (void)hipFree(c->d_recv_parts);
-        c->d_recv_recs = nullptr; c->d_recv_parts = nullptr;
-        c->recv_cap = 0;
-        const uint64_t cap = total_in + total_in / 4 + 4096;
-        err.hip(hipMalloc((void**)&c->d_recv_recs, cap * (uint64_t)rw * 8), "hipMalloc (receive region)");
-        if (!err.rc) err.hip(hipMalloc((void**)&c->d_recv_parts, cap * 4), "hipMalloc (receive region)");
-        if (!err.rc) c->recv_cap = cap;
-    }
-    {   // a rank that could not make room says so before anybody sends to it
-        uint64_t verdict = 0;
-        const int arc = agree_max(c, err.rc ? 1 : 0, &verdict, st);
-        if (arc) err.set(arc, pg_last_error());
-        if (verdict || err.rc) { err.set(PG_ENODEV, "pg_count_reads_sharded: another rank failed in this round"); return err.done(); }
-    }
-    int rc = pg_exchange_records(c, c->d_send_recs, c->d_send_parts, c->cap, rw, c->h_counts.data(), c->h_rcounts.data(), c->d_recv_recs, c->d_recv_parts, st);
-    if (rc) return rc;
-    c->recv_records += total_in;
+    // ---- the previous round's records have arrived while this batch was cut: append them; then send this round's
+    { const int rc = pipe_ingest(c, ctx, prev, st); if (rc) err.set(rc, pg_last_error()); }
+    pipe_exchange_records(c, sl, rw, st, err);
     c->rounds++;
-    rc = pg::e2_ingest(ctx, c->d_recv_recs, c->d_recv_parts, total_in, st);
-    if (rc) return rc;
-    ctx->batches++;
-    return PG_OK;
+    c->round_no++;
+    if (getenv("PG_PIPE_SERIAL")) (void)pipe_drain(c, ctx, st);     // A/B: no overlap, every round complete when the call returns
+    return err.done();
+}
+
+// everything the sharded pass 1 still has in flight is appended to the partition streams of `ctx` (pg_finalize does this by itself)
+extern "C" int pg_comm_flush(pg_ctx* ctx, pg_comm* c, void* stream) {
+    if (!ctx || !c) { pg_set_error("null argument"); return PG_EINVAL; }
+    const int rc = pipe_drain(c, ctx, (hipStream_t)stream);
+    c->pipe_ctx = nullptr;
+    if (ctx->pending_user == c) { ctx->pending_drain = nullptr; ctx->pending_detach = nullptr; ctx->pending_user = nullptr; }
+    return rc;
+}
+
+// the caller brings the all-to-all (host buffers): ranks in several processes without RCCL between them -- e.g. sharing one GPU
+extern "C" pg_comm* pg_comm_create_host(int n_ranks, int rank, int device, pg_host_alltoallv_fn fn, void* user) {
+    if (n_ranks < 1 || n_ranks > 256 || rank < 0 || rank >= n_ranks || !fn) { pg_set_error("pg_comm_create_host: bad arguments"); return nullptr; }
+    if (hipSetDevice(device) != hipSuccess) { pg_set_error("pg_comm_create_host: hipSetDevice failed"); return nullptr; }
+    pg_comm* c = new pg_comm();
+    c->n = n_ranks; c->rank = rank; c->device = device; c->transport = PG_COMM_HOST;
+    c->host_a2a = fn; c->host_user = user;
+    if (comm_alloc_small(c) != PG_OK) { pg_comm_destroy(c); return nullptr; }
+    return c;
 }
 
 // ---- the regroup after pass 1 ("reference set id -> GPU") ----------------------------------------------------------
@@ -655,7 +892,15 @@ extern "C" int pg_exchange_gather_records(pg_comm* c, const uint64_t* d_records,
 
 extern "C" int pg_comm_stats(const pg_comm* c, uint64_t out[4]) {
     if (!c || !out) { pg_set_error("null argument"); return PG_EINVAL; }
-    out[0] = c->rounds; out[1] = c->sent_records; out[2] = c->recv_records; out[3] = c->cap;
+    out[0] = c->rounds; out[1] = c->sent_records; out[2] = c->recv_records; out[3] = c->pipe_cap ? c->pipe_cap : c->cap;
+    return PG_OK;
+}
+// out: 0 device microseconds of the record exchanges (events on the exchange stream), 1 bytes sent to other ranks, 2 host waits
+// (one a round), 3 repeated cuts, 4 rounds, 5 records per owner region
+extern "C" int pg_comm_pipeline_stats(const pg_comm* c, uint64_t out[8]) {
+    if (!c || !out) { pg_set_error("null argument"); return PG_EINVAL; }
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    out[0] = (uint64_t)(c->exchange_ms * 1000.0); out[1] = c->bytes_sent; out[2] = c->host_syncs; out[3] = c->repeats; out[4] = c->rounds; out[5] = c->pipe_cap;
     return PG_OK;
 }
 extern "C" int pg_comm_regroup_stats(const pg_comm* c, uint64_t out[2]) {

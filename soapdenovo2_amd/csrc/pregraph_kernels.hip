@@ -578,6 +578,7 @@ extern "C" int pg_reset(pg_ctx* c, void* stream) {
     if (!c) { g_err = "null context"; return PG_EINVAL; }
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(c->device));
+    (void)pg_ctx_drain(c, st);                                    // (records of a sharded round still in flight: let them land, then forget them)
     if (c->engine == 2) { int rc = e2_reset(c, st); if (rc) return rc; }
     else HIP_TRY(hipMemsetAsync(c->slots, 0xFF, ((size_t)1 << c->log2_slots) * slot_bytes(c->NW), st));
     HIP_TRY(hipMemsetAsync(c->ctr, 0, sizeof(DevCounters), st));
@@ -596,6 +597,8 @@ extern "C" int pg_set_autogrow(pg_ctx* c, int on) {
 extern "C" void pg_destroy(pg_ctx* c) {
     if (!c) return;
     hipSetDevice(c->device);
+    (void)pg_ctx_drain(c, nullptr);
+    if (c->pending_detach) c->pending_detach(c, c->pending_user);
     if (c->engine == 2) e2_destroy(c);
     if (c->slots) hipFree(c->slots);
     if (c->ctr) hipFree(c->ctr);
@@ -845,6 +848,7 @@ extern "C" int pg_finalize(pg_ctx* c, int delow, uint64_t hist_out[256], uint64_
     if (c->finalized) { g_err = "pg_finalize called twice"; return PG_ESTATE; }
     hipStream_t st = (hipStream_t)stream;
     HIP_TRY(hipSetDevice(c->device));
+    { const int rc = pg_ctx_drain(c, st); if (rc) return rc; }      // the last sharded round's records are appended first
     if (c->engine == 2) {
         int rc = e2_count(c, delow, set_last_put_out != nullptr, st);
         if (rc) return rc;

@@ -793,3 +793,26 @@ def test_cli_round3_switches_do_not_change_the_files(golden, tmp_path, name, tog
         for ext in ("kmerFreq", "preGraphBasic", "vertex", "preArc"):
             assert md5_file(pre + "." + ext) == want[ext], (t, ext, toggle)
         assert md5_gz_text(pre + ".edge.gz") == want["edge"], (t, toggle)
+
+
+def test_bench_two_ranks_share_the_gpu_over_gloo(tmp_path):
+    """The N > 1 bench path end to end without an 8-GPU node: `torch.distributed.run --nproc-per-node 2 bench.py --gpus 2 --share-gpu
+    --comm gloo` -- two PROCESSES, one rank each, both on this GPU; the library's own pipelined pg_count_reads_sharded (cut, flags,
+    records of round i travelling while batch i + 1 is cut, appends) over the host-staged transport (pg_comm_create_host + gloo
+    all-to-all), every occurrence conserved across the ranks, and the line carries the exchange's time, volume and the owner rule."""
+    import json, socket, sys
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--share-gpu", "--comm", "gloo", "--reads", "2000000", "--batch-reads", "500000", "--steps", "2", "--warmup", "1"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    j = json.loads(line)
+    assert j["n_gpus"] == 2 and j["conservation"]["ok"], j["conservation"]
+    assert j["conservation"]["kmer_occurrences_in"] == 2 * 2000000 * 88 == j["conservation"]["sum_of_coverage_histogram"]
+    assert j["exchange_ms"] > 0 and j["bytes_sent_per_rank"] > 0
+    ex = j["exchange"]
+    assert ex["transport"] == "host" and ex["rounds_per_step"] == 4 and ex["host_waits_per_round"] <= 1.5, ex      # one host wait a round (two in the first)
+    assert "minimizer partition mod 2" in j["config"]["parallelism"] and "reference set id mod 2" in j["config"]["parallelism"]
