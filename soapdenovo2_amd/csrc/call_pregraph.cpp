@@ -769,6 +769,11 @@ int run(int argc, char** argv, bool mer127) {
                 fprintf(stderr, "[cli] rank %d (device %d): %llu distinct k-mers after pass 1, %llu of %llu after the regroup by set; %llu rounds, %llu records sent, %llu received\n",
                         r, devices[r], (unsigned long long)n_before[r], (unsigned long long)sh_n[r], (unsigned long long)n_all, (unsigned long long)cs[0],
                         (unsigned long long)cs[1], (unsigned long long)cs[2]);
+                uint64_t ps[8];
+                pg_comm_pipeline_stats(comms[r], ps);
+                fprintf(stderr, "[cli] rank %d exchange: %.1f ms of record exchanges on their own stream (%.2f GB to other ranks), %llu host wait(s) in %llu round(s), %llu repeated cut(s), "
+                                "%llu records an owner region\n", r, (double)ps[0] / 1000.0, (double)ps[1] / 1e9, (unsigned long long)ps[2], (unsigned long long)ps[4],
+                        (unsigned long long)ps[3], (unsigned long long)ps[5]);
             }
             pg_comm_destroy(comms[r]);
         }

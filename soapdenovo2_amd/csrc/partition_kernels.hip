@@ -786,6 +786,10 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                   for (uint32_t tile = (uint32_t)wave;;) {
                     const uint32_t vlane = VT == 1 ? threadIdx.x : tile * 64u + (uint32_t)lane;
                     if (VT != 1 && (tile * 64u * share >= total_occ || __hip_atomic_load(&aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) break;
+                    // opt bit 1: the wave's next tile is asked for NOW and looked at after this one (the returned LDS atomic's latency behind
+                    // the tile's work; a wave asks for one tile more than it works on, which is past the end)
+                    unsigned int nt_early = 0;
+                    if (VT != 1 && (opt & 2) && lane == 0) nt_early = atomicAdd(&tile_ctr, 1u);
                     uint32_t idx = min(total_occ, vlane * share);
                     const uint32_t idx1 = min(total_occ, idx + share);
                     if (idx < idx1) {
@@ -835,8 +839,8 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                         }
                     }
                     if (VT == 1) break;
-                    unsigned int nt = 0;
-                    if (lane == 0) nt = atomicAdd(&tile_ctr, 1u);
+                    unsigned int nt = nt_early;
+                    if (!(opt & 2) && lane == 0) nt = atomicAdd(&tile_ctr, 1u);
                     tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)nt);
                   }
                 }
