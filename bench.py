@@ -85,10 +85,17 @@ def whole_command(args, cores):
     td = tempfile.mkdtemp(prefix="pgbench_", dir=os.environ.get("PG_BENCH_TMP"))
     try:
         t0 = time.time()
-        codes = synth.gpu_reads_codes(args.genome, n, args.read_len, args.err, args.seed + 1)
         fq, cfg = os.path.join(td, "reads.fq"), os.path.join(td, "lib.cfg")
-        synth.write_fastq_fast(fq, codes)
-        del codes
+        gen = os.path.join(ROOT, "soapdenovo2_amd", "bin", "synth_fastq")
+        if os.path.exists(gen):
+            # the C++ generator (scripts/synth_fastq.cpp): the same read distribution, and no GPU context in THIS process while the
+            # executable runs -- a child that allocates its tens of gigabytes beside a parent holding a context on the same GPU waited
+            # 2.5 - 4 s for them in round 3's driver run (device_context_s), 0.03 s on its own
+            subprocess.check_call([gen, fq, str(args.genome), str(n), str(args.read_len), str(args.err), str(args.seed + 1)])
+        else:
+            codes = synth.gpu_reads_codes(args.genome, n, args.read_len, args.err, args.seed + 1)
+            synth.write_fastq_fast(fq, codes)
+            del codes
         synth.write_config(cfg, fq, args.read_len)
         os.sync()                                   # the generator's write-back is not part of the command being timed
         t_gen = time.time() - t0
@@ -307,6 +314,23 @@ def main():
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE {world}"
     if args.share_gpu:
         local = 0
+    # The executable's runs (and the reference's, = the CPU baseline) come FIRST, before this process has a context on the GPU: a child
+    # that allocates its record pool beside a parent holding a context on the same GPU pays seconds for it (round 3's driver run:
+    # device_context_s 2.5 - 4 s; on its own 0.03 s) -- that is the neighbour's cost, not the command's.  Nothing of this touches
+    # the timed region below.
+    commands = {}
+    if world == 1 and args.engine == 2 and not args.no_cpu_baseline and args.whole_reads > 0:
+        # the reference's workers each scan the whole k-mer buffer (prlHashReads.c:79-90), so its pass 1 stops scaling long before a
+        # 100+-core host is used up (-p 256 was slower than -p 16 in round 1); it runs at the same -p as the executable, which also
+        # makes its files comparable byte for byte
+        wc, cpu = whole_command(args, args.sets)
+        commands["whole_command"] = wc
+        if cpu:
+            commands["cpu_baseline"] = cpu
+        if not args.no_big:
+            big = big_command(args)
+            if big:
+                commands.update(big)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
@@ -368,24 +392,6 @@ def main():
         log2_slots = 20
         while (1 << log2_slots) * 0.6 < expected:
             log2_slots += 1
-    # The executable's runs (and the reference's, = the CPU baseline) come FIRST, on a GPU nobody has used yet in this process: a
-    # process that starts right after another one has released a hundred GB of device memory pays seconds for its own allocations
-    # (measured: the 4 M-read command 5.1 s behind the timed pass, 1.4 s on its own) -- that is the neighbour's cost, not the
-    # command's.  Nothing of this touches the timed region below.
-    commands = {}
-    if world == 1 and args.engine == 2 and not args.no_cpu_baseline and args.whole_reads > 0:
-        # the reference's workers each scan the whole k-mer buffer (prlHashReads.c:79-90), so its pass 1 stops scaling long before a
-        # 100+-core host is used up (-p 256 was slower than -p 16 in round 1); it runs at the same -p as the executable, which also
-        # makes its files comparable byte for byte
-        wc, cpu = whole_command(args, args.sets)
-        commands["whole_command"] = wc
-        if cpu:
-            commands["cpu_baseline"] = cpu
-        if not args.no_big:
-            big = big_command(args)
-            if big:
-                commands.update(big)
-        torch.cuda.empty_cache()
     packed = gen_packed_reads(torch, dev, args.genome, n_reads, L, args.err, args.seed + 1000 * rank)
     engine = args.engine
     mer127 = args.mer127 or K > 63

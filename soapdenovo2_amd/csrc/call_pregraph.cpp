@@ -680,7 +680,9 @@ int run(int argc, char** argv, bool mer127) {
         // ---- pass 1 on n_ranks GPUs: cut + all-to-all + append per batch, then every rank counts its own partitions
         std::vector<pg_ctx*> ctxs(n_ranks, nullptr);
         std::vector<pg_comm*> comms(n_ranks, nullptr);
+        mark("input files sized");
         if (pg_comm_create_local(n_ranks, devices.data(), -1, comms.data()) != PG_OK) die("pg_comm_create_local");
+        mark("communicator created");
         fprintf(stderr, "%d k-mer set(s), pass 1 on %d rank(s) (HIP devices", o.sets, n_ranks);
         for (int r = 0; r < n_ranks; r++) fprintf(stderr, " %d", devices[r]);
         fprintf(stderr, "), records exchanged by %s.\n", pg_comm_transport(comms[0]) == PG_COMM_RCCL ? "RCCL all-to-all" : "peer copies");
@@ -694,15 +696,19 @@ int run(int argc, char** argv, bool mer127) {
             ctxs[r] = pg_create_sized(devices[r], K, mer127 ? 1 : 0, o.sets, ls, 2, est_kmers + 1);
             if (!ctxs[r]) die("pg_create");
         }
+        mark("device context created (HIP start-up, record pools, export arrays of all ranks)");
         {
             ShardedPass1 p1(ctxs, comms, devices, K, batch_words, batch_reads);
+            mark("pinned batch buffers allocated");
             p1.keep_reads(keep_budget);
             for (const pg::InputFile& f : files) {
                 fprintf(stderr, "Import reads from file:\n %s\n", f.path1.c_str());
                 if (!f.path2.empty()) fprintf(stderr, "Import reads from file:\n %s\n", f.path2.c_str());
                 n_records += pg::stream_reads(f, p1);
             }
+            mark("files read");
             if (!p1.finish_ok()) { fprintf(stderr, "pass 1 failed on a rank\n"); exit(-1); }
+            mark("last round cut and sent on every rank");
             total_kmers = p1.total_kmers();
             have_kept = p1.take_kept(kept);
         }

@@ -648,8 +648,19 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
         uint64_t* stage = (uint64_t*)rl2[sb] + LIST_WORDS;
         // The export slots come from one global counter every workgroup of the grid adds to: its answer takes a while.  The
         // group's first lane asks now and looks at the answer only after its share of the finalisation.
+        // (Written as an instruction: the compiler's atomic optimizer turns an atomicAdd on a uniform address into "one lane adds, the
+        //  others read its answer through readfirstlane" -- which waits for the answer on the spot (s_waitcnt vmcnt(0) right behind the
+        //  atomic in round 3's code: workgroup thread 0 stood there for a round trip to the memory side while fifteen waves went on to
+        //  the barrier and waited for it).  The wait is the s_waitcnt below, in front of the only use.)
+        // The asker is the group's LAST lane: its wave has no slot to finalise unless the set is nearly full, so nothing of its own
+        // (the compiler guards every read of a window buffer with a wait for the global_load_lds traffic, which would wait for the
+        // atomic too) stands between the question and the answer; the other waves finalise meanwhile.
         unsigned long long ticket = 0;
-        if (gtid == 0 && c0 == 0) ticket = atomicAdd(&ctr->n_export, (unsigned long long)n_live);
+        if (gtid == GS - 1 && c0 == 0) {
+            unsigned long long* const addr = &ctr->n_export;
+            const unsigned long long add = (unsigned long long)n_live;
+            asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0" : "=v"(ticket) : "v"(addr), "v"(add) : "memory");
+        }
         for (unsigned int i = gtid; i < cn; i += GS) {
             const int si = live_list[c0 + i];
             unsigned int cl[4], cr[4];
@@ -696,7 +707,10 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
             o[NW] = (uint64_t)A | ((uint64_t)B << 32);
             o[NW + 1] = ((uint64_t)sid << PG_ORD_BITS) | (first & PG_ORD_MASK);
         }
-        if (gtid == 0 && c0 == 0) out_base = ticket;
+        if (gtid == GS - 1 && c0 == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket) :: "memory");
+            out_base = ticket;
+        }
     };
     auto e_copy = [&](auto gs_, int gtid, int sb, unsigned int c0, unsigned int cn) {
         constexpr int GS = decltype(gs_)::value;
@@ -709,22 +723,34 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     };
     const std::integral_constant<int, THREADS> whole{};
 
+    // (the chunk list of a partition: its first `direct` chunks lie at computed addresses, the others come from a table.  Only the
+    //  table entry is asked for ahead of time -- into a register nothing else writes: were the computed id and the loaded one the
+    //  same register, the compiler would make the computing lanes wait for every memory operation in flight before they may overwrite
+    //  it, the previous partition's export stores included, at the top of every partition)
+    auto chunk_ask = [&](uint32_t pid, uint32_t ci) -> uint32_t {
+        uint32_t v = 0;
+        if (ci >= e.direct && ci - e.direct < e.maxc) v = e.chunk_tbl[(uint64_t)pid * e.maxc + (ci - e.direct)];
+        return v;
+    };
+    auto chunk_take = [&](uint32_t pid, uint32_t ci, uint32_t asked) -> uint32_t {
+        return ci < e.direct ? (uint32_t)((((uint64_t)ci << e.g.log2_parts) + pid) + 1) : asked;
+    };
     uint32_t pf_nrec = 0, pf_cid = 0;
     // (the record count is the same for every lane, which would make it a scalar load -- and scalar loads are waited for at
     //  the very next barrier together with the LDS traffic (lgkmcnt); through a vector register it stays in flight until used)
     auto peek_cursor = [&](uint32_t p) { const uint32_t* q = e.cursor + p; asm volatile("" : "+v"(q)); return *q; };
     if (blockIdx.x < parts) {
         pf_nrec = peek_cursor(blockIdx.x);
-        if (threadIdx.x < nchunks) pf_cid = chunk_id_of(e, blockIdx.x, threadIdx.x);
+        if (threadIdx.x < nchunks) pf_cid = chunk_ask(blockIdx.x, threadIdx.x);
     }
     int b = 0, cl = 0;                                                    // the current window's buffer, the current partition's chunk list
     bool staged = false;                                                  // its first window is already on its way into rl2[b] (asked for by the previous emit)
     for (uint32_t pid = blockIdx.x; pid < parts; pid += gridDim.x) {
-        const uint32_t nrec = pf_nrec, my_cid = pf_cid;
+        const uint32_t nrec = pf_nrec, my_cid = chunk_take(pid, threadIdx.x, pf_cid);
         const uint32_t nxt = pid + gridDim.x;
         if (nxt < parts) {
             pf_nrec = peek_cursor(nxt);
-            if (threadIdx.x < nchunks) pf_cid = chunk_id_of(e, nxt, threadIdx.x);
+            if (threadIdx.x < nchunks) pf_cid = chunk_ask(nxt, threadIdx.x);
         }
         const uint32_t usable = min(nrec, nchunks * e.rpc);              // an overfull partition was flagged by K1
         my_records += usable;
@@ -846,7 +872,11 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 }
                 K2_TICK(4);
                 // the next partition's chunk list, for the prepare that runs beside this partition's last emit
-                if (threadIdx.x < nchunks) chunk_ids2[cl ^ 1][threadIdx.x] = pf_cid;
+                if (threadIdx.x < nchunks) {
+                    uint32_t asked = pf_cid;
+                    asm volatile("" : "+v"(asked));                          // (looked at here, not where it was asked for: see usable_next below)
+                    chunk_ids2[cl ^ 1][threadIdx.x] = chunk_take(nxt, threadIdx.x, asked);
+                }
                 if (threadIdx.x == 0) s_nlive = 0;                          // (e_list_any adds to it; its last readers are a barrier back)
                 K2_SYNC();                                                  // the window and its tables are rewritten by the next one
                 // (every wave is past the tile loop: the counter starts over for the next occurrence phase -- the next window,
@@ -876,7 +906,13 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     top += 2;
                 }
             } else {
-                const uint32_t usable_next = nxt < parts ? min(pf_nrec, nchunks * e.rpc) : 0u;
+                // (the next partition's record count was asked for at the top of this partition and is looked at HERE: without the
+                //  empty instruction the compiler computes usable_next in front of the range loop, i.e. right behind the load -- every
+                //  wave of the workgroup then waits out a trip to HBM, and the acknowledgements of the previous partition's export
+                //  stores with it, at every partition's start: the "partition header" phase of round 3's profile)
+                uint32_t pfn = pf_nrec;
+                asm volatile("" : "+v"(pfn));
+                const uint32_t usable_next = nxt < parts ? min(pfn, nchunks * e.rpc) : 0u;
                 // The last emit of a partition borrows its own window (dead now) and, first of all, asks for the next partition's
                 // first window: global_load_lds copies 16 bytes a lane straight into the other buffer, no registers, so the
                 // loads fly during the whole emit (p_stage_async / p_unpack).  Earlier emits (more key ranges to come) borrow
@@ -1326,6 +1362,8 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     if (const char* v = getenv("PG_K2_VT")) vt = atoi(v);                 // 1 = static shares (round 2), 2 / 4 = tiles of virtual lanes with a share table (round 3: 177.8 -> 168.7 ms)
     if (const char* v = getenv("PG_DBG")) dbg = atoi(v);
     if (const char* v = getenv("PG_K2CFG")) cfg = atoi(v);
+    int k2win = 512;                                                      // records a window (PG_K2_WIN=256: the 127-mer flavour's partitions hold ~60 records)
+    if (const char* v = getenv("PG_K2_WIN")) k2win = atoi(v);
     int k2opt = 1;                                                        // bit 0: live slots listed in any order (162.9 -> 157.0 ms; with vt = 0: 148.9 ms)
     if (const char* v = getenv("PG_K2_OPT")) k2opt = atoi(v);
     bool ks = true;                                                       // the instantiations for K = 31 / 63 / 127 (PG_K2_KS=0: the general kernel)
@@ -1352,6 +1390,7 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
         } else {
             if (cfg == 0 && (dbg & 2) && vt == 0) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, true, 0>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
             else if (cfg == 0 && (dbg & 2)) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, true, 4>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
+            else if (cfg == 0 && vt == 0 && ks && c->K == 127 && k2win == 256) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 256, false, 0, 127>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
             else if (cfg == 0 && vt == 0 && ks && c->K == 127) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false, 0, 127>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
             else if (cfg == 0 && vt == 0) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false, 0>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
             else if (cfg == 0 && vt == 4 && ks && c->K == 127) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false, 4, 127>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);

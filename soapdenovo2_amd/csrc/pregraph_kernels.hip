@@ -506,6 +506,7 @@ static int parts_for_kmers(uint64_t total_kmers, int nw) {
     // the NEAREST power of two: at 200 M x 150 bp, K = 63 (17.6 G occurrences) 2^21 partitions of 8.4 k beat 2^22 of 4.2 k by 7 % in K2
     // (the 127-mer flavour keeps rounding up: 2^22 partitions of 1.1 k beat 2^21 of 2.3 k by 10 % there)
     while (lp < 24 && (double)((uint64_t)(nw == 4 ? 2048 : 8192) << lp) * (nw == 4 ? 1.0 : 1.4142) < (double)total_kmers) lp++;
+    if (const char* v = getenv("PG_PARTS_SHIFT")) lp = std::max(8, std::min(24, lp + atoi(v)));      // A/B runs: twice / half the partitions
     return lp;
 }
 extern "C" pg_ctx* pg_create_sized(int device, int K, int mer127, int n_sets, int log2_slots, int engine, uint64_t expected_kmers);

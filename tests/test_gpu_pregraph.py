@@ -560,7 +560,9 @@ def test_cli_sharded_matches_reference_files(golden, tmp_path, name, devices):
                  re.finditer(r"graph lane (\d+) \(device \d+\): pass 2 threaded (\d+) read\(s\) in (\d+) batch\(es\), \d+ distinct pre-arc\(s\); (\d+) per-set scan", log)]
         assert [l[0] for l in lanes] == list(range(n_ranks)), log[-3000:]
         n_reads = sum(l[1] for l in lanes)
-        assert n_reads == c["N"] and all(l[2] >= 1 for l in lanes)
+        assert n_reads == c["N"]
+        if c["N"] >= n_ranks * 7000:                                       # (at least a batch of 7000 reads for every lane)
+            assert all(l[2] >= 1 for l in lanes), lanes
         assert max(l[1] for l in lanes) <= n_reads / n_ranks + 2 * 7000, lanes
         owners = min(P, n_ranks)
         assert sum(1 for l in lanes if l[3] > 0) == owners, lanes              # a lane that owns a set scanned it; a lane that owns none scanned nothing
