@@ -627,6 +627,10 @@ int run(int argc, char** argv, bool mer127) {
             double bases = (double)st.st_size * ((f.type == 2 || f.type == 6) ? 0.5 : 1.0);
             if (path->size() > 3 && path->compare(path->size() - 3, 3, ".gz") == 0) bases *= 4.0;
             if (f.type == 4) bases *= 3.0;                              // BAM: 4-bit bases + qualities, deflated
+            // a read of l <= max_rd_len bases has l - K + 1 k-mers: at most (max_rd_len - K + 1) / max_rd_len of its bases
+            // (what is sized from this -- the record pool, the partition count, the export array -- is handed out cleared by
+            //  the driver, by the gigabyte: an estimate twice too large cost the start of the command up to two seconds)
+            if (max_read_len > K) bases *= (double)(max_read_len - K + 1) / (double)max_read_len;
             est_kmers += (uint64_t)bases;
         }
     // The device export array: room for one distinct k-mer per 6 occurrences (it is enlarged and the partitions are

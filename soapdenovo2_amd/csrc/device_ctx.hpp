@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <string>
+#include <thread>
 
 #include "kmer.hpp"
 #include "skm.hpp"
@@ -51,6 +52,11 @@ struct E2 {
     uint64_t out_capacity = 0;    // records
     bool counted = false;
     uint64_t est_chunks = 0;      // host estimate of chunks in use (pool growth without a sync per batch)
+    // The export array is needed when the partitions are counted, not while the batches are cut: it is allocated by a thread of its
+    // own (tens of gigabytes of device memory take the driver up to seconds to hand out on some boxes -- it clears what it gives),
+    // joined by whoever needs `out` first (e2_count, e2_destroy).
+    std::thread* out_thread = nullptr;
+    int out_err = 0;              // hipError_t of that allocation
 };
 
 }  // namespace pg

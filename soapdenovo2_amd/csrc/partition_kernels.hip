@@ -1070,7 +1070,20 @@ int e2_create(pg_ctx* c) {
     E2_TRY(hipMalloc(&s.cursor, parts * sizeof(uint32_t)));
     E2_TRY(hipMalloc(&s.chunk_tbl, parts * s.maxc * sizeof(uint32_t)));
     E2_TRY(hipMalloc(&s.pool, s.pool_chunks * chunk_bytes + 64));
-    E2_TRY(hipMalloc(&s.out, std::max<uint64_t>(out_bytes, 64)));
+    s.out = nullptr; s.out_err = 0;
+    if (getenv("PG_EXPORT_ASYNC") && atoi(getenv("PG_EXPORT_ASYNC")) == 0) E2_TRY(hipMalloc(&s.out, std::max<uint64_t>(out_bytes, 64)));
+    else {
+        const int dev = c->device;
+        const uint64_t bytes = std::max<uint64_t>(out_bytes, 64);
+        E2* const sp = &s;
+        s.out_thread = new std::thread([sp, dev, bytes] {
+            void* p = nullptr;
+            hipError_t e = hipSetDevice(dev);
+            if (e == hipSuccess) e = hipMalloc(&p, bytes);
+            sp->out = (uint64_t*)p;
+            sp->out_err = (int)e;
+        });
+    }
     E2_TRY(hipMemset(s.cursor, 0, parts * sizeof(uint32_t)));
     E2_TRY(hipMemset(s.chunk_tbl, 0, parts * s.maxc * sizeof(uint32_t)));
     s.counted = false;
@@ -1078,8 +1091,21 @@ int e2_create(pg_ctx* c) {
     return PG_OK;
 }
 
+// the export array is there (or could not be had)
+static int e2_join_out(pg_ctx* c) {
+    E2& s = c->e2;
+    if (s.out_thread) { s.out_thread->join(); delete s.out_thread; s.out_thread = nullptr; }
+    if (s.out_err) {
+        pg_set_error(std::string("partition engine: the export array could not be allocated: ") + hipGetErrorString((hipError_t)s.out_err));
+        return (hipError_t)s.out_err == hipErrorOutOfMemory ? PG_ENOMEM : PG_ENODEV;
+    }
+    return PG_OK;
+}
+
 void e2_destroy(pg_ctx* c) {
     E2& s = c->e2;
+    (void)e2_join_out(c);
+    (void)hipSetDevice(c->device);
     if (s.cursor) (void)hipFree(s.cursor);
     if (s.chunk_tbl) (void)hipFree(s.chunk_tbl);
     if (s.pool) (void)hipFree(s.pool);
@@ -1345,6 +1371,7 @@ int e2_set_counts(pg_ctx* c, uint64_t out[256], hipStream_t st) {
 
 int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     E2& s = c->e2;
+    { const int rc = e2_join_out(c); if (rc) return rc; }
     const SetParams sp{(uint32_t)c->P, set_bias((uint32_t)c->P)};
     E2_TRY(hipMemsetAsync(&c->ctr->n_export, 0, sizeof(unsigned long long), st));
     E2_TRY(hipMemsetAsync(c->ctr->hist, 0, sizeof(unsigned long long) * 256, st));
