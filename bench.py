@@ -699,7 +699,7 @@ def main():
                 try:
                     tj = json.load(open(tf))
                     ipr = tj.get("skm_count_kernel_valu_insts_per_read_K127" if mer127 else "skm_count_kernel_valu_insts_per_read")
-                    if ipr:
+                    if ipr and L == 150 and K in (63, 127) and abs(args.genome * 300 - n_reads * L) <= 0.5 * n_reads * L:   # (the counters were taken at this read geometry and coverage)
                         issue_peak = 256 * 4 * 2.4e9 / 4
                         extra["valu_issue_frac"] = ipr * n_reads / issue_peak / k2_s
                         extra["valu_issue_note"] = (f"{ipr:.0f} wave-level vector instructions per read (SQ_INSTS_VALU, {tj.get('sq_source', 'profiles/')}) x reads / "
