@@ -196,7 +196,7 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_seg_kernel(ReadsArg a, E2De
         if (r >= nr) continue;
         const int j0 = seg * S, cnt = min(S, kpr - j0);
         uint32_t pid[S];
-        const uint32_t mk = tile_segment<S, W>(v0 + r * npad, np, j0, cnt, w, e.g.nmax, e.g.log2_parts, pid);
+        const uint32_t mk = tile_segment<S, W>(v0 + r * npad, np, j0, cnt, w, e.g.nmax, e.g.part_mul, pid);
         smask[r * nseg + seg] = mk;
 #pragma unroll
         for (int i = 0; i < S; i++) pids[r * kpad + j0 + i] = pid[i];
@@ -1024,6 +1024,8 @@ int e2_create(pg_ctx* c) {
     if (c->hint_log2_parts >= 0) s.log2_parts = std::max(8, std::min(24, c->hint_log2_parts));
     if (const char* v = getenv("PG_LOG2_PARTS")) s.log2_parts = std::max(4, std::min(24, atoi(v)));
     s.g = skm_geometry(c->K, s.log2_parts, c->NW);
+    // PG_PARTS_EFF_PCT: only that share of the partition ids is used (the hash is scaled to it): partitions between two powers of two
+    if (const char* v = getenv("PG_PARTS_EFF_PCT")) { const int pct = atoi(v); if (pct >= 50 && pct <= 100) s.g.part_mul = (uint32_t)(((uint64_t)1 << s.log2_parts) * (uint64_t)pct / 100); }
     s.rpc = 128;
     if (const char* v = getenv("PG_RPC")) { const int q = atoi(v); if (q == 16 || q == 32 || q == 64 || q == 128) s.rpc = (uint32_t)q; }
     const uint64_t parts = (uint64_t)1 << s.log2_parts;
@@ -1038,7 +1040,7 @@ int e2_create(pg_ctx* c) {
     {
         // default: with the input size known, room for 1.25x the mean partition at computed addresses (at most eight chunks a
         // partition and a quarter of the device memory); PG_DIRECT_CHUNKS=M sets it, 0 switches it off
-        int q = c->hint_kmers ? (int)(((double)c->hint_kmers * 2.0 / (double)(s.g.w + 1) / (double)parts * 1.25 + (double)s.rpc - 1) / (double)s.rpc) : 0;
+        int q = c->hint_kmers ? (int)(((double)c->hint_kmers * 2.0 / (double)(s.g.w + 1) / (double)s.g.part_mul * 1.25 + (double)s.rpc - 1) / (double)s.rpc) : 0;
         q = std::min(q, 8);
         if (const char* v = getenv("PG_DIRECT_CHUNKS")) { const int e = atoi(v); if (e >= 0) q = std::min(e, 192); }
         size_t free_b0 = 0, total_b0 = 0;

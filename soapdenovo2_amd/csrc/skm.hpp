@@ -25,7 +25,9 @@ struct SkmGeom {
     int pw;         // payload words per record
     int rw;         // record words = 1 + pw
     int nmax;       // max k-mers per record
-    int log2_parts; // partitions = 1 << log2_parts
+    int log2_parts; // partition ids = 1 << log2_parts (what the cursors, chunk lists and the counting grid are sized for)
+    uint32_t part_mul;  // partitions in use <= 1 << log2_parts: pid = (hash * part_mul) >> 32.  1 << log2_parts: all of them (= the
+                        // top log2_parts bits of the hash); fewer: every partition holds more, the ids above part_mul stay empty
 };
 
 // nw = words per k-mer of the build flavour (2 or 4): fixes the record size so kernels can keep it static
@@ -43,6 +45,7 @@ PG_HD SkmGeom skm_geometry(int K, int log2_parts, int nw = 2) {
     g.nmax = 32 * g.pw - (K - 1) - 2;             // leaves room for both flanks
     if (g.nmax > 127) g.nmax = 127;               // ... and the count fits 7 bits: the counting kernel keeps a copy count beside it
     g.log2_parts = log2_parts;
+    g.part_mul = 1u << log2_parts;
     return g;
 }
 
@@ -84,10 +87,16 @@ PG_HD uint32_t mmer_value(const uint64_t* rd, int p, int m) {          // m <= 1
     const uint32_t rc = rev2bit32(fwd ^ 0xAAAAAAAAu) >> (32 - 2 * m);
     return mmer_hash(fwd < rc ? fwd : rc);
 }
-PG_HD uint32_t skm_partition(uint32_t minval, int log2_parts) {
+PG_HD uint32_t skm_partition(uint32_t minval, uint32_t part_mul) {
     uint32_t x = minval * 0x85EBCA6Bu;            // the minimum of a window is a small number: spread it over all bits
     x ^= x >> 15;                                 // (one multiply alone leaves the partitions visibly less even: the largest
-    return (uint32_t)(x * 0xC2B2AE35u) >> (32 - log2_parts);   //  held 1052 / 3465 distinct k-mers instead of 820 / 2535 on the K = 63 / 127 fixtures)
+    x *= 0xC2B2AE35u;                             //  held 1052 / 3465 distinct k-mers instead of 820 / 2535 on the K = 63 / 127 fixtures)
+    // the hash scaled to [0, part_mul): with part_mul = 2^k this is its top k bits
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __umulhi(x, part_mul);
+#else
+    return (uint32_t)(((uint64_t)x * part_mul) >> 32);
+#endif
 }
 
 // ---- cutting a read into runs ------------------------------------------------------------------------------
@@ -105,7 +114,7 @@ PG_HD void skm_split_read(const uint64_t* rd, int len, const SkmGeom& g, Emit&& 
         const uint32_t v = mmer_value(rd, p, g.m);
         if (v <= minval) { minval = v; minpos = p; }
     }
-    uint32_t cur = skm_partition(minval, g.log2_parts);
+    uint32_t cur = skm_partition(minval, g.part_mul);
     int j0 = 0;
     for (int j = 1; j < nk; j++) {
         const int pnew = j + g.w - 1;
@@ -117,7 +126,7 @@ PG_HD void skm_split_read(const uint64_t* rd, int len, const SkmGeom& g, Emit&& 
                 if (u <= minval) { minval = u; minpos = p; }
             }
         } else if (v <= minval) { minval = v; minpos = pnew; }
-        const uint32_t pid = skm_partition(minval, g.log2_parts);
+        const uint32_t pid = skm_partition(minval, g.part_mul);
         if (pid != cur || j % g.nmax == 0) {
             emit(j0, j - j0, cur);
             j0 = j;

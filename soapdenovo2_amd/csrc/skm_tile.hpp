@@ -59,7 +59,7 @@ PG_HD void tile_mmer_chunk(const uint32_t* row, int c, int m, uint32_t* out) {
 // middle part has w - S positions for every lane and, with W = w at compile time, all three loops unroll into loads with
 // immediate offsets.
 template <int S, int W = 0>
-PG_HD uint32_t tile_segment(const uint32_t* v, int np, int j0, int cnt, int w_rt, int nmax, int log2_parts, uint32_t* pid_out) {
+PG_HD uint32_t tile_segment(const uint32_t* v, int np, int j0, int cnt, int w_rt, int nmax, uint32_t part_mul, uint32_t* pid_out) {
     // window q = k-mer j0 - 1 + q, q = 0 .. cnt: q = 0 is the predecessor of the segment's first k-mer (none when j0 = 0),
     // wanted only for the partition comparison.  All indices below are compile-time, so the arrays stay in registers.
     const int w = W ? W : w_rt;
@@ -95,7 +95,7 @@ PG_HD uint32_t tile_segment(const uint32_t* v, int np, int j0, int cnt, int w_rt
     for (int q = 0; q <= S; q++) {
         uint32_t mv = suf[q] < core ? suf[q] : core;
         mv = pre[q] < mv ? pre[q] : mv;
-        const uint32_t pid = skm_partition(mv, log2_parts);        // (q = 0 without a predecessor, q > cnt: junk nobody uses)
+        const uint32_t pid = skm_partition(mv, part_mul);        // (q = 0 without a predecessor, q > cnt: junk nobody uses)
         if (q >= 1) {
             const int j = j0 + q - 1;
             const bool cut = j == next_cut;

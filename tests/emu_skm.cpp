@@ -147,15 +147,15 @@ static int64_t tile_check(const uint64_t* packed, int64_t n_reads, int len, int 
         for (int t = 0; t < nr * nseg; t++) {
             const int seg = t / nr, r = t % nr, j0 = seg * S, cnt = std::min(S, kpr - j0);
             uint32_t pid[S];
-            masks[(size_t)r * nseg + seg] = tile_segment<S>(v0.data() + (size_t)r * npad, np, j0, cnt, g.w, g.nmax, log2_parts, pid);
+            masks[(size_t)r * nseg + seg] = tile_segment<S>(v0.data() + (size_t)r * npad, np, j0, cnt, g.w, g.nmax, g.part_mul, pid);
             for (int i = 0; i < cnt; i++) pids[(size_t)r * kpr + j0 + i] = pid[i];
             // the instantiations with the window length at compile time (what the kernel runs for K = 31 / 63 / 127): same bits, same ids
             uint32_t pid2[S];
             uint32_t mk2 = masks[(size_t)r * nseg + seg];
             bool have = true;
-            if (g.w == 48 && S <= 48) mk2 = tile_segment<S, 48>(v0.data() + (size_t)r * npad, np, j0, cnt, g.w, g.nmax, log2_parts, pid2);
-            else if (g.w == 112 && S <= 112) mk2 = tile_segment<S, 112>(v0.data() + (size_t)r * npad, np, j0, cnt, g.w, g.nmax, log2_parts, pid2);
-            else if (g.w == 16 && S <= 16) mk2 = tile_segment<S, 16>(v0.data() + (size_t)r * npad, np, j0, cnt, g.w, g.nmax, log2_parts, pid2);
+            if (g.w == 48 && S <= 48) mk2 = tile_segment<S, 48>(v0.data() + (size_t)r * npad, np, j0, cnt, g.w, g.nmax, g.part_mul, pid2);
+            else if (g.w == 112 && S <= 112) mk2 = tile_segment<S, 112>(v0.data() + (size_t)r * npad, np, j0, cnt, g.w, g.nmax, g.part_mul, pid2);
+            else if (g.w == 16 && S <= 16) mk2 = tile_segment<S, 16>(v0.data() + (size_t)r * npad, np, j0, cnt, g.w, g.nmax, g.part_mul, pid2);
             else have = false;
             if (have) {
                 if (mk2 != masks[(size_t)r * nseg + seg]) return -105;
