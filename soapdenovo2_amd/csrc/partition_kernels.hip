@@ -1406,6 +1406,7 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
         if (c->NW == 2) {
             if (cfg == 0 && (dbg & 2) && vt == 0) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, true, 0>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
             else if (cfg == 0 && (dbg & 2)) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, true, 4>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
+            else if (cfg == 3 && c->K == 63) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 512, 512, false, 0, 63>), dim3(grid), dim3(512), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);      // (A/B: the same set and window, half the lanes)
             else if (cfg == 0 && vt == 0 && ks && c->K == 63) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 0, 63>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
             else if (cfg == 0 && vt == 0 && ks && c->K == 31) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 0, 31>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
             else if (cfg == 0 && vt == 0) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 0>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);

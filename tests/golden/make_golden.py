@@ -6,6 +6,7 @@ files for the small cases, and md5 digests for the larger ones.
 
     python tests/golden/make_golden.py
     python tests/golden/make_golden.py --quirk rq_bam_odd     # add / refresh one reader corner case, everything else stays
+    python tests/golden/make_golden.py --case l1500k_k31      # ... or one case
 """
 import gzip, hashlib, json, os, shutil, subprocess, sys, tempfile
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -28,6 +29,10 @@ CASES = {
     "d8k_k127": dict(G=40000, N=8000, L=250, err=0.001, seed=21, K=127, model="diploid", runs=[(3,0,0,1), (8,0,0,1), (3,1,0,1)], full=[]),
     "r8k_k127": dict(G=40000, N=8000, L=250, err=0.001, seed=22, K=127, model="repeat", runs=[(3,0,0,1)], full=[]),
     "d8k_k63":  dict(G=40000, N=8000, L=150, err=0.002, seed=23, K=63, model="diploid", runs=[(5,0,0,0), (5,0,0,1), (5,1,0,0), (4,0,1,1)], full=[]),
+    # -a pools under LOAD: the smallest pool is 16.7 M slots a set (prlHashReads.c:372-390), so the -a runs above sit below 0.1 % load and never
+    # collide.  Here two sets of 33.5 M slots take ~17 M k-mers each (~52 %): probe clusters, kick-free first-come-first-served linear probing as
+    # the device layout (dev_graph.hpp: layout_static) has to reproduce it, a cluster that wraps round the end of a table
+    "l1500k_k31": dict(G=12000000, N=1500000, L=100, err=0.005, seed=77, K=31, runs=[(2,0,1,0)], full=[]),
 }
 EXTS = ("kmerFreq", "preGraphBasic", "vertex", "edge", "preArc")
 
@@ -40,9 +45,10 @@ def tag(name, run):
 def main():
     digests = {}
     only_quirks = [sys.argv[i + 1] for i, a in enumerate(sys.argv[:-1]) if a == "--quirk"]
-    old = json.load(open(os.path.join(HERE, "cases.json"))) if only_quirks else None
+    only_cases = [sys.argv[i + 1] for i, a in enumerate(sys.argv[:-1]) if a == "--case"]
+    old = json.load(open(os.path.join(HERE, "cases.json"))) if (only_quirks or only_cases) else None
     with tempfile.TemporaryDirectory() as td:
-        for name, c in ({} if only_quirks else CASES).items():
+        for name, c in ({k: v for k, v in CASES.items() if k in only_cases} if (only_quirks or only_cases) else CASES).items():
             cfg = synth.make_case(td, name, c["G"], c["N"], c["L"], c["err"], c["seed"], model=c.get("model", "uniform"), K=c["K"])
             for run in c["runs"]:
                 P, D, a, m = run
@@ -79,7 +85,7 @@ def main():
         # reader corner cases: K = 31, -p 3; also pin the reference's "read(s) processed" count
         import re
         quirks = {}
-        for name in (only_quirks or synth.QUIRK_CASES):
+        for name in (only_quirks or ([] if only_cases else synth.QUIRK_CASES)):
             cfg = synth.make_quirk_case(td, name)
             pre = os.path.join(td, name)
             binary = os.path.join(ROOT, "oracle", "_ref", "SOAPdenovo-63mer")

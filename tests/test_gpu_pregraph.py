@@ -223,6 +223,31 @@ def test_cli_matches_reference_files(golden, tmp_path, name, engine):
         assert md5_file(pre + ".contig") == golden["md5"][t]["contig"], t
 
 
+def test_cli_static_pools_under_load(golden, tmp_path):
+    """-a pools at a realistic load: the smallest pool is 16.7 M slots a set (prlHashReads.c:372-390), so the other -a fixtures never
+    collide.  1.5 M reads x 100 bp over a 12 Mb genome, K = 31, -p 2 -a 1: two sets of 33.5 M slots at about 52 % -- probe clusters of
+    dozens of keys, first-come-first-served linear probing in first-occurrence order as the device layout (dev_graph.hpp: layout_static,
+    K6Sweep) has to rebuild it, the cluster that runs round the end of a table.  The reference's md5s are in the golden file; one rank
+    and three ranks (the sets on two of them)."""
+    import re
+    name = "l1500k_k31"
+    c = golden["cases"][name]
+    cfg = case_config(c, str(tmp_path), name)
+    run = c["runs"][0]
+    P, D, a, m = run
+    t = case_tag(name, run)
+    want = golden["md5"][t]
+    for tag, env in (("one", dict(PARALLEL_PARSE, PG_HOST_VERBOSE="1")), ("three", dict(PARALLEL_PARSE, PG_HOST_VERBOSE="1", SOAPDENOVO2_AMD_DEVICES="0,0,0"))):
+        pre = str(tmp_path / (t + "_" + tag))
+        log = _run_cli(cfg, c["K"], pre, P, D, a, m, extra_env=env)
+        assert "K6 on device" in log, log[-2000:]                          # the layout was made on the device, not replayed
+        nodes = int(re.search(r"(\d+) node\(s\) allocated", log).group(1))
+        assert 0.40 < nodes / (2 * 2 * 0xFFFFFF) < 0.70, nodes             # (the load the case was made for)
+        for ext in ("kmerFreq", "preGraphBasic", "vertex", "preArc"):
+            assert md5_file(pre + "." + ext) == want[ext], (tag, ext)
+        assert md5_gz_text(pre + ".edge.gz") == want["edge"], tag
+
+
 def test_cli_fasta_and_reference_binary(golden, tmp_path):
     """FASTA input (f=) gives the same files as FASTQ (q=); and, when the reference binary travelled with the
     snapshot (oracle/_ref), a direct byte comparison on a fresh seed that has no golden file."""
