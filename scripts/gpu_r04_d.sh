@@ -12,10 +12,14 @@ run eff80 PG_PARTS_EFF_PCT=80
 run eff70 PG_PARTS_EFF_PCT=70
 run eff60 PG_PARTS_EFF_PCT=60
 run cfg3 PG_K2CFG=3
+run opt5 PG_K2_OPT=5
+run opt5_eff80 PG_K2_OPT=5 PG_PARTS_EFF_PCT=80
 B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --kmer 127"
 run k127_base PG_NOP=1
 run k127_eff85 PG_PARTS_EFF_PCT=85
 run k127_eff70 PG_PARTS_EFF_PCT=70
+run k127_opt5 PG_K2_OPT=5
+run k127_opt5_eff85 PG_K2_OPT=5 PG_PARTS_EFF_PCT=85
 B="python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extras --genome 200000000 --err 0.0005"
 run cov150 PG_NOP=1
 python - <<PY

@@ -743,6 +743,11 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
         pf_nrec = peek_cursor(blockIdx.x);
         if (threadIdx.x < nchunks) pf_cid = chunk_ask(blockIdx.x, threadIdx.x);
     }
+    // opt bit 2: a key range that is going to overflow the set is split BEFORE it is counted.  A dropped attempt costs the attempt and two
+    // sittings over the same window; what a single-window partition will hold is foreseeable from its occurrences after the dedupe
+    // (s_tot) and the share of occurrences that turned out distinct in this workgroup's partitions so far (acc_live / acc_occ, the
+    // same in every lane): beyond ~55 % of the slots a probe sequence of 48 is to be expected.
+    uint32_t acc_live = 0, acc_occ = 0;
     int b = 0, cl = 0;                                                    // the current window's buffer, the current partition's chunk list
     bool staged = false;                                                  // its first window is already on its way into rl2[b] (asked for by the previous emit)
     for (uint32_t pid = blockIdx.x; pid < parts; pid += gridDim.x) {
@@ -783,6 +788,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 K2_SYNC();
             }
             K2_TICK(1);
+            bool presplit = false;
             for (uint32_t w0 = 0; w0 < usable; w0 += WIN) {
                 const uint32_t wn = min((uint32_t)WIN, usable - w0);
                 if (!(window_ready && w0 == 0)) {
@@ -807,7 +813,9 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 if (more && !(dbg & 16)) p_stage_async(b ^ 1, cl, w0 + WIN, min((uint32_t)WIN, usable - w0 - WIN));
                 const uint32_t total_occ = s_tot, share = VT == 0 ? 1u : (total_occ + VL - 1) / VL;
                 const uint32_t* const rl = rl2[b];
-                if (!__hip_atomic_load(&aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                if ((opt & 4) && mask == 0 && usable <= (uint32_t)WIN && acc_occ >= 4096u &&
+                    (unsigned long long)total_occ * acc_live * 100ull > 55ull * SLOTS * (unsigned long long)acc_occ) presplit = true;
+                if (!presplit && !__hip_atomic_load(&aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
                   // (VT > 1) tiles of 64 virtual lanes: the wave's first one is its own number, the next ones come off the counter
                   for (uint32_t tile = (uint32_t)wave;;) {
                     const uint32_t vlane = VT == 1 ? threadIdx.x : tile * 64u + (uint32_t)lane;
@@ -891,9 +899,9 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 if (more && !(dbg & 16)) { b ^= 1; raw = true; }
                 K2_TICK(5);
             }
-            if (aborted) {                                                // (read behind the window loop's last barrier: the same for every lane)
+            if (aborted || presplit) {                                    // (read behind the window loop's last barrier: the same for every lane)
                 if (TIMERS) tp[9 * TIMERS]++;
-                dirty = true;
+                dirty = !presplit;                                        // (a range split ahead of time never touched the set)
                 // too many distinct keys for the LDS set: split this key range on the next hash bit and redo both halves
                 const uint32_t bit = mask + 1;                            // masks are 2^k - 1
                 if (bit >= (1u << 20) || top + 2 > 40) {
@@ -933,6 +941,10 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     }
                     K2_TICK(6);
                     const unsigned int n_live = s_nlive;
+                    if (mask == 0 && usable <= (uint32_t)WIN) {            // a whole single-window partition: what share of its occurrences were distinct
+                        acc_live += n_live; acc_occ += s_tot;
+                        if (acc_occ > (1u << 30)) { acc_live >>= 1; acc_occ >>= 1; }
+                    }
                     for (unsigned int c0 = 0; c0 < n_live; c0 += STAGE_CAP) {
                         const unsigned int cn = min(STAGE_CAP, n_live - c0);
                         e_final(whole, threadIdx.x, sb, c0, cn, n_live);
