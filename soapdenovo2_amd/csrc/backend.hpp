@@ -94,6 +94,15 @@ struct HostBackend {
     template <typename T> void to_host_at(int, T* dst, const T* src, size_t n) { to_host(dst, src, n); }
     template <typename T> void gather_at(int, T* dst_lead, const T* src_place, size_t n) { copy(dst_lead, src_place, n); }
     template <typename F> void launch_at(int, uint64_t n, F f) { launch(n, f); }
+    // append the values f(i) != ~0, i in [0, n), to `list` (any order), counting them all in *cnt
+    template <typename F> void append_at(int, uint64_t n, F f, unsigned long long* list, unsigned long long* cnt, unsigned long long cap) {
+        launch(n, [=](uint64_t i) {
+            const unsigned long long v = f(i);
+            if (v == ~0ULL) return;
+            const unsigned long long at = hd_atomic_add(cnt, 1ULL);
+            if (at < cap) list[at] = v;
+        });
+    }
     void sync_places() {}
     uint64_t launches_at[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // (kept for symmetry with the device backend's per-place launch counts)
 

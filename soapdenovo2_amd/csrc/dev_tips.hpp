@@ -303,14 +303,13 @@ int tip_scan(BE& be, const SetsView& view, const SetsGeo& geo, int cut_len, bool
                 const uint64_t first = geo.first[s], cap_now = pl_cap[pl];
                 unsigned long long* const list_now = pl_list[pl];
                 unsigned long long* const cnt_now = pl_cnt[pl];
-                be.launch_at(pl, geo.size[s], [=] PG_LAMBDA(uint64_t i) {
+                be.append_at(pl, geo.size[s], [=] PG_LAMBDA(uint64_t i) -> unsigned long long {
                     const uint64_t* nd = base + i * (NW + 1);
-                    if (nd[0] == SV_EMPTY) return;
+                    if (nd[0] == SV_EMPTY) return ~0ULL;
                     const uint64_t ab = nd[NW];
-                    if (!(ab_startable(ab, thin) && ab_dead_end(ab))) return;
-                    const unsigned long long j = hd_atomic_add(cnt_now, 1ULL);
-                    if (j < cap_now) list_now[j] = first + i;
-                });
+                    if (!(ab_startable(ab, thin) && ab_dead_end(ab))) return ~0ULL;
+                    return first + i;
+                }, list_now, cnt_now, cap_now);
             }
             for (int pl = 0; pl < NPL && !be.error; pl++) {
                 if (pl_n[pl]) continue;

@@ -329,17 +329,38 @@ struct WalkState {
 };
 
 // one set's vertices (live non-linear nodes) as global slots, in any order
-// (cap: room in `list`; what does not fit is still counted, so the caller can come again with a list that holds them all)
-__global__ void eb_list_branch(const uint64_t* nodes, int nw1, uint64_t n_slots, uint64_t first, unsigned long long* list, unsigned long long* n_list,
-                               unsigned long long cap) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n_slots; i += (uint64_t)gridDim.x * blockDim.x) {
-        const uint64_t* nd = nodes + i * nw1;
-        if (nd[0] == P2_EMPTY) continue;
-        const uint32_t B = (uint32_t)(nd[nw1 - 1] >> 32);
-        if (B & (B_LINEAR | B_DELETED)) continue;
-        const unsigned long long at = atomicAdd(n_list, 1ULL);
-        if (at < cap) list[at] = first + i;
+// (cap: room in `list`; what does not fit is still counted, so the caller can come again with a list that holds them all).
+// The hits of a workgroup are collected in LDS and get their room in the list ~1000 at a time: appended one returned atomic apiece,
+// 2.6 M vertices took 29 ms at 60 M reads -- the rate ONE address serves atomics at (88 per microsecond), not the scan's.
+__global__ __launch_bounds__(256) void eb_list_branch(const uint64_t* nodes, int nw1, uint64_t n_slots, uint64_t first, unsigned long long* list, unsigned long long* n_list,
+                                                      unsigned long long cap) {
+    constexpr unsigned FLUSH = 1024;
+    __shared__ unsigned long long buf[FLUSH + 256];
+    __shared__ unsigned int s_n;
+    __shared__ unsigned long long s_base;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    auto flush = [&]() {
+        const unsigned int m = s_n;
+        if (threadIdx.x == 0 && m) s_base = atomicAdd(n_list, (unsigned long long)m);
+        __syncthreads();
+        for (unsigned int j = threadIdx.x; j < m; j += 256) { const unsigned long long at = s_base + j; if (at < cap) list[at] = buf[j]; }
+        __syncthreads();
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+    };
+    for (uint64_t i0 = (uint64_t)blockIdx.x * 256; i0 < n_slots; i0 += (uint64_t)gridDim.x * 256) {
+        const uint64_t i = i0 + threadIdx.x;
+        bool hit = false;
+        if (i < n_slots) {
+            const uint64_t* nd = nodes + i * nw1;
+            hit = nd[0] != P2_EMPTY && !((uint32_t)(nd[nw1 - 1] >> 32) & (B_LINEAR | B_DELETED));
+        }
+        if (hit) buf[atomicAdd(&s_n, 1u)] = first + i;
+        __syncthreads();
+        if (s_n > FLUSH) flush();
     }
+    flush();
 }
 
 template <int NW>
