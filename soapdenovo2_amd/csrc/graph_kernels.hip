@@ -113,10 +113,10 @@ __device__ inline void add_prearc(const P2Params& p, uint32_t from, uint32_t to,
         unsigned long long cur = __hip_atomic_load(&p.arc_key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur == 0) {
             unsigned long long expected = 0;
-            if (__hip_atomic_compare_exchange_strong(&p.arc_key[h], &expected, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) {
-                atomicAdd(&p.counters[3], 1ULL);
-                cur = key;
-            } else cur = expected;
+            // (the distinct pairs are counted when the table is read out, p2_count_arcs: a counter bumped here would take one atomic on
+            //  ONE address per new pair -- a billion of them at configs[3], at the 88 per microsecond an address serves)
+            if (__hip_atomic_compare_exchange_strong(&p.arc_key[h], &expected, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) cur = key;
+            else cur = expected;
         }
         if (cur == key) {
             atomicAdd(&p.arc_cnt[h], 1u);
@@ -587,14 +587,33 @@ __global__ void tip_remark(uint64_t* nodes, int nw1, uint64_t n_slots) {
     }
 }
 
-// the occupied slots of the pre-arc table, densely (order does not matter: the host sorts)
-__global__ void p2_compact_arcs(const unsigned long long* key, const unsigned int* cnt, const unsigned long long* first, uint64_t cap,
-                                P2Arc* out, unsigned long long* n_out) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * blockDim.x) {
-        const unsigned long long k = key[i];
-        if (!k) continue;
-        const unsigned long long at = atomicAdd(n_out, 1ULL);
-        out[at] = P2Arc{(uint32_t)(k >> 32), (uint32_t)k, cnt[i], first[i]};
+// the occupied slots of the pre-arc table: counted (one atomic a workgroup), then written out densely (order does not matter: the host
+// sorts; a workgroup reserves room for its slots of a trip with one returned atomic)
+__global__ __launch_bounds__(256) void p2_count_arcs(const unsigned long long* key, uint64_t cap, unsigned long long* n_out) {
+    __shared__ unsigned int s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    unsigned int mine = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * 256) mine += key[i] != 0;
+    if (mine) atomicAdd(&s_n, mine);
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n) atomicAdd(n_out, (unsigned long long)s_n);
+}
+__global__ __launch_bounds__(256) void p2_compact_arcs(const unsigned long long* key, const unsigned int* cnt, const unsigned long long* first, uint64_t cap,
+                                                       P2Arc* out, unsigned long long* n_out, unsigned long long out_cap) {
+    __shared__ unsigned int s_n;
+    __shared__ unsigned long long s_base;
+    for (uint64_t i0 = (uint64_t)blockIdx.x * 256; i0 < cap; i0 += (uint64_t)gridDim.x * 256) {
+        if (threadIdx.x == 0) s_n = 0;
+        __syncthreads();
+        const uint64_t i = i0 + threadIdx.x;
+        const unsigned long long k = i < cap ? key[i] : 0ULL;
+        unsigned int my = 0;
+        if (k) my = atomicAdd(&s_n, 1u);
+        __syncthreads();
+        if (threadIdx.x == 0 && s_n) s_base = atomicAdd(n_out, (unsigned long long)s_n);
+        __syncthreads();
+        if (k && s_base + my < out_cap) out[s_base + my] = P2Arc{(uint32_t)(k >> 32), (uint32_t)k, cnt[i], first[i]};
     }
 }
 
@@ -1592,6 +1611,10 @@ int p2_finish(P2Device* d, P2Result& out) {
         if (!ln.tables) continue;
         P2_HIP(hipSetDevice(ln.device));
         P2_HIP(hipStreamSynchronize(ln.stream));
+        P2_HIP(hipMemsetAsync(ln.d_counters + 3, 0, sizeof(unsigned long long), ln.stream));
+        hipLaunchKernelGGL(p2_count_arcs, dim3(2048), dim3(256), 0, ln.stream, ln.d_arc_key, ln.prm.arc_mask + 1, ln.d_counters + 3);
+        P2_HIP(hipGetLastError());
+        P2_HIP(hipStreamSynchronize(ln.stream));
         unsigned long long cl[8];
         P2_HIP(hipMemcpy(cl, ln.d_counters, sizeof(cl), hipMemcpyDeviceToHost));
         for (int q = 0; q < 8; q++) c[q] += cl[q];
@@ -1622,7 +1645,7 @@ int p2_finish(P2Device* d, P2Result& out) {
             P2Arc* d_arcs = nullptr;
             P2_HIP(hipMalloc((void**)&d_arcs, n_l * sizeof(P2Arc)));
             P2_HIP(hipMemsetAsync(ln.d_counters + 6, 0, sizeof(unsigned long long), ln.stream));
-            hipLaunchKernelGGL(p2_compact_arcs, dim3(2048), dim3(256), 0, ln.stream, ln.d_arc_key, ln.d_arc_cnt, ln.d_arc_first, cap, d_arcs, ln.d_counters + 6);
+            hipLaunchKernelGGL(p2_compact_arcs, dim3(2048), dim3(256), 0, ln.stream, ln.d_arc_key, ln.d_arc_cnt, ln.d_arc_first, cap, d_arcs, ln.d_counters + 6, (unsigned long long)n_l);
             P2_HIP(hipMemcpyAsync(out.arcs.data() + at, d_arcs, n_l * sizeof(P2Arc), hipMemcpyDeviceToHost, ln.stream));
             unsigned long long got = 0;
             P2_HIP(hipMemcpyAsync(&got, ln.d_counters + 6, sizeof(got), hipMemcpyDeviceToHost, ln.stream));
