@@ -814,7 +814,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 const uint32_t total_occ = s_tot, share = VT == 0 ? 1u : (total_occ + VL - 1) / VL;
                 const uint32_t* const rl = rl2[b];
                 if ((opt & 4) && mask == 0 && usable <= (uint32_t)WIN && acc_occ >= 4096u &&
-                    (unsigned long long)total_occ * acc_live * 100ull > 55ull * SLOTS * (unsigned long long)acc_occ) presplit = true;
+                    (unsigned long long)total_occ * acc_live * 100ull > (unsigned long long)(((opt >> 8) & 0xFF) ? ((opt >> 8) & 0xFF) : 55) * SLOTS * (unsigned long long)acc_occ) presplit = true;
                 if (!presplit && !__hip_atomic_load(&aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
                   // (VT > 1) tiles of 64 virtual lanes: the wave's first one is its own number, the next ones come off the counter
                   for (uint32_t tile = (uint32_t)wave;;) {
@@ -1405,8 +1405,12 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     if (const char* v = getenv("PG_K2CFG")) cfg = atoi(v);
     int k2win = 512;                                                      // records a window (PG_K2_WIN=256: the 127-mer flavour's partitions hold ~60 records)
     if (const char* v = getenv("PG_K2_WIN")) k2win = atoi(v);
-    int k2opt = 1;                                                        // bit 0: live slots listed in any order (162.9 -> 157.0 ms; with vt = 0: 148.9 ms)
+    // bit 0: live slots listed in any order (162.9 -> 157.0 ms; with vt = 0: 148.9 ms); bit 2: key ranges foreseen to overflow are split before they
+    // are counted -- the 127-mer flavour drops one attempt in ten (198.2 -> 194.2 ms), the 63-mer one in a hundred and loses more to false alarms
+    // (152.6 -> 162.8 ms): on for the former only; bits 8..15: the foreseen load in percent from which on it splits (0 = 55)
+    int k2opt = c->NW == 4 ? 5 : 1;
     if (const char* v = getenv("PG_K2_OPT")) k2opt = atoi(v);
+    if (const char* v = getenv("PG_K2_PRESPLIT_PCT")) k2opt = (k2opt & 0xFF) | ((atoi(v) & 0xFF) << 8);
     bool ks = true;                                                       // the instantiations for K = 31 / 63 / 127 (PG_K2_KS=0: the general kernel)
     if (const char* v = getenv("PG_K2_KS")) ks = atoi(v) != 0;
     if (dbg) ks = false;
