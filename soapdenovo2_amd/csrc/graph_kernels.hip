@@ -328,12 +328,58 @@ struct WalkState {
     int next_ch;                      // last base of the second node
 };
 
-// one set's vertices (live non-linear nodes) as global slots, in any order
+// ---- waypoints: chains of linear nodes far longer than a lane should walk -------------------------------------------------------
+// A walk is serial by nature (the next node is a function of the present one), and the reference's graph of a nearly repeat-free
+// genome at a large K is a few hundred chains of millions of nodes: one lane a chain took 23.5 s for the edges of the 60 M-read
+// K = 127 run (the reference: 103 s).  So every linear node whose global slot hashes to 0 modulo a period is a WAYPOINT:
+//   eb_way_walk   a lane per (waypoint, direction) walks to the next waypoint or branch node: expected `period` steps, all at once;
+//   eb_walk       steps node by node until it meets a waypoint, then JUMPS from waypoint to waypoint through those segments (count and
+//                 coverage sum added up), noting at every waypoint it passes which walk it is and how many nodes it has behind it;
+//   eb_apply      writes the bases and tags the nodes up to the first waypoint; eb_apply_seg, a lane per (waypoint, direction) a KEPT
+//                 walk passed, does the segment behind it -- at the text offset and with the edge id the walk's record got.
+// Same records, same text, same tags as the node-by-node walk (SOAPDENOVO2_AMD_EB_WAYPOINTS=0; a period of 4 in the tests puts
+// waypoints into every chain of the golden cases).
+struct EbWay {
+    unsigned long long* key;          // open addressing: global slot + 1 of a waypoint, 0 = free; cap = mask + 1 entries
+    uint64_t mask;
+    unsigned long long* seg_end;      // [2 cap] entry 2 h + d: the stop of the segment that leaves waypoint h forward (d = 0: as its canonical k-mer reads) / backward
+    unsigned long long* seg_info;     //         nodes stepped (the stop is the n-th) | stop is a waypoint << 32 | stop's k-mer is canonical in walk direction << 33 |
+                                      //         first base of the k-mer in front of the stop << 34
+    unsigned long long* seg_sum;      //         left-arc counters of the nodes strictly between (coverage)
+    unsigned long long* vis_own;      // [2 cap] the walk (EdgeRec::key) that passed the waypoint leaving that way, ~0 = none
+    unsigned int* vis_info;           //         nodes on that walk up to and including the waypoint | the base it leaves by << 30
+    uint32_t period_mask;             // waypoint <=> linear, live and (slot_hash(slot) & period_mask) == 0
+};
+__device__ __forceinline__ bool eb_is_way(uint64_t g, uint32_t pm) { return ((uint32_t)slot_hash(g) & pm) == 0; }
+__device__ __forceinline__ uint64_t eb_way_home(uint64_t g, uint64_t mask) { return (slot_hash(g) >> 24) & mask; }      // (other bits than the test above looks at)
+__device__ __forceinline__ uint64_t eb_way_find(const EbWay& w, uint64_t g) {           // ~0: not a waypoint (the caller counts an error)
+    uint64_t h = eb_way_home(g, w.mask);
+    for (uint64_t step = 0; step <= w.mask; step++) {
+        const unsigned long long k = w.key[h];
+        if (k == g + 1) return h;
+        if (k == 0) break;
+        h = (h + 1) & w.mask;
+    }
+    return ~0ULL;
+}
+__global__ void eb_way_insert(EbWay w, const unsigned long long* list, uint64_t n) {
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) {
+        const unsigned long long g = list[i];
+        uint64_t h = eb_way_home(g, w.mask);
+        for (;;) {
+            const unsigned long long old = atomicCAS(&w.key[h], 0ULL, g + 1);
+            if (old == 0 || old == g + 1) break;
+            h = (h + 1) & w.mask;
+        }
+    }
+}
+
+// one set's vertices (live non-linear nodes) as global slots, in any order -- or (way_mask != 0xFFFFFFFF... see `ways`) its waypoints
 // (cap: room in `list`; what does not fit is still counted, so the caller can come again with a list that holds them all).
 // The hits of a workgroup are collected in LDS and get their room in the list ~1000 at a time: appended one returned atomic apiece,
 // 2.6 M vertices took 29 ms at 60 M reads -- the rate ONE address serves atomics at (88 per microsecond), not the scan's.
 __global__ __launch_bounds__(256) void eb_list_branch(const uint64_t* nodes, int nw1, uint64_t n_slots, uint64_t first, unsigned long long* list, unsigned long long* n_list,
-                                                      unsigned long long cap) {
+                                                      unsigned long long cap, int ways = 0, uint32_t period_mask = 0) {
     constexpr unsigned FLUSH = 1024;
     __shared__ unsigned long long buf[FLUSH + 256];
     __shared__ unsigned int s_n;
@@ -354,7 +400,8 @@ __global__ __launch_bounds__(256) void eb_list_branch(const uint64_t* nodes, int
         bool hit = false;
         if (i < n_slots) {
             const uint64_t* nd = nodes + i * nw1;
-            hit = nd[0] != P2_EMPTY && !((uint32_t)(nd[nw1 - 1] >> 32) & (B_LINEAR | B_DELETED));
+            const uint32_t B = (uint32_t)(nd[nw1 - 1] >> 32);
+            hit = nd[0] != P2_EMPTY && (ways ? ((B & B_LINEAR) && eb_is_way(first + i, period_mask)) : !(B & (B_LINEAR | B_DELETED)));
         }
         if (hit) buf[atomicAdd(&s_n, 1u)] = first + i;
         __syncthreads();
@@ -363,9 +410,50 @@ __global__ __launch_bounds__(256) void eb_list_branch(const uint64_t* nodes, int
     flush();
 }
 
+// the segment that leaves waypoint list[t / 2] forward (t even) or backward: to the next waypoint or branch node
+template <int NW>
+__global__ __launch_bounds__(256) void eb_way_walk(P2Params p, EbWay way, const unsigned long long* list, uint64_t n, unsigned long long* errors) {
+    P2_PROLOGUE(p);
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * n) return;
+    const uint64_t g0 = list[t >> 1];
+    const int d = (int)(t & 1);
+    const uint64_t h = eb_way_find(way, g0);
+    if (h == ~0ULL) { atomicAdd(errors, 1ULL); return; }
+    const uint64_t* nd0 = sv_node<NW>(sv, g0);
+    const int K = p.K;
+    const Kmer<NW> filter = kmer_filter<NW>(K);
+    Kmer<NW> seq;
+#pragma unroll
+    for (int i = 0; i < NW; i++) seq.w[i] = nd0[i];
+    Kmer<NW> prev = d ? kmer_rc<NW>(seq, K) : seq;
+    Kmer<NW> cur = kmer_next<NW>(prev, linear_out_ab(nd0[NW], d == 0), filter);
+    uint64_t slot, ab;
+    uint64_t* node;
+    bool smaller;
+    unsigned long long sum = 0, count = 0;
+    for (;;) {
+        if (!sv_step<NW>(sv, cur, slot, node, smaller)) { atomicAdd(errors, 1ULL); return; }
+        ab = node[NW];
+        count++;
+        const bool linear = ((uint32_t)(ab >> 32) & B_LINEAR) != 0;
+        if (!linear || eb_is_way(slot, way.period_mask)) {
+            way.seg_end[2 * h + d] = slot;
+            way.seg_info[2 * h + d] = count | ((unsigned long long)(linear ? 1 : 0) << 32) | ((unsigned long long)(smaller ? 1 : 0) << 33) |
+                                      ((unsigned long long)kmer_first<NW>(prev, K) << 34);
+            way.seg_sum[2 * h + d] = sum;
+            return;
+        }
+        const uint32_t A = (uint32_t)ab;
+        sum += (A & 63) + ((A >> 6) & 63) + ((A >> 12) & 63) + ((A >> 18) & 63);
+        prev = cur;
+        cur = kmer_next<NW>(cur, linear_out_ab(ab, smaller), filter);
+    }
+}
+
 template <int NW>
 __global__ __launch_bounds__(256) void eb_walk(P2Params p, const unsigned long long* list, uint64_t n_list, EdgeRec* out, uint64_t cap,
-                                               unsigned long long* n_out, unsigned long long* n_len1, unsigned long long* errors) {
+                                               unsigned long long* n_out, unsigned long long* n_len1, unsigned long long* errors, EbWay way) {
     P2_PROLOGUE(p);
     const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_list * 8) return;
@@ -393,18 +481,41 @@ __global__ __launch_bounds__(256) void eb_walk(P2Params p, const unsigned long l
     const int next_ch = kmer_last<NW>(cur);
     uint32_t count = 2;
     unsigned long long sum = 0;
+    const unsigned long long own = ((unsigned long long)slot0 << 3) | (unsigned)order;
+    int prev_known = -1;                                            // the first base of the k-mer in front of `cur`, when a jump brought us here
     while ((uint32_t)(ab >> 32) & B_LINEAR) {
         const uint32_t A = (uint32_t)ab;
         sum += (A & 63) + ((A >> 6) & 63) + ((A >> 12) & 63) + ((A >> 18) & 63);
+        if (way.key && eb_is_way(slot, way.period_mask)) {
+            // a waypoint: leave a note (which walk, how far in, which way out) and take its segment in one step
+            const uint64_t h = eb_way_find(way, slot);
+            if (h == ~0ULL) { atomicAdd(errors, 1ULL); return; }
+            const int d = smaller ? 0 : 1;
+            way.vis_own[2 * h + d] = own;
+            way.vis_info[2 * h + d] = count | ((unsigned int)linear_out_ab(ab, smaller) << 30);
+            const unsigned long long info = way.seg_info[2 * h + d];
+            count += (uint32_t)info;
+            sum += way.seg_sum[2 * h + d];
+            slot = way.seg_end[2 * h + d];
+            smaller = (info >> 33) & 1;
+            prev_known = (int)((info >> 34) & 3);
+            node = sv_node<NW>(sv, slot);
+            ab = node[NW];
+            Kmer<NW> kk;
+#pragma unroll
+            for (int i = 0; i < NW; i++) kk.w[i] = node[i];
+            cur = smaller ? kk : kmer_rc<NW>(kk, K);
+            continue;
+        }
         prev = cur;
+        prev_known = -1;
         cur = kmer_next<NW>(cur, linear_out_ab(ab, smaller), filter);
         if (!sv_step<NW>(sv, cur, slot, node, smaller)) { atomicAdd(errors, 1ULL); return; }
         ab = node[NW];
         count++;
     }
-    const int prev_ch = kmer_first<NW>(prev, K);
+    const int prev_ch = prev_known >= 0 ? prev_known : kmer_first<NW>(prev, K);
     // where the slot-order scan would start this chain from its other end
-    const unsigned long long own = ((unsigned long long)slot0 << 3) | (unsigned)order;
     const unsigned long long twin = ((unsigned long long)slot << 3) | (unsigned)(smaller ? 4 + prev_ch : (prev_ch ^ 2));
     if (twin < own) return;
     EdgeRec r;
@@ -441,10 +552,59 @@ __global__ void eb_export(const EdgeRec* recs, const uint32_t* order, const unsi
     }
 }
 
+// the segment behind a waypoint a kept walk passed: bases and tags as eb_apply writes them, at the walk's text offset and with its id
+template <int NW>
+__global__ __launch_bounds__(256) void eb_apply_seg(P2Params p, EbWay way, const EdgeRec* recs, const uint32_t* order, const unsigned long long* sorted_key, uint64_t n_rec,
+                                                    const unsigned long long* id_before, const unsigned long long* base_before, char* text, unsigned long long* errors) {
+    P2_PROLOGUE(p);
+    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= 2 * (way.mask + 1)) return;
+    const unsigned long long own = way.vis_own[t];
+    if (own == ~0ULL) return;
+    // the walk's record, if it was kept (binary search over the records' keys in slot order)
+    uint64_t lo = 0, hi = n_rec;
+    while (lo < hi) { const uint64_t mid = (lo + hi) >> 1; if (sorted_key[mid] < own) lo = mid + 1; else hi = mid; }
+    if (lo >= n_rec || sorted_key[lo] != own) return;
+    const EdgeRec& r = recs[order[lo]];
+    const uint32_t id = (uint32_t)id_before[lo] + 1, bal = (r.flags >> 6) & 1;
+    const uint64_t h = t >> 1;
+    const int d = (int)(t & 1);
+    const unsigned int vi = way.vis_info[t];
+    const uint32_t c_w = vi & 0x3FFFFFFFu;                              // nodes on the walk up to and including the waypoint
+    const unsigned long long info = way.seg_info[t];
+    const uint32_t n = (uint32_t)info;
+    const bool end_is_way = (info >> 32) & 1;
+    const int K = p.K;
+    const Kmer<NW> filter = kmer_filter<NW>(K);
+    const uint64_t g0 = way.key[h] - 1;
+    const uint64_t* nd0 = sv_node<NW>(sv, g0);
+    Kmer<NW> seq;
+#pragma unroll
+    for (int i = 0; i < NW; i++) seq.w[i] = nd0[i];
+    Kmer<NW> cur = kmer_next<NW>(d ? kmer_rc<NW>(seq, K) : seq, (int)(vi >> 30), filter);   // (the way out was noted by the walk: the waypoint's own word is being tagged by another lane)
+    char* out = text + base_before[lo] + (c_w - 1);                     // the c-th node of a walk writes base c - 2
+    uint64_t slot, ab;
+    uint64_t* node;
+    bool smaller;
+    for (uint32_t j = 1; j <= n; j++) {
+        if (!sv_step<NW>(sv, cur, slot, node, smaller)) { atomicAdd(errors, 1ULL); return; }
+        ab = node[NW];
+        out[j - 1] = "ACTG"[kmer_last<NW>(cur)];
+        if (j == n && !end_is_way) break;                               // the far branch node
+        const uint32_t A = smaller ? id : id + bal;
+        const uint32_t twin = smaller ? bal + 1 : 1 - bal;
+        const uint32_t B = ((uint32_t)(ab >> 32) & 0x0FFFFFFFu) | (twin << B_TWIN_SHIFT) | (1u << B_INEDGE_SHIFT);
+        const int o = linear_out_ab(ab, smaller);
+        node[NW] = (uint64_t)A | ((uint64_t)B << 32);
+        cur = kmer_next<NW>(cur, o, filter);
+    }
+    if (slot != way.seg_end[t]) atomicAdd(errors, 1ULL);
+}
+
 template <int NW>
 __global__ __launch_bounds__(256) void eb_apply(P2Params p, const EdgeRec* recs, const uint32_t* order, uint64_t n,
                                                 const unsigned long long* id_before, const unsigned long long* base_before, char* text,
-                                                uint64_t* patch_keys, uint32_t* patch_val, uint64_t patch_mask, unsigned long long* errors) {
+                                                uint64_t* patch_keys, uint32_t* patch_val, uint64_t patch_mask, unsigned long long* errors, EbWay way) {
     P2_PROLOGUE(p);
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -465,6 +625,7 @@ __global__ __launch_bounds__(256) void eb_apply(P2Params p, const EdgeRec* recs,
     uint64_t slot, ab;
     uint64_t* node;
     bool smaller;
+    bool handed_over = false;                                       // the rest of the walk belongs to the lanes of eb_apply_seg
     for (uint32_t b = 0; b < r.length; b++) {
         if (!sv_step<NW>(sv, cur, slot, node, smaller)) { atomicAdd(errors, 1ULL); return; }
         ab = node[NW];
@@ -475,9 +636,10 @@ __global__ __launch_bounds__(256) void eb_apply(P2Params p, const EdgeRec* recs,
         const uint32_t B = ((uint32_t)(ab >> 32) & 0x0FFFFFFFu) | (twin << B_TWIN_SHIFT) | (1u << B_INEDGE_SHIFT);
         const int out = linear_out_ab(ab, smaller);
         node[NW] = (uint64_t)A | ((uint64_t)B << 32);
+        if (way.key && eb_is_way(slot, way.period_mask)) { handed_over = true; break; }
         cur = kmer_next<NW>(cur, out, filter);
     }
-    if (slot != r.far_slot) { atomicAdd(errors, 1ULL); return; }
+    if (!handed_over && slot != r.far_slot) { atomicAdd(errors, 1ULL); return; }
     // dislink2prevUncertain on the far node, dislink2nextUncertain on the start node (64-bit word: A low, B high)
     {
         const int bit = last_smaller ? 6 * prev_ch : 32 + 6 * (prev_ch ^ 2);
@@ -1422,7 +1584,11 @@ int p2_build_edges(P2Device* d, P2Edges& out) {
     void* d_tmp = nullptr;
     size_t tmp_bytes = 0, tmp2 = 0;
     unsigned long long cnt[4] = {0, 0, 0, 0};        // vertices, kept walks, length-1 walks, errors
-    uint64_t n_list = 0, n_rec = 0, cap_rec = 0, patch_cap = 1024;
+    uint64_t n_list = 0, n_rec = 0, cap_rec = 0, patch_cap = 1024, n_way = 0;
+    EbWay way;
+    memset(&way, 0, sizeof way);
+    way.period_mask = 0xFFFFFFFFu;
+    unsigned long long *d_way = nullptr, *d_wcnt = nullptr;
     unsigned long long total_ids = 0, total_bases = 0, last_ids = 0, last_bases = 0, last_idb = 0, last_bb = 0;
     if (hipSetDevice(d->device) != hipSuccess) { pg_set_error("edges: hipSetDevice failed"); return PG_ENODEV; }
     P2_HIP_GOTO(hipMalloc((void**)&d_cnt, 4 * sizeof(unsigned long long)));
@@ -1436,6 +1602,48 @@ int p2_build_edges(P2Device* d, P2Edges& out) {
         if (rc) goto done;
         n_list = n_listed;
     }
+    // ---- waypoints (see EbWay): list them, map them, walk their segments
+    {
+        // on by itself where chains are long on average (slots per vertex; a 60 M-read K = 63 graph has ~300, the K = 127 one over a
+        // million): the segment walks probe every linear node twice more, which a graph of short chains need not pay for
+        uint32_t period = d->n_slots / (n_list + 1) > 4096 ? 512 : 0;
+        if (const char* v = getenv("SOAPDENOVO2_AMD_EB_WAYPOINTS")) period = (uint32_t)std::max(0, atoi(v));
+        while (period & (period - 1)) period &= period - 1;           // (a power of two)
+        if (period) {
+            way.period_mask = period - 1;
+            unsigned long long n_w = 0;
+            P2_HIP_GOTO(hipMalloc((void**)&d_wcnt, sizeof(unsigned long long)));
+            for (unsigned long long cap_w = d->n_slots / period * 2 + 65536;;) {
+                P2_HIP_GOTO(hipMalloc((void**)&d_way, cap_w * sizeof(unsigned long long)));
+                P2_HIP_GOTO(hipMemsetAsync(d_wcnt, 0, sizeof(unsigned long long), st));
+                for (int si = 0; si < d->P; si++)
+                    if (d->set_sizes[si]) hipLaunchKernelGGL(eb_list_branch, dim3(4096), dim3(256), 0, st, d->set_ptr[si], d->nw + 1, d->set_sizes[si], d->set_first[si], d_way, d_wcnt, cap_w, 1, way.period_mask);
+                P2_HIP_GOTO(hipMemcpyAsync(&n_w, d_wcnt, sizeof n_w, hipMemcpyDeviceToHost, st));
+                P2_HIP_GOTO(hipStreamSynchronize(st));
+                if (n_w <= cap_w) break;
+                hipFree(d_way); d_way = nullptr;
+                cap_w = n_w;
+            }
+            n_way = n_w;
+            if (n_way) {
+                uint64_t cap_m = 1024;
+                while (cap_m < 2 * n_way) cap_m <<= 1;
+                way.mask = cap_m - 1;
+                P2_HIP_GOTO(hipMalloc((void**)&way.key, cap_m * sizeof(unsigned long long)));
+                P2_HIP_GOTO(hipMalloc((void**)&way.seg_end, 2 * cap_m * sizeof(unsigned long long)));
+                P2_HIP_GOTO(hipMalloc((void**)&way.seg_info, 2 * cap_m * sizeof(unsigned long long)));
+                P2_HIP_GOTO(hipMalloc((void**)&way.seg_sum, 2 * cap_m * sizeof(unsigned long long)));
+                P2_HIP_GOTO(hipMalloc((void**)&way.vis_own, 2 * cap_m * sizeof(unsigned long long)));
+                P2_HIP_GOTO(hipMalloc((void**)&way.vis_info, 2 * cap_m * sizeof(unsigned int)));
+                P2_HIP_GOTO(hipMemsetAsync(way.key, 0, cap_m * sizeof(unsigned long long), st));
+                hipLaunchKernelGGL(eb_way_insert, dim3(1024), dim3(256), 0, st, way, d_way, n_way);
+                const dim3 grid((unsigned)((2 * n_way + 255) / 256));
+                if (d->nw == 2) hipLaunchKernelGGL(eb_way_walk<2>, grid, dim3(256), 0, st, d->prm, way, d_way, n_way, d_cnt + 3);
+                else hipLaunchKernelGGL(eb_way_walk<4>, grid, dim3(256), 0, st, d->prm, way, d_way, n_way, d_cnt + 3);
+                P2_HIP_GOTO(hipGetLastError());
+            }
+        }
+    }
     // a vertex has at most eight arcs and every chain is kept from one of its two ends (palindromes aside, which are few):
     // room for five walks a vertex, and a second go with room for all eight should that ever be short
     if (n_list * 8 / 256 >= 0x7FFFFFFFULL) { pg_set_error("edges: too many vertices for one launch"); rc = PG_EINVAL; goto done; }
@@ -1443,11 +1651,12 @@ int p2_build_edges(P2Device* d, P2Edges& out) {
         cap_rec = n_list * (attempt ? 8 : 5) + 1024;
         hipFree(d_recs); d_recs = nullptr;
         P2_HIP_GOTO(hipMalloc((void**)&d_recs, cap_rec * sizeof(EdgeRec)));
-        P2_HIP_GOTO(hipMemsetAsync(d_cnt + 1, 0, 3 * sizeof(unsigned long long), st));
+        P2_HIP_GOTO(hipMemsetAsync(d_cnt + 1, 0, 2 * sizeof(unsigned long long), st));      // (the error counter stays: the segment walks may have used it)
+        if (way.key) P2_HIP_GOTO(hipMemsetAsync(way.vis_own, 0xFF, 2 * (way.mask + 1) * sizeof(unsigned long long), st));
         if (n_list) {
             const dim3 grid((unsigned)((n_list * 8 + 255) / 256));
-            if (d->nw == 2) hipLaunchKernelGGL(eb_walk<2>, grid, dim3(256), 0, st, d->prm, d_list, n_list, d_recs, cap_rec, d_cnt + 1, d_cnt + 2, d_cnt + 3);
-            else hipLaunchKernelGGL(eb_walk<4>, grid, dim3(256), 0, st, d->prm, d_list, n_list, d_recs, cap_rec, d_cnt + 1, d_cnt + 2, d_cnt + 3);
+            if (d->nw == 2) hipLaunchKernelGGL(eb_walk<2>, grid, dim3(256), 0, st, d->prm, d_list, n_list, d_recs, cap_rec, d_cnt + 1, d_cnt + 2, d_cnt + 3, way);
+            else hipLaunchKernelGGL(eb_walk<4>, grid, dim3(256), 0, st, d->prm, d_list, n_list, d_recs, cap_rec, d_cnt + 1, d_cnt + 2, d_cnt + 3, way);
             P2_HIP_GOTO(hipGetLastError());
         }
         P2_HIP_GOTO(hipMemcpyAsync(cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, st));
@@ -1498,10 +1707,16 @@ int p2_build_edges(P2Device* d, P2Edges& out) {
         {
             const dim3 grid((unsigned)((n_rec + 255) / 256));
             if (d->nw == 2) hipLaunchKernelGGL(eb_apply<2>, grid, dim3(256), 0, st, d->prm, d_recs, d_order, n_rec, d_id_before, d_base_before, d_text,
-                                               d->d_patch_keys, d->d_patch_val, patch_cap - 1, d_cnt + 3);
+                                               d->d_patch_keys, d->d_patch_val, patch_cap - 1, d_cnt + 3, way);
             else hipLaunchKernelGGL(eb_apply<4>, grid, dim3(256), 0, st, d->prm, d_recs, d_order, n_rec, d_id_before, d_base_before, d_text,
-                                    d->d_patch_keys, d->d_patch_val, patch_cap - 1, d_cnt + 3);
+                                    d->d_patch_keys, d->d_patch_val, patch_cap - 1, d_cnt + 3, way);
             P2_HIP_GOTO(hipGetLastError());
+            if (way.key) {                                              // the segments behind the waypoints the kept walks passed
+                const dim3 gs((unsigned)((2 * (way.mask + 1) + 255) / 256));
+                if (d->nw == 2) hipLaunchKernelGGL(eb_apply_seg<2>, gs, dim3(256), 0, st, d->prm, way, d_recs, d_order, d_key2, n_rec, d_id_before, d_base_before, d_text, d_cnt + 3);
+                else hipLaunchKernelGGL(eb_apply_seg<4>, gs, dim3(256), 0, st, d->prm, way, d_recs, d_order, d_key2, n_rec, d_id_before, d_base_before, d_text, d_cnt + 3);
+                P2_HIP_GOTO(hipGetLastError());
+            }
         }
         // what the host needs for the text records: the walks in slot order with their text offsets, and the bases
         {
@@ -1522,6 +1737,8 @@ int p2_build_edges(P2Device* d, P2Edges& out) {
 done:
     hipFree(d_list); hipFree(d_cnt); hipFree(d_key); hipFree(d_key2); hipFree(d_ids); hipFree(d_bases); hipFree(d_id_before); hipFree(d_base_before);
     hipFree(d_idx); hipFree(d_order); hipFree(d_recs); hipFree(d_export); hipFree(d_text); hipFree(d_tmp);
+    hipFree(d_way); hipFree(d_wcnt); hipFree(way.key); hipFree(way.seg_end); hipFree(way.seg_info); hipFree(way.seg_sum); hipFree(way.vis_own); hipFree(way.vis_info);
+    if (getenv("PG_HOST_VERBOSE") && n_way) fprintf(stderr, "edges: %llu waypoint(s) (about every %u-th linear node): chains walked by jumps\n", (unsigned long long)n_way, way.period_mask + 1);
     return rc;
 }
 

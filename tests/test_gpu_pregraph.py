@@ -223,6 +223,26 @@ def test_cli_matches_reference_files(golden, tmp_path, name, engine):
         assert md5_file(pre + ".contig") == golden["md5"][t]["contig"], t
 
 
+@pytest.mark.parametrize("period", [1, 4, 32])
+@pytest.mark.parametrize("name", ["t6k_k31", "t8k_k63", "t6k_k127", "m100k_k31", "m60k_k63", "d8k_k127", "r8k_k127", "d8k_k63"])
+def test_cli_edges_through_waypoints(golden, tmp_path, name, period):
+    """The edge builder's jumps (graph_kernels.hip: EbWay): with every linear node (period 1), every 4th or every 32nd a waypoint, the
+    chains of the golden cases -- a few dozen to a few thousand nodes, SNP bubbles with length-1 edges, repeats, both flavours -- are walked
+    by jumps and written by the segment lanes: same edge text, same ids, same tags (the pre-arcs of pass 2 read them), same -R files."""
+    c = golden["cases"][name]
+    cfg = case_config(c, str(tmp_path), name)
+    for run in c["runs"]:
+        P, D, a, m = run
+        t = case_tag(name, run)
+        pre = str(tmp_path / t)
+        log = _run_cli(cfg, c["K"], pre, P, D, a, m, R=True, extra_env=dict(PARALLEL_PARSE, PG_HOST_VERBOSE="1", SOAPDENOVO2_AMD_EB_WAYPOINTS=str(period)))
+        assert "waypoint(s)" in log, log[-1500:]
+        want = golden["md5"][t]
+        for ext in ("kmerFreq", "preGraphBasic", "vertex", "preArc", "path", "markOnEdge"):
+            assert md5_file(pre + "." + ext) == want[ext], (t, ext)
+        assert md5_gz_text(pre + ".edge.gz") == want["edge"], t
+
+
 def test_cli_static_pools_under_load(golden, tmp_path):
     """-a pools at a realistic load: the smallest pool is 16.7 M slots a set (prlHashReads.c:372-390), so the other -a fixtures never
     collide.  1.5 M reads x 100 bp over a 12 Mb genome, K = 31, -p 2 -a 1: two sets of 33.5 M slots at about 52 % -- probe clusters of
@@ -800,8 +820,10 @@ def test_cli_layout_on_the_device_and_on_the_host(golden, tmp_path, name, layout
 @pytest.mark.gpu
 @pytest.mark.parametrize("toggle", [{"PG_K2_KS": "0", "PG_K1_W": "0"}, {"SOAPDENOVO2_AMD_KEEP_ON_HOST": "1"}, {"SOAPDENOVO2_AMD_EDGE_FILE_INLINE": "1"},
                                     {"SOAPDENOVO2_AMD_PARSE_SIMD": "0", "SOAPDENOVO2_AMD_READER": "map"}, {"SOAPDENOVO2_AMD_LAYOUT_LANES": "1"},
-                                    {"PG_K2_VT": "4", "PG_K2_OPT": "0", "SOAPDENOVO2_AMD_P2_BLOCK": "4"}, {"PG_K2_VT": "1", "PG_K2_KS": "0", "SOAPDENOVO2_AMD_P2_BLOCK": "8"}],
-                         ids=["general-kernels", "reads-kept-on-host", "edge-file-inline", "scalar-mapped-reader", "one-layout-lane", "round3-k2-shares", "round2-k2-static"])
+                                    {"PG_K2_VT": "4", "PG_K2_OPT": "0", "SOAPDENOVO2_AMD_P2_BLOCK": "4"}, {"PG_K2_VT": "1", "PG_K2_KS": "0", "SOAPDENOVO2_AMD_P2_BLOCK": "8"},
+                                    {"SOAPDENOVO2_AMD_EB_WAYPOINTS": "0", "PG_K2_OPT": "5", "PG_EXPORT_ASYNC": "0"}],
+                         ids=["general-kernels", "reads-kept-on-host", "edge-file-inline", "scalar-mapped-reader", "one-layout-lane", "round3-k2-shares", "round2-k2-static",
+                              "no-waypoints-presplit-sync-export"])
 @pytest.mark.parametrize("name", ["m60k_k63", "t6k_k127"])
 def test_cli_round3_switches_do_not_change_the_files(golden, tmp_path, name, toggle):
     """What round 3 made the default has a switch back, and the files do not depend on it: the K2 / K1 kernels instantiated for one K
