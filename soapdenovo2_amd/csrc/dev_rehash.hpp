@@ -163,11 +163,13 @@ struct RhApply {
     unsigned int* dirty;
     uint32_t* list_next;
     unsigned long long* n_dirty;
-    int want_list;
+    const unsigned long long* n_chg;    // the sweep's count of time changes: a list of the clusters to sweep again is made here while it is short (the host
+    unsigned long long list_max;        // reads both counters in ONE go afterwards and decides the same way)
     PG_HD void operator()(uint64_t lane) const {
         const uint64_t j = list ? list[lane] : lane;
         const uint32_t k = chg_n[j];
         if (!k) return;
+        const bool want_list = *n_chg <= list_max;
         chg_n[j] = 0;
         uint32_t fresh = 0;
         for (uint32_t i = 0; i < k; i++) {
@@ -341,21 +343,39 @@ int layout_growable(BE& be, RhWork<BE>& wk, const uint64_t* rec, uint64_t n, con
         uint32_t* list_next = wk.list_a;
         uint64_t n_list = 0;
         const uint64_t list_max = std::max<uint64_t>(1024, M >> 10);  // more changes than this: the list is made from the flags by a prefix sum, not by an atomic a cluster
-        for (int round = 0;; round++) {
+        // Small sizes are nothing but rounds, and a round's work there is microseconds against the ~0.6 ms its read-back costs (a drained
+        // stream and a copy): eight rounds at a time are launched blind -- full sweeps that skip the clusters whose flag is down, no lists --
+        // and the host looks at the last one's change count; the rounds behind the fixed point find nothing to do.
+        const char* const blind_env = getenv("PG_RH_BLIND_MAX");              // (0: every round read back, for A/B runs and tests)
+        const uint64_t blind_max = blind_env ? (uint64_t)atoll(blind_env) : (uint64_t)1 << 18;
+        const bool blind = n_old && M <= blind_max;
+        for (int round = 0; blind;) {
+            if (round > 100000) { rc = PG_EINVAL; be.error_text = "layout_growable: the fixed point did not settle"; break; }
+            for (int q = 0; q < 8; q++, round++) {
+                if (rounds_out) (*rounds_out)++;
+                be.fill(scal, 2, 0ULL);
+                be.launch(M, RhSweep{hs_use, is_use, m, Ts, T_old, dirty, nullptr, heap_t, heap_e, slot_new, elem_prev, chg_e, chg_t, chg_n, scal, M, S, origin, s_prev, round > 0});
+                be.launch(M, RhApply{nullptr, chg_n, chg_e, chg_t, pos_of, cs, slot_prev, Ts, T_old, dirty, list_next, scal + 1, scal, 0ULL});
+            }
+            unsigned long long last_chg = 0;
+            be.to_host(&last_chg, scal, 1);
+            if (be.error || !last_chg) break;
+        }
+        for (int round = 0; !blind; round++) {
             if (round > 100000) { rc = PG_EINVAL; be.error_text = "layout_growable: the fixed point did not settle"; break; }
             if (rounds_out) (*rounds_out)++;
             be.fill(scal, 2, 0ULL);
             be.launch(list_cur ? n_list : M, RhSweep{hs_use, is_use, m, Ts, T_old, dirty, list_cur, heap_t, heap_e, slot_new, elem_prev, chg_e, chg_t, chg_n, scal, M, S, origin,
                                                      n_old ? s_prev : 0, round > 0});
             if (!n_old) break;                                        // nobody was there before: arrival order is all there is
-            unsigned long long n_chg = 0;
-            be.to_host(&n_chg, scal, 1);
+            // (the changes are applied before the host knows whether there were any: one read-back a round instead of two -- a read-back is a
+            //  drained stream and a copy, ~0.6 ms, and the small sizes of a set are nothing but rounds)
+            be.launch(list_cur ? n_list : M, RhApply{list_cur, chg_n, chg_e, chg_t, pos_of, cs, slot_prev, Ts, T_old, dirty, list_next, scal + 1, scal, (unsigned long long)list_max});
+            unsigned long long both[2] = {0, 0};
+            be.to_host(both, scal, 2);
+            const unsigned long long n_chg = both[0], n_dirty_h = both[1];
             if (be.error || !n_chg) break;
             const bool want_list = n_chg <= list_max;
-            be.launch(list_cur ? n_list : M, RhApply{list_cur, chg_n, chg_e, chg_t, pos_of, cs, slot_prev, Ts, T_old, dirty, list_next, scal + 1, want_list});
-            unsigned long long n_dirty_h = 0;
-            be.to_host(&n_dirty_h, scal + 1, 1);
-            if (be.error) break;
             if (rh_debug) fprintf(stderr, "rh size %llu keys %llu round %d: %llu time changes, %llu clusters to sweep again, %.3f ms since the size began\n", (unsigned long long)S,
                                   (unsigned long long)M, round, n_chg, n_dirty_h, 1e3 * (rh_now() - t_epoch));
             if (!want_list) {

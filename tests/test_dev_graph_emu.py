@@ -167,9 +167,13 @@ def test_layout_growable_equals_the_host_replay(golden, tmp_path, name, P, m):
     assert int(rounds.max()) >= 2
 
 
-def test_layout_growable_random_keys_and_the_trailing_duplicate():
+@pytest.mark.parametrize("blind_max", [None, 0, 2000])
+def test_layout_growable_random_keys_and_the_trailing_duplicate(blind_max, monkeypatch):
     """Random keys (no genome structure), set sizes right at the growth thresholds, with and without a duplicate put behind the
-    last new key (newhash.c:477 tests the growth before it probes)."""
+    last new key (newhash.c:477 tests the growth before it probes).  blind_max: up to which size the fixed point's rounds are
+    launched eight at a time without a read-back (dev_rehash.hpp; default 2^18 keys: all of these sets; 0: none; 2000: some sizes of a set)."""
+    if blind_max is not None:
+        monkeypatch.setenv("PG_RH_BLIND_MAX", str(blind_max))
     rng = np.random.default_rng(77)
     for n in (1, 5, 793, 794, 795, 1590, 1591, 5000, 40000):
         for trailing in (False, True):
