@@ -426,6 +426,7 @@ public:
         hipStreamDestroy(stream_);
     }
     bool finish_ok() override { submit(); HIP_OK(hipStreamSynchronize(stream_)); return !failed_; }
+    void set_ctx(pg_ctx* ctx) { ctx_ = ctx; }                       // (the buffers are made while the context's pools are still being allocated)
 
 private:
     struct Dev { uint64_t *d_words, *d_off, *d_base; hipEvent_t done; bool busy; };
@@ -796,14 +797,23 @@ int run(int argc, char** argv, bool mer127) {
     if (const char* e = getenv("PG_ENGINE")) engine = atoi(e);
     for (int attempt = 0;; attempt++) {
         mark("input files sized");
-        ctx = pg_create_sized(device, K, mer127 ? 1 : 0, o.sets, log2_slots, engine, est_kmers);
-        if (!ctx) die("pg_create");
-        mark("device context created (HIP start-up, record pool, export array)");
-        if (attempt == 0) fprintf(stderr, "%d k-mer set(s) on HIP device %d.\n", o.sets, device);
+        // the context (HIP start-up, the record pool: tens of gigabytes the driver hands out cleared) on a thread of its own while this one
+        // page-locks the batch buffers (which takes half a second when the page cache is full of a file somebody has just written)
+        std::string ctx_err;
+        std::thread ctx_thread([&] {
+            (void)hipSetDevice(device);
+            ctx = pg_create_sized(device, K, mer127 ? 1 : 0, o.sets, log2_slots, engine, est_kmers);
+            if (!ctx) ctx_err = pg_last_error();
+        });
         bool ok = true;
         {
-            Pass1 p1(ctx, K, batch_words, batch_reads);
+            Pass1 p1(nullptr, K, batch_words, batch_reads);
             mark("pinned batch buffers allocated");
+            ctx_thread.join();
+            if (!ctx) { fprintf(stderr, "%s\n", ctx_err.c_str()); die("pg_create"); }
+            p1.set_ctx(ctx);
+            mark("device context created (HIP start-up, record pool; the export array follows beside pass 1)");
+            if (attempt == 0) fprintf(stderr, "%d k-mer set(s) on HIP device %d.\n", o.sets, device);
             if (attempt == 0) {
                 p1.keep_reads(keep_budget);
                 p1.keep_reads_on_device(dev_keep_budget);

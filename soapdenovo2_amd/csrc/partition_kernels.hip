@@ -814,7 +814,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 const uint32_t total_occ = s_tot, share = VT == 0 ? 1u : (total_occ + VL - 1) / VL;
                 const uint32_t* const rl = rl2[b];
                 if ((opt & 4) && mask == 0 && usable <= (uint32_t)WIN && acc_occ >= 4096u &&
-                    (unsigned long long)total_occ * acc_live * 100ull > (unsigned long long)(((opt >> 8) & 0xFF) ? ((opt >> 8) & 0xFF) : 65) * SLOTS * (unsigned long long)acc_occ) presplit = true;
+                    (unsigned long long)total_occ * acc_live * 100ull > (unsigned long long)(((opt >> 8) & 0xFF) ? ((opt >> 8) & 0xFF) : 75) * SLOTS * (unsigned long long)acc_occ) presplit = true;
                 if (!presplit && !__hip_atomic_load(&aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
                   // (VT > 1) tiles of 64 virtual lanes: the wave's first one is its own number, the next ones come off the counter
                   for (uint32_t tile = (uint32_t)wave;;) {
@@ -1407,7 +1407,7 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     if (const char* v = getenv("PG_K2_WIN")) k2win = atoi(v);
     // bit 0: live slots listed in any order (162.9 -> 157.0 ms; with vt = 0: 148.9 ms); bit 2: key ranges foreseen to overflow are split before they
     // are counted -- the 127-mer flavour drops one attempt in ten (198.2 -> 194.2 ms), the 63-mer one in a hundred and loses more to false alarms
-    // (152.6 -> 162.8 ms): on for the former only; bits 8..15: the foreseen load in percent from which on it splits (0 = 65: 45 % 198.8 ms, 55 % 194.3, 65 % 191.1, never 199.3)
+    // (152.6 -> 162.8 ms): on for the former only; bits 8..15: the foreseen load in percent from which on it splits (0 = 75: 45 % 198.8 ms, 55 % 194.3, 65 % 191.1, never 199.3 on one box; 65 % 190.8, 75 % 188.8, 90 % 189.9 on another)
     int k2opt = c->NW == 4 ? 5 : 1;
     if (const char* v = getenv("PG_K2_OPT")) k2opt = atoi(v);
     if (const char* v = getenv("PG_K2_PRESPLIT_PCT")) k2opt = (k2opt & 0xFF) | ((atoi(v) & 0xFF) << 8);
