@@ -241,11 +241,15 @@ public:
         bool uniform = true;
     };
     BatchFiller(int K, size_t max_words, size_t max_reads, int n_bufs) : K_(K), max_words_(max_words), max_reads_(max_reads), buf_(n_bufs) {
+        const bool trace = getenv("PG_STARTUP_TRACE") && atoi(getenv("PG_STARTUP_TRACE"));
+        const auto t0 = std::chrono::steady_clock::now();
         for (Buf& b : buf_) {
             HIP_OK(hipHostMalloc((void**)&b.h_words, (max_words_ + 8) * sizeof(uint64_t), hipHostMallocDefault));
+            if (trace && &b == &buf_[0]) fprintf(stderr, "[cli]   first page-locked buffer (with this thread's share of the runtime start-up): %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
             HIP_OK(hipHostMalloc((void**)&b.h_off, max_reads_ * sizeof(uint64_t), hipHostMallocDefault));
             HIP_OK(hipHostMalloc((void**)&b.h_base, (max_reads_ + 1) * sizeof(uint64_t), hipHostMallocDefault));
         }
+        if (trace) fprintf(stderr, "[cli]   all page-locked batch buffers: %.3f s\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
         reset(buf_[0]);
     }
     ~BatchFiller() override {
@@ -407,7 +411,16 @@ protected:
 class Pass1 : public BatchFiller {
 public:
     Pass1(pg_ctx* ctx, int K, size_t max_words, size_t max_reads) : BatchFiller(K, max_words, max_reads, 2), ctx_(ctx) {
+        const bool trace = getenv("PG_STARTUP_TRACE") && atoi(getenv("PG_STARTUP_TRACE"));
+        auto t0 = std::chrono::steady_clock::now();
+        auto step = [&](const char* what) {
+            if (!trace) return;
+            const auto t = std::chrono::steady_clock::now();
+            fprintf(stderr, "[cli]   %s: %.3f s\n", what, std::chrono::duration<double>(t - t0).count());
+            t0 = t;
+        };
         HIP_OK(hipStreamCreate(&stream_));
+        step("pass 1's stream");
         for (int i = 0; i < 2; i++) {
             Dev& d = dev_[i];
             HIP_OK(hipMalloc((void**)&d.d_words, (max_words_ + 8) * sizeof(uint64_t)));
@@ -415,6 +428,7 @@ public:
             HIP_OK(hipMalloc((void**)&d.d_base, (max_reads_ + 1) * sizeof(uint64_t)));
             HIP_OK(hipEventCreateWithFlags(&d.done, hipEventDisableTiming));
             d.busy = false;
+            step("a batch's device buffers (96 MiB) + event");
         }
     }
     ~Pass1() override {
@@ -805,11 +819,12 @@ int run(int argc, char** argv, bool mer127) {
             ctx = pg_create_sized(device, K, mer127 ? 1 : 0, o.sets, log2_slots, engine, est_kmers);
             if (!ctx) ctx_err = pg_last_error();
         });
+        if (getenv("PG_CTX_THREAD") && atoi(getenv("PG_CTX_THREAD")) == 0) ctx_thread.join();      // (A/B: one after the other)
         bool ok = true;
         {
             Pass1 p1(nullptr, K, batch_words, batch_reads);
             mark("pinned batch buffers allocated");
-            ctx_thread.join();
+            if (ctx_thread.joinable()) ctx_thread.join();
             if (!ctx) { fprintf(stderr, "%s\n", ctx_err.c_str()); die("pg_create"); }
             p1.set_ctx(ctx);
             mark("device context created (HIP start-up, record pool; the export array follows beside pass 1)");

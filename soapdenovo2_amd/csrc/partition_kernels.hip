@@ -27,6 +27,8 @@
 #include <algorithm>
 #include <vector>
 
+#include <chrono>
+
 #include "device_ctx.hpp"
 #include "extract.hpp"
 #include "occ32.hpp"
@@ -39,9 +41,12 @@ constexpr uint64_t L_EMPTY = ~0ULL;
 constexpr unsigned long long F_POOL = 1, F_CHUNKS = 2, F_OUT = 4, F_SPLIT = 8, F_ROUTE = 16;   // F_ROUTE: an owner's send region overflowed (multi-GPU cut)
 
 template <int NW> struct E2Cfg;
-// LDS slot = KW key words | ord | 10 x u32 counters (L[4], R[4], puts, spare)
-template <> struct E2Cfg<2> { static constexpr int PW = 5, KW = 2; };    // LDS slot: 2 key words + ord + 9 counters = 60 B
-template <> struct E2Cfg<4> { static constexpr int PW = 7, KW = 5; };    // 5 key words + ord + 9 counters = 84 B
+// LDS slot = KW key words | ord | 5 x u32 of counters (LdsSet below).  Two-word flavour: words of 63 bits, so that no word of a key
+// is the empty mark ~0 and a slot is claimed word by word.  Four-word flavour: 254 bits do not fit four such words, and a fifth costs
+// 8 of 68 bytes a slot -- the k-mer's own four words instead (the first, the most significant, has its two top bits free: never ~0,
+// and bit 63 marks a slot whose other words are still being written; lds_put)
+template <> struct E2Cfg<2> { static constexpr int PW = 5, KW = 2; };    // LDS slot: 2 key words + ord + 20 B of counters = 44 B
+template <> struct E2Cfg<4> { static constexpr int PW = 7, KW = 4; };    // 4 key words + ord + 20 B = 60 B: 2048 slots in 120 KB
 
 struct E2Dev {
     SkmGeom g;
@@ -333,6 +338,42 @@ __device__ __forceinline__ bool lds_put(LdsSet<NW, SLOTS>& t, const uint64_t (&k
                                          uint64_t ord, uint32_t copies) {
     constexpr int KW = E2Cfg<NW>::KW;
     uint32_t h = hash & (SLOTS - 1);
+    if constexpr (NW == 4) {
+        // The claim is ONE compare-and-swap on word 0 (empty -> mine | L_PENDING); the winner then writes words 1..3 and, released
+        // behind them, word 0 without the mark.  Everybody reads word 0 FIRST (volatile: the four reads keep their order, and the LDS
+        // serves a wave's operations in order): a clean word 0 therefore comes with final words 1..3.  Whoever meets the mark -- or
+        // loses the claim -- looks at the same slot again; the winner never waits for anybody, so this ends.
+        constexpr unsigned long long L_PENDING = 1ULL << 63;
+        for (int probes = 0; probes < K2_MAXPROBE + 16; probes++) {
+            unsigned long long seen[KW];
+#pragma unroll
+            for (int i = 0; i < KW; i++) seen[i] = *(volatile unsigned long long*)&t.key[i][h];
+            const unsigned long long so = t.ord[h];
+            bool mine = false, again = false;
+            if (seen[0] == L_EMPTY) {
+                const unsigned long long old = atomicCAS(&t.key[0][h], L_EMPTY, (unsigned long long)kw[0] | L_PENDING);
+                if (old == L_EMPTY) {
+#pragma unroll
+                    for (int i = 1; i < KW; i++) t.key[i][h] = (unsigned long long)kw[i];
+                    __hip_atomic_store(&t.key[0][h], (unsigned long long)kw[0], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    mine = true;
+                } else again = true;
+            } else if (seen[0] & L_PENDING) again = true;
+            else {
+                mine = true;
+#pragma unroll
+                for (int i = 0; i < KW; i++) mine = mine && seen[i] == kw[i];
+            }
+            if (mine) {
+                atomicAdd(&t.cnt[left < 4 ? left >> 1 : 4][h], left < 4 ? copies << ((left & 1u) * 16u) : copies);
+                if (right < 4) atomicAdd(&t.cnt[2 + (right >> 1)][h], copies << ((right & 1u) * 16u));
+                if (ord < so) atomicMin(&t.ord[h], (unsigned long long)ord);
+                return true;
+            }
+            if (!again) h = (h + 1) & (SLOTS - 1);
+        }
+        return false;
+    }
     for (int probes = 0; probes < K2_MAXPROBE; probes++) {
         unsigned long long seen[KW];
 #pragma unroll
@@ -379,6 +420,8 @@ __device__ __forceinline__ unsigned int wave_inclusive_sum(unsigned int x) {
     return x;
 }
 
+constexpr int pow2_at_least(int x) { int p = 1; while (p < x) p <<= 1; return p; }
+
 // VT: the occurrences of a window are cut into VT * THREADS equal shares ("virtual lanes"); a wave takes 64 of them at a time
 // from a counter in LDS until none are left.  VT = 1 is the static split (lane l takes share l); with more shares than lanes a
 // wave that finishes early -- shorter probe sequences, fewer lost CAS -- takes the next tile instead of waiting at the barrier.
@@ -407,9 +450,10 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     // first window arrives in the other buffer.
     __shared__ __align__(16) uint32_t rl2[2][RL_WORDS];
     // one scratch area, two lives: the record-dedupe table (DT slots), then the flattening tables
-    constexpr int DT = 2 * WIN;                                           // open addressing over the window's records, <= 50 % full
+    constexpr int DT = pow2_at_least(2 * WIN);                            // open addressing over the window's records, <= 50 % full
     constexpr int VL = (VT ? VT : 1) * THREADS;                           // virtual lanes
-    constexpr int SB_WORDS = (WIN * 127 + 31) / 32 + 2;                   // VT = 0: a start bit per occurrence of a window (<= WIN * 127)
+    constexpr int NMAX = KS ? (32 * PW - (KS - 1) - 2 < 127 ? 32 * PW - (KS - 1) - 2 : 127) : 127;   // k-mers a record (skm_geometry)
+    constexpr int SB_WORDS = (WIN * NMAX + 31) / 32 + 2;                  // VT = 0: a start bit per occurrence of a window (<= WIN * NMAX)
     constexpr int SB_AT = ((DT > WIN + 1 + WIN ? DT : WIN + 1 + WIN) + 1) & ~1;      //         behind the dedupe table and behind tile_rep0; read 64 bits at a time
     constexpr int FL_WORDS = VT == 0 ? SB_AT + SB_WORDS : (DT > WIN + 1 + VL / 2 ? DT : WIN + 1 + VL / 2) + 2;
     static_assert(VT != 0 || WIN * 127 / 64 + 1 <= 2 * WIN, "tile_rep0 holds a short per tile");
@@ -671,9 +715,9 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 cr[2 * c] = rw2 & 0xFFFFu; cr[2 * c + 1] = rw2 >> 16;
             }
             const unsigned int puts = cl[0] + cl[1] + cl[2] + cl[3] + set.cnt[4][si];
-            Key63<NW> k63;
+            unsigned long long kws[KW];
 #pragma unroll
-            for (int w = 0; w < KW; w++) k63.w[w] = set.key[w][si];
+            for (int w = 0; w < KW; w++) kws[w] = set.key[w][si];
             const unsigned long long first = set.ord[si];
             // wipe the slot
 #pragma unroll
@@ -681,7 +725,16 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
             set.ord[si] = L_EMPTY;
 #pragma unroll
             for (int q = 0; q < 5; q++) set.cnt[q][si] = 0;
-            const Kmer<NW> key = kmer_from_key63<NW>(k63);
+            Kmer<NW> key;
+            if constexpr (NW == 4) {
+#pragma unroll
+                for (int w = 0; w < NW; w++) key.w[w] = kws[w];
+            } else {
+                Key63<NW> k63;
+#pragma unroll
+                for (int w = 0; w < KW; w++) k63.w[w] = kws[w];
+                key = kmer_from_key63<NW>(k63);
+            }
             uint32_t A = min(puts, 255u) << 24, B = puts == 1 ? B_SINGLE : 0u;
             int nin = 0, nout = 0;
 #pragma unroll
@@ -862,7 +915,10 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                             if (((hh >> 11) & mask) != val) continue;
                             if (dbg & 1) { if (hh == 0x1234) aborted = 1; continue; }      // measurement aid: extraction only
                             uint64_t kw[KW];
-                            occ_key63<NW>(c, kw);
+                            if constexpr (NW == 4) {
+#pragma unroll
+                                for (int q = 0; q < KW; q++) kw[q] = ((uint64_t)c[2 * q] << 32) | c[2 * q + 1];
+                            } else occ_key63<NW>(c, kw);
                             const uint32_t h_lo = rec[0], h_hi = rec[1];
                             const uint32_t copies = ((h_lo >> 9) & 0x1FFu) + 1u;
                             const uint64_t ord = ((((uint64_t)h_hi << 32) | h_lo) >> SKM_ORD_SHIFT) + t;
@@ -1030,9 +1086,9 @@ static E2Dev dev_view(const pg_ctx* c) {
 
 int e2_create(pg_ctx* c) {
     E2& s = c->e2;
-    // partitions: expected distinct / ~1000 so a partition usually fits the LDS set in one attempt; a quarter of that for the
-    // 127-mer flavour (a 1024-slot set, five key words to claim per new k-mer: measured best, profiles/r02_bench_k127.json)
-    s.log2_parts = std::max(8, std::min(24, c->log2_slots - (c->NW == 4 ? 9 : 11)));
+    // partitions: expected distinct / ~1000 so a partition usually fits the LDS set in one attempt; half of that for the
+    // 127-mer flavour (fewer occurrences a distinct k-mer at the same read length)
+    s.log2_parts = std::max(8, std::min(24, c->log2_slots - (c->NW == 4 ? 10 : 11)));
     if (c->hint_log2_parts >= 0) s.log2_parts = std::max(8, std::min(24, c->hint_log2_parts));
     if (const char* v = getenv("PG_LOG2_PARTS")) s.log2_parts = std::max(4, std::min(24, atoi(v)));
     s.g = skm_geometry(c->K, s.log2_parts, c->NW);
@@ -1081,9 +1137,21 @@ int e2_create(pg_ctx* c) {
     // chunk table: up to 2^29 entries in total (2 GB), at least enough for an even spread x8
     const uint64_t even = (s.pool_chunks - (uint64_t)s.direct * parts + parts - 1) / parts;
     s.maxc = (uint32_t)std::max<uint64_t>(8, std::min<uint64_t>(std::min<uint64_t>(256 - s.direct, ((uint64_t)1 << 29) / parts), even * 16));
+    // PG_STARTUP_TRACE=1: what each step of the start-up took (stderr), for boxes on which a command's first second is not its own
+    const bool trace = getenv("PG_STARTUP_TRACE") && atoi(getenv("PG_STARTUP_TRACE"));
+    auto t_last = std::chrono::steady_clock::now();
+    auto step = [&](const char* what, double gb) {
+        if (!trace) return;
+        const auto t = std::chrono::steady_clock::now();
+        fprintf(stderr, "[ctx]   %-44s %7.3f s  (%.2f GB)\n", what, std::chrono::duration<double>(t - t_last).count(), gb);
+        t_last = t;
+    };
+    step("geometry, hipMemGetInfo", 0.0);
     E2_TRY(hipMalloc(&s.cursor, parts * sizeof(uint32_t)));
     E2_TRY(hipMalloc(&s.chunk_tbl, parts * s.maxc * sizeof(uint32_t)));
+    step("hipMalloc: cursors + chunk table", (double)(parts * (s.maxc + 1) * sizeof(uint32_t)) / 1e9);
     E2_TRY(hipMalloc(&s.pool, s.pool_chunks * chunk_bytes + 64));
+    step("hipMalloc: record pool", (double)(s.pool_chunks * chunk_bytes) / 1e9);
     s.out = nullptr; s.out_err = 0;
     if (getenv("PG_EXPORT_ASYNC") && atoi(getenv("PG_EXPORT_ASYNC")) == 0) E2_TRY(hipMalloc(&s.out, std::max<uint64_t>(out_bytes, 64)));
     else {
@@ -1100,6 +1168,7 @@ int e2_create(pg_ctx* c) {
     }
     E2_TRY(hipMemset(s.cursor, 0, parts * sizeof(uint32_t)));
     E2_TRY(hipMemset(s.chunk_tbl, 0, parts * s.maxc * sizeof(uint32_t)));
+    if (trace) { (void)hipDeviceSynchronize(); step("hipMemset: cursors + chunk table (first device work of the process)", (double)(parts * (s.maxc + 1) * sizeof(uint32_t)) / 1e9); }
     s.counted = false;
     s.est_chunks = 0;
     return PG_OK;
@@ -1403,8 +1472,6 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     if (const char* v = getenv("PG_K2_VT")) vt = atoi(v);                 // 1 = static shares (round 2), 2 / 4 = tiles of virtual lanes with a share table (round 3: 177.8 -> 168.7 ms)
     if (const char* v = getenv("PG_DBG")) dbg = atoi(v);
     if (const char* v = getenv("PG_K2CFG")) cfg = atoi(v);
-    int k2win = 512;                                                      // records a window (PG_K2_WIN=256: the 127-mer flavour's partitions hold ~60 records)
-    if (const char* v = getenv("PG_K2_WIN")) k2win = atoi(v);
     // bit 0: live slots listed in any order (162.9 -> 157.0 ms; with vt = 0: 148.9 ms); bit 2: key ranges foreseen to overflow are split before they
     // are counted -- the 127-mer flavour drops one attempt in ten (198.2 -> 194.2 ms), the 63-mer one in a hundred and loses more to false alarms
     // (152.6 -> 162.8 ms): on for the former only; bits 8..15: the foreseen load in percent from which on it splits (0 = 75: 45 % 198.8 ms, 55 % 194.3, 65 % 191.1, never 199.3 on one box; 65 % 190.8, 75 % 188.8, 90 % 189.9 on another)
@@ -1434,14 +1501,15 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
             else if (cfg == 1) hipLaunchKernelGGL((skm_count_kernel<2, 1024, 512, 256, false>), dim3(grid), dim3(512), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
             else hipLaunchKernelGGL((skm_count_kernel<2, 512, 256, 128, false>), dim3(grid * 2), dim3(256), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
         } else {
-            if (cfg == 0 && (dbg & 2) && vt == 0) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, true, 0>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
-            else if (cfg == 0 && (dbg & 2)) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, true, 4>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
-            else if (cfg == 0 && vt == 0 && ks && c->K == 127 && k2win == 256) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 256, false, 0, 127>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
-            else if (cfg == 0 && vt == 0 && ks && c->K == 127) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false, 0, 127>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
-            else if (cfg == 0 && vt == 0) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false, 0>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
-            else if (cfg == 0 && vt == 4 && ks && c->K == 127) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false, 4, 127>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
+            // the 127-mer flavour.  cfg 0: 2048 slots of 60 bytes, windows of 192 records (partitions of ~4 k occurrences); cfg 4: round 4's
+            // shape, 1024 slots and windows of 512 (for partitions half as large: PG_PARTS_SHIFT=1); PG_K2_VT=4 / 1: round 3's / round 2's
+            // way of dealing the occurrences, in that shape
+            if (cfg == 0 && (dbg & 2)) hipLaunchKernelGGL((skm_count_kernel<4, 2048, 1024, 192, true, 0>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
+            else if (cfg == 0 && vt == 0 && ks && c->K == 127) hipLaunchKernelGGL((skm_count_kernel<4, 2048, 1024, 192, false, 0, 127>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
+            else if (cfg == 0 && vt == 0) hipLaunchKernelGGL((skm_count_kernel<4, 2048, 1024, 192, false, 0>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
+            else if (cfg == 4 && ks && c->K == 127) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false, 0, 127>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
+            else if (cfg == 4) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false, 0>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
             else if (cfg == 0 && vt == 4) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false, 4>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
-            else if (cfg == 0 && vt == 2) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false, 2>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
             else if (cfg == 0) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
             else if (cfg == 1) hipLaunchKernelGGL((skm_count_kernel<4, 512, 512, 256, false>), dim3(grid), dim3(512), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
             else hipLaunchKernelGGL((skm_count_kernel<4, 256, 256, 128, false>), dim3(grid * 2), dim3(256), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);

@@ -21,6 +21,7 @@
 // HBM-bound integer/atomic work: no MFMA.  One lane per k-mer occurrence (window extraction from the 2-bit
 // packed read instead of a serial roll, so every lane has exactly one probe sequence in flight).
 #include <hip/hip_runtime.h>
+#include <chrono>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -505,7 +506,8 @@ static int parts_for_kmers(uint64_t total_kmers, int nw) {
     // about 8 k occurrences a partition (2 k for the 127-mer flavour: its LDS set holds half as many keys, and likes them sparse), to
     // the NEAREST power of two: at 200 M x 150 bp, K = 63 (17.6 G occurrences) 2^21 partitions of 8.4 k beat 2^22 of 4.2 k by 7 % in K2
     // (the 127-mer flavour keeps rounding up: 2^22 partitions of 1.1 k beat 2^21 of 2.3 k by 10 % there)
-    while (lp < 24 && (double)((uint64_t)(nw == 4 ? 2048 : 8192) << lp) * (nw == 4 ? 1.0 : 1.4142) < (double)total_kmers) lp++;
+    // round 4, later: the 127-mer flavour's set holds 2048 keys of four words (one claim a key): 4 k occurrences a partition
+    while (lp < 24 && (double)((uint64_t)(nw == 4 ? 4096 : 8192) << lp) * (nw == 4 ? 1.0 : 1.4142) < (double)total_kmers) lp++;
     if (const char* v = getenv("PG_PARTS_SHIFT")) lp = std::max(8, std::min(24, lp + atoi(v)));      // A/B runs: twice / half the partitions
     return lp;
 }
@@ -515,7 +517,11 @@ extern "C" pg_ctx* pg_create_engine(int device, int K, int mer127, int n_sets, i
 }
 extern "C" pg_ctx* pg_create_sized(int device, int K, int mer127, int n_sets, int log2_slots, int engine, uint64_t expected_kmers) {
     int n = 0;
+    const bool trace = getenv("PG_STARTUP_TRACE") && atoi(getenv("PG_STARTUP_TRACE"));
+    const auto t_in = std::chrono::steady_clock::now();
+    auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_in).count(); };
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { g_err = "pg_create: no HIP device available"; return nullptr; }
+    if (trace) fprintf(stderr, "[ctx]   %-44s %7.3f s\n", "hipGetDeviceCount (runtime start-up)", since());
     if (device < 0 || device >= n) { g_err = "pg_create: bad device ordinal"; return nullptr; }
     const int maxK = mer127 ? 127 : 63;
     if (K < 13 || K > maxK || (K & 1) == 0) { g_err = "pg_create: K must be odd and within 13.." + std::to_string(maxK); return nullptr; }
@@ -532,9 +538,11 @@ extern "C" pg_ctx* pg_create_sized(int device, int K, int mer127, int n_sets, in
     if (const char* v = getenv("PG_VARIANT")) c->variant = atoi(v);
     if (engine == 2) {
         if (hipMalloc(&c->ctr, sizeof(DevCounters)) != hipSuccess) { g_err = "pg_create: hipMalloc failed"; delete c; return nullptr; }
+        if (trace) fprintf(stderr, "[ctx]   %-44s %7.3f s (since the call)\n", "hipSetDevice + first hipMalloc", since());
         (void)hipMemset(c->ctr, 0, sizeof(DevCounters));
         if (e2_create(c) != PG_OK) { e2_destroy(c); (void)hipFree(c->ctr); delete c; return nullptr; }
         (void)hipDeviceSynchronize();
+        if (trace) fprintf(stderr, "[ctx]   %-44s %7.3f s (since the call)\n", "context ready", since());
         return c;
     }
     const size_t bytes = ((size_t)1 << log2_slots) * slot_bytes(c->NW);

@@ -821,9 +821,9 @@ def test_cli_layout_on_the_device_and_on_the_host(golden, tmp_path, name, layout
 @pytest.mark.parametrize("toggle", [{"PG_K2_KS": "0", "PG_K1_W": "0"}, {"SOAPDENOVO2_AMD_KEEP_ON_HOST": "1"}, {"SOAPDENOVO2_AMD_EDGE_FILE_INLINE": "1"},
                                     {"SOAPDENOVO2_AMD_PARSE_SIMD": "0", "SOAPDENOVO2_AMD_READER": "map"}, {"SOAPDENOVO2_AMD_LAYOUT_LANES": "1"},
                                     {"PG_K2_VT": "4", "PG_K2_OPT": "0", "SOAPDENOVO2_AMD_P2_BLOCK": "4"}, {"PG_K2_VT": "1", "PG_K2_KS": "0", "SOAPDENOVO2_AMD_P2_BLOCK": "8"},
-                                    {"SOAPDENOVO2_AMD_EB_WAYPOINTS": "0", "PG_K2_OPT": "5", "PG_EXPORT_ASYNC": "0"}],
+                                    {"SOAPDENOVO2_AMD_EB_WAYPOINTS": "0", "PG_K2_OPT": "5", "PG_EXPORT_ASYNC": "0"}, {"PG_K2CFG": "1", "PG_PARTS_SHIFT": "1"}],
                          ids=["general-kernels", "reads-kept-on-host", "edge-file-inline", "scalar-mapped-reader", "one-layout-lane", "round3-k2-shares", "round2-k2-static",
-                              "no-waypoints-presplit-sync-export"])
+                              "no-waypoints-presplit-sync-export", "k2-two-workgroups-a-cu"])
 @pytest.mark.parametrize("name", ["m60k_k63", "t6k_k127"])
 def test_cli_round3_switches_do_not_change_the_files(golden, tmp_path, name, toggle):
     """What round 3 made the default has a switch back, and the files do not depend on it: the K2 / K1 kernels instantiated for one K
