@@ -180,7 +180,7 @@ def big_command(args):
                 pre = os.path.join(td, "amd_" + key)
                 t0 = time.time()
                 r = subprocess.run([api.binary(mer127), "pregraph", "-s", cfg, "-K", str(w["kmer"]), "-o", pre, "-p", str(w["sets"])] + (["-a", str(w["a_gb"])] if w["a_gb"] else []),
-                                   capture_output=True, text=True, env=dict(os.environ, PG_HOST_VERBOSE="1"))
+                                   capture_output=True, text=True, env=dict(os.environ, PG_HOST_VERBOSE="1", PG_STARTUP_TRACE="1"))
                 wall = time.time() - t0
                 out.update({"rc": r.returncode, "wall_s": wall, "reads_per_sec": w["reads"] / wall if r.returncode == 0 else None,
                             "stages_s": {m.group(1): float(m.group(2)) for m in re.finditer(r"\[cli\] ([^:]+): ([0-9.]+)s", r.stderr)}})
@@ -192,6 +192,10 @@ def big_command(args):
                 m0, m1 = re.search(r"at ([0-9.]+)s: input files sized", r.stderr), re.search(r"at ([0-9.]+)s: device context created", r.stderr)
                 if m0 and m1:
                     out["device_context_s"] = round(float(m1.group(1)) - float(m0.group(1)), 2)
+                    # what it was made of (PG_STARTUP_TRACE): the steps that took more than 50 ms -- on a box whose device memory another process has
+                    # just released, or has never been handed out cleared, the record pool's hipMalloc waits for the driver to clear it
+                    out["device_context_steps_s"] = {m.group(1).strip(): float(m.group(2)) for m in re.finditer(r"\[(?:ctx|cli)\]   ([^\n]*?):?\s+([0-9.]+) s(?! \(since)", r.stderr)
+                                                     if float(m.group(2)) >= 0.05}
                 m = re.search(r"reader: ([0-9.]+)s cutting \+ parsing", r.stderr)
                 if m:
                     out["reader_s"] = float(m.group(1))

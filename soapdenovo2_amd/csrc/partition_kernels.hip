@@ -45,8 +45,11 @@ template <int NW> struct E2Cfg;
 // is the empty mark ~0 and a slot is claimed word by word.  Four-word flavour: 254 bits do not fit four such words, and a fifth costs
 // 8 of 68 bytes a slot -- the k-mer's own four words instead (the first, the most significant, has its two top bits free: never ~0,
 // and bit 63 marks a slot whose other words are still being written; lds_put)
-template <> struct E2Cfg<2> { static constexpr int PW = 5, KW = 2; };    // LDS slot: 2 key words + ord + 20 B of counters = 44 B
-template <> struct E2Cfg<4> { static constexpr int PW = 7, KW = 4; };    // 4 key words + ord + 20 B = 60 B: 2048 slots in 120 KB
+#ifndef PG_K2_RAW2
+#define PG_K2_RAW2 0                                                       // (1: the two-word flavour with its own two words and one claim too -- built and measured: 156.7 ms
+#endif                                                                     //  against 155.6, profiles/r04k_k2_keys_static_tiles_ab.json; it has no fifth word to lose)
+template <> struct E2Cfg<2> { static constexpr int PW = 5, KW = 2; static constexpr bool RAW = PG_K2_RAW2 != 0; };    // LDS slot: 2 key words + ord + 20 B of counters = 44 B
+template <> struct E2Cfg<4> { static constexpr int PW = 7, KW = 4; static constexpr bool RAW = true; };              // 4 key words + ord + 20 B = 60 B: 2048 slots in 120 KB
 
 struct E2Dev {
     SkmGeom g;
@@ -338,7 +341,7 @@ __device__ __forceinline__ bool lds_put(LdsSet<NW, SLOTS>& t, const uint64_t (&k
                                          uint64_t ord, uint32_t copies) {
     constexpr int KW = E2Cfg<NW>::KW;
     uint32_t h = hash & (SLOTS - 1);
-    if constexpr (NW == 4) {
+    if constexpr (E2Cfg<NW>::RAW) {
         // The claim is ONE compare-and-swap on word 0 (empty -> mine | L_PENDING); the winner then writes words 1..3 and, released
         // behind them, word 0 without the mark.  Everybody reads word 0 FIRST (volatile: the four reads keep their order, and the LDS
         // serves a wave's operations in order): a clean word 0 therefore comes with final words 1..3.  Whoever meets the mark -- or
@@ -488,6 +491,14 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
 #define K2_SYNC() lds_barrier()
 #define K2_TICK(i) do { if (TIMERS) { const unsigned long long tn_ = clock64(); tp[(i) * TIMERS] += tn_ - tlast; tlast = tn_; } } while (0)
 
+    // opt bit 3 (VT = 0): a wave's first tiles are its own (tile = wave + 16 r for the first rounds but the last full one), only the tail
+    // comes off the counter -- three of four returned LDS atomics (and the wait for each) less a wave and window
+    auto static_rounds = [&](unsigned int tot) -> unsigned int {
+        if (VT != 0 || !(opt & 8) || (opt & 2)) return 1u;                    // (bit 1 asks a tile ahead at every turn: not with it)
+        const unsigned int r = ((tot + 63u) >> 6) / NWAVE;
+        return r > 1u ? r - 1u : 1u;
+    };
+    auto tile_start = [&](unsigned int tot) -> unsigned int { return static_rounds(tot) * NWAVE; };
     // ---- prepare a window: stage -> dedupe -> flatten.  Written as barrier-free steps for a group of GS lanes (gtid = lane
     // index in the group, gwave = wave index in the group); the caller puts a barrier between the steps.
     struct Prep { bool is_rep; unsigned int n, incl; };
@@ -629,7 +640,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
             for (unsigned int l = l0; l < l1; l++) first_rec[l] = (unsigned short)k;
             }
         }
-        if (gtid == 0) { noff[n_rep] = tot; s_tot = tot; tile_ctr = NWAVE; }
+        if (gtid == 0) { noff[n_rep] = tot; s_tot = tot; tile_ctr = tile_start(tot); }
     };
 
     // ---- emit: finalize every stored node and append it to the export array.  The set is a quarter full on average, so
@@ -726,7 +737,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
 #pragma unroll
             for (int q = 0; q < 5; q++) set.cnt[q][si] = 0;
             Kmer<NW> key;
-            if constexpr (NW == 4) {
+            if constexpr (E2Cfg<NW>::RAW) {
 #pragma unroll
                 for (int w = 0; w < NW; w++) key.w[w] = kws[w];
             } else {
@@ -870,6 +881,8 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     (unsigned long long)total_occ * acc_live * 100ull > (unsigned long long)(((opt >> 8) & 0xFF) ? ((opt >> 8) & 0xFF) : 75) * SLOTS * (unsigned long long)acc_occ) presplit = true;
                 if (!presplit && !__hip_atomic_load(&aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
                   // (VT > 1) tiles of 64 virtual lanes: the wave's first one is its own number, the next ones come off the counter
+                  const uint32_t sr = static_rounds(total_occ);
+                  uint32_t round = 0;
                   for (uint32_t tile = (uint32_t)wave;;) {
                     const uint32_t vlane = VT == 1 ? threadIdx.x : tile * 64u + (uint32_t)lane;
                     if (VT != 1 && (tile * 64u * share >= total_occ || __hip_atomic_load(&aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) break;
@@ -915,7 +928,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                             if (((hh >> 11) & mask) != val) continue;
                             if (dbg & 1) { if (hh == 0x1234) aborted = 1; continue; }      // measurement aid: extraction only
                             uint64_t kw[KW];
-                            if constexpr (NW == 4) {
+                            if constexpr (E2Cfg<NW>::RAW) {
 #pragma unroll
                                 for (int q = 0; q < KW; q++) kw[q] = ((uint64_t)c[2 * q] << 32) | c[2 * q + 1];
                             } else occ_key63<NW>(c, kw);
@@ -929,6 +942,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                         }
                     }
                     if (VT == 1) break;
+                    if (++round < sr) { tile += NWAVE; continue; }
                     unsigned int nt = nt_early;
                     if (!(opt & 2) && lane == 0) nt = atomicAdd(&tile_ctr, 1u);
                     tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)nt);
@@ -945,7 +959,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 K2_SYNC();                                                  // the window and its tables are rewritten by the next one
                 // (every wave is past the tile loop: the counter starts over for the next occurrence phase -- the next window,
                 //  or the same window again for another key range -- which is at least one barrier away)
-                if (VT != 1 && threadIdx.x == 0) tile_ctr = NWAVE;
+                if (VT != 1 && threadIdx.x == 0) tile_ctr = tile_start(total_occ);
                 if (w0 + WIN < usable) {                                    // more windows add to these counters: keep the halves small
                     for (int i = threadIdx.x; i < SLOTS; i += THREADS) {    // (they saturate at 63 / 255 in the end anyway)
 #pragma unroll
@@ -1475,7 +1489,8 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     // bit 0: live slots listed in any order (162.9 -> 157.0 ms; with vt = 0: 148.9 ms); bit 2: key ranges foreseen to overflow are split before they
     // are counted -- the 127-mer flavour drops one attempt in ten (198.2 -> 194.2 ms), the 63-mer one in a hundred and loses more to false alarms
     // (152.6 -> 162.8 ms): on for the former only; bits 8..15: the foreseen load in percent from which on it splits (0 = 75: 45 % 198.8 ms, 55 % 194.3, 65 % 191.1, never 199.3 on one box; 65 % 190.8, 75 % 188.8, 90 % 189.9 on another)
-    int k2opt = c->NW == 4 ? 5 : 1;
+    // bit 3: a wave's first tiles are its own, the tail comes off the counter (K = 63: 155.6 -> 154.7 ms; K = 127: no difference)
+    int k2opt = c->NW == 4 ? 5 : 9;
     if (const char* v = getenv("PG_K2_OPT")) k2opt = atoi(v);
     if (const char* v = getenv("PG_K2_PRESPLIT_PCT")) k2opt = (k2opt & 0xFF) | ((atoi(v) & 0xFF) << 8);
     bool ks = true;                                                       // the instantiations for K = 31 / 63 / 127 (PG_K2_KS=0: the general kernel)
