@@ -501,7 +501,15 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     auto tile_start = [&](unsigned int tot) -> unsigned int { return static_rounds(tot) * NWAVE; };
     // ---- prepare a window: stage -> dedupe -> flatten.  Written as barrier-free steps for a group of GS lanes (gtid = lane
     // index in the group, gwave = wave index in the group); the caller puts a barrier between the steps.
-    struct Prep { bool is_rep; unsigned int n, incl; };
+    struct Prep { bool is_rep; unsigned int n, incl, n_rep; };
+    // The search for exact copies pays where there are copies (K = 63 at 300x: every other record; 155.5 ms against 194.1 without it) and costs where there are few (K = 127 from
+    // 150-base reads: a record is most of a read; 162.2 ms against 141.7 without): every workgroup looks at its first 4096 records and stops searching when more than dd_pct % of
+    // them represented themselves.  opt bit 4: never search; bits 16..23: the percentage.  The default is where the search's share of the kernel equals what it saves: 70 % for the
+    // four-word flavour (a 64-byte record to hash and compare; K = 127 from 150-base reads lies between 70 and 85 %: 142.5 ms off, 162.3 on), 82 % for the two-word one (its 15x case
+    // -- 100 M reads over 1 Gb, more than 70 % of the records their own -- still gains 5 % from the search: 218.2 ms on, 229.7 off; profiles/r04m_k2_adaptive_dedupe_ab.json)
+    bool dd_on = !(opt & 16);
+    uint32_t dd_rec = 0, dd_rep = 0;
+    const uint32_t dd_pct = ((opt >> 16) & 0xFF) ? ((opt >> 16) & 0xFF) : (NW == 4 ? 70u : 82u);
     // stage the window's records: 16 bytes per lane and step; the header word as it is, every payload word high dword first
     auto p_stage = [&](auto gs_, int gtid, int nb, int cl, uint32_t w0, uint32_t wn) {
         constexpr int GS = decltype(gs_)::value;
@@ -562,7 +570,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     auto p_dedupe = [&](int gtid, int nb, uint32_t wn, Prep& ps) {
         uint32_t* const rlb = rl2[nb];
         bool is_rep = (uint32_t)gtid < wn;
-        if (is_rep && !(dbg & 4)) {
+        if (is_rep && !(dbg & 4) && dd_on) {
             const uint32_t* me = rlb + PAD + gtid * RD;
             uint32_t w[RD - 1];
             w[0] = me[0] & ((1u << SKM_ORD_SHIFT) - 1);                    // n, has_left, has_right
@@ -574,13 +582,19 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
             hsh *= 0x85EBCA6Bu;
             hsh ^= hsh >> 15;
             uint32_t sl = hsh & (DT - 1);
+            // a table entry = the taker's place in the window + 1 (10 bits) under 22 bits of its hash: a record with another hash is passed by
+            // without reading it (opt bit 5: without the tag, every met record is read and compared)
+            const unsigned int tag = (opt & 32) ? 0u : (hsh >> 10) << 10;
+            static_assert(WIN <= 1023, "a record's place + 1 fits 10 bits");
             for (int probes = 0; probes < DT; probes++) {
                 unsigned int v = dtab[sl];
                 if (v == 0) {
-                    const unsigned int old = atomicCAS(&dtab[sl], 0u, (unsigned int)gtid + 1u);
+                    const unsigned int old = atomicCAS(&dtab[sl], 0u, tag | ((unsigned int)gtid + 1u));
                     if (old == 0) break;                                      // first of its kind: it represents the rest
                     v = old;
                 }
+                if ((v & ~1023u) != tag) { sl = (sl + 1) & (DT - 1); continue; }
+                v &= 1023u;
                 const uint32_t* it = rlb + PAD + (v - 1) * RD;
                 bool same = (it[0] & ((1u << SKM_ORD_SHIFT) - 1)) == w[0];
 #pragma unroll
@@ -614,6 +628,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
 #pragma unroll
         for (int wv = 0; wv < GW; wv++) { const unsigned int cw = wave_cnt_f[wv]; if (wv < gwave) base += cw; tot += cw; }
         const unsigned int n_rep = tot >> 20;
+        ps.n_rep = n_rep;
         tot &= (1u << 20) - 1;
         const unsigned int share = (tot + VL - 1) / VL;
         if (ps.is_rep) {
@@ -868,6 +883,10 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     K2_TICK(10);
                     K2_SYNC();                                            // dtab is dead from here, counts and minima are final
                     p_flat2(whole, threadIdx.x, wave, b, ps);
+                    if (dd_on && dd_rec < 4096u) {                         // (the same numbers in every lane)
+                        dd_rec += wn; dd_rep += ps.n_rep;
+                        if (dd_rec >= 4096u && dd_rep * 100u > dd_rec * dd_pct) dd_on = false;
+                    }
                     K2_SYNC();
                     K2_TICK(3);
                 }
@@ -1492,7 +1511,8 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     // bit 3: a wave's first tiles are its own, the tail comes off the counter (K = 63: 155.6 -> 154.7 ms; K = 127: no difference)
     int k2opt = c->NW == 4 ? 5 : 9;
     if (const char* v = getenv("PG_K2_OPT")) k2opt = atoi(v);
-    if (const char* v = getenv("PG_K2_PRESPLIT_PCT")) k2opt = (k2opt & 0xFF) | ((atoi(v) & 0xFF) << 8);
+    if (const char* v = getenv("PG_K2_PRESPLIT_PCT")) k2opt = (k2opt & ~0xFF00) | ((atoi(v) & 0xFF) << 8);
+    if (const char* v = getenv("PG_K2_DEDUPE_PCT")) k2opt = (k2opt & ~0xFF0000) | ((atoi(v) & 0xFF) << 16);     // (100: always search for copies; default 70, see the kernel)
     bool ks = true;                                                       // the instantiations for K = 31 / 63 / 127 (PG_K2_KS=0: the general kernel)
     if (const char* v = getenv("PG_K2_KS")) ks = atoi(v) != 0;
     if (dbg) ks = false;
