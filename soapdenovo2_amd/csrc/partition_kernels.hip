@@ -45,6 +45,9 @@ template <int NW> struct E2Cfg;
 // is the empty mark ~0 and a slot is claimed word by word.  Four-word flavour: 254 bits do not fit four such words, and a fifth costs
 // 8 of 68 bytes a slot -- the k-mer's own four words instead (the first, the most significant, has its two top bits free: never ~0,
 // and bit 63 marks a slot whose other words are still being written; lds_put)
+#ifndef PG_K2_DMA
+#define PG_K2_DMA 0                                                        // (1: the next window by global_load_lds, rounds 2 - 4, for an A/B build -- see "the next window" in the kernel)
+#endif
 #ifndef PG_K2_RAW2
 #define PG_K2_RAW2 0                                                       // (1: the two-word flavour with its own two words and one claim too -- built and measured: 156.7 ms
 #endif                                                                     //  against 155.6, profiles/r04k_k2_keys_static_tiles_ab.json; it has no fifth word to lose)
@@ -350,7 +353,8 @@ __device__ __forceinline__ bool lds_put(LdsSet<NW, SLOTS>& t, const uint64_t (&k
         for (int probes = 0; probes < K2_MAXPROBE + 16; probes++) {
             unsigned long long seen[KW];
 #pragma unroll
-            for (int i = 0; i < KW; i++) seen[i] = *(volatile unsigned long long*)&t.key[i][h];
+            for (int i = 0; i < KW; i++)                                  // (an LDS pointer, said so: a plain volatile one is read through the flat path, one load at a time)
+                seen[i] = *(volatile __attribute__((address_space(3))) unsigned long long*)(&t.key[i][h]);
             const unsigned long long so = t.ord[h];
             bool mine = false, again = false;
             if (seen[0] == L_EMPTY) {
@@ -515,7 +519,9 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
         constexpr int GS = decltype(gs_)::value;
         uint32_t* const rlb = rl2[nb];
         const unsigned int* const cids = chunk_ids2[cl];
-        for (uint32_t pc = gtid; pc < wn * PIECES; pc += GS) {
+        uint32_t pc_first = (uint32_t)gtid;
+        asm volatile("" : "+v"(pc_first));                                 // (what follows from the lane's number alone is computed here, not at kernel start and then spilled:
+        for (uint32_t pc = pc_first; pc < wn * PIECES; pc += GS) {         //  a reload from scratch waits for every store in flight)
             const uint32_t ri = pc / PIECES, part = pc - ri * PIECES;
             const uint32_t gi = w0 + ri, cid = cids[gi >> e.rpc_log2];
             ulonglong2 v = make_ulonglong2(0, 0);
@@ -528,6 +534,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
         for (int i = gtid; i < WIN; i += GS) dcount[i] = 1;
         if (VT == 0) for (int i = gtid; i < SB_WORDS; i += GS) sbits[i] = 0;
     };
+#if PG_K2_DMA
     // the same in two halves with the memory latency in between: ask (16 bytes a lane from global memory straight into LDS,
     // lane l of a wave to wave base + 16 l: the staging layout but for the dword order), and later turn the dwords round in
     // place, every lane the pieces it asked for
@@ -556,6 +563,48 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
             uint4 v = ((const uint4*)(rlb + PAD))[pc];                       // lo, hi, lo, hi
             if (cid == 0 || cid == 0xFFFFFFFFu) v = make_uint4(0, 0, 0, 0);
             ((uint4*)(rlb + PAD))[pc] = make_uint4(part ? v.y : v.x, part ? v.x : v.y, v.w, v.z);
+        }
+        for (int i = threadIdx.x; i < DT; i += THREADS) dtab[i] = 0;
+        for (int i = threadIdx.x; i < WIN; i += THREADS) dcount[i] = 1;
+        if (VT == 0) for (int i = threadIdx.x; i < SB_WORDS; i += THREADS) sbits[i] = 0;
+    };
+#endif
+    // The next window (round 4, late).  global_load_lds looked ideal for it -- no registers, the loads fly while the emit runs -- but the compiler
+    // guards every LDS WRITE that follows such a load with s_waitcnt vmcnt(0) (it cannot tell what the load will overwrite), and the emit starts
+    // with LDS writes: every wave waited out the trip to HBM at the emit's first store, and, vmcnt counting in order, the next partition's first
+    // global read then waited for the acknowledgements of the export stores too -- 1 - 2 us of 18 a partition, in two places.  Now the window's
+    // pieces are asked for into REGISTERS when the emit starts (p_ask: two 16-byte pieces a lane, one for the 127-mer flavour) and written to the
+    // other buffer, dwords turned round, behind the first finalise and IN FRONT OF the export stores (p_put): the wait is for these loads alone,
+    // with a listing and a finalise between question and answer, and the next partition starts on a prepared window.
+    constexpr int PPL = (WIN * PIECES + THREADS - 1) / THREADS;
+    struct Ahead { ulonglong2 v[PPL]; };
+    auto p_ask = [&](int cln, uint32_t wn, Ahead& a) {
+        const unsigned int* const cids = chunk_ids2[cln];
+#pragma unroll
+        for (int j = 0; j < PPL; j++) {
+            uint32_t pc = threadIdx.x + j * THREADS;
+            asm volatile("" : "+v"(pc));
+            a.v[j] = make_ulonglong2(0, 0);
+            if (pc < wn * PIECES) {
+                const uint32_t ri = pc / PIECES, part = pc - ri * PIECES;
+                const uint32_t cid = cids[ri >> e.rpc_log2];
+                if (cid != 0 && cid != 0xFFFFFFFFu)
+                    a.v[j] = ((const ulonglong2*)(e.pool + ((uint64_t)(cid - 1) * e.rpc + (ri & (e.rpc - 1))) * (uint64_t)e.rs))[part];
+            }
+        }
+    };
+    auto p_put = [&](int nb, uint32_t wn, const Ahead& a) {
+        uint32_t* const rlb = rl2[nb];
+#pragma unroll
+        for (int j = 0; j < PPL; j++) {
+            uint32_t pc = threadIdx.x + j * THREADS;
+            asm volatile("" : "+v"(pc));
+            if (pc < wn * PIECES) {
+                const uint32_t part = pc % PIECES;
+                const ulonglong2 v = a.v[j];
+                const uint32_t x0 = part ? (uint32_t)(v.x >> 32) : (uint32_t)v.x, x1 = part ? (uint32_t)v.x : (uint32_t)(v.x >> 32);
+                ((uint4*)(rlb + PAD))[pc] = make_uint4(x0, x1, (uint32_t)(v.y >> 32), (uint32_t)v.y);
+            }
         }
         for (int i = threadIdx.x; i < DT; i += THREADS) dtab[i] = 0;
         for (int i = threadIdx.x; i < WIN; i += THREADS) dcount[i] = 1;
@@ -807,9 +856,13 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     //  same register, the compiler would make the computing lanes wait for every memory operation in flight before they may overwrite
     //  it, the previous partition's export stores included, at the top of every partition)
     auto chunk_ask = [&](uint32_t pid, uint32_t ci) -> uint32_t {
-        uint32_t v = 0;
-        if (ci >= e.direct && ci - e.direct < e.maxc) v = e.chunk_tbl[(uint64_t)pid * e.maxc + (ci - e.direct)];
-        return v;
+        uint32_t c2 = ci;
+        asm volatile("" : "+v"(c2));                                        // (or the lane's address in the table -- or its index -- is computed at kernel start, kept, spilled, and the
+                                                                            //  reload waits, s_waitcnt vmcnt(0), for every store in flight at the top of every partition)
+        // always a load, never "0 or a load": a register that is written before it is loaded to makes the write wait for whatever the compiler thinks
+        // may still be coming into it.  (Callers ask with ci < direct + maxc; a lane whose chunk lies at a computed address reads entry 0 and ignores it.)
+        const uint32_t rel = c2 >= e.direct ? min(c2 - e.direct, e.maxc - 1u) : 0u;
+        return e.chunk_tbl[(uint64_t)pid * e.maxc + rel];
     };
     auto chunk_take = [&](uint32_t pid, uint32_t ci, uint32_t asked) -> uint32_t {
         return ci < e.direct ? (uint32_t)((((uint64_t)ci << e.g.log2_parts) + pid) + 1) : asked;
@@ -817,10 +870,16 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     uint32_t pf_nrec = 0, pf_cid = 0;
     // (the record count is the same for every lane, which would make it a scalar load -- and scalar loads are waited for at
     //  the very next barrier together with the LDS traffic (lgkmcnt); through a vector register it stays in flight until used)
-    auto peek_cursor = [&](uint32_t p) { const uint32_t* q = e.cursor + p; asm volatile("" : "+v"(q)); return *q; };
+    //  (the INDEX goes through the register: a pointer that does would lose its address space and become a flat load, which waits for everything)
+    auto peek_cursor = [&](uint32_t p) { uint32_t pp = p; asm volatile("" : "+v"(pp)); return e.cursor[pp]; };
+    // what was asked for the next partition is LOOKED AT in the middle of the current one (nrec_next, cid_next: behind the occurrence phase, where
+    // nothing else of this wave is in flight) and carried in registers: a use at the top of the next partition would wait for the export stores
+    uint32_t nrec_next = 0, cid_next = 0;
     if (blockIdx.x < parts) {
         pf_nrec = peek_cursor(blockIdx.x);
         if (threadIdx.x < nchunks) pf_cid = chunk_ask(blockIdx.x, threadIdx.x);
+        nrec_next = pf_nrec;
+        cid_next = chunk_take(blockIdx.x, threadIdx.x, pf_cid);
     }
     // opt bit 2: a key range that is going to overflow the set is split BEFORE it is counted.  A dropped attempt costs the attempt and two
     // sittings over the same window; what a single-window partition will hold is foreseeable from its occurrences after the dedupe
@@ -830,7 +889,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     int b = 0, cl = 0;                                                    // the current window's buffer, the current partition's chunk list
     bool staged = false;                                                  // its first window is already on its way into rl2[b] (asked for by the previous emit)
     for (uint32_t pid = blockIdx.x; pid < parts; pid += gridDim.x) {
-        const uint32_t nrec = pf_nrec, my_cid = chunk_take(pid, threadIdx.x, pf_cid);
+        const uint32_t nrec = nrec_next, my_cid = cid_next;
         const uint32_t nxt = pid + gridDim.x;
         if (nxt < parts) {
             pf_nrec = peek_cursor(nxt);
@@ -838,7 +897,12 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
         }
         const uint32_t usable = min(nrec, nchunks * e.rpc);              // an overfull partition was flagged by K1
         my_records += usable;
-        if (usable == 0) continue;                                        // (never one that was asked for)
+        if (usable == 0) {                                                // (never one that was asked for)
+            asm volatile("" ::: "memory");                                // (a branch, not two selects in front of it: they would wait for the loads just asked for)
+            nrec_next = pf_nrec;
+            cid_next = chunk_take(nxt, threadIdx.x, pf_cid);
+            continue;
+        }
         if (!staged) {                                                    // (the list's last readers are at least an emit's barriers back)
             if (threadIdx.x < nchunks) chunk_ids2[cl][threadIdx.x] = my_cid;
             K2_SYNC();
@@ -848,7 +912,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
         int top = 0;
         uint32_t mask = 0, val = 0;
         bool window_ready = false;                                        // rl2[b] holds window 0, prepared
-        bool raw = staged;                                                // ... or window 0 as global_load_lds left it
+        bool raw = staged;                                                // ... or window 0 as the previous partition's emit left it (PG_K2_DMA: as global_load_lds left it)
         staged = false;
         for (;;) {
             // (no barrier of its own for the flag: whoever read it last did so before the barriers of the emit or of the range
@@ -872,7 +936,11 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 const uint32_t wn = min((uint32_t)WIN, usable - w0);
                 if (!(window_ready && w0 == 0)) {
                     Prep ps;
+#if PG_K2_DMA
                     if (raw) p_unpack(b, cl, w0, wn); else p_stage(whole, threadIdx.x, b, cl, w0, wn);
+#else
+                    if (!raw) p_stage(whole, threadIdx.x, b, cl, w0, wn);   // (raw: p_put wrote the window and cleared the tables)
+#endif
                     raw = false;
                     K2_SYNC();
                     K2_TICK(2);
@@ -893,7 +961,10 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 window_ready = usable <= WIN;                             // a single window stays good for the other key ranges
                 // the partition's next window flies into the other buffer while this one is counted
                 const bool more = w0 + WIN < usable;
+                (void)more;
+#if PG_K2_DMA
                 if (more && !(dbg & 16)) p_stage_async(b ^ 1, cl, w0 + WIN, min((uint32_t)WIN, usable - w0 - WIN));
+#endif
                 const uint32_t total_occ = s_tot, share = VT == 0 ? 1u : (total_occ + VL - 1) / VL;
                 const uint32_t* const rl = rl2[b];
                 if ((opt & 4) && mask == 0 && usable <= (uint32_t)WIN && acc_occ >= 4096u &&
@@ -969,10 +1040,16 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 }
                 K2_TICK(4);
                 // the next partition's chunk list, for the prepare that runs beside this partition's last emit
-                if (threadIdx.x < nchunks) {
+                {
                     uint32_t asked = pf_cid;
-                    asm volatile("" : "+v"(asked));                          // (looked at here, not where it was asked for: see usable_next below)
-                    chunk_ids2[cl ^ 1][threadIdx.x] = chunk_take(nxt, threadIdx.x, asked);
+                    asm volatile("" : "+v"(asked));                          // (looked at here, by every lane: the register is known to be at rest when the top of the next
+                    if (threadIdx.x < nchunks)                               //  partition writes to it again -- or that write waits for the export stores)
+                        chunk_ids2[cl ^ 1][threadIdx.x] = cid_next = chunk_take(nxt, threadIdx.x, asked);
+                }
+                {
+                    uint32_t pfn = pf_nrec;
+                    asm volatile("" : "+v"(pfn));
+                    nrec_next = pfn;
                 }
                 if (threadIdx.x == 0) s_nlive = 0;                          // (e_list_any adds to it; its last readers are a barrier back)
                 K2_SYNC();                                                  // the window and its tables are rewritten by the next one
@@ -985,7 +1062,9 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                         for (int q = 0; q < 4; q++) set.cnt[q][i] = clip_halves_255(set.cnt[q][i]);
                     }
                 }
+#if PG_K2_DMA
                 if (more && !(dbg & 16)) { b ^= 1; raw = true; }
+#endif
                 K2_TICK(5);
             }
             if (aborted || presplit) {                                    // (read behind the window loop's last barrier: the same for every lane)
@@ -1007,16 +1086,21 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 //  empty instruction the compiler computes usable_next in front of the range loop, i.e. right behind the load -- every
                 //  wave of the workgroup then waits out a trip to HBM, and the acknowledgements of the previous partition's export
                 //  stores with it, at every partition's start: the "partition header" phase of round 3's profile)
-                uint32_t pfn = pf_nrec;
-                asm volatile("" : "+v"(pfn));
-                const uint32_t usable_next = nxt < parts ? min(pfn, nchunks * e.rpc) : 0u;
+                const uint32_t usable_next = nxt < parts ? min(nrec_next, nchunks * e.rpc) : 0u;
                 // The last emit of a partition borrows its own window (dead now) and, first of all, asks for the next partition's
                 // first window: global_load_lds copies 16 bytes a lane straight into the other buffer, no registers, so the
                 // loads fly during the whole emit (p_stage_async / p_unpack).  Earlier emits (more key ranges to come) borrow
                 // the other buffer, and a single-window partition keeps its prepared window for the remaining ranges.
                 const bool ahead = top == 0 && usable_next > 0 && !(dbg & 16);
                 const int sb = top == 0 ? b : b ^ 1;
-                if (ahead) { p_stage_async(b ^ 1, cl ^ 1, 0u, min((uint32_t)WIN, usable_next)); staged = true; }
+                const uint32_t wn_next = min((uint32_t)WIN, usable_next);
+#if PG_K2_DMA
+                if (ahead) { p_stage_async(b ^ 1, cl ^ 1, 0u, wn_next); staged = true; }
+#else
+                Ahead ah;
+                bool put = !ahead;
+                if (ahead) { p_ask(cl ^ 1, wn_next, ah); staged = true; }
+#endif
                 {
                     if (opt & 1) {
                         e_list_any(whole, threadIdx.x, sb);
@@ -1039,9 +1123,15 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                         e_final(whole, threadIdx.x, sb, c0, cn, n_live);
                         K2_TICK(11);
                         K2_SYNC();
+#if !PG_K2_DMA
+                        if (!put) { p_put(b ^ 1, wn_next, ah); put = true; }
+#endif
                         e_copy(whole, threadIdx.x, sb, c0, cn);
                         if (c0 + STAGE_CAP < n_live) K2_SYNC();           // the staging area is filled again (after the last chunk the
                     }                                                     // buffer's next writer is several barriers away)
+#if !PG_K2_DMA
+                    if (!put) p_put(b ^ 1, wn_next, ah);                    // (an emit without a node)
+#endif
                     K2_TICK(8);
                 }
             }
