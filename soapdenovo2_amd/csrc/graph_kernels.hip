@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void p2_thread_kernel(P2Params p, const uint64
                     const uint32_t s = (uint32_t)(setq >> (8 * q)) & 0xff;
                     const uint64_t* nd = (const uint64_t*)(uintptr_t)set_geo[SV_GEO * s + 2] + hc[q] * (NW + 1);
 #pragma unroll
-                    for (int i = 0; i <= NW; i++) d[q][i] = nd[i];
+                    for (int i = 0; i <= NW; i++) d[q][i] = sv_word(nd + i);     // (global loads: graph_lookup.hpp)
                 }
 #pragma unroll
             for (int q = 0; q < BL; q++)

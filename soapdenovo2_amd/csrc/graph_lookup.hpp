@@ -25,6 +25,15 @@ struct SetsView {
 PG_HD uint64_t sv_first(const SetsView& v, uint32_t s) { return v.geo[SV_GEO * s]; }
 PG_HD uint64_t sv_size(const SetsView& v, uint32_t s) { return v.geo[SV_GEO * s + 1]; }
 PG_HD uint64_t* sv_base(const SetsView& v, uint32_t s) { return (uint64_t*)(uintptr_t)v.geo[SV_GEO * s + 2]; }
+// a word of a set image.  An address that was read from memory could be anything, and a load through it is a flat load -- which counts as LDS
+// traffic too and is waited for together with everything else in flight; the images are device memory (this rank's or a peer's): say so
+PG_HD uint64_t sv_word(const uint64_t* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return *(const __attribute__((address_space(1))) uint64_t*)p;
+#else
+    return *p;
+#endif
+}
 // the set a global slot lies in (binary search over <= 255 firsts), and the slot's address
 PG_HD uint32_t sv_set_of_slot(const SetsView& v, uint64_t g) {
     uint32_t lo = 0, hi = v.P;                           // last s with first[s] <= g
@@ -97,11 +106,11 @@ PG_HD uint64_t sv_find(const SetsView& v, const Kmer<NW>& key, uint64_t*& node) 
     uint64_t hc = home_slot<NW>(key, ModConst{size, v.geo[SV_GEO * s + 3], (uint32_t)v.geo[SV_GEO * s + 4]});
     for (uint64_t step = 0; step < size; step++) {
         uint64_t* nd = base + hc * (NW + 1);
-        const uint64_t w0 = nd[0];
+        const uint64_t w0 = sv_word(nd);
         if (w0 == SV_EMPTY) break;
         bool eq = w0 == key.w[0];
 #pragma unroll
-        for (int i = 1; i < NW; i++) eq = eq && nd[i] == key.w[i];
+        for (int i = 1; i < NW; i++) eq = eq && sv_word(nd + i) == key.w[i];
         if (eq) { node = nd; return sv_first(v, s) + hc; }
         if (++hc == size) hc = 0;
     }
