@@ -48,6 +48,18 @@ template <int NW> struct E2Cfg;
 #ifndef PG_K2_DMA
 #define PG_K2_DMA 0                                                        // (1: the next window by global_load_lds, rounds 2 - 4, for an A/B build -- see "the next window" in the kernel)
 #endif
+#ifndef PG_K2_STATIC_TILES
+#define PG_K2_STATIC_TILES 0                                               // (1: PG_K2_OPT bit 3 = a wave's first tiles are its own, the tail comes off the counter.  Measured: the rounds gain
+                                                                           //  0.7 ms at K = 63 when on, and their two wave-uniform values cost 1.5 ms in the tile loop, on or off, in scalar
+                                                                           //  registers spilled to vector lanes: profiles/r04t_k2_same_box_bisect.json)
+#endif
+#ifndef PG_K2_ADAPT2
+#define PG_K2_ADAPT2 0                                                     // (1: the two-word flavour counts records and representatives too and may stop searching for copies.  It never
+                                                                           //  stopped on anything measured (300x, 150x, 15x), and the counting cost it 2 ms of 154 -- scalar registers again)
+#endif
+#ifndef PG_K2_NMAX127
+#define PG_K2_NMAX127 0                                                    // (1: start bits for 127 k-mers a record whatever K: the LDS layout of the round's first kernels, A/B build)
+#endif
 #ifndef PG_K2_RAW2
 #define PG_K2_RAW2 0                                                       // (1: the two-word flavour with its own two words and one claim too -- built and measured: 156.7 ms
 #endif                                                                     //  against 155.6, profiles/r04k_k2_keys_static_tiles_ab.json; it has no fifth word to lose)
@@ -459,7 +471,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     // one scratch area, two lives: the record-dedupe table (DT slots), then the flattening tables
     constexpr int DT = pow2_at_least(2 * WIN);                            // open addressing over the window's records, <= 50 % full
     constexpr int VL = (VT ? VT : 1) * THREADS;                           // virtual lanes
-    constexpr int NMAX = KS ? (32 * PW - (KS - 1) - 2 < 127 ? 32 * PW - (KS - 1) - 2 : 127) : 127;   // k-mers a record (skm_geometry)
+    constexpr int NMAX = (KS && !PG_K2_NMAX127) ? (32 * PW - (KS - 1) - 2 < 127 ? 32 * PW - (KS - 1) - 2 : 127) : 127;   // k-mers a record (skm_geometry)
     constexpr int SB_WORDS = (WIN * NMAX + 31) / 32 + 2;                  // VT = 0: a start bit per occurrence of a window (<= WIN * NMAX)
     constexpr int SB_AT = ((DT > WIN + 1 + WIN ? DT : WIN + 1 + WIN) + 1) & ~1;      //         behind the dedupe table and behind tile_rep0; read 64 bits at a time
     constexpr int FL_WORDS = VT == 0 ? SB_AT + SB_WORDS : (DT > WIN + 1 + VL / 2 ? DT : WIN + 1 + VL / 2) + 2;
@@ -498,7 +510,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     // opt bit 3 (VT = 0): a wave's first tiles are its own (tile = wave + 16 r for the first rounds but the last full one), only the tail
     // comes off the counter -- three of four returned LDS atomics (and the wait for each) less a wave and window
     auto static_rounds = [&](unsigned int tot) -> unsigned int {
-        if (VT != 0 || !(opt & 8) || (opt & 2)) return 1u;                    // (bit 1 asks a tile ahead at every turn: not with it)
+        if (!PG_K2_STATIC_TILES || VT != 0 || !(opt & 8) || (opt & 2)) return 1u;   // (bit 1 asks a tile ahead at every turn: not with it)
         const unsigned int r = ((tot + 63u) >> 6) / NWAVE;
         return r > 1u ? r - 1u : 1u;
     };
@@ -511,7 +523,8 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     // them represented themselves.  opt bit 4: never search; bits 16..23: the percentage.  The default is where the search's share of the kernel equals what it saves: 70 % for the
     // four-word flavour (a 64-byte record to hash and compare; K = 127 from 150-base reads lies between 70 and 85 %: 142.5 ms off, 162.3 on), 82 % for the two-word one (its 15x case
     // -- 100 M reads over 1 Gb, more than 70 % of the records their own -- still gains 5 % from the search: 218.2 ms on, 229.7 off; profiles/r04m_k2_adaptive_dedupe_ab.json)
-    bool dd_on = !(opt & 16);
+    constexpr bool ADAPT = NW == 4 || PG_K2_ADAPT2 != 0;
+    bool dd_on = ADAPT ? !(opt & 16) : true;
     uint32_t dd_rec = 0, dd_rep = 0;
     const uint32_t dd_pct = ((opt >> 16) & 0xFF) ? ((opt >> 16) & 0xFF) : (NW == 4 ? 70u : 82u);
     // stage the window's records: 16 bytes per lane and step; the header word as it is, every payload word high dword first
@@ -619,7 +632,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     auto p_dedupe = [&](int gtid, int nb, uint32_t wn, Prep& ps) {
         uint32_t* const rlb = rl2[nb];
         bool is_rep = (uint32_t)gtid < wn;
-        if (is_rep && !(dbg & 4) && dd_on) {
+        if (is_rep && !(dbg & 4) && (!ADAPT || dd_on)) {
             const uint32_t* me = rlb + PAD + gtid * RD;
             uint32_t w[RD - 1];
             w[0] = me[0] & ((1u << SKM_ORD_SHIFT) - 1);                    // n, has_left, has_right
@@ -951,7 +964,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     K2_TICK(10);
                     K2_SYNC();                                            // dtab is dead from here, counts and minima are final
                     p_flat2(whole, threadIdx.x, wave, b, ps);
-                    if (dd_on && dd_rec < 4096u) {                         // (the same numbers in every lane)
+                    if (ADAPT && dd_on && dd_rec < 4096u) {                // (the same numbers in every lane)
                         dd_rec += wn; dd_rep += ps.n_rep;
                         if (dd_rec >= 4096u && dd_rep * 100u > dd_rec * dd_pct) dd_on = false;
                     }
@@ -1032,7 +1045,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                         }
                     }
                     if (VT == 1) break;
-                    if (++round < sr) { tile += NWAVE; continue; }
+                    if (PG_K2_STATIC_TILES && ++round < sr) { tile += NWAVE; continue; }
                     unsigned int nt = nt_early;
                     if (!(opt & 2) && lane == 0) nt = atomicAdd(&tile_ctr, 1u);
                     tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)nt);
@@ -1598,8 +1611,8 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     // bit 0: live slots listed in any order (162.9 -> 157.0 ms; with vt = 0: 148.9 ms); bit 2: key ranges foreseen to overflow are split before they
     // are counted -- the 127-mer flavour drops one attempt in ten (198.2 -> 194.2 ms), the 63-mer one in a hundred and loses more to false alarms
     // (152.6 -> 162.8 ms): on for the former only; bits 8..15: the foreseen load in percent from which on it splits (0 = 75: 45 % 198.8 ms, 55 % 194.3, 65 % 191.1, never 199.3 on one box; 65 % 190.8, 75 % 188.8, 90 % 189.9 on another)
-    // bit 3: a wave's first tiles are its own, the tail comes off the counter (K = 63: 155.6 -> 154.7 ms; K = 127: no difference)
-    int k2opt = c->NW == 4 ? 5 : 9;
+    // bit 3 (builds with -DPG_K2_STATIC_TILES=1 only): a wave's first tiles are its own, the tail comes off the counter
+    int k2opt = c->NW == 4 ? 5 : 1;
     if (const char* v = getenv("PG_K2_OPT")) k2opt = atoi(v);
     if (const char* v = getenv("PG_K2_PRESPLIT_PCT")) k2opt = (k2opt & ~0xFF00) | ((atoi(v) & 0xFF) << 8);
     if (const char* v = getenv("PG_K2_DEDUPE_PCT")) k2opt = (k2opt & ~0xFF0000) | ((atoi(v) & 0xFF) << 16);     // (100: always search for copies; default 70, see the kernel)
