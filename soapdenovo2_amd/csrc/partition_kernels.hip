@@ -496,7 +496,10 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     if (threadIdx.x == 0) tile_ctr = NWAVE;
     if (threadIdx.x < 2 * PAD) rl2[threadIdx.x / PAD][threadIdx.x % PAD] = 0;
     if (threadIdx.x < 16) rl2[threadIdx.x >> 3][PAD + WIN * RD + (threadIdx.x & 7)] = 0;
-    const int K = e.g.K;
+    // (a kernel for one K is launched on the usual record geometry only -- 128 records a chunk, records without padding: e2_count -- and has it as constants)
+    const int K = KS ? KS : e.g.K;
+    const uint32_t RPC = KS ? 128u : e.rpc, RPC_LOG2 = KS ? 7u : e.rpc_log2;
+    const uint64_t RS = KS ? (uint64_t)RW : (uint64_t)e.rs;
     const uint32_t parts = 1u << e.g.log2_parts;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long my_records = 0;
@@ -536,10 +539,10 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
         asm volatile("" : "+v"(pc_first));                                 // (what follows from the lane's number alone is computed here, not at kernel start and then spilled:
         for (uint32_t pc = pc_first; pc < wn * PIECES; pc += GS) {         //  a reload from scratch waits for every store in flight)
             const uint32_t ri = pc / PIECES, part = pc - ri * PIECES;
-            const uint32_t gi = w0 + ri, cid = cids[gi >> e.rpc_log2];
+            const uint32_t gi = w0 + ri, cid = cids[gi >> RPC_LOG2];
             ulonglong2 v = make_ulonglong2(0, 0);
             if (cid != 0 && cid != 0xFFFFFFFFu)
-                v = ((const ulonglong2*)(e.pool + ((uint64_t)(cid - 1) * e.rpc + (gi & (e.rpc - 1))) * (uint64_t)e.rs))[part];
+                v = ((const ulonglong2*)(e.pool + ((uint64_t)(cid - 1) * RPC + (gi & (RPC - 1))) * RS))[part];
             const uint32_t x0 = part ? (uint32_t)(v.x >> 32) : (uint32_t)v.x, x1 = part ? (uint32_t)v.x : (uint32_t)(v.x >> 32);
             ((uint4*)(rlb + PAD))[pc] = make_uint4(x0, x1, (uint32_t)(v.y >> 32), (uint32_t)v.y);
         }
@@ -558,9 +561,9 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
             const uint32_t pc = p0 + threadIdx.x;
             if (pc < wn * PIECES) {
                 const uint32_t ri = pc / PIECES, part = pc - ri * PIECES;
-                const uint32_t gi = w0 + ri, cid = cids[gi >> e.rpc_log2];
+                const uint32_t gi = w0 + ri, cid = cids[gi >> RPC_LOG2];
                 if (cid != 0 && cid != 0xFFFFFFFFu) {
-                    const ulonglong2* src = (const ulonglong2*)(e.pool + ((uint64_t)(cid - 1) * e.rpc + (gi & (e.rpc - 1))) * (uint64_t)e.rs) + part;
+                    const ulonglong2* src = (const ulonglong2*)(e.pool + ((uint64_t)(cid - 1) * RPC + (gi & (RPC - 1))) * RS) + part;
                     __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)(rlb + PAD + (p0 + wave * 64) * 4), 16, 0, 0);
                 }
             }
@@ -572,7 +575,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         for (uint32_t pc = threadIdx.x; pc < wn * PIECES; pc += THREADS) {
             const uint32_t ri = pc / PIECES, part = pc - ri * PIECES;
-            const uint32_t cid = cids[(w0 + ri) >> e.rpc_log2];
+            const uint32_t cid = cids[(w0 + ri) >> RPC_LOG2];
             uint4 v = ((const uint4*)(rlb + PAD))[pc];                       // lo, hi, lo, hi
             if (cid == 0 || cid == 0xFFFFFFFFu) v = make_uint4(0, 0, 0, 0);
             ((uint4*)(rlb + PAD))[pc] = make_uint4(part ? v.y : v.x, part ? v.x : v.y, v.w, v.z);
@@ -600,9 +603,9 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
             a.v[j] = make_ulonglong2(0, 0);
             if (pc < wn * PIECES) {
                 const uint32_t ri = pc / PIECES, part = pc - ri * PIECES;
-                const uint32_t cid = cids[ri >> e.rpc_log2];
+                const uint32_t cid = cids[ri >> RPC_LOG2];
                 if (cid != 0 && cid != 0xFFFFFFFFu)
-                    a.v[j] = ((const ulonglong2*)(e.pool + ((uint64_t)(cid - 1) * e.rpc + (ri & (e.rpc - 1))) * (uint64_t)e.rs))[part];
+                    a.v[j] = ((const ulonglong2*)(e.pool + ((uint64_t)(cid - 1) * RPC + (ri & (RPC - 1))) * RS))[part];
             }
         }
     };
@@ -908,7 +911,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
             pf_nrec = peek_cursor(nxt);
             if (threadIdx.x < nchunks) pf_cid = chunk_ask(nxt, threadIdx.x);
         }
-        const uint32_t usable = min(nrec, nchunks * e.rpc);              // an overfull partition was flagged by K1
+        const uint32_t usable = min(nrec, nchunks * RPC);              // an overfull partition was flagged by K1
         my_records += usable;
         if (usable == 0) {                                                // (never one that was asked for)
             asm volatile("" ::: "memory");                                // (a branch, not two selects in front of it: they would wait for the loads just asked for)
@@ -1099,7 +1102,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 //  empty instruction the compiler computes usable_next in front of the range loop, i.e. right behind the load -- every
                 //  wave of the workgroup then waits out a trip to HBM, and the acknowledgements of the previous partition's export
                 //  stores with it, at every partition's start: the "partition header" phase of round 3's profile)
-                const uint32_t usable_next = nxt < parts ? min(nrec_next, nchunks * e.rpc) : 0u;
+                const uint32_t usable_next = nxt < parts ? min(nrec_next, nchunks * RPC) : 0u;
                 // The last emit of a partition borrows its own window (dead now) and, first of all, asks for the next partition's
                 // first window: global_load_lds copies 16 bytes a lane straight into the other buffer, no registers, so the
                 // loads fly during the whole emit (p_stage_async / p_unpack).  Earlier emits (more key ranges to come) borrow
@@ -1619,6 +1622,7 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     bool ks = true;                                                       // the instantiations for K = 31 / 63 / 127 (PG_K2_KS=0: the general kernel)
     if (const char* v = getenv("PG_K2_KS")) ks = atoi(v) != 0;
     if (dbg) ks = false;
+    if (s.rpc != 128 || s.rs != (uint32_t)s.g.rw) ks = false;            // (PG_RPC / PG_REC_STRIDE experiments: the general kernels)
     // cfg 0: 2048-slot set, 1024 lanes, 512-record windows  -> ~150 KB LDS, one workgroup per CU
     // cfg 1: 1024-slot set,  512 lanes, 256-record windows  ->  ~77 KB LDS, two workgroups per CU
     {
