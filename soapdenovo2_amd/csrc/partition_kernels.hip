@@ -57,9 +57,6 @@ template <int NW> struct E2Cfg;
 #define PG_K2_ADAPT2 0                                                     // (1: the two-word flavour counts records and representatives too and may stop searching for copies.  It never
                                                                            //  stopped on anything measured (300x, 150x, 15x), and the counting cost it 2 ms of 154 -- scalar registers again)
 #endif
-#ifndef PG_K2_NMAX127
-#define PG_K2_NMAX127 0                                                    // (1: start bits for 127 k-mers a record whatever K: the LDS layout of the round's first kernels, A/B build)
-#endif
 #ifndef PG_K2_RAW2
 #define PG_K2_RAW2 0                                                       // (1: the two-word flavour with its own two words and one claim too -- built and measured: 156.7 ms
 #endif                                                                     //  against 155.6, profiles/r04k_k2_keys_static_tiles_ab.json; it has no fifth word to lose)
@@ -471,7 +468,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     // one scratch area, two lives: the record-dedupe table (DT slots), then the flattening tables
     constexpr int DT = pow2_at_least(2 * WIN);                            // open addressing over the window's records, <= 50 % full
     constexpr int VL = (VT ? VT : 1) * THREADS;                           // virtual lanes
-    constexpr int NMAX = (KS && !PG_K2_NMAX127) ? (32 * PW - (KS - 1) - 2 < 127 ? 32 * PW - (KS - 1) - 2 : 127) : 127;   // k-mers a record (skm_geometry)
+    constexpr int NMAX = KS ? (32 * PW - (KS - 1) - 2 < 127 ? 32 * PW - (KS - 1) - 2 : 127) : 127;   // k-mers a record (skm_geometry)
     constexpr int SB_WORDS = (WIN * NMAX + 31) / 32 + 2;                  // VT = 0: a start bit per occurrence of a window (<= WIN * NMAX)
     constexpr int SB_AT = ((DT > WIN + 1 + WIN ? DT : WIN + 1 + WIN) + 1) & ~1;      //         behind the dedupe table and behind tile_rep0; read 64 bits at a time
     constexpr int FL_WORDS = VT == 0 ? SB_AT + SB_WORDS : (DT > WIN + 1 + VL / 2 ? DT : WIN + 1 + VL / 2) + 2;
