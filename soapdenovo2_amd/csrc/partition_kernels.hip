@@ -449,7 +449,10 @@ constexpr int pow2_at_least(int x) { int p = 1; while (p < x) p <<= 1; return p;
 // KS: the kernel for ONE k-mer length (0 = any): the K-only shift amounts of occ_extract become immediates and its two wave-uniform
 // switches -- a dozen scalar branches an occurrence -- go away.
 template <int NW, int SLOTS, int THREADS, int WIN, bool TIMERS, int VT = 1, int KS = 0>
-__global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetParams sp, OccConst oc, DevCounters* ctr, int dbg_arg, int opt) {
+__global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetParams sp, OccConst oc, DevCounters* ctr, int dbg_arg, int opt_arg) {
+    // (a kernel for one K has the default switches as constants -- e2_count launches the general kernel for anything else: the live-slot listing with exact ranks, the early tile
+    //  request, the split-ahead of the two-word flavour and their bookkeeping are not in it, and with them go a third of the scalar registers the kernel spilled to vector lanes)
+    const int opt = KS ? (NW == 4 ? 5 : 1) : opt_arg;
     const int dbg = KS == 0 ? dbg_arg : 0;                               // the measurement switches (PG_DBG) live in the general kernel only
     // opt (PG_K2_OPT, wave-uniform): bit 0 = the emit lists the live slots through one returned LDS atomic a wave and stripe (the
     // export order is unspecified anyway) instead of exact ranks from a table of per-wave counts behind a second barrier
@@ -1620,6 +1623,7 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     if (const char* v = getenv("PG_K2_KS")) ks = atoi(v) != 0;
     if (dbg) ks = false;
     if (s.rpc != 128 || s.rs != (uint32_t)s.g.rw) ks = false;            // (PG_RPC / PG_REC_STRIDE experiments: the general kernels)
+    if (k2opt != (c->NW == 4 ? 5 : 1)) ks = false;                        // (the one-K kernels have the default switches compiled in)
     // cfg 0: 2048-slot set, 1024 lanes, 512-record windows  -> ~150 KB LDS, one workgroup per CU
     // cfg 1: 1024-slot set,  512 lanes, 256-record windows  ->  ~77 KB LDS, two workgroups per CU
     {
