@@ -1624,6 +1624,7 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     if (dbg) ks = false;
     if (s.rpc != 128 || s.rs != (uint32_t)s.g.rw) ks = false;            // (PG_RPC / PG_REC_STRIDE experiments: the general kernels)
     if (k2opt != (c->NW == 4 ? 5 : 1)) ks = false;                        // (the one-K kernels have the default switches compiled in)
+    if (cfg == 3 && !(ks && c->K == 63)) cfg = 0;                         // (the half-lanes shape exists as a one-K kernel only)
     // cfg 0: 2048-slot set, 1024 lanes, 512-record windows  -> ~150 KB LDS, one workgroup per CU
     // cfg 1: 1024-slot set,  512 lanes, 256-record windows  ->  ~77 KB LDS, two workgroups per CU
     {
