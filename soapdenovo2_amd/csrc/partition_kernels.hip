@@ -329,8 +329,8 @@ __device__ __forceinline__ const uint64_t* record_ptr(const E2Dev& e, uint32_t p
 }
 
 // ---- K2 ------------------------------------------------------------------------------------------------------------
-// One workgroup per partition (persistent grid).  The partition's records are taken WIN at a time.  A window arrives in LDS
-// by global_load_lds one window ahead (while the previous window is counted, or the previous partition emitted), exact
+// One workgroup per partition (persistent grid).  The partition's records are taken WIN at a time.  A partition's first window
+// is fetched while the previous partition is emitted (through registers: p_ask / p_put below), its further ones where they are needed; exact
 // copies of a record are merged (dedupe), the representatives' k-mer counts go through a prefix sum so that every lane
 // gets an equal contiguous share of occurrences, and the occurrences are expanded and inserted into the LDS set.  If the
 // set overflows, the attempt is dropped and the key range is split on a hash bit.  Then the set is finalised (-d filter,
@@ -788,8 +788,8 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
         //  atomic in round 3's code: workgroup thread 0 stood there for a round trip to the memory side while fifteen waves went on to
         //  the barrier and waited for it).  The wait is the s_waitcnt below, in front of the only use.)
         // The asker is the group's LAST lane: its wave has no slot to finalise unless the set is nearly full, so nothing of its own
-        // (the compiler guards every read of a window buffer with a wait for the global_load_lds traffic, which would wait for the
-        // atomic too) stands between the question and the answer; the other waves finalise meanwhile.
+        // (a wait the compiler puts in front of one of its memory operations would wait for the atomic too) stands between the question
+        // and the answer; the other waves finalise meanwhile.
         unsigned long long ticket = 0;
         if (gtid == GS - 1 && c0 == 0) {
             unsigned long long* const addr = &ctr->n_export;
@@ -1098,15 +1098,14 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     top += 2;
                 }
             } else {
-                // (the next partition's record count was asked for at the top of this partition and is looked at HERE: without the
-                //  empty instruction the compiler computes usable_next in front of the range loop, i.e. right behind the load -- every
-                //  wave of the workgroup then waits out a trip to HBM, and the acknowledgements of the previous partition's export
-                //  stores with it, at every partition's start: the "partition header" phase of round 3's profile)
+                // (the next partition's record count was asked for at the top of this partition and looked at behind the occurrence phase
+                //  -- nrec_next: a use right behind the load, or at the next partition's top, makes every wave wait out a trip to HBM and the
+                //  acknowledgements of the export stores with it: the "partition header" phase of round 3's profile)
                 const uint32_t usable_next = nxt < parts ? min(nrec_next, nchunks * RPC) : 0u;
                 // The last emit of a partition borrows its own window (dead now) and, first of all, asks for the next partition's
-                // first window: global_load_lds copies 16 bytes a lane straight into the other buffer, no registers, so the
-                // loads fly during the whole emit (p_stage_async / p_unpack).  Earlier emits (more key ranges to come) borrow
-                // the other buffer, and a single-window partition keeps its prepared window for the remaining ranges.
+                // first window (p_ask: into registers; p_put writes it to the other buffer in front of the export stores).  Earlier
+                // emits (more key ranges to come) borrow the other buffer, and a single-window partition keeps its prepared window
+                // for the remaining ranges.
                 const bool ahead = top == 0 && usable_next > 0 && !(dbg & 16);
                 const int sb = top == 0 ? b : b ^ 1;
                 const uint32_t wn_next = min((uint32_t)WIN, usable_next);
