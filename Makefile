@@ -6,18 +6,33 @@ OUT     := soapdenovo2_amd
 CXX     ?= g++
 CXXFLAGS := -O3 -std=c++17 -fPIC -Wall -Wno-unknown-pragmas -Wno-unused-function -Wno-unused-result -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include
 HIPFLAGS := --offload-arch=$(ARCH) -O3 -std=c++17 -fPIC -Wall -Wno-unused-function -Wno-unused-value
-HOSTOBJ := $(CSRC)/host_graph.o $(CSRC)/host_reads.o $(CSRC)/call_pregraph.o $(CSRC)/host_skm.o $(CSRC)/host_emu.o
-DEVOBJ  := $(CSRC)/pregraph_kernels.o $(CSRC)/partition_kernels.o $(CSRC)/graph_kernels.o $(CSRC)/sort_records.o $(CSRC)/exchange.o
+# `make MEASURE=1` builds libsoapdenovo2_amd_measure.so beside the product: the same sources with -DPG_MEASURE, i.e. with the kernels' geometry
+# knobs read from the environment (csrc/env.hpp: env_measure) and K2's phase-timer instantiation.  The product library has neither.
+ifeq ($(MEASURE),1)
+O       := m.o
+LIBNAME := libsoapdenovo2_amd_measure.so
+CXXFLAGS += -DPG_MEASURE
+HIPFLAGS += -DPG_MEASURE
+else
+O       := o
+LIBNAME := libsoapdenovo2_amd.so
+endif
+HOSTOBJ := $(CSRC)/host_graph.$(O) $(CSRC)/host_reads.$(O) $(CSRC)/call_pregraph.$(O) $(CSRC)/host_skm.$(O) $(CSRC)/host_emu.$(O)
+DEVOBJ  := $(CSRC)/pregraph_kernels.$(O) $(CSRC)/partition_kernels.$(O) $(CSRC)/graph_kernels.$(O) $(CSRC)/sort_records.$(O) $(CSRC)/exchange.$(O)
 HDRS    := $(wildcard $(CSRC)/*.hpp) include/soapdenovo2_amd.h
 
+ifeq ($(MEASURE),1)
+all: $(OUT)/$(LIBNAME)
+else
 all: $(OUT)/libsoapdenovo2_amd.so $(OUT)/bin/SOAPdenovo-63mer $(OUT)/bin/SOAPdenovo-127mer $(OUT)/bin/synth_fastq
+endif
 
-$(CSRC)/%.o: $(CSRC)/%.cpp $(HDRS)
+$(CSRC)/%.$(O): $(CSRC)/%.cpp $(HDRS)
 	$(CXX) $(CXXFLAGS) -c $< -o $@
-$(CSRC)/%.o: $(CSRC)/%.hip $(HDRS)
+$(CSRC)/%.$(O): $(CSRC)/%.hip $(HDRS)
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
 
-$(OUT)/libsoapdenovo2_amd.so: $(HOSTOBJ) $(DEVOBJ)
+$(OUT)/$(LIBNAME): $(HOSTOBJ) $(DEVOBJ)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -o $@ $^ -lz -lpthread -ldl
 
 $(OUT)/bin/SOAPdenovo-63mer: $(CSRC)/main.cpp $(OUT)/libsoapdenovo2_amd.so
@@ -33,5 +48,5 @@ $(OUT)/bin/synth_fastq: scripts/synth_fastq.cpp
 	$(CXX) -O3 -std=c++17 -pthread $< -o $@
 
 clean:
-	rm -f $(CSRC)/*.o $(OUT)/libsoapdenovo2_amd.so $(OUT)/bin/SOAPdenovo-*
+	rm -f $(CSRC)/*.o $(OUT)/libsoapdenovo2_amd.so $(OUT)/libsoapdenovo2_amd_measure.so $(OUT)/bin/SOAPdenovo-*
 .PHONY: all clean

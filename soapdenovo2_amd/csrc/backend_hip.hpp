@@ -37,21 +37,23 @@ __global__ __launch_bounds__(256) void be_append_kernel(uint64_t n, F f, unsigne
     __shared__ unsigned long long s_base;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
+    // `held` = the entries in buf, the same number in every lane (the barrier that ends a trip counts the trip's hits).  The workgroup decides to
+    // flush on it and never on s_n: a wave a trip ahead adds to s_n while a slower one still reads it, and lanes that disagree about entering
+    // flush() pair its barriers up wrongly
+    unsigned int held = 0;
     auto flush = [&]() {                                                   // (called by the whole workgroup, behind a barrier)
-        const unsigned int m = s_n;
-        if (threadIdx.x == 0 && m) s_base = atomicAdd(cnt, (unsigned long long)m);
+        if (threadIdx.x == 0 && held) { s_base = atomicAdd(cnt, (unsigned long long)held); s_n = 0; }
         __syncthreads();
-        for (unsigned int j = threadIdx.x; j < m; j += 256) { const unsigned long long at = s_base + j; if (at < cap) list[at] = buf[j]; }
+        for (unsigned int j = threadIdx.x; j < held; j += 256) { const unsigned long long at = s_base + j; if (at < cap) list[at] = buf[j]; }
         __syncthreads();
-        if (threadIdx.x == 0) s_n = 0;
-        __syncthreads();
+        held = 0;
     };
     for (uint64_t i0 = (uint64_t)blockIdx.x * 256; i0 < n; i0 += (uint64_t)gridDim.x * 256) {        // (the same trips for every lane of the workgroup)
         const uint64_t i = i0 + threadIdx.x;
         const unsigned long long v = i < n ? f(i) : ~0ULL;
         if (v != ~0ULL) buf[atomicAdd(&s_n, 1u)] = v;
-        __syncthreads();
-        if (s_n > FLUSH) flush();
+        held += (unsigned int)__syncthreads_count(v != ~0ULL ? 1 : 0);
+        if (held > FLUSH) flush();
     }
     flush();
 }

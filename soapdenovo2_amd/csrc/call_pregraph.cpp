@@ -25,6 +25,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include "host_graph.hpp"
+#include "env.hpp"
 #include "host_reads.hpp"
 #include "../../include/soapdenovo2_amd.h"
 
@@ -241,7 +242,7 @@ public:
         bool uniform = true;
     };
     BatchFiller(int K, size_t max_words, size_t max_reads, int n_bufs) : K_(K), max_words_(max_words), max_reads_(max_reads), buf_(n_bufs) {
-        const bool trace = getenv("PG_STARTUP_TRACE") && atoi(getenv("PG_STARTUP_TRACE"));
+        const bool trace = pg::env_user("PG_STARTUP_TRACE") && atoi(pg::env_user("PG_STARTUP_TRACE"));
         const auto t0 = std::chrono::steady_clock::now();
         for (Buf& b : buf_) {
             HIP_OK(hipHostMalloc((void**)&b.h_words, (max_words_ + 8) * sizeof(uint64_t), hipHostMallocDefault));
@@ -411,7 +412,7 @@ protected:
 class Pass1 : public BatchFiller {
 public:
     Pass1(pg_ctx* ctx, int K, size_t max_words, size_t max_reads) : BatchFiller(K, max_words, max_reads, 2), ctx_(ctx) {
-        const bool trace = getenv("PG_STARTUP_TRACE") && atoi(getenv("PG_STARTUP_TRACE"));
+        const bool trace = pg::env_user("PG_STARTUP_TRACE") && atoi(pg::env_user("PG_STARTUP_TRACE"));
         auto t0 = std::chrono::steady_clock::now();
         auto step = [&](const char* what) {
             if (!trace) return;
@@ -593,7 +594,7 @@ private:
 
 int run(int argc, char** argv, bool mer127) {
     const time_t t_start = time(nullptr);
-    const bool verbose = getenv("PG_HOST_VERBOSE") != nullptr;
+    const bool verbose = pg::env_user("PG_HOST_VERBOSE") != nullptr;
     auto nowf = []() { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
     double tv = nowf();
     auto lap = [&](const char* what) { if (verbose) { const double t = nowf(); fprintf(stderr, "[cli] %s: %.2fs\n", what, t - tv); tv = t; } };
@@ -619,9 +620,9 @@ int run(int argc, char** argv, bool mer127) {
     // SOAPDENOVO2_AMD_DEVICES=0,1,2,...: pass 1 sharded over these GPUs (one rank each; an ordinal may repeat, which puts
     // several ranks on one GPU -- how the N-rank path is tested on a 1-GPU box); everything after pass 1 runs on the first.
     int device = 0;
-    if (const char* e = getenv("SOAPDENOVO2_AMD_DEVICE")) device = atoi(e);
+    if (const char* e = pg::env_user("SOAPDENOVO2_AMD_DEVICE")) device = atoi(e);
     std::vector<int> devices;
-    if (const char* e = getenv("SOAPDENOVO2_AMD_DEVICES")) {
+    if (const char* e = pg::env_user("SOAPDENOVO2_AMD_DEVICES")) {
         for (const char* q = e; *q;) {
             char* end = nullptr;
             const long v = strtol(q, &end, 10);
@@ -664,20 +665,20 @@ int run(int argc, char** argv, bool mer127) {
     }
     // a pass-1 batch: 64 MiB of packed reads / 2 M reads (SOAPDENOVO2_AMD_BATCH_READS: smaller batches, for tests)
     size_t batch_words = (size_t)1 << 23, batch_reads = (size_t)1 << 21;
-    if (const char* e = getenv("SOAPDENOVO2_AMD_BATCH_READS")) { const long v = atol(e); if (v > 0) { batch_reads = (size_t)v; batch_words = std::min(batch_words, batch_reads * 160 + 64); } }
+    if (const char* e = pg::env_user("SOAPDENOVO2_AMD_BATCH_READS")) { const long v = atol(e); if (v > 0) { batch_reads = (size_t)v; batch_words = std::min(batch_words, batch_reads * 160 + 64); } }
     size_t keep_budget = (size_t)sysconf(_SC_PHYS_PAGES) * (size_t)sysconf(_SC_PAGE_SIZE) / 4;
-    if (const char* e = getenv("SOAPDENOVO2_AMD_KEEP_READS_GB")) keep_budget = (size_t)(atof(e) * 1073741824.0);
+    if (const char* e = pg::env_user("SOAPDENOVO2_AMD_KEEP_READS_GB")) keep_budget = (size_t)(atof(e) * 1073741824.0);
     KeptReads kept;
     bool have_kept = false;
     // ... on the device instead, while the reads are of one length and pass 2 runs there without -R (SOAPDENOVO2_AMD_KEEP_ON_HOST=1: never)
     DevKept devkept;
     size_t dev_keep_budget = 0;
     {
-        const char* e2 = getenv("SOAPDENOVO2_AMD_PASS2");
-        const char* e1 = getenv("SOAPDENOVO2_AMD_EDGES");
+        const char* e2 = pg::env_user("SOAPDENOVO2_AMD_PASS2");
+        const char* e1 = pg::env_user("SOAPDENOVO2_AMD_EDGES");
         const bool host_side = (e2 && !strcmp(e2, "host")) || (e1 && !strcmp(e1, "host"));
         size_t free_b = 0, total_b = 0;
-        if (!o.reps && !host_side && !getenv("SOAPDENOVO2_AMD_KEEP_ON_HOST") && keep_budget > 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+        if (!o.reps && !host_side && !pg::env_test("SOAPDENOVO2_AMD_KEEP_ON_HOST") && keep_budget > 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess)
             dev_keep_budget = total_b / 8;
     }
     long long n_records = 0;
@@ -808,7 +809,7 @@ int run(int argc, char** argv, bool mer127) {
     // Pass 1 on the partition engine; should one partition outgrow its chunk list (one minimizer owning a huge share of
     // the input) the reads go through the global-set engine instead -- slower, indifferent to skew, same result.
     int engine = 2;
-    if (const char* e = getenv("PG_ENGINE")) engine = atoi(e);
+    if (const char* e = pg::env_user("PG_ENGINE")) engine = atoi(e);
     for (int attempt = 0;; attempt++) {
         mark("input files sized");
         // the context (HIP start-up, the record pool: tens of gigabytes the driver hands out cleared) on a thread of its own while this one
@@ -819,7 +820,7 @@ int run(int argc, char** argv, bool mer127) {
             ctx = pg_create_sized(device, K, mer127 ? 1 : 0, o.sets, log2_slots, engine, est_kmers);
             if (!ctx) ctx_err = pg_last_error();
         });
-        if (getenv("PG_CTX_THREAD") && atoi(getenv("PG_CTX_THREAD")) == 0) ctx_thread.join();      // (A/B: one after the other)
+        if (pg::env_measure("PG_CTX_THREAD") && atoi(pg::env_measure("PG_CTX_THREAD")) == 0) ctx_thread.join();      // (A/B: one after the other)
         bool ok = true;
         {
             Pass1 p1(nullptr, K, batch_words, batch_reads);
@@ -921,7 +922,7 @@ int run(int argc, char** argv, bool mer127) {
     // Records in replay order stay on the device and are pulled set by set, chunk by chunk, while the layout is rebuilt
     // (pg_graph_begin_streamed); with SOAPDENOVO2_AMD_STREAM_RECORDS=0 they are downloaded whole.
     bool stream_records = n_distinct > 0;
-    if (const char* e = getenv("SOAPDENOVO2_AMD_STREAM_RECORDS")) stream_records = stream_records && atoi(e) != 0;
+    if (const char* e = pg::env_test("SOAPDENOVO2_AMD_STREAM_RECORDS")) stream_records = stream_records && atoi(e) != 0;
     std::vector<uint64_t> per_set(o.sets, 0);
     void* d_ws = nullptr;
     uint64_t ws_bytes = 0;
@@ -969,11 +970,11 @@ int run(int argc, char** argv, bool mer127) {
     t0 = time(nullptr);
     // edges and pass 2 on the device; SOAPDENOVO2_AMD_EDGES=host / SOAPDENOVO2_AMD_PASS2=host keep them on the host threads
     bool host_edges = false, host_pass2 = false;
-    if (const char* e = getenv("SOAPDENOVO2_AMD_EDGES")) host_edges = strcmp(e, "host") == 0;
-    if (const char* e = getenv("SOAPDENOVO2_AMD_PASS2")) host_pass2 = strcmp(e, "host") == 0;
+    if (const char* e = pg::env_user("SOAPDENOVO2_AMD_EDGES")) host_edges = strcmp(e, "host") == 0;
+    if (const char* e = pg::env_user("SOAPDENOVO2_AMD_PASS2")) host_pass2 = strcmp(e, "host") == 0;
     if (host_pass2) host_edges = true;                               // host pass 2 needs the host copy of the sets tagged
     // records still on the device: with -a the layout is made there (K6), otherwise the replay's workers pull their stretches
-    (void)pg_host_edge_file_in_background(getenv("SOAPDENOVO2_AMD_EDGE_FILE_INLINE") ? 0 : 1);    // <o>.edge.gz is formatted and deflated beside pass 2
+    (void)pg_host_edge_file_in_background(pg::env_test("SOAPDENOVO2_AMD_EDGE_FILE_INLINE") ? 0 : 1);    // <o>.edge.gz is formatted and deflated beside pass 2
     for (int r = 0; r < (int)sh_ws.size(); r++)                      // one block a device (ranks that share a GPU in test set-ups: the first one's)
         if (sh_ws[r] && sh_ws_front[r] && pg_device_scratch_offer(devices[r], sh_ws[r], sh_ws_front[r]) == PG_OK) sh_offered[r] = 1;
     pg_graph* graph = n_ranks > 1

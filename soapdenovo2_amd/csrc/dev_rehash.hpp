@@ -36,6 +36,7 @@
 #include <vector>
 
 #include "backend.hpp"
+#include "env.hpp"
 #include "graph_lookup.hpp"
 #include "ref_sizes.hpp"
 #include "../../include/soapdenovo2_amd.h"
@@ -248,7 +249,7 @@ int layout_growable(BE& be, RhWork<BE>& wk, const uint64_t* rec, uint64_t n, con
     unsigned int* dirty = wk.dirty;
     unsigned long long* slot_new = slots_out;
     int rc = PG_OK;
-    const bool rh_debug = getenv("PG_RH_DEBUG") != nullptr;
+    const bool rh_debug = pg::env_measure("PG_RH_DEBUG") != nullptr;
     auto rh_now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
     for (size_t ei = 0; ei < sched.size() && !be.error && rc == PG_OK; ei++) {
         const GrowEpoch ep = sched[ei];
@@ -346,7 +347,7 @@ int layout_growable(BE& be, RhWork<BE>& wk, const uint64_t* rec, uint64_t n, con
         // Small sizes are nothing but rounds, and a round's work there is microseconds against the ~0.6 ms its read-back costs (a drained
         // stream and a copy): eight rounds at a time are launched blind -- full sweeps that skip the clusters whose flag is down, no lists --
         // and the host looks at the last one's change count; the rounds behind the fixed point find nothing to do.
-        const char* const blind_env = getenv("PG_RH_BLIND_MAX");              // (0: every round read back, for A/B runs and tests)
+        const char* const blind_env = pg::env_test("PG_RH_BLIND_MAX");              // (0: every round read back, for A/B runs and tests)
         const uint64_t blind_max = blind_env ? (uint64_t)atoll(blind_env) : (uint64_t)1 << 18;
         const bool blind = n_old && M <= blind_max;
         for (int round = 0; blind;) {

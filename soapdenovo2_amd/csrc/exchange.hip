@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "device_ctx.hpp"
+#include "env.hpp"
 #include "../../include/soapdenovo2_amd.h"
 
 namespace {
@@ -57,7 +58,7 @@ struct Rccl {
     std::string why;
     bool load() {
         if (lib) return true;
-        const char* names[] = {getenv("SOAPDENOVO2_AMD_RCCL"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        const char* names[] = {pg::env_user("SOAPDENOVO2_AMD_RCCL"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
         for (const char* n : names) {
             if (!n || !*n) continue;
             lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
@@ -294,7 +295,7 @@ extern "C" int pg_comm_create_local(int n_ranks, const int* devices, int transpo
     for (int i = 0; i < n_ranks; i++) for (int j = 0; j < i; j++) distinct = distinct && devices[i] != devices[j];
     if (transport < 0) {
         transport = (distinct && n_ranks > 1) ? PG_COMM_RCCL : PG_COMM_P2P;
-        if (const char* e = getenv("SOAPDENOVO2_AMD_EXCHANGE")) {
+        if (const char* e = pg::env_user("SOAPDENOVO2_AMD_EXCHANGE")) {
             if (!strcmp(e, "p2p")) transport = PG_COMM_P2P;
             else if (!strcmp(e, "rccl")) transport = PG_COMM_RCCL;
         }
@@ -636,7 +637,7 @@ extern "C" int pg_count_reads_sharded(pg_ctx* ctx, pg_comm* c, const uint64_t* d
     // a read of k k-mers makes about 2k / (w + 1) + 1 records; twice that, spread over n owners, plus slack
     const uint64_t est = 2 * n_kmers / (uint64_t)(ctx->e2.g.w + 1) + n_reads;
     uint64_t want_cap = n_reads ? 2 * est / (uint64_t)n + 4096 : 0;
-    if (const char* e = getenv("PG_ROUTE_CAP")) { const long v = atol(e); if (v > 0 && n_reads) want_cap = std::max<uint64_t>(c->pipe_cap * 4 / 5, (uint64_t)v); }   // tests: start small, exercise the repeat
+    if (const char* e = pg::env_test("PG_ROUTE_CAP")) { const long v = atol(e); if (v > 0 && n_reads) want_cap = std::max<uint64_t>(c->pipe_cap * 4 / 5, (uint64_t)v); }   // tests: start small, exercise the repeat
     pg_comm::Slot& sl = c->slot[c->round_no & 1];
     pg_comm::Slot& prev = c->slot[(c->round_no & 1) ^ 1];
     const bool one_process = c->transport == PG_COMM_P2P && n > 1;
@@ -701,7 +702,7 @@ extern "C" int pg_count_reads_sharded(pg_ctx* ctx, pg_comm* c, const uint64_t* d
     pipe_exchange_records(c, sl, rw, st, err);
     c->rounds++;
     c->round_no++;
-    if (getenv("PG_PIPE_SERIAL")) (void)pipe_drain(c, ctx, st);     // A/B: no overlap, every round complete when the call returns
+    if (pg::env_measure("PG_PIPE_SERIAL")) (void)pipe_drain(c, ctx, st);     // A/B: no overlap, every round complete when the call returns
     return err.done();
 }
 

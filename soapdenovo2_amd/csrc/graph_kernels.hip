@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "../../include/soapdenovo2_amd.h"
+#include "env.hpp"
 #include "device_ctx.hpp"
 #include "extract.hpp"
 #include "kmer.hpp"
@@ -281,7 +282,7 @@ __global__ __launch_bounds__(256) void p2_thread_kernel(P2Params p, const uint64
 // system at the rate it serves random lines at -- 23.7 G lookups/s x ~1.6 lines a lookup (a 24-byte slot straddles two 64-byte
 // lines one time in four, a lookup probes 1.75 slots on average) = 38 G lines/s, the ceiling profiles/r01_membench_random_access.log
 // measured -- so more probes a lane only cost registers, i.e. waves.  What the round bought came from the sliced CRC and the reciprocal.
-static int p2_block() { static const int v = [] { const char* e = getenv("SOAPDENOVO2_AMD_P2_BLOCK"); return e ? atoi(e) : 1; }(); return v; }
+static int p2_block() { static const int v = [] { const char* e = pg::env_measure("SOAPDENOVO2_AMD_P2_BLOCK"); return e ? atoi(e) : 1; }(); return v; }
 static void p2_launch_thread_kernel(int nw, dim3 grid, hipStream_t st, const P2Params& p, const uint64_t* words, const uint64_t* word_off, const int32_t* lens,
                                     uint64_t n_reads, uint64_t first_ordinal, int uniform_len) {
     const int bl = p2_block();
@@ -386,14 +387,16 @@ __global__ __launch_bounds__(256) void eb_list_branch(const uint64_t* nodes, int
     __shared__ unsigned long long s_base;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    auto flush = [&]() {
-        const unsigned int m = s_n;
-        if (threadIdx.x == 0 && m) s_base = atomicAdd(n_list, (unsigned long long)m);
+    // `held` = the entries in buf, the same number in every lane (the barrier that ends a trip counts the trip's hits): the decision to flush is
+    // taken on it, never on s_n itself -- a wave that is already a trip ahead adds to s_n while a slower one still looks at it, the workgroup would
+    // disagree about entering flush() and its barriers would pair up wrongly
+    unsigned int held = 0;
+    auto flush = [&]() {                                                   // (called by the whole workgroup, behind a barrier)
+        if (threadIdx.x == 0 && held) { s_base = atomicAdd(n_list, (unsigned long long)held); s_n = 0; }
         __syncthreads();
-        for (unsigned int j = threadIdx.x; j < m; j += 256) { const unsigned long long at = s_base + j; if (at < cap) list[at] = buf[j]; }
+        for (unsigned int j = threadIdx.x; j < held; j += 256) { const unsigned long long at = s_base + j; if (at < cap) list[at] = buf[j]; }
         __syncthreads();
-        if (threadIdx.x == 0) s_n = 0;
-        __syncthreads();
+        held = 0;
     };
     for (uint64_t i0 = (uint64_t)blockIdx.x * 256; i0 < n_slots; i0 += (uint64_t)gridDim.x * 256) {
         const uint64_t i = i0 + threadIdx.x;
@@ -404,8 +407,8 @@ __global__ __launch_bounds__(256) void eb_list_branch(const uint64_t* nodes, int
             hit = nd[0] != P2_EMPTY && (ways ? ((B & B_LINEAR) && eb_is_way(first + i, period_mask)) : !(B & (B_LINEAR | B_DELETED)));
         }
         if (hit) buf[atomicAdd(&s_n, 1u)] = first + i;
-        __syncthreads();
-        if (s_n > FLUSH) flush();
+        held += (unsigned int)__syncthreads_count(hit ? 1 : 0);
+        if (held > FLUSH) flush();
     }
     flush();
 }
@@ -1056,7 +1059,7 @@ int p2_layout_rank(int device, int nw, int n_own, const uint64_t* d_records, con
     *d_nodes_out = nullptr;
     if (alloc_out) *alloc_out = nullptr;
     if (n_own < 1) return PG_OK;
-    const bool verbose = getenv("PG_HOST_VERBOSE") != nullptr;
+    const bool verbose = pg::env_user("PG_HOST_VERBOSE") != nullptr;
     auto now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
     const double t0 = now();
     for (int s = 0; s < n_own; s++) if (own_counts[s] >= set_size || own_counts[s] >= 0xFFFFFFFFULL) return K6_UNSUITED;
@@ -1105,7 +1108,7 @@ int p2_layout_rank_growable(int device, int nw, int n_own, const uint64_t* d_rec
     *d_nodes_out = nullptr;
     if (alloc_out) *alloc_out = nullptr;
     if (n_own < 1) return PG_OK;
-    const bool verbose = getenv("PG_HOST_VERBOSE") != nullptr;
+    const bool verbose = pg::env_user("PG_HOST_VERBOSE") != nullptr;
     auto now = [] { struct timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec; };
     const double t0 = now();
     std::vector<uint64_t> first_slot((size_t)n_own + 1, 0);
@@ -1146,7 +1149,7 @@ int p2_layout_rank_growable(int device, int nw, int n_own, const uint64_t* d_rec
         // (two: 1.15 s -> 1.0 s at 60 M reads; eight bought another 0.05 s for four times the scratch -- and a fresh process pays for its
         //  allocations by the gigabyte)
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) lanes = (int)std::min<uint64_t>(2, (uint64_t)((double)free_b * 0.85) / std::max<uint64_t>(one, 1));
-        if (const char* v = getenv("SOAPDENOVO2_AMD_LAYOUT_LANES")) lanes = atoi(v);
+        if (const char* v = pg::env_measure("SOAPDENOVO2_AMD_LAYOUT_LANES")) lanes = atoi(v);
         lanes = std::max(1, std::min(lanes, n_own));
     }
     if (hipStreamSynchronize(st) != hipSuccess) { rc = PG_ENODEV; why = "kernel failure"; }      // the image is empty before anybody writes to it
@@ -1607,7 +1610,7 @@ int p2_build_edges(P2Device* d, P2Edges& out) {
         // on by itself where chains are long on average (slots per vertex; a 60 M-read K = 63 graph has ~300, the K = 127 one over a
         // million): the segment walks probe every linear node twice more, which a graph of short chains need not pay for
         uint32_t period = d->n_slots / (n_list + 1) > 4096 ? 512 : 0;
-        if (const char* v = getenv("SOAPDENOVO2_AMD_EB_WAYPOINTS")) period = (uint32_t)std::max(0, atoi(v));
+        if (const char* v = pg::env_test("SOAPDENOVO2_AMD_EB_WAYPOINTS")) period = (uint32_t)std::max(0, atoi(v));
         while (period & (period - 1)) period &= period - 1;           // (a power of two)
         if (period) {
             way.period_mask = period - 1;
@@ -1738,7 +1741,7 @@ done:
     hipFree(d_list); hipFree(d_cnt); hipFree(d_key); hipFree(d_key2); hipFree(d_ids); hipFree(d_bases); hipFree(d_id_before); hipFree(d_base_before);
     hipFree(d_idx); hipFree(d_order); hipFree(d_recs); hipFree(d_export); hipFree(d_text); hipFree(d_tmp);
     hipFree(d_way); hipFree(d_wcnt); hipFree(way.key); hipFree(way.seg_end); hipFree(way.seg_info); hipFree(way.seg_sum); hipFree(way.vis_own); hipFree(way.vis_info);
-    if (getenv("PG_HOST_VERBOSE") && n_way) fprintf(stderr, "edges: %llu waypoint(s) (about every %u-th linear node): chains walked by jumps\n", (unsigned long long)n_way, way.period_mask + 1);
+    if (pg::env_user("PG_HOST_VERBOSE") && n_way) fprintf(stderr, "edges: %llu waypoint(s) (about every %u-th linear node): chains walked by jumps\n", (unsigned long long)n_way, way.period_mask + 1);
     return rc;
 }
 
@@ -1837,7 +1840,7 @@ int p2_finish(P2Device* d, P2Result& out) {
         for (int q = 0; q < 8; q++) c[q] += cl[q];
         lane_arcs[l] = cl[3];
     }
-    if (getenv("PG_HOST_VERBOSE"))
+    if (pg::env_user("PG_HOST_VERBOSE"))
         for (size_t l = 0; l < d->lanes.size(); l++)
             fprintf(stderr, "graph lane %zu (device %d): pass 2 threaded %llu read(s) in %llu batch(es), %llu distinct pre-arc(s); %llu per-set scan(s) ran here\n", l, d->lanes[l].device,
                     (unsigned long long)d->lanes[l].reads, (unsigned long long)d->lanes[l].batches, lane_arcs[l], (unsigned long long)d->lanes[l].scans);

@@ -40,6 +40,7 @@
 #include <vector>
 
 #include "kmer.hpp"
+#include "env.hpp"
 #include "host_graph.hpp"
 #include "graph_dev.hpp"
 #include "backend.hpp"
@@ -58,7 +59,7 @@ int host_threads(int n_threads);
 static int pick_threads(int n_threads) { return host_threads(n_threads); }
 int host_threads(int n_threads) {
     if (n_threads > 0) return n_threads;
-    if (const char* e = getenv("SOAPDENOVO2_AMD_HOST_THREADS")) { const int v = atoi(e); if (v > 0) return v; }
+    if (const char* e = pg::env_user("SOAPDENOVO2_AMD_HOST_THREADS")) { const int v = atoi(e); if (v > 0) return v; }
     static const int usable = []() {
         int hw = (int)std::thread::hardware_concurrency();
         if (hw < 1) hw = 1;
@@ -165,7 +166,7 @@ struct HugeArray {
         uintptr_t a = (uintptr_t)q, al = (a + HP - 1) / HP * HP;
         if (al > a) munmap(q, al - a);
         if (al + nb < a + nb + HP) munmap((void*)(al + nb), a + HP - al);
-        if (!getenv("PG_NO_THP")) madvise((void*)al, nb, MADV_HUGEPAGE);
+        if (!pg::env_measure("PG_NO_THP")) madvise((void*)al, nb, MADV_HUGEPAGE);
         T* np = (T*)al;
         if (keep) memcpy((void*)np, (const void*)p, keep * sizeof(T));
         release();
@@ -347,7 +348,7 @@ struct HSet {
             }
         }
         occ = std::move(st);
-        if (getenv("PG_GROW_VERBOSE")) {
+        if (pg::env_measure("PG_GROW_VERBOSE")) {
             auto d = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
             fprintf(stderr, "grow %llu -> %llu: prepare %.3fs, re-home %.3fs (%llu moved, %llu kicks)\n", (unsigned long long)old, (unsigned long long)n, d(tg0, tg1),
                     d(tg1, std::chrono::steady_clock::now()), (unsigned long long)n_moved, (unsigned long long)n_kick);
@@ -768,7 +769,7 @@ struct Graph {
             const int rc = p2_mirror_nodes(tip_dev, changed.data(), ab.data(), changed.size());
             if (rc) { tip_error = rc; return removed; }
         }
-        if (getenv("PG_HOST_VERBOSE"))
+        if (pg::env_user("PG_HOST_VERBOSE"))
             fprintf(stderr, "tip scan: %lld removed, %lld walked again, %lld decided again; walks %.2fs, replay %.2fs (%d threads)\n", removed, rewalked,
                     redecided, tt1 - tt0, nowt() - tt1, nt);
         return removed;
@@ -1072,7 +1073,7 @@ struct ParallelEdgeBuilder {
         // SOAPDENOVO2_AMD_GZIP_LEVEL=0..9 (0 = stored); anything else is refused loudly rather than clamped.  Level 6 (zlib's default,
         // what the reference's gzopen(..., "w") uses) gives files ~25 % smaller at several times the deflate time (README).
         static const int level = []() {
-            const char* e = getenv("SOAPDENOVO2_AMD_GZIP_LEVEL");
+            const char* e = pg::env_user("SOAPDENOVO2_AMD_GZIP_LEVEL");
             if (!e) return 1;
             char* end = nullptr;
             const long v = strtol(e, &end, 10);
@@ -1144,7 +1145,7 @@ struct ParallelEdgeBuilder {
             body();
             for (auto& th : pool) th.join();
         };
-        const bool verbose = getenv("PG_HOST_VERBOSE") != nullptr;
+        const bool verbose = pg::env_user("PG_HOST_VERBOSE") != nullptr;
         auto nowf = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
         const double te0 = nowf();
         for_chunks([&](Chunk& c, Walker& w) { scan(w, c); });
@@ -1178,7 +1179,7 @@ struct ParallelEdgeBuilder {
 // make_edge over all sets -> <prefix>.edge.gz; fills the counters of the stderr banner
 template <int NW>
 static int construct_edges(Graph<NW>& g, const std::string& prefix, int n_threads, int& edge_c, long long& records, long long& extra_nodes) {
-    const char* serial = getenv("PG_SERIAL_EDGES");
+    const char* serial = pg::env_user("PG_SERIAL_EDGES");
     if (serial && atoi(serial)) {
         GzText gz;
         if (!gz.open(prefix + ".edge.gz")) { pg_set_error("cannot open " + prefix + ".edge.gz"); return PG_EIO; }
@@ -1354,8 +1355,8 @@ static int replay_layout(Graph<NW>& g, const uint64_t* records, uint64_t n, cons
         }
     }
     const uint64_t init_size = ref_initial_set_size(a_gb, P, NW == 4);
-    if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "replay: bucketing done\n");
-    const bool verbose = getenv("PG_HOST_VERBOSE") != nullptr;
+    if (pg::env_user("PG_HOST_VERBOSE")) fprintf(stderr, "replay: bucketing done\n");
+    const bool verbose = pg::env_user("PG_HOST_VERBOSE") != nullptr;
     auto nowf = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     std::atomic<int> next{0}, pool_full{0};
     auto worker = [&]() {
@@ -1450,7 +1451,7 @@ static int replay_streamed(Graph<NW>& g, pg_fetch_fn fetch, void* user, uint64_t
     for (int s = 0; s < P; s++) first[s + 1] = first[s] + per_set_count[s];
     if (first[P] != n) { pg_set_error("per-set counts do not add up to the record count"); return PG_EINVAL; }
     const uint64_t init_size = ref_initial_set_size(a_gb, P, NW == 4);
-    const bool verbose = getenv("PG_HOST_VERBOSE") != nullptr;
+    const bool verbose = pg::env_user("PG_HOST_VERBOSE") != nullptr;
     auto nowf = []() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     std::atomic<int> next{0}, failed{0};
     auto worker = [&]() {
@@ -1783,7 +1784,7 @@ struct GraphHandle : GraphHandleBase {
     int dev_build_edges(int device, int n_threads, int& edge_c, long long& records_c, long long& extra_nodes) {
         const double tv0 = now();
         start_vertex_writer();
-        if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "vertex list from the device: %.2fs\n", now() - tv0);
+        if (pg::env_user("PG_HOST_VERBOSE")) fprintf(stderr, "vertex list from the device: %.2fs\n", now() - tv0);
         if (!dev) { const int rc0 = dev_open(device); if (rc0) return rc0; }
         g.tip_dev = nullptr;                         // the device copy is about to be tagged: no more tip walks on it
         P2Edges ed;
@@ -1815,7 +1816,7 @@ struct GraphHandle : GraphHandleBase {
         if (!edge_started) return PG_OK;
         const double tw0 = now();
         if (edge_thread.joinable()) edge_thread.join();
-        if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "finish: waited %.2fs for the edge file\n", now() - tw0);
+        if (pg::env_user("PG_HOST_VERBOSE")) fprintf(stderr, "finish: waited %.2fs for the edge file\n", now() - tw0);
         edge_started = false;
         if (edge_rc) pg_set_error(edge_err);
         return edge_rc;
@@ -1869,7 +1870,7 @@ struct GraphHandle : GraphHandleBase {
             if (!m.empty()) { any = true; if (fwrite(m.data(), 1, m.size(), fp) != m.size()) { fclose(fp); pg_set_error("short write on " + prefix + ".edge.gz"); return PG_EIO; } }
         if (!any) { std::vector<uint8_t> e; ParallelEdgeBuilder<NW>::gz_member(std::string(), e); fwrite(e.data(), 1, e.size(), fp); }
         fclose(fp);
-        if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "edges: device (walk, sort, tag, download) %.2fs, text + deflate + file %.2fs\n", te1 - te0, now() - te1);
+        if (pg::env_user("PG_HOST_VERBOSE")) fprintf(stderr, "edges: device (walk, sort, tag, download) %.2fs, text + deflate + file %.2fs\n", te1 - te0, now() - te1);
         return PG_OK;
     }
     bool dev_edges = false;
@@ -1894,7 +1895,7 @@ struct GraphHandle : GraphHandleBase {
         fprintf(stderr, "Start to remove tips with minority links.\n");
         for (size_t i = 0; i < tot.per_cycle.size(); i++) fprintf(stderr, "%llu tip(s) removed in cycle %d.\n", tot.per_cycle[i], (int)i + 1);
         fprintf(stderr, "Total %llu tip(s) removed.\n", tot.minor);
-        if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "tips decided on the device: %d scan(s), %d fixed-point round(s), %.2fs\n", (int)tot.per_cycle.size() + (cut_single ? 1 : 0), tot.rounds, now() - t0);
+        if (pg::env_user("PG_HOST_VERBOSE")) fprintf(stderr, "tips decided on the device: %d scan(s), %d fixed-point round(s), %.2fs\n", (int)tot.per_cycle.size() + (cut_single ? 1 : 0), tot.rounds, now() - t0);
         sets_on_device_only = true;
         g.tip_dev = nullptr;
         return PG_OK;
@@ -1908,14 +1909,14 @@ struct GraphHandle : GraphHandleBase {
                 const double tv0 = now();
                 vertex_rc = write_vertex_keys<NW>(prefix, vertex_keys, g.n_threads, vertex_count);
                 std::vector<uint64_t>().swap(vertex_keys);
-                if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "vertex writer: %.2fs (beside the edges)\n", now() - tv0);
+                if (pg::env_user("PG_HOST_VERBOSE")) fprintf(stderr, "vertex writer: %.2fs (beside the edges)\n", now() - tv0);
             });
             return;
         }
         vertex_thread = std::thread([this]() {
             const double tv0 = now();
             vertex_rc = write_vertex_file<NW>(g, prefix, vertex_count, true);
-            if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "vertex writer: %.2fs (beside the edges)\n", now() - tv0);
+            if (pg::env_user("PG_HOST_VERBOSE")) fprintf(stderr, "vertex writer: %.2fs (beside the edges)\n", now() - tv0);
         });
     }
     // (Releasing the host copy of the sets as soon as <prefix>.vertex is written -- nothing reads it after that in device mode --
@@ -2238,7 +2239,7 @@ struct GraphHandle : GraphHandleBase {
         if (vertex_started) {
             const double tw0 = now();
             if (vertex_thread.joinable()) vertex_thread.join();
-            if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "finish: waited %.2fs for the vertex writer\n", now() - tw0);
+            if (pg::env_user("PG_HOST_VERBOSE")) fprintf(stderr, "finish: waited %.2fs for the vertex writer\n", now() - tw0);
             if (vertex_rc) return vertex_rc;
             num_vt = vertex_count;
             fprintf(stderr, "%d vertex(es) output.\n", num_vt);
@@ -2335,7 +2336,7 @@ static int layout_on_device(GraphHandle<NW>* h, const uint64_t* d_records, const
     if (failed.load()) { p2_destroy(dev); return PG_ENODEV; }
     h->dev = dev; h->dev_on = true; h->dev_id = device;
     g.tip_dev = dev;
-    if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "k-mer set layout on the device (%s): %.2fs; host copy %s: %.2fs\n", a_gb ? "static pools" : "growable sets", t1 - t0,
+    if (pg::env_user("PG_HOST_VERBOSE")) fprintf(stderr, "k-mer set layout on the device (%s): %.2fs; host copy %s: %.2fs\n", a_gb ? "static pools" : "growable sets", t1 - t0,
                                            host_copy ? "downloaded" : "not needed", now() - t1);
     return PG_OK;
 }
@@ -2375,7 +2376,7 @@ static int layout_on_ranks(GraphHandle<NW>* h, const ShardedRecords& sr, const u
     // (test hook: SOAPDENOVO2_AMD_TEST_UNSUITED_RANK=r makes rank r report "unsuited" -- as a set of >= 2^32 keys or a pool filled to
     //  the last slot would -- so that the path "some ranks laid out, one did not, everybody replays on the host" can be walked with
     //  small inputs)
-    const int forced_unsuited = getenv("SOAPDENOVO2_AMD_TEST_UNSUITED_RANK") ? atoi(getenv("SOAPDENOVO2_AMD_TEST_UNSUITED_RANK")) : -1;
+    const int forced_unsuited = pg::env_test("SOAPDENOVO2_AMD_TEST_UNSUITED_RANK") ? atoi(pg::env_test("SOAPDENOVO2_AMD_TEST_UNSUITED_RANK")) : -1;
     for (int r = 0; r < N; r++)
         pool.emplace_back([&, r] {
             std::vector<uint64_t> own, own_last, own_sizes;
@@ -2430,20 +2431,20 @@ static GraphHandleBase* graph_begin(const uint64_t* records, uint64_t n, const u
     int rc_replay = 1;
     DeviceRecords dr{d_records, NW + 2, rec_device};
     // SOAPDENOVO2_AMD_TIPS=replay: round 2's hybrid (walks on the device, decisions replayed by the host in slot order), for A/B runs
-    const bool tips_replay = getenv("SOAPDENOVO2_AMD_TIPS") && !strcmp(getenv("SOAPDENOVO2_AMD_TIPS"), "replay");
+    const bool tips_replay = pg::env_user("SOAPDENOVO2_AMD_TIPS") && !strcmp(pg::env_user("SOAPDENOVO2_AMD_TIPS"), "replay");
     if (d_records) {
         // the layout is made where the records are (SOAPDENOVO2_AMD_LAYOUT=host keeps the host replay, for A/B runs)
-        const char* where = getenv("SOAPDENOVO2_AMD_LAYOUT");
-        if (device >= 0 && device == rec_device && !(where && !strcmp(where, "host")) && !getenv("SOAPDENOVO2_AMD_TIPS_HOST"))
+        const char* where = pg::env_user("SOAPDENOVO2_AMD_LAYOUT");
+        if (device >= 0 && device == rec_device && !(where && !strcmp(where, "host")) && !pg::env_user("SOAPDENOVO2_AMD_TIPS_HOST"))
             rc_replay = layout_on_device<NW>(h, d_records, per_set_count, set_last_put, K, P, a_gb, n_threads, device, /*host_copy=*/tips_replay);
         if (rc_replay == 1) { fetch = &fetch_device_records; fetch_user = &dr; }
     }
     if (sharded) {
-        const char* where = getenv("SOAPDENOVO2_AMD_LAYOUT");
+        const char* where = pg::env_user("SOAPDENOVO2_AMD_LAYOUT");
         h->set_devices.resize(P);
         for (int si = 0; si < P; si++) h->set_devices[si] = sharded->devices[si % sharded->n_ranks];
         h->lane_devices = sharded->devices;
-        if (!(where && !strcmp(where, "host")) && !tips_replay && !getenv("SOAPDENOVO2_AMD_TIPS_HOST"))
+        if (!(where && !strcmp(where, "host")) && !tips_replay && !pg::env_user("SOAPDENOVO2_AMD_TIPS_HOST"))
             rc_replay = layout_on_ranks<NW>(h, *sharded, per_set_count, set_last_put, K, P, a_gb, n_threads);
         if (rc_replay == 1) { fetch = &fetch_sharded_records; fetch_user = (void*)sharded; }
     }
@@ -2453,8 +2454,8 @@ static GraphHandleBase* graph_begin(const uint64_t* records, uint64_t n, const u
     if (rc_replay != PG_OK) { delete h; return nullptr; }
     fprintf(stderr, "Time spent on rebuilding the k-mer set layout: %.1fs.\n", now() - t0);
     t0 = now();
-    if (device >= 0 && !getenv("SOAPDENOVO2_AMD_TIPS_HOST") && !h->dev && h->dev_open(device) != PG_OK) { delete h; return nullptr; }
-    if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "k-mer sets uploaded to the device: %.2fs\n", now() - t0);
+    if (device >= 0 && !pg::env_user("SOAPDENOVO2_AMD_TIPS_HOST") && !h->dev && h->dev_open(device) != PG_OK) { delete h; return nullptr; }
+    if (pg::env_user("PG_HOST_VERBOSE")) fprintf(stderr, "k-mer sets uploaded to the device: %.2fs\n", now() - t0);
     if (h->dev && !tips_replay) {                // decided on the device (dev_tips.hpp); the host copy of the sets is not touched
         if (h->dev_clip_tips(cut_single != 0) != PG_OK) { delete h; return nullptr; }
     } else {
@@ -2624,7 +2625,7 @@ extern "C" int pg_host_graph_finish(pg_graph* g, int* out_num_vertex, int* out_n
     if (out_num_edge) *out_num_edge = h->num_ed;
     // Unmapping tens of gigabytes of k-mer sets takes seconds (page by page, with TLB shoot-downs to every core a worker
     // ran on); a process that is about to exit leaves that to the kernel's exit path, which has none of it to do.
-    if (getenv("PG_HOST_VERBOSE")) {                       // resident memory, and how much of it sits on huge pages
+    if (pg::env_user("PG_HOST_VERBOSE")) {                       // resident memory, and how much of it sits on huge pages
         if (FILE* fp = fopen("/proc/self/smaps_rollup", "r")) {
             char line[256];
             while (fgets(line, sizeof line, fp))
@@ -2635,7 +2636,7 @@ extern "C" int pg_host_graph_finish(pg_graph* g, int* out_num_vertex, int* out_n
     const auto td0 = std::chrono::steady_clock::now();
     if (g_process_exits_next) h->shutdown();
     else delete h;
-    if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "graph released: %.2fs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - td0).count());
+    if (pg::env_user("PG_HOST_VERBOSE")) fprintf(stderr, "graph released: %.2fs\n", std::chrono::duration<double>(std::chrono::steady_clock::now() - td0).count());
     return rc;
 }
 
@@ -2674,7 +2675,7 @@ static int emu_clip_tips(const uint64_t* records, uint64_t n, const uint64_t* se
     }
     SetsView view{geo_words.data(), host_crc_table(), (uint32_t)P, set_bias((uint32_t)P), K};
     HostBackend be(n_threads);
-    if (const char* e = getenv("PG_EMU_PLACES")) be.places = std::max(1, atoi(e));     // the per-place lists and gathers of a sharded run, on one memory
+    if (const char* e = pg::env_test("PG_EMU_PLACES")) be.places = std::max(1, atoi(e));     // the per-place lists and gathers of a sharded run, on one memory
     TipTotals tot;
     rc = clip_tips<HostBackend, NW>(be, view, geo, cut_single != 0, tot);
     if (rc) { pg_set_error(be.error_text.empty() ? "emulated tip clipping failed" : be.error_text); return rc; }

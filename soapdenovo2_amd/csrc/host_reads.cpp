@@ -7,6 +7,7 @@
 // it the bytes of .vertex / .edge.gz, including its corner cases (reads cut at max_rd_len, records that
 // straddle a 32 KiB chunk, a file whose size is a multiple of 32768).
 #include "host_reads.hpp"
+#include "env.hpp"
 
 #include <fcntl.h>
 #include <stdlib.h>
@@ -335,7 +336,7 @@ static bool simd_parse_on() {
 #if defined(__x86_64__)
     static const bool have = [] { __builtin_cpu_init(); return __builtin_cpu_supports("avx2") != 0; }();
     if (!have) return false;
-    const char* e = getenv("SOAPDENOVO2_AMD_PARSE_SIMD");
+    const char* e = pg::env_test("SOAPDENOVO2_AMD_PARSE_SIMD");
     return !(e && e[0] == '0');
 #else
     return false;
@@ -545,7 +546,7 @@ long long stream_file_parallel(const InputFile& in, const std::string& path, boo
     // threads they replace (19 GB: 2.6 - 2.7 s against 2.0 - 2.3 s).
     const char* map = nullptr;
     size_t map_len = 0;
-    if (!src.sequential() && getenv("SOAPDENOVO2_AMD_READER") && !strcmp(getenv("SOAPDENOVO2_AMD_READER"), "map")) {
+    if (!src.sequential() && pg::env_user("SOAPDENOVO2_AMD_READER") && !strcmp(pg::env_user("SOAPDENOVO2_AMD_READER"), "map")) {
         struct stat st;
         if (fstat(fileno(src.fp), &st) == 0 && st.st_size > 0) {
             void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fileno(src.fp), 0);
@@ -713,7 +714,7 @@ long long stream_file_parallel(const InputFile& in, const std::string& path, boo
     }
     if (map) (void)munmap((void*)map, map_len);
     src.close();
-    if (getenv("PG_HOST_VERBOSE")) fprintf(stderr, "reader: %.2fs cutting + parsing (with the next window's read), %.2fs handing over beside it (%d threads); of the first: cuts %.2fs, parsing %.2fs, the read beside it %.2fs\n", t_parse, t_hand, nt, t_cut, t_pa, t_read);
+    if (pg::env_user("PG_HOST_VERBOSE")) fprintf(stderr, "reader: %.2fs cutting + parsing (with the next window's read), %.2fs handing over beside it (%d threads); of the first: cuts %.2fs, parsing %.2fs, the read beside it %.2fs\n", t_parse, t_hand, nt, t_cut, t_pa, t_read);
     return n_records;
 }
 
@@ -922,11 +923,11 @@ long long stream_reads(const InputFile& in, ReadSink& sink) {
         sink.on_read(codes.data(), n);
     };
     int par_threads = host_threads(0);
-    if (const char* e = getenv("SOAPDENOVO2_AMD_PARSE_THREADS")) { const int v = atoi(e); if (v > 0) par_threads = v; }
+    if (const char* e = pg::env_user("SOAPDENOVO2_AMD_PARSE_THREADS")) { const int v = atoi(e); if (v > 0) par_threads = v; }
     size_t par_window = 4096;                                    // 128 MiB of text at a time
-    if (const char* e = getenv("SOAPDENOVO2_AMD_PARSE_WINDOW")) { const long v = atol(e); if (v > 0) par_window = (size_t)v; }
+    if (const char* e = pg::env_test("SOAPDENOVO2_AMD_PARSE_WINDOW")) { const long v = atol(e); if (v > 0) par_window = (size_t)v; }
     size_t par_min_bytes = (size_t)8 << 20;
-    if (const char* e = getenv("SOAPDENOVO2_AMD_PARSE_PARALLEL_MIN")) par_min_bytes = (size_t)atol(e);
+    if (const char* e = pg::env_test("SOAPDENOVO2_AMD_PARSE_PARALLEL_MIN")) par_min_bytes = (size_t)atol(e);
     auto is_big = [&](const std::string& path) {
         struct stat st;
         return stat(path.c_str(), &st) != 0 || (size_t)st.st_size >= par_min_bytes || !S_ISREG(st.st_mode);

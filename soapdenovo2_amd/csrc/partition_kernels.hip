@@ -30,6 +30,7 @@
 #include <chrono>
 
 #include "device_ctx.hpp"
+#include "env.hpp"
 #include "extract.hpp"
 #include "occ32.hpp"
 #include "skm_tile.hpp"
@@ -45,22 +46,7 @@ template <int NW> struct E2Cfg;
 // is the empty mark ~0 and a slot is claimed word by word.  Four-word flavour: 254 bits do not fit four such words, and a fifth costs
 // 8 of 68 bytes a slot -- the k-mer's own four words instead (the first, the most significant, has its two top bits free: never ~0,
 // and bit 63 marks a slot whose other words are still being written; lds_put)
-#ifndef PG_K2_DMA
-#define PG_K2_DMA 0                                                        // (1: the next window by global_load_lds, rounds 2 - 4, for an A/B build -- see "the next window" in the kernel)
-#endif
-#ifndef PG_K2_STATIC_TILES
-#define PG_K2_STATIC_TILES 0                                               // (1: PG_K2_OPT bit 3 = a wave's first tiles are its own, the tail comes off the counter.  Measured: the rounds gain
-                                                                           //  0.7 ms at K = 63 when on, and their two wave-uniform values cost 1.5 ms in the tile loop, on or off, in scalar
-                                                                           //  registers spilled to vector lanes: profiles/r04t_k2_same_box_bisect.json)
-#endif
-#ifndef PG_K2_ADAPT2
-#define PG_K2_ADAPT2 0                                                     // (1: the two-word flavour counts records and representatives too and may stop searching for copies.  It never
-                                                                           //  stopped on anything measured (300x, 150x, 15x), and the counting cost it 2 ms of 154 -- scalar registers again)
-#endif
-#ifndef PG_K2_RAW2
-#define PG_K2_RAW2 0                                                       // (1: the two-word flavour with its own two words and one claim too -- built and measured: 156.7 ms
-#endif                                                                     //  against 155.6, profiles/r04k_k2_keys_static_tiles_ab.json; it has no fifth word to lose)
-template <> struct E2Cfg<2> { static constexpr int PW = 5, KW = 2; static constexpr bool RAW = PG_K2_RAW2 != 0; };    // LDS slot: 2 key words + ord + 20 B of counters = 44 B
+template <> struct E2Cfg<2> { static constexpr int PW = 5, KW = 2; static constexpr bool RAW = false; };   // LDS slot: 2 key words + ord + 20 B of counters = 44 B
 template <> struct E2Cfg<4> { static constexpr int PW = 7, KW = 4; static constexpr bool RAW = true; };              // 4 key words + ord + 20 B = 60 B: 2048 slots in 120 KB
 
 struct E2Dev {
@@ -175,7 +161,7 @@ __device__ __forceinline__ uint32_t fastdiv1(uint32_t i, uint32_t d, uint32_t in
 //   D     thread = the same segment: one LDS atomic reserves its items, every start bit finds the next start
 //   E     one lane per run: slot in the partition's stream (or the owner's send region), record from the dword string
 // Lanes of a wave take different reads (read index fastest), so the row stride -- forced odd -- is the bank stride.
-struct SegArg { int R, np, npad, wsd, nseg, nca; uint32_t inv_R, inv_wpr; int dbg; };   // dbg (PG_K1DBG, measurement aid): 1 = no record stores, 2 = no slot reservation either
+struct SegArg { int R, np, npad, wsd, nseg, nca; uint32_t inv_R, inv_wpr; };
 
 // W: the window length (m-mers a k-mer) at compile time, with 16-mers (0: whatever the geometry says) -- the loops of phase B
 // unroll into loads with immediate offsets, phase A loses its shifts by 32 - 2m.
@@ -260,7 +246,7 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_seg_kernel(ReadsArg a, E2De
         uint64_t* out;
         uint32_t q = 0;
         // the returned atomic on the partition's cursor is asked first and looked at after the record is built
-        if (!ROUTE && !(sa.dbg & 2)) q = atomicAdd(&e.cursor[pid], 1u);
+        if (!ROUTE) q = atomicAdd(&e.cursor[pid], 1u);
         uint64_t rec[RW];
         tile_make_record<PW>(dw + r * wsd, len, j0, n, a.ord_base + (r0 + (uint64_t)r) * (uint64_t)kpr, e.g.K, rec);
         if (ROUTE) {
@@ -269,12 +255,8 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_seg_kernel(ReadsArg a, E2De
             if (at >= ro.cap) { atomicOr(&ctr->e2_flags, F_ROUTE); continue; }
             ro.pids[(uint64_t)o * ro.cap + at] = pid;
             out = ro.recs + ((uint64_t)o * ro.cap + at) * RW;
-        } else {
-            if (sa.dbg & 2) { if (pid == 0xFFFFFFFFu || rec[0] == 0x1234567) atomicOr(&ctr->e2_flags, F_POOL); continue; }
-            out = record_slot(e, pid, q, ctr, RW);
-        }
+        } else out = record_slot(e, pid, q, ctr, RW);
         if (!out) continue;
-        if (sa.dbg & 1) { if (rec[0] == 0x1234567 && rec[1] == 77) atomicOr(&ctr->e2_flags, F_POOL); continue; }
         ulonglong2* o2 = (ulonglong2*)out;
 #pragma unroll
         for (int k = 0; k < RW / 2; k++) o2[k] = make_ulonglong2(rec[2 * k], rec[2 * k + 1]);
@@ -321,6 +303,7 @@ __device__ __forceinline__ unsigned int clip_halves_255(unsigned int x) { return
 // splits the key range.  No shared key counter and no list of claimed slots on this path: measured again in round 2 (one
 // wave-aggregated LDS atomic per step that claims a slot), the put loop lost more than the emit's listing phase costs.
 constexpr int K2_MAXPROBE = 48;
+constexpr int K2_MAXSPIN = 4096;                                           // looks at a slot that is being claimed (four-word flavour)
 
 __device__ __forceinline__ const uint64_t* record_ptr(const E2Dev& e, uint32_t pid, uint32_t i, int) {
     const uint32_t c = chunk_id_of(e, pid, i >> e.rpc_log2);
@@ -358,8 +341,10 @@ __device__ __forceinline__ bool lds_put(LdsSet<NW, SLOTS>& t, const uint64_t (&k
         // behind them, word 0 without the mark.  Everybody reads word 0 FIRST (volatile: the four reads keep their order, and the LDS
         // serves a wave's operations in order): a clean word 0 therefore comes with final words 1..3.  Whoever meets the mark -- or
         // loses the claim -- looks at the same slot again; the winner never waits for anybody, so this ends.
+        // (looking again is not a probe: a lane that keeps meeting a slot another wave is still filling must not run out of the probe budget and
+        //  report a full set -- the attempt would be dropped and the key range split for nothing; the spins have their own, larger bound)
         constexpr unsigned long long L_PENDING = 1ULL << 63;
-        for (int probes = 0; probes < K2_MAXPROBE + 16; probes++) {
+        for (int probes = 0, spins = 0; probes < K2_MAXPROBE && spins < K2_MAXSPIN;) {
             unsigned long long seen[KW];
 #pragma unroll
             for (int i = 0; i < KW; i++)                                  // (an LDS pointer, said so: a plain volatile one is read through the flat path, one load at a time)
@@ -386,7 +371,8 @@ __device__ __forceinline__ bool lds_put(LdsSet<NW, SLOTS>& t, const uint64_t (&k
                 if (ord < so) atomicMin(&t.ord[h], (unsigned long long)ord);
                 return true;
             }
-            if (!again) h = (h + 1) & (SLOTS - 1);
+            if (again) spins++;
+            else { h = (h + 1) & (SLOTS - 1); probes++; }
         }
         return false;
     }
@@ -438,24 +424,26 @@ __device__ __forceinline__ unsigned int wave_inclusive_sum(unsigned int x) {
 
 constexpr int pow2_at_least(int x) { int p = 1; while (p < x) p <<= 1; return p; }
 
-// VT: the occurrences of a window are cut into VT * THREADS equal shares ("virtual lanes"); a wave takes 64 of them at a time
-// from a counter in LDS until none are left.  VT = 1 is the static split (lane l takes share l); with more shares than lanes a
-// wave that finishes early -- shorter probe sequences, fewer lost CAS -- takes the next tile instead of waiting at the barrier.
-// VT = 0: no shares at all -- occurrence idx of the window goes to lane idx mod 64 of whichever wave takes tile idx / 64 (the same
-// counter).  The flatten step then only marks where every representative's occurrences start (one bit an occurrence: sbits) and
-// which representative is running at each tile's first occurrence (tile_rep0); a lane finds its representative with a population
-// count over its tile's 64 start bits.  The table "share -> first representative" (first_rec: every representative wrote the ~19
-// shares that start inside it, a loop of up to 64 steps a wave) is gone, and so is the inner loop over a share.
-// KS: the kernel for ONE k-mer length (0 = any): the K-only shift amounts of occ_extract become immediates and its two wave-uniform
-// switches -- a dozen scalar branches an occurrence -- go away.
-template <int NW, int SLOTS, int THREADS, int WIN, bool TIMERS, int VT = 1, int KS = 0>
-__global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetParams sp, OccConst oc, DevCounters* ctr, int dbg_arg, int opt_arg) {
-    // (a kernel for one K has the default switches as constants -- e2_count launches the general kernel for anything else: the live-slot listing with exact ranks, the early tile
-    //  request, the split-ahead of the two-word flavour and their bookkeeping are not in it, and with them go a third of the scalar registers the kernel spilled to vector lanes)
-    const int opt = KS ? (NW == 4 ? 5 : 1) : opt_arg;
-    const int dbg = KS == 0 ? dbg_arg : 0;                               // the measurement switches (PG_DBG) live in the general kernel only
-    // opt (PG_K2_OPT, wave-uniform): bit 0 = the emit lists the live slots through one returned LDS atomic a wave and stripe (the
-    // export order is unspecified anyway) instead of exact ranks from a table of per-wave counts behind a second barrier
+// The occurrences of a window are dealt 64 at a time: occurrence idx goes to lane idx mod 64 of whichever wave takes tile idx / 64 off a
+// counter in LDS -- a wave that finishes early (shorter probe sequences, fewer lost claims) takes the next tile instead of waiting at the
+// barrier.  The flatten step marks where every representative's occurrences start (one bit an occurrence: sbits) and which representative is
+// running at each tile's first occurrence (tile_rep0); a lane finds its representative with a population count over its tile's 64 start bits.
+// (Rounds 2 - 3 cut the window into equal shares a lane, static or dealt as "virtual lanes" through a share table: 177.8 / 168.7 ms against
+//  154.3 for this form, profiles/r04a_k2_vt0_opt1_ab.json; those forms are gone.)
+// KS: the kernel for ONE k-mer length (0 = any): the K-only shift amounts of occ_extract become immediates, its two wave-uniform switches -- a
+// dozen scalar branches an occurrence -- go away, and the record geometry is the usual one (128 records a chunk, records without padding).
+// TIMERS: thread 0's cycles per phase into ctr->phase (instantiated in -DPG_MEASURE builds only; 25 registers).
+template <int NW, int SLOTS, int THREADS, int WIN, bool TIMERS, int KS = 0>
+__global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetParams sp, OccConst oc, DevCounters* ctr) {
+    // What round 4 measured as switches is fixed here (each of them held wave-uniform state in scalar registers the kernel then spilled to vector
+    // lanes -- 116 -> 65 of them when they became constants, 152.5 -> 145.3 ms at K = 63, profiles/r04y_k2_switches_as_constants.json):
+    //   * the emit lists the live slots in any order through one returned LDS atomic a wave and stripe (the export order is unspecified anyway);
+    //   * a wave asks for its next tile when it has finished the current one;
+    //   * PRESPLIT (four-word flavour only: it drops one attempt in ten, the two-word one in a hundred and loses more to false alarms): a key range
+    //     foreseen to overflow the set is split BEFORE it is counted, from PRESPLIT_PCT % foreseen load on;
+    //   * ADAPT (four-word flavour only): the search for exact copies stops where a workgroup finds few (see p_dedupe).
+    constexpr bool PRESPLIT = NW == 4;
+    constexpr unsigned PRESPLIT_PCT = 75;
     constexpr int PW = E2Cfg<NW>::PW, RW = PW + 1, KW = E2Cfg<NW>::KW, NWAVE = THREADS / 64, PIECES = RW / 2, N2 = 2 * NW;
     constexpr int RD = 2 * RW;                                            // dwords a record
     constexpr int PAD = 16;                                               // readable dwords in front of record 0 (a window reaches back 2 NW + 2)
@@ -470,24 +458,21 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     __shared__ __align__(16) uint32_t rl2[2][RL_WORDS];
     // one scratch area, two lives: the record-dedupe table (DT slots), then the flattening tables
     constexpr int DT = pow2_at_least(2 * WIN);                            // open addressing over the window's records, <= 50 % full
-    constexpr int VL = (VT ? VT : 1) * THREADS;                           // virtual lanes
     constexpr int NMAX = KS ? (32 * PW - (KS - 1) - 2 < 127 ? 32 * PW - (KS - 1) - 2 : 127) : 127;   // k-mers a record (skm_geometry)
-    constexpr int SB_WORDS = (WIN * NMAX + 31) / 32 + 2;                  // VT = 0: a start bit per occurrence of a window (<= WIN * NMAX)
-    constexpr int SB_AT = ((DT > WIN + 1 + WIN ? DT : WIN + 1 + WIN) + 1) & ~1;      //         behind the dedupe table and behind tile_rep0; read 64 bits at a time
-    constexpr int FL_WORDS = VT == 0 ? SB_AT + SB_WORDS : (DT > WIN + 1 + VL / 2 ? DT : WIN + 1 + VL / 2) + 2;
-    static_assert(VT != 0 || WIN * 127 / 64 + 1 <= 2 * WIN, "tile_rep0 holds a short per tile");
+    constexpr int SB_WORDS = (WIN * NMAX + 31) / 32 + 2;                  // a start bit per occurrence of a window (<= WIN * NMAX)
+    constexpr int SB_AT = ((DT > WIN + 1 + WIN ? DT : WIN + 1 + WIN) + 1) & ~1;      // behind the dedupe table and behind tile_rep0; read 64 bits at a time
+    constexpr int FL_WORDS = SB_AT + SB_WORDS;
+    static_assert(WIN * 127 / 64 + 1 <= 2 * WIN, "tile_rep0 holds a short per tile");
     __shared__ __align__(8) unsigned int fl_raw[FL_WORDS];
     unsigned int* const dtab = fl_raw;                                    // record index + 1 of the slot's first taker, 0 = free
     unsigned int* const noff = fl_raw;                                    // [n_rep + 1] exclusive prefix sum of the representatives' k-mer counts
-    unsigned short* const first_rec = (unsigned short*)(fl_raw + WIN + 1);   // [VL] representative in which virtual lane l's share starts
-    unsigned short* const tile_rep0 = (unsigned short*)(fl_raw + WIN + 1);   // VT = 0: [tiles] the representative running at occurrence 64 * tile (lives in the dead dedupe table)
-    unsigned int* const sbits = fl_raw + SB_AT;                              // VT = 0: bit idx = occurrence idx is the first of its representative
-    __shared__ unsigned int tile_ctr;                                     // next tile of 64 virtual lanes (VT > 1)
+    unsigned short* const tile_rep0 = (unsigned short*)(fl_raw + WIN + 1);   // [tiles] the representative running at occurrence 64 * tile (lives in the dead dedupe table)
+    unsigned int* const sbits = fl_raw + SB_AT;                              // bit idx = occurrence idx is the first of its representative
+    __shared__ unsigned int tile_ctr;                                     // next tile of 64 occurrences
     __shared__ unsigned int dcount[WIN];                                  // copies of a representative record in the window
     __shared__ uint32_t crc_tab[4 * 256];                                 // CRC-32 sliced by four (kmer.hpp)
     __shared__ unsigned int hist[256];
-    constexpr int MAXSTRIPES = SLOTS / THREADS;
-    __shared__ unsigned int aborted, s_mask[40], s_val[40], wave_cnt_e[MAXSTRIPES][NWAVE], wave_cnt_f[NWAVE], s_nlive, s_tot;
+    __shared__ unsigned int aborted, s_mask[40], s_val[40], wave_cnt_f[NWAVE], s_nlive, s_tot;
     __shared__ unsigned int chunk_ids2[2][256];                           // the partitions' chunk lists (direct + maxc <= 256)
     const uint32_t nchunks = e.direct + e.maxc;
     __shared__ unsigned long long out_base;
@@ -504,32 +489,25 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long my_records = 0;
     bool dirty = true;                                                   // the LDS set needs a full wipe before the next attempt
-    unsigned long long tp[TIMERS ? 12 : 1] = {0}, tlast = TIMERS ? clock64() : 0;      // phase timers: their own instantiation (PG_DBG & 2), 25 registers
+    unsigned long long tp[TIMERS ? 12 : 1] = {0}, tlast = TIMERS ? clock64() : 0;      // phase timers: their own instantiation (-DPG_MEASURE), 25 registers
     // Every barrier of this kernel orders LDS traffic only (lds_barrier): its global stores are never read back and its
     // global loads are waited for where their registers are used.
 #define K2_SYNC() lds_barrier()
 #define K2_TICK(i) do { if (TIMERS) { const unsigned long long tn_ = clock64(); tp[(i) * TIMERS] += tn_ - tlast; tlast = tn_; } } while (0)
 
-    // opt bit 3 (VT = 0): a wave's first tiles are its own (tile = wave + 16 r for the first rounds but the last full one), only the tail
-    // comes off the counter -- three of four returned LDS atomics (and the wait for each) less a wave and window
-    auto static_rounds = [&](unsigned int tot) -> unsigned int {
-        if (!PG_K2_STATIC_TILES || VT != 0 || !(opt & 8) || (opt & 2)) return 1u;   // (bit 1 asks a tile ahead at every turn: not with it)
-        const unsigned int r = ((tot + 63u) >> 6) / NWAVE;
-        return r > 1u ? r - 1u : 1u;
-    };
-    auto tile_start = [&](unsigned int tot) -> unsigned int { return static_rounds(tot) * NWAVE; };
     // ---- prepare a window: stage -> dedupe -> flatten.  Written as barrier-free steps for a group of GS lanes (gtid = lane
     // index in the group, gwave = wave index in the group); the caller puts a barrier between the steps.
     struct Prep { bool is_rep; unsigned int n, incl, n_rep; };
     // The search for exact copies pays where there are copies (K = 63 at 300x: every other record; 155.5 ms against 194.1 without it) and costs where there are few (K = 127 from
     // 150-base reads: a record is most of a read; 162.2 ms against 141.7 without): every workgroup looks at its first 4096 records and stops searching when more than dd_pct % of
-    // them represented themselves.  opt bit 4: never search; bits 16..23: the percentage.  The default is where the search's share of the kernel equals what it saves: 70 % for the
+    // them represented themselves.  The threshold is where the search's share of the kernel equals what it saves: 70 % for the
     // four-word flavour (a 64-byte record to hash and compare; K = 127 from 150-base reads lies between 70 and 85 %: 142.5 ms off, 162.3 on), 82 % for the two-word one (its 15x case
     // -- 100 M reads over 1 Gb, more than 70 % of the records their own -- still gains 5 % from the search: 218.2 ms on, 229.7 off; profiles/r04m_k2_adaptive_dedupe_ab.json)
-    constexpr bool ADAPT = NW == 4 || PG_K2_ADAPT2 != 0;
-    bool dd_on = ADAPT ? !(opt & 16) : true;
+    // (the two-word flavour never stopped searching on anything measured -- 300x, 150x, 15x -- and the bookkeeping cost it 2 ms of 154: it always searches)
+    constexpr bool ADAPT = NW == 4;
+    bool dd_on = true;
     uint32_t dd_rec = 0, dd_rep = 0;
-    const uint32_t dd_pct = ((opt >> 16) & 0xFF) ? ((opt >> 16) & 0xFF) : (NW == 4 ? 70u : 82u);
+    constexpr uint32_t dd_pct = 70u;
     // stage the window's records: 16 bytes per lane and step; the header word as it is, every payload word high dword first
     auto p_stage = [&](auto gs_, int gtid, int nb, int cl, uint32_t w0, uint32_t wn) {
         constexpr int GS = decltype(gs_)::value;
@@ -548,43 +526,8 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
         }
         for (int i = gtid; i < DT; i += GS) dtab[i] = 0;
         for (int i = gtid; i < WIN; i += GS) dcount[i] = 1;
-        if (VT == 0) for (int i = gtid; i < SB_WORDS; i += GS) sbits[i] = 0;
+        for (int i = gtid; i < SB_WORDS; i += GS) sbits[i] = 0;
     };
-#if PG_K2_DMA
-    // the same in two halves with the memory latency in between: ask (16 bytes a lane from global memory straight into LDS,
-    // lane l of a wave to wave base + 16 l: the staging layout but for the dword order), and later turn the dwords round in
-    // place, every lane the pieces it asked for
-    auto p_stage_async = [&](int nb, int cl, uint32_t w0, uint32_t wn) {
-        uint32_t* const rlb = rl2[nb];
-        const unsigned int* const cids = chunk_ids2[cl];
-        for (uint32_t p0 = 0; p0 < wn * PIECES; p0 += THREADS) {
-            const uint32_t pc = p0 + threadIdx.x;
-            if (pc < wn * PIECES) {
-                const uint32_t ri = pc / PIECES, part = pc - ri * PIECES;
-                const uint32_t gi = w0 + ri, cid = cids[gi >> RPC_LOG2];
-                if (cid != 0 && cid != 0xFFFFFFFFu) {
-                    const ulonglong2* src = (const ulonglong2*)(e.pool + ((uint64_t)(cid - 1) * RPC + (gi & (RPC - 1))) * RS) + part;
-                    __builtin_amdgcn_global_load_lds((const void*)src, (__attribute__((address_space(3))) void*)(rlb + PAD + (p0 + wave * 64) * 4), 16, 0, 0);
-                }
-            }
-        }
-    };
-    auto p_unpack = [&](int nb, int cl, uint32_t w0, uint32_t wn) {
-        uint32_t* const rlb = rl2[nb];
-        const unsigned int* const cids = chunk_ids2[cl];
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        for (uint32_t pc = threadIdx.x; pc < wn * PIECES; pc += THREADS) {
-            const uint32_t ri = pc / PIECES, part = pc - ri * PIECES;
-            const uint32_t cid = cids[(w0 + ri) >> RPC_LOG2];
-            uint4 v = ((const uint4*)(rlb + PAD))[pc];                       // lo, hi, lo, hi
-            if (cid == 0 || cid == 0xFFFFFFFFu) v = make_uint4(0, 0, 0, 0);
-            ((uint4*)(rlb + PAD))[pc] = make_uint4(part ? v.y : v.x, part ? v.x : v.y, v.w, v.z);
-        }
-        for (int i = threadIdx.x; i < DT; i += THREADS) dtab[i] = 0;
-        for (int i = threadIdx.x; i < WIN; i += THREADS) dcount[i] = 1;
-        if (VT == 0) for (int i = threadIdx.x; i < SB_WORDS; i += THREADS) sbits[i] = 0;
-    };
-#endif
     // The next window (round 4, late).  global_load_lds looked ideal for it -- no registers, the loads fly while the emit runs -- but the compiler
     // guards every LDS WRITE that follows such a load with s_waitcnt vmcnt(0) (it cannot tell what the load will overwrite), and the emit starts
     // with LDS writes: every wave waited out the trip to HBM at the emit's first store, and, vmcnt counting in order, the next partition's first
@@ -624,7 +567,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
         }
         for (int i = threadIdx.x; i < DT; i += THREADS) dtab[i] = 0;
         for (int i = threadIdx.x; i < WIN; i += THREADS) dcount[i] = 1;
-        if (VT == 0) for (int i = threadIdx.x; i < SB_WORDS; i += THREADS) sbits[i] = 0;
+        for (int i = threadIdx.x; i < SB_WORDS; i += THREADS) sbits[i] = 0;
     };
     // dedupe: at high coverage most records of a partition are exact copies of one another (every read that covers a
     // super-k-mer completely cuts out the same bases with the same flanks).  Copies are found through a small hash table over
@@ -635,7 +578,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     auto p_dedupe = [&](int gtid, int nb, uint32_t wn, Prep& ps) {
         uint32_t* const rlb = rl2[nb];
         bool is_rep = (uint32_t)gtid < wn;
-        if (is_rep && !(dbg & 4) && (!ADAPT || dd_on)) {
+        if (is_rep && (!ADAPT || dd_on)) {
             const uint32_t* me = rlb + PAD + gtid * RD;
             uint32_t w[RD - 1];
             w[0] = me[0] & ((1u << SKM_ORD_SHIFT) - 1);                    // n, has_left, has_right
@@ -648,8 +591,8 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
             hsh ^= hsh >> 15;
             uint32_t sl = hsh & (DT - 1);
             // a table entry = the taker's place in the window + 1 (10 bits) under 22 bits of its hash: a record with another hash is passed by
-            // without reading it (opt bit 5: without the tag, every met record is read and compared)
-            const unsigned int tag = (opt & 32) ? 0u : (hsh >> 10) << 10;
+            // without reading it
+            const unsigned int tag = (hsh >> 10) << 10;
             static_assert(WIN <= 1023, "a record's place + 1 fits 10 bits");
             for (int probes = 0; probes < DT; probes++) {
                 unsigned int v = dtab[sl];
@@ -695,7 +638,6 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
         const unsigned int n_rep = tot >> 20;
         ps.n_rep = n_rep;
         tot &= (1u << 20) - 1;
-        const unsigned int share = (tot + VL - 1) / VL;
         if (ps.is_rep) {
             uint32_t* me = rl2[nb] + PAD + gtid * RD;
             const uint32_t h0 = me[0];
@@ -703,66 +645,23 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
             const unsigned int upto = base + ps.incl, k = (upto >> 20) - 1;          // this representative's rank
             const unsigned int o_hi = upto & ((1u << 20) - 1), o_lo = o_hi - ps.n;
             noff[k] = o_lo | ((unsigned int)gtid << 16) | ((h0 & 3u) << 25);          // bit 25 = has_right, bit 26 = has_left
-            if constexpr (VT == 0) {
-                atomicOr(&sbits[o_lo >> 5], 1u << (o_lo & 31u));
-                // the tiles whose first occurrence lies in this representative (at most two more: a record has <= 127 k-mers)
-                for (unsigned int t = (o_lo + 63u) >> 6; (t << 6) < o_hi; t++) tile_rep0[t] = (unsigned short)k;
-            } else {
-            // lanes whose share starts inside this record: l * share in [o_lo, o_hi)
-            const float inv = 1.0f / (float)share;
-            auto div_up = [&](unsigned int x) {                                // ceil(x / share), x < 2^16
-                unsigned int q = (unsigned int)((float)x * inv);
-                if (q * share > x) q--;
-                if ((q + 1) * share <= x) q++;
-                return q + (q * share < x ? 1u : 0u);
-            };
-            const unsigned int l0 = div_up(o_lo), l1 = min((unsigned int)VL, div_up(o_hi));
-            for (unsigned int l = l0; l < l1; l++) first_rec[l] = (unsigned short)k;
-            }
+            atomicOr(&sbits[o_lo >> 5], 1u << (o_lo & 31u));
+            // the tiles whose first occurrence lies in this representative (at most two more: a record has <= 127 k-mers)
+            for (unsigned int t = (o_lo + 63u) >> 6; (t << 6) < o_hi; t++) tile_rep0[t] = (unsigned short)k;
         }
-        if (gtid == 0) { noff[n_rep] = tot; s_tot = tot; tile_ctr = tile_start(tot); }
+        if (gtid == 0) { noff[n_rep] = tot; s_tot = tot; tile_ctr = NWAVE; }
     };
 
     // ---- emit: finalize every stored node and append it to the export array.  The set is a quarter full on average, so
-    // the live slots are first listed (rank = wave prefix sums over the ballots) and then worked on by dense waves: lane i
+    // the live slots are first listed (e_list_any) and then worked on by dense waves: lane i
     // takes the i-th live slot, finalises it into a staging area (the -d filter, the linear flag, the coverage histogram:
     // prlHashReads.c:953-1132) and wipes the slot behind it, which is all the clearing the next attempt needs; the staged
     // records go out as whole 16-byte pieces, coalesced.  One global atomic per attempt.  Barrier-free steps as above; `sb` =
     // the window buffer whose storage the list and the staging area borrow.
-    struct Emit { bool live[MAXSTRIPES]; unsigned long long bal[MAXSTRIPES]; };
     constexpr unsigned int LIST_WORDS = SLOTS * 2 / 8;                    // the list's share of the buffer, in 64-bit words
     constexpr unsigned int STAGE_CAP = (RL_WORDS * 4 - SLOTS * 2) / ((NW + 2) * 8) / 64 * 64;
     static_assert(STAGE_CAP >= 64, "staging area");
-    auto e_list1 = [&](auto gs_, int gtid, int gwave, Emit& es) {
-        constexpr int GS = decltype(gs_)::value, STR = SLOTS / GS;
-#pragma unroll
-        for (int st = 0; st < STR; st++) {
-            // every put of this attempt is complete (barrier), so a slot whose first key word is taken holds a whole key and
-            // at least one put
-            es.live[st] = set.key[0][st * GS + gtid] != L_EMPTY;
-            es.bal[st] = __ballot(es.live[st]);
-            if (lane == 0) wave_cnt_e[st][gwave] = (unsigned int)__popcll(es.bal[st]);
-        }
-    };
-    auto e_list2 = [&](auto gs_, int gtid, int gwave, int sb, Emit& es) {
-        constexpr int GS = decltype(gs_)::value, STR = SLOTS / GS, GW = GS / 64;
-        unsigned short* live_list = (unsigned short*)rl2[sb];
-        unsigned int running = 0;
-#pragma unroll
-        for (int st = 0; st < STR; st++) {
-            unsigned int before = 0, total = 0;
-#pragma unroll
-            for (int wv = 0; wv < GW; wv++) {
-                const unsigned int cw = wave_cnt_e[st][wv];
-                if (wv < gwave) before += cw;
-                total += cw;
-            }
-            if (es.live[st]) live_list[running + before + (unsigned int)__popcll(es.bal[st] & ((1ULL << lane) - 1))] = (unsigned short)(st * GS + gtid);
-            running += total;
-        }
-        if (gtid == 0) s_nlive = running;
-    };
-    // the same list in any order: a wave reserves room for its live slots of a stripe with one returned atomic on s_nlive (zeroed
+    // the list, in any order: a wave reserves room for its live slots of a stripe with one returned atomic on s_nlive (zeroed
     // in front of the barrier that ends the occurrence phase)
     auto e_list_any = [&](auto gs_, int gtid, int sb) {
         constexpr int GS = decltype(gs_)::value, STR = SLOTS / GS;
@@ -897,7 +796,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
         nrec_next = pf_nrec;
         cid_next = chunk_take(blockIdx.x, threadIdx.x, pf_cid);
     }
-    // opt bit 2: a key range that is going to overflow the set is split BEFORE it is counted.  A dropped attempt costs the attempt and two
+    // PRESPLIT: a key range that is going to overflow the set is split BEFORE it is counted.  A dropped attempt costs the attempt and two
     // sittings over the same window; what a single-window partition will hold is foreseeable from its occurrences after the dedupe
     // (s_tot) and the share of occurrences that turned out distinct in this workgroup's partitions so far (acc_live / acc_occ, the
     // same in every lane): beyond ~55 - 65 % of the slots a probe sequence of 48 is to be expected.
@@ -928,7 +827,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
         int top = 0;
         uint32_t mask = 0, val = 0;
         bool window_ready = false;                                        // rl2[b] holds window 0, prepared
-        bool raw = staged;                                                // ... or window 0 as the previous partition's emit left it (PG_K2_DMA: as global_load_lds left it)
+        bool raw = staged;                                                // ... or window 0 as the previous partition's emit wrote it (p_put), tables cleared
         staged = false;
         for (;;) {
             // (no barrier of its own for the flag: whoever read it last did so before the barriers of the emit or of the range
@@ -952,11 +851,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 const uint32_t wn = min((uint32_t)WIN, usable - w0);
                 if (!(window_ready && w0 == 0)) {
                     Prep ps;
-#if PG_K2_DMA
-                    if (raw) p_unpack(b, cl, w0, wn); else p_stage(whole, threadIdx.x, b, cl, w0, wn);
-#else
                     if (!raw) p_stage(whole, threadIdx.x, b, cl, w0, wn);   // (raw: p_put wrote the window and cleared the tables)
-#endif
                     raw = false;
                     K2_SYNC();
                     K2_TICK(2);
@@ -975,49 +870,26 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     K2_TICK(3);
                 }
                 window_ready = usable <= WIN;                             // a single window stays good for the other key ranges
-                // the partition's next window flies into the other buffer while this one is counted
-                const bool more = w0 + WIN < usable;
-                (void)more;
-#if PG_K2_DMA
-                if (more && !(dbg & 16)) p_stage_async(b ^ 1, cl, w0 + WIN, min((uint32_t)WIN, usable - w0 - WIN));
-#endif
-                const uint32_t total_occ = s_tot, share = VT == 0 ? 1u : (total_occ + VL - 1) / VL;
+                const uint32_t total_occ = s_tot;
                 const uint32_t* const rl = rl2[b];
-                if ((opt & 4) && mask == 0 && usable <= (uint32_t)WIN && acc_occ >= 4096u &&
-                    (unsigned long long)total_occ * acc_live * 100ull > (unsigned long long)(((opt >> 8) & 0xFF) ? ((opt >> 8) & 0xFF) : 75) * SLOTS * (unsigned long long)acc_occ) presplit = true;
+                if (PRESPLIT && mask == 0 && usable <= (uint32_t)WIN && acc_occ >= 4096u &&
+                    (unsigned long long)total_occ * acc_live * 100ull > (unsigned long long)PRESPLIT_PCT * SLOTS * (unsigned long long)acc_occ) presplit = true;
                 if (!presplit && !__hip_atomic_load(&aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
-                  // (VT > 1) tiles of 64 virtual lanes: the wave's first one is its own number, the next ones come off the counter
-                  const uint32_t sr = static_rounds(total_occ);
-                  uint32_t round = 0;
+                  // tiles of 64 occurrences: the wave's first one is its own number, the next ones come off the counter
                   for (uint32_t tile = (uint32_t)wave;;) {
-                    const uint32_t vlane = VT == 1 ? threadIdx.x : tile * 64u + (uint32_t)lane;
-                    if (VT != 1 && (tile * 64u * share >= total_occ || __hip_atomic_load(&aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP))) break;
-                    // opt bit 1: the wave's next tile is asked for NOW and looked at after this one (the returned LDS atomic's latency behind
-                    // the tile's work; a wave asks for one tile more than it works on, which is past the end)
-                    unsigned int nt_early = 0;
-                    if (VT != 1 && (opt & 2) && lane == 0) nt_early = atomicAdd(&tile_ctr, 1u);
-                    uint32_t idx = min(total_occ, vlane * share);
-                    const uint32_t idx1 = min(total_occ, idx + share);
-                    if (idx < idx1) {
-                        uint32_t k;
-                        if constexpr (VT == 0) {
-                            // the representative running at the tile's first occurrence + the starts among the tile's occurrences 1 .. lane
-                            const unsigned long long tb = *(const unsigned long long*)(sbits + 2 * tile);
-                            const unsigned long long upto = lane == 63 ? ~0ULL : (2ULL << lane) - 1ULL;
-                            k = (uint32_t)tile_rep0[tile] + (uint32_t)__popcll(tb & upto & ~1ULL);
-                        } else k = first_rec[vlane];
-                        uint32_t nk = noff[k], nk1 = noff[k + 1];              // idx lies inside representative k
-                        for (; idx < idx1; idx++) {
+                    if (tile * 64u >= total_occ || __hip_atomic_load(&aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
+                    const uint32_t idx = tile * 64u + (uint32_t)lane;
+                    if (idx < total_occ) {
+                        // the representative running at the tile's first occurrence + the starts among the tile's occurrences 1 .. lane
+                        const unsigned long long tb = *(const unsigned long long*)(sbits + 2 * tile);
+                        const unsigned long long upto = lane == 63 ? ~0ULL : (2ULL << lane) - 1ULL;
+                        const uint32_t k = (uint32_t)tile_rep0[tile] + (uint32_t)__popcll(tb & upto & ~1ULL);
+                        const uint32_t nk = noff[k], nk1 = noff[k + 1];        // idx lies inside representative k
+                        do {
                             const uint32_t o_lo = nk & 0xFFFFu, o_hi = nk1 & 0xFFFFu;
                             const uint32_t* rec = rl + PAD + ((nk >> 16) & 0x1FFu) * RD;
                             const uint32_t hl = (nk >> 26) & 1u, hr = (nk >> 25) & 1u, n = o_hi - o_lo;
                             const uint32_t t = idx - o_lo;
-                            if constexpr (VT != 0) {
-                                // the table entries of the next occurrence, asked for before this one is worked on
-                                k += idx + 1 >= o_hi ? 1u : 0u;
-                                nk = noff[k];
-                                nk1 = noff[k + 1];
-                            }
                             uint32_t f[N2], rc[N2], prev, next;
                             if constexpr (KS != 0) {
                                 constexpr OccConst ock = occ_const(KS, NW);
@@ -1031,8 +903,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
 #pragma unroll
                             for (int q = 0; q < N2; q++) c[q] = lt ? f[q] : rc[q];
                             const uint32_t hh = occ_hash<N2>(c);
-                            if (((hh >> 11) & mask) != val) continue;
-                            if (dbg & 1) { if (hh == 0x1234) aborted = 1; continue; }      // measurement aid: extraction only
+                            if (((hh >> 11) & mask) != val) break;                  // (another key range's occurrence)
                             uint64_t kw[KW];
                             if constexpr (E2Cfg<NW>::RAW) {
 #pragma unroll
@@ -1041,16 +912,11 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                             const uint32_t h_lo = rec[0], h_hi = rec[1];
                             const uint32_t copies = ((h_lo >> 9) & 0x1FFu) + 1u;
                             const uint64_t ord = ((((uint64_t)h_hi << 32) | h_lo) >> SKM_ORD_SHIFT) + t;
-                            if (!lds_put<NW, SLOTS>(set, kw, hh, left, right, ord, copies)) {
-                                aborted = 1;
-                                break;
-                            }
-                        }
+                            if (!lds_put<NW, SLOTS>(set, kw, hh, left, right, ord, copies)) aborted = 1;
+                        } while (0);
                     }
-                    if (VT == 1) break;
-                    if (PG_K2_STATIC_TILES && ++round < sr) { tile += NWAVE; continue; }
-                    unsigned int nt = nt_early;
-                    if (!(opt & 2) && lane == 0) nt = atomicAdd(&tile_ctr, 1u);
+                    unsigned int nt = 0;
+                    if (lane == 0) nt = atomicAdd(&tile_ctr, 1u);
                     tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)nt);
                   }
                 }
@@ -1071,16 +937,13 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 K2_SYNC();                                                  // the window and its tables are rewritten by the next one
                 // (every wave is past the tile loop: the counter starts over for the next occurrence phase -- the next window,
                 //  or the same window again for another key range -- which is at least one barrier away)
-                if (VT != 1 && threadIdx.x == 0) tile_ctr = tile_start(total_occ);
+                if (threadIdx.x == 0) tile_ctr = NWAVE;
                 if (w0 + WIN < usable) {                                    // more windows add to these counters: keep the halves small
                     for (int i = threadIdx.x; i < SLOTS; i += THREADS) {    // (they saturate at 63 / 255 in the end anyway)
 #pragma unroll
                         for (int q = 0; q < 4; q++) set.cnt[q][i] = clip_halves_255(set.cnt[q][i]);
                     }
                 }
-#if PG_K2_DMA
-                if (more && !(dbg & 16)) { b ^= 1; raw = true; }
-#endif
                 K2_TICK(5);
             }
             if (aborted || presplit) {                                    // (read behind the window loop's last barrier: the same for every lane)
@@ -1106,27 +969,15 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 // first window (p_ask: into registers; p_put writes it to the other buffer in front of the export stores).  Earlier
                 // emits (more key ranges to come) borrow the other buffer, and a single-window partition keeps its prepared window
                 // for the remaining ranges.
-                const bool ahead = top == 0 && usable_next > 0 && !(dbg & 16);
+                const bool ahead = top == 0 && usable_next > 0;
                 const int sb = top == 0 ? b : b ^ 1;
                 const uint32_t wn_next = min((uint32_t)WIN, usable_next);
-#if PG_K2_DMA
-                if (ahead) { p_stage_async(b ^ 1, cl ^ 1, 0u, wn_next); staged = true; }
-#else
                 Ahead ah;
                 bool put = !ahead;
                 if (ahead) { p_ask(cl ^ 1, wn_next, ah); staged = true; }
-#endif
                 {
-                    if (opt & 1) {
-                        e_list_any(whole, threadIdx.x, sb);
-                        K2_SYNC();
-                    } else {
-                        Emit es;
-                        e_list1(whole, threadIdx.x, wave, es);
-                        K2_SYNC();
-                        e_list2(whole, threadIdx.x, wave, sb, es);
-                        K2_SYNC();
-                    }
+                    e_list_any(whole, threadIdx.x, sb);
+                    K2_SYNC();
                     K2_TICK(6);
                     const unsigned int n_live = s_nlive;
                     if (mask == 0 && usable <= (uint32_t)WIN) {            // a whole single-window partition: what share of its occurrences were distinct
@@ -1138,15 +989,11 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                         e_final(whole, threadIdx.x, sb, c0, cn, n_live);
                         K2_TICK(11);
                         K2_SYNC();
-#if !PG_K2_DMA
                         if (!put) { p_put(b ^ 1, wn_next, ah); put = true; }
-#endif
                         e_copy(whole, threadIdx.x, sb, c0, cn);
                         if (c0 + STAGE_CAP < n_live) K2_SYNC();           // the staging area is filled again (after the last chunk the
                     }                                                     // buffer's next writer is several barriers away)
-#if !PG_K2_DMA
                     if (!put) p_put(b ^ 1, wn_next, ah);                    // (an emit without a node)
-#endif
                     K2_TICK(8);
                 }
             }
@@ -1228,17 +1075,17 @@ int e2_create(pg_ctx* c) {
     // 127-mer flavour (fewer occurrences a distinct k-mer at the same read length)
     s.log2_parts = std::max(8, std::min(24, c->log2_slots - (c->NW == 4 ? 10 : 11)));
     if (c->hint_log2_parts >= 0) s.log2_parts = std::max(8, std::min(24, c->hint_log2_parts));
-    if (const char* v = getenv("PG_LOG2_PARTS")) s.log2_parts = std::max(4, std::min(24, atoi(v)));
+    if (const char* v = env_test("PG_LOG2_PARTS")) s.log2_parts = std::max(4, std::min(24, atoi(v)));
     s.g = skm_geometry(c->K, s.log2_parts, c->NW);
     // PG_PARTS_EFF_PCT: only that share of the partition ids is used (the hash is scaled to it): partitions between two powers of two
-    if (const char* v = getenv("PG_PARTS_EFF_PCT")) { const int pct = atoi(v); if (pct >= 50 && pct <= 100) s.g.part_mul = (uint32_t)(((uint64_t)1 << s.log2_parts) * (uint64_t)pct / 100); }
+    if (const char* v = env_measure("PG_PARTS_EFF_PCT")) { const int pct = atoi(v); if (pct >= 50 && pct <= 100) s.g.part_mul = (uint32_t)(((uint64_t)1 << s.log2_parts) * (uint64_t)pct / 100); }
     s.rpc = 128;
-    if (const char* v = getenv("PG_RPC")) { const int q = atoi(v); if (q == 16 || q == 32 || q == 64 || q == 128) s.rpc = (uint32_t)q; }
+    if (const char* v = env_measure("PG_RPC")) { const int q = atoi(v); if (q == 16 || q == 32 || q == 64 || q == 128) s.rpc = (uint32_t)q; }
     const uint64_t parts = (uint64_t)1 << s.log2_parts;
     // record slots: PG_REC_STRIDE=8 gives every 48-byte record of the two-word flavour its own 64-byte line (whole-line writes
     // in K1; the four-word flavour's records are 64 bytes anyway)
     s.rs = (uint32_t)s.g.rw;
-    if (const char* v = getenv("PG_REC_STRIDE")) { const int q = atoi(v); if (q >= s.g.rw && q <= 16 && (q & 1) == 0) s.rs = (uint32_t)q; }
+    if (const char* v = env_measure("PG_REC_STRIDE")) { const int q = atoi(v); if (q >= s.g.rw && q <= 16 && (q & 1) == 0) s.rs = (uint32_t)q; }
     const uint64_t rec_bytes = (uint64_t)s.rs * 8, chunk_bytes = rec_bytes * s.rpc;
     // PG_DIRECT_CHUNKS=M: the first M chunks of every partition at computed addresses (M * parts chunks set aside up front);
     // -1 = about 1.25x the mean partition when the input size is known
@@ -1248,7 +1095,7 @@ int e2_create(pg_ctx* c) {
         // partition and a quarter of the device memory); PG_DIRECT_CHUNKS=M sets it, 0 switches it off
         int q = c->hint_kmers ? (int)(((double)c->hint_kmers * 2.0 / (double)(s.g.w + 1) / (double)s.g.part_mul * 1.25 + (double)s.rpc - 1) / (double)s.rpc) : 0;
         q = std::min(q, 8);
-        if (const char* v = getenv("PG_DIRECT_CHUNKS")) { const int e = atoi(v); if (e >= 0) q = std::min(e, 192); }
+        if (const char* v = env_measure("PG_DIRECT_CHUNKS")) { const int e = atoi(v); if (e >= 0) q = std::min(e, 192); }
         size_t free_b0 = 0, total_b0 = 0;
         if (hipMemGetInfo(&free_b0, &total_b0) == hipSuccess)
             while (q > 0 && (uint64_t)q * parts * chunk_bytes > total_b0 / 4) q--;
@@ -1264,7 +1111,7 @@ int e2_create(pg_ctx* c) {
     uint64_t pool_bytes = ((uint64_t)1 << c->log2_slots) * 64 + parts * chunk_bytes * 2;
     if (c->hint_kmers)                       // known input size: 2 / (w + 1) records a k-mer, half as much again, it grows
         pool_bytes = (uint64_t)((double)c->hint_kmers * (s.direct ? 1.5 : 3.0) / (double)(s.g.w + 1)) * rec_bytes + parts * chunk_bytes * 2 + ((uint64_t)64 << 20);
-    if (const char* v = getenv("PG_POOL_MB")) pool_bytes = (uint64_t)atoll(v) << 20;
+    if (const char* v = env_measure("PG_POOL_MB")) pool_bytes = (uint64_t)atoll(v) << 20;
     const uint64_t budget = (uint64_t)(free_b * 0.85);
     if (out_bytes + parts * 8 > budget) { pg_set_error("partition engine: export array does not fit in device memory"); return PG_ENOMEM; }
     pool_bytes += (uint64_t)s.direct * parts * chunk_bytes;
@@ -1276,7 +1123,7 @@ int e2_create(pg_ctx* c) {
     const uint64_t even = (s.pool_chunks - (uint64_t)s.direct * parts + parts - 1) / parts;
     s.maxc = (uint32_t)std::max<uint64_t>(8, std::min<uint64_t>(std::min<uint64_t>(256 - s.direct, ((uint64_t)1 << 29) / parts), even * 16));
     // PG_STARTUP_TRACE=1: what each step of the start-up took (stderr), for boxes on which a command's first second is not its own
-    const bool trace = getenv("PG_STARTUP_TRACE") && atoi(getenv("PG_STARTUP_TRACE"));
+    const bool trace = env_user("PG_STARTUP_TRACE") && atoi(env_user("PG_STARTUP_TRACE"));
     auto t_last = std::chrono::steady_clock::now();
     auto step = [&](const char* what, double gb) {
         if (!trace) return;
@@ -1291,7 +1138,7 @@ int e2_create(pg_ctx* c) {
     E2_TRY(hipMalloc(&s.pool, s.pool_chunks * chunk_bytes + 64));
     step("hipMalloc: record pool", (double)(s.pool_chunks * chunk_bytes) / 1e9);
     s.out = nullptr; s.out_err = 0;
-    if (getenv("PG_EXPORT_ASYNC") && atoi(getenv("PG_EXPORT_ASYNC")) == 0) E2_TRY(hipMalloc(&s.out, std::max<uint64_t>(out_bytes, 64)));
+    if (env_measure("PG_EXPORT_ASYNC") && atoi(env_measure("PG_EXPORT_ASYNC")) == 0) E2_TRY(hipMalloc(&s.out, std::max<uint64_t>(out_bytes, 64)));
     else {
         const int dev = c->device;
         const uint64_t bytes = std::max<uint64_t>(out_bytes, 64);
@@ -1407,7 +1254,7 @@ static void launch_seg_s(int S, dim3 grid, size_t smem, hipStream_t st, const Re
 template <int NW, bool ROUTE>
 static void launch_seg(int S, int m, int w, dim3 grid, size_t smem, hipStream_t st, const ReadsArg& a, const E2Dev& e, DevCounters* ctr, const SegArg& sa, const RouteArg& ro) {
     bool fixed = m == 16 && S <= w;
-    if (const char* v = getenv("PG_K1_W")) fixed = fixed && atoi(v) != 0;
+    if (const char* v = env_measure("PG_K1_W")) fixed = fixed && atoi(v) != 0;
     if (fixed && NW == 2 && w == 48) launch_seg_s<NW, ROUTE, 48>(S, grid, smem, st, a, e, ctr, sa, ro);
     else if (fixed && NW == 2 && w == 16) launch_seg_s<NW, ROUTE, 16>(S, grid, smem, st, a, e, ctr, sa, ro);
     else if (fixed && NW == 4 && w == 112) launch_seg_s<NW, ROUTE, 112>(S, grid, smem, st, a, e, ctr, sa, ro);
@@ -1419,7 +1266,7 @@ static int launch_tiled(pg_ctx* c, const ReadsArg& a, const RouteArg* route, hip
     const SkmGeom& g = c->e2.g;
     const int kpr = (int)a.kpr, wpr = (int)a.wpr, np = (int)a.uniform_len - g.m + 1;
     int S = tile_pick_segment(kpr, g.w);
-    if (const char* v = getenv("PG_K1_S")) { const int q = atoi(v); if (q >= 7 && q <= 15 && (q & 1) && (q <= g.w || q == 7)) S = q; }
+    if (const char* v = env_measure("PG_K1_S")) { const int q = atoi(v); if (q >= 7 && q <= 15 && (q & 1) && (q <= g.w || q == 7)) S = q; }
     const int nseg = (kpr + S - 1) / S, nca = (np + 15) / 16, npad = (16 * nca) | 1, wsd = (2 * wpr + 3) | 1;   // value rows: whole 16-position chunks, odd stride
     const size_t per_read = (size_t)(wsd + npad + nseg * S + nseg + (route ? kpr : 0)) * 4;
     int R = std::min<int>(128, std::max(1, BLOCK / nseg));                     // one pass of phase B per tile
@@ -1431,14 +1278,12 @@ static int launch_tiled(pg_ctx* c, const ReadsArg& a, const RouteArg* route, hip
         const int r_lds = (int)(((25 * 1024) / per_read) & ~(size_t)7);
         if (r_lds >= 8) R = std::min(R, r_lds);
     }
-    if (const char* v = getenv("PG_K1_R")) R = std::max(1, std::min(atoi(v), (int)std::min<size_t>(128, (60 * 1024) / per_read)));
+    if (const char* v = env_measure("PG_K1_R")) R = std::max(1, std::min(atoi(v), (int)std::min<size_t>(128, (60 * 1024) / per_read)));
     if (R < 1) return 1;
     const uint64_t grid = (a.n_reads + R - 1) / R;
     if (grid > 0x7FFFFFFFULL) { pg_set_error("batch too large for one launch"); return PG_EINVAL; }
     auto inv = [](uint32_t d) { return (uint32_t)(((1ULL << 32) + d - 1) / d); };
-    int k1dbg = 0;
-    if (const char* v = getenv("PG_K1DBG")) k1dbg = atoi(v);
-    SegArg sa{R, np, npad, wsd, nseg, nca, inv((uint32_t)R), inv(a.wpr), k1dbg};
+    SegArg sa{R, np, npad, wsd, nseg, nca, inv((uint32_t)R), inv(a.wpr)};
     RouteArg ro{nullptr, nullptr, nullptr, 0, 1};
     if (route) ro = *route;
     const size_t smem = per_read * R;
@@ -1537,7 +1382,7 @@ int e2_scatter(pg_ctx* c, const uint64_t* d_packed, const uint64_t* d_word_off, 
     a.ord_base = ord_base;
     // tiled kernel for uniform batches whose per-read LDS footprint fits
     int tiled = uniform_len && uniform_len < 4096 && (int)a.kpr < 4096;
-    if (const char* v = getenv("PG_K1")) tiled = tiled && atoi(v) != 0;
+    if (const char* v = env_measure("PG_K1")) tiled = tiled && atoi(v) != 0;
     if (tiled) {
         int rc = launch_tiled(c, a, nullptr, st);
         if (rc != 1) return rc;
@@ -1603,59 +1448,32 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     hipDeviceProp_t prop;
     if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) n_cu = prop.multiProcessorCount;
     unsigned per_cu = 2;                                                            // persistent workgroups: two per CU measured best (1 .. 32 tried; every start of a workgroup builds its tables and wipes the set)
-    if (const char* v = getenv("PG_K2_WG_PER_CU")) per_cu = (unsigned)std::max(1, atoi(v));
+    if (const char* v = env_measure("PG_K2_WG_PER_CU")) per_cu = (unsigned)std::max(1, atoi(v));
     const unsigned grid = std::min<unsigned>(parts, (unsigned)n_cu * per_cu);
-    int dbg = 0, cfg = 0, vt = 0;                                         // 0 = occurrences dealt 64 at a time, representative by population count over start bits (round 4:
-                                                                          // K2 162.9 -> 154.3 ms at K = 63, profiles/r04a_k2_vt0_opt1_ab.json)
-    if (const char* v = getenv("PG_K2_VT")) vt = atoi(v);                 // 1 = static shares (round 2), 2 / 4 = tiles of virtual lanes with a share table (round 3: 177.8 -> 168.7 ms)
-    if (const char* v = getenv("PG_DBG")) dbg = atoi(v);
-    if (const char* v = getenv("PG_K2CFG")) cfg = atoi(v);
-    // bit 0: live slots listed in any order (162.9 -> 157.0 ms; with vt = 0: 148.9 ms); bit 2: key ranges foreseen to overflow are split before they
-    // are counted -- the 127-mer flavour drops one attempt in ten (198.2 -> 194.2 ms), the 63-mer one in a hundred and loses more to false alarms
-    // (152.6 -> 162.8 ms): on for the former only; bits 8..15: the foreseen load in percent from which on it splits (0 = 75: 45 % 198.8 ms, 55 % 194.3, 65 % 191.1, never 199.3 on one box; 65 % 190.8, 75 % 188.8, 90 % 189.9 on another)
-    // bit 3 (builds with -DPG_K2_STATIC_TILES=1 only): a wave's first tiles are its own, the tail comes off the counter
-    int k2opt = c->NW == 4 ? 5 : 1;
-    if (const char* v = getenv("PG_K2_OPT")) k2opt = atoi(v);
-    if (const char* v = getenv("PG_K2_PRESPLIT_PCT")) k2opt = (k2opt & ~0xFF00) | ((atoi(v) & 0xFF) << 8);
-    if (const char* v = getenv("PG_K2_DEDUPE_PCT")) k2opt = (k2opt & ~0xFF0000) | ((atoi(v) & 0xFF) << 16);     // (100: always search for copies; default 70, see the kernel)
-    bool ks = true;                                                       // the instantiations for K = 31 / 63 / 127 (PG_K2_KS=0: the general kernel)
-    if (const char* v = getenv("PG_K2_KS")) ks = atoi(v) != 0;
-    if (dbg) ks = false;
-    if (s.rpc != 128 || s.rs != (uint32_t)s.g.rw) ks = false;            // (PG_RPC / PG_REC_STRIDE experiments: the general kernels)
-    if (k2opt != (c->NW == 4 ? 5 : 1)) ks = false;                        // (the one-K kernels have the default switches compiled in)
-    if (cfg == 3 && !(ks && c->K == 63)) cfg = 0;                         // (the half-lanes shape exists as a one-K kernel only)
-    // cfg 0: 2048-slot set, 1024 lanes, 512-record windows  -> ~150 KB LDS, one workgroup per CU
-    // cfg 1: 1024-slot set,  512 lanes, 256-record windows  ->  ~77 KB LDS, two workgroups per CU
+    // The kernels: 2048-slot set, 1024 lanes, windows of 512 records (192 in the four-word flavour) -> ~150 KB of LDS, one workgroup a CU; an
+    // instantiation for each of K = 31 / 63 / 127 on the usual record geometry, the general kernel for everything else.  (Measured and gone:
+    // half-size and quarter-size workgroups, half the lanes on the same set, static and share-table dealing, 1024-slot four-word sets: DESIGN.md §6.)
+    const bool usual = s.rpc == 128 && s.rs == (uint32_t)s.g.rw;
+    bool timers = false;
+#ifdef PG_MEASURE
+    timers = env_on(env_measure("PG_K2_TIMERS"));                        // thread 0's cycles per phase -> stderr (below)
+#endif
     {
         const OccConst oc = occ_const(c->K, c->NW);
-        // cfg 2: 512-slot set, 256 lanes, 128-record windows -> ~38 KB LDS, four workgroups per CU (meant for 4x the partitions)
+        const dim3 g(grid), b(1024);
         if (c->NW == 2) {
-            if (cfg == 0 && (dbg & 2) && vt == 0) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, true, 0>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
-            else if (cfg == 0 && (dbg & 2)) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, true, 4>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
-            else if (cfg == 3 && c->K == 63) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 512, 512, false, 0, 63>), dim3(grid), dim3(512), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);      // (A/B: the same set and window, half the lanes)
-            else if (cfg == 0 && vt == 0 && ks && c->K == 63) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 0, 63>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
-            else if (cfg == 0 && vt == 0 && ks && c->K == 31) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 0, 31>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
-            else if (cfg == 0 && vt == 0) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 0>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
-            else if (cfg == 0 && vt == 4 && ks && c->K == 63) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 4, 63>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
-            else if (cfg == 0 && vt == 4 && ks && c->K == 31) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 4, 31>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
-            else if (cfg == 0 && vt == 4) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 4>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
-            else if (cfg == 0 && vt == 2) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 2>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
-            else if (cfg == 0) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
-            else if (cfg == 1) hipLaunchKernelGGL((skm_count_kernel<2, 1024, 512, 256, false>), dim3(grid), dim3(512), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
-            else hipLaunchKernelGGL((skm_count_kernel<2, 512, 256, 128, false>), dim3(grid * 2), dim3(256), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
+#ifdef PG_MEASURE
+            if (timers) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, true>), g, b, 0, st, dev_view(c), delow, sp, oc, c->ctr); else
+#endif
+            if (usual && c->K == 63) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 63>), g, b, 0, st, dev_view(c), delow, sp, oc, c->ctr);
+            else if (usual && c->K == 31) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 31>), g, b, 0, st, dev_view(c), delow, sp, oc, c->ctr);
+            else hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false>), g, b, 0, st, dev_view(c), delow, sp, oc, c->ctr);
         } else {
-            // the 127-mer flavour.  cfg 0: 2048 slots of 60 bytes, windows of 192 records (partitions of ~4 k occurrences); cfg 4: round 4's
-            // shape, 1024 slots and windows of 512 (for partitions half as large: PG_PARTS_SHIFT=1); PG_K2_VT=4 / 1: round 3's / round 2's
-            // way of dealing the occurrences, in that shape
-            if (cfg == 0 && (dbg & 2)) hipLaunchKernelGGL((skm_count_kernel<4, 2048, 1024, 192, true, 0>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
-            else if (cfg == 0 && vt == 0 && ks && c->K == 127) hipLaunchKernelGGL((skm_count_kernel<4, 2048, 1024, 192, false, 0, 127>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
-            else if (cfg == 0 && vt == 0) hipLaunchKernelGGL((skm_count_kernel<4, 2048, 1024, 192, false, 0>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
-            else if (cfg == 4 && ks && c->K == 127) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false, 0, 127>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
-            else if (cfg == 4) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false, 0>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
-            else if (cfg == 0 && vt == 4) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false, 4>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
-            else if (cfg == 0) hipLaunchKernelGGL((skm_count_kernel<4, 1024, 1024, 512, false>), dim3(grid), dim3(1024), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
-            else if (cfg == 1) hipLaunchKernelGGL((skm_count_kernel<4, 512, 512, 256, false>), dim3(grid), dim3(512), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
-            else hipLaunchKernelGGL((skm_count_kernel<4, 256, 256, 128, false>), dim3(grid * 2), dim3(256), 0, st, dev_view(c), delow, sp, oc, c->ctr, dbg, k2opt);
+#ifdef PG_MEASURE
+            if (timers) hipLaunchKernelGGL((skm_count_kernel<4, 2048, 1024, 192, true>), g, b, 0, st, dev_view(c), delow, sp, oc, c->ctr); else
+#endif
+            if (usual && c->K == 127) hipLaunchKernelGGL((skm_count_kernel<4, 2048, 1024, 192, false, 127>), g, b, 0, st, dev_view(c), delow, sp, oc, c->ctr);
+            else hipLaunchKernelGGL((skm_count_kernel<4, 2048, 1024, 192, false>), g, b, 0, st, dev_view(c), delow, sp, oc, c->ctr);
         }
     }
     E2_TRY(hipGetLastError());
@@ -1683,7 +1501,7 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     }
     if (h.e2_flags & F_OUT) { pg_set_error("partition engine: more distinct k-mers than the export array holds (raise log2_slots)"); return PG_ENOMEM; }
     if (h.e2_flags & F_SPLIT) { pg_set_error("partition engine: a partition could not be split to fit the LDS set"); return PG_ENOMEM; }
-    if (dbg & 2) {
+    if (timers) {
         static const char* names[12] = {"partition header", "clear after a dropped attempt", "window: unpack / stage + barrier", "barrier + flatten (prefix sum, tables) + barriers", "occurrences (thread 0's share)",
                                         "wait for the slowest wave + barrier", "emit: ask for the next window, list the live slots", "-", "emit: barrier + coalesced copy out", "dropped attempts (count)",
                                         "dedupe (hash, probe, compare)", "emit: finalise into the staging area"};

@@ -30,6 +30,7 @@
 #include <algorithm>
 
 #include "kmer.hpp"
+#include "env.hpp"
 #include "extract.hpp"
 #include "device_ctx.hpp"
 #include "../../include/soapdenovo2_amd.h"
@@ -497,7 +498,7 @@ static inline uint64_t slot_bytes(int NW) { return (NW == 2 ? 4 : 8) * sizeof(ui
 extern "C" pg_ctx* pg_create_engine(int device, int K, int mer127, int n_sets, int log2_slots, int engine);
 extern "C" pg_ctx* pg_create(int device, int K, int mer127, int n_sets, int log2_slots) {
     int engine = 2;
-    if (const char* v = getenv("PG_ENGINE")) engine = atoi(v);
+    if (const char* v = pg::env_user("PG_ENGINE")) engine = atoi(v);
     return pg_create_engine(device, K, mer127, n_sets, log2_slots, engine);
 }
 
@@ -508,7 +509,7 @@ static int parts_for_kmers(uint64_t total_kmers, int nw) {
     // (the 127-mer flavour keeps rounding up: 2^22 partitions of 1.1 k beat 2^21 of 2.3 k by 10 % there)
     // round 4, later: the 127-mer flavour's set holds 2048 keys of four words (one claim a key): 4 k occurrences a partition
     while (lp < 24 && (double)((uint64_t)(nw == 4 ? 4096 : 8192) << lp) * (nw == 4 ? 1.0 : 1.4142) < (double)total_kmers) lp++;
-    if (const char* v = getenv("PG_PARTS_SHIFT")) lp = std::max(8, std::min(24, lp + atoi(v)));      // A/B runs: twice / half the partitions
+    if (const char* v = pg::env_measure("PG_PARTS_SHIFT")) lp = std::max(8, std::min(24, lp + atoi(v)));      // A/B runs: twice / half the partitions
     return lp;
 }
 extern "C" pg_ctx* pg_create_sized(int device, int K, int mer127, int n_sets, int log2_slots, int engine, uint64_t expected_kmers);
@@ -517,7 +518,7 @@ extern "C" pg_ctx* pg_create_engine(int device, int K, int mer127, int n_sets, i
 }
 extern "C" pg_ctx* pg_create_sized(int device, int K, int mer127, int n_sets, int log2_slots, int engine, uint64_t expected_kmers) {
     int n = 0;
-    const bool trace = getenv("PG_STARTUP_TRACE") && atoi(getenv("PG_STARTUP_TRACE"));
+    const bool trace = pg::env_user("PG_STARTUP_TRACE") && atoi(pg::env_user("PG_STARTUP_TRACE"));
     const auto t_in = std::chrono::steady_clock::now();
     auto since = [&] { return std::chrono::duration<double>(std::chrono::steady_clock::now() - t_in).count(); };
     if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { g_err = "pg_create: no HIP device available"; return nullptr; }
@@ -535,7 +536,7 @@ extern "C" pg_ctx* pg_create_sized(int device, int K, int mer127, int n_sets, in
     c->variant = 1;
     c->engine = engine;
     if (expected_kmers) { c->hint_kmers = expected_kmers; c->hint_log2_parts = parts_for_kmers(expected_kmers, c->NW); }
-    if (const char* v = getenv("PG_VARIANT")) c->variant = atoi(v);
+    if (const char* v = pg::env_measure("PG_VARIANT")) c->variant = atoi(v);
     if (engine == 2) {
         if (hipMalloc(&c->ctr, sizeof(DevCounters)) != hipSuccess) { g_err = "pg_create: hipMalloc failed"; delete c; return nullptr; }
         if (trace) fprintf(stderr, "[ctx]   %-44s %7.3f s (since the call)\n", "hipSetDevice + first hipMalloc", since());

@@ -16,6 +16,7 @@
 #include <string>
 
 #include "../../include/soapdenovo2_amd.h"
+#include "env.hpp"
 #include "device_ctx.hpp"
 
 namespace pg {
@@ -77,7 +78,7 @@ __global__ __launch_bounds__(256) void sr_checksum(const uint64_t* __restrict__ 
 template <int RW, typename Idx>
 static int sort_impl(uint64_t* d_records, uint64_t n, void* d_ws, size_t ws_bytes, hipStream_t stream) {
     int rc = PG_OK;
-    const bool verbose = getenv("PG_SORT_VERBOSE") != nullptr;
+    const bool verbose = pg::env_measure("PG_SORT_VERBOSE") != nullptr;
     auto now = [] { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
     double t0 = now();
     auto lap = [&](const char* what) { if (verbose) { (void)hipStreamSynchronize(stream); const double t = now(); fprintf(stderr, "[sort] %s: %.3fs\n", what, t - t0); t0 = t; } };
@@ -142,7 +143,7 @@ extern "C" int pg_sort_records_ws(uint64_t* d_records, uint64_t n, int mer127, v
     hipStream_t stream = (hipStream_t)stream_v;
     // 32-bit record indices while they suffice; PG_SORT_WIDE=1 forces the 64-bit flavour (tests)
     bool wide = n > 0xFFFFFFFFULL;
-    if (const char* e = getenv("PG_SORT_WIDE")) wide = wide || atoi(e) != 0;
+    if (const char* e = pg::env_test("PG_SORT_WIDE")) wide = wide || atoi(e) != 0;
     if (mer127) return wide ? sort_impl<6, uint64_t>(d_records, n, d_workspace, workspace_bytes, stream) : sort_impl<6, uint32_t>(d_records, n, d_workspace, workspace_bytes, stream);
     return wide ? sort_impl<4, uint64_t>(d_records, n, d_workspace, workspace_bytes, stream) : sort_impl<4, uint32_t>(d_records, n, d_workspace, workspace_bytes, stream);
 }
