@@ -314,12 +314,21 @@ int pg_last_put(pg_ctx *ctx, uint64_t *set_last_put_out, void *stream);
 int pg_host_last_put_matters(const uint64_t *set_counts, int n_sets, int a_gb, int mer127);
 
 /* Partition engine: the export array itself instead of a copy of it (the caller owns *d_records_out and frees it with
- * hipFree); everything else the context holds on the device is released, the context can only be destroyed afterwards. */
+ * pg_device_free -- the block comes out of the library's device arena, csrc/arena.hpp, not out of hipMalloc); everything else the context holds on the device is released, the context can only be destroyed afterwards. */
 int pg_export_take(pg_ctx *ctx, uint64_t **d_records_out, uint64_t *n_out);
-/* The same, with the record pool handed over too (*d_workspace_out, hipFree it when done): scratch memory for
+/* The same, with the record pool handed over too (*d_workspace_out, pg_device_free it when done): scratch memory for
  * pg_sort_records_ws, so that the hand-over needs no large allocation (hipMalloc right after a big hipFree takes seconds). */
 int pg_export_take_ws(pg_ctx *ctx, uint64_t **d_records_out, uint64_t *n_out, void **d_workspace_out, uint64_t *workspace_bytes_out);
-void pg_device_free(void *d_ptr);   /* hipFree, for callers that do not link the HIP runtime */
+void pg_device_free(void *d_ptr);   /* gives a block the library handed over back to its device arena (a pointer from hipMalloc: hipFree) */
+/* Everything the library allocates on a GPU is cut from one arena per device: a reserved virtual range whose physical memory is created as its
+ * high-water mark grows and goes back to the driver only when the arena is empty and unpinned -- the driver clears released memory, and a
+ * hipMalloc behind a large hipFree waits for that.  call_pregraph pins its devices for the command; a library caller that creates and destroys
+ * contexts in a loop may pin a device around the loop.  SOAPDENOVO2_AMD_ARENA=0: plain hipMalloc / hipFree. */
+void pg_device_arena_pin(int device);
+void pg_device_arena_unpin(int device);
+/* out[0..7] = active (1 = arena, 0 = plain hipMalloc), bytes reserved, mapped, in use, peak in use, blocks cut, physical pieces created,
+ * microseconds spent creating + mapping them */
+void pg_device_arena_stats(int device, uint64_t out[8]);
 /* A read-only look at the partition engine's export array after pg_finalize (no copy; valid until the next pg_reset,
  * pg_export_take or pg_destroy). */
 int pg_export_peek(pg_ctx *ctx, const uint64_t **d_records_out, uint64_t *n_out);

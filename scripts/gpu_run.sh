@@ -1,0 +1,49 @@
+#!/bin/bash
+# One parameterised recipe for the GPU box (replaces the 74 one-off scripts of rounds 2 - 4):
+#   gpurun --timeout 1500 -- 'bash scripts/gpu_run.sh <tag> <step> [<step> ...]'
+# Everything lands under gpurun_out/<tag>/.  Steps:
+#   tests[:<pytest -k expression>]   the -m gpu suite (or a subset)
+#   smoke                            __graft_entry__.smoke()
+#   bench[:<extra bench.py args>]    one bench.py line -> bench<i>.json (default arguments = the driver's run)
+#   stats[:<bench args>]             rocprofv3 --kernel-trace --stats of a kernels-only bench run -> kernel_stats<i>.csv
+#   pmc:<counters>[:<bench args>]    one rocprofv3 --pmc pass (comma-separated counters) of a short kernels-only run -> pmc<i>_*.csv
+#   phases[:<bench args>]            K2's phase cycles from the -DPG_MEASURE library (SOAPDENOVO2_AMD_LIB=..._measure.so, PG_K2_TIMERS=1)
+#   sh:<command>                     anything else, logged to sh<i>.log
+# A step's bench arguments use ',' for ' ' (gpurun hands one string to bash).
+set -u
+TAG=$1; shift
+O=gpurun_out/$TAG; mkdir -p "$O"
+cd "$(dirname "$0")/.." || exit 1
+export TMPDIR=/tmp
+i=0
+KERNELS_ONLY="--no-cpu-baseline --no-extras"
+for step in "$@"; do
+    i=$((i + 1))
+    kind=${step%%:*}; arg=""; [ "$kind" != "$step" ] && arg=${step#*:}
+    t0=$(date +%s)
+    case $kind in
+    tests)
+        if [ -n "$arg" ]; then timeout 1200 python -m pytest tests -m gpu -x -q -k "$arg" > "$O/tests$i.log" 2>&1; else timeout 1200 python -m pytest tests -m gpu -x -q > "$O/tests$i.log" 2>&1; fi
+        echo "[$i] tests rc=$? $(tail -1 "$O/tests$i.log" | cut -c1-160)";;
+    smoke)
+        timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$O/smoke$i.log" 2>&1; echo "[$i] smoke rc=$? $(tail -1 "$O/smoke$i.log")";;
+    bench)
+        timeout 1500 python bench.py ${arg//,/ } > "$O/bench$i.json" 2> "$O/bench$i.err"; echo "[$i] bench rc=$?"
+        python scripts/bench_digest.py "$O/bench$i.json";;
+    stats)
+        rm -rf /tmp/prof_$i; timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$i -o s -- python bench.py $KERNELS_ONLY --no-k127 ${arg//,/ } > "$O/stats$i.json" 2> "$O/stats$i.err"; echo "[$i] stats rc=$?"
+        f=$(find /tmp/prof_$i -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$O/kernel_stats$i.csv" && head -8 "$O/kernel_stats$i.csv" | cut -c1-200
+        python scripts/bench_digest.py "$O/stats$i.json";;
+    pmc)
+        ctrs=${arg%%:*}; bargs=""; [ "$ctrs" != "$arg" ] && bargs=${arg#*:}
+        rm -rf /tmp/pmc_$i; timeout 900 rocprofv3 --kernel-trace --pmc ${ctrs//,/ } -d /tmp/pmc_$i -o p -- python bench.py $KERNELS_ONLY --no-k127 --steps 1 --warmup 0 ${bargs//,/ } > "$O/pmc$i.json" 2> "$O/pmc$i.err"; echo "[$i] pmc $ctrs rc=$?"
+        f=$(find /tmp/pmc_$i -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python scripts/pmc_summary.py /tmp/pmc_$i > "$O/pmc${i}_${ctrs//,/_}.txt" 2>&1 && tail -12 "$O/pmc${i}_${ctrs//,/_}.txt" | cut -c1-220;;
+    phases)
+        SOAPDENOVO2_AMD_LIB=$PWD/soapdenovo2_amd/libsoapdenovo2_amd_measure.so PG_K2_TIMERS=1 timeout 600 python bench.py $KERNELS_ONLY --no-k127 --steps 1 --warmup 0 ${arg//,/ } > "$O/phases$i.json" 2> "$O/phases$i.txt"; echo "[$i] phases rc=$?"
+        grep "K2 phase" "$O/phases$i.txt" | tail -12;;
+    sh)
+        timeout 1500 bash -c "$arg" > "$O/sh$i.log" 2>&1; echo "[$i] sh rc=$? $(tail -3 "$O/sh$i.log" | cut -c1-200)";;
+    *) echo "[$i] unknown step $step";;
+    esac
+    echo "[$i] $kind took $(( $(date +%s) - t0 )) s"
+done

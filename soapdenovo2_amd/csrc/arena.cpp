@@ -1,0 +1,277 @@
+// arena.cpp -- see arena.hpp.
+#include "arena.hpp"
+
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <atomic>
+#include <chrono>
+#include <map>
+#include <mutex>
+#include <unordered_map>
+#include <vector>
+
+#include "env.hpp"
+
+namespace pg {
+namespace {
+
+constexpr size_t ALIGN = 256;                       // what hipMalloc promises at least; blocks of a megabyte and more start on 4 KiB
+constexpr int MAX_DEVICES = 64;
+
+inline size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+struct Arena {
+    int device = -1;
+    bool tried = false, active = false;
+    std::mutex list_mu;                             // the free list, the live blocks, the pins
+    std::mutex map_mu;                              // the physical chunks (growing the mapping may take the driver seconds; cutting blocks never waits for it)
+    char* base = nullptr;
+    size_t reserved = 0, chunk = 0;
+    std::atomic<size_t> mapped_end{0};
+    std::vector<hipMemGenericAllocationHandle_t> handles;
+    std::vector<hipMemAccessDesc> access;
+    hipMemAllocationProp prop;
+    std::map<size_t, size_t> free_;                 // offset -> bytes, coalesced
+    std::unordered_map<size_t, size_t> used;        // offset -> bytes
+    int pins = 0;
+    uint64_t in_use = 0, peak = 0, n_malloc = 0, n_free = 0, n_chunks = 0;
+    double map_seconds = 0;
+
+    void init(int dev) {
+        tried = true;
+        device = dev;
+        if (const char* e = env_user("SOAPDENOVO2_AMD_ARENA")) if (atoi(e) == 0) return;
+        struct OnDevice {                                                   // (hipMemGetInfo and the reservation speak of the current device)
+            int cur = -1, dev;
+            explicit OnDevice(int d) : dev(d) { (void)hipGetDevice(&cur); if (cur != dev) (void)hipSetDevice(dev); }
+            ~OnDevice() { if (cur >= 0 && cur != dev) (void)hipSetDevice(cur); }
+        } on_device(dev);
+        int vmm = 0;
+        if (hipDeviceGetAttribute(&vmm, hipDeviceAttributeVirtualMemoryManagementSupported, dev) != hipSuccess || !vmm) return;
+        memset(&prop, 0, sizeof prop);
+        prop.type = hipMemAllocationTypePinned;
+        prop.location.type = hipMemLocationTypeDevice;
+        prop.location.id = dev;
+        size_t gran = 0;
+        if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityRecommended) != hipSuccess || gran == 0) return;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) return;
+        chunk = round_up((size_t)512 << 20, gran);                        // physical memory comes in pieces of this size
+        reserved = round_up(total_b, chunk);
+        void* p = nullptr;
+        if (hipMemAddressReserve(&p, reserved, 0, nullptr, 0) != hipSuccess || !p) { (void)hipGetLastError(); return; }
+        base = (char*)p;
+        // who may touch the memory: this GPU, and every GPU of the process that can reach it (a sharded run probes the k-mer sets of
+        // the other ranks through peer mappings)
+        int n_dev = 0;
+        (void)hipGetDeviceCount(&n_dev);
+        for (int d = 0; d < n_dev; d++) {
+            int can = d == dev;
+            if (d != dev && hipDeviceCanAccessPeer(&can, d, dev) != hipSuccess) can = 0;
+            if (!can) continue;
+            hipMemAccessDesc a;
+            memset(&a, 0, sizeof a);
+            a.location.type = hipMemLocationTypeDevice;
+            a.location.id = d;
+            a.flags = hipMemAccessFlagsProtReadWrite;
+            access.push_back(a);
+        }
+        free_[0] = reserved;
+        active = true;
+    }
+
+    // physical memory under [0, end); called without list_mu
+    hipError_t ensure_mapped(size_t end) {
+        if (end <= mapped_end.load(std::memory_order_acquire)) return hipSuccess;
+        std::lock_guard<std::mutex> g(map_mu);
+        const auto t0 = std::chrono::steady_clock::now();
+        hipError_t rc = hipSuccess;
+        size_t at = mapped_end.load(std::memory_order_relaxed);
+        while (at < end) {
+            hipMemGenericAllocationHandle_t h;
+            rc = hipMemCreate(&h, chunk, &prop, 0);
+            if (rc != hipSuccess) break;
+            rc = hipMemMap(base + at, chunk, 0, h, 0);
+            if (rc != hipSuccess) { (void)hipMemRelease(h); break; }
+            rc = hipMemSetAccess(base + at, chunk, access.data(), access.size());
+            if (rc != hipSuccess) { (void)hipMemUnmap(base + at, chunk); (void)hipMemRelease(h); break; }
+            handles.push_back(h);
+            n_chunks++;
+            at += chunk;
+            mapped_end.store(at, std::memory_order_release);
+        }
+        map_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (rc != hipSuccess) (void)hipGetLastError();
+        return rc == hipSuccess ? hipSuccess : hipErrorOutOfMemory;
+    }
+
+    // list_mu held
+    void give_back(size_t off, size_t bytes) {
+        auto nx = free_.lower_bound(off);
+        if (nx != free_.end() && off + bytes == nx->first) { bytes += nx->second; nx = free_.erase(nx); }
+        if (nx != free_.begin()) {
+            auto pv = std::prev(nx);
+            if (pv->first + pv->second == off) { pv->second += bytes; return; }
+        }
+        free_[off] = bytes;
+    }
+
+    // list_mu held, nothing allocated, nobody pins: the physical memory goes back to the driver
+    void trim() {
+        std::lock_guard<std::mutex> g(map_mu);
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (cur != device) (void)hipSetDevice(device);
+        (void)hipDeviceSynchronize();
+        size_t at = 0;
+        for (auto h : handles) { (void)hipMemUnmap(base + at, chunk); (void)hipMemRelease(h); at += chunk; }
+        handles.clear();
+        mapped_end.store(0, std::memory_order_release);
+        if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
+        if (env_user("PG_HOST_VERBOSE"))
+            fprintf(stderr, "arena (device %d): %.2f GB of physical memory in %llu piece(s), created in %.2fs in all; peak in use %.2f GB; %llu block(s) cut, %llu given back\n", device,
+                    (double)at / 1e9, (unsigned long long)n_chunks, map_seconds, (double)peak / 1e9, (unsigned long long)n_malloc, (unsigned long long)n_free);
+    }
+
+    hipError_t malloc_(void** out, size_t bytes) {
+        const size_t need = round_up(bytes ? bytes : 1, ALIGN);
+        const size_t al = need >= ((size_t)1 << 20) ? 4096 : ALIGN;
+        size_t off = 0;
+        {
+            std::lock_guard<std::mutex> g(list_mu);
+            auto it = free_.begin();
+            size_t pad = 0;
+            for (; it != free_.end(); ++it) {
+                pad = round_up(it->first, al) - it->first;
+                if (it->second >= need + pad) break;
+            }
+            if (it == free_.end()) return hipErrorOutOfMemory;
+            const size_t hole_off = it->first, hole = it->second;
+            off = hole_off + pad;
+            free_.erase(it);
+            if (pad) free_[hole_off] = pad;
+            if (hole > pad + need) free_[off + need] = hole - pad - need;
+            used[off] = need;
+            in_use += need;
+            if (in_use > peak) peak = in_use;
+            n_malloc++;
+        }
+        const hipError_t rc = ensure_mapped(off + need);
+        if (rc != hipSuccess) {
+            std::lock_guard<std::mutex> g(list_mu);
+            used.erase(off);
+            in_use -= need;
+            give_back(off, need);
+            return rc;
+        }
+        *out = base + off;
+        return hipSuccess;
+    }
+
+    bool owns(const void* p) const { return active && (const char*)p >= base && (const char*)p < base + reserved; }
+
+    hipError_t free_block(void* p) {
+        // hipFree waits for the device: whoever frees a block behind a kernel that still reads it relies on that
+        int cur = -1;
+        (void)hipGetDevice(&cur);
+        if (cur != device) (void)hipSetDevice(device);
+        const hipError_t rc = hipDeviceSynchronize();
+        if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
+        std::lock_guard<std::mutex> g(list_mu);
+        const size_t off = (size_t)((char*)p - base);
+        auto it = used.find(off);
+        if (it == used.end()) return hipErrorInvalidValue;
+        const size_t bytes = it->second;
+        used.erase(it);
+        in_use -= bytes;
+        n_free++;
+        give_back(off, bytes);
+        if (used.empty() && pins == 0) trim();
+        return rc;
+    }
+};
+
+std::mutex g_init_mu;
+Arena* g_arena[MAX_DEVICES];
+
+Arena* arena_of(int dev) {
+    if (dev < 0 || dev >= MAX_DEVICES) return nullptr;
+    std::lock_guard<std::mutex> g(g_init_mu);
+    if (!g_arena[dev]) g_arena[dev] = new Arena();          // (never deleted: HIP calls from static destructors run after the runtime is gone)
+    if (!g_arena[dev]->tried) g_arena[dev]->init(dev);
+    return g_arena[dev];
+}
+
+}  // namespace
+
+hipError_t arena_malloc(void** p, size_t bytes) {
+    int dev = 0;
+    hipError_t rc = hipGetDevice(&dev);
+    if (rc != hipSuccess) return rc;
+    Arena* a = arena_of(dev);
+    if (!a || !a->active) return hipMalloc(p, bytes);
+    return a->malloc_(p, bytes);
+}
+
+hipError_t arena_free(void* p) {
+    if (!p) return hipSuccess;
+    {
+        std::unique_lock<std::mutex> g(g_init_mu);
+        for (int d = 0; d < MAX_DEVICES; d++) {
+            Arena* a = g_arena[d];
+            if (a && a->owns(p)) { g.unlock(); return a->free_block(p); }
+        }
+    }
+    return hipFree(p);
+}
+
+hipError_t arena_mem_info(size_t* free_bytes, size_t* total_bytes) {
+    const hipError_t rc = hipMemGetInfo(free_bytes, total_bytes);
+    if (rc != hipSuccess) return rc;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return hipSuccess;
+    Arena* a = arena_of(dev);
+    if (a && a->active) {
+        std::lock_guard<std::mutex> g(a->list_mu);
+        const size_t mapped = a->mapped_end.load();
+        if (mapped > a->in_use) *free_bytes += mapped - a->in_use;
+    }
+    return hipSuccess;
+}
+
+void arena_pin(int device) {
+    Arena* a = arena_of(device);
+    if (!a || !a->active) return;
+    std::lock_guard<std::mutex> g(a->list_mu);
+    a->pins++;
+}
+
+void arena_unpin(int device) {
+    Arena* a = arena_of(device);
+    if (!a || !a->active) return;
+    std::lock_guard<std::mutex> g(a->list_mu);
+    if (a->pins > 0) a->pins--;
+    if (a->pins == 0 && a->used.empty() && a->mapped_end.load() != 0) a->trim();
+}
+
+ArenaStats arena_stats(int device) {
+    ArenaStats s;
+    memset(&s, 0, sizeof s);
+    Arena* a = arena_of(device);
+    if (!a || !a->active) return s;
+    std::lock_guard<std::mutex> g(a->list_mu);
+    s.active = 1;
+    s.reserved = a->reserved;
+    s.mapped = a->mapped_end.load();
+    s.in_use = a->in_use;
+    s.peak_in_use = a->peak;
+    s.n_malloc = a->n_malloc;
+    s.n_free = a->n_free;
+    s.n_chunks_created = a->n_chunks;
+    s.map_seconds = a->map_seconds;
+    return s;
+}
+
+}  // namespace pg

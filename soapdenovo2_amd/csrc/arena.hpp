@@ -1,0 +1,48 @@
+// arena.hpp -- one device arena per GPU for everything the library allocates in device memory.
+//
+// Why: the driver clears what a process releases (27 - 33 GB/s on the boxes measured, scripts/startup_probe.hip) and an allocation that lands
+// on memory still being cleared waits for it -- a command that makes dozens of hipMalloc / hipFree calls of tens of gigabytes (pass 1's pool,
+// the export array, the set layout, the tip / edge / pass-2 temporaries) waits behind its OWN hipFrees: 0.7 s became 3.65 s of "pass 2 batches"
+// on one box with nothing of it in the kernels.  Here a GPU's memory is ONE reserved virtual range (hipMemAddressReserve) backed
+// by physical chunks (hipMemCreate + hipMemMap) as its high-water mark grows; blocks are cut from it first-fit and go back to a free list --
+// never to the driver -- until the arena is empty and nobody pins it.  call_pregraph pins its devices for the whole command, so the command's
+// physical memory is created once, on the way up, and released once, at its end.
+//
+// arena_malloc / arena_free have hipMalloc's / hipFree's contract (current device; arena_free waits for the device like hipFree does, so a block
+// is never handed out again under a kernel that still uses it).  A GPU or driver without the virtual-memory calls, or SOAPDENOVO2_AMD_ARENA=0,
+// makes both plain hipMalloc / hipFree.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace pg {
+
+hipError_t arena_malloc(void** p, size_t bytes);
+template <typename T> inline hipError_t arena_malloc(T** p, size_t bytes) { return arena_malloc((void**)p, bytes); }
+hipError_t arena_free(void* p);
+
+// the arena of `device` keeps its physical memory while it is pinned, even when nothing is allocated from it
+void arena_pin(int device);
+void arena_unpin(int device);            // (the last unpin of an empty arena releases its physical memory)
+
+// hipMemGetInfo of the current device, with what the arena holds mapped but has not handed out counted as free (it is, to this library)
+hipError_t arena_mem_info(size_t* free_bytes, size_t* total_bytes);
+
+struct ArenaStats {
+    int active;                          // 1 = the virtual-memory arena, 0 = plain hipMalloc / hipFree
+    uint64_t reserved, mapped, in_use, peak_in_use;
+    uint64_t n_malloc, n_free, n_chunks_created;
+    double map_seconds;                  // spent creating + mapping physical chunks (the driver's clearing shows up here, once)
+};
+ArenaStats arena_stats(int device);
+
+struct ArenaPin {                        // RAII for call_pregraph
+    int device;
+    explicit ArenaPin(int d) : device(d) { arena_pin(d); }
+    ~ArenaPin() { arena_unpin(device); }
+    ArenaPin(const ArenaPin&) = delete;
+    ArenaPin& operator=(const ArenaPin&) = delete;
+};
+
+}  // namespace pg

@@ -11,6 +11,7 @@
 #include <vector>
 
 #include "backend.hpp"
+#include "arena.hpp"
 #include "../../include/soapdenovo2_amd.h"
 
 namespace pg {
@@ -89,11 +90,11 @@ struct HipBackend {
     template <typename T> T* alloc_at(int pl, size_t n) {
         void* p = nullptr;
         (void)hipSetDevice(dev_at(pl));
-        const bool good = ok(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)), "hipMalloc (at a place)");
+        const bool good = ok(pg::arena_malloc(&p, std::max<size_t>(n, 1) * sizeof(T)), "hipMalloc (at a place)");
         (void)hipSetDevice(device);
         return good ? (T*)p : nullptr;
     }
-    void release_at(int pl, void* p) { if (p) { (void)hipSetDevice(dev_at(pl)); (void)hipFree(p); (void)hipSetDevice(device); } }
+    void release_at(int pl, void* p) { if (p) { (void)hipSetDevice(dev_at(pl)); (void)pg::arena_free(p); (void)hipSetDevice(device); } }
     template <typename T> void fill_at(int pl, T* p, size_t n, T v) {
         if (!n || error) return;
         (void)hipSetDevice(dev_at(pl));
@@ -137,7 +138,7 @@ struct HipBackend {
     }
     HipBackend(const HipBackend&) = delete;
     HipBackend& operator=(const HipBackend&) = delete;
-    ~HipBackend() { if (tmp) (void)hipFree(tmp); if (pinned) (void)hipHostFree(pinned); }
+    ~HipBackend() { if (tmp) (void)pg::arena_free(tmp); if (pinned) (void)hipHostFree(pinned); }
 
     bool ok(hipError_t e, const char* what) {
         if (e == hipSuccess) return true;
@@ -147,10 +148,10 @@ struct HipBackend {
     template <typename T> T* alloc(size_t n) {
         void* p = nullptr;
         (void)hipSetDevice(device);
-        if (!ok(hipMalloc(&p, std::max<size_t>(n, 1) * sizeof(T)), "hipMalloc")) return nullptr;
+        if (!ok(pg::arena_malloc(&p, std::max<size_t>(n, 1) * sizeof(T)), "hipMalloc")) return nullptr;
         return (T*)p;
     }
-    void release(void* p) { if (p) (void)hipFree(p); }
+    void release(void* p) { if (p) (void)pg::arena_free(p); }
     template <typename T> void fill(T* p, size_t n, T v) {
         if (!n || error) return;
         const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 1u << 16);
@@ -184,9 +185,9 @@ struct HipBackend {
     }
     bool scratch(size_t bytes) {
         if (bytes <= tmp_bytes) return true;
-        if (tmp) (void)hipFree(tmp);
+        if (tmp) (void)pg::arena_free(tmp);
         tmp = nullptr; tmp_bytes = 0;
-        if (!ok(hipMalloc(&tmp, bytes), "hipMalloc (scratch)")) return false;
+        if (!ok(pg::arena_malloc(&tmp, bytes), "hipMalloc (scratch)")) return false;
         tmp_bytes = bytes;
         return true;
     }

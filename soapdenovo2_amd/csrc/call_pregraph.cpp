@@ -20,11 +20,13 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <memory>
 #include <vector>
 
 #include <hip/hip_runtime_api.h>
 
 #include "host_graph.hpp"
+#include "arena.hpp"
 #include "env.hpp"
 #include "host_reads.hpp"
 #include "../../include/soapdenovo2_amd.h"
@@ -208,7 +210,7 @@ struct DevKept {
     DevKept& operator=(const DevKept&) = delete;
     ~DevKept() { clear(); }
     void clear() {
-        for (void* c : chunks) (void)hipFree(c);
+        for (void* c : chunks) (void)pg::arena_free(c);
         chunks.clear(); segs.clear(); used_in_last = 0; total_bytes = 0; len = 0;
     }
     void swap(DevKept& o) { chunks.swap(o.chunks); segs.swap(o.segs); std::swap(used_in_last, o.used_in_last); std::swap(total_bytes, o.total_bytes); std::swap(len, o.len); std::swap(device, o.device); }
@@ -217,7 +219,7 @@ struct DevKept {
         if (n_words > CHUNK_WORDS) return nullptr;
         if (chunks.empty() || used_in_last + n_words > CHUNK_WORDS) {
             void* c = nullptr;
-            if (hipMalloc(&c, CHUNK_WORDS * sizeof(uint64_t)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+            if (pg::arena_malloc(&c, CHUNK_WORDS * sizeof(uint64_t)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
             chunks.push_back(c);
             used_in_last = 0;
         }
@@ -424,9 +426,9 @@ public:
         step("pass 1's stream");
         for (int i = 0; i < 2; i++) {
             Dev& d = dev_[i];
-            HIP_OK(hipMalloc((void**)&d.d_words, (max_words_ + 8) * sizeof(uint64_t)));
-            HIP_OK(hipMalloc((void**)&d.d_off, max_reads_ * sizeof(uint64_t)));
-            HIP_OK(hipMalloc((void**)&d.d_base, (max_reads_ + 1) * sizeof(uint64_t)));
+            HIP_OK(pg::arena_malloc((void**)&d.d_words, (max_words_ + 8) * sizeof(uint64_t)));
+            HIP_OK(pg::arena_malloc((void**)&d.d_off, max_reads_ * sizeof(uint64_t)));
+            HIP_OK(pg::arena_malloc((void**)&d.d_base, (max_reads_ + 1) * sizeof(uint64_t)));
             HIP_OK(hipEventCreateWithFlags(&d.done, hipEventDisableTiming));
             d.busy = false;
             step("a batch's device buffers (96 MiB) + event");
@@ -435,7 +437,7 @@ public:
     ~Pass1() override {
         for (int i = 0; i < 2; i++) {
             Dev& d = dev_[i];
-            hipFree(d.d_words); hipFree(d.d_off); hipFree(d.d_base);
+            pg::arena_free(d.d_words); pg::arena_free(d.d_off); pg::arena_free(d.d_base);
             hipEventDestroy(d.done);
         }
         hipStreamDestroy(stream_);
@@ -545,9 +547,9 @@ private:
         hipStream_t st;
         HIP_OK(hipStreamCreate(&st));
         uint64_t *d_words, *d_off, *d_base;
-        HIP_OK(hipMalloc((void**)&d_words, (max_words_ + 8) * sizeof(uint64_t)));
-        HIP_OK(hipMalloc((void**)&d_off, max_reads_ * sizeof(uint64_t)));
-        HIP_OK(hipMalloc((void**)&d_base, (max_reads_ + 1) * sizeof(uint64_t)));
+        HIP_OK(pg::arena_malloc((void**)&d_words, (max_words_ + 8) * sizeof(uint64_t)));
+        HIP_OK(pg::arena_malloc((void**)&d_off, max_reads_ * sizeof(uint64_t)));
+        HIP_OK(pg::arena_malloc((void**)&d_base, (max_reads_ + 1) * sizeof(uint64_t)));
         for (uint64_t round = 1;; round++) {
             int set = -1;
             {
@@ -575,7 +577,7 @@ private:
                 if (++done_in_round_ == n_) { done_in_round_ = 0; rounds_done_++; cv_.notify_all(); }
             }
         }
-        hipFree(d_words); hipFree(d_off); hipFree(d_base);
+        pg::arena_free(d_words); pg::arena_free(d_off); pg::arena_free(d_base);
         hipStreamDestroy(st);
     }
     int n_;
@@ -634,6 +636,18 @@ int run(int argc, char** argv, bool mer127) {
         if (!devices.empty()) device = devices[0];
     }
     const int n_ranks = devices.size() > 1 ? (int)devices.size() : 1;
+    // After pass 1 a reference k-mer set lives whole on one GPU (set s on rank s mod N: the layout and the scans are per set), so
+    // -p is also the number of GPUs the graph stages can use: with fewer sets than ranks the other ranks only help in pass 1 and pass 2's threading.
+    if (n_ranks > 1 && o.sets < n_ranks)
+        fprintf(stderr, "warning: -p %d gives %d k-mer set(s) for %d GPU ranks: %d rank(s) will hold no set after pass 1 (use -p >= %d, or a multiple of it, to spread the graph stages).\n",
+                o.sets, o.sets, n_ranks, n_ranks - o.sets, n_ranks);
+    // every device of the command keeps its arena's physical memory until the command ends (csrc/arena.hpp)
+    std::vector<std::unique_ptr<pg::ArenaPin>> arena_pins;
+    {
+        std::vector<int> seen;
+        for (int d : n_ranks > 1 ? devices : std::vector<int>{device})
+            if (std::find(seen.begin(), seen.end(), d) == seen.end()) { seen.push_back(d); arena_pins.emplace_back(new pg::ArenaPin(d)); }
+    }
     // how much is coming: bases ~ half the bytes of a FASTQ file, all of a FASTA file (x4 behind gzip)
     uint64_t est_kmers = 0;
     for (const pg::InputFile& f : files)
@@ -657,7 +671,7 @@ int run(int argc, char** argv, bool mer127) {
     {
         size_t free_b = 0, total_b = 0;
         HIP_OK(hipSetDevice(device));
-        HIP_OK(hipMemGetInfo(&free_b, &total_b));
+        HIP_OK(pg::arena_mem_info(&free_b, &total_b));
         const double rec_bytes = (mer127 ? 6 : 4) * 8.0;
         while (log2_slots < 34 && (double)((uint64_t)1 << log2_slots) * 0.7 < (double)est_kmers / 6.0 &&
                (double)((uint64_t)2 << log2_slots) * 0.7 * rec_bytes <= (double)total_b / 3.0)
@@ -678,7 +692,7 @@ int run(int argc, char** argv, bool mer127) {
         const char* e1 = pg::env_user("SOAPDENOVO2_AMD_EDGES");
         const bool host_side = (e2 && !strcmp(e2, "host")) || (e1 && !strcmp(e1, "host"));
         size_t free_b = 0, total_b = 0;
-        if (!o.reps && !host_side && !pg::env_test("SOAPDENOVO2_AMD_KEEP_ON_HOST") && keep_budget > 0 && hipMemGetInfo(&free_b, &total_b) == hipSuccess)
+        if (!o.reps && !host_side && !pg::env_test("SOAPDENOVO2_AMD_KEEP_ON_HOST") && keep_budget > 0 && pg::arena_mem_info(&free_b, &total_b) == hipSuccess)
             dev_keep_budget = total_b / 8;
     }
     long long n_records = 0;
@@ -757,12 +771,12 @@ int run(int argc, char** argv, bool mer127) {
                     if (ok && pg_set_counts(ctxs[r], h + 256, nullptr) != PG_OK) { ok = false; fail("pg_set_counts"); }
                     if (!ok) memset(h, 0, sizeof h);
                     // the collectives below are entered by every rank, failed or not
-                    if (hipSetDevice(devices[r]) != hipSuccess || hipMalloc((void**)&d_h, sizeof h) != hipSuccess ||
+                    if (hipSetDevice(devices[r]) != hipSuccess || pg::arena_malloc((void**)&d_h, sizeof h) != hipSuccess ||
                         hipMemcpy(d_h, h, sizeof h, hipMemcpyHostToDevice) != hipSuccess) { fprintf(stderr, "rank %d: no device memory\n", r); exit(-1); }
                     if (pg_exchange_allreduce_u64(comms[r], d_h, 512, nullptr) != PG_OK && ok) { ok = false; fail("pg_exchange_allreduce_u64"); }
                     HIP_OK(hipMemcpy(h, d_h, sizeof h, hipMemcpyDeviceToHost));
                     if (r == 0) { memcpy(hist, h, 256 * sizeof(uint64_t)); for (int sidx = 0; sidx < o.sets; sidx++) sh_per_set[sidx] = h[256 + sidx]; }
-                    hipFree(d_h);
+                    pg::arena_free(d_h);
                     // every rank sees the same totals, so all of them take the same decision about the last put
                     if (ok && pg_host_last_put_matters(h + 256, o.sets, o.a_gb, mer127 ? 1 : 0) && pg_last_put(ctxs[r], last[r].data(), nullptr) != PG_OK) { ok = false; fail("pg_last_put"); }
                     uint64_t* d_mine = nullptr;
@@ -933,7 +947,7 @@ int run(int argc, char** argv, bool mer127) {
             uint64_t got = 0;
             if (engine_used == 2) { if (pg_export_take_ws(ctx, &d_rec, &got, &d_ws, &ws_bytes) != PG_OK) die("pg_export_take"); }
             else {
-                HIP_OK(hipMalloc((void**)&d_rec, (size_t)n_distinct * rw * sizeof(uint64_t)));
+                HIP_OK(pg::arena_malloc((void**)&d_rec, (size_t)n_distinct * rw * sizeof(uint64_t)));
                 if (pg_export(ctx, d_rec, n_distinct, &got, nullptr) != PG_OK) die("pg_export");
             }
             if (got != n_distinct) { fprintf(stderr, "export count mismatch\n"); exit(-1); }
@@ -954,7 +968,7 @@ int run(int argc, char** argv, bool mer127) {
         } else {
             records.alloc((size_t)n_distinct * rw + 1);
             HIP_OK(hipMemcpy(records.data(), d_rec, (size_t)n_distinct * rw * sizeof(uint64_t), hipMemcpyDeviceToHost));
-            hipFree(d_rec);
+            pg::arena_free(d_rec);
             d_rec = nullptr;
         }
     }
@@ -963,7 +977,7 @@ int run(int argc, char** argv, bool mer127) {
     // seconds); when the records go to the host it goes now -- the host replay gives the driver the time
     bool ws_offered = false;
     if (d_ws && stream_records && pg_device_scratch_offer(device, d_ws, ws_bytes) == PG_OK) ws_offered = true;
-    else if (d_ws) { (void)hipFree(d_ws); d_ws = nullptr; }
+    else if (d_ws) { (void)pg::arena_free(d_ws); d_ws = nullptr; }
     lap("export + download records");
 
     // ---- tips + edges (removeSingleTips / removeMinorTips / kmer2edges), graph kept for pass 2
@@ -986,17 +1000,17 @@ int run(int argc, char** argv, bool mer127) {
         : pg_graph_begin(records.data(), n_distinct, set_last.data(), K, mer127 ? 1 : 0, o.sets, o.delow == 0, o.a_gb,
                          max_read_len, 0, o.prefix.c_str(), host_edges ? -1 : device);
     (void)pg_host_edge_file_in_background(0);                         // (the decision was taken while the edges were built; other callers in this process keep the default)
-    if (ws_offered) { if (void* back = pg_device_scratch_withdraw(device)) (void)hipFree(back); d_ws = nullptr; }
-    if (d_rec) { hipFree(d_rec); d_rec = nullptr; }
+    if (ws_offered) { if (void* back = pg_device_scratch_withdraw(device)) (void)pg::arena_free(back); d_ws = nullptr; }
+    if (d_rec) { pg::arena_free(d_rec); d_rec = nullptr; }
     for (int r = 0; r < (int)sh_rec.size(); r++) {
         (void)hipSetDevice(devices[r]);
         // the pool: offered and still there -> ours to release; offered and gone -> a layout laid its k-mer sets out in it and the
         // graph owns it now (the records in its tail are done with either way)
-        if (sh_offered[r]) { if (void* back = pg_device_scratch_withdraw(devices[r])) hipFree(back); }
-        else if (sh_ws[r]) hipFree(sh_ws[r]);
-        if (sh_rec[r] && !sh_in_ws[r]) hipFree(sh_rec[r]);
+        if (sh_offered[r]) { if (void* back = pg_device_scratch_withdraw(devices[r])) pg::arena_free(back); }
+        else if (sh_ws[r]) pg::arena_free(sh_ws[r]);
+        if (sh_rec[r] && !sh_in_ws[r]) pg::arena_free(sh_rec[r]);
         sh_rec[r] = nullptr;
-        if (sh_mine[r]) hipFree(sh_mine[r]);
+        if (sh_mine[r]) pg::arena_free(sh_mine[r]);
     }
     (void)hipSetDevice(device);
     if (!graph) die("pg_host_graph_begin");

@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "device_ctx.hpp"
+#include "arena.hpp"
 #include "env.hpp"
 #include "../../include/soapdenovo2_amd.h"
 
@@ -163,8 +164,8 @@ namespace {
 
 int comm_alloc_small(pg_comm* c) {
     X_TRY(hipSetDevice(c->device));
-    X_TRY(hipMalloc((void**)&c->d_counts, sizeof(uint64_t) * (size_t)c->n));
-    X_TRY(hipMalloc((void**)&c->d_rcounts, sizeof(uint64_t) * (size_t)c->n));
+    X_TRY(pg::arena_malloc((void**)&c->d_counts, sizeof(uint64_t) * (size_t)c->n));
+    X_TRY(pg::arena_malloc((void**)&c->d_rcounts, sizeof(uint64_t) * (size_t)c->n));
     c->h_counts.assign(c->n, 0);
     c->h_rcounts.assign(c->n, 0);
     return PG_OK;
@@ -353,13 +354,13 @@ extern "C" void pg_comm_destroy(pg_comm* c) {
     (void)hipSetDevice(c->device);
     if (c->nccl) g_rccl.CommDestroy(c->nccl);
     for (void* p : {(void*)c->d_send_recs, (void*)c->d_send_parts, (void*)c->d_counts, (void*)c->d_rcounts, (void*)c->d_recv_recs, (void*)c->d_recv_parts})
-        if (p) (void)hipFree(p);
+        if (p) (void)pg::arena_free(p);
     if (c->xstream) (void)hipStreamSynchronize(c->xstream);
     if (c->pipe_ctx && c->pipe_ctx->pending_user == c) { c->pipe_ctx->pending_drain = nullptr; c->pipe_ctx->pending_detach = nullptr; c->pipe_ctx->pending_user = nullptr; }
     pipe_free(c);
     for (auto& sl : c->slot) for (hipEvent_t e : {sl.routed, sl.exchanged, sl.t0, sl.t1}) if (e) (void)hipEventDestroy(e);
-    if (c->d_pairs) (void)hipFree(c->d_pairs);
-    if (c->d_rpairs) (void)hipFree(c->d_rpairs);
+    if (c->d_pairs) (void)pg::arena_free(c->d_pairs);
+    if (c->d_rpairs) (void)pg::arena_free(c->d_rpairs);
     if (c->h_pairs) (void)hipHostFree(c->h_pairs);
     if (c->xstream) (void)hipStreamDestroy(c->xstream);
     if (c->grp) {
@@ -450,7 +451,7 @@ __global__ void pack_pairs_kernel(const uint64_t* counts, int n, uint64_t floor,
 
 void pipe_free(pg_comm* c) {
     for (auto& sl : c->slot) {
-        for (void* p : {(void*)sl.d_send_recs, (void*)sl.d_send_parts, (void*)sl.d_recv_recs, (void*)sl.d_recv_parts}) if (p) (void)hipFree(p);
+        for (void* p : {(void*)sl.d_send_recs, (void*)sl.d_send_parts, (void*)sl.d_recv_recs, (void*)sl.d_recv_parts}) if (p) (void)pg::arena_free(p);
         sl.d_send_recs = nullptr; sl.d_send_parts = nullptr; sl.d_recv_recs = nullptr; sl.d_recv_parts = nullptr;
     }
     c->pipe_cap = 0;
@@ -459,10 +460,10 @@ int pipe_alloc(pg_comm* c, uint64_t cap, int rw, FirstError& err) {
     pipe_free(c);
     const uint64_t n = (uint64_t)c->n;
     for (auto& sl : c->slot) {
-        err.hip(hipMalloc((void**)&sl.d_send_recs, cap * n * rw * 8), "hipMalloc (send region)");
-        err.hip(hipMalloc((void**)&sl.d_send_parts, cap * n * 4), "hipMalloc (send region)");
-        err.hip(hipMalloc((void**)&sl.d_recv_recs, cap * n * rw * 8), "hipMalloc (receive region)");
-        err.hip(hipMalloc((void**)&sl.d_recv_parts, cap * n * 4), "hipMalloc (receive region)");
+        err.hip(pg::arena_malloc((void**)&sl.d_send_recs, cap * n * rw * 8), "hipMalloc (send region)");
+        err.hip(pg::arena_malloc((void**)&sl.d_send_parts, cap * n * 4), "hipMalloc (send region)");
+        err.hip(pg::arena_malloc((void**)&sl.d_recv_recs, cap * n * rw * 8), "hipMalloc (receive region)");
+        err.hip(pg::arena_malloc((void**)&sl.d_recv_parts, cap * n * 4), "hipMalloc (receive region)");
     }
     if (err.rc) { pipe_free(c); return err.rc; }
     c->pipe_cap = cap; c->pipe_rw = rw;
@@ -477,8 +478,8 @@ int pipe_init(pg_comm* c, FirstError& err) {
         err.hip(hipEventCreate(&sl.t0), "hipEventCreate");
         err.hip(hipEventCreate(&sl.t1), "hipEventCreate");
     }
-    err.hip(hipMalloc((void**)&c->d_pairs, sizeof(uint64_t) * 2 * (size_t)c->n), "hipMalloc");
-    err.hip(hipMalloc((void**)&c->d_rpairs, sizeof(uint64_t) * 2 * (size_t)c->n), "hipMalloc");
+    err.hip(pg::arena_malloc((void**)&c->d_pairs, sizeof(uint64_t) * 2 * (size_t)c->n), "hipMalloc");
+    err.hip(pg::arena_malloc((void**)&c->d_rpairs, sizeof(uint64_t) * 2 * (size_t)c->n), "hipMalloc");
     err.hip(hipHostMalloc((void**)&c->h_pairs, sizeof(uint64_t) * 4 * (size_t)c->n, hipHostMallocPortable), "hipHostMalloc");
     return err.rc;
 }
@@ -780,9 +781,9 @@ extern "C" int pg_exchange_regroup_by_set_ws(pg_comm* c, uint64_t* d_records, ui
     const uint64_t send_bytes = (n_local * (uint64_t)rec_words * 8 + 255) & ~255ULL;
     const bool send_in_ws = d_workspace && out_in_workspace && send_bytes <= workspace_bytes;
     std::vector<uint64_t> scnt(n, 0), soff(n, 0), rcnt(n, 0), roff(n, 0);
-    if (!err.rc) err.hip(hipMalloc((void**)&d_cur, sizeof(unsigned long long) * (size_t)n), "hipMalloc");
+    if (!err.rc) err.hip(pg::arena_malloc((void**)&d_cur, sizeof(unsigned long long) * (size_t)n), "hipMalloc");
     if (send_in_ws) d_send = (uint64_t*)d_workspace;
-    else if (!err.rc && n_local) err.hip(hipMalloc((void**)&d_send, n_local * (uint64_t)rec_words * 8), "hipMalloc (regroup send buffer)");
+    else if (!err.rc && n_local) err.hip(pg::arena_malloc((void**)&d_send, n_local * (uint64_t)rec_words * 8), "hipMalloc (regroup send buffer)");
     if (!err.rc) {
         err.hip(hipMemsetAsync(c->d_counts, 0, sizeof(uint64_t) * (size_t)n, st), "memset");
         if (n_local) hipLaunchKernelGGL(rg_count, dim3((unsigned)std::min<uint64_t>((n_local + 255) / 256, 4096)), dim3(256), 0, st, d_records, n_local, rec_words, n,
@@ -798,7 +799,7 @@ extern "C" int pg_exchange_regroup_by_set_ws(pg_comm* c, uint64_t* d_records, ui
         err.hip(hipGetLastError(), "rg_scatter");
         err.hip(hipStreamSynchronize(st), "sync");
     }
-    if (d_records && !(d_workspace && out_in_workspace)) (void)hipFree(d_records);   // the caller's array has been regrouped into d_send: halve the peak
+    if (d_records && !(d_workspace && out_in_workspace)) (void)pg::arena_free(d_records);   // the caller's array has been regrouped into d_send: halve the peak
     if (err.rc) (void)hipMemsetAsync(c->d_counts, 0, sizeof(uint64_t) * (size_t)n, st);
     {   // counts (zeros from a rank that failed)
         const int rc = alltoall_words(c, c->d_counts, c->d_rcounts, 1, st);
@@ -817,7 +818,7 @@ extern "C" int pg_exchange_regroup_by_set_ws(pg_comm* c, uint64_t* d_records, ui
             if (off >= send_bytes) { out = (uint64_t*)((char*)d_workspace + off); out_in_ws = true; }
         }
     }
-    if (!err.rc && total && !out) err.hip(hipMalloc((void**)&out, total * (uint64_t)rec_words * 8), "hipMalloc (regrouped records)");
+    if (!err.rc && total && !out) err.hip(pg::arena_malloc((void**)&out, total * (uint64_t)rec_words * 8), "hipMalloc (regrouped records)");
     uint64_t verdict = 0;
     {
         const int arc = agree_max(c, err.rc ? 1 : 0, &verdict, st);
@@ -830,9 +831,9 @@ extern "C" int pg_exchange_regroup_by_set_ws(pg_comm* c, uint64_t* d_records, ui
         if (rc) err.set(rc, pg_last_error());
         err.hip(hipStreamSynchronize(st), "sync");
     } else err.set(PG_ENODEV, "pg_exchange_regroup_by_set: another rank failed");
-    if (d_send && !send_in_ws) (void)hipFree(d_send);
-    if (d_cur) (void)hipFree(d_cur);
-    if (err.rc) { if (out && !out_in_ws) (void)hipFree(out); return err.done(); }
+    if (d_send && !send_in_ws) (void)pg::arena_free(d_send);
+    if (d_cur) (void)pg::arena_free(d_cur);
+    if (err.rc) { if (out && !out_in_ws) (void)pg::arena_free(out); return err.done(); }
     *d_out = out; *n_out = total;
     if (out_in_workspace) *out_in_workspace = out_in_ws ? 1 : 0;
     c->regrouped_in = total; c->regrouped_from = n_local;
@@ -867,7 +868,7 @@ extern "C" int pg_exchange_gather_records(pg_comm* c, const uint64_t* d_records,
             // a root without room still has to take what is sent to it: it receives into nothing only if nothing is sent, so
             // on error it drains into a scratch allocation
             uint64_t* sink = d_out;
-            if (is_root && err) { X_TRY(hipMalloc((void**)&sink, std::max<uint64_t>(off[c->n], 1) * (uint64_t)rec_words * 8)); }
+            if (is_root && err) { X_TRY(pg::arena_malloc((void**)&sink, std::max<uint64_t>(off[c->n], 1) * (uint64_t)rec_words * 8)); }
             N_TRY(g_rccl.GroupStart());
             if (!is_root && n_local) N_TRY(g_rccl.Send(d_records, n_local * (uint64_t)rec_words, ncclUint64, root, c->nccl, st));
             if (is_root)
@@ -875,7 +876,7 @@ extern "C" int pg_exchange_gather_records(pg_comm* c, const uint64_t* d_records,
                     if (q != root && c->h_rcounts[q]) N_TRY(g_rccl.Recv(sink + off[q] * rec_words, c->h_rcounts[q] * (uint64_t)rec_words, ncclUint64, q, c->nccl, st));
             N_TRY(g_rccl.GroupEnd());
             X_TRY(hipStreamSynchronize(st));
-            if (sink != d_out) (void)hipFree(sink);
+            if (sink != d_out) (void)pg::arena_free(sink);
         }
         return err;
     }

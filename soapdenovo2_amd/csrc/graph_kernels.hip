@@ -30,6 +30,7 @@
 #include <vector>
 
 #include "../../include/soapdenovo2_amd.h"
+#include "arena.hpp"
 #include "env.hpp"
 #include "device_ctx.hpp"
 #include "extract.hpp"
@@ -845,23 +846,23 @@ struct P2Device {
 namespace { void forget_taken(void* ptr); }       // (the offered-block bookkeeping further down)
 static void p2_free(P2Device* d) {
     if (!d) return;
-    for (auto& o : d->owned) { forget_taken(o.second); (void)hipSetDevice(o.first); (void)hipFree(o.second); }
+    for (auto& o : d->owned) { forget_taken(o.second); (void)hipSetDevice(o.first); (void)pg::arena_free(o.second); }
     for (size_t l = 0; l < d->lanes.size(); l++) {
         P2Lane& ln = d->lanes[l];
         (void)hipSetDevice(ln.device);
-        if (ln.own_geo) hipFree(ln.d_geo3);
-        if (ln.own_patch) { hipFree(ln.d_patch_keys); hipFree(ln.d_patch_val); }
-        hipFree(ln.d_arc_key); hipFree(ln.d_arc_cnt); hipFree(ln.d_arc_first);
-        if (l) hipFree(ln.d_counters);
-        hipFree(ln.d_marker);
-        hipFree(ln.d_words); hipFree(ln.d_off); hipFree(ln.d_lens); hipFree(ln.d_stage); hipFree(ln.d_walk_len);
+        if (ln.own_geo) pg::arena_free(ln.d_geo3);
+        if (ln.own_patch) { pg::arena_free(ln.d_patch_keys); pg::arena_free(ln.d_patch_val); }
+        pg::arena_free(ln.d_arc_key); pg::arena_free(ln.d_arc_cnt); pg::arena_free(ln.d_arc_first);
+        if (l) pg::arena_free(ln.d_counters);
+        pg::arena_free(ln.d_marker);
+        pg::arena_free(ln.d_words); pg::arena_free(ln.d_off); pg::arena_free(ln.d_lens); pg::arena_free(ln.d_stage); pg::arena_free(ln.d_walk_len);
         if (ln.copied) (void)hipEventDestroy(ln.copied);
         if (l && ln.stream) (void)hipStreamDestroy(ln.stream);
     }
     hipSetDevice(d->device);
-    hipFree(d->d_patch_keys); hipFree(d->d_patch_val);
-    hipFree(d->d_counters);
-    hipFree(d->d_geo3); hipFree(d->d_crc); hipFree(d->d_vlist);
+    pg::arena_free(d->d_patch_keys); pg::arena_free(d->d_patch_val);
+    pg::arena_free(d->d_counters);
+    pg::arena_free(d->d_geo3); pg::arena_free(d->d_crc); pg::arena_free(d->d_vlist);
     if (d->stream) hipStreamDestroy(d->stream);
     delete d;
 }
@@ -889,15 +890,15 @@ static int p2_finish_open(P2Device* d) {
         }
     }
     d->n_slots = first;
-    P2_HIP(hipMalloc((void**)&d->d_geo3, words.size() * sizeof(uint64_t)));
+    P2_HIP(pg::arena_malloc((void**)&d->d_geo3, words.size() * sizeof(uint64_t)));
     P2_HIP(hipMemcpy(d->d_geo3, words.data(), words.size() * sizeof(uint64_t), hipMemcpyHostToDevice));
-    P2_HIP(hipMalloc((void**)&d->d_crc, 256 * sizeof(uint32_t)));
+    P2_HIP(pg::arena_malloc((void**)&d->d_crc, 256 * sizeof(uint32_t)));
     {
         uint32_t tab[256];
         for (uint32_t i = 0; i < 256; i++) tab[i] = crc32_table_entry(i);
         P2_HIP(hipMemcpy(d->d_crc, tab, sizeof tab, hipMemcpyHostToDevice));
     }
-    P2_HIP(hipMalloc((void**)&d->d_counters, 8 * sizeof(unsigned long long)));
+    P2_HIP(pg::arena_malloc((void**)&d->d_counters, 8 * sizeof(unsigned long long)));
     P2_HIP(hipMemsetAsync(d->d_counters, 0, 8 * sizeof(unsigned long long), d->stream));
     P2_HIP(hipStreamSynchronize(d->stream));
     P2Params& p = d->prm;
@@ -963,10 +964,10 @@ static int p2_open_impl(P2Device* d, const P2Sets& sets, const int* set_device) 
         for (int s = 0; s < d->P; s++) if (d->set_dev[s] == dev) total += sets.size[s];
         uint64_t* base = nullptr;
         hipStream_t st = nullptr;
-        if (hipSetDevice(dev) != hipSuccess || hipMalloc((void**)&base, std::max<uint64_t>(total, 1) * NW1 * sizeof(uint64_t)) != hipSuccess ||
+        if (hipSetDevice(dev) != hipSuccess || pg::arena_malloc((void**)&base, std::max<uint64_t>(total, 1) * NW1 * sizeof(uint64_t)) != hipSuccess ||
             hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) {
             pg_set_error("out of device memory for the k-mer sets (" + std::to_string(total * NW1 * 8 >> 20) + " MiB on device " + std::to_string(dev) + ")");
-            if (base) (void)hipFree(base);
+            if (base) (void)pg::arena_free(base);
             rc = PG_ENOMEM;
             break;
         }
@@ -1071,7 +1072,7 @@ int p2_layout_rank(int device, int nw, int n_own, const uint64_t* d_records, con
     uint64_t* nodes = nullptr;
     void* block = take_offered(device, total * NW1 * sizeof(uint64_t));        // memory pass 1 is done with, if it was offered and is large enough
     if (block) nodes = (uint64_t*)(((uintptr_t)block + 255) & ~(uintptr_t)255);
-    else if (hipMalloc((void**)&nodes, total * NW1 * sizeof(uint64_t)) != hipSuccess) {
+    else if (pg::arena_malloc((void**)&nodes, total * NW1 * sizeof(uint64_t)) != hipSuccess) {
         (void)hipStreamDestroy(st);
         pg_set_error("layout: out of device memory for the k-mer sets (" + std::to_string(total * NW1 * 8 >> 20) + " MiB on device " + std::to_string(device) + ")");
         return PG_ENOMEM;
@@ -1089,7 +1090,7 @@ int p2_layout_rank(int device, int nw, int n_own, const uint64_t* d_records, con
     if (rc == PG_OK && hipStreamSynchronize(st) != hipSuccess) { rc = PG_ENODEV; why = "kernel failure"; }
     (void)hipStreamDestroy(st);
     if (rc) {
-        if (block) hand_back_offered(block); else (void)hipFree(nodes);            // only what was allocated here is freed here
+        if (block) hand_back_offered(block); else (void)pg::arena_free(nodes);            // only what was allocated here is freed here
         if (rc < 0) pg_set_error("layout: " + (why.empty() ? std::string("failed") : why));
         return rc;
     }
@@ -1125,7 +1126,7 @@ int p2_layout_rank_growable(int device, int nw, int n_own, const uint64_t* d_rec
     uint64_t* nodes = nullptr;
     void* block = take_offered(device, total * NW1 * sizeof(uint64_t));
     if (block) nodes = (uint64_t*)(((uintptr_t)block + 255) & ~(uintptr_t)255);
-    else if (hipMalloc((void**)&nodes, total * NW1 * sizeof(uint64_t)) != hipSuccess) {
+    else if (pg::arena_malloc((void**)&nodes, total * NW1 * sizeof(uint64_t)) != hipSuccess) {
         (void)hipStreamDestroy(st);
         pg_set_error("layout: out of device memory for the k-mer sets (" + std::to_string(total * NW1 * 8 >> 20) + " MiB on device " + std::to_string(device) + ")");
         return PG_ENOMEM;
@@ -1148,7 +1149,7 @@ int p2_layout_rank_growable(int device, int nw, int n_own, const uint64_t* d_rec
         const uint64_t one = growable_scratch_bytes(n_max, owner_max);
         // (two: 1.15 s -> 1.0 s at 60 M reads; eight bought another 0.05 s for four times the scratch -- and a fresh process pays for its
         //  allocations by the gigabyte)
-        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess) lanes = (int)std::min<uint64_t>(2, (uint64_t)((double)free_b * 0.85) / std::max<uint64_t>(one, 1));
+        if (pg::arena_mem_info(&free_b, &total_b) == hipSuccess) lanes = (int)std::min<uint64_t>(2, (uint64_t)((double)free_b * 0.85) / std::max<uint64_t>(one, 1));
         if (const char* v = pg::env_measure("SOAPDENOVO2_AMD_LAYOUT_LANES")) lanes = atoi(v);
         lanes = std::max(1, std::min(lanes, n_own));
     }
@@ -1177,7 +1178,7 @@ int p2_layout_rank_growable(int device, int nw, int n_own, const uint64_t* d_rec
     }
     (void)hipStreamDestroy(st);
     if (rc) {
-        if (block) hand_back_offered(block); else (void)hipFree(nodes);            // only what was allocated here is freed here
+        if (block) hand_back_offered(block); else (void)pg::arena_free(nodes);            // only what was allocated here is freed here
         if (rc == PG_ENOMEM) {                                            // no room for the scratch beside the image: the sequential host replay needs none
             fprintf(stderr, "growable sets on device %d: out of device memory for the layout's scratch; replaying on the host\n", device);
             return K6_UNSUITED;
@@ -1271,7 +1272,7 @@ int p2_fetch_words(int device, const uint64_t* d_src, uint64_t n_words, uint64_t
     return hipStreamSynchronize(st) == hipSuccess ? PG_OK : PG_ENODEV;
 }
 
-void pg_device_free_on(int device, void* d_ptr) { if (d_ptr) { (void)hipSetDevice(device); (void)hipFree(d_ptr); } }
+void pg_device_free_on(int device, void* d_ptr) { if (d_ptr) { (void)hipSetDevice(device); (void)pg::arena_free(d_ptr); } }
 // a layout's allocation that is not going to be used after all: back on offer if it was taken over from a caller, freed otherwise
 void pg_device_release_layout(int device, void* d_ptr) { if (d_ptr && !hand_back_offered(d_ptr)) pg_device_free_on(device, d_ptr); }
 
@@ -1279,10 +1280,10 @@ void pg_device_release_layout(int device, void* d_ptr) { if (d_ptr && !hand_back
 int p2_set_patch(P2Device* d, const uint64_t* patch_keys, const uint32_t* patch_val, uint64_t patch_cap) {
     if ((patch_cap & (patch_cap - 1)) || !patch_cap) { pg_set_error("pass 2: patch table size must be a power of two"); return PG_EINVAL; }
     P2_HIP(hipSetDevice(d->device));
-    hipFree(d->d_patch_keys); hipFree(d->d_patch_val);
+    pg::arena_free(d->d_patch_keys); pg::arena_free(d->d_patch_val);
     d->d_patch_keys = nullptr; d->d_patch_val = nullptr;
-    P2_HIP(hipMalloc((void**)&d->d_patch_keys, patch_cap * d->nw * sizeof(uint64_t)));
-    P2_HIP(hipMalloc((void**)&d->d_patch_val, patch_cap * 2 * sizeof(uint32_t)));
+    P2_HIP(pg::arena_malloc((void**)&d->d_patch_keys, patch_cap * d->nw * sizeof(uint64_t)));
+    P2_HIP(pg::arena_malloc((void**)&d->d_patch_val, patch_cap * 2 * sizeof(uint32_t)));
     P2_HIP(hipMemcpy(d->d_patch_keys, patch_keys, patch_cap * d->nw * sizeof(uint64_t), hipMemcpyHostToDevice));
     P2_HIP(hipMemcpy(d->d_patch_val, patch_val, patch_cap * 2 * sizeof(uint32_t), hipMemcpyHostToDevice));
     d->prm.patch_keys = d->d_patch_keys; d->prm.patch_val = d->d_patch_val; d->prm.patch_mask = patch_cap - 1;
@@ -1305,25 +1306,25 @@ int p2_begin_reads(P2Device* d, uint32_t num_ed, bool reps) {
         ln.prm = d->prm;
         if (ln.device != d->device) {
             const size_t gb = (size_t)SV_GEO * d->P * sizeof(uint64_t), kb = patch_cap * d->nw * sizeof(uint64_t), vb = patch_cap * 2 * sizeof(uint32_t);
-            P2_HIP(hipMalloc((void**)&ln.d_geo3, gb)); ln.own_geo = true;
-            P2_HIP(hipMalloc((void**)&ln.d_patch_keys, kb)); ln.own_patch = true;
-            P2_HIP(hipMalloc((void**)&ln.d_patch_val, vb));
+            P2_HIP(pg::arena_malloc((void**)&ln.d_geo3, gb)); ln.own_geo = true;
+            P2_HIP(pg::arena_malloc((void**)&ln.d_patch_keys, kb)); ln.own_patch = true;
+            P2_HIP(pg::arena_malloc((void**)&ln.d_patch_val, vb));
             P2_HIP(hipMemcpyPeerAsync(ln.d_geo3, ln.device, d->d_geo3, d->device, gb, ln.stream));
             P2_HIP(hipMemcpyPeerAsync(ln.d_patch_keys, ln.device, d->d_patch_keys, d->device, kb, ln.stream));
             P2_HIP(hipMemcpyPeerAsync(ln.d_patch_val, ln.device, d->d_patch_val, d->device, vb, ln.stream));
             ln.prm.geo3 = ln.d_geo3; ln.prm.patch_keys = ln.d_patch_keys; ln.prm.patch_val = ln.d_patch_val;
         }
         if (l == 0) ln.d_counters = d->d_counters;
-        else P2_HIP(hipMalloc((void**)&ln.d_counters, 8 * sizeof(unsigned long long)));
-        P2_HIP(hipMalloc((void**)&ln.d_arc_key, arc_cap * sizeof(unsigned long long)));
-        P2_HIP(hipMalloc((void**)&ln.d_arc_cnt, arc_cap * sizeof(unsigned int)));
-        P2_HIP(hipMalloc((void**)&ln.d_arc_first, arc_cap * sizeof(unsigned long long)));
+        else P2_HIP(pg::arena_malloc((void**)&ln.d_counters, 8 * sizeof(unsigned long long)));
+        P2_HIP(pg::arena_malloc((void**)&ln.d_arc_key, arc_cap * sizeof(unsigned long long)));
+        P2_HIP(pg::arena_malloc((void**)&ln.d_arc_cnt, arc_cap * sizeof(unsigned int)));
+        P2_HIP(pg::arena_malloc((void**)&ln.d_arc_first, arc_cap * sizeof(unsigned long long)));
         P2_HIP(hipMemsetAsync(ln.d_arc_key, 0, arc_cap * sizeof(unsigned long long), ln.stream));
         P2_HIP(hipMemsetAsync(ln.d_arc_cnt, 0, arc_cap * sizeof(unsigned int), ln.stream));
         hipLaunchKernelGGL(p2_fill_u64, dim3(1024), dim3(256), 0, ln.stream, ln.d_arc_first, arc_cap, ~0ULL);
         P2_HIP(hipMemsetAsync(ln.d_counters, 0, 8 * sizeof(unsigned long long), ln.stream));
         if (d->reps) {
-            P2_HIP(hipMalloc((void**)&ln.d_marker, ((size_t)d->num_ed + 1) * sizeof(unsigned int)));
+            P2_HIP(pg::arena_malloc((void**)&ln.d_marker, ((size_t)d->num_ed + 1) * sizeof(unsigned int)));
             P2_HIP(hipMemsetAsync(ln.d_marker, 0, ((size_t)d->num_ed + 1) * sizeof(unsigned int), ln.stream));
         }
         P2_HIP(hipEventCreateWithFlags(&ln.copied, hipEventDisableTiming));
@@ -1369,10 +1370,10 @@ int p2_tip_walks(P2Device* d, int cut_len, bool thin, std::vector<P2TipWalk>& ou
     out.clear();
     if (hipSetDevice(d->device) != hipSuccess) { pg_set_error("tips: hipSetDevice failed"); return PG_ENODEV; }
     for (int si = 0; si < d->P; si++) if (d->set_sizes[si] / 256 >= 0x7FFFFFFFULL) { pg_set_error("tips: too many slots for one launch"); return PG_EINVAL; }
-    P2_HIP_GOTO(hipMalloc((void**)&d_cnt, 2 * sizeof(unsigned long long)));
+    P2_HIP_GOTO(pg::arena_malloc((void**)&d_cnt, 2 * sizeof(unsigned long long)));
     for (int attempt = 0; attempt < 2; attempt++) {
-        hipFree(d_w); d_w = nullptr;
-        P2_HIP_GOTO(hipMalloc((void**)&d_w, cap * sizeof(P2TipWalk)));
+        pg::arena_free(d_w); d_w = nullptr;
+        P2_HIP_GOTO(pg::arena_malloc((void**)&d_w, cap * sizeof(P2TipWalk)));
         P2_HIP_GOTO(hipMemsetAsync(d_cnt, 0, 2 * sizeof(unsigned long long), st));
         for (int si = 0; si < d->P; si++) {
             if (!d->set_sizes[si]) continue;
@@ -1391,14 +1392,14 @@ int p2_tip_walks(P2Device* d, int cut_len, bool thin, std::vector<P2TipWalk>& ou
     if (cnt[0] >= 0x7FFFFFFFULL) { pg_set_error("tips: more than 2^31 - 1 dead ends"); rc = PG_EINVAL; goto done; }
     if (cnt[0]) {
         const uint64_t n = cnt[0];
-        P2_HIP_GOTO(hipMalloc((void**)&d_key, n * sizeof(unsigned long long)));
-        P2_HIP_GOTO(hipMalloc((void**)&d_key2, n * sizeof(unsigned long long)));
-        P2_HIP_GOTO(hipMalloc((void**)&d_idx, n * sizeof(uint32_t)));
-        P2_HIP_GOTO(hipMalloc((void**)&d_order, n * sizeof(uint32_t)));
-        P2_HIP_GOTO(hipMalloc((void**)&d_sorted, n * sizeof(P2TipWalk)));
+        P2_HIP_GOTO(pg::arena_malloc((void**)&d_key, n * sizeof(unsigned long long)));
+        P2_HIP_GOTO(pg::arena_malloc((void**)&d_key2, n * sizeof(unsigned long long)));
+        P2_HIP_GOTO(pg::arena_malloc((void**)&d_idx, n * sizeof(uint32_t)));
+        P2_HIP_GOTO(pg::arena_malloc((void**)&d_order, n * sizeof(uint32_t)));
+        P2_HIP_GOTO(pg::arena_malloc((void**)&d_sorted, n * sizeof(P2TipWalk)));
         hipLaunchKernelGGL(tip_keys, dim3(1024), dim3(256), 0, st, d_w, n, d_key, d_idx);
         P2_HIP_GOTO((rocprim::radix_sort_pairs<rocprim::default_config, unsigned long long*, unsigned long long*, uint32_t*, uint32_t*, size_t>(nullptr, tmp_bytes, d_key, d_key2, d_idx, d_order, (size_t)n, 0u, 64u, st)));
-        P2_HIP_GOTO(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
+        P2_HIP_GOTO(pg::arena_malloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
         P2_HIP_GOTO((rocprim::radix_sort_pairs<rocprim::default_config, unsigned long long*, unsigned long long*, uint32_t*, uint32_t*, size_t>(d_tmp, tmp_bytes, d_key, d_key2, d_idx, d_order, (size_t)n, 0u, 64u, st)));
         hipLaunchKernelGGL(tip_gather, dim3(1024), dim3(256), 0, st, d_w, d_order, n, d_sorted);
         out.resize(n);
@@ -1406,7 +1407,7 @@ int p2_tip_walks(P2Device* d, int cut_len, bool thin, std::vector<P2TipWalk>& ou
         P2_HIP_GOTO(hipStreamSynchronize(st));
     }
 done:
-    hipFree(d_w); hipFree(d_sorted); hipFree(d_cnt); hipFree(d_key); hipFree(d_key2); hipFree(d_idx); hipFree(d_order); hipFree(d_tmp);
+    pg::arena_free(d_w); pg::arena_free(d_sorted); pg::arena_free(d_cnt); pg::arena_free(d_key); pg::arena_free(d_key2); pg::arena_free(d_idx); pg::arena_free(d_order); pg::arena_free(d_tmp);
     return rc;
 }
 
@@ -1414,14 +1415,14 @@ int p2_mirror_nodes(P2Device* d, const uint64_t* slots, const uint64_t* ab, uint
     if (!n) return PG_OK;
     P2_HIP(hipSetDevice(d->device));
     uint64_t *d_s = nullptr, *d_ab = nullptr;
-    P2_HIP(hipMalloc((void**)&d_s, n * sizeof(uint64_t)));
-    P2_HIP(hipMalloc((void**)&d_ab, n * sizeof(uint64_t)));
+    P2_HIP(pg::arena_malloc((void**)&d_s, n * sizeof(uint64_t)));
+    P2_HIP(pg::arena_malloc((void**)&d_ab, n * sizeof(uint64_t)));
     P2_HIP(hipMemcpyAsync(d_s, slots, n * sizeof(uint64_t), hipMemcpyHostToDevice, d->stream));
     P2_HIP(hipMemcpyAsync(d_ab, ab, n * sizeof(uint64_t), hipMemcpyHostToDevice, d->stream));
     if (d->nw == 2) hipLaunchKernelGGL(tip_mirror<2>, dim3(1024), dim3(256), 0, d->stream, d->prm, d_s, d_ab, n);
     else hipLaunchKernelGGL(tip_mirror<4>, dim3(1024), dim3(256), 0, d->stream, d->prm, d_s, d_ab, n);
     P2_HIP(hipStreamSynchronize(d->stream));
-    hipFree(d_s); hipFree(d_ab);
+    pg::arena_free(d_s); pg::arena_free(d_ab);
     return PG_OK;
 }
 
@@ -1496,8 +1497,8 @@ static int p2_list_branch_nodes(P2Device* d, unsigned long long** d_list_out, un
             if (l_done[l] || !l_slots[l]) { l_done[l] = 1; continue; }
             P2Lane& ln = d->lanes[l];
             P2_HIP_GOTO(hipSetDevice(ln.device));
-            if (!l_cnt[l]) P2_HIP_GOTO(hipMalloc((void**)&l_cnt[l], sizeof(unsigned long long)));
-            P2_HIP_GOTO(hipMalloc((void**)&l_list[l], l_cap[l] * sizeof(unsigned long long)));
+            if (!l_cnt[l]) P2_HIP_GOTO(pg::arena_malloc((void**)&l_cnt[l], sizeof(unsigned long long)));
+            P2_HIP_GOTO(pg::arena_malloc((void**)&l_list[l], l_cap[l] * sizeof(unsigned long long)));
             P2_HIP_GOTO(hipMemsetAsync(l_cnt[l], 0, sizeof(unsigned long long), ln.stream));
             for (int si = 0; si < d->P; si++)
                 if (d->set_lane[si] == l && d->set_sizes[si]) {
@@ -1514,7 +1515,7 @@ static int p2_list_branch_nodes(P2Device* d, unsigned long long** d_list_out, un
             P2_HIP_GOTO(hipMemcpyAsync(&l_n[l], l_cnt[l], sizeof(unsigned long long), hipMemcpyDeviceToHost, ln.stream));
             P2_HIP_GOTO(hipStreamSynchronize(ln.stream));
             if (l_n[l] <= l_cap[l]) { l_done[l] = 1; continue; }
-            hipFree(l_list[l]); l_list[l] = nullptr;
+            pg::arena_free(l_list[l]); l_list[l] = nullptr;
             l_cap[l] = l_n[l]; l_n[l] = 0;
             again = true;
         }
@@ -1523,7 +1524,7 @@ static int p2_list_branch_nodes(P2Device* d, unsigned long long** d_list_out, un
     for (int l = 0; l < NL; l++) total += l_n[l];
     P2_HIP_GOTO(hipSetDevice(d->device));
     if (total) {
-        P2_HIP_GOTO(hipMalloc((void**)&d_list, total * sizeof(unsigned long long)));
+        P2_HIP_GOTO(pg::arena_malloc((void**)&d_list, total * sizeof(unsigned long long)));
         for (int l = 0; l < NL; l++) {
             if (!l_n[l]) continue;
             P2_HIP_GOTO(hipMemcpyAsync(d_list + at, l_list[l], l_n[l] * sizeof(unsigned long long), hipMemcpyDefault, d->stream));
@@ -1534,9 +1535,9 @@ static int p2_list_branch_nodes(P2Device* d, unsigned long long** d_list_out, un
     *d_list_out = d_list; d_list = nullptr;
     *n_out = total;
 done:
-    for (int l = 0; l < NL; l++) { (void)hipSetDevice(d->lanes[l].device); hipFree(l_list[l]); hipFree(l_cnt[l]); }
+    for (int l = 0; l < NL; l++) { (void)hipSetDevice(d->lanes[l].device); pg::arena_free(l_list[l]); pg::arena_free(l_cnt[l]); }
     (void)hipSetDevice(d->device);
-    hipFree(d_list);
+    pg::arena_free(d_list);
     return rc;
 }
 
@@ -1555,22 +1556,22 @@ int p2_list_vertices(P2Device* d, std::vector<uint64_t>& keys) {
     if (rc) goto done;
     if (n) {
         while (bits < 64 && (d->n_slots >> bits)) bits++;
-        P2_HIP_GOTO(hipMalloc((void**)&d_sorted, n * sizeof(unsigned long long)));
-        P2_HIP_GOTO(hipMalloc((void**)&d_keys, n * d->nw * sizeof(uint64_t)));
+        P2_HIP_GOTO(pg::arena_malloc((void**)&d_sorted, n * sizeof(unsigned long long)));
+        P2_HIP_GOTO(pg::arena_malloc((void**)&d_keys, n * d->nw * sizeof(uint64_t)));
         P2_HIP_GOTO((rocprim::radix_sort_keys<rocprim::default_config, unsigned long long*, unsigned long long*, size_t>(nullptr, tmp_bytes, d_list, d_sorted, (size_t)n, 0u, (unsigned)bits, st)));
-        P2_HIP_GOTO(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
+        P2_HIP_GOTO(pg::arena_malloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
         P2_HIP_GOTO((rocprim::radix_sort_keys<rocprim::default_config, unsigned long long*, unsigned long long*, size_t>(d_tmp, tmp_bytes, d_list, d_sorted, (size_t)n, 0u, (unsigned)bits, st)));
         if (d->nw == 2) hipLaunchKernelGGL(vx_gather<2>, dim3(4096), dim3(256), 0, st, d->prm, d_sorted, (uint64_t)n, d_keys);
         else hipLaunchKernelGGL(vx_gather<4>, dim3(4096), dim3(256), 0, st, d->prm, d_sorted, (uint64_t)n, d_keys);
         keys.resize((size_t)n * d->nw);
         P2_HIP_GOTO(hipMemcpyAsync(keys.data(), d_keys, keys.size() * sizeof(uint64_t), hipMemcpyDeviceToHost, st));
         P2_HIP_GOTO(hipStreamSynchronize(st));
-        hipFree(d->d_vlist);
+        pg::arena_free(d->d_vlist);
         d->d_vlist = d_sorted; d->n_vlist = n;                     // the edges are built from these very nodes: no second scan of the sets
         d_sorted = nullptr;
     }
 done:
-    hipFree(d_list); hipFree(d_sorted); hipFree(d_cnt); hipFree(d_keys); hipFree(d_tmp);
+    pg::arena_free(d_list); pg::arena_free(d_sorted); pg::arena_free(d_cnt); pg::arena_free(d_keys); pg::arena_free(d_tmp);
     return rc;
 }
 
@@ -1594,7 +1595,7 @@ int p2_build_edges(P2Device* d, P2Edges& out) {
     unsigned long long *d_way = nullptr, *d_wcnt = nullptr;
     unsigned long long total_ids = 0, total_bases = 0, last_ids = 0, last_bases = 0, last_idb = 0, last_bb = 0;
     if (hipSetDevice(d->device) != hipSuccess) { pg_set_error("edges: hipSetDevice failed"); return PG_ENODEV; }
-    P2_HIP_GOTO(hipMalloc((void**)&d_cnt, 4 * sizeof(unsigned long long)));
+    P2_HIP_GOTO(pg::arena_malloc((void**)&d_cnt, 4 * sizeof(unsigned long long)));
     P2_HIP_GOTO(hipMemsetAsync(d_cnt, 0, 4 * sizeof(unsigned long long), st));
     if (d->d_vlist) {                                            // listed for <prefix>.vertex a moment ago (nothing changed a flag since)
         d_list = d->d_vlist; d->d_vlist = nullptr;
@@ -1615,16 +1616,16 @@ int p2_build_edges(P2Device* d, P2Edges& out) {
         if (period) {
             way.period_mask = period - 1;
             unsigned long long n_w = 0;
-            P2_HIP_GOTO(hipMalloc((void**)&d_wcnt, sizeof(unsigned long long)));
+            P2_HIP_GOTO(pg::arena_malloc((void**)&d_wcnt, sizeof(unsigned long long)));
             for (unsigned long long cap_w = d->n_slots / period * 2 + 65536;;) {
-                P2_HIP_GOTO(hipMalloc((void**)&d_way, cap_w * sizeof(unsigned long long)));
+                P2_HIP_GOTO(pg::arena_malloc((void**)&d_way, cap_w * sizeof(unsigned long long)));
                 P2_HIP_GOTO(hipMemsetAsync(d_wcnt, 0, sizeof(unsigned long long), st));
                 for (int si = 0; si < d->P; si++)
                     if (d->set_sizes[si]) hipLaunchKernelGGL(eb_list_branch, dim3(4096), dim3(256), 0, st, d->set_ptr[si], d->nw + 1, d->set_sizes[si], d->set_first[si], d_way, d_wcnt, cap_w, 1, way.period_mask);
                 P2_HIP_GOTO(hipMemcpyAsync(&n_w, d_wcnt, sizeof n_w, hipMemcpyDeviceToHost, st));
                 P2_HIP_GOTO(hipStreamSynchronize(st));
                 if (n_w <= cap_w) break;
-                hipFree(d_way); d_way = nullptr;
+                pg::arena_free(d_way); d_way = nullptr;
                 cap_w = n_w;
             }
             n_way = n_w;
@@ -1632,12 +1633,12 @@ int p2_build_edges(P2Device* d, P2Edges& out) {
                 uint64_t cap_m = 1024;
                 while (cap_m < 2 * n_way) cap_m <<= 1;
                 way.mask = cap_m - 1;
-                P2_HIP_GOTO(hipMalloc((void**)&way.key, cap_m * sizeof(unsigned long long)));
-                P2_HIP_GOTO(hipMalloc((void**)&way.seg_end, 2 * cap_m * sizeof(unsigned long long)));
-                P2_HIP_GOTO(hipMalloc((void**)&way.seg_info, 2 * cap_m * sizeof(unsigned long long)));
-                P2_HIP_GOTO(hipMalloc((void**)&way.seg_sum, 2 * cap_m * sizeof(unsigned long long)));
-                P2_HIP_GOTO(hipMalloc((void**)&way.vis_own, 2 * cap_m * sizeof(unsigned long long)));
-                P2_HIP_GOTO(hipMalloc((void**)&way.vis_info, 2 * cap_m * sizeof(unsigned int)));
+                P2_HIP_GOTO(pg::arena_malloc((void**)&way.key, cap_m * sizeof(unsigned long long)));
+                P2_HIP_GOTO(pg::arena_malloc((void**)&way.seg_end, 2 * cap_m * sizeof(unsigned long long)));
+                P2_HIP_GOTO(pg::arena_malloc((void**)&way.seg_info, 2 * cap_m * sizeof(unsigned long long)));
+                P2_HIP_GOTO(pg::arena_malloc((void**)&way.seg_sum, 2 * cap_m * sizeof(unsigned long long)));
+                P2_HIP_GOTO(pg::arena_malloc((void**)&way.vis_own, 2 * cap_m * sizeof(unsigned long long)));
+                P2_HIP_GOTO(pg::arena_malloc((void**)&way.vis_info, 2 * cap_m * sizeof(unsigned int)));
                 P2_HIP_GOTO(hipMemsetAsync(way.key, 0, cap_m * sizeof(unsigned long long), st));
                 hipLaunchKernelGGL(eb_way_insert, dim3(1024), dim3(256), 0, st, way, d_way, n_way);
                 const dim3 grid((unsigned)((2 * n_way + 255) / 256));
@@ -1652,8 +1653,8 @@ int p2_build_edges(P2Device* d, P2Edges& out) {
     if (n_list * 8 / 256 >= 0x7FFFFFFFULL) { pg_set_error("edges: too many vertices for one launch"); rc = PG_EINVAL; goto done; }
     for (int attempt = 0; attempt < 2; attempt++) {
         cap_rec = n_list * (attempt ? 8 : 5) + 1024;
-        hipFree(d_recs); d_recs = nullptr;
-        P2_HIP_GOTO(hipMalloc((void**)&d_recs, cap_rec * sizeof(EdgeRec)));
+        pg::arena_free(d_recs); d_recs = nullptr;
+        P2_HIP_GOTO(pg::arena_malloc((void**)&d_recs, cap_rec * sizeof(EdgeRec)));
         P2_HIP_GOTO(hipMemsetAsync(d_cnt + 1, 0, 2 * sizeof(unsigned long long), st));      // (the error counter stays: the segment walks may have used it)
         if (way.key) P2_HIP_GOTO(hipMemsetAsync(way.vis_own, 0xFF, 2 * (way.mask + 1) * sizeof(unsigned long long), st));
         if (n_list) {
@@ -1671,29 +1672,29 @@ int p2_build_edges(P2Device* d, P2Edges& out) {
     if (n_rec > cap_rec) { pg_set_error("edges: more walks than arcs"); rc = PG_EINVAL; goto done; }
     if (n_rec >= 0x7FFFFFFFULL) { pg_set_error("edges: more than 2^31 - 1 edge records"); rc = PG_EINVAL; goto done; }
     while (patch_cap < 2 * cnt[2] + 2) patch_cap <<= 1;
-    hipFree(d->d_patch_keys); hipFree(d->d_patch_val);
+    pg::arena_free(d->d_patch_keys); pg::arena_free(d->d_patch_val);
     d->d_patch_keys = nullptr; d->d_patch_val = nullptr;
-    P2_HIP_GOTO(hipMalloc((void**)&d->d_patch_keys, patch_cap * d->nw * sizeof(uint64_t)));
-    P2_HIP_GOTO(hipMalloc((void**)&d->d_patch_val, patch_cap * 2 * sizeof(uint32_t)));
+    P2_HIP_GOTO(pg::arena_malloc((void**)&d->d_patch_keys, patch_cap * d->nw * sizeof(uint64_t)));
+    P2_HIP_GOTO(pg::arena_malloc((void**)&d->d_patch_val, patch_cap * 2 * sizeof(uint32_t)));
     P2_HIP_GOTO(hipMemsetAsync(d->d_patch_keys, 0, patch_cap * d->nw * sizeof(uint64_t), st));
     P2_HIP_GOTO(hipMemsetAsync(d->d_patch_val, 0, patch_cap * 2 * sizeof(uint32_t), st));
     d->prm.patch_keys = d->d_patch_keys; d->prm.patch_val = d->d_patch_val; d->prm.patch_mask = patch_cap - 1;
     out.recs.clear(); out.text.clear();
     out.n_ids = 0; out.n_len1 = (long long)cnt[2];
     if (n_rec) {
-        P2_HIP_GOTO(hipMalloc((void**)&d_key, n_rec * sizeof(unsigned long long)));
-        P2_HIP_GOTO(hipMalloc((void**)&d_key2, n_rec * sizeof(unsigned long long)));
-        P2_HIP_GOTO(hipMalloc((void**)&d_idx, n_rec * sizeof(uint32_t)));
-        P2_HIP_GOTO(hipMalloc((void**)&d_order, n_rec * sizeof(uint32_t)));
-        P2_HIP_GOTO(hipMalloc((void**)&d_ids, n_rec * sizeof(unsigned long long)));
-        P2_HIP_GOTO(hipMalloc((void**)&d_bases, n_rec * sizeof(unsigned long long)));
-        P2_HIP_GOTO(hipMalloc((void**)&d_id_before, n_rec * sizeof(unsigned long long)));
-        P2_HIP_GOTO(hipMalloc((void**)&d_base_before, n_rec * sizeof(unsigned long long)));
+        P2_HIP_GOTO(pg::arena_malloc((void**)&d_key, n_rec * sizeof(unsigned long long)));
+        P2_HIP_GOTO(pg::arena_malloc((void**)&d_key2, n_rec * sizeof(unsigned long long)));
+        P2_HIP_GOTO(pg::arena_malloc((void**)&d_idx, n_rec * sizeof(uint32_t)));
+        P2_HIP_GOTO(pg::arena_malloc((void**)&d_order, n_rec * sizeof(uint32_t)));
+        P2_HIP_GOTO(pg::arena_malloc((void**)&d_ids, n_rec * sizeof(unsigned long long)));
+        P2_HIP_GOTO(pg::arena_malloc((void**)&d_bases, n_rec * sizeof(unsigned long long)));
+        P2_HIP_GOTO(pg::arena_malloc((void**)&d_id_before, n_rec * sizeof(unsigned long long)));
+        P2_HIP_GOTO(pg::arena_malloc((void**)&d_base_before, n_rec * sizeof(unsigned long long)));
         hipLaunchKernelGGL(eb_keys, dim3(2048), dim3(256), 0, st, d_recs, n_rec, d_key, d_idx);
         P2_HIP_GOTO((rocprim::radix_sort_pairs<rocprim::default_config, unsigned long long*, unsigned long long*, uint32_t*, uint32_t*, size_t>(nullptr, tmp_bytes, d_key, d_key2, d_idx, d_order, (size_t)n_rec, 0u, 64u, st)));
         P2_HIP_GOTO((rocprim::exclusive_scan<rocprim::default_config, unsigned long long*, unsigned long long*, unsigned long long, rocprim::plus<unsigned long long>>(nullptr, tmp2, d_ids, d_id_before, 0ULL, (size_t)n_rec, rocprim::plus<unsigned long long>(), st)));
         tmp_bytes = std::max(tmp_bytes, tmp2);
-        P2_HIP_GOTO(hipMalloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
+        P2_HIP_GOTO(pg::arena_malloc(&d_tmp, tmp_bytes ? tmp_bytes : 1));
         P2_HIP_GOTO((rocprim::radix_sort_pairs<rocprim::default_config, unsigned long long*, unsigned long long*, uint32_t*, uint32_t*, size_t>(d_tmp, tmp_bytes, d_key, d_key2, d_idx, d_order, (size_t)n_rec, 0u, 64u, st)));
         hipLaunchKernelGGL(eb_sizes, dim3(2048), dim3(256), 0, st, d_recs, d_order, n_rec, d_ids, d_bases);
         P2_HIP_GOTO((rocprim::exclusive_scan<rocprim::default_config, unsigned long long*, unsigned long long*, unsigned long long, rocprim::plus<unsigned long long>>(d_tmp, tmp_bytes, d_ids, d_id_before, 0ULL, (size_t)n_rec, rocprim::plus<unsigned long long>(), st)));
@@ -1706,7 +1707,7 @@ int p2_build_edges(P2Device* d, P2Edges& out) {
         total_ids = last_idb + last_ids;
         total_bases = last_bb + last_bases;
         if (total_ids >= 0xFFFFFFFFULL) { pg_set_error("edges: edge ids exceed 32 bits"); rc = PG_EINVAL; goto done; }
-        P2_HIP_GOTO(hipMalloc((void**)&d_text, std::max<unsigned long long>(total_bases, 1)));
+        P2_HIP_GOTO(pg::arena_malloc((void**)&d_text, std::max<unsigned long long>(total_bases, 1)));
         {
             const dim3 grid((unsigned)((n_rec + 255) / 256));
             if (d->nw == 2) hipLaunchKernelGGL(eb_apply<2>, grid, dim3(256), 0, st, d->prm, d_recs, d_order, n_rec, d_id_before, d_base_before, d_text,
@@ -1724,7 +1725,7 @@ int p2_build_edges(P2Device* d, P2Edges& out) {
         // what the host needs for the text records: the walks in slot order with their text offsets, and the bases
         {
             P2EdgeRec* d_out = nullptr;
-            P2_HIP_GOTO(hipMalloc((void**)&d_out, n_rec * sizeof(P2EdgeRec)));
+            P2_HIP_GOTO(pg::arena_malloc((void**)&d_out, n_rec * sizeof(P2EdgeRec)));
             d_export = d_out;
             hipLaunchKernelGGL(eb_export, dim3(2048), dim3(256), 0, st, d_recs, d_order, d_base_before, n_rec, d_out);
             out.recs.resize(n_rec);
@@ -1738,9 +1739,9 @@ int p2_build_edges(P2Device* d, P2Edges& out) {
     }
     out.n_ids = (long long)total_ids;
 done:
-    hipFree(d_list); hipFree(d_cnt); hipFree(d_key); hipFree(d_key2); hipFree(d_ids); hipFree(d_bases); hipFree(d_id_before); hipFree(d_base_before);
-    hipFree(d_idx); hipFree(d_order); hipFree(d_recs); hipFree(d_export); hipFree(d_text); hipFree(d_tmp);
-    hipFree(d_way); hipFree(d_wcnt); hipFree(way.key); hipFree(way.seg_end); hipFree(way.seg_info); hipFree(way.seg_sum); hipFree(way.vis_own); hipFree(way.vis_info);
+    pg::arena_free(d_list); pg::arena_free(d_cnt); pg::arena_free(d_key); pg::arena_free(d_key2); pg::arena_free(d_ids); pg::arena_free(d_bases); pg::arena_free(d_id_before); pg::arena_free(d_base_before);
+    pg::arena_free(d_idx); pg::arena_free(d_order); pg::arena_free(d_recs); pg::arena_free(d_export); pg::arena_free(d_text); pg::arena_free(d_tmp);
+    pg::arena_free(d_way); pg::arena_free(d_wcnt); pg::arena_free(way.key); pg::arena_free(way.seg_end); pg::arena_free(way.seg_info); pg::arena_free(way.seg_sum); pg::arena_free(way.vis_own); pg::arena_free(way.vis_info);
     if (pg::env_user("PG_HOST_VERBOSE") && n_way) fprintf(stderr, "edges: %llu waypoint(s) (about every %u-th linear node): chains walked by jumps\n", (unsigned long long)n_way, way.period_mask + 1);
     return rc;
 }
@@ -1757,21 +1758,21 @@ int p2_add_packed(P2Device* d, const uint64_t* words, const uint64_t* word_off, 
     P2_HIP(hipSetDevice(ln.device));
     if (n_words + 8 > ln.cap_words || n_reads > ln.cap_reads || (d->reps && n_reads > ln.cap_stage_reads)) P2_HIP(hipStreamSynchronize(ln.stream));   // nobody reads the buffers that go
     if (n_words + 8 > ln.cap_words) {
-        hipFree(ln.d_words);
+        pg::arena_free(ln.d_words);
         ln.cap_words = (n_words + 8) * 5 / 4;
-        P2_HIP(hipMalloc((void**)&ln.d_words, ln.cap_words * sizeof(uint64_t)));
+        P2_HIP(pg::arena_malloc((void**)&ln.d_words, ln.cap_words * sizeof(uint64_t)));
     }
     if (n_reads > ln.cap_reads) {
-        hipFree(ln.d_off); hipFree(ln.d_lens);
+        pg::arena_free(ln.d_off); pg::arena_free(ln.d_lens);
         ln.cap_reads = n_reads * 5 / 4;
-        P2_HIP(hipMalloc((void**)&ln.d_off, ln.cap_reads * sizeof(uint64_t)));
-        P2_HIP(hipMalloc((void**)&ln.d_lens, ln.cap_reads * sizeof(int32_t)));
+        P2_HIP(pg::arena_malloc((void**)&ln.d_off, ln.cap_reads * sizeof(uint64_t)));
+        P2_HIP(pg::arena_malloc((void**)&ln.d_lens, ln.cap_reads * sizeof(int32_t)));
     }
     if (d->reps && n_reads > ln.cap_stage_reads) {
-        hipFree(ln.d_stage); hipFree(ln.d_walk_len);
+        pg::arena_free(ln.d_stage); pg::arena_free(ln.d_walk_len);
         ln.cap_stage_reads = n_reads;
-        P2_HIP(hipMalloc((void**)&ln.d_stage, ln.cap_stage_reads * (size_t)d->max_nk * sizeof(uint32_t)));
-        P2_HIP(hipMalloc((void**)&ln.d_walk_len, ln.cap_stage_reads * sizeof(uint16_t)));
+        P2_HIP(pg::arena_malloc((void**)&ln.d_stage, ln.cap_stage_reads * (size_t)d->max_nk * sizeof(uint32_t)));
+        P2_HIP(pg::arena_malloc((void**)&ln.d_walk_len, ln.cap_stage_reads * sizeof(uint16_t)));
     }
     // (the copies are ordered behind the lane's previous batch by its stream: that batch read the same buffers)
     P2_HIP(hipMemcpyAsync(ln.d_words, words, n_words * sizeof(uint64_t), hipMemcpyHostToDevice, ln.stream));
@@ -1863,14 +1864,14 @@ int p2_finish(P2Device* d, P2Result& out) {
         const size_t n_l = (size_t)lane_arcs[l];
         if (n_l) {
             P2Arc* d_arcs = nullptr;
-            P2_HIP(hipMalloc((void**)&d_arcs, n_l * sizeof(P2Arc)));
+            P2_HIP(pg::arena_malloc((void**)&d_arcs, n_l * sizeof(P2Arc)));
             P2_HIP(hipMemsetAsync(ln.d_counters + 6, 0, sizeof(unsigned long long), ln.stream));
             hipLaunchKernelGGL(p2_compact_arcs, dim3(2048), dim3(256), 0, ln.stream, ln.d_arc_key, ln.d_arc_cnt, ln.d_arc_first, cap, d_arcs, ln.d_counters + 6, (unsigned long long)n_l);
             P2_HIP(hipMemcpyAsync(out.arcs.data() + at, d_arcs, n_l * sizeof(P2Arc), hipMemcpyDeviceToHost, ln.stream));
             unsigned long long got = 0;
             P2_HIP(hipMemcpyAsync(&got, ln.d_counters + 6, sizeof(got), hipMemcpyDeviceToHost, ln.stream));
             P2_HIP(hipStreamSynchronize(ln.stream));
-            hipFree(d_arcs);
+            pg::arena_free(d_arcs);
             if (got != n_l) { pg_set_error("pass 2: pre-arc table is inconsistent"); return PG_EINVAL; }
             at += n_l;
         }

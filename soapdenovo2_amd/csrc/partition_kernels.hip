@@ -30,6 +30,7 @@
 #include <chrono>
 
 #include "device_ctx.hpp"
+#include "arena.hpp"
 #include "env.hpp"
 #include "extract.hpp"
 #include "occ32.hpp"
@@ -1097,12 +1098,12 @@ int e2_create(pg_ctx* c) {
         q = std::min(q, 8);
         if (const char* v = env_measure("PG_DIRECT_CHUNKS")) { const int e = atoi(v); if (e >= 0) q = std::min(e, 192); }
         size_t free_b0 = 0, total_b0 = 0;
-        if (hipMemGetInfo(&free_b0, &total_b0) == hipSuccess)
+        if (pg::arena_mem_info(&free_b0, &total_b0) == hipSuccess)
             while (q > 0 && (uint64_t)q * parts * chunk_bytes > total_b0 / 4) q--;
         s.direct = (uint32_t)std::max(0, q);
     }
     size_t free_b = 0, total_b = 0;
-    E2_TRY(hipMemGetInfo(&free_b, &total_b));
+    E2_TRY(pg::arena_mem_info(&free_b, &total_b));
     // export array: what a set of 2^log2_slots slots would hold at 70 % load
     s.out_capacity = (uint64_t)(0.7 * (double)((uint64_t)1 << c->log2_slots));
     const uint64_t out_bytes = s.out_capacity * (uint64_t)(c->NW + 2) * 8;
@@ -1132,13 +1133,13 @@ int e2_create(pg_ctx* c) {
         t_last = t;
     };
     step("geometry, hipMemGetInfo", 0.0);
-    E2_TRY(hipMalloc(&s.cursor, parts * sizeof(uint32_t)));
-    E2_TRY(hipMalloc(&s.chunk_tbl, parts * s.maxc * sizeof(uint32_t)));
+    E2_TRY(pg::arena_malloc(&s.cursor, parts * sizeof(uint32_t)));
+    E2_TRY(pg::arena_malloc(&s.chunk_tbl, parts * s.maxc * sizeof(uint32_t)));
     step("hipMalloc: cursors + chunk table", (double)(parts * (s.maxc + 1) * sizeof(uint32_t)) / 1e9);
-    E2_TRY(hipMalloc(&s.pool, s.pool_chunks * chunk_bytes + 64));
+    E2_TRY(pg::arena_malloc(&s.pool, s.pool_chunks * chunk_bytes + 64));
     step("hipMalloc: record pool", (double)(s.pool_chunks * chunk_bytes) / 1e9);
     s.out = nullptr; s.out_err = 0;
-    if (env_measure("PG_EXPORT_ASYNC") && atoi(env_measure("PG_EXPORT_ASYNC")) == 0) E2_TRY(hipMalloc(&s.out, std::max<uint64_t>(out_bytes, 64)));
+    if (env_measure("PG_EXPORT_ASYNC") && atoi(env_measure("PG_EXPORT_ASYNC")) == 0) E2_TRY(pg::arena_malloc(&s.out, std::max<uint64_t>(out_bytes, 64)));
     else {
         const int dev = c->device;
         const uint64_t bytes = std::max<uint64_t>(out_bytes, 64);
@@ -1146,7 +1147,7 @@ int e2_create(pg_ctx* c) {
         s.out_thread = new std::thread([sp, dev, bytes] {
             void* p = nullptr;
             hipError_t e = hipSetDevice(dev);
-            if (e == hipSuccess) e = hipMalloc(&p, bytes);
+            if (e == hipSuccess) e = pg::arena_malloc(&p, bytes);
             sp->out = (uint64_t*)p;
             sp->out_err = (int)e;
         });
@@ -1174,10 +1175,10 @@ void e2_destroy(pg_ctx* c) {
     E2& s = c->e2;
     (void)e2_join_out(c);
     (void)hipSetDevice(c->device);
-    if (s.cursor) (void)hipFree(s.cursor);
-    if (s.chunk_tbl) (void)hipFree(s.chunk_tbl);
-    if (s.pool) (void)hipFree(s.pool);
-    if (s.out) (void)hipFree(s.out);
+    if (s.cursor) (void)pg::arena_free(s.cursor);
+    if (s.chunk_tbl) (void)pg::arena_free(s.chunk_tbl);
+    if (s.pool) (void)pg::arena_free(s.pool);
+    if (s.out) (void)pg::arena_free(s.out);
     s = E2();
 }
 
@@ -1219,9 +1220,9 @@ static int e2_ensure_pool(pg_ctx* c, uint64_t n_reads, uint64_t n_kmers, hipStre
     const uint64_t fresh_chunks = std::max(need2 * 2 - fixed, s.pool_chunks * 2 - fixed);
     if (fresh_chunks >= 0xFFFFFFF0ULL) { pg_set_error("partition engine: more than 2^32 record chunks"); return PG_ENOMEM; }
     uint64_t* fresh = nullptr;
-    E2_TRY(hipMalloc(&fresh, fresh_chunks * chunk_bytes + 64));
+    E2_TRY(pg::arena_malloc(&fresh, fresh_chunks * chunk_bytes + 64));
     E2_TRY(hipMemcpy(fresh, s.pool, std::min<uint64_t>(fixed + used, s.pool_chunks) * chunk_bytes, hipMemcpyDeviceToDevice));
-    E2_TRY(hipFree(s.pool));
+    E2_TRY(pg::arena_free(s.pool));
     s.pool = fresh;
     s.pool_chunks = fresh_chunks;
     // a longer chunk list per partition too, if the table allows (rebuild with the wider stride)
@@ -1229,10 +1230,10 @@ static int e2_ensure_pool(pg_ctx* c, uint64_t n_reads, uint64_t n_kmers, hipStre
     const uint32_t want = (uint32_t)std::max<uint64_t>(s.maxc, std::min<uint64_t>(std::min<uint64_t>(256 - s.direct, ((uint64_t)1 << 29) / parts), even * 16));
     if (want > s.maxc) {
         uint32_t* tbl = nullptr;
-        E2_TRY(hipMalloc(&tbl, parts * want * sizeof(uint32_t)));
+        E2_TRY(pg::arena_malloc(&tbl, parts * want * sizeof(uint32_t)));
         E2_TRY(hipMemset(tbl, 0, parts * want * sizeof(uint32_t)));
         E2_TRY(hipMemcpy2D(tbl, want * sizeof(uint32_t), s.chunk_tbl, s.maxc * sizeof(uint32_t), s.maxc * sizeof(uint32_t), parts, hipMemcpyDeviceToDevice));
-        E2_TRY(hipFree(s.chunk_tbl));
+        E2_TRY(pg::arena_free(s.chunk_tbl));
         s.chunk_tbl = tbl;
         s.maxc = want;
     }
@@ -1491,8 +1492,8 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
         // the streams are intact: count again into an export array that holds everything (n_export is the true count)
         const uint64_t want = h.n_export + h.n_export / 8 + 64;
         uint64_t* fresh = nullptr;
-        E2_TRY(hipMalloc(&fresh, want * (uint64_t)(c->NW + 2) * 8));
-        E2_TRY(hipFree(s.out));
+        E2_TRY(pg::arena_malloc(&fresh, want * (uint64_t)(c->NW + 2) * 8));
+        E2_TRY(pg::arena_free(s.out));
         s.out = fresh;
         s.out_capacity = want;
         unsigned long long keep = h.e2_flags & ~F_OUT;

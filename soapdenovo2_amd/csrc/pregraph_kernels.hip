@@ -30,6 +30,7 @@
 #include <algorithm>
 
 #include "kmer.hpp"
+#include "arena.hpp"
 #include "env.hpp"
 #include "extract.hpp"
 #include "device_ctx.hpp"
@@ -538,17 +539,17 @@ extern "C" pg_ctx* pg_create_sized(int device, int K, int mer127, int n_sets, in
     if (expected_kmers) { c->hint_kmers = expected_kmers; c->hint_log2_parts = parts_for_kmers(expected_kmers, c->NW); }
     if (const char* v = pg::env_measure("PG_VARIANT")) c->variant = atoi(v);
     if (engine == 2) {
-        if (hipMalloc(&c->ctr, sizeof(DevCounters)) != hipSuccess) { g_err = "pg_create: hipMalloc failed"; delete c; return nullptr; }
+        if (pg::arena_malloc(&c->ctr, sizeof(DevCounters)) != hipSuccess) { g_err = "pg_create: hipMalloc failed"; delete c; return nullptr; }
         if (trace) fprintf(stderr, "[ctx]   %-44s %7.3f s (since the call)\n", "hipSetDevice + first hipMalloc", since());
         (void)hipMemset(c->ctr, 0, sizeof(DevCounters));
-        if (e2_create(c) != PG_OK) { e2_destroy(c); (void)hipFree(c->ctr); delete c; return nullptr; }
+        if (e2_create(c) != PG_OK) { e2_destroy(c); (void)pg::arena_free(c->ctr); delete c; return nullptr; }
         (void)hipDeviceSynchronize();
         if (trace) fprintf(stderr, "[ctx]   %-44s %7.3f s (since the call)\n", "context ready", since());
         return c;
     }
     const size_t bytes = ((size_t)1 << log2_slots) * slot_bytes(c->NW);
-    if (hipMalloc(&c->slots, bytes) != hipSuccess) { g_err = "pg_create: hipMalloc of the k-mer set failed"; delete c; return nullptr; }
-    if (hipMalloc(&c->ctr, sizeof(DevCounters)) != hipSuccess) { g_err = "pg_create: hipMalloc failed"; hipFree(c->slots); delete c; return nullptr; }
+    if (pg::arena_malloc(&c->slots, bytes) != hipSuccess) { g_err = "pg_create: hipMalloc of the k-mer set failed"; delete c; return nullptr; }
+    if (pg::arena_malloc(&c->ctr, sizeof(DevCounters)) != hipSuccess) { g_err = "pg_create: hipMalloc failed"; pg::arena_free(c->slots); delete c; return nullptr; }
     hipMemset(c->slots, 0xFF, bytes);
     hipMemset(c->ctr, 0, sizeof(DevCounters));
     hipDeviceSynchronize();
@@ -610,8 +611,8 @@ extern "C" void pg_destroy(pg_ctx* c) {
     (void)pg_ctx_drain(c, nullptr);
     if (c->pending_detach) c->pending_detach(c, c->pending_user);
     if (c->engine == 2) e2_destroy(c);
-    if (c->slots) hipFree(c->slots);
-    if (c->ctr) hipFree(c->ctr);
+    if (c->slots) pg::arena_free(c->slots);
+    if (c->ctr) pg::arena_free(c->ctr);
     delete c;
 }
 
@@ -640,7 +641,7 @@ template <int NW>
 static int grow_to(pg_ctx* c, int new_log2, hipStream_t st) {
     uint64_t* fresh = nullptr;
     const size_t bytes = ((size_t)1 << new_log2) * slot_bytes(NW);
-    HIP_TRY(hipMalloc(&fresh, bytes));
+    HIP_TRY(pg::arena_malloc(&fresh, bytes));
     HIP_TRY(hipMemsetAsync(fresh, 0xFF, bytes, st));
     Table<NW> t{fresh, ((uint64_t)1 << new_log2) - 1};
     const uint64_t old_cap = (uint64_t)1 << c->log2_slots;
@@ -648,7 +649,7 @@ static int grow_to(pg_ctx* c, int new_log2, hipStream_t st) {
     hipLaunchKernelGGL(rehash_kernel<NW>, dim3(grid), dim3(BLOCK), 0, st, c->slots, old_cap, t, c->ctr);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
-    HIP_TRY(hipFree(c->slots));
+    HIP_TRY(pg::arena_free(c->slots));
     c->slots = fresh; c->log2_slots = new_log2;
     return PG_OK;
 }
@@ -668,7 +669,7 @@ static int ensure_capacity(pg_ctx* c, uint64_t incoming, hipStream_t st) {
     while ((double)(real + incoming) > LOAD * (double)((uint64_t)1 << want)) want++;
     if (want > c->log2_slots) {
         size_t free_b = 0, total_b = 0;
-        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        HIP_TRY(pg::arena_mem_info(&free_b, &total_b));
         // cannot afford the worst case: fall back to the smallest table that holds what is stored plus
         // a quarter of the batch (a batch of reads is mostly repeats); the overflow flag guards the rest
         while (want > c->log2_slots + 1 && ((size_t)1 << want) * slot_bytes(c->NW) > free_b - (free_b >> 4)) want--;
@@ -942,7 +943,14 @@ extern "C" int pg_export_peek(pg_ctx* c, const uint64_t** d_records_out, uint64_
 extern "C" int pg_export_take(pg_ctx* c, uint64_t** d_records_out, uint64_t* n_out) { return pg_export_take_ws(c, d_records_out, n_out, nullptr, nullptr); }
 
 // hipFree for callers that do not link the HIP runtime themselves (what pg_export_take hands over)
-extern "C" void pg_device_free(void* d_ptr) { if (d_ptr) (void)hipFree(d_ptr); }
+extern "C" void pg_device_free(void* d_ptr) { if (d_ptr) (void)pg::arena_free(d_ptr); }
+extern "C" void pg_device_arena_pin(int device) { pg::arena_pin(device); }
+extern "C" void pg_device_arena_unpin(int device) { pg::arena_unpin(device); }
+extern "C" void pg_device_arena_stats(int device, uint64_t out[8]) {
+    const pg::ArenaStats s = pg::arena_stats(device);
+    out[0] = (uint64_t)s.active; out[1] = s.reserved; out[2] = s.mapped; out[3] = s.in_use; out[4] = s.peak_in_use; out[5] = s.n_malloc; out[6] = s.n_chunks_created;
+    out[7] = (uint64_t)(s.map_seconds * 1e6);
+}
 
 extern "C" int pg_export(pg_ctx* c, uint64_t* d_records, uint64_t capacity, uint64_t* n_out, void* stream) {
     if (!c || !d_records || !n_out) { g_err = "null argument"; return PG_EINVAL; }

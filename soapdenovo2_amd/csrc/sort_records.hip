@@ -16,6 +16,7 @@
 #include <string>
 
 #include "../../include/soapdenovo2_amd.h"
+#include "arena.hpp"
 #include "env.hpp"
 #include "device_ctx.hpp"
 
@@ -95,7 +96,7 @@ static int sort_impl(uint64_t* d_records, uint64_t n, void* d_ws, size_t ws_byte
     const size_t key_bytes = (n * sizeof(uint64_t) + a16) & ~a16, idx_bytes = (n * sizeof(Idx) + a16) & ~a16;
     uint64_t *tag_in, *tag_out;
     Idx *idx_in, *idx_out;
-    SR_HIP(hipMalloc((void**)&d_max, sizeof(unsigned long long)));
+    SR_HIP(pg::arena_malloc((void**)&d_max, sizeof(unsigned long long)));
     SR_HIP(hipMemsetAsync(d_max, 0, sizeof(unsigned long long), stream));
     hipLaunchKernelGGL(sr_max_ord<RW>, dim3(2048), dim3(256), 0, stream, d_records, n, d_max);
     SR_HIP(hipMemcpyAsync(&h_max, d_max, sizeof h_max, hipMemcpyDeviceToHost, stream));
@@ -109,7 +110,7 @@ static int sort_impl(uint64_t* d_records, uint64_t n, void* d_ws, size_t ws_byte
     sorted_bytes = n * RW * sizeof(uint64_t);
     own_work = !d_ws || ws_bytes < work_bytes + 256;
     own_sorted = own_work || ws_bytes < work_bytes + sorted_bytes + 512;
-    if (own_work) SR_HIP(hipMalloc((void**)&work, work_bytes));
+    if (own_work) SR_HIP(pg::arena_malloc((void**)&work, work_bytes));
     else work = (unsigned char*)(((uintptr_t)d_ws + 255) & ~(uintptr_t)255);
     tag_in = (uint64_t*)work; tag_out = (uint64_t*)(work + key_bytes);
     idx_in = (Idx*)(work + 2 * key_bytes); idx_out = (Idx*)(work + 2 * key_bytes + idx_bytes);
@@ -119,7 +120,7 @@ static int sort_impl(uint64_t* d_records, uint64_t n, void* d_ws, size_t ws_byte
     SR_HIP((rocprim::radix_sort_pairs<rocprim::default_config, uint64_t*, uint64_t*, Idx*, Idx*, size_t>(
         work + 2 * key_bytes + 2 * idx_bytes, tmp_bytes, tag_in, tag_out, idx_in, idx_out, (size_t)n, 0u, (unsigned)(ord_bits + 8), stream)));
     lap("radix sort of the tags");
-    if (own_sorted) SR_HIP(hipMalloc((void**)&sorted, sorted_bytes));
+    if (own_sorted) SR_HIP(pg::arena_malloc((void**)&sorted, sorted_bytes));
     else sorted = (uint64_t*)(work + work_bytes);
     hipLaunchKernelGGL((sr_gather<RW, Idx>), dim3(8192), dim3(256), 0, stream, d_records, idx_out, n, sorted);
     SR_HIP(hipGetLastError());
@@ -127,9 +128,9 @@ static int sort_impl(uint64_t* d_records, uint64_t n, void* d_ws, size_t ws_byte
     SR_HIP(hipStreamSynchronize(stream));
     lap("gather + copy back");
 done:
-    if (own_work) (void)hipFree(work);
-    if (own_sorted) (void)hipFree(sorted);
-    (void)hipFree(d_max);
+    if (own_work) (void)pg::arena_free(work);
+    if (own_sorted) (void)pg::arena_free(sorted);
+    (void)pg::arena_free(d_max);
     lap("free");
     return rc;
 }
@@ -158,13 +159,13 @@ extern "C" int pg_records_checksum(const uint64_t* d_records, uint64_t n, int re
     hipStream_t stream = (hipStream_t)stream_v;
     int rc = PG_OK;
     unsigned long long* d = nullptr;
-    SR_HIP(hipMalloc((void**)&d, 8 * sizeof(unsigned long long)));
+    SR_HIP(pg::arena_malloc((void**)&d, 8 * sizeof(unsigned long long)));
     SR_HIP(hipMemsetAsync(d, 0, 8 * sizeof(unsigned long long), stream));
     if (n) hipLaunchKernelGGL(sr_checksum, dim3(4096), dim3(256), 0, stream, d_records, n, rec_words, d);
     SR_HIP(hipGetLastError());
     SR_HIP(hipMemcpyAsync(out, d, 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost, stream));
     SR_HIP(hipStreamSynchronize(stream));
 done:
-    (void)hipFree(d);
+    (void)pg::arena_free(d);
     return rc;
 }
