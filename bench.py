@@ -200,6 +200,12 @@ def big_command(args):
                 if m:
                     out["reader_s"] = float(m.group(1))
                 out["layout_on_device"] = "k-mer set layout on the device" in r.stderr
+                # the command's device arena (csrc/arena.hpp): how much physical memory it created, once, and how long that took
+                m = re.search(r"arena \(device \d+\): ([0-9.]+) GB of physical memory in (\d+) piece\(s\), created in ([0-9.]+)s in all; peak in use ([0-9.]+) GB; (\d+) block\(s\) cut, (\d+) given back", r.stderr)
+                if m:
+                    out["arena"] = {"physical_gb": float(m.group(1)), "create_s": float(m.group(3)), "peak_in_use_gb": float(m.group(4)), "blocks_cut": int(m.group(5)), "driver_frees_before_exit": 0}
+                if os.environ.get("PG_BENCH_KEEP_STDERR"):                # (GPU calls: the command's own account of itself, for profiles/)
+                    open(os.path.join(os.environ["PG_BENCH_KEEP_STDERR"], key + ".stderr.txt"), "w").write(r.stderr)
                 m = re.search(r"tips decided on the device: (\d+) scan\(s\), (\d+) fixed-point round\(s\), ([0-9.]+)s", r.stderr)
                 if m:
                     out["tips"] = {"scans": int(m.group(1)), "rounds": int(m.group(2)), "seconds": float(m.group(3))}

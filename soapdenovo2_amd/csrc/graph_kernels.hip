@@ -130,20 +130,87 @@ __device__ inline void add_prearc(const P2Params& p, uint32_t from, uint32_t to,
     atomicAdd(&p.counters[2], 1ULL);
 }
 
-// one lane = one read (chopKmer4read + searchKmer + parse1read + search1kmerPlus + thread_add1preArc + recordPathBin).
-// The read is taken BL k-mers at a time, in two phases.  LOOK UP: roll the BL k-mers, and for each the canonical form, its set
-// (CRC-32 sliced by four: four independent table reads a step instead of a chain of sixteen), its home slot (key mod size by
-// the set's precomputed reciprocal) -- then ask for all BL home slots at once and look at them together; the probes that did
-// not end at their home slot (linear probing, newhash.c:277-318) go round again, together.  A lane so has BL random 24 / 40-byte
-// probes of the sets in flight instead of one: the kernel waits for memory, and with one probe a lane it ran at a sixth of the
-// rate HBM serves random lines at (profiles/r03_graph_kernels_60M.csv).  THREAD: parse1read's state machine (prlRead2path.c:
-// 598-745) over the BL counter words, in read order, exactly as before.  (The reference looks every k-mer of its buffer up
-// before it threads any read, prlRead2path.c:159-248: a k-mer behind the point where the state machine gives a read up is
-// looked up there too.)
-template <int NW, int BL>
+// ---- pass 2: a lane a read (chopKmer4read + searchKmer + parse1read + search1kmerPlus + thread_add1preArc + recordPathBin) -------------
+// parse1read's state machine (prlRead2path.c:598-745) over the node words of a read's k-mers, in read order.  The two kernels that
+// run it differ only in where a node word comes from: p2_thread_kernel probes the k-mer sets itself (one GPU, or peer-mapped sets),
+// p2_thread_routed_kernel reads what the sets' owners answered (the routed form of a sharded run, further down).
+template <int NW>
+struct P2Walk {
+    unsigned retain = 0;
+    bool is_prev = false, stop = false;
+    Kmer<NW> prev_k;
+    int n_items = 0;             // items pushed since the last restart
+    int n_valid = -1;            // index of the first unresolved item (id 0), -1 while there is none
+    uint32_t last_id = 0;        // id of the latest item
+};
+// one k-mer of the read: `canon` its canonical form, `smaller` = the read spells the canonical form, `ab` = its node's two words
+template <int NW>
+__device__ __forceinline__ void p2_thread_step(const P2Params& p, P2Walk<NW>& w, const Kmer<NW>& canon, bool smaller, uint64_t ab, uint32_t* row, unsigned long long seq0) {
+    const int K = p.K;
+    const uint32_t A = (uint32_t)ab, B = (uint32_t)(ab >> 32);
+    const bool linear = B & B_LINEAR, in_edge = (B >> B_INEDGE_SHIFT) & 3;
+    if ((B & B_DELETED) || (linear && !in_edge)) {                   // deleted, or on a floating loop
+        if (w.retain < 2) { w.retain = 0; w.n_items = 0; w.n_valid = -1; }
+        else w.stop = true;
+        return;
+    }
+    uint32_t id = 0;
+    bool push = false;
+    if (linear) {
+        const uint32_t twin = (B >> B_TWIN_SHIFT) & 3;
+        id = smaller ? A : A + twin - 1;
+        if (w.retain == 0 || w.is_prev) { push = true; w.is_prev = false; }
+        else if (id != w.last_id) push = true;
+    } else {
+        const Kmer<NW> wq = smaller ? canon : kmer_rc<NW>(canon, K);    // the k-mer as the read spells it
+        if (w.is_prev) {                                             // branch node after branch node: a length-1 edge
+            const Kmer<NW> plus = kmer_plus<NW>(w.prev_k, kmer_last<NW>(wq));
+            const Kmer<NW> bal_plus = rc_plus<NW>(plus, K);
+            const bool sm = kmer_less<NW>(plus, bal_plus);
+            id = find_patch<NW>(p, sm ? plus : bal_plus, sm);
+            push = true;
+        }
+        w.is_prev = true;
+        w.prev_k = wq;
+    }
+    if (!push) return;
+    w.retain++;
+    // thread_add1preArc walks the items pairwise up to the first unresolved one (prlRead2path.c:405-424); an item is
+    // never taken back once two are retained, so the pair can go out as soon as its second half is known
+    if (w.n_items >= 1 && w.n_valid < 0 && id != 0) {
+        if (w.last_id >= p.id_end || id >= p.id_end) atomicAdd(&p.counters[5], 1ULL);
+        else add_prearc(p, w.last_id, id, seq0 | (unsigned)(w.n_items - 1));
+    }
+    if (id == 0 && w.n_valid < 0) w.n_valid = w.n_items;
+    if (row && w.n_items < p.max_nk) row[w.n_items] = id;
+    w.last_id = id;
+    w.n_items++;
+}
+// the read is through: recordPathBin (prlRead2path.c:478-543), the walk up to the first unresolved entry if its first three are resolved
+template <int NW>
+__device__ __forceinline__ void p2_thread_end(const P2Params& p, const P2Walk<NW>& w, uint32_t* row, uint64_t r) {
+    if (w.retain < 1) atomicAdd(&p.counters[0], 1ULL);
+    if (w.retain < 2 || !row) return;
+    const int upto = w.n_valid < 0 ? w.n_items : w.n_valid;
+    if (upto < 3) return;
+    p.walk_len[r] = (uint16_t)upto;
+    for (int i = 0; i < upto; i++) {
+        const uint32_t e = row[i];
+        if (e < p.id_end) atomicAdd(&p.marker[e], 1u); else atomicAdd(&p.counters[5], 1ULL);
+    }
+    atomicAdd(&p.counters[4], (unsigned long long)upto);
+}
+
+// The direct form: roll the k-mer, canonical form, set (CRC-32 sliced by four: four independent table reads a step instead of a chain of
+// sixteen), home slot (key mod size by the set's precomputed reciprocal), linear probing in the set image (newhash.c:277-318) -- one random
+// 24 / 40-byte probe in flight a lane.  With 58 registers (eight waves a SIMD) that already asks the memory system for random lines at the
+// rate it serves them (23.7 G lookups/s x ~1.6 lines = 38 G lines/s, profiles/r01_membench_random_access.log); blocks of 4 / 8 k-mers
+// looked up together were built and measured slower (230.9 / 304.9 ms against 222.7 per 60 M reads, profiles/r04a_p2_block_ab.csv) and are gone.
+// (The reference looks every k-mer of its buffer up before it threads any read, prlRead2path.c:159-248; here a read that the state machine
+// gives up is not looked up further.)
+template <int NW>
 __global__ __launch_bounds__(256) void p2_thread_kernel(P2Params p, const uint64_t* __restrict__ words, const uint64_t* __restrict__ word_off,
                                                         const int32_t* __restrict__ lens, uint64_t n_reads, uint64_t first_ordinal, int uniform_len) {
-    static_assert(BL >= 1 && BL <= 8, "set ids of a block are packed into one 64-bit word");
     __shared__ uint32_t crc4[4 * 256];
     __shared__ uint64_t set_geo[SV_GEO * P2_MAX_SETS];
     for (int i = threadIdx.x; i < 1024; i += 256) crc4[i] = crc32_slice_entry(i >> 8, i & 255);
@@ -160,142 +227,188 @@ __global__ __launch_bounds__(256) void p2_thread_kernel(P2Params p, const uint64
     const int nk = len - K + 1;
     uint32_t* row = p.stage ? p.stage + r * (uint64_t)p.max_nk : nullptr;
     const unsigned long long seq0 = (first_ordinal + r) << 16;
-
     Kmer<NW> word = read_kmer<NW>(rd, 0, K, filter);
     Kmer<NW> bal = kmer_rc<NW>(word, K);
-    unsigned retain = 0;
-    bool is_prev = false;
-    Kmer<NW> prev_k;
+    P2Walk<NW> w;
 #pragma unroll
-    for (int i = 0; i < NW; i++) prev_k.w[i] = 0;
-    int n_items = 0;             // items pushed since the last restart
-    int n_valid = -1;            // index of the first unresolved item (id 0), -1 while there is none
-    uint32_t last_id = 0;        // id of the latest item
-    bool stop = false;
-    for (int j0 = 0; j0 < nk && !stop; j0 += BL) {
-        const int nb = min(BL, nk - j0);
-        // ---- look up
-        Kmer<NW> ck[BL];
-        uint64_t hc[BL], abv[BL];
-        uint64_t setq = 0;                                               // the probes' set ids, a byte each
-        uint32_t smaller_mask = 0;
+    for (int i = 0; i < NW; i++) w.prev_k.w[i] = 0;
+    for (int j = 0; j < nk && !w.stop; j++) {
+        if (j) kmer_roll<NW>(word, bal, read_base(rd, j + K - 1), K, filter);
+        const bool sm = kmer_less<NW>(word, bal);
+        const Kmer<NW> ck = sm ? word : bal;
+        const uint32_t s = set_of_crc(kmer_crc32_sliced<NW>(ck, crc4), p.P, p.bias);
+        const uint64_t size = set_geo[SV_GEO * s + 1];
+        uint64_t hc = home_slot<NW>(ck, ModConst{size, set_geo[SV_GEO * s + 3], (uint32_t)set_geo[SV_GEO * s + 4]});
+        const uint64_t* base = (const uint64_t*)(uintptr_t)set_geo[SV_GEO * s + 2];
+        uint64_t ab = 0;
+        for (;;) {
+            const uint64_t* nd = base + hc * (NW + 1);
+            uint64_t d[NW + 1];
 #pragma unroll
-        for (int q = 0; q < BL; q++) {
-            if (q < nb) {
-                if (j0 + q) kmer_roll<NW>(word, bal, read_base(rd, j0 + q + K - 1), K, filter);
-                const bool sm = kmer_less<NW>(word, bal);
-                ck[q] = sm ? word : bal;
-                smaller_mask |= (sm ? 1u : 0u) << q;
-                const uint32_t s = set_of_crc(kmer_crc32_sliced<NW>(ck[q], crc4), p.P, p.bias);
-                setq |= (uint64_t)s << (8 * q);
-                hc[q] = home_slot<NW>(ck[q], ModConst{set_geo[SV_GEO * s + 1], set_geo[SV_GEO * s + 3], (uint32_t)set_geo[SV_GEO * s + 4]});
-            } else {                                                     // behind the read's last k-mer: probe 0 once more (nobody looks)
-                ck[q] = ck[0]; hc[q] = hc[0];
-                setq |= (setq & 0xff) << (8 * q);
-            }
-            abv[q] = 0;
+            for (int i = 0; i <= NW; i++) d[i] = sv_word(nd + i);         // (global loads: graph_lookup.hpp)
+            if (d[0] == SV_EMPTY) { atomicAdd(&p.counters[1], 1ULL); return; }      // not in the sets
+            bool eq = true;
+#pragma unroll
+            for (int i = 0; i < NW; i++) eq = eq && d[i] == ck.w[i];
+            if (eq) { ab = d[NW]; break; }
+            if (++hc == size) hc = 0;
         }
-        uint32_t pend = (1u << nb) - 1u;
-        for (bool first = true; pend; first = false) {
-            uint64_t d[BL][NW + 1];
-#pragma unroll
-            for (int q = 0; q < BL; q++)
-                if (first || ((pend >> q) & 1u)) {                       // (the first round asks for everything, unconditionally)
-                    const uint32_t s = (uint32_t)(setq >> (8 * q)) & 0xff;
-                    const uint64_t* nd = (const uint64_t*)(uintptr_t)set_geo[SV_GEO * s + 2] + hc[q] * (NW + 1);
-#pragma unroll
-                    for (int i = 0; i <= NW; i++) d[q][i] = sv_word(nd + i);     // (global loads: graph_lookup.hpp)
-                }
-#pragma unroll
-            for (int q = 0; q < BL; q++)
-                if ((pend >> q) & 1u) {
-                    if (d[q][0] == SV_EMPTY) { atomicAdd(&p.counters[1], 1ULL); return; }      // not in the sets
-                    bool eq = true;
-#pragma unroll
-                    for (int i = 0; i < NW; i++) eq = eq && d[q][i] == ck[q].w[i];
-                    if (eq) { abv[q] = d[q][NW]; pend &= ~(1u << q); }
-                    else {
-                        const uint32_t s = (uint32_t)(setq >> (8 * q)) & 0xff;
-                        if (++hc[q] == set_geo[SV_GEO * s + 1]) hc[q] = 0;
-                    }
-                }
-        }
-        // ---- thread
-#pragma unroll
-        for (int q = 0; q < BL; q++) {
-            if (q >= nb || stop) continue;
-            const bool smaller = (smaller_mask >> q) & 1u;
-            const uint64_t ab = abv[q];
-            const uint32_t A = (uint32_t)ab, B = (uint32_t)(ab >> 32);
-            const bool linear = B & B_LINEAR, in_edge = (B >> B_INEDGE_SHIFT) & 3;
-            if ((B & B_DELETED) || (linear && !in_edge)) {                   // deleted, or on a floating loop
-                if (retain < 2) { retain = 0; n_items = 0; n_valid = -1; }
-                else stop = true;
-                continue;
-            }
-            uint32_t id = 0;
-            bool push = false;
-            if (linear) {
-                const uint32_t twin = (B >> B_TWIN_SHIFT) & 3;
-                id = smaller ? A : A + twin - 1;
-                if (retain == 0 || is_prev) { push = true; is_prev = false; }
-                else if (id != last_id) push = true;
-            } else {
-                const Kmer<NW> wq = smaller ? ck[q] : kmer_rc<NW>(ck[q], K);    // the k-mer as the read spells it
-                if (is_prev) {                                               // branch node after branch node: a length-1 edge
-                    const Kmer<NW> plus = kmer_plus<NW>(prev_k, kmer_last<NW>(wq));
-                    const Kmer<NW> bal_plus = rc_plus<NW>(plus, K);
-                    const bool sm = kmer_less<NW>(plus, bal_plus);
-                    id = find_patch<NW>(p, sm ? plus : bal_plus, sm);
-                    push = true;
-                }
-                is_prev = true;
-                prev_k = wq;
-            }
-            if (!push) continue;
-            retain++;
-            // thread_add1preArc walks the items pairwise up to the first unresolved one (prlRead2path.c:405-424); an item is
-            // never taken back once two are retained, so the pair can go out as soon as its second half is known
-            if (n_items >= 1 && n_valid < 0 && id != 0) {
-                if (last_id >= p.id_end || id >= p.id_end) atomicAdd(&p.counters[5], 1ULL);
-                else add_prearc(p, last_id, id, seq0 | (unsigned)(n_items - 1));
-            }
-            if (id == 0 && n_valid < 0) n_valid = n_items;
-            if (row && n_items < p.max_nk) row[n_items] = id;
-            last_id = id;
-            n_items++;
-        }
+        p2_thread_step<NW>(p, w, ck, sm, ab, row, seq0);
     }
-    if (retain < 1) atomicAdd(&p.counters[0], 1ULL);
-    if (retain < 2 || !row) return;
-    // recordPathBin (prlRead2path.c:478-543): the walk up to the first unresolved entry, if its first three are resolved
-    const int upto = n_valid < 0 ? n_items : n_valid;
-    if (upto < 3) return;
-    p.walk_len[r] = (uint16_t)upto;
-    for (int i = 0; i < upto; i++) {
-        const uint32_t e = row[i];
-        if (e < p.id_end) atomicAdd(&p.marker[e], 1u); else atomicAdd(&p.counters[5], 1ULL);
-    }
-    atomicAdd(&p.counters[4], (unsigned long long)upto);
+    p2_thread_end<NW>(p, w, row, r);
 }
-// probes a lane keeps in flight (SOAPDENOVO2_AMD_P2_BLOCK).  Measured at 60 M reads (profiles/r04a_p2_block_ab.csv): 1 -> 222.7 ms, 4 -> 230.9 ms,
-// 8 -> 304.9 ms (round 3's kernel: 272.6 ms).  One probe a lane with 58 registers (eight waves a SIMD) already keeps the memory
-// system at the rate it serves random lines at -- 23.7 G lookups/s x ~1.6 lines a lookup (a 24-byte slot straddles two 64-byte
-// lines one time in four, a lookup probes 1.75 slots on average) = 38 G lines/s, the ceiling profiles/r01_membench_random_access.log
-// measured -- so more probes a lane only cost registers, i.e. waves.  What the round bought came from the sliced CRC and the reciprocal.
-static int p2_block() { static const int v = [] { const char* e = pg::env_measure("SOAPDENOVO2_AMD_P2_BLOCK"); return e ? atoi(e) : 1; }(); return v; }
 static void p2_launch_thread_kernel(int nw, dim3 grid, hipStream_t st, const P2Params& p, const uint64_t* words, const uint64_t* word_off, const int32_t* lens,
                                     uint64_t n_reads, uint64_t first_ordinal, int uniform_len) {
-    const int bl = p2_block();
     const dim3 block(256);
-    if (nw == 2) {
-        if (bl == 8) hipLaunchKernelGGL((p2_thread_kernel<2, 8>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len);
-        else if (bl == 4) hipLaunchKernelGGL((p2_thread_kernel<2, 4>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len);
-        else hipLaunchKernelGGL((p2_thread_kernel<2, 1>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len);
-    } else {
-        if (bl == 4) hipLaunchKernelGGL((p2_thread_kernel<4, 4>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len);
-        else hipLaunchKernelGGL((p2_thread_kernel<4, 1>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len);
+    if (nw == 2) hipLaunchKernelGGL((p2_thread_kernel<2>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len);
+    else hipLaunchKernelGGL((p2_thread_kernel<4>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len);
+}
+
+// ---- pass 2, routed: the lookups go to the sets' owners ---------------------------------------------------------------------------------
+// In a sharded run set s lives on lane s mod N, and a lane that threads a batch by probing the peer-mapped sets sends 7 of 8 probes over
+// xGMI as random 64-byte reads (~10 s a GPU at configs[3] against ~1 s for the whole hash-insert path).  The reference gives
+// every read one worker and every set one owner (prlRead2path.c:159-248, :248 `mixBuffer[j].low % thrd_num != id`); so does this form:
+//   p2_route_hist      a lane a read: roll the k-mers, owner(k-mer) = lane of its set; per workgroup and owner, how many
+//   (exclusive sum over the owner-major histogram: where every workgroup's queries for every owner start in the send buffer)
+//   p2_route_scatter   roll again: the canonical k-mers (NW words each) go out grouped by owner; where[k-mer] = the place of its query,
+//                      which is the place of its answer
+//   (the owners pull their segments of every lane's send buffer: streamed copies, 16 / 32 bytes a lookup)
+//   p2_answer_kernel   the owner probes ITS sets -- local HBM -- and writes the node words (8 bytes a lookup; ~0 = not in the sets)
+//   (the lanes pull their answers back)
+//   p2_thread_routed_kernel   a lane a read: roll once more (which strand is canonical; the read-oriented k-mer of a branch node), node
+//                      word = answers[where[k-mer]], parse1read's state machine as in the direct form
+// Every k-mer is rolled three times and probed once, where it lives; nothing crosses xGMI but two streams.  No atomics on the way: the
+// places are prefix sums, so a batch's buffers are a function of the batch.
+constexpr int P2R_MAX_LANES = 16;                    // per-thread counters in LDS: 16 x 256 words
+struct P2Route {
+    int n_own;
+    uint32_t nblocks;
+    const uint8_t* owner_of_set;                     // [P]
+    uint32_t* hist;                                  // [n_own * nblocks + 1] owner-major; after the sum: first place of (owner, workgroup)
+    uint64_t* send;                                  // [Q * NW]
+    uint32_t* where;                                 // [Q]
+    const uint64_t* kbase;                           // [n_reads] first k-mer of a read among the batch's (ragged batches; null: r * (uniform_len - K + 1))
+};
+// the k-mers of a read, in read order: f(j, canonical k-mer, smaller, owner)
+template <int NW, typename F>
+__device__ __forceinline__ void p2r_for_kmers(const P2Params& p, const uint32_t* crc4, const uint8_t* owner_s, const uint64_t* rd, int nk, F f) {
+    const int K = p.K;
+    const Kmer<NW> filter = kmer_filter<NW>(K);
+    Kmer<NW> word = read_kmer<NW>(rd, 0, K, filter);
+    Kmer<NW> bal = kmer_rc<NW>(word, K);
+    for (int j = 0; j < nk; j++) {
+        if (j) kmer_roll<NW>(word, bal, read_base(rd, j + K - 1), K, filter);
+        const bool sm = kmer_less<NW>(word, bal);
+        const Kmer<NW> ck = sm ? word : bal;
+        const uint32_t s = set_of_crc(kmer_crc32_sliced<NW>(ck, crc4), p.P, p.bias);
+        f(j, ck, sm, (uint32_t)owner_s[s]);
     }
+}
+#define P2R_PROLOGUE()                                                                                                     \
+    __shared__ uint32_t crc4[4 * 256];                                                                                     \
+    __shared__ uint8_t owner_s[256];                                                                                       \
+    __shared__ uint32_t cnt[P2R_MAX_LANES * 256];                                                                          \
+    for (int i = threadIdx.x; i < 1024; i += 256) crc4[i] = crc32_slice_entry(i >> 8, i & 255);                            \
+    owner_s[threadIdx.x] = threadIdx.x < p.P ? ro.owner_of_set[threadIdx.x] : (uint8_t)0;                                  \
+    for (int o = 0; o < ro.n_own; o++) cnt[o * 256 + threadIdx.x] = 0;                                                     \
+    __syncthreads();                                                                                                       \
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;                                                           \
+    const int len = r < n_reads ? (uniform_len ? uniform_len : lens[r]) : 0;                                               \
+    const int nk = len >= p.K + 1 ? len - p.K + 1 : 0;                               /* prlRead2path.c:1103 */              \
+    const uint64_t* rd = r < n_reads ? words + (uniform_len ? r * (uint64_t)((uniform_len + 31) / 32) : word_off[r]) : words
+template <int NW>
+__global__ __launch_bounds__(256) void p2_route_hist(P2Params p, P2Route ro, const uint64_t* __restrict__ words, const uint64_t* __restrict__ word_off,
+                                                     const int32_t* __restrict__ lens, uint64_t n_reads, int uniform_len) {
+    P2R_PROLOGUE();
+    if (nk) p2r_for_kmers<NW>(p, crc4, owner_s, rd, nk, [&](int, const Kmer<NW>&, bool, uint32_t o) { cnt[o * 256 + threadIdx.x]++; });
+    __syncthreads();
+    if ((int)threadIdx.x < ro.n_own) {
+        uint32_t sum = 0;
+        for (int t = 0; t < 256; t++) sum += cnt[threadIdx.x * 256 + ((t + threadIdx.x) & 255)];       // (rotated: the owners' threads start in different banks)
+        ro.hist[(uint64_t)threadIdx.x * ro.nblocks + blockIdx.x] = sum;
+    }
+}
+template <int NW>
+__global__ __launch_bounds__(256) void p2_route_scatter(P2Params p, P2Route ro, const uint64_t* __restrict__ words, const uint64_t* __restrict__ word_off,
+                                                        const int32_t* __restrict__ lens, uint64_t n_reads, int uniform_len) {
+    P2R_PROLOGUE();
+    if (nk) p2r_for_kmers<NW>(p, crc4, owner_s, rd, nk, [&](int, const Kmer<NW>&, bool, uint32_t o) { cnt[o * 256 + threadIdx.x]++; });
+    __syncthreads();
+    if ((int)threadIdx.x < ro.n_own) {                       // exclusive sum over the threads, from the place the workgroup's segment for this owner starts at
+        uint32_t at = ro.hist[(uint64_t)threadIdx.x * ro.nblocks + blockIdx.x];
+        for (int t = 0; t < 256; t++) { const uint32_t c = cnt[threadIdx.x * 256 + t]; cnt[threadIdx.x * 256 + t] = at; at += c; }
+    }
+    __syncthreads();
+    if (!nk) return;
+    const uint64_t kb = ro.kbase ? ro.kbase[r] : r * (uint64_t)nk;
+    p2r_for_kmers<NW>(p, crc4, owner_s, rd, nk, [&](int j, const Kmer<NW>& ck, bool, uint32_t o) {
+        const uint32_t at = cnt[o * 256 + threadIdx.x]++;
+#pragma unroll
+        for (int i = 0; i < NW; i++) ro.send[(uint64_t)at * NW + i] = ck.w[i];
+        ro.where[kb + j] = at;
+    });
+}
+// the owner's side: n canonical k-mers, all of sets that live here
+template <int NW>
+__global__ __launch_bounds__(256) void p2_answer_kernel(P2Params p, const uint64_t* __restrict__ keys, uint64_t n, uint64_t* __restrict__ answers) {
+    __shared__ uint32_t crc4[4 * 256];
+    __shared__ uint64_t set_geo[SV_GEO * P2_MAX_SETS];
+    for (int i = threadIdx.x; i < 1024; i += 256) crc4[i] = crc32_slice_entry(i >> 8, i & 255);
+    for (int i = threadIdx.x; i < SV_GEO * (int)p.P; i += 256) set_geo[i] = p.geo3[i];
+    __syncthreads();
+    for (uint64_t q = (uint64_t)blockIdx.x * 256 + threadIdx.x; q < n; q += (uint64_t)gridDim.x * 256) {
+        Kmer<NW> ck;
+#pragma unroll
+        for (int i = 0; i < NW; i++) ck.w[i] = keys[q * NW + i];
+        const uint32_t s = set_of_crc(kmer_crc32_sliced<NW>(ck, crc4), p.P, p.bias);
+        const uint64_t size = set_geo[SV_GEO * s + 1];
+        uint64_t hc = home_slot<NW>(ck, ModConst{size, set_geo[SV_GEO * s + 3], (uint32_t)set_geo[SV_GEO * s + 4]});
+        const uint64_t* base = (const uint64_t*)(uintptr_t)set_geo[SV_GEO * s + 2];
+        uint64_t ab = ~0ULL;
+        for (;;) {
+            const uint64_t* nd = base + hc * (NW + 1);
+            uint64_t d[NW + 1];
+#pragma unroll
+            for (int i = 0; i <= NW; i++) d[i] = sv_word(nd + i);
+            if (d[0] == SV_EMPTY) break;                                  // not in the sets: ~0 (no node has every flag of word B set)
+            bool eq = true;
+#pragma unroll
+            for (int i = 0; i < NW; i++) eq = eq && d[i] == ck.w[i];
+            if (eq) { ab = d[NW]; break; }
+            if (++hc == size) hc = 0;
+        }
+        answers[q] = ab;
+    }
+}
+template <int NW>
+__global__ __launch_bounds__(256) void p2_thread_routed_kernel(P2Params p, const uint32_t* __restrict__ where, const uint64_t* __restrict__ kbase, const uint64_t* __restrict__ answers,
+                                                               const uint64_t* __restrict__ words, const uint64_t* __restrict__ word_off, const int32_t* __restrict__ lens,
+                                                               uint64_t n_reads, uint64_t first_ordinal, int uniform_len) {
+    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_reads) return;
+    const int K = p.K;
+    const int len = uniform_len ? uniform_len : lens[r];
+    if (p.walk_len) p.walk_len[r] = 0;
+    if (len < K + 1) return;
+    const uint64_t* rd = words + (uniform_len ? r * (uint64_t)((uniform_len + 31) / 32) : word_off[r]);
+    const Kmer<NW> filter = kmer_filter<NW>(K);
+    const int nk = len - K + 1;
+    const uint64_t kb = kbase ? kbase[r] : r * (uint64_t)nk;
+    uint32_t* row = p.stage ? p.stage + r * (uint64_t)p.max_nk : nullptr;
+    const unsigned long long seq0 = (first_ordinal + r) << 16;
+    Kmer<NW> word = read_kmer<NW>(rd, 0, K, filter);
+    Kmer<NW> bal = kmer_rc<NW>(word, K);
+    P2Walk<NW> w;
+#pragma unroll
+    for (int i = 0; i < NW; i++) w.prev_k.w[i] = 0;
+    for (int j = 0; j < nk && !w.stop; j++) {
+        if (j) kmer_roll<NW>(word, bal, read_base(rd, j + K - 1), K, filter);
+        const bool sm = kmer_less<NW>(word, bal);
+        const uint64_t ab = answers[where[kb + j]];
+        if (ab == ~0ULL) { atomicAdd(&p.counters[1], 1ULL); return; }      // not in the sets
+        p2_thread_step<NW>(p, w, sm ? word : bal, sm, ab, row, seq0);
+    }
+    p2_thread_end<NW>(p, w, row, r);
 }
 
 
@@ -816,6 +929,26 @@ struct P2Lane {
     uint32_t* d_stage = nullptr; uint16_t* d_walk_len = nullptr; size_t cap_stage_reads = 0;
     hipEvent_t copied = nullptr;
     uint64_t reads = 0, batches = 0, scans = 0;      // what the lane did (PG_HOST_VERBOSE; asserted by the sharded tests)
+    uint64_t walks = 0;                              // tip / edge walks that started from a node of this lane's sets and ran here
+    // ---- routed pass 2 (p2_route_round): a batch waits here until every lane has one
+    struct Pending {
+        bool have = false;
+        const uint64_t* d_words = nullptr; const uint64_t* d_off = nullptr; const int32_t* d_lens = nullptr;
+        uint64_t n_reads = 0, ordinal = 0, q = 0;    // q = k-mers of the batch (the lookups it asks for)
+        int uniform_len = 0;
+        uint32_t* walks_out = nullptr; uint16_t* walk_len_out = nullptr;
+    } pend;
+    std::vector<uint64_t> h_kbase;                   // ragged batches: first k-mer of every read
+    uint8_t* d_owner_of_set = nullptr;
+    template <typename T> struct Buf { T* p = nullptr; size_t cap = 0; };        // grow-only device buffers (the arena makes growing cheap)
+    Buf<uint64_t> kbase;
+    Buf<uint32_t> hist_in, hist;
+    Buf<unsigned char> scan_tmp;
+    Buf<uint64_t> send, ans;                         // as a reader of batches: the keys it asks for, the node words that come back
+    Buf<uint32_t> where;
+    Buf<uint64_t> rkeys, rans;                       // as an owner of sets: the keys it is asked for, its answers
+    uint32_t* h_starts = nullptr;                    // page-locked: where every owner's segment starts in this lane's send buffer, and the total
+    uint64_t lookups_sent = 0, lookups_sent_away = 0, lookups_answered = 0, route_rounds = 0;
 };
 
 struct P2Device {
@@ -838,6 +971,7 @@ struct P2Device {
     uint64_t ordinal = 0;
     uint64_t n_slots = 0;
     bool reads_ready = false;
+    bool route = false;                              // pass 2's lookups go to the sets' owners (several lanes; SOAPDENOVO2_AMD_P2_ROUTE=0: peer-mapped probes)
     hipStream_t stream = nullptr;
     unsigned long long* d_vlist = nullptr;           // the vertices' global slots as p2_list_vertices left them (the edge builder starts from the same list)
     uint64_t n_vlist = 0;
@@ -856,6 +990,9 @@ static void p2_free(P2Device* d) {
         if (l) pg::arena_free(ln.d_counters);
         pg::arena_free(ln.d_marker);
         pg::arena_free(ln.d_words); pg::arena_free(ln.d_off); pg::arena_free(ln.d_lens); pg::arena_free(ln.d_stage); pg::arena_free(ln.d_walk_len);
+        pg::arena_free(ln.d_owner_of_set); pg::arena_free(ln.kbase.p); pg::arena_free(ln.hist_in.p); pg::arena_free(ln.hist.p); pg::arena_free(ln.scan_tmp.p);
+        pg::arena_free(ln.send.p); pg::arena_free(ln.where.p); pg::arena_free(ln.ans.p); pg::arena_free(ln.rkeys.p); pg::arena_free(ln.rans.p);
+        if (ln.h_starts) (void)hipHostFree(ln.h_starts);
         if (ln.copied) (void)hipEventDestroy(ln.copied);
         if (l && ln.stream) (void)hipStreamDestroy(ln.stream);
     }
@@ -1296,6 +1433,9 @@ int p2_begin_reads(P2Device* d, uint32_t num_ed, bool reps) {
     P2_HIP(hipSetDevice(d->device));
     if (!d->d_patch_val) { pg_set_error("pass 2: no (K+1)-mer table yet"); return PG_ESTATE; }
     d->num_ed = num_ed; d->reps = reps;
+    // several lanes: the lookups are routed to the sets' owners (SOAPDENOVO2_AMD_P2_ROUTE=0: every lane probes the peer-mapped sets itself, the A/B form)
+    d->route = d->lanes.size() > 1 && (int)d->lanes.size() <= P2R_MAX_LANES;
+    if (const char* e = pg::env_user("SOAPDENOVO2_AMD_P2_ROUTE")) d->route = d->route && atoi(e) != 0;
     // every edge has a handful of successors: eight slots an edge id keep the load low; the kernel counts overflows
     uint64_t arc_cap = 1 << 16;
     while (arc_cap < (uint64_t)d->num_ed * 8) arc_cap <<= 1;
@@ -1328,6 +1468,13 @@ int p2_begin_reads(P2Device* d, uint32_t num_ed, bool reps) {
             P2_HIP(hipMemsetAsync(ln.d_marker, 0, ((size_t)d->num_ed + 1) * sizeof(unsigned int), ln.stream));
         }
         P2_HIP(hipEventCreateWithFlags(&ln.copied, hipEventDisableTiming));
+        if (d->route) {
+            std::vector<uint8_t> own(256, 0);
+            for (int s2 = 0; s2 < d->P; s2++) own[s2] = (uint8_t)d->set_lane[s2];
+            P2_HIP(pg::arena_malloc((void**)&ln.d_owner_of_set, 256));
+            P2_HIP(hipMemcpyAsync(ln.d_owner_of_set, own.data(), 256, hipMemcpyHostToDevice, ln.stream));
+            P2_HIP(hipHostMalloc((void**)&ln.h_starts, (P2R_MAX_LANES + 1) * sizeof(uint32_t), hipHostMallocPortable));
+        }
         P2_HIP(hipStreamSynchronize(ln.stream));
         P2Params& p = ln.prm;
         p.counters = ln.d_counters;
@@ -1748,6 +1895,144 @@ done:
 
 void p2_destroy(P2Device* d) { p2_free(d); }
 
+
+// ---- routed pass 2: one round = the batches that wait on the lanes (one each at most), all lanes working at once ---------------------------
+template <typename T>
+static int p2r_grow(P2Lane::Buf<T>& b, size_t need) {
+    if (need <= b.cap && b.p) return PG_OK;
+    if (b.p) P2_HIP(pg::arena_free(b.p));
+    b.p = nullptr;
+    b.cap = need + need / 4 + 64;
+    P2_HIP(pg::arena_malloc((void**)&b.p, b.cap * sizeof(T)));
+    return PG_OK;
+}
+static hipError_t p2r_copy(void* dst, int dst_dev, const void* src, int src_dev, size_t bytes, hipStream_t st) {
+    if (!bytes) return hipSuccess;
+    if (dst_dev == src_dev) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
+    return hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, st);
+}
+static int p2_route_round(P2Device* d) {
+    const int N = (int)d->lanes.size(), nw = d->nw;
+    bool any = false;
+    for (P2Lane& ln : d->lanes) any = any || ln.pend.have;
+    if (!any) return PG_OK;
+    // A: every lane cuts its batch's lookups by owner
+    for (P2Lane& ln : d->lanes) {
+        if (!ln.pend.have) continue;
+        P2Lane::Pending& b = ln.pend;
+        P2_HIP(hipSetDevice(ln.device));
+        const uint32_t nblocks = (uint32_t)((b.n_reads + 255) / 256);
+        const size_t nh = (size_t)N * nblocks + 1;
+        int rc = p2r_grow(ln.hist_in, nh);
+        if (!rc) rc = p2r_grow(ln.hist, nh);
+        if (!rc) rc = p2r_grow(ln.where, (size_t)b.q);
+        if (!rc) rc = p2r_grow(ln.ans, (size_t)b.q);
+        if (!rc) rc = p2r_grow(ln.send, (size_t)b.q * nw);
+        if (rc) return rc;
+        P2Route ro{N, nblocks, ln.d_owner_of_set, ln.hist_in.p, ln.send.p, ln.where.p, b.d_off ? ln.kbase.p : nullptr};
+        const dim3 grid(nblocks), block(256);
+        P2_HIP(hipMemsetAsync(ln.hist_in.p + (nh - 1), 0, sizeof(uint32_t), ln.stream));
+        if (nw == 2) hipLaunchKernelGGL((p2_route_hist<2>), grid, block, 0, ln.stream, ln.prm, ro, b.d_words, b.d_off, b.d_lens, b.n_reads, b.uniform_len);
+        else hipLaunchKernelGGL((p2_route_hist<4>), grid, block, 0, ln.stream, ln.prm, ro, b.d_words, b.d_off, b.d_lens, b.n_reads, b.uniform_len);
+        P2_HIP(hipGetLastError());
+        size_t need = 0;
+        P2_HIP(rocprim::exclusive_scan(nullptr, need, ln.hist_in.p, ln.hist.p, 0u, nh, rocprim::plus<uint32_t>(), ln.stream));
+        rc = p2r_grow(ln.scan_tmp, need);
+        if (rc) return rc;
+        P2_HIP(rocprim::exclusive_scan((void*)ln.scan_tmp.p, need, ln.hist_in.p, ln.hist.p, 0u, nh, rocprim::plus<uint32_t>(), ln.stream));
+        ro.hist = ln.hist.p;
+        if (nw == 2) hipLaunchKernelGGL((p2_route_scatter<2>), grid, block, 0, ln.stream, ln.prm, ro, b.d_words, b.d_off, b.d_lens, b.n_reads, b.uniform_len);
+        else hipLaunchKernelGGL((p2_route_scatter<4>), grid, block, 0, ln.stream, ln.prm, ro, b.d_words, b.d_off, b.d_lens, b.n_reads, b.uniform_len);
+        P2_HIP(hipGetLastError());
+        // the owners' segments start at hist[o * nblocks]; the total behind the last
+        for (int o = 0; o <= N; o++) P2_HIP(hipMemcpyAsync(ln.h_starts + o, ln.hist.p + (size_t)o * nblocks, sizeof(uint32_t), hipMemcpyDeviceToHost, ln.stream));
+    }
+    for (P2Lane& ln : d->lanes) if (ln.pend.have) { P2_HIP(hipSetDevice(ln.device)); P2_HIP(hipStreamSynchronize(ln.stream)); }
+    // who sends how much to whom
+    std::vector<uint64_t> cnt((size_t)N * N, 0), recv_off((size_t)N * N, 0), recv_total(N, 0);
+    for (int l = 0; l < N; l++) {
+        P2Lane& ln = d->lanes[l];
+        if (!ln.pend.have) continue;
+        if (ln.h_starts[N] != ln.pend.q) { pg_set_error("pass 2 (routed): a batch's lookups do not add up"); return PG_EINVAL; }
+        for (int o = 0; o < N; o++) cnt[(size_t)l * N + o] = (uint64_t)ln.h_starts[o + 1] - ln.h_starts[o];
+    }
+    for (int o = 0; o < N; o++)
+        for (int l = 0; l < N; l++) { recv_off[(size_t)o * N + l] = recv_total[o]; recv_total[o] += cnt[(size_t)l * N + o]; }
+    // B: the owners pull their segments and answer
+    for (int o = 0; o < N; o++) {
+        P2Lane& ow = d->lanes[o];
+        if (!recv_total[o]) continue;
+        P2_HIP(hipSetDevice(ow.device));
+        int rc = p2r_grow(ow.rans, (size_t)recv_total[o]);
+        if (!rc) rc = p2r_grow(ow.rkeys, (size_t)recv_total[o] * nw);
+        if (rc) return rc;
+        for (int l = 0; l < N; l++) {
+            const uint64_t c = cnt[(size_t)l * N + o];
+            if (!c) continue;
+            P2Lane& ln = d->lanes[l];
+            P2_HIP(p2r_copy(ow.rkeys.p + recv_off[(size_t)o * N + l] * nw, ow.device, ln.send.p + (uint64_t)ln.h_starts[o] * nw, ln.device, c * nw * sizeof(uint64_t), ow.stream));
+            ln.lookups_sent += c;
+            if (l != o) ln.lookups_sent_away += c;
+        }
+        const dim3 grid((unsigned)std::min<uint64_t>((recv_total[o] + 255) / 256, 1u << 20)), block(256);
+        if (nw == 2) hipLaunchKernelGGL((p2_answer_kernel<2>), grid, block, 0, ow.stream, ow.prm, ow.rkeys.p, recv_total[o], ow.rans.p);
+        else hipLaunchKernelGGL((p2_answer_kernel<4>), grid, block, 0, ow.stream, ow.prm, ow.rkeys.p, recv_total[o], ow.rans.p);
+        P2_HIP(hipGetLastError());
+        ow.lookups_answered += recv_total[o];
+    }
+    for (int o = 0; o < N; o++) if (recv_total[o]) { P2_HIP(hipSetDevice(d->lanes[o].device)); P2_HIP(hipStreamSynchronize(d->lanes[o].stream)); }
+    // C: the answers go home, the lanes thread their reads
+    for (int l = 0; l < N; l++) {
+        P2Lane& ln = d->lanes[l];
+        if (!ln.pend.have) continue;
+        P2Lane::Pending& b = ln.pend;
+        P2_HIP(hipSetDevice(ln.device));
+        for (int o = 0; o < N; o++) {
+            const uint64_t c = cnt[(size_t)l * N + o];
+            if (c) P2_HIP(p2r_copy(ln.ans.p + ln.h_starts[o], ln.device, d->lanes[o].rans.p + recv_off[(size_t)o * N + l], d->lanes[o].device, c * sizeof(uint64_t), ln.stream));
+        }
+        P2Params p = ln.prm;
+        p.stage = d->reps ? ln.d_stage : nullptr;
+        p.walk_len = d->reps ? ln.d_walk_len : nullptr;
+        const dim3 grid((unsigned)((b.n_reads + 255) / 256)), block(256);
+        if (nw == 2) hipLaunchKernelGGL((p2_thread_routed_kernel<2>), grid, block, 0, ln.stream, p, ln.where.p, b.d_off ? ln.kbase.p : nullptr, ln.ans.p, b.d_words, b.d_off, b.d_lens, b.n_reads, b.ordinal, b.uniform_len);
+        else hipLaunchKernelGGL((p2_thread_routed_kernel<4>), grid, block, 0, ln.stream, p, ln.where.p, b.d_off ? ln.kbase.p : nullptr, ln.ans.p, b.d_words, b.d_off, b.d_lens, b.n_reads, b.ordinal, b.uniform_len);
+        P2_HIP(hipGetLastError());
+        if (d->reps && b.walks_out && b.walk_len_out) {
+            P2_HIP(hipMemcpyAsync(b.walks_out, ln.d_stage, b.n_reads * (size_t)d->max_nk * sizeof(uint32_t), hipMemcpyDeviceToHost, ln.stream));
+            P2_HIP(hipMemcpyAsync(b.walk_len_out, ln.d_walk_len, b.n_reads * sizeof(uint16_t), hipMemcpyDeviceToHost, ln.stream));
+        }
+        ln.route_rounds++;
+    }
+    // (the owners' answer buffers are read by the lanes' copies: everybody is through before the next round writes them)
+    for (P2Lane& ln : d->lanes) if (ln.pend.have) { P2_HIP(hipSetDevice(ln.device)); P2_HIP(hipStreamSynchronize(ln.stream)); ln.pend.have = false; }
+    P2_HIP(hipSetDevice(d->device));
+    return PG_OK;
+}
+// a batch is in a lane's buffers: thread it now (the direct form), or let it wait for the round (the routed form)
+static int p2_batch_ready(P2Device* d, P2Lane& ln, const uint64_t* d_words, const uint64_t* d_off, const int32_t* d_lens, uint64_t n_reads, uint64_t q, int uniform_len,
+                          uint32_t* walks_out, uint16_t* walk_len_out, bool round_now) {
+    if (!d->route) {
+        P2Params p = ln.prm;
+        p.stage = d->reps && !uniform_len ? ln.d_stage : nullptr;
+        p.walk_len = d->reps && !uniform_len ? ln.d_walk_len : nullptr;
+        const dim3 grid((unsigned)((n_reads + 255) / 256));
+        p2_launch_thread_kernel(d->nw, grid, ln.stream, p, d_words, d_off, d_lens, n_reads, d->ordinal, uniform_len);
+        P2_HIP(hipGetLastError());
+        return PG_OK;
+    }
+    if (q >= 0xFFFFFFFFull) { pg_set_error("pass 2 (routed): more than 2^32 k-mers in one batch"); return PG_EINVAL; }
+    if (ln.pend.have) { const int rc = p2_route_round(d); if (rc) return rc; P2_HIP(hipSetDevice(ln.device)); }
+    ln.pend.have = true;
+    ln.pend.d_words = d_words; ln.pend.d_off = d_off; ln.pend.d_lens = d_lens;
+    ln.pend.n_reads = n_reads; ln.pend.ordinal = d->ordinal; ln.pend.q = q; ln.pend.uniform_len = uniform_len;
+    ln.pend.walks_out = walks_out; ln.pend.walk_len_out = walk_len_out;
+    bool all = true;
+    for (const P2Lane& o : d->lanes) all = all && o.pend.have;
+    if (all || round_now) return p2_route_round(d);
+    return PG_OK;
+}
+
 // One batch of reads goes to the next lane in turn.  Without -R the call returns as soon as the batch has left the host buffers
 // (the lane threads it while the caller fetches the next batch for the next lane); with -R the walks come back, so it waits.
 int p2_add_packed(P2Device* d, const uint64_t* words, const uint64_t* word_off, const int32_t* lens, uint64_t n_reads, uint64_t n_words,
@@ -1755,6 +2040,7 @@ int p2_add_packed(P2Device* d, const uint64_t* words, const uint64_t* word_off, 
     if (!d->reads_ready) { pg_set_error("pass 2: p2_begin_reads was not called"); return PG_ESTATE; }
     if (!n_reads) return PG_OK;
     P2Lane& ln = d->lanes[d->next_lane++ % d->lanes.size()];
+    if (d->route && ln.pend.have) { const int rc = p2_route_round(d); if (rc) return rc; }      // (its buffers still hold a batch that waits for its round)
     P2_HIP(hipSetDevice(ln.device));
     if (n_words + 8 > ln.cap_words || n_reads > ln.cap_reads || (d->reps && n_reads > ln.cap_stage_reads)) P2_HIP(hipStreamSynchronize(ln.stream));   // nobody reads the buffers that go
     if (n_words + 8 > ln.cap_words) {
@@ -1779,14 +2065,18 @@ int p2_add_packed(P2Device* d, const uint64_t* words, const uint64_t* word_off, 
     P2_HIP(hipMemsetAsync(ln.d_words + n_words, 0, 8 * sizeof(uint64_t), ln.stream));      // readable padding for the window loads
     P2_HIP(hipMemcpyAsync(ln.d_off, word_off, n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, ln.stream));
     P2_HIP(hipMemcpyAsync(ln.d_lens, lens, n_reads * sizeof(int32_t), hipMemcpyHostToDevice, ln.stream));
+    uint64_t q = 0;
+    if (d->route) {                                                   // the first k-mer of every read among the batch's (prlRead2path.c:1103: reads shorter than K + 1 have none)
+        ln.h_kbase.resize(n_reads);
+        for (uint64_t r = 0; r < n_reads; r++) { ln.h_kbase[r] = q; if (lens[r] >= d->K + 1) q += (uint64_t)(lens[r] - d->K + 1); }
+        { const int rc = p2r_grow(ln.kbase, (size_t)n_reads); if (rc) return rc; }
+        P2_HIP(hipMemcpyAsync(ln.kbase.p, ln.h_kbase.data(), n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, ln.stream));
+    }
     P2_HIP(hipEventRecord(ln.copied, ln.stream));
-    P2Params p = ln.prm;
-    p.stage = d->reps ? ln.d_stage : nullptr;
-    p.walk_len = d->reps ? ln.d_walk_len : nullptr;
-    const dim3 grid((unsigned)((n_reads + 255) / 256));
-    p2_launch_thread_kernel(d->nw, grid, ln.stream, p, ln.d_words, ln.d_off, ln.d_lens, n_reads, d->ordinal, 0);
-    P2_HIP(hipGetLastError());
-    if (d->reps && walks_out && walk_len_out) {
+    // (-R: the walks come back with the call, so a routed batch does not wait for the other lanes' batches)
+    { const int rc = p2_batch_ready(d, ln, ln.d_words, ln.d_off, ln.d_lens, n_reads, q, 0, walks_out, walk_len_out, d->reps); if (rc) return rc; }
+    if (d->route) { P2_HIP(hipSetDevice(ln.device)); P2_HIP(hipEventSynchronize(ln.copied)); }
+    else if (d->reps && walks_out && walk_len_out) {
         P2_HIP(hipMemcpyAsync(walks_out, ln.d_stage, n_reads * (size_t)d->max_nk * sizeof(uint32_t), hipMemcpyDeviceToHost, ln.stream));
         P2_HIP(hipMemcpyAsync(walk_len_out, ln.d_walk_len, n_reads * sizeof(uint16_t), hipMemcpyDeviceToHost, ln.stream));
         P2_HIP(hipStreamSynchronize(ln.stream));
@@ -1811,13 +2101,10 @@ int p2_add_packed_device(P2Device* d, const uint64_t* d_words, uint64_t n_reads,
     }
     if (!ln) { pg_set_error("pass 2: no lane of the graph runs on the device the reads lie on"); return PG_EINVAL; }
     P2_HIP(hipSetDevice(ln->device));
-    P2Params p = ln->prm;
-    p.stage = nullptr;
-    p.walk_len = nullptr;
-    const dim3 grid((unsigned)((n_reads + 255) / 256));
-    p2_launch_thread_kernel(d->nw, grid, ln->stream, p, d_words, nullptr, nullptr, n_reads, d->ordinal, read_len);
-    P2_HIP(hipGetLastError());
-    P2_HIP(hipStreamSynchronize(ln->stream));                       // (the caller may release the reads)
+    // (the caller may release the reads when the call returns: a routed batch has its round at once)
+    { const int rc = p2_batch_ready(d, *ln, d_words, nullptr, nullptr, n_reads, read_len >= d->K + 1 ? n_reads * (uint64_t)(read_len - d->K + 1) : 0, read_len, nullptr, nullptr, true); if (rc) return rc; }
+    P2_HIP(hipSetDevice(ln->device));
+    P2_HIP(hipStreamSynchronize(ln->stream));
     d->ordinal += n_reads;
     ln->reads += n_reads; ln->batches++;
     P2_HIP(hipSetDevice(d->device));
@@ -1825,6 +2112,7 @@ int p2_add_packed_device(P2Device* d, const uint64_t* d_words, uint64_t n_reads,
 }
 
 int p2_finish(P2Device* d, P2Result& out) {
+    if (d->route) { const int rc = p2_route_round(d); if (rc) return rc; }        // the batches still waiting for a full round
     unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     std::vector<unsigned long long> lane_arcs(d->lanes.size(), 0);
     for (size_t l = 0; l < d->lanes.size(); l++) {
@@ -1845,6 +2133,18 @@ int p2_finish(P2Device* d, P2Result& out) {
         for (size_t l = 0; l < d->lanes.size(); l++)
             fprintf(stderr, "graph lane %zu (device %d): pass 2 threaded %llu read(s) in %llu batch(es), %llu distinct pre-arc(s); %llu per-set scan(s) ran here\n", l, d->lanes[l].device,
                     (unsigned long long)d->lanes[l].reads, (unsigned long long)d->lanes[l].batches, lane_arcs[l], (unsigned long long)d->lanes[l].scans);
+    if (pg::env_user("PG_HOST_VERBOSE") && d->lanes.size() > 1) {
+        if (d->route) {
+            unsigned long long reads = 0, sent = 0, away = 0;
+            for (const P2Lane& ln : d->lanes) {
+                fprintf(stderr, "pass 2 routed, lane of device %d: asked %llu lookup(s), %llu of them of other lanes, in %llu round(s); answered %llu from its own sets; 0 probes of peer-mapped sets\n", ln.device,
+                        (unsigned long long)ln.lookups_sent, (unsigned long long)ln.lookups_sent_away, (unsigned long long)ln.route_rounds, (unsigned long long)ln.lookups_answered);
+                reads += ln.reads; sent += ln.lookups_sent; away += ln.lookups_sent_away;
+            }
+            fprintf(stderr, "pass 2 routed: %.1f bytes a read crossed between lanes (%d-byte keys out, 8-byte node words back; %.1f lookups a read, %.0f %% of them of another lane)\n",
+                    reads ? (double)away * (d->nw * 8 + 8) / (double)reads : 0.0, d->nw * 8, reads ? (double)sent / (double)reads : 0.0, sent ? 100.0 * (double)away / (double)sent : 0.0);
+        } else fprintf(stderr, "pass 2 direct: every lane probed the peer-mapped sets itself (about %d of %d probes remote)\n", (int)d->lanes.size() - 1, (int)d->lanes.size());
+    }
     if (c[1]) { pg_set_error("pass 2: " + std::to_string(c[1]) + " k-mer(s) of the reads are not in the sets"); return PG_EINVAL; }
     if (c[2]) { pg_set_error("pass 2: pre-arc table overflow"); return PG_ENOMEM; }
     if (c[5]) { pg_set_error("pass 2: edge id out of range"); return PG_EINVAL; }

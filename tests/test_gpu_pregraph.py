@@ -611,8 +611,48 @@ def test_cli_sharded_matches_reference_files(golden, tmp_path, name, devices):
         assert max(l[1] for l in lanes) <= n_reads / n_ranks + 2 * 7000, lanes
         owners = min(P, n_ranks)
         assert sum(1 for l in lanes if l[3] > 0) == owners, lanes              # a lane that owns a set scanned it; a lane that owns none scanned nothing
+        # ... and pass 2's LOOKUPS go to the sets' owners (the routed form: keys out, node words back, the owner probes its own HBM)
+        routed = [(int(m.group(1)), int(m.group(2)), int(m.group(3))) for m in
+                  re.finditer(r"pass 2 routed, lane of device \d+: asked (\d+) lookup\(s\), (\d+) of them of other lanes, in \d+ round\(s\); answered (\d+) from its own sets; 0 probes of peer-mapped sets", log)]
+        assert len(routed) == n_ranks, log[-3000:]
+        assert sum(r[0] for r in routed) == sum(r[2] for r in routed) > 0
+        assert sum(1 for r in routed if r[2] > 0) == owners, routed            # exactly the owners answered
         want = golden["md5"][t]
         for ext in ("kmerFreq", "preGraphBasic", "vertex", "preArc", "path", "markOnEdge"):
+            assert md5_file(pre + "." + ext) == want[ext], (t, ext)
+        assert md5_gz_text(pre + ".edge.gz") == want["edge"], t
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("route", ["1", "0"], ids=["routed", "peer-probes"])
+@pytest.mark.parametrize("name", ["m60k_k63", "t6k_k127", "t5k_k24"])
+def test_cli_sharded_pass2_lookups_routed_to_the_owners(golden, tmp_path, name, route):
+    """Pass 2 of a sharded run without -R, so that the routed form runs in full rounds (a batch on every lane, all lanes cutting,
+    answering and threading at once): every k-mer of every read of K + 1 bases and more is looked up exactly once, by the lane that owns
+    its set; SOAPDENOVO2_AMD_P2_ROUTE=0 is the A/B form (every lane probes the peer-mapped sets itself).  Same files either way.
+    (prlRead2path.c:159-248: every read one worker, every set one owner.)"""
+    import re
+    c = golden["cases"][name]
+    cfg = case_config(c, str(tmp_path), name)
+    for run in c["runs"]:
+        P, D, a, m = run
+        t = case_tag(name, run)
+        pre = str(tmp_path / t)
+        env = dict(PARALLEL_PARSE, SOAPDENOVO2_AMD_DEVICES="0,0,0", PG_HOST_VERBOSE="1", SOAPDENOVO2_AMD_BATCH_READS="5000", SOAPDENOVO2_AMD_P2_ROUTE=route)
+        log = _run_cli(cfg, c["K"], pre, P, D, a, m, extra_env=env)
+        if route == "1":
+            routed = [(int(x.group(1)), int(x.group(2)), int(x.group(3)), int(x.group(4))) for x in
+                      re.finditer(r"pass 2 routed, lane of device \d+: asked (\d+) lookup\(s\), (\d+) of them of other lanes, in (\d+) round\(s\); answered (\d+) from its own sets; 0 probes of peer-mapped sets", log)]
+            assert len(routed) == 3, log[-3000:]
+            assert sum(r[0] for r in routed) == sum(r[3] for r in routed) > 0
+            if "N" in c and "L" in c:                                      # uniform reads: N x (L - K + 1) lookups in all
+                Ke = c["K"] + (1 - c["K"] % 2)                              # (pregraph.c:71-97: an even K becomes K + 1)
+                assert sum(r[0] for r in routed) == c["N"] * (c["L"] - Ke + 1), routed
+            assert "bytes a read crossed between lanes" in log
+        else:
+            assert "pass 2 direct: every lane probed the peer-mapped sets itself" in log and "pass 2 routed" not in log
+        want = golden["md5"][t]
+        for ext in ("kmerFreq", "preGraphBasic", "vertex", "preArc"):
             assert md5_file(pre + "." + ext) == want[ext], (t, ext)
         assert md5_gz_text(pre + ".edge.gz") == want["edge"], t
 
