@@ -94,6 +94,9 @@ struct HostBackend {
     template <typename T> void to_host_at(int, T* dst, const T* src, size_t n) { to_host(dst, src, n); }
     template <typename T> void gather_at(int, T* dst_lead, const T* src_place, size_t n) { copy(dst_lead, src_place, n); }
     template <typename F> void launch_at(int, uint64_t n, F f) { launch(n, f); }
+    template <typename F> void launch_walks_at(int pl, uint64_t n, F f) { launch(n, f); if (pl >= 0 && pl < 8) walks_at[pl] += n; }
+    template <typename V> V view_at(int, V v) const { return v; }
+    uint64_t walks_at[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // append the values f(i) != ~0, i in [0, n), to `list` (any order), counting them all in *cnt
     template <typename F> void append_at(int, uint64_t n, F f, unsigned long long* list, unsigned long long* cnt, unsigned long long cap) {
         launch(n, [=](uint64_t i) {

@@ -82,7 +82,18 @@ struct HipBackend {
     std::vector<Place> place;
     std::vector<int> set_place;
     std::vector<uint64_t> launches_at;            // launches per place, for the verbose lines and the tests
-    void use_places(const std::vector<Place>& pl, const std::vector<int>& of_set) { place = pl; set_place = of_set; launches_at.assign(pl.size(), 0); }
+    std::vector<uint64_t> walks_at;               // walks dealt to a place (launch_walks_at)
+    // the set geometry and the CRC table as a place reads them: its own copies when it is another GPU than the lead (a walk looks both up at
+    // every step; through the lead's memory every step would cross xGMI twice more)
+    struct PlaceView { const uint64_t* geo; const uint32_t* crc_tab; };
+    std::vector<PlaceView> place_view;
+    void use_places(const std::vector<Place>& pl, const std::vector<int>& of_set, const std::vector<PlaceView>& views = {}) {
+        place = pl; set_place = of_set; place_view = views; launches_at.assign(pl.size(), 0); walks_at.assign(pl.size(), 0);
+    }
+    template <typename V> V view_at(int pl, V v) const {
+        if (pl < (int)place_view.size() && place_view[pl].geo) { v.geo = place_view[pl].geo; v.crc_tab = place_view[pl].crc_tab; }
+        return v;
+    }
     int n_places() const { return place.empty() ? 1 : (int)place.size(); }
     int place_of_set(int s) const { return place.empty() || s >= (int)set_place.size() ? 0 : set_place[s]; }
     int dev_at(int pl) const { return place.empty() ? device : place[pl].device; }
@@ -120,6 +131,16 @@ struct HipBackend {
         hipLaunchKernelGGL(be_launch_kernel<F>, dim3(grid), dim3(256), 0, stream_at(pl), n, f);
         ok(hipGetLastError(), "launch (at a place)");
         if (pl < (int)launches_at.size()) launches_at[pl]++;
+        (void)hipSetDevice(device);
+    }
+    // walks dealt to a place: lane q of the launch calls f(q) (the caller's share starts where it says); counted apart from the per-set scans
+    template <typename F> void launch_walks_at(int pl, uint64_t n, F f) {
+        if (!n || error) return;
+        (void)hipSetDevice(dev_at(pl));
+        const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 1u << 20);
+        hipLaunchKernelGGL(be_launch_kernel<F>, dim3(grid), dim3(256), 0, stream_at(pl), n, f);
+        ok(hipGetLastError(), "launch (walks at a place)");
+        if (pl < (int)walks_at.size()) walks_at[pl] += n;
         (void)hipSetDevice(device);
     }
     // append the values f(i) != ~0, i in [0, n), to `list` at place pl (any order), counting them in *cnt (memory of that place)

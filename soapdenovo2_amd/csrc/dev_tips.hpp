@@ -377,7 +377,11 @@ int tip_scan(BE& be, const SetsView& view, const SetsGeo& geo, int cut_len, bool
     unsigned long long* spawn = be.template alloc<unsigned long long>(spawn_cap);
     int rc = PG_OK;
     uint64_t n_cand = n_init;
+    const int NPL = be.n_places();
+    std::vector<unsigned long long*> pl_counters(NPL, nullptr);
+    if (NPL > 1) for (int pl = 0; pl < NPL; pl++) pl_counters[pl] = be.template alloc_at<unsigned long long>(pl, 12);
     auto cleanup = [&]() {
+        for (int pl = 0; pl < NPL; pl++) be.release_at(pl, pl_counters[pl]);
         be.release(t.c_slot); be.release(t.c_ab); be.release(t.c_started); be.release(t.c_prev); be.release(t.c_far); be.release(t.c_flags);
         be.release(t.c_dir); be.release(t.c_first); be.release(t.c_action); be.release(t.cmap.key); be.release(t.cmap.val);
         be.release(t.bl.key); be.release(t.bl.val); be.release(t.bl_ab); be.release(k1); be.release(k2); be.release(v1); be.release(v2);
@@ -411,7 +415,28 @@ int tip_scan(BE& be, const SetsView& view, const SetsGeo& geo, int cut_len, bool
         const bool use_bl = any_bl;
         const uint64_t n = n_cand;
         be.fill(counters + 1, 11, 0ULL);
-        // 1. walks that are missing or stale
+        // 1. walks that are missing or stale.  A walk is a lane a candidate and crosses sets by nature (the next k-mer hashes anywhere): with
+        //    several places the candidates are dealt to them in equal shares -- every GPU of a sharded run walks its share against the
+        //    peer-mapped sets, the state arrays stay the lead's (streamed through the peer mapping), every place counts into counters of its own
+        //    (cutTipPreGraph.c:363-488 gives the scan to thrd_num workers the same way: each its own sets, the walks wherever they lead)
+        if (NPL > 1) {
+            be.sync();                                               // what the lead wrote for this round is in place
+            for (int pl = 0; pl < NPL; pl++) {
+                const uint64_t first = n * (uint64_t)pl / (uint64_t)NPL, count = n * (uint64_t)(pl + 1) / (uint64_t)NPL - first;
+                TipState tp = tt;
+                tp.view = be.view_at(pl, tt.view);
+                tp.counters = pl_counters[pl];
+                be.fill_at(pl, pl_counters[pl], 12, 0ULL);
+                be.launch_walks_at(pl, count, [=] PG_LAMBDA(uint64_t q) {
+                    const uint64_t i = first + q;
+                    if (!tp.c_started[i]) return;
+                    const unsigned int fl = tp.c_flags[i];
+                    if ((fl & CF_WALKED) && !(fl & (CF_VIA_BL | CF_REWALK)) && tp.c_dir[i] == tip_dir(tp.c_ab[i])) return;
+                    tip_walk_candidate<NW>(tp, i, use_bl);
+                });
+            }
+            be.sync_places();
+        } else
         be.launch(n, [=] PG_LAMBDA(uint64_t i) {
             if (!tt.c_started[i]) return;
             const unsigned int fl = tt.c_flags[i];
@@ -444,6 +469,11 @@ int tip_scan(BE& be, const SetsView& view, const SetsGeo& geo, int cut_len, bool
             if (tt.c_action[i]) hd_atomic_add(&tt.counters[3], 1ULL);
         });
         be.to_host(h_cnt, counters, 12);
+        for (int pl = 0; pl < NPL && NPL > 1 && !be.error; pl++) {       // what the places' walks counted: errors (4) and walks that ended elsewhere (6)
+            unsigned long long pc[12];
+            be.to_host_at(pl, pc, pl_counters[pl], 12);
+            h_cnt[4] += pc[4]; h_cnt[6] += pc[6];
+        }
         if (be.error) break;
         if (h_cnt[4]) { rc = PG_EINVAL; be.error_text = "Kmer is not found while clipping a tip."; break; }
         if (h_cnt[5] >= bl_cap) { rc = PG_ENOMEM; be.error_text = "tips: too many nodes turned linear in one scan"; break; }

@@ -53,6 +53,12 @@ namespace pg {
         }                                                                                                    \
     } while (0)
 
+// a copy between two devices of the process (or inside one)
+static hipError_t p2r_copy(void* dst, int dst_dev, const void* src, int src_dev, size_t bytes, hipStream_t st) {
+    if (!bytes) return hipSuccess;
+    if (dst_dev == src_dev) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
+    return hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, st);
+}
 constexpr uint64_t P2_EMPTY = ~0ULL;
 constexpr int P2_MAX_SETS = 255;
 
@@ -529,10 +535,11 @@ __global__ __launch_bounds__(256) void eb_list_branch(const uint64_t* nodes, int
 
 // the segment that leaves waypoint list[t / 2] forward (t even) or backward: to the next waypoint or branch node
 template <int NW>
-__global__ __launch_bounds__(256) void eb_way_walk(P2Params p, EbWay way, const unsigned long long* list, uint64_t n, unsigned long long* errors) {
+__global__ __launch_bounds__(256) void eb_way_walk(P2Params p, EbWay way, const unsigned long long* list, uint64_t t0, uint64_t n_share, unsigned long long* errors) {
     P2_PROLOGUE(p);
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 2 * n) return;
+    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // this launch's share of the 2 n (waypoint, direction) pairs: [t0, t0 + n_share)
+    if (q >= n_share) return;
+    const uint64_t t = t0 + q;
     const uint64_t g0 = list[t >> 1];
     const int d = (int)(t & 1);
     const uint64_t h = eb_way_find(way, g0);
@@ -569,11 +576,12 @@ __global__ __launch_bounds__(256) void eb_way_walk(P2Params p, EbWay way, const 
 }
 
 template <int NW>
-__global__ __launch_bounds__(256) void eb_walk(P2Params p, const unsigned long long* list, uint64_t n_list, EdgeRec* out, uint64_t cap,
+__global__ __launch_bounds__(256) void eb_walk(P2Params p, const unsigned long long* list, uint64_t t0, uint64_t n_share, EdgeRec* out, uint64_t cap,
                                                unsigned long long* n_out, unsigned long long* n_len1, unsigned long long* errors, EbWay way) {
     P2_PROLOGUE(p);
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= n_list * 8) return;
+    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // this launch's share of the 8 n_list (vertex, arc) pairs: [t0, t0 + n_share)
+    if (q >= n_share) return;
+    const uint64_t t = t0 + q;
     const uint64_t slot0 = list[t >> 3];
     const int order = (int)(t & 7);
     const uint64_t* nd0 = sv_node<NW>(sv, slot0);
@@ -672,10 +680,12 @@ __global__ void eb_export(const EdgeRec* recs, const uint32_t* order, const unsi
 // the segment behind a waypoint a kept walk passed: bases and tags as eb_apply writes them, at the walk's text offset and with its id
 template <int NW>
 __global__ __launch_bounds__(256) void eb_apply_seg(P2Params p, EbWay way, const EdgeRec* recs, const uint32_t* order, const unsigned long long* sorted_key, uint64_t n_rec,
-                                                    const unsigned long long* id_before, const unsigned long long* base_before, char* text, unsigned long long* errors) {
+                                                    const unsigned long long* id_before, const unsigned long long* base_before, char* text, unsigned long long* errors,
+                                                    uint64_t t0, uint64_t n_share) {
     P2_PROLOGUE(p);
-    const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= 2 * (way.mask + 1)) return;
+    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // this launch's share of the table's 2 (mask + 1) entries
+    if (q >= n_share) return;
+    const uint64_t t = t0 + q;
     const unsigned long long own = way.vis_own[t];
     if (own == ~0ULL) return;
     // the walk's record, if it was kept (binary search over the records' keys in slot order)
@@ -719,12 +729,13 @@ __global__ __launch_bounds__(256) void eb_apply_seg(P2Params p, EbWay way, const
 }
 
 template <int NW>
-__global__ __launch_bounds__(256) void eb_apply(P2Params p, const EdgeRec* recs, const uint32_t* order, uint64_t n,
+__global__ __launch_bounds__(256) void eb_apply(P2Params p, const EdgeRec* recs, const uint32_t* order, uint64_t i0, uint64_t n_share,
                                                 const unsigned long long* id_before, const unsigned long long* base_before, char* text,
                                                 uint64_t* patch_keys, uint32_t* patch_val, uint64_t patch_mask, unsigned long long* errors, EbWay way) {
     P2_PROLOGUE(p);
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const uint64_t q = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;      // this launch's share of the kept walks (in slot order): [i0, i0 + n_share)
+    if (q >= n_share) return;
+    const uint64_t i = i0 + q;
     const EdgeRec r = recs[order[i]];
     const int K = p.K;
     const Kmer<NW> filter = kmer_filter<NW>(K);
@@ -776,7 +787,9 @@ __global__ __launch_bounds__(256) void eb_apply(P2Params p, const EdgeRec* recs,
         const uint32_t pid = sm ? id : id + bal, ptwin = sm ? bal + 1 : 1 - bal;
         uint64_t h = kmer_mix<NW>(key) & patch_mask;
         for (;;) {
-            const unsigned int old = atomicCAS(&patch_val[2 * h], 0u, pid);
+            // (system scope: in a sharded run the walks are dealt to all lanes, and the table is the lead's)
+            unsigned int old = 0u;
+            (void)__hip_atomic_compare_exchange_strong(&patch_val[2 * h], &old, pid, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (old == 0) {
 #pragma unroll
                 for (int k = 0; k < NW; k++) patch_keys[h * NW + k] = key.w[k];
@@ -916,6 +929,8 @@ struct P2Lane {
     bool tables = false;                             // the pass-2 tables below exist
     P2Params prm;
     uint64_t* d_geo3 = nullptr;                      // copies on this lane's device (lane 0 and lanes on the lead's device: the lead's own)
+    uint32_t* d_crc = nullptr;                       // (made by p2_use_lanes: the walks of the tip and edge stages run on every lane too)
+    unsigned long long* d_wcnt = nullptr;            // [4] this lane's counters of a dealt step: -, kept walks, length-1 walks, errors
     uint64_t* d_patch_keys = nullptr;
     uint32_t* d_patch_val = nullptr;
     bool own_geo = false, own_patch = false;
@@ -984,7 +999,8 @@ static void p2_free(P2Device* d) {
     for (size_t l = 0; l < d->lanes.size(); l++) {
         P2Lane& ln = d->lanes[l];
         (void)hipSetDevice(ln.device);
-        if (ln.own_geo) pg::arena_free(ln.d_geo3);
+        if (ln.own_geo) { pg::arena_free(ln.d_geo3); pg::arena_free(ln.d_crc); }
+        pg::arena_free(ln.d_wcnt);
         if (ln.own_patch) { pg::arena_free(ln.d_patch_keys); pg::arena_free(ln.d_patch_val); }
         pg::arena_free(ln.d_arc_key); pg::arena_free(ln.d_arc_cnt); pg::arena_free(ln.d_arc_first);
         if (l) pg::arena_free(ln.d_counters);
@@ -1081,6 +1097,35 @@ int p2_use_lanes(P2Device* d, const int* lane_devices, int n_lanes) {
         if (rc) return rc;
     }
     for (int s = 0; s < d->P; s++) d->set_lane[s] = s % n_lanes;
+    // a lane on another GPU than the lead reads the set geometry and the CRC table from copies of its own
+    for (int l = 0; l < n_lanes; l++) {
+        P2Lane& ln = d->lanes[l];
+        P2_HIP(hipSetDevice(ln.device));
+        P2_HIP(pg::arena_malloc((void**)&ln.d_wcnt, 4 * sizeof(unsigned long long)));
+        if (ln.device == d->device) continue;
+        const size_t gb = (size_t)SV_GEO * d->P * sizeof(uint64_t);
+        P2_HIP(pg::arena_malloc((void**)&ln.d_geo3, gb)); ln.own_geo = true;
+        P2_HIP(pg::arena_malloc((void**)&ln.d_crc, 256 * sizeof(uint32_t)));
+        P2_HIP(hipMemcpyPeerAsync(ln.d_geo3, ln.device, d->d_geo3, d->device, gb, ln.stream));
+        P2_HIP(hipMemcpyPeerAsync(ln.d_crc, ln.device, d->d_crc, d->device, 256 * sizeof(uint32_t), ln.stream));
+        P2_HIP(hipStreamSynchronize(ln.stream));
+    }
+    P2_HIP(hipSetDevice(d->device));
+    return PG_OK;
+}
+// the graph's parameters as lane l reads them (the set geometry from its own copy), and an equal share of n work items for every lane
+static P2Params p2_lane_params(const P2Device* d, size_t l) {
+    P2Params p = d->prm;
+    if (l < d->lanes.size() && d->lanes[l].own_geo) p.geo3 = d->lanes[l].d_geo3;
+    return p;
+}
+static void p2_share(const P2Device* d, size_t l, uint64_t n, uint64_t& first, uint64_t& count) {
+    const uint64_t N = d->lanes.size();
+    first = n * l / N;
+    count = n * (l + 1) / N - first;
+}
+static int p2_sync_lanes(P2Device* d) {
+    for (P2Lane& ln : d->lanes) { P2_HIP(hipSetDevice(ln.device)); P2_HIP(hipStreamSynchronize(ln.stream)); }
     P2_HIP(hipSetDevice(d->device));
     return PG_OK;
 }
@@ -1446,7 +1491,7 @@ int p2_begin_reads(P2Device* d, uint32_t num_ed, bool reps) {
         ln.prm = d->prm;
         if (ln.device != d->device) {
             const size_t gb = (size_t)SV_GEO * d->P * sizeof(uint64_t), kb = patch_cap * d->nw * sizeof(uint64_t), vb = patch_cap * 2 * sizeof(uint32_t);
-            P2_HIP(pg::arena_malloc((void**)&ln.d_geo3, gb)); ln.own_geo = true;
+            if (!ln.own_geo) { P2_HIP(pg::arena_malloc((void**)&ln.d_geo3, gb)); ln.own_geo = true; }
             P2_HIP(pg::arena_malloc((void**)&ln.d_patch_keys, kb)); ln.own_patch = true;
             P2_HIP(pg::arena_malloc((void**)&ln.d_patch_val, vb));
             P2_HIP(hipMemcpyPeerAsync(ln.d_geo3, ln.device, d->d_geo3, d->device, gb, ln.stream));
@@ -1605,13 +1650,17 @@ int p2_clip_tips(P2Device* d, bool cut_single, P2TipTotals& out) {
     HipBackend be(d->device, d->stream);
     if (d->lanes.size() > 1) {                                       // the scans over a set's slots run on the lane that owns the set
         std::vector<HipBackend::Place> pl;
-        for (auto& ln : d->lanes) pl.push_back(HipBackend::Place{ln.device, ln.stream});
-        be.use_places(pl, d->set_lane);
+        std::vector<HipBackend::PlaceView> pv;
+        for (auto& ln : d->lanes) {
+            pl.push_back(HipBackend::Place{ln.device, ln.stream});
+            pv.push_back(ln.own_geo && ln.d_crc ? HipBackend::PlaceView{ln.d_geo3, ln.d_crc} : HipBackend::PlaceView{nullptr, nullptr});
+        }
+        be.use_places(pl, d->set_lane, pv);
     }
     TipTotals tot;
     rc = d->nw == 2 ? clip_tips<HipBackend, 2>(be, view, geo, cut_single, tot) : clip_tips<HipBackend, 4>(be, view, geo, cut_single, tot);
     if (rc) { pg_set_error(be.error_text.empty() ? "tip clipping on the device failed" : be.error_text); return rc; }
-    for (size_t l = 0; l < be.launches_at.size() && l < d->lanes.size(); l++) d->lanes[l].scans += be.launches_at[l];
+    for (size_t l = 0; l < be.launches_at.size() && l < d->lanes.size(); l++) { d->lanes[l].scans += be.launches_at[l]; d->lanes[l].walks += be.walks_at[l]; }
     out.single = tot.single; out.minor = tot.minor; out.cycles = tot.minor_cycles; out.rounds = tot.rounds;
     out.per_cycle.assign(tot.per_cycle.begin(), tot.per_cycle.end());
     return PG_OK;
@@ -1741,7 +1790,19 @@ int p2_build_edges(P2Device* d, P2Edges& out) {
     way.period_mask = 0xFFFFFFFFu;
     unsigned long long *d_way = nullptr, *d_wcnt = nullptr;
     unsigned long long total_ids = 0, total_bases = 0, last_ids = 0, last_bases = 0, last_idb = 0, last_bb = 0;
+    const size_t NL = d->lanes.size();
+    std::vector<EdgeRec*> lane_recs(NL, nullptr);
+    std::vector<uint64_t> lane_cap(NL, 0);
+    std::vector<unsigned long long> lane_cnt(4 * NL, 0);
     if (hipSetDevice(d->device) != hipSuccess) { pg_set_error("edges: hipSetDevice failed"); return PG_ENODEV; }
+    for (size_t l = 0; l < NL; l++) {                                     // the lanes' counters of this stage (lane 0's d_wcnt exists from p2_use_lanes on, or now)
+        P2Lane& ln = d->lanes[l];
+        P2_HIP_GOTO(hipSetDevice(ln.device));
+        if (!ln.d_wcnt) P2_HIP_GOTO(pg::arena_malloc((void**)&ln.d_wcnt, 4 * sizeof(unsigned long long)));
+        P2_HIP_GOTO(hipMemsetAsync(ln.d_wcnt, 0, 4 * sizeof(unsigned long long), ln.stream));
+        P2_HIP_GOTO(hipStreamSynchronize(ln.stream));
+    }
+    P2_HIP_GOTO(hipSetDevice(d->device));
     P2_HIP_GOTO(pg::arena_malloc((void**)&d_cnt, 4 * sizeof(unsigned long long)));
     P2_HIP_GOTO(hipMemsetAsync(d_cnt, 0, 4 * sizeof(unsigned long long), st));
     if (d->d_vlist) {                                            // listed for <prefix>.vertex a moment ago (nothing changed a flag since)
@@ -1788,10 +1849,22 @@ int p2_build_edges(P2Device* d, P2Edges& out) {
                 P2_HIP_GOTO(pg::arena_malloc((void**)&way.vis_info, 2 * cap_m * sizeof(unsigned int)));
                 P2_HIP_GOTO(hipMemsetAsync(way.key, 0, cap_m * sizeof(unsigned long long), st));
                 hipLaunchKernelGGL(eb_way_insert, dim3(1024), dim3(256), 0, st, way, d_way, n_way);
-                const dim3 grid((unsigned)((2 * n_way + 255) / 256));
-                if (d->nw == 2) hipLaunchKernelGGL(eb_way_walk<2>, grid, dim3(256), 0, st, d->prm, way, d_way, n_way, d_cnt + 3);
-                else hipLaunchKernelGGL(eb_way_walk<4>, grid, dim3(256), 0, st, d->prm, way, d_way, n_way, d_cnt + 3);
-                P2_HIP_GOTO(hipGetLastError());
+                // the segment walks: every lane an equal share (the table, the list and what the walks write are the lead's, read and written
+                // through the peer mapping; the walk itself probes sets everywhere, whoever runs it)
+                P2_HIP_GOTO(hipStreamSynchronize(st));
+                for (size_t l = 0; l < NL; l++) {
+                    P2Lane& ln = d->lanes[l];
+                    uint64_t t0, cnt_l;
+                    p2_share(d, l, 2 * n_way, t0, cnt_l);
+                    if (!cnt_l) continue;
+                    P2_HIP_GOTO(hipSetDevice(ln.device));
+                    const dim3 grid((unsigned)((cnt_l + 255) / 256));
+                    if (d->nw == 2) hipLaunchKernelGGL(eb_way_walk<2>, grid, dim3(256), 0, ln.stream, p2_lane_params(d, l), way, d_way, t0, cnt_l, ln.d_wcnt + 3);
+                    else hipLaunchKernelGGL(eb_way_walk<4>, grid, dim3(256), 0, ln.stream, p2_lane_params(d, l), way, d_way, t0, cnt_l, ln.d_wcnt + 3);
+                    P2_HIP_GOTO(hipGetLastError());
+                    ln.walks += cnt_l;
+                }
+                if ((rc = p2_sync_lanes(d)) != PG_OK) goto done;
             }
         }
     }
@@ -1799,23 +1872,54 @@ int p2_build_edges(P2Device* d, P2Edges& out) {
     // room for five walks a vertex, and a second go with room for all eight should that ever be short
     if (n_list * 8 / 256 >= 0x7FFFFFFFULL) { pg_set_error("edges: too many vertices for one launch"); rc = PG_EINVAL; goto done; }
     for (int attempt = 0; attempt < 2; attempt++) {
-        cap_rec = n_list * (attempt ? 8 : 5) + 1024;
-        pg::arena_free(d_recs); d_recs = nullptr;
-        P2_HIP_GOTO(pg::arena_malloc((void**)&d_recs, cap_rec * sizeof(EdgeRec)));
-        P2_HIP_GOTO(hipMemsetAsync(d_cnt + 1, 0, 2 * sizeof(unsigned long long), st));      // (the error counter stays: the segment walks may have used it)
+        // every lane walks an equal share of the (vertex, arc) pairs into records and counters of its own; the lead gathers the records
+        bool short_of_room = false;
+        P2_HIP_GOTO(hipSetDevice(d->device));
         if (way.key) P2_HIP_GOTO(hipMemsetAsync(way.vis_own, 0xFF, 2 * (way.mask + 1) * sizeof(unsigned long long), st));
-        if (n_list) {
-            const dim3 grid((unsigned)((n_list * 8 + 255) / 256));
-            if (d->nw == 2) hipLaunchKernelGGL(eb_walk<2>, grid, dim3(256), 0, st, d->prm, d_list, n_list, d_recs, cap_rec, d_cnt + 1, d_cnt + 2, d_cnt + 3, way);
-            else hipLaunchKernelGGL(eb_walk<4>, grid, dim3(256), 0, st, d->prm, d_list, n_list, d_recs, cap_rec, d_cnt + 1, d_cnt + 2, d_cnt + 3, way);
-            P2_HIP_GOTO(hipGetLastError());
-        }
-        P2_HIP_GOTO(hipMemcpyAsync(cnt, d_cnt, sizeof(cnt), hipMemcpyDeviceToHost, st));
         P2_HIP_GOTO(hipStreamSynchronize(st));
+        for (size_t l = 0; l < NL; l++) {
+            P2Lane& ln = d->lanes[l];
+            uint64_t t0, cnt_l;
+            p2_share(d, l, n_list * 8, t0, cnt_l);
+            lane_cap[l] = cnt_l / 8 * (attempt ? 8 : 5) + (attempt ? 8 : 5) + 1024;
+            P2_HIP_GOTO(hipSetDevice(ln.device));
+            pg::arena_free(lane_recs[l]); lane_recs[l] = nullptr;
+            P2_HIP_GOTO(pg::arena_malloc((void**)&lane_recs[l], lane_cap[l] * sizeof(EdgeRec)));
+            P2_HIP_GOTO(hipMemsetAsync(ln.d_wcnt, 0, 3 * sizeof(unsigned long long), ln.stream));      // (the error counter stays: the segment walks may have used it)
+            if (cnt_l) {
+                const dim3 grid((unsigned)((cnt_l + 255) / 256));
+                if (d->nw == 2) hipLaunchKernelGGL(eb_walk<2>, grid, dim3(256), 0, ln.stream, p2_lane_params(d, l), d_list, t0, cnt_l, lane_recs[l], lane_cap[l], ln.d_wcnt + 1, ln.d_wcnt + 2, ln.d_wcnt + 3, way);
+                else hipLaunchKernelGGL(eb_walk<4>, grid, dim3(256), 0, ln.stream, p2_lane_params(d, l), d_list, t0, cnt_l, lane_recs[l], lane_cap[l], ln.d_wcnt + 1, ln.d_wcnt + 2, ln.d_wcnt + 3, way);
+                P2_HIP_GOTO(hipGetLastError());
+                ln.walks += cnt_l;
+            }
+            P2_HIP_GOTO(hipMemcpyAsync(&lane_cnt[4 * l], ln.d_wcnt, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ln.stream));
+        }
+        if ((rc = p2_sync_lanes(d)) != PG_OK) goto done;
+        cnt[1] = cnt[2] = cnt[3] = 0;
+        for (size_t l = 0; l < NL; l++) {
+            cnt[1] += lane_cnt[4 * l + 1]; cnt[2] += lane_cnt[4 * l + 2]; cnt[3] += lane_cnt[4 * l + 3];
+            if (lane_cnt[4 * l + 1] > lane_cap[l]) short_of_room = true;
+        }
         if (cnt[3]) { pg_set_error("Kmer is not found while building an edge."); rc = PG_EINVAL; goto done; }
         n_rec = cnt[1];
-        if (n_rec <= cap_rec) break;
+        cap_rec = n_rec;
+        if (!short_of_room) break;
+        if (attempt) { cap_rec = 0; break; }
     }
+    if (n_rec && cap_rec) {                                               // the lanes' records, one behind the other (the sort below puts them in slot order)
+        P2_HIP_GOTO(hipSetDevice(d->device));
+        P2_HIP_GOTO(pg::arena_malloc((void**)&d_recs, n_rec * sizeof(EdgeRec)));
+        uint64_t at = 0;
+        for (size_t l = 0; l < NL; l++) {
+            const uint64_t c = lane_cnt[4 * l + 1];
+            if (c) P2_HIP_GOTO(p2r_copy(d_recs + at, d->device, lane_recs[l], d->lanes[l].device, c * sizeof(EdgeRec), st));
+            at += c;
+        }
+        P2_HIP_GOTO(hipStreamSynchronize(st));
+    }
+    for (size_t l = 0; l < NL; l++) { (void)hipSetDevice(d->lanes[l].device); pg::arena_free(lane_recs[l]); lane_recs[l] = nullptr; }
+    P2_HIP_GOTO(hipSetDevice(d->device));
     if (n_rec > cap_rec) { pg_set_error("edges: more walks than arcs"); rc = PG_EINVAL; goto done; }
     if (n_rec >= 0x7FFFFFFFULL) { pg_set_error("edges: more than 2^31 - 1 edge records"); rc = PG_EINVAL; goto done; }
     while (patch_cap < 2 * cnt[2] + 2) patch_cap <<= 1;
@@ -1856,18 +1960,35 @@ int p2_build_edges(P2Device* d, P2Edges& out) {
         if (total_ids >= 0xFFFFFFFFULL) { pg_set_error("edges: edge ids exceed 32 bits"); rc = PG_EINVAL; goto done; }
         P2_HIP_GOTO(pg::arena_malloc((void**)&d_text, std::max<unsigned long long>(total_bases, 1)));
         {
-            const dim3 grid((unsigned)((n_rec + 255) / 256));
-            if (d->nw == 2) hipLaunchKernelGGL(eb_apply<2>, grid, dim3(256), 0, st, d->prm, d_recs, d_order, n_rec, d_id_before, d_base_before, d_text,
-                                               d->d_patch_keys, d->d_patch_val, patch_cap - 1, d_cnt + 3, way);
-            else hipLaunchKernelGGL(eb_apply<4>, grid, dim3(256), 0, st, d->prm, d_recs, d_order, n_rec, d_id_before, d_base_before, d_text,
-                                    d->d_patch_keys, d->d_patch_val, patch_cap - 1, d_cnt + 3, way);
-            P2_HIP_GOTO(hipGetLastError());
-            if (way.key) {                                              // the segments behind the waypoints the kept walks passed
-                const dim3 gs((unsigned)((2 * (way.mask + 1) + 255) / 256));
-                if (d->nw == 2) hipLaunchKernelGGL(eb_apply_seg<2>, gs, dim3(256), 0, st, d->prm, way, d_recs, d_order, d_key2, n_rec, d_id_before, d_base_before, d_text, d_cnt + 3);
-                else hipLaunchKernelGGL(eb_apply_seg<4>, gs, dim3(256), 0, st, d->prm, way, d_recs, d_order, d_key2, n_rec, d_id_before, d_base_before, d_text, d_cnt + 3);
-                P2_HIP_GOTO(hipGetLastError());
+            // the second walk of every kept chain (bases, tags, unlinking), dealt like the first: a lane of the graph an equal share of the walks in
+            // slot order, then of the waypoint table's entries
+            P2_HIP_GOTO(hipStreamSynchronize(st));
+            for (size_t l = 0; l < NL; l++) {
+                P2Lane& ln = d->lanes[l];
+                uint64_t i0, cnt_l;
+                p2_share(d, l, n_rec, i0, cnt_l);
+                P2_HIP_GOTO(hipSetDevice(ln.device));
+                if (cnt_l) {
+                    const dim3 grid((unsigned)((cnt_l + 255) / 256));
+                    if (d->nw == 2) hipLaunchKernelGGL(eb_apply<2>, grid, dim3(256), 0, ln.stream, p2_lane_params(d, l), d_recs, d_order, i0, cnt_l, d_id_before, d_base_before, d_text,
+                                                       d->d_patch_keys, d->d_patch_val, patch_cap - 1, ln.d_wcnt + 3, way);
+                    else hipLaunchKernelGGL(eb_apply<4>, grid, dim3(256), 0, ln.stream, p2_lane_params(d, l), d_recs, d_order, i0, cnt_l, d_id_before, d_base_before, d_text,
+                                            d->d_patch_keys, d->d_patch_val, patch_cap - 1, ln.d_wcnt + 3, way);
+                    P2_HIP_GOTO(hipGetLastError());
+                    ln.walks += cnt_l;
+                }
+                if (way.key) {                                              // the segments behind the waypoints the kept walks passed
+                    uint64_t t0, cnt_s;
+                    p2_share(d, l, 2 * (way.mask + 1), t0, cnt_s);
+                    const dim3 gs((unsigned)((cnt_s + 255) / 256));
+                    if (cnt_s && d->nw == 2) hipLaunchKernelGGL(eb_apply_seg<2>, gs, dim3(256), 0, ln.stream, p2_lane_params(d, l), way, d_recs, d_order, d_key2, n_rec, d_id_before, d_base_before, d_text, ln.d_wcnt + 3, t0, cnt_s);
+                    else if (cnt_s) hipLaunchKernelGGL(eb_apply_seg<4>, gs, dim3(256), 0, ln.stream, p2_lane_params(d, l), way, d_recs, d_order, d_key2, n_rec, d_id_before, d_base_before, d_text, ln.d_wcnt + 3, t0, cnt_s);
+                    P2_HIP_GOTO(hipGetLastError());
+                }
+                P2_HIP_GOTO(hipMemcpyAsync(&lane_cnt[4 * l], ln.d_wcnt, 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost, ln.stream));
             }
+            if ((rc = p2_sync_lanes(d)) != PG_OK) goto done;
+            for (size_t l = 0; l < NL; l++) if (lane_cnt[4 * l + 3]) { pg_set_error("edges: a walk did not repeat itself"); rc = PG_EINVAL; goto done; }
         }
         // what the host needs for the text records: the walks in slot order with their text offsets, and the bases
         {
@@ -1905,11 +2026,6 @@ static int p2r_grow(P2Lane::Buf<T>& b, size_t need) {
     b.cap = need + need / 4 + 64;
     P2_HIP(pg::arena_malloc((void**)&b.p, b.cap * sizeof(T)));
     return PG_OK;
-}
-static hipError_t p2r_copy(void* dst, int dst_dev, const void* src, int src_dev, size_t bytes, hipStream_t st) {
-    if (!bytes) return hipSuccess;
-    if (dst_dev == src_dev) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, st);
-    return hipMemcpyPeerAsync(dst, dst_dev, src, src_dev, bytes, st);
 }
 static int p2_route_round(P2Device* d) {
     const int N = (int)d->lanes.size(), nw = d->nw;
@@ -2131,8 +2247,8 @@ int p2_finish(P2Device* d, P2Result& out) {
     }
     if (pg::env_user("PG_HOST_VERBOSE"))
         for (size_t l = 0; l < d->lanes.size(); l++)
-            fprintf(stderr, "graph lane %zu (device %d): pass 2 threaded %llu read(s) in %llu batch(es), %llu distinct pre-arc(s); %llu per-set scan(s) ran here\n", l, d->lanes[l].device,
-                    (unsigned long long)d->lanes[l].reads, (unsigned long long)d->lanes[l].batches, lane_arcs[l], (unsigned long long)d->lanes[l].scans);
+            fprintf(stderr, "graph lane %zu (device %d): pass 2 threaded %llu read(s) in %llu batch(es), %llu distinct pre-arc(s); %llu per-set scan(s) ran here; %llu tip / edge walk(s) ran here\n", l, d->lanes[l].device,
+                    (unsigned long long)d->lanes[l].reads, (unsigned long long)d->lanes[l].batches, lane_arcs[l], (unsigned long long)d->lanes[l].scans, (unsigned long long)d->lanes[l].walks);
     if (pg::env_user("PG_HOST_VERBOSE") && d->lanes.size() > 1) {
         if (d->route) {
             unsigned long long reads = 0, sent = 0, away = 0;

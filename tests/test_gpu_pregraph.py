@@ -601,8 +601,8 @@ def test_cli_sharded_matches_reference_files(golden, tmp_path, name, devices):
         # the graph stages' COMPUTE is sharded too: every rank is a lane of the graph -- pass 2 deals its read batches to the lanes in
         # turn (each threads about 1 / n_ranks of the reads against the peer-mapped sets, own pre-arc table, merged at the end) and the
         # scans over a set's slots run on the lane that owns the set
-        lanes = [(int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4))) for m in
-                 re.finditer(r"graph lane (\d+) \(device \d+\): pass 2 threaded (\d+) read\(s\) in (\d+) batch\(es\), \d+ distinct pre-arc\(s\); (\d+) per-set scan", log)]
+        lanes = [(int(m.group(1)), int(m.group(2)), int(m.group(3)), int(m.group(4)), int(m.group(5))) for m in
+                 re.finditer(r"graph lane (\d+) \(device \d+\): pass 2 threaded (\d+) read\(s\) in (\d+) batch\(es\), \d+ distinct pre-arc\(s\); (\d+) per-set scan\(s\) ran here; (\d+) tip / edge walk", log)]
         assert [l[0] for l in lanes] == list(range(n_ranks)), log[-3000:]
         n_reads = sum(l[1] for l in lanes)
         assert n_reads == c["N"]
@@ -611,6 +611,9 @@ def test_cli_sharded_matches_reference_files(golden, tmp_path, name, devices):
         assert max(l[1] for l in lanes) <= n_reads / n_ranks + 2 * 7000, lanes
         owners = min(P, n_ranks)
         assert sum(1 for l in lanes if l[3] > 0) == owners, lanes              # a lane that owns a set scanned it; a lane that owns none scanned nothing
+        # the WALKS of the tip and edge stages (a lane a candidate, crossing sets by nature) are dealt to the lanes in equal shares
+        walks = [l[4] for l in lanes]
+        assert min(walks) > 0 and max(walks) <= sum(walks) / n_ranks * 1.05 + 64, lanes
         # ... and pass 2's LOOKUPS go to the sets' owners (the routed form: keys out, node words back, the owner probes its own HBM)
         routed = [(int(m.group(1)), int(m.group(2)), int(m.group(3))) for m in
                   re.finditer(r"pass 2 routed, lane of device \d+: asked (\d+) lookup\(s\), (\d+) of them of other lanes, in \d+ round\(s\); answered (\d+) from its own sets; 0 probes of peer-mapped sets", log)]
