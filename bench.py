@@ -60,6 +60,26 @@ def gen_packed_reads(torch, dev, genome_len, n_reads, read_len, err, seed, chunk
     return out
 
 
+def workload_label(n_reads, L, genome, err, K, P, world):
+    """config.workload, built from the arguments; a BASELINE.json config is named only when the arguments ARE that config."""
+    named = {(10_000_000, 100, 4_600_000, 0.005, 31, 1): "BASELINE.json configs[1]", (200_000_000, 150, 100_000_000, 0.001, 63, 1): "BASELINE.json configs[2]",
+             (375_000_000, 150, 3_100_000_000, 0.0005, 63, 8): "BASELINE.json configs[3]: 3 G reads over 8 GPUs", (375_000_000, 150, 3_100_000_000, 0.0005, 127, 8): "BASELINE.json configs[4]: 3 G reads over 8 GPUs"}
+    name = named.get((n_reads, L, genome, err, K, world))
+    return (f"synthetic (SURVEY.md 8d): {n_reads} reads/GPU x {L} bp, genome {genome} bp, err {err}, K={K}, -p {P} sets, {world} GPU(s)"
+            + (f" = {name}" if name else " (not one of BASELINE.json's configs)"))
+
+
+def library_source_sha():
+    """What the counters in profiles/pmc_traffic.json were taken on: a hash of the kernels' sources (csrc/*.hip, *.hpp)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(glob.glob(os.path.join(ROOT, "soapdenovo2_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "soapdenovo2_amd", "csrc", "*.hpp"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def md5_outputs(prefix):
     import gzip
     import hashlib
@@ -144,8 +164,10 @@ def big_command(args):
     (profiles/r0*_ref_*.json): 60 M reads at K = 63 with -a 16 (static pools) and with the default growable sets -- either way the
     k-mer-set layout is made on the device (SURVEY.md App. C "K6": dev_graph.hpp / dev_rehash.hpp); 20 M reads at K = 127 (the
     SOAPdenovo-127mer flavour, configs[4]'s path); configs[2] at its full 200 M reads with -a 40.
-    Returns {"whole_command_60M_a16": {...}, "whole_command_60M": {...}, "whole_command_k127_20M": {...}, "whole_command_200M_a40": {...}}."""
-    groups = [[("whole_command_60M_a16", "r03_ref_60M_K63_a16.json"), ("whole_command_60M", "r03_ref_60M_K63.json")],
+    BASELINE.json configs[1] at its full size (10 M x 100 bp over 4.6 Mb, err 0.005, K = 31, -p 8; the reference: profiles/r05_ref_10M_K31.json).
+    Returns {"whole_command_10M_k31": {...}, "whole_command_60M_a16": {...}, "whole_command_60M": {...}, "whole_command_k127_20M": {...}, "whole_command_200M_a40": {...}}."""
+    groups = [[("whole_command_10M_k31", "r05_ref_10M_K31.json")],
+              [("whole_command_60M_a16", "r03_ref_60M_K63_a16.json"), ("whole_command_60M", "r03_ref_60M_K63.json")],
               [("whole_command_k127_20M", "r04_ref_20M_K127.json")],
               [("whole_command_200M_a40", "r04_ref_200M_K63_a40.json")]]
     gen = os.path.join(ROOT, "soapdenovo2_amd", "bin", "synth_fastq")
@@ -237,11 +259,11 @@ def shutil_free_gb(path):
     return shutil.disk_usage(path).free / 1e9
 
 
-def pass_k127(torch, api, packed, n_reads, L, P, genome, err, batch_reads, device):
-    """configs[4]'s path on the same resident reads: pass 1 with the four-word k-mers of the SOAPdenovo-127mer flavour (K = 127:
-    prlHashReads.c:374-378, kmer.c:532), timed like the headline pass (1 warm-up, 2 timed passes, inputs resident), with the same
-    conservation check on the timed result.  Its algorithmic bytes: 80 B per k-mer occurrence (40-byte node read + write) + the packed read."""
-    K = 127
+def pass_other_k(torch, api, packed, n_reads, L, P, genome, err, batch_reads, device, K=127):
+    """Pass 1 at another K over resident reads, timed like the headline pass (1 warm-up, 2 timed passes, inputs resident), with the same
+    conservation check on the timed result.  K = 127: configs[4]'s path, the four-word k-mers of the SOAPdenovo-127mer flavour
+    (prlHashReads.c:374-378, kmer.c:532), 80 B per k-mer occurrence (40-byte node read + write) + the packed read; K <= 63: 48 B an occurrence."""
+    mer127 = K > 63
     kpr = L - K + 1
     if kpr < 1:
         return None
@@ -250,7 +272,7 @@ def pass_k127(torch, api, packed, n_reads, L, P, genome, err, batch_reads, devic
     log2_slots = 20
     while (1 << log2_slots) * 0.6 < expected:
         log2_slots += 1
-    kc = api.KmerCounter(K, n_sets=P, mer127=True, log2_slots=log2_slots, device=device, engine=2)
+    kc = api.KmerCounter(K, n_sets=P, mer127=mer127, log2_slots=log2_slots, device=device, engine=2)
     try:
         api._check(api.lib().pg_expect_kmers(kc.h, n_kmers), "pg_expect_kmers")
         kc.set_autogrow(False)
@@ -276,9 +298,9 @@ def pass_k127(torch, api, packed, n_reads, L, P, genome, err, batch_reads, devic
         distinct = kc.distinct()
         cov = int((hist * np.arange(256, dtype=np.uint64)).sum())
         sat = int(hist[255])
-        bytes_per_read = kpr * 80 + (L + 3) // 4
+        bytes_per_read = kpr * (80 if mer127 else 48) + (L + 3) // 4
         ok = int(hist.sum()) == distinct and (cov == n_kmers if sat == 0 else cov <= n_kmers)
-        return {"workload": f"the same {n_reads} resident reads x {L} bp, K=127 (four-word k-mers, {kpr} k-mers a read), -p {P}",
+        return {"workload": f"{n_reads} resident reads x {L} bp, genome {genome}, err {err}, K={K} ({'four' if mer127 else 'two'}-word k-mers, {kpr} k-mers a read), -p {P}",
                 "ms_per_pass": k1 + k2, "reads_per_sec": n_reads / ((k1 + k2) * 1e-3), "k1_scatter_ms": k1, "k2_count_ms": k2, "distinct_kmers": distinct,
                 "algorithmic_bytes_per_read": bytes_per_read, "roofline_frac_k2": n_reads * bytes_per_read / (k2 * 1e-3) / 1e9 / 8000.0,
                 "roofline_frac_both_kernels": n_reads * bytes_per_read / ((k1 + k2) * 1e-3) / 1e9 / 8000.0,
@@ -589,15 +611,27 @@ def main():
         api.hip_free(ptr)
         api.hip_free(ws)
 
-    k127 = None
+    k127 = k31 = None
     if world == 1 and engine == 2 and K <= 63 and L >= 128 and not args.no_extras and not args.no_k127:
         st_final = st_snapshot if extras else kc.stats()
         kc.close()                                              # (its pools go; the 127-mer pass makes its own)
         torch.cuda.empty_cache()
         try:
-            k127 = pass_k127(torch, api, packed, n_reads, L, P, args.genome, args.err, args.batch_reads, local)
+            k127 = pass_other_k(torch, api, packed, n_reads, L, P, args.genome, args.err, args.batch_reads, local, K=127)
         except Exception as e:
             k127 = {"error": f"{type(e).__name__}: {e}"}
+        # BASELINE.json configs[1] at its full size: 10 M x 100 bp over 4.6 Mb, err 0.005, K = 31 -- its own reads (a fraction of a second to draw)
+        try:
+            del packed
+            torch.cuda.empty_cache()
+            c1 = dict(n=10_000_000, L=100, genome=4_600_000, err=0.005, K=31)
+            p1 = gen_packed_reads(torch, dev, c1["genome"], c1["n"], c1["L"], c1["err"], 20260926)
+            k31 = pass_other_k(torch, api, p1, c1["n"], c1["L"], P, c1["genome"], c1["err"], args.batch_reads, local, K=c1["K"])
+            if k31:
+                k31["config"] = "BASELINE.json configs[1]"
+            del p1
+        except Exception as e:
+            k31 = {"error": f"{type(e).__name__}: {e}"}
     else:
         st_final = None
     if rank == 0:
@@ -609,8 +643,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "u64", "data": "synthetic",
             "distinct_kmers_per_sec": distinct / (dt / args.steps), "conservation": conservation,
             "kmer_occurrences_per_sec": n_kmers * world / (dt / args.steps),
-            "config": {"workload": f"C. elegans-scale synthetic: {n_reads} reads/GPU x {L} bp, genome {args.genome} bp, err {args.err}, "
-                                   f"K={K}, -p {P} sets (BASELINE.json configs[2])",
+            "config": {"workload": workload_label(n_reads, L, args.genome, args.err, K, P, world),
                        "reads_per_gpu": n_reads, "read_len": L, "K": K, "genome": args.genome, "err": args.err,
                        "distinct_kmers": distinct, "table_slots_log2": log2_slots,
                        "engine": engine,
@@ -674,17 +707,24 @@ def main():
                          "k1_moved_GBps": k1_bytes / k1_s / 1e9, "k2_moved_GBps": k2_bytes / k2_s / 1e9,
                          "moved_bytes_per_step": k1_bytes + k2_bytes, "moved_over_algorithmic": (k1_bytes + k2_bytes) / alg_pass,
                          "records_per_read": st["records"] / n_reads, "record_bytes": st["unit_bytes"], "partitions": st["parts_or_slots"]}
+            traffic_note = None
             if os.path.exists(tf):
-                # PMC bytes (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes over this command at its full 200 M reads) are kept
-                # per read in profiles/pmc_traffic.json and scaled to the reads of one launch of the dominant kernel
+                # PMC bytes (FETCH_SIZE + WRITE_SIZE, separate rocprofv3 passes over this command at its full 200 M reads) are kept per read in
+                # profiles/pmc_traffic.json together with a hash of the kernels' sources they were taken on: counters of another library are
+                # not this run's traffic (null + "stale").  FETCH_SIZE of K2 is doubled as MI355X_MICROARCH.md prescribes for 16-byte-a-lane
+                # streamed reads on gfx950 (its record reads); K1's 8-byte loads and WRITE_SIZE are uncalibrated there and stay as counted.
                 try:
                     tj = json.load(open(tf))
                     kn = kernel.split("<")[0]
-                    if kn + "_bytes_per_read" in tj:
+                    sha = library_source_sha()
+                    if tj.get("library_sha") != sha:
+                        traffic_note = f"stale: profiles/pmc_traffic.json was taken on library {tj.get('library_sha')}, this is {sha}"
+                    elif not (L == 150 and K == 63 and abs(args.genome * 300 - n_reads * L) <= 0.5 * n_reads * L):
+                        traffic_note = "the counters were taken at 150 bp, K = 63, 300x: not this workload"
+                    elif kn + "_bytes_per_read" in tj:
                         reads_per_launch = n_reads if kn == "skm_count_kernel" else n_reads / len(batches)
                         traffic = tj[kn + "_bytes_per_read"] * reads_per_launch
-                    else:
-                        traffic = tj.get(kn + "_bytes_per_launch")
+                        traffic_note = tj.get("note")
                 except Exception:
                     traffic = None
             # `bound` names the roofline the contract prices this path against (HBM bytes of a hash-table
@@ -709,6 +749,8 @@ def main():
                 try:
                     tj = json.load(open(tf))
                     ipr = tj.get("skm_count_kernel_valu_insts_per_read_K127" if mer127 else "skm_count_kernel_valu_insts_per_read")
+                    if tj.get("library_sha") != library_source_sha():
+                        ipr = None
                     if ipr and L == 150 and K in (63, 127) and abs(args.genome * 300 - n_reads * L) <= 0.5 * n_reads * L:   # (the counters were taken at this read geometry and coverage)
                         issue_peak = 256 * 4 * 2.4e9 / 4
                         extra["valu_issue_frac"] = ipr * n_reads / issue_peak / k2_s
@@ -720,10 +762,12 @@ def main():
                                                              "moves a fraction of those bytes (see traffic / hbm_counter_frac) and is limited as `limiter_bound` says",
                                "limiter_bound": "valu-issue/lds" if engine == 2 else "random-atomic rate",
                                "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
-                               "traffic": traffic, "hbm_counter_frac": counter_frac, "kernel": kernel, "launches": launches, "avg_launch_ms": avg_ms,
+                               "traffic": traffic, "traffic_note": traffic_note, "hbm_counter_frac": counter_frac, "kernel": kernel, "launches": launches, "avg_launch_ms": avg_ms,
                                "algorithmic_bytes_per_launch": per_launch, "limiter": limiter, **extra}
             if k127 is not None:
                 rec["k127"] = k127
+            if k31 is not None:
+                rec["k31_config1"] = k31
             rec.update(commands)                                      # whole_command, cpu_baseline, whole_command_60M*: run before the pass (above)
         print(json.dumps(rec), flush=True)
     kc.close()

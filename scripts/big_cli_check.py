@@ -80,7 +80,8 @@ def main():
         binary = os.path.join(ROOT, "soapdenovo2_amd", "bin", "SOAPdenovo-127mer" if mer127 else "SOAPdenovo-63mer")
     pre = os.path.join(a.out, "ref" if a.reference else "amd")
     cmd = [binary, "pregraph", "-s", cfg, "-K", str(a.kmer), "-o", pre, "-p", str(a.sets)] + (["-a", str(a.a_gb)] if a.a_gb else [])
-    env = dict(os.environ, PG_HOST_VERBOSE="1", **dict(kv.split("=", 1) for kv in a.env))
+    env = dict(os.environ, PG_HOST_VERBOSE="1")
+    env.update(dict(kv.split("=", 1) for kv in a.env))
     cwd = None
     if a.rocprof:
         prof_dir = os.path.abspath(os.path.join(a.out, "prof" + a.tag))
