@@ -165,7 +165,8 @@ pg_graph *pg_graph_begin_sharded(int n_ranks, const int *devices, const uint64_t
 /* <prefix>.edge.gz written beside pass 2 (on != 0): the graph stages that build edges on the device return once the device has
  * handed the edges back, a background thread formats and deflates the text, and pg_host_graph_finish (or destroying the graph)
  * waits for it and reports its error.  A choice of the calling thread for the graphs it begins (graphs of other threads are not
- * touched); off by default, so a caller that reads the file right after pg_graph_begin* finds it complete.
+ * touched: the flag is thread-local -- set it on the thread that calls pg_graph_begin*, a Python worker thread included; api.edge_file_in_background
+ * says the same); off by default, so a caller that reads the file right after pg_graph_begin* finds it complete.
  * call_pregraph turns it on (output_1edge, node2edge.c:88-110, has no reader before the process ends). */
 int pg_host_edge_file_in_background(int on);
 /* Device memory the caller is done with, offered to the graph stages for reuse (one block per device): with -a, pg_graph_begin_device
@@ -371,6 +372,9 @@ pg_comm *pg_comm_create(int n_ranks, int rank, int device, const uint8_t id[128]
 /* transport: PG_COMM_RCCL, PG_COMM_P2P, or -1 = RCCL when the devices are pairwise distinct (SOAPDENOVO2_AMD_EXCHANGE=p2p|rccl
  * overrides), else P2P.  out[n_ranks] receives the ranks' communicators. */
 int pg_comm_create_local(int n_ranks, const int *devices, int transport, pg_comm **out);
+/* COLLECTIVE for the ranks of one process (PG_COMM_P2P): the peers pull out of THIS rank's send regions on their own streams, and a rank's
+ * destroy (or pg_comm_flush) waits for its own streams only -- destroy the communicators of a group after every rank has finalized or
+ * flushed (call_pregraph and api.LocalGroup do), never one rank's while another rank is still counting. */
 void pg_comm_destroy(pg_comm *comm);
 int pg_comm_rank(const pg_comm *comm);
 int pg_comm_size(const pg_comm *comm);
@@ -387,7 +391,10 @@ typedef int (*pg_host_alltoallv_fn)(void *user, const void *send, const uint64_t
                                     const uint64_t *recv_off, const uint64_t *recv_cnt);
 pg_comm *pg_comm_create_host(int n_ranks, int rank, int device, pg_host_alltoallv_fn fn, void *user);
 /* Appends what pg_count_reads_sharded still has in flight (its last round travels when the call returns) to the partition streams of
- * ctx and waits for it.  pg_finalize / pg_reset / pg_destroy do this by themselves; callers that look at the streams otherwise use it. */
+ * ctx and waits for it.  pg_finalize / pg_reset / pg_destroy do this by themselves; callers that look at the streams otherwise use it.
+ * Like pg_comm_destroy it waits for this rank's streams: with PG_COMM_P2P every rank of the group flushes before any send region is reused
+ * or released.  (A rank whose pipeline could not be set up -- stream / event creation failed -- still takes part in the round's collective
+ * steps with nothing to give and raises the error flag of the round: all ranks return the error together.) */
 int pg_comm_flush(pg_ctx *ctx, pg_comm *comm, void *stream);
 
 /* d_send_counts[o] goes to rank o, d_recv_counts[q] comes from rank q (device memory, n_ranks words each). */

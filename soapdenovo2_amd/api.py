@@ -444,6 +444,12 @@ class arena_pinned:
         lib().pg_device_arena_unpin(self.device)
 
 
+def edge_file_in_background(on: bool) -> None:
+    """<prefix>.edge.gz of the graphs THIS THREAD begins is written beside pass 2 (the library's flag is thread-local: call it on the
+    thread that calls graph_begin*, not on another one)."""
+    lib().pg_host_edge_file_in_background(1 if on else 0)
+
+
 def hip_free(ptr) -> None:
     """hipFree of a device pointer the library handed over (pg_export_take)."""
     lib().pg_device_free(ptr)

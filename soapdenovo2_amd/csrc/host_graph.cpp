@@ -50,6 +50,8 @@
 #include "../../include/soapdenovo2_amd.h"
 
 namespace pg {
+// SOAPDENOVO2_AMD_TIPS=host: the tip stage on the host threads (the A/B twin of the device form; =replay: device walks, host decisions)
+static bool tips_on_host() { const char* e = env_user("SOAPDENOVO2_AMD_TIPS"); return e && !strcmp(e, "host"); }
 
 static uint32_t g_crc_tab[256];
 static std::atomic<bool> g_crc_ready{false};
@@ -1068,13 +1070,12 @@ struct ParallelEdgeBuilder {
     static bool gz_member(const std::string& text, std::vector<uint8_t>& out) {
         z_stream z;
         memset(&z, 0, sizeof(z));
-        // level 1: <prefix>.edge.gz is a multi-member gzip file here anyway (never the reference's bytes, always its text), the
-        // later stages only gzread it, and at level 6 the deflate was most of the edge stage's host time
-        // SOAPDENOVO2_AMD_GZIP_LEVEL=0..9 (0 = stored); anything else is refused loudly rather than clamped.  Level 6 (zlib's default,
-        // what the reference's gzopen(..., "w") uses) gives files ~25 % smaller at several times the deflate time (README).
+        // zlib's default level, 6: what the reference's gzopen(..., "w") writes with (node2edge.c:66) -- the same text in a file of about the same
+        // size.  The members are deflated by all host threads beside pass 2 (pg_host_edge_file_in_background), where the time does not show;
+        // rounds 2 - 4 wrote level 1 (files ~25 % larger).  SOAPDENOVO2_AMD_GZIP_LEVEL=0..9 (0 = stored); anything else is refused loudly.
         static const int level = []() {
             const char* e = pg::env_user("SOAPDENOVO2_AMD_GZIP_LEVEL");
-            if (!e) return 1;
+            if (!e) return 6;
             char* end = nullptr;
             const long v = strtol(e, &end, 10);
             if (end == e || *end || v < 0 || v > 9) { fprintf(stderr, "SOAPDENOVO2_AMD_GZIP_LEVEL must be 0..9 (got '%s')\n", e); exit(-1); }
@@ -1179,7 +1180,7 @@ struct ParallelEdgeBuilder {
 // make_edge over all sets -> <prefix>.edge.gz; fills the counters of the stderr banner
 template <int NW>
 static int construct_edges(Graph<NW>& g, const std::string& prefix, int n_threads, int& edge_c, long long& records, long long& extra_nodes) {
-    const char* serial = pg::env_user("PG_SERIAL_EDGES");
+    const char* serial = pg::env_test("PG_SERIAL_EDGES");
     if (serial && atoi(serial)) {
         GzText gz;
         if (!gz.open(prefix + ".edge.gz")) { pg_set_error("cannot open " + prefix + ".edge.gz"); return PG_EIO; }
@@ -2435,7 +2436,7 @@ static GraphHandleBase* graph_begin(const uint64_t* records, uint64_t n, const u
     if (d_records) {
         // the layout is made where the records are (SOAPDENOVO2_AMD_LAYOUT=host keeps the host replay, for A/B runs)
         const char* where = pg::env_user("SOAPDENOVO2_AMD_LAYOUT");
-        if (device >= 0 && device == rec_device && !(where && !strcmp(where, "host")) && !pg::env_user("SOAPDENOVO2_AMD_TIPS_HOST"))
+        if (device >= 0 && device == rec_device && !(where && !strcmp(where, "host")) && !tips_on_host())
             rc_replay = layout_on_device<NW>(h, d_records, per_set_count, set_last_put, K, P, a_gb, n_threads, device, /*host_copy=*/tips_replay);
         if (rc_replay == 1) { fetch = &fetch_device_records; fetch_user = &dr; }
     }
@@ -2444,7 +2445,7 @@ static GraphHandleBase* graph_begin(const uint64_t* records, uint64_t n, const u
         h->set_devices.resize(P);
         for (int si = 0; si < P; si++) h->set_devices[si] = sharded->devices[si % sharded->n_ranks];
         h->lane_devices = sharded->devices;
-        if (!(where && !strcmp(where, "host")) && !tips_replay && !pg::env_user("SOAPDENOVO2_AMD_TIPS_HOST"))
+        if (!(where && !strcmp(where, "host")) && !tips_replay && !tips_on_host())
             rc_replay = layout_on_ranks<NW>(h, *sharded, per_set_count, set_last_put, K, P, a_gb, n_threads);
         if (rc_replay == 1) { fetch = &fetch_sharded_records; fetch_user = (void*)sharded; }
     }
@@ -2454,7 +2455,7 @@ static GraphHandleBase* graph_begin(const uint64_t* records, uint64_t n, const u
     if (rc_replay != PG_OK) { delete h; return nullptr; }
     fprintf(stderr, "Time spent on rebuilding the k-mer set layout: %.1fs.\n", now() - t0);
     t0 = now();
-    if (device >= 0 && !pg::env_user("SOAPDENOVO2_AMD_TIPS_HOST") && !h->dev && h->dev_open(device) != PG_OK) { delete h; return nullptr; }
+    if (device >= 0 && !tips_on_host() && !h->dev && h->dev_open(device) != PG_OK) { delete h; return nullptr; }
     if (pg::env_user("PG_HOST_VERBOSE")) fprintf(stderr, "k-mer sets uploaded to the device: %.2fs\n", now() - t0);
     if (h->dev && !tips_replay) {                // decided on the device (dev_tips.hpp); the host copy of the sets is not touched
         if (h->dev_clip_tips(cut_single != 0) != PG_OK) { delete h; return nullptr; }

@@ -162,7 +162,7 @@ __device__ __forceinline__ uint32_t fastdiv1(uint32_t i, uint32_t d, uint32_t in
 //   D     thread = the same segment: one LDS atomic reserves its items, every start bit finds the next start
 //   E     one lane per run: slot in the partition's stream (or the owner's send region), record from the dword string
 // Lanes of a wave take different reads (read index fastest), so the row stride -- forced odd -- is the bank stride.
-struct SegArg { int R, np, npad, wsd, nseg, nca; uint32_t inv_R, inv_wpr; int shared; };   // shared: phase B shares the block minima of a read (skm_tile.hpp; one pass a tile, W a constant)
+struct SegArg { int R, np, npad, wsd, nseg, nca; uint32_t inv_R, inv_wpr; };
 
 // W: the window length (m-mers a k-mer) at compile time, with 16-mers (0: whatever the geometry says) -- the loops of phase B
 // unroll into loads with immediate offsets, phase A loses its shifts by 32 - 2m.
@@ -180,10 +180,7 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_seg_kernel(ReadsArg a, E2De
     const int mpad = nseg | 1;
     uint32_t* pids = v0 + (size_t)R * npad;                       // R * kpad
     uint32_t* smask = pids + (size_t)R * kpad;                    // R * mpad  run-start bits
-    constexpr int NB = W ? tile_shared_blocks(S, W) : 0;         // whole blocks in a segment's core (phase B, shared form)
-    const int bpad = (nseg + NB) | 1;
-    uint32_t* bmin = smask + (size_t)R * mpad;                    // R * bpad  block minima (shared form only)
-    uint32_t* ranks = bmin + (sa.shared ? (size_t)R * bpad : 0);  // R * kpr   (ROUTE only)
+    uint32_t* ranks = smask + (size_t)R * mpad;                   // R * kpr   (ROUTE only)
     uint32_t* items = v0;
     __shared__ unsigned int n_items;
     const uint64_t r0 = (uint64_t)blockIdx.x * R;
@@ -204,35 +201,9 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_seg_kernel(ReadsArg a, E2De
         if (r < nr) tile_mmer_chunk<(W ? 16 : 0)>(dw + r * wsd, c, m, v0 + r * npad);
     }
     __syncthreads();
-    if constexpr (W != 0) {
-      if (sa.shared) {
-        // phase B with the neighbours' work shared: the suffix minima of every segment (kept in registers), the minimum of its first S positions into the
-        // read's row of block minima -- and the NB blocks behind the read's last segment --, a barrier, then cores from NB block minima instead of
-        // W - S values: 29 LDS loads a segment instead of 59 at K = 63, 41 instead of 125 at K = 127.  (One pass a tile: R * nseg <= BLOCK.)
-        const int t = threadIdx.x;
-        const int seg = (int)fastdiv1(t, R, sa.inv_R), r = t - seg * R;
-        const bool mine = t < R * nseg && r < nr;
-        uint32_t suf[S + 1];
-        if (mine) {
-            tile_segment_suffix<S>(v0 + r * npad, seg * S, suf);
-            bmin[r * bpad + seg] = suf[0];
-        }
-        for (int q = t; q < R * NB; q += BLOCK) {
-            const int vb = (int)fastdiv1(q, R, sa.inv_R), r2 = q - vb * R;
-            if (r2 < nr) bmin[r2 * bpad + nseg + vb] = tile_block_min<S>(v0 + r2 * npad, nseg + vb);
-        }
-        __syncthreads();
-        if (mine) {
-            const int j0 = seg * S, cnt = min(S, kpr - j0);
-            uint32_t pid[S];
-            const uint32_t mk = tile_segment_shared<S, W>(v0 + r * npad, bmin + r * bpad + seg + 1, suf, np, j0, cnt, e.g.nmax, e.g.part_mul, pid);
-            smask[r * mpad + seg] = mk;
-#pragma unroll
-            for (int i = 0; i < S; i++) pids[r * kpad + j0 + i] = pid[i];
-        }
-      }
-    }
-    if (W == 0 || !sa.shared)
+    // (Phase B with the block minima of a read shared between its segments -- suffix minima first, a barrier, cores from three block minima instead of
+    //  37 values: 29 LDS loads a segment instead of 59 -- was built and measured in round 5: 62.3 ms against 57.0 per 200 M reads on one box,
+    //  profiles/r05c_k1_shared_minima_ab.json.  The loads it saves have immediate offsets and pipeline; the barrier and the second pass do not.)
     for (int t = threadIdx.x; t < R * nseg; t += BLOCK) {
         const int seg = (int)fastdiv1(t, R, sa.inv_R), r = t - seg * R;
         if (r >= nr) continue;
@@ -1304,12 +1275,7 @@ static int launch_tiled(pg_ctx* c, const ReadsArg& a, const RouteArg* route, hip
     int S = tile_pick_segment(kpr, g.w);
     if (const char* v = env_measure("PG_K1_S")) { const int q = atoi(v); if (q >= 7 && q <= 15 && (q & 1) && (q <= g.w || q == 7)) S = q; }
     const int nseg = (kpr + S - 1) / S, nca = (np + 15) / 16, npad = (16 * nca) | 1, wsd = (2 * wpr + 3) | 1;   // value rows: whole 16-position chunks, odd stride
-    // phase B shares the block minima of a read where the window length is a compile-time constant of the kernel (launch_seg: 16-mers, w = 48 / 16 / 112, S <= w)
-    bool shared = g.m == 16 && S <= g.w && ((c->NW == 2 && (g.w == 48 || g.w == 16)) || (c->NW == 4 && g.w == 112));
-    if (const char* v = env_measure("PG_K1_W")) shared = shared && atoi(v) != 0;
-    if (const char* v = env_measure("PG_K1_SHARED")) shared = shared && atoi(v) != 0;
-    const int nb_shared = shared ? (g.w - S) / S : 0;
-    const size_t per_read = (size_t)(wsd + npad + ((nseg * S) | 1) + (nseg | 1) + (shared ? ((nseg + nb_shared) | 1) : 0) + (route ? kpr : 0)) * 4;     // (the kernel's rows: dword string, values, partition ids, start bits, block minima, ranks)
+    const size_t per_read = (size_t)(wsd + npad + ((nseg * S) | 1) + (nseg | 1) + (route ? kpr : 0)) * 4;     // (the kernel's rows: dword string, values, partition ids, start bits, ranks)
     int R = std::min<int>(128, std::max(1, BLOCK / nseg));                     // one pass of phase B per tile
     R = (int)std::min<size_t>((size_t)R, (60 * 1024) / per_read);
     // ... and about 25 KB of LDS a tile, i.e. five workgroups a CU: measured at 150 bp (profiles/r03v_k1_tile_sizes.json), K = 63
@@ -1324,8 +1290,7 @@ static int launch_tiled(pg_ctx* c, const ReadsArg& a, const RouteArg* route, hip
     const uint64_t grid = (a.n_reads + R - 1) / R;
     if (grid > 0x7FFFFFFFULL) { pg_set_error("batch too large for one launch"); return PG_EINVAL; }
     auto inv = [](uint32_t d) { return (uint32_t)(((1ULL << 32) + d - 1) / d); };
-    if ((size_t)R * nseg > (size_t)BLOCK) shared = false;                       // (the shared form is one pass a tile; R was sized with its row -- a spare row does no harm)
-    SegArg sa{R, np, npad, wsd, nseg, nca, inv((uint32_t)R), inv(a.wpr), shared ? 1 : 0};
+    SegArg sa{R, np, npad, wsd, nseg, nca, inv((uint32_t)R), inv(a.wpr)};
     RouteArg ro{nullptr, nullptr, nullptr, 0, 1};
     if (route) ro = *route;
     const size_t smem = per_read * R;

@@ -109,78 +109,6 @@ PG_HD uint32_t tile_segment(const uint32_t* v, int np, int j0, int cnt, int w_rt
     return mask;
 }
 
-// B, with the neighbours' work shared (W at compile time).  tile_segment reads w + S values a segment, and the w - S of its core are read
-// again by every neighbour whose core overlaps -- 5.4 loads a k-mer at K = 63.  The core of segment s, positions [J_s, j0 - 1 + w) with
-// J_s = (s + 1) S - 1, is a row of whole BLOCKS block(b) = [b S - 1, b S + S - 1) for b = s + 1 .. s + NB, NB = (W - S) / S, plus
-// LO = (W - S) % S positions behind them -- and the minimum of block(b) is exactly suf[0] of segment b, which that segment's suffix scan
-// computes anyway.  So:
-//   B1  tile_segment_suffix   the suffix minima of the segment (S loads, kept in registers); suf[0] goes to the read's row of block minima
-//       tile_block_min        the same minimum for the NB blocks behind the read's last segment (no k-mer starts there, but cores reach them)
-//   (a barrier)
-//   B2  tile_segment_shared   core = NB block minima + LO values; prefix minima (S loads); ids and start bits as before
-// 2 S + NB + LO loads a segment instead of w + S: 29 instead of 59 at K = 63 (S = 11, w = 48), 41 instead of 125 at K = 127 (S = 13, w = 112).
-// Every block a core uses lies inside that core, hence inside the read's np values; block 0 (which would start at position -1) is in no core.
-template <int S>
-PG_HD void tile_segment_suffix(const uint32_t* v, int j0, uint32_t* suf /* [S + 1] */) {
-    const int jl = j0 - 1;
-    suf[S] = 0xFFFFFFFFu;
-#pragma unroll
-    for (int q = S - 1; q >= 0; q--) {
-        const int at = jl + q;
-        const uint32_t x = v[at < 0 ? 0 : at];
-        const uint32_t mn = x < suf[q + 1] ? x : suf[q + 1];
-        suf[q] = at >= 0 ? mn : 0xFFFFFFFFu;
-    }
-}
-template <int S>
-PG_HD uint32_t tile_block_min(const uint32_t* v, int b) {           // block(b), b >= 1
-    uint32_t mn = 0xFFFFFFFFu;
-#pragma unroll
-    for (int i = 0; i < S; i++) { const uint32_t x = v[b * S - 1 + i]; mn = x < mn ? x : mn; }
-    return mn;
-}
-// bm_next = the read's block minima from block(seg + 1) on
-template <int S, int W>
-PG_HD uint32_t tile_segment_shared(const uint32_t* v, const uint32_t* bm_next, const uint32_t* suf, int np, int j0, int cnt, int nmax, uint32_t part_mul, uint32_t* pid_out) {
-    static_assert(W >= S, "a segment is no longer than a window");
-    constexpr int NB = (W - S) / S, LO = (W - S) % S;
-    const int jl = j0 - 1, J = j0 + S - 1;
-    uint32_t core = 0xFFFFFFFFu;
-#pragma unroll
-    for (int b = 0; b < NB; b++) { const uint32_t x = bm_next[b]; core = x < core ? x : core; }
-#pragma unroll
-    for (int i = 0; i < LO; i++) { const uint32_t x = v[J + NB * S + i]; core = x < core ? x : core; }
-    uint32_t pre[S + 1];
-    pre[0] = 0xFFFFFFFFu;
-#pragma unroll
-    for (int q = 1; q <= S; q++) {
-        const int at = jl + W + q - 1;
-        const uint32_t x = v[at < np ? at : np - 1];
-        const uint32_t xx = q <= cnt ? x : 0xFFFFFFFFu;
-        pre[q] = xx < pre[q - 1] ? xx : pre[q - 1];
-    }
-    uint32_t mask = 0, prev_pid = 0;
-    int next_cut = 0;
-    while (next_cut < j0) next_cut += nmax;
-#pragma unroll
-    for (int q = 0; q <= S; q++) {
-        uint32_t mv = suf[q] < core ? suf[q] : core;
-        mv = pre[q] < mv ? pre[q] : mv;
-        const uint32_t pid = skm_partition(mv, part_mul);
-        if (q >= 1) {
-            const int j = j0 + q - 1;
-            const bool cut = j == next_cut;
-            const bool start = (j == 0 || pid != prev_pid || cut) && q <= cnt;
-            next_cut += cut ? nmax : 0;
-            mask |= start ? 1u << (q - 1) : 0u;
-            pid_out[q - 1] = pid;
-        }
-        prev_pid = pid;
-    }
-    return mask;
-}
-constexpr int tile_shared_blocks(int S, int W) { return W >= S ? (W - S) / S : 0; }
-
 // D: end of the run that starts at bit i of segment `seg`: the next start bit of the read (segments seg .. nseg - 1, S
 // k-mers each), or kpr.  masks = the read's segment masks.
 PG_HD int tile_next_start(const uint32_t* masks, int seg, int nseg, int S, int i, int kpr) {

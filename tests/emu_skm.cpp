@@ -162,30 +162,6 @@ static int64_t tile_check(const uint64_t* packed, int64_t n_reads, int len, int 
                 for (int i = 0; i < cnt; i++) if (pid2[i] != pid[i]) return -106;
             }
         }
-        // phase B with the block minima shared between the segments of a read (what the kernel runs when W is a constant): B1 for every
-        // segment and for the NB blocks behind the last one, then B2 -- same bits, same ids as tile_segment
-        if ((g.w == 48 || g.w == 112 || g.w == 16) && S <= g.w) {
-            const int NB = tile_shared_blocks(S, g.w), bpad = (nseg + NB) | 1;
-            std::vector<uint32_t> bm((size_t)nr * bpad, 0xCDCDCDCDu), sufs((size_t)nr * nseg * (S + 1));
-            for (int t = 0; t < nr * nseg; t++) {
-                const int seg = t / nr, r = t % nr;
-                uint32_t* suf = sufs.data() + ((size_t)r * nseg + seg) * (S + 1);
-                tile_segment_suffix<S>(v0.data() + (size_t)r * npad, seg * S, suf);
-                bm[(size_t)r * bpad + seg] = suf[0];
-            }
-            for (int t = 0; t < nr * NB; t++) { const int vb = t / nr, r = t % nr; bm[(size_t)r * bpad + nseg + vb] = tile_block_min<S>(v0.data() + (size_t)r * npad, nseg + vb); }
-            for (int t = 0; t < nr * nseg; t++) {
-                const int seg = t / nr, r = t % nr, j0 = seg * S, cnt = std::min(S, kpr - j0);
-                uint32_t pid3[S], mk3 = 0;
-                const uint32_t* suf = sufs.data() + ((size_t)r * nseg + seg) * (S + 1);
-                const uint32_t* bmn = bm.data() + (size_t)r * bpad + seg + 1;
-                if (g.w == 48) mk3 = tile_segment_shared<S, 48>(v0.data() + (size_t)r * npad, bmn, suf, np, j0, cnt, g.nmax, g.part_mul, pid3);
-                else if (g.w == 112) mk3 = tile_segment_shared<S, 112>(v0.data() + (size_t)r * npad, bmn, suf, np, j0, cnt, g.nmax, g.part_mul, pid3);
-                else if constexpr (S <= 16) mk3 = tile_segment_shared<S, 16>(v0.data() + (size_t)r * npad, bmn, suf, np, j0, cnt, g.nmax, g.part_mul, pid3);
-                if (mk3 != masks[(size_t)r * nseg + seg]) return -107;
-                for (int i = 0; i < cnt; i++) if (pid3[i] != pids[(size_t)r * kpr + j0 + i]) return -108;
-            }
-        }
         for (int r = 0; r < nr; r++) {
             struct Run { int j0, n; uint32_t pid; };
             std::vector<Run> got, want;
