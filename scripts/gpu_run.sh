@@ -31,13 +31,13 @@ for step in "$@"; do
         timeout 1500 python bench.py ${arg//,/ } > "$O/bench$i.json" 2> "$O/bench$i.err"; echo "[$i] bench rc=$?"
         python scripts/bench_digest.py "$O/bench$i.json";;
     stats)
-        rm -rf /tmp/prof_$i; timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$i -o s -- python bench.py $KERNELS_ONLY --no-k127 ${arg//,/ } > "$O/stats$i.json" 2> "$O/stats$i.err"; echo "[$i] stats rc=$?"
+        rm -rf /tmp/prof_$i; timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_$i -o s -- python bench.py $KERNELS_ONLY --no-k127 ${arg//,/ } > "$O/stats$i.json" 2> "$O/stats$i.err"; echo "[$i] stats rc=$?"
         f=$(find /tmp/prof_$i -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$O/kernel_stats$i.csv" && head -8 "$O/kernel_stats$i.csv" | cut -c1-200
         python scripts/bench_digest.py "$O/stats$i.json";;
     pmc)
         ctrs=${arg%%:*}; bargs=""; [ "$ctrs" != "$arg" ] && bargs=${arg#*:}
-        rm -rf /tmp/pmc_$i; timeout 900 rocprofv3 --kernel-trace --pmc ${ctrs//,/ } -d /tmp/pmc_$i -o p -- python bench.py $KERNELS_ONLY --no-k127 --steps 1 --warmup 0 ${bargs//,/ } > "$O/pmc$i.json" 2> "$O/pmc$i.err"; echo "[$i] pmc $ctrs rc=$?"
-        f=$(find /tmp/pmc_$i -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python scripts/pmc_summary.py /tmp/pmc_$i > "$O/pmc${i}_${ctrs//,/_}.txt" 2>&1 && tail -12 "$O/pmc${i}_${ctrs//,/_}.txt" | cut -c1-220;;
+        rm -rf /tmp/pmc_$i; timeout 900 rocprofv3 --kernel-trace --output-format csv --pmc ${ctrs//,/ } -d /tmp/pmc_$i -o p -- python bench.py $KERNELS_ONLY --no-k127 --steps 1 --warmup 0 ${bargs//,/ } > "$O/pmc$i.json" 2> "$O/pmc$i.err"; echo "[$i] pmc $ctrs rc=$?"
+        f=$(find /tmp/pmc_$i -name "*counter_collection.csv" | head -1); [ -n "$f" ] && python scripts/pmc_summary.py /tmp/pmc_$i "$O/pmc${i}_summary.json" > "$O/pmc${i}_summary.txt" 2>&1 && grep -A9 "skm_count_kernel\|skm_scatter_seg" "$O/pmc${i}_summary.txt" | head -40 | cut -c1-160;;
     phases)
         SOAPDENOVO2_AMD_LIB=$PWD/soapdenovo2_amd/libsoapdenovo2_amd_measure.so PG_K2_TIMERS=1 timeout 600 python bench.py $KERNELS_ONLY --no-k127 --steps 1 --warmup 0 ${arg//,/ } > "$O/phases$i.json" 2> "$O/phases$i.txt"; echo "[$i] phases rc=$?"
         grep "K2 phase" "$O/phases$i.txt" | tail -12;;
