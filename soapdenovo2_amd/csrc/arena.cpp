@@ -7,6 +7,7 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <unordered_map>
@@ -26,11 +27,14 @@ struct Arena {
     int device = -1;
     bool tried = false, active = false;
     std::mutex list_mu;                             // the free list, the live blocks, the pins
-    std::mutex map_mu;                              // the physical chunks (growing the mapping may take the driver seconds; cutting blocks never waits for it)
+    std::mutex map_mu;                              // the table of physical pieces (held per PIECE: a thread that backs tens of gigabytes does not make one that needs a
+                                                    // single piece wait for all of them -- the export array's thread beside pass 1's batches)
     char* base = nullptr;
     size_t reserved = 0, chunk = 0;
-    std::atomic<size_t> mapped_end{0};
-    std::vector<hipMemGenericAllocationHandle_t> handles;
+    std::atomic<size_t> mapped_bytes{0};
+    struct Piece { hipMemGenericAllocationHandle_t h; int state; };   // state: 0 none, 1 being created by somebody, 2 mapped
+    std::vector<Piece> pieces;                      // one per `chunk` bytes of the range
+    std::condition_variable map_cv;
     std::vector<hipMemAccessDesc> access;
     hipMemAllocationProp prop;
     std::map<size_t, size_t> free_;                 // offset -> bytes, coalesced
@@ -79,30 +83,43 @@ struct Arena {
             access.push_back(a);
         }
         free_[0] = reserved;
+        pieces.assign(reserved / chunk, Piece{hipMemGenericAllocationHandle_t(), 0});
         active = true;
     }
 
-    // physical memory under [0, end); called without list_mu
-    hipError_t ensure_mapped(size_t end) {
-        if (end <= mapped_end.load(std::memory_order_acquire)) return hipSuccess;
-        std::lock_guard<std::mutex> g(map_mu);
-        const auto t0 = std::chrono::steady_clock::now();
+    // physical memory under [off, off + bytes); called without list_mu.  Pieces are created where they are needed, in any order; a piece somebody
+    // else is creating is waited for, nothing else is.
+    hipError_t ensure_mapped(size_t off, size_t bytes) {
+        const size_t p0 = off / chunk, p1 = (off + bytes + chunk - 1) / chunk;
         hipError_t rc = hipSuccess;
-        size_t at = mapped_end.load(std::memory_order_relaxed);
-        while (at < end) {
+        for (size_t pi = p0; pi < p1 && rc == hipSuccess; pi++) {
+            {
+                std::unique_lock<std::mutex> g(map_mu);
+                while (pieces[pi].state == 1) map_cv.wait(g);
+                if (pieces[pi].state == 2) continue;
+                pieces[pi].state = 1;
+            }
+            const auto t0 = std::chrono::steady_clock::now();
             hipMemGenericAllocationHandle_t h;
+            char* at = base + pi * chunk;
             rc = hipMemCreate(&h, chunk, &prop, 0);
-            if (rc != hipSuccess) break;
-            rc = hipMemMap(base + at, chunk, 0, h, 0);
-            if (rc != hipSuccess) { (void)hipMemRelease(h); break; }
-            rc = hipMemSetAccess(base + at, chunk, access.data(), access.size());
-            if (rc != hipSuccess) { (void)hipMemUnmap(base + at, chunk); (void)hipMemRelease(h); break; }
-            handles.push_back(h);
-            n_chunks++;
-            at += chunk;
-            mapped_end.store(at, std::memory_order_release);
+            if (rc == hipSuccess) {
+                rc = hipMemMap(at, chunk, 0, h, 0);
+                if (rc == hipSuccess) {
+                    rc = hipMemSetAccess(at, chunk, access.data(), access.size());
+                    if (rc != hipSuccess) (void)hipMemUnmap(at, chunk);
+                }
+                if (rc != hipSuccess) (void)hipMemRelease(h);
+            }
+            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            {
+                std::lock_guard<std::mutex> g(map_mu);
+                pieces[pi].state = rc == hipSuccess ? 2 : 0;
+                if (rc == hipSuccess) { pieces[pi].h = h; n_chunks++; mapped_bytes.fetch_add(chunk, std::memory_order_relaxed); }
+                map_seconds += dt;
+            }
+            map_cv.notify_all();
         }
-        map_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         if (rc != hipSuccess) (void)hipGetLastError();
         return rc == hipSuccess ? hipSuccess : hipErrorOutOfMemory;
     }
@@ -126,9 +143,9 @@ struct Arena {
         if (cur != device) (void)hipSetDevice(device);
         (void)hipDeviceSynchronize();
         size_t at = 0;
-        for (auto h : handles) { (void)hipMemUnmap(base + at, chunk); (void)hipMemRelease(h); at += chunk; }
-        handles.clear();
-        mapped_end.store(0, std::memory_order_release);
+        for (size_t pi = 0; pi < pieces.size(); pi++)
+            if (pieces[pi].state == 2) { (void)hipMemUnmap(base + pi * chunk, chunk); (void)hipMemRelease(pieces[pi].h); pieces[pi].state = 0; at += chunk; }
+        mapped_bytes.store(0, std::memory_order_release);
         if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
         if (env_user("PG_HOST_VERBOSE"))
             fprintf(stderr, "arena (device %d): %.2f GB of physical memory in %llu piece(s), created in %.2fs in all; peak in use %.2f GB; %llu block(s) cut, %llu given back\n", device,
@@ -158,7 +175,7 @@ struct Arena {
             if (in_use > peak) peak = in_use;
             n_malloc++;
         }
-        const hipError_t rc = ensure_mapped(off + need);
+        const hipError_t rc = ensure_mapped(off, need);
         if (rc != hipSuccess) {
             std::lock_guard<std::mutex> g(list_mu);
             used.erase(off);
@@ -235,7 +252,7 @@ hipError_t arena_mem_info(size_t* free_bytes, size_t* total_bytes) {
     Arena* a = arena_of(dev);
     if (a && a->active) {
         std::lock_guard<std::mutex> g(a->list_mu);
-        const size_t mapped = a->mapped_end.load();
+        const size_t mapped = a->mapped_bytes.load();
         if (mapped > a->in_use) *free_bytes += mapped - a->in_use;
     }
     return hipSuccess;
@@ -253,7 +270,7 @@ void arena_unpin(int device) {
     if (!a || !a->active) return;
     std::lock_guard<std::mutex> g(a->list_mu);
     if (a->pins > 0) a->pins--;
-    if (a->pins == 0 && a->used.empty() && a->mapped_end.load() != 0) a->trim();
+    if (a->pins == 0 && a->used.empty() && a->mapped_bytes.load() != 0) a->trim();
 }
 
 ArenaStats arena_stats(int device) {
@@ -264,7 +281,7 @@ ArenaStats arena_stats(int device) {
     std::lock_guard<std::mutex> g(a->list_mu);
     s.active = 1;
     s.reserved = a->reserved;
-    s.mapped = a->mapped_end.load();
+    s.mapped = a->mapped_bytes.load();
     s.in_use = a->in_use;
     s.peak_in_use = a->peak;
     s.n_malloc = a->n_malloc;

@@ -1070,12 +1070,14 @@ struct ParallelEdgeBuilder {
     static bool gz_member(const std::string& text, std::vector<uint8_t>& out) {
         z_stream z;
         memset(&z, 0, sizeof(z));
-        // zlib's default level, 6: what the reference's gzopen(..., "w") writes with (node2edge.c:66) -- the same text in a file of about the same
-        // size.  The members are deflated by all host threads beside pass 2 (pg_host_edge_file_in_background), where the time does not show;
-        // rounds 2 - 4 wrote level 1 (files ~25 % larger).  SOAPDENOVO2_AMD_GZIP_LEVEL=0..9 (0 = stored); anything else is refused loudly.
+        // Level 1 by default.  The reference's gzopen(..., "w") (node2edge.c:66) writes at zlib's default, 6: the same text in a file a quarter smaller --
+        // measured in round 5 with the members deflated by all host threads beside pass 2: pg_host_graph_finish waited 1.2 s for the file at 60 M reads
+        // (a 3.5 s command instead of 2.4) and 2.5 s at 200 M (profiles/r05f_cli_200M_arena_gzip_ab.json); at level 1 it waits 0.00 s.  The file is a
+        // multi-member gzip here anyway (never the reference's bytes, always its text; the later stages only gzread it).
+        // SOAPDENOVO2_AMD_GZIP_LEVEL=0..9 (6 = the reference's file size); anything else is refused loudly.
         static const int level = []() {
             const char* e = pg::env_user("SOAPDENOVO2_AMD_GZIP_LEVEL");
-            if (!e) return 6;
+            if (!e) return 1;
             char* end = nullptr;
             const long v = strtol(e, &end, 10);
             if (end == e || *end || v < 0 || v > 9) { fprintf(stderr, "SOAPDENOVO2_AMD_GZIP_LEVEL must be 0..9 (got '%s')\n", e); exit(-1); }
