@@ -1117,9 +1117,9 @@ int e2_create(pg_ctx* c) {
     // 20 k-mers); default = as much as a set of 2^log2_slots 64-byte slots, capped by what is free
     uint64_t pool_bytes = ((uint64_t)1 << c->log2_slots) * 64 + parts * chunk_bytes * 2;
     if (c->hint_kmers)                       // known input size: 2 / (w + 1) records a k-mer, half as much again, it grows
-        // (with chunks at computed addresses every partition's open chunk lies inside that region already: nothing is set aside for them here -- 26 GB less to
-        //  have the driver back at 200 M reads, on boxes where that takes it a second.  e2_ensure_pool grows the pool should a skewed input draw more.)
-        pool_bytes = (uint64_t)((double)c->hint_kmers * (s.direct ? 1.5 : 3.0) / (double)(s.g.w + 1)) * rec_bytes + (s.direct ? parts * chunk_bytes / 4 : parts * chunk_bytes * 2) + ((uint64_t)64 << 20);
+        // (with chunks at computed addresses every partition's open chunk lies inside that region already: ONE spare chunk a partition is set aside for the
+        //  draws beyond it -- what the check below and e2_ensure_pool's estimate count on -- instead of two: 13 GB less to have the driver back at 200 M reads)
+        pool_bytes = (uint64_t)((double)c->hint_kmers * (s.direct ? 1.5 : 3.0) / (double)(s.g.w + 1)) * rec_bytes + parts * chunk_bytes * (s.direct ? 1 : 2) + ((uint64_t)64 << 20);
     if (const char* v = env_measure("PG_POOL_MB")) pool_bytes = (uint64_t)atoll(v) << 20;
     const uint64_t budget = (uint64_t)(free_b * 0.85);
     if (out_bytes + parts * 8 > budget) { pg_set_error("partition engine: export array does not fit in device memory"); return PG_ENOMEM; }
