@@ -70,13 +70,13 @@ def workload_label(n_reads, L, genome, err, K, P, world):
 
 
 def library_source_sha():
-    """What the counters in profiles/pmc_traffic.json were taken on: a hash of the kernels' sources (csrc/*.hip, *.hpp)."""
-    import glob
+    """What the counters in profiles/pmc_traffic.json were taken on: a hash of the sources of the two pass-1 kernels -- partition_kernels.hip and the
+    headers its device code comes from."""
     import hashlib
     h = hashlib.sha256()
-    for f in sorted(glob.glob(os.path.join(ROOT, "soapdenovo2_amd", "csrc", "*.hip")) + glob.glob(os.path.join(ROOT, "soapdenovo2_amd", "csrc", "*.hpp"))):
-        h.update(os.path.basename(f).encode())
-        h.update(open(f, "rb").read())
+    for f in ("partition_kernels.hip", "device_ctx.hpp", "extract.hpp", "kmer.hpp", "occ32.hpp", "skm.hpp", "skm_tile.hpp"):
+        h.update(f.encode())
+        h.update(open(os.path.join(ROOT, "soapdenovo2_amd", "csrc", f), "rb").read())
     return h.hexdigest()[:16]
 
 
@@ -729,10 +729,10 @@ def main():
                     traffic = None
             # `bound` names the roofline the contract prices this path against (HBM bytes of a hash-table
             # formulation).  The kernel itself moves 0.15x those bytes and is limited elsewhere, see `limiter`.
-            limiter = ("instruction issue: ~230 vector instructions per read over 4 waves a SIMD (the 88 KB LDS set allows one 1024-lane "
-                       "workgroup per CU), random 8-byte LDS accesses replayed for bank conflicts, nine workgroup barriers per partition; "
-                       "vector ALU ~44 % busy, HBM ~9 % of peak (profiles/r03j_pmc_sq_bench20M.json, profiles/r03j_k2_phase_cycles_20M_k63.txt, "
-                       "DESIGN.md 3.2)") if engine == 2 else "random-atomic rate of the DRAM-resident set"
+            limiter = ("instruction issue at four waves a SIMD: ~185 wave-level vector instructions per read (0.42 of the issue rate), SQ_WAIT_ANY 0.63 of the wave cycles -- dependent LDS "
+                       "round trips between six workgroup barriers a partition (the 88 KB LDS set allows one 1024-lane workgroup per CU), 0.84 bank-conflict cycles per LDS issue cycle on the "
+                       "random 8-byte accesses; HBM ~7 % of peak (profiles/r05_final_pmc_sq_200M_K63.json, profiles/pmc_traffic.json, profiles/r05_final_k2_phase_cycles_200M_K63.txt, "
+                       "DESIGN.md 3)") if engine == 2 else "random-atomic rate of the DRAM-resident set"
             # what the counters say about the same launch: PMC bytes / launch time against the same peak (never `frac`)
             counter_frac = (traffic / (avg_ms * 1e-3) / 1e9 / 8000.0) if traffic else None
             if engine == 2:

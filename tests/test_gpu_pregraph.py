@@ -1,5 +1,6 @@
 """GPU parity tests (run with -m gpu on an MI355X): the HIP path through the C ABI against the CPU oracle on the
 same seeded inputs and against the golden files produced by the real reference."""
+import ctypes as C
 import os
 import subprocess
 
@@ -562,6 +563,26 @@ def test_sharded_pass1_ranks_on_one_gpu(golden, tmp_path, name, P, m, n_ranks):
         assert o[4] == "p2p" and o[3]["rounds"] == (5 + n_ranks - 1) // n_ranks
     assert sum(o[3]["sent_records"] for o in out) == sum(o[3]["recv_records"] for o in out) > 0
     assert all(len(o[0]) > 0 for o in out)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K,reads,L,log2_slots", [(127, 20_000_000, 150, 28), (127, 60_000_000, 150, 30), (63, 60_000_000, 150, 30), (63, 200_000_000, 150, 31), (31, 10_000_000, 100, 28),
+                                                  (25, 3_000_000, 80, 26)])
+def test_context_sized_like_the_command_legs_can_be_created(K, reads, L, log2_slots):
+    """pg_create_sized with the k-mer estimate call_pregraph derives for the bench's command legs (allocation only, nothing is counted): the
+    record pool must satisfy the engine's own floor -- the computed-address region + one spare chunk a partition -- at every geometry.  (Round
+    5: a pool trimmed by too much passed every golden case and failed `pregraph -K 127` at 20 M reads with "record pool too small".)"""
+    from soapdenovo2_amd import api
+    L_ = api.lib()
+    n_kmers = reads * (L - K + 1)
+    h = L_.pg_create_sized(0, K, 1 if K > 63 else 0, 8, log2_slots, 2, n_kmers)
+    assert h, L_.pg_last_error().decode()
+    st = (C.c_uint64 * 8)()
+    assert L_.pg_stats(h, C.cast(st, C.POINTER(C.c_uint64))) == 0
+    assert st[0] == 2 and st[5] > st[6]                                      # engine 2; more pool chunks than partitions
+    L_.pg_destroy(h)
+    a = api.arena_stats(0)
+    assert a["active"] in (0, 1) and a["in_use"] == 0                         # everything went back to the arena (and, unpinned, to the driver)
 
 
 def test_sharded_pass1_rccl_single_rank(golden, tmp_path):
