@@ -8,8 +8,10 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <algorithm>
 #include <map>
 #include <mutex>
+#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -89,39 +91,62 @@ struct Arena {
 
     // physical memory under [off, off + bytes); called without list_mu.  Pieces are created where they are needed, in any order; a piece somebody
     // else is creating is waited for, nothing else is.
+    hipError_t ensure_piece(size_t pi) {
+        {
+            std::unique_lock<std::mutex> g(map_mu);
+            while (pieces[pi].state == 1) map_cv.wait(g);
+            if (pieces[pi].state == 2) return hipSuccess;
+            pieces[pi].state = 1;
+        }
+        const auto t0 = std::chrono::steady_clock::now();
+        hipMemGenericAllocationHandle_t h;
+        char* at = base + pi * chunk;
+        hipError_t rc = hipMemCreate(&h, chunk, &prop, 0);
+        if (rc == hipSuccess) {
+            rc = hipMemMap(at, chunk, 0, h, 0);
+            if (rc == hipSuccess) {
+                rc = hipMemSetAccess(at, chunk, access.data(), access.size());
+                if (rc != hipSuccess) (void)hipMemUnmap(at, chunk);
+            }
+            if (rc != hipSuccess) (void)hipMemRelease(h);
+        }
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        {
+            std::lock_guard<std::mutex> g(map_mu);
+            pieces[pi].state = rc == hipSuccess ? 2 : 0;
+            if (rc == hipSuccess) { pieces[pi].h = h; n_chunks++; mapped_bytes.fetch_add(chunk, std::memory_order_relaxed); }
+            map_seconds += dt;
+        }
+        map_cv.notify_all();
+        if (rc != hipSuccess) (void)hipGetLastError();
+        return rc;
+    }
     hipError_t ensure_mapped(size_t off, size_t bytes) {
         const size_t p0 = off / chunk, p1 = (off + bytes + chunk - 1) / chunk;
-        hipError_t rc = hipSuccess;
-        for (size_t pi = p0; pi < p1 && rc == hipSuccess; pi++) {
-            {
-                std::unique_lock<std::mutex> g(map_mu);
-                while (pieces[pi].state == 1) map_cv.wait(g);
-                if (pieces[pi].state == 2) continue;
-                pieces[pi].state = 1;
+        for (size_t pi = p0; pi < p1; pi++)
+            if (ensure_piece(pi) != hipSuccess) return hipErrorOutOfMemory;
+        return hipSuccess;
+    }
+    // pieces [0, bytes / chunk) on a thread of the arena's own (arena.hpp: arena_prefetch)
+    std::thread pf;
+    std::atomic<bool> pf_stop{false};
+    uint64_t pf_made = 0;
+    void stop_prefetch() {
+        pf_stop.store(true);
+        if (pf.joinable()) pf.join();
+    }
+    void prefetch(size_t bytes) {
+        stop_prefetch();
+        pf_stop.store(false);
+        const size_t n = std::min(pieces.size(), (bytes + chunk - 1) / chunk);
+        pf = std::thread([this, n] {
+            if (hipSetDevice(device) != hipSuccess) return;
+            for (size_t pi = 0; pi < n && !pf_stop.load(); pi++) {
+                { std::lock_guard<std::mutex> g(map_mu); if (pieces[pi].state == 2) continue; }
+                if (ensure_piece(pi) != hipSuccess) break;            // (no memory left for it: whoever needs the piece will say so)
+                pf_made++;
             }
-            const auto t0 = std::chrono::steady_clock::now();
-            hipMemGenericAllocationHandle_t h;
-            char* at = base + pi * chunk;
-            rc = hipMemCreate(&h, chunk, &prop, 0);
-            if (rc == hipSuccess) {
-                rc = hipMemMap(at, chunk, 0, h, 0);
-                if (rc == hipSuccess) {
-                    rc = hipMemSetAccess(at, chunk, access.data(), access.size());
-                    if (rc != hipSuccess) (void)hipMemUnmap(at, chunk);
-                }
-                if (rc != hipSuccess) (void)hipMemRelease(h);
-            }
-            const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            {
-                std::lock_guard<std::mutex> g(map_mu);
-                pieces[pi].state = rc == hipSuccess ? 2 : 0;
-                if (rc == hipSuccess) { pieces[pi].h = h; n_chunks++; mapped_bytes.fetch_add(chunk, std::memory_order_relaxed); }
-                map_seconds += dt;
-            }
-            map_cv.notify_all();
-        }
-        if (rc != hipSuccess) (void)hipGetLastError();
-        return rc == hipSuccess ? hipSuccess : hipErrorOutOfMemory;
+        });
     }
 
     // list_mu held
@@ -137,6 +162,7 @@ struct Arena {
 
     // list_mu held, nothing allocated, nobody pins: the physical memory goes back to the driver
     void trim() {
+        stop_prefetch();
         std::lock_guard<std::mutex> g(map_mu);
         int cur = -1;
         (void)hipGetDevice(&cur);
@@ -148,8 +174,8 @@ struct Arena {
         mapped_bytes.store(0, std::memory_order_release);
         if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
         if (env_user("PG_HOST_VERBOSE"))
-            fprintf(stderr, "arena (device %d): %.2f GB of physical memory in %llu piece(s), created in %.2fs in all; peak in use %.2f GB; %llu block(s) cut, %llu given back\n", device,
-                    (double)at / 1e9, (unsigned long long)n_chunks, map_seconds, (double)peak / 1e9, (unsigned long long)n_malloc, (unsigned long long)n_free);
+            fprintf(stderr, "arena (device %d): %.2f GB of physical memory in %llu piece(s), created in %.2fs in all; peak in use %.2f GB; %llu block(s) cut, %llu given back; %llu piece(s) made ahead of their use\n", device,
+                    (double)at / 1e9, (unsigned long long)n_chunks, map_seconds, (double)peak / 1e9, (unsigned long long)n_malloc, (unsigned long long)n_free, (unsigned long long)pf_made);
     }
 
     hipError_t malloc_(void** out, size_t bytes) {
@@ -256,6 +282,13 @@ hipError_t arena_mem_info(size_t* free_bytes, size_t* total_bytes) {
         if (mapped > a->in_use) *free_bytes += mapped - a->in_use;
     }
     return hipSuccess;
+}
+
+void arena_prefetch(int device, size_t bytes) {
+    Arena* a = arena_of(device);
+    if (!a || !a->active || !bytes) return;
+    std::lock_guard<std::mutex> g(a->list_mu);
+    a->prefetch(bytes);
 }
 
 void arena_pin(int device) {
