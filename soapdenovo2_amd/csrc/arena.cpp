@@ -162,6 +162,7 @@ struct Arena {
 
     // list_mu held, nothing allocated, nobody pins: the physical memory goes back to the driver
     void trim() {
+        const auto t_trim = std::chrono::steady_clock::now();
         stop_prefetch();
         std::lock_guard<std::mutex> g(map_mu);
         int cur = -1;
@@ -174,8 +175,9 @@ struct Arena {
         mapped_bytes.store(0, std::memory_order_release);
         if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
         if (env_user("PG_HOST_VERBOSE"))
-            fprintf(stderr, "arena (device %d): %.2f GB of physical memory in %llu piece(s), created in %.2fs in all; peak in use %.2f GB; %llu block(s) cut, %llu given back; %llu piece(s) made ahead of their use\n", device,
-                    (double)at / 1e9, (unsigned long long)n_chunks, map_seconds, (double)peak / 1e9, (unsigned long long)n_malloc, (unsigned long long)n_free, (unsigned long long)pf_made);
+            fprintf(stderr, "arena (device %d): %.2f GB of physical memory in %llu piece(s), created in %.2fs in all; peak in use %.2f GB; %llu block(s) cut, %llu given back; %llu piece(s) made ahead of their use; given back to the driver in %.2fs\n", device,
+                    (double)at / 1e9, (unsigned long long)n_chunks, map_seconds, (double)peak / 1e9, (unsigned long long)n_malloc, (unsigned long long)n_free, (unsigned long long)pf_made,
+                    std::chrono::duration<double>(std::chrono::steady_clock::now() - t_trim).count());
     }
 
     hipError_t malloc_(void** out, size_t bytes) {

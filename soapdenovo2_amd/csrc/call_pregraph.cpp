@@ -651,13 +651,17 @@ int run(int argc, char** argv, bool mer127) {
     // What the command will hold on a device at its peak, from what it holds once pass 1's pool is there: the export array beside it, then the sort's
     // and the layout's arrays and the k-mer sets (1.5x pool + export array at 10 M .. 200 M reads, profiles/r05_final_*.stderr.txt).  The arena makes
     // those pieces beside pass 1 (arena_prefetch) instead of in front of every stage -- seconds on a box whose driver is slow to hand memory out.
-    auto prefetch_arena = [&](int dev, uint64_t export_bytes) {
-        const pg::ArenaStats st = pg::arena_stats(dev);
-        if (!st.active) return;
+    auto prefetch_arena = [&](int dev, pg_ctx* const* cs, int n_cs, uint64_t export_bytes) {
+        if (!pg::arena_stats(dev).active) return;
         size_t free_b = 0, total_b = 0;
         (void)hipSetDevice(dev);
         if (pg::arena_mem_info(&free_b, &total_b) != hipSuccess) return;
-        const uint64_t want = (uint64_t)(1.5 * (double)(st.in_use + export_bytes));
+        uint64_t pools = 0;                                          // (from the contexts themselves: the export array's thread may or may not have cut its block yet)
+        for (int q = 0; q < n_cs; q++) {
+            uint64_t st[8];
+            if (cs[q] && pg_stats(cs[q], st) == PG_OK && st[0] == 2) pools += st[5] * 128 * st[3];     // pool chunks x records a chunk x bytes a record
+        }
+        const uint64_t want = (uint64_t)(1.5 * (double)(pools + export_bytes));
         pg::arena_prefetch(dev, (size_t)std::min<uint64_t>(want, (uint64_t)(0.8 * (double)total_b)));
     };
     // how much is coming: bases ~ half the bytes of a FASTQ file, all of a FASTA file (x4 behind gzip)
@@ -746,7 +750,12 @@ int run(int argc, char** argv, bool mer127) {
         {
             std::vector<int> seen;
             for (int r = 0; r < n_ranks; r++)
-                if (std::find(seen.begin(), seen.end(), devices[r]) == seen.end()) { seen.push_back(devices[r]); prefetch_arena(devices[r], 0); }        // (the ranks' export arrays are there already)
+                if (std::find(seen.begin(), seen.end(), devices[r]) == seen.end()) {
+                    seen.push_back(devices[r]);
+                    std::vector<pg_ctx*> here;
+                    for (int q = 0; q < n_ranks; q++) if (devices[q] == devices[r]) here.push_back(ctxs[q]);
+                    prefetch_arena(devices[r], here.data(), (int)here.size(), (uint64_t)(0.7 * (double)((uint64_t)1 << ls)) * (mer127 ? 6 : 4) * 8 * here.size());
+                }
         }
         {
             ShardedPass1 p1(ctxs, comms, devices, K, batch_words, batch_reads);
@@ -860,7 +869,7 @@ int run(int argc, char** argv, bool mer127) {
             if (!ctx) { fprintf(stderr, "%s\n", ctx_err.c_str()); die("pg_create"); }
             p1.set_ctx(ctx);
             mark("device context created (HIP start-up, record pool; the export array follows beside pass 1)");
-            if (attempt == 0) prefetch_arena(device, (uint64_t)(0.7 * (double)((uint64_t)1 << log2_slots)) * (mer127 ? 6 : 4) * 8);
+            if (attempt == 0) prefetch_arena(device, &ctx, 1, (uint64_t)(0.7 * (double)((uint64_t)1 << log2_slots)) * (mer127 ? 6 : 4) * 8);
             if (attempt == 0) fprintf(stderr, "%d k-mer set(s) on HIP device %d.\n", o.sets, device);
             if (attempt == 0) {
                 p1.keep_reads(keep_budget);
