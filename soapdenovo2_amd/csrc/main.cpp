@@ -3,9 +3,13 @@
 // Only the pregraph sub-command lives here; contig / map / scaff are the reference's unchanged stages and
 // consume the files this one writes.
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
+#include <time.h>
+#include <unistd.h>
 
 #include "../../include/soapdenovo2_amd.h"
+#include "env.hpp"
 
 static void usage(void) {
     fprintf(stderr, "\n%s\n\nUsage: SOAPdenovo <command> [option]\n", pg_version());
@@ -16,12 +20,20 @@ static void usage(void) {
 int main(int argc, char** argv) {
     if (argc < 2) { usage(); return 1; }
     if (strcmp(argv[1], "pregraph") == 0) {
+        struct timespec t0, t1;
+        clock_gettime(CLOCK_MONOTONIC, &t0);
         pg_process_exits_after_this(1);              // nothing follows in this process: big tables are left to the exit path
 #ifdef PG_MER127
-        return call_pregraph_127mer(argc - 1, argv + 1);
+        const int rc = call_pregraph_127mer(argc - 1, argv + 1);
 #else
-        return call_pregraph(argc - 1, argv + 1);
+        const int rc = call_pregraph(argc - 1, argv + 1);
 #endif
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if (pg::env_user("PG_HOST_VERBOSE")) fprintf(stderr, "[cli] call_pregraph returned after %.2fs\n", (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec));
+        // Every file is written and closed, every thread joined, the device arena given back: what is left is the HIP runtime's own tear-down (module
+        // unloading, the 288 GB address reservation, ...), up to a second of it on a process that held 200 GB -- the process ends here instead.
+        fflush(NULL);
+        _exit(rc);
     }
     fprintf(stderr, "Command '%s' is not part of this build.\n", argv[1]);
     usage();
