@@ -11,7 +11,6 @@
 #include <algorithm>
 #include <map>
 #include <mutex>
-#include <thread>
 #include <unordered_map>
 #include <vector>
 
@@ -127,28 +126,6 @@ struct Arena {
             if (ensure_piece(pi) != hipSuccess) return hipErrorOutOfMemory;
         return hipSuccess;
     }
-    // pieces [0, bytes / chunk) on a thread of the arena's own (arena.hpp: arena_prefetch)
-    std::thread pf;
-    std::atomic<bool> pf_stop{false};
-    uint64_t pf_made = 0;
-    void stop_prefetch() {
-        pf_stop.store(true);
-        if (pf.joinable()) pf.join();
-    }
-    void prefetch(size_t bytes) {
-        stop_prefetch();
-        pf_stop.store(false);
-        const size_t n = std::min(pieces.size(), (bytes + chunk - 1) / chunk);
-        pf = std::thread([this, n] {
-            if (hipSetDevice(device) != hipSuccess) return;
-            for (size_t pi = 0; pi < n && !pf_stop.load(); pi++) {
-                { std::lock_guard<std::mutex> g(map_mu); if (pieces[pi].state == 2) continue; }
-                if (ensure_piece(pi) != hipSuccess) break;            // (no memory left for it: whoever needs the piece will say so)
-                pf_made++;
-            }
-        });
-    }
-
     // list_mu held
     void give_back(size_t off, size_t bytes) {
         auto nx = free_.lower_bound(off);
@@ -163,7 +140,6 @@ struct Arena {
     // list_mu held, nothing allocated, nobody pins: the physical memory goes back to the driver
     void trim() {
         const auto t_trim = std::chrono::steady_clock::now();
-        stop_prefetch();
         std::lock_guard<std::mutex> g(map_mu);
         int cur = -1;
         (void)hipGetDevice(&cur);
@@ -175,8 +151,8 @@ struct Arena {
         mapped_bytes.store(0, std::memory_order_release);
         if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
         if (env_user("PG_HOST_VERBOSE"))
-            fprintf(stderr, "arena (device %d): %.2f GB of physical memory in %llu piece(s), created in %.2fs in all; peak in use %.2f GB; %llu block(s) cut, %llu given back; %llu piece(s) made ahead of their use; given back to the driver in %.2fs\n", device,
-                    (double)at / 1e9, (unsigned long long)n_chunks, map_seconds, (double)peak / 1e9, (unsigned long long)n_malloc, (unsigned long long)n_free, (unsigned long long)pf_made,
+            fprintf(stderr, "arena (device %d): %.2f GB of physical memory in %llu piece(s), created in %.2fs in all; peak in use %.2f GB; %llu block(s) cut, %llu given back; given back to the driver in %.2fs\n", device,
+                    (double)at / 1e9, (unsigned long long)n_chunks, map_seconds, (double)peak / 1e9, (unsigned long long)n_malloc, (unsigned long long)n_free,
                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t_trim).count());
     }
 
@@ -284,13 +260,6 @@ hipError_t arena_mem_info(size_t* free_bytes, size_t* total_bytes) {
         if (mapped > a->in_use) *free_bytes += mapped - a->in_use;
     }
     return hipSuccess;
-}
-
-void arena_prefetch(int device, size_t bytes) {
-    Arena* a = arena_of(device);
-    if (!a || !a->active || !bytes) return;
-    std::lock_guard<std::mutex> g(a->list_mu);
-    a->prefetch(bytes);
 }
 
 void arena_pin(int device) {

@@ -26,12 +26,6 @@ hipError_t arena_free(void* p);
 void arena_pin(int device);
 void arena_unpin(int device);            // (the last unpin of an empty arena releases its physical memory)
 
-// The pieces under the first `bytes` of the range are created by a thread of the arena's own, in address order, beside whatever the caller does next.
-// On a box whose driver takes seconds for a hundred gigabytes (it clears memory another process released) call_pregraph asks for what the command will
-// need in the end as soon as pass 1's pool is there: the pieces the later stages cut their blocks from are then made beside the reader instead of in
-// front of every stage.  Costs nothing where the driver is quick; a piece somebody needs earlier is made by whoever needs it (per-piece lock).
-void arena_prefetch(int device, size_t bytes);
-
 // hipMemGetInfo of the current device, with what the arena holds mapped but has not handed out counted as free (it is, to this library)
 hipError_t arena_mem_info(size_t* free_bytes, size_t* total_bytes);
 

@@ -648,22 +648,6 @@ int run(int argc, char** argv, bool mer127) {
         for (int d : n_ranks > 1 ? devices : std::vector<int>{device})
             if (std::find(seen.begin(), seen.end(), d) == seen.end()) { seen.push_back(d); arena_pins.emplace_back(new pg::ArenaPin(d)); }
     }
-    // What the command will hold on a device at its peak, from what it holds once pass 1's pool is there: the export array beside it, then the sort's
-    // and the layout's arrays and the k-mer sets (1.5x pool + export array at 10 M .. 200 M reads, profiles/r05_final_*.stderr.txt).  The arena makes
-    // those pieces beside pass 1 (arena_prefetch) instead of in front of every stage -- seconds on a box whose driver is slow to hand memory out.
-    auto prefetch_arena = [&](int dev, pg_ctx* const* cs, int n_cs, uint64_t export_bytes) {
-        if (!pg::arena_stats(dev).active) return;
-        size_t free_b = 0, total_b = 0;
-        (void)hipSetDevice(dev);
-        if (pg::arena_mem_info(&free_b, &total_b) != hipSuccess) return;
-        uint64_t pools = 0;                                          // (from the contexts themselves: the export array's thread may or may not have cut its block yet)
-        for (int q = 0; q < n_cs; q++) {
-            uint64_t st[8];
-            if (cs[q] && pg_stats(cs[q], st) == PG_OK && st[0] == 2) pools += st[5] * 128 * st[3];     // pool chunks x records a chunk x bytes a record
-        }
-        const uint64_t want = (uint64_t)(1.5 * (double)(pools + export_bytes));
-        pg::arena_prefetch(dev, (size_t)std::min<uint64_t>(want, (uint64_t)(0.8 * (double)total_b)));
-    };
     // how much is coming: bases ~ half the bytes of a FASTQ file, all of a FASTA file (x4 behind gzip)
     uint64_t est_kmers = 0;
     for (const pg::InputFile& f : files)
@@ -747,16 +731,6 @@ int run(int argc, char** argv, bool mer127) {
             if (!ctxs[r]) die("pg_create");
         }
         mark("device context created (HIP start-up, record pools, export arrays of all ranks)");
-        {
-            std::vector<int> seen;
-            for (int r = 0; r < n_ranks; r++)
-                if (std::find(seen.begin(), seen.end(), devices[r]) == seen.end()) {
-                    seen.push_back(devices[r]);
-                    std::vector<pg_ctx*> here;
-                    for (int q = 0; q < n_ranks; q++) if (devices[q] == devices[r]) here.push_back(ctxs[q]);
-                    prefetch_arena(devices[r], here.data(), (int)here.size(), (uint64_t)(0.7 * (double)((uint64_t)1 << ls)) * (mer127 ? 6 : 4) * 8 * here.size());
-                }
-        }
         {
             ShardedPass1 p1(ctxs, comms, devices, K, batch_words, batch_reads);
             mark("pinned batch buffers allocated");
@@ -869,7 +843,6 @@ int run(int argc, char** argv, bool mer127) {
             if (!ctx) { fprintf(stderr, "%s\n", ctx_err.c_str()); die("pg_create"); }
             p1.set_ctx(ctx);
             mark("device context created (HIP start-up, record pool; the export array follows beside pass 1)");
-            if (attempt == 0) prefetch_arena(device, &ctx, 1, (uint64_t)(0.7 * (double)((uint64_t)1 << log2_slots)) * (mer127 ? 6 : 4) * 8);
             if (attempt == 0) fprintf(stderr, "%d k-mer set(s) on HIP device %d.\n", o.sets, device);
             if (attempt == 0) {
                 p1.keep_reads(keep_budget);

@@ -6,7 +6,6 @@
 #include <stdlib.h>
 #include <string.h>
 #include <time.h>
-#include <unistd.h>
 
 #include "../../include/soapdenovo2_amd.h"
 #include "env.hpp"
@@ -30,10 +29,7 @@ int main(int argc, char** argv) {
 #endif
         clock_gettime(CLOCK_MONOTONIC, &t1);
         if (pg::env_user("PG_HOST_VERBOSE")) fprintf(stderr, "[cli] call_pregraph returned after %.2fs\n", (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec));
-        // Every file is written and closed, every thread joined, the device arena given back: what is left is the HIP runtime's own tear-down (module
-        // unloading, the 288 GB address reservation, ...), up to a second of it on a process that held 200 GB -- the process ends here instead.
-        fflush(NULL);
-        _exit(rc);
+        return rc;
     }
     fprintf(stderr, "Command '%s' is not part of this build.\n", argv[1]);
     usage();
