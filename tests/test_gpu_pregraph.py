@@ -575,6 +575,7 @@ def test_context_sized_like_the_command_legs_can_be_created(K, reads, L, log2_sl
     from soapdenovo2_amd import api
     L_ = api.lib()
     n_kmers = reads * (L - K + 1)
+    before = api.arena_stats(0)["in_use"]
     h = L_.pg_create_sized(0, K, 1 if K > 63 else 0, 8, log2_slots, 2, n_kmers)
     assert h, L_.pg_last_error().decode()
     st = (C.c_uint64 * 8)()
@@ -582,7 +583,43 @@ def test_context_sized_like_the_command_legs_can_be_created(K, reads, L, log2_sl
     assert st[0] == 2 and st[5] > st[6]                                      # engine 2; more pool chunks than partitions
     L_.pg_destroy(h)
     a = api.arena_stats(0)
-    assert a["active"] in (0, 1) and a["in_use"] == 0                         # everything went back to the arena (and, unpinned, to the driver)
+    assert a["active"] in (0, 1) and a["in_use"] == before                    # everything went back to the arena (and, unpinned and empty, to the driver)
+
+
+@pytest.mark.gpu
+def test_device_arena_gives_memory_back_when_empty_and_keeps_it_while_pinned():
+    """csrc/arena.hpp through the C ABI: a context's blocks come out of the arena (in use > 0, physical memory mapped); destroying the last
+    context of an unpinned arena gives the physical memory back to the driver; a pinned arena keeps it across contexts (what call_pregraph does
+    for the length of a command) until the unpin."""
+    from soapdenovo2_amd import api
+    L_ = api.lib()
+    if not api.arena_stats(0)["active"] and os.environ.get("SOAPDENOVO2_AMD_ARENA") == "0":
+        pytest.skip("the arena is switched off")
+    import gc
+    gc.collect()                                                              # (contexts of earlier tests that were left to the collector)
+    base = api.arena_stats(0)
+    alone = base["in_use"] == 0                                               # nothing else of this process holds a block
+    h = L_.pg_create_sized(0, 31, 0, 8, 24, 2, 70_000_000)
+    assert h, L_.pg_last_error().decode()
+    a = api.arena_stats(0)
+    assert a["active"] == 1 and a["in_use"] > base["in_use"] and a["mapped"] >= a["in_use"] and a["reserved"] >= a["mapped"]
+    L_.pg_destroy(h)
+    b = api.arena_stats(0)
+    assert b["in_use"] == base["in_use"]
+    if alone:
+        assert b["mapped"] == 0                                               # empty and unpinned: back to the driver
+    with api.arena_pinned(0):
+        h = L_.pg_create_sized(0, 31, 0, 8, 24, 2, 70_000_000)
+        assert h
+        L_.pg_destroy(h)
+        c = api.arena_stats(0)
+        assert c["in_use"] == base["in_use"] and c["mapped"] > 0              # pinned: the pieces stay
+        made = c["pieces_created"]
+        h = L_.pg_create_sized(0, 31, 0, 8, 24, 2, 70_000_000)
+        assert h and api.arena_stats(0)["pieces_created"] == made              # ... and the next context is cut from them: nothing new from the driver
+        L_.pg_destroy(h)
+    if alone:
+        assert api.arena_stats(0)["mapped"] == 0
 
 
 def test_sharded_pass1_rccl_single_rank(golden, tmp_path):
