@@ -8,7 +8,7 @@
 #   stats[:<bench args>]             rocprofv3 --kernel-trace --stats of a kernels-only bench run -> kernel_stats<i>.csv
 #   pmc:<counters>[:<bench args>]    one rocprofv3 --pmc pass (comma-separated counters) of a short kernels-only run -> pmc<i>_*.csv
 #   phases[:<bench args>]            K2's phase cycles from the -DPG_MEASURE library (SOAPDENOVO2_AMD_LIB=..._measure.so, PG_K2_TIMERS=1)
-#   cli:<reads>:<a_gb>:<expect json>:<tag>[:ENV=V,ENV=V]   the executable on a synth_fastq file of <reads> x 150 bp (kept in /tmp across the steps of a call),
+#   cli:<reads>:<a_gb>:<expect json>:<tag>[:ENV=V+ENV=V]   the executable on a synth_fastq file of <reads> x 150 bp (kept in /tmp across the steps of a call),
 #                                    md5s against the reference's (scripts/big_cli_check.py) -> result_<tag>.json, stderr_<tag>.txt
 #   sh:<command>                     anything else, logged to sh<i>.log
 # A step's bench arguments use ',' for ' ' (gpurun hands one string to bash).
@@ -45,7 +45,7 @@ for step in "$@"; do
         grep "K2 phase" "$O/phases$i.txt" | tail -12;;
     cli)
         IFS=: read -r c_reads c_agb c_exp c_tag c_env <<< "$arg"
-        envs=""; for kv in ${c_env//,/ }; do envs="$envs --env $kv"; done
+        envs=""; for kv in ${c_env//+/ }; do envs="$envs --env $kv"; done
         mkdir -p /tmp/big_$c_reads
         timeout 1500 python scripts/big_cli_check.py --reads "$c_reads" --a-gb "$c_agb" --expect "$c_exp" --out /tmp/big_$c_reads --keep-fastq --tag "_$c_tag" $envs > "$O/cli$i.log" 2>&1; echo "[$i] cli $c_tag rc=$?"
         cp /tmp/big_$c_reads/result_$c_tag.json /tmp/big_$c_reads/stderr_$c_tag.txt "$O/" 2>/dev/null

@@ -2090,7 +2090,9 @@ static int p2_route_round(P2Device* d) {
             ln.lookups_sent += c;
             if (l != o) ln.lookups_sent_away += c;
         }
-        const dim3 grid((unsigned)std::min<uint64_t>((recv_total[o] + 255) / 256, 1u << 20)), block(256);
+        // (a workgroup builds the CRC table and the set geometry in LDS before its first probe: a few thousand workgroups that stride over the keys, not one per 256 keys --
+        //  36 launches of 147 M keys took 509 ms with half a million workgroups each, profiles/r05n_kernel_stats_cli_60M_sh3_routed.csv)
+        const dim3 grid((unsigned)std::min<uint64_t>((recv_total[o] + 255) / 256, 256u * 16u)), block(256);
         if (nw == 2) hipLaunchKernelGGL((p2_answer_kernel<2>), grid, block, 0, ow.stream, ow.prm, ow.rkeys.p, recv_total[o], ow.rans.p);
         else hipLaunchKernelGGL((p2_answer_kernel<4>), grid, block, 0, ow.stream, ow.prm, ow.rkeys.p, recv_total[o], ow.rans.p);
         P2_HIP(hipGetLastError());
