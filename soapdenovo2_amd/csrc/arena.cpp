@@ -65,9 +65,7 @@ struct Arena {
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) return;
         chunk = round_up((size_t)512 << 20, gran);                        // physical memory comes in pieces of this size
         reserved = round_up(total_b, chunk);
-        void* p = nullptr;
-        if (hipMemAddressReserve(&p, reserved, 0, nullptr, 0) != hipSuccess || !p) { (void)hipGetLastError(); return; }
-        base = (char*)p;
+        if (!reserve_range()) return;
         // who may touch the memory: this GPU, and every GPU of the process that can reach it (a sharded run probes the k-mer sets of
         // the other ranks through peer mappings)
         int n_dev = 0;
@@ -83,9 +81,22 @@ struct Arena {
             a.flags = hipMemAccessFlagsProtReadWrite;
             access.push_back(a);
         }
+        if (const char* e = env_test("PG_ARENA_KEEP")) if (atoi(e) != 0) pins = 1;      // (test hook: the pieces stay for the life of the process)
+        active = true;
+    }
+    // A fresh virtual range for the arena's next life.  A range whose pieces were given back (trim) is RETIRED, never mapped again: with new physical
+    // memory mapped at addresses the GPU had translations for, contexts created behind a trim read back something else than they had just written --
+    // five of six runs of the counting tests right behind a process that had released 150 GB failed that way, none with the pieces kept, none with plain
+    // hipMalloc (profiles/r05w_arena_remap_hazard.txt).  Address space is not scarce: a retired range costs 288 GB of a 47-bit space.
+    std::vector<std::pair<char*, size_t>> retired;
+    bool reserve_range() {
+        void* p = nullptr;
+        if (hipMemAddressReserve(&p, reserved, 0, nullptr, 0) != hipSuccess || !p) { (void)hipGetLastError(); return false; }
+        base = (char*)p;
+        free_.clear();
         free_[0] = reserved;
         pieces.assign(reserved / chunk, Piece{hipMemGenericAllocationHandle_t(), 0});
-        active = true;
+        return true;
     }
 
     // physical memory under [off, off + bytes); called without list_mu.  Pieces are created where they are needed, in any order; a piece somebody
@@ -149,6 +160,8 @@ struct Arena {
         for (size_t pi = 0; pi < pieces.size(); pi++)
             if (pieces[pi].state == 2) { (void)hipMemUnmap(base + pi * chunk, chunk); (void)hipMemRelease(pieces[pi].h); pieces[pi].state = 0; at += chunk; }
         mapped_bytes.store(0, std::memory_order_release);
+        retired.emplace_back(base, reserved);                              // (see reserve_range: this range is never mapped again)
+        if (!reserve_range()) { active = false; base = nullptr; }          // (no address space left: plain hipMalloc from here on)
         if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
         if (env_user("PG_HOST_VERBOSE"))
             fprintf(stderr, "arena (device %d): %.2f GB of physical memory in %llu piece(s), created in %.2fs in all; peak in use %.2f GB; %llu block(s) cut, %llu given back; given back to the driver in %.2fs\n", device,
@@ -233,7 +246,13 @@ hipError_t arena_malloc(void** p, size_t bytes) {
     if (rc != hipSuccess) return rc;
     Arena* a = arena_of(dev);
     if (!a || !a->active) return hipMalloc(p, bytes);
-    return a->malloc_(p, bytes);
+    rc = a->malloc_(p, bytes);
+    // A block of the arena holds whatever its last user (of this process, or -- pieces are not cleared by the driver -- of an earlier one) left there,
+    // where hipMalloc hands out zeroes.  PG_ARENA_POISON=1 (test hook) fills every block with 0xA5 so that code that counts on zeroes fails every time,
+    // not once in a while.
+    static const bool poison = env_test("PG_ARENA_POISON") != nullptr && atoi(env_test("PG_ARENA_POISON")) != 0;
+    if (rc == hipSuccess && poison) { rc = hipMemset(*p, 0xA5, bytes); if (rc == hipSuccess) rc = hipDeviceSynchronize(); }     // (the fill is done before any stream of the caller touches the block)
+    return rc;
 }
 
 hipError_t arena_free(void* p) {

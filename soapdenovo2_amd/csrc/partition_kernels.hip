@@ -47,8 +47,11 @@ template <int NW> struct E2Cfg;
 // is the empty mark ~0 and a slot is claimed word by word.  Four-word flavour: 254 bits do not fit four such words, and a fifth costs
 // 8 of 68 bytes a slot -- the k-mer's own four words instead (the first, the most significant, has its two top bits free: never ~0,
 // and bit 63 marks a slot whose other words are still being written; lds_put)
-template <> struct E2Cfg<2> { static constexpr int PW = 5, KW = 2; static constexpr bool RAW = false; };   // LDS slot: 2 key words + ord + 20 B of counters = 44 B
-template <> struct E2Cfg<4> { static constexpr int PW = 7, KW = 4; static constexpr bool RAW = true; };              // 4 key words + ord + 20 B = 60 B: 2048 slots in 120 KB
+// MAXPROBE: a put gives up behind that many slots and the attempt is dropped (below).  48 until round 5; measured then at 200 M reads (profiles/r05q_k2_maxprobe_ab.json):
+// K = 63  48 -> 142.6 ms, 64 -> 139.4, 96 -> 137.3, 128 -> 136.7, 192 -> 136.3, 256 -> 136.4;  K = 127  48 -> 128.6, 96 -> 126.0, 128 -> 126.5, 192 -> 128.1 --
+// one partition in fifty was dropped and counted again in two sittings for a probe sequence the set could well have taken.
+template <> struct E2Cfg<2> { static constexpr int PW = 5, KW = 2, MAXPROBE = 128; static constexpr bool RAW = false; };   // LDS slot: 2 key words + ord + 20 B of counters = 44 B
+template <> struct E2Cfg<4> { static constexpr int PW = 7, KW = 4, MAXPROBE = 96; static constexpr bool RAW = true; };    // 4 key words + ord + 20 B = 60 B: 2048 slots in 120 KB
 
 struct E2Dev {
     SkmGeom g;
@@ -306,10 +309,9 @@ struct LdsSet {
 };
 __device__ __forceinline__ unsigned int clip_halves_255(unsigned int x) { return min(x & 0xFFFFu, 255u) | (min(x >> 16, 255u) << 16); }
 
-// A put gives up when the set is too full (a probe sequence longer than MAXPROBE): the caller aborts the attempt and
+// A put gives up when the set is too full (a probe sequence longer than E2Cfg<NW>::MAXPROBE): the caller aborts the attempt and
 // splits the key range.  No shared key counter and no list of claimed slots on this path: measured again in round 2 (one
 // wave-aggregated LDS atomic per step that claims a slot), the put loop lost more than the emit's listing phase costs.
-constexpr int K2_MAXPROBE = 48;
 constexpr int K2_MAXSPIN = 4096;                                           // looks at a slot that is being claimed (four-word flavour)
 
 __device__ __forceinline__ const uint64_t* record_ptr(const E2Dev& e, uint32_t pid, uint32_t i, int) {
@@ -351,7 +353,7 @@ __device__ __forceinline__ bool lds_put(LdsSet<NW, SLOTS>& t, const uint64_t (&k
         // (looking again is not a probe: a lane that keeps meeting a slot another wave is still filling must not run out of the probe budget and
         //  report a full set -- the attempt would be dropped and the key range split for nothing; the spins have their own, larger bound)
         constexpr unsigned long long L_PENDING = 1ULL << 63;
-        for (int probes = 0, spins = 0; probes < K2_MAXPROBE && spins < K2_MAXSPIN;) {
+        for (int probes = 0, spins = 0; probes < E2Cfg<NW>::MAXPROBE && spins < K2_MAXSPIN;) {
             unsigned long long seen[KW];
 #pragma unroll
             for (int i = 0; i < KW; i++)                                  // (an LDS pointer, said so: a plain volatile one is read through the flat path, one load at a time)
@@ -383,7 +385,7 @@ __device__ __forceinline__ bool lds_put(LdsSet<NW, SLOTS>& t, const uint64_t (&k
         }
         return false;
     }
-    for (int probes = 0; probes < K2_MAXPROBE; probes++) {
+    for (int probes = 0; probes < E2Cfg<NW>::MAXPROBE; probes++) {
         unsigned long long seen[KW];
 #pragma unroll
         for (int i = 0; i < KW; i++) seen[i] = t.key[i][h];
