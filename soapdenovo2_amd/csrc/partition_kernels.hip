@@ -448,11 +448,9 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     // lanes -- 116 -> 65 of them when they became constants, 152.5 -> 145.3 ms at K = 63, profiles/r04y_k2_switches_as_constants.json):
     //   * the emit lists the live slots in any order through one returned LDS atomic a wave and stripe (the export order is unspecified anyway);
     //   * a wave asks for its next tile when it has finished the current one;
-    //   * PRESPLIT (four-word flavour only: it drops one attempt in ten, the two-word one in a hundred and loses more to false alarms): a key range
-    //     foreseen to overflow the set is split BEFORE it is counted, from PRESPLIT_PCT % foreseen load on;
+    //   * no split ahead of a foreseen overflow (round 4 split a four-word key range before counting it at 75 % foreseen load: with the probe limit at 96
+    //     instead of 48 it stopped paying -- 126.0 ms with it, 125.4 without, profiles/r05q_k2_maxprobe_ab.json);
     //   * ADAPT (four-word flavour only): the search for exact copies stops where a workgroup finds few (see p_dedupe).
-    constexpr bool PRESPLIT = NW == 4;
-    constexpr unsigned PRESPLIT_PCT = 75;
     constexpr int PW = E2Cfg<NW>::PW, RW = PW + 1, KW = E2Cfg<NW>::KW, NWAVE = THREADS / 64, PIECES = RW / 2, N2 = 2 * NW;
     constexpr int RD = 2 * RW;                                            // dwords a record
     constexpr int PAD = 16;                                               // readable dwords in front of record 0 (a window reaches back 2 NW + 2)
@@ -805,11 +803,6 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
         nrec_next = pf_nrec;
         cid_next = chunk_take(blockIdx.x, threadIdx.x, pf_cid);
     }
-    // PRESPLIT: a key range that is going to overflow the set is split BEFORE it is counted.  A dropped attempt costs the attempt and two
-    // sittings over the same window; what a single-window partition will hold is foreseeable from its occurrences after the dedupe
-    // (s_tot) and the share of occurrences that turned out distinct in this workgroup's partitions so far (acc_live / acc_occ, the
-    // same in every lane): beyond ~55 - 65 % of the slots a probe sequence of 48 is to be expected.
-    uint32_t acc_live = 0, acc_occ = 0;
     int b = 0, cl = 0;                                                    // the current window's buffer, the current partition's chunk list
     bool staged = false;                                                  // its first window is already on its way into rl2[b] (asked for by the previous emit)
     for (uint32_t pid = blockIdx.x; pid < parts; pid += gridDim.x) {
@@ -855,7 +848,6 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 K2_SYNC();
             }
             K2_TICK(1);
-            bool presplit = false;
             for (uint32_t w0 = 0; w0 < usable; w0 += WIN) {
                 const uint32_t wn = min((uint32_t)WIN, usable - w0);
                 if (!(window_ready && w0 == 0)) {
@@ -881,9 +873,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 window_ready = usable <= WIN;                             // a single window stays good for the other key ranges
                 const uint32_t total_occ = s_tot;
                 const uint32_t* const rl = rl2[b];
-                if (PRESPLIT && mask == 0 && usable <= (uint32_t)WIN && acc_occ >= 4096u &&
-                    (unsigned long long)total_occ * acc_live * 100ull > (unsigned long long)PRESPLIT_PCT * SLOTS * (unsigned long long)acc_occ) presplit = true;
-                if (!presplit && !__hip_atomic_load(&aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
+                if (!__hip_atomic_load(&aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) {
                   // tiles of 64 occurrences: the wave's first one is its own number, the next ones come off the counter
                   for (uint32_t tile = (uint32_t)wave;;) {
                     if (tile * 64u >= total_occ || __hip_atomic_load(&aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) break;
@@ -955,9 +945,9 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 }
                 K2_TICK(5);
             }
-            if (aborted || presplit) {                                    // (read behind the window loop's last barrier: the same for every lane)
+            if (aborted) {                                                // (read behind the window loop's last barrier: the same for every lane)
                 if (TIMERS) tp[9 * TIMERS]++;
-                dirty = !presplit;                                        // (a range split ahead of time never touched the set)
+                dirty = true;
                 // too many distinct keys for the LDS set: split this key range on the next hash bit and redo both halves
                 const uint32_t bit = mask + 1;                            // masks are 2^k - 1
                 if (bit >= (1u << 20) || top + 2 > 40) {
@@ -989,10 +979,6 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                     K2_SYNC();
                     K2_TICK(6);
                     const unsigned int n_live = s_nlive;
-                    if (mask == 0 && usable <= (uint32_t)WIN) {            // a whole single-window partition: what share of its occurrences were distinct
-                        acc_live += n_live; acc_occ += s_tot;
-                        if (acc_occ > (1u << 30)) { acc_live >>= 1; acc_occ >>= 1; }
-                    }
                     for (unsigned int c0 = 0; c0 < n_live; c0 += STAGE_CAP) {
                         const unsigned int cn = min(STAGE_CAP, n_live - c0);
                         e_final(whole, threadIdx.x, sb, c0, cn, n_live);
