@@ -8,6 +8,12 @@
 // never to the driver -- until the arena is empty and nobody pins it.  call_pregraph pins its devices for the whole command, so the command's
 // physical memory is created once, on the way up, and released once, at its end.
 //
+// A range lives from its first block to the moment the arena is empty and unpinned; its pieces are then given back and the RANGE IS RETIRED -- the
+// arena's next life gets a fresh reservation (mapping new memory at addresses the GPU already had translations for read back wrong data,
+// profiles/r05w_arena_remap_hazard.txt).  A retired range costs address space only (288 GB of 2^47 each); a process that has used that up -- hundreds
+// of create / destroy cycles without a pin -- goes on with plain hipMalloc.  Callers that cycle contexts pin the device around the loop (ArenaPin,
+// pg_device_arena_pin): one life, one range.
+//
 // arena_malloc / arena_free have hipMalloc's / hipFree's contract (current device; arena_free waits for the device like hipFree does, so a block
 // is never handed out again under a kernel that still uses it).  A GPU or driver without the virtual-memory calls, or SOAPDENOVO2_AMD_ARENA=0,
 // makes both plain hipMalloc / hipFree.
