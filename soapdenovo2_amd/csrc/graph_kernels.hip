@@ -2007,6 +2007,8 @@ int p2_build_edges(P2Device* d, P2Edges& out) {
     }
     out.n_ids = (long long)total_ids;
 done:
+    for (size_t l = 0; l < NL; l++) if (lane_recs[l]) { (void)hipSetDevice(d->lanes[l].device); pg::arena_free(lane_recs[l]); lane_recs[l] = nullptr; }     // (an error between the walks and the gather)
+    (void)hipSetDevice(d->device);
     pg::arena_free(d_list); pg::arena_free(d_cnt); pg::arena_free(d_key); pg::arena_free(d_key2); pg::arena_free(d_ids); pg::arena_free(d_bases); pg::arena_free(d_id_before); pg::arena_free(d_base_before);
     pg::arena_free(d_idx); pg::arena_free(d_order); pg::arena_free(d_recs); pg::arena_free(d_export); pg::arena_free(d_text); pg::arena_free(d_tmp);
     pg::arena_free(d_way); pg::arena_free(d_wcnt); pg::arena_free(way.key); pg::arena_free(way.seg_end); pg::arena_free(way.seg_info); pg::arena_free(way.seg_sum); pg::arena_free(way.vis_own); pg::arena_free(way.vis_info);
