@@ -116,6 +116,19 @@ struct Arena {
             rc = hipMemMap(at, chunk, 0, h, 0);
             if (rc == hipSuccess) {
                 rc = hipMemSetAccess(at, chunk, access.data(), access.size());
+                if (rc != hipSuccess && access.size() > 1) {
+                    // (the peers could not all be granted -- a process that sees GPUs it never opened, one rank a process: this GPU alone then, for this
+                    //  and every later piece; a sharded run INSIDE one process would have failed at its peer mappings anyway)
+                    (void)hipGetLastError();
+                    hipMemAccessDesc self = access[0];
+                    for (const hipMemAccessDesc& a : access) if (a.location.id == device) self = a;
+                    rc = hipMemSetAccess(at, chunk, &self, 1);
+                    if (rc == hipSuccess) {
+                        std::lock_guard<std::mutex> g(map_mu);
+                        access.assign(1, self);
+                        if (env_user("PG_HOST_VERBOSE")) fprintf(stderr, "arena (device %d): peer access could not be granted, the arena's memory is this GPU's alone\n", device);
+                    }
+                }
                 if (rc != hipSuccess) (void)hipMemUnmap(at, chunk);
             }
             if (rc != hipSuccess) (void)hipMemRelease(h);
