@@ -35,6 +35,13 @@
 
 namespace {
 
+// Memory a communicator owns for its exchanges (count words, send / receive regions).  With the RCCL transport it comes straight from hipMalloc: these
+// buffers are handed to ncclSend / ncclRecv, they are allocated once per communicator (nothing for the arena to save), and RCCL has only ever met
+// plain device allocations here -- one unknown less on the first multi-GPU run.  (pg::arena_free gives either kind back.)
+static hipError_t comm_malloc(int transport, void** p, size_t bytes) {
+    if (transport == PG_COMM_RCCL) return hipMalloc(p, bytes ? bytes : 1);
+    return pg::arena_malloc(p, bytes);
+}
 #define X_TRY(expr)                                                                            \
     do {                                                                                       \
         hipError_t e_ = (expr);                                                                \
@@ -164,8 +171,8 @@ namespace {
 
 int comm_alloc_small(pg_comm* c) {
     X_TRY(hipSetDevice(c->device));
-    X_TRY(pg::arena_malloc((void**)&c->d_counts, sizeof(uint64_t) * (size_t)c->n));
-    X_TRY(pg::arena_malloc((void**)&c->d_rcounts, sizeof(uint64_t) * (size_t)c->n));
+    X_TRY(comm_malloc(c->transport, (void**)&c->d_counts, sizeof(uint64_t) * (size_t)c->n));
+    X_TRY(comm_malloc(c->transport, (void**)&c->d_rcounts, sizeof(uint64_t) * (size_t)c->n));
     c->h_counts.assign(c->n, 0);
     c->h_rcounts.assign(c->n, 0);
     return PG_OK;
@@ -460,10 +467,10 @@ int pipe_alloc(pg_comm* c, uint64_t cap, int rw, FirstError& err) {
     pipe_free(c);
     const uint64_t n = (uint64_t)c->n;
     for (auto& sl : c->slot) {
-        err.hip(pg::arena_malloc((void**)&sl.d_send_recs, cap * n * rw * 8), "hipMalloc (send region)");
-        err.hip(pg::arena_malloc((void**)&sl.d_send_parts, cap * n * 4), "hipMalloc (send region)");
-        err.hip(pg::arena_malloc((void**)&sl.d_recv_recs, cap * n * rw * 8), "hipMalloc (receive region)");
-        err.hip(pg::arena_malloc((void**)&sl.d_recv_parts, cap * n * 4), "hipMalloc (receive region)");
+        err.hip(comm_malloc(c->transport, (void**)&sl.d_send_recs, cap * n * rw * 8), "hipMalloc (send region)");
+        err.hip(comm_malloc(c->transport, (void**)&sl.d_send_parts, cap * n * 4), "hipMalloc (send region)");
+        err.hip(comm_malloc(c->transport, (void**)&sl.d_recv_recs, cap * n * rw * 8), "hipMalloc (receive region)");
+        err.hip(comm_malloc(c->transport, (void**)&sl.d_recv_parts, cap * n * 4), "hipMalloc (receive region)");
     }
     if (err.rc) { pipe_free(c); return err.rc; }
     c->pipe_cap = cap; c->pipe_rw = rw;
@@ -478,8 +485,8 @@ int pipe_init(pg_comm* c, FirstError& err) {
         err.hip(hipEventCreate(&sl.t0), "hipEventCreate");
         err.hip(hipEventCreate(&sl.t1), "hipEventCreate");
     }
-    err.hip(pg::arena_malloc((void**)&c->d_pairs, sizeof(uint64_t) * 2 * (size_t)c->n), "hipMalloc");
-    err.hip(pg::arena_malloc((void**)&c->d_rpairs, sizeof(uint64_t) * 2 * (size_t)c->n), "hipMalloc");
+    err.hip(comm_malloc(c->transport, (void**)&c->d_pairs, sizeof(uint64_t) * 2 * (size_t)c->n), "hipMalloc");
+    err.hip(comm_malloc(c->transport, (void**)&c->d_rpairs, sizeof(uint64_t) * 2 * (size_t)c->n), "hipMalloc");
     err.hip(hipHostMalloc((void**)&c->h_pairs, sizeof(uint64_t) * 4 * (size_t)c->n, hipHostMallocPortable), "hipHostMalloc");
     return err.rc;
 }
