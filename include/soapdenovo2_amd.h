@@ -330,6 +330,9 @@ void pg_device_arena_unpin(int device);
 /* out[0..7] = active (1 = arena, 0 = plain hipMalloc), bytes reserved, mapped, in use, peak in use, blocks cut, physical pieces created,
  * microseconds spent creating + mapping them */
 void pg_device_arena_stats(int device, uint64_t out[8]);
+/* TEST HOOK (no GPU): the arena's block list on a random sequence of n_ops cuts and returns over `size` bytes with its invariants checked after
+ * every step (csrc/host_emu.cpp); 0 = all held.  out[0..3] = cuts granted, cuts refused, peak bytes in use, most holes at once. */
+long long pg_host_emu_arena_blocks(uint64_t seed, uint64_t n_ops, uint64_t size, uint64_t max_block, uint64_t out[4]);
 /* A read-only look at the partition engine's export array after pg_finalize (no copy; valid until the next pg_reset,
  * pg_export_take or pg_destroy). */
 int pg_export_peek(pg_ctx *ctx, const uint64_t **d_records_out, uint64_t *n_out);

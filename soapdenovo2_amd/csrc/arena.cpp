@@ -9,17 +9,15 @@
 #include <chrono>
 #include <condition_variable>
 #include <algorithm>
-#include <map>
 #include <mutex>
-#include <unordered_map>
 #include <vector>
 
+#include "arena_list.hpp"
 #include "env.hpp"
 
 namespace pg {
 namespace {
 
-constexpr size_t ALIGN = 256;                       // what hipMalloc promises at least; blocks of a megabyte and more start on 4 KiB
 constexpr int MAX_DEVICES = 64;
 
 inline size_t round_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
@@ -38,10 +36,9 @@ struct Arena {
     std::condition_variable map_cv;
     std::vector<hipMemAccessDesc> access;
     hipMemAllocationProp prop;
-    std::map<size_t, size_t> free_;                 // offset -> bytes, coalesced
-    std::unordered_map<size_t, size_t> used;        // offset -> bytes
+    BlockList blocks;                               // the free list and the live blocks (arena_list.hpp)
     int pins = 0;
-    uint64_t in_use = 0, peak = 0, n_malloc = 0, n_free = 0, n_chunks = 0;
+    uint64_t n_chunks = 0;
     double map_seconds = 0;
 
     void init(int dev) {
@@ -93,8 +90,7 @@ struct Arena {
         void* p = nullptr;
         if (hipMemAddressReserve(&p, reserved, 0, nullptr, 0) != hipSuccess || !p) { (void)hipGetLastError(); return false; }
         base = (char*)p;
-        free_.clear();
-        free_[0] = reserved;
+        blocks.reset(reserved);
         pieces.assign(reserved / chunk, Piece{hipMemGenericAllocationHandle_t(), 0});
         return true;
     }
@@ -150,17 +146,6 @@ struct Arena {
             if (ensure_piece(pi) != hipSuccess) return hipErrorOutOfMemory;
         return hipSuccess;
     }
-    // list_mu held
-    void give_back(size_t off, size_t bytes) {
-        auto nx = free_.lower_bound(off);
-        if (nx != free_.end() && off + bytes == nx->first) { bytes += nx->second; nx = free_.erase(nx); }
-        if (nx != free_.begin()) {
-            auto pv = std::prev(nx);
-            if (pv->first + pv->second == off) { pv->second += bytes; return; }
-        }
-        free_[off] = bytes;
-    }
-
     // list_mu held, nothing allocated, nobody pins: the physical memory goes back to the driver
     void trim() {
         const auto t_trim = std::chrono::steady_clock::now();
@@ -178,39 +163,20 @@ struct Arena {
         if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
         if (env_user("PG_HOST_VERBOSE"))
             fprintf(stderr, "arena (device %d): %.2f GB of physical memory in %llu piece(s), created in %.2fs in all; peak in use %.2f GB; %llu block(s) cut, %llu given back; given back to the driver in %.2fs\n", device,
-                    (double)at / 1e9, (unsigned long long)n_chunks, map_seconds, (double)peak / 1e9, (unsigned long long)n_malloc, (unsigned long long)n_free,
+                    (double)at / 1e9, (unsigned long long)n_chunks, map_seconds, (double)blocks.peak / 1e9, (unsigned long long)blocks.n_cut, (unsigned long long)blocks.n_back,
                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t_trim).count());
     }
 
     hipError_t malloc_(void** out, size_t bytes) {
-        const size_t need = round_up(bytes ? bytes : 1, ALIGN);
-        const size_t al = need >= ((size_t)1 << 20) ? 4096 : ALIGN;
-        size_t off = 0;
+        size_t off = 0, need = 0;
         {
             std::lock_guard<std::mutex> g(list_mu);
-            auto it = free_.begin();
-            size_t pad = 0;
-            for (; it != free_.end(); ++it) {
-                pad = round_up(it->first, al) - it->first;
-                if (it->second >= need + pad) break;
-            }
-            if (it == free_.end()) return hipErrorOutOfMemory;
-            const size_t hole_off = it->first, hole = it->second;
-            off = hole_off + pad;
-            free_.erase(it);
-            if (pad) free_[hole_off] = pad;
-            if (hole > pad + need) free_[off + need] = hole - pad - need;
-            used[off] = need;
-            in_use += need;
-            if (in_use > peak) peak = in_use;
-            n_malloc++;
+            if (!blocks.cut(bytes, &off, &need)) return hipErrorOutOfMemory;
         }
         const hipError_t rc = ensure_mapped(off, need);
         if (rc != hipSuccess) {
             std::lock_guard<std::mutex> g(list_mu);
-            used.erase(off);
-            in_use -= need;
-            give_back(off, need);
+            (void)blocks.give_back(off);
             return rc;
         }
         *out = base + off;
@@ -227,15 +193,8 @@ struct Arena {
         const hipError_t rc = hipDeviceSynchronize();
         if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
         std::lock_guard<std::mutex> g(list_mu);
-        const size_t off = (size_t)((char*)p - base);
-        auto it = used.find(off);
-        if (it == used.end()) return hipErrorInvalidValue;
-        const size_t bytes = it->second;
-        used.erase(it);
-        in_use -= bytes;
-        n_free++;
-        give_back(off, bytes);
-        if (used.empty() && pins == 0) trim();
+        if (!blocks.give_back((size_t)((char*)p - base))) return hipErrorInvalidValue;
+        if (blocks.empty() && pins == 0) trim();
         return rc;
     }
 };
@@ -289,7 +248,7 @@ hipError_t arena_mem_info(size_t* free_bytes, size_t* total_bytes) {
     if (a && a->active) {
         std::lock_guard<std::mutex> g(a->list_mu);
         const size_t mapped = a->mapped_bytes.load();
-        if (mapped > a->in_use) *free_bytes += mapped - a->in_use;
+        if (mapped > a->blocks.in_use) *free_bytes += mapped - a->blocks.in_use;
     }
     return hipSuccess;
 }
@@ -306,7 +265,7 @@ void arena_unpin(int device) {
     if (!a || !a->active) return;
     std::lock_guard<std::mutex> g(a->list_mu);
     if (a->pins > 0) a->pins--;
-    if (a->pins == 0 && a->used.empty() && a->mapped_bytes.load() != 0) a->trim();
+    if (a->pins == 0 && a->blocks.empty() && a->mapped_bytes.load() != 0) a->trim();
 }
 
 ArenaStats arena_stats(int device) {
@@ -318,10 +277,10 @@ ArenaStats arena_stats(int device) {
     s.active = 1;
     s.reserved = a->reserved;
     s.mapped = a->mapped_bytes.load();
-    s.in_use = a->in_use;
-    s.peak_in_use = a->peak;
-    s.n_malloc = a->n_malloc;
-    s.n_free = a->n_free;
+    s.in_use = a->blocks.in_use;
+    s.peak_in_use = a->blocks.peak;
+    s.n_malloc = a->blocks.n_cut;
+    s.n_free = a->blocks.n_back;
     s.n_chunks_created = a->n_chunks;
     s.map_seconds = a->map_seconds;
     return s;
