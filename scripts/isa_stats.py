@@ -3,7 +3,7 @@
 the scalar registers spilled to vector lanes (and the v_readlane / v_writelane moves that go with them, by loop depth), scratch and flat memory
 operations, and the s_waitcnt vmcnt waits -- the things that cost K2 between 2 and 5 % each in round 4 (DESIGN.md 3.2 "one box", "four more").
 
-    python scripts/isa_stats.py soapdenovo2_amd/csrc/partition_kernels.hip --match skm_count_kernel -D PG_K2_DMA=1
+    python scripts/isa_stats.py soapdenovo2_amd/csrc/partition_kernels.hip --match skm_count_kernel -D PG_MEASURE=1
     python scripts/isa_stats.py soapdenovo2_amd/csrc/graph_kernels.hip --match p2_thread --waits
 
 --match keeps the kernels whose (mangled) name contains the text; --waits lists every vmcnt wait, scratch and flat operation with the instruction
