@@ -27,6 +27,9 @@
 // elements whose time can change are those whose old slot lies in such a cluster -- the sweep meets them on its way.  Chains are a
 // dozen levels deep (a fifth of the moves are kicks), a set settles in 20 - 30 rounds a size, all but the first few tiny.
 // Which slots are occupied, the clusters and the wrap-around frame depend on the homes alone and are computed once per size.
+// What a size costs is random memory accesses (profiles/r05x_growable_layout_ab.json): its preparation gathers the times in sorted order and
+// finds the slot -> element map of the previous size where that size's sweeps left it (RhSweep::elem_at), and the first round of a large size
+// runs over a list of the cluster starts, every lane of a wave a walk.
 #pragma once
 #include <stdint.h>
 #include <stdio.h>
@@ -60,16 +63,23 @@ struct RhSweep {
     unsigned long long* heap_t;
     uint32_t* heap_e;
     unsigned long long* slot_new;       // table slot of every element
-    const uint32_t* elem_prev;          // ... and which element that is
+    const uint32_t* elem_prev;          // per table slot j < n_prev: which element that is
+    uint32_t* elem_at;                  // per table slot of THIS size: the element the sweep puts there (what the next size finds there; null: no next size)
     uint32_t* chg_e;                    // changes (element, time): a cluster's go into ITS stretch of these arrays (it places as many
     unsigned long long* chg_t;          //   elements as it has, and every placement changes at most one old element), chg_n[start] of them --
     uint32_t* chg_n;                    //   one counter for all of them would be a returned atomic on one address inside the loop
     unsigned long long* n_chg;          // their number over the round
     uint64_t n, S, origin, n_prev;
     int only_dirty;                     // (list == null) skip the clusters whose flag is down
+    const unsigned long long* list_n;   // (list != null) entries of the list, where only the device knows the number (null: every lane has one)
+    // A lane's walk is a chain of loads that depend on each other through the loop (is the next key's home at or before this slot? then its time,
+    // its element; the old time of the slot): issued where they are needed, every one of them is a full memory latency on the lane's critical
+    // path, and the sweep is bound by exactly that (more lanes in flight helped, several clusters a lane made it slower:
+    // profiles/r05x_growable_layout_ab.json).  So the next key (home, time, element) is loaded one key AHEAD, and the slot's old time and old
+    // element at the top of the iteration, before the pending set is touched -- an iteration then waits for memory once.
     PG_HD void operator()(uint64_t lane) const {
         uint64_t j = lane;
-        if (list) j = list[lane];
+        if (list) { if (list_n && lane >= *list_n) return; j = list[lane]; }
         else if ((j && m[j] <= m[j - 1]) || (only_dirty && !dirty[j])) return;     // not the first key of a cluster / nothing changed in it
         dirty[j] = 0;
         uint32_t n_found = 0;
@@ -84,10 +94,20 @@ struct RhSweep {
         unsigned long long* ht = heap_t + j;
         uint32_t* he = heap_e + j;
         uint64_t hn = 0, nxt = j, p = hs[j];
+        uint64_t h_nx = p;                                          // the key at sorted position nxt, loaded ahead (valid while nxt < n)
+        unsigned long long t_nx = Ts[j];
+        uint32_t e_nx = is[j];
         for (;;) {
-            while (nxt < n && hs[nxt] <= p) {
-                unsigned long long t = Ts[nxt];
-                uint32_t e = is[nxt++];
+            uint64_t slot = p + origin;
+            if (slot >= S) slot -= S;
+            const bool had_owner = slot < n_prev;
+            const unsigned long long told = had_owner ? T_old[slot] : RH_NO_TIME;      // (read-only during a sweep: the changes are applied between the rounds)
+            const uint32_t e_old = had_owner ? elem_prev[slot] : RH_NONE;
+            while (nxt < n && h_nx <= p) {
+                unsigned long long t = t_nx;
+                uint32_t e = e_nx;
+                nxt++;
+                if (nxt < n) { h_nx = hs[nxt]; t_nx = Ts[nxt]; e_nx = is[nxt]; }
 #pragma unroll
                 for (int i = 0; i < RF; i++)                         // into the sorted registers; what falls out at the end is the latest of them
                     if (t < rt[i]) { const unsigned long long xt = rt[i]; const uint32_t xe = re[i]; rt[i] = t; re[i] = e; t = xt; e = xe; }
@@ -124,21 +144,17 @@ struct RhSweep {
                 for (int i = 0; i + 1 < RF; i++) { rt[i] = rt[i + 1]; re[i] = re[i + 1]; }
                 rt[RF - 1] = RH_NO_TIME;
             }
-            uint64_t slot = p + origin;
-            if (slot >= S) slot -= S;
             slot_new[first] = slot;
-            if (slot < n_prev) {
-                // (times are unique, so "the slot's old element came to rest on it itself" is t_first == told; everything the
-                //  sweep reads lies in the order it walks: sorted position or slot)
-                const unsigned long long told = T_old[slot];
-                if (told != RH_NO_TIME) {
-                    const unsigned long long natural = (unsigned long long)slot << RH_DEPTH_BITS;
-                    unsigned long long t = natural;
-                    if (t_first != told && t_first < natural) t = t_first + 1;   // `first` came to rest here before the walk reached the slot: the old element went next
-                    if (t != told) {
-                        chg_e[j + n_found] = elem_prev[slot]; chg_t[j + n_found] = t;
-                        n_found++;
-                    }
+            if (elem_at) elem_at[slot] = first;                     // (a cluster's slots are the same in every round; its last sweep is the one that counts)
+            // (times are unique, so "the slot's old element came to rest on it itself" is t_first == told; everything the
+            //  sweep reads lies in the order it walks: sorted position or slot)
+            if (told != RH_NO_TIME) {
+                const unsigned long long natural = (unsigned long long)slot << RH_DEPTH_BITS;
+                unsigned long long t = natural;
+                if (t_first != told && t_first < natural) t = t_first + 1;   // `first` came to rest here before the walk reached the slot: the old element went next
+                if (t != told) {
+                    chg_e[j + n_found] = e_old; chg_t[j + n_found] = t;
+                    n_found++;
                 }
             }
             p++;
@@ -166,7 +182,9 @@ struct RhApply {
     unsigned long long* n_dirty;
     const unsigned long long* n_chg;    // the sweep's count of time changes: a list of the clusters to sweep again is made here while it is short (the host
     unsigned long long list_max;        // reads both counters in ONE go afterwards and decides the same way)
+    const unsigned long long* list_n;   // as RhSweep's
     PG_HD void operator()(uint64_t lane) const {
+        if (list && list_n && lane >= *list_n) return;
         const uint64_t j = list ? list[lane] : lane;
         const uint32_t k = chg_n[j];
         if (!k) return;
@@ -193,7 +211,7 @@ struct RhApply {
 template <class BE>
 struct RhWork {
     uint64_t *hk = nullptr, *hs = nullptr, *hr = nullptr;
-    uint32_t *iv = nullptr, *is = nullptr, *ir = nullptr, *pos_of = nullptr, *heap_e = nullptr, *elem_prev = nullptr, *chg_e = nullptr, *chg_n = nullptr, *list_a = nullptr, *list_b = nullptr;
+    uint32_t *iv = nullptr, *is = nullptr, *ir = nullptr, *pos_of = nullptr, *heap_e = nullptr, *elem_prev = nullptr, *elem_next = nullptr, *chg_e = nullptr, *chg_n = nullptr, *list_a = nullptr, *list_b = nullptr;
     long long *v = nullptr, *m = nullptr, *cs = nullptr;
     unsigned long long *Ts = nullptr, *T_old = nullptr, *chg_t = nullptr, *heap_t = nullptr, *slot_prev = nullptr, *scal = nullptr;
     unsigned int* dirty = nullptr;
@@ -212,14 +230,14 @@ struct RhWork {
         dirty = be.template alloc<unsigned int>(n);
         heap_t = be.template alloc<unsigned long long>(n); heap_e = be.template alloc<uint32_t>(n);
         slot_prev = be.template alloc<unsigned long long>(n);
-        elem_prev = be.template alloc<uint32_t>(owner_cap); T_old = be.template alloc<unsigned long long>(owner_cap);
+        elem_prev = be.template alloc<uint32_t>(owner_cap); elem_next = be.template alloc<uint32_t>(owner_cap); T_old = be.template alloc<unsigned long long>(owner_cap);
         scal = be.template alloc<unsigned long long>(4);
         return !be.error;
     }
     void release(BE& be) {
         be.release(hk); be.release(hs); be.release(hr); be.release(iv); be.release(is); be.release(ir); be.release(v); be.release(m); be.release(cs);
         be.release(pos_of); be.release(Ts); be.release(T_old); be.release(chg_e); be.release(chg_t); be.release(chg_n); be.release(list_a); be.release(list_b); be.release(dirty); be.release(heap_t); be.release(heap_e);
-        be.release(slot_prev); be.release(elem_prev); be.release(scal);
+        be.release(slot_prev); be.release(elem_prev); be.release(elem_next); be.release(scal);
         *this = RhWork();
     }
     // bytes a key / an old slot (for the caller's memory planning)
@@ -243,7 +261,7 @@ int layout_growable(BE& be, RhWork<BE>& wk, const uint64_t* rec, uint64_t n, con
     if (n >= 0xFFFFFFF0ULL) { be.error_text = "layout_growable: more than 2^32 keys in a set"; return PG_EINVAL; }
     if (n > wk.cap || grow_owner_slots(sched) > wk.owner_cap) { be.error_text = "layout_growable: scratch too small"; return PG_EINVAL; }
     uint64_t *hk = wk.hk, *hs = wk.hs, *hr = wk.hr;
-    uint32_t *iv = wk.iv, *is = wk.is, *ir = wk.ir, *pos_of = wk.pos_of, *heap_e = wk.heap_e, *elem_prev = wk.elem_prev, *chg_e = wk.chg_e, *chg_n = wk.chg_n;
+    uint32_t *iv = wk.iv, *is = wk.is, *ir = wk.ir, *pos_of = wk.pos_of, *heap_e = wk.heap_e, *elem_prev = wk.elem_prev, *elem_next = wk.elem_next, *chg_e = wk.chg_e, *chg_n = wk.chg_n;
     long long *v = wk.v, *m = wk.m, *cs = wk.cs;
     unsigned long long *Ts = wk.Ts, *T_old = wk.T_old, *chg_t = wk.chg_t, *heap_t = wk.heap_t, *slot_prev = wk.slot_prev, *scal = wk.scal;
     unsigned int* dirty = wk.dirty;
@@ -316,29 +334,40 @@ int layout_growable(BE& be, RhWork<BE>& wk, const uint64_t* rec, uint64_t n, con
             if ((uint64_t)((long long)(M - 1) + m_last) >= S) { rc = PG_EINVAL; be.error_text = "layout_growable: the rotated frame still wraps"; break; }
             hs_use = hr; is_use = ir;
         }
-        // ---- where every element sits in the sorted order, and the cluster it belongs to; times; everything to be swept
+        // ---- where every element sits in the sorted order, and the cluster it belongs to; times; everything to be swept.
+        //      The times are GATHERED in sorted order (an old element's: the slot it sat in; a new key's: its arrival rank, no memory at all), and which
+        //      element sat in which old slot is what the previous size's sweeps left behind (elem_at, written slot by slot as they walk): setting both up by
+        //      scatters -- Ts[pos_of[i]], elem_prev[slot_prev[i]], T_old[slot_prev[i]] -- was 60 % of the random accesses of a size's preparation.
+        uint32_t* const elem_at = ei + 1 < sched.size() ? elem_next : nullptr;
         {
             const uint32_t* isu = is_use;
             const long long* mm = m;
+            const unsigned long long* sp = slot_prev;
             be.launch(M, [=] PG_LAMBDA(uint64_t j) {
-                pos_of[isu[j]] = (uint32_t)j;
+                const uint64_t i = isu[j];
+                pos_of[i] = (uint32_t)j;
                 v[j] = (j == 0 || mm[j] > mm[j - 1]) ? (long long)j : 0;
                 dirty[j] = 0u;
                 chg_n[j] = 0u;
+                Ts[j] = (i < n_old ? sp[i] : (unsigned long long)(s_prev + (i - n_old))) << RH_DEPTH_BITS;
             });
             be.inclusive_max(v, cs, M);
-            const unsigned long long* sp = slot_prev;
             if (n_old) {
-                be.fill(elem_prev, (size_t)s_prev, RH_NONE);
-                be.fill(T_old, (size_t)s_prev, RH_NO_TIME);
+                const uint32_t* ep = elem_prev;
+                be.launch(s_prev, [=] PG_LAMBDA(uint64_t slot) { T_old[slot] = ep[slot] != RH_NONE ? (unsigned long long)slot << RH_DEPTH_BITS : RH_NO_TIME; });
             }
-            be.launch(M, [=] PG_LAMBDA(uint64_t i) {
-                const unsigned long long t = (i < n_old ? sp[i] : (unsigned long long)(s_prev + (i - n_old))) << RH_DEPTH_BITS;
-                Ts[pos_of[i]] = t;
-                if (i < n_old) { elem_prev[sp[i]] = (uint32_t)i; T_old[sp[i]] = t; }
-            });
+            if (elem_at) be.fill(elem_at, (size_t)S, RH_NONE);
         }
-        if (rh_debug) { be.sync(); fprintf(stderr, "rh size %llu keys %llu: sort, clusters, times ready %.3f ms since the size began\n", (unsigned long long)S, (unsigned long long)M, 1e3 * (rh_now() - t_epoch)); }
+        if (rh_debug) {
+            unsigned long long* longest = scal + 3;
+            const long long* cc = cs;
+            be.fill(longest, 1, 0ULL);
+            be.launch(M, [=] PG_LAMBDA(uint64_t j) { if (j + 1 == M || cc[j + 1] != cc[j]) hd_atomic_max(longest, (unsigned long long)(j + 1 - (uint64_t)cc[j])); });
+            unsigned long long lg = 0;
+            be.to_host(&lg, longest, 1);
+            fprintf(stderr, "rh size %llu keys %llu (%llu there before): sort, clusters, times ready %.3f ms since the size began; longest cluster %llu keys\n", (unsigned long long)S,
+                    (unsigned long long)M, (unsigned long long)n_old, 1e3 * (rh_now() - t_epoch), lg);
+        }
         // ---- the fixed point: sweep (every cluster first, then the listed ones), apply the changes it found, list their clusters
         const uint32_t* list_cur = nullptr;                           // null: the sweep runs over all positions
         uint32_t* list_next = wk.list_a;
@@ -355,23 +384,48 @@ int layout_growable(BE& be, RhWork<BE>& wk, const uint64_t* rec, uint64_t n, con
             for (int q = 0; q < 8; q++, round++) {
                 if (rounds_out) (*rounds_out)++;
                 be.fill(scal, 2, 0ULL);
-                be.launch(M, RhSweep{hs_use, is_use, m, Ts, T_old, dirty, nullptr, heap_t, heap_e, slot_new, elem_prev, chg_e, chg_t, chg_n, scal, M, S, origin, s_prev, round > 0});
-                be.launch(M, RhApply{nullptr, chg_n, chg_e, chg_t, pos_of, cs, slot_prev, Ts, T_old, dirty, list_next, scal + 1, scal, 0ULL});
+                be.launch(M, RhSweep{hs_use, is_use, m, Ts, T_old, dirty, nullptr, heap_t, heap_e, slot_new, elem_prev, elem_at, chg_e, chg_t, chg_n, scal, M, S, origin, s_prev, round > 0, nullptr});
+                be.launch(M, RhApply{nullptr, chg_n, chg_e, chg_t, pos_of, cs, slot_prev, Ts, T_old, dirty, list_next, scal + 1, scal, 0ULL, nullptr});
             }
             unsigned long long last_chg = 0;
             be.to_host(&last_chg, scal, 1);
             if (be.error || !last_chg) break;
         }
+        // The first round of a large size sweeps every cluster.  With a lane a sorted position two lanes in three leave at once (they are not
+        // the first key of a cluster) and a wave's 64 lanes hold some twenty walks; over a LIST of the cluster starts every lane of a wave
+        // walks -- a third of the waves for the same walks.  The list is a prefix sum over the start flags; its length stays on the
+        // device (scal[2]: no read-back), the launch has a lane a position and the lanes behind the list's end leave.
+        const char* const dense_env = pg::env_test("PG_RH_DENSE_MIN");             // (keys from which the first round runs over a list; 0: never)
+        const uint64_t dense_min = dense_env ? (uint64_t)atoll(dense_env) : (uint64_t)1 << 18;
+        const unsigned long long* list_n_dev = nullptr;
+        if (!blind && dense_min && M >= dense_min) {
+            unsigned long long* f64 = (unsigned long long*)hk;          // (the unsorted homes are done with)
+            unsigned long long* at64 = (unsigned long long*)v;          // (so are the scans' inputs)
+            const long long* mm = m;
+            uint32_t* ln = wk.list_a;
+            unsigned long long* nl = scal + 2;
+            be.launch(M, [=] PG_LAMBDA(uint64_t j) { f64[j] = (j == 0 || mm[j] > mm[j - 1]) ? 1ULL : 0ULL; });
+            be.exclusive_sum(f64, at64, M);
+            be.launch(M, [=] PG_LAMBDA(uint64_t j) {
+                if (f64[j]) ln[at64[j]] = (uint32_t)j;
+                if (j + 1 == M) *nl = at64[j] + f64[j];
+            });
+            list_cur = wk.list_a;
+            list_next = wk.list_b;
+            n_list = M;
+            list_n_dev = scal + 2;
+        }
         for (int round = 0; !blind; round++) {
             if (round > 100000) { rc = PG_EINVAL; be.error_text = "layout_growable: the fixed point did not settle"; break; }
             if (rounds_out) (*rounds_out)++;
             be.fill(scal, 2, 0ULL);
-            be.launch(list_cur ? n_list : M, RhSweep{hs_use, is_use, m, Ts, T_old, dirty, list_cur, heap_t, heap_e, slot_new, elem_prev, chg_e, chg_t, chg_n, scal, M, S, origin,
-                                                     n_old ? s_prev : 0, round > 0});
+            const unsigned long long* const bound = round == 0 ? list_n_dev : nullptr;      // (later lists: the host knows their length)
+            be.launch(list_cur ? n_list : M, RhSweep{hs_use, is_use, m, Ts, T_old, dirty, list_cur, heap_t, heap_e, slot_new, elem_prev, elem_at, chg_e, chg_t, chg_n, scal, M, S, origin,
+                                                     n_old ? s_prev : 0, round > 0, bound});
             if (!n_old) break;                                        // nobody was there before: arrival order is all there is
             // (the changes are applied before the host knows whether there were any: one read-back a round instead of two -- a read-back is a
             //  drained stream and a copy, ~0.6 ms, and the small sizes of a set are nothing but rounds)
-            be.launch(list_cur ? n_list : M, RhApply{list_cur, chg_n, chg_e, chg_t, pos_of, cs, slot_prev, Ts, T_old, dirty, list_next, scal + 1, scal, (unsigned long long)list_max});
+            be.launch(list_cur ? n_list : M, RhApply{list_cur, chg_n, chg_e, chg_t, pos_of, cs, slot_prev, Ts, T_old, dirty, list_next, scal + 1, scal, (unsigned long long)list_max, bound});
             unsigned long long both[2] = {0, 0};
             be.to_host(both, scal, 2);
             const unsigned long long n_chg = both[0], n_dirty_h = both[1];
@@ -394,7 +448,8 @@ int layout_growable(BE& be, RhWork<BE>& wk, const uint64_t* rec, uint64_t n, con
             list_cur = list_next;
             list_next = list_cur == wk.list_a ? wk.list_b : wk.list_a;
         }
-        if (ei + 1 < sched.size()) be.copy(slot_prev, slot_new, M);
+        if (rh_debug) { be.sync(); fprintf(stderr, "rh size %llu keys %llu: settled %.3f ms since the size began\n", (unsigned long long)S, (unsigned long long)M, 1e3 * (rh_now() - t_epoch)); }
+        if (ei + 1 < sched.size()) { be.copy(slot_prev, slot_new, M); std::swap(elem_prev, elem_next); }
     }
     be.sync();
     if (be.error) return be.error;
@@ -402,7 +457,7 @@ int layout_growable(BE& be, RhWork<BE>& wk, const uint64_t* rec, uint64_t n, con
 }
 
 // scratch bytes one call of layout_growable_sets takes for sets of at most n_max keys that grow out of at most owner_max slots
-inline uint64_t growable_scratch_bytes(uint64_t n_max, uint64_t owner_max) { return (RhWork<int>::bytes_per_key + 8) * n_max + 12 * owner_max + (1u << 20); }
+inline uint64_t growable_scratch_bytes(uint64_t n_max, uint64_t owner_max) { return (RhWork<int>::bytes_per_key + 8) * n_max + 16 * owner_max + (1u << 20); }
 
 // P growable sets: records sorted by (set, ordinal) in backend memory; per_set_count, trailing (a duplicate put arrived after
 // the set's last new key), set_first_slot (the set's slot 0 in `nodes`, in slots) on the host.  nodes (optional): the image,

@@ -167,13 +167,17 @@ def test_layout_growable_equals_the_host_replay(golden, tmp_path, name, P, m):
     assert int(rounds.max()) >= 2
 
 
-@pytest.mark.parametrize("blind_max", [None, 0, 2000])
-def test_layout_growable_random_keys_and_the_trailing_duplicate(blind_max, monkeypatch):
+@pytest.mark.parametrize("blind_max,dense_min", [(None, None), (0, None), (2000, None), (0, 1), (2000, 1), (0, 3000), (0, 0)])
+def test_layout_growable_random_keys_and_the_trailing_duplicate(blind_max, dense_min, monkeypatch):
     """Random keys (no genome structure), set sizes right at the growth thresholds, with and without a duplicate put behind the
     last new key (newhash.c:477 tests the growth before it probes).  blind_max: up to which size the fixed point's rounds are
-    launched eight at a time without a read-back (dev_rehash.hpp; default 2^18 keys: all of these sets; 0: none; 2000: some sizes of a set)."""
+    launched eight at a time without a read-back (dev_rehash.hpp; default 2^18 keys: all of these sets; 0: none; 2000: some sizes of a set).
+    dense_min: from which size the first round runs over a list of the cluster starts whose length stays on the device (default 2^18
+    keys: none of these sets; 1: every size that is not launched blind; 0: never)."""
     if blind_max is not None:
         monkeypatch.setenv("PG_RH_BLIND_MAX", str(blind_max))
+    if dense_min is not None:
+        monkeypatch.setenv("PG_RH_DENSE_MIN", str(dense_min))
     rng = np.random.default_rng(77)
     for n in (1, 5, 793, 794, 795, 1590, 1591, 5000, 40000):
         for trailing in (False, True):
