@@ -372,7 +372,12 @@ int layout_growable(BE& be, RhWork<BE>& wk, const uint64_t* rec, uint64_t n, con
         const uint32_t* list_cur = nullptr;                           // null: the sweep runs over all positions
         uint32_t* list_next = wk.list_a;
         uint64_t n_list = 0;
-        const uint64_t list_max = std::max<uint64_t>(1024, M >> 10);  // more changes than this: the list is made from the flags by a prefix sum, not by an atomic a cluster
+        const char* const shift_env = pg::env_test("PG_RH_LIST_SHIFT");
+        const int list_shift = shift_env ? std::max(0, std::min(40, atoi(shift_env))) : 5;
+        // more changes than this: the list is made from the flags by a prefix sum (three passes over all M positions), not by an append a cluster.  The
+        // append is ONE returned atomic a wave (the compiler folds a wave's adds on one address into one), so it wins until a round changes a few
+        // per cent of the keys: M / 1024 -> M / 32 took 5 % off the layout at 60 M reads, M / 8 put 13 % on (profiles/r05x_growable_layout_ab.json)
+        const uint64_t list_max = std::max<uint64_t>(1024, M >> list_shift);
         // Small sizes are nothing but rounds, and a round's work there is microseconds against the ~0.6 ms its read-back costs (a drained
         // stream and a copy): eight rounds at a time are launched blind -- full sweeps that skip the clusters whose flag is down, no lists --
         // and the host looks at the last one's change count; the rounds behind the fixed point find nothing to do.
