@@ -10,6 +10,8 @@
 #   phases[:<bench args>]            K2's phase cycles from the -DPG_MEASURE library (SOAPDENOVO2_AMD_LIB=..._measure.so, PG_K2_TIMERS=1)
 #   cli:<reads>:<a_gb>:<expect json>:<tag>[:ENV=V+ENV=V]   the executable on a synth_fastq file of <reads> x 150 bp (kept in /tmp across the steps of a call),
 #                                    md5s against the reference's (scripts/big_cli_check.py) -> result_<tag>.json, stderr_<tag>.txt
+#   cliprof:<reads>:<a_gb>:<expect json>:<tag>   the same command under `rocprofv3 --kernel-trace --stats` -> kernel_stats_cli_<tag>.csv (how
+#                                    profiles/r05_kernel_stats_cli_*.csv were made)
 #   sh:<command>                     anything else, logged to sh<i>.log
 # A step's bench arguments use ',' for ' ' (gpurun hands one string to bash).
 set -u
@@ -55,6 +57,12 @@ j=json.load(open('$O/result_$c_tag.json')); print('   wall', j.get('wall_s'), 'i
 for l in j.get('log',[]):
     if any(k in l for k in ('[cli] ','reader:','arena','waited','routed:','edges: device')): print('     ', l[:200])
 ";;
+    cliprof)
+        IFS=: read -r c_reads c_agb c_exp c_tag <<< "$arg"
+        mkdir -p /tmp/big_$c_reads
+        timeout 1500 python scripts/big_cli_check.py --reads "$c_reads" --a-gb "$c_agb" --expect "$c_exp" --out /tmp/big_$c_reads --keep-fastq --tag "_$c_tag" --rocprof "--kernel-trace --stats" > "$O/cliprof$i.log" 2>&1; echo "[$i] cliprof $c_tag rc=$?"
+        f=$(find /tmp/big_$c_reads/prof_$c_tag -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp "$f" "$O/kernel_stats_cli_$c_tag.csv" && head -8 "$O/kernel_stats_cli_$c_tag.csv" | cut -c1-200
+        cp /tmp/big_$c_reads/result_$c_tag.json "$O/" 2>/dev/null;;
     sh)
         timeout 1500 bash -c "$arg" > "$O/sh$i.log" 2>&1; echo "[$i] sh rc=$? $(tail -3 "$O/sh$i.log" | cut -c1-200)";;
     *) echo "[$i] unknown step $step";;
