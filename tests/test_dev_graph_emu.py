@@ -237,3 +237,29 @@ def test_home_slot_by_reciprocal_equals_the_reference_modulus(mer127):
                     t = (((t << 32) & M) | (x & 0xFFFFFFFF)) % size
                 want = t
             assert int(out[i]) == want, (size, w)
+
+
+def test_layout_growable_fuzz_over_thresholds_and_skewed_homes(monkeypatch):
+    """Many small random sets against the host replay with the fixed point's three thresholds drawn at random (rounds launched blind, first
+    round over a list of the cluster starts, the re-sweep list by appends or by a prefix sum), both key widths, one to four host threads, and every
+    third set with small numbers for keys: their homes crowd (runs of consecutive slots), clusters are thousands of keys long -- the heap behind the
+    sweep's six registers -- and wrap around the end of the table."""
+    for seed in range(120):
+        rng = np.random.default_rng(9000 + seed)
+        monkeypatch.setenv("PG_RH_BLIND_MAX", str(rng.choice([0, 0, 500, 5000])))
+        monkeypatch.setenv("PG_RH_DENSE_MIN", str(rng.choice([0, 1, 1, 700, 4000])))
+        monkeypatch.setenv("PG_RH_LIST_SHIFT", str(rng.choice([0, 2, 5, 10])))
+        n = int(rng.choice([3, 50, 700, 793, 794, 1591, 3000, 9000, 25000]))
+        four = bool(rng.integers(0, 2))
+        nw = 4 if four else 2
+        rec = np.zeros((n, nw + 2), dtype=np.uint64)
+        rec[:, :nw] = rng.integers(0, 1 << 62, size=(n, nw), dtype=np.uint64)
+        if rng.integers(0, 3) == 0:                                  # small numbers: home = key while the table is larger than they are, key mod size after
+            rec[:, : nw - 1] = 0
+            rec[:, nw - 1] = rng.integers(0, 1 << int(rng.integers(8, 20)), size=n, dtype=np.uint64)
+        rec[:, 0] >>= np.uint64(3)
+        rec = rec[np.unique(rec[:, :nw], axis=0, return_index=True)[1]]
+        rec = rec[rng.permutation(len(rec))]
+        rec[:, nw + 1] = np.arange(len(rec), dtype=np.uint64) * np.uint64(3)
+        last = np.array([int(rec[-1, nw + 1]) + (5 if rng.integers(0, 2) else 1)], dtype=np.uint64)
+        _growable_vs_replay(rec, last, 1, four, threads=int(rng.integers(1, 5)))
