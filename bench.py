@@ -165,11 +165,15 @@ def big_command(args):
     k-mer-set layout is made on the device (SURVEY.md App. C "K6": dev_graph.hpp / dev_rehash.hpp); 20 M reads at K = 127 (the
     SOAPdenovo-127mer flavour, configs[4]'s path); configs[2] at its full 200 M reads with -a 40.
     BASELINE.json configs[1] at its full size (10 M x 100 bp over 4.6 Mb, err 0.005, K = 31, -p 8; the reference: profiles/r05_ref_10M_K31.json).
-    Returns {"whole_command_10M_k31": {...}, "whole_command_60M_a16": {...}, "whole_command_60M": {...}, "whole_command_k127_20M": {...}, "whole_command_200M_a40": {...}}."""
+    Returns {"whole_command_10M_k31": {...}, "whole_command_60M_a16": {...}, "whole_command_60M": {...}, "whole_command_k127_20M": {...}, "whole_command_200M_a40": {...},
+    "whole_command_20M_ragged": {...}}."""
     groups = [[("whole_command_10M_k31", "r05_ref_10M_K31.json")],
               [("whole_command_60M_a16", "r03_ref_60M_K63_a16.json"), ("whole_command_60M", "r03_ref_60M_K63.json")],
               [("whole_command_k127_20M", "r04_ref_20M_K127.json")],
-              [("whole_command_200M_a40", "r04_ref_200M_K63_a40.json")]]
+              [("whole_command_200M_a40", "r04_ref_200M_K63_a40.json")],
+              # round 6: trimmed reads, lengths uniform in [100, 150] (synth_fastq's min_len) -- every batch ragged, cut by the tiled K1 and
+              # threaded by pass 2 where pass 1 left them; the reference chops reads of any length alike (prlHashReads.c:163-259,642-648)
+              [("whole_command_20M_ragged", "r06_ref_20M_ragged_K63.json")]]
     gen = os.path.join(ROOT, "soapdenovo2_amd", "bin", "synth_fastq")
     if not os.path.exists(gen):
         return None
@@ -189,7 +193,8 @@ def big_command(args):
                 continue
             fq, cfg = os.path.join(td, "reads.fq"), os.path.join(td, "lib.cfg")
             t0 = time.time()
-            subprocess.check_call([gen, fq, str(w["genome"]), str(w["reads"]), str(w["read_len"]), str(w["err"]), str(w["seed"])])
+            subprocess.check_call([gen, fq, str(w["genome"]), str(w["reads"]), str(w["read_len"]), str(w["err"]), str(w["seed"])]
+                                  + ([str(os.cpu_count() or 8), str(w["min_len"])] if w.get("min_len") else []))
             open(cfg, "w").write(f"max_rd_len={w['read_len']}\n[LIB]\navg_ins=200\nreverse_seq=0\nasm_flags=3\nrank=1\nq={fq}\n")
             os.sync()
             gen_s = round(time.time() - t0, 1)
@@ -197,7 +202,7 @@ def big_command(args):
                 exp = json.load(open(exp_path))
                 w = exp["workload"]
                 mer127 = w["kmer"] > 63
-                out = {"workload": f"{w['reads']} reads x {w['read_len']} bp, genome {w['genome']}, err {w['err']} (scripts/synth_fastq.cpp, seed {w['seed']}), "
+                out = {"workload": f"{w['reads']} reads x {(str(w['min_len']) + ' - ') if w.get('min_len') else ''}{w['read_len']} bp, genome {w['genome']}, err {w['err']} (scripts/synth_fastq.cpp, seed {w['seed']}), "
                                    f"K={w['kmer']}, -p {w['sets']} -a {w['a_gb']}", "reads": w["reads"], "fastq_bytes": os.path.getsize(fq), "generate_s": gen_s}
                 pre = os.path.join(td, "amd_" + key)
                 t0 = time.time()
@@ -396,20 +401,30 @@ def main():
             comm = api.Comm.host(world, rank, local, host_a2a)
             exchange = "lib-host"
         if exchange == "lib":
-            ok = 1
+            # No substitute: a run asked to time the library's exchange that cannot create the library's communicator FAILS with the
+            # RCCL error (round 5 fell back to torch.distributed here and carried on -- the line would then have timed torch's RCCL
+            # under the library's name).  `--exchange torch` is how torch's all-to-all is asked for.  The ranks agree first, so that a
+            # rank whose create failed does not leave the others hanging in their first collective.
+            err = ""
             try:
                 box = [api.Comm.unique_id() if rank == 0 else None]
                 dist.broadcast_object_list(box, src=0)
                 comm = api.Comm.rccl(world, rank, local, box[0])
-            except Exception as e:                               # e.g. librccl missing: say so and use torch's RCCL
-                print(f"[bench rank {rank}] pg_comm_create failed ({e}); falling back to torch.distributed", file=sys.stderr)
-                ok = 0
-            flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+            except Exception as e:
+                err = f"{type(e).__name__}: {e}"
+            flag = torch.tensor([0 if err else 1], dtype=torch.int32, device=dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 0:
                 if comm is not None:
                     comm.close()
-                comm, exchange = None, "torch (fallback)"
+                print(f"[bench rank {rank}] pg_comm_create failed{': ' + err if err else ' on another rank'} -- not substituting torch.distributed "
+                      f"(--exchange torch asks for it)", file=sys.stderr)
+                dist.destroy_process_group()
+                sys.exit(3)
+            # the rank count the LIBRARY's communicator reports (not torch's): goes into the line
+            if comm.size != world or comm.rank != rank:
+                print(f"[bench rank {rank}] the library's communicator reports rank {comm.rank} of {comm.size}, torch {rank} of {world}", file=sys.stderr)
+                sys.exit(3)
 
     K, L, P = args.kmer, args.read_len, args.sets
     kpr = L - K + 1
@@ -662,7 +677,7 @@ def main():
             # (rank 0's numbers; the ranks cut equal batches of one read distribution)
             rec["exchange_ms"] = d["exchange_ms"] / args.steps           # device time of the record exchanges per step (events on the exchange stream)
             rec["bytes_sent_per_rank"] = d["bytes_sent"] / args.steps    # to the other ranks, per step
-            rec["exchange"] = {"transport": comm.transport, "rounds_per_step": d["rounds"] / args.steps, "host_waits_per_round": d["host_waits"] / max(d["rounds"], 1),
+            rec["exchange"] = {"transport": comm.transport, "library_comm_ranks": comm.size, "rounds_per_step": d["rounds"] / args.steps, "host_waits_per_round": d["host_waits"] / max(d["rounds"], 1),
                                "repeated_cuts": d["repeated_cuts"], "owner_region_records": pipe1["owner_region_records"],
                                "exchange_GBps_per_rank": (d["bytes_sent"] / 1e9) / (d["exchange_ms"] / 1e3) if d["exchange_ms"] > 0 else None,
                                "exchange_over_step": d["exchange_ms"] / args.steps / ms,

@@ -184,6 +184,11 @@ int pg_host_graph_add_packed(pg_graph *g, const uint64_t *words, const int32_t *
  * read_len bases, packed back to back, 8 readable words behind the last -- what pass 1 leaves there when it keeps its batches;
  * no copy, no index arrays.  Not for -R runs (the walks of a read come back through the host path). */
 int pg_graph_add_packed_device(pg_graph *g, const uint64_t *d_words, uint64_t n_reads, int read_len, int device);
+/* ... and for a ragged batch left there with the index arrays pg_count_reads took (d_word_off[n_reads], d_kmer_base[n_reads + 1];
+ * every read has >= K + 1 bases, none more than max_len; n_kmers = d_kmer_base[n_reads]): prlRead2path.c:1056-1110 threads reads of
+ * any length, lengths from lenBuffer.  Same restrictions. */
+int pg_graph_add_packed_device_ragged(pg_graph *g, const uint64_t *d_words, const uint64_t *d_word_off, const uint64_t *d_kmer_base,
+                                      uint64_t n_reads, uint64_t n_kmers, int max_len, int device);
 int pg_host_graph_add_reads(pg_graph *g, const uint8_t *codes, const int32_t *lens, uint64_t n_reads, uint64_t stride,
                             int n_threads);
 int pg_host_graph_finish(pg_graph *g, int *out_num_vertex, int *out_num_edge, long long *out_num_prearc);
@@ -252,6 +257,13 @@ int pg_set_autogrow(pg_ctx *ctx, int on);
 int pg_count_reads(pg_ctx *ctx, const uint64_t *d_packed, const uint64_t *d_word_off,
                    const uint64_t *d_kmer_base, uint64_t n_reads, uint32_t uniform_len,
                    uint64_t n_kmers, uint64_t ord_base, void *stream);
+
+/* Ragged batches (uniform_len = 0) of any mix of lengths are cut by the same tiled kernel as uniform ones
+ * (prlHashReads.c:163-259,642-648: the reference chops every read of >= K + 1 bases the same way, lengths from lenBuffer); the
+ * tiles are sized for the longest read.  max_len = an upper bound on the read lengths of the ragged batches to come (the
+ * reference's maxReadLen); 0 = none known: every ragged batch then costs a device reduction and one host wait.  A read
+ * longer than the bound fails the pass (reported by pg_finalize). */
+int pg_set_read_len_bound(pg_ctx *ctx, uint32_t max_len);
 
 /* Multi-GPU path, step 1: extract the batch's k-mer occurrences as routed records instead of inserting.
  * Record = (nw + 1) uint64_t: key words, then meta = ordinal << 6 | left << 3 | right (left/right = base code

@@ -45,6 +45,7 @@ def main():
     ap.add_argument("--kmer", type=int, default=63)
     ap.add_argument("--sets", type=int, default=8)
     ap.add_argument("--a-gb", type=int, default=0, help="the reference's -a (0 = growable sets)")
+    ap.add_argument("--min-len", type=int, default=0, help="ragged reads: lengths uniform in [min_len, read_len] (synth_fastq's min_len; 0 = one length)")
     ap.add_argument("--reference", action="store_true", help="run oracle/_ref instead of the executable and --save its md5s")
     ap.add_argument("--save", default="", help="with --reference: where the expectation goes")
     ap.add_argument("--expect", default="", help="JSON written by --reference --save for the same arguments")
@@ -55,10 +56,15 @@ def main():
     ap.add_argument("--rocprof", default="", help="run the command under rocprofv3 with these arguments (e.g. '--kernel-trace --stats'), output next to result.json")
     a = ap.parse_args()
     key = {k: getattr(a, k) for k in ("reads", "read_len", "genome", "err", "seed", "kmer", "sets", "a_gb")}
+    if a.min_len:
+        key["min_len"] = a.min_len                                 # (absent from the expectation files of one-length runs)
     want, want_kind = None, None
     if not a.reference:
         if a.expect:
             e = json.load(open(a.expect))
+            if not a.min_len and e.get("workload", {}).get("min_len"):      # (the expectation says how the reads were trimmed)
+                a.min_len = e["workload"]["min_len"]
+                key["min_len"] = a.min_len
             if e.get("workload") != key or not e.get("md5"):
                 sys.exit(f"{a.expect} holds no md5s for these arguments: {e.get('workload')} vs {key}")
             want = e["md5"]
@@ -68,8 +74,11 @@ def main():
     os.makedirs(a.out, exist_ok=True)
     fq, cfg = os.path.abspath(os.path.join(a.out, "reads.fq")), os.path.join(a.out, "lib.cfg")
     t = time.time()
-    if not (a.keep_fastq and os.path.exists(fq)):
-        subprocess.check_call([GEN, fq, str(a.genome), str(a.reads), str(a.read_len), str(a.err), str(a.seed)])
+    gen_args = [str(a.genome), str(a.reads), str(a.read_len), str(a.err), str(a.seed), str(a.min_len)]
+    made_with = open(fq + ".args").read().split() if os.path.exists(fq + ".args") else None
+    if not (a.keep_fastq and os.path.exists(fq) and (made_with is None or made_with == gen_args)):      # (a kept file is reused only for the arguments it was made with)
+        subprocess.check_call([GEN, fq, str(a.genome), str(a.reads), str(a.read_len), str(a.err), str(a.seed)] + ([str(os.cpu_count() or 8), str(a.min_len)] if a.min_len else []))
+        open(fq + ".args", "w").write(" ".join(gen_args))
     open(cfg, "w").write(f"max_rd_len={a.read_len}\n[LIB]\navg_ins=200\nreverse_seq=0\nasm_flags=3\nrank=1\nq={fq}\n")
     os.sync()
     res = {"workload": key, "fastq_bytes": os.path.getsize(fq), "generate_s": round(time.time() - t, 1)}
@@ -109,7 +118,7 @@ def main():
         res["stderr_tail"] = r.stderr[-1500:]
     for f in os.listdir(a.out):
         full = os.path.join(a.out, f)
-        if os.path.isfile(full) and not f.startswith(("result", "stderr")) and not (a.keep_fastq and f in ("reads.fq", "lib.cfg")):
+        if os.path.isfile(full) and not f.startswith(("result", "stderr")) and not (a.keep_fastq and f in ("reads.fq", "reads.fq.args", "lib.cfg")):
             os.remove(full)
     print(json.dumps(res, indent=1))
     json.dump(res, open(os.path.join(a.out, f"result{a.tag}.json"), "w"), indent=1)

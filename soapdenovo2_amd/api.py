@@ -79,6 +79,7 @@ def lib() -> C.CDLL:
     L.pg_host_graph_resolve_repeats.argtypes = [C.c_void_p, C.c_int]
     L.pg_graph_use_device.argtypes = [C.c_void_p, C.c_int]
     L.pg_expect_kmers.argtypes = [C.c_void_p, C.c_uint64]
+    L.pg_set_read_len_bound.argtypes = [C.c_void_p, C.c_uint32]
     L.pg_sort_records.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
     L.pg_host_graph_add_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
     L.pg_host_read_all.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
@@ -162,6 +163,7 @@ EXPORTED_SYMBOLS = [
     "pg_comm_transport", "pg_comm_stats", "pg_exchange_counts", "pg_exchange_records", "pg_exchange_allreduce_u64",
     "pg_exchange_gather_records", "pg_count_reads_sharded", "pg_host_skm_cut", "pg_host_skm_expand",
     "pg_host_emu_layout_static", "pg_graph_begin_device", "pg_host_emu_clip_tips", "pg_exchange_regroup_by_set", "pg_comm_regroup_stats", "pg_graph_begin_sharded", "pg_host_regroup_plan", "pg_host_bam_pair_state", "pg_device_scratch_offer", "pg_device_scratch_withdraw", "pg_host_emu_layout_growable", "pg_exchange_regroup_by_set_ws", "pg_host_edge_file_in_background", "pg_graph_add_packed_device", "pg_host_emu_home_slots", "pg_comm_pipeline_stats", "pg_comm_create_host", "pg_comm_flush",
+    "pg_set_read_len_bound", "pg_graph_add_packed_device_ragged",
 ]
 
 
@@ -508,6 +510,10 @@ class KmerCounter:
         _check(lib().pg_count_reads(self.h, d_packed.data_ptr(), None, None, n_reads, read_len, n_kmers, ord_base,
                                     self._stream()), "pg_count_reads")
         return n_kmers
+
+    def set_read_len_bound(self, max_len: int) -> None:
+        """No read of the ragged batches to come is longer (0: unknown -- every ragged batch then asks the device and waits)."""
+        _check(lib().pg_set_read_len_bound(self.h, max_len), "pg_set_read_len_bound")
 
     def count_ragged(self, d_packed, d_word_off, d_kmer_base, n_reads: int, n_kmers: int, ord_base: int = 0) -> int:
         _check(lib().pg_count_reads(self.h, d_packed.data_ptr(), d_word_off.data_ptr(), d_kmer_base.data_ptr(), n_reads, 0,

@@ -194,26 +194,45 @@ struct KeptReads {
     }
 };
 
-// Reads kept for pass 2 in DEVICE memory: while every read so far has one length, the batches pass 1 has uploaded anyway are
-// copied on (device to device) into chunks of 1 GiB, one segment a batch; pass 2 threads them where they are
-// (pg_graph_add_packed_device) -- no copy back, no index arrays.  The first read of another length moves everything into the host
-// store (KeptReads), which then goes on as before.
+// Reads kept for pass 2 in DEVICE memory: the batches pass 1 has uploaded anyway are copied on (device to device) into chunks of
+// 1 GiB, one segment a batch; pass 2 threads them where they are (pg_graph_add_packed_device[_ragged]) -- no copy back.  A batch of one
+// read length is its words alone; a ragged batch (round 6: any mix of lengths stays on the device, as the reference threads reads of
+// any length the same way, prlRead2path.c:1056-1110) keeps the two index arrays pass 1 took behind its words.  Only a budget that
+// runs out moves everything into the host store (KeptReads), which then goes on as before.
 struct DevKept {
-    struct Seg { uint64_t* d; uint64_t n_reads; };
+    // len > 0: n_reads reads of len bases back to back.  len = 0: n_words words of reads, 8 words of padding, word_off[n_reads],
+    // kmer_base[n_reads + 1] (all 64-bit); max_len = the longest read.
+    struct Seg {
+        uint64_t* d; uint64_t n_reads; int len; uint64_t n_words, n_kmers; int max_len;
+        const uint64_t* d_off() const { return d + n_words + 8; }
+        const uint64_t* d_base() const { return d + n_words + 8 + n_reads; }
+    };
     static constexpr size_t CHUNK_WORDS = (size_t)1 << 27;
     std::vector<void*> chunks;
     std::vector<Seg> segs;
     size_t used_in_last = 0, total_bytes = 0;
-    int len = 0, device = 0;
+    int device = 0;
     DevKept() {}
     DevKept(const DevKept&) = delete;
     DevKept& operator=(const DevKept&) = delete;
     ~DevKept() { clear(); }
     void clear() {
         for (void* c : chunks) (void)pg::arena_free(c);
-        chunks.clear(); segs.clear(); used_in_last = 0; total_bytes = 0; len = 0;
+        chunks.clear(); segs.clear(); used_in_last = 0; total_bytes = 0;
     }
-    void swap(DevKept& o) { chunks.swap(o.chunks); segs.swap(o.segs); std::swap(used_in_last, o.used_in_last); std::swap(total_bytes, o.total_bytes); std::swap(len, o.len); std::swap(device, o.device); }
+    void swap(DevKept& o) { chunks.swap(o.chunks); segs.swap(o.segs); std::swap(used_in_last, o.used_in_last); std::swap(total_bytes, o.total_bytes); std::swap(device, o.device); }
+    // a segment's reads into the host store's form: words back to back + a length a read; false = the copy failed
+    static bool fetch(const Seg& sg, int K, std::vector<uint64_t>& words, std::vector<int32_t>& lens) {
+        const size_t nw = sg.len ? sg.n_reads * (((size_t)sg.len + 31) / 32) : sg.n_words;
+        words.resize(nw);
+        if (hipMemcpy(words.data(), sg.d, nw * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) return false;
+        if (sg.len) { lens.assign(sg.n_reads, (int32_t)sg.len); return true; }
+        std::vector<uint64_t> base(sg.n_reads + 1);
+        if (hipMemcpy(base.data(), sg.d_base(), base.size() * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) return false;
+        lens.resize(sg.n_reads);
+        for (uint64_t r = 0; r < sg.n_reads; r++) lens[r] = (int32_t)(base[r + 1] - base[r]) + K - 1;
+        return true;
+    }
     // room for n_words words (<= CHUNK_WORDS); nullptr = no device memory
     uint64_t* take(size_t n_words) {
         if (n_words > CHUNK_WORDS) return nullptr;
@@ -240,7 +259,7 @@ public:
         uint64_t *h_words = nullptr, *h_off = nullptr, *h_base = nullptr;
         size_t n_reads = 0, n_words = 0;
         uint64_t n_kmers = 0, ord_base = 0;
-        int first_len = 0;
+        int first_len = 0, max_len = 0;
         bool uniform = true;
     };
     BatchFiller(int K, size_t max_words, size_t max_reads, int n_bufs) : K_(K), max_words_(max_words), max_reads_(max_reads), buf_(n_bufs) {
@@ -264,8 +283,7 @@ public:
         Buf* b = &buf_[cur_];
         if (b->n_reads == max_reads_ || b->n_words + nw > max_words_) { submit(); b = &buf_[cur_]; }
         pg_pack_read(codes, (uint32_t)len, b->h_words + b->n_words);
-        if (keep_ && dev_keep_) dev_keep_to_host();
-        if (keep_) { const int32_t l32 = len; keep_append(b->h_words + b->n_words, nw, &l32, 1); }   // pass 2 threads the same reads again
+        if (keep_ && !dev_keep_) { const int32_t l32 = len; keep_append(b->h_words + b->n_words, nw, &l32, 1); }   // pass 2 threads the same reads again (dev_keep_: the batch stays on the device, submit)
         b->h_off[b->n_reads] = b->n_words;
         b->h_base[b->n_reads] = b->n_kmers;
         note_length(b, len);
@@ -294,10 +312,7 @@ public:
                         b->h_off[b->n_reads + i] = b->n_words + i * wpr;
                         b->h_base[b->n_reads + i] = b->n_kmers + i * kpr;
                     }
-                if (keep_) {
-                    if (dev_keep_ && (dev_len_ == 0 || dev_len_ == len)) dev_len_ = len;      // kept when the batch is on the device (submit)
-                    else { if (dev_keep_) dev_keep_to_host(); if (keep_) keep_append(words + at, take * wpr, lens + r, take); }
-                }
+                if (keep_ && !dev_keep_) keep_append(words + at, take * wpr, lens + r, take);      // (dev_keep_: kept when the batch is on the device, submit)
                 b->n_words += take * wpr; b->n_kmers += take * kpr; b->n_reads += take;
                 accepted_ += (long long)take;
                 at += take * wpr; r += take;
@@ -311,8 +326,7 @@ public:
                 Buf* b = &buf_[cur_];
                 if (b->n_reads == max_reads_ || b->n_words + nw > max_words_) { submit(); b = &buf_[cur_]; }
                 memcpy(b->h_words + b->n_words, words + at, nw * sizeof(uint64_t));
-                if (keep_ && dev_keep_) { dev_keep_to_host(); b = &buf_[cur_]; }
-                if (keep_) keep_append(words + at, nw, &lens[r], 1);
+                if (keep_ && !dev_keep_) keep_append(words + at, nw, &lens[r], 1);
                 b->h_off[b->n_reads] = b->n_words;
                 b->h_base[b->n_reads] = b->n_kmers;
                 note_length(b, len);
@@ -327,6 +341,7 @@ public:
     // first read of a batch, or a read of another length: from then on the batch needs its index arrays, and the block
     // copies above did not fill them while every read had the same length
     void note_length(Buf* b, int len) {
+        if (len > b->max_len) b->max_len = len;
         if (b->n_reads == 0) { b->first_len = len; return; }
         if (!b->uniform || len == b->first_len) return;
         const size_t wpr = pg_packed_words((uint32_t)b->first_len);
@@ -342,7 +357,6 @@ public:
     void keep_reads_on_device(size_t budget_bytes) { dev_keep_ = keep_ && budget_bytes > 0; dev_budget_ = budget_bytes; }
     bool take_dev_kept(DevKept& out) {
         if (!dev_keep_) return false;
-        dev_kept_.len = dev_len_;
         out.swap(dev_kept_);
         return !out.segs.empty();
     }
@@ -351,22 +365,25 @@ public:
     virtual void dev_keep_to_host() {
         if (!dev_keep_) return;
         dev_keep_ = false;
-        const size_t wpr = dev_len_ ? pg_packed_words((uint32_t)dev_len_) : 0;
         std::vector<uint64_t> tmp;
         std::vector<int32_t> ls;
         (void)hipDeviceSynchronize();
         for (const DevKept::Seg& sg : dev_kept_.segs) {
-            tmp.resize(sg.n_reads * wpr);
-            ls.assign(sg.n_reads, (int32_t)dev_len_);
-            if (hipMemcpy(tmp.data(), sg.d, tmp.size() * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess) { keep_ = false; kept_.clear(); break; }
+            if (!DevKept::fetch(sg, K_, tmp, ls)) { keep_ = false; kept_.clear(); break; }
             if (keep_) keep_append(tmp.data(), tmp.size(), ls.data(), sg.n_reads);
         }
         dev_kept_.clear();
         const Buf& b = buf_[cur_];
-        if (keep_ && b.n_reads && wpr) {                          // (filled by the one-length block copies alone while the device kept them)
-            ls.assign(b.n_reads, (int32_t)dev_len_);
-            keep_append(b.h_words, b.n_reads * wpr, ls.data(), b.n_reads);
+        if (keep_ && b.n_reads) {                                 // (no host copy was made of these while the device kept the batches)
+            batch_lens(b, ls);
+            keep_append(b.h_words, b.n_words, ls.data(), b.n_reads);
         }
+    }
+    // the lengths of a batch's reads (a batch that is still being filled has no h_base[n_reads] yet)
+    void batch_lens(const Buf& b, std::vector<int32_t>& ls) const {
+        if (b.uniform) { ls.assign(b.n_reads, (int32_t)b.first_len); return; }
+        ls.resize(b.n_reads);
+        for (size_t r = 0; r < b.n_reads; r++) ls[r] = (int32_t)((r + 1 < b.n_reads ? b.h_base[r + 1] : b.n_kmers) - b.h_base[r]) + K_ - 1;
     }
     bool take_kept(KeptReads& out) {
         if (!keep_) return false;
@@ -383,7 +400,7 @@ protected:
         b.ord_base = ord_;
         ord_ += b.n_kmers;
     }
-    void reset(Buf& b) { b.n_reads = 0; b.n_words = 0; b.n_kmers = 0; b.first_len = 0; b.uniform = true; }
+    void reset(Buf& b) { b.n_reads = 0; b.n_words = 0; b.n_kmers = 0; b.first_len = 0; b.max_len = 0; b.uniform = true; }
     int K_;
     size_t max_words_, max_reads_;
     std::vector<Buf> buf_;
@@ -405,7 +422,6 @@ private:
 protected:
     void keep_host(const uint64_t* w, size_t nw, const int32_t* lens, size_t n) { if (keep_) keep_append(w, nw, lens, n); }
     bool dev_keep_ = false;
-    int dev_len_ = 0;
     size_t dev_budget_ = 0;
     DevKept dev_kept_;
 };
@@ -457,21 +473,27 @@ private:
                 HIP_OK(hipMemcpyAsync(d.d_off, b.h_off, b.n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, stream_));
                 HIP_OK(hipMemcpyAsync(d.d_base, b.h_base, (b.n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, stream_));
             }
+            if (!b.uniform && !failed_ && pg_set_read_len_bound(ctx_, (uint32_t)b.max_len) != PG_OK) failed_ = true;   // (the tiles of a ragged batch are sized for its longest read)
             if (!failed_ && pg_count_reads(ctx_, d.d_words, b.uniform ? nullptr : d.d_off, b.uniform ? nullptr : d.d_base, b.n_reads,
                                            b.uniform ? (uint32_t)b.first_len : 0u, b.n_kmers, b.ord_base, stream_) != PG_OK)
                 failed_ = true;                                     // the caller decides (finish_ok)
-            if (dev_keep_) {                                        // the batch is of one length (or dev_keep_ would be off): it stays on the device for pass 2
-                uint64_t* dst = dev_kept_.total_bytes + (b.n_words + 8) * sizeof(uint64_t) <= dev_budget_ ? dev_kept_.take(b.n_words + 8) : nullptr;
-                if (dst && hipMemcpyAsync(dst, d.d_words, (b.n_words + 8) * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream_) == hipSuccess)
-                    dev_kept_.segs.push_back(DevKept::Seg{dst, b.n_reads});
+            if (dev_keep_) {                                        // the batch stays on the device for pass 2 (a ragged one with its index arrays)
+                const size_t extra = b.uniform ? 0 : 2 * b.n_reads + 1, need = b.n_words + 8 + extra;
+                uint64_t* dst = dev_kept_.total_bytes + need * sizeof(uint64_t) <= dev_budget_ ? dev_kept_.take(need) : nullptr;
+                bool ok = dst && hipMemcpyAsync(dst, d.d_words, (b.n_words + 8) * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream_) == hipSuccess;
+                if (ok && !b.uniform)
+                    ok = hipMemcpyAsync(dst + b.n_words + 8, d.d_off, b.n_reads * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream_) == hipSuccess &&
+                         hipMemcpyAsync(dst + b.n_words + 8 + b.n_reads, d.d_base, (b.n_reads + 1) * sizeof(uint64_t), hipMemcpyDeviceToDevice, stream_) == hipSuccess;
+                if (ok) dev_kept_.segs.push_back(DevKept::Seg{dst, b.n_reads, b.uniform ? b.first_len : 0, b.n_words, b.n_kmers, b.max_len});
                 else {                                              // no room: this batch and all before it go to the host store
-                    const size_t wpr = pg_packed_words((uint32_t)dev_len_);
-                    std::vector<int32_t> ls(b.n_reads, (int32_t)dev_len_);
+                    (void)hipGetLastError();
                     Buf hold = b;                                   // (dev_keep_to_host looks at buf_[cur_]: make it see an empty batch, this one is appended below)
                     b.n_reads = 0;
                     dev_keep_to_host();
                     b = hold;
-                    keep_host(b.h_words, b.n_reads * wpr, ls.data(), b.n_reads);
+                    std::vector<int32_t> ls;
+                    batch_lens(b, ls);
+                    keep_host(b.h_words, b.n_words, ls.data(), b.n_reads);
                 }
             }
             HIP_OK(hipEventRecord(d.done, stream_));
@@ -566,6 +588,7 @@ private:
                     HIP_OK(hipMemcpyAsync(d_base, b.h_base, (b.n_reads + 1) * sizeof(uint64_t), hipMemcpyHostToDevice, st));
                 }
             }
+            if (!b.uniform && b.n_reads) (void)pg_set_read_len_bound(ctx_[r], (uint32_t)b.max_len);      // (the tiles of a ragged batch are sized for its longest read)
             if (pg_count_reads_sharded(ctx_[r], comm_[r], d_words, b.uniform ? nullptr : d_off, b.uniform ? nullptr : d_base, b.n_reads,
                                        (b.uniform && b.n_reads) ? (uint32_t)b.first_len : 0u, b.n_kmers, b.ord_base, st) != PG_OK) {
                 fprintf(stderr, "rank %d: pg_count_reads_sharded: %s\n", r, pg_last_error());
@@ -889,16 +912,10 @@ int run(int argc, char** argv, bool mer127) {
         pg_destroy(ctx);
         engine = 1;
         if (!devkept.segs.empty()) {                               // the second attempt is fed from the host store
-            const size_t wpr = pg_packed_words((uint32_t)devkept.len);
             std::vector<uint64_t> tmp;
             std::vector<int32_t> ls;
-            for (const DevKept::Seg& sg : devkept.segs) {
-                tmp.resize(sg.n_reads * wpr);
-                ls.assign(sg.n_reads, (int32_t)devkept.len);
-                if (hipMemcpy(tmp.data(), sg.d, tmp.size() * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess || !kept.append(tmp.data(), tmp.size(), ls.data(), sg.n_reads)) {
-                    have_kept = false; kept.clear(); break;
-                }
-            }
+            for (const DevKept::Seg& sg : devkept.segs)
+                if (!DevKept::fetch(sg, K, tmp, ls) || !kept.append(tmp.data(), tmp.size(), ls.data(), sg.n_reads)) { have_kept = false; kept.clear(); break; }
             devkept.clear();
         }
     }
@@ -1023,10 +1040,12 @@ int run(int argc, char** argv, bool mer127) {
     // ---- pass 2 (prlRead2edge): the reads again, in the same order, threaded through the edges -> .preArc
     t0 = time(nullptr);
     if (have_kept && !devkept.segs.empty() && !host_pass2) {
-        // the reads of pass 1 are still on the device (one length, one segment a batch): threaded where they are
+        // the reads of pass 1 are still on the device (one segment a batch): threaded where they are
         fprintf(stderr, "In file: %s, max seq len %d, max name len %d.\n", o.config.c_str(), max_read_len, 256);
-        for (const DevKept::Seg& sg : devkept.segs)
-            if (pg_graph_add_packed_device(graph, sg.d, sg.n_reads, devkept.len, devkept.device) != PG_OK) die("pg_graph_add_packed_device");
+        for (const DevKept::Seg& sg : devkept.segs) {
+            if (sg.len) { if (pg_graph_add_packed_device(graph, sg.d, sg.n_reads, sg.len, devkept.device) != PG_OK) die("pg_graph_add_packed_device"); }
+            else if (pg_graph_add_packed_device_ragged(graph, sg.d, sg.d_off(), sg.d_base(), sg.n_reads, sg.n_kmers, sg.max_len, devkept.device) != PG_OK) die("pg_graph_add_packed_device_ragged");
+        }
         devkept.clear();
         fprintf(stderr, "%lld read(s) processed.\n", n_records);
     } else if (have_kept) {

@@ -25,6 +25,7 @@ struct DevCounters {
     unsigned long long e2_flags;       // bit 0 pool exhausted, bit 1 partition chunk list full, bit 2 output full, bit 3 split exhausted
     unsigned long long n_records;      // super-k-mer records written
     unsigned long long phase[12];      // PG_DBG=2: cycles of workgroup thread 0 per K2 phase (measurement aid)
+    unsigned long long ragged_max;     // k-mers of the longest read of a ragged batch (partition_kernels.hip: ragged_geometry)
     // Chunks of the record pool are handed out by POOL_SUBS counters, one 64-byte line each, picked by the partition id: a
     // single counter took every chunk request of the chip -- 7 M returned atomics on one address per 200 M reads, and one
     // address serves about 88 of them per microsecond (MI355X_MICROARCH.md, "dequeue"): that alone was K1's 84 ms.
@@ -73,6 +74,7 @@ struct pg_ctx {
     int hint_log2_parts = -1;    // engine 2: partition count asked for by pg_expect_kmers (-1 = derive from log2_slots)
     uint64_t hint_kmers = 0;     // engine 2: k-mer occurrences to come, 0 = unknown (sizes the record pool)
     uint64_t batches = 0;        // batches taken since create / reset
+    uint32_t read_len_bound = 0; // engine 2: no read of a ragged batch is longer (pg_set_read_len_bound; 0 = ask the device, one host wait a batch)
     pg::E2 e2;
     // the sharded pass 1 (exchange.hip) keeps its last round's records in flight when it returns: whatever consumes the partition
     // streams next (pg_finalize, pg_reset, pg_destroy, ...) has them appended first

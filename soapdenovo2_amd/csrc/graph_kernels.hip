@@ -2231,6 +2231,49 @@ int p2_add_packed_device(P2Device* d, const uint64_t* d_words, uint64_t n_reads,
     return PG_OK;
 }
 
+// ... and for reads of ANY mix of lengths that pass 1 left on the device with their index arrays (the ragged batches of
+// pg_count_reads: d_word_off[n_reads], d_kmer_base[n_reads + 1], every read >= K + 1 bases): the lengths pass 2's kernels want come from
+// kmer_base on the device, nothing goes through the host.
+__global__ __launch_bounds__(256) void p2_lens_from_kbase(const uint64_t* __restrict__ kbase, uint64_t n_reads, int K, int32_t* __restrict__ lens) {
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r < n_reads) lens[r] = (int32_t)(kbase[r + 1] - kbase[r]) + K - 1;
+}
+int p2_add_packed_device_ragged(P2Device* d, const uint64_t* d_words, const uint64_t* d_word_off, const uint64_t* d_kmer_base, uint64_t n_reads, uint64_t n_kmers, int device) {
+    if (!d->reads_ready) { pg_set_error("pass 2: p2_begin_reads was not called"); return PG_ESTATE; }
+    if (d->reps) { pg_set_error("pass 2: device-resident reads are not for -R runs"); return PG_ESTATE; }
+    if (!n_reads) return PG_OK;
+    if (!d_words || !d_word_off || !d_kmer_base) { pg_set_error("pass 2: bad argument"); return PG_EINVAL; }
+    P2Lane* ln = nullptr;
+    for (size_t q = 0; q < d->lanes.size() && !ln; q++) {          // the next lane in turn among those on that device
+        P2Lane& c = d->lanes[(d->next_lane + q) % d->lanes.size()];
+        if (c.device == device) { ln = &c; d->next_lane = (unsigned)((d->next_lane + q + 1) % d->lanes.size()); }
+    }
+    if (!ln) { pg_set_error("pass 2: no lane of the graph runs on the device the reads lie on"); return PG_EINVAL; }
+    if (d->route && ln->pend.have) { const int rc = p2_route_round(d); if (rc) return rc; }      // (its length row still serves a batch that waits for its round)
+    P2_HIP(hipSetDevice(ln->device));
+    if (n_reads > ln->cap_reads) {
+        P2_HIP(hipStreamSynchronize(ln->stream));
+        pg::arena_free(ln->d_off); pg::arena_free(ln->d_lens);
+        ln->d_off = nullptr; ln->d_lens = nullptr;
+        ln->cap_reads = n_reads * 5 / 4;
+        P2_HIP(pg::arena_malloc((void**)&ln->d_off, ln->cap_reads * sizeof(uint64_t)));
+        P2_HIP(pg::arena_malloc((void**)&ln->d_lens, ln->cap_reads * sizeof(int32_t)));
+    }
+    hipLaunchKernelGGL(p2_lens_from_kbase, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, ln->stream, d_kmer_base, n_reads, d->K, ln->d_lens);
+    P2_HIP(hipGetLastError());
+    if (d->route) {                                                   // (every read has k-mers here: kmer_base IS the first k-mer of a read among the batch's)
+        { const int rc = p2r_grow(ln->kbase, (size_t)n_reads); if (rc) return rc; }
+        P2_HIP(hipMemcpyAsync(ln->kbase.p, d_kmer_base, n_reads * sizeof(uint64_t), hipMemcpyDeviceToDevice, ln->stream));
+    }
+    { const int rc = p2_batch_ready(d, *ln, d_words, d_word_off, ln->d_lens, n_reads, n_kmers, 0, nullptr, nullptr, true); if (rc) return rc; }
+    P2_HIP(hipSetDevice(ln->device));
+    P2_HIP(hipStreamSynchronize(ln->stream));
+    d->ordinal += n_reads;
+    ln->reads += n_reads; ln->batches++;
+    P2_HIP(hipSetDevice(d->device));
+    return PG_OK;
+}
+
 int p2_finish(P2Device* d, P2Result& out) {
     if (d->route) { const int rc = p2_route_round(d); if (rc) return rc; }        // the batches still waiting for a full round
     unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};

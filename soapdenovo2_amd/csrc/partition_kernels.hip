@@ -41,6 +41,7 @@ namespace pg {
 
 constexpr uint64_t L_EMPTY = ~0ULL;
 constexpr unsigned long long F_POOL = 1, F_CHUNKS = 2, F_OUT = 4, F_SPLIT = 8, F_ROUTE = 16;   // F_ROUTE: an owner's send region overflowed (multi-GPU cut)
+constexpr unsigned long long F_LEN = 32;   // a read of a ragged batch is longer than the bound its tiles were sized for, or shorter than K + 1
 
 template <int NW> struct E2Cfg;
 // LDS slot = KW key words | ord | 5 x u32 of counters (LdsSet below).  Two-word flavour: words of 63 bits, so that no word of a key
@@ -70,8 +71,9 @@ struct ReadsArg {
     const uint64_t* word_off;
     const uint64_t* kmer_base;
     uint64_t n_reads;
-    uint32_t uniform_len, kpr, wpr;
+    uint32_t uniform_len, kpr, wpr;  // ragged batches through the tiled kernel: uniform_len = 0, kpr / wpr = those of the longest read (max_len)
     uint64_t ord_base;
+    uint32_t max_len;                // ragged batches: no read is longer (0 = unknown: the one-lane-a-read kernel)
 };
 
 // address of record q of partition pid.  The lane that draws the first record of a chunk (q % rpc == 0) takes a
@@ -155,7 +157,7 @@ __device__ __forceinline__ uint32_t fastdiv(uint32_t i, uint32_t inv) { return _
 // i / d for small i with inv = ceil(2^32 / d); d = 1 has no 32-bit reciprocal
 __device__ __forceinline__ uint32_t fastdiv1(uint32_t i, uint32_t d, uint32_t inv) { return d == 1 ? i : __umulhi(i, inv); }
 
-// Tiled K1 for uniform-length reads: every thread does a short serial piece of work on consecutive positions
+// Tiled K1: every thread does a short serial piece of work on consecutive positions
 // (skm_tile.hpp).  (Round 1 had one lane per k-mer and a log-step sliding minimum by wave shuffles: ~480 vector
 // instructions per read, profiles/r01_pmc_sq_bench20M_engine2.json; this form measures 1.65x faster,
 // profiles/r02_k1k2_rewrite_ab.json.)
@@ -165,16 +167,19 @@ __device__ __forceinline__ uint32_t fastdiv1(uint32_t i, uint32_t d, uint32_t in
 //   D     thread = the same segment: one LDS atomic reserves its items, every start bit finds the next start
 //   E     one lane per run: slot in the partition's stream (or the owner's send region), record from the dword string
 // Lanes of a wave take different reads (read index fastest), so the row stride -- forced odd -- is the bank stride.
+// RAGGED: the reads of the batch have their own lengths (prlHashReads.c:642-648: lenBuffer[r], any read of K + 1 bases and more is
+// chopped the same way).  The tile's rows are as long as the batch's longest read needs; a read's length and first ordinal sit in LDS
+// beside its row, a segment past the read's last k-mer has no start bits, and everything else is the uniform kernel.
 struct SegArg { int R, np, npad, wsd, nseg, nca; uint32_t inv_R, inv_wpr; };
 
 // W: the window length (m-mers a k-mer) at compile time, with 16-mers (0: whatever the geometry says) -- the loops of phase B
 // unroll into loads with immediate offsets, phase A loses its shifts by 32 - 2m.
-template <int NW, bool ROUTE, int S, int W = 0>
+template <int NW, bool ROUTE, int S, int W = 0, bool RAGGED = false>
 __global__ __launch_bounds__(BLOCK) void skm_scatter_seg_kernel(ReadsArg a, E2Dev e, DevCounters* ctr, SegArg sa, RouteArg ro) {
     constexpr int PW = E2Cfg<NW>::PW, RW = PW + 1;
     extern __shared__ __align__(16) unsigned char smem_raw[];
     const int R = sa.R, np = sa.np, npad = sa.npad, wsd = sa.wsd, nseg = sa.nseg, nca = sa.nca;
-    const int wpr = (int)a.wpr, kpr = (int)a.kpr, len = (int)a.uniform_len;
+    const int wpr = (int)a.wpr, kpr = (int)a.kpr, len = (int)a.uniform_len;      // (RAGGED: wpr, kpr, np = the longest read's)
     uint32_t* dw = (uint32_t*)smem_raw;                           // R * wsd   dword strings
     uint32_t* v0 = dw + (size_t)R * wsd;                          // R * npad  m-mer values; the item list after B
     // (odd row strides here too: lanes of a wave take different reads, so the row stride is the bank stride -- nseg * S = 88 and nseg = 8 at 150 bp, K = 63
@@ -185,14 +190,33 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_seg_kernel(ReadsArg a, E2De
     uint32_t* smask = pids + (size_t)R * kpad;                    // R * mpad  run-start bits
     uint32_t* ranks = smask + (size_t)R * mpad;                   // R * kpr   (ROUTE only)
     uint32_t* items = v0;
+    // RAGGED: per read its first k-mer among the batch's (8-byte aligned: the rows above are dwords) and its length
+    uint64_t* rkb = (uint64_t*)(((uintptr_t)(ranks + (ROUTE ? (size_t)R * kpr : 0)) + 7) & ~(uintptr_t)7);
+    int* rlen = (int*)(rkb + R);
     __shared__ unsigned int n_items;
     const uint64_t r0 = (uint64_t)blockIdx.x * R;
     const int nr = (int)min((uint64_t)R, a.n_reads - r0);
     if (threadIdx.x == 0) n_items = 0;
-    for (int i = threadIdx.x; i < nr * wpr; i += BLOCK) {
-        const int r = (int)fastdiv1(i, wpr, sa.inv_wpr), k = i - r * wpr;
-        const uint64_t wd = a.packed[r0 * wpr + i];
-        *(uint2*)(dw + r * wsd + 2 * k) = make_uint2((uint32_t)(wd >> 32), (uint32_t)wd);
+    if (RAGGED) {
+        for (int r = threadIdx.x; r < nr; r += BLOCK) {
+            const uint64_t kb = a.kmer_base[r0 + r];
+            int l = (int)(a.kmer_base[r0 + r + 1] - kb) + e.g.K - 1;
+            if (l > (int)a.max_len || l < e.g.K + 1) { atomicOr(&ctr->e2_flags, F_LEN); l = 0; }      // (a read without k-mers from here on; the batch fails in e2_count)
+            rkb[r] = kb; rlen[r] = l;
+        }
+        __syncthreads();
+        // lanes over (read, word of the longest read): a read's words are consecutive lanes, the reads of a tile consecutive in memory
+        for (int i = threadIdx.x; i < nr * wpr; i += BLOCK) {
+            const int r = (int)fastdiv1(i, wpr, sa.inv_wpr), k = i - r * wpr;
+            const uint64_t wd = 32 * k < rlen[r] ? a.packed[a.word_off[r0 + r] + k] : 0ULL;
+            *(uint2*)(dw + r * wsd + 2 * k) = make_uint2((uint32_t)(wd >> 32), (uint32_t)wd);
+        }
+    } else {
+        for (int i = threadIdx.x; i < nr * wpr; i += BLOCK) {
+            const int r = (int)fastdiv1(i, wpr, sa.inv_wpr), k = i - r * wpr;
+            const uint64_t wd = a.packed[r0 * wpr + i];
+            *(uint2*)(dw + r * wsd + 2 * k) = make_uint2((uint32_t)(wd >> 32), (uint32_t)wd);
+        }
     }
     for (int r = threadIdx.x; r < nr; r += BLOCK)
         for (int k = 2 * wpr; k < wsd; k++) dw[r * wsd + k] = 0;
@@ -210,9 +234,12 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_seg_kernel(ReadsArg a, E2De
     for (int t = threadIdx.x; t < R * nseg; t += BLOCK) {
         const int seg = (int)fastdiv1(t, R, sa.inv_R), r = t - seg * R;
         if (r >= nr) continue;
-        const int j0 = seg * S, cnt = min(S, kpr - j0);
+        const int j0 = seg * S;
+        const int kpr_r = RAGGED ? rlen[r] - e.g.K + 1 : kpr, np_r = RAGGED ? rlen[r] - m + 1 : np;
+        const int cnt = min(S, kpr_r - j0);
+        if (RAGGED && cnt <= 0) { smask[r * mpad + seg] = 0; continue; }       // behind the read's last k-mer
         uint32_t pid[S];
-        const uint32_t mk = tile_segment<S, W>(v0 + r * npad, np, j0, cnt, w, e.g.nmax, e.g.part_mul, pid);
+        const uint32_t mk = tile_segment<S, W>(v0 + r * npad, np_r, j0, cnt, w, e.g.nmax, e.g.part_mul, pid);
         smask[r * mpad + seg] = mk;
 #pragma unroll
         for (int i = 0; i < S; i++) pids[r * kpad + j0 + i] = pid[i];
@@ -227,7 +254,7 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_seg_kernel(ReadsArg a, E2De
                 const int i = __ffs((int)mk) - 1;
                 mk &= mk - 1;
                 const int j = seg * S + i;
-                const int nxt = tile_next_start(smask + r * mpad, seg, nseg, S, i, kpr);
+                const int nxt = tile_next_start(smask + r * mpad, seg, nseg, S, i, RAGGED ? rlen[r] - e.g.K + 1 : kpr);
                 items[at++] = ((uint32_t)r << 24) | ((uint32_t)j << 12) | (uint32_t)(nxt - j);
             }
         }
@@ -258,7 +285,8 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_seg_kernel(ReadsArg a, E2De
         // the returned atomic on the partition's cursor is asked first and looked at after the record is built
         if (!ROUTE) q = atomicAdd(&e.cursor[pid], 1u);
         uint64_t rec[RW];
-        tile_make_record<PW>(dw + r * wsd, len, j0, n, a.ord_base + (r0 + (uint64_t)r) * (uint64_t)kpr, e.g.K, rec);
+        if (RAGGED) tile_make_record<PW>(dw + r * wsd, rlen[r], j0, n, a.ord_base + rkb[r], e.g.K, rec);
+        else tile_make_record<PW>(dw + r * wsd, len, j0, n, a.ord_base + (r0 + (uint64_t)r) * (uint64_t)kpr, e.g.K, rec);
         if (ROUTE) {
             const uint32_t o = pid % (uint32_t)ro.n_owners;
             const unsigned long long at = obase[o] + ranks[it];
@@ -1236,36 +1264,42 @@ static int e2_ensure_pool(pg_ctx* c, uint64_t n_reads, uint64_t n_kmers, hipStre
     return PG_OK;
 }
 
-template <int NW, bool ROUTE, int W>
+template <int NW, bool ROUTE, int W, bool RG>
 static void launch_seg_s(int S, dim3 grid, size_t smem, hipStream_t st, const ReadsArg& a, const E2Dev& e, DevCounters* ctr, const SegArg& sa, const RouteArg& ro) {
     switch (S) {
-        case 7: hipLaunchKernelGGL((skm_scatter_seg_kernel<NW, ROUTE, 7, W>), grid, dim3(BLOCK), smem, st, a, e, ctr, sa, ro); break;
-        case 9: hipLaunchKernelGGL((skm_scatter_seg_kernel<NW, ROUTE, 9, W>), grid, dim3(BLOCK), smem, st, a, e, ctr, sa, ro); break;
-        case 11: hipLaunchKernelGGL((skm_scatter_seg_kernel<NW, ROUTE, 11, W>), grid, dim3(BLOCK), smem, st, a, e, ctr, sa, ro); break;
-        case 13: hipLaunchKernelGGL((skm_scatter_seg_kernel<NW, ROUTE, 13, W>), grid, dim3(BLOCK), smem, st, a, e, ctr, sa, ro); break;
-        default: hipLaunchKernelGGL((skm_scatter_seg_kernel<NW, ROUTE, 15, W>), grid, dim3(BLOCK), smem, st, a, e, ctr, sa, ro); break;
+        case 7: hipLaunchKernelGGL((skm_scatter_seg_kernel<NW, ROUTE, 7, W, RG>), grid, dim3(BLOCK), smem, st, a, e, ctr, sa, ro); break;
+        case 9: hipLaunchKernelGGL((skm_scatter_seg_kernel<NW, ROUTE, 9, W, RG>), grid, dim3(BLOCK), smem, st, a, e, ctr, sa, ro); break;
+        case 11: hipLaunchKernelGGL((skm_scatter_seg_kernel<NW, ROUTE, 11, W, RG>), grid, dim3(BLOCK), smem, st, a, e, ctr, sa, ro); break;
+        case 13: hipLaunchKernelGGL((skm_scatter_seg_kernel<NW, ROUTE, 13, W, RG>), grid, dim3(BLOCK), smem, st, a, e, ctr, sa, ro); break;
+        default: hipLaunchKernelGGL((skm_scatter_seg_kernel<NW, ROUTE, 15, W, RG>), grid, dim3(BLOCK), smem, st, a, e, ctr, sa, ro); break;
     }
 }
 // the instantiations with the window length at compile time: K = 63 (48 16-mers a k-mer) and K = 31 (16) in the two-word flavour,
 // K = 127 (112) in the four-word one; every other geometry runs the general kernel (PG_K1_W=0: always)
-template <int NW, bool ROUTE>
+template <int NW, bool ROUTE, bool RG>
 static void launch_seg(int S, int m, int w, dim3 grid, size_t smem, hipStream_t st, const ReadsArg& a, const E2Dev& e, DevCounters* ctr, const SegArg& sa, const RouteArg& ro) {
     bool fixed = m == 16 && S <= w;
     if (const char* v = env_measure("PG_K1_W")) fixed = fixed && atoi(v) != 0;
-    if (fixed && NW == 2 && w == 48) launch_seg_s<NW, ROUTE, 48>(S, grid, smem, st, a, e, ctr, sa, ro);
-    else if (fixed && NW == 2 && w == 16) launch_seg_s<NW, ROUTE, 16>(S, grid, smem, st, a, e, ctr, sa, ro);
-    else if (fixed && NW == 4 && w == 112) launch_seg_s<NW, ROUTE, 112>(S, grid, smem, st, a, e, ctr, sa, ro);
-    else launch_seg_s<NW, ROUTE, 0>(S, grid, smem, st, a, e, ctr, sa, ro);
+    if (fixed && NW == 2 && w == 48) launch_seg_s<NW, ROUTE, 48, RG>(S, grid, smem, st, a, e, ctr, sa, ro);
+    else if (fixed && NW == 2 && w == 16) launch_seg_s<NW, ROUTE, 16, RG>(S, grid, smem, st, a, e, ctr, sa, ro);
+    else if (fixed && NW == 4 && w == 112) launch_seg_s<NW, ROUTE, 112, RG>(S, grid, smem, st, a, e, ctr, sa, ro);
+    else launch_seg_s<NW, ROUTE, 0, RG>(S, grid, smem, st, a, e, ctr, sa, ro);
+}
+template <int NW, bool ROUTE>
+static void launch_seg_rg(bool ragged, int S, int m, int w, dim3 grid, size_t smem, hipStream_t st, const ReadsArg& a, const E2Dev& e, DevCounters* ctr, const SegArg& sa, const RouteArg& ro) {
+    if (ragged) launch_seg<NW, ROUTE, true>(S, m, w, grid, smem, st, a, e, ctr, sa, ro);
+    else launch_seg<NW, ROUTE, false>(S, m, w, grid, smem, st, a, e, ctr, sa, ro);
 }
 
 // launch the tiled K1; returns PG_OK / an error, or 1 when the reads are too long for a tile (caller falls back)
 static int launch_tiled(pg_ctx* c, const ReadsArg& a, const RouteArg* route, hipStream_t st) {
     const SkmGeom& g = c->e2.g;
-    const int kpr = (int)a.kpr, wpr = (int)a.wpr, np = (int)a.uniform_len - g.m + 1;
+    const bool ragged = a.uniform_len == 0;                                   // rows for the batch's longest read (a.kpr, a.wpr: its)
+    const int kpr = (int)a.kpr, wpr = (int)a.wpr, np = (int)(ragged ? a.max_len : a.uniform_len) - g.m + 1;
     int S = tile_pick_segment(kpr, g.w);
     if (const char* v = env_measure("PG_K1_S")) { const int q = atoi(v); if (q >= 7 && q <= 15 && (q & 1) && (q <= g.w || q == 7)) S = q; }
     const int nseg = (kpr + S - 1) / S, nca = (np + 15) / 16, npad = (16 * nca) | 1, wsd = (2 * wpr + 3) | 1;   // value rows: whole 16-position chunks, odd stride
-    const size_t per_read = (size_t)(wsd + npad + ((nseg * S) | 1) + (nseg | 1) + (route ? kpr : 0)) * 4;     // (the kernel's rows: dword string, values, partition ids, start bits, ranks)
+    const size_t per_read = (size_t)(wsd + npad + ((nseg * S) | 1) + (nseg | 1) + (route ? kpr : 0)) * 4 + (ragged ? 12 : 0);     // (the kernel's rows: dword string, values, partition ids, start bits, ranks; ragged: first k-mer + length)
     int R = std::min<int>(128, std::max(1, BLOCK / nseg));                     // one pass of phase B per tile
     R = (int)std::min<size_t>((size_t)R, (60 * 1024) / per_read);
     // ... and about 25 KB of LDS a tile, i.e. five workgroups a CU: measured at 150 bp (profiles/r03v_k1_tile_sizes.json), K = 63
@@ -1283,13 +1317,13 @@ static int launch_tiled(pg_ctx* c, const ReadsArg& a, const RouteArg* route, hip
     SegArg sa{R, np, npad, wsd, nseg, nca, inv((uint32_t)R), inv(a.wpr)};
     RouteArg ro{nullptr, nullptr, nullptr, 0, 1};
     if (route) ro = *route;
-    const size_t smem = per_read * R;
+    const size_t smem = per_read * R + (ragged ? 8 : 0);                      // (+ the alignment of the 8-byte row)
     if (c->NW == 2) {
-        if (route) launch_seg<2, true>(S, g.m, g.w, dim3((unsigned)grid), smem, st, a, dev_view(c), c->ctr, sa, ro);
-        else launch_seg<2, false>(S, g.m, g.w, dim3((unsigned)grid), smem, st, a, dev_view(c), c->ctr, sa, ro);
+        if (route) launch_seg_rg<2, true>(ragged, S, g.m, g.w, dim3((unsigned)grid), smem, st, a, dev_view(c), c->ctr, sa, ro);
+        else launch_seg_rg<2, false>(ragged, S, g.m, g.w, dim3((unsigned)grid), smem, st, a, dev_view(c), c->ctr, sa, ro);
     } else {
-        if (route) launch_seg<4, true>(S, g.m, g.w, dim3((unsigned)grid), smem, st, a, dev_view(c), c->ctr, sa, ro);
-        else launch_seg<4, false>(S, g.m, g.w, dim3((unsigned)grid), smem, st, a, dev_view(c), c->ctr, sa, ro);
+        if (route) launch_seg_rg<4, true>(ragged, S, g.m, g.w, dim3((unsigned)grid), smem, st, a, dev_view(c), c->ctr, sa, ro);
+        else launch_seg_rg<4, false>(ragged, S, g.m, g.w, dim3((unsigned)grid), smem, st, a, dev_view(c), c->ctr, sa, ro);
     }
     E2_TRY(hipGetLastError());
     c->e2.counted = false;
@@ -1314,6 +1348,38 @@ static int launch_serial(pg_ctx* c, const ReadsArg& a, const RouteArg* route, hi
     return PG_OK;
 }
 
+// The longest read of a ragged batch sizes the rows of its tiles: the caller's bound (pg_set_read_len_bound) or, without one, a
+// reduction over kmer_base and one host wait a batch.
+__global__ __launch_bounds__(BLOCK) void ragged_max_kernel(const uint64_t* __restrict__ kmer_base, uint64_t n_reads, DevCounters* ctr) {
+    unsigned long long mx = 0;
+    for (uint64_t r = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; r < n_reads; r += (uint64_t)gridDim.x * BLOCK)
+        mx = max(mx, (unsigned long long)(kmer_base[r + 1] - kmer_base[r]));
+    for (int o = 32; o; o >>= 1) mx = max(mx, (unsigned long long)__shfl_xor((unsigned long long)mx, o));
+    if ((threadIdx.x & 63) == 0 && mx) atomicMax(&ctr->ragged_max, mx);
+}
+// (PG_K1_RAGGED=0 in a -DPG_MEASURE build: ragged batches through the one-lane-a-read kernel, the round-5 form, for the A/B)
+static bool ragged_tiles_wanted() {
+    if (const char* v = env_measure("PG_K1_RAGGED")) return atoi(v) != 0;
+    return true;
+}
+static int ragged_geometry(pg_ctx* c, ReadsArg& a, hipStream_t st) {
+    uint32_t L = c->read_len_bound;
+    if (!L) {
+        E2_TRY(hipMemsetAsync(&c->ctr->ragged_max, 0, sizeof(unsigned long long), st));
+        const unsigned grid = (unsigned)std::min<uint64_t>((a.n_reads + BLOCK - 1) / BLOCK, 2048);
+        hipLaunchKernelGGL(ragged_max_kernel, dim3(grid), dim3(BLOCK), 0, st, a.kmer_base, a.n_reads, c->ctr);
+        E2_TRY(hipGetLastError());
+        unsigned long long mk = 0;
+        E2_TRY(hipMemcpyAsync(&mk, &c->ctr->ragged_max, sizeof(mk), hipMemcpyDeviceToHost, st));
+        E2_TRY(hipStreamSynchronize(st));
+        L = (uint32_t)std::min<unsigned long long>(mk + (unsigned long long)c->K - 1, 0xFFFFFFFFull);
+    }
+    a.max_len = L;
+    if (L >= (uint32_t)c->K + 1 && L < 4096) { a.kpr = L - c->K + 1; a.wpr = (L + 31) / 32; }
+    else a.max_len = 0;                                          // (too long for a tile: the one-lane-a-read kernel)
+    return PG_OK;
+}
+
 // multi-GPU step 1: cut a batch into records grouped by owner (partition mod n_owners).  Uniform batches go through the
 // tiled kernel, ragged ones (d_word_off / d_kmer_base given) through the one-lane-per-read kernel.
 int e2_route(pg_ctx* c, const uint64_t* d_packed, const uint64_t* d_word_off, const uint64_t* d_kmer_base, uint64_t n_reads,
@@ -1327,10 +1393,11 @@ int e2_route(pg_ctx* c, const uint64_t* d_packed, const uint64_t* d_word_off, co
     if ((ord_base >> (64 - SKM_ORD_SHIFT)) != 0) { pg_set_error("ordinal exceeds the 46 bits of a super-k-mer header"); return PG_EINVAL; }
     ReadsArg a;
     a.packed = d_packed; a.word_off = d_word_off; a.kmer_base = d_kmer_base; a.n_reads = n_reads; a.uniform_len = uniform_len;
-    a.kpr = uniform_len ? uniform_len - c->K + 1 : 0; a.wpr = uniform_len ? (uniform_len + 31) / 32 : 0; a.ord_base = ord_base;
+    a.kpr = uniform_len ? uniform_len - c->K + 1 : 0; a.wpr = uniform_len ? (uniform_len + 31) / 32 : 0; a.ord_base = ord_base; a.max_len = 0;
     E2_TRY(hipMemsetAsync(d_counts, 0, sizeof(uint64_t) * n_owners, st));
     RouteArg ro{d_recs, d_pids, (unsigned long long*)d_counts, cap, n_owners};
-    if (uniform_len && uniform_len < 4096 && (int)a.kpr < 4096) {
+    if (!uniform_len && ragged_tiles_wanted()) { int rc = ragged_geometry(c, a, st); if (rc) return rc; }
+    if ((uniform_len && uniform_len < 4096 && (int)a.kpr < 4096) || a.max_len) {
         int rc = launch_tiled(c, a, &ro, st);
         if (rc != 1) return rc;
     }
@@ -1377,8 +1444,10 @@ int e2_scatter(pg_ctx* c, const uint64_t* d_packed, const uint64_t* d_word_off, 
     a.kpr = uniform_len ? uniform_len - c->K + 1 : 0;
     a.wpr = uniform_len ? (uniform_len + 31) / 32 : 0;
     a.ord_base = ord_base;
-    // tiled kernel for uniform batches whose per-read LDS footprint fits
-    int tiled = uniform_len && uniform_len < 4096 && (int)a.kpr < 4096;
+    a.max_len = 0;
+    if (!uniform_len && ragged_tiles_wanted()) { int rc = ragged_geometry(c, a, st); if (rc) return rc; }
+    // tiled kernel for the batches whose per-read LDS footprint fits (ragged ones: rows for their longest read)
+    int tiled = (uniform_len && uniform_len < 4096 && (int)a.kpr < 4096) || a.max_len;
     if (const char* v = env_measure("PG_K1")) tiled = tiled && atoi(v) != 0;
     if (tiled) {
         int rc = launch_tiled(c, a, nullptr, st);
@@ -1481,6 +1550,7 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     E2_TRY(hipStreamSynchronize(st));
     DevCounters h;
     E2_TRY(hipMemcpy(&h, c->ctr, sizeof h, hipMemcpyDeviceToHost));
+    if (h.e2_flags & F_LEN) { pg_set_error("partition engine: a ragged batch holds a read longer than the bound given with pg_set_read_len_bound, or shorter than K + 1"); return PG_EINVAL; }
     if (h.e2_flags & F_ROUTE) { pg_set_error("partition engine: an owner's send region overflowed and the cut was not repeated"); return PG_ENOMEM; }
     if (h.e2_flags & F_POOL) { pg_set_error("partition engine: record pool exhausted (raise log2_slots or PG_POOL_MB)"); return PG_ENOMEM; }
     if (h.e2_flags & F_CHUNKS) { pg_set_error("partition engine: one partition outgrew its chunk list (heavily skewed minimizers)"); return PG_ENOMEM; }

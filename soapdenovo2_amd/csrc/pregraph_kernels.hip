@@ -556,6 +556,16 @@ extern "C" pg_ctx* pg_create_sized(int device, int K, int mer127, int n_sets, in
     return c;
 }
 
+// Ragged batches: an upper bound on the read lengths to come (the reference's own lenBuffer has one too: maxReadLen sizes its
+// buffers, prlHashReads.c:1251-1263).  The tiles of the super-k-mer cutter are sized for it; without one every ragged batch asks the
+// device for its longest read and waits for the answer.  A read longer than the bound fails the pass (pg_finalize reports it).
+extern "C" int pg_set_read_len_bound(pg_ctx* c, uint32_t max_len) {
+    if (!c) { g_err = "null context"; return PG_EINVAL; }
+    if (max_len && max_len < (uint32_t)c->K + 1) { g_err = "pg_set_read_len_bound: the bound is shorter than K + 1"; return PG_EINVAL; }
+    c->read_len_bound = max_len;
+    return PG_OK;
+}
+
 // The partition count of engine 2 follows the number of k-mer occurrences to come (about 8 k of them, i.e. some 400
 // super-k-mer records, a partition), not the number of distinct k-mers the export array is sized for.  Before the first
 // batch only; a no-op for engine 1.

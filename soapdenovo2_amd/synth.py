@@ -160,11 +160,28 @@ def write_config(path: str, fastq: str, max_rd_len: int, key: str = "q", avg_ins
                 f"rank=1\n{key}={os.path.abspath(fastq)}\n")
 
 
+def ragged_lens(n_reads: int, min_len: int, read_len: int, seed: int) -> np.ndarray:
+    """Read lengths of a trimmed library: uniform in [min_len, read_len] (its own random stream, so the bases are those of
+    the untrimmed case)."""
+    return np.random.default_rng(seed + 7919).integers(min_len, read_len + 1, size=n_reads).astype(np.int32)
+
+
 def make_case(outdir: str, name: str, genome_len: int, n_reads: int, read_len: int, err: float,
-              seed: int, fmt: str = "fastq", model: str = "uniform", K: int = 0) -> str:
-    """Generate <outdir>/<name>.fq (or .fa) + <name>.cfg; return the config path."""
+              seed: int, fmt: str = "fastq", model: str = "uniform", K: int = 0, min_len: int = 0) -> str:
+    """Generate <outdir>/<name>.fq (or .fa) + <name>.cfg; return the config path.  min_len: reads trimmed to ragged_lens."""
     os.makedirs(outdir, exist_ok=True)
     codes = reads_codes_model(model, genome_len, n_reads, read_len, err, seed, K)
+    if min_len:
+        lens = ragged_lens(n_reads, min_len, read_len, seed)
+        data = os.path.join(outdir, name + ".fq")
+        blob = b"".join(_fastq_blob([codes[i, :lens[i]] for i in range(n_reads)], [b"r%d" % i for i in range(n_reads)]))
+        if len(blob) % 32768 == 0:                 # (the reference would drop the tail, prlHashReads.c:873-877)
+            blob = blob[:-1] + b" \n"
+        with open(data, "wb") as f:
+            f.write(blob)
+        cfg = os.path.join(outdir, name + ".cfg")
+        write_config(cfg, data, read_len, "q")
+        return cfg
     if fmt == "fastq":
         data = os.path.join(outdir, name + ".fq")
         write_fastq(data, codes)

@@ -57,7 +57,14 @@ def case_codes(case):
 def case_config(case, outdir, name):
     """FASTQ + config of a golden case, as tests/golden/make_golden.py wrote them for the reference."""
     from soapdenovo2_amd import synth
-    return synth.make_case(outdir, name, case["G"], case["N"], case["L"], case["err"], case["seed"], model=case.get("model", "uniform"), K=case["K"])
+    return synth.make_case(outdir, name, case["G"], case["N"], case["L"], case["err"], case["seed"], model=case.get("model", "uniform"), K=case["K"],
+                           min_len=case.get("min_len", 0))
+
+
+def case_lens(case):
+    """Read lengths of a golden case: None when every read has case["L"] bases, else the trimmed lengths (synth.ragged_lens)."""
+    from soapdenovo2_amd import synth
+    return synth.ragged_lens(case["N"], case["min_len"], case["L"], case["seed"]) if case.get("min_len") else None
 
 
 def oracle_records(codes, K, P, D=0, mer127=False, a_gb=0, prefix=None):

@@ -121,41 +121,53 @@ extern "C" int64_t emu_skm_count(const uint64_t* packed, int64_t n_reads, int le
 // and word for word with skm_split_read + skm_make_record.  Returns 0 or a negative code.
 #include "../soapdenovo2_amd/csrc/skm_tile.hpp"
 
+// word_off / lens = null: n_reads reads of `len` bases back to back; otherwise a ragged batch whose longest read has `len` bases (the
+// rows of a tile are sized for it, a read's own length masks its segments: the RAGGED instantiation of skm_scatter_seg_kernel)
 template <int NW, int S>
-static int64_t tile_check(const uint64_t* packed, int64_t n_reads, int len, int K, int log2_parts, int R) {
+static int64_t tile_check(const uint64_t* packed, const uint64_t* word_off, const int32_t* lens, int64_t n_reads, int len, int K, int log2_parts, int R) {
     constexpr int PW = NW == 2 ? 5 : 7, RW = PW + 1;
     const SkmGeom g = skm_geometry(K, log2_parts, NW);
     const int wpr = (len + 31) / 32, kpr = len - K + 1, np = len - g.m + 1;
     const int wsd = (2 * wpr + 3) | 1, nseg = (kpr + S - 1) / S, nca = (np + 15) / 16, npad = (16 * nca) | 1;
     if (S > g.w && S != 7) return -100;
     int64_t checked = 0;
+    uint64_t kb = 0;
     for (int64_t r0 = 0; r0 < n_reads; r0 += R) {
         const int nr = (int)std::min<int64_t>(R, n_reads - r0);
         std::vector<uint32_t> dw((size_t)nr * wsd, 0), v0((size_t)nr * npad, 0xABABABABu), pids((size_t)nr * kpr, 0), masks((size_t)nr * nseg, 0);
-        for (int r = 0; r < nr; r++)
+        std::vector<int> rlen(nr);
+        std::vector<uint64_t> rkb(nr);
+        std::vector<const uint64_t*> rd_of(nr);
+        for (int r = 0; r < nr; r++) {
+            rlen[r] = lens ? lens[r0 + r] : len;
+            if (rlen[r] > len || rlen[r] < K + 1) return -107;
+            rd_of[r] = packed + (word_off ? word_off[r0 + r] : (uint64_t)(r0 + r) * wpr);
+            rkb[r] = kb; kb += (uint64_t)(rlen[r] - K + 1);
             for (int k = 0; k < wpr; k++) {
-                const uint64_t wd = packed[(r0 + r) * wpr + k];
+                const uint64_t wd = 32 * k < rlen[r] ? rd_of[r][k] : 0ULL;
                 dw[(size_t)r * wsd + 2 * k] = (uint32_t)(wd >> 32); dw[(size_t)r * wsd + 2 * k + 1] = (uint32_t)wd;
             }
+        }
         for (int t = 0; t < nr * nca; t++) {
             const int c = t / nr, r = t % nr;
             if (g.m == 16 && (t & 1)) tile_mmer_chunk<16>(dw.data() + (size_t)r * wsd, c, g.m, v0.data() + (size_t)r * npad);      // (both forms; every position is compared below)
             else tile_mmer_chunk(dw.data() + (size_t)r * wsd, c, g.m, v0.data() + (size_t)r * npad);
         }
         for (int r = 0; r < nr; r++)                                // phase A against the 64-bit formulation
-            for (int p = 0; p < np; p++) if (v0[(size_t)r * npad + p] != mmer_value(packed + (r0 + r) * wpr, p, g.m)) return -101;
+            for (int p = 0; p < rlen[r] - g.m + 1; p++) if (v0[(size_t)r * npad + p] != mmer_value(rd_of[r], p, g.m)) return -101;
         for (int t = 0; t < nr * nseg; t++) {
-            const int seg = t / nr, r = t % nr, j0 = seg * S, cnt = std::min(S, kpr - j0);
+            const int seg = t / nr, r = t % nr, j0 = seg * S, kpr_r = rlen[r] - K + 1, np_r = rlen[r] - g.m + 1, cnt = std::min(S, kpr_r - j0);
+            if (cnt <= 0) { masks[(size_t)r * nseg + seg] = 0; continue; }
             uint32_t pid[S];
-            masks[(size_t)r * nseg + seg] = tile_segment<S>(v0.data() + (size_t)r * npad, np, j0, cnt, g.w, g.nmax, g.part_mul, pid);
+            masks[(size_t)r * nseg + seg] = tile_segment<S>(v0.data() + (size_t)r * npad, np_r, j0, cnt, g.w, g.nmax, g.part_mul, pid);
             for (int i = 0; i < cnt; i++) pids[(size_t)r * kpr + j0 + i] = pid[i];
             // the instantiations with the window length at compile time (what the kernel runs for K = 31 / 63 / 127): same bits, same ids
             uint32_t pid2[S];
             uint32_t mk2 = masks[(size_t)r * nseg + seg];
             bool have = true;
-            if (g.w == 48 && S <= 48) mk2 = tile_segment<S, 48>(v0.data() + (size_t)r * npad, np, j0, cnt, g.w, g.nmax, g.part_mul, pid2);
-            else if (g.w == 112 && S <= 112) mk2 = tile_segment<S, 112>(v0.data() + (size_t)r * npad, np, j0, cnt, g.w, g.nmax, g.part_mul, pid2);
-            else if (g.w == 16 && S <= 16) mk2 = tile_segment<S, 16>(v0.data() + (size_t)r * npad, np, j0, cnt, g.w, g.nmax, g.part_mul, pid2);
+            if (g.w == 48 && S <= 48) mk2 = tile_segment<S, 48>(v0.data() + (size_t)r * npad, np_r, j0, cnt, g.w, g.nmax, g.part_mul, pid2);
+            else if (g.w == 112 && S <= 112) mk2 = tile_segment<S, 112>(v0.data() + (size_t)r * npad, np_r, j0, cnt, g.w, g.nmax, g.part_mul, pid2);
+            else if (g.w == 16 && S <= 16) mk2 = tile_segment<S, 16>(v0.data() + (size_t)r * npad, np_r, j0, cnt, g.w, g.nmax, g.part_mul, pid2);
             else have = false;
             if (have) {
                 if (mk2 != masks[(size_t)r * nseg + seg]) return -105;
@@ -165,24 +177,25 @@ static int64_t tile_check(const uint64_t* packed, int64_t n_reads, int len, int 
         for (int r = 0; r < nr; r++) {
             struct Run { int j0, n; uint32_t pid; };
             std::vector<Run> got, want;
+            const int kpr_r = rlen[r] - K + 1;
             for (int seg = 0; seg < nseg; seg++) {
                 uint32_t mk = masks[(size_t)r * nseg + seg];
                 while (mk) {
                     const int i = __builtin_ffs((int)mk) - 1;
                     mk &= mk - 1;
-                    const int j = seg * S + i, nxt = tile_next_start(masks.data() + (size_t)r * nseg, seg, nseg, S, i, kpr);
+                    const int j = seg * S + i, nxt = tile_next_start(masks.data() + (size_t)r * nseg, seg, nseg, S, i, kpr_r);
                     got.push_back(Run{j, nxt - j, pids[(size_t)r * kpr + j]});
                 }
             }
-            const uint64_t* rd = packed + (r0 + r) * wpr;
-            skm_split_read(rd, len, g, [&](int j0, int n, uint32_t pid) { want.push_back(Run{j0, n, pid}); });
+            const uint64_t* rd = rd_of[r];
+            skm_split_read(rd, rlen[r], g, [&](int j0, int n, uint32_t pid) { want.push_back(Run{j0, n, pid}); });
             if (got.size() != want.size()) return -102;
             for (size_t q = 0; q < got.size(); q++) {
                 if (got[q].j0 != want[q].j0 || got[q].n != want[q].n || got[q].pid != want[q].pid) return -103;
                 uint64_t a[RW], b[RW];
-                const uint64_t ord0 = (uint64_t)(r0 + r) * (uint64_t)kpr + 12345;
-                tile_make_record<PW>(dw.data() + (size_t)r * wsd, len, got[q].j0, got[q].n, ord0, K, a);
-                skm_make_record<PW>(rd, len, want[q].j0, want[q].n, ord0, g, b);
+                const uint64_t ord0 = rkb[r] + 12345;
+                tile_make_record<PW>(dw.data() + (size_t)r * wsd, rlen[r], got[q].j0, got[q].n, ord0, K, a);
+                skm_make_record<PW>(rd, rlen[r], want[q].j0, want[q].n, ord0, g, b);
                 for (int k = 0; k < RW; k++) if (a[k] != b[k]) return -104;
                 checked++;
             }
@@ -192,7 +205,15 @@ static int64_t tile_check(const uint64_t* packed, int64_t n_reads, int len, int 
 }
 
 extern "C" int64_t emu_tile_check(const uint64_t* packed, int64_t n_reads, int len, int K, int mer127, int log2_parts, int S, int R) {
-#define TC(NWV, SV) case SV: return tile_check<NWV, SV>(packed, n_reads, len, K, log2_parts, R);
+#define TC(NWV, SV) case SV: return tile_check<NWV, SV>(packed, nullptr, nullptr, n_reads, len, K, log2_parts, R);
+    if (mer127) switch (S) { TC(4, 7) TC(4, 9) TC(4, 11) TC(4, 13) TC(4, 15) default: return -99; }
+    switch (S) { TC(2, 7) TC(2, 9) TC(2, 11) TC(2, 13) TC(2, 15) default: return -99; }
+#undef TC
+}
+// a ragged batch: word_off[r] = first word of read r, lens[r] its bases, max_len >= every length
+extern "C" int64_t emu_tile_check_ragged(const uint64_t* packed, const uint64_t* word_off, const int32_t* lens, int64_t n_reads, int max_len, int K, int mer127,
+                                         int log2_parts, int S, int R) {
+#define TC(NWV, SV) case SV: return tile_check<NWV, SV>(packed, word_off, lens, n_reads, max_len, K, log2_parts, R);
     if (mer127) switch (S) { TC(4, 7) TC(4, 9) TC(4, 11) TC(4, 13) TC(4, 15) default: return -99; }
     switch (S) { TC(2, 7) TC(2, 9) TC(2, 11) TC(2, 13) TC(2, 15) default: return -99; }
 #undef TC

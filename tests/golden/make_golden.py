@@ -16,11 +16,13 @@ from soapdenovo2_amd import synth
 
 # name: genome, reads, len, err, seed, K, runs [(P, D, a, mer127)], keep full files?
 CASES = {
+    # (round 6: -p beyond 8 -- 16, 37, 64, 255: the set id is an unsigned char and fixes every output byte, pregraph.c:142-220,
+    #  prlHashReads.c:66-126 -- and -d together with -a)
     "t6k_k31":  dict(G=30000, N=6000, L=100, err=0.005, seed=20260926, K=31,
-                     runs=[(1,0,0,0), (8,0,0,0), (7,0,0,0), (3,1,0,0), (2,0,1,0)], full=[(1,0,0,0), (8,0,0,0)]),
+                     runs=[(1,0,0,0), (8,0,0,0), (7,0,0,0), (3,1,0,0), (2,0,1,0), (16,0,0,0), (255,0,0,0), (37,1,1,0)], full=[(1,0,0,0), (8,0,0,0)]),
     "t8k_k63":  dict(G=40000, N=8000, L=150, err=0.003, seed=3, K=63,
-                     runs=[(2,0,0,0), (8,0,0,0), (2,0,0,1), (2,0,1,0), (2,0,1,1), (3,1,0,0), (3,2,0,1)], full=[(2,0,0,0)]),
-    "t6k_k127": dict(G=40000, N=6000, L=250, err=0.002, seed=5, K=127, runs=[(3,0,0,1), (3,0,1,1), (3,1,0,1)], full=[]),
+                     runs=[(2,0,0,0), (8,0,0,0), (2,0,0,1), (2,0,1,0), (2,0,1,1), (3,1,0,0), (3,2,0,1), (37,0,0,0), (64,0,0,0), (16,1,1,0)], full=[(2,0,0,0)]),
+    "t6k_k127": dict(G=40000, N=6000, L=250, err=0.002, seed=5, K=127, runs=[(3,0,0,1), (3,0,1,1), (3,1,0,1), (16,0,0,1), (64,0,0,1), (255,0,0,1)], full=[]),
     "t5k_k24":  dict(G=20000, N=5000, L=80, err=0.01, seed=12, K=24, runs=[(8,0,0,0)], full=[]),
     "m100k_k31": dict(G=500000, N=100000, L=100, err=0.005, seed=7, K=31, runs=[(8,0,0,0)], full=[]),
     "m60k_k63": dict(G=400000, N=60000, L=150, err=0.002, seed=8, K=63, runs=[(8,0,0,0), (8,0,0,1)], full=[]),
@@ -33,6 +35,11 @@ CASES = {
     # collide.  Here two sets of 33.5 M slots take ~17 M k-mers each (~52 %): probe clusters, kick-free first-come-first-served linear probing as
     # the device layout (dev_graph.hpp: layout_static) has to reproduce it, a cluster that wraps round the end of a table
     "l1500k_k31": dict(G=12000000, N=1500000, L=100, err=0.005, seed=77, K=31, runs=[(2,0,1,0)], full=[]),
+    # trimmed reads (round 6): lengths uniform in [min_len, L] (synth.ragged_lens) -- every batch is ragged, the tiles of the super-k-mer cutter
+    # are sized for the longest read and pass 2 threads the reads where pass 1 left them; prlHashReads.c:163-259,642-648 chops any read alike
+    "g120k_k63": dict(G=600000, N=120000, L=150, min_len=100, err=0.002, seed=31, K=63, runs=[(8,0,0,0), (8,0,1,0)], full=[]),
+    "g40k_k127": dict(G=300000, N=40000, L=250, min_len=160, err=0.002, seed=32, K=127, runs=[(5,0,0,1)], full=[]),
+    "g60k_k31": dict(G=300000, N=60000, L=100, min_len=40, err=0.004, seed=33, K=31, runs=[(8,1,0,0)], full=[]),
 }
 EXTS = ("kmerFreq", "preGraphBasic", "vertex", "edge", "preArc")
 
@@ -49,7 +56,7 @@ def main():
     old = json.load(open(os.path.join(HERE, "cases.json"))) if (only_quirks or only_cases) else None
     with tempfile.TemporaryDirectory() as td:
         for name, c in ({k: v for k, v in CASES.items() if k in only_cases} if (only_quirks or only_cases) else CASES).items():
-            cfg = synth.make_case(td, name, c["G"], c["N"], c["L"], c["err"], c["seed"], model=c.get("model", "uniform"), K=c["K"])
+            cfg = synth.make_case(td, name, c["G"], c["N"], c["L"], c["err"], c["seed"], model=c.get("model", "uniform"), K=c["K"], min_len=c.get("min_len", 0))
             for run in c["runs"]:
                 P, D, a, m = run
                 t = tag(name, run)

@@ -7,7 +7,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from conftest import ROOT, case_codes, case_config, case_tag, md5_file, md5_gz_text, oracle_records
+from conftest import ROOT, case_codes, case_config, case_lens, case_tag, md5_file, md5_gz_text, oracle_records
 
 pytestmark = pytest.mark.gpu
 
@@ -46,7 +46,10 @@ def _gpu_records(codes, K, P, mer127=False, D=0, log2_slots=20, batches=1, engin
 @pytest.mark.parametrize("engine", ENGINES)
 @pytest.mark.parametrize("name,P,m,D", [("t6k_k31", 8, False, 0), ("t6k_k31", 7, False, 1), ("t8k_k63", 2, False, 0),
                                         ("t8k_k63", 5, True, 0), ("t6k_k127", 3, True, 0), ("t5k_k24", 8, False, 0),
-                                        ("d8k_k127", 3, True, 0), ("d8k_k63", 5, False, 0)])
+                                        ("d8k_k127", 3, True, 0), ("d8k_k63", 5, False, 0),
+                                        # -p beyond 8: the set id is hash % thrd_num in an unsigned char (prlHashReads.c:66-126)
+                                        ("t6k_k31", 16, False, 0), ("t6k_k31", 255, False, 1), ("t8k_k63", 37, False, 0),
+                                        ("t8k_k63", 64, True, 0), ("t6k_k127", 255, True, 0)])
 def test_count_matches_oracle(golden, tmp_path, name, P, m, D, engine):
     c = golden["cases"][name]
     codes = case_codes(c)
@@ -102,6 +105,64 @@ def test_ragged_batch(tmp_path, engine):
     got = kc.export()
     kc.close()
     assert (_sorted(got, 2) == _sorted(want, 2)).all()
+
+
+@pytest.mark.parametrize("bound", ["exact", "loose", "none"])
+@pytest.mark.parametrize("name,m127", [("g120k_k63", False), ("g40k_k127", True), ("g60k_k31", False)])
+def test_ragged_tiles_match_oracle(golden, tmp_path, name, m127, bound):
+    """Trimmed reads -- every batch ragged -- through the TILED cutter (round 6: rows for the batch's longest read, a read's own length
+    masks its segments) in several batches: keys, counters, flags, set ids and first ordinals bit-exact against the oracle at 40 - 120 k
+    reads.  With the longest read given exactly, given loosely, and not given (the device finds it)."""
+    import torch
+    from soapdenovo2_amd import api
+    from oracle_binding import Oracle
+    c = golden["cases"][name]
+    codes, lens = case_codes(c), case_lens(c)
+    K, P = c["K"], 5
+    o = Oracle(K, P=P, mer127=m127, max_read_len=c["L"])
+    o.add_reads(codes, lens=lens)
+    o.finish_count(str(tmp_path / "o"))
+    nd = o.nodes()
+    nw = o.NW
+    want = np.zeros((len(nd["A"]), nw + 2), dtype=np.uint64)
+    want[:, :nw] = nd["keys"]
+    want[:, nw] = nd["A"].astype(np.uint64) | (nd["B"].astype(np.uint64) << np.uint64(32))
+    want[:, nw + 1] = (nd["set"].astype(np.uint64) << np.uint64(56)) | nd["ord"]
+    o.close()
+    kc = api.KmerCounter(K, n_sets=P, mer127=m127, log2_slots=22)
+    n = codes.shape[0]
+    bounds = [0, 1, 25, n // 3, n // 3 + 24, n]                    # a batch of one read, one of a single full tile, large ones
+    ord_base = 0
+    for lo, hi in zip(bounds[:-1], bounds[1:]):
+        reads = [codes[i, :lens[i]] for i in range(lo, hi)]
+        words, off, kb = api.pack_reads_ragged(reads, K)
+        kc.set_read_len_bound({"exact": int(lens[lo:hi].max()), "loose": c["L"] + 37, "none": 0}[bound])
+        kc.count_ragged(torch.from_numpy(words.view(np.int64)).cuda(), torch.from_numpy(off.view(np.int64)).cuda(),
+                        torch.from_numpy(kb.view(np.int64)).cuda(), len(reads), int(kb[-1]), ord_base=ord_base)
+        ord_base += int(kb[-1])
+    kc.finalize(0)
+    got = kc.export()
+    kc.close()
+    assert got.shape == want.shape
+    assert (_sorted(got, nw) == _sorted(want, nw)).all()
+
+
+def test_ragged_read_longer_than_the_bound_fails_loudly(golden):
+    """A ragged batch with a read longer than pg_set_read_len_bound said: the pass fails in pg_finalize, nothing is cut wrongly."""
+    import torch
+    from soapdenovo2_amd import api
+    c = golden["cases"]["g60k_k31"]
+    codes, lens = case_codes(c)[:500], case_lens(c)[:500]
+    K = c["K"]
+    reads = [codes[i, :lens[i]] for i in range(500)]
+    words, off, kb = api.pack_reads_ragged(reads, K)
+    kc = api.KmerCounter(K, n_sets=3, log2_slots=18)
+    kc.set_read_len_bound(int(lens.max()) - 1)
+    kc.count_ragged(torch.from_numpy(words.view(np.int64)).cuda(), torch.from_numpy(off.view(np.int64)).cuda(),
+                    torch.from_numpy(kb.view(np.int64)).cuda(), len(reads), int(kb[-1]))
+    with pytest.raises(api.PgError, match="longer than the bound"):
+        kc.finalize(0)
+    kc.close()
 
 
 def test_route_then_count_equals_fused(golden, tmp_path):
@@ -195,7 +256,8 @@ def _run_cli(cfg, K, prefix, P, D, a, m, engine=None, R=False, extra_env=None):
 
 
 @pytest.mark.parametrize("engine", ENGINES)
-@pytest.mark.parametrize("name", ["t6k_k31", "t8k_k63", "t6k_k127", "t5k_k24", "m100k_k31", "m60k_k63", "d8k_k127", "r8k_k127", "d8k_k63"])
+@pytest.mark.parametrize("name", ["t6k_k31", "t8k_k63", "t6k_k127", "t5k_k24", "m100k_k31", "m60k_k63", "d8k_k127", "r8k_k127", "d8k_k63",
+                                  "g120k_k63", "g40k_k127", "g60k_k31"])
 def test_cli_matches_reference_files(golden, tmp_path, name, engine):
     """`SOAPdenovo-63mer|127mer pregraph -s cfg -K k -o pfx -p n [-d -a]` end to end against the reference's files."""
     from soapdenovo2_amd import synth
@@ -635,7 +697,7 @@ def test_sharded_pass1_rccl_single_rank(golden, tmp_path):
 
 
 @pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
-@pytest.mark.parametrize("name", ["m60k_k63", "t6k_k127", "t5k_k24", "d8k_k127"])
+@pytest.mark.parametrize("name", ["m60k_k63", "t6k_k127", "t5k_k24", "d8k_k127", "t6k_k31", "g120k_k63"])   # (t6k_k31: -p 1 and 2, fewer sets than ranks; g120k_k63: trimmed reads)
 def test_cli_sharded_matches_reference_files(golden, tmp_path, name, devices):
     """`pregraph` with pass 1 sharded over several ranks (SOAPDENOVO2_AMD_DEVICES, here all on GPU 0): the five files (and
     the -R pair) equal the reference's byte for byte, as with one rank."""
@@ -686,7 +748,7 @@ def test_cli_sharded_matches_reference_files(golden, tmp_path, name, devices):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("route", ["1", "0"], ids=["routed", "peer-probes"])
-@pytest.mark.parametrize("name", ["m60k_k63", "t6k_k127", "t5k_k24"])
+@pytest.mark.parametrize("name", ["m60k_k63", "t6k_k127", "t5k_k24", "g40k_k127"])
 def test_cli_sharded_pass2_lookups_routed_to_the_owners(golden, tmp_path, name, route):
     """Pass 2 of a sharded run without -R, so that the routed form runs in full rounds (a batch on every lane, all lanes cutting,
     answering and threading at once): every k-mer of every read of K + 1 bases and more is looked up exactly once, by the lane that owns
@@ -706,8 +768,10 @@ def test_cli_sharded_pass2_lookups_routed_to_the_owners(golden, tmp_path, name, 
                       re.finditer(r"pass 2 routed, lane of device \d+: asked (\d+) lookup\(s\), (\d+) of them of other lanes, in (\d+) round\(s\); answered (\d+) from its own sets; 0 probes of peer-mapped sets", log)]
             assert len(routed) == 3, log[-3000:]
             assert sum(r[0] for r in routed) == sum(r[3] for r in routed) > 0
-            if "N" in c and "L" in c:                                      # uniform reads: N x (L - K + 1) lookups in all
-                Ke = c["K"] + (1 - c["K"] % 2)                              # (pregraph.c:71-97: an even K becomes K + 1)
+            Ke = c["K"] + (1 - c["K"] % 2)                                  # (pregraph.c:71-97: an even K becomes K + 1)
+            if c.get("min_len"):                                           # trimmed reads: the sum over the reads of (len - K + 1)
+                assert sum(r[0] for r in routed) == int((case_lens(c).astype(np.int64) - Ke + 1).sum()), routed
+            else:                                                          # uniform reads: N x (L - K + 1) lookups in all
                 assert sum(r[0] for r in routed) == c["N"] * (c["L"] - Ke + 1), routed
             assert "bytes a read crossed between lanes" in log
         else:

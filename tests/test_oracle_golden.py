@@ -3,7 +3,7 @@ import os
 
 import pytest
 
-from conftest import GOLDEN, case_codes, case_tag, md5_file
+from conftest import GOLDEN, case_codes, case_lens, case_tag, md5_file
 from oracle_binding import run_oracle
 
 SMALL = ["t6k_k31", "t8k_k63", "t6k_k127", "t5k_k24", "d8k_k127", "r8k_k127", "d8k_k63"]
@@ -16,7 +16,8 @@ def _cases(golden, names):
             yield name, c, run
 
 
-@pytest.mark.parametrize("name", SMALL + ["m60k_k63"])
+# (g*: trimmed reads, lengths uniform in [min_len, L]; the runs of t6k_k31 / t8k_k63 / t6k_k127 include -p 16, 37, 64, 255 and -d with -a)
+@pytest.mark.parametrize("name", SMALL + ["m60k_k63", "g120k_k63", "g40k_k127", "g60k_k31"])
 def test_oracle_matches_reference_digests(golden, tmp_path, name):
     c = golden["cases"][name]
     codes = case_codes(c)
@@ -24,7 +25,7 @@ def test_oracle_matches_reference_digests(golden, tmp_path, name):
         P, D, a, m = run
         t = case_tag(name, run)
         pre = str(tmp_path / t)
-        run_oracle(codes, c["K"], P, pre, D=D, a_gb=a, mer127=bool(m))
+        run_oracle(codes, c["K"], P, pre, D=D, a_gb=a, mer127=bool(m), lens=case_lens(c))
         want = golden["md5"][t]
         for ext in ("kmerFreq", "preGraphBasic", "vertex", "edge"):
             assert md5_file(f"{pre}.{ext}") == want[ext], (t, ext)

@@ -69,5 +69,35 @@ def test_tiled_cutter_matches_serial_walk(golden, emu, name, m127):
     assert emu.emu_tile_pick_segment(88, 48) == 11
 
 
+@pytest.mark.parametrize("name,m127", [("t6k_k31", False), ("t8k_k63", False), ("t6k_k127", True), ("t5k_k24", False)])
+def test_tiled_cutter_ragged_matches_serial_walk(golden, emu, name, m127):
+    """The RAGGED form of K1's tiles (rows sized for the batch's longest read, a read's own length masks its segments; the
+    reference chops reads of any length >= K + 1 the same way, prlHashReads.c:163-259,642-648): same runs, same records as the
+    serial walk, for reads trimmed to every length from K + 1 to the full one -- including tiles of one length and a bound
+    larger than any read."""
+    c = golden["cases"][name]
+    codes = case_codes(c)[:1200]
+    K = c["K"] | 1
+    full = codes.shape[1]
+    rng = np.random.default_rng(11)
+    lens = rng.integers(K + 1, full + 1, size=codes.shape[0]).astype(np.int32)
+    lens[:7] = [K + 1, full, K + 2, full, K + 1, K + 1, full]
+    lens[100:140] = full - 3                                   # a stretch of one length inside the mix
+    reads = [codes[i, :lens[i]] for i in range(codes.shape[0])]
+    words, word_off, kmer_base = api.pack_reads_ragged(reads, K)
+    emu.emu_tile_check_ragged.restype = C.c_int64
+    emu.emu_tile_check_ragged.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64] + [C.c_int] * 6
+    m = max(7, min(16, K - 6))
+    w = K - m + 1
+    for S in (7, 9, 11, 13, 15):
+        if S > w and S != 7:
+            continue
+        for R, bound in ((1, full), (5, full), (32, full), (24, full + 9)):
+            n = emu.emu_tile_check_ragged(words.ctypes.data, word_off.ctypes.data, lens.ctypes.data, len(reads), bound, K, int(m127), 9, S, R)
+            assert n >= len(reads), (S, R, bound, n)
+    # a read longer than the bound is refused, not cut wrongly
+    assert emu.emu_tile_check_ragged(words.ctypes.data, word_off.ctypes.data, lens.ctypes.data, len(reads), full - 1, K, int(m127), 9, 7, 8) == -107
+
+
 def test_sliced_crc_equals_bytewise(emu):
     assert emu.emu_crc_check(20000) == 0
