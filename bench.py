@@ -315,6 +315,85 @@ def pass_other_k(torch, api, packed, n_reads, L, P, genome, err, batch_reads, de
         kc.close()
 
 
+def pass_ragged(torch, api, packed, n_reads, L, P, genome, err, batch_reads, device, K, min_len, seed, uniform_k1_ms=None):
+    """Pass 1 over the SAME resident reads trimmed to lengths uniform in [min_len, L] -- every batch ragged (word_off / kmer_base index arrays,
+    pg_set_read_len_bound(L)), cut by the RAGGED form of the tiled K1 (round 6; round 5 dropped such batches to a one-lane-a-read kernel).
+    Timed like the headline pass (1 warm-up, 2 timed passes, inputs resident), conservation on the timed result; `k1_per_base_vs_uniform` =
+    K1's time per BASE against the uniform pass's.  The reference chops reads of any length alike: prlHashReads.c:163-259,642-648."""
+    mer127 = K > 63
+    if min_len < K + 1 or min_len > L:
+        return None
+    wpr = (L + 31) // 32
+    dev = packed.device
+    g = torch.Generator(device=dev)
+    g.manual_seed(seed)
+    p2 = packed[: n_reads * wpr].view(n_reads, wpr)
+    batches, n_kmers, n_bases, ord_base = [], 0, 0, 0
+    for lo in range(0, n_reads, batch_reads):
+        n = min(batch_reads, n_reads - lo)
+        lens = torch.randint(min_len, L + 1, (n,), device=dev, generator=g, dtype=torch.int64)
+        nw = (lens + 31) // 32
+        off = torch.cumsum(nw, 0) - nw
+        total = int((off[-1] + nw[-1]).item())
+        ridx = torch.repeat_interleave(torch.arange(n, device=dev), nw, output_size=total)
+        k = torch.arange(total, device=dev) - off[ridx]
+        vals = p2[lo + ridx, k]
+        valid = lens[ridx] - 32 * k
+        shift = torch.clamp(64 - 2 * valid, min=0)
+        mask = torch.where(valid >= 32, torch.full_like(vals, -1), -torch.bitwise_left_shift(torch.ones_like(vals), shift))
+        words = torch.zeros(total + 8, dtype=torch.int64, device=dev)
+        words[:total] = vals & mask
+        kb = torch.zeros(n + 1, dtype=torch.int64, device=dev)
+        kb[1:] = torch.cumsum(lens - K + 1, 0)
+        nk = int(kb[-1].item())
+        batches.append((words, off.contiguous(), kb, n, nk, ord_base))
+        ord_base += nk
+        n_kmers += nk
+        n_bases += int(lens.sum().item())
+        del ridx, k, vals, valid, shift, mask, lens, nw
+    expected = min(n_kmers, genome + n_bases * err * min(K, L - K + 1))
+    log2_slots = 20
+    while (1 << log2_slots) * 0.6 < expected:
+        log2_slots += 1
+    kc = api.KmerCounter(K, n_sets=P, mer127=mer127, log2_slots=log2_slots, device=device.index if hasattr(device, "index") else device, engine=2)
+    try:
+        api._check(api.lib().pg_expect_kmers(kc.h, n_kmers), "pg_expect_kmers")
+        kc.set_autogrow(False)
+        kc.set_read_len_bound(L)
+        ev, hist, steps = [], None, 2
+        for it in range(1 + steps):
+            kc.reset()
+            e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+            e[0].record()
+            for words, off, kb, n, nk, ob in batches:
+                kc.count_ragged(words, off, kb, n, nk, ord_base=ob)
+            e[1].record()
+            hist, _ = kc.finalize(0, want_last_put=False)
+            e[2].record()
+            if it:
+                ev.append(e)
+        torch.cuda.synchronize()
+        k1 = sum(e[0].elapsed_time(e[1]) for e in ev) / steps
+        k2 = sum(e[1].elapsed_time(e[2]) for e in ev) / steps
+        distinct = kc.distinct()
+        cov = int((hist * np.arange(256, dtype=np.uint64)).sum())
+        sat = int(hist[255])
+        ok = int(hist.sum()) == distinct and (cov == n_kmers if sat == 0 else cov <= n_kmers)
+        out = {"workload": f"the same {n_reads} resident reads trimmed to {min_len} - {L} bp (uniform lengths, every batch ragged), K={K}, -p {P}",
+               "bases": n_bases, "kmer_occurrences": n_kmers, "ms_per_pass": k1 + k2, "reads_per_sec": n_reads / ((k1 + k2) * 1e-3),
+               "k1_scatter_ms": k1, "k2_count_ms": k2, "k1_ps_per_base": k1 * 1e9 / n_bases, "distinct_kmers": distinct,
+               "k1_kernel": "skm_scatter_seg_kernel<..., RAGGED> (tiles sized for the longest read)",
+               "conservation": {"histogram_sum_equals_distinct": int(hist.sum()) == distinct, "kmer_occurrences_in": n_kmers, "sum_of_coverage_histogram": cov,
+                                "saturated_nodes": sat, "ok": ok}}
+        if uniform_k1_ms:
+            uni = uniform_k1_ms * 1e9 / (n_reads * L)
+            out["uniform_k1_ps_per_base"] = uni
+            out["k1_per_base_vs_uniform"] = out["k1_ps_per_base"] / uni
+        return out
+    finally:
+        kc.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -335,6 +414,8 @@ def main():
     ap.add_argument("--no-big", action="store_true", help="skip the 60 M-read -a 16 command (19 GB of FASTQ on local disk, ~25 s)")
     ap.add_argument("--no-extras", action="store_true", help="skip the export + sort and the PCIe-inclusive measurements")
     ap.add_argument("--no-k127", action="store_true", help="skip the K = 127 pass over the same reads (the `k127` entry of the line)")
+    ap.add_argument("--ragged", action="store_true", help="the `ragged` entry even with --no-extras")
+    ap.add_argument("--ragged-min-len", type=int, default=100, help="the `ragged` entry: the same reads trimmed to lengths uniform in [this, read_len] (0 = skip)")
     ap.add_argument("--exchange", default="lib", help="N > 1: lib = pg_count_reads_sharded (librccl through the C ABI), torch = torch.distributed all_to_all")
     ap.add_argument("--engine", type=int, default=2, help="2 = super-k-mer partitions counted in LDS (default), 1 = one DRAM-resident set")
     ap.add_argument("--comm", default="nccl", help="nccl (RCCL over xGMI) or gloo (test only: exchange staged through the host)")
@@ -626,11 +707,22 @@ def main():
         api.hip_free(ptr)
         api.hip_free(ws)
 
-    k127 = k31 = None
-    if world == 1 and engine == 2 and K <= 63 and L >= 128 and not args.no_extras and not args.no_k127:
+    k127 = k31 = ragged = None
+    want_ragged = world == 1 and engine == 2 and args.ragged_min_len > 0 and (not args.no_extras or args.ragged)
+    want_k127 = world == 1 and engine == 2 and K <= 63 and L >= 128 and not args.no_extras and not args.no_k127
+    st_final = None
+    if want_ragged or want_k127:
         st_final = st_snapshot if extras else kc.stats()
-        kc.close()                                              # (its pools go; the 127-mer pass makes its own)
+        kc.close()                                              # (its pools go; the passes below make their own)
         torch.cuda.empty_cache()
+    if want_ragged:
+        try:
+            ragged = pass_ragged(torch, api, packed, n_reads, L, P, args.genome, args.err, args.batch_reads, dev, K, args.ragged_min_len, args.seed + 77,
+                                 uniform_k1_ms=sum(e0.elapsed_time(e1) for e0, e1, _ in ev) / args.steps if ev else None)
+        except Exception as e:
+            ragged = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+    if want_k127:
         try:
             k127 = pass_other_k(torch, api, packed, n_reads, L, P, args.genome, args.err, args.batch_reads, local, K=127)
         except Exception as e:
@@ -647,8 +739,6 @@ def main():
             del p1
         except Exception as e:
             k31 = {"error": f"{type(e).__name__}: {e}"}
-    else:
-        st_final = None
     if rank == 0:
         ms = dt / args.steps * 1e3
         total_reads = n_reads * world
@@ -779,6 +869,8 @@ def main():
                                "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                                "traffic": traffic, "traffic_note": traffic_note, "hbm_counter_frac": counter_frac, "kernel": kernel, "launches": launches, "avg_launch_ms": avg_ms,
                                "algorithmic_bytes_per_launch": per_launch, "limiter": limiter, **extra}
+            if ragged is not None:
+                rec["ragged"] = ragged
             if k127 is not None:
                 rec["k127"] = k127
             if k31 is not None:
