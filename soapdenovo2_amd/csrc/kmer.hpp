@@ -214,6 +214,41 @@ PG_HD uint32_t kmer_crc32_sliced(const Kmer<NW>& a, const Table4& t) {
     return crc ^ 0xffffffffu;
 }
 
+// The same CRC with NO dependent look-ups (round 6).  With init 0 the CRC is linear over GF(2) in the message bits, so it is the xor of
+// one table entry per NIBBLE of the key: nib[q][v] = the CRC of the message whose nibble q is v and whose other bits are 0 (q = 2 * byte
+// position + (high nibble ? 1 : 0); bytes in the order kmer_crc32 walks them: word 0 first, low byte first).  16 NW tables of 16 entries
+// = 1 KB a key word.  Against slicing by four: twice the look-ups, none of which waits for another (the sliced form is a chain of 2 NW
+// rounds, each an LDS round trip), and a table's 16 entries lie in 16 different LDS banks, so the 64 lanes of a wave never collide (256
+// entries of a sliced table do: conflict cycles were 0.77 of the LDS issue cycles of K2 at K = 127).  A nibble that is zero for every key
+// (the bits above 2 K) contributes nothing and is skipped: `K` = the k-mer length (0: unknown, all nibbles).
+PG_HD uint32_t crc32_nibble_entry(int n_bytes, int q, uint32_t v) {
+    const int p = q >> 1;
+    uint32_t c = crc32_table_entry((q & 1) ? v << 4 : v);
+    for (int z = p + 1; z < n_bytes; z++) c = (c >> 8) ^ crc32_table_entry(c & 0xff);
+    return c;
+}
+template <int NW, int K = 0, typename TableN>
+PG_HD uint32_t kmer_crc32_nibbles(const Kmer<NW>& a, const TableN& t) {
+    uint32_t crc = 0;
+#pragma unroll
+    for (int i = 0; i < NW; i++) {
+        // word i holds the key's bits [64 (NW - 1 - i), 64 (NW - i)): of a k-mer of K bases only the lowest 2 K bits of the key are ever set
+        const int live_bits = K ? (2 * K - 64 * (NW - 1 - i) > 64 ? 64 : 2 * K - 64 * (NW - 1 - i)) : 64;
+        const uint32_t lo = (uint32_t)a.w[i], hi = (uint32_t)(a.w[i] >> 32);
+#pragma unroll
+        for (int j = 0; j < 16; j++) {
+            if (4 * j >= live_bits) continue;
+            const uint32_t x = j < 8 ? lo : hi;
+            crc ^= t[(16 * i + j) * 16 + ((x >> (4 * (j & 7))) & 15u)];
+#if defined(__HIP_DEVICE_COMPILE__)
+            // (eight look-ups in flight at a time, not all 16 NW: hoisted together they took 64 registers and the counting kernel spilled to scratch)
+            if ((j & 7) == 7) asm volatile("" : "+v"(crc) :: "memory");
+#endif
+        }
+    }
+    return crc ^ 0xffffffffu;
+}
+
 // set picker: signext(crc) % P.  For a negative crc the 64-bit value is 2^64 - 2^32 + crc, so the result is
 // ((2^64 - 2^32) % P + crc % P) % P; `bias` = (2^64 - 2^32) % P is precomputed by the caller.
 PG_HD uint32_t set_of_crc(uint32_t crc, uint32_t P, uint32_t bias) {

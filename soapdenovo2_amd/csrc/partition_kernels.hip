@@ -469,7 +469,10 @@ constexpr int pow2_at_least(int x) { int p = 1; while (p < x) p <<= 1; return p;
 //  154.3 for this form, profiles/r04a_k2_vt0_opt1_ab.json; those forms are gone.)
 // KS: the kernel for ONE k-mer length (0 = any): the K-only shift amounts of occ_extract become immediates, its two wave-uniform switches -- a
 // dozen scalar branches an occurrence -- go away, and the record geometry is the usual one (128 records a chunk, records without padding).
-// TIMERS: thread 0's cycles per phase into ctr->phase (instantiated in -DPG_MEASURE builds only; 25 registers).
+// TIMERS: thread 0's cycles per phase into ctr->phase (instantiated in -DPG_MEASURE builds only).  The sums live in LDS, not in registers, and
+// there is a timed instantiation for each K the product has one for: until round 6 the timed kernel was the general one with 25 registers of
+// sums -- it spilled to scratch where the product does not (the reload of a window piece's address waited out the piece before it: "ask for
+// the next window" read 8 % of a kernel whose product form spends next to nothing there), so its shares were those of another kernel.
 template <int NW, int SLOTS, int THREADS, int WIN, bool TIMERS, int KS = 0>
 __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetParams sp, OccConst oc, DevCounters* ctr) {
     // What round 4 measured as switches is fixed here (each of them held wave-uniform state in scalar registers the kernel then spilled to vector
@@ -524,11 +527,13 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     unsigned long long my_records = 0;
     bool dirty = true;                                                   // the LDS set needs a full wipe before the next attempt
-    unsigned long long tp[TIMERS ? 12 : 1] = {0}, tlast = TIMERS ? clock64() : 0;      // phase timers: their own instantiation (-DPG_MEASURE), 25 registers
+    __shared__ unsigned long long tp[TIMERS ? 12 : 1];                    // phase timers: their own instantiations (-DPG_MEASURE); thread 0's alone
+    if (TIMERS && threadIdx.x == 0) for (int i = 0; i < 12; i++) tp[i] = 0;
+    unsigned long long tlast = TIMERS ? clock64() : 0;
     // Every barrier of this kernel orders LDS traffic only (lds_barrier): its global stores are never read back and its
     // global loads are waited for where their registers are used.
 #define K2_SYNC() lds_barrier()
-#define K2_TICK(i) do { if (TIMERS) { const unsigned long long tn_ = clock64(); tp[(i) * TIMERS] += tn_ - tlast; tlast = tn_; } } while (0)
+#define K2_TICK(i) do { if (TIMERS) { const unsigned long long tn_ = clock64(); if (threadIdx.x == 0) tp[(i) * TIMERS] += tn_ - tlast; tlast = tn_; } } while (0)
 
     // ---- prepare a window: stage -> dedupe -> flatten.  Written as barrier-free steps for a group of GS lanes (gtid = lane
     // index in the group, gwave = wave index in the group); the caller puts a barrier between the steps.
@@ -689,13 +694,11 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
 
     // ---- emit: finalize every stored node and append it to the export array.  The set is a quarter full on average, so
     // the live slots are first listed (e_list_any) and then worked on by dense waves: lane i
-    // takes the i-th live slot, finalises it into a staging area (the -d filter, the linear flag, the coverage histogram:
-    // prlHashReads.c:953-1132) and wipes the slot behind it, which is all the clearing the next attempt needs; the staged
-    // records go out as whole 16-byte pieces, coalesced.  One global atomic per attempt.  Barrier-free steps as above; `sb` =
-    // the window buffer whose storage the list and the staging area borrow.
-    constexpr unsigned int LIST_WORDS = SLOTS * 2 / 8;                    // the list's share of the buffer, in 64-bit words
-    constexpr unsigned int STAGE_CAP = (RL_WORDS * 4 - SLOTS * 2) / ((NW + 2) * 8) / 64 * 64;
-    static_assert(STAGE_CAP >= 64, "staging area");
+    // takes the i-th live slot, finalises it in registers (the -d filter, the linear flag, the coverage histogram:
+    // prlHashReads.c:953-1132) and wipes the slot behind it, which is all the clearing the next attempt needs; the record
+    // goes out from the registers (e_store).  One global atomic per attempt.  Barrier-free steps as above; `sb` =
+    // the window buffer whose storage the list borrows.
+    static_assert(RL_WORDS * 4 >= SLOTS * 2, "the list of the live slots fits a window buffer");
     // the list, in any order: a wave reserves room for its live slots of a stripe with one returned atomic on s_nlive (zeroed
     // in front of the barrier that ends the occurrence phase)
     auto e_list_any = [&](auto gs_, int gtid, int sb) {
@@ -711,17 +714,21 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
             if (live) live_list[base + (unsigned int)__popcll(bal & ((1ULL << lane) - 1))] = (unsigned short)(st * GS + gtid);
         }
     };
-    auto e_final = [&](auto gs_, int gtid, int sb, unsigned int c0, unsigned int cn, unsigned int n_live) {
+    // (Rounds 2 - 5 finalised into a staging area in LDS and copied it out as whole 16-byte pieces, coalesced.  The emit runs with every wave of
+    //  the workgroup in it at once and is bound by the LDS bytes a key moves -- slot read, slot wipe, CRC entries, staging write, staging read:
+    //  round 6 keeps the record in REGISTERS across the one barrier that publishes the export base and stores it from there, (NW + 2) / 2 pieces
+    //  a lane with a record's stride between lanes; the L2 puts the lines together.  A lane a live slot, THREADS slots a round: two rounds at most.)
+    struct Fin { uint64_t w[NW + 2]; };
+    auto e_final = [&](auto gs_, int gtid, int sb, unsigned int c0, unsigned int n_live, Fin& fin) -> bool {
         constexpr int GS = decltype(gs_)::value;
         const unsigned short* live_list = (const unsigned short*)rl2[sb];
-        uint64_t* stage = (uint64_t*)rl2[sb] + LIST_WORDS;
         // The export slots come from one global counter every workgroup of the grid adds to: its answer takes a while.  The
-        // group's first lane asks now and looks at the answer only after its share of the finalisation.
+        // group's last lane asks now and looks at the answer only after its share of the finalisation.
         // (Written as an instruction: the compiler's atomic optimizer turns an atomicAdd on a uniform address into "one lane adds, the
         //  others read its answer through readfirstlane" -- which waits for the answer on the spot (s_waitcnt vmcnt(0) right behind the
         //  atomic in round 3's code: workgroup thread 0 stood there for a round trip to the memory side while fifteen waves went on to
         //  the barrier and waited for it).  The wait is the s_waitcnt below, in front of the only use.)
-        // The asker is the group's LAST lane: its wave has no slot to finalise unless the set is nearly full, so nothing of its own
+        // The asker is the group's LAST lane: its wave has no slot to finalise unless the set is half full, so nothing of its own
         // (a wait the compiler puts in front of one of its memory operations would wait for the atomic too) stands between the question
         // and the answer; the other waves finalise meanwhile.
         unsigned long long ticket = 0;
@@ -730,8 +737,10 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
             const unsigned long long add = (unsigned long long)n_live;
             asm volatile("global_atomic_add_x2 %0, %1, %2, off sc0" : "=v"(ticket) : "v"(addr), "v"(add) : "memory");
         }
-        for (unsigned int i = gtid; i < cn; i += GS) {
-            const int si = live_list[c0 + i];
+        const unsigned int i = c0 + (unsigned int)gtid;
+        const bool have = i < n_live;
+        if (have) {
+            const int si = live_list[i];
             unsigned int cl[4], cr[4];
 #pragma unroll
             for (int c = 0; c < 2; c++) {
@@ -744,9 +753,10 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
 #pragma unroll
             for (int w = 0; w < KW; w++) kws[w] = set.key[w][si];
             const unsigned long long first = set.ord[si];
-            // wipe the slot
+            // wipe the slot: the four-word flavour's claim is one compare-and-swap on word 0, whose winner writes words 1 .. 3 before anybody
+            // reads them (lds_put) -- an empty word 0 is all its next attempt needs; the two-word flavour claims word by word
 #pragma unroll
-            for (int w = 0; w < KW; w++) set.key[w][si] = L_EMPTY;
+            for (int w = 0; w < (E2Cfg<NW>::RAW ? 1 : KW); w++) set.key[w][si] = L_EMPTY;
             set.ord[si] = L_EMPTY;
 #pragma unroll
             for (int q = 0; q < 5; q++) set.cnt[q][si] = 0;
@@ -773,31 +783,35 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
             if (D > 0 && nin == 0 && nout == 0) B |= B_DELETED;
             if (nin == 1 && nout == 1) B |= B_LINEAR;
             const uint32_t cov = A >> 24;
+            // (round 6 tried the CRC as the xor of one entry per NIBBLE -- kmer_crc32_nibbles: no look-up waits for another, 16-entry tables never
+            //  collide -- against this chain of 2 NW rounds: 163.4 ms against 124.7 at K = 127, 142.7 against 135.8 at K = 63,
+            //  profiles/r06_k2_crc_nibbles_ab.json.  The emit is bound by the LDS bytes a key moves and the instructions it issues, not by the chain.)
             const uint32_t sid = set_of_crc(kmer_crc32_sliced<NW>(key, crc_tab), sp.P, sp.bias);
             // coverage histogram: most nodes of a partition share one or two coverage values (1 for error k-mers), so count
             // those per wave instead of hammering one LDS word
             const unsigned long long ones = __ballot(cov == 1);
             if (lane == __ffsll((long long)ones) - 1) atomicAdd(&hist[1], (unsigned int)__popcll(ones));
             if (cov > 1) atomicAdd(&hist[cov], 1u);
-            uint64_t* o = stage + (size_t)i * (NW + 2);
 #pragma unroll
-            for (int w = 0; w < NW; w++) o[w] = key.w[w];
-            o[NW] = (uint64_t)A | ((uint64_t)B << 32);
-            o[NW + 1] = ((uint64_t)sid << PG_ORD_BITS) | (first & PG_ORD_MASK);
+            for (int w = 0; w < NW; w++) fin.w[w] = key.w[w];
+            fin.w[NW] = (uint64_t)A | ((uint64_t)B << 32);
+            fin.w[NW + 1] = ((uint64_t)sid << PG_ORD_BITS) | (first & PG_ORD_MASK);
         }
         if (gtid == GS - 1 && c0 == 0) {
             asm volatile("s_waitcnt vmcnt(0)" : "+v"(ticket) :: "memory");
             out_base = ticket;
         }
+        return have;
     };
-    auto e_copy = [&](auto gs_, int gtid, int sb, unsigned int c0, unsigned int cn) {
-        constexpr int GS = decltype(gs_)::value;
-        const unsigned long long ob = out_base + c0;
-        if (ob + cn <= e.out_capacity) {
-            ulonglong2* dst = (ulonglong2*)(e.out + ob * (NW + 2));               // (NW + 2) * 8 is a multiple of 16
-            const ulonglong2* src = (const ulonglong2*)((const uint64_t*)rl2[sb] + LIST_WORDS);
-            for (unsigned int q = gtid; q < cn * ((NW + 2) / 2); q += GS) dst[q] = src[q];
-        } else if (gtid == 0) atomicOr(&ctr->e2_flags, F_OUT);
+    auto e_store = [&](int gtid, unsigned int c0, unsigned int n_live, bool have, const Fin& fin) {
+        const unsigned long long ob = out_base;
+        if (ob + n_live <= e.out_capacity) {
+            if (have) {
+                ulonglong2* dst = (ulonglong2*)(e.out + (ob + c0 + (unsigned int)gtid) * (NW + 2));      // (NW + 2) * 8 is a multiple of 16
+#pragma unroll
+                for (int q = 0; q < (NW + 2) / 2; q++) dst[q] = make_ulonglong2(fin.w[2 * q], fin.w[2 * q + 1]);
+            }
+        } else if (gtid == 0 && c0 == 0) atomicOr(&ctr->e2_flags, F_OUT);
     };
     const std::integral_constant<int, THREADS> whole{};
 
@@ -974,7 +988,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 K2_TICK(5);
             }
             if (aborted) {                                                // (read behind the window loop's last barrier: the same for every lane)
-                if (TIMERS) tp[9 * TIMERS]++;
+                if (TIMERS && threadIdx.x == 0) tp[9 * TIMERS]++;
                 dirty = true;
                 // too many distinct keys for the LDS set: split this key range on the next hash bit and redo both halves
                 const uint32_t bit = mask + 1;                            // masks are 2^k - 1
@@ -1002,20 +1016,22 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                 Ahead ah;
                 bool put = !ahead;
                 if (ahead) { p_ask(cl ^ 1, wn_next, ah); staged = true; }
+                K2_TICK(7);
                 {
                     e_list_any(whole, threadIdx.x, sb);
                     K2_SYNC();
                     K2_TICK(6);
                     const unsigned int n_live = s_nlive;
-                    for (unsigned int c0 = 0; c0 < n_live; c0 += STAGE_CAP) {
-                        const unsigned int cn = min(STAGE_CAP, n_live - c0);
-                        e_final(whole, threadIdx.x, sb, c0, cn, n_live);
+                    for (unsigned int c0 = 0; c0 < n_live; c0 += THREADS) {
+                        Fin fin;
+                        const bool have = e_final(whole, threadIdx.x, sb, c0, n_live, fin);
                         K2_TICK(11);
-                        K2_SYNC();
-                        if (!put) { p_put(b ^ 1, wn_next, ah); put = true; }
-                        e_copy(whole, threadIdx.x, sb, c0, cn);
-                        if (c0 + STAGE_CAP < n_live) K2_SYNC();           // the staging area is filled again (after the last chunk the
-                    }                                                     // buffer's next writer is several barriers away)
+                        if (c0 == 0) {
+                            K2_SYNC();                                        // the export base is there for everybody
+                            if (!put) { p_put(b ^ 1, wn_next, ah); put = true; }
+                        }
+                        e_store(threadIdx.x, c0, n_live, have, fin);
+                    }
                     if (!put) p_put(b ^ 1, wn_next, ah);                    // (an emit without a node)
                     K2_TICK(8);
                 }
@@ -1529,14 +1545,17 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
         const dim3 g(grid), b(1024);
         if (c->NW == 2) {
 #ifdef PG_MEASURE
-            if (timers) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, true>), g, b, 0, st, dev_view(c), delow, sp, oc, c->ctr); else
+            if (timers && usual && c->K == 63) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, true, 63>), g, b, 0, st, dev_view(c), delow, sp, oc, c->ctr);
+            else if (timers && usual && c->K == 31) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, true, 31>), g, b, 0, st, dev_view(c), delow, sp, oc, c->ctr);
+            else if (timers) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, true>), g, b, 0, st, dev_view(c), delow, sp, oc, c->ctr); else
 #endif
             if (usual && c->K == 63) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 63>), g, b, 0, st, dev_view(c), delow, sp, oc, c->ctr);
             else if (usual && c->K == 31) hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false, 31>), g, b, 0, st, dev_view(c), delow, sp, oc, c->ctr);
             else hipLaunchKernelGGL((skm_count_kernel<2, 2048, 1024, 512, false>), g, b, 0, st, dev_view(c), delow, sp, oc, c->ctr);
         } else {
 #ifdef PG_MEASURE
-            if (timers) hipLaunchKernelGGL((skm_count_kernel<4, 2048, 1024, 192, true>), g, b, 0, st, dev_view(c), delow, sp, oc, c->ctr); else
+            if (timers && usual && c->K == 127) hipLaunchKernelGGL((skm_count_kernel<4, 2048, 1024, 192, true, 127>), g, b, 0, st, dev_view(c), delow, sp, oc, c->ctr);
+            else if (timers) hipLaunchKernelGGL((skm_count_kernel<4, 2048, 1024, 192, true>), g, b, 0, st, dev_view(c), delow, sp, oc, c->ctr); else
 #endif
             if (usual && c->K == 127) hipLaunchKernelGGL((skm_count_kernel<4, 2048, 1024, 192, false, 127>), g, b, 0, st, dev_view(c), delow, sp, oc, c->ctr);
             else hipLaunchKernelGGL((skm_count_kernel<4, 2048, 1024, 192, false>), g, b, 0, st, dev_view(c), delow, sp, oc, c->ctr);
@@ -1570,8 +1589,8 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     if (h.e2_flags & F_SPLIT) { pg_set_error("partition engine: a partition could not be split to fit the LDS set"); return PG_ENOMEM; }
     if (timers) {
         static const char* names[12] = {"partition header", "clear after a dropped attempt", "window: unpack / stage + barrier", "barrier + flatten (prefix sum, tables) + barriers", "occurrences (thread 0's share)",
-                                        "wait for the slowest wave + barrier", "emit: ask for the next window, list the live slots", "-", "emit: barrier + coalesced copy out", "dropped attempts (count)",
-                                        "dedupe (hash, probe, compare)", "emit: finalise into the staging area"};
+                                        "wait for the slowest wave + barrier", "emit: list the live slots + barrier", "emit: ask for the next window", "emit: barrier + export stores from registers", "dropped attempts (count)",
+                                        "dedupe (hash, probe, compare)", "emit: finalise in registers"};
         unsigned long long tot = 0;
         for (int i = 0; i < 12; i++) if (i != 9) tot += h.phase[i];
         for (int i = 0; i < 12; i++) fprintf(stderr, "K2 phase %-40s %14llu  %5.1f%%\n", names[i], h.phase[i], i != 9 ? 100.0 * h.phase[i] / (double)(tot ? tot : 1) : 0.0);

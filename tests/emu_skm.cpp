@@ -233,5 +233,30 @@ extern "C" int emu_crc_check(int n) {
         if (kmer_crc32<2>(a, t1) != kmer_crc32_sliced<2>(a, t4)) return 1;
         if (kmer_crc32<4>(b, t1) != kmer_crc32_sliced<4>(b, t4)) return 2;
     }
+    // the nibble tables (no dependent look-ups), for every key and, with the k-mer length known, for keys of that length
+    static uint32_t n2[32 * 16], n4[64 * 16];
+    for (int q = 0; q < 32; q++) for (int v = 0; v < 16; v++) n2[q * 16 + v] = crc32_nibble_entry(16, q, (uint32_t)v);
+    for (int q = 0; q < 64; q++) for (int v = 0; v < 16; v++) n4[q * 16 + v] = crc32_nibble_entry(32, q, (uint32_t)v);
+    auto rnd = [&] { x = x * 6364136223846793005ULL + 1442695040888963407ULL; return x ^ (x >> 29); };
+    for (int i = 0; i < n; i++) {
+        Kmer<2> a; Kmer<4> b;
+        for (int q = 0; q < 2; q++) a.w[q] = rnd();
+        for (int q = 0; q < 4; q++) b.w[q] = rnd();
+        if (kmer_crc32<2>(a, t1) != kmer_crc32_nibbles<2>(a, n2)) return 3;
+        if (kmer_crc32<4>(b, t1) != kmer_crc32_nibbles<4>(b, n4)) return 4;
+        Kmer<2> a31 = a, a63 = a, a25 = a; Kmer<4> b127 = b, b65 = b, b95 = b;
+        a31.w[0] = 0; a31.w[1] &= (1ULL << 62) - 1;
+        a25.w[0] = 0; a25.w[1] &= (1ULL << 50) - 1;
+        a63.w[0] &= (1ULL << 62) - 1;
+        b127.w[0] &= (1ULL << 62) - 1;
+        b65.w[0] = b65.w[1] = 0; b65.w[2] &= 3;
+        b95.w[0] = 0; b95.w[1] &= (1ULL << 62) - 1;
+        if (kmer_crc32<2>(a31, t1) != kmer_crc32_nibbles<2, 31>(a31, n2)) return 5;
+        if (kmer_crc32<2>(a25, t1) != kmer_crc32_nibbles<2, 25>(a25, n2)) return 6;
+        if (kmer_crc32<2>(a63, t1) != kmer_crc32_nibbles<2, 63>(a63, n2)) return 7;
+        if (kmer_crc32<4>(b127, t1) != kmer_crc32_nibbles<4, 127>(b127, n4)) return 8;
+        if (kmer_crc32<4>(b65, t1) != kmer_crc32_nibbles<4, 65>(b65, n4)) return 9;
+        if (kmer_crc32<4>(b95, t1) != kmer_crc32_nibbles<4, 95>(b95, n4)) return 10;
+    }
     return 0;
 }
