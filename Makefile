@@ -17,7 +17,7 @@ else
 O       := o
 LIBNAME := libsoapdenovo2_amd.so
 endif
-HOSTOBJ := $(CSRC)/host_graph.$(O) $(CSRC)/host_reads.$(O) $(CSRC)/call_pregraph.$(O) $(CSRC)/host_skm.$(O) $(CSRC)/host_emu.$(O) $(CSRC)/arena.$(O)
+HOSTOBJ := $(CSRC)/host_graph.$(O) $(CSRC)/host_reads.$(O) $(CSRC)/call_pregraph.$(O) $(CSRC)/host_skm.$(O) $(CSRC)/host_emu.$(O) $(CSRC)/host_plan.$(O) $(CSRC)/arena.$(O)
 DEVOBJ  := $(CSRC)/pregraph_kernels.$(O) $(CSRC)/partition_kernels.$(O) $(CSRC)/graph_kernels.$(O) $(CSRC)/sort_records.$(O) $(CSRC)/exchange.$(O)
 HDRS    := $(wildcard $(CSRC)/*.hpp) include/soapdenovo2_amd.h
 

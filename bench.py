@@ -528,7 +528,8 @@ def main():
         # the input size is known up front, as call_pregraph knows it from the file sizes: the partition count and the record
         # pool follow it.  N > 1: it follows the whole job -- a partition holds what ALL ranks send to it (every rank must cut
         # with the same geometry); the export array (log2_slots) follows this rank's share
-        api._check(api.lib().pg_expect_kmers(kc.h, n_kmers * world), "pg_expect_kmers")
+        # (N > 1, round 6: a rank STORES only the partitions it owns -- pg_expect's n_owners -- so cursors, chunk table and pool follow 1 / N of the job)
+        api._check(api.lib().pg_expect(kc.h, n_kmers * world, n_reads * world, 0, world), "pg_expect")
     kc.set_autogrow(False)
     wpr = (L + 31) // 32
     batches = [(lo, min(args.batch_reads, n_reads - lo)) for lo in range(0, n_reads, args.batch_reads)]

@@ -300,8 +300,23 @@ int pg_table_info(pg_ctx *ctx, uint64_t *slots, uint32_t *slot_bytes);
  * sizes its partition count from it -- about 8 k occurrences a partition, so that one partition is counted in one LDS
  * pass -- instead of from log2_slots, which sizes the export array for the DISTINCT k-mers.  Before the first batch. */
 int pg_expect_kmers(pg_ctx *ctx, uint64_t total_kmers);
+/* The same with the other things a caller may know (round 6; pg_expect_kmers(ctx, t) = pg_expect(ctx, t, 0, 0, 1)):
+ *   total_reads    the job's reads (0: unknown): every read makes at least one super-k-mer record, which is most of the records
+ *                  where a read has few k-mers (K = 127 from 150-base reads); sizes the record pool;
+ *   distinct_here  distinct k-mers this context's export array should hold (0: what log2_slots says, 0.7 x 2^log2_slots); too
+ *                  few is not an error: pg_finalize then counts the partitions again into an array of the true size;
+ *   n_owners       ranks that share the job's partition ids (pg_count_reads_sharded over a communicator of that size): the
+ *                  context then stores only the partitions it owns -- id mod n_owners == its rank, at id / n_owners -- and its
+ *                  cursors, chunk table and record pool are sized for 1 / n_owners of the job.  What the reference does with
+ *                  shared memory (prlHashReads.c:79-90: worker t keeps hash % thrd_num == t) as per-rank storage.  Such a
+ *                  context takes its batches through pg_count_reads_sharded only.
+ * total_kmers is the WHOLE job's count (all ranks).  Before the first batch. */
+int pg_expect(pg_ctx *ctx, uint64_t total_kmers, uint64_t total_reads, uint64_t distinct_here, int n_owners);
 /* pg_create_engine with that estimate known up front (no second allocation); expected_kmers = 0: unknown. */
 pg_ctx *pg_create_sized(int device, int K, int mer127, int n_sets, int log2_slots, int engine, uint64_t expected_kmers);
+/* ... and with pg_expect's other figures (expected_reads = 0, distinct_here = 0, n_owners = 1: pg_create_sized). */
+pg_ctx *pg_create_planned(int device, int K, int mer127, int n_sets, int log2_slots, int engine, uint64_t expected_kmers,
+                          uint64_t expected_reads, uint64_t distinct_here, int n_owners);
 
 /* Counters for reporting (synchronise first): out[0] engine, out[1] distinct k-mers, out[2] super-k-mer records,
  * out[3] bytes per record (engine 2) / per slot (engine 1), out[4] pool chunks handed out, out[5] pool chunks,
@@ -325,6 +340,22 @@ int pg_set_counts(pg_ctx *ctx, uint64_t out[256], void *stream);
 int pg_last_put(pg_ctx *ctx, uint64_t *set_last_put_out, void *stream);
 /* 1 when, for some set, a duplicate put arriving after its last new key would grow the reference's table (newhash.c:477). */
 int pg_host_last_put_matters(const uint64_t *set_counts, int n_sets, int a_gb, int mer127);
+
+/* The device memory one rank of a `pregraph` command takes, stage by stage, computed on the host from the sizing functions the
+ * command and the partition engine allocate by (csrc/cmd_plan.hpp, e2_plan.hpp, ref_sizes.hpp) -- no GPU is touched.  Replaces no
+ * reference function: the reference sizes its host tables from -a (prlHashReads.c:369-390) and grows them otherwise; this is the
+ * check that a configuration fits a 288 GB GPU before a terabyte of reads has been parsed.
+ *   reads_total, read_len   the whole job's reads;  fastq_bytes  the input files' size (0: reads x (2 read_len + 16))
+ *   distinct_total          distinct k-mers of the job (an estimate: genome + about 35 error k-mers an erroneous base at K = 63)
+ *   n_sets, a_gb            the reference's -p and -a;  n_ranks  GPUs (one rank each);  device_bytes  a GPU's memory
+ * out[24] (bytes unless said): 0 peak, 1 its stage (1 pass 1 + count, 2 hand-over, 3 layout, 4 graph + pass 2), 2 cursors + chunk
+ * table, 3 record pool, 4 export array as allocated, 5 ... after the count, 6 reads kept on the device, 7 batch buffers + exchange
+ * regions, 8 k-mer sets, 9 layout arrays, 10 the sort's copy outside the pool, 11 log2 partition ids of the job, 12 log2
+ * partitions a rank stores, 13 chunks a partition at computed addresses, 14 records the pool holds, 15 fits (peak <= 0.97 x
+ * device_bytes), 16 - 19 the four stages, 20 k-mer occurrences estimated, 21 export records allocated for, 22 slots a set,
+ * 23 log2_slots (+ 2^32 when the export array is made for fewer k-mers than distinct_total says: one more counting pass).  PG_OK, PG_EINVAL, or PG_ENOMEM when the partition engine's own checks refuse the size. */
+int pg_host_plan_memory(uint64_t reads_total, uint32_t read_len, uint64_t fastq_bytes, uint64_t distinct_total, int K, int mer127,
+                        int n_sets, int a_gb, int n_ranks, uint64_t device_bytes, uint64_t out[24]);
 
 /* Partition engine: the export array itself instead of a copy of it (the caller owns *d_records_out and frees it with
  * pg_device_free -- the block comes out of the library's device arena, csrc/arena.hpp, not out of hipMalloc); everything else the context holds on the device is released, the context can only be destroyed afterwards. */

@@ -3,6 +3,7 @@
 #   gpurun --timeout 1500 -- 'bash scripts/gpu_run.sh <tag> <step> [<step> ...]'
 # Everything lands under gpurun_out/<tag>/.  Steps:
 #   tests[:<pytest -k expression>]   the -m gpu suite (or a subset)
+#   poison[:<pytest -k expression>]  the -m gpu suite (or a subset) with PG_ARENA_POISON=1: every arena block filled with 0xA5 as it is cut
 #   smoke                            __graft_entry__.smoke()
 #   bench[:<extra bench.py args>]    one bench.py line -> bench<i>.json (default arguments = the driver's run)
 #   stats[:<bench args>]             rocprofv3 --kernel-trace --stats of a kernels-only bench run -> kernel_stats<i>.csv
@@ -29,6 +30,9 @@ for step in "$@"; do
     tests)
         if [ -n "$arg" ]; then timeout 1200 python -m pytest tests -m gpu -x -q -k "$arg" > "$O/tests$i.log" 2>&1; else timeout 1200 python -m pytest tests -m gpu -x -q > "$O/tests$i.log" 2>&1; fi
         echo "[$i] tests rc=$? $(tail -1 "$O/tests$i.log" | cut -c1-160)";;
+    poison)
+        if [ -n "$arg" ]; then PG_ARENA_POISON=1 timeout 1400 python -m pytest tests -m gpu -x -q -k "$arg" > "$O/poison$i.log" 2>&1; else PG_ARENA_POISON=1 timeout 1400 python -m pytest tests -m gpu -x -q > "$O/poison$i.log" 2>&1; fi
+        echo "[$i] poison rc=$? $(grep -E "passed|failed" "$O/poison$i.log" | tail -1 | cut -c1-160)";;
     smoke)
         timeout 300 python -c "import __graft_entry__ as g; g.smoke()" > "$O/smoke$i.log" 2>&1; echo "[$i] smoke rc=$? $(tail -1 "$O/smoke$i.log")";;
     bench)

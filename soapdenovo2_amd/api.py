@@ -80,6 +80,8 @@ def lib() -> C.CDLL:
     L.pg_graph_use_device.argtypes = [C.c_void_p, C.c_int]
     L.pg_expect_kmers.argtypes = [C.c_void_p, C.c_uint64]
     L.pg_set_read_len_bound.argtypes = [C.c_void_p, C.c_uint32]
+    L.pg_expect.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_int]
+    L.pg_host_plan_memory.argtypes = [C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, u64p]
     L.pg_sort_records.argtypes = [C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
     L.pg_host_graph_add_packed.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_int]
     L.pg_host_read_all.argtypes = [C.c_char_p, C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64,
@@ -89,6 +91,8 @@ def lib() -> C.CDLL:
     L.pg_create.argtypes = [C.c_int] * 5
     L.pg_create_engine.restype = C.c_void_p
     L.pg_create_engine.argtypes = [C.c_int] * 6
+    L.pg_create_planned.restype = C.c_void_p
+    L.pg_create_planned.argtypes = [C.c_int] * 6 + [C.c_uint64, C.c_uint64, C.c_uint64, C.c_int]
     L.pg_create_sized.restype = C.c_void_p
     L.pg_create_sized.argtypes = [C.c_int] * 6 + [C.c_uint64]
     L.pg_destroy.argtypes = [C.c_void_p]
@@ -163,8 +167,25 @@ EXPORTED_SYMBOLS = [
     "pg_comm_transport", "pg_comm_stats", "pg_exchange_counts", "pg_exchange_records", "pg_exchange_allreduce_u64",
     "pg_exchange_gather_records", "pg_count_reads_sharded", "pg_host_skm_cut", "pg_host_skm_expand",
     "pg_host_emu_layout_static", "pg_graph_begin_device", "pg_host_emu_clip_tips", "pg_exchange_regroup_by_set", "pg_comm_regroup_stats", "pg_graph_begin_sharded", "pg_host_regroup_plan", "pg_host_bam_pair_state", "pg_device_scratch_offer", "pg_device_scratch_withdraw", "pg_host_emu_layout_growable", "pg_exchange_regroup_by_set_ws", "pg_host_edge_file_in_background", "pg_graph_add_packed_device", "pg_host_emu_home_slots", "pg_comm_pipeline_stats", "pg_comm_create_host", "pg_comm_flush",
-    "pg_set_read_len_bound", "pg_graph_add_packed_device_ragged",
+    "pg_set_read_len_bound", "pg_graph_add_packed_device_ragged", "pg_expect", "pg_host_plan_memory", "pg_create_planned",
 ]
+
+
+PLAN_FIELDS = ["peak", "peak_stage", "tables", "record_pool", "export_allocated", "export_after_count", "reads_kept", "batch_and_exchange", "kmer_sets",
+               "layout_arrays", "sort_work_space_outside_pool", "log2_partition_ids", "log2_partitions_stored", "direct_chunks", "pool_records", "fits",
+               "stage1_pass1_count", "stage2_hand_over", "stage3_layout", "stage4_graph_pass2", "est_kmers", "export_records", "set_slots", "log2_slots"]
+
+
+def plan_memory(reads_total: int, read_len: int, distinct_total: int, K: int, n_sets: int = 8, a_gb: int = 0, n_ranks: int = 1,
+                device_bytes: int = 288 * 10**9, fastq_bytes: int = 0) -> dict:
+    """pg_host_plan_memory: the device memory one rank of the command takes, stage by stage (no GPU)."""
+    out = np.zeros(24, dtype=np.uint64)
+    _check(lib().pg_host_plan_memory(reads_total, read_len, fastq_bytes, distinct_total, K, 1 if K > 63 else 0, n_sets, a_gb, n_ranks, device_bytes,
+                                     out.ctypes.data_as(C.POINTER(C.c_uint64))), "pg_host_plan_memory")
+    d = {k: int(v) for k, v in zip(PLAN_FIELDS, out)}
+    d["counts_twice"] = bool(d["log2_slots"] >> 32)
+    d["log2_slots"] &= 0xFFFFFFFF
+    return d
 
 
 def _check(rc: int, what: str) -> None:

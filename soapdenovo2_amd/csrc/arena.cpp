@@ -61,8 +61,11 @@ struct Arena {
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || total_b == 0) return;
         chunk = round_up((size_t)512 << 20, gran);                        // physical memory comes in pieces of this size
-        reserved = round_up(total_b, chunk);
-        if (!reserve_range()) return;
+        // Twice the device's memory in ADDRESSES: blocks are cut first-fit and a freed hole keeps its physical pieces, so a pattern with a small live
+        // block between large ones (a pool that grows, the export array's re-allocation) can need fresh addresses while physical memory is still there --
+        // with a range of exactly the device's size it ran out of addresses first and failed where hipMalloc would not.
+        reserved = round_up(2 * total_b, chunk);
+        if (!reserve_range()) { reserved = round_up(total_b, chunk); if (!reserve_range()) return; }
         // who may touch the memory: this GPU, and every GPU of the process that can reach it (a sharded run probes the k-mer sets of
         // the other ranks through peer mappings)
         int n_dev = 0;
@@ -98,11 +101,13 @@ struct Arena {
     // physical memory under [off, off + bytes); called without list_mu.  Pieces are created where they are needed, in any order; a piece somebody
     // else is creating is waited for, nothing else is.
     hipError_t ensure_piece(size_t pi) {
+        std::vector<hipMemAccessDesc> access_now;                          // (a copy taken under the lock: another thread's fallback below rewrites `access`)
         {
             std::unique_lock<std::mutex> g(map_mu);
             while (pieces[pi].state == 1) map_cv.wait(g);
             if (pieces[pi].state == 2) return hipSuccess;
             pieces[pi].state = 1;
+            access_now = access;
         }
         const auto t0 = std::chrono::steady_clock::now();
         hipMemGenericAllocationHandle_t h;
@@ -111,13 +116,13 @@ struct Arena {
         if (rc == hipSuccess) {
             rc = hipMemMap(at, chunk, 0, h, 0);
             if (rc == hipSuccess) {
-                rc = hipMemSetAccess(at, chunk, access.data(), access.size());
-                if (rc != hipSuccess && access.size() > 1) {
+                rc = hipMemSetAccess(at, chunk, access_now.data(), access_now.size());
+                if (rc != hipSuccess && access_now.size() > 1) {
                     // (the peers could not all be granted -- a process that sees GPUs it never opened, one rank a process: this GPU alone then, for this
                     //  and every later piece; a sharded run INSIDE one process would have failed at its peer mappings anyway)
                     (void)hipGetLastError();
-                    hipMemAccessDesc self = access[0];
-                    for (const hipMemAccessDesc& a : access) if (a.location.id == device) self = a;
+                    hipMemAccessDesc self = access_now[0];
+                    for (const hipMemAccessDesc& a : access_now) if (a.location.id == device) self = a;
                     rc = hipMemSetAccess(at, chunk, &self, 1);
                     if (rc == hipSuccess) {
                         std::lock_guard<std::mutex> g(map_mu);
@@ -159,7 +164,10 @@ struct Arena {
             if (pieces[pi].state == 2) { (void)hipMemUnmap(base + pi * chunk, chunk); (void)hipMemRelease(pieces[pi].h); pieces[pi].state = 0; at += chunk; }
         mapped_bytes.store(0, std::memory_order_release);
         retired.emplace_back(base, reserved);                              // (see reserve_range: this range is never mapped again)
-        if (!reserve_range()) { active = false; base = nullptr; }          // (no address space left: plain hipMalloc from here on)
+        if (!reserve_range()) {                                            // (no address space left: plain hipMalloc from here on -- said aloud, it changes every timing)
+            active = false; base = nullptr;
+            fprintf(stderr, "soapdenovo2_amd: arena (device %d): no address range for the arena's next life (%zu retired); device memory comes from hipMalloc from here on\n", device, retired.size());
+        }
         if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
         if (env_user("PG_HOST_VERBOSE"))
             fprintf(stderr, "arena (device %d): %.2f GB of physical memory in %llu piece(s), created in %.2fs in all; peak in use %.2f GB; %llu block(s) cut, %llu given back; given back to the driver in %.2fs\n", device,
@@ -167,11 +175,20 @@ struct Arena {
                     std::chrono::duration<double>(std::chrono::steady_clock::now() - t_trim).count());
     }
 
+    // PG_ARENA_TRACE=1: every block of 64 MB and more as it is cut and given back, with what is in use behind it (stderr) -- what the executable's
+    // memory plan (pg_host_plan_memory) was written from and is checked against
+    void trace(const char* what, size_t bytes, uint64_t in_use_after) const {
+        static const bool on = env_user("PG_ARENA_TRACE") != nullptr && atoi(env_user("PG_ARENA_TRACE")) != 0;
+        static const auto t0 = std::chrono::steady_clock::now();
+        if (on && bytes >= ((size_t)64 << 20))
+            fprintf(stderr, "[arena %d] %8.3fs %s %9.3f GB -> in use %9.3f GB\n", device, std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count(), what, (double)bytes / 1e9, (double)in_use_after / 1e9);
+    }
     hipError_t malloc_(void** out, size_t bytes) {
         size_t off = 0, need = 0;
         {
             std::lock_guard<std::mutex> g(list_mu);
             if (!blocks.cut(bytes, &off, &need)) return hipErrorOutOfMemory;
+            trace("cut ", need, blocks.in_use);
         }
         const hipError_t rc = ensure_mapped(off, need);
         if (rc != hipSuccess) {
@@ -193,7 +210,12 @@ struct Arena {
         const hipError_t rc = hipDeviceSynchronize();
         if (cur >= 0 && cur != device) (void)hipSetDevice(cur);
         std::lock_guard<std::mutex> g(list_mu);
-        if (!blocks.give_back((size_t)((char*)p - base))) return hipErrorInvalidValue;
+        {
+            auto it = blocks.used.find((size_t)((char*)p - base));
+            const size_t bytes = it == blocks.used.end() ? 0 : it->second;
+            if (!blocks.give_back((size_t)((char*)p - base))) return hipErrorInvalidValue;
+            trace("back", bytes, blocks.in_use);
+        }
         if (blocks.empty() && pins == 0) trim();
         return rc;
     }
@@ -239,6 +261,23 @@ hipError_t arena_free(void* p) {
     return hipFree(p);
 }
 
+void arena_shrink(void* p, size_t bytes) {
+    if (!p) return;
+    std::unique_lock<std::mutex> g(g_init_mu);
+    for (int d = 0; d < MAX_DEVICES; d++) {
+        Arena* a = g_arena[d];
+        if (a && a->owns(p)) {
+            g.unlock();
+            std::lock_guard<std::mutex> gl(a->list_mu);
+            const size_t off = (size_t)((char*)p - a->base);
+            auto it = a->blocks.used.find(off);
+            const size_t had = it == a->blocks.used.end() ? 0 : it->second;
+            if (a->blocks.shrink(off, bytes)) a->trace("trim", had - a->blocks.used[off], a->blocks.in_use);
+            return;
+        }
+    }
+}
+
 hipError_t arena_mem_info(size_t* free_bytes, size_t* total_bytes) {
     const hipError_t rc = hipMemGetInfo(free_bytes, total_bytes);
     if (rc != hipSuccess) return rc;
@@ -258,6 +297,16 @@ void arena_pin(int device) {
     if (!a || !a->active) return;
     std::lock_guard<std::mutex> g(a->list_mu);
     a->pins++;
+}
+
+// The API path (pg_create without a pin of the caller's): the device's arena is pinned for the life of the process, once -- a library or Python
+// caller that creates and destroys contexts would otherwise pay an unmap, a fresh reservation and a re-creation of the pieces per cycle and retire
+// 2 x 288 GB of address space each time.  pg_device_arena_unpin gives the pin up.
+void arena_pin_for_process(int device) {
+    Arena* a = arena_of(device);
+    if (!a || !a->active) return;
+    std::lock_guard<std::mutex> g(a->list_mu);
+    if (a->pins == 0) a->pins = 1;
 }
 
 void arena_unpin(int device) {

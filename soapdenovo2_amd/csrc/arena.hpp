@@ -27,6 +27,9 @@ namespace pg {
 hipError_t arena_malloc(void** p, size_t bytes);
 template <typename T> inline hipError_t arena_malloc(T** p, size_t bytes) { return arena_malloc((void**)p, bytes); }
 hipError_t arena_free(void* p);
+// the block keeps its first `bytes` bytes, the rest goes back to the arena's free list at once (nothing is copied; a block that did not come from
+// the arena stays as it is).  The caller knows that nothing in flight touches the part given up.
+void arena_shrink(void* p, size_t bytes);
 
 // the arena of `device` keeps its physical memory while it is pinned, even when nothing is allocated from it
 void arena_pin(int device);
@@ -43,6 +46,7 @@ struct ArenaStats {
 };
 ArenaStats arena_stats(int device);
 
+void arena_pin_for_process(int device);   // pins the device's arena unless somebody holds a pin already (pg_create: the API path)
 struct ArenaPin {                        // RAII for call_pregraph
     int device;
     explicit ArenaPin(int d) : device(d) { arena_pin(d); }

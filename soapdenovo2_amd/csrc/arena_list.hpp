@@ -56,6 +56,20 @@ struct BlockList {
         free_[off] = bytes;
         return true;
     }
+    // the block at `off` keeps its first `bytes` bytes (rounded up), the rest becomes a hole; false: no such block, or it is not larger
+    bool shrink(size_t off, size_t bytes) {
+        auto it = used.find(off);
+        if (it == used.end()) return false;
+        const size_t keep = round_up(bytes ? bytes : 1, 4096), had = it->second;
+        if (keep >= had) return false;
+        it->second = keep;
+        in_use -= had - keep;
+        size_t hole_off = off + keep, hole = had - keep;
+        auto nx = free_.lower_bound(hole_off);
+        if (nx != free_.end() && hole_off + hole == nx->first) { hole += nx->second; free_.erase(nx); }
+        free_[hole_off] = hole;
+        return true;
+    }
     bool empty() const { return used.empty(); }
 };
 

@@ -27,6 +27,7 @@
 
 #include "host_graph.hpp"
 #include "arena.hpp"
+#include "cmd_plan.hpp"
 #include "env.hpp"
 #include "host_reads.hpp"
 #include "../../include/soapdenovo2_amd.h"
@@ -672,7 +673,7 @@ int run(int argc, char** argv, bool mer127) {
             if (std::find(seen.begin(), seen.end(), d) == seen.end()) { seen.push_back(d); arena_pins.emplace_back(new pg::ArenaPin(d)); }
     }
     // how much is coming: bases ~ half the bytes of a FASTQ file, all of a FASTA file (x4 behind gzip)
-    uint64_t est_kmers = 0;
+    uint64_t est_kmers = 0, est_reads = 0;
     for (const pg::InputFile& f : files)
         for (const std::string* path : {&f.path1, &f.path2}) {
             struct stat st;
@@ -683,6 +684,7 @@ int run(int argc, char** argv, bool mer127) {
             // a read of l <= max_rd_len bases has l - K + 1 k-mers: at most (max_rd_len - K + 1) / max_rd_len of its bases
             // (what is sized from this -- the record pool, the partition count, the export array -- is handed out cleared by
             //  the driver, by the gigabyte: an estimate twice too large cost the start of the command up to two seconds)
+            if (max_read_len > 0) est_reads += (uint64_t)(bases / (double)max_read_len);       // (reads of max_rd_len bases: shorter reads make more of them, and fewer k-mers each)
             if (max_read_len > K) bases *= (double)(max_read_len - K + 1) / (double)max_read_len;
             est_kmers += (uint64_t)bases;
         }
@@ -691,17 +693,16 @@ int run(int argc, char** argv, bool mer127) {
     // the rest.  -a only presizes the reference's HOST k-mer sets (prlHashReads.c:369-390) and is used for exactly that
     // in the layout replay; it does not size anything on the device.
     int log2_slots = 24;
+    uint64_t export_records = 0;                                   // distinct k-mers a rank's export array is made for (cmd_plan.hpp)
     {
         size_t free_b = 0, total_b = 0;
         HIP_OK(hipSetDevice(device));
         HIP_OK(pg::arena_mem_info(&free_b, &total_b));
-        const double rec_bytes = (mer127 ? 6 : 4) * 8.0;
-        while (log2_slots < 34 && (double)((uint64_t)1 << log2_slots) * 0.7 < (double)est_kmers / 6.0 &&
-               (double)((uint64_t)2 << log2_slots) * 0.7 * rec_bytes <= (double)total_b / 3.0)
-            log2_slots++;
+        log2_slots = pg::cmd_log2_slots(est_kmers, mer127, total_b);
+        export_records = pg::cmd_export_records(est_kmers, mer127, n_ranks, total_b);
     }
     // a pass-1 batch: 64 MiB of packed reads / 2 M reads (SOAPDENOVO2_AMD_BATCH_READS: smaller batches, for tests)
-    size_t batch_words = (size_t)1 << 23, batch_reads = (size_t)1 << 21;
+    size_t batch_words = (size_t)pg::CMD_BATCH_WORDS, batch_reads = (size_t)pg::CMD_BATCH_READS;
     if (const char* e = pg::env_user("SOAPDENOVO2_AMD_BATCH_READS")) { const long v = atol(e); if (v > 0) { batch_reads = (size_t)v; batch_words = std::min(batch_words, batch_reads * 160 + 64); } }
     size_t keep_budget = (size_t)sysconf(_SC_PHYS_PAGES) * (size_t)sysconf(_SC_PAGE_SIZE) / 4;
     if (const char* e = pg::env_user("SOAPDENOVO2_AMD_KEEP_READS_GB")) keep_budget = (size_t)(atof(e) * 1073741824.0);
@@ -716,7 +717,7 @@ int run(int argc, char** argv, bool mer127) {
         const bool host_side = (e2 && !strcmp(e2, "host")) || (e1 && !strcmp(e1, "host"));
         size_t free_b = 0, total_b = 0;
         if (!o.reps && !host_side && !pg::env_test("SOAPDENOVO2_AMD_KEEP_ON_HOST") && keep_budget > 0 && pg::arena_mem_info(&free_b, &total_b) == hipSuccess)
-            dev_keep_budget = total_b / 8;
+            dev_keep_budget = (size_t)pg::cmd_dev_keep_budget(total_b);
     }
     long long n_records = 0;
     uint64_t total_kmers = 0;
@@ -750,7 +751,8 @@ int run(int argc, char** argv, bool mer127) {
         for (int r = 0; r < n_ranks; r++) {
             // the partition count follows the WHOLE input (every rank cuts with the same geometry, and a partition holds what all
             // ranks send to it); the export array follows this rank's share
-            ctxs[r] = pg_create_sized(devices[r], K, mer127 ? 1 : 0, o.sets, ls, 2, est_kmers + 1);
+            // (round 6: a rank STORES the partitions it owns and no others -- cursors, chunk table and pool follow 1 / n_ranks of the job)
+            ctxs[r] = pg_create_planned(devices[r], K, mer127 ? 1 : 0, o.sets, ls, 2, est_kmers + 1, est_reads, export_records, n_ranks);
             if (!ctxs[r]) die("pg_create");
         }
         mark("device context created (HIP start-up, record pools, export arrays of all ranks)");
@@ -854,7 +856,7 @@ int run(int argc, char** argv, bool mer127) {
         std::string ctx_err;
         std::thread ctx_thread([&] {
             (void)hipSetDevice(device);
-            ctx = pg_create_sized(device, K, mer127 ? 1 : 0, o.sets, log2_slots, engine, est_kmers);
+            ctx = pg_create_planned(device, K, mer127 ? 1 : 0, o.sets, log2_slots, engine, est_kmers, est_reads, engine == 2 ? export_records : 0, 1);
             if (!ctx) ctx_err = pg_last_error();
         });
         if (pg::env_measure("PG_CTX_THREAD") && atoi(pg::env_measure("PG_CTX_THREAD")) == 0) ctx_thread.join();      // (A/B: one after the other)
@@ -969,7 +971,9 @@ int run(int argc, char** argv, bool mer127) {
             }
             if (got != n_distinct) { fprintf(stderr, "export count mismatch\n"); exit(-1); }
         }
-        // replay order (set, first occurrence) on the device, in the memory pass 1 is done with
+        // replay order (set, first occurrence) on the device, in the memory pass 1 is done with -- or, when that cannot hold the sort's work space, without it:
+        // the pool goes back to the arena first and the sort cuts what it needs out of the hole (cmd_plan.hpp)
+        if (d_ws && ws_bytes < pg::cmd_sort_ws_bytes(n_distinct, mer127)) { (void)pg::arena_free(d_ws); d_ws = nullptr; ws_bytes = 0; }
         if (pg_sort_records_ws(d_rec, n_distinct, mer127 ? 1 : 0, d_ws, ws_bytes, nullptr) != PG_OK) die("pg_sort_records");
         if (stream_records) {
             // where every set starts: binary search over the sorted tags (a few hundred 8-byte copies)

@@ -39,7 +39,8 @@ struct SetParams { uint32_t P, bias; };
 // Partition engine (engine 2): super-k-mer streams + per-partition LDS counting.
 struct E2 {
     SkmGeom g;
-    int log2_parts = 0;
+    int log2_parts = 0;           // partitions STORED here (cursors, chunk table, computed chunk addresses, the counting grid)
+    int log2_global = 0;          // partition ids of the job (= log2_parts unless the ids are shared out between ranks: pg_expect)
     uint32_t rpc = 128;           // records per chunk
     uint32_t rs = 0;              // words from one record to the next (>= g.rw; 8 = every 48-byte record in its own 64-byte line)
     uint32_t direct = 0;          // the first `direct` chunks of every partition lie at computed addresses (chunk c of partition p
@@ -74,6 +75,9 @@ struct pg_ctx {
     int hint_log2_parts = -1;    // engine 2: partition count asked for by pg_expect_kmers (-1 = derive from log2_slots)
     uint64_t hint_kmers = 0;     // engine 2: k-mer occurrences to come, 0 = unknown (sizes the record pool)
     uint64_t batches = 0;        // batches taken since create / reset
+    int n_owners = 1;            // engine 2: ranks that share the job's partition ids (pg_expect); this context stores id / n_owners of those it owns
+    uint64_t hint_reads = 0;     // engine 2: reads to come (pg_expect), 0 = unknown
+    uint64_t hint_distinct = 0;  // engine 2: distinct k-mers expected in this context's export array (pg_expect), 0 = what log2_slots says
     uint32_t read_len_bound = 0; // engine 2: no read of a ragged batch is longer (pg_set_read_len_bound; 0 = ask the device, one host wait a batch)
     pg::E2 e2;
     // the sharded pass 1 (exchange.hip) keeps its last round's records in flight when it returns: whatever consumes the partition

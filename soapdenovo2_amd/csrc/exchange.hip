@@ -633,6 +633,7 @@ extern "C" int pg_count_reads_sharded(pg_ctx* ctx, pg_comm* c, const uint64_t* d
     if (ctx->engine != 2) { pg_set_error("pg_count_reads_sharded needs the partition engine"); return PG_ESTATE; }
     if (ctx->finalized) { pg_set_error("pg_count_reads_sharded after pg_finalize"); return PG_ESTATE; }
     if (ctx->device != c->device) { pg_set_error("context and communicator live on different devices"); return PG_EINVAL; }
+    if (ctx->n_owners != 1 && ctx->n_owners != c->n) { pg_set_error("the context shares its partitions between " + std::to_string(ctx->n_owners) + " owner(s) (pg_expect), the communicator has " + std::to_string(c->n) + " rank(s)"); return PG_EINVAL; }
     if (c->pipe_ctx && c->pipe_ctx != ctx) { pg_set_error("the communicator is in use by another context (pg_comm_flush it first)"); return PG_ESTATE; }
     hipStream_t st = (hipStream_t)stream;
     X_TRY(hipSetDevice(c->device));

@@ -1517,7 +1517,7 @@ int p2_begin_reads(P2Device* d, uint32_t num_ed, bool reps) {
             std::vector<uint8_t> own(256, 0);
             for (int s2 = 0; s2 < d->P; s2++) own[s2] = (uint8_t)d->set_lane[s2];
             P2_HIP(pg::arena_malloc((void**)&ln.d_owner_of_set, 256));
-            P2_HIP(hipMemcpyAsync(ln.d_owner_of_set, own.data(), 256, hipMemcpyHostToDevice, ln.stream));
+            P2_HIP(hipMemcpy(ln.d_owner_of_set, own.data(), 256, hipMemcpyHostToDevice));      // (synchronous: `own` is pageable and leaves scope before the stream is waited for)
             P2_HIP(hipHostMalloc((void**)&ln.h_starts, (P2R_MAX_LANES + 1) * sizeof(uint32_t), hipHostMallocPortable));
         }
         P2_HIP(hipStreamSynchronize(ln.stream));

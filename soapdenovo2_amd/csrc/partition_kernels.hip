@@ -35,6 +35,7 @@
 #include "extract.hpp"
 #include "occ32.hpp"
 #include "skm_tile.hpp"
+#include "e2_plan.hpp"
 #include "../../include/soapdenovo2_amd.h"
 
 namespace pg {
@@ -64,6 +65,7 @@ struct E2Dev {
     uint64_t* pool;
     uint64_t* out;
     uint64_t out_capacity;
+    uint32_t own_div;                    // ranks that share the job's partition ids (1: this context stores them all)
 };
 
 struct ReadsArg {
@@ -307,7 +309,8 @@ __global__ __launch_bounds__(BLOCK) void skm_ingest_kernel(const uint64_t* recs,
     constexpr int RW = E2Cfg<NW>::PW + 1;
     const uint32_t parts = 1u << e.g.log2_parts;
     for (uint64_t i = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; i < n; i += (uint64_t)gridDim.x * BLOCK) {
-        const uint32_t pid = rpids[i];
+        // the sender's id is the job's; this rank owns the ids with id mod own_div == its rank and stores them at id / own_div
+        const uint32_t pid = e.own_div > 1 ? rpids[i] / e.own_div : rpids[i];
         if (pid >= parts) { atomicOr(&ctr->e2_flags, F_CHUNKS); continue; }
         const uint32_t q = atomicAdd(&e.cursor[pid], 1u);
         uint64_t* out = record_slot(e, pid, q, ctr, RW);
@@ -1105,64 +1108,45 @@ __global__ __launch_bounds__(BLOCK) void set_count_kernel(const uint64_t* out, u
 static E2Dev dev_view(const pg_ctx* c) {
     const E2& s = c->e2;
     uint32_t lg = 0; while ((1u << lg) < s.rpc) lg++;
-    return E2Dev{s.g, s.rpc, s.maxc, lg, s.rs, s.direct, s.pool_chunks, s.cursor, s.chunk_tbl, s.pool, s.out, s.out_capacity};
+    return E2Dev{s.g, s.rpc, s.maxc, lg, s.rs, s.direct, s.pool_chunks, s.cursor, s.chunk_tbl, s.pool, s.out, s.out_capacity, (uint32_t)std::max(1, c->n_owners)};
 }
 
 int e2_create(pg_ctx* c) {
     E2& s = c->e2;
-    // partitions: expected distinct / ~1000 so a partition usually fits the LDS set in one attempt; half of that for the
-    // 127-mer flavour (fewer occurrences a distinct k-mer at the same read length)
-    s.log2_parts = std::max(8, std::min(24, c->log2_slots - (c->NW == 4 ? 10 : 11)));
-    if (c->hint_log2_parts >= 0) s.log2_parts = std::max(8, std::min(24, c->hint_log2_parts));
-    if (const char* v = env_test("PG_LOG2_PARTS")) s.log2_parts = std::max(4, std::min(24, atoi(v)));
-    s.g = skm_geometry(c->K, s.log2_parts, c->NW);
-    // PG_PARTS_EFF_PCT: only that share of the partition ids is used (the hash is scaled to it): partitions between two powers of two
-    if (const char* v = env_measure("PG_PARTS_EFF_PCT")) { const int pct = atoi(v); if (pct >= 50 && pct <= 100) s.g.part_mul = (uint32_t)(((uint64_t)1 << s.log2_parts) * (uint64_t)pct / 100); }
-    s.rpc = 128;
-    if (const char* v = env_measure("PG_RPC")) { const int q = atoi(v); if (q == 16 || q == 32 || q == 64 || q == 128) s.rpc = (uint32_t)q; }
-    const uint64_t parts = (uint64_t)1 << s.log2_parts;
-    // record slots: PG_REC_STRIDE=8 gives every 48-byte record of the two-word flavour its own 64-byte line (whole-line writes
-    // in K1; the four-word flavour's records are 64 bytes anyway)
-    s.rs = (uint32_t)s.g.rw;
-    if (const char* v = env_measure("PG_REC_STRIDE")) { const int q = atoi(v); if (q >= s.g.rw && q <= 16 && (q & 1) == 0) s.rs = (uint32_t)q; }
-    const uint64_t rec_bytes = (uint64_t)s.rs * 8, chunk_bytes = rec_bytes * s.rpc;
-    // PG_DIRECT_CHUNKS=M: the first M chunks of every partition at computed addresses (M * parts chunks set aside up front);
-    // -1 = about 1.25x the mean partition when the input size is known
-    s.direct = 0;
-    {
-        // default: with the input size known, room for 1.25x the mean partition at computed addresses (at most eight chunks a
-        // partition and a quarter of the device memory); PG_DIRECT_CHUNKS=M sets it, 0 switches it off
-        int q = c->hint_kmers ? (int)(((double)c->hint_kmers * 2.0 / (double)(s.g.w + 1) / (double)s.g.part_mul * 1.25 + (double)s.rpc - 1) / (double)s.rpc) : 0;
-        q = std::min(q, 8);
-        if (const char* v = env_measure("PG_DIRECT_CHUNKS")) { const int e = atoi(v); if (e >= 0) q = std::min(e, 192); }
-        size_t free_b0 = 0, total_b0 = 0;
-        if (pg::arena_mem_info(&free_b0, &total_b0) == hipSuccess)
-            while (q > 0 && (uint64_t)q * parts * chunk_bytes > total_b0 / 4) q--;
-        s.direct = (uint32_t)std::max(0, q);
-    }
+    // every size comes from ONE place, e2_plan (e2_plan.hpp): the executable memory plan (pg_host_plan_memory) calls the same function
     size_t free_b = 0, total_b = 0;
     E2_TRY(pg::arena_mem_info(&free_b, &total_b));
-    // export array: what a set of 2^log2_slots slots would hold at 70 % load
-    s.out_capacity = (uint64_t)(0.7 * (double)((uint64_t)1 << c->log2_slots));
-    const uint64_t out_bytes = s.out_capacity * (uint64_t)(c->NW + 2) * 8;
-    // record pool: every partition keeps one partly filled chunk, plus the records themselves (about one record per
-    // 20 k-mers); default = as much as a set of 2^log2_slots 64-byte slots, capped by what is free
-    uint64_t pool_bytes = ((uint64_t)1 << c->log2_slots) * 64 + parts * chunk_bytes * 2;
-    if (c->hint_kmers)                       // known input size: 2 / (w + 1) records a k-mer, half as much again, it grows
-        // (with chunks at computed addresses every partition's open chunk lies inside that region already: ONE spare chunk a partition is set aside for the
-        //  draws beyond it -- what the check below and e2_ensure_pool's estimate count on -- instead of two: 13 GB less to have the driver back at 200 M reads)
-        pool_bytes = (uint64_t)((double)c->hint_kmers * (s.direct ? 1.5 : 3.0) / (double)(s.g.w + 1)) * rec_bytes + parts * chunk_bytes * (s.direct ? 1 : 2) + ((uint64_t)64 << 20);
-    if (const char* v = env_measure("PG_POOL_MB")) pool_bytes = (uint64_t)atoll(v) << 20;
-    const uint64_t budget = (uint64_t)(free_b * 0.85);
-    if (out_bytes + parts * 8 > budget) { pg_set_error("partition engine: export array does not fit in device memory"); return PG_ENOMEM; }
-    pool_bytes += (uint64_t)s.direct * parts * chunk_bytes;
-    pool_bytes = std::min<uint64_t>(pool_bytes, (budget - out_bytes) * 9 / 10);
-    s.pool_chunks = pool_bytes / chunk_bytes;
-    if (s.pool_chunks < (uint64_t)s.direct * parts + parts + 16) { pg_set_error("partition engine: record pool too small for the partition count"); return PG_ENOMEM; }
-    if ((((uint64_t)s.direct + 1) << s.log2_parts) >= 0xFFFFFFFFULL || s.pool_chunks >= 0xFFFFFFFFULL) s.pool_chunks = std::min<uint64_t>(s.pool_chunks, 0xFFFFFFF0ULL);   // chunk ids are 32 bits
-    // chunk table: up to 2^29 entries in total (2 GB), at least enough for an even spread x8
-    const uint64_t even = (s.pool_chunks - (uint64_t)s.direct * parts + parts - 1) / parts;
-    s.maxc = (uint32_t)std::max<uint64_t>(8, std::min<uint64_t>(std::min<uint64_t>(256 - s.direct, ((uint64_t)1 << 29) / parts), even * 16));
+    uint32_t rpc = 128;
+    int rs_o = 0, direct_o = -1, test_lp = -1;
+    uint64_t pool_mb = 0;
+    if (const char* v = env_measure("PG_RPC")) { const int q = atoi(v); if (q == 16 || q == 32 || q == 64 || q == 128) rpc = (uint32_t)q; }
+    // record slots: PG_REC_STRIDE=8 gives every 48-byte record of the two-word flavour its own 64-byte line (whole-line writes
+    // in K1; the four-word flavour's records are 64 bytes anyway)
+    if (const char* v = env_measure("PG_REC_STRIDE")) rs_o = atoi(v);
+    // PG_DIRECT_CHUNKS=M: the first M chunks of every partition at computed addresses (M * parts chunks set aside up front)
+    if (const char* v = env_measure("PG_DIRECT_CHUNKS")) { const int e = atoi(v); if (e >= 0) direct_o = e; }
+    if (const char* v = env_measure("PG_POOL_MB")) pool_mb = (uint64_t)atoll(v);
+    if (const char* v = env_test("PG_LOG2_PARTS")) test_lp = atoi(v);
+    const E2Plan pl = e2_plan(c->K, c->NW, c->log2_slots, c->hint_kmers, c->hint_reads, c->hint_log2_parts, c->hint_distinct, c->n_owners, free_b, total_b, rpc, rs_o, direct_o, pool_mb, test_lp);
+    if (pl.err == 1) { pg_set_error("partition engine: export array does not fit in device memory"); return PG_ENOMEM; }
+    if (pl.err == 2) { pg_set_error("partition engine: record pool too small for the partition count"); return PG_ENOMEM; }
+    // Two partition counts: the ids of the job (the hash is scaled to part_mul = 2^log2_global of them) and what THIS context stores -- all of
+    // them, or, as one of n_owners ranks, those with id mod n_owners == its rank at id / n_owners (skm_ingest_kernel).  Everything that
+    // addresses storage -- cursors, chunk table, computed chunk addresses, the counting grid -- goes by g.log2_parts = log2_store.
+    s.log2_global = pl.log2_global;
+    s.log2_parts = pl.log2_store;
+    s.g = skm_geometry(c->K, pl.log2_global, c->NW);
+    s.g.log2_parts = pl.log2_store;
+    // PG_PARTS_EFF_PCT: only that share of the partition ids is used (the hash is scaled to it): partitions between two powers of two
+    if (const char* v = env_measure("PG_PARTS_EFF_PCT")) { const int pct = atoi(v); if (pct >= 50 && pct <= 100) s.g.part_mul = (uint32_t)(((uint64_t)1 << pl.log2_global) * (uint64_t)pct / 100); }
+    s.rpc = pl.rpc;
+    s.rs = pl.rs;
+    s.direct = pl.direct;
+    s.maxc = pl.maxc;
+    s.pool_chunks = pl.pool_chunks;
+    s.out_capacity = pl.out_capacity;
+    const uint64_t parts = (uint64_t)1 << s.log2_parts;
+    const uint64_t chunk_bytes = pl.chunk_bytes, out_bytes = pl.out_bytes;
     // PG_STARTUP_TRACE=1: what each step of the start-up took (stderr), for boxes on which a command's first second is not its own
     const bool trace = env_user("PG_STARTUP_TRACE") && atoi(env_user("PG_STARTUP_TRACE"));
     auto t_last = std::chrono::steady_clock::now();
@@ -1239,7 +1223,9 @@ static int e2_ensure_pool(pg_ctx* c, uint64_t n_reads, uint64_t n_kmers, hipStre
     E2& s = c->e2;
     if (!c->autogrow) return PG_OK;
     const uint64_t parts = (uint64_t)1 << s.log2_parts;
-    const uint64_t est_records = 4 * (2 * n_kmers / (uint64_t)(s.g.w + 1) + n_reads) + 64;
+    // (the input's size is known and the pool was made for it -- pg_expect: a batch is taken at half as much again as expected, not at four times;
+    //  at 10 M reads a batch is a fifth of the input and the larger figure grew a pool that was large enough)
+    const uint64_t est_records = (c->hint_kmers ? 3 * (2 * n_kmers / (uint64_t)(s.g.w + 1) + n_reads) / 2 : 4 * (2 * n_kmers / (uint64_t)(s.g.w + 1) + n_reads)) + 64;
     s.est_chunks += est_records / s.rpc + 1;
     const uint64_t fixed = (uint64_t)s.direct * parts;                 // chunks at computed addresses: always there, never handed out
     const uint64_t need = s.est_chunks + parts + 16 + fixed;
@@ -1449,6 +1435,7 @@ int e2_ingest(pg_ctx* c, const uint64_t* d_recs, const uint32_t* d_pids, uint64_
 
 int e2_scatter(pg_ctx* c, const uint64_t* d_packed, const uint64_t* d_word_off, const uint64_t* d_kmer_base, uint64_t n_reads,
                uint32_t uniform_len, uint64_t n_kmers_hint, uint64_t ord_base, hipStream_t st) {
+    if (c->n_owners > 1) { pg_set_error("pg_count_reads: this context stores one rank's share of the partitions (pg_expect with n_owners > 1): its batches go through pg_count_reads_sharded"); return PG_ESTATE; }
     {
         const uint64_t nk = uniform_len ? n_reads * (uint64_t)(uniform_len - c->K + 1) : n_kmers_hint;
         int rc = e2_ensure_pool(c, n_reads, nk, st);
@@ -1575,10 +1562,12 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
     if (h.e2_flags & F_CHUNKS) { pg_set_error("partition engine: one partition outgrew its chunk list (heavily skewed minimizers)"); return PG_ENOMEM; }
     if ((h.e2_flags & F_OUT) && c->autogrow && !(h.e2_flags & (F_POOL | F_CHUNKS | F_SPLIT))) {
         // the streams are intact: count again into an export array that holds everything (n_export is the true count)
+        // (the array that was too small goes first: nothing in it is kept, and the two together were what did not fit at configs[4])
         const uint64_t want = h.n_export + h.n_export / 8 + 64;
         uint64_t* fresh = nullptr;
-        E2_TRY(pg::arena_malloc(&fresh, want * (uint64_t)(c->NW + 2) * 8));
         E2_TRY(pg::arena_free(s.out));
+        s.out = nullptr;
+        E2_TRY(pg::arena_malloc(&fresh, want * (uint64_t)(c->NW + 2) * 8));
         s.out = fresh;
         s.out_capacity = want;
         unsigned long long keep = h.e2_flags & ~F_OUT;
@@ -1596,6 +1585,16 @@ int e2_count(pg_ctx* c, int delow, bool want_last_put, hipStream_t st) {
         for (int i = 0; i < 12; i++) fprintf(stderr, "K2 phase %-40s %14llu  %5.1f%%\n", names[i], h.phase[i], i != 9 ? 100.0 * h.phase[i] / (double)(tot ? tot : 1) : 0.0);
     }
     s.counted = true;
+    // the export array was sized from an estimate (a set of 2^log2_slots slots, or the caller's pg_expect): what the distinct k-mers do not
+    // fill goes back to the arena now -- 60 of 96 GB at 200 M reads -- and is there for the layout, the tips, the edges and pass 2
+    // (a context whose capacity the caller guarantees -- pg_set_autogrow(0) -- keeps what it was given: it may be reset and filled again)
+    if (s.out && c->autogrow && h.n_export < s.out_capacity) {
+        const uint64_t keep = std::max<uint64_t>(h.n_export, 1);
+        if ((s.out_capacity - keep) * (uint64_t)(c->NW + 2) * 8 >= ((uint64_t)64 << 20)) {
+            pg::arena_shrink(s.out, keep * (uint64_t)(c->NW + 2) * 8 + 64);
+            s.out_capacity = keep;
+        }
+    }
     return PG_OK;
 }
 

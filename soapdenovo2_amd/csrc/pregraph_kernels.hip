@@ -34,6 +34,7 @@
 #include "env.hpp"
 #include "extract.hpp"
 #include "device_ctx.hpp"
+#include "e2_plan.hpp"
 #include "../../include/soapdenovo2_amd.h"
 
 namespace pg {
@@ -503,21 +504,22 @@ extern "C" pg_ctx* pg_create(int device, int K, int mer127, int n_sets, int log2
     return pg_create_engine(device, K, mer127, n_sets, log2_slots, engine);
 }
 
-static int parts_for_kmers(uint64_t total_kmers, int nw) {
-    int lp = 8;
-    // about 8 k occurrences a partition (2 k for the 127-mer flavour: its LDS set holds half as many keys, and likes them sparse), to
-    // the NEAREST power of two: at 200 M x 150 bp, K = 63 (17.6 G occurrences) 2^21 partitions of 8.4 k beat 2^22 of 4.2 k by 7 % in K2
-    // (the 127-mer flavour keeps rounding up: 2^22 partitions of 1.1 k beat 2^21 of 2.3 k by 10 % there)
-    // round 4, later: the 127-mer flavour's set holds 2048 keys of four words (one claim a key): 4 k occurrences a partition
-    while (lp < 24 && (double)((uint64_t)(nw == 4 ? 4096 : 8192) << lp) * (nw == 4 ? 1.0 : 1.4142) < (double)total_kmers) lp++;
-    if (const char* v = pg::env_measure("PG_PARTS_SHIFT")) lp = std::max(8, std::min(24, lp + atoi(v)));      // A/B runs: twice / half the partitions
-    return lp;
+// (the rule itself: e2_plan.hpp, shared with the memory plan)
+static int parts_for(uint64_t total_kmers, int nw, int n_owners = 1) {
+    int shift = 0;
+    if (const char* v = pg::env_measure("PG_PARTS_SHIFT")) shift = atoi(v);      // A/B runs: twice / half the partitions
+    return pg::parts_for_kmers(total_kmers, nw, n_owners, shift);
 }
 extern "C" pg_ctx* pg_create_sized(int device, int K, int mer127, int n_sets, int log2_slots, int engine, uint64_t expected_kmers);
+extern "C" pg_ctx* pg_create_planned(int device, int K, int mer127, int n_sets, int log2_slots, int engine, uint64_t expected_kmers, uint64_t expected_reads, uint64_t distinct_here, int n_owners);
 extern "C" pg_ctx* pg_create_engine(int device, int K, int mer127, int n_sets, int log2_slots, int engine) {
     return pg_create_sized(device, K, mer127, n_sets, log2_slots, engine, 0);
 }
 extern "C" pg_ctx* pg_create_sized(int device, int K, int mer127, int n_sets, int log2_slots, int engine, uint64_t expected_kmers) {
+    return pg_create_planned(device, K, mer127, n_sets, log2_slots, engine, expected_kmers, 0, 0, 1);
+}
+// ... with everything pg_expect can be told known up front (no second allocation)
+extern "C" pg_ctx* pg_create_planned(int device, int K, int mer127, int n_sets, int log2_slots, int engine, uint64_t expected_kmers, uint64_t expected_reads, uint64_t distinct_here, int n_owners) {
     int n = 0;
     const bool trace = pg::env_user("PG_STARTUP_TRACE") && atoi(pg::env_user("PG_STARTUP_TRACE"));
     const auto t_in = std::chrono::steady_clock::now();
@@ -530,13 +532,16 @@ extern "C" pg_ctx* pg_create_sized(int device, int K, int mer127, int n_sets, in
     if (n_sets < 1 || n_sets > 255) { g_err = "pg_create: n_sets must be 1..255"; return nullptr; }
     if (log2_slots < 10 || log2_slots > 40) { g_err = "pg_create: log2_slots out of range"; return nullptr; }
     if (engine != 1 && engine != 2) { g_err = "pg_create: engine must be 1 (global set) or 2 (partitions)"; return nullptr; }
+    if (n_owners < 1 || n_owners > 4096) { g_err = "pg_create: bad number of owners"; return nullptr; }
     if (hipSetDevice(device) != hipSuccess) { g_err = "pg_create: hipSetDevice failed"; return nullptr; }
+    pg::arena_pin_for_process(device);      // (a caller without a pin of its own -- call_pregraph holds one for the command -- keeps the arena's pieces for the process)
     pg_ctx* c = new pg_ctx();
     c->device = device; c->K = K; c->NW = mer127 ? 4 : 2; c->P = n_sets; c->log2_slots = log2_slots;
     c->ub_distinct = 0; c->finalized = false; c->autogrow = true; c->slots = nullptr; c->ctr = nullptr;
     c->variant = 1;
     c->engine = engine;
-    if (expected_kmers) { c->hint_kmers = expected_kmers; c->hint_log2_parts = parts_for_kmers(expected_kmers, c->NW); }
+    if (engine == 2) { c->n_owners = n_owners; c->hint_distinct = distinct_here; c->hint_reads = expected_reads; }
+    if (expected_kmers) { c->hint_kmers = expected_kmers; c->hint_log2_parts = parts_for(expected_kmers, c->NW, c->n_owners); }
     if (const char* v = pg::env_measure("PG_VARIANT")) c->variant = atoi(v);
     if (engine == 2) {
         if (pg::arena_malloc(&c->ctr, sizeof(DevCounters)) != hipSuccess) { g_err = "pg_create: hipMalloc failed"; delete c; return nullptr; }
@@ -569,30 +574,38 @@ extern "C" int pg_set_read_len_bound(pg_ctx* c, uint32_t max_len) {
 // The partition count of engine 2 follows the number of k-mer occurrences to come (about 8 k of them, i.e. some 400
 // super-k-mer records, a partition), not the number of distinct k-mers the export array is sized for.  Before the first
 // batch only; a no-op for engine 1.
-extern "C" int pg_expect_kmers(pg_ctx* c, uint64_t total_kmers) {
+extern "C" int pg_expect(pg_ctx* c, uint64_t total_kmers, uint64_t total_reads, uint64_t distinct_here, int n_owners) {
     if (!c) { g_err = "null context"; return PG_EINVAL; }
     if (c->engine != 2) return PG_OK;
-    if (c->batches) { g_err = "pg_expect_kmers: batches were already counted"; return PG_ESTATE; }
-    const int lp = parts_for_kmers(total_kmers, c->NW);
-    if (lp == c->e2.log2_parts && c->hint_kmers == total_kmers) return PG_OK;
+    if (n_owners < 1 || n_owners > 4096) { g_err = "pg_expect: bad number of owners"; return PG_EINVAL; }
+    if (c->batches) { g_err = "pg_expect: batches were already counted"; return PG_ESTATE; }
+    const int lp = total_kmers ? parts_for(total_kmers, c->NW, n_owners) : c->hint_log2_parts;
+    if (lp == c->e2.log2_global && c->hint_kmers == total_kmers && c->hint_reads == total_reads && c->hint_distinct == distinct_here && c->n_owners == n_owners) return PG_OK;
     HIP_TRY(hipSetDevice(c->device));
-    const int old = c->hint_log2_parts;
-    const uint64_t old_kmers = c->hint_kmers;
+    const int old = c->hint_log2_parts, old_own = c->n_owners;
+    const uint64_t old_kmers = c->hint_kmers, old_distinct = c->hint_distinct, old_reads = c->hint_reads;
     e2_destroy(c);
     c->hint_log2_parts = lp;
     c->hint_kmers = total_kmers;
+    c->hint_distinct = distinct_here;
+    c->hint_reads = total_reads;
+    c->n_owners = n_owners;
     int rc = e2_create(c);
     if (rc != PG_OK) {                       // e.g. no room for that many open chunks: keep the previous geometry
         e2_destroy(c);
         c->hint_log2_parts = old;
         c->hint_kmers = old_kmers;
+        c->hint_distinct = old_distinct;
+        c->hint_reads = old_reads;
+        c->n_owners = old_own;
         const std::string why = g_err;
         if (e2_create(c) != PG_OK) return PG_ENOMEM;
-        g_err = why;
+        g_err = why;                         // (the context goes on as it was: one owner's storage takes any partition id)
     }
     (void)hipDeviceSynchronize();
     return PG_OK;
 }
+extern "C" int pg_expect_kmers(pg_ctx* c, uint64_t total_kmers) { return pg_expect(c, total_kmers, 0, 0, 1); }
 
 // forget everything counted so far, keep the capacity (bench / repeated runs)
 extern "C" int pg_reset(pg_ctx* c, void* stream) {
