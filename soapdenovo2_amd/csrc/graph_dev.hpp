@@ -22,6 +22,10 @@ struct P2Result {
     std::vector<unsigned int> marker;                             // per edge id, unsaturated (-R only)
     long long reads_deleted = 0, markers = 0;
     int lanes = 1;                                                // > 1: a (from, to) pair may come from several lanes -- merge by sum and minimum
+    // folded on the device (round 6): from, to, multiplicity of every pre-arc in FILE order -- source edges ascending, a source's targets latest
+    // first-met first, the lanes' entries of one pair merged (prlRead2path.c:388-403, 426-476) -- and `arcs` stays empty; the host only prints
+    bool folded = false;
+    std::vector<uint32_t> folded3;
 };
 
 // one edge record as the device built it, in the reference's order (the host formats output_1edge's text from it)

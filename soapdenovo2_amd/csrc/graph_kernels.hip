@@ -909,6 +909,42 @@ __global__ __launch_bounds__(256) void p2_compact_arcs(const unsigned long long*
     }
 }
 
+// ---- the fold of the pre-arc table on the device (round 6; until then 26 M pre-arcs at 200 M reads went to the host as 24-byte entries and were
+// bucketed and std::sort-ed there: 0.8 s of a 5.5 s command).  thread_add1preArc keeps, per source edge, a list with the NEWEST first-met target at
+// its head and counts repeats (prlRead2path.c:388-403); output_1edge prints the lists in edge order (:426-476).  Here: the lanes' entries of one
+// (from, to) pair are merged (multiplicities add up, the first meeting is the earliest), then two stable radix sorts -- by descending first
+// meeting, then by source edge -- give the file order, and (from, to, multiplicity) goes to the host in that order, 12 bytes a pre-arc.
+__global__ __launch_bounds__(256) void pf_pair_keys(const P2Arc* a, uint64_t n, unsigned long long* key, uint32_t* idx) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) { key[i] = ((unsigned long long)a[i].from << 32) | a[i].to; idx[i] = (uint32_t)i; }
+}
+__global__ __launch_bounds__(256) void pf_heads(const unsigned long long* key_sorted, uint64_t n, unsigned long long* head) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) head[i] = (i == 0 || key_sorted[i] != key_sorted[i - 1]) ? 1ULL : 0ULL;
+}
+__global__ __launch_bounds__(256) void pf_merge(const P2Arc* a, const unsigned long long* key_sorted, const uint32_t* order, const unsigned long long* head, const unsigned long long* pos,
+                                                uint64_t n, P2Arc* out) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        if (!head[i]) continue;
+        P2Arc m = a[order[i]];
+        for (uint64_t j = i + 1; j < n && key_sorted[j] == key_sorted[i]; j++) {           // (at most one entry a lane)
+            const P2Arc& b = a[order[j]];
+            m.mult += b.mult;
+            m.first = b.first < m.first ? b.first : m.first;
+        }
+        out[pos[i]] = m;
+    }
+}
+__global__ __launch_bounds__(256) void pf_first_keys(const P2Arc* a, uint64_t n, unsigned long long* key, uint32_t* idx) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) { key[i] = ~a[i].first; idx[i] = (uint32_t)i; }
+}
+__global__ __launch_bounds__(256) void pf_from_keys(const P2Arc* a, const uint32_t* order, uint64_t n, unsigned long long* key) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) key[i] = a[order[i]].from;
+}
+__global__ __launch_bounds__(256) void pf_gather(const P2Arc* a, const uint32_t* order, uint64_t n, uint32_t* out3) {
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (uint64_t)gridDim.x * 256) {
+        const P2Arc& x = a[order[i]];
+        out3[3 * i] = x.from; out3[3 * i + 1] = x.to; out3[3 * i + 2] = x.mult;
+    }
+}
 __global__ void p2_fill_u64(unsigned long long* a, uint64_t n, unsigned long long v) {
     for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) a[i] = v;
 }
@@ -2274,6 +2310,57 @@ int p2_add_packed_device_ragged(P2Device* d, const uint64_t* d_words, const uint
     return PG_OK;
 }
 
+// d_all: n entries on the current device (consumed); merge: entries of one pair may repeat (several lanes)
+static int p2_fold_arcs(P2Arc* d_all, uint64_t n, bool merge, hipStream_t st, std::vector<uint32_t>& out3) {
+    out3.clear();
+    if (!n) return PG_OK;
+    if (n >= 0xFFFFFFFFull) { pg_set_error("pass 2: more than 2^32 pre-arcs in one fold"); return PG_EINVAL; }
+    int rc = PG_OK;
+    unsigned long long *key = nullptr, *key2 = nullptr, *head = nullptr, *pos = nullptr;
+    uint32_t *idx = nullptr, *ord = nullptr, *ord2 = nullptr, *d_out3 = nullptr;
+    P2Arc* merged = nullptr;
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0, t2 = 0;
+    const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 8192);
+    using SortP = unsigned long long;
+    P2_HIP_GOTO((rocprim::radix_sort_pairs<rocprim::default_config, SortP*, SortP*, uint32_t*, uint32_t*, size_t>(nullptr, tmp_bytes, key, key2, idx, ord, (size_t)n, 0u, 64u, st)));
+    P2_HIP_GOTO((rocprim::exclusive_scan<rocprim::default_config, SortP*, SortP*, SortP, rocprim::plus<SortP>>(nullptr, t2, head, pos, 0ULL, (size_t)n, rocprim::plus<SortP>(), st)));
+    tmp_bytes = std::max(tmp_bytes, t2);
+    P2_HIP_GOTO(pg::arena_malloc(&tmp, tmp_bytes));
+    P2_HIP_GOTO(pg::arena_malloc((void**)&key, n * 8)); P2_HIP_GOTO(pg::arena_malloc((void**)&key2, n * 8));
+    P2_HIP_GOTO(pg::arena_malloc((void**)&idx, n * 4)); P2_HIP_GOTO(pg::arena_malloc((void**)&ord, n * 4)); P2_HIP_GOTO(pg::arena_malloc((void**)&ord2, n * 4));
+    if (merge) {
+        P2_HIP_GOTO(pg::arena_malloc((void**)&head, n * 8)); P2_HIP_GOTO(pg::arena_malloc((void**)&pos, n * 8));
+        P2_HIP_GOTO(pg::arena_malloc((void**)&merged, n * sizeof(P2Arc)));
+        hipLaunchKernelGGL(pf_pair_keys, dim3(grid), dim3(256), 0, st, d_all, n, key, idx);
+        P2_HIP_GOTO((rocprim::radix_sort_pairs<rocprim::default_config, SortP*, SortP*, uint32_t*, uint32_t*, size_t>(tmp, tmp_bytes, key, key2, idx, ord, (size_t)n, 0u, 64u, st)));
+        hipLaunchKernelGGL(pf_heads, dim3(grid), dim3(256), 0, st, key2, n, head);
+        P2_HIP_GOTO((rocprim::exclusive_scan<rocprim::default_config, SortP*, SortP*, SortP, rocprim::plus<SortP>>(tmp, tmp_bytes, head, pos, 0ULL, (size_t)n, rocprim::plus<SortP>(), st)));
+        hipLaunchKernelGGL(pf_merge, dim3(grid), dim3(256), 0, st, d_all, key2, ord, head, pos, n, merged);
+        unsigned long long last[2] = {0, 0};
+        P2_HIP_GOTO(hipMemcpyAsync(&last[0], pos + n - 1, 8, hipMemcpyDeviceToHost, st));
+        P2_HIP_GOTO(hipMemcpyAsync(&last[1], head + n - 1, 8, hipMemcpyDeviceToHost, st));
+        P2_HIP_GOTO(hipStreamSynchronize(st));
+        n = last[0] + last[1];
+        std::swap(d_all, merged);                                    // (both are released below)
+    }
+    hipLaunchKernelGGL(pf_first_keys, dim3(grid), dim3(256), 0, st, d_all, n, key, idx);
+    P2_HIP_GOTO((rocprim::radix_sort_pairs<rocprim::default_config, SortP*, SortP*, uint32_t*, uint32_t*, size_t>(tmp, tmp_bytes, key, key2, idx, ord, (size_t)n, 0u, 64u, st)));
+    hipLaunchKernelGGL(pf_from_keys, dim3(grid), dim3(256), 0, st, d_all, ord, n, key);
+    P2_HIP_GOTO((rocprim::radix_sort_pairs<rocprim::default_config, SortP*, SortP*, uint32_t*, uint32_t*, size_t>(tmp, tmp_bytes, key, key2, ord, ord2, (size_t)n, 0u, 32u, st)));
+    P2_HIP_GOTO(pg::arena_malloc((void**)&d_out3, n * 12));
+    hipLaunchKernelGGL(pf_gather, dim3(grid), dim3(256), 0, st, d_all, ord2, n, d_out3);
+    P2_HIP_GOTO(hipGetLastError());
+    out3.resize((size_t)n * 3);
+    P2_HIP_GOTO(hipMemcpyAsync(out3.data(), d_out3, n * 12, hipMemcpyDeviceToHost, st));
+    P2_HIP_GOTO(hipStreamSynchronize(st));
+done:
+    if (rc) (void)hipStreamSynchronize(st);
+    pg::arena_free(tmp); pg::arena_free(key); pg::arena_free(key2); pg::arena_free(idx); pg::arena_free(ord); pg::arena_free(ord2); pg::arena_free(head); pg::arena_free(pos);
+    pg::arena_free(d_out3); pg::arena_free(merged); pg::arena_free(d_all);
+    return rc;
+}
+
 int p2_finish(P2Device* d, P2Result& out) {
     if (d->route) { const int rc = p2_route_round(d); if (rc) return rc; }        // the batches still waiting for a full round
     unsigned long long c[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -2314,10 +2401,16 @@ int p2_finish(P2Device* d, P2Result& out) {
     out.reads_deleted = (long long)c[0];
     out.markers = (long long)c[4];
     out.lanes = (int)d->lanes.size();
-    const size_t n_arcs = (size_t)c[3];                            // (a pair met on several lanes is counted by each: the caller merges)
-    out.arcs.assign(n_arcs, P2Arc{0, 0, 0, 0});
+    const size_t n_arcs = (size_t)c[3];                            // (a pair met on several lanes is counted by each: merged below, or by the caller)
+    // SOAPDENOVO2_AMD_PREARC_FOLD=host: the round-5 form (24-byte entries to the host, bucketed and sorted there), for the A/B
+    const char* fold_env = pg::env_user("SOAPDENOVO2_AMD_PREARC_FOLD");
+    const bool dev_fold = !(fold_env && !strcmp(fold_env, "host")) && n_arcs > 0 && n_arcs < 0xFFFFFFFFull;
+    out.folded = false; out.folded3.clear(); out.arcs.clear();
+    if (!dev_fold) out.arcs.assign(n_arcs, P2Arc{0, 0, 0, 0});
     out.marker.clear();
     if (d->reps) out.marker.assign((size_t)d->num_ed + 1, 0u);
+    P2Arc* d_all = nullptr;                                         // on the lead device: every lane's entries, one after the other
+    if (dev_fold) { P2_HIP(hipSetDevice(d->device)); P2_HIP(pg::arena_malloc((void**)&d_all, n_arcs * sizeof(P2Arc))); }
     size_t at = 0;
     for (size_t l = 0; l < d->lanes.size(); l++) {
         P2Lane& ln = d->lanes[l];
@@ -2327,15 +2420,18 @@ int p2_finish(P2Device* d, P2Result& out) {
         const size_t n_l = (size_t)lane_arcs[l];
         if (n_l) {
             P2Arc* d_arcs = nullptr;
-            P2_HIP(pg::arena_malloc((void**)&d_arcs, n_l * sizeof(P2Arc)));
+            const bool in_place = dev_fold && ln.device == d->device;      // a lane of the lead's GPU writes straight into the common array
+            if (in_place) d_arcs = d_all + at;
+            else P2_HIP(pg::arena_malloc((void**)&d_arcs, n_l * sizeof(P2Arc)));
             P2_HIP(hipMemsetAsync(ln.d_counters + 6, 0, sizeof(unsigned long long), ln.stream));
             hipLaunchKernelGGL(p2_compact_arcs, dim3(2048), dim3(256), 0, ln.stream, ln.d_arc_key, ln.d_arc_cnt, ln.d_arc_first, cap, d_arcs, ln.d_counters + 6, (unsigned long long)n_l);
-            P2_HIP(hipMemcpyAsync(out.arcs.data() + at, d_arcs, n_l * sizeof(P2Arc), hipMemcpyDeviceToHost, ln.stream));
+            if (!dev_fold) P2_HIP(hipMemcpyAsync(out.arcs.data() + at, d_arcs, n_l * sizeof(P2Arc), hipMemcpyDeviceToHost, ln.stream));
+            else if (!in_place) P2_HIP(hipMemcpyPeerAsync(d_all + at, d->device, d_arcs, ln.device, n_l * sizeof(P2Arc), ln.stream));
             unsigned long long got = 0;
             P2_HIP(hipMemcpyAsync(&got, ln.d_counters + 6, sizeof(got), hipMemcpyDeviceToHost, ln.stream));
             P2_HIP(hipStreamSynchronize(ln.stream));
-            pg::arena_free(d_arcs);
-            if (got != n_l) { pg_set_error("pass 2: pre-arc table is inconsistent"); return PG_EINVAL; }
+            if (!in_place) pg::arena_free(d_arcs);
+            if (got != n_l) { pg_set_error("pass 2: pre-arc table is inconsistent"); if (d_all) { (void)hipSetDevice(d->device); pg::arena_free(d_all); } return PG_EINVAL; }
             at += n_l;
         }
         if (d->reps) {
@@ -2343,6 +2439,12 @@ int p2_finish(P2Device* d, P2Result& out) {
             P2_HIP(hipMemcpy(m.data(), ln.d_marker, m.size() * sizeof(unsigned int), hipMemcpyDeviceToHost));
             for (size_t e = 0; e < m.size(); e++) out.marker[e] += m[e];
         }
+    }
+    if (dev_fold) {
+        P2_HIP(hipSetDevice(d->device));
+        const int rc = p2_fold_arcs(d_all, n_arcs, d->lanes.size() > 1, d->lanes[0].stream, out.folded3);      // (releases d_all)
+        if (rc) return rc;
+        out.folded = true;
     }
     P2_HIP(hipSetDevice(d->device));
     return PG_OK;

@@ -26,6 +26,8 @@
 #include <math.h>
 #include <zlib.h>
 #include <sys/mman.h>
+#include <fcntl.h>
+#include <unistd.h>
 
 #include <algorithm>
 #include <atomic>
@@ -1074,16 +1076,19 @@ struct ParallelEdgeBuilder {
         // measured in round 5 with the members deflated by all host threads beside pass 2: pg_host_graph_finish waited 1.2 s for the file at 60 M reads
         // (a 3.5 s command instead of 2.4) and 2.5 s at 200 M (profiles/r05f_cli_200M_arena_gzip_ab.json); at level 1 it waits 0.00 s.  The file is a
         // multi-member gzip here anyway (never the reference's bytes, always its text; the later stages only gzread it).
-        // SOAPDENOVO2_AMD_GZIP_LEVEL=0..9 (6 = the reference's file size); anything else is refused loudly.
+        // Round 6: the default is Huffman coding WITHOUT string matching (Z_HUFFMAN_ONLY): an edge file is DNA, which a 32 KB window finds next to nothing
+        // to match in -- on 200 MB of edge-like text 98 MB/s a thread against 52 at level 1, and a file 6 % SMALLER (ratio 0.383 against 0.408; level 6:
+        // 0.362 at 9 MB/s).  The writer had become the last thing pass 2's finish waits for once the pre-arcs were folded on the device.
+        // SOAPDENOVO2_AMD_GZIP_LEVEL=0..9 (zlib's usual strategy at that level; 6 = the reference's file size); anything else is refused loudly.
         static const int level = []() {
             const char* e = pg::env_user("SOAPDENOVO2_AMD_GZIP_LEVEL");
-            if (!e) return 1;
+            if (!e) return -1;
             char* end = nullptr;
             const long v = strtol(e, &end, 10);
             if (end == e || *end || v < 0 || v > 9) { fprintf(stderr, "SOAPDENOVO2_AMD_GZIP_LEVEL must be 0..9 (got '%s')\n", e); exit(-1); }
             return (int)v;
         }();
-        if (deflateInit2(&z, level, Z_DEFLATED, 15 + 16, 8, Z_DEFAULT_STRATEGY) != Z_OK) return false;
+        if (deflateInit2(&z, level < 0 ? 1 : level, Z_DEFLATED, 15 + 16, 8, level < 0 ? Z_HUFFMAN_ONLY : Z_DEFAULT_STRATEGY) != Z_OK) return false;
         out.resize(deflateBound(&z, (uLong)text.size()) + 64);
         z.next_in = (Bytef*)text.data(); z.avail_in = (uInt)text.size();
         z.next_out = out.data(); z.avail_out = (uInt)out.size();
@@ -2004,11 +2009,47 @@ struct GraphHandle : GraphHandleBase {
         P2Result res;
         rc = p2_finish(dev, res);
         if (rc) return rc;
+        const double t_dev = now();
         reads_deleted = res.reads_deleted;
         mark_count = res.markers;
+        const int nt = std::max(1, pick_threads(0));
+        std::vector<std::string> text(nt);
+        std::vector<size_t> merged_n(nt, 0);
+        if (res.folded) {
+            // folded on the device: (from, to, multiplicity) in file order; the host threads print ranges cut where the source edge changes
+            const size_t n = res.folded3.size() / 3;
+            const uint32_t* a3 = res.folded3.data();
+            std::vector<size_t> cut(nt + 1, n);
+            cut[0] = 0;
+            for (int t = 1; t < nt; t++) {
+                size_t i = std::max(cut[t - 1], n * (size_t)t / nt);
+                while (i < n && i > 0 && a3[3 * i] == a3[3 * (i - 1)]) i++;
+                cut[t] = i;
+            }
+            auto body3 = [&](int t) {
+                // (a raw buffer of the worst-case size and pointer writes: push_back a character was 0.26 s of the 0.42 s the fold took at 26 M pre-arcs)
+                std::string& out = text[t];
+                const size_t n_t = cut[t + 1] - cut[t];
+                out.resize(n_t * 33 + 16);
+                char* const base = &out[0];
+                char* p = base;
+                auto put = [&](uint32_t v) { char tmp[10]; int k = 0; do { tmp[k++] = (char)('0' + v % 10); v /= 10; } while (v); while (k) *p++ = tmp[--k]; };
+                for (size_t i = cut[t]; i < cut[t + 1];) {
+                    const uint32_t from = a3[3 * i];
+                    put(from);
+                    for (; i < cut[t + 1] && a3[3 * i] == from; ++i) { *p++ = ' '; put(a3[3 * i + 1]); *p++ = ' '; put(a3[3 * i + 2]); }
+                    *p++ = '\n';
+                }
+                out.resize((size_t)(p - base));
+                merged_n[t] = n_t;
+            };
+            std::vector<std::thread> pool;
+            for (int t = 1; t < nt; t++) pool.emplace_back(body3, t);
+            body3(0);
+            for (auto& th : pool) th.join();
+        } else {
         // a list shows its targets latest first-met first (prlRead2path.c:388-403, 443-467); the source edges are cut
         // into ranges that are sorted and printed by all host threads
-        const int nt = std::max(1, pick_threads(0));
         const uint64_t n_from = (uint64_t)num_ed + 1;
         std::vector<size_t> start(nt + 1, 0);
         for (const P2Arc& a : res.arcs) start[(size_t)((uint64_t)a.from * nt / n_from) + 1]++;
@@ -2018,9 +2059,7 @@ struct GraphHandle : GraphHandleBase {
             std::vector<size_t> cur(start.begin(), start.end() - 1);
             for (const P2Arc& a : res.arcs) sorted[cur[(size_t)((uint64_t)a.from * nt / n_from)]++] = a;
         }
-        std::vector<std::string> text(nt);
         const bool merge = res.lanes > 1;
-        std::vector<size_t> merged_n(nt, 0);
         auto body = [&](int t) {
             P2Arc* lo = sorted.data() + start[t];
             P2Arc* hi = sorted.data() + start[t + 1];
@@ -2054,11 +2093,30 @@ struct GraphHandle : GraphHandleBase {
             body(0);
             for (auto& th : pool) th.join();
         }
-        FILE* fp = fopen((prefix + ".preArc").c_str(), "w");
-        if (!fp) { pg_set_error("cannot open " + prefix + ".preArc"); return PG_EIO; }
-        for (int t = 0; t < nt; t++)
-            if (!text[t].empty() && fwrite(text[t].data(), 1, text[t].size(), fp) != text[t].size()) { fclose(fp); pg_set_error("short write on " + prefix + ".preArc"); return PG_EIO; }
-        fclose(fp);
+        }
+        const double t_text = now();
+        {   // every thread writes its own stretch of the file (the offsets are the prefix sums of the text sizes)
+            const int fd = open((prefix + ".preArc").c_str(), O_WRONLY | O_CREAT | O_TRUNC, 0644);
+            if (fd < 0) { pg_set_error("cannot open " + prefix + ".preArc"); return PG_EIO; }
+            std::vector<size_t> off(nt + 1, 0);
+            for (int t = 0; t < nt; t++) off[t + 1] = off[t] + text[t].size();
+            std::atomic<int> bad{0};
+            auto wr = [&](int t) {
+                size_t done = 0;
+                while (done < text[t].size()) {
+                    const ssize_t w = pwrite(fd, text[t].data() + done, text[t].size() - done, (off_t)(off[t] + done));
+                    if (w <= 0) { bad.store(1); return; }
+                    done += (size_t)w;
+                }
+            };
+            std::vector<std::thread> pool;
+            for (int t = 1; t < nt; t++) pool.emplace_back(wr, t);
+            wr(0);
+            for (auto& th : pool) th.join();
+            if (close(fd) != 0 || bad.load()) { pg_set_error("short write on " + prefix + ".preArc"); return PG_EIO; }
+        }
+        if (pg::env_user("PG_HOST_VERBOSE"))
+            fprintf(stderr, "pre-arcs: %s, table read out + sorted + downloaded %.2fs, text %.2fs, file %.2fs\n", res.folded ? "folded on the device" : "folded on the host", t_dev - t0, t_text - t_dev, now() - t_text);
         dev_arc_count = 0;
         for (int t = 0; t < nt; t++) dev_arc_count += (long long)merged_n[t];
         if (path_fp) for (size_t e = 0; e < marker.size() && e < res.marker.size(); e++) marker[e] = (uint8_t)std::min(255u, res.marker[e]);
