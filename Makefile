@@ -13,6 +13,9 @@ O       := m.o
 LIBNAME := libsoapdenovo2_amd_measure.so
 CXXFLAGS += -DPG_MEASURE
 HIPFLAGS += -DPG_MEASURE
+ifneq ($(K2_LOOK),)
+HIPFLAGS += -DPG_K2_LOOK=$(K2_LOOK)
+endif
 else
 O       := o
 LIBNAME := libsoapdenovo2_amd.so

@@ -44,6 +44,9 @@ constexpr uint64_t L_EMPTY = ~0ULL;
 constexpr unsigned long long F_POOL = 1, F_CHUNKS = 2, F_OUT = 4, F_SPLIT = 8, F_ROUTE = 16;   // F_ROUTE: an owner's send region overflowed (multi-GPU cut)
 constexpr unsigned long long F_LEN = 32;   // a read of a ragged batch is longer than the bound its tiles were sized for, or shorter than K + 1
 
+// Slots a probe step looks ahead (word 0 only: lds_put), measured at 200 M reads / configs[1] (profiles/r06_k2_probe_look_ahead_ab.json): 0 -> 1 -> 2 -> 3 slots:
+// K = 63 131.0 -> 125.8 -> 124.3 -> 124.5 ms, K = 127 108.2 -> 99.0 -> 97.9 -> 99.3, K = 31 (10 M x 100 bp) 16.8 -> 14.6 -> 14.0 -> 13.5: two, and three for the short
+// k-mers of the K = 31 kernel (its partitions are the fullest: 95.8 M distinct k-mers in 2^16 partitions).  -DPG_K2_LOOK=n overrides all of them (A/B builds).
 template <int NW> struct E2Cfg;
 // LDS slot = KW key words | ord | 5 x u32 of counters (LdsSet below).  Two-word flavour: words of 63 bits, so that no word of a key
 // is the empty mark ~0 and a slot is claimed word by word.  Four-word flavour: 254 bits do not fit four such words, and a fifth costs
@@ -371,7 +374,7 @@ __device__ __forceinline__ const uint64_t* record_ptr(const E2Dev& e, uint32_t p
 //   * the put counter is gone: every put adds to exactly one of L[0..3] / "no left neighbour", so puts = their sum, and
 //     the first-occurrence ordinal is only sent through atomicMin when it is smaller than the value just read with the key
 //     (a hot k-mer's lanes hit the same word: same-address LDS atomics serialise, same-address reads broadcast).
-template <int NW, int SLOTS>
+template <int NW, int SLOTS, int LOOK>
 __device__ __forceinline__ bool lds_put(LdsSet<NW, SLOTS>& t, const uint64_t (&kw)[E2Cfg<NW>::KW], uint32_t hash, uint32_t left, uint32_t right,
                                          uint64_t ord, uint32_t copies) {
     constexpr int KW = E2Cfg<NW>::KW;
@@ -390,6 +393,9 @@ __device__ __forceinline__ bool lds_put(LdsSet<NW, SLOTS>& t, const uint64_t (&k
             for (int i = 0; i < KW; i++)                                  // (an LDS pointer, said so: a plain volatile one is read through the flat path, one load at a time)
                 seen[i] = *(volatile __attribute__((address_space(3))) unsigned long long*)(&t.key[i][h]);
             const unsigned long long so = t.ord[h];
+            unsigned long long nxt0[LOOK];                      // (see the two-word flavour below)
+#pragma unroll
+            for (int q = 0; q < LOOK; q++) nxt0[q] = *(volatile __attribute__((address_space(3))) unsigned long long*)(&t.key[0][(h + 1 + q) & (SLOTS - 1)]);
             bool mine = false, again = false;
             if (seen[0] == L_EMPTY) {
                 const unsigned long long old = atomicCAS(&t.key[0][h], L_EMPTY, (unsigned long long)kw[0] | L_PENDING);
@@ -412,7 +418,15 @@ __device__ __forceinline__ bool lds_put(LdsSet<NW, SLOTS>& t, const uint64_t (&k
                 return true;
             }
             if (again) spins++;
-            else { h = (h + 1) & (SLOTS - 1); probes++; }
+            else {
+                // (a next slot that is taken -- or being taken: the mark aside, word 0 is final -- by another key is passed by without a step of its own)
+                uint32_t adv = 1;
+                bool run = true;
+#pragma unroll
+                for (int q = 0; q < LOOK; q++) { run = run && nxt0[q] != L_EMPTY && (nxt0[q] & ~L_PENDING) != kw[0]; adv += run ? 1u : 0u; }
+                h = (h + adv) & (SLOTS - 1);
+                probes += (int)adv;
+            }
         }
         return false;
     }
@@ -421,6 +435,12 @@ __device__ __forceinline__ bool lds_put(LdsSet<NW, SLOTS>& t, const uint64_t (&k
 #pragma unroll
         for (int i = 0; i < KW; i++) seen[i] = t.key[i][h];
         const unsigned long long so = t.ord[h];
+        // (round 6) word 0 of the NEXT slot comes with this slot's words -- one more 8-byte read in the same wait: a next slot that is taken by another key
+        // (word 0 of a slot never changes once it is set) is passed by without a step of its own.  A step is an LDS round trip, a workgroup's occurrence phase
+        // ends when its longest probe sequence does, and the others wait for it at the barrier: the sequences through a crowded stretch are half as long.
+        unsigned long long nxt0[LOOK];
+#pragma unroll
+        for (int q = 0; q < LOOK; q++) nxt0[q] = t.key[0][(h + 1 + q) & (SLOTS - 1)];
         bool mine = true;
 #pragma unroll
         for (int i = 0; i < KW; i++) {
@@ -439,7 +459,12 @@ __device__ __forceinline__ bool lds_put(LdsSet<NW, SLOTS>& t, const uint64_t (&k
             if (ord < so) atomicMin(&t.ord[h], (unsigned long long)ord);
             return true;
         }
-        h = (h + 1) & (SLOTS - 1);
+        uint32_t adv = 1;                                                  // ... plus the slots ahead, while they are another key's
+        bool run = true;
+#pragma unroll
+        for (int q = 0; q < LOOK; q++) { run = run && nxt0[q] != L_EMPTY && nxt0[q] != kw[0]; adv += run ? 1u : 0u; }
+        h = (h + adv) & (SLOTS - 1);
+        probes += (int)adv - 1;
     }
     return false;
 }
@@ -956,7 +981,12 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
                             const uint32_t h_lo = rec[0], h_hi = rec[1];
                             const uint32_t copies = ((h_lo >> 9) & 0x1FFu) + 1u;
                             const uint64_t ord = ((((uint64_t)h_hi << 32) | h_lo) >> SKM_ORD_SHIFT) + t;
-                            if (!lds_put<NW, SLOTS>(set, kw, hh, left, right, ord, copies)) aborted = 1;
+#ifdef PG_K2_LOOK
+                            constexpr int LOOK = PG_K2_LOOK;
+#else
+                            constexpr int LOOK = KS == 31 ? 3 : 2;
+#endif
+                            if (!lds_put<NW, SLOTS, LOOK>(set, kw, hh, left, right, ord, copies)) aborted = 1;
                         } while (0);
                     }
                     unsigned int nt = 0;
