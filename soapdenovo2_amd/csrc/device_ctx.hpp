@@ -59,6 +59,10 @@ struct E2 {
     // joined by whoever needs `out` first (e2_count, e2_destroy).
     std::thread* out_thread = nullptr;
     int out_err = 0;              // hipError_t of that allocation
+    // ragged batches cut by length class (partition_kernels.hip: launch_ragged_by_class): the batch's reads sorted by class, the classes' counters
+    uint32_t* rg_perm = nullptr;      // per class the gathered rows: start words, first k-mers (8 B each), lengths (4 B), rg_perm_cap reads each
+    uint64_t rg_perm_cap = 0;
+    unsigned int* rg_hist = nullptr;   // [2 * 32] histogram | cursors
 };
 
 }  // namespace pg

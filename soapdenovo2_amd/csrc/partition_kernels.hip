@@ -79,6 +79,10 @@ struct ReadsArg {
     uint32_t uniform_len, kpr, wpr;  // ragged batches through the tiled kernel: uniform_len = 0, kpr / wpr = those of the longest read (max_len)
     uint64_t ord_base;
     uint32_t max_len;                // ragged batches: no read is longer (0 = unknown: the one-lane-a-read kernel)
+    // ragged batches cut by length class: a class's reads, gathered -- word_off points at the class's own row of start words, and these at its rows of
+    // first k-mers and lengths (null: kmer_base[i], kmer_base[i + 1] of the batch as it lies)
+    const uint64_t* cls_kb;
+    const int32_t* cls_len;
 };
 
 // address of record q of partition pid.  The lane that draws the first record of a chunk (q % rpc == 0) takes a
@@ -204,8 +208,8 @@ __global__ __launch_bounds__(BLOCK) void skm_scatter_seg_kernel(ReadsArg a, E2De
     if (threadIdx.x == 0) n_items = 0;
     if (RAGGED) {
         for (int r = threadIdx.x; r < nr; r += BLOCK) {
-            const uint64_t kb = a.kmer_base[r0 + r];
-            int l = (int)(a.kmer_base[r0 + r + 1] - kb) + e.g.K - 1;
+            const uint64_t kb = a.cls_len ? a.cls_kb[r0 + r] : a.kmer_base[r0 + r];
+            int l = a.cls_len ? a.cls_len[r0 + r] : (int)(a.kmer_base[r0 + r + 1] - kb) + e.g.K - 1;
             if (l > (int)a.max_len || l < e.g.K + 1) { atomicOr(&ctr->e2_flags, F_LEN); l = 0; }      // (a read without k-mers from here on; the batch fails in e2_count)
             rkb[r] = kb; rlen[r] = l;
         }
@@ -1233,6 +1237,8 @@ void e2_destroy(pg_ctx* c) {
     if (s.chunk_tbl) (void)pg::arena_free(s.chunk_tbl);
     if (s.pool) (void)pg::arena_free(s.pool);
     if (s.out) (void)pg::arena_free(s.out);
+    if (s.rg_perm) (void)pg::arena_free(s.rg_perm);
+    if (s.rg_hist) (void)pg::arena_free(s.rg_hist);
     s = E2();
 }
 
@@ -1389,6 +1395,51 @@ __global__ __launch_bounds__(BLOCK) void ragged_max_kernel(const uint64_t* __res
     for (int o = 32; o; o >>= 1) mx = max(mx, (unsigned long long)__shfl_xor((unsigned long long)mx, o));
     if ((threadIdx.x & 63) == 0 && mx) atomicMax(&ctr->ragged_max, mx);
 }
+// ---- ragged batches by LENGTH CLASS.  A tile's rows are as long as its longest read needs, and a read of 100 bases in a tile sized for 150 leaves a
+// third of its lanes idle in every phase: the trimmed reads of round 6's first build cost 1.32 - 1.35 x the uniform reads per BASE.  The order in which
+// reads are cut does not matter to anything (a record carries its ordinal, a partition's records arrive in any order anyway), so a batch is cut class by
+// class: class = segments of S k-mers a read has; a counting sort of the batch's reads by class (a histogram, one host wait for its 32 counters, a
+// scatter) gathers every class's start words, first k-mers and lengths into rows of its own, and every class is a launch of its own with tiles for ITS longest read.
+// (A first form handed the cutter a permutation instead: one more dependent load in front of every tile, 75.6 ms against 65.3 without classes.)
+constexpr int RG_CLASSES = 32;
+__global__ __launch_bounds__(BLOCK) void ragged_class_hist(const uint64_t* __restrict__ kmer_base, uint64_t n_reads, uint32_t S, unsigned int* hist) {
+    __shared__ unsigned int h[RG_CLASSES];
+    if (threadIdx.x < RG_CLASSES) h[threadIdx.x] = 0;
+    __syncthreads();
+    for (uint64_t r = (uint64_t)blockIdx.x * BLOCK + threadIdx.x; r < n_reads; r += (uint64_t)gridDim.x * BLOCK) {
+        const uint64_t k = kmer_base[r + 1] - kmer_base[r];
+        atomicAdd(&h[max(1u, min((uint32_t)((k + S - 1) / S), (uint32_t)RG_CLASSES - 1u))], 1u);      // (a read without k-mers is flagged by the cutter: with the shortest)
+    }
+    __syncthreads();
+    if (threadIdx.x < RG_CLASSES && h[threadIdx.x]) atomicAdd(&hist[threadIdx.x], h[threadIdx.x]);
+}
+// cursor[c] starts at the class's first place in perm; a workgroup reserves its reads of a class with one atomic
+__global__ __launch_bounds__(BLOCK) void ragged_class_scatter(const uint64_t* __restrict__ kmer_base, const uint64_t* __restrict__ word_off, uint64_t n_reads, uint32_t S, int K,
+                                                             unsigned int* cursor, uint64_t* cls_off, uint64_t* cls_kb, int32_t* cls_len) {
+    __shared__ unsigned int h[RG_CLASSES], base[RG_CLASSES];
+    for (uint64_t r0 = (uint64_t)blockIdx.x * BLOCK; r0 < n_reads; r0 += (uint64_t)gridDim.x * BLOCK) {
+        if (threadIdx.x < RG_CLASSES) h[threadIdx.x] = 0;
+        __syncthreads();
+        const uint64_t r = r0 + threadIdx.x;
+        uint32_t cls = 0, my = 0;
+        if (r < n_reads) {
+            const uint64_t k = kmer_base[r + 1] - kmer_base[r];
+            cls = max(1u, min((uint32_t)((k + S - 1) / S), (uint32_t)RG_CLASSES - 1u));
+            my = atomicAdd(&h[cls], 1u);
+        }
+        __syncthreads();
+        if (threadIdx.x < RG_CLASSES && h[threadIdx.x]) base[threadIdx.x] = atomicAdd(&cursor[threadIdx.x], h[threadIdx.x]);
+        __syncthreads();
+        if (r < n_reads) {                                            // the class's rows: a launch reads them as it reads a batch's (no indirection in the cutter)
+            const unsigned int at = base[cls] + my;
+            cls_off[at] = word_off[r];
+            cls_kb[at] = kmer_base[r];
+            cls_len[at] = (int32_t)(kmer_base[r + 1] - kmer_base[r]) + K - 1;
+        }
+        __syncthreads();
+    }
+}
+
 // (PG_K1_RAGGED=0 in a -DPG_MEASURE build: ragged batches through the one-lane-a-read kernel, the round-5 form, for the A/B)
 static bool ragged_tiles_wanted() {
     if (const char* v = env_measure("PG_K1_RAGGED")) return atoi(v) != 0;
@@ -1412,6 +1463,56 @@ static int ragged_geometry(pg_ctx* c, ReadsArg& a, hipStream_t st) {
     return PG_OK;
 }
 
+// a ragged batch through the tiles, class by class (see ragged_class_hist); returns what launch_tiled returns
+static int launch_ragged_by_class(pg_ctx* c, const ReadsArg& a, const RouteArg* route, hipStream_t st) {
+    E2& s = c->e2;
+    // Built and measured in round 6, and NOT the product's form (PG_K1_CLASSES=1 in a -DPG_MEASURE build runs it): 200 M reads trimmed to 100 - 150 bp, K1 per pass
+    // 65.1 ms as the batches lie, 67.9 ms class by class with gathered rows, 75.6 ms through a permutation (profiles/r06_k1_ragged_length_classes_ab.json) --
+    // the idle lanes of a padded tile are not what a trimmed batch pays for; the sort, its host wait and five launches a batch cost more than they save.
+    bool by_class = false;
+    if (const char* v = env_measure("PG_K1_CLASSES")) by_class = atoi(v) != 0 && a.n_reads >= 4096 && a.n_reads < 0xFFFFFFFFull;
+    if (!by_class) return launch_tiled(c, a, route, st);
+    int S = tile_pick_segment((int)a.kpr, s.g.w);
+    if (const char* v = env_measure("PG_K1_S")) { const int q = atoi(v); if (q >= 7 && q <= 15 && (q & 1) && (q <= s.g.w || q == 7)) S = q; }
+    if (!s.rg_hist) E2_TRY(pg::arena_malloc(&s.rg_hist, 2 * RG_CLASSES * sizeof(unsigned int)));
+    E2_TRY(hipMemsetAsync(s.rg_hist, 0, RG_CLASSES * sizeof(unsigned int), st));
+    const unsigned grid = (unsigned)std::min<uint64_t>((a.n_reads + BLOCK - 1) / BLOCK, 4096);
+    hipLaunchKernelGGL(ragged_class_hist, dim3(grid), dim3(BLOCK), 0, st, a.kmer_base, a.n_reads, (uint32_t)S, s.rg_hist);
+    E2_TRY(hipGetLastError());
+    unsigned int h[RG_CLASSES], first[RG_CLASSES];
+    E2_TRY(hipMemcpyAsync(h, s.rg_hist, sizeof h, hipMemcpyDeviceToHost, st));
+    E2_TRY(hipStreamSynchronize(st));
+    int used = 0;
+    for (int q = 0; q < RG_CLASSES; q++) used += h[q] != 0;
+    if (used <= 1) return launch_tiled(c, a, route, st);               // one class: the batch as it lies
+    if (a.n_reads > s.rg_perm_cap) {                                   // 20 bytes a read: start word, first k-mer, length
+        if (s.rg_perm) E2_TRY(pg::arena_free(s.rg_perm));
+        s.rg_perm = nullptr;
+        s.rg_perm_cap = a.n_reads + a.n_reads / 4;
+        E2_TRY(pg::arena_malloc(&s.rg_perm, s.rg_perm_cap * 20));
+    }
+    uint64_t* const cls_off = (uint64_t*)s.rg_perm;
+    uint64_t* const cls_kb = cls_off + s.rg_perm_cap;
+    int32_t* const cls_len = (int32_t*)(cls_kb + s.rg_perm_cap);
+    unsigned int at = 0;
+    for (int q = 0; q < RG_CLASSES; q++) { first[q] = at; at += h[q]; }
+    E2_TRY(hipMemcpyAsync(s.rg_hist + RG_CLASSES, first, sizeof first, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(ragged_class_scatter, dim3(grid), dim3(BLOCK), 0, st, a.kmer_base, a.word_off, a.n_reads, (uint32_t)S, c->K, s.rg_hist + RG_CLASSES, cls_off, cls_kb, cls_len);
+    E2_TRY(hipGetLastError());
+    E2_TRY(hipStreamSynchronize(st));                                  // (`first` is on this stack frame)
+    for (int q = RG_CLASSES - 1; q >= 1; q--) {                        // the longest first: if ITS tile does not fit, nothing has been launched yet
+        if (!h[q]) continue;
+        ReadsArg b = a;
+        const uint32_t len_q = q == RG_CLASSES - 1 ? a.max_len : std::min<uint32_t>(a.max_len, (uint32_t)q * (uint32_t)S + (uint32_t)c->K - 1);
+        b.word_off = cls_off + first[q]; b.cls_kb = cls_kb + first[q]; b.cls_len = cls_len + first[q];
+        b.n_reads = h[q];
+        b.max_len = len_q; b.kpr = len_q - c->K + 1; b.wpr = (len_q + 31) / 32;
+        const int rc = launch_tiled(c, b, route, st);
+        if (rc) return rc;
+    }
+    return PG_OK;
+}
+
 // multi-GPU step 1: cut a batch into records grouped by owner (partition mod n_owners).  Uniform batches go through the
 // tiled kernel, ragged ones (d_word_off / d_kmer_base given) through the one-lane-per-read kernel.
 int e2_route(pg_ctx* c, const uint64_t* d_packed, const uint64_t* d_word_off, const uint64_t* d_kmer_base, uint64_t n_reads,
@@ -1425,12 +1526,12 @@ int e2_route(pg_ctx* c, const uint64_t* d_packed, const uint64_t* d_word_off, co
     if ((ord_base >> (64 - SKM_ORD_SHIFT)) != 0) { pg_set_error("ordinal exceeds the 46 bits of a super-k-mer header"); return PG_EINVAL; }
     ReadsArg a;
     a.packed = d_packed; a.word_off = d_word_off; a.kmer_base = d_kmer_base; a.n_reads = n_reads; a.uniform_len = uniform_len;
-    a.kpr = uniform_len ? uniform_len - c->K + 1 : 0; a.wpr = uniform_len ? (uniform_len + 31) / 32 : 0; a.ord_base = ord_base; a.max_len = 0;
+    a.kpr = uniform_len ? uniform_len - c->K + 1 : 0; a.wpr = uniform_len ? (uniform_len + 31) / 32 : 0; a.ord_base = ord_base; a.max_len = 0; a.cls_kb = nullptr; a.cls_len = nullptr;
     E2_TRY(hipMemsetAsync(d_counts, 0, sizeof(uint64_t) * n_owners, st));
     RouteArg ro{d_recs, d_pids, (unsigned long long*)d_counts, cap, n_owners};
     if (!uniform_len && ragged_tiles_wanted()) { int rc = ragged_geometry(c, a, st); if (rc) return rc; }
     if ((uniform_len && uniform_len < 4096 && (int)a.kpr < 4096) || a.max_len) {
-        int rc = launch_tiled(c, a, &ro, st);
+        int rc = a.max_len ? launch_ragged_by_class(c, a, &ro, st) : launch_tiled(c, a, &ro, st);
         if (rc != 1) return rc;
     }
     return launch_serial(c, a, &ro, st);
@@ -1478,12 +1579,13 @@ int e2_scatter(pg_ctx* c, const uint64_t* d_packed, const uint64_t* d_word_off, 
     a.wpr = uniform_len ? (uniform_len + 31) / 32 : 0;
     a.ord_base = ord_base;
     a.max_len = 0;
+    a.cls_kb = nullptr; a.cls_len = nullptr;
     if (!uniform_len && ragged_tiles_wanted()) { int rc = ragged_geometry(c, a, st); if (rc) return rc; }
     // tiled kernel for the batches whose per-read LDS footprint fits (ragged ones: rows for their longest read)
     int tiled = (uniform_len && uniform_len < 4096 && (int)a.kpr < 4096) || a.max_len;
     if (const char* v = env_measure("PG_K1")) tiled = tiled && atoi(v) != 0;
     if (tiled) {
-        int rc = launch_tiled(c, a, nullptr, st);
+        int rc = a.max_len ? launch_ragged_by_class(c, a, nullptr, st) : launch_tiled(c, a, nullptr, st);
         if (rc != 1) return rc;
     }
     return launch_serial(c, a, nullptr, st);
