@@ -142,6 +142,16 @@ def whole_command(args, cores):
             cpu = {"value": n / sec, "unit": "reads/s", "cores": cores, "kind": "reference",
                    "sample": f"{n} reads x {args.read_len} bp, genome {args.genome}, err {args.err}, K={args.kmer}, -p {cores}: pass 1 ('Time spent on hashing "
                              f"reads') {sec:.0f} s of {rwall:.0f} s whole command", "whole_command_reads_per_sec": n / rwall}
+            # the same reference binary on the headline workload at its FULL size (it cannot run inside a bench: 50 minutes): the committed run of the build
+            # container, whose md5s the 200 M-read leg below is held against
+            try:
+                fr = json.load(open(os.path.join(ROOT, "profiles", "r04_ref_200M_K63_a40.json")))
+                hs = next((float(re.search(r"hashing reads: (\d+)s", l).group(1)) for l in fr.get("log", []) if "hashing reads" in l), None)
+                cpu["full_size_reference"] = {"reads": fr["workload"]["reads"], "read_len": fr["workload"]["read_len"], "K": fr["workload"]["kmer"], "threads": fr["workload"]["sets"],
+                                              "whole_command_s": fr.get("reference_wall_s"), "pass1_s": hs,
+                                              "pass1_reads_per_sec": fr["workload"]["reads"] / hs if hs else None, "where": "the build container's 8 cores (profiles/r04_ref_200M_K63_a40.json)"}
+            except Exception:
+                pass
             wc["reference_wall_s"] = rwall
             wc["reference_threads"] = cores
             wc["speedup_vs_reference"] = rwall / wall if out.returncode == 0 else None
@@ -164,7 +174,8 @@ def big_command(args):
     (profiles/r0*_ref_*.json): 60 M reads at K = 63 with -a 16 (static pools) and with the default growable sets -- either way the
     k-mer-set layout is made on the device (SURVEY.md App. C "K6": dev_graph.hpp / dev_rehash.hpp); 20 M reads at K = 127 (the
     SOAPdenovo-127mer flavour, configs[4]'s path); configs[2] at its full 200 M reads with -a 40.
-    BASELINE.json configs[1] at its full size (10 M x 100 bp over 4.6 Mb, err 0.005, K = 31, -p 8; the reference: profiles/r05_ref_10M_K31.json).
+    BASELINE.json configs[1] at its full size (10 M x 100 bp over 4.6 Mb, err 0.005, K = 31, -p 8; the reference: profiles/r05_ref_10M_K31.json -- the reads are
+    scripts/synth_fastq.cpp's at seed 7, 95 807 825 distinct k-mers, not SURVEY.md's numpy draw of the same model (95 803 852): the reference was run on THIS file).
     Returns {"whole_command_10M_k31": {...}, "whole_command_60M_a16": {...}, "whole_command_60M": {...}, "whole_command_k127_20M": {...}, "whole_command_200M_a40": {...},
     "whole_command_20M_ragged": {...}}."""
     groups = [[("whole_command_10M_k31", "r05_ref_10M_K31.json")],
@@ -835,10 +846,10 @@ def main():
                     traffic = None
             # `bound` names the roofline the contract prices this path against (HBM bytes of a hash-table
             # formulation).  The kernel itself moves 0.15x those bytes and is limited elsewhere, see `limiter`.
-            limiter = ("instruction issue at four waves a SIMD: ~185 wave-level vector instructions per read (0.42 of the issue rate), SQ_WAIT_ANY 0.63 of the wave cycles -- dependent LDS "
-                       "round trips between six workgroup barriers a partition (the 88 KB LDS set allows one 1024-lane workgroup per CU), 0.84 bank-conflict cycles per LDS issue cycle on the "
-                       "random 8-byte accesses; HBM ~7 % of peak (profiles/r05_final_pmc_sq_200M_K63.json, profiles/pmc_traffic.json, profiles/r05_final_k2_phase_cycles_200M_K63.txt, "
-                       "DESIGN.md 3)") if engine == 2 else "random-atomic rate of the DRAM-resident set"
+            limiter = ("instruction issue at four waves a SIMD: ~182 wave-level vector instructions per read (0.48 of the issue rate), SQ_WAIT_ANY 0.60 of the wave cycles -- dependent LDS "
+                       "round trips between five workgroup barriers a partition (the 88 KB LDS set allows one 1024-lane workgroup per CU; a workgroup's occurrence phase ends with its longest "
+                       "probe sequence), 0.97 bank-conflict cycles per LDS issue cycle on the random 8-byte accesses; HBM ~8 % of peak (profiles/r06_final_pmc_sq_200M_K63.json, "
+                       "profiles/pmc_traffic.json, profiles/r06_final_k2_phase_cycles_200M_K63.txt, DESIGN.md 3)") if engine == 2 else "random-atomic rate of the DRAM-resident set"
             # what the counters say about the same launch: PMC bytes / launch time against the same peak (never `frac`)
             counter_frac = (traffic / (avg_ms * 1e-3) / 1e9 / 8000.0) if traffic else None
             if engine == 2:
