@@ -16,6 +16,9 @@ HIPFLAGS += -DPG_MEASURE
 ifneq ($(K2_LOOK),)
 HIPFLAGS += -DPG_K2_LOOK=$(K2_LOOK)
 endif
+ifneq ($(XDEF),)
+HIPFLAGS += -D$(XDEF)
+endif
 else
 O       := o
 LIBNAME := libsoapdenovo2_amd.so
