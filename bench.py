@@ -181,7 +181,8 @@ def big_command(args):
     groups = [[("whole_command_10M_k31", "r05_ref_10M_K31.json")],
               [("whole_command_60M_a16", "r03_ref_60M_K63_a16.json"), ("whole_command_60M", "r03_ref_60M_K63.json")],
               [("whole_command_k127_20M", "r04_ref_20M_K127.json")],
-              [("whole_command_200M_a40", "r04_ref_200M_K63_a40.json")],
+              # (round 6: configs[2] at its full size with GROWABLE sets too -- the layout of 143 M-key sets through every size they live through, on the device)
+              [("whole_command_200M_a40", "r04_ref_200M_K63_a40.json"), ("whole_command_200M_a0", "r06_ref_200M_K63_a0.json")],
               # round 6: trimmed reads, lengths uniform in [100, 150] (synth_fastq's min_len) -- every batch ragged, cut by the tiled K1 and
               # threaded by pass 2 where pass 1 left them; the reference chops reads of any length alike (prlHashReads.c:163-259,642-648)
               [("whole_command_20M_ragged", "r06_ref_20M_ragged_K63.json")]]

@@ -41,6 +41,13 @@ def case_tag(name, run):
     return f"{name}_p{P}_d{D}_a{a}_{'127' if m else '63'}"
 
 
+def host_runs(case):
+    """The runs of a golden case the CPU twins of the graph stages go through: -p up to 8.  The runs with -p 16 / 37 / 64 / 255 (round 6) are held against the
+    reference by the oracle (tests/test_oracle_golden.py) and by the device path and the executable (-m gpu); through the host twins they only repeat the same
+    code with more, emptier sets -- and took the CPU suite from 20 to 32 minutes (a -a pool of 37 sets is 15 GB of host memory)."""
+    return [r for r in case["runs"] if r[0] <= 8]
+
+
 def md5_file(path):
     return hashlib.md5(open(path, "rb").read()).hexdigest()
 

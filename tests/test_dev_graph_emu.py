@@ -5,7 +5,7 @@ import ctypes as C
 import numpy as np
 import pytest
 
-from conftest import case_codes, oracle_records
+from conftest import case_codes, oracle_records, host_runs
 from soapdenovo2_amd import api
 
 EMPTY = np.uint64(0xFFFFFFFFFFFFFFFF)
@@ -117,7 +117,7 @@ def test_device_tip_decisions_equal_the_sequential_scan(golden, tmp_path, name, 
     monkeypatch.setenv("PG_EMU_PLACES", str(places))
     c = golden["cases"][name]
     codes = case_codes(c)
-    for run in c["runs"]:
+    for run in host_runs(c):
         P, D, a, m = run
         rec, last, K = oracle_records(codes, c["K"], P, D=D, mer127=bool(m), a_gb=a, prefix=str(tmp_path / "o"))
         rec = np.ascontiguousarray(rec)

@@ -6,7 +6,7 @@ import os
 import numpy as np
 import pytest
 
-from conftest import case_codes, case_tag, md5_file, md5_gz_text, oracle_records
+from conftest import case_codes, case_tag, md5_file, md5_gz_text, oracle_records, host_runs
 from soapdenovo2_amd import api
 
 CASES = ["t6k_k31", "t8k_k63", "t6k_k127", "t5k_k24", "m60k_k63", "d8k_k127", "r8k_k127", "d8k_k63"]
@@ -16,7 +16,7 @@ CASES = ["t6k_k31", "t8k_k63", "t6k_k127", "t5k_k24", "m60k_k63", "d8k_k127", "r
 def test_host_graph_matches_reference(golden, tmp_path, name):
     c = golden["cases"][name]
     codes = case_codes(c)
-    for run in c["runs"]:
+    for run in host_runs(c):
         P, D, a, m = run
         t = case_tag(name, run)
         rec, last, K = oracle_records(codes, c["K"], P, D=D, mer127=bool(m), a_gb=a, prefix=str(tmp_path / ("o_" + t)))

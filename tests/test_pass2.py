@@ -4,7 +4,7 @@ fed with the oracle's pass-1 records and the same reads it must reproduce the re
 import numpy as np
 import pytest
 
-from conftest import case_codes, case_tag, md5_file, md5_gz_text, oracle_records
+from conftest import case_codes, case_tag, md5_file, md5_gz_text, oracle_records, host_runs
 from soapdenovo2_amd import api
 
 
@@ -12,7 +12,7 @@ from soapdenovo2_amd import api
 def test_prearc_matches_reference(golden, tmp_path, name):
     c = golden["cases"][name]
     codes = case_codes(c)
-    for run in c["runs"]:
+    for run in host_runs(c):
         P, D, a, m = run
         t = case_tag(name, run)
         rec, last, K = oracle_records(codes, c["K"], P, D=D, mer127=bool(m), a_gb=a, prefix=str(tmp_path / ("o_" + t)))
@@ -117,7 +117,7 @@ def test_streamed_records_give_the_same_graph(golden, tmp_path, name):
     with the device-sorted records) -- same layout, same files, incl. the -a pools and the trailing-duplicate growth."""
     c = golden["cases"][name]
     codes = case_codes(c)
-    for run in c["runs"]:
+    for run in host_runs(c):
         P, D, a, m = run
         t = case_tag(name, run)
         rec, last, K = oracle_records(codes, c["K"], P, D=D, mer127=bool(m), a_gb=a, prefix=str(tmp_path / ("o_" + t)))
