@@ -65,7 +65,7 @@ extern "C" long long pg_host_emu_arena_blocks(uint64_t seed, uint64_t n_ops, uin
         return used_sum == bl.in_use && sum + used_sum == size && bl.used.size() == live.size();
     };
     for (uint64_t step = 1; step <= n_ops; step++) {
-        const bool cut = live.empty() || (rnd() % 100) < 55;
+        const bool cut = live.empty() || (rnd() % 100) < 50;
         if (cut) {
             uint64_t want = rnd() % 7 == 0 ? (rnd() % max_block) + 1 : (rnd() % (max_block / 64 + 1)) + 1;       // mostly small, now and then large
             if (rnd() % 50 == 0) want = 0;
@@ -76,6 +76,16 @@ extern "C" long long pg_host_emu_arena_blocks(uint64_t seed, uint64_t n_ops, uin
             if (need < std::max<uint64_t>(want, 1) || need % pg::BlockList::ALIGN || off % al || off + need > size) return -(long long)step;
             for (const auto& b : live) if (off < b.first + b.second && b.first < off + need) return -(long long)step;          // overlaps a live block
             live.emplace_back(off, need);
+        } else if (rnd() % 5 == 0) {
+            // a block is cut back to a part of itself (arena_shrink: the export array behind the counting pass): the rest is a hole at once, merged with the hole behind it
+            const size_t i = (size_t)(rnd() % live.size());
+            const size_t keep = (size_t)(rnd() % (live[i].second + 1));
+            const size_t had = live[i].second;
+            const bool did = bl.shrink(live[i].first, keep);
+            const size_t want = pg::BlockList::round_up(keep ? keep : 1, 4096);
+            if (did != (want < had)) return -(long long)step;
+            if (did) live[i].second = want;
+            if (bl.shrink(live[i].first + 1, 1)) return -(long long)step;                                                       // (not a block's start: refused)
         } else {
             const size_t i = (size_t)(rnd() % live.size());
             if (!bl.give_back(live[i].first)) return -(long long)step;

@@ -1,4 +1,4 @@
-"""The device arena's block list (csrc/arena_list.hpp: first fit, coalescing holes) on random sequences -- no GPU needed: the bookkeeping the
+"""The device arena's block list (csrc/arena_list.hpp: first fit, coalescing holes, blocks cut back to a part of themselves) on random sequences -- no GPU needed: the bookkeeping the
 arena (csrc/arena.cpp) cuts every device block of the library with.  pg_host_emu_arena_blocks checks after every step that blocks are aligned,
 inside the range and disjoint, that holes never touch (they merge), that holes + blocks = the range, and that the list is one hole again at the end."""
 import ctypes as C
