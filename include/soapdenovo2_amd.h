@@ -184,6 +184,14 @@ int pg_host_graph_add_packed(pg_graph *g, const uint64_t *words, const int32_t *
  * read_len bases, packed back to back, 8 readable words behind the last -- what pass 1 leaves there when it keeps its batches;
  * no copy, no index arrays.  Not for -R runs (the walks of a read come back through the host path). */
 int pg_graph_add_packed_device(pg_graph *g, const uint64_t *d_words, uint64_t n_reads, int read_len, int device);
+/* ... all the batches pass 1 left there at once (n_segs segments of seg_reads[0] reads each, the last may hold fewer; host arrays of device
+ * pointers / counts): one launch threads them sorted by their smallest hashed 16-mer -- reads of one place of the genome side by side, whose
+ * lookups the L2 then serves -- instead of in file order.  The order reads are threaded in changes nothing (prlRead2path.c:388-403: a pre-arc
+ * list is ordered by the ordinal of the read that met it first, which every read carries).  Measured in round 6 and NOT the default
+ * (SOAPDENOVO2_AMD_P2_SORT=1 asks for it; profiles/r06_p2_genome_order_ab.json): without it, with several lanes or with -R the segments are
+ * threaded one by one in file order, as by pg_graph_add_packed_device. */
+int pg_graph_add_packed_device_segments(pg_graph *g, const uint64_t *const *d_segs, const uint64_t *seg_reads, int n_segs, int read_len,
+                                        int device);
 /* ... and for a ragged batch left there with the index arrays pg_count_reads took (d_word_off[n_reads], d_kmer_base[n_reads + 1];
  * every read has >= K + 1 bases, none more than max_len; n_kmers = d_kmer_base[n_reads]): prlRead2path.c:1056-1110 threads reads of
  * any length, lengths from lenBuffer.  Same restrictions. */

@@ -167,7 +167,7 @@ EXPORTED_SYMBOLS = [
     "pg_comm_transport", "pg_comm_stats", "pg_exchange_counts", "pg_exchange_records", "pg_exchange_allreduce_u64",
     "pg_exchange_gather_records", "pg_count_reads_sharded", "pg_host_skm_cut", "pg_host_skm_expand",
     "pg_host_emu_layout_static", "pg_graph_begin_device", "pg_host_emu_clip_tips", "pg_exchange_regroup_by_set", "pg_comm_regroup_stats", "pg_graph_begin_sharded", "pg_host_regroup_plan", "pg_host_bam_pair_state", "pg_device_scratch_offer", "pg_device_scratch_withdraw", "pg_host_emu_layout_growable", "pg_exchange_regroup_by_set_ws", "pg_host_edge_file_in_background", "pg_graph_add_packed_device", "pg_host_emu_home_slots", "pg_comm_pipeline_stats", "pg_comm_create_host", "pg_comm_flush",
-    "pg_set_read_len_bound", "pg_graph_add_packed_device_ragged", "pg_expect", "pg_host_plan_memory", "pg_create_planned",
+    "pg_set_read_len_bound", "pg_graph_add_packed_device_ragged", "pg_expect", "pg_host_plan_memory", "pg_create_planned", "pg_graph_add_packed_device_segments",
 ]
 
 

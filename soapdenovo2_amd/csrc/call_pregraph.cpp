@@ -1046,7 +1046,14 @@ int run(int argc, char** argv, bool mer127) {
     if (have_kept && !devkept.segs.empty() && !host_pass2) {
         // the reads of pass 1 are still on the device (one segment a batch): threaded where they are
         fprintf(stderr, "In file: %s, max seq len %d, max name len %d.\n", o.config.c_str(), max_read_len, 256);
-        for (const DevKept::Seg& sg : devkept.segs) {
+        bool one_length = true;
+        for (const DevKept::Seg& sg : devkept.segs) one_length = one_length && sg.len != 0 && sg.len == devkept.segs[0].len;
+        if (one_length) {                                              // all of them at once, threaded in genome order (graph_kernels.hip: p2_add_packed_device_segments)
+            std::vector<const uint64_t*> ptrs;
+            std::vector<uint64_t> counts;
+            for (const DevKept::Seg& sg : devkept.segs) { ptrs.push_back(sg.d); counts.push_back(sg.n_reads); }
+            if (pg_graph_add_packed_device_segments(graph, ptrs.data(), counts.data(), (int)ptrs.size(), devkept.segs[0].len, devkept.device) != PG_OK) die("pg_graph_add_packed_device_segments");
+        } else for (const DevKept::Seg& sg : devkept.segs) {
             if (sg.len) { if (pg_graph_add_packed_device(graph, sg.d, sg.n_reads, sg.len, devkept.device) != PG_OK) die("pg_graph_add_packed_device"); }
             else if (pg_graph_add_packed_device_ragged(graph, sg.d, sg.d_off(), sg.d_base(), sg.n_reads, sg.n_kmers, sg.max_len, devkept.device) != PG_OK) die("pg_graph_add_packed_device_ragged");
         }

@@ -94,6 +94,7 @@ void p2_destroy(P2Device* d);
 int p2_add_packed(P2Device* d, const uint64_t* words, const uint64_t* word_off, const int32_t* lens, uint64_t n_reads, uint64_t n_words,
                   uint32_t* walks_out, uint16_t* walk_len_out);
 int p2_add_packed_device(P2Device* d, const uint64_t* d_words, uint64_t n_reads, int read_len, int device);   // reads already on a lane's device, one length, back to back
+int p2_add_packed_device_segments(P2Device* d, const uint64_t* const* d_segs, const uint64_t* seg_reads, int n_segs, int read_len, int device);   // ... all of pass 1's batches at once, threaded in genome order
 int p2_add_packed_device_ragged(P2Device* d, const uint64_t* d_words, const uint64_t* d_word_off, const uint64_t* d_kmer_base, uint64_t n_reads, uint64_t n_kmers,
                                 int device);                                                                    // ... any mix of lengths, with pass 1's index arrays
 // the ranks of a sharded run (lane 0 = the lead's device): the per-set scans run on the owner's lane (set s -> lane s mod n_lanes),

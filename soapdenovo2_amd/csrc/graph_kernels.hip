@@ -214,21 +214,29 @@ __device__ __forceinline__ void p2_thread_end(const P2Params& p, const P2Walk<NW
 // looked up together were built and measured slower (230.9 / 304.9 ms against 222.7 per 60 M reads, profiles/r04a_p2_block_ab.csv) and are gone.
 // (The reference looks every k-mer of its buffer up before it threads any read, prlRead2path.c:159-248; here a read that the state machine
 // gives up is not looked up further.)
+// The reads of a launch in an order of the caller's (round 6: p2_add_packed_device_segments): read i of the launch is read perm[i] of the reads that lie, one
+// length, back to back, in segments of `per_seg` reads each (the batches pass 1 kept on the device).
+struct P2Order { const uint32_t* perm; const uint64_t* const* segs; uint32_t per_seg; };
 template <int NW>
 __global__ __launch_bounds__(256) void p2_thread_kernel(P2Params p, const uint64_t* __restrict__ words, const uint64_t* __restrict__ word_off,
-                                                        const int32_t* __restrict__ lens, uint64_t n_reads, uint64_t first_ordinal, int uniform_len) {
+                                                        const int32_t* __restrict__ lens, uint64_t n_reads, uint64_t first_ordinal, int uniform_len, P2Order order) {
     __shared__ uint32_t crc4[4 * 256];
     __shared__ uint64_t set_geo[SV_GEO * P2_MAX_SETS];
     for (int i = threadIdx.x; i < 1024; i += 256) crc4[i] = crc32_slice_entry(i >> 8, i & 255);
     for (int i = threadIdx.x; i < SV_GEO * (int)p.P; i += 256) set_geo[i] = p.geo3[i];
     __syncthreads();
-    const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_reads) return;
+    const uint64_t r_launch = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r_launch >= n_reads) return;
+    const uint64_t r = order.perm ? (uint64_t)order.perm[r_launch] : r_launch;     // the read's place in read order: its ordinal, its row of walks
     const int K = p.K;
     const int len = uniform_len ? uniform_len : lens[r];                 // (uniform_len: reads of one length back to back, no index arrays)
     if (p.walk_len) p.walk_len[r] = 0;
     if (len < K + 1) return;                                             // prlRead2path.c:1103
-    const uint64_t* rd = words + (uniform_len ? r * (uint64_t)((uniform_len + 31) / 32) : word_off[r]);
+    const uint64_t* rd;
+    if (order.perm) {
+        const uint32_t sg = (uint32_t)(r / order.per_seg);
+        rd = order.segs[sg] + (r - (uint64_t)sg * order.per_seg) * (uint64_t)((uniform_len + 31) / 32);
+    } else rd = words + (uniform_len ? r * (uint64_t)((uniform_len + 31) / 32) : word_off[r]);
     const Kmer<NW> filter = kmer_filter<NW>(K);
     const int nk = len - K + 1;
     uint32_t* row = p.stage ? p.stage + r * (uint64_t)p.max_nk : nullptr;
@@ -264,10 +272,23 @@ __global__ __launch_bounds__(256) void p2_thread_kernel(P2Params p, const uint64
     p2_thread_end<NW>(p, w, row, r);
 }
 static void p2_launch_thread_kernel(int nw, dim3 grid, hipStream_t st, const P2Params& p, const uint64_t* words, const uint64_t* word_off, const int32_t* lens,
-                                    uint64_t n_reads, uint64_t first_ordinal, int uniform_len) {
+                                    uint64_t n_reads, uint64_t first_ordinal, int uniform_len, P2Order order = P2Order{nullptr, nullptr, 0}) {
     const dim3 block(256);
-    if (nw == 2) hipLaunchKernelGGL((p2_thread_kernel<2>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len);
-    else hipLaunchKernelGGL((p2_thread_kernel<4>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len);
+    if (nw == 2) hipLaunchKernelGGL((p2_thread_kernel<2>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len, order);
+    else hipLaunchKernelGGL((p2_thread_kernel<4>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len, order);
+}
+// a read's place in the genome, as far as a read can tell: its smallest hashed canonical 16-mer (the partition engine's m-mer hash, skm.hpp).  Reads that
+// overlap share it when it lies in their overlap -- at 30 x coverage some 130 reads have the same one, and between them they look up the same few hundred k-mers.
+__global__ __launch_bounds__(256) void p2_read_place_keys(const uint64_t* const* segs, uint32_t per_seg, uint64_t n_reads, int read_len, uint32_t* keys, uint32_t* idx) {
+    const uint64_t r = (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (r >= n_reads) return;
+    const uint32_t sg = (uint32_t)(r / per_seg);
+    const uint64_t* rd = segs[sg] + (r - (uint64_t)sg * per_seg) * (uint64_t)((read_len + 31) / 32);
+    const int m = read_len < 16 ? read_len : 16;
+    uint32_t best = 0xFFFFFFFFu;
+    for (int q = 0; q + m <= read_len; q++) { const uint32_t v = mmer_value(rd, q, m); best = v < best ? v : best; }
+    keys[r] = best;
+    idx[r] = (uint32_t)r;
 }
 
 // ---- pass 2, routed: the lookups go to the sets' owners ---------------------------------------------------------------------------------
@@ -2265,6 +2286,62 @@ int p2_add_packed_device(P2Device* d, const uint64_t* d_words, uint64_t n_reads,
     ln->reads += n_reads; ln->batches++;
     P2_HIP(hipSetDevice(d->device));
     return PG_OK;
+}
+
+// All of them at once, in GENOME order as far as a read can tell (round 6).  Pass 2 is bound by the random lines its lookups ask HBM for: 17.6 G lookups x 1.6
+// lines at 200 M reads, every one of them somewhere else in 45 GB of k-mer sets, because reads come in file order.  But nothing of pass 2 depends on the order
+// reads are threaded in -- a pre-arc carries the ordinal of the read that met it first, a read's walk goes to its own row -- so the reads are threaded sorted by
+// their smallest hashed 16-mer (p2_read_place_keys): a workgroup's 256 reads then come from two or three places of the genome and ask for the same few hundred
+// k-mers, which the L2 serves.  n_segs segments of per_seg reads each (the last may hold fewer), one length, on `device`.
+int p2_add_packed_device_segments(P2Device* d, const uint64_t* const* d_segs, const uint64_t* seg_reads, int n_segs, int read_len, int device) {
+    if (!d->reads_ready) { pg_set_error("pass 2: p2_begin_reads was not called"); return PG_ESTATE; }
+    if (n_segs < 1 || !d_segs || !seg_reads || read_len < 1) { pg_set_error("pass 2: bad argument"); return PG_EINVAL; }
+    uint64_t total = 0;
+    bool even = true;
+    for (int q = 0; q < n_segs; q++) { total += seg_reads[q]; even = even && (q == n_segs - 1 ? seg_reads[q] <= seg_reads[0] : seg_reads[q] == seg_reads[0]) && seg_reads[q] > 0; }
+    // NOT the default (SOAPDENOVO2_AMD_P2_SORT=1 asks for it): measured at 200 M reads, p2_thread_kernel 666 ms in one sorted launch against 720 ms in 120 launches in file
+    // order, + 61 ms for the keys + the sort -- nothing gained (profiles/r06_p2_genome_order_ab.json).  The lanes of a workgroup meet a shared k-mer up to 135 steps apart, a
+    // millisecond at this kernel's pace, and an XCD's 4 MB of L2 turn over every 12 us under the misses of everybody else: the reuse is there, not the residency.
+    const char* sw = pg::env_user("SOAPDENOVO2_AMD_P2_SORT");
+    const bool sorted = sw && atoi(sw) != 0 && even && total < 0xFFFFFFFFull && total >= 4096 && d->lanes.size() == 1 && !d->route && !d->reps &&
+                        d->lanes[0].device == device && read_len >= d->K + 1 && seg_reads[0] < 0xFFFFFFFFull;
+    if (!sorted) {                                                  // segment by segment, in file order (the round-5 form; also what several lanes take)
+        for (int q = 0; q < n_segs; q++) { const int rc = p2_add_packed_device(d, d_segs[q], seg_reads[q], read_len, device); if (rc) return rc; }
+        return PG_OK;
+    }
+    P2Lane& ln = d->lanes[0];
+    P2_HIP(hipSetDevice(ln.device));
+    int rc = PG_OK;
+    uint32_t *keys = nullptr, *keys2 = nullptr, *idx = nullptr, *perm = nullptr;
+    const uint64_t** d_table = nullptr;
+    void* tmp = nullptr;
+    size_t tmp_bytes = 0;
+    hipStream_t st = ln.stream;
+    const unsigned grid = (unsigned)((total + 255) / 256);
+    P2_HIP_GOTO(pg::arena_malloc((void**)&d_table, (size_t)n_segs * sizeof(uint64_t*)));
+    P2_HIP_GOTO(hipMemcpyAsync(d_table, d_segs, (size_t)n_segs * sizeof(uint64_t*), hipMemcpyHostToDevice, st));
+    P2_HIP_GOTO(pg::arena_malloc((void**)&keys, total * 4)); P2_HIP_GOTO(pg::arena_malloc((void**)&keys2, total * 4));
+    P2_HIP_GOTO(pg::arena_malloc((void**)&idx, total * 4)); P2_HIP_GOTO(pg::arena_malloc((void**)&perm, total * 4));
+    P2_HIP_GOTO((rocprim::radix_sort_pairs<rocprim::default_config, uint32_t*, uint32_t*, uint32_t*, uint32_t*, size_t>(nullptr, tmp_bytes, keys, keys2, idx, perm, (size_t)total, 0u, 32u, st)));
+    P2_HIP_GOTO(pg::arena_malloc(&tmp, tmp_bytes));
+    hipLaunchKernelGGL(p2_read_place_keys, dim3(grid), dim3(256), 0, st, (const uint64_t* const*)d_table, (uint32_t)seg_reads[0], total, read_len, keys, idx);
+    P2_HIP_GOTO(hipGetLastError());
+    P2_HIP_GOTO((rocprim::radix_sort_pairs<rocprim::default_config, uint32_t*, uint32_t*, uint32_t*, uint32_t*, size_t>(tmp, tmp_bytes, keys, keys2, idx, perm, (size_t)total, 0u, 32u, st)));
+    {
+        P2Params p = ln.prm;
+        p.stage = nullptr; p.walk_len = nullptr;
+        p2_launch_thread_kernel(d->nw, dim3(grid), st, p, nullptr, nullptr, nullptr, total, d->ordinal, read_len, P2Order{perm, (const uint64_t* const*)d_table, (uint32_t)seg_reads[0]});
+        P2_HIP_GOTO(hipGetLastError());
+    }
+    P2_HIP_GOTO(hipStreamSynchronize(st));
+    d->ordinal += total;
+    ln.reads += total; ln.batches += (uint64_t)n_segs;
+    if (pg::env_user("PG_HOST_VERBOSE")) fprintf(stderr, "pass 2: %llu read(s) of %d segment(s) threaded in one launch, sorted by their smallest hashed 16-mer\n", (unsigned long long)total, n_segs);
+done:
+    if (rc) (void)hipStreamSynchronize(st);
+    pg::arena_free(tmp); pg::arena_free(keys); pg::arena_free(keys2); pg::arena_free(idx); pg::arena_free(perm); pg::arena_free((void*)d_table);
+    P2_HIP(hipSetDevice(d->device));
+    return rc;
 }
 
 // ... and for reads of ANY mix of lengths that pass 1 left on the device with their index arrays (the ragged batches of

@@ -1713,6 +1713,7 @@ struct GraphHandleBase {
     virtual int add_reads(const uint8_t* codes, const int32_t* lens, uint64_t n, uint64_t stride, int n_threads) = 0;
     virtual int add_packed(const uint64_t* words, const int32_t* lens, uint64_t n, int n_threads) = 0;
     virtual int add_packed_device(const uint64_t* d_words, uint64_t n, int read_len, int device) = 0;
+    virtual int add_packed_device_segments(const uint64_t* const* d_segs, const uint64_t* seg_reads, int n_segs, int read_len, int device) = 0;
     virtual int add_packed_device_ragged(const uint64_t* d_words, const uint64_t* d_word_off, const uint64_t* d_kmer_base, uint64_t n, uint64_t n_kmers, int max_len, int device) = 0;
     virtual int finish(long long* n_arcs) = 0;
     virtual int resolve_repeats(int on) = 0;
@@ -2181,6 +2182,19 @@ struct GraphHandle : GraphHandleBase {
         rc = p2_add_packed_device(dev, d_words, n, read_len, device);      // (a lane of the graph on that device, or an error)
         if (rc) return rc;
         reads_seen += (long long)n;
+        t_thread += now() - t0;
+        return PG_OK;
+    }
+    int add_packed_device_segments(const uint64_t* const* d_segs, const uint64_t* seg_reads, int n_segs, int read_len, int device) override {
+        if (!dev_on) { pg_set_error("pg_graph_add_packed_device_segments: the graph is not on a device (pg_graph_use_device first)"); return PG_ESTATE; }
+        if (path_fp) { pg_set_error("pg_graph_add_packed_device_segments: not with -R (the walks come back through the host path)"); return PG_ESTATE; }
+        if (read_len - g.K + 1 > max_nk()) { pg_set_error("a read is longer than the maximum read length given at pg_host_graph_begin"); return PG_EINVAL; }
+        const double t0 = now();
+        int rc = dev_begin();
+        if (rc) return rc;
+        rc = p2_add_packed_device_segments(dev, d_segs, seg_reads, n_segs, read_len, device);
+        if (rc) return rc;
+        for (int q = 0; q < n_segs; q++) reads_seen += (long long)seg_reads[q];
         t_thread += now() - t0;
         return PG_OK;
     }
@@ -2694,6 +2708,10 @@ extern "C" int pg_host_graph_add_packed(pg_graph* g, const uint64_t* words, cons
 extern "C" int pg_graph_add_packed_device(pg_graph* g, const uint64_t* d_words, uint64_t n_reads, int read_len, int device) {
     if (!g || (!d_words && n_reads) || read_len < 1) { pg_set_error("bad argument"); return PG_EINVAL; }
     return ((pg::GraphHandleBase*)g)->add_packed_device(d_words, n_reads, read_len, device);
+}
+extern "C" int pg_graph_add_packed_device_segments(pg_graph* g, const uint64_t* const* d_segs, const uint64_t* seg_reads, int n_segs, int read_len, int device) {
+    if (!g || !d_segs || !seg_reads || n_segs < 1 || read_len < 1) { pg_set_error("bad argument"); return PG_EINVAL; }
+    return ((pg::GraphHandleBase*)g)->add_packed_device_segments(d_segs, seg_reads, n_segs, read_len, device);
 }
 extern "C" int pg_graph_add_packed_device_ragged(pg_graph* g, const uint64_t* d_words, const uint64_t* d_word_off, const uint64_t* d_kmer_base, uint64_t n_reads,
                                                 uint64_t n_kmers, int max_len, int device) {
