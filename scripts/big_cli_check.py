@@ -15,7 +15,7 @@ import argparse, gzip, hashlib, json, os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 GEN = os.path.join(ROOT, "soapdenovo2_amd", "bin", "synth_fastq")
-KEEP = ("[cli]", "finish: waited", "pass 2 routed", "pass 2 direct", "graph lane", "arena (", "Time spent on", "replay set", "node(s) allocated", "edge(s)", "pre-arc", "again", "reader:", "tip scan", "tips decided", "edges:", "layout", "vertex")
+KEEP = ("sharded:", "[cli]", "finish: waited", "pass 2 routed", "pass 2 direct", "graph lane", "arena (", "Time spent on", "replay set", "node(s) allocated", "edge(s)", "pre-arc", "again", "reader:", "tip scan", "tips decided", "edges:", "layout", "vertex")
 
 
 def md5s(prefix):

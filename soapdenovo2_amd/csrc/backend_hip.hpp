@@ -70,6 +70,29 @@ struct HipBackend {
     void* pinned = nullptr;                       // 256 bytes of page-locked host memory: the fixed points read a counter or two per round
     double t_readback = 0;                        // seconds spent in small read-backs (copy + wait), for the verbose lines
     unsigned long long n_readback = 0;
+    // PG_HOST_VERBOSE with several places: the device time of the steps that run on the LEAD alone (launch, sort_pairs, the scans) against the steps
+    // dealt to the places -- an event before and behind every step, read when the stage is over (lead_share)
+    bool timing = false;
+    struct Timed { hipEvent_t a, b; int place; };      // place -1: the lead alone
+    std::vector<Timed> timed;
+    void tick_begin(int pl, hipStream_t st, hipEvent_t& a) { a = nullptr; if (!timing) return; if (hipEventCreate(&a) != hipSuccess) { a = nullptr; return; } (void)pl; (void)hipEventRecord(a, st); }
+    void tick_end(int pl, hipStream_t st, hipEvent_t a) {
+        if (!a) return;
+        hipEvent_t b = nullptr;
+        if (hipEventCreate(&b) != hipSuccess) { (void)hipEventDestroy(a); return; }
+        (void)hipEventRecord(b, st);
+        timed.push_back(Timed{a, b, pl});
+    }
+    // device milliseconds of the lead-only steps and of the steps at every place so far (everything must have been waited for); forgets them
+    void lead_share(double& lead_ms, std::vector<double>& place_ms) {
+        lead_ms = 0; place_ms.assign((size_t)n_places(), 0.0);
+        for (Timed& t : timed) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, t.a, t.b) == hipSuccess) { if (t.place < 0) lead_ms += ms; else if (t.place < (int)place_ms.size()) place_ms[t.place] += ms; }
+            (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b);
+        }
+        timed.clear();
+    }
     HipBackend(int device_, hipStream_t stream_) : device(device_), stream(stream_) {
         (void)hipSetDevice(device);
         if (hipHostMalloc(&pinned, 256, hipHostMallocPortable) != hipSuccess) pinned = nullptr;
@@ -128,7 +151,9 @@ struct HipBackend {
         if (!n || error) return;
         (void)hipSetDevice(dev_at(pl));
         const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 1u << 20);
+        hipEvent_t ev; tick_begin(pl, stream_at(pl), ev);
         hipLaunchKernelGGL(be_launch_kernel<F>, dim3(grid), dim3(256), 0, stream_at(pl), n, f);
+        tick_end(pl, stream_at(pl), ev);
         ok(hipGetLastError(), "launch (at a place)");
         if (pl < (int)launches_at.size()) launches_at[pl]++;
         (void)hipSetDevice(device);
@@ -138,7 +163,9 @@ struct HipBackend {
         if (!n || error) return;
         (void)hipSetDevice(dev_at(pl));
         const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 1u << 20);
+        hipEvent_t ev; tick_begin(pl, stream_at(pl), ev);
         hipLaunchKernelGGL(be_launch_kernel<F>, dim3(grid), dim3(256), 0, stream_at(pl), n, f);
+        tick_end(pl, stream_at(pl), ev);
         ok(hipGetLastError(), "launch (walks at a place)");
         if (pl < (int)walks_at.size()) walks_at[pl] += n;
         (void)hipSetDevice(device);
@@ -148,7 +175,9 @@ struct HipBackend {
         if (!n || error) return;
         (void)hipSetDevice(dev_at(pl));
         const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 256u * 16u);
+        hipEvent_t ev; tick_begin(pl, stream_at(pl), ev);
         hipLaunchKernelGGL(be_append_kernel<F>, dim3(grid), dim3(256), 0, stream_at(pl), n, f, list, cnt, cap);
+        tick_end(pl, stream_at(pl), ev);
         ok(hipGetLastError(), "launch (append at a place)");
         if (pl < (int)launches_at.size()) launches_at[pl]++;
         (void)hipSetDevice(device);
@@ -201,7 +230,9 @@ struct HipBackend {
     template <typename F> void launch(uint64_t n, F f) {
         if (!n || error) return;
         const unsigned grid = (unsigned)std::min<uint64_t>((n + 255) / 256, 1u << 20);
+        hipEvent_t ev; tick_begin(-1, stream, ev);
         hipLaunchKernelGGL(be_launch_kernel<F>, dim3(grid), dim3(256), 0, stream, n, f);
+        tick_end(-1, stream, ev);
         ok(hipGetLastError(), "launch");
     }
     bool scratch(size_t bytes) {
@@ -219,8 +250,10 @@ struct HipBackend {
         if (!ok((rocprim::radix_sort_pairs<rocprim::default_config, const KT*, KT*, const V*, V*, size_t>(
                     nullptr, need, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)bits, stream)), "radix sort (size)")) return;
         if (!scratch(need)) return;
+        hipEvent_t ev; tick_begin(-1, stream, ev);
         ok((rocprim::radix_sort_pairs<rocprim::default_config, const KT*, KT*, const V*, V*, size_t>(
                tmp, need, kin, kout, vin, vout, (size_t)n, 0u, (unsigned)bits, stream)), "radix sort");
+        tick_end(-1, stream, ev);
     }
     void inclusive_max(const long long* in, long long* out, uint64_t n) {
         if (!n || error) return;
