@@ -107,4 +107,6 @@ int e2_route(pg_ctx* c, const uint64_t* d_packed, const uint64_t* d_word_off, co
              hipStream_t st);
 int e2_clear_route_overflow(pg_ctx* c, hipStream_t st);
 int e2_ingest(pg_ctx* c, const uint64_t* d_recs, const uint32_t* d_pids, uint64_t n, hipStream_t st);
+int e2_answer(pg_ctx* c, const uint64_t* d_geo, uint32_t P, uint32_t bias, unsigned long long* d_ans, unsigned long long ord_base, hipStream_t st);
+int e2_answer_check(pg_ctx* c, hipStream_t st);
 }  // namespace pg

@@ -67,6 +67,8 @@ struct P2Params {
     const uint64_t* geo3;               // per set (SV_GEO words): first global slot, size, address of its slot 0 ((NW + 1) words a slot: key
                                         // words, then A | B << 32), the size's reciprocal (graph_lookup.hpp: ModConst); the sets of one graph may
                                         // lie on several GPUs of the process
+    const uint64_t* look;               // pass 2's lookup table (p2_make_look) or null: every key of the sets with its node word, two 32-byte entries a
+    uint64_t look_buckets;              // 64-byte bucket (K <= 63; one 64-byte entry a bucket at K <= 127), probed from the bucket the key hashes to
     uint32_t P, bias;
     int K;
     // (K+1)-mer patch table
@@ -218,14 +220,57 @@ __device__ __forceinline__ void p2_thread_end(const P2Params& p, const P2Walk<NW
 // The reads of a launch in an order of the caller's (round 6: p2_add_packed_device_segments): read i of the launch is read perm[i] of the reads that lie, one
 // length, back to back, in segments of `per_seg` reads each (the batches pass 1 kept on the device).
 struct P2Order { const uint32_t* perm; const uint64_t* const* segs; uint32_t per_seg; };
+// Round 6, opt-in (SOAPDENOVO2_AMD_P2_LOOK=1): LOOK = the node word comes from pass 2's lookup table (p2_make_look) instead of the reference's set
+// image.  The idea: a lookup costs the 64-byte lines it touches, and the image is not laid out for that (24-byte slots at a load of 0.64, linear
+// probing from any slot); the table has every key once more in entries of 32 bytes, two a line, at a load of at most 0.5, a key's probes starting
+// at the FIRST entry of its line -- and needs no set selection (CRC-32, set geometry, key mod size).  Measured at 200 M reads
+// (profiles/r06_p2_lookup_ab.json): FETCH_SIZE 97 -> 94 B a lookup (90 B at a load of 0.33), kernel 730 -> 937 ms (745 ms at 0.33) + 105 ms to build
+// it.  The memory side fetches ~1.5 requests a lookup whatever the alignment, and time follows the random PLACES a lookup visits, not its bytes:
+// one place a lookup either way.  So the default stays the probe of the image; this form is kept for the A/B (scripts/p2_look_ab.sh).
+template <int NW> constexpr int p2_look_words() { return NW == 2 ? 4 : 8; }            // words an entry
+template <int NW> constexpr int p2_look_epb() { return NW == 2 ? 2 : 1; }              // entries a 64-byte bucket
 template <int NW>
+__device__ __forceinline__ uint64_t p2_look_home(const Kmer<NW>& ck, uint64_t n_buckets) { return __umul64hi(kmer_mix<NW>(ck), n_buckets) * p2_look_epb<NW>(); }
+// occupied slots of one set image
+__global__ __launch_bounds__(256) void p2_look_count(const uint64_t* __restrict__ src, int nw1, uint64_t n_slots, unsigned long long* n_keys) {
+    unsigned long long mine = 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_slots; i += (uint64_t)gridDim.x * 256) mine += src[i * nw1] != SV_EMPTY;
+    for (int o = 32; o; o >>= 1) mine += __shfl_down(mine, o);
+    if ((threadIdx.x & 63) == 0 && mine) atomicAdd(n_keys, mine);
+}
+// every key of one set image into the table (the table is all ~0 when the first set comes; nobody reads it before the last is in)
+template <int NW>
+__global__ __launch_bounds__(256) void p2_look_build(const uint64_t* __restrict__ src, uint64_t n_slots, unsigned long long* tab, uint64_t n_buckets) {
+    constexpr int ES = p2_look_words<NW>();
+    const uint64_t n_entries = n_buckets * p2_look_epb<NW>();
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < n_slots; i += (uint64_t)gridDim.x * 256) {
+        const uint64_t* nd = src + i * (NW + 1);
+        Kmer<NW> k;
+        k.w[0] = nd[0];
+        if (k.w[0] == SV_EMPTY) continue;
+#pragma unroll
+        for (int q = 1; q < NW; q++) k.w[q] = nd[q];
+        const uint64_t ab = nd[NW];
+        uint64_t e = p2_look_home<NW>(k, n_buckets);
+        for (;;) {
+            if (atomicCAS(&tab[e * ES], (unsigned long long)SV_EMPTY, (unsigned long long)k.w[0]) == SV_EMPTY) break;
+            if (++e == n_entries) e = 0;
+        }
+#pragma unroll
+        for (int q = 1; q < NW; q++) tab[e * ES + q] = k.w[q];
+        tab[e * ES + NW] = ab;
+    }
+}
+template <int NW, bool LOOK>
 __global__ __launch_bounds__(256) void p2_thread_kernel(P2Params p, const uint64_t* __restrict__ words, const uint64_t* __restrict__ word_off,
                                                         const int32_t* __restrict__ lens, uint64_t n_reads, uint64_t first_ordinal, int uniform_len, P2Order order) {
-    __shared__ uint32_t crc4[4 * 256];
-    __shared__ uint64_t set_geo[SV_GEO * P2_MAX_SETS];
-    for (int i = threadIdx.x; i < 1024; i += 256) crc4[i] = crc32_slice_entry(i >> 8, i & 255);
-    for (int i = threadIdx.x; i < SV_GEO * (int)p.P; i += 256) set_geo[i] = p.geo3[i];
-    __syncthreads();
+    __shared__ uint32_t crc4[LOOK ? 1 : 4 * 256];
+    __shared__ uint64_t set_geo[LOOK ? 1 : SV_GEO * P2_MAX_SETS];
+    if constexpr (!LOOK) {
+        for (int i = threadIdx.x; i < 1024; i += 256) crc4[i] = crc32_slice_entry(i >> 8, i & 255);
+        for (int i = threadIdx.x; i < SV_GEO * (int)p.P; i += 256) set_geo[i] = p.geo3[i];
+        __syncthreads();
+    }
     const uint64_t r_launch = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r_launch >= n_reads) return;
     const uint64_t r = order.perm ? (uint64_t)order.perm[r_launch] : r_launch;     // the read's place in read order: its ordinal, its row of walks
@@ -251,22 +296,45 @@ __global__ __launch_bounds__(256) void p2_thread_kernel(P2Params p, const uint64
         if (j) kmer_roll<NW>(word, bal, read_base(rd, j + K - 1), K, filter);
         const bool sm = kmer_less<NW>(word, bal);
         const Kmer<NW> ck = sm ? word : bal;
-        const uint32_t s = set_of_crc(kmer_crc32_sliced<NW>(ck, crc4), p.P, p.bias);
-        const uint64_t size = set_geo[SV_GEO * s + 1];
-        uint64_t hc = home_slot<NW>(ck, ModConst{size, set_geo[SV_GEO * s + 3], (uint32_t)set_geo[SV_GEO * s + 4]});
-        const uint64_t* base = (const uint64_t*)(uintptr_t)set_geo[SV_GEO * s + 2];
         uint64_t ab = 0;
-        for (;;) {
-            const uint64_t* nd = base + hc * (NW + 1);
-            uint64_t d[NW + 1];
+        if constexpr (LOOK) {
+            constexpr int ES = p2_look_words<NW>();
+            typedef unsigned long long u64x2 __attribute__((ext_vector_type(2)));
+            const uint64_t n_entries = p.look_buckets * p2_look_epb<NW>();
+            uint64_t e = p2_look_home<NW>(ck, p.look_buckets);
+            for (;;) {
+                const uint64_t* nd = p.look + e * ES;                     // (entries aligned to their size: 16-byte loads)
+                uint64_t d[NW + 1];
 #pragma unroll
-            for (int i = 0; i <= NW; i++) d[i] = sv_word(nd + i);         // (global loads: graph_lookup.hpp)
-            if (d[0] == SV_EMPTY) { atomicAdd(&p.counters[1], 1ULL); return; }      // not in the sets
-            bool eq = true;
+                for (int i = 0; i < NW; i += 2) {
+                    const u64x2 v = *(const __attribute__((address_space(1))) u64x2*)(nd + i);
+                    d[i] = v.x; d[i + 1] = v.y;
+                }
+                d[NW] = sv_word(nd + NW);
+                if (d[0] == SV_EMPTY) { atomicAdd(&p.counters[1], 1ULL); return; }      // not in the sets
+                bool eq = true;
 #pragma unroll
-            for (int i = 0; i < NW; i++) eq = eq && d[i] == ck.w[i];
-            if (eq) { ab = d[NW]; break; }
-            if (++hc == size) hc = 0;
+                for (int i = 0; i < NW; i++) eq = eq && d[i] == ck.w[i];
+                if (eq) { ab = d[NW]; break; }
+                if (++e == n_entries) e = 0;
+            }
+        } else {
+            const uint32_t s = set_of_crc(kmer_crc32_sliced<NW>(ck, crc4), p.P, p.bias);
+            const uint64_t size = set_geo[SV_GEO * s + 1];
+            uint64_t hc = home_slot<NW>(ck, ModConst{size, set_geo[SV_GEO * s + 3], (uint32_t)set_geo[SV_GEO * s + 4]});
+            const uint64_t* base = (const uint64_t*)(uintptr_t)set_geo[SV_GEO * s + 2];
+            for (;;) {
+                const uint64_t* nd = base + hc * (NW + 1);
+                uint64_t d[NW + 1];
+#pragma unroll
+                for (int i = 0; i <= NW; i++) d[i] = sv_word(nd + i);     // (global loads: graph_lookup.hpp)
+                if (d[0] == SV_EMPTY) { atomicAdd(&p.counters[1], 1ULL); return; }      // not in the sets
+                bool eq = true;
+#pragma unroll
+                for (int i = 0; i < NW; i++) eq = eq && d[i] == ck.w[i];
+                if (eq) { ab = d[NW]; break; }
+                if (++hc == size) hc = 0;
+            }
         }
         p2_thread_step<NW>(p, w, ck, sm, ab, row, seq0);
     }
@@ -275,8 +343,13 @@ __global__ __launch_bounds__(256) void p2_thread_kernel(P2Params p, const uint64
 static void p2_launch_thread_kernel(int nw, dim3 grid, hipStream_t st, const P2Params& p, const uint64_t* words, const uint64_t* word_off, const int32_t* lens,
                                     uint64_t n_reads, uint64_t first_ordinal, int uniform_len, P2Order order = P2Order{nullptr, nullptr, 0}) {
     const dim3 block(256);
-    if (nw == 2) hipLaunchKernelGGL((p2_thread_kernel<2>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len, order);
-    else hipLaunchKernelGGL((p2_thread_kernel<4>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len, order);
+    if (p.look) {
+        if (nw == 2) hipLaunchKernelGGL((p2_thread_kernel<2, true>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len, order);
+        else hipLaunchKernelGGL((p2_thread_kernel<4, true>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len, order);
+        return;
+    }
+    if (nw == 2) hipLaunchKernelGGL((p2_thread_kernel<2, false>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len, order);
+    else hipLaunchKernelGGL((p2_thread_kernel<4, false>), grid, block, 0, st, p, words, word_off, lens, n_reads, first_ordinal, uniform_len, order);
 }
 // a read's place in the genome, as far as a read can tell: its smallest hashed canonical 16-mer (the partition engine's m-mer hash, skm.hpp).  Reads that
 // overlap share it when it lies in their overlap -- at 30 x coverage some 130 reads have the same one, and between them they look up the same few hundred k-mers.
@@ -432,7 +505,7 @@ __global__ __launch_bounds__(256) void p2_thread_routed_kernel(P2Params p, const
     for (int j = 0; j < nk && !w.stop; j++) {
         if (j) kmer_roll<NW>(word, bal, read_base(rd, j + K - 1), K, filter);
         const bool sm = kmer_less<NW>(word, bal);
-        const uint64_t ab = answers[where[kb + j]];
+        const uint64_t ab = answers[where ? where[kb + j] : kb + j];      // (where = null: the answers lie in k-mer order -- pass 2 through the partitions)
         if (ab == ~0ULL) { atomicAdd(&p.counters[1], 1ULL); return; }      // not in the sets
         p2_thread_step<NW>(p, w, sm ? word : bal, sm, ab, row, seq0);
     }
@@ -1048,9 +1121,12 @@ struct P2Device {
     hipStream_t stream = nullptr;
     unsigned long long* d_vlist = nullptr;           // the vertices' global slots as p2_list_vertices left them (the edge builder starts from the same list)
     uint64_t n_vlist = 0;
+    uint64_t* d_look = nullptr;                      // pass 2's lookup table (p2_make_look); gone again when pass 2 is (p2_finish)
+    bool look_plain = false;
 };
 
 namespace { void forget_taken(void* ptr); }       // (the offered-block bookkeeping further down)
+static void p2_drop_look(P2Device* d);
 static void p2_free(P2Device* d) {
     if (!d) return;
     for (auto& o : d->owned) { forget_taken(o.second); (void)hipSetDevice(o.first); (void)pg::arena_free(o.second); }
@@ -1074,6 +1150,7 @@ static void p2_free(P2Device* d) {
     pg::arena_free(d->d_patch_keys); pg::arena_free(d->d_patch_val);
     pg::arena_free(d->d_counters);
     pg::arena_free(d->d_geo3); pg::arena_free(d->d_crc); pg::arena_free(d->d_vlist);
+    p2_drop_look(d);
     if (d->stream) hipStreamDestroy(d->stream);
     delete d;
 }
@@ -1530,6 +1607,63 @@ int p2_set_patch(P2Device* d, const uint64_t* patch_keys, const uint32_t* patch_
     return PG_OK;
 }
 
+// Pass 2's lookup table (round 6, opt-in: SOAPDENOVO2_AMD_P2_LOOK=1; the kernels, the reasoning and what was measured: above p2_thread_kernel).
+// Pass 2 reads the sets and writes none of their words (parse1read, prlRead2path.c:598-745: the node words are what the edge builder left), so for
+// its length every key can be entered once more, with its node word, into ONE table laid out for lookups -- when a single GPU holds all sets and
+// has the room (2 entries a key; down to 1.4 when memory is short).  Same node words, same results; p2_finish releases it.
+static double p2_now() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static int p2_make_look(P2Device* d) {
+    if (d->d_look || d->lanes.size() != 1) return PG_OK;
+    const char* on = pg::env_user("SOAPDENOVO2_AMD_P2_LOOK");                       // opt-in: measured no faster than the probes it replaces (above p2_thread_kernel)
+    if (!on || atoi(on) == 0) return PG_OK;
+    for (int s = 0; s < d->P; s++) if (d->set_dev[s] != d->device) return PG_OK;
+    const bool verbose = pg::env_user("PG_HOST_VERBOSE") != nullptr;
+    const double t0 = p2_now();
+    unsigned long long* d_n = nullptr;
+    P2_HIP(pg::arena_malloc((void**)&d_n, sizeof(unsigned long long)));
+    P2_HIP(hipMemsetAsync(d_n, 0, sizeof(unsigned long long), d->stream));
+    for (int s = 0; s < d->P; s++)
+        hipLaunchKernelGGL(p2_look_count, dim3((unsigned)std::min<uint64_t>((d->set_sizes[s] + 255) / 256, 1u << 15)), dim3(256), 0, d->stream, d->set_ptr[s], d->nw + 1, d->set_sizes[s], d_n);
+    unsigned long long n_keys = 0;
+    P2_HIP(hipMemcpyAsync(&n_keys, d_n, sizeof n_keys, hipMemcpyDeviceToHost, d->stream));
+    P2_HIP(hipStreamSynchronize(d->stream));
+    pg::arena_free(d_n);
+    const int ES = d->nw == 2 ? 4 : 8, EPB = d->nw == 2 ? 2 : 1;
+    size_t free_b = 0, total_b = 0;
+    P2_HIP(pg::arena_mem_info(&free_b, &total_b));
+    const uint64_t room = free_b > ((uint64_t)8 << 30) ? free_b - ((uint64_t)8 << 30) : 0;
+    double per_key = 2.0;
+    if (const char* e = getenv("PG_P2_LOOK_PER_KEY")) per_key = std::max(1.1, atof(e));            // (A/B knobs of round 6: table size, plain hipMalloc)
+    const bool plain = getenv("PG_P2_LOOK_MALLOC") != nullptr;
+    if ((double)n_keys * per_key * ES * 8 > (double)room) per_key = (double)room / ((double)n_keys * ES * 8 + 1);
+    if (n_keys == 0 || per_key < 1.4) {
+        if (verbose) fprintf(stderr, "pass 2: no lookup table (%llu keys, %.1f GB free): probing the sets as they lie\n", n_keys, free_b / 1e9);
+        return PG_OK;
+    }
+    const uint64_t n_buckets = std::max<uint64_t>(64, (uint64_t)((double)n_keys * per_key) / EPB);
+    const uint64_t bytes = n_buckets * EPB * ES * 8;
+    if ((plain ? hipMalloc((void**)&d->d_look, bytes) : pg::arena_malloc((void**)&d->d_look, bytes)) != hipSuccess) { (void)hipGetLastError(); d->d_look = nullptr; return PG_OK; }
+    d->look_plain = plain;
+    P2_HIP(hipMemsetAsync(d->d_look, 0xFF, bytes, d->stream));
+    for (int s = 0; s < d->P; s++) {
+        const dim3 grid((unsigned)std::min<uint64_t>((d->set_sizes[s] + 255) / 256, 1u << 16));
+        if (d->nw == 2) hipLaunchKernelGGL((p2_look_build<2>), grid, dim3(256), 0, d->stream, d->set_ptr[s], d->set_sizes[s], (unsigned long long*)d->d_look, n_buckets);
+        else hipLaunchKernelGGL((p2_look_build<4>), grid, dim3(256), 0, d->stream, d->set_ptr[s], d->set_sizes[s], (unsigned long long*)d->d_look, n_buckets);
+    }
+    P2_HIP(hipGetLastError());
+    P2_HIP(hipStreamSynchronize(d->stream));
+    d->prm.look = d->d_look; d->prm.look_buckets = n_buckets;
+    if (verbose) fprintf(stderr, "pass 2: lookup table of %llu keys in %llu entries of %d bytes (%.1f GB), built in %.3fs\n", n_keys, (unsigned long long)(n_buckets * EPB), ES * 8, bytes / 1e9, p2_now() - t0);
+    return PG_OK;
+}
+static void p2_drop_look(P2Device* d) {
+    if (!d->d_look) return;
+    (void)hipSetDevice(d->device);
+    if (d->look_plain) (void)hipFree(d->d_look); else pg::arena_free(d->d_look);
+    d->d_look = nullptr; d->prm.look = nullptr;
+    for (P2Lane& ln : d->lanes) ln.prm.look = nullptr;
+}
+
 // the pre-arc table and, with -R, the marker counts: one of each per lane; lanes on another device than the lead's get their own
 // copy of the set geometry and of the (K+1)-mer table (a few MB: every probe of them would otherwise cross xGMI)
 int p2_begin_reads(P2Device* d, uint32_t num_ed, bool reps) {
@@ -1539,6 +1673,7 @@ int p2_begin_reads(P2Device* d, uint32_t num_ed, bool reps) {
     // several lanes: the lookups are routed to the sets' owners (SOAPDENOVO2_AMD_P2_ROUTE=0: every lane probes the peer-mapped sets itself, the A/B form)
     d->route = d->lanes.size() > 1 && (int)d->lanes.size() <= P2R_MAX_LANES;
     if (const char* e = pg::env_user("SOAPDENOVO2_AMD_P2_ROUTE")) d->route = d->route && atoi(e) != 0;
+    { const int rc = p2_make_look(d); if (rc) return rc; }
     // every edge has a handful of successors: eight slots an edge id keep the load low; the kernel counts overflows
     uint64_t arc_cap = 1 << 16;
     while (arc_cap < (uint64_t)d->num_ed * 8) arc_cap <<= 1;
@@ -2332,6 +2467,57 @@ int p2_add_packed_device_segments(P2Device* d, const uint64_t* const* d_segs, co
     const char* sw = pg::env_user("SOAPDENOVO2_AMD_P2_SORT");
     const bool sorted = sw && atoi(sw) != 0 && even && total < 0xFFFFFFFFull && total >= 4096 && d->lanes.size() == 1 && !d->route && !d->reps &&
                         d->lanes[0].device == device && read_len >= d->K + 1 && seg_reads[0] < 0xFFFFFFFFull;
+    // SOAPDENOVO2_AMD_P2_PARTITIONED=1 (round 6, opt-in): the lookups through the partition engine -- the reads cut into super-k-mer records once more, every distinct
+    // k-mer of a partition looked up ONCE (partition_kernels.hip: skm_answer_kernel), the reads threaded over the answers in k-mer order.  Rounds of as many
+    // segments as 40 GB of answers (8 bytes a k-mer occurrence) hold.
+    const char* pw = pg::env_user("SOAPDENOVO2_AMD_P2_PARTITIONED");
+    if (pw && atoi(pw) != 0 && even && total < 0xFFFFFFFFull && d->lanes.size() == 1 && !d->route && !d->reps && d->lanes[0].device == device && read_len >= d->K + 1) {
+        P2Lane& ln = d->lanes[0];
+        P2_HIP(hipSetDevice(ln.device));
+        p2_drop_look(d);                                  // (this form does not read the lookup table: its room goes to the answers)
+        hipStream_t st = ln.stream;
+        const uint64_t kpr = (uint64_t)(read_len - d->K + 1), per_seg = seg_reads[0];
+        uint64_t segs_a_round = std::max<uint64_t>(1, (((uint64_t)40 << 30) / 8) / std::max<uint64_t>(1, per_seg * kpr));
+        segs_a_round = std::min<uint64_t>(segs_a_round, (uint64_t)n_segs);
+        const uint64_t reads_round = segs_a_round * per_seg;
+        pg_ctx* ctx = pg_create_planned(ln.device, d->K, d->nw == 4 ? 1 : 0, d->P, 24, 2, reads_round * kpr, reads_round, 1, 1);
+        if (!ctx) return PG_ENOMEM;
+        unsigned long long* d_ans = nullptr;
+        int rc = PG_OK;
+        if (pg::arena_malloc((void**)&d_ans, reads_round * kpr * sizeof(unsigned long long)) != hipSuccess) { pg_destroy(ctx); pg_set_error("pass 2 through the partitions: no memory for the answers"); return PG_ENOMEM; }
+        uint64_t g_first = 0;                                           // the round's first read among all
+        for (int q0 = 0; q0 < n_segs && rc == PG_OK; q0 += (int)segs_a_round) {
+            const int q1 = std::min(n_segs, q0 + (int)segs_a_round);
+            if (q0 && pg_reset(ctx, st) != PG_OK) { rc = PG_ENODEV; break; }
+            uint64_t local = 0;
+            for (int q = q0; q < q1 && rc == PG_OK; q++) {
+                if (pg_count_reads(ctx, d_segs[q], nullptr, nullptr, seg_reads[q], (uint32_t)read_len, seg_reads[q] * kpr, local * kpr, st) != PG_OK) rc = PG_ENODEV;
+                local += seg_reads[q];
+            }
+            if (rc == PG_OK) rc = pg::e2_answer(ctx, ln.prm.geo3, (uint32_t)d->P, ln.prm.bias, d_ans, 0, st);
+            if (rc == PG_OK) rc = pg::e2_answer_check(ctx, st);
+            local = 0;
+            for (int q = q0; q < q1 && rc == PG_OK; q++) {
+                P2Params p = ln.prm;
+                p.stage = nullptr; p.walk_len = nullptr;
+                const dim3 grid((unsigned)((seg_reads[q] + 255) / 256)), block(256);
+                if (d->nw == 2) hipLaunchKernelGGL((p2_thread_routed_kernel<2>), grid, block, 0, st, p, (const uint32_t*)nullptr, (const uint64_t*)nullptr, (const uint64_t*)(d_ans + local * kpr), d_segs[q], (const uint64_t*)nullptr, (const int32_t*)nullptr, seg_reads[q], d->ordinal + g_first + local, read_len);
+                else hipLaunchKernelGGL((p2_thread_routed_kernel<4>), grid, block, 0, st, p, (const uint32_t*)nullptr, (const uint64_t*)nullptr, (const uint64_t*)(d_ans + local * kpr), d_segs[q], (const uint64_t*)nullptr, (const int32_t*)nullptr, seg_reads[q], d->ordinal + g_first + local, read_len);
+                if (hipGetLastError() != hipSuccess) { pg_set_error("pass 2 through the partitions: launch failed"); rc = PG_ENODEV; }
+                local += seg_reads[q];
+            }
+            if (hipStreamSynchronize(st) != hipSuccess && rc == PG_OK) { pg_set_error("pass 2 through the partitions: a kernel failed"); rc = PG_ENODEV; }
+            g_first += local;
+        }
+        pg::arena_free(d_ans);
+        pg_destroy(ctx);
+        if (rc) return rc;
+        d->ordinal += total;
+        ln.reads += total; ln.batches += (uint64_t)n_segs;
+        if (pg::env_user("PG_HOST_VERBOSE")) fprintf(stderr, "pass 2: %llu read(s) through the partition engine, %llu segment(s) a round\n", (unsigned long long)total, (unsigned long long)segs_a_round);
+        P2_HIP(hipSetDevice(d->device));
+        return PG_OK;
+    }
     if (!sorted) {                                                  // segment by segment, in file order (the round-5 form; also what several lanes take)
         for (int q = 0; q < n_segs; q++) { const int rc = p2_add_packed_device(d, d_segs[q], seg_reads[q], read_len, device); if (rc) return rc; }
         return PG_OK;
@@ -2483,6 +2669,7 @@ int p2_finish(P2Device* d, P2Result& out) {
         for (int q = 0; q < 8; q++) c[q] += cl[q];
         lane_arcs[l] = cl[3];
     }
+    p2_drop_look(d);                                   // (every batch is through: the room goes to the fold)
     if (pg::env_user("PG_HOST_VERBOSE"))
         for (size_t l = 0; l < d->lanes.size(); l++)
             fprintf(stderr, "graph lane %zu (device %d): pass 2 threaded %llu read(s) in %llu batch(es), %llu distinct pre-arc(s); %llu per-set scan(s) ran here; %llu tip / edge walk(s) ran here\n", l, d->lanes[l].device,

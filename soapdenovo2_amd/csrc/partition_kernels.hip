@@ -36,6 +36,7 @@
 #include "occ32.hpp"
 #include "skm_tile.hpp"
 #include "e2_plan.hpp"
+#include "graph_lookup.hpp"
 #include "../../include/soapdenovo2_amd.h"
 
 namespace pg {
@@ -1089,6 +1090,306 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
 #undef K2_SYNC
 }
 
+// ---- pass 2 through the partitions (round 6, opt-in: SOAPDENOVO2_AMD_P2_PARTITIONED=1) ---------------------------------------------------------------
+// Pass 2 asks the k-mer sets for the node of every k-mer of every read: 17.6 G lookups at 200 M reads, each a random line of HBM or two, although only 1.15 G
+// k-mers are distinct.  All occurrences of a k-mer meet in ONE partition -- what pass 1 is built on -- so the reads are cut into super-k-mer records once more
+// (K1, as they lie on the device), and this kernel takes a partition at a time: the distinct k-mers of the partition into the LDS set (claims only), ONE lookup in
+// the sets in HBM per distinct k-mer (dense waves over the live slots; the node word goes where pass 1 keeps the first ordinal), then every occurrence finds its
+// k-mer's word in LDS and writes it at its ordinal: ans[ordinal - ord_base].  The reads are then threaded over their stretch of `ans` in read order
+// (graph_kernels.hip: p2_thread_routed_kernel without a permutation).  A simpler sibling of skm_count_kernel: no dedupe of records (every record's ordinals are
+// its own), no counters, one window buffer; a set that overflows splits its key range on a hash bit, as there.
+struct AnsArg {
+    unsigned long long* ans;          // [occurrences of the round] node word of every k-mer occurrence, ~0 = not in the sets
+    unsigned long long ord_base;      // ordinal of ans[0]
+    const uint64_t* geo;              // the sets' geometry (graph_lookup.hpp: SV_GEO words a set)
+    uint32_t P, bias;
+};
+template <int NW, int SLOTS, int LOOK>
+__device__ __forceinline__ int lds_claim(LdsSet<NW, SLOTS>& t, const uint64_t (&kw)[E2Cfg<NW>::KW], uint32_t hash) {
+    constexpr int KW = E2Cfg<NW>::KW;
+    uint32_t h = hash & (SLOTS - 1);
+    if constexpr (E2Cfg<NW>::RAW) {
+        constexpr unsigned long long L_PENDING = 1ULL << 63;
+        for (int probes = 0, spins = 0; probes < E2Cfg<NW>::MAXPROBE && spins < K2_MAXSPIN;) {
+            unsigned long long seen[KW];
+#pragma unroll
+            for (int i = 0; i < KW; i++) seen[i] = *(volatile __attribute__((address_space(3))) unsigned long long*)(&t.key[i][h]);
+            unsigned long long nxt0[LOOK];
+#pragma unroll
+            for (int q = 0; q < LOOK; q++) nxt0[q] = *(volatile __attribute__((address_space(3))) unsigned long long*)(&t.key[0][(h + 1 + q) & (SLOTS - 1)]);
+            bool mine = false, again = false;
+            if (seen[0] == L_EMPTY) {
+                const unsigned long long old = atomicCAS(&t.key[0][h], L_EMPTY, (unsigned long long)kw[0] | L_PENDING);
+                if (old == L_EMPTY) {
+#pragma unroll
+                    for (int i = 1; i < KW; i++) t.key[i][h] = (unsigned long long)kw[i];
+                    __hip_atomic_store(&t.key[0][h], (unsigned long long)kw[0], __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    mine = true;
+                } else again = true;
+            } else if (seen[0] & L_PENDING) again = true;
+            else {
+                mine = true;
+#pragma unroll
+                for (int i = 0; i < KW; i++) mine = mine && seen[i] == kw[i];
+            }
+            if (mine) return (int)h;
+            if (again) spins++;
+            else {
+                uint32_t adv = 1;
+                bool run = true;
+#pragma unroll
+                for (int q = 0; q < LOOK; q++) { run = run && nxt0[q] != L_EMPTY && (nxt0[q] & ~L_PENDING) != kw[0]; adv += run ? 1u : 0u; }
+                h = (h + adv) & (SLOTS - 1);
+                probes += (int)adv;
+            }
+        }
+        return -1;
+    }
+    for (int probes = 0; probes < E2Cfg<NW>::MAXPROBE; probes++) {
+        unsigned long long seen[KW];
+#pragma unroll
+        for (int i = 0; i < KW; i++) seen[i] = t.key[i][h];
+        unsigned long long nxt0[LOOK];
+#pragma unroll
+        for (int q = 0; q < LOOK; q++) nxt0[q] = t.key[0][(h + 1 + q) & (SLOTS - 1)];
+        bool mine = true;
+#pragma unroll
+        for (int i = 0; i < KW; i++) {
+            if (!mine) break;
+            unsigned long long cur = seen[i];
+            if (cur == L_EMPTY) {
+                const unsigned long long old = atomicCAS(&t.key[i][h], L_EMPTY, (unsigned long long)kw[i]);
+                cur = old == L_EMPTY ? (unsigned long long)kw[i] : old;
+            }
+            mine = cur == kw[i];
+        }
+        if (mine) return (int)h;
+        uint32_t adv = 1;
+        bool run = true;
+#pragma unroll
+        for (int q = 0; q < LOOK; q++) { run = run && nxt0[q] != L_EMPTY && nxt0[q] != kw[0]; adv += run ? 1u : 0u; }
+        h = (h + adv) & (SLOTS - 1);
+        probes += (int)adv - 1;
+    }
+    return -1;
+}
+// the slot of a key that is in the set (every word final: the claims are a barrier back)
+template <int NW, int SLOTS>
+__device__ __forceinline__ int lds_find(const LdsSet<NW, SLOTS>& t, const uint64_t (&kw)[E2Cfg<NW>::KW], uint32_t hash) {
+    constexpr int KW = E2Cfg<NW>::KW;
+    uint32_t h = hash & (SLOTS - 1);
+    for (int probes = 0; probes < SLOTS; probes++) {
+        bool eq = true;
+#pragma unroll
+        for (int i = 0; i < KW; i++) eq = eq && t.key[i][h] == (unsigned long long)kw[i];
+        if (eq) return (int)h;
+        if (t.key[0][h] == L_EMPTY) return -1;
+        h = (h + 1) & (SLOTS - 1);
+    }
+    return -1;
+}
+
+template <int NW, int SLOTS, int THREADS, int WIN, int KS>
+__global__ __launch_bounds__(THREADS) void skm_answer_kernel(E2Dev e, OccConst oc, AnsArg aa, DevCounters* ctr) {
+    constexpr int PW = E2Cfg<NW>::PW, RW = PW + 1, KW = E2Cfg<NW>::KW, NWAVE = THREADS / 64, PIECES = RW / 2, N2 = 2 * NW;
+    constexpr int RD = 2 * RW, PAD = 16;
+    constexpr int RL_WORDS = PAD + WIN * RD + 8;
+    constexpr int NMAX = KS ? (32 * PW - (KS - 1) - 2 < 127 ? 32 * PW - (KS - 1) - 2 : 127) : 127;
+    constexpr int SB_WORDS = (WIN * NMAX + 31) / 32 + 2;
+    constexpr int SB_AT = (WIN + 1 + WIN + 1) & ~1;
+    constexpr int LOOK = KS == 31 ? 3 : 2;
+    __shared__ LdsSet<NW, SLOTS> set;                                     // key words; `ord` holds the node word from the lookup phase on
+    __shared__ __align__(16) uint32_t rl[RL_WORDS];
+    __shared__ __align__(8) unsigned int fl_raw[SB_AT + SB_WORDS];
+    unsigned int* const noff = fl_raw;
+    unsigned short* const tile_rep0 = (unsigned short*)(fl_raw + WIN + 1);
+    unsigned int* const sbits = fl_raw + SB_AT;
+    __shared__ unsigned short live_list[SLOTS];
+    __shared__ uint32_t crc_tab[4 * 256];
+    __shared__ unsigned int tile_ctr, aborted, s_mask[40], s_val[40], wave_cnt_f[NWAVE], s_nlive, s_tot, chunk_ids[256];
+    const uint32_t nchunks = e.direct + e.maxc;
+    for (int i = threadIdx.x; i < 1024; i += THREADS) crc_tab[i] = crc32_slice_entry(i >> 8, i & 255);
+    if (threadIdx.x < PAD) rl[threadIdx.x] = 0;
+    if (threadIdx.x < 8) rl[PAD + WIN * RD + threadIdx.x] = 0;
+    const int K = KS ? KS : e.g.K;
+    const uint32_t RPC = e.rpc, RPC_LOG2 = e.rpc_log2;
+    const uint64_t RS = (uint64_t)e.rs;
+    const uint32_t parts = 1u << e.g.log2_parts;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    unsigned long long lost = 0;
+    __syncthreads();
+    // stage window [w0, w0 + wn) of the partition and build its tables: occurrence idx -> (record, t)
+    auto prepare = [&](uint32_t w0, uint32_t wn) {
+        for (uint32_t pc = threadIdx.x; pc < wn * PIECES; pc += THREADS) {
+            const uint32_t ri = pc / PIECES, part = pc - ri * PIECES;
+            const uint32_t gi = w0 + ri, cid = chunk_ids[gi >> RPC_LOG2];
+            ulonglong2 v = make_ulonglong2(0, 0);
+            if (cid != 0 && cid != 0xFFFFFFFFu) v = ((const ulonglong2*)(e.pool + ((uint64_t)(cid - 1) * RPC + (gi & (RPC - 1))) * RS))[part];
+            const uint32_t x0 = part ? (uint32_t)(v.x >> 32) : (uint32_t)v.x, x1 = part ? (uint32_t)v.x : (uint32_t)(v.x >> 32);
+            ((uint4*)(rl + PAD))[pc] = make_uint4(x0, x1, (uint32_t)(v.y >> 32), (uint32_t)v.y);
+        }
+        for (int i = threadIdx.x; i < SB_WORDS; i += THREADS) sbits[i] = 0;
+        __syncthreads();
+        const bool have = threadIdx.x < wn;
+        const unsigned int n = have ? ((rl[PAD + threadIdx.x * RD] >> 2) & 0x7Fu) : 0u;
+        const unsigned int incl = wave_inclusive_sum(n);
+        if (lane == 63) wave_cnt_f[wave] = incl;
+        __syncthreads();
+        unsigned int base = 0, tot = 0;
+#pragma unroll
+        for (int wv = 0; wv < NWAVE; wv++) { const unsigned int cw = wave_cnt_f[wv]; if (wv < wave) base += cw; tot += cw; }
+        if (have) {
+            const uint32_t h0 = rl[PAD + threadIdx.x * RD];
+            const unsigned int o_hi = base + incl, o_lo = o_hi - n;
+            noff[threadIdx.x] = o_lo | ((unsigned int)threadIdx.x << 16) | ((h0 & 3u) << 25);
+            if (n) {
+                atomicOr(&sbits[o_lo >> 5], 1u << (o_lo & 31u));
+                for (unsigned int t = (o_lo + 63u) >> 6; (t << 6) < o_hi; t++) tile_rep0[t] = (unsigned short)threadIdx.x;
+            }
+        }
+        if (threadIdx.x == 0) { noff[wn] = tot; s_tot = tot; tile_ctr = NWAVE; }
+        __syncthreads();
+    };
+    // the occurrences of the prepared window, 64 at a time: f(key words, slot hash, ordinal)
+    auto for_occurrences = [&](uint32_t mask, uint32_t val, auto&& f) {
+        const uint32_t total_occ = s_tot;
+        for (uint32_t tile = (uint32_t)wave;;) {
+            if (tile * 64u >= total_occ) break;
+            const uint32_t idx = tile * 64u + (uint32_t)lane;
+            if (idx < total_occ) {
+                const unsigned long long tb = *(const unsigned long long*)(sbits + 2 * tile);
+                const unsigned long long upto = lane == 63 ? ~0ULL : (2ULL << lane) - 1ULL;
+                // (every record has at least one k-mer, hence exactly one start bit: the record running at the tile's first occurrence + the starts behind it)
+                const uint32_t k = (uint32_t)tile_rep0[tile] + (uint32_t)__popcll(tb & upto & ~1ULL);
+                const uint32_t nk = noff[k], nk1 = noff[k + 1];
+                const uint32_t o_lo = nk & 0xFFFFu, o_hi = nk1 & 0xFFFFu;
+                const uint32_t* rec = rl + PAD + ((nk >> 16) & 0x1FFu) * RD;
+                const uint32_t hl = (nk >> 26) & 1u;
+                const uint32_t t = idx - o_lo;
+                (void)o_hi;
+                uint32_t fw[N2], rc[N2], prev, next;
+                if constexpr (KS != 0) {
+                    constexpr OccConst ock = occ_const(KS, NW);
+                    occ_extract<NW>(rec + 2, (int)(hl + t), KS, ock, fw, rc, prev, next);
+                } else occ_extract<NW>(rec + 2, (int)(hl + t), K, oc, fw, rc, prev, next);
+                const bool lt = occ_less<N2>(fw, rc);
+                uint32_t c[N2];
+#pragma unroll
+                for (int q = 0; q < N2; q++) c[q] = lt ? fw[q] : rc[q];
+                const uint32_t hh = occ_hash<N2>(c);
+                if (((hh >> 11) & mask) == val) {
+                    uint64_t kw[KW];
+                    if constexpr (E2Cfg<NW>::RAW) {
+#pragma unroll
+                        for (int q = 0; q < KW; q++) kw[q] = ((uint64_t)c[2 * q] << 32) | c[2 * q + 1];
+                    } else occ_key63<NW>(c, kw);
+                    const uint64_t ord = ((((uint64_t)rec[1] << 32) | rec[0]) >> SKM_ORD_SHIFT) + t;
+                    f(kw, hh, ord);
+                }
+            }
+            unsigned int nt = 0;
+            if (lane == 0) nt = atomicAdd(&tile_ctr, 1u);
+            tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)nt);
+        }
+    };
+    for (uint32_t pid = blockIdx.x; pid < parts; pid += gridDim.x) {
+        const uint32_t usable = min(e.cursor[pid], nchunks * RPC);
+        if (usable == 0) continue;
+        __syncthreads();                                                  // (the previous partition's last readers of the chunk list and the tables)
+        if (threadIdx.x < nchunks) chunk_ids[threadIdx.x] = chunk_id_of(e, pid, threadIdx.x);
+        int top = 0;
+        uint32_t mask = 0, val = 0;
+        for (;;) {
+            for (int i = threadIdx.x; i < SLOTS; i += THREADS) {
+#pragma unroll
+                for (int q = 0; q < KW; q++) set.key[q][i] = L_EMPTY;
+                set.ord[i] = L_EMPTY;
+            }
+            if (threadIdx.x == 0) { aborted = 0; s_nlive = 0; }
+            __syncthreads();
+            // A: the distinct k-mers of the key range into the set
+            for (uint32_t w0 = 0; w0 < usable; w0 += WIN) {
+                prepare(w0, min((uint32_t)WIN, usable - w0));
+                for_occurrences(mask, val, [&](const uint64_t (&kw)[KW], uint32_t hh, uint64_t) {
+                    if (__hip_atomic_load(&aborted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP)) return;
+                    if (lds_claim<NW, SLOTS, LOOK>(set, kw, hh) < 0) aborted = 1;
+                });
+                __syncthreads();
+            }
+            if (aborted) {                                                // too many distinct keys: split the range on the next hash bit
+                const uint32_t bit = mask + 1;
+                if (bit >= (1u << 20) || top + 2 > 40) { if (threadIdx.x == 0) atomicOr(&ctr->e2_flags, F_SPLIT); }
+                else {
+                    if (threadIdx.x == 0) { s_mask[top] = mask | bit; s_val[top] = val; s_mask[top + 1] = mask | bit; s_val[top + 1] = val | bit; }
+                    top += 2;
+                }
+            } else {
+                // B: one lookup in the sets per distinct k-mer, dense waves over the live slots
+                for (int st = 0; st < SLOTS / THREADS; st++) {
+                    const int si = st * THREADS + threadIdx.x;
+                    const bool live = set.key[0][si] != L_EMPTY;
+                    const unsigned long long bal = __ballot(live);
+                    unsigned int basep = 0;
+                    if (lane == 0 && bal) basep = atomicAdd(&s_nlive, (unsigned int)__popcll(bal));
+                    basep = (unsigned int)__builtin_amdgcn_readfirstlane((int)basep);
+                    if (live) live_list[basep + (unsigned int)__popcll(bal & ((1ULL << lane) - 1))] = (unsigned short)si;
+                }
+                __syncthreads();
+                const unsigned int n_live = s_nlive;
+                for (unsigned int i = threadIdx.x; i < n_live; i += THREADS) {
+                    const int si = live_list[i];
+                    Kmer<NW> key;
+                    if constexpr (E2Cfg<NW>::RAW) {
+#pragma unroll
+                        for (int w = 0; w < NW; w++) key.w[w] = set.key[w][si];
+                    } else {
+                        Key63<NW> k63;
+#pragma unroll
+                        for (int w = 0; w < KW; w++) k63.w[w] = set.key[w][si];
+                        key = kmer_from_key63<NW>(k63);
+                    }
+                    const uint32_t sidx = set_of_crc(kmer_crc32_sliced<NW>(key, crc_tab), aa.P, aa.bias);
+                    const uint64_t size = aa.geo[SV_GEO * sidx + 1];
+                    const uint64_t* base = (const uint64_t*)(uintptr_t)aa.geo[SV_GEO * sidx + 2];
+                    uint64_t hc = home_slot<NW>(key, ModConst{size, aa.geo[SV_GEO * sidx + 3], (uint32_t)aa.geo[SV_GEO * sidx + 4]});
+                    unsigned long long ab = ~0ULL;
+                    for (uint64_t step = 0; step < size; step++) {
+                        const uint64_t* nd = base + hc * (NW + 1);
+                        uint64_t dd[NW + 1];
+#pragma unroll
+                        for (int q = 0; q <= NW; q++) dd[q] = sv_word(nd + q);
+                        if (dd[0] == SV_EMPTY) break;
+                        bool eq = true;
+#pragma unroll
+                        for (int q = 0; q < NW; q++) eq = eq && dd[q] == key.w[q];
+                        if (eq) { ab = dd[NW]; break; }
+                        if (++hc == size) hc = 0;
+                    }
+                    set.ord[si] = ab;
+                }
+                __syncthreads();
+                // C: every occurrence of the range takes its k-mer's word to its ordinal
+                for (uint32_t w0 = 0; w0 < usable; w0 += WIN) {
+                    if (usable > WIN) prepare(w0, min((uint32_t)WIN, usable - w0));
+                    else { if (threadIdx.x == 0) tile_ctr = NWAVE; __syncthreads(); }      // (a single window is still there, with its tables)
+                    for_occurrences(mask, val, [&](const uint64_t (&kw)[KW], uint32_t hh, uint64_t ord) {
+                        const int si = lds_find<NW, SLOTS>(set, kw, hh);
+                        if (si < 0) { lost++; return; }
+                        aa.ans[ord - aa.ord_base] = set.ord[si];
+                    });
+                    __syncthreads();
+                }
+            }
+            if (top == 0) break;
+            __syncthreads();
+            top--;
+            mask = s_mask[top];
+            val = s_val[top];
+        }
+    }
+    if (lost) atomicAdd(&ctr->overflow, lost);
+}
+
 // per reference set: 1 + ordinal of the last k-mer occurrence routed to it (see host_graph.cpp, before_put)
 template <int NW>
 __global__ __launch_bounds__(BLOCK) void skm_lastput_kernel(E2Dev e, SetParams sp, DevCounters* ctr) {
@@ -1589,6 +1890,44 @@ int e2_scatter(pg_ctx* c, const uint64_t* d_packed, const uint64_t* d_word_off, 
         if (rc != 1) return rc;
     }
     return launch_serial(c, a, nullptr, st);
+}
+
+// pass 2 through the partitions: the node word of every k-mer occurrence of the records in the streams -> d_ans[ordinal - ord_base] (skm_answer_kernel)
+int e2_answer(pg_ctx* c, const uint64_t* d_geo, uint32_t P, uint32_t bias, unsigned long long* d_ans, unsigned long long ord_base, hipStream_t st) {
+    E2& s = c->e2;
+    if (!s.pool) { pg_set_error("the partition streams are gone"); return PG_ESTATE; }
+    if (c->n_owners > 1) { pg_set_error("e2_answer: a context that shares its partitions is not taken here"); return PG_ESTATE; }
+    const uint32_t parts = 1u << s.log2_parts;
+    int n_cu = 256;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, c->device) == hipSuccess) n_cu = prop.multiProcessorCount;
+    const dim3 g(std::min<unsigned>(parts, (unsigned)n_cu * 2u)), b(1024);
+    const OccConst oc = occ_const(c->K, c->NW);
+    const AnsArg aa{d_ans, ord_base, d_geo, P, bias};
+    const bool usual = s.rpc == 128 && s.rs == (uint32_t)s.g.rw;
+    (void)usual;
+    if (c->NW == 2) {
+        if (c->K == 63) hipLaunchKernelGGL((skm_answer_kernel<2, 2048, 1024, 512, 63>), g, b, 0, st, dev_view(c), oc, aa, c->ctr);
+        else if (c->K == 31) hipLaunchKernelGGL((skm_answer_kernel<2, 2048, 1024, 512, 31>), g, b, 0, st, dev_view(c), oc, aa, c->ctr);
+        else hipLaunchKernelGGL((skm_answer_kernel<2, 2048, 1024, 512, 0>), g, b, 0, st, dev_view(c), oc, aa, c->ctr);
+    } else {
+        if (c->K == 127) hipLaunchKernelGGL((skm_answer_kernel<4, 2048, 1024, 192, 127>), g, b, 0, st, dev_view(c), oc, aa, c->ctr);
+        else hipLaunchKernelGGL((skm_answer_kernel<4, 2048, 1024, 192, 0>), g, b, 0, st, dev_view(c), oc, aa, c->ctr);
+    }
+    E2_TRY(hipGetLastError());
+    return PG_OK;
+}
+// ... and what the pass left in the counters: flags (pool / chunk list / split) and occurrences whose k-mer was not found in the LDS set (must be 0)
+int e2_answer_check(pg_ctx* c, hipStream_t st) {
+    E2_TRY(hipStreamSynchronize(st));
+    DevCounters* h = new DevCounters;
+    const hipError_t rc = hipMemcpy(h, c->ctr, sizeof(DevCounters), hipMemcpyDeviceToHost);
+    const unsigned long long flags = h->e2_flags, lost = h->overflow;
+    delete h;
+    E2_TRY(rc);
+    if (flags & (F_POOL | F_CHUNKS | F_SPLIT | F_LEN)) { pg_set_error("pass 2 through the partitions: the partition engine gave up (flags " + std::to_string(flags) + ")"); return PG_ENOMEM; }
+    if (lost) { pg_set_error("pass 2 through the partitions: " + std::to_string(lost) + " occurrence(s) without their k-mer in the set"); return PG_EINVAL; }
+    return PG_OK;
 }
 
 // K3: per reference set, 1 + the ordinal of the last k-mer occurrence routed to it -> ctr->set_last (the streams must still exist)
