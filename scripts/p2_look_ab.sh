@@ -32,9 +32,9 @@ j = json.load(open(f"{o}/result_{name}.json"))
 rows = {r["Name"].split("(")[0].replace("void pg::", ""): r for r in csv.DictReader(open(f"{o}/kernel_stats_{name}.csv"))}
 out = {"arm": name, "identical": j.get("identical_to_reference"), "wall_s": j.get("wall_s")}
 for k, r in rows.items():
-    if k.startswith(("p2_thread", "p2_look", "skm_answer")): out[k] = {"calls": int(r["Calls"]), "total_ms": round(int(r["TotalDurationNs"]) / 1e6, 1), "max_ms": round(int(r["MaxNs"]) / 1e6, 2)}
+    if k.startswith(("p2_thread", "p2_look", "skm_answer", "p2_route", "p2_answer")): out[k] = {"calls": int(r["Calls"]), "total_ms": round(int(r["TotalDurationNs"]) / 1e6, 1), "max_ms": round(int(r["MaxNs"]) / 1e6, 2)}
 for l in j.get("log", []):
-    if "lookup table" in l or "pass 2 batches" in l: out.setdefault("log", []).append(l.strip()[:160])
+    if "lookup table" in l or "pass 2 batches" in l or "pass 2 routed:" in l: out.setdefault("log", []).append(l.strip()[:160])
 print(json.dumps(out))
 PY
 done

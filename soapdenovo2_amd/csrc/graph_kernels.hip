@@ -371,13 +371,15 @@ __global__ __launch_bounds__(256) void p2_read_place_keys(const uint64_t* const*
 // every read one worker and every set one owner (prlRead2path.c:159-248, :248 `mixBuffer[j].low % thrd_num != id`); so does this form:
 //   p2_route_hist      a lane a read: roll the k-mers, owner(k-mer) = lane of its set; per workgroup and owner, how many
 //   (exclusive sum over the owner-major histogram: where every workgroup's queries for every owner start in the send buffer)
-//   p2_route_scatter   roll again: the canonical k-mers (NW words each) go out grouped by owner; where[k-mer] = the place of its query,
-//                      which is the place of its answer
+//   p2_route_scatter   roll again: the canonical k-mers (NW words each) go out grouped by owner.  A read's queries for one owner lie back to
+//                      back, in read order, from starts[owner][read] on -- and so will its answers
 //   (the owners pull their segments of every lane's send buffer: streamed copies, 16 / 32 bytes a lookup)
 //   p2_answer_kernel   the owner probes ITS sets -- local HBM -- and writes the node words (8 bytes a lookup; ~0 = not in the sets)
 //   (the lanes pull their answers back)
 //   p2_thread_routed_kernel   a lane a read: roll once more (which strand is canonical; the read-oriented k-mer of a branch node), node
-//                      word = answers[where[k-mer]], parse1read's state machine as in the direct form
+//                      word = the next answer of the k-mer's owner (a cursor per owner, from starts[][]), parse1read's state machine as in the
+//                      direct form.  (Until round 6 scatter wrote where[k-mer] = the place of its query and this kernel read answers[where[k-mer]]:
+//                      a second random 8-byte read per lookup, on the reading side; 391 ms of 36 launches at 60 M reads on three lanes.)
 // Every k-mer is rolled three times and probed once, where it lives; nothing crosses xGMI but two streams.  No atomics on the way: the
 // places are prefix sums, so a batch's buffers are a function of the batch.
 constexpr int P2R_MAX_LANES = 16;                    // per-thread counters in LDS: 16 x 256 words
@@ -387,8 +389,7 @@ struct P2Route {
     const uint8_t* owner_of_set;                     // [P]
     uint32_t* hist;                                  // [n_own * nblocks + 1] owner-major; after the sum: first place of (owner, workgroup)
     uint64_t* send;                                  // [Q * NW]
-    uint32_t* where;                                 // [Q]
-    const uint64_t* kbase;                           // [n_reads] first k-mer of a read among the batch's (ragged batches; null: r * (uniform_len - K + 1))
+    uint32_t* starts;                                // [n_own][nblocks * 256] where a read's queries for an owner start in the send buffer
 };
 // the k-mers of a read, in read order: f(j, canonical k-mer, smaller, owner)
 template <int NW, typename F>
@@ -440,13 +441,12 @@ __global__ __launch_bounds__(256) void p2_route_scatter(P2Params p, P2Route ro, 
         for (int t = 0; t < 256; t++) { const uint32_t c = cnt[threadIdx.x * 256 + t]; cnt[threadIdx.x * 256 + t] = at; at += c; }
     }
     __syncthreads();
+    for (int o = 0; o < ro.n_own; o++) ro.starts[((uint64_t)o * ro.nblocks + blockIdx.x) * 256 + threadIdx.x] = cnt[o * 256 + threadIdx.x];
     if (!nk) return;
-    const uint64_t kb = ro.kbase ? ro.kbase[r] : r * (uint64_t)nk;
-    p2r_for_kmers<NW>(p, crc4, owner_s, rd, nk, [&](int j, const Kmer<NW>& ck, bool, uint32_t o) {
+    p2r_for_kmers<NW>(p, crc4, owner_s, rd, nk, [&](int, const Kmer<NW>& ck, bool, uint32_t o) {
         const uint32_t at = cnt[o * 256 + threadIdx.x]++;
 #pragma unroll
         for (int i = 0; i < NW; i++) ro.send[(uint64_t)at * NW + i] = ck.w[i];
-        ro.where[kb + j] = at;
     });
 }
 // the owner's side: n canonical k-mers, all of sets that live here
@@ -481,10 +481,22 @@ __global__ __launch_bounds__(256) void p2_answer_kernel(P2Params p, const uint64
         answers[q] = ab;
     }
 }
-template <int NW>
-__global__ __launch_bounds__(256) void p2_thread_routed_kernel(P2Params p, const uint32_t* __restrict__ where, const uint64_t* __restrict__ kbase, const uint64_t* __restrict__ answers,
+// The answers come in one of two orders: CURSORS -- the routed form: a read's answers from owner o lie back to back from ro.starts[o][read] on (the
+// owner of a k-mer from its CRC, as in the scatter); !CURSORS -- pass 2 through the partitions (SOAPDENOVO2_AMD_P2_PARTITIONED=1): k-mer order,
+// read r's from kbase[r] (null: r x the k-mers of a read) on.
+template <int NW, bool CURSORS>
+__global__ __launch_bounds__(256) void p2_thread_routed_kernel(P2Params p, P2Route ro, const uint64_t* __restrict__ kbase, const uint64_t* __restrict__ answers,
                                                                const uint64_t* __restrict__ words, const uint64_t* __restrict__ word_off, const int32_t* __restrict__ lens,
                                                                uint64_t n_reads, uint64_t first_ordinal, int uniform_len) {
+    __shared__ uint32_t crc4[CURSORS ? 4 * 256 : 1];
+    __shared__ uint8_t owner_s[CURSORS ? 256 : 1];
+    __shared__ uint32_t cur[CURSORS ? P2R_MAX_LANES * 256 : 1];
+    if constexpr (CURSORS) {
+        for (int i = threadIdx.x; i < 1024; i += 256) crc4[i] = crc32_slice_entry(i >> 8, i & 255);
+        owner_s[threadIdx.x] = threadIdx.x < p.P ? ro.owner_of_set[threadIdx.x] : (uint8_t)0;
+        for (int o = 0; o < ro.n_own; o++) cur[o * 256 + threadIdx.x] = ro.starts[((uint64_t)o * ro.nblocks + blockIdx.x) * 256 + threadIdx.x];
+        __syncthreads();
+    }
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     const int K = p.K;
@@ -494,7 +506,7 @@ __global__ __launch_bounds__(256) void p2_thread_routed_kernel(P2Params p, const
     const uint64_t* rd = words + (uniform_len ? r * (uint64_t)((uniform_len + 31) / 32) : word_off[r]);
     const Kmer<NW> filter = kmer_filter<NW>(K);
     const int nk = len - K + 1;
-    const uint64_t kb = kbase ? kbase[r] : r * (uint64_t)nk;
+    const uint64_t kb = CURSORS ? 0 : (kbase ? kbase[r] : r * (uint64_t)nk);
     uint32_t* row = p.stage ? p.stage + r * (uint64_t)p.max_nk : nullptr;
     const unsigned long long seq0 = (first_ordinal + r) << 16;
     Kmer<NW> word = read_kmer<NW>(rd, 0, K, filter);
@@ -505,9 +517,14 @@ __global__ __launch_bounds__(256) void p2_thread_routed_kernel(P2Params p, const
     for (int j = 0; j < nk && !w.stop; j++) {
         if (j) kmer_roll<NW>(word, bal, read_base(rd, j + K - 1), K, filter);
         const bool sm = kmer_less<NW>(word, bal);
-        const uint64_t ab = answers[where ? where[kb + j] : kb + j];      // (where = null: the answers lie in k-mer order -- pass 2 through the partitions)
+        const Kmer<NW> ck = sm ? word : bal;
+        uint64_t ab;
+        if constexpr (CURSORS) {
+            const uint32_t o = owner_s[set_of_crc(kmer_crc32_sliced<NW>(ck, crc4), p.P, p.bias)];
+            ab = answers[cur[o * 256 + threadIdx.x]++];
+        } else ab = answers[kb + j];
         if (ab == ~0ULL) { atomicAdd(&p.counters[1], 1ULL); return; }      // not in the sets
-        p2_thread_step<NW>(p, w, sm ? word : bal, sm, ab, row, seq0);
+        p2_thread_step<NW>(p, w, ck, sm, ab, row, seq0);
     }
     p2_thread_end<NW>(p, w, row, r);
 }
@@ -1084,14 +1101,12 @@ struct P2Lane {
         int uniform_len = 0;
         uint32_t* walks_out = nullptr; uint16_t* walk_len_out = nullptr;
     } pend;
-    std::vector<uint64_t> h_kbase;                   // ragged batches: first k-mer of every read
     uint8_t* d_owner_of_set = nullptr;
     template <typename T> struct Buf { T* p = nullptr; size_t cap = 0; };        // grow-only device buffers (the arena makes growing cheap)
-    Buf<uint64_t> kbase;
     Buf<uint32_t> hist_in, hist;
     Buf<unsigned char> scan_tmp;
     Buf<uint64_t> send, ans;                         // as a reader of batches: the keys it asks for, the node words that come back
-    Buf<uint32_t> where;
+    Buf<uint32_t> where;                             // starts[owner][read]: where a read's queries for an owner begin (its answers come back at the same places)
     Buf<uint64_t> rkeys, rans;                       // as an owner of sets: the keys it is asked for, its answers
     uint32_t* h_starts = nullptr;                    // page-locked: where every owner's segment starts in this lane's send buffer, and the total
     uint64_t lookups_sent = 0, lookups_sent_away = 0, lookups_answered = 0, route_rounds = 0;
@@ -1140,7 +1155,7 @@ static void p2_free(P2Device* d) {
         if (l) pg::arena_free(ln.d_counters);
         pg::arena_free(ln.d_marker);
         pg::arena_free(ln.d_words); pg::arena_free(ln.d_off); pg::arena_free(ln.d_lens); pg::arena_free(ln.d_stage); pg::arena_free(ln.d_walk_len);
-        pg::arena_free(ln.d_owner_of_set); pg::arena_free(ln.kbase.p); pg::arena_free(ln.hist_in.p); pg::arena_free(ln.hist.p); pg::arena_free(ln.scan_tmp.p);
+        pg::arena_free(ln.d_owner_of_set); pg::arena_free(ln.hist_in.p); pg::arena_free(ln.hist.p); pg::arena_free(ln.scan_tmp.p);
         pg::arena_free(ln.send.p); pg::arena_free(ln.where.p); pg::arena_free(ln.ans.p); pg::arena_free(ln.rkeys.p); pg::arena_free(ln.rans.p);
         if (ln.h_starts) (void)hipHostFree(ln.h_starts);
         if (ln.copied) (void)hipEventDestroy(ln.copied);
@@ -2262,11 +2277,11 @@ static int p2_route_round(P2Device* d) {
         const size_t nh = (size_t)N * nblocks + 1;
         int rc = p2r_grow(ln.hist_in, nh);
         if (!rc) rc = p2r_grow(ln.hist, nh);
-        if (!rc) rc = p2r_grow(ln.where, (size_t)b.q);
+        if (!rc) rc = p2r_grow(ln.where, (size_t)N * nblocks * 256);
         if (!rc) rc = p2r_grow(ln.ans, (size_t)b.q);
         if (!rc) rc = p2r_grow(ln.send, (size_t)b.q * nw);
         if (rc) return rc;
-        P2Route ro{N, nblocks, ln.d_owner_of_set, ln.hist_in.p, ln.send.p, ln.where.p, b.d_off ? ln.kbase.p : nullptr};
+        P2Route ro{N, nblocks, ln.d_owner_of_set, ln.hist_in.p, ln.send.p, ln.where.p};
         const dim3 grid(nblocks), block(256);
         P2_HIP(hipMemsetAsync(ln.hist_in.p + (nh - 1), 0, sizeof(uint32_t), ln.stream));
         if (nw == 2) hipLaunchKernelGGL((p2_route_hist<2>), grid, block, 0, ln.stream, ln.prm, ro, b.d_words, b.d_off, b.d_lens, b.n_reads, b.uniform_len);
@@ -2333,9 +2348,11 @@ static int p2_route_round(P2Device* d) {
         P2Params p = ln.prm;
         p.stage = d->reps ? ln.d_stage : nullptr;
         p.walk_len = d->reps ? ln.d_walk_len : nullptr;
-        const dim3 grid((unsigned)((b.n_reads + 255) / 256)), block(256);
-        if (nw == 2) hipLaunchKernelGGL((p2_thread_routed_kernel<2>), grid, block, 0, ln.stream, p, ln.where.p, b.d_off ? ln.kbase.p : nullptr, ln.ans.p, b.d_words, b.d_off, b.d_lens, b.n_reads, b.ordinal, b.uniform_len);
-        else hipLaunchKernelGGL((p2_thread_routed_kernel<4>), grid, block, 0, ln.stream, p, ln.where.p, b.d_off ? ln.kbase.p : nullptr, ln.ans.p, b.d_words, b.d_off, b.d_lens, b.n_reads, b.ordinal, b.uniform_len);
+        const uint32_t nblocks = (uint32_t)((b.n_reads + 255) / 256);
+        const dim3 grid(nblocks), block(256);
+        const P2Route ro{N, nblocks, ln.d_owner_of_set, nullptr, nullptr, ln.where.p};
+        if (nw == 2) hipLaunchKernelGGL((p2_thread_routed_kernel<2, true>), grid, block, 0, ln.stream, p, ro, (const uint64_t*)nullptr, ln.ans.p, b.d_words, b.d_off, b.d_lens, b.n_reads, b.ordinal, b.uniform_len);
+        else hipLaunchKernelGGL((p2_thread_routed_kernel<4, true>), grid, block, 0, ln.stream, p, ro, (const uint64_t*)nullptr, ln.ans.p, b.d_words, b.d_off, b.d_lens, b.n_reads, b.ordinal, b.uniform_len);
         P2_HIP(hipGetLastError());
         if (d->reps && b.walks_out && b.walk_len_out) {
             P2_HIP(hipMemcpyAsync(b.walks_out, ln.d_stage, b.n_reads * (size_t)d->max_nk * sizeof(uint32_t), hipMemcpyDeviceToHost, ln.stream));
@@ -2405,12 +2422,8 @@ int p2_add_packed(P2Device* d, const uint64_t* words, const uint64_t* word_off, 
     P2_HIP(hipMemcpyAsync(ln.d_off, word_off, n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, ln.stream));
     P2_HIP(hipMemcpyAsync(ln.d_lens, lens, n_reads * sizeof(int32_t), hipMemcpyHostToDevice, ln.stream));
     uint64_t q = 0;
-    if (d->route) {                                                   // the first k-mer of every read among the batch's (prlRead2path.c:1103: reads shorter than K + 1 have none)
-        ln.h_kbase.resize(n_reads);
-        for (uint64_t r = 0; r < n_reads; r++) { ln.h_kbase[r] = q; if (lens[r] >= d->K + 1) q += (uint64_t)(lens[r] - d->K + 1); }
-        { const int rc = p2r_grow(ln.kbase, (size_t)n_reads); if (rc) return rc; }
-        P2_HIP(hipMemcpyAsync(ln.kbase.p, ln.h_kbase.data(), n_reads * sizeof(uint64_t), hipMemcpyHostToDevice, ln.stream));
-    }
+    if (d->route)                                                     // the lookups the batch asks for (prlRead2path.c:1103: reads shorter than K + 1 have none)
+        for (uint64_t r = 0; r < n_reads; r++) if (lens[r] >= d->K + 1) q += (uint64_t)(lens[r] - d->K + 1);
     P2_HIP(hipEventRecord(ln.copied, ln.stream));
     // (-R: the walks come back with the call, so a routed batch does not wait for the other lanes' batches)
     { const int rc = p2_batch_ready(d, ln, ln.d_words, ln.d_off, ln.d_lens, n_reads, q, 0, walks_out, walk_len_out, d->reps); if (rc) return rc; }
@@ -2501,8 +2514,8 @@ int p2_add_packed_device_segments(P2Device* d, const uint64_t* const* d_segs, co
                 P2Params p = ln.prm;
                 p.stage = nullptr; p.walk_len = nullptr;
                 const dim3 grid((unsigned)((seg_reads[q] + 255) / 256)), block(256);
-                if (d->nw == 2) hipLaunchKernelGGL((p2_thread_routed_kernel<2>), grid, block, 0, st, p, (const uint32_t*)nullptr, (const uint64_t*)nullptr, (const uint64_t*)(d_ans + local * kpr), d_segs[q], (const uint64_t*)nullptr, (const int32_t*)nullptr, seg_reads[q], d->ordinal + g_first + local, read_len);
-                else hipLaunchKernelGGL((p2_thread_routed_kernel<4>), grid, block, 0, st, p, (const uint32_t*)nullptr, (const uint64_t*)nullptr, (const uint64_t*)(d_ans + local * kpr), d_segs[q], (const uint64_t*)nullptr, (const int32_t*)nullptr, seg_reads[q], d->ordinal + g_first + local, read_len);
+                if (d->nw == 2) hipLaunchKernelGGL((p2_thread_routed_kernel<2, false>), grid, block, 0, st, p, P2Route{}, (const uint64_t*)nullptr, (const uint64_t*)(d_ans + local * kpr), d_segs[q], (const uint64_t*)nullptr, (const int32_t*)nullptr, seg_reads[q], d->ordinal + g_first + local, read_len);
+                else hipLaunchKernelGGL((p2_thread_routed_kernel<4, false>), grid, block, 0, st, p, P2Route{}, (const uint64_t*)nullptr, (const uint64_t*)(d_ans + local * kpr), d_segs[q], (const uint64_t*)nullptr, (const int32_t*)nullptr, seg_reads[q], d->ordinal + g_first + local, read_len);
                 if (hipGetLastError() != hipSuccess) { pg_set_error("pass 2 through the partitions: launch failed"); rc = PG_ENODEV; }
                 local += seg_reads[q];
             }
@@ -2587,10 +2600,6 @@ int p2_add_packed_device_ragged(P2Device* d, const uint64_t* d_words, const uint
     }
     hipLaunchKernelGGL(p2_lens_from_kbase, dim3((unsigned)((n_reads + 255) / 256)), dim3(256), 0, ln->stream, d_kmer_base, n_reads, d->K, ln->d_lens);
     P2_HIP(hipGetLastError());
-    if (d->route) {                                                   // (every read has k-mers here: kmer_base IS the first k-mer of a read among the batch's)
-        { const int rc = p2r_grow(ln->kbase, (size_t)n_reads); if (rc) return rc; }
-        P2_HIP(hipMemcpyAsync(ln->kbase.p, d_kmer_base, n_reads * sizeof(uint64_t), hipMemcpyDeviceToDevice, ln->stream));
-    }
     { const int rc = p2_batch_ready(d, *ln, d_words, d_word_off, ln->d_lens, n_reads, n_kmers, 0, nullptr, nullptr, true); if (rc) return rc; }
     P2_HIP(hipSetDevice(ln->device));
     P2_HIP(hipStreamSynchronize(ln->stream));
