@@ -76,10 +76,8 @@ struct P2Params {
     const uint32_t* patch_val;          // id, twin an entry; id 0 = empty
     uint64_t patch_mask;
     // pre-arc table
-    unsigned long long* arc_key;        // from << 32 | to, 0 = empty
-    unsigned int* arc_cnt;
-    unsigned long long* arc_first;
-    uint64_t arc_mask;
+    unsigned long long* arc;            // ARC_WORDS words an entry: from << 32 | to (0 = empty), the earliest meeting (read ordinal << 16 | item), the
+    uint64_t arc_mask;                  // multiplicity (32 bits), padding -- 32 bytes, so that one pre-arc touches ONE 64-byte line (p2_add_prearc)
     // -R
     uint32_t* stage;                    // [read in batch][max_nk]
     uint16_t* walk_len;                 // valid entries per read (0 when the walk does not qualify)
@@ -116,22 +114,30 @@ __device__ inline uint32_t find_patch(const P2Params& p, const Kmer<NW>& key, bo
     }
 }
 
+// One pre-arc of one read into the lane's table (thread_add1preArc, prlRead2path.c:388-403: a multiplicity and who met it first).  Until round 6 the key,
+// the multiplicity and the first meeting were three arrays -- three random lines and three atomics a call, 167 ms of p2_thread_kernel's 729 ms at 200 M
+// reads (measured by leaving the calls out).  Now an entry is 32 bytes in one line: key and first meeting are read together, the multiplicity goes up with
+// an atomic nobody waits for, and the minimum is only taken by a read that is earlier than what it saw (first meetings only ever go down, so a stale
+// value can make a read take a minimum it need not have, never skip one it needed).
+constexpr int ARC_WORDS = 4;
 __device__ inline void add_prearc(const P2Params& p, uint32_t from, uint32_t to, unsigned long long seq) {
     const unsigned long long key = ((unsigned long long)from << 32) | to;
     uint64_t h = (key * 0x9E3779B97F4A7C15ULL) >> 20;
     h &= p.arc_mask;
     for (uint64_t step = 0; step <= p.arc_mask; step++) {
-        unsigned long long cur = __hip_atomic_load(&p.arc_key[h], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned long long* e = p.arc + h * ARC_WORDS;
+        unsigned long long cur = __hip_atomic_load(&e[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long seen = __hip_atomic_load(&e[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (cur == 0) {
             unsigned long long expected = 0;
             // (the distinct pairs are counted when the table is read out, p2_count_arcs: a counter bumped here would take one atomic on
             //  ONE address per new pair -- a billion of them at configs[3], at the 88 per microsecond an address serves)
-            if (__hip_atomic_compare_exchange_strong(&p.arc_key[h], &expected, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) cur = key;
+            if (__hip_atomic_compare_exchange_strong(&e[0], &expected, key, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) cur = key;
             else cur = expected;
         }
         if (cur == key) {
-            atomicAdd(&p.arc_cnt[h], 1u);
-            atomicMin(&p.arc_first[h], seq);
+            atomicAdd((unsigned int*)&e[2], 1u);
+            if (seq < seen) atomicMin(&e[1], seq);
             return;
         }
         h = (h + 1) & p.arc_mask;
@@ -481,22 +487,19 @@ __global__ __launch_bounds__(256) void p2_answer_kernel(P2Params p, const uint64
         answers[q] = ab;
     }
 }
-// The answers come in one of two orders: CURSORS -- the routed form: a read's answers from owner o lie back to back from ro.starts[o][read] on (the
-// owner of a k-mer from its CRC, as in the scatter); !CURSORS -- pass 2 through the partitions (SOAPDENOVO2_AMD_P2_PARTITIONED=1): k-mer order,
-// read r's from kbase[r] (null: r x the k-mers of a read) on.
-template <int NW, bool CURSORS>
-__global__ __launch_bounds__(256) void p2_thread_routed_kernel(P2Params p, P2Route ro, const uint64_t* __restrict__ kbase, const uint64_t* __restrict__ answers,
+// The routed form's reading side: a read's answers from owner o lie back to back from ro.starts[o][read] on (the owner of a k-mer from its CRC, as in
+// the scatter).
+template <int NW>
+__global__ __launch_bounds__(256) void p2_thread_routed_kernel(P2Params p, P2Route ro, const uint64_t* __restrict__ answers,
                                                                const uint64_t* __restrict__ words, const uint64_t* __restrict__ word_off, const int32_t* __restrict__ lens,
                                                                uint64_t n_reads, uint64_t first_ordinal, int uniform_len) {
-    __shared__ uint32_t crc4[CURSORS ? 4 * 256 : 1];
-    __shared__ uint8_t owner_s[CURSORS ? 256 : 1];
-    __shared__ uint32_t cur[CURSORS ? P2R_MAX_LANES * 256 : 1];
-    if constexpr (CURSORS) {
-        for (int i = threadIdx.x; i < 1024; i += 256) crc4[i] = crc32_slice_entry(i >> 8, i & 255);
-        owner_s[threadIdx.x] = threadIdx.x < p.P ? ro.owner_of_set[threadIdx.x] : (uint8_t)0;
-        for (int o = 0; o < ro.n_own; o++) cur[o * 256 + threadIdx.x] = ro.starts[((uint64_t)o * ro.nblocks + blockIdx.x) * 256 + threadIdx.x];
-        __syncthreads();
-    }
+    __shared__ uint32_t crc4[4 * 256];
+    __shared__ uint8_t owner_s[256];
+    __shared__ uint32_t cur[P2R_MAX_LANES * 256];
+    for (int i = threadIdx.x; i < 1024; i += 256) crc4[i] = crc32_slice_entry(i >> 8, i & 255);
+    owner_s[threadIdx.x] = threadIdx.x < p.P ? ro.owner_of_set[threadIdx.x] : (uint8_t)0;
+    for (int o = 0; o < ro.n_own; o++) cur[o * 256 + threadIdx.x] = ro.starts[((uint64_t)o * ro.nblocks + blockIdx.x) * 256 + threadIdx.x];
+    __syncthreads();
     const uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_reads) return;
     const int K = p.K;
@@ -506,7 +509,6 @@ __global__ __launch_bounds__(256) void p2_thread_routed_kernel(P2Params p, P2Rou
     const uint64_t* rd = words + (uniform_len ? r * (uint64_t)((uniform_len + 31) / 32) : word_off[r]);
     const Kmer<NW> filter = kmer_filter<NW>(K);
     const int nk = len - K + 1;
-    const uint64_t kb = CURSORS ? 0 : (kbase ? kbase[r] : r * (uint64_t)nk);
     uint32_t* row = p.stage ? p.stage + r * (uint64_t)p.max_nk : nullptr;
     const unsigned long long seq0 = (first_ordinal + r) << 16;
     Kmer<NW> word = read_kmer<NW>(rd, 0, K, filter);
@@ -518,15 +520,58 @@ __global__ __launch_bounds__(256) void p2_thread_routed_kernel(P2Params p, P2Rou
         if (j) kmer_roll<NW>(word, bal, read_base(rd, j + K - 1), K, filter);
         const bool sm = kmer_less<NW>(word, bal);
         const Kmer<NW> ck = sm ? word : bal;
-        uint64_t ab;
-        if constexpr (CURSORS) {
-            const uint32_t o = owner_s[set_of_crc(kmer_crc32_sliced<NW>(ck, crc4), p.P, p.bias)];
-            ab = answers[cur[o * 256 + threadIdx.x]++];
-        } else ab = answers[kb + j];
+        const uint32_t o = owner_s[set_of_crc(kmer_crc32_sliced<NW>(ck, crc4), p.P, p.bias)];
+        const uint64_t ab = answers[cur[o * 256 + threadIdx.x]++];
         if (ab == ~0ULL) { atomicAdd(&p.counters[1], 1ULL); return; }      // not in the sets
         p2_thread_step<NW>(p, w, ck, sm, ab, row, seq0);
     }
     p2_thread_end<NW>(p, w, row, r);
+}
+// Pass 2 through the partitions (SOAPDENOVO2_AMD_P2_PARTITIONED=1): the answers lie in k-mer order, read r's nk of them from r x nk on (reads of one
+// length).  A lane a read walking its own row visits every 64-byte line eight times with 45 KB of rows a wave between the visits -- the lines do not
+// stay in L2 (419 ms per 200 M reads).  So a workgroup brings its 256 rows in through LDS, P2O_CHUNK answers a row at a time: the loads are whole
+// 128-byte pieces of rows, the walk reads LDS.
+constexpr int P2O_CHUNK = 16;
+template <int NW>
+__global__ __launch_bounds__(256) void p2_thread_ordered_kernel(P2Params p, const uint64_t* __restrict__ answers, const uint64_t* __restrict__ words,
+                                                                uint64_t n_reads, uint64_t first_ordinal, int uniform_len) {
+    __shared__ uint64_t tile[256 * (P2O_CHUNK + 1)];
+    const uint64_t r0 = (uint64_t)blockIdx.x * 256, r = r0 + threadIdx.x;
+    const int K = p.K;
+    const int nk = uniform_len - K + 1;
+    const uint64_t* rd = words + (r < n_reads ? r : 0) * (uint64_t)((uniform_len + 31) / 32);
+    const Kmer<NW> filter = kmer_filter<NW>(K);
+    uint32_t* row = p.stage ? p.stage + r * (uint64_t)p.max_nk : nullptr;
+    const unsigned long long seq0 = (first_ordinal + r) << 16;
+    bool alive = r < n_reads;
+    if (alive && p.walk_len) p.walk_len[r] = 0;
+    Kmer<NW> word = read_kmer<NW>(rd, 0, K, filter);
+    Kmer<NW> bal = kmer_rc<NW>(word, K);
+    P2Walk<NW> w;
+#pragma unroll
+    for (int i = 0; i < NW; i++) w.prev_k.w[i] = 0;
+    const uint64_t rows_here = n_reads - r0 < 256 ? n_reads - r0 : 256;
+    for (int c0 = 0; c0 < nk; c0 += P2O_CHUNK) {
+        const int cn = nk - c0 < P2O_CHUNK ? nk - c0 : P2O_CHUNK;
+        for (int i = threadIdx.x; i < 256 * P2O_CHUNK; i += 256) {
+            const int rr = i / P2O_CHUNK, cc = i % P2O_CHUNK;
+            if ((uint64_t)rr < rows_here && cc < cn) tile[rr * (P2O_CHUNK + 1) + cc] = answers[(r0 + rr) * (uint64_t)nk + c0 + cc];
+        }
+        __syncthreads();
+        if (alive) {
+            for (int j = c0; j < c0 + cn; j++) {
+                if (j) kmer_roll<NW>(word, bal, read_base(rd, j + K - 1), K, filter);
+                const bool sm = kmer_less<NW>(word, bal);
+                const uint64_t ab = tile[threadIdx.x * (P2O_CHUNK + 1) + (j - c0)];
+                if (ab == ~0ULL) { atomicAdd(&p.counters[1], 1ULL); alive = false; break; }      // not in the sets
+                p2_thread_step<NW>(p, w, sm ? word : bal, sm, ab, row, seq0);
+                if (w.stop) break;
+            }
+            if (alive && w.stop) { p2_thread_end<NW>(p, w, row, r); alive = false; }
+        }
+        __syncthreads();
+    }
+    if (alive) p2_thread_end<NW>(p, w, row, r);
 }
 
 
@@ -993,31 +1038,30 @@ __global__ void tip_remark(uint64_t* nodes, int nw1, uint64_t n_slots) {
 
 // the occupied slots of the pre-arc table: counted (one atomic a workgroup), then written out densely (order does not matter: the host
 // sorts; a workgroup reserves room for its slots of a trip with one returned atomic)
-__global__ __launch_bounds__(256) void p2_count_arcs(const unsigned long long* key, uint64_t cap, unsigned long long* n_out) {
+__global__ __launch_bounds__(256) void p2_count_arcs(const unsigned long long* key /* the table: ARC_WORDS words an entry */, uint64_t cap, unsigned long long* n_out) {
     __shared__ unsigned int s_n;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
     unsigned int mine = 0;
-    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * 256) mine += key[i] != 0;
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < cap; i += (uint64_t)gridDim.x * 256) mine += key[i * ARC_WORDS] != 0;
     if (mine) atomicAdd(&s_n, mine);
     __syncthreads();
     if (threadIdx.x == 0 && s_n) atomicAdd(n_out, (unsigned long long)s_n);
 }
-__global__ __launch_bounds__(256) void p2_compact_arcs(const unsigned long long* key, const unsigned int* cnt, const unsigned long long* first, uint64_t cap,
-                                                       P2Arc* out, unsigned long long* n_out, unsigned long long out_cap) {
+__global__ __launch_bounds__(256) void p2_compact_arcs(const unsigned long long* tab, uint64_t cap, P2Arc* out, unsigned long long* n_out, unsigned long long out_cap) {
     __shared__ unsigned int s_n;
     __shared__ unsigned long long s_base;
     for (uint64_t i0 = (uint64_t)blockIdx.x * 256; i0 < cap; i0 += (uint64_t)gridDim.x * 256) {
         if (threadIdx.x == 0) s_n = 0;
         __syncthreads();
         const uint64_t i = i0 + threadIdx.x;
-        const unsigned long long k = i < cap ? key[i] : 0ULL;
+        const unsigned long long k = i < cap ? tab[i * ARC_WORDS] : 0ULL;
         unsigned int my = 0;
         if (k) my = atomicAdd(&s_n, 1u);
         __syncthreads();
         if (threadIdx.x == 0 && s_n) s_base = atomicAdd(n_out, (unsigned long long)s_n);
         __syncthreads();
-        if (k && s_base + my < out_cap) out[s_base + my] = P2Arc{(uint32_t)(k >> 32), (uint32_t)k, cnt[i], first[i]};
+        if (k && s_base + my < out_cap) out[s_base + my] = P2Arc{(uint32_t)(k >> 32), (uint32_t)k, (uint32_t)tab[i * ARC_WORDS + 2], tab[i * ARC_WORDS + 1]};
     }
 }
 
@@ -1057,8 +1101,8 @@ __global__ __launch_bounds__(256) void pf_gather(const P2Arc* a, const uint32_t*
         out3[3 * i] = x.from; out3[3 * i + 1] = x.to; out3[3 * i + 2] = x.mult;
     }
 }
-__global__ void p2_fill_u64(unsigned long long* a, uint64_t n, unsigned long long v) {
-    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x) a[i] = v;
+__global__ void p2_arc_init(unsigned long long* tab, uint64_t cap) {                // empty entries: no key, no meeting yet, multiplicity 0
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < cap * ARC_WORDS; i += (uint64_t)gridDim.x * blockDim.x) tab[i] = (i % ARC_WORDS) == 1 ? ~0ULL : 0ULL;
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -1082,9 +1126,7 @@ struct P2Lane {
     uint64_t* d_patch_keys = nullptr;
     uint32_t* d_patch_val = nullptr;
     bool own_geo = false, own_patch = false;
-    unsigned long long* d_arc_key = nullptr;
-    unsigned int* d_arc_cnt = nullptr;
-    unsigned long long* d_arc_first = nullptr;
+    unsigned long long* d_arc = nullptr;             // the lane's pre-arc table (P2Params::arc)
     unsigned long long* d_counters = nullptr;
     unsigned int* d_marker = nullptr;
     uint64_t* d_words = nullptr; size_t cap_words = 0;
@@ -1151,7 +1193,7 @@ static void p2_free(P2Device* d) {
         if (ln.own_geo) { pg::arena_free(ln.d_geo3); pg::arena_free(ln.d_crc); }
         pg::arena_free(ln.d_wcnt);
         if (ln.own_patch) { pg::arena_free(ln.d_patch_keys); pg::arena_free(ln.d_patch_val); }
-        pg::arena_free(ln.d_arc_key); pg::arena_free(ln.d_arc_cnt); pg::arena_free(ln.d_arc_first);
+        pg::arena_free(ln.d_arc);
         if (l) pg::arena_free(ln.d_counters);
         pg::arena_free(ln.d_marker);
         pg::arena_free(ln.d_words); pg::arena_free(ln.d_off); pg::arena_free(ln.d_lens); pg::arena_free(ln.d_stage); pg::arena_free(ln.d_walk_len);
@@ -1709,12 +1751,8 @@ int p2_begin_reads(P2Device* d, uint32_t num_ed, bool reps) {
         }
         if (l == 0) ln.d_counters = d->d_counters;
         else P2_HIP(pg::arena_malloc((void**)&ln.d_counters, 8 * sizeof(unsigned long long)));
-        P2_HIP(pg::arena_malloc((void**)&ln.d_arc_key, arc_cap * sizeof(unsigned long long)));
-        P2_HIP(pg::arena_malloc((void**)&ln.d_arc_cnt, arc_cap * sizeof(unsigned int)));
-        P2_HIP(pg::arena_malloc((void**)&ln.d_arc_first, arc_cap * sizeof(unsigned long long)));
-        P2_HIP(hipMemsetAsync(ln.d_arc_key, 0, arc_cap * sizeof(unsigned long long), ln.stream));
-        P2_HIP(hipMemsetAsync(ln.d_arc_cnt, 0, arc_cap * sizeof(unsigned int), ln.stream));
-        hipLaunchKernelGGL(p2_fill_u64, dim3(1024), dim3(256), 0, ln.stream, ln.d_arc_first, arc_cap, ~0ULL);
+        P2_HIP(pg::arena_malloc((void**)&ln.d_arc, arc_cap * ARC_WORDS * sizeof(unsigned long long)));
+        hipLaunchKernelGGL(p2_arc_init, dim3(2048), dim3(256), 0, ln.stream, ln.d_arc, arc_cap);
         P2_HIP(hipMemsetAsync(ln.d_counters, 0, 8 * sizeof(unsigned long long), ln.stream));
         if (d->reps) {
             P2_HIP(pg::arena_malloc((void**)&ln.d_marker, ((size_t)d->num_ed + 1) * sizeof(unsigned int)));
@@ -1731,7 +1769,7 @@ int p2_begin_reads(P2Device* d, uint32_t num_ed, bool reps) {
         P2_HIP(hipStreamSynchronize(ln.stream));
         P2Params& p = ln.prm;
         p.counters = ln.d_counters;
-        p.arc_key = ln.d_arc_key; p.arc_cnt = ln.d_arc_cnt; p.arc_first = ln.d_arc_first; p.arc_mask = arc_cap - 1;
+        p.arc = ln.d_arc; p.arc_mask = arc_cap - 1;
         p.marker = ln.d_marker; p.id_end = d->num_ed + 1;
         ln.tables = true;
     }
@@ -2351,8 +2389,8 @@ static int p2_route_round(P2Device* d) {
         const uint32_t nblocks = (uint32_t)((b.n_reads + 255) / 256);
         const dim3 grid(nblocks), block(256);
         const P2Route ro{N, nblocks, ln.d_owner_of_set, nullptr, nullptr, ln.where.p};
-        if (nw == 2) hipLaunchKernelGGL((p2_thread_routed_kernel<2, true>), grid, block, 0, ln.stream, p, ro, (const uint64_t*)nullptr, ln.ans.p, b.d_words, b.d_off, b.d_lens, b.n_reads, b.ordinal, b.uniform_len);
-        else hipLaunchKernelGGL((p2_thread_routed_kernel<4, true>), grid, block, 0, ln.stream, p, ro, (const uint64_t*)nullptr, ln.ans.p, b.d_words, b.d_off, b.d_lens, b.n_reads, b.ordinal, b.uniform_len);
+        if (nw == 2) hipLaunchKernelGGL((p2_thread_routed_kernel<2>), grid, block, 0, ln.stream, p, ro, ln.ans.p, b.d_words, b.d_off, b.d_lens, b.n_reads, b.ordinal, b.uniform_len);
+        else hipLaunchKernelGGL((p2_thread_routed_kernel<4>), grid, block, 0, ln.stream, p, ro, ln.ans.p, b.d_words, b.d_off, b.d_lens, b.n_reads, b.ordinal, b.uniform_len);
         P2_HIP(hipGetLastError());
         if (d->reps && b.walks_out && b.walk_len_out) {
             P2_HIP(hipMemcpyAsync(b.walks_out, ln.d_stage, b.n_reads * (size_t)d->max_nk * sizeof(uint32_t), hipMemcpyDeviceToHost, ln.stream));
@@ -2490,7 +2528,9 @@ int p2_add_packed_device_segments(P2Device* d, const uint64_t* const* d_segs, co
         p2_drop_look(d);                                  // (this form does not read the lookup table: its room goes to the answers)
         hipStream_t st = ln.stream;
         const uint64_t kpr = (uint64_t)(read_len - d->K + 1), per_seg = seg_reads[0];
-        uint64_t segs_a_round = std::max<uint64_t>(1, (((uint64_t)40 << 30) / 8) / std::max<uint64_t>(1, per_seg * kpr));
+        uint64_t ans_gb = 40;
+        if (const char* e = getenv("PG_P2_PART_GB")) ans_gb = (uint64_t)std::max(1, atoi(e));           // (A/B knob)
+        uint64_t segs_a_round = std::max<uint64_t>(1, ((ans_gb << 30) / 8) / std::max<uint64_t>(1, per_seg * kpr));
         segs_a_round = std::min<uint64_t>(segs_a_round, (uint64_t)n_segs);
         const uint64_t reads_round = segs_a_round * per_seg;
         pg_ctx* ctx = pg_create_planned(ln.device, d->K, d->nw == 4 ? 1 : 0, d->P, 24, 2, reads_round * kpr, reads_round, 1, 1);
@@ -2514,8 +2554,8 @@ int p2_add_packed_device_segments(P2Device* d, const uint64_t* const* d_segs, co
                 P2Params p = ln.prm;
                 p.stage = nullptr; p.walk_len = nullptr;
                 const dim3 grid((unsigned)((seg_reads[q] + 255) / 256)), block(256);
-                if (d->nw == 2) hipLaunchKernelGGL((p2_thread_routed_kernel<2, false>), grid, block, 0, st, p, P2Route{}, (const uint64_t*)nullptr, (const uint64_t*)(d_ans + local * kpr), d_segs[q], (const uint64_t*)nullptr, (const int32_t*)nullptr, seg_reads[q], d->ordinal + g_first + local, read_len);
-                else hipLaunchKernelGGL((p2_thread_routed_kernel<4, false>), grid, block, 0, st, p, P2Route{}, (const uint64_t*)nullptr, (const uint64_t*)(d_ans + local * kpr), d_segs[q], (const uint64_t*)nullptr, (const int32_t*)nullptr, seg_reads[q], d->ordinal + g_first + local, read_len);
+                if (d->nw == 2) hipLaunchKernelGGL((p2_thread_ordered_kernel<2>), grid, block, 0, st, p, (const uint64_t*)(d_ans + local * kpr), d_segs[q], seg_reads[q], d->ordinal + g_first + local, read_len);
+                else hipLaunchKernelGGL((p2_thread_ordered_kernel<4>), grid, block, 0, st, p, (const uint64_t*)(d_ans + local * kpr), d_segs[q], seg_reads[q], d->ordinal + g_first + local, read_len);
                 if (hipGetLastError() != hipSuccess) { pg_set_error("pass 2 through the partitions: launch failed"); rc = PG_ENODEV; }
                 local += seg_reads[q];
             }
@@ -2670,7 +2710,7 @@ int p2_finish(P2Device* d, P2Result& out) {
         P2_HIP(hipSetDevice(ln.device));
         P2_HIP(hipStreamSynchronize(ln.stream));
         P2_HIP(hipMemsetAsync(ln.d_counters + 3, 0, sizeof(unsigned long long), ln.stream));
-        hipLaunchKernelGGL(p2_count_arcs, dim3(2048), dim3(256), 0, ln.stream, ln.d_arc_key, ln.prm.arc_mask + 1, ln.d_counters + 3);
+        hipLaunchKernelGGL(p2_count_arcs, dim3(2048), dim3(256), 0, ln.stream, ln.d_arc, ln.prm.arc_mask + 1, ln.d_counters + 3);
         P2_HIP(hipGetLastError());
         P2_HIP(hipStreamSynchronize(ln.stream));
         unsigned long long cl[8];
@@ -2724,7 +2764,7 @@ int p2_finish(P2Device* d, P2Result& out) {
             if (in_place) d_arcs = d_all + at;
             else P2_HIP(pg::arena_malloc((void**)&d_arcs, n_l * sizeof(P2Arc)));
             P2_HIP(hipMemsetAsync(ln.d_counters + 6, 0, sizeof(unsigned long long), ln.stream));
-            hipLaunchKernelGGL(p2_compact_arcs, dim3(2048), dim3(256), 0, ln.stream, ln.d_arc_key, ln.d_arc_cnt, ln.d_arc_first, cap, d_arcs, ln.d_counters + 6, (unsigned long long)n_l);
+            hipLaunchKernelGGL(p2_compact_arcs, dim3(2048), dim3(256), 0, ln.stream, ln.d_arc, cap, d_arcs, ln.d_counters + 6, (unsigned long long)n_l);
             if (!dev_fold) P2_HIP(hipMemcpyAsync(out.arcs.data() + at, d_arcs, n_l * sizeof(P2Arc), hipMemcpyDeviceToHost, ln.stream));
             else if (!in_place) P2_HIP(hipMemcpyPeerAsync(d_all + at, d->device, d_arcs, ln.device, n_l * sizeof(P2Arc), ln.stream));
             unsigned long long got = 0;
