@@ -114,6 +114,19 @@ __device__ inline uint32_t find_patch(const P2Params& p, const Kmer<NW>& key, bo
     }
 }
 
+// the bases of a packed read one after the other: the 32-base word at hand stays in a register (read_base loads it anew for every base -- a load in
+// every step of a lane's walk, 88 a read of 150 bases where 3 do)
+struct ReadBases {
+    const uint64_t* rd;
+    uint64_t w = 0;
+    int wi = -1;
+    __device__ __forceinline__ explicit ReadBases(const uint64_t* r) : rd(r) {}
+    __device__ __forceinline__ int at(int i) {
+        if ((i >> 5) != wi) { wi = i >> 5; w = rd[wi]; }
+        return (int)((w >> (62 - 2 * (i & 31))) & 3);
+    }
+};
+
 // One pre-arc of one read into the lane's table (thread_add1preArc, prlRead2path.c:388-403: a multiplicity and who met it first).  Until round 6 the key,
 // the multiplicity and the first meeting were three arrays -- three random lines and three atomics a call, 167 ms of p2_thread_kernel's 729 ms at 200 M
 // reads (measured by leaving the calls out).  Now an entry is 32 bytes in one line: key and first meeting are read together, the multiplicity goes up with
@@ -295,11 +308,12 @@ __global__ __launch_bounds__(256) void p2_thread_kernel(P2Params p, const uint64
     const unsigned long long seq0 = (first_ordinal + r) << 16;
     Kmer<NW> word = read_kmer<NW>(rd, 0, K, filter);
     Kmer<NW> bal = kmer_rc<NW>(word, K);
+    ReadBases bases(rd);
     P2Walk<NW> w;
 #pragma unroll
     for (int i = 0; i < NW; i++) w.prev_k.w[i] = 0;
     for (int j = 0; j < nk && !w.stop; j++) {
-        if (j) kmer_roll<NW>(word, bal, read_base(rd, j + K - 1), K, filter);
+        if (j) kmer_roll<NW>(word, bal, bases.at(j + K - 1), K, filter);
         const bool sm = kmer_less<NW>(word, bal);
         const Kmer<NW> ck = sm ? word : bal;
         uint64_t ab = 0;
@@ -404,8 +418,9 @@ __device__ __forceinline__ void p2r_for_kmers(const P2Params& p, const uint32_t*
     const Kmer<NW> filter = kmer_filter<NW>(K);
     Kmer<NW> word = read_kmer<NW>(rd, 0, K, filter);
     Kmer<NW> bal = kmer_rc<NW>(word, K);
+    ReadBases bases(rd);
     for (int j = 0; j < nk; j++) {
-        if (j) kmer_roll<NW>(word, bal, read_base(rd, j + K - 1), K, filter);
+        if (j) kmer_roll<NW>(word, bal, bases.at(j + K - 1), K, filter);
         const bool sm = kmer_less<NW>(word, bal);
         const Kmer<NW> ck = sm ? word : bal;
         const uint32_t s = set_of_crc(kmer_crc32_sliced<NW>(ck, crc4), p.P, p.bias);
@@ -513,11 +528,12 @@ __global__ __launch_bounds__(256) void p2_thread_routed_kernel(P2Params p, P2Rou
     const unsigned long long seq0 = (first_ordinal + r) << 16;
     Kmer<NW> word = read_kmer<NW>(rd, 0, K, filter);
     Kmer<NW> bal = kmer_rc<NW>(word, K);
+    ReadBases bases(rd);
     P2Walk<NW> w;
 #pragma unroll
     for (int i = 0; i < NW; i++) w.prev_k.w[i] = 0;
     for (int j = 0; j < nk && !w.stop; j++) {
-        if (j) kmer_roll<NW>(word, bal, read_base(rd, j + K - 1), K, filter);
+        if (j) kmer_roll<NW>(word, bal, bases.at(j + K - 1), K, filter);
         const bool sm = kmer_less<NW>(word, bal);
         const Kmer<NW> ck = sm ? word : bal;
         const uint32_t o = owner_s[set_of_crc(kmer_crc32_sliced<NW>(ck, crc4), p.P, p.bias)];
@@ -547,6 +563,7 @@ __global__ __launch_bounds__(256) void p2_thread_ordered_kernel(P2Params p, cons
     if (alive && p.walk_len) p.walk_len[r] = 0;
     Kmer<NW> word = read_kmer<NW>(rd, 0, K, filter);
     Kmer<NW> bal = kmer_rc<NW>(word, K);
+    ReadBases bases(rd);
     P2Walk<NW> w;
 #pragma unroll
     for (int i = 0; i < NW; i++) w.prev_k.w[i] = 0;
@@ -560,7 +577,7 @@ __global__ __launch_bounds__(256) void p2_thread_ordered_kernel(P2Params p, cons
         __syncthreads();
         if (alive) {
             for (int j = c0; j < c0 + cn; j++) {
-                if (j) kmer_roll<NW>(word, bal, read_base(rd, j + K - 1), K, filter);
+                if (j) kmer_roll<NW>(word, bal, bases.at(j + K - 1), K, filter);
                 const bool sm = kmer_less<NW>(word, bal);
                 const uint64_t ab = tile[threadIdx.x * (P2O_CHUNK + 1) + (j - c0)];
                 if (ab == ~0ULL) { atomicAdd(&p.counters[1], 1ULL); alive = false; break; }      // not in the sets
