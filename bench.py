@@ -173,11 +173,11 @@ def big_command(args):
     REFERENCE's own runs on the same files, which took it a quarter of an hour to an hour each in the build container and are committed
     (profiles/r0*_ref_*.json): 60 M reads at K = 63 with -a 16 (static pools) and with the default growable sets -- either way the
     k-mer-set layout is made on the device (SURVEY.md App. C "K6": dev_graph.hpp / dev_rehash.hpp); 20 M reads at K = 127 (the
-    SOAPdenovo-127mer flavour, configs[4]'s path); configs[2] at its full 200 M reads with -a 40.
+    SOAPdenovo-127mer flavour, configs[4]'s path); configs[2] at its full 200 M reads with -a 40 and with growable sets (the reference: 2982 s / 5562 s).
     BASELINE.json configs[1] at its full size (10 M x 100 bp over 4.6 Mb, err 0.005, K = 31, -p 8; the reference: profiles/r05_ref_10M_K31.json -- the reads are
     scripts/synth_fastq.cpp's at seed 7, 95 807 825 distinct k-mers, not SURVEY.md's numpy draw of the same model (95 803 852): the reference was run on THIS file).
     Returns {"whole_command_10M_k31": {...}, "whole_command_60M_a16": {...}, "whole_command_60M": {...}, "whole_command_k127_20M": {...}, "whole_command_200M_a40": {...},
-    "whole_command_20M_ragged": {...}}."""
+    "whole_command_200M_a0": {...}, "whole_command_20M_ragged": {...}}."""
     groups = [[("whole_command_10M_k31", "r05_ref_10M_K31.json")],
               [("whole_command_60M_a16", "r03_ref_60M_K63_a16.json"), ("whole_command_60M", "r03_ref_60M_K63.json")],
               [("whole_command_k127_20M", "r04_ref_20M_K127.json")],
