@@ -1,6 +1,7 @@
 #!/bin/bash
 # A/B of pass 2's lookup table (round 6): the 200 M-read command under rocprofv3 --kernel-trace --stats, one run an arm; prints p2_thread_kernel's and
-# p2_look_build's totals.  Arms: "name:ENV=V+ENV=V" (no env = the default).   gpurun -- 'bash scripts/p2_look_ab.sh <tag> <arm> ...'
+# p2_look_build's totals.  Arms: "name:ENV=V+ENV=V" (no env = the default).  The PG_P2_* knobs (table size, answers a round) are
+# measure knobs: such an arm also needs LD_PRELOAD=$PWD/soapdenovo2_amd/libsoapdenovo2_amd_measure.so (make MEASURE=1).   gpurun -- 'bash scripts/p2_look_ab.sh <tag> <arm> ...'
 set -u
 TAG=$1; shift
 O=gpurun_out/$TAG; mkdir -p "$O"

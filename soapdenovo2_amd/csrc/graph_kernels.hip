@@ -1707,8 +1707,8 @@ static int p2_make_look(P2Device* d) {
     P2_HIP(pg::arena_mem_info(&free_b, &total_b));
     const uint64_t room = free_b > ((uint64_t)8 << 30) ? free_b - ((uint64_t)8 << 30) : 0;
     double per_key = 2.0;
-    if (const char* e = getenv("PG_P2_LOOK_PER_KEY")) per_key = std::max(1.1, atof(e));            // (A/B knobs of round 6: table size, plain hipMalloc)
-    const bool plain = getenv("PG_P2_LOOK_MALLOC") != nullptr;
+    if (const char* e = pg::env_measure("PG_P2_LOOK_PER_KEY")) per_key = std::max(1.1, atof(e));   // (A/B knobs of round 6, -DPG_MEASURE library: table size, plain hipMalloc)
+    const bool plain = pg::env_measure("PG_P2_LOOK_MALLOC") != nullptr;
     if ((double)n_keys * per_key * ES * 8 > (double)room) per_key = (double)room / ((double)n_keys * ES * 8 + 1);
     if (n_keys == 0 || per_key < 1.4) {
         if (verbose) fprintf(stderr, "pass 2: no lookup table (%llu keys, %.1f GB free): probing the sets as they lie\n", n_keys, free_b / 1e9);
@@ -2546,7 +2546,7 @@ int p2_add_packed_device_segments(P2Device* d, const uint64_t* const* d_segs, co
         hipStream_t st = ln.stream;
         const uint64_t kpr = (uint64_t)(read_len - d->K + 1), per_seg = seg_reads[0];
         uint64_t ans_gb = 40;
-        if (const char* e = getenv("PG_P2_PART_GB")) ans_gb = (uint64_t)std::max(1, atoi(e));           // (A/B knob)
+        if (const char* e = pg::env_measure("PG_P2_PART_GB")) ans_gb = (uint64_t)std::max(1, atoi(e));   // (A/B knob, -DPG_MEASURE library)
         uint64_t segs_a_round = std::max<uint64_t>(1, ((ans_gb << 30) / 8) / std::max<uint64_t>(1, per_seg * kpr));
         segs_a_round = std::min<uint64_t>(segs_a_round, (uint64_t)n_segs);
         const uint64_t reads_round = segs_a_round * per_seg;
