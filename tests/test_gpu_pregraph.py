@@ -286,6 +286,31 @@ def test_cli_matches_reference_files(golden, tmp_path, name, engine):
         assert md5_file(pre + ".contig") == golden["md5"][t]["contig"], t
 
 
+@pytest.mark.parametrize("form,says", [("SOAPDENOVO2_AMD_P2_SORT", "sorted by their smallest hashed 16-mer"),
+                                       ("SOAPDENOVO2_AMD_P2_PARTITIONED", "through the partition engine"),
+                                       ("SOAPDENOVO2_AMD_P2_LOOK", "pass 2: lookup table of")])
+@pytest.mark.parametrize("name", ["t6k_k31", "t8k_k63", "t6k_k127", "d8k_k63"])
+def test_cli_pass2_opt_in_forms_write_the_same_files(golden, tmp_path, name, form, says):
+    """Pass 2's three opt-in forms of the lookups (round 6: reads in genome order; every distinct k-mer of a partition looked up once through the
+    partition engine; a line-aligned lookup table beside the sets -- graph_kernels.hip, profiles/r06_p2_lookup_ab.json) are not the default, but they
+    ship: each must say that it ran and leave the reference's five files (prlRead2path.c:159-248,388-403: a pre-arc is a multiplicity and a first
+    meeting, whatever order the reads were threaded in and wherever the node words came from)."""
+    c = golden["cases"][name]
+    cfg = case_config(c, str(tmp_path), name)
+    for run in c["runs"]:
+        P, D, a, m = run
+        t = case_tag(name, run)
+        pre = str(tmp_path / t)
+        log = _run_cli(cfg, c["K"], pre, P, D, a, m, extra_env=dict(PARALLEL_PARSE, PG_HOST_VERBOSE="1", **{form: "1"}))
+        assert says in log, (t, form)
+        want = golden["md5"][t]
+        assert md5_file(pre + ".kmerFreq") == want["kmerFreq"], t
+        assert md5_file(pre + ".preGraphBasic") == want["preGraphBasic"], t
+        assert md5_file(pre + ".vertex") == want["vertex"], t
+        assert md5_gz_text(pre + ".edge.gz") == want["edge"], t
+        assert md5_file(pre + ".preArc") == want["preArc"], t
+
+
 @pytest.mark.parametrize("period", [1, 4, 32])
 @pytest.mark.parametrize("name", ["t6k_k31", "t8k_k63", "t6k_k127", "m100k_k31", "m60k_k63", "d8k_k127", "r8k_k127", "d8k_k63"])
 def test_cli_edges_through_waypoints(golden, tmp_path, name, period):
