@@ -77,7 +77,7 @@ struct P2Params {
     uint64_t patch_mask;
     // pre-arc table
     unsigned long long* arc;            // ARC_WORDS words an entry: from << 32 | to (0 = empty), the earliest meeting (read ordinal << 16 | item), the
-    uint64_t arc_mask;                  // multiplicity (32 bits), padding -- 32 bytes, so that one pre-arc touches ONE 64-byte line (p2_add_prearc)
+    uint64_t arc_mask;                  // multiplicity (32 bits), padding -- 32 bytes, so that one pre-arc touches ONE 64-byte line (add_prearc)
     // -R
     uint32_t* stage;                    // [read in batch][max_nk]
     uint16_t* walk_len;                 // valid entries per read (0 when the walk does not qualify)

@@ -1096,7 +1096,7 @@ __global__ __launch_bounds__(THREADS) void skm_count_kernel(E2Dev e, int D, SetP
 // (K1, as they lie on the device), and this kernel takes a partition at a time: the distinct k-mers of the partition into the LDS set (claims only), ONE lookup in
 // the sets in HBM per distinct k-mer (dense waves over the live slots; the node word goes where pass 1 keeps the first ordinal), then every occurrence finds its
 // k-mer's word in LDS and writes it at its ordinal: ans[ordinal - ord_base].  The reads are then threaded over their stretch of `ans` in read order
-// (graph_kernels.hip: p2_thread_routed_kernel without a permutation).  A simpler sibling of skm_count_kernel: no dedupe of records (every record's ordinals are
+// (graph_kernels.hip: p2_thread_ordered_kernel).  A simpler sibling of skm_count_kernel: no dedupe of records (every record's ordinals are
 // its own), no counters, one window buffer; a set that overflows splits its key range on a hash bit, as there.
 struct AnsArg {
     unsigned long long* ans;          // [occurrences of the round] node word of every k-mer occurrence, ~0 = not in the sets
@@ -1920,9 +1920,9 @@ int e2_answer(pg_ctx* c, const uint64_t* d_geo, uint32_t P, uint32_t bias, unsig
 // ... and what the pass left in the counters: flags (pool / chunk list / split) and occurrences whose k-mer was not found in the LDS set (must be 0)
 int e2_answer_check(pg_ctx* c, hipStream_t st) {
     E2_TRY(hipStreamSynchronize(st));
-    DevCounters* h = new DevCounters;
+    DevCounters* h = new DevCounters();
     const hipError_t rc = hipMemcpy(h, c->ctr, sizeof(DevCounters), hipMemcpyDeviceToHost);
-    const unsigned long long flags = h->e2_flags, lost = h->overflow;
+    const unsigned long long flags = h->e2_flags, lost = h->overflow;        // (zeroes if the copy failed: it is reported first)
     delete h;
     E2_TRY(rc);
     if (flags & (F_POOL | F_CHUNKS | F_SPLIT | F_LEN)) { pg_set_error("pass 2 through the partitions: the partition engine gave up (flags " + std::to_string(flags) + ")"); return PG_ENOMEM; }
