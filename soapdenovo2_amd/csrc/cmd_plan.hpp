@@ -36,6 +36,18 @@ inline uint64_t cmd_export_records(uint64_t est_kmers, bool mer127, int n_ranks,
 // rank's pool of 130 GB, its 83 GB of distinct k-mers and their sorted copy did not fit 288 GB together).
 inline uint64_t cmd_sort_ws_bytes(uint64_t n, bool mer127) { return n * ((mer127 ? 6 : 4) * 8 + 36) + ((uint64_t)64 << 20); }
 
+// pass 2's pre-arc table of one lane (graph_kernels.hip: add_prearc -- open addressing, 32 bytes an entry): eight entries an edge id (the distinct
+// pre-arcs are about one an edge: 26.2 M for 26.4 M edge ids at 200 M reads), as a power of two -- but no more than an eighth of the device while that
+// still leaves two entries an edge: a human genome's ~0.5 G edge ids would otherwise ask for 137 GB a lane (34 GB so, at a load of ~0.45; what does not
+// fit is counted and fails the command, never dropped).
+constexpr uint64_t CMD_PREARC_ENTRY_BYTES = 32;
+inline uint64_t cmd_prearc_entries(uint64_t num_ed, uint64_t total_b) {
+    uint64_t cap = (uint64_t)1 << 16;
+    while (cap < num_ed * 8) cap <<= 1;
+    while (total_b && cap * CMD_PREARC_ENTRY_BYTES > total_b / 8 && (cap >> 1) >= num_ed * 2) cap >>= 1;
+    return cap;
+}
+
 // a pass-1 batch: 64 MiB of packed reads / 2 M reads
 constexpr uint64_t CMD_BATCH_WORDS = (uint64_t)1 << 23, CMD_BATCH_READS = (uint64_t)1 << 21;
 // the reads of pass 1 stay on the device for pass 2 while they fit this share of it

@@ -38,6 +38,7 @@
 #include "kmer.hpp"
 #include "graph_dev.hpp"
 #include "graph_lookup.hpp"
+#include "cmd_plan.hpp"
 #include "backend_hip.hpp"
 #include "dev_graph.hpp"
 #include "dev_rehash.hpp"
@@ -133,6 +134,7 @@ struct ReadBases {
 // an atomic nobody waits for, and the minimum is only taken by a read that is earlier than what it saw (first meetings only ever go down, so a stale
 // value can make a read take a minimum it need not have, never skip one it needed).
 constexpr int ARC_WORDS = 4;
+static_assert(ARC_WORDS * 8 == (int)CMD_PREARC_ENTRY_BYTES, "the plan's entry size");
 __device__ inline void add_prearc(const P2Params& p, uint32_t from, uint32_t to, unsigned long long seq) {
     const unsigned long long key = ((unsigned long long)from << 32) | to;
     uint64_t h = (key * 0x9E3779B97F4A7C15ULL) >> 20;
@@ -1747,10 +1749,13 @@ int p2_begin_reads(P2Device* d, uint32_t num_ed, bool reps) {
     // several lanes: the lookups are routed to the sets' owners (SOAPDENOVO2_AMD_P2_ROUTE=0: every lane probes the peer-mapped sets itself, the A/B form)
     d->route = d->lanes.size() > 1 && (int)d->lanes.size() <= P2R_MAX_LANES;
     if (const char* e = pg::env_user("SOAPDENOVO2_AMD_P2_ROUTE")) d->route = d->route && atoi(e) != 0;
-    { const int rc = p2_make_look(d); if (rc) return rc; }
     // every edge has a handful of successors: eight slots an edge id keep the load low; the kernel counts overflows
-    uint64_t arc_cap = 1 << 16;
-    while (arc_cap < (uint64_t)d->num_ed * 8) arc_cap <<= 1;
+    uint64_t arc_cap;
+    {
+        size_t free_b = 0, total_b = 0;
+        P2_HIP(hipMemGetInfo(&free_b, &total_b));
+        arc_cap = pg::cmd_prearc_entries((uint64_t)d->num_ed, (uint64_t)total_b);      // (cmd_plan.hpp: the rule pg_host_plan_memory plans by)
+    }
     const uint64_t patch_cap = d->prm.patch_mask + 1;
     for (size_t l = 0; l < d->lanes.size(); l++) {
         P2Lane& ln = d->lanes[l];
@@ -1792,6 +1797,8 @@ int p2_begin_reads(P2Device* d, uint32_t num_ed, bool reps) {
     }
     P2_HIP(hipSetDevice(d->device));
     d->prm = d->lanes[0].prm;
+    // (the opt-in lookup table takes what is free AFTER the tables pass 2 cannot do without)
+    { const int rc = p2_make_look(d); if (rc) return rc; d->lanes[0].prm.look = d->prm.look; d->lanes[0].prm.look_buckets = d->prm.look_buckets; }
     d->reads_ready = true;
     return PG_OK;
 }

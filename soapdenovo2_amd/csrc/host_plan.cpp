@@ -106,7 +106,9 @@ extern "C" int pg_host_plan_memory(uint64_t reads_total, uint32_t read_len, uint
     const uint64_t s3 = (pool_stays ? e2.pool_bytes : 0) + out_kept + kept + sets_outside + layout_arrays;
     // ---- stage 4: pool and records are gone; sets, reads, the graph's lists and pass 2's table
     const uint64_t edges_guess = distinct_rank / 40 + (1 << 20);                                          // (vertices + edges: a few per cent of the k-mers)
-    const uint64_t s4 = set_bytes + kept + batch + edges_guess * 64 + distinct_rank / 8 * 24;
+    // pass 2's pre-arc table: a lane's reads meet any edge, so it is made for the GRAPH's edge ids (about one per 40 k-mers), not for the rank's share
+    const uint64_t prearc = pg::cmd_prearc_entries(distinct_total / 40 + (1 << 20), device_bytes) * pg::CMD_PREARC_ENTRY_BYTES;
+    const uint64_t s4 = set_bytes + kept + batch + edges_guess * 64 + prearc;
     const uint64_t peak = std::max(std::max(s1, s2), std::max(s3, s4));
     out[0] = peak;
     out[1] = peak == s1 ? 1 : peak == s2 ? 2 : peak == s3 ? 3 : 4;

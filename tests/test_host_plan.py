@@ -63,6 +63,17 @@ def test_a_rank_stores_the_partitions_it_owns_and_no_others():
     assert p["record_pool"] < 1.1 * one["record_pool"]                         # a rank's pool is that of a one-GPU job of its share
 
 
+def test_pass_2s_pre_arc_table_is_planned_for_the_graphs_edges_and_bounded():
+    """A lane's reads meet any edge of the graph, so its pre-arc table is made for ALL edge ids (cmd_plan.hpp: cmd_prearc_entries, 32 bytes an entry, eight
+    entries an edge id) -- a rule that would ask a rank of configs[3] for 137 GB; it stops at an eighth of the device while two entries an edge remain."""
+    big = api.plan_memory(reads_total=3_000_000_000, read_len=150, distinct_total=18_800_000_000, K=63, n_sets=64, n_ranks=8)
+    sets_only = big["kmer_sets"]
+    assert 30 * GB < big["stage4_graph_pass2"] - sets_only < 45 * GB            # the table (34 GB) + the edge lists
+    small = api.plan_memory(reads_total=200_000_000, read_len=150, distinct_total=1_146_737_909, K=63, n_sets=8, a_gb=40, n_ranks=1)
+    assert 8 * GB < small["stage4_graph_pass2"] - small["kmer_sets"] - small["reads_kept"] < 12 * GB   # 2^28 entries x 32 B = 8.6 GB + lists
+    assert big["stage4_graph_pass2"] < big["peak"] and small["stage4_graph_pass2"] < small["peak"]
+
+
 @pytest.mark.parametrize("K,distinct", [(63, 18_800_000_000), (127, 13_800_000_000)])
 def test_configs_3_and_4_fit_a_288_GB_GPU_with_enough_sets(K, distinct):
     """BASELINE.json configs[3] / configs[4]: 3 G x 150 bp on 8 MI355X (distinct k-mers: the genome's 3 G + about 35 / 24 error k-mers an
