@@ -40,6 +40,12 @@ CASES = {
     "g120k_k63": dict(G=600000, N=120000, L=150, min_len=100, err=0.002, seed=31, K=63, runs=[(8,0,0,0), (8,0,1,0)], full=[]),
     "g40k_k127": dict(G=300000, N=40000, L=250, min_len=160, err=0.002, seed=32, K=127, runs=[(5,0,0,1)], full=[]),
     "g60k_k31": dict(G=300000, N=60000, L=100, min_len=40, err=0.004, seed=33, K=31, runs=[(8,1,0,0)], full=[]),
+    # long reads (round 6): max_rd_len is whatever the config says (lib.c:163), and a read of 5 - 6 k bases fills a tile of the super-k-mer cutter on its own, one of
+    # 9 k is more than a tile holds (partition_kernels.hip: launch_tiled returns 1, skm_scatter_kernel takes the batch a lane a read); pass 2 walks ~5.9 k k-mers a read
+    "x500_k63": dict(G=300000, N=500, L=6000, err=0.002, seed=41, K=63, runs=[(4,0,0,0), (4,0,1,0)], full=[]),
+    "x400_k127": dict(G=300000, N=400, L=5000, err=0.002, seed=42, K=127, runs=[(3,0,0,1)], full=[]),
+    # (6000 bases still fit a tile of ONE read; 9000 do not)
+    "y300_k63": dict(G=300000, N=300, L=9000, err=0.002, seed=43, K=63, runs=[(4,0,0,0)], full=[]),
 }
 EXTS = ("kmerFreq", "preGraphBasic", "vertex", "edge", "preArc")
 

@@ -257,7 +257,7 @@ def _run_cli(cfg, K, prefix, P, D, a, m, engine=None, R=False, extra_env=None):
 
 @pytest.mark.parametrize("engine", ENGINES)
 @pytest.mark.parametrize("name", ["t6k_k31", "t8k_k63", "t6k_k127", "t5k_k24", "m100k_k31", "m60k_k63", "d8k_k127", "r8k_k127", "d8k_k63",
-                                  "g120k_k63", "g40k_k127", "g60k_k31"])
+                                  "g120k_k63", "g40k_k127", "g60k_k31", "x500_k63", "x400_k127", "y300_k63"])
 def test_cli_matches_reference_files(golden, tmp_path, name, engine):
     """`SOAPdenovo-63mer|127mer pregraph -s cfg -K k -o pfx -p n [-d -a]` end to end against the reference's files."""
     from soapdenovo2_amd import synth
@@ -730,7 +730,7 @@ def test_sharded_pass1_rccl_single_rank(golden, tmp_path):
 
 
 @pytest.mark.parametrize("devices", ["0,0", "0,0,0"])
-@pytest.mark.parametrize("name", ["m60k_k63", "t6k_k127", "t5k_k24", "d8k_k127", "t6k_k31", "g120k_k63"])   # (t6k_k31: -p 1 and 2, fewer sets than ranks; g120k_k63: trimmed reads)
+@pytest.mark.parametrize("name", ["m60k_k63", "t6k_k127", "t5k_k24", "d8k_k127", "t6k_k31", "g120k_k63", "x500_k63"])   # (t6k_k31: -p 1 and 2, fewer sets than ranks; g120k_k63: trimmed reads)
 def test_cli_sharded_matches_reference_files(golden, tmp_path, name, devices):
     """`pregraph` with pass 1 sharded over several ranks (SOAPDENOVO2_AMD_DEVICES, here all on GPU 0): the five files (and
     the -R pair) equal the reference's byte for byte, as with one rank."""

@@ -17,7 +17,7 @@ def _cases(golden, names):
 
 
 # (g*: trimmed reads, lengths uniform in [min_len, L]; the runs of t6k_k31 / t8k_k63 / t6k_k127 include -p 16, 37, 64, 255 and -d with -a)
-@pytest.mark.parametrize("name", SMALL + ["m60k_k63", "g120k_k63", "g40k_k127", "g60k_k31"])
+@pytest.mark.parametrize("name", SMALL + ["m60k_k63", "g120k_k63", "g40k_k127", "g60k_k31", "x500_k63", "x400_k127", "y300_k63"])
 def test_oracle_matches_reference_digests(golden, tmp_path, name):
     c = golden["cases"][name]
     codes = case_codes(c)
