@@ -553,6 +553,27 @@ def test_cli_option_semantics_against_the_reference_binary(tmp_path, opts):
     assert md5_gz_text(outs["amd"] + ".edge.gz") == md5_gz_text(outs["ref"] + ".edge.gz"), opts
 
 
+@pytest.mark.parametrize("opts", [["-K", "31"], ["-K", "76"], ["-K", "129"], ["-K", "13", "-p", "2"], ["-K", "63", "-d", "1", "-R", "-p", "3"]])
+def test_cli_option_semantics_of_the_127mer_flavour_against_the_reference_binary(tmp_path, opts):
+    """The same for SOAPdenovo-127mer (four-word k-mers whatever K is): a small K in the wide flavour, even K -> K + 1, K > 127 -> 127 (on reads of
+    150 bases: with K beyond max_rd_len the reference asks for a negative number of bytes and dies -- no behaviour to match), K = 13, -d with -R."""
+    from soapdenovo2_amd import api, synth
+    ref = os.path.join(ROOT, "oracle", "_ref", "SOAPdenovo-127mer")
+    if not os.path.exists(ref):
+        pytest.skip("reference binary not built")
+    cfg = synth.make_case(str(tmp_path), "opt", 25000, 5000 if int(opts[1]) < 100 else 3000, 90 if int(opts[1]) < 100 else 150, 0.006, 1234)
+    outs = {}
+    for tag, binary in (("amd", api.binary(True)), ("ref", ref)):
+        pre = str(tmp_path / tag)
+        r = subprocess.run([binary, "pregraph", "-s", cfg, "-o", pre] + opts, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+        assert r.returncode == 0, (tag, r.stderr[-1500:])
+        outs[tag] = pre
+    exts = ["kmerFreq", "preGraphBasic", "vertex", "preArc"] + (["path", "markOnEdge"] if "-R" in opts else [])
+    for ext in exts:
+        assert md5_file(outs["amd"] + "." + ext) == md5_file(outs["ref"] + "." + ext), (opts, ext)
+    assert md5_gz_text(outs["amd"] + ".edge.gz") == md5_gz_text(outs["ref"] + ".edge.gz"), opts
+
+
 @pytest.mark.parametrize("kind", ["empty", "all_short"])
 def test_cli_degenerate_inputs_against_the_reference_binary(tmp_path, kind):
     """No read at all / no read of K + 1 bases: both binaries must finish and write the same (empty) graph."""
