@@ -16,6 +16,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -110,13 +113,66 @@ struct HostBackend {
     uint64_t launches_at[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // (kept for symmetry with the device backend's per-place launch counts)
 
     // f(i) for every i in [0, n): thread t takes i = t, t + T, t + 2T, ... so that neighbouring indices run concurrently,
-    // as the lanes of a wavefront do
+    // as the lanes of a wavefront do.  The threads are the backend's own and live as long as it does (round 6: a std::thread per
+    // launch and thread was 14 of the CPU suite's 15 minutes in the kernel -- a fixed point is thousands of small launches).
+    struct Workers {
+        std::vector<std::thread> th;
+        std::mutex mu;
+        std::condition_variable go, done;
+        uint64_t round = 0;
+        int active = 0, pending = 0;
+        bool stop = false;
+        void (*fn)(void*, int, int) = nullptr;
+        void* arg = nullptr;
+        explicit Workers(int n) {
+            for (int t = 1; t < n; t++)
+                th.emplace_back([this, t] {
+                    uint64_t seen = 0;
+                    for (;;) {
+                        void (*f)(void*, int, int);
+                        void* a;
+                        int T;
+                        {
+                            std::unique_lock<std::mutex> g(mu);
+                            go.wait(g, [&] { return stop || round != seen; });
+                            if (stop) return;
+                            seen = round; f = fn; a = arg; T = active;
+                        }
+                        if (t < T) f(a, t, T);
+                        {
+                            std::lock_guard<std::mutex> g(mu);
+                            if (--pending == 0) done.notify_one();
+                        }
+                    }
+                });
+        }
+        ~Workers() {
+            { std::lock_guard<std::mutex> g(mu); stop = true; }
+            go.notify_all();
+            for (auto& t : th) t.join();
+        }
+        void run(void (*f)(void*, int, int), void* a, int T) {             // the caller is thread 0
+            {
+                std::lock_guard<std::mutex> g(mu);
+                fn = f; arg = a; active = T; pending = (int)th.size(); round++;
+            }
+            go.notify_all();
+            f(a, 0, T);
+            std::unique_lock<std::mutex> g(mu);
+            done.wait(g, [&] { return pending == 0; });
+        }
+    };
+    std::shared_ptr<Workers> workers;
     template <typename F> void launch(uint64_t n, F f) {
         const int T = (int)std::min<uint64_t>((uint64_t)n_threads, std::max<uint64_t>(n, 1));
         if (T <= 1) { for (uint64_t i = 0; i < n; i++) f(i); return; }
-        std::vector<std::thread> pool;
-        for (int t = 0; t < T; t++) pool.emplace_back([=]() mutable { for (uint64_t i = (uint64_t)t; i < n; i += (uint64_t)T) f(i); });
-        for (auto& th : pool) th.join();
+        if (!workers) workers = std::make_shared<Workers>(n_threads);
+        struct Job { F* f; uint64_t n; } job{&f, n};
+        workers->run([](void* a, int t, int TT) {
+            Job& j = *(Job*)a;
+            F g = *j.f;                                                   // (every thread its own copy, as the per-launch threads had)
+            for (uint64_t i = (uint64_t)t; i < j.n; i += (uint64_t)TT) g(i);
+        }, &job, T);
     }
     // stable sort of (key, value) pairs by the low `bits` bits of the key
     template <typename KT, typename V> void sort_pairs(const KT* kin, KT* kout, const V* vin, V* vout, uint64_t n, int bits) {

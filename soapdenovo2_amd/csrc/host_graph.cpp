@@ -170,7 +170,10 @@ struct HugeArray {
         uintptr_t a = (uintptr_t)q, al = (a + HP - 1) / HP * HP;
         if (al > a) munmap(q, al - a);
         if (al + nb < a + nb + HP) munmap((void*)(al + nb), a + HP - al);
-        if (!pg::env_measure("PG_NO_THP")) madvise((void*)al, nb, MADV_HUGEPAGE);
+        // (huge pages make the host replay's random accesses cheaper where the kernel hands them out quickly; SOAPDENOVO2_AMD_THP=0 for hosts where it does not --
+        //  the build container's VM takes 80 s to touch 2 GB in 2 MB pages and 8 s in 4 KB ones, and several threads touching at once are slower still)
+        static const bool thp = [] { const char* v = pg::env_user("SOAPDENOVO2_AMD_THP"); return !(v && atoi(v) == 0) && !pg::env_measure("PG_NO_THP"); }();
+        if (thp) madvise((void*)al, nb, MADV_HUGEPAGE);
         T* np = (T*)al;
         if (keep) memcpy((void*)np, (const void*)p, keep * sizeof(T));
         release();

@@ -5,6 +5,11 @@ import os
 import subprocess
 import sys
 
+# (numpy asks for transparent huge pages for large arrays; on the build container's VM a first touch of 2 GB takes 8 s in 4 KB pages and 80 s in
+#  2 MB ones -- the -a pools of the host twins are gigabytes of zeroes)
+os.environ.setdefault("NUMPY_MADVISE_HUGEPAGE", "0")
+if not os.path.exists("/dev/kfd"):                          # (no GPU = the build container: the host twins' k-mer sets in 4 KB pages too, csrc/host_graph.cpp: HugeArray)
+    os.environ.setdefault("SOAPDENOVO2_AMD_THP", "0")
 import numpy as np
 import pytest
 
