@@ -38,3 +38,16 @@ def test_committed_hbm_counters_belong_to_the_committed_pass1_kernels():
     assert tj["library_sha"] == b.library_source_sha(), (
         "partition_kernels.hip or one of its headers changed after profiles/pmc_traffic.json was taken: re-run the pmc:FETCH_SIZE / pmc:WRITE_SIZE steps of "
         "scripts/gpu_run.sh and scripts/pmc_traffic.py, or bench.py prints roofline.traffic = null")
+
+
+def test_every_whole_command_leg_has_its_expectation_in_profiles():
+    """bench.py's big legs compare the executable's files with md5s of the REFERENCE's own runs, committed under profiles/; a leg whose file is missing is skipped
+    without a word in the line.  Every file bench.py names must be there, carry the five md5s and the reference's wall time, and say what it was run on."""
+    import re
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    names = sorted(set(re.findall(r'\("whole_command_[A-Za-z0-9_]+", "(r0\d_ref_[A-Za-z0-9_]+\.json)"\)', src)))
+    assert len(names) >= 7, names
+    for f in names:
+        j = json.load(open(os.path.join(ROOT, "profiles", f)))
+        assert set(j["md5"]) >= {"kmerFreq", "preGraphBasic", "vertex", "preArc", "edge"}, f
+        assert j.get("reference_wall_s", 0) > 100 and {"reads", "read_len", "genome", "err", "seed", "kmer", "sets", "a_gb"} <= set(j["workload"]), f
